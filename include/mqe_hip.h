@@ -1,0 +1,214 @@
+/* mqe_hip.h -- C ABI of the MI355X-native MQE rollout engine (drop-in boundary).
+ *
+ * The reference (ziyanx02/multiagent-quadruped-environment) is pure Python on top of the Isaac Gym tensor API;
+ * this library replaces that *inner* boundary and adds a fused fast path.  Each entry point cites the reference
+ * call it stands in for.  Conventions: every function returns 0 on success or a negative code and records a
+ * message retrievable with mqe_last_error(); no exceptions cross the ABI; the handle owns all device memory it
+ * allocates; caller owns buffers it passes in; one handle per GPU; calls on one handle are serialised by the
+ * caller; all work is enqueued on the `stream` argument (a hipStream_t passed as void*; NULL = default stream).
+ *
+ * Memory contract (reference mqe/envs/base/legged_robot.py:549-645, "_init_buffers"): all tensors are float32,
+ * env-major:
+ *   ROOT_STATE     [N, A+P, 13]  pos3, quat4 (xyzw), linvel3, angvel3 in world frame; agents first   (:567-574)
+ *   DOF_STATE      [N, 12A+Dn, 2] (pos, vel); agent dofs first, NPC dofs after                        (:577-585)
+ *   CONTACT_FORCE  [N, 17A+Bn, 3] net contact force per reported rigid body, agents first             (:595)
+ *   TORQUES        [N, 12A]                                                                            (:605)
+ * Leg/DOF order inside one robot: FL, FR, RL, RR x (hip, thigh, calf); bodies: base, then per leg hip, thigh,
+ * calf, foot.
+ */
+#ifndef MQE_HIP_H
+#define MQE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MQE_ABI_VERSION 1
+#define MQE_MAX_SPHERES 32
+#define MQE_NBODY 13      /* dynamic bodies of one Go1 after fixed-joint collapsing */
+#define MQE_NREP 17       /* reported rigid bodies of one Go1 (feet kept, go1.urdf dont_collapse) */
+#define MQE_NDOF 12
+#define MQE_MAX_AGENTS 4
+#define MQE_MAX_NPCS 9
+#define MQE_FRAME 72      /* 70-float locomotion observation padded to 72 (16-byte rows) */
+#define MQE_HIST 30       /* frames of history fed to the locomotion policy (go1.py:395) */
+#define MQE_MAX_LAYERS 6
+#define MQE_MAX_REWARD_TERMS 12
+
+/* tasks whose wrapper observation / reward are evaluated in-kernel (reference mqe/envs/wrappers) */
+enum { MQE_TASK_PLAIN = 0, MQE_TASK_GATE = 1, MQE_TASK_SHEEP = 2, MQE_TASK_SEESAW = 3, MQE_TASK_FOOTBALL_DEFENDER = 4 };
+/* NPC kinds (reference resources/objects/{ball,sheep,seesaw}.urdf) */
+enum { MQE_NPC_NONE = 0, MQE_NPC_BALL = 1, MQE_NPC_SHEEP = 2, MQE_NPC_SEESAW = 3 };
+/* control types (reference legged_robot.py:368-392 "P","V","T"; go1.py:315-354 "C") */
+enum { MQE_CTRL_C = 0, MQE_CTRL_P = 1, MQE_CTRL_V = 2, MQE_CTRL_T = 3 };
+/* termination terms (reference legged_robot_field.py:121-146) */
+enum { MQE_TERM_ROLL = 1, MQE_TERM_PITCH = 2, MQE_TERM_Z_LOW = 4, MQE_TERM_Z_HIGH = 8 };
+/* reset-noise modes: hash RNG keyed by (seed, global env id, reset count) | scripted (tests: the sequence
+ * tools/gen_golden.py's ScriptedRand produces) */
+enum { MQE_NOISE_HASH = 0, MQE_NOISE_SCRIPTED = 1 };
+
+typedef struct {
+  int32_t n_layers;                       /* Linear layers */
+  int32_t dims[MQE_MAX_LAYERS + 1];       /* in, hidden..., out */
+  const float* W[MQE_MAX_LAYERS];         /* host pointers, W[l] is (dims[l+1], dims[l]) row-major (torch Linear) */
+  const float* b[MQE_MAX_LAYERS];
+} mqe_mlp;
+
+typedef struct {
+  /* floating-base tree of 13 bodies: 0 = base, 1+3k+{0,1,2} = hip, thigh, calf(+foot) of leg k */
+  float mass[MQE_NBODY];
+  float com[MQE_NBODY][3];                /* body frame */
+  float inertia[MQE_NBODY][6];            /* xx, yy, zz, xy, xz, yz about the COM, body axes */
+  float joint_offset[MQE_NBODY][3];       /* joint origin in the parent frame (entry 0 unused) */
+  float joint_axis[MQE_NBODY][3];         /* in the child (= parent at q=0) frame */
+  float dof_lower[MQE_NDOF], dof_upper[MQE_NDOF];
+  int32_t n_spheres;
+  int32_t sphere_body[MQE_MAX_SPHERES];
+  int32_t sphere_reported[MQE_MAX_SPHERES];
+  float sphere_center[MQE_MAX_SPHERES][3];
+  float sphere_radius[MQE_MAX_SPHERES];
+} mqe_robot_model;
+
+typedef struct {
+  int32_t abi_version;
+  /* sizes */
+  int32_t num_envs, num_agents, num_npcs, npc_kind, task;
+  int32_t env_id_offset;                  /* global index of local env 0 (env sharding across GPUs) */
+  int32_t seed;
+  /* simulation (reference legged_robot_config.py:211-229) */
+  float dt;                               /* 0.005 */
+  int32_t decimation;                     /* 4 (go1_config.py:119) */
+  float gravity_z;                        /* -9.81 */
+  int32_t solver_iterations;
+  float contact_offset, max_depenetration_velocity, friction, erp;
+  /* robot */
+  mqe_robot_model robot;
+  /* NPC free bodies (ball / sheep): mass, isotropic inertia, spheres in the body frame */
+  float npc_mass, npc_inertia;
+  int32_t npc_n_spheres;
+  float npc_sphere_center[2][3];
+  float npc_sphere_radius[2];
+  /* seesaw (fixed base + revolute plank), reference resources/objects/seesaw.urdf */
+  float seesaw_joint_offset[3], seesaw_plank_center[3], seesaw_plank_half[3], seesaw_base_half[3];
+  float seesaw_plank_mass, seesaw_plank_inertia_yy, seesaw_vel_limit, seesaw_default_angle;
+  /* control (reference go1_config.py:108-155) */
+  int32_t control_type;
+  float action_scale, hip_scale_reduction, clip_actions;
+  float torque_limits[MQE_NDOF];
+  float kp, kd;
+  float default_dof_pos[MQE_NDOF];
+  float command_obs[70];                  /* _fill_command_obs (go1.py:411-479) */
+  float cmd_lin_scale, cmd_ang_scale;     /* 2.0, 0.25 */
+  int32_t clip_command;                   /* 1: Go1.step re-clips to +-1 (go1.py:38); 0: defender variant */
+  /* terrain: 2D signed distance [m] to the wall set, sampled at cell centres of the BarrierTrack heightfield */
+  const float* wall_sdf;                  /* host pointer, [sdf_nx][sdf_ny] */
+  int32_t sdf_nx, sdf_ny;
+  float horizontal_scale, wall_height, ground_z;
+  /* per-env constants, host pointers */
+  const float* env_origins;               /* [N,3] */
+  const float* agent_origins;             /* [N,A,3] */
+  const float* base_init_state;           /* [A,13] */
+  const float* npc_init_state;            /* [P,13] */
+  const float* gate_pos;                  /* [N,2] task specific (wrappers' gate_pos / football gate) or NULL */
+  /* termination (reference go1_config.py:187-207, legged_robot.py:159-169) */
+  int32_t termination_flags, terminate_on_base_contact, max_episode_length;
+  float roll_threshold, pitch_threshold, z_low_threshold, z_high_threshold;
+  /* reset distribution (reference legged_robot.py:394-470) */
+  int32_t noise_mode;
+  float dof_ratio_lo, dof_ratio_hi;
+  int32_t has_base_pos_range, has_npc_pos_range;
+  float base_pos_x_lo, base_pos_x_hi, base_pos_y_lo, base_pos_y_hi;
+  float npc_pos_x_lo, npc_pos_x_hi, npc_pos_y_lo, npc_pos_y_hi;
+  float base_vel_lo, base_vel_hi;
+  /* sheep script (reference go1_sheep.py:35-64) */
+  float sheep_movement_scale, sheep_movement_randomness;
+  /* wrapper parameters: reward scales in the order documented in mqe/envs/wrappers of this package */
+  float reward_scale[MQE_MAX_REWARD_TERMS];
+  float wrapper_param[8];
+  /* networks */
+  mqe_mlp actuator, adaptation, body;
+} mqe_sim_desc;
+
+/* tensor kinds for mqe_sim_tensor (device pointers into handle-owned memory, valid for the handle's lifetime;
+ * the zero-copy analogue of gym.acquire_*_tensor + gymtorch.wrap_tensor, legged_robot.py:554-567,595) */
+enum {
+  MQE_T_ROOT_STATE = 0, MQE_T_DOF_STATE, MQE_T_CONTACT_FORCE, MQE_T_TORQUES, MQE_T_ACTIONS, MQE_T_LAST_ACTIONS,
+  MQE_T_LOCOMOTION_OBS, MQE_T_HISTORY, MQE_T_LAST_LOCO_ACTION, MQE_T_LAST_TWO_LOCO_ACTION,
+  MQE_T_ACT_HIST,          /* [4][R][12]: pos_err_last, pos_err_last_last, vel_last, vel_last_last */
+  MQE_T_GAIT_INDICES, MQE_T_CLOCK_INPUTS,
+  MQE_T_BASE_LIN_VEL, MQE_T_BASE_ANG_VEL, MQE_T_PROJECTED_GRAVITY, MQE_T_BASE_QUAT,
+  MQE_T_EPISODE_LENGTH,    /* int32 [N] */
+  MQE_T_RESET_BUF, MQE_T_COLLIDE_BUF, MQE_T_TIME_OUT_BUF, MQE_T_R_TERM, MQE_T_P_TERM, MQE_T_Z_HIGH_TERM, /* uint8 [N] */
+  MQE_T_OBS_BAG,           /* [R][74]: base_pos3 base_rpy3 dof_pos12 dof_vel12 lin_vel3 ang_vel3 last_action12
+                              last_last_action12 projected_gravity3 clock_inputs4 base_quat4, filled by
+                              compute_observations (go1.py:153-196) */
+  MQE_T_WRAPPER_OBS, MQE_T_WRAPPER_REWARD, MQE_T_REWARD_SUMS, /* [N,A',D], [N,A'], [MQE_MAX_REWARD_TERMS] */
+  MQE_T_SHEEP_POS_AVG, MQE_T_SHEEP_POS_VAR,
+  MQE_T_RESET_COUNT,       /* int32 [N] */
+  MQE_T_SUBSTEP_TORQUES,   /* [N,4,12A] (legged_robot.py:112-115) */
+  MQE_T_NPC_NOISE,         /* [N,P,3] injected N(0,1) for the sheep script when noise_mode is SCRIPTED */
+  MQE_T_COUNT
+};
+
+typedef struct {
+  void* ptr;               /* device pointer */
+  int32_t ndim;
+  int64_t shape[4];
+  int32_t dtype;           /* 0 f32, 1 i32, 2 u8 */
+} mqe_tensor_view;
+
+typedef struct mqe_sim mqe_sim;
+
+const char* mqe_last_error(void);
+int mqe_abi_version(void);
+
+/* gym.create_sim + load_asset + create_env/create_actor + add_triangle_mesh + prepare_sim
+ * (reference legged_robot.py:255-261,754-923; barrier_track.py:395-410; base_task.py:91) */
+int mqe_sim_create(const mqe_sim_desc* desc, mqe_sim** out);
+int mqe_sim_destroy(mqe_sim* s);
+/* gym.acquire_*_tensor + gymtorch.wrap_tensor (legged_robot.py:554-567) */
+int mqe_sim_tensor(mqe_sim* s, int kind, mqe_tensor_view* out);
+
+/* ---- unfused, Isaac-Gym-shaped entry points (inner boundary) ---- */
+/* Go1.preprocess_action (go1.py:64-108): command -> locomotion obs -> history -> adaptation+body MLP ->
+ * clipped joint-target actions.  `command` is [R,3] device memory (already scaled by the task wrapper). */
+int mqe_policy_step(mqe_sim* s, const float* command, void* stream);
+/* Go1FootballDefender._get_defender_action (go1_football_defender.py:56-80): scripted (x, y, yaw) command of agent 2
+ * from the current state -> out_dev [N,3] */
+int mqe_defender_command(mqe_sim* s, float* out_dev, void* stream);
+/* Go1._compute_torques (go1.py:315-354) / LeggedRobot._compute_torques (legged_robot.py:368-392) */
+int mqe_compute_torques(mqe_sim* s, void* stream);
+/* gym.set_dof_actuation_force_tensor + gym.simulate + refresh_dof_state_tensor (go1.py:52-56): one dt of rigid-body
+ * dynamics with the torques currently in MQE_T_TORQUES; also refreshes the net contact forces */
+int mqe_simulate(mqe_sim* s, void* stream);
+/* post_decimation_step (legged_robot.py:112-115) */
+int mqe_post_decimation_step(mqe_sim* s, int dec_i, void* stream);
+/* post_physics_step (legged_robot_field.py:117-119 -> legged_robot.py:117-157) incl. termination, NPC script,
+ * in-kernel reset, compute_observations, and the task wrapper's observation / reward */
+int mqe_post_physics_step(mqe_sim* s, void* stream);
+/* task wrapper observation + reward only (mqe/envs/wrappers/*.py step()/reset() bodies) from the current contents of
+ * MQE_T_OBS_BAG, MQE_T_ROOT_STATE (NPC rows), the termination flags and MQE_T_SHEEP_POS_*; part of
+ * mqe_post_physics_step / mqe_reset_all, exposed separately so the wrappers can be checked against golden vectors */
+int mqe_wrapper_eval(mqe_sim* s, int is_reset_call, void* stream);
+/* gym.set_actor_root_state_tensor_indexed / set_dof_state_tensor_indexed (legged_robot.py:419-421,468-470):
+ * state tensors are live device memory, so these only invalidate cached per-env data for the listed actors */
+int mqe_set_actor_root_state_indexed(mqe_sim* s, const int32_t* actor_ids_dev, int n, void* stream);
+int mqe_set_dof_state_indexed(mqe_sim* s, const int32_t* actor_ids_dev, int n, void* stream);
+/* Go1.reset (go1.py:147-151): reset_idx(all) + compute_observations, no physics step */
+int mqe_reset_all(mqe_sim* s, void* stream);
+
+/* ---- fused fast path: one Go1.step (go1.py:35-62) + task wrapper ----
+ * actions: [N, A', 3] raw policy actions in [-1,1] (the wrapper's clip and action_scale are applied inside);
+ * results land in MQE_T_WRAPPER_OBS / MQE_T_WRAPPER_REWARD / MQE_T_RESET_BUF. */
+int mqe_step(mqe_sim* s, const float* actions, void* stream);
+
+/* bookkeeping for benchmarks: time of the dominant kernel measured with HIP events on `stream` */
+int mqe_profile_enable(mqe_sim* s, int on);
+int mqe_profile_read(mqe_sim* s, float* ms_per_kernel, int n, int* n_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,267 @@
+"""MQE config class -> `mqe_sim_desc` (include/mqe_hip.h).  Everything the reference hands to Isaac Gym at scene
+construction (legged_robot.py:754-923, go1.py:357-479, legged_robot_config.py:211-229) ends up in this one struct."""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import abi
+from ..utils import policy_weights, urdf_model
+
+# reward-term order per task: (scale attribute on cfg.rewards.scales, key in the wrapper's reward_buffer)
+REWARD_TERMS = {
+    "gate": [("target_reward_scale", "target reward"), ("contact_punishment_scale", "contact punishment"),
+             ("success_reward_scale", "success reward"), ("agent_distance_punishment_scale", "agent distance punishment")],
+    "sheep": [("success_reward_scale", "success reward"), ("contact_punishment_scale", "contact punishment"),
+              ("sheep_movement_reward_scale", "sheep movement reward"), ("mixed_sheep_reward_scale", "mixed sheep reward"),
+              ("sheep_pos_var_exp_punishment_scale", "sheep pos var punishment"), ("sheep_pos_var_lin_punishment_scale", None)],
+    "seesaw": [("x_movement_reward_scale", "x movement reward"), ("height_reward_scale", "height reward"),
+               ("y_punishment_scale", "y punishment"), ("contact_punishment_scale", "contact punishment"),
+               ("agent_distance_punishment_scale", "agent distance punishment"), ("success_reward_scale", "success reward"),
+               ("fall_punishment_scale", "fall punishment")],
+    "football_defender": [("goal_reward_scale", "goal reward"), ("ball_gate_distance_reward_scale", "ball gate distance reward")],
+    "plain": [],
+}
+
+
+def fill_command_obs(cfg):
+    """Default 70-float locomotion observation and the action-slot layout (reference go1.py:411-479)."""
+    dc, sc, cc = cfg.control.default_command, cfg.control.obs_scales, cfg.command.cfg
+    o = np.zeros(70, np.float32)
+    idx = {}
+    n = 0
+    if not cc.vel:
+        o[3], o[4], o[5] = dc.lin_vel_x * sc.lin_vel, dc.lin_vel_y * sc.lin_vel, dc.ang_vel * sc.ang_vel
+    else:
+        idx["vel"], n = n, n + 3
+    for flag, slot, val, scale in (("body_height", 6, dc.body_height, sc.body_height), ("gait_freq", 7, dc.gait_freq, sc.gait_freq)):
+        if not getattr(cc, flag):
+            o[slot] = val * scale
+        else:
+            idx[flag], n = n, n + 1
+    if not cc.gait:
+        g = cfg.command.gaits[dc.gait]
+        o[8], o[9], o[10], o[11] = g[0] * sc.gait_phase, g[1] * sc.gait_phase, g[2] * sc.gait_phase, 0.5 * sc.gait_phase
+    else:
+        idx["gait"], n = n, n + 4
+    if not cc.footswing_height:
+        o[12] = dc.footswing_height * sc.footswing_height
+    else:
+        idx["footswing_height"], n = n, n + 1
+    if not cc.body_pose:
+        o[13], o[14] = dc.body_pitch * sc.body_pitch, dc.body_roll * sc.body_roll
+    else:
+        idx["body_pose"], n = n, n + 2
+    for flag, slot, val, scale in (("stance_width", 15, dc.stance_width, sc.stance_width),
+                                   ("stance_length", 16, dc.stance_length, sc.stance_length),
+                                   ("aux_reward", 17, dc.aux_reward, sc.aux_reward)):
+        if not getattr(cc, flag):
+            o[slot] = val * scale
+        else:
+            idx[flag], n = n, n + 1
+    return o, idx
+
+
+def _fp(arr, keep):
+    a = np.ascontiguousarray(arr, dtype=np.float32)
+    keep.append(a)
+    return a.ctypes.data_as(abi.FP)
+
+
+def _fill_mlp(m, Ws, bs, keep):
+    m.n_layers = len(Ws)
+    m.dims[0] = Ws[0].shape[1]
+    for i, (w, b) in enumerate(zip(Ws, bs)):
+        m.dims[i + 1] = w.shape[0]
+        m.W[i] = _fp(w, keep)
+        m.b[i] = _fp(b, keep)
+
+
+def task_kind(cfg):
+    name = getattr(cfg.env, "env_name", "")
+    npc = getattr(cfg.asset, "name_npc", "")
+    if name == "go1gate":
+        return "gate"
+    if name == "go1sheep":
+        return "sheep"
+    if name == "go1seesaw":
+        return "seesaw"
+    if name == "go1football" and cfg.env.num_agents == 3 and npc == "ball":
+        return "football_defender"
+    return "plain"
+
+
+def build_desc(cfg, num_envs, terrain, env_origins, agent_origins, gate_pos=None, env_id_offset=0, seed=0,
+               task=None, body=None, resources_root=None, solver_iterations=8, erp=0.2, noise_mode=0):
+    """Returns (SimDesc, keepalive) -- keepalive holds the numpy arrays the struct points into."""
+    keep = []
+    d = abi.SimDesc()
+    A = getattr(cfg.env, "num_agents", 1)
+    P = getattr(cfg.env, "num_npcs", 0)
+    task = task or task_kind(cfg)
+    d.abi_version = abi.ABI_VERSION
+    d.num_envs, d.num_agents, d.num_npcs = num_envs, A, P
+    d.npc_kind = abi.NPC[getattr(cfg.asset, "name_npc", "") or "none"]
+    d.task = abi.TASK[task]
+    d.env_id_offset, d.seed = env_id_offset, seed
+    px = cfg.sim.physx
+    d.dt, d.decimation, d.gravity_z = cfg.sim.dt, cfg.control.decimation, cfg.sim.gravity[2]
+    d.solver_iterations = solver_iterations
+    d.contact_offset, d.max_depenetration_velocity = px.contact_offset, px.max_depenetration_velocity
+    d.friction = 0.5 * (cfg.terrain.static_friction + 1.0)   # average of terrain and (default 1.0) shape friction
+    d.erp = erp
+    # robot model
+    m = urdf_model.load_model("go1", resources_root)
+    r = d.robot
+    for b in range(abi.NBODY):
+        r.mass[b] = m["mass"][b]
+        I = np.asarray(m["inertia"][b])
+        for k, v in enumerate((I[0, 0], I[1, 1], I[2, 2], I[0, 1], I[0, 2], I[1, 2])):
+            r.inertia[b][k] = v
+        for k in range(3):
+            r.com[b][k] = m["com"][b][k]
+            r.joint_offset[b][k] = m["joint_offset"][b][k]
+            r.joint_axis[b][k] = m["joint_axis"][b][k]
+    for j in range(abi.NDOF):
+        r.dof_lower[j], r.dof_upper[j] = m["dof_lower"][j], m["dof_upper"][j]
+    r.n_spheres = len(m["sphere_body"])
+    for s in range(r.n_spheres):
+        r.sphere_body[s], r.sphere_reported[s], r.sphere_radius[s] = m["sphere_body"][s], m["sphere_reported"][s], m["sphere_radius"][s]
+        for k in range(3):
+            r.sphere_center[s][k] = m["sphere_center"][s][k]
+    # NPC objects
+    if d.npc_kind in (abi.NPC["ball"], abi.NPC["sheep"]):
+        om = urdf_model.load_model("ball" if d.npc_kind == abi.NPC["ball"] else "sheep", resources_root)["bodies"][0]
+        d.npc_mass, d.npc_inertia = om["mass"], om["inertia"][0][0]
+        kind, prm, _, t = om["shapes"][0]
+        if kind == "sphere":
+            d.npc_n_spheres = 1
+            d.npc_sphere_radius[0] = prm
+            for k in range(3):
+                d.npc_sphere_center[0][k] = t[k]
+        else:  # upright cylinder (radius, length) -> two stacked spheres spanning the same height
+            rad, length = prm
+            d.npc_n_spheres = 2
+            for i, sgn in enumerate((-1.0, 1.0)):
+                d.npc_sphere_radius[i] = rad
+                d.npc_sphere_center[i][0], d.npc_sphere_center[i][1] = t[0], t[1]
+                d.npc_sphere_center[i][2] = t[2] + sgn * max(0.0, length / 2 - rad)
+    if d.npc_kind == abi.NPC["seesaw"]:
+        bodies = urdf_model.load_model("seesaw", resources_root)["bodies"]
+        base, plank = bodies[0], bodies[1]
+        for k in range(3):
+            d.seesaw_joint_offset[k] = plank["joint_offset"][k]
+            d.seesaw_plank_center[k] = plank["shapes"][0][3][k]
+            d.seesaw_plank_half[k] = plank["shapes"][0][1][k]
+            d.seesaw_base_half[k] = base["shapes"][0][1][k]
+        d.seesaw_plank_mass, d.seesaw_plank_inertia_yy = plank["mass"], plank["inertia"][1][1]
+        d.seesaw_vel_limit = plank["velocity"]
+        d.seesaw_default_angle = getattr(cfg.init_state, "default_npc_joint_angles", [0.0])[0]
+    # control
+    ctl = cfg.control
+    d.control_type = abi.CTRL[ctl.control_type]
+    d.action_scale, d.hip_scale_reduction = ctl.action_scale, getattr(ctl, "hip_scale_reduction", 1.0)
+    d.clip_actions = cfg.normalization.clip_actions
+    names = m["dof_names"]
+    tl = getattr(ctl, "torque_limits", None)
+    for j in range(abi.NDOF):
+        d.torque_limits[j] = (tl[j % len(tl)] if isinstance(tl, (list, tuple)) else tl) if tl is not None else m["dof_effort"][j]
+        d.default_dof_pos[j] = cfg.init_state.default_joint_angles[names[j]]
+    d.kp = next((v for k, v in ctl.stiffness.items() if k in names[0]), 0.0)
+    d.kd = next((v for k, v in ctl.damping.items() if k in names[0]), 0.0)
+    cmd, _ = fill_command_obs(cfg)
+    for k in range(70):
+        d.command_obs[k] = cmd[k]
+    d.cmd_lin_scale, d.cmd_ang_scale = ctl.obs_scales.lin_vel, ctl.obs_scales.ang_vel
+    d.clip_command = 0 if task == "football_defender" else 1
+    # terrain
+    d.wall_sdf = _fp(terrain.wall_sdf, keep)
+    d.sdf_nx, d.sdf_ny = terrain.wall_sdf.shape
+    d.horizontal_scale, d.wall_height, d.ground_z = cfg.terrain.horizontal_scale, terrain.wall_height, terrain.ground_z
+    d.env_origins = _fp(env_origins, keep)
+    d.agent_origins = _fp(agent_origins, keep)
+    st = cfg.init_state
+    if getattr(st, "multi_init_state", False):
+        base = [s.pos + s.rot + s.lin_vel + s.ang_vel for s in st.init_states]
+    else:
+        base = [st.pos + st.rot + st.lin_vel + st.ang_vel] * A
+    assert len(base) == A, "need one init state per agent"
+    d.base_init_state = _fp(np.asarray(base, np.float32), keep)
+    if P:
+        npc_init = _npc_init_states(cfg, P)
+        d.npc_init_state = _fp(npc_init, keep)
+    if gate_pos is not None:
+        d.gate_pos = _fp(gate_pos, keep)
+    # termination
+    dt_policy = ctl.decimation * cfg.sim.dt
+    d.max_episode_length = int(np.ceil(cfg.env.episode_length_s / dt_policy))
+    tm = getattr(cfg, "termination", None)
+    flags = 0
+    if tm is not None:
+        for t in tm.termination_terms:
+            flags |= abi.TERM[t]
+        d.roll_threshold, d.pitch_threshold = tm.roll_kwargs["threshold"], tm.pitch_kwargs["threshold"]
+        d.z_low_threshold, d.z_high_threshold = tm.z_low_kwargs["threshold"], tm.z_high_kwargs["threshold"]
+    d.termination_flags = flags
+    d.terminate_on_base_contact = 1 if len(cfg.asset.terminate_after_contacts_on) else 0
+    # reset distribution
+    dr = cfg.domain_rand
+    d.noise_mode = noise_mode
+    rr = getattr(dr, "init_dof_pos_ratio_range", None) or [1.0, 1.0]
+    d.dof_ratio_lo, d.dof_ratio_hi = rr
+    bp = getattr(dr, "init_base_pos_range", None)
+    if bp is not None:
+        d.has_base_pos_range = 1
+        d.base_pos_x_lo, d.base_pos_x_hi = bp["x"]
+        d.base_pos_y_lo, d.base_pos_y_hi = bp["y"]
+    npr = getattr(dr, "init_npc_base_pos_range", None)
+    if npr is not None and P:
+        d.has_npc_pos_range = 1
+        d.npc_pos_x_lo, d.npc_pos_x_hi = npr["x"]
+        d.npc_pos_y_lo, d.npc_pos_y_hi = npr["y"]
+    bv = getattr(dr, "init_base_vel_range", None) or (-0.5, 0.5)
+    d.base_vel_lo, d.base_vel_hi = bv
+    d.sheep_movement_scale = getattr(cfg.asset, "sheep_movement_scale", 0.0)
+    d.sheep_movement_randomness = getattr(cfg.asset, "sheep_movement_randomness", 0.0)
+    for i, (attr, _) in enumerate(REWARD_TERMS[task]):
+        d.reward_scale[i] = float(getattr(cfg.rewards.scales, attr, 0.0))
+    kw = cfg.terrain.BarrierTrack_kwargs
+    if task == "gate":
+        d.wrapper_param[0] = kw["init"]["block_length"] + kw["gate"]["block_length"] + kw["plane"]["block_length"] / 2
+        d.wrapper_param[1] = kw["track_width"] / 4
+    # networks
+    aW, ab = policy_weights.load_actuator_net()
+    dW, db = policy_weights.load_adaptation_module()
+    if body is None:
+        bW, bb, synthetic = policy_weights.load_body(getattr(ctl, "locomotion_policy_dir", None), seed=0)
+    else:
+        bW, bb = body
+        synthetic = False
+    _fill_mlp(d.actuator, aW, ab, keep)
+    _fill_mlp(d.adaptation, dW, db, keep)
+    _fill_mlp(d.body, bW, bb, keep)
+    keep.append(("body_is_synthetic", synthetic))
+    return d, keep
+
+
+def _npc_init_states(cfg, P):
+    """Per-NPC initial root state.  ball/seesaw: cfg.init_state.init_states_npc (go1_object.py:27-51);
+    sheep: a num_rows x num_cols grid centred on the second block (go1_sheep.py:84-118) -- the reference also
+    draws a random yaw per sheep from np.random there; we draw the same way so seeded runs agree."""
+    if hasattr(cfg.init_state, "init_states_npc"):
+        return np.asarray([s.pos + s.rot + s.lin_vel + s.ang_vel for s in cfg.init_state.init_states_npc], np.float32)
+    a, kw = cfg.asset, cfg.terrain.BarrierTrack_kwargs
+    nr, nc, dis = a.num_rows, a.num_cols, a.dis_sheep
+    origin = np.array([kw["init"]["block_length"] + kw["plane"]["block_length"] / 2 - nr // 2 * dis[0], -(nc // 2) * dis[1], 0.3])
+    pos = origin.copy()
+    out = []
+    for i in range(nr):
+        for j in range(nc):
+            rot = np.array([0.0, 0.0, 0.0, 1.0]) + np.random.randn(4) * np.array([0, 0, math.pi, 1])
+            rot = rot / np.linalg.norm(rot)   # the reference hands the raw 4-vector to PhysX, which normalises it
+            out.append(np.concatenate((pos, rot, np.zeros(3), np.zeros(3))))
+            pos[1] += dis[1]
+        pos[0] += dis[0]
+        pos[1] = origin[1]
+    assert len(out) == P
+    return np.asarray(out, np.float32)

@@ -1,0 +1,82 @@
+"""Loader of the HIP engine (csrc/ -> libmqe_hip.so).  There is NO CPU fallback: without the built library or
+without a GPU this raises -- the product path never silently runs anything else."""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from . import abi
+from .base import EngineBase, _DevArray, _TORCH_DT
+
+_LIB = None
+LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "csrc", "libmqe_hip.so")
+
+
+def load_library():
+    global _LIB
+    if _LIB is None:
+        if not os.path.isfile(LIB_PATH):
+            raise RuntimeError(f"HIP engine not built: {LIB_PATH} missing (run `python -c 'import __graft_entry__ as g; g.build()'`)")
+        _LIB = C.CDLL(LIB_PATH)
+    return _LIB
+
+
+class HipEngine(EngineBase):
+    prefix = "mqe_"
+    device = "cuda"
+
+    def __init__(self, desc, keepalive, device="cuda:0"):
+        if not torch.cuda.is_available():
+            raise RuntimeError("mqe HIP engine needs an AMD GPU (torch.cuda.is_available() is False); there is no CPU path")
+        self.torch_device = torch.device(device)
+        torch.cuda.set_device(self.torch_device)
+        super().__init__(load_library(), desc, keepalive)
+        lib = self.lib
+        vp = C.c_void_p
+        for name, args in (("policy_step", [vp, vp, vp]), ("compute_torques", [vp, vp]), ("simulate", [vp, vp]),
+                           ("post_decimation_step", [vp, C.c_int, vp]), ("post_physics_step", [vp, vp]),
+                           ("reset_all", [vp, vp]), ("step", [vp, vp, vp]),
+                           ("profile_enable", [vp, C.c_int]),
+                           ("profile_read", [vp, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)])):
+            f = getattr(lib, "mqe_" + name)
+            f.argtypes, f.restype = args, C.c_int
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.torch_device).cuda_stream)
+
+    def _wrap(self, ptr, shape, dtype):
+        typestr = {0: "<f4", 1: "<i4", 2: "|u1"}[dtype]
+        return torch.as_tensor(_DevArray(ptr, shape, typestr), device=self.torch_device)
+
+    def policy_step(self, command):
+        assert command.is_cuda and command.dtype == torch.float32 and command.is_contiguous()
+        self._call("policy_step", C.c_void_p(command.data_ptr()), self._stream())
+
+    def compute_torques(self):
+        self._call("compute_torques", self._stream())
+
+    def simulate(self):
+        self._call("simulate", self._stream())
+
+    def post_decimation_step(self, i):
+        self._call("post_decimation_step", int(i), self._stream())
+
+    def post_physics_step(self):
+        self._call("post_physics_step", self._stream())
+
+    def reset_all(self):
+        self._call("reset_all", self._stream())
+
+    def step(self, actions):
+        assert actions.is_cuda and actions.dtype == torch.float32 and actions.is_contiguous()
+        self._call("step", C.c_void_p(actions.data_ptr()), self._stream())
+
+    def profile_enable(self, on=True):
+        self._call("profile_enable", int(bool(on)))
+
+    def profile_read(self, n=16):
+        buf = (C.c_float * n)()
+        cnt = C.c_int(0)
+        self._call("profile_read", buf, n, C.byref(cnt))
+        return list(buf), cnt.value

@@ -1,0 +1,279 @@
+"""Go1: the vectorised multi-agent Go1 environment, host side.
+
+Mirrors the surface of the reference class stack Go1 -> LeggedRobotField -> LeggedRobot -> BaseTask
+(mqe/envs/go1/go1.py:19-62,147-151; mqe/envs/base/legged_robot.py:54-157,549-645; mqe/envs/base/base_task.py:40-105)
+but owns no simulation logic: every per-step computation runs in the HIP engine behind the C ABI
+(include/mqe_hip.h).  This class (1) builds the scene description once -- BarrierTrack terrain, env/agent origins,
+robot model, MLP weights -- and (2) exposes the long-lived state tensors the reference's wrappers and users reach
+for (`root_states`, `dof_pos`, `obs_buf.base_pos`, `collide_buf`, ...) as zero-copy views of engine memory.
+"""
+import types
+
+import numpy as np
+import torch
+
+from mqe.engine import abi
+from mqe.engine.desc import build_desc, task_kind, REWARD_TERMS
+from mqe.utils.helpers import class_to_dict
+from mqe.utils.terrain import get_terrain_cls
+
+
+class ObsBag:
+    """Attribute bag returned by Go1.step()/reset() (reference: obs_buf = copy(cfg.obs), go1.py:26,153-196).
+    Every field is a live view into the engine's observation buffer."""
+
+    def __init__(self, cfg_obs, bag, env_info):
+        self.cfgs = cfg_obs.cfgs
+        self.scales = getattr(cfg_obs, "scales", None)
+        for name, (a, b) in abi.BAG.items():
+            setattr(self, name, bag[:, a:b])
+        if env_info is not None and getattr(cfg_obs.cfgs, "env_info", False):
+            self.env_info = env_info
+
+    def keys(self):
+        return [k for k in dir(self.cfgs) if getattr(self.cfgs, k) is True]
+
+
+def _default_engine_factory(desc, keep, device):
+    from mqe.engine.hip_engine import HipEngine
+    return HipEngine(desc, keep, device=device)
+
+
+class Go1:
+    # engine_factory(desc, keepalive, device) -> engine; the default (and only product) engine is the HIP one.
+    engine_factory = staticmethod(_default_engine_factory)
+    # sharding of a global batch across processes / GPUs: (global_num_envs, first_global_env) or None
+    shard = None
+
+    def __init__(self, cfg, sim_params, physics_engine, sim_device, headless):
+        self.cfg = cfg
+        self.env_name = getattr(cfg.env, "env_name", "go1")
+        self.sim_params = sim_params
+        self.physics_engine = physics_engine
+        self.sim_device = sim_device
+        self.headless = headless
+        self.device = sim_device if getattr(sim_params, "use_gpu_pipeline", True) else "cpu"
+        self.num_envs = cfg.env.num_envs
+        self.num_agents = getattr(cfg.env, "num_agents", 1)
+        self.num_npcs = getattr(cfg.env, "num_npcs", 0)
+        self.num_obs = cfg.env.num_observations
+        self.num_privileged_obs = cfg.env.num_privileged_obs
+        self.num_action = cfg.env.num_actions
+        self.num_actions = self.num_agents * cfg.env.num_actions
+        self.num_actions_npc = getattr(cfg.env, "num_actions_npc", 0) * self.num_npcs
+        self.num_dof = 12
+        self.num_actuated_dof = 12 * self.num_agents
+        self.num_bodies = abi.NREP
+        self.decimation = cfg.control.decimation
+        self._parse_cfg()
+        self._create_scene()
+        self._init_buffers()
+        self.init_done = True
+
+    # ---- configuration (reference legged_robot.py:1013-1024) -------------------------------------------------
+    def _parse_cfg(self):
+        cfg = self.cfg
+        self.dt = cfg.control.decimation * self.sim_params.dt
+        self.obs_scales = cfg.normalization.obs_scales
+        self.reward_scales = class_to_dict(cfg.rewards.scales)
+        self.max_episode_length_s = cfg.env.episode_length_s
+        self.max_episode_length = np.ceil(self.max_episode_length_s / self.dt)
+        cfg.env.max_episode_length = self.max_episode_length
+
+    # ---- scene construction (reference create_sim, legged_robot.py:255-261,754-923,972-997) ---------------------
+    def _create_scene(self):
+        cfg = self.cfg
+        N, A = self.num_envs, self.num_agents
+        gN, g0 = self.shard if self.shard is not None else (N, 0)
+        terrain_cls = get_terrain_cls(cfg.terrain.selected)
+        self.terrain = terrain_cls(cfg.terrain, N, A).build()
+        self.custom_origins = True
+        t = self.terrain
+        max_init_level = cfg.terrain.max_init_terrain_level if cfg.terrain.curriculum else cfg.terrain.num_rows - 1
+        # levels/types are functions of the GLOBAL env index so that a sharded run sees the same scene
+        levels = torch.randint(0, max_init_level + 1, (gN,))[g0:g0 + N]
+        types_ = (torch.arange(gN) % cfg.terrain.num_cols)[g0:g0 + N]
+        self.terrain_levels, self.terrain_types = levels, types_
+        self.max_terrain_level = cfg.terrain.num_rows
+        eo = torch.from_numpy(t.env_origins).float()[levels, types_]
+        ao = torch.from_numpy(t.agent_origins).float()[levels, types_]
+        info = {k: torch.from_numpy(v).float()[levels, types_] for k, v in (t.env_info or {}).items()}
+        self._env_origins_np = eo.numpy().copy()
+        self._agent_origins_np = ao.numpy().copy()
+        self._env_info_np = {k: v.numpy().copy() for k, v in info.items()}
+        self.task = task_kind(cfg)
+        gate_pos = self._task_gate_pos()
+        desc, keep = build_desc(cfg, N, t, self._env_origins_np, self._agent_origins_np, gate_pos=gate_pos,
+                                env_id_offset=g0, seed=int(getattr(self, "seed", 0)), task=self.task)
+        self.body_is_synthetic = dict(k for k in keep if isinstance(k, tuple)).get("body_is_synthetic", True)
+        self.engine = type(self).engine_factory(desc, keep, self.device)
+        self.device = str(self.engine.torch_device) if hasattr(self.engine, "torch_device") else self.device
+
+    def _task_gate_pos(self):
+        """(N,2) per-env gate position the task wrapper / scripted defender uses, or None."""
+        kw = self.cfg.terrain.BarrierTrack_kwargs
+        gd = self._env_info_np.get("gate_deviation")
+        if self.task == "gate":      # go1_gate_wrapper.py:41-42
+            g = gd.copy()
+            g[:, 0] += kw["init"]["block_length"] + kw["gate"]["block_length"] / 2
+            return g
+        if self.task == "sheep":     # go1_sheep_wrapper.py:31-33
+            g = gd.copy()
+            g[:, 0] += kw["init"]["block_length"] + kw["plane"]["block_length"] + kw["gate"]["block_length"] / 2
+            return g
+        if self.task == "football_defender":   # go1_football_defender.py:61-63 (absolute frame)
+            g = self._env_origins_np[:, :2].copy()
+            g[:, 0] += kw["init"]["block_length"] + kw["plane"]["block_length"]
+            return g
+        return None
+
+    # ---- buffers: zero-copy views (reference _init_buffers, legged_robot.py:549-645; go1.py:357-387) ------------
+    def _init_buffers(self):
+        e, N, A, P = self.engine, self.num_envs, self.num_agents, self.num_npcs
+        T = e.tensor
+        dev = e.torch_device
+        self.all_root_states = T(abi.T_ROOT_STATE).view(N * (A + P), 13)
+        self._root3 = T(abi.T_ROOT_STATE)
+        self.all_dof_states = T(abi.T_DOF_STATE).view(-1, 2)
+        self.dof_state = T(abi.T_DOF_STATE)[:, :12 * A, :]
+        self.dof_pos = self.dof_state[:, :, 0]
+        self.dof_vel = self.dof_state[:, :, 1]
+        if self.num_actions_npc > 0:
+            self.dof_state_npc = T(abi.T_DOF_STATE)[:, 12 * A:, :]
+            self.dof_pos_npc = self.dof_state_npc[:, :, 0]
+            self.dof_vel_npc = self.dof_state_npc[:, :, 1]
+        self.contact_forces = T(abi.T_CONTACT_FORCE)
+        self.torques = T(abi.T_TORQUES)
+        self.actions = T(abi.T_ACTIONS)
+        self.last_actions = T(abi.T_LAST_ACTIONS)
+        self.locomotion_obs = T(abi.T_LOCOMOTION_OBS)[:, :70]
+        self.last_locomotion_action = T(abi.T_LAST_LOCO_ACTION)
+        self.last_two_locomotion_action = T(abi.T_LAST_TWO_LOCO_ACTION)
+        ah = T(abi.T_ACT_HIST)
+        self.joint_pos_err_last, self.joint_pos_err_last_last, self.joint_vel_last, self.joint_vel_last_last = ah[0], ah[1], ah[2], ah[3]
+        self.gait_indices = T(abi.T_GAIT_INDICES)
+        self.clock_inputs = T(abi.T_CLOCK_INPUTS)
+        self.base_lin_vel = T(abi.T_BASE_LIN_VEL)
+        self.base_ang_vel = T(abi.T_BASE_ANG_VEL)
+        self.projected_gravity = T(abi.T_PROJECTED_GRAVITY)
+        self.base_quat = T(abi.T_BASE_QUAT)
+        self.episode_length_buf = T(abi.T_EPISODE_LENGTH)
+        self.reset_buf = T(abi.T_RESET_BUF).view(torch.bool)
+        self.collide_buf = T(abi.T_COLLIDE_BUF).view(torch.bool)
+        self.time_out_buf = T(abi.T_TIME_OUT_BUF).view(torch.bool)
+        self.r_term_buff = T(abi.T_R_TERM).view(torch.bool)
+        self.p_term_buff = T(abi.T_P_TERM).view(torch.bool)
+        self.z_high_term_buff = T(abi.T_Z_HIGH_TERM).view(torch.bool)
+        self.substep_torques = T(abi.T_SUBSTEP_TORQUES)
+        self.sheep_pos_avg = T(abi.T_SHEEP_POS_AVG)
+        self.sheep_pos_var = T(abi.T_SHEEP_POS_VAR)
+        self.npc_noise = T(abi.T_NPC_NOISE)
+        self.rew_buf = torch.zeros(N * A, device=dev)                    # Go1 registers no reward functions (go1.py:198-219)
+        self.env_origins = torch.from_numpy(self._env_origins_np).to(dev)
+        self.env_origins_repeat = self.env_origins.unsqueeze(1).repeat(1, A, 1).reshape(-1, 3)
+        self.agent_origins = torch.from_numpy(self._agent_origins_np).to(dev)
+        self.npc_env_origins = self.env_origins.unsqueeze(1).repeat(1, max(P, 1), 1)[:, :P]
+        self.env_info = {k: torch.from_numpy(v).to(dev) for k, v in self._env_info_np.items()}
+        self.default_dof_pos = torch.tensor([self.engine.desc.default_dof_pos[j] for j in range(12)] * A, device=dev).unsqueeze(0)
+        self.torque_limits = torch.tensor([self.engine.desc.torque_limits[j] for j in range(12)] * A, device=dev)
+        self.base_init_state = torch.from_numpy(np.ctypeslib.as_array(self.engine.desc.base_init_state, shape=(A, 13)).copy()).to(dev).repeat(N, 1)
+        self.env_agent_indices = torch.arange(N * A, device=dev).reshape(N, A)
+        self.env_npc_indices = torch.arange(N * P, device=dev).reshape(N, P)
+        self.actor_indices = torch.arange(N * (A + P), dtype=torch.int32, device=dev).reshape(N, A + P)
+        self.agent_indices = self.actor_indices[:, :A]
+        self.npc_indices = self.actor_indices[:, A:]
+        self.obs_buf = ObsBag(self.cfg.obs, T(abi.T_OBS_BAG), self.env_info if self.env_info else None)
+        self.privileged_obs_buf = None
+        self.extras = {"time_outs": self.time_out_buf, "episode": {}}
+        self.common_step_counter = 0
+        if self.task == "football_defender":
+            self.gate_pos = torch.zeros(N, 3, device=dev)
+            self.gate_pos[:, :2] = torch.from_numpy(self._task_gate_pos()).to(dev)
+            self.gate_pos[:, 2] = self.env_origins[:, 2]
+
+    # ---- derived views ------------------------------------------------------------------------------------------
+    @property
+    def root_states(self):
+        """(N*A, 13): agents' rows of the actor root-state tensor (legged_robot.py:130)."""
+        r = self._root3[:, :self.num_agents, :]
+        return r.reshape(-1, 13)
+
+    @property
+    def root_states_npc(self):
+        return self._root3[:, self.num_agents:, :].reshape(-1, 13)
+
+    @property
+    def base_pos(self):
+        return self.root_states[:, 0:3]
+
+    @property
+    def reset_ids(self):
+        """Indices of the envs reset by the last step (legged_robot.py:145-147).  Materialising them is a
+        device->host sync; the fused path never needs it."""
+        return self.reset_buf.nonzero(as_tuple=False).flatten()
+
+    @property
+    def history_locomotion_obs(self):
+        """(R, 2100) time-ordered history (go1.py:102,395) gathered from the engine's ring buffer."""
+        h = self.engine.tensor(abi.T_HISTORY)
+        pos = self._hist_pos()
+        idx = (torch.arange(abi.HIST, device=h.device) + pos) % abi.HIST
+        return h[:, idx, :70].reshape(h.shape[0], -1)
+
+    def _hist_pos(self):
+        return getattr(self, "_steps_policy", 0) % abi.HIST
+
+    # ---- reference API --------------------------------------------------------------------------------------------
+    def reset(self):
+        """Reset all robots (go1.py:147-151): no physics step, observations recomputed."""
+        self.engine.reset_all()
+        return self.obs_buf
+
+    def step(self, action):
+        """One policy step from already-scaled commands (go1.py:35-62); action: (N*A, 3) or (N, A, 3)."""
+        if self.cfg.control.control_type != "C":
+            raise NotImplementedError("this entry point drives control_type 'C'; P/V/T torques are engine modes set at construction")
+        cmd = action.reshape(-1, 3).to(self.engine.torch_device, torch.float32).contiguous()
+        if self.task == "football_defender" and cmd.shape[0] == self.num_envs * 2:
+            raise NotImplementedError("call the task wrapper (fused path) for go1football-defender; the scripted "
+                                      "defender command is generated inside the engine")
+        e = self.engine
+        e.policy_step(cmd)
+        self._steps_policy = getattr(self, "_steps_policy", 0) + 1
+        for dec_i in range(self.decimation):
+            e.compute_torques()
+            e.simulate()
+            e.post_decimation_step(dec_i)
+        e.post_physics_step()
+        self.common_step_counter += 1
+        return self.obs_buf, self.rew_buf, self.reset_buf, self.extras
+
+    def step_fused(self, actions):
+        """Wrapper-level step: raw actions (N, A', 3) in [-1,1]; clip, task action scale, policy, 4 substeps,
+        post-step, task observation and reward all inside the engine (mqe_step)."""
+        a = actions.to(self.engine.torch_device, torch.float32).contiguous()
+        self.engine.step(a)
+        self._steps_policy = getattr(self, "_steps_policy", 0) + 1
+        self.common_step_counter += 1
+
+    def get_observations(self):
+        return self.obs_buf
+
+    def get_privileged_observations(self):
+        return None
+
+    def render(self, *a, **k):
+        return None
+
+    def close(self):
+        self.engine.close()
+
+    # indexed setters of the Isaac Gym tensor API are no-ops here: state tensors are live engine memory
+    def set_dof_state_tensor_indexed(self, *a):
+        return True
+
+    def set_actor_root_state_tensor_indexed(self, *a):
+        return True
+
+
+__all__ = ["Go1", "ObsBag", "REWARD_TERMS"]

@@ -1,0 +1,1317 @@
+/* mqe_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Scalar CPU restatement of the env.step() hot path of ziyanx02/multiagent-quadruped-environment (MQE) used as
+ * the parity checker for the HIP engine (tests/, __graft_entry__.smoke(), bench.py's cpu_baseline leg only).
+ *
+ * Pinning status:
+ *   - everything AROUND the physics (policy MLPs, torque pipeline, command observation/history, gait clock,
+ *     termination, reset bookkeeping, observation bag, task wrappers, NPC scripts) restates the reference's
+ *     Python line by line (citations at each function) and is pinned by tests/golden/*.npz, which were produced
+ *     by importing that Python (tools/gen_golden.py).
+ *   - the rigid-body physics (mqo_simulate) has NO reference to restate: in MQE it lives inside Isaac Gym
+ *     Preview 4 / PhysX (closed source, CUDA only; call sites go1.py:52-56).  PARITY UNPINNED for that row: the
+ *     algorithm here is the build's own specification (DESIGN.md "physics"), written the textbook way
+ *     (per-body Jacobian sums for the mass matrix, dense Cholesky, row-wise projected Gauss-Seidel) so that it
+ *     is an independent check of the wavefront-parallel HIP formulation (CRBA, Schur-complement inverse).
+ *     It is pinned by physical known-answer tests (free fall, momentum, energy, static stand) in tests/.
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -fopenmp).  -DREAL=double builds the float64 variant.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/mqe_hip.h"
+
+#ifndef REAL
+#define REAL float
+#endif
+typedef REAL real;
+
+#define MAXA MQE_MAX_AGENTS
+#define MAXP MQE_MAX_NPCS
+#define NB MQE_NBODY
+#define RD 18                       /* dofs of one robot: 3 lin + 3 ang + 12 joints */
+#define MAXDOF (MAXA * RD + MAXP * 6 + 1)
+#define MAXC 64                     /* contacts per env */
+#define FR MQE_FRAME
+#define OBS_BAG 74
+
+static char g_err[512];
+const char* mqo_last_error(void) { return g_err; }
+
+typedef struct {
+  int n_layers;
+  int dims[MQE_MAX_LAYERS + 1];
+  float* W[MQE_MAX_LAYERS];
+  float* b[MQE_MAX_LAYERS];
+} mlp_t;
+
+typedef struct mqo_sim {
+  mqe_sim_desc d;
+  int N, A, P, R, ND, NBR, Aw, D;   /* ND dofs per env in DOF_STATE, NBR reported bodies per env, Aw wrapper agents */
+  int npc_dofs, npc_bodies;
+  mlp_t act, ada, body;
+  float* sdf;
+  float *env_origins, *agent_origins, *base_init, *npc_init, *gate_pos;
+  /* state */
+  float *root, *dof, *cf, *torques, *actions, *last_actions, *loco_obs, *hist, *last_loco, *last_two_loco;
+  float *act_hist, *gait, *clock, *blv, *bav, *pg, *bquat, *obs_bag, *wobs, *wrew, *rsum, *sheep_avg, *sheep_var;
+  float *sub_tau, *npc_noise;
+  int32_t *ep_len, *reset_count;
+  uint8_t *reset_buf, *collide_buf, *time_out, *r_term, *p_term, *zh_term;
+  /* wrapper memory */
+  float *w_last, *w_last2;          /* per env: previous distances / x positions */
+  uint8_t *w_have_last, *w_delayed_reset;
+  int hist_pos;                     /* ring slot that holds the OLDEST frame == next write slot */
+  int n_post_steps;                 /* post_physics_step calls so far (base_quat aliasing, see mqo_reset_all) */
+  void* tens[MQE_T_COUNT];
+} mqo_sim;
+
+/* ------------------------------------------------------------------------------------------ small math */
+static inline void cross3(const real* a, const real* b, real* o) {
+  real x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+static inline real dot3(const real* a, const real* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static inline void mat3_vec(const real* M, const real* v, real* o) {
+  real x = M[0] * v[0] + M[1] * v[1] + M[2] * v[2], y = M[3] * v[0] + M[4] * v[1] + M[5] * v[2],
+       z = M[6] * v[0] + M[7] * v[1] + M[8] * v[2];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+static inline void mat3_mul(const real* A, const real* B, real* C) {
+  real t[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) t[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+  memcpy(C, t, sizeof t);
+}
+static void quat_to_mat(const real* q, real* R) { /* xyzw */
+  real x = q[0], y = q[1], z = q[2], w = q[3];
+  R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w); R[2] = 2 * (x * z + y * w);
+  R[3] = 2 * (x * y + z * w); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
+  R[6] = 2 * (x * z - y * w); R[7] = 2 * (y * z + x * w); R[8] = 1 - 2 * (x * x + y * y);
+}
+static void axis_angle_mat(const real* a, real th, real* R) {
+  real c = (real)cos((double)th), s = (real)sin((double)th), t = 1 - c;
+  R[0] = t * a[0] * a[0] + c; R[1] = t * a[0] * a[1] - s * a[2]; R[2] = t * a[0] * a[2] + s * a[1];
+  R[3] = t * a[0] * a[1] + s * a[2]; R[4] = t * a[1] * a[1] + c; R[5] = t * a[1] * a[2] - s * a[0];
+  R[6] = t * a[0] * a[2] - s * a[1]; R[7] = t * a[1] * a[2] + s * a[0]; R[8] = t * a[2] * a[2] + c;
+}
+
+/* quat_rotate_inverse of isaacgym.torch_utils as used at legged_robot.py:133-135 (float32, same op order) */
+static void quat_rotate_inverse_f(const float* q, const float* v, float* o) {
+  float qw = q[3];
+  float s = 2.0f * qw * qw - 1.0f;
+  float cx = q[1] * v[2] - q[2] * v[1], cy = q[2] * v[0] - q[0] * v[2], cz = q[0] * v[1] - q[1] * v[0];
+  float dt = q[0] * v[0] + q[1] * v[1] + q[2] * v[2];
+  o[0] = v[0] * s - cx * qw * 2.0f + q[0] * dt * 2.0f;
+  o[1] = v[1] * s - cy * qw * 2.0f + q[1] * dt * 2.0f;
+  o[2] = v[2] * s - cz * qw * 2.0f + q[2] * dt * 2.0f;
+}
+static float wrap2pi(float a) { /* python float32 % (2*pi) */
+  const float T = 6.2831855f;
+  float r = fmodf(a, T);
+  if (r < 0) r += T;
+  return r;
+}
+/* get_euler_xyz of isaacgym.torch_utils (go1.py:193, legged_robot_field.py:125): each angle in [0, 2pi) */
+static void euler_xyz_f(const float* q, float* rpy) {
+  float x = q[0], y = q[1], z = q[2], w = q[3];
+  float sinr = 2.0f * (w * x + y * z), cosr = w * w - x * x - y * y + z * z;
+  float sinp = 2.0f * (w * y - z * x);
+  float siny = 2.0f * (w * z + x * y), cosy = w * w + x * x - y * y - z * z;
+  float roll = atan2f(sinr, cosr);
+  float pitch = fabsf(sinp) >= 1.0f ? copysignf(1.5707964f, sinp) : asinf(sinp);
+  float yaw = atan2f(siny, cosy);
+  rpy[0] = wrap2pi(roll); rpy[1] = wrap2pi(pitch); rpy[2] = wrap2pi(yaw);
+}
+
+/* ------------------------------------------------------------------------------------------ RNG (resets) */
+static inline uint32_t mqo_hash(uint32_t seed, uint32_t genv, uint32_t count, uint32_t k) {
+  uint32_t x = seed * 0x9E3779B1u ^ genv * 0x85EBCA77u ^ count * 0xC2B2AE3Du ^ k * 0x27D4EB2Fu;
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  return x;
+}
+static inline float mqo_u01(uint32_t seed, uint32_t genv, uint32_t count, uint32_t k) {
+  return (float)(mqo_hash(seed, genv, count, k) >> 8) * (1.0f / 16777216.0f);
+}
+static inline float mqo_rand(const mqo_sim* s, int env, uint32_t k, float lo, float hi) {
+  float u = mqo_u01((uint32_t)s->d.seed, (uint32_t)(env + s->d.env_id_offset), (uint32_t)s->reset_count[env], k);
+  return (hi - lo) * u + lo; /* torch_rand_float: (upper-lower)*rand + lower */
+}
+float mqo_debug_u01(uint32_t seed, uint32_t genv, uint32_t count, uint32_t k) { return mqo_u01(seed, genv, count, k); }
+
+/* ------------------------------------------------------------------------------------------ MLPs */
+static void mlp_copy(mlp_t* dst, const mqe_mlp* src) {
+  dst->n_layers = src->n_layers;
+  memcpy(dst->dims, src->dims, sizeof dst->dims);
+  for (int l = 0; l < src->n_layers; l++) {
+    size_t nw = (size_t)src->dims[l] * src->dims[l + 1];
+    dst->W[l] = (float*)malloc(nw * 4);
+    memcpy(dst->W[l], src->W[l], nw * 4);
+    dst->b[l] = (float*)malloc((size_t)src->dims[l + 1] * 4);
+    memcpy(dst->b[l], src->b[l], (size_t)src->dims[l + 1] * 4);
+  }
+}
+static inline float softsign(float x) { return x / (1.0f + fabsf(x)); }
+static inline float elu(float x) { return x > 0 ? x : expm1f(x); }
+/* y = W x (+ b afterwards): k-ordered fmaf chain from 0, bias added last -- the accumulation order the HIP
+ * kernels use (an f32 MFMA is bitwise a k-ordered fmaf chain on gfx950) */
+static inline float dot_chain(const float* w, const float* x, int K) {
+  float acc = 0.0f;
+  for (int k = 0; k < K; k++) acc = fmaf(w[k], x[k], acc);
+  return acc;
+}
+/* actuator net, reference go1.py:367-382 (unitree_go1.pt: Linear(6,32) softsign Linear(32,32) softsign Linear(32,1)) */
+static float actuator_net(const mlp_t* m, const float* x6) {
+  float h1[32], h2[32];
+  for (int i = 0; i < 32; i++) h1[i] = softsign(dot_chain(m->W[0] + i * 6, x6, 6) + m->b[0][i]);
+  for (int i = 0; i < 32; i++) h2[i] = softsign(dot_chain(m->W[1] + i * 32, h1, 32) + m->b[1][i]);
+  return dot_chain(m->W[2], h2, 32) + m->b[2][0];
+}
+float mqo_actuator_net(mqo_sim* s, const float* x6) { return actuator_net(&s->act, x6); }
+
+/* logical (time-ordered, 2100) history of robot i gathered from the ring */
+static void gather_history(const mqo_sim* s, int i, float* out2100) {
+  for (int f = 0; f < MQE_HIST; f++) {
+    int slot = (s->hist_pos + f) % MQE_HIST;
+    memcpy(out2100 + f * 70, s->hist + ((size_t)i * MQE_HIST + slot) * FR, 70 * 4);
+  }
+}
+void mqo_history(mqo_sim* s, float* out) {
+  for (int i = 0; i < s->R; i++) gather_history(s, i, out + (size_t)i * 2100);
+}
+/* adaptation module + body, reference go1.py:400-407 */
+static void policy_forward(const mqo_sim* s, const float* h2100, float* latent2, float* act12) {
+  const mlp_t* a = &s->ada;
+  float buf0[1024], buf1[1024];
+  const float* x = h2100;
+  int K = 2100;
+  for (int l = 0; l < a->n_layers; l++) {
+    float* y = (l & 1) ? buf1 : buf0;
+    int O = a->dims[l + 1];
+    for (int o = 0; o < O; o++) {
+      float v = dot_chain(a->W[l] + (size_t)o * K, x, K) + a->b[l][o];
+      y[o] = (l < a->n_layers - 1) ? elu(v) : v;
+    }
+    x = y; K = O;
+  }
+  latent2[0] = x[0]; latent2[1] = x[1];
+  const mlp_t* b = &s->body;
+  /* layer 0: 2100 history columns as a chain, + bias, then the two latent columns */
+  int O = b->dims[1], K0 = b->dims[0];
+  float* y = buf0;
+  for (int o = 0; o < O; o++) {
+    const float* w = b->W[0] + (size_t)o * K0;
+    float v = dot_chain(w, h2100, 2100) + b->b[0][o];
+    v = fmaf(latent2[0], w[2100], v);
+    v = fmaf(latent2[1], w[2101], v);
+    y[o] = elu(v);
+  }
+  x = y; K = O;
+  for (int l = 1; l < b->n_layers; l++) {
+    float* yy = (l & 1) ? buf1 : buf0;
+    int OO = b->dims[l + 1];
+    for (int o = 0; o < OO; o++) {
+      float v = dot_chain(b->W[l] + (size_t)o * K, x, K) + b->b[l][o];
+      yy[o] = (l < b->n_layers - 1) ? elu(v) : v;
+    }
+    x = yy; K = OO;
+  }
+  for (int j = 0; j < 12; j++) act12[j] = x[j];
+}
+void mqo_policy_forward(mqo_sim* s, const float* h2100, float* latent2, float* act12) { policy_forward(s, h2100, latent2, act12); }
+
+/* ------------------------------------------------------------------------------------------ create / tensors */
+#define ALLOCF(n) ((float*)calloc((size_t)(n) > 0 ? (size_t)(n) : 1, sizeof(float)))
+static void* dupmem(const void* p, size_t n) {
+  if (!p) return NULL;
+  void* q = malloc(n);
+  memcpy(q, p, n);
+  return q;
+}
+static int wrapper_dims(const mqe_sim_desc* d, int* Aw, int* D) {
+  int A = d->num_agents, P = d->num_npcs;
+  switch (d->task) {
+    case MQE_TASK_GATE: *Aw = A; *D = 14 + A; break;
+    case MQE_TASK_SHEEP: *Aw = A; *D = 14 + 2 * P + A; break;
+    case MQE_TASK_SEESAW: *Aw = A; *D = 12 + A; break;
+    case MQE_TASK_FOOTBALL_DEFENDER: *Aw = 2; *D = 20; break;
+    default: *Aw = A; *D = 6 + A; break; /* plain: [id, base_pos, base_rpy] */
+  }
+  return 0;
+}
+
+int mqo_sim_create(const mqe_sim_desc* d, mqo_sim** out) {
+  if (d->abi_version != MQE_ABI_VERSION) { snprintf(g_err, sizeof g_err, "abi version mismatch"); return -1; }
+  if (d->num_agents > MAXA || d->num_npcs > MAXP) { snprintf(g_err, sizeof g_err, "too many agents/npcs"); return -2; }
+  mqo_sim* s = (mqo_sim*)calloc(1, sizeof *s);
+  s->d = *d;
+  int N = s->N = d->num_envs, A = s->A = d->num_agents, P = s->P = d->num_npcs;
+  s->R = N * A;
+  s->npc_dofs = d->npc_kind == MQE_NPC_SEESAW ? 1 : 0;
+  s->npc_bodies = d->npc_kind == MQE_NPC_SEESAW ? 2 * P : P;
+  s->ND = 12 * A + s->npc_dofs;
+  s->NBR = MQE_NREP * A + s->npc_bodies;
+  wrapper_dims(d, &s->Aw, &s->D);
+  mlp_copy(&s->act, &d->actuator);
+  mlp_copy(&s->ada, &d->adaptation);
+  mlp_copy(&s->body, &d->body);
+  s->sdf = (float*)dupmem(d->wall_sdf, (size_t)d->sdf_nx * d->sdf_ny * 4);
+  s->env_origins = (float*)dupmem(d->env_origins, (size_t)N * 3 * 4);
+  s->agent_origins = (float*)dupmem(d->agent_origins, (size_t)N * A * 3 * 4);
+  s->base_init = (float*)dupmem(d->base_init_state, (size_t)A * 13 * 4);
+  s->npc_init = (float*)dupmem(d->npc_init_state, (size_t)P * 13 * 4);
+  s->gate_pos = (float*)dupmem(d->gate_pos, (size_t)N * 2 * 4);
+  int R = s->R;
+  s->root = ALLOCF((size_t)N * (A + P) * 13);
+  for (int i = 0; i < N * (A + P); i++) s->root[i * 13 + 6] = 1.0f;
+  s->dof = ALLOCF((size_t)N * s->ND * 2);
+  s->cf = ALLOCF((size_t)N * s->NBR * 3);
+  s->torques = ALLOCF((size_t)N * 12 * A);
+  s->actions = ALLOCF((size_t)N * 12 * A);
+  s->last_actions = ALLOCF((size_t)N * 12 * A);
+  s->loco_obs = ALLOCF((size_t)R * FR);
+  for (int i = 0; i < R; i++) memcpy(s->loco_obs + (size_t)i * FR, d->command_obs, 70 * 4);
+  s->hist = ALLOCF((size_t)R * MQE_HIST * FR);
+  s->last_loco = ALLOCF((size_t)R * 12);
+  s->last_two_loco = ALLOCF((size_t)R * 12);
+  s->act_hist = ALLOCF((size_t)4 * R * 12);
+  s->gait = ALLOCF(R);
+  s->clock = ALLOCF((size_t)R * 4);
+  s->blv = ALLOCF((size_t)R * 3);
+  s->bav = ALLOCF((size_t)R * 3);
+  s->pg = ALLOCF((size_t)R * 3);
+  for (int i = 0; i < R; i++) s->pg[i * 3 + 2] = -1.0f;
+  s->bquat = ALLOCF((size_t)R * 4);
+  for (int i = 0; i < R; i++) s->bquat[i * 4 + 3] = 1.0f;
+  s->obs_bag = ALLOCF((size_t)R * OBS_BAG);
+  s->wobs = ALLOCF((size_t)N * s->Aw * s->D);
+  s->wrew = ALLOCF((size_t)N * s->Aw);
+  s->rsum = ALLOCF((size_t)N * MQE_MAX_REWARD_TERMS);
+  s->sheep_avg = ALLOCF((size_t)N * 2);
+  s->sheep_var = ALLOCF(N);
+  s->sub_tau = ALLOCF((size_t)N * 4 * 12 * A);
+  s->npc_noise = ALLOCF((size_t)N * (P ? P : 1) * 3);
+  s->ep_len = (int32_t*)calloc(N, 4);
+  s->reset_count = (int32_t*)calloc(N, 4);
+  s->reset_buf = (uint8_t*)calloc(N, 1);
+  memset(s->reset_buf, 1, N);
+  s->collide_buf = (uint8_t*)calloc(N, 1);
+  s->time_out = (uint8_t*)calloc(N, 1);
+  s->r_term = (uint8_t*)calloc(N, 1);
+  s->p_term = (uint8_t*)calloc(N, 1);
+  s->zh_term = (uint8_t*)calloc(N, 1);
+  s->w_last = ALLOCF((size_t)N * MAXA);
+  s->w_last2 = ALLOCF((size_t)N * 2);
+  s->w_have_last = (uint8_t*)calloc(N, 1);
+  s->w_delayed_reset = (uint8_t*)calloc(N, 1);
+  s->hist_pos = 0;
+  void** t = s->tens;
+  t[MQE_T_ROOT_STATE] = s->root; t[MQE_T_DOF_STATE] = s->dof; t[MQE_T_CONTACT_FORCE] = s->cf; t[MQE_T_TORQUES] = s->torques;
+  t[MQE_T_ACTIONS] = s->actions; t[MQE_T_LAST_ACTIONS] = s->last_actions; t[MQE_T_LOCOMOTION_OBS] = s->loco_obs;
+  t[MQE_T_HISTORY] = s->hist; t[MQE_T_LAST_LOCO_ACTION] = s->last_loco; t[MQE_T_LAST_TWO_LOCO_ACTION] = s->last_two_loco;
+  t[MQE_T_ACT_HIST] = s->act_hist; t[MQE_T_GAIT_INDICES] = s->gait; t[MQE_T_CLOCK_INPUTS] = s->clock;
+  t[MQE_T_BASE_LIN_VEL] = s->blv; t[MQE_T_BASE_ANG_VEL] = s->bav; t[MQE_T_PROJECTED_GRAVITY] = s->pg; t[MQE_T_BASE_QUAT] = s->bquat;
+  t[MQE_T_EPISODE_LENGTH] = s->ep_len; t[MQE_T_RESET_BUF] = s->reset_buf; t[MQE_T_COLLIDE_BUF] = s->collide_buf;
+  t[MQE_T_TIME_OUT_BUF] = s->time_out; t[MQE_T_R_TERM] = s->r_term; t[MQE_T_P_TERM] = s->p_term; t[MQE_T_Z_HIGH_TERM] = s->zh_term;
+  t[MQE_T_OBS_BAG] = s->obs_bag; t[MQE_T_WRAPPER_OBS] = s->wobs; t[MQE_T_WRAPPER_REWARD] = s->wrew; t[MQE_T_REWARD_SUMS] = s->rsum;
+  t[MQE_T_SHEEP_POS_AVG] = s->sheep_avg; t[MQE_T_SHEEP_POS_VAR] = s->sheep_var; t[MQE_T_RESET_COUNT] = s->reset_count;
+  t[MQE_T_SUBSTEP_TORQUES] = s->sub_tau; t[MQE_T_NPC_NOISE] = s->npc_noise;
+  *out = s;
+  return 0;
+}
+
+int mqo_sim_destroy(mqo_sim* s) { free(s); return 0; } /* test helper: leaks the arrays on purpose (short-lived processes) */
+
+int mqo_sim_tensor(mqo_sim* s, int kind, mqe_tensor_view* v) {
+  if (kind < 0 || kind >= MQE_T_COUNT) { snprintf(g_err, sizeof g_err, "bad tensor kind %d", kind); return -1; }
+  memset(v, 0, sizeof *v);
+  v->ptr = s->tens[kind];
+  int N = s->N, A = s->A, P = s->P, R = s->R;
+#define SH(nd, a, b, c, e, dt) do { v->ndim = nd; v->shape[0] = a; v->shape[1] = b; v->shape[2] = c; v->shape[3] = e; v->dtype = dt; } while (0)
+  switch (kind) {
+    case MQE_T_ROOT_STATE: SH(3, N, A + P, 13, 0, 0); break;
+    case MQE_T_DOF_STATE: SH(3, N, s->ND, 2, 0, 0); break;
+    case MQE_T_CONTACT_FORCE: SH(3, N, s->NBR, 3, 0, 0); break;
+    case MQE_T_TORQUES: case MQE_T_ACTIONS: case MQE_T_LAST_ACTIONS: SH(2, N, 12 * A, 0, 0, 0); break;
+    case MQE_T_LOCOMOTION_OBS: SH(2, R, FR, 0, 0, 0); break;
+    case MQE_T_HISTORY: SH(3, R, MQE_HIST, FR, 0, 0); break;
+    case MQE_T_LAST_LOCO_ACTION: case MQE_T_LAST_TWO_LOCO_ACTION: SH(2, R, 12, 0, 0, 0); break;
+    case MQE_T_ACT_HIST: SH(3, 4, R, 12, 0, 0); break;
+    case MQE_T_GAIT_INDICES: SH(1, R, 0, 0, 0, 0); break;
+    case MQE_T_CLOCK_INPUTS: case MQE_T_BASE_QUAT: SH(2, R, 4, 0, 0, 0); break;
+    case MQE_T_BASE_LIN_VEL: case MQE_T_BASE_ANG_VEL: case MQE_T_PROJECTED_GRAVITY: SH(2, R, 3, 0, 0, 0); break;
+    case MQE_T_EPISODE_LENGTH: case MQE_T_RESET_COUNT: SH(1, N, 0, 0, 0, 1); break;
+    case MQE_T_RESET_BUF: case MQE_T_COLLIDE_BUF: case MQE_T_TIME_OUT_BUF: case MQE_T_R_TERM: case MQE_T_P_TERM:
+    case MQE_T_Z_HIGH_TERM: SH(1, N, 0, 0, 0, 2); break;
+    case MQE_T_OBS_BAG: SH(2, R, OBS_BAG, 0, 0, 0); break;
+    case MQE_T_WRAPPER_OBS: SH(3, N, s->Aw, s->D, 0, 0); break;
+    case MQE_T_WRAPPER_REWARD: SH(2, N, s->Aw, 0, 0, 0); break;
+    case MQE_T_REWARD_SUMS: SH(2, N, MQE_MAX_REWARD_TERMS, 0, 0, 0); break;
+    case MQE_T_SHEEP_POS_AVG: SH(2, N, 2, 0, 0, 0); break;
+    case MQE_T_SHEEP_POS_VAR: SH(1, N, 0, 0, 0, 0); break;
+    case MQE_T_SUBSTEP_TORQUES: SH(3, N, 4, 12 * A, 0, 0); break;
+    case MQE_T_NPC_NOISE: SH(3, N, P, 3, 0, 0); break;
+  }
+  return 0;
+}
+int mqo_hist_pos(mqo_sim* s) { return s->hist_pos; }
+
+/* ------------------------------------------------------------------------------------------ row A/B: policy */
+/* Go1.step head (go1.py:37-41) + preprocess_action (go1.py:64-108).  command: [R,3] */
+int mqo_policy_step(mqo_sim* s, const float* command) {
+  int R = s->R;
+  const mqe_sim_desc* d = &s->d;
+  for (int i = 0; i < R; i++) {
+    float* lo = s->loco_obs + (size_t)i * FR;
+    const float* ob = s->obs_bag + (size_t)i * OBS_BAG;
+    float c[3];
+    for (int k = 0; k < 3; k++) {
+      c[k] = command[i * 3 + k];
+      if (d->clip_command) c[k] = fminf(fmaxf(c[k], -1.0f), 1.0f);   /* go1.py:38 */
+    }
+    lo[3] = c[0] * d->cmd_lin_scale; lo[4] = c[1] * d->cmd_lin_scale; lo[5] = c[2] * d->cmd_ang_scale; /* :67-68 */
+    for (int k = 0; k < 3; k++) lo[k] = ob[60 + k];              /* projected gravity  :95 */
+    for (int k = 0; k < 12; k++) lo[18 + k] = ob[6 + k];         /* dof_pos            :96 */
+    for (int k = 0; k < 12; k++) lo[30 + k] = ob[18 + k];        /* dof_vel            :97 */
+    for (int k = 0; k < 12; k++) lo[42 + k] = s->last_loco[i * 12 + k];      /* :98 */
+    for (int k = 0; k < 12; k++) lo[54 + k] = s->last_two_loco[i * 12 + k];  /* :99 */
+    for (int k = 0; k < 4; k++) lo[66 + k] = ob[63 + k];         /* clock inputs       :100 */
+    memcpy(s->hist + ((size_t)i * MQE_HIST + s->hist_pos) * FR, lo, FR * 4);  /* :102 (ring write) */
+  }
+  s->hist_pos = (s->hist_pos + 1) % MQE_HIST;
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < R; i++) {
+    float h[2100], lat[2], a12[12];
+    gather_history(s, i, h);
+    policy_forward(s, h, lat, a12);                               /* :104 */
+    for (int k = 0; k < 12; k++) {
+      s->last_two_loco[i * 12 + k] = s->last_loco[i * 12 + k];    /* :106 */
+      s->last_loco[i * 12 + k] = a12[k];                          /* :107 */
+      s->actions[i * 12 + k] = fminf(fmaxf(a12[k], -d->clip_actions), d->clip_actions); /* :40-41 */
+    }
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ row E/F/G: torques */
+int mqo_compute_torques(mqo_sim* s) {
+  const mqe_sim_desc* d = &s->d;
+  int R = s->R, A = s->A;
+  float* e1 = s->act_hist; float* e2 = e1 + (size_t)R * 12; float* v1 = e2 + (size_t)R * 12; float* v2 = v1 + (size_t)R * 12;
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < R; i++) {
+    int env = i / A, a = i % A;
+    for (int j = 0; j < 12; j++) {
+      float act = s->actions[i * 12 + j];
+      float q = s->dof[((size_t)env * s->ND + a * 12 + j) * 2], qd = s->dof[((size_t)env * s->ND + a * 12 + j) * 2 + 1];
+      float as = act * d->action_scale;                                 /* go1.py:329 */
+      float tau;
+      if (d->control_type == MQE_CTRL_C) {
+        if (j % 3 == 0) as *= d->hip_scale_reduction;                     /* :331 */
+        float target = as + d->default_dof_pos[j];                         /* :341 */
+        float err = q - target;                                            /* :343 */
+        float x[6] = {err, e1[i * 12 + j], e2[i * 12 + j], qd, v1[i * 12 + j], v2[i * 12 + j]};
+        tau = actuator_net(&s->act, x);                                    /* :345 */
+        e2[i * 12 + j] = e1[i * 12 + j]; e1[i * 12 + j] = err;             /* :347-348 */
+        v2[i * 12 + j] = v1[i * 12 + j]; v1[i * 12 + j] = qd;              /* :349-350 */
+      } else if (d->control_type == MQE_CTRL_P) {
+        tau = d->kp * (as + d->default_dof_pos[j] - q) - d->kd * qd;       /* legged_robot.py:385 */
+      } else if (d->control_type == MQE_CTRL_T) {
+        tau = as;                                                          /* :389 */
+      } else {
+        tau = 0;
+      }
+      float lim = d->torque_limits[j];
+      s->torques[i * 12 + j] = fminf(fmaxf(tau, -lim), lim);               /* go1.py:352 */
+    }
+  }
+  return 0;
+}
+
+int mqo_post_decimation_step(mqo_sim* s, int dec_i) { /* legged_robot.py:112-115 */
+  int n = 12 * s->A;
+  for (int e = 0; e < s->N; e++) memcpy(s->sub_tau + ((size_t)e * 4 + dec_i) * n, s->torques + (size_t)e * n, n * 4);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ row H: physics */
+typedef struct {
+  real R[9], p[3], c[3], Iw[9], w[3], vp[3], a[3], al[3], ap[3];
+} bodyk_t;
+
+typedef struct {
+  int kind;           /* 0 terrain, 1 sphere-sphere */
+  int actA, sphA, actB, sphB;   /* actor index in env: 0..A-1 robots, A.. npcs; actB=-1 static */
+  real p[3], n[3], t1[3], t2[3], sd;
+  real J[3][MAXDOF], B[3][MAXDOF], K[3][3], lam[3];
+} contact_t;
+
+static void sym6_to_mat(const float* s6, real* I) {
+  I[0] = s6[0]; I[4] = s6[1]; I[8] = s6[2]; I[1] = I[3] = s6[3]; I[2] = I[6] = s6[4]; I[5] = I[7] = s6[5];
+}
+
+/* bilinear sample of the wall SDF at world (x,y) + gradient */
+static real sdf_sample(const mqo_sim* s, real x, real y, real* gx, real* gy) {
+  const mqe_sim_desc* d = &s->d;
+  real hs = d->horizontal_scale;
+  real fx = x / hs - (real)0.5, fy = y / hs - (real)0.5;   /* samples sit at cell centres */
+  int nx = d->sdf_nx, ny = d->sdf_ny;
+  if (fx < 0) fx = 0; if (fy < 0) fy = 0;
+  if (fx > nx - 1) fx = (real)(nx - 1); if (fy > ny - 1) fy = (real)(ny - 1);
+  int ix = (int)fx, iy = (int)fy;
+  if (ix > nx - 2) ix = nx - 2; if (iy > ny - 2) iy = ny - 2;
+  real tx = fx - ix, ty = fy - iy;
+  real s00 = s->sdf[(size_t)ix * ny + iy], s01 = s->sdf[(size_t)ix * ny + iy + 1];
+  real s10 = s->sdf[(size_t)(ix + 1) * ny + iy], s11 = s->sdf[(size_t)(ix + 1) * ny + iy + 1];
+  real a0 = s00 + (s01 - s00) * ty, a1 = s10 + (s11 - s10) * ty;
+  *gx = (a1 - a0) / hs;
+  *gy = ((s01 - s00) + ((s11 - s10) - (s01 - s00)) * tx) / hs;
+  return a0 + (a1 - a0) * tx;
+}
+
+static void make_tangents(const real* n, real* t1, real* t2) {
+  real a[3] = {0, 0, 1};
+  if (fabs((double)n[2]) > 0.7) { a[0] = 1; a[2] = 0; }
+  cross3(a, n, t1);
+  real l = (real)sqrt((double)dot3(t1, t1));
+  t1[0] /= l; t1[1] /= l; t1[2] /= l;
+  cross3(n, t1, t2);
+}
+
+static int chol(real* Aa, int n, int ld) { /* in place lower Cholesky */
+  for (int j = 0; j < n; j++) {
+    real d = Aa[j * ld + j];
+    for (int k = 0; k < j; k++) d -= Aa[j * ld + k] * Aa[j * ld + k];
+    if (d <= 0) return -1;
+    d = (real)sqrt((double)d);
+    Aa[j * ld + j] = d;
+    for (int i = j + 1; i < n; i++) {
+      real v = Aa[i * ld + j];
+      for (int k = 0; k < j; k++) v -= Aa[i * ld + k] * Aa[j * ld + k];
+      Aa[i * ld + j] = v / d;
+    }
+  }
+  return 0;
+}
+static void chol_solve(const real* L, int n, int ld, real* b) {
+  for (int i = 0; i < n; i++) {
+    real v = b[i];
+    for (int k = 0; k < i; k++) v -= L[i * ld + k] * b[k];
+    b[i] = v / L[i * ld + i];
+  }
+  for (int i = n - 1; i >= 0; i--) {
+    real v = b[i];
+    for (int k = i + 1; k < n; k++) v -= L[k * ld + i] * b[k];
+    b[i] = v / L[i * ld + i];
+  }
+}
+
+typedef struct {
+  bodyk_t bk[MAXA][NB];
+  real L[MAXA][RD * RD];       /* Cholesky factor of each robot's mass matrix */
+  real sph_c[MAXA + MAXP][MQE_MAX_SPHERES][3];
+  real sph_r[MAXA + MAXP][MQE_MAX_SPHERES];
+  int sph_n[MAXA + MAXP];
+  real npcR[MAXP][9];
+  real v[MAXDOF], tau[MAXDOF];
+  contact_t con[MAXC];
+  int nc;
+} envwork_t;
+
+static int is_ancestor_or_self(const int* parent, int anc, int b) {
+  while (b >= 0) { if (b == anc) return 1; b = parent[b]; }
+  return 0;
+}
+static const int g_parent[NB] = {-1, 0, 1, 2, 0, 4, 5, 0, 7, 8, 0, 10, 11};
+
+/* point-velocity Jacobian column block of actor `act` for a point p rigidly attached to (robot body b | npc) */
+static void fill_jac(const mqo_sim* s, const envwork_t* w, int act, int body, const real* p, real sign, const real dirs[3][3],
+                     real J[3][MAXDOF], const real npc_pos[][3]) {
+  int A = s->A;
+  if (act < A) {
+    int o = act * RD;
+    const bodyk_t* bk = w->bk[act];
+    for (int k = 0; k < 3; k++) {
+      real e[3] = {0, 0, 0}; e[k] = 1;
+      real r[3] = {p[0] - bk[0].p[0], p[1] - bk[0].p[1], p[2] - bk[0].p[2]};
+      real wv[3]; cross3(e, r, wv);
+      for (int q = 0; q < 3; q++) { J[q][o + k] += sign * dirs[q][k]; J[q][o + 3 + k] += sign * dot3(dirs[q], wv); }
+    }
+    for (int j = 1; j < NB; j++) {
+      if (!is_ancestor_or_self(g_parent, j, body)) continue;
+      real r[3] = {p[0] - bk[j].p[0], p[1] - bk[j].p[1], p[2] - bk[j].p[2]};
+      real wv[3]; cross3(bk[j].a, r, wv);
+      for (int q = 0; q < 3; q++) J[q][o + 6 + (j - 1)] += sign * dot3(dirs[q], wv);
+    }
+  } else {
+    int pi = act - A, o = A * RD + pi * 6;
+    for (int k = 0; k < 3; k++) {
+      real e[3] = {0, 0, 0}; e[k] = 1;
+      real r[3] = {p[0] - npc_pos[pi][0], p[1] - npc_pos[pi][1], p[2] - npc_pos[pi][2]};
+      real wv[3]; cross3(e, r, wv);
+      for (int q = 0; q < 3; q++) { J[q][o + k] += sign * dirs[q][k]; J[q][o + 3 + k] += sign * dot3(dirs[q], wv); }
+    }
+  }
+}
+
+static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
+  const mqe_sim_desc* d = &s->d;
+  const mqe_robot_model* m = &d->robot;
+  int A = s->A, P = (d->npc_kind == MQE_NPC_BALL || d->npc_kind == MQE_NPC_SHEEP) ? s->P : 0;
+  real dt = d->dt;
+  float* root = s->root + (size_t)env * (A + s->P) * 13;
+  float* dofs = s->dof + (size_t)env * s->ND * 2;
+  int ndof = A * RD + P * 6;
+  real g[3] = {0, 0, d->gravity_z};
+  real npc_pos[MAXP][3];
+
+  /* ---- forward kinematics, mass matrix, bias, unconstrained velocity per robot */
+  for (int r = 0; r < A; r++) {
+    bodyk_t* bk = w->bk[r];
+    const float* rs = root + r * 13;
+    real q[4] = {rs[3], rs[4], rs[5], rs[6]};
+    quat_to_mat(q, bk[0].R);
+    for (int k = 0; k < 3; k++) { bk[0].p[k] = rs[k]; bk[0].vp[k] = rs[7 + k]; bk[0].w[k] = rs[10 + k]; bk[0].al[k] = 0; bk[0].ap[k] = 0; bk[0].a[k] = 0; }
+    for (int b = 1; b < NB; b++) {
+      int pb = g_parent[b];
+      real qj = dofs[(r * 12 + b - 1) * 2], qdj = dofs[(r * 12 + b - 1) * 2 + 1];
+      real off[3] = {m->joint_offset[b][0], m->joint_offset[b][1], m->joint_offset[b][2]}, dd[3];
+      mat3_vec(bk[pb].R, off, dd);
+      for (int k = 0; k < 3; k++) bk[b].p[k] = bk[pb].p[k] + dd[k];
+      real ax[3] = {m->joint_axis[b][0], m->joint_axis[b][1], m->joint_axis[b][2]}, Rj[9];
+      axis_angle_mat(ax, qj, Rj);
+      mat3_mul(bk[pb].R, Rj, bk[b].R);
+      mat3_vec(bk[pb].R, ax, bk[b].a);
+      real t[3], t2[3];
+      for (int k = 0; k < 3; k++) bk[b].w[k] = bk[pb].w[k] + bk[b].a[k] * qdj;
+      cross3(bk[pb].w, dd, t);
+      for (int k = 0; k < 3; k++) bk[b].vp[k] = bk[pb].vp[k] + t[k];
+      /* bias accelerations (all generalized accelerations zero) */
+      real aq[3] = {bk[b].a[0] * qdj, bk[b].a[1] * qdj, bk[b].a[2] * qdj};
+      cross3(bk[pb].w, aq, t);
+      for (int k = 0; k < 3; k++) bk[b].al[k] = bk[pb].al[k] + t[k];
+      cross3(bk[pb].al, dd, t);
+      real wd[3]; cross3(bk[pb].w, dd, wd); cross3(bk[pb].w, wd, t2);
+      for (int k = 0; k < 3; k++) bk[b].ap[k] = bk[pb].ap[k] + t[k] + t2[k];
+    }
+    for (int b = 0; b < NB; b++) {
+      real cl[3] = {m->com[b][0], m->com[b][1], m->com[b][2]}, cw[3], Il[9], T[9], Rt[9];
+      mat3_vec(bk[b].R, cl, cw);
+      for (int k = 0; k < 3; k++) bk[b].c[k] = bk[b].p[k] + cw[k];
+      sym6_to_mat(m->inertia[b], Il);
+      mat3_mul(bk[b].R, Il, T);
+      for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Rt[i * 3 + j] = bk[b].R[j * 3 + i];
+      mat3_mul(T, Rt, bk[b].Iw);
+    }
+    /* M = sum_b m Jv^T Jv + Jw^T I Jw ; h = sum_b Jv.f + Jw.n */
+    real M[RD * RD], h[RD];
+    memset(M, 0, sizeof M); memset(h, 0, sizeof h);
+    for (int b = 0; b < NB; b++) {
+      real Jv[RD][3], Jw[RD][3];
+      memset(Jv, 0, sizeof Jv); memset(Jw, 0, sizeof Jw);
+      real rc0[3] = {bk[b].c[0] - bk[0].p[0], bk[b].c[1] - bk[0].p[1], bk[b].c[2] - bk[0].p[2]};
+      for (int k = 0; k < 3; k++) {
+        Jv[k][k] = 1;
+        real e[3] = {0, 0, 0}; e[k] = 1;
+        Jw[3 + k][k] = 1;
+        cross3(e, rc0, Jv[3 + k]);
+      }
+      for (int j = 1; j < NB; j++) {
+        if (!is_ancestor_or_self(g_parent, j, b)) continue;
+        real rr[3] = {bk[b].c[0] - bk[j].p[0], bk[b].c[1] - bk[j].p[1], bk[b].c[2] - bk[j].p[2]};
+        for (int k = 0; k < 3; k++) Jw[6 + j - 1][k] = bk[j].a[k];
+        cross3(bk[j].a, rr, Jv[6 + j - 1]);
+      }
+      real mb = m->mass[b];
+      for (int i = 0; i < RD; i++) {
+        real IJ[3]; mat3_vec(bk[b].Iw, Jw[i], IJ);
+        for (int j = 0; j < RD; j++) M[i * RD + j] += mb * dot3(Jv[i], Jv[j]) + dot3(IJ, Jw[j]);
+      }
+      real rc[3] = {bk[b].c[0] - bk[b].p[0], bk[b].c[1] - bk[b].p[1], bk[b].c[2] - bk[b].p[2]};
+      real t[3], t2[3], wr[3], ac[3], f[3], nn[3], Iw_[3], Ial[3];
+      cross3(bk[b].al, rc, t); cross3(bk[b].w, rc, wr); cross3(bk[b].w, wr, t2);
+      for (int k = 0; k < 3; k++) { ac[k] = bk[b].ap[k] + t[k] + t2[k]; f[k] = mb * (ac[k] - g[k]); }
+      mat3_vec(bk[b].Iw, bk[b].w, Iw_); cross3(bk[b].w, Iw_, t); mat3_vec(bk[b].Iw, bk[b].al, Ial);
+      for (int k = 0; k < 3; k++) nn[k] = Ial[k] + t[k];
+      for (int i = 0; i < RD; i++) h[i] += dot3(Jv[i], f) + dot3(Jw[i], nn);
+    }
+    memcpy(w->L[r], M, sizeof M);
+    if (chol(w->L[r], RD, RD) != 0) { fprintf(stderr, "mqe_oracle: mass matrix not SPD (env %d robot %d)\n", env, r); }
+    real rhs[RD];
+    for (int i = 0; i < 6; i++) rhs[i] = -h[i];
+    for (int j = 0; j < 12; j++) rhs[6 + j] = (real)s->torques[(size_t)env * 12 * A + r * 12 + j] - h[6 + j];
+    chol_solve(w->L[r], RD, RD, rhs);
+    real* v = w->v + r * RD;
+    for (int k = 0; k < 3; k++) { v[k] = bk[0].vp[k] + dt * rhs[k]; v[3 + k] = bk[0].w[k] + dt * rhs[3 + k]; }
+    for (int j = 0; j < 12; j++) v[6 + j] = (real)dofs[(r * 12 + j) * 2 + 1] + dt * rhs[6 + j];
+    /* collision spheres */
+    w->sph_n[r] = m->n_spheres;
+    for (int si = 0; si < m->n_spheres; si++) {
+      int b = m->sphere_body[si];
+      real cl[3] = {m->sphere_center[si][0], m->sphere_center[si][1], m->sphere_center[si][2]}, cw[3];
+      mat3_vec(bk[b].R, cl, cw);
+      for (int k = 0; k < 3; k++) w->sph_c[r][si][k] = bk[b].p[k] + cw[k];
+      w->sph_r[r][si] = m->sphere_radius[si];
+    }
+  }
+  /* ---- free NPC bodies (ball / sheep): isotropic inertia => no gyroscopic term */
+  for (int p = 0; p < P; p++) {
+    const float* rs = root + (A + p) * 13;
+    real q[4] = {rs[3], rs[4], rs[5], rs[6]};
+    quat_to_mat(q, w->npcR[p]);
+    real* v = w->v + A * RD + p * 6;
+    for (int k = 0; k < 3; k++) { npc_pos[p][k] = rs[k]; v[k] = rs[7 + k] + dt * g[k]; v[3 + k] = rs[10 + k]; }
+    w->sph_n[A + p] = d->npc_n_spheres;
+    for (int si = 0; si < d->npc_n_spheres; si++) {
+      real cl[3] = {d->npc_sphere_center[si][0], d->npc_sphere_center[si][1], d->npc_sphere_center[si][2]}, cw[3];
+      mat3_vec(w->npcR[p], cl, cw);
+      for (int k = 0; k < 3; k++) w->sph_c[A + p][si][k] = npc_pos[p][k] + cw[k];
+      w->sph_r[A + p][si] = d->npc_sphere_radius[si];
+    }
+  }
+
+  /* ---- contact generation (canonical order: terrain contacts actor by actor, sphere by sphere, ground before
+   * wall; then sphere pairs for actor pairs (a<b), outer loop over b's spheres, inner over a's) */
+  int nact = A + P;
+  w->nc = 0;
+  for (int act = 0; act < nact; act++) {
+    for (int si = 0; si < w->sph_n[act]; si++) {
+      const real* c = w->sph_c[act][si];
+      real r = w->sph_r[act][si];
+      for (int pass = 0; pass < 2; pass++) {
+        real n[3], sd;
+        if (pass == 0) { sd = c[2] - d->ground_z - r; n[0] = 0; n[1] = 0; n[2] = 1; }
+        else {
+          real gx, gy;
+          real sh = sdf_sample(s, c[0], c[1], &gx, &gy);
+          real gl = (real)sqrt((double)(gx * gx + gy * gy));
+          if (gl < (real)1e-6) { gx = 1; gy = 0; gl = 1; }
+          gx /= gl; gy /= gl;
+          real dz = c[2] - d->wall_height;
+          if (dz <= 0) {               /* beside (or inside) the wall prism: lateral contact */
+            if (sh <= 0 && -sh > -dz) { sd = dz - r; n[0] = 0; n[1] = 0; n[2] = 1; }  /* deep inside, closer to the top */
+            else { sd = sh - r; n[0] = gx; n[1] = gy; n[2] = 0; }
+          } else if (sh <= 0) {        /* above the top face */
+            sd = dz - r; n[0] = 0; n[1] = 0; n[2] = 1;
+          } else {                     /* near the top edge */
+            real dist = (real)sqrt((double)(sh * sh + dz * dz));
+            sd = dist - r; n[0] = gx * sh / dist; n[1] = gy * sh / dist; n[2] = dz / dist;
+          }
+        }
+        if (sd < d->contact_offset && w->nc < MAXC) {
+          contact_t* ct = &w->con[w->nc++];
+          memset(ct, 0, sizeof *ct);
+          ct->kind = 0; ct->actA = act; ct->sphA = si; ct->actB = -1; ct->sd = sd;
+          for (int k = 0; k < 3; k++) { ct->n[k] = n[k]; ct->p[k] = c[k] - r * n[k]; }
+        }
+      }
+    }
+  }
+  for (int a = 0; a < nact; a++)
+    for (int b = a + 1; b < nact; b++) {
+      const real* pa = a < A ? w->bk[a][0].p : npc_pos[a - A];
+      const real* pb = b < A ? w->bk[b][0].p : npc_pos[b - A];
+      real dd[3] = {pa[0] - pb[0], pa[1] - pb[1], pa[2] - pb[2]};
+      if (dot3(dd, dd) > (real)(1.2 * 1.2)) continue;   /* broad phase: actors farther apart than 1.2 m cannot touch */
+      for (int sb = 0; sb < w->sph_n[b]; sb++)
+        for (int sa = 0; sa < w->sph_n[a]; sa++) {
+          const real* ca = w->sph_c[a][sa]; const real* cb = w->sph_c[b][sb];
+          real e[3] = {ca[0] - cb[0], ca[1] - cb[1], ca[2] - cb[2]};
+          real dist = (real)sqrt((double)dot3(e, e));
+          real sd = dist - w->sph_r[a][sa] - w->sph_r[b][sb];
+          if (sd < d->contact_offset && w->nc < MAXC && dist > (real)1e-9) {
+            contact_t* ct = &w->con[w->nc++];
+            memset(ct, 0, sizeof *ct);
+            ct->kind = 1; ct->actA = a; ct->sphA = sa; ct->actB = b; ct->sphB = sb; ct->sd = sd;
+            for (int k = 0; k < 3; k++) { ct->n[k] = e[k] / dist; ct->p[k] = cb[k] + ct->n[k] * (w->sph_r[b][sb] + (real)0.5 * sd); }
+          }
+        }
+    }
+
+  /* ---- contact rows: J, B = Minv J^T, K = J B */
+  for (int ci = 0; ci < w->nc; ci++) {
+    contact_t* ct = &w->con[ci];
+    make_tangents(ct->n, ct->t1, ct->t2);
+    real dirs[3][3];
+    for (int k = 0; k < 3; k++) { dirs[0][k] = ct->n[k]; dirs[1][k] = ct->t1[k]; dirs[2][k] = ct->t2[k]; }
+    int bodyA = ct->actA < A ? m->sphere_body[ct->sphA] : 0;
+    fill_jac(s, w, ct->actA, bodyA, ct->p, (real)1, dirs, ct->J, npc_pos);
+    if (ct->actB >= 0) {
+      int bodyB = ct->actB < A ? m->sphere_body[ct->sphB] : 0;
+      fill_jac(s, w, ct->actB, bodyB, ct->p, (real)-1, dirs, ct->J, npc_pos);
+    }
+    for (int q = 0; q < 3; q++) {
+      for (int r = 0; r < A; r++) {
+        real tmp[RD];
+        for (int i = 0; i < RD; i++) tmp[i] = ct->J[q][r * RD + i];
+        chol_solve(w->L[r], RD, RD, tmp);
+        for (int i = 0; i < RD; i++) ct->B[q][r * RD + i] = tmp[i];
+      }
+      for (int p = 0; p < P; p++) {
+        int o = A * RD + p * 6;
+        for (int k = 0; k < 3; k++) { ct->B[q][o + k] = ct->J[q][o + k] / d->npc_mass; ct->B[q][o + 3 + k] = ct->J[q][o + 3 + k] / d->npc_inertia; }
+      }
+    }
+    for (int q = 0; q < 3; q++) for (int r2 = 0; r2 < 3; r2++) {
+      real acc = 0;
+      for (int i = 0; i < ndof; i++) acc += ct->J[q][i] * ct->B[r2][i];
+      ct->K[q][r2] = acc;
+    }
+  }
+
+  /* ---- projected Gauss-Seidel on velocities */
+  real mu = d->friction;
+  for (int it = 0; it < d->solver_iterations; it++) {
+    for (int ci = 0; ci < w->nc; ci++) {
+      contact_t* ct = &w->con[ci];
+      real u[3];
+      for (int q = 0; q < 3; q++) { real acc = 0; for (int i = 0; i < ndof; i++) acc += ct->J[q][i] * w->v[i]; u[q] = acc; }
+      real bias = ct->sd >= 0 ? -ct->sd / dt : fminf((float)(-ct->sd * d->erp / dt), d->max_depenetration_velocity);
+      real dl[3];
+      /* normal row */
+      real ln = ct->lam[0] - (u[0] - bias) / ct->K[0][0];
+      if (ln < 0) ln = 0;
+      dl[0] = ln - ct->lam[0]; ct->lam[0] = ln;
+      u[1] += ct->K[1][0] * dl[0]; u[2] += ct->K[2][0] * dl[0];
+      /* tangent rows, box friction |lt| <= mu ln */
+      real lim = mu * ct->lam[0];
+      real l1 = ct->lam[1] - u[1] / ct->K[1][1];
+      if (l1 > lim) l1 = lim; if (l1 < -lim) l1 = -lim;
+      dl[1] = l1 - ct->lam[1]; ct->lam[1] = l1;
+      u[2] += ct->K[2][1] * dl[1];
+      real l2 = ct->lam[2] - u[2] / ct->K[2][2];
+      if (l2 > lim) l2 = lim; if (l2 < -lim) l2 = -lim;
+      dl[2] = l2 - ct->lam[2]; ct->lam[2] = l2;
+      for (int i = 0; i < ndof; i++) w->v[i] += ct->B[0][i] * dl[0] + ct->B[1][i] * dl[1] + ct->B[2][i] * dl[2];
+    }
+    /* joint limits: q + dt*qd within [lower, upper] */
+    for (int r = 0; r < A; r++)
+      for (int j = 0; j < 12; j++) {
+        real q = dofs[(r * 12 + j) * 2];
+        real* v = w->v + r * RD;
+        real lo = (m->dof_lower[j] - q) / dt, hi = (m->dof_upper[j] - q) / dt;
+        real viol = 0;
+        if (v[6 + j] < lo) viol = lo - v[6 + j];
+        else if (v[6 + j] > hi) viol = hi - v[6 + j];
+        if (viol != 0) {
+          /* impulse along e_j: dv = Minv e_j * lambda with (Minv)_jj lambda = viol */
+          real col[RD];
+          memset(col, 0, sizeof col); col[6 + j] = 1;
+          chol_solve(w->L[r], RD, RD, col);
+          real lam = viol / col[6 + j];
+          for (int i = 0; i < RD; i++) v[i] += col[i] * lam;
+        }
+      }
+  }
+
+  /* ---- net contact forces per reported body (gym.refresh_net_contact_force_tensor analogue) */
+  float* cf = s->cf + (size_t)env * s->NBR * 3;
+  memset(cf, 0, (size_t)s->NBR * 3 * 4);
+  for (int ci = 0; ci < w->nc; ci++) {
+    contact_t* ct = &w->con[ci];
+    real F[3];
+    for (int k = 0; k < 3; k++) F[k] = (ct->lam[0] * ct->n[k] + ct->lam[1] * ct->t1[k] + ct->lam[2] * ct->t2[k]) / dt;
+    int ra = ct->actA < A ? ct->actA * MQE_NREP + m->sphere_reported[ct->sphA] : A * MQE_NREP + (ct->actA - A);
+    for (int k = 0; k < 3; k++) cf[ra * 3 + k] += (float)F[k];
+    if (ct->actB >= 0) {
+      int rb = ct->actB < A ? ct->actB * MQE_NREP + m->sphere_reported[ct->sphB] : A * MQE_NREP + (ct->actB - A);
+      for (int k = 0; k < 3; k++) cf[rb * 3 + k] -= (float)F[k];
+    }
+  }
+
+  /* ---- integrate (semi-implicit Euler; quaternion: first-order update + renormalise) */
+  for (int act = 0; act < nact; act++) {
+    float* rs = root + act * 13;
+    real* v = act < A ? w->v + act * RD : w->v + A * RD + (act - A) * 6;
+    for (int k = 0; k < 3; k++) { rs[k] = (float)(rs[k] + dt * v[k]); rs[7 + k] = (float)v[k]; rs[10 + k] = (float)v[3 + k]; }
+    real q[4] = {rs[3], rs[4], rs[5], rs[6]}, wq[3] = {v[3], v[4], v[5]};
+    /* qdot = 0.5 * (w,0) * q */
+    real dq[4];
+    dq[0] = (real)0.5 * (wq[0] * q[3] + wq[1] * q[2] - wq[2] * q[1]);
+    dq[1] = (real)0.5 * (-wq[0] * q[2] + wq[1] * q[3] + wq[2] * q[0]);
+    dq[2] = (real)0.5 * (wq[0] * q[1] - wq[1] * q[0] + wq[2] * q[3]);
+    dq[3] = (real)0.5 * (-wq[0] * q[0] - wq[1] * q[1] - wq[2] * q[2]);
+    real nq = 0;
+    for (int k = 0; k < 4; k++) { q[k] += dt * dq[k]; nq += q[k] * q[k]; }
+    nq = (real)sqrt((double)nq);
+    for (int k = 0; k < 4; k++) rs[3 + k] = (float)(q[k] / nq);
+    if (act < A)
+      for (int j = 0; j < 12; j++) {
+        float* ds = dofs + (act * 12 + j) * 2;
+        ds[0] = (float)(ds[0] + dt * v[6 + j]);
+        ds[1] = (float)v[6 + j];
+      }
+  }
+}
+
+int mqo_simulate(mqo_sim* s) {
+#pragma omp parallel
+  {
+    envwork_t* w = (envwork_t*)malloc(sizeof(envwork_t));
+#pragma omp for schedule(static)
+    for (int e = 0; e < s->N; e++) simulate_env(s, e, w);
+    free(w);
+  }
+  return 0;
+}
+
+/* debug: mass matrix / bias / contact list of one env for fine-grained HIP parity */
+int mqo_debug_dynamics(mqo_sim* s, int env, int robot, float* M_out /*18x18*/, float* Minv_out, int* nc_out, float* contacts_out /*[MAXC][8]: actA,sphA,actB,sphB,sd,n*/) {
+  envwork_t* w = (envwork_t*)malloc(sizeof(envwork_t));
+  /* run on a copy of the state so that nothing moves */
+  int A = s->A;
+  size_t nr = (size_t)(A + s->P) * 13, ndf = (size_t)s->ND * 2, ncf = (size_t)s->NBR * 3;
+  float* r0 = (float*)dupmem(s->root + env * nr, nr * 4);
+  float* d0 = (float*)dupmem(s->dof + env * ndf, ndf * 4);
+  float* c0 = (float*)dupmem(s->cf + env * ncf, ncf * 4);
+  simulate_env(s, env, w);
+  memcpy(s->root + env * nr, r0, nr * 4); memcpy(s->dof + env * ndf, d0, ndf * 4); memcpy(s->cf + env * ncf, c0, ncf * 4);
+  free(r0); free(d0); free(c0);
+  const real* L = w->L[robot];
+  for (int i = 0; i < RD; i++) for (int j = 0; j < RD; j++) {
+    real acc = 0;
+    for (int k = 0; k <= (i < j ? i : j); k++) acc += L[i * RD + k] * L[j * RD + k];
+    M_out[i * RD + j] = (float)acc;
+  }
+  for (int j = 0; j < RD; j++) {
+    real col[RD]; memset(col, 0, sizeof col); col[j] = 1;
+    chol_solve(L, RD, RD, col);
+    for (int i = 0; i < RD; i++) Minv_out[i * RD + j] = (float)col[i];
+  }
+  *nc_out = w->nc;
+  for (int c = 0; c < w->nc; c++) {
+    float* o = contacts_out + c * 8;
+    o[0] = (float)w->con[c].actA; o[1] = (float)w->con[c].sphA; o[2] = (float)w->con[c].actB; o[3] = (float)w->con[c].sphB;
+    o[4] = (float)w->con[c].sd; o[5] = (float)w->con[c].n[0]; o[6] = (float)w->con[c].n[1]; o[7] = (float)w->con[c].n[2];
+  }
+  free(w);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ rows J..N: post-physics */
+/* in_step: obs_buf.last_last_action is a VIEW of self.last_actions (go1.py:183), and legged_robot.py:151 overwrites
+ * last_actions in place right after compute_observations -- so what any caller of step() observes is the new value */
+static void compute_observations_env(mqo_sim* s, int e, int in_step) { /* go1.py:153-196 */
+  int A = s->A;
+  const mqe_sim_desc* d = &s->d;
+  for (int a = 0; a < A; a++) {
+    int i = e * A + a;
+    float* ob = s->obs_bag + (size_t)i * OBS_BAG;
+    const float* rs = s->root + ((size_t)e * (A + s->P) + a) * 13;
+    for (int k = 0; k < 3; k++) ob[k] = rs[k] - s->env_origins[e * 3 + k];          /* base_pos :162 */
+    euler_xyz_f(s->bquat + i * 4, ob + 3);                                          /* base_rpy :193 */
+    for (int j = 0; j < 12; j++) {
+      const float* ds = s->dof + ((size_t)e * s->ND + a * 12 + j) * 2;
+      ob[6 + j] = (ds[0] - d->default_dof_pos[j]) * 1.0f;                           /* dof_pos :168 */
+      ob[18 + j] = ds[1] * 0.05f;                                                   /* dof_vel :171 */
+      ob[36 + j] = s->actions[i * 12 + j];                                          /* last_action :180 */
+      ob[48 + j] = in_step ? s->actions[i * 12 + j] : s->last_actions[i * 12 + j];  /* last_last_action :183 (+ :151 aliasing) */
+    }
+    for (int k = 0; k < 3; k++) {
+      ob[30 + k] = s->blv[i * 3 + k] * 2.0f;                                        /* lin_vel :174 */
+      ob[33 + k] = s->bav[i * 3 + k] * 0.25f;                                       /* ang_vel :177 */
+      ob[60 + k] = s->pg[i * 3 + k];                                                /* projected_gravity :186 */
+    }
+    for (int k = 0; k < 4; k++) { ob[63 + k] = s->clock[i * 4 + k]; ob[67 + k] = s->bquat[i * 4 + k]; }  /* :190, :165 */
+  }
+}
+/* NOTE on the bag layout used above: [0:3] base_pos, [3:6] base_rpy, [6:18] dof_pos, [18:30] dof_vel, [30:33] lin_vel,
+ * [33:36] ang_vel, [36:48] last_action, [48:60] last_last_action, [60:63] projected_gravity, [63:67] clock_inputs,
+ * [67:71] base_quat, [71:74] pad.  mqo_policy_step reads gravity/clock at these offsets. */
+
+static void reset_env(mqo_sim* s, int e) { /* go1.py:110-145, legged_robot.py:394-470,647-652 */
+  const mqe_sim_desc* d = &s->d;
+  int A = s->A, P = s->P;
+  float* root = s->root + (size_t)e * (A + P) * 13;
+  float* dofs = s->dof + (size_t)e * s->ND * 2;
+  for (int a = 0; a < A; a++)
+    for (int j = 0; j < 12; j++) {
+      float ratio = mqo_rand(s, e, (uint32_t)(a * 12 + j), d->dof_ratio_lo, d->dof_ratio_hi);
+      dofs[(a * 12 + j) * 2] = d->default_dof_pos[j] * ratio;     /* legged_robot.py:403 */
+      dofs[(a * 12 + j) * 2 + 1] = 0.0f;                          /* :411 */
+    }
+  for (int k = 0; k < s->npc_dofs; k++) { dofs[(12 * A + k) * 2] = d->seesaw_default_angle; dofs[(12 * A + k) * 2 + 1] *= 0.0f; } /* :414-415 */
+  for (int a = 0; a < A; a++) {
+    float* rs = root + a * 13;
+    memcpy(rs, s->base_init + a * 13, 13 * 4);                     /* :433 */
+    for (int k = 0; k < 3; k++) rs[k] += s->agent_origins[((size_t)e * A + a) * 3 + k];  /* :434 */
+  }
+  for (int p = 0; p < P; p++) {
+    float* rs = root + (A + p) * 13;
+    memcpy(rs, s->npc_init + p * 13, 13 * 4);                      /* :436 */
+    for (int k = 0; k < 3; k++) rs[k] += s->env_origins[e * 3 + k];  /* :437 */
+  }
+  if (d->has_base_pos_range)
+    for (int a = 0; a < A; a++) {
+      root[a * 13 + 0] += mqo_rand(s, e, (uint32_t)(64 + a), d->base_pos_x_lo, d->base_pos_x_hi);   /* :441 */
+      root[a * 13 + 1] += mqo_rand(s, e, (uint32_t)(72 + a), d->base_pos_y_lo, d->base_pos_y_hi);   /* :442 */
+    }
+  if (d->has_npc_pos_range)
+    for (int p = 0; p < P; p++) {
+      root[(A + p) * 13 + 0] += mqo_rand(s, e, (uint32_t)(128 + p), d->npc_pos_x_lo, d->npc_pos_x_hi);  /* :445 */
+      root[(A + p) * 13 + 1] += mqo_rand(s, e, (uint32_t)(160 + p), d->npc_pos_y_lo, d->npc_pos_y_hi);  /* :446 */
+    }
+  for (int a = 0; a < A; a++)
+    for (int c = 0; c < 6; c++) root[a * 13 + 7 + c] = mqo_rand(s, e, (uint32_t)(80 + a * 6 + c), d->base_vel_lo, d->base_vel_hi); /* :458 */
+  /* _reset_buffers: legged_robot.py:647-652, go1.py:141-145 */
+  for (int k = 0; k < 12 * A; k++) s->last_actions[(size_t)e * 12 * A + k] = 0.0f;
+  s->ep_len[e] = 0;
+  s->reset_buf[e] = 1;
+  for (int a = 0; a < A; a++) {
+    int i = e * A + a;
+    s->gait[i] = 0.0f;
+    memset(s->hist + (size_t)i * MQE_HIST * FR, 0, (size_t)MQE_HIST * FR * 4);
+  }
+  s->reset_count[e] += 1;
+}
+
+/* sheep flocking script, go1_sheep.py:14-18,35-64.  noise: injected N(0,1) [P][3] */
+static void step_sheep_env(mqo_sim* s, int e) {
+  const mqe_sim_desc* d = &s->d;
+  int A = s->A, P = s->P;
+  float* root = s->root + (size_t)e * (A + P) * 13;
+  float avg[3] = {0, 0, 0};
+  for (int p = 0; p < P; p++) for (int k = 0; k < 3; k++) avg[k] += root[(A + p) * 13 + k];
+  for (int k = 0; k < 3; k++) avg[k] /= (float)P;
+  s->sheep_avg[e * 2] = avg[0]; s->sheep_avg[e * 2 + 1] = avg[1];
+  float var = 0;
+  for (int k = 0; k < 2; k++) {
+    float acc = 0;
+    for (int p = 0; p < P; p++) { float t = root[(A + p) * 13 + k] - avg[k]; acc += t * t; }
+    var += acc / (float)P;
+  }
+  s->sheep_var[e] = var;
+  float dvs[MAXP][3];
+  for (int p = 0; p < P; p++) {
+    const float* sp = root + (A + p) * 13;
+    float dv[3];
+    for (int k = 0; k < 3; k++) dv[k] = d->sheep_movement_randomness * s->npc_noise[((size_t)e * P + p) * 3 + k] * 2.0f;  /* :43 */
+    if (P != 1) {
+      float rel[3] = {avg[0] - sp[0], avg[1] - sp[1], avg[2] - sp[2]};
+      float nr = sqrtf(rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2]);
+      for (int k = 0; k < 3; k++) dv[k] += d->sheep_movement_randomness * rel[k] / nr / 1.5f;   /* :47 */
+    }
+    for (int a = 0; a < A; a++) {
+      const float* dp = root + a * 13;
+      float rel[3] = {sp[0] - dp[0], sp[1] - dp[1], sp[2] - dp[2]};
+      float sq[3] = {rel[0] * rel[0], rel[1] * rel[1], rel[2] * rel[2]};
+      float dis = sqrtf(sq[0] * sq[0] + sq[1] * sq[1] + sq[2] * sq[2]);    /* norm of the element-wise square, :15 */
+      float den = powf(dis, 1.4f);
+      for (int k = 0; k < 3; k++) { float t = rel[k] / den; if (dis > 9.0f) t = 0.0f; dv[k] += d->sheep_movement_scale * t; } /* :16-17,52 */
+    }
+    dv[2] = 0.0f;                                                             /* :54 */
+    for (int k = 0; k < 3; k++) dvs[p][k] = dv[k];
+  }
+  for (int p = 0; p < P; p++) {
+    float* sp = root + (A + p) * 13;
+    for (int k = 0; k < 3; k++) sp[7 + k] += dvs[p][k];                         /* :58 */
+    for (int k = 0; k < 2; k++) sp[7 + k] = fminf(fmaxf(sp[7 + k], -2.0f), 2.0f);  /* :59 */
+    sp[2] = fminf(fmaxf(sp[2], 0.0f), 0.3f);                                    /* :60 */
+    sp[3] = 0.0f; sp[4] = 0.0f;                                                 /* :61 */
+  }
+}
+
+static void wrapper_env(mqo_sim* s, int e, int is_reset_call, const float* pre_npc);
+
+int mqo_post_physics_step(mqo_sim* s) {
+  const mqe_sim_desc* d = &s->d;
+  int N = s->N, A = s->A, P = s->P;
+  float dtp = d->dt * (float)d->decimation;     /* self.dt = decimation * sim dt (legged_robot.py:1014) */
+  for (int e = 0; e < N; e++) {
+    float* root = s->root + (size_t)e * (A + P) * 13;
+    s->ep_len[e] += 1;                                                           /* legged_robot.py:126 */
+    for (int a = 0; a < A; a++) {
+      int i = e * A + a;
+      const float* rs = root + a * 13;
+      float g3[3] = {0.0f, 0.0f, -1.0f};
+      for (int k = 0; k < 4; k++) s->bquat[i * 4 + k] = rs[3 + k];               /* :132 */
+      quat_rotate_inverse_f(rs + 3, rs + 7, s->blv + i * 3);                     /* :133 */
+      quat_rotate_inverse_f(rs + 3, rs + 10, s->bav + i * 3);                    /* :134 */
+      quat_rotate_inverse_f(rs + 3, g3, s->pg + i * 3);                          /* :135 */
+      /* gait clock, go1.py:240-279 */
+      const float* lo = s->loco_obs + (size_t)i * FR;
+      float f = lo[7], ph = lo[8], off = lo[9], bnd = lo[10], dur = lo[11];
+      float gi = s->gait[i] + dtp * f;
+      gi = gi - floorf(gi);                                                       /* torch.remainder(x, 1.0) */
+      s->gait[i] = gi;
+      float fi[4] = {gi + ph + off + bnd, gi + off, gi + bnd, gi + ph};
+      for (int k = 0; k < 4; k++) {
+        float r = fi[k] - floorf(fi[k]);
+        if (r < dur) fi[k] = r * (0.5f / dur);
+        else if (r > dur) fi[k] = 0.5f + (r - dur) * (0.5f / (1.0f - dur));
+        s->clock[i * 4 + k] = sinf(6.2831855f * fi[k]);
+      }
+    }
+    /* check_termination: legged_robot.py:159-169 + legged_robot_field.py:121-146 */
+    uint8_t reset = 0, collide = 0, rterm = 0, pterm = 0, zh = 0;
+    if (d->terminate_on_base_contact) {
+      for (int a = 0; a < A; a++) {
+        const float* f3 = s->cf + ((size_t)e * s->NBR + a * MQE_NREP) * 3;
+        if (sqrtf(f3[0] * f3[0] + f3[1] * f3[1] + f3[2] * f3[2]) > 1.0f) collide = 1;
+      }
+      reset = collide;
+    }
+    uint8_t to = s->ep_len[e] > d->max_episode_length;
+    s->time_out[e] = to;
+    reset |= to;
+    for (int a = 0; a < A; a++) {
+      int i = e * A + a;
+      float rpy[3];
+      euler_xyz_f(s->bquat + i * 4, rpy);
+      float r = rpy[0], p = rpy[1];
+      if (r > 3.1415927f) r -= 6.2831855f;
+      if (p > 3.1415927f) p -= 6.2831855f;
+      float z = root[a * 13 + 2] - s->agent_origins[((size_t)e * A + a) * 3 + 2];
+      if ((d->termination_flags & MQE_TERM_ROLL) && fabsf(r) > d->roll_threshold) rterm = 1;
+      if ((d->termination_flags & MQE_TERM_PITCH) && fabsf(p) > d->pitch_threshold) pterm = 1;
+      if ((d->termination_flags & MQE_TERM_Z_LOW) && z < d->z_low_threshold) reset = 1;
+      if ((d->termination_flags & MQE_TERM_Z_HIGH) && z > d->z_high_threshold) zh = 1;
+    }
+    if (d->termination_flags & MQE_TERM_ROLL) s->r_term[e] = rterm;
+    if (d->termination_flags & MQE_TERM_PITCH) s->p_term[e] = pterm;
+    if (d->termination_flags & MQE_TERM_Z_HIGH) s->zh_term[e] = zh;
+    reset |= rterm | pterm | zh;
+    s->reset_buf[e] = reset;
+    /* reset_buf aliases collide_buf when contact termination is on (legged_robot.py:165) */
+    if (d->terminate_on_base_contact) s->collide_buf[e] = reset;
+  }
+  /* NPC script before resets (legged_robot.py:146), sees this step's post-physics states */
+  float* pre_npc = NULL;
+  if (P) {
+    pre_npc = (float*)malloc((size_t)N * P * 13 * 4);
+    for (int e = 0; e < N; e++) memcpy(pre_npc + (size_t)e * P * 13, s->root + ((size_t)e * (A + P) + A) * 13, (size_t)P * 13 * 4);
+  }
+  if (d->npc_kind == MQE_NPC_SHEEP) for (int e = 0; e < N; e++) step_sheep_env(s, e);
+  for (int e = 0; e < N; e++) {
+    if (s->reset_buf[e]) {
+      reset_env(s, e);                                                            /* :148 */
+      if (P) memcpy(pre_npc + (size_t)e * P * 13, s->root + ((size_t)e * (A + P) + A) * 13, (size_t)P * 13 * 4);
+      if (P == 0) /* root_states is a live view when there are no NPCs: base_quat shows the post-reset value */
+        for (int a = 0; a < A; a++) for (int k = 0; k < 4; k++) s->bquat[(e * A + a) * 4 + k] = s->root[((size_t)e * A + a) * 13 + 3 + k];
+    }
+    compute_observations_env(s, e, 1);                                            /* :149 */
+    for (int k = 0; k < 12 * A; k++) s->last_actions[(size_t)e * 12 * A + k] = s->actions[(size_t)e * 12 * A + k];  /* :151 */
+    wrapper_env(s, e, 0, pre_npc ? pre_npc + (size_t)e * P * 13 : NULL);
+  }
+  free(pre_npc);
+  s->n_post_steps++;
+  return 0;
+}
+
+int mqo_reset_all(mqo_sim* s) { /* Go1.reset go1.py:147-151 + wrapper.reset() */
+  for (int e = 0; e < s->N; e++) {
+    reset_env(s, e);
+    /* base_quat is a view of the root_states tensor made in _init_buffers (legged_robot.py:568-570).  Without NPCs
+     * that tensor aliases the simulator state for ever; with NPCs it is a private copy that reset_idx still writes
+     * to only until the first post_physics_step rebinds self.root_states (:130) */
+    if (s->P == 0 || s->n_post_steps == 0)
+      for (int a = 0; a < s->A; a++) for (int k = 0; k < 4; k++) s->bquat[(e * s->A + a) * 4 + k] = s->root[((size_t)e * (s->A + s->P) + a) * 13 + 3 + k];
+    compute_observations_env(s, e, 0);
+    s->w_have_last[e] = 0;
+    s->w_delayed_reset[e] = 0;
+    wrapper_env(s, e, 1, s->P ? s->root + ((size_t)e * (s->A + s->P) + s->A) * 13 : NULL);
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ rows W1-W4: task wrappers
+ * npc: the (N*P,13) `root_states_npc` the wrapper sees = copy taken before the NPC script, overwritten by reset
+ * (legged_robot.py:136,436).  Reward terms are also accumulated per env into rsum[e][term]. */
+static void base_info(const mqo_sim* s, int i, float* o6) {
+  const float* ob = s->obs_bag + (size_t)i * OBS_BAG;
+  for (int k = 0; k < 6; k++) o6[k] = ob[k];
+}
+static void wrapper_env(mqo_sim* s, int e, int is_reset_call, const float* npc) {
+  const mqe_sim_desc* d = &s->d;
+  int A = s->A, P = s->P, Aw = s->Aw, D = s->D;
+  float* obs = s->wobs + (size_t)e * Aw * D;
+  float* rew = s->wrew + (size_t)e * Aw;
+  float* rs = s->rsum + (size_t)e * MQE_MAX_REWARD_TERMS;
+  const float* sc = d->reward_scale;
+  for (int a = 0; a < Aw; a++) {
+    float* o = obs + a * D;
+    int c = 0;
+    for (int k = 0; k < Aw; k++) o[c++] = (k == a) ? 1.0f : 0.0f;             /* obs_ids (empty_wrapper.py:18) */
+    base_info(s, e * A + a, o + c); c += 6;
+    if (d->task != MQE_TASK_PLAIN) { base_info(s, e * A + (Aw - 1 - a), o + c); c += 6; }  /* torch.flip(base_info,[1]) */
+    if (d->task == MQE_TASK_GATE || d->task == MQE_TASK_SHEEP) { o[c++] = s->gate_pos[e * 2]; o[c++] = s->gate_pos[e * 2 + 1]; }
+    if (d->task == MQE_TASK_SHEEP)
+      for (int p = 0; p < P; p++) { o[c++] = npc[p * 13] - s->env_origins[e * 3]; o[c++] = npc[p * 13 + 1] - s->env_origins[e * 3 + 1]; }
+    if (d->task == MQE_TASK_FOOTBALL_DEFENDER) {
+      for (int k = 0; k < 3; k++) o[c++] = npc[k] - s->env_origins[e * 3 + k];
+      for (int k = 0; k < 3; k++) o[c++] = npc[7 + k];
+    }
+  }
+  if (is_reset_call) { for (int a = 0; a < Aw; a++) rew[a] = 0; return; }
+  float r_env = 0.0f;            /* the (N,1) reward column */
+  float r_ag[MAXA] = {0, 0, 0, 0};
+  uint8_t was_reset = s->reset_buf[e];
+  if (d->task == MQE_TASK_GATE) {
+    /* documented-but-commented semantics of go1_gate_wrapper.py:78-154 (live code returns 0: SURVEY F7) */
+    float tsum = 0;
+    for (int a = 0; a < A; a++) {
+      const float* ob = s->obs_bag + (size_t)(e * A + a) * OBS_BAG;
+      float tx = d->wrapper_param[0], ty = (a == 0 ? 1.0f : -1.0f) * d->wrapper_param[1];
+      float dist = sqrtf((ob[0] - tx) * (ob[0] - tx) + (ob[1] - ty) * (ob[1] - ty));
+      if (!s->w_have_last[e]) s->w_last[e * MAXA + a] = dist;
+      tsum += s->w_last[e * MAXA + a] - dist;
+      s->w_last[e * MAXA + a] = dist;
+    }
+    s->w_have_last[e] = 1;
+    if (was_reset) tsum = 0;
+    tsum *= sc[0];
+    for (int a = 0; a < A; a++) r_ag[a] += tsum;
+    rs[0] += tsum;
+    float col = sc[1] * (float)s->collide_buf[e];
+    for (int a = 0; a < A; a++) r_ag[a] += col;
+    rs[1] += col;
+    for (int a = 0; a < A; a++) {
+      const float* ob = s->obs_bag + (size_t)(e * A + a) * OBS_BAG;
+      if (ob[0] > s->gate_pos[e * 2] + 0.25f) { r_ag[a] += sc[2]; rs[2] += sc[2]; }
+      const float* ob2 = s->obs_bag + (size_t)(e * A + (A - 1 - a)) * OBS_BAG;
+      float d2 = (ob[0] - ob2[0]) * (ob[0] - ob2[0]) + (ob[1] - ob2[1]) * (ob[1] - ob2[1]);
+      if (d2 < 0.25f) { float pn = sc[3] / d2; r_ag[a] += pn; rs[3] += pn; }
+    }
+    float tot = 0;
+    for (int a = 0; a < A; a++) tot += r_ag[a];
+    for (int a = 0; a < A; a++) rew[a] = tot;                                  /* sum over agents, broadcast (:154) */
+    return;
+  }
+  if (d->task == MQE_TASK_SHEEP) {   /* go1_sheep_wrapper.py:54-118 */
+    float gate_x = s->gate_pos[e * 2];
+    if (sc[0] != 0) {
+      int cnt = 0;
+      for (int p = 0; p < P; p++) if ((npc[p * 13] - s->env_origins[e * 3]) - gate_x > 0) cnt++;
+      r_env = (float)cnt;                                                       /* assigned, unscaled (:73) */
+      rs[0] += (float)cnt;
+    }
+    if (sc[1] != 0) { float c = sc[1] * (float)s->collide_buf[e]; r_env += c; rs[1] += c; }
+    if (sc[2] != 0) {
+      if (s->w_have_last[e]) {
+        float xm = s->sheep_avg[e * 2] - s->w_last2[e * 2];
+        if (s->w_delayed_reset[e]) xm = 0;
+        float v = sc[2] * xm;
+        r_env += v; rs[2] += v;
+      }
+      s->w_last2[e * 2] = s->sheep_avg[e * 2]; s->w_last2[e * 2 + 1] = s->sheep_avg[e * 2 + 1];
+      s->w_have_last[e] = 1;
+    }
+    if (sc[3] != 0) {
+      float acc = 0;
+      for (int p = 0; p < P; p++) {
+        float x = npc[p * 13] - s->env_origins[e * 3], y = npc[p * 13 + 1] - s->env_origins[e * 3 + 1];
+        float dg = sqrtf((x - gate_x) * (x - gate_x) + (y - s->gate_pos[e * 2 + 1]) * (y - s->gate_pos[e * 2 + 1]));
+        float v = expf(-dg / 2.0f) * sc[3];
+        if (x >= gate_x) v = sc[3];
+        acc += v;
+      }
+      r_env += acc; rs[3] += acc;
+    }
+    if (sc[4] != 0 || sc[5] != 0) {
+      float v = sc[5] * (s->sheep_var[e] - 1.0f) + sc[4] * expf(s->sheep_var[e] / 2.0f - 1.0f);
+      r_env += v; rs[4] += v;
+    }
+    s->w_delayed_reset[e] = was_reset;
+    for (int a = 0; a < Aw; a++) rew[a] = r_env;
+    return;
+  }
+  if (d->task == MQE_TASK_SEESAW) {   /* go1_seesaw_wrapper.py:48-120 */
+    float xs = 0, zs = 0, y2 = 0;
+    for (int a = 0; a < A; a++) {
+      const float* ob = s->obs_bag + (size_t)(e * A + a) * OBS_BAG;
+      if (!s->w_have_last[e]) s->w_last[e * MAXA + a] = ob[0];
+      xs += ob[0] - s->w_last[e * MAXA + a];
+      s->w_last[e * MAXA + a] = ob[0];
+      zs += ob[2]; y2 += ob[1] * ob[1];
+    }
+    s->w_have_last[e] = 1;
+    if (sc[0] != 0) { if (was_reset) xs = 0; xs *= sc[0]; r_env += xs; rs[0] += xs; }
+    if (sc[1] != 0) { float v = sc[1] * (zs - 0.56f); r_env += v; rs[1] += v; }
+    if (sc[2] != 0) { float v = sc[2] * (y2 - 0.5f); r_env += v; rs[2] += v; }
+    if (sc[3] != 0) { float v = sc[3] * (float)s->collide_buf[e]; r_env += v; rs[3] += v; }
+    if (sc[4] != 0) {
+      const float* o0 = s->obs_bag + (size_t)(e * A) * OBS_BAG; const float* o1 = s->obs_bag + (size_t)(e * A + A - 1) * OBS_BAG;
+      float d2 = (o0[0] - o1[0]) * (o0[0] - o1[0]) + (o0[1] - o1[1]) * (o0[1] - o1[1]);
+      if (d2 < 0.25f) { float v = sc[4] / d2; r_env += v; rs[4] += v; }
+    }
+    if (sc[5] != 0) {
+      int cnt = 0;
+      for (int a = 0; a < A; a++) { const float* ob = s->obs_bag + (size_t)(e * A + a) * OBS_BAG; if (ob[0] > 7.7f && ob[2] > 1.3f) cnt++; }
+      float v = sc[5] * (float)cnt; r_env += v; rs[5] += v;
+    }
+    if (sc[6] != 0) { if (s->r_term[e] | s->p_term[e]) { r_env += sc[6]; rs[6] += sc[6]; } }
+    for (int a = 0; a < Aw; a++) rew[a] = r_env;
+    return;
+  }
+  if (d->task == MQE_TASK_FOOTBALL_DEFENDER) {   /* go1_football_wrapper.py:57-91 */
+    float bx = npc[0] - s->env_origins[e * 3], by = npc[1] - s->env_origins[e * 3 + 1];
+    if (sc[0] != 0) { if (bx > s->gate_pos[e * 2]) { r_env += sc[0]; rs[0] += sc[0]; } }
+    if (sc[1] != 0) {
+      float dg = sqrtf((bx - s->gate_pos[e * 2]) * (bx - s->gate_pos[e * 2]) + (by - s->gate_pos[e * 2 + 1]) * (by - s->gate_pos[e * 2 + 1]));
+      float v = sc[1] * expf(-dg / 3.0f);
+      r_env += v; rs[1] += v;
+    }
+    for (int a = 0; a < Aw; a++) rew[a] = r_env;
+    return;
+  }
+  for (int a = 0; a < Aw; a++) rew[a] = 0;
+}
+
+int mqo_wrapper_eval(mqo_sim* s, int is_reset_call) {
+  for (int e = 0; e < s->N; e++) {
+    if (is_reset_call) { s->w_have_last[e] = 0; s->w_delayed_reset[e] = 0; }
+    wrapper_env(s, e, is_reset_call, s->P ? s->root + ((size_t)e * (s->A + s->P) + s->A) * 13 : NULL);
+  }
+  return 0;
+}
+
+/* scripted defender command, go1_football_defender.py:56-80 */
+static void defender_command(const mqo_sim* s, int e, float* cmd3) {
+  int A = s->A, P = s->P;
+  const float* root = s->root + (size_t)e * (A + P) * 13;
+  const float* dp = root + 2 * 13;
+  const float* bp = root + A * 13;
+  float gate[3] = {s->gate_pos[e * 2], s->gate_pos[e * 2 + 1], s->env_origins[e * 3 + 2]};
+  float tp[3];
+  for (int k = 0; k < 3; k++) tp[k] = 0.6f * bp[k] + 0.4f * gate[k];
+  float yaw = s->obs_bag[(size_t)(e * A + 2) * OBS_BAG + 5];
+  float yaw_to_gate = 3.1415927f + atanf((gate[1] - dp[1]) / (gate[0] - dp[0]));
+  float yc = fminf(fmaxf(yaw_to_gate - yaw, -0.3f), 0.3f) / 0.3f;
+  float tdg = sqrtf((tp[0] - gate[0]) * (tp[0] - gate[0]) + (tp[1] - gate[1]) * (tp[1] - gate[1]));
+  float ddg = sqrtf((dp[0] - gate[0]) * (dp[0] - gate[0]) + (dp[1] - gate[1]) * (dp[1] - gate[1]));
+  float xc = fminf(fmaxf(tdg - ddg, -0.5f), 0.5f);
+  float yy = -fminf(fmaxf(gate[1] + (tp[1] - gate[1]) * (dp[0] - gate[0]) / (tp[0] - gate[0]) - dp[1], -0.5f), 0.5f);
+  cmd3[0] = xc; cmd3[1] = yy; cmd3[2] = yc;
+}
+int mqo_defender_command(mqo_sim* s, float* out /*[N,3]*/) { for (int e = 0; e < s->N; e++) defender_command(s, e, out + e * 3); return 0; }
+
+/* ------------------------------------------------------------------------------------------ fused step */
+/* wrapper.step + Go1.step: actions [N, Aw, 3] */
+int mqo_step(mqo_sim* s, const float* actions) {
+  const mqe_sim_desc* d = &s->d;
+  int N = s->N, A = s->A, Aw = s->Aw;
+  float* cmd = (float*)malloc((size_t)s->R * 3 * 4);
+  static const float scale[3] = {2.0f, 0.5f, 0.5f};
+  for (int e = 0; e < N; e++) {
+    for (int a = 0; a < Aw; a++)
+      for (int k = 0; k < 3; k++) {
+        float v = actions[((size_t)e * Aw + a) * 3 + k];
+        v = fminf(fmaxf(v, -1.0f), 1.0f);                   /* wrapper clip (go1_sheep_wrapper.py:55) */
+        cmd[((size_t)e * A + a) * 3 + k] = d->task == MQE_TASK_PLAIN ? v : v * scale[k];
+      }
+    if (d->task == MQE_TASK_FOOTBALL_DEFENDER) defender_command(s, e, cmd + ((size_t)e * A + 2) * 3);
+  }
+  mqo_policy_step(s, cmd);
+  free(cmd);
+  for (int k = 0; k < d->decimation; k++) {
+    mqo_compute_torques(s);
+    mqo_simulate(s);
+    mqo_post_decimation_step(s, k);
+  }
+  mqo_post_physics_step(s);
+  return 0;
+}

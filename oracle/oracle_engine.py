@@ -1,0 +1,91 @@
+"""TEST INFRASTRUCTURE: ctypes loader of the CPU oracle (oracle/libmqe_oracle*.so) with the same Python surface
+as mqe.engine.hip_engine.HipEngine, on host memory.  Imported only by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg -- never by the package."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "multiagent-quadruped-environment_amd"))
+from mqe.engine import abi  # noqa: E402
+from mqe.engine.base import EngineBase, _NP_DT  # noqa: E402
+
+_LIBS = {}
+
+
+def build():
+    subprocess.check_call(["make", "-C", HERE, "-s"])
+
+
+def load_library(f64=False):
+    name = "libmqe_oracle_f64.so" if f64 else "libmqe_oracle.so"
+    if name not in _LIBS:
+        path = os.path.join(HERE, name)
+        if not os.path.isfile(path):
+            build()
+        _LIBS[name] = C.CDLL(path)
+    return _LIBS[name]
+
+
+class OracleEngine(EngineBase):
+    prefix = "mqo_"
+    device = "cpu"
+
+    def __init__(self, desc, keepalive, f64=False, device="cpu"):
+        self.torch_device = torch.device("cpu")
+        super().__init__(load_library(f64), desc, keepalive)
+        vp = C.c_void_p
+        for name, args in (("policy_step", [vp, vp]), ("compute_torques", [vp]), ("simulate", [vp]),
+                           ("post_decimation_step", [vp, C.c_int]), ("post_physics_step", [vp]),
+                           ("reset_all", [vp]), ("step", [vp, vp]), ("hist_pos", [vp]), ("wrapper_eval", [vp, C.c_int])):
+            f = getattr(self.lib, "mqo_" + name)
+            f.argtypes, f.restype = args, C.c_int
+
+    def _wrap(self, ptr, shape, dtype):
+        n = int(np.prod(shape)) if len(shape) else 1
+        ct = {0: C.c_float, 1: C.c_int32, 2: C.c_uint8}[dtype]
+        arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ct)), shape=(max(n, 1),))[:n].reshape(shape)
+        return torch.from_numpy(arr)
+
+    def policy_step(self, command):
+        c = np.ascontiguousarray(command.detach().cpu().numpy(), np.float32)
+        self._call("policy_step", C.c_void_p(c.ctypes.data))
+
+    def compute_torques(self):
+        self._call("compute_torques")
+
+    def simulate(self):
+        self._call("simulate")
+
+    def post_decimation_step(self, i):
+        self._call("post_decimation_step", int(i))
+
+    def post_physics_step(self):
+        self._call("post_physics_step")
+
+    def reset_all(self):
+        self._call("reset_all")
+
+    def step(self, actions):
+        a = np.ascontiguousarray(actions.detach().cpu().numpy(), np.float32)
+        self._call("step", C.c_void_p(a.ctypes.data))
+
+    def wrapper_eval(self, is_reset):
+        self._call("wrapper_eval", int(is_reset))
+
+    def defender_command(self, out):
+        o = np.zeros((self.desc.num_envs, 3), np.float32)
+        self.lib.mqo_defender_command.argtypes = [C.c_void_p, C.c_void_p]
+        self.lib.mqo_defender_command(self.h, C.c_void_p(o.ctypes.data))
+        out.copy_(torch.from_numpy(o))
+
+    def history(self):
+        R = self.desc.num_envs * self.desc.num_agents
+        out = np.zeros((R, 2100), np.float32)
+        self.lib.mqo_history.argtypes = [C.c_void_p, C.c_void_p]
+        self.lib.mqo_history(self.h, C.c_void_p(out.ctypes.data))
+        return torch.from_numpy(out)

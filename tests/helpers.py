@@ -1,0 +1,91 @@
+"""Shared test plumbing: build engine descriptors for the BASELINE tasks, load golden fixtures, make engines."""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from mqe.engine import abi
+from mqe.engine.desc import build_desc, task_kind
+from mqe.utils.terrain import BarrierTrack
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def golden(name):
+    return np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False)
+
+
+def task_cfg(task):
+    from mqe.envs.configs.go1_gate_config import Go1GateCfg
+    from mqe.envs.configs.go1_sheep_config import SingleSheepCfg, NineSheepCfg
+    from mqe.envs.configs.go1_seesaw_config import Go1SeesawCfg
+    from mqe.envs.configs.go1_football_config import Go1FootballDefenderCfg
+    from mqe.envs.configs.go1_plane_config import Go1PlaneCfg
+    return {"go1gate": Go1GateCfg, "go1sheep-easy": SingleSheepCfg, "go1sheep-hard": NineSheepCfg,
+            "go1seesaw": Go1SeesawCfg, "go1football-defender": Go1FootballDefenderCfg, "go1plane": Go1PlaneCfg}[task]
+
+
+def make_desc(task, N, seed=0, levels=None, types=None, max_episode_length=None, npc_init=None, env_id_offset=0, **kw):
+    """Scene exactly as Go1._create_scene builds it, but with explicit track assignment for replaying fixtures."""
+    cfg = task_cfg(task)
+    A = cfg.env.num_agents
+    np.random.seed(seed)
+    t = BarrierTrack(cfg.terrain, N, A).build()
+    if levels is None:
+        levels = np.zeros(N, np.int64)
+        types = np.arange(N) % cfg.terrain.num_cols
+    eo = t.env_origins[levels, types]
+    ao = t.agent_origins[levels, types]
+    info = {k: v[levels, types] for k, v in (t.env_info or {}).items()}
+    tk = task_kind(cfg)
+    kwb = cfg.terrain.BarrierTrack_kwargs
+    gate = None
+    if tk == "gate":
+        gate = info["gate_deviation"].copy()
+        gate[:, 0] += kwb["init"]["block_length"] + kwb["gate"]["block_length"] / 2
+    elif tk == "sheep":
+        gate = info["gate_deviation"].copy()
+        gate[:, 0] += kwb["init"]["block_length"] + kwb["plane"]["block_length"] + kwb["gate"]["block_length"] / 2
+    elif tk == "football_defender":
+        gate = eo[:, :2].copy()
+        gate[:, 0] += kwb["init"]["block_length"] + kwb["plane"]["block_length"]
+    d, keep = build_desc(cfg, N, t, eo, ao, gate_pos=gate, env_id_offset=env_id_offset, seed=0, **kw)
+    if max_episode_length is not None:
+        d.max_episode_length = int(max_episode_length)
+    if npc_init is not None:
+        arr = np.ascontiguousarray(npc_init, np.float32)
+        keep.append(arr)
+        d.npc_init_state = arr.ctypes.data_as(abi.FP)
+    return d, keep, dict(cfg=cfg, terrain=t, env_origins=eo, agent_origins=ao, info=info, gate=gate)
+
+
+def oracle_engine(d, keep, f64=False):
+    from oracle_engine import OracleEngine
+    return OracleEngine(d, keep, f64=f64)
+
+
+def hip_engine(d, keep):
+    from mqe.engine.hip_engine import HipEngine
+    return HipEngine(d, keep)
+
+
+def bag(engine, name):
+    a, b = abi.BAG[name]
+    return engine.tensor(abi.T_OBS_BAG)[:, a:b]
+
+
+def to_dev(engine, arr, dtype=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(arr), dtype=dtype).to(engine.torch_device)
+
+
+def close(a, b, atol, rtol=0.0, what=""):
+    a = np.asarray(a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a, np.float64)
+    b = np.asarray(b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else b, np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = np.abs(a - b)
+    tol = atol + rtol * np.abs(b)
+    if not (err <= tol).all():
+        i = np.unravel_index(np.argmax(err - tol), err.shape)
+        raise AssertionError(f"{what}: max err {err.max():.3e} at {i}: got {a[i]!r} want {b[i]!r} (atol {atol}, rtol {rtol})")

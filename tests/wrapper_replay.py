@@ -1,0 +1,60 @@
+"""Task wrappers (rows W2-W4): feed the synthetic env attributes of tests/golden/wrapper_*.npz (produced by running
+the reference's wrapper classes) into an engine and compare observation, reward and the reward log."""
+import numpy as np
+import torch
+
+from mqe.engine import abi
+from mqe.engine.desc import REWARD_TERMS
+from helpers import golden, make_desc, to_dev, close
+
+TASK_OF = {"sheep_hard": "go1sheep-hard", "sheep_easy": "go1sheep-easy", "seesaw": "go1seesaw", "football_defender": "go1football-defender"}
+
+
+def wrapper_replay(name, make_engine):
+    z = golden("wrapper_" + name)
+    T, N = z["obs"].shape[0], z["obs"].shape[1]
+    d, keep, ctx = make_desc(TASK_OF[name], N)
+    A, P = d.num_agents, d.num_npcs
+    # the fixture uses synthetic origins / gate positions: patch the descriptor's per-env constants
+    eo = np.ascontiguousarray(z["env_origins"], np.float32)
+    kw = ctx["cfg"].terrain.BarrierTrack_kwargs
+    gate = np.ascontiguousarray(z["gate_deviation"], np.float32).copy()
+    if name.startswith("sheep"):
+        gate[:, 0] += kw["init"]["block_length"] + kw["plane"]["block_length"] + kw["gate"]["block_length"] / 2
+    elif name == "football_defender":
+        gate = eo[:, :2].copy()
+        gate[:, 0] += kw["init"]["block_length"] + kw["plane"]["block_length"]
+    keep += [eo, gate]
+    d.env_origins = eo.ctypes.data_as(abi.FP)
+    d.gate_pos = gate.ctypes.data_as(abi.FP)
+    e = make_engine(d, keep)
+    Tn = e.tensor
+    bagt, root = Tn(abi.T_OBS_BAG), Tn(abi.T_ROOT_STATE)
+    R = N * A
+
+    def load(t):
+        bagt[:, 0:3] = to_dev(e, z["base_pos"][t])
+        bagt[:, 3:6] = to_dev(e, z["base_rpy"][t])
+        root[:, A:, :] = to_dev(e, z["root_states_npc"][t].reshape(N, P, 13))
+        Tn(abi.T_RESET_BUF).copy_(to_dev(e, z["reset_buf"][t].astype(np.uint8), torch.uint8))
+        Tn(abi.T_COLLIDE_BUF).copy_(to_dev(e, z["collide_buf"][t].astype(np.uint8), torch.uint8))
+        Tn(abi.T_R_TERM).copy_(to_dev(e, z["r_term_buff"][t].astype(np.uint8), torch.uint8))
+        Tn(abi.T_P_TERM).copy_(to_dev(e, z["p_term_buff"][t].astype(np.uint8), torch.uint8))
+        Tn(abi.T_SHEEP_POS_AVG).copy_(to_dev(e, z["sheep_pos_avg"][t]))
+        Tn(abi.T_SHEEP_POS_VAR).copy_(to_dev(e, z["sheep_pos_var"][t]))
+    load(0)
+    e.wrapper_eval(1)
+    close(Tn(abi.T_WRAPPER_OBS), z["obs_reset"], what="reset obs", atol=1e-6)
+    for t in range(T):
+        load(t + 1)
+        e.wrapper_eval(0)
+        close(Tn(abi.T_WRAPPER_OBS), z["obs"][t], what=f"t{t} obs", atol=1e-6)
+        close(Tn(abi.T_WRAPPER_REWARD), z["reward"][t], what=f"t{t} reward", atol=2e-5, rtol=1e-5)
+    sums = Tn(abi.T_REWARD_SUMS).double().sum(0).cpu().numpy()
+    names = [n for _, n in REWARD_TERMS[{"sheep_hard": "sheep", "sheep_easy": "sheep"}.get(name, name)]]
+    want = dict(zip([str(k) for k in z["reward_buffer_keys"]], z["reward_buffer_vals"]))
+    for i, n in enumerate(names):
+        if n is not None:
+            assert abs(sums[i] - want[n]) <= 1e-3 + 1e-5 * abs(want[n]), (n, sums[i], want[n])
+    e.close()
+    return True

@@ -307,19 +307,64 @@ def finish_env(env, terrain_origins, agent_origins, env_info, Ws, bs, ada):
     return env
 
 
-class ScriptedRand:
-    """torch_rand_float replacement: u = 0.5 + 0.45*sin(counter) so resets are reproducible by the product's
-    'scripted' reset-noise mode (tests only).  counter increments per CALL; within a call element e of the
-    flattened output uses phase counter + 0.37*e."""
+def hash_u01(seed, genv, count, k):
+    """The engine's reset RNG (include/mqe_hip.h MQE_NOISE_HASH; oracle/mqe_oracle.c mqo_u01), in numpy."""
+    with np.errstate(over="ignore"):
+        x = (np.uint32(seed) * np.uint32(0x9E3779B1)) ^ (np.uint32(genv) * np.uint32(0x85EBCA77)) ^ \
+            (np.uint32(count) * np.uint32(0xC2B2AE3D)) ^ (np.uint32(k) * np.uint32(0x27D4EB2F))
+        x ^= x >> np.uint32(16); x *= np.uint32(0x85EBCA6B); x ^= x >> np.uint32(13); x *= np.uint32(0xC2B2AE35); x ^= x >> np.uint32(16)
+    return np.float32(x >> np.uint32(8)) * np.float32(1.0 / 16777216.0)
 
-    def __init__(self):
-        self.c = 0
+
+class ScriptedRand:
+    """torch_rand_float replacement used while generating traces: returns what the ENGINE's counter-based reset
+    RNG would return for (seed 0, env id, per-env reset count, stream), by looking at the caller's `env_ids`
+    (legged_robot.py:394-470).  Streams: dof (a*12+j); base x 64+a, y 72+a; base vel 80+6a+c; npc x 128+p, y 160+p.
+    This makes resets inside the trace reproducible by the product without any special test mode."""
+
+    def __init__(self, env):
+        self.env = env
+        self.counts = {}
+        self.frames = {}
 
     def __call__(self, lower, upper, shape, device):
-        n = int(np.prod(shape))
-        u = 0.5 + 0.45 * np.sin(self.c + 0.37 * np.arange(n, dtype=np.float64))
-        self.c += 1
-        return torch.tensor((lower + (upper - lower) * u).reshape(shape), dtype=torch.float)
+        import sys as _s
+        f = _s._getframe(1)
+        name = f.f_code.co_name
+        env_ids = [int(e) for e in f.f_locals["env_ids"]]
+        A, P = self.env.num_agents, self.env.num_npcs
+        cfg = self.env.cfg
+        lo, hi = np.float32(lower), np.float32(upper)
+        out = np.zeros(shape, np.float32)
+        if name == "_reset_dofs":
+            for i, e in enumerate(env_ids):
+                for c in range(shape[1]):
+                    out[i, c] = (hi - lo) * hash_u01(0, e, self.counts.get(e, 0), c) + lo
+            return torch.from_numpy(out)
+        assert name == "_reset_root_states", name
+        kinds = []
+        if getattr(cfg.domain_rand, "init_base_pos_range", None) is not None:
+            kinds += ["bx", "by"]
+        if getattr(cfg.domain_rand, "init_npc_base_pos_range", None) is not None:
+            kinds += ["nx", "ny"]
+        kinds += ["vel"]
+        n = self.frames.get(id(f), 0)
+        self.frames[id(f)] = n + 1
+        kind = kinds[n]
+        for i in range(shape[0]):
+            if kind in ("bx", "by", "vel"):
+                e, a = env_ids[i // A], i % A
+            else:
+                e, a = env_ids[i // max(P, 1)], i % max(P, 1)
+            cnt = self.counts.get(e, 0)
+            for c in range(shape[1]):
+                k = {"bx": 64 + a, "by": 72 + a, "nx": 128 + a, "ny": 160 + a, "vel": 80 + a * 6 + c}[kind]
+                out[i, c] = (hi - lo) * hash_u01(0, e, cnt, k) + lo
+        if kind == "vel":
+            for e in env_ids:
+                self.counts[e] = self.counts.get(e, 0) + 1
+            self.frames.pop(id(f), None)
+        return torch.from_numpy(out)
 
 
 def barrier_track_for(cfg, N, seed=0):
@@ -388,7 +433,7 @@ def gen_fullstep(name, cls, cfg, N, T, act, ada, action_gain=1.0, seed=0):
         env.base_init_state_npc = torch.stack(lst, 0).repeat(N, 1)
         env.npc_env_origins = env.env_origins.unsqueeze(1).repeat(1, P, 1)
     rng = np.random.RandomState(seed + 7)
-    sr = ScriptedRand()
+    sr = ScriptedRand(env)
     ref_lr.torch_rand_float = sr
     noise_script = rng.standard_normal((T, N, P, 3)).astype(np.float32) if P else None
     _state = {"t": 0}
