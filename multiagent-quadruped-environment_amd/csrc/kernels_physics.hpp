@@ -1,0 +1,673 @@
+// kernels_physics.hpp -- k_simulate: one 5 ms step of articulated rigid-body dynamics with contact for every env.
+// Replaces gym.set_dof_actuation_force_tensor + gym.simulate + refresh_* (reference go1.py:52-56, legged_robot.py:
+// 122-124); the reference delegates this to Isaac Gym / PhysX, so the algorithm is this build's own.
+//
+// Mapping: ONE ENVIRONMENT PER 64-LANE WAVEFRONT (one wave per workgroup).  Lanes take different roles per phase:
+//   body lanes   (A*13 + P)   forward kinematics by tree level, spatial inertia / bias wrench about the base origin,
+//                             composite sums up the 3-link leg chains with lane shuffles
+//   leg lanes    (A*4)        3x3 leg block inverse, Schur terms;   (A*6) lanes: 6x6 base Schur complement inverse
+//   dof lanes    (A*18 + P*k) rows of M^-1, unconstrained velocity, and the velocity-space projected Gauss-Seidel
+//                             sweep: per contact every dof lane forms its Jacobian column on the fly, three wave
+//                             reductions give the contact-point velocity, the impulse update is uniform, and each lane
+//                             applies its own row of B = M^-1 J^T from LDS
+//   sphere lanes (A*27 + ..)  collision spheres vs ground plane / wall signed-distance field / other actors' spheres,
+//                             compacted with ballots into a bounded, canonically ordered contact list
+// Link transforms, M^-1 (18x18 per robot), B rows and the contact list live in LDS; state is read from and written to
+// HBM exactly once per launch, coalesced (the env-major rows of one env are contiguous).
+#pragma once
+#include "mqe_common.hpp"
+
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(float s, V3 a) { return v3(s * a.x, s * a.y, s * a.z); }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+__device__ __forceinline__ V3 ld3(const float* p) { return v3(p[0], p[1], p[2]); }
+__device__ __forceinline__ void st3(float* p, V3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
+__device__ __forceinline__ V3 mat_vec(const float* R, V3 v) {
+  return v3(R[0] * v.x + R[1] * v.y + R[2] * v.z, R[3] * v.x + R[4] * v.y + R[5] * v.z, R[6] * v.x + R[7] * v.y + R[8] * v.z);
+}
+// symmetric 3x3 stored (xx, yy, zz, xy, xz, yz)
+__device__ __forceinline__ V3 sym_vec(const float* S, V3 v) {
+  return v3(S[0] * v.x + S[3] * v.y + S[4] * v.z, S[3] * v.x + S[1] * v.y + S[5] * v.z, S[4] * v.x + S[5] * v.y + S[2] * v.z);
+}
+
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+  return x;
+}
+
+#define BODY_STRIDE 32
+#define CON_STRIDE 32
+enum { B_R = 0, B_P = 9, B_W = 12, B_VP = 15, B_A = 18, B_AL = 21, B_AP = 24, B_C = 27, B_M = 30 };
+enum { C_IDS = 0, C_P = 4, C_N = 7, C_T1 = 10, C_T2 = 13, C_SD = 16, C_BIAS = 17, C_K = 18, C_LAM = 24, C_REP = 27 };
+
+__host__ __device__ inline int mqe_maxc(int A, int P) { int v = 16 * A + 4 * P; return v > 48 ? 48 : v; }
+
+struct PhysLds {   // float offsets into dynamic LDS
+  int root, dof, tau, body, minv, rhs, fcol, leg, basei, sinv, sph, con, B, W, cfacc, total;
+};
+__host__ __device__ inline PhysLds phys_lds_layout(int A, int P, int ND, int nbody, int ndof, int nsph, int maxc, int bstride) {
+  PhysLds L; int o = 0;
+  L.root = o; o += (A + P) * 13;
+  L.dof = o; o += ND * 2;
+  L.tau = o; o += 12 * A;
+  o = (o + 3) & ~3;
+  L.body = o; o += nbody * BODY_STRIDE;
+  L.minv = o; o += A * MQE_RD * MQE_RD;
+  L.rhs = o; o += 128;
+  L.fcol = o; o += A * 12 * 6;
+  L.leg = o; o += A * 4 * 54;
+  L.basei = o; o += A * 10;
+  L.sinv = o; o += A * 36;
+  o = (o + 3) & ~3;
+  L.sph = o; o += nsph * 4;
+  L.con = o; o += maxc * CON_STRIDE;
+  L.B = o; o += maxc * 3 * bstride;
+  L.W = o; o += 64 * 4;
+  L.total = o;
+  return L;
+}
+
+struct PhysDebug { float* minv; int* nc; float* contacts; int robot; };
+
+__global__ void __launch_bounds__(64) k_simulate(const DevModel* __restrict__ m, DevState st, int env_base, int no_write, PhysDebug dbg) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x;
+  const int e = env_base + blockIdx.x;
+  const int A = m->A, P = m->P, PD = m->n_npc_dyn, npcdof = m->npc_dofs_each;
+  const int nbody = m->nbody_env, ndof = m->ndof_env, nsph = m->nsph_env, maxc = m->maxc, bs = m->ldsB_stride;
+  const PhysLds L = phys_lds_layout(A, P, m->ND, nbody, ndof, nsph, maxc, bs);
+  const float dt = m->dt;
+  const mqe_robot_model& rm = m->robot;
+  float* g_root = st.root + (size_t)e * (A + P) * 13;
+  float* g_dof = st.dof + (size_t)e * m->ND * 2;
+
+  // ---- coalesced state load -------------------------------------------------------------------------------
+  for (int i = lane; i < (A + P) * 13; i += 64) lds[L.root + i] = g_root[i];
+  for (int i = lane; i < m->ND * 2; i += 64) lds[L.dof + i] = g_dof[i];
+  for (int i = lane; i < 12 * A; i += 64) lds[L.tau + i] = st.torques[(size_t)e * 12 * A + i];
+  __syncthreads();
+
+  // ---- forward kinematics by tree level (body lanes) ---------------------------------------------------------
+  const bool is_body = lane < nbody;
+  const bool is_rbody = lane < A * MQE_NBODY;
+  const int br = is_rbody ? lane / MQE_NBODY : 0;              // robot of this body lane
+  const int bb = is_rbody ? lane - br * MQE_NBODY : 0;         // body index in the robot
+  const int depth = (is_rbody && bb > 0) ? ((bb - 1) % 3 + 1) : 0;
+  float Rm[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  V3 bp = v3(0, 0, 0), bw = bp, bvp = bp, bax = bp, bal = bp, bap = bp, bc = bp;
+  float Iw[6] = {0, 0, 0, 0, 0, 0};
+  float bmass = 0.0f;
+  float* myrec = lds + L.body + lane * BODY_STRIDE;
+  if (is_body && depth == 0) {
+    const float* rs = lds + L.root + (is_rbody ? br : (A + (lane - A * MQE_NBODY))) * 13;
+    float x = rs[3], y = rs[4], z = rs[5], w = rs[6];
+    Rm[0] = 1 - 2 * (y * y + z * z); Rm[1] = 2 * (x * y - z * w); Rm[2] = 2 * (x * z + y * w);
+    Rm[3] = 2 * (x * y + z * w); Rm[4] = 1 - 2 * (x * x + z * z); Rm[5] = 2 * (y * z - x * w);
+    Rm[6] = 2 * (x * z - y * w); Rm[7] = 2 * (y * z + x * w); Rm[8] = 1 - 2 * (x * x + y * y);
+    bp = ld3(rs); bvp = ld3(rs + 7); bw = ld3(rs + 10);
+    for (int k = 0; k < 9; k++) myrec[B_R + k] = Rm[k];
+    st3(myrec + B_P, bp); st3(myrec + B_W, bw); st3(myrec + B_VP, bvp); st3(myrec + B_A, bax); st3(myrec + B_AL, bal); st3(myrec + B_AP, bap);
+  }
+  __syncthreads();
+  for (int lev = 1; lev <= 3; lev++) {
+    if (depth == lev) {
+      const int pl = (lev == 1) ? br * MQE_NBODY : lane - 1;
+      const float* pr = lds + L.body + pl * BODY_STRIDE;
+      float PR[9];
+      for (int k = 0; k < 9; k++) PR[k] = pr[B_R + k];
+      V3 pp = ld3(pr + B_P), pw = ld3(pr + B_W), pvp = ld3(pr + B_VP), pal = ld3(pr + B_AL), pap = ld3(pr + B_AP);
+      const int j = bb - 1;
+      float qj = lds[L.dof + (br * 12 + j) * 2], qdj = lds[L.dof + (br * 12 + j) * 2 + 1];
+      V3 off = v3(rm.joint_offset[bb][0], rm.joint_offset[bb][1], rm.joint_offset[bb][2]);
+      V3 ax = v3(rm.joint_axis[bb][0], rm.joint_axis[bb][1], rm.joint_axis[bb][2]);
+      V3 dd = mat_vec(PR, off);
+      bp = pp + dd;
+      float c = cosf(qj), s = sinf(qj), t = 1 - c;
+      float Rj[9] = {t * ax.x * ax.x + c, t * ax.x * ax.y - s * ax.z, t * ax.x * ax.z + s * ax.y,
+                     t * ax.x * ax.y + s * ax.z, t * ax.y * ax.y + c, t * ax.y * ax.z - s * ax.x,
+                     t * ax.x * ax.z - s * ax.y, t * ax.y * ax.z + s * ax.x, t * ax.z * ax.z + c};
+      for (int r = 0; r < 3; r++)
+        for (int cc = 0; cc < 3; cc++) Rm[r * 3 + cc] = PR[r * 3] * Rj[cc] + PR[r * 3 + 1] * Rj[3 + cc] + PR[r * 3 + 2] * Rj[6 + cc];
+      bax = mat_vec(PR, ax);
+      bw = pw + qdj * bax;
+      bvp = pvp + cross(pw, dd);
+      bal = pal + cross(pw, qdj * bax);
+      bap = pap + cross(pal, dd) + cross(pw, cross(pw, dd));
+      for (int k = 0; k < 9; k++) myrec[B_R + k] = Rm[k];
+      st3(myrec + B_P, bp); st3(myrec + B_W, bw); st3(myrec + B_VP, bvp); st3(myrec + B_A, bax); st3(myrec + B_AL, bal); st3(myrec + B_AP, bap);
+    }
+    __syncthreads();
+  }
+  // world COM / inertia of robot bodies
+  if (is_rbody) {
+    bmass = rm.mass[bb];
+    bc = bp + mat_vec(Rm, v3(rm.com[bb][0], rm.com[bb][1], rm.com[bb][2]));
+    const float* S = rm.inertia[bb];
+    float Il[9] = {S[0], S[3], S[4], S[3], S[1], S[5], S[4], S[5], S[2]}, T[9];
+    for (int r = 0; r < 3; r++)
+      for (int cc = 0; cc < 3; cc++) T[r * 3 + cc] = Rm[r * 3] * Il[cc] + Rm[r * 3 + 1] * Il[3 + cc] + Rm[r * 3 + 2] * Il[6 + cc];
+    // Iw = T * R^T (symmetric)
+    Iw[0] = T[0] * Rm[0] + T[1] * Rm[1] + T[2] * Rm[2];
+    Iw[1] = T[3] * Rm[3] + T[4] * Rm[4] + T[5] * Rm[5];
+    Iw[2] = T[6] * Rm[6] + T[7] * Rm[7] + T[8] * Rm[8];
+    Iw[3] = T[0] * Rm[3] + T[1] * Rm[4] + T[2] * Rm[5];
+    Iw[4] = T[0] * Rm[6] + T[1] * Rm[7] + T[2] * Rm[8];
+    Iw[5] = T[3] * Rm[6] + T[4] * Rm[7] + T[5] * Rm[8];
+    st3(myrec + B_C, bc);
+    myrec[B_M] = bmass;
+  }
+
+  // ---- spatial inertia + bias wrench about o = base origin; composite sums up each leg ------------------------
+  // X[0]=m, X[1:4]=h=m*(c-o), X[4:10]=Ibar (sym6), X[10:13]=moment about o, X[13:16]=force
+  float X[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) X[k] = 0.0f;
+  V3 o = v3(0, 0, 0);
+  if (is_rbody) {
+    o = ld3(lds + L.body + br * MQE_NBODY * BODY_STRIDE + B_P);
+    V3 rc = bc - o;
+    X[0] = bmass; X[1] = bmass * rc.x; X[2] = bmass * rc.y; X[3] = bmass * rc.z;
+    float r2 = dot(rc, rc);
+    X[4] = Iw[0] + bmass * (r2 - rc.x * rc.x); X[5] = Iw[1] + bmass * (r2 - rc.y * rc.y); X[6] = Iw[2] + bmass * (r2 - rc.z * rc.z);
+    X[7] = Iw[3] - bmass * rc.x * rc.y; X[8] = Iw[4] - bmass * rc.x * rc.z; X[9] = Iw[5] - bmass * rc.y * rc.z;
+    V3 rcb = bc - bp;
+    V3 ac = bap + cross(bal, rcb) + cross(bw, cross(bw, rcb));
+    V3 f = bmass * (ac - v3(0, 0, m->gravity_z));
+    V3 nc = sym_vec(Iw, bal) + cross(bw, sym_vec(Iw, bw));
+    V3 no = nc + cross(rc, f);
+    X[10] = no.x; X[11] = no.y; X[12] = no.z; X[13] = f.x; X[14] = f.y; X[15] = f.z;
+  }
+#pragma unroll
+  for (int k = 0; k < 16; k++) { float t = __shfl_down(X[k], 1, 64); if (depth == 2) X[k] += t; }
+#pragma unroll
+  for (int k = 0; k < 16; k++) { float t = __shfl_down(X[k], 1, 64); if (depth == 1) X[k] += t; }
+  {
+    const int basel = br * MQE_NBODY;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      float t = __shfl(X[k], basel + 1, 64) + __shfl(X[k], basel + 4, 64) + __shfl(X[k], basel + 7, 64) + __shfl(X[k], basel + 10, 64);
+      if (is_rbody && bb == 0) X[k] += t;
+    }
+  }
+  // ---- mass-matrix columns (CRBA in the common frame) and generalized bias ------------------------------------
+  // joint lane: S = (w: a, v_o: (p - o) x a);  F = Ic S = (f, n)
+  V3 Sa = bax, Sv = cross(bp - o, bax);
+  V3 Ff = X[0] * Sv + cross(Sa, v3(X[1], X[2], X[3]));
+  V3 Fn = sym_vec(X + 4, Sa) + cross(v3(X[1], X[2], X[3]), Sv);
+  {
+    // ancestors' S through shuffles (lane-1: parent joint if depth>=2, lane-2: grandparent if depth==3)
+    V3 Sa1 = v3(__shfl_up(Sa.x, 1, 64), __shfl_up(Sa.y, 1, 64), __shfl_up(Sa.z, 1, 64));
+    V3 Sv1 = v3(__shfl_up(Sv.x, 1, 64), __shfl_up(Sv.y, 1, 64), __shfl_up(Sv.z, 1, 64));
+    V3 Sa2 = v3(__shfl_up(Sa.x, 2, 64), __shfl_up(Sa.y, 2, 64), __shfl_up(Sa.z, 2, 64));
+    V3 Sv2 = v3(__shfl_up(Sv.x, 2, 64), __shfl_up(Sv.y, 2, 64), __shfl_up(Sv.z, 2, 64));
+    if (depth >= 1) {
+      const int j = bb - 1, leg = j / 3;
+      float* Ml = lds + L.leg + (br * 4 + leg) * 54;     // Mll: [hh, tt, cc, ht, hc, tc]
+      float mjj = dot(Sa, Fn) + dot(Sv, Ff);
+      float hj = dot(Sa, v3(X[10], X[11], X[12])) + dot(Sv, v3(X[13], X[14], X[15]));
+      Ml[depth - 1] = mjj;
+      if (depth == 2) Ml[3] = dot(Sa1, Fn) + dot(Sv1, Ff);
+      if (depth == 3) { Ml[5] = dot(Sa1, Fn) + dot(Sv1, Ff); Ml[4] = dot(Sa2, Fn) + dot(Sv2, Ff); }
+      float* fc = lds + L.fcol + (br * 12 + j) * 6;
+      fc[0] = Ff.x; fc[1] = Ff.y; fc[2] = Ff.z; fc[3] = Fn.x; fc[4] = Fn.y; fc[5] = Fn.z;
+      lds[L.rhs + br * MQE_RD + 6 + j] = lds[L.tau + br * 12 + j] - hj;
+    } else if (is_rbody) {
+      float* bi = lds + L.basei + br * 10;
+      for (int k = 0; k < 10; k++) bi[k] = X[k];
+      float* rh = lds + L.rhs + br * MQE_RD;
+      rh[0] = -X[13]; rh[1] = -X[14]; rh[2] = -X[15]; rh[3] = -X[10]; rh[4] = -X[11]; rh[5] = -X[12];
+    }
+  }
+  __syncthreads();
+  // ---- leg blocks: Mi = Mll^-1, G = Mbl Mi (6x3), C = G Mbl^T (6x6 sym) ----------------------------------------
+  if (lane < A * 4) {
+    float* Ml = lds + L.leg + lane * 54;
+    const float* fc = lds + L.fcol + lane * 18;     // three consecutive joints x 6
+    float a = Ml[0], b = Ml[1], c = Ml[2], d = Ml[3], ee = Ml[4], f = Ml[5];   // [[a,d,ee],[d,b,f],[ee,f,c]]
+    float c00 = b * c - f * f, c01 = ee * f - d * c, c02 = d * f - ee * b;
+    float c11 = a * c - ee * ee, c12 = d * ee - a * f, c22 = a * b - d * d;
+    float idet = 1.0f / (a * c00 + d * c01 + ee * c02);
+    float Mi[9] = {c00 * idet, c01 * idet, c02 * idet, c01 * idet, c11 * idet, c12 * idet, c02 * idet, c12 * idet, c22 * idet};
+    float G[18];
+    for (int mm = 0; mm < 6; mm++)
+      for (int i = 0; i < 3; i++) G[mm * 3 + i] = fc[mm] * Mi[i] + fc[6 + mm] * Mi[3 + i] + fc[12 + mm] * Mi[6 + i];
+    Ml[6] = Mi[0]; Ml[7] = Mi[4]; Ml[8] = Mi[8]; Ml[9] = Mi[1]; Ml[10] = Mi[2]; Ml[11] = Mi[5];   // sym6: 00,11,22,01,02,12
+    for (int k = 0; k < 18; k++) Ml[12 + k] = G[k];
+    int q = 0;
+    for (int mm = 0; mm < 6; mm++)
+      for (int n = mm; n < 6; n++) Ml[30 + q++] = G[mm * 3] * fc[n] + G[mm * 3 + 1] * fc[6 + n] + G[mm * 3 + 2] * fc[12 + n];
+  }
+  __syncthreads();
+  // ---- 6x6 Schur complement inverse: lane (robot, column) --------------------------------------------------------
+  if (lane < A * 6) {
+    const int r = lane / 6, col = lane - r * 6;
+    const float* bi = lds + L.basei + r * 10;
+    float mt = bi[0], hx = bi[1], hy = bi[2], hz = bi[3];
+    float S[6][6];
+    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) S[i][j] = 0.0f;
+    S[0][0] = S[1][1] = S[2][2] = mt;
+    // M_lin,ang = -[h]x
+    S[0][4] = hz; S[0][5] = -hy; S[1][3] = -hz; S[1][5] = hx; S[2][3] = hy; S[2][4] = -hx;
+    S[3][3] = bi[4]; S[4][4] = bi[5]; S[5][5] = bi[6]; S[3][4] = bi[7]; S[3][5] = bi[8]; S[4][5] = bi[9];
+    for (int k = 0; k < 4; k++) {
+      const float* Cc = lds + L.leg + (r * 4 + k) * 54 + 30;
+      int q = 0;
+      for (int i = 0; i < 6; i++) for (int j = i; j < 6; j++) S[i][j] -= Cc[q++];
+    }
+    for (int i = 0; i < 6; i++) for (int j = 0; j < i; j++) S[i][j] = S[j][i];
+    // Cholesky (lower), then solve S x = e_col
+    float Lc[6][6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      float dgn = S[j][j];
+#pragma unroll
+      for (int k = 0; k < j; k++) dgn -= Lc[j][k] * Lc[j][k];
+      dgn = sqrtf(dgn);
+      Lc[j][j] = dgn;
+      float inv = 1.0f / dgn;
+#pragma unroll
+      for (int i = j + 1; i < 6; i++) {
+        float v = S[i][j];
+#pragma unroll
+        for (int k = 0; k < j; k++) v -= Lc[i][k] * Lc[j][k];
+        Lc[i][j] = v * inv;
+      }
+    }
+    float x[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      float v = (i == col) ? 1.0f : 0.0f;
+#pragma unroll
+      for (int k = 0; k < i; k++) v -= Lc[i][k] * x[k];
+      x[i] = v / Lc[i][i];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; i--) {
+      float v = x[i];
+#pragma unroll
+      for (int k = i + 1; k < 6; k++) v -= Lc[k][i] * x[k];
+      x[i] = v / Lc[i][i];
+    }
+    float* Si = lds + L.sinv + r * 36;
+    for (int i = 0; i < 6; i++) Si[i * 6 + col] = x[i];
+  }
+  __syncthreads();
+  // ---- rows of M^-1 (18 x 18 per robot) ---------------------------------------------------------------------------
+  for (int d = lane; d < A * MQE_RD; d += 64) {
+    const int r = d / MQE_RD, k = d - r * MQE_RD;
+    const float* Si = lds + L.sinv + r * 36;
+    float* row = lds + L.minv + (r * MQE_RD + k) * MQE_RD;
+    float T[6];
+    int legk = -1, li = 0;
+    if (k < 6) {
+      for (int mm = 0; mm < 6; mm++) { T[mm] = Si[k * 6 + mm]; row[mm] = T[mm]; }
+    } else {
+      legk = (k - 6) / 3; li = (k - 6) - legk * 3;
+      const float* G = lds + L.leg + (r * 4 + legk) * 54 + 12;
+      for (int mm = 0; mm < 6; mm++) {
+        float acc = 0.0f;
+        for (int n = 0; n < 6; n++) acc += G[n * 3 + li] * Si[n * 6 + mm];
+        T[mm] = acc; row[mm] = -acc;
+      }
+    }
+    for (int kk = 0; kk < 4; kk++) {
+      const float* G = lds + L.leg + (r * 4 + kk) * 54 + 12;
+      for (int i = 0; i < 3; i++) {
+        float acc = 0.0f;
+        for (int mm = 0; mm < 6; mm++) acc += T[mm] * G[mm * 3 + i];
+        if (k < 6) acc = -acc;
+        else if (kk == legk) {
+          const float* Mi = lds + L.leg + (r * 4 + kk) * 54 + 6;   // sym6 00,11,22,01,02,12
+          const int a = li < i ? li : i, b = li < i ? i : li;
+          acc += (a == b) ? Mi[a] : (a == 0 ? (b == 1 ? Mi[3] : Mi[4]) : Mi[5]);
+        }
+        row[6 + kk * 3 + i] = acc;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- dof-lane constants + unconstrained velocity ------------------------------------------------------------------
+  const bool is_dof = lane < ndof;
+  const bool is_rdof = lane < A * MQE_RD;
+  int dact = -1, dk = 0;        // actor and local dof index
+  uint32_t dmask = 0;           // robot bodies moved by this dof
+  bool dlin = false;
+  V3 dax = v3(0, 0, 0), danc = v3(0, 0, 0);
+  float vd = 0.0f, dinvm = 0.0f;
+  if (is_rdof) {
+    dact = lane / MQE_RD; dk = lane - dact * MQE_RD;
+    if (dk < 6) {
+      dmask = 0x1FFFu; dlin = dk < 3;
+      const int ax = dk % 3;
+      dax = v3(ax == 0, ax == 1, ax == 2);
+      danc = ld3(lds + L.body + dact * MQE_NBODY * BODY_STRIDE + B_P);
+      vd = lds[L.root + dact * 13 + 7 + dk];
+    } else {
+      const int j = dk - 6, i3 = j % 3, b = 1 + j;
+      dmask = ((i3 == 0 ? 7u : (i3 == 1 ? 6u : 4u)) << (1 + (j / 3) * 3));
+      const float* rec = lds + L.body + (dact * MQE_NBODY + b) * BODY_STRIDE;
+      dax = ld3(rec + B_A); danc = ld3(rec + B_P);
+      vd = lds[L.dof + (dact * 12 + j) * 2 + 1];
+    }
+    float acc = 0.0f;
+    const float* Mc = lds + L.minv + dact * MQE_RD * MQE_RD + dk;     // column dk == row dk (symmetric)
+    const float* rh = lds + L.rhs + dact * MQE_RD;
+    for (int ee = 0; ee < MQE_RD; ee++) acc += Mc[ee * MQE_RD] * rh[ee];
+    vd += dt * acc;
+  } else if (is_dof) {
+    const int q = lane - A * MQE_RD;
+    const int p = q / npcdof; dk = q - p * npcdof;
+    dact = A + p; dmask = 1u; dlin = dk < 3;
+    const int ax = dk % 3;
+    dax = v3(ax == 0, ax == 1, ax == 2);
+    danc = ld3(lds + L.root + (A + p) * 13);
+    vd = lds[L.root + (A + p) * 13 + 7 + dk];
+    dinvm = dk < 3 ? 1.0f / m->npc_mass : 1.0f / m->npc_inertia;
+    if (dk == 2) vd += dt * m->gravity_z;
+  }
+
+  // ---- collision spheres ----------------------------------------------------------------------------------------------
+  const int nsr = rm.n_spheres;
+  for (int s = lane; s < nsph; s += 64) {
+    V3 c; float rad;
+    if (s < A * nsr) {
+      const int r = s / nsr, si = s - r * nsr;
+      const float* rec = lds + L.body + (r * MQE_NBODY + rm.sphere_body[si]) * BODY_STRIDE;
+      c = ld3(rec + B_P) + mat_vec(rec + B_R, v3(rm.sphere_center[si][0], rm.sphere_center[si][1], rm.sphere_center[si][2]));
+      rad = rm.sphere_radius[si];
+    } else {
+      const int q = s - A * nsr, p = q / m->npc_n_spheres, si = q - p * m->npc_n_spheres;
+      const float* rec = lds + L.body + (A * MQE_NBODY + p) * BODY_STRIDE;
+      c = ld3(rec + B_P) + mat_vec(rec + B_R, v3(m->npc_sphere_center[si][0], m->npc_sphere_center[si][1], m->npc_sphere_center[si][2]));
+      rad = m->npc_sphere_radius[si];
+    }
+    float* sp = lds + L.sph + s * 4;
+    sp[0] = c.x; sp[1] = c.y; sp[2] = c.z; sp[3] = rad;
+  }
+  __syncthreads();
+
+  // ---- contact generation: terrain (ground plane, wall SDF), canonical order --------------------------------------------
+  int nc = 0;
+  for (int s0 = 0; s0 < nsph; s0 += 64) {
+    const int s = s0 + lane;
+    bool gflag = false, wflag = false;
+    float gsd = 0, wsd = 0; V3 wn = v3(0, 0, 1); V3 c = v3(0, 0, 0); float rad = 0;
+    int act = 0, body = 0, rep = 0;
+    if (s < nsph) {
+      const float* sp = lds + L.sph + s * 4;
+      c = ld3(sp); rad = sp[3];
+      if (s < A * nsr) { act = s / nsr; const int si = s - act * nsr; body = rm.sphere_body[si]; rep = act * MQE_NREP + rm.sphere_reported[si]; }
+      else { const int p = (s - A * nsr) / m->npc_n_spheres; act = A + p; body = 0; rep = A * MQE_NREP + p; }
+      gsd = c.z - m->ground_z - rad;
+      gflag = gsd < m->contact_offset;
+      // wall prism set: bilinear SDF sample at cell centres
+      const float hs = m->hs;
+      float fx = c.x / hs - 0.5f, fy = c.y / hs - 0.5f;
+      const int nx = m->sdf_nx, ny = m->sdf_ny;
+      fx = fminf(fmaxf(fx, 0.0f), (float)(nx - 1)); fy = fminf(fmaxf(fy, 0.0f), (float)(ny - 1));
+      int ix = (int)fx, iy = (int)fy;
+      if (ix > nx - 2) ix = nx - 2;
+      if (iy > ny - 2) iy = ny - 2;
+      const float tx = fx - ix, ty = fy - iy;
+      const float* sd = m->wall_sdf + (size_t)ix * ny + iy;
+      const float s00 = sd[0], s01 = sd[1], s10 = sd[ny], s11 = sd[ny + 1];
+      const float a0 = s00 + (s01 - s00) * ty, a1 = s10 + (s11 - s10) * ty;
+      float gx = (a1 - a0) / hs;
+      float gy = ((s01 - s00) + ((s11 - s10) - (s01 - s00)) * tx) / hs;
+      const float sh = a0 + (a1 - a0) * tx;
+      float gl = sqrtf(gx * gx + gy * gy);
+      if (gl < 1e-6f) { gx = 1; gy = 0; gl = 1; }
+      gx /= gl; gy /= gl;
+      const float dz = c.z - m->wall_height;
+      if (dz <= 0) {
+        if (sh <= 0 && -sh > -dz) { wsd = dz - rad; wn = v3(0, 0, 1); }
+        else { wsd = sh - rad; wn = v3(gx, gy, 0); }
+      } else if (sh <= 0) { wsd = dz - rad; wn = v3(0, 0, 1); }
+      else { const float dist = sqrtf(sh * sh + dz * dz); wsd = dist - rad; wn = v3(gx * sh / dist, gy * sh / dist, dz / dist); }
+      wflag = wsd < m->contact_offset;
+    }
+    const unsigned long long bg = __ballot(gflag), bw2 = __ballot(wflag);
+    const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int pre = __popcll(bg & lower) + __popcll(bw2 & lower);
+    if (gflag) {
+      const int slot = nc + pre;
+      if (slot < maxc) {
+        float* cr = lds + L.con + slot * CON_STRIDE;
+        cr[C_IDS] = __int_as_float(act); cr[C_IDS + 1] = __int_as_float(body); cr[C_IDS + 2] = __int_as_float(-1); cr[C_IDS + 3] = __int_as_float(0);
+        cr[C_P] = c.x; cr[C_P + 1] = c.y; cr[C_P + 2] = c.z - rad;
+        cr[C_N] = 0; cr[C_N + 1] = 0; cr[C_N + 2] = 1; cr[C_SD] = gsd;
+        cr[C_REP] = __int_as_float(rep); cr[C_REP + 1] = __int_as_float(-1);
+      }
+    }
+    if (wflag) {
+      const int slot = nc + pre + (gflag ? 1 : 0);
+      if (slot < maxc) {
+        float* cr = lds + L.con + slot * CON_STRIDE;
+        cr[C_IDS] = __int_as_float(act); cr[C_IDS + 1] = __int_as_float(body); cr[C_IDS + 2] = __int_as_float(-1); cr[C_IDS + 3] = __int_as_float(0);
+        cr[C_P] = c.x - rad * wn.x; cr[C_P + 1] = c.y - rad * wn.y; cr[C_P + 2] = c.z - rad * wn.z;
+        cr[C_N] = wn.x; cr[C_N + 1] = wn.y; cr[C_N + 2] = wn.z; cr[C_SD] = wsd;
+        cr[C_REP] = __int_as_float(rep); cr[C_REP + 1] = __int_as_float(-1);
+      }
+    }
+    nc += __popcll(bg) + __popcll(bw2);
+    if (nc > maxc) nc = maxc;
+  }
+  // ---- sphere-sphere contacts between different actors (a < b; outer loop over b's spheres, lanes = a's spheres) -------
+  {
+    const int nact = A + PD;
+    for (int a = 0; a < nact; a++)
+      for (int b = a + 1; b < nact; b++) {
+        const V3 pa = ld3(lds + L.body + (a < A ? a * MQE_NBODY : A * MQE_NBODY + (a - A)) * BODY_STRIDE + B_P);
+        const V3 pb = ld3(lds + L.body + (b < A ? b * MQE_NBODY : A * MQE_NBODY + (b - A)) * BODY_STRIDE + B_P);
+        const V3 dd = pa - pb;
+        if (dot(dd, dd) > 1.2f * 1.2f) continue;              // wave-uniform broad phase
+        const int na = a < A ? nsr : m->npc_n_spheres, nb = b < A ? nsr : m->npc_n_spheres;
+        const int oa = a < A ? a * nsr : A * nsr + (a - A) * m->npc_n_spheres;
+        const int ob = b < A ? b * nsr : A * nsr + (b - A) * m->npc_n_spheres;
+        for (int sb = 0; sb < nb; sb++) {
+          const float* spb = lds + L.sph + (ob + sb) * 4;
+          const V3 cb = ld3(spb); const float rb = spb[3];
+          bool hit = false; float sd = 0, dist = 1; V3 ev = v3(0, 0, 0); float ra = 0;
+          if (lane < na) {
+            const float* spa = lds + L.sph + (oa + lane) * 4;
+            ev = ld3(spa) - cb; ra = spa[3];
+            dist = sqrtf(dot(ev, ev));
+            sd = dist - ra - rb;
+            hit = sd < m->contact_offset && dist > 1e-9f;
+          }
+          const unsigned long long bh = __ballot(hit);
+          if (bh == 0ull) continue;
+          const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+          const int slot = nc + __popcll(bh & lower);
+          if (hit && slot < maxc) {
+            float* cr = lds + L.con + slot * CON_STRIDE;
+            const int bodyA = a < A ? rm.sphere_body[lane] : 0, bodyB = b < A ? rm.sphere_body[sb] : 0;
+            const int repA = a < A ? a * MQE_NREP + rm.sphere_reported[lane] : A * MQE_NREP + (a - A);
+            const int repB = b < A ? b * MQE_NREP + rm.sphere_reported[sb] : A * MQE_NREP + (b - A);
+            cr[C_IDS] = __int_as_float(a); cr[C_IDS + 1] = __int_as_float(bodyA); cr[C_IDS + 2] = __int_as_float(b); cr[C_IDS + 3] = __int_as_float(bodyB);
+            const V3 n = (1.0f / dist) * ev;
+            const V3 p = cb + (rb + 0.5f * sd) * n;
+            cr[C_P] = p.x; cr[C_P + 1] = p.y; cr[C_P + 2] = p.z; cr[C_N] = n.x; cr[C_N + 1] = n.y; cr[C_N + 2] = n.z; cr[C_SD] = sd;
+            cr[C_REP] = __int_as_float(repA); cr[C_REP + 1] = __int_as_float(repB);
+          }
+          nc += __popcll(bh);
+          if (nc > maxc) nc = maxc;
+        }
+      }
+  }
+  __syncthreads();
+
+  // ---- per contact: tangents, B = M^-1 J^T rows, K = J B, bias ---------------------------------------------------------------
+  float* Wx = lds + L.W;
+  for (int c = 0; c < nc; c++) {
+    float* cr = lds + L.con + c * CON_STRIDE;
+    const int actA = __float_as_int(cr[C_IDS]), bodyA = __float_as_int(cr[C_IDS + 1]);
+    const int actB = __float_as_int(cr[C_IDS + 2]), bodyB = __float_as_int(cr[C_IDS + 3]);
+    const V3 p = ld3(cr + C_P), n = ld3(cr + C_N);
+    V3 aa = fabsf(n.z) > 0.7f ? v3(1, 0, 0) : v3(0, 0, 1);
+    V3 t1 = cross(aa, n);
+    t1 = (1.0f / sqrtf(dot(t1, t1))) * t1;
+    const V3 t2 = cross(n, t1);
+    float sgn = 0.0f;
+    if (is_dof) {
+      if (dact == actA && ((dmask >> bodyA) & 1u)) sgn = 1.0f;
+      else if (dact == actB && ((dmask >> bodyB) & 1u)) sgn = -1.0f;
+    }
+    const V3 wv = sgn * (dlin ? dax : cross(dax, p - danc));
+    Wx[lane * 4] = wv.x; Wx[lane * 4 + 1] = wv.y; Wx[lane * 4 + 2] = wv.z;
+    __syncthreads();
+    V3 bwv = v3(0, 0, 0);
+    if (is_rdof) {
+      const float* Mc = lds + L.minv + dact * MQE_RD * MQE_RD + dk;
+      const float* Wr = Wx + dact * MQE_RD * 4;
+      for (int ee = 0; ee < MQE_RD; ee++) {
+        const float mv = Mc[ee * MQE_RD];
+        bwv.x += mv * Wr[ee * 4]; bwv.y += mv * Wr[ee * 4 + 1]; bwv.z += mv * Wr[ee * 4 + 2];
+      }
+    } else if (is_dof) {
+      bwv = dinvm * wv;
+    }
+    const float j0 = dot(n, wv), j1 = dot(t1, wv), j2 = dot(t2, wv);
+    const float b0 = dot(n, bwv), b1 = dot(t1, bwv), b2 = dot(t2, bwv);
+    if (is_dof) {
+      float* Bc = lds + L.B + c * 3 * bs;
+      Bc[lane] = b0; Bc[bs + lane] = b1; Bc[2 * bs + lane] = b2;
+    }
+    const float k00 = wave_sum(j0 * b0), k11 = wave_sum(j1 * b1), k22 = wave_sum(j2 * b2);
+    const float k10 = wave_sum(j1 * b0), k20 = wave_sum(j2 * b0), k21 = wave_sum(j2 * b1);
+    if (lane == 0) {
+      st3(cr + C_T1, t1); st3(cr + C_T2, t2);
+      const float sd = cr[C_SD];
+      cr[C_BIAS] = sd >= 0 ? -sd / dt : fminf(-sd * m->erp / dt, m->max_depen);
+      cr[C_K] = k00; cr[C_K + 1] = k11; cr[C_K + 2] = k22; cr[C_K + 3] = k10; cr[C_K + 4] = k20; cr[C_K + 5] = k21;
+      cr[C_LAM] = 0; cr[C_LAM + 1] = 0; cr[C_LAM + 2] = 0;
+    }
+    __syncthreads();
+  }
+
+  // ---- projected Gauss-Seidel in velocity space -----------------------------------------------------------------------------
+  const float mu = m->friction;
+  float jlo = 0, jhi = 0;
+  const bool is_joint = is_rdof && dk >= 6;
+  if (is_joint) {
+    const float q = lds[L.dof + (dact * 12 + dk - 6) * 2];
+    jlo = (rm.dof_lower[dk - 6] - q) / dt; jhi = (rm.dof_upper[dk - 6] - q) / dt;
+  }
+  for (int it = 0; it < m->solver_iterations; it++) {
+    for (int c = 0; c < nc; c++) {
+      float* cr = lds + L.con + c * CON_STRIDE;
+      const int actA = __float_as_int(cr[C_IDS]), bodyA = __float_as_int(cr[C_IDS + 1]);
+      const int actB = __float_as_int(cr[C_IDS + 2]), bodyB = __float_as_int(cr[C_IDS + 3]);
+      const V3 p = ld3(cr + C_P), n = ld3(cr + C_N), t1 = ld3(cr + C_T1), t2 = ld3(cr + C_T2);
+      float sgn = 0.0f;
+      if (is_dof) {
+        if (dact == actA && ((dmask >> bodyA) & 1u)) sgn = 1.0f;
+        else if (dact == actB && ((dmask >> bodyB) & 1u)) sgn = -1.0f;
+      }
+      const V3 wv = (sgn * vd) * (dlin ? dax : cross(dax, p - danc));
+      const V3 uw = v3(wave_sum(wv.x), wave_sum(wv.y), wave_sum(wv.z));
+      float u0 = dot(n, uw), u1 = dot(t1, uw), u2 = dot(t2, uw);
+      const float l0o = cr[C_LAM], l1o = cr[C_LAM + 1], l2o = cr[C_LAM + 2];
+      float ln = l0o - (u0 - cr[C_BIAS]) / cr[C_K];
+      ln = fmaxf(ln, 0.0f);
+      const float d0 = ln - l0o;
+      u1 += cr[C_K + 3] * d0; u2 += cr[C_K + 4] * d0;
+      const float lim = mu * ln;
+      float l1 = clampf(l1o - u1 / cr[C_K + 1], -lim, lim);
+      const float d1 = l1 - l1o;
+      u2 += cr[C_K + 5] * d1;
+      float l2 = clampf(l2o - u2 / cr[C_K + 2], -lim, lim);
+      const float d2 = l2 - l2o;
+      __syncthreads();
+      if (lane == 0) { cr[C_LAM] = ln; cr[C_LAM + 1] = l1; cr[C_LAM + 2] = l2; }
+      if (is_dof) {
+        const float* Bc = lds + L.B + c * 3 * bs;
+        vd += Bc[lane] * d0 + Bc[bs + lane] * d1 + Bc[2 * bs + lane] * d2;
+      }
+      __syncthreads();
+    }
+    // joint limits: sequential over joints in (robot, joint) order, only when some lane violates
+    bool viol = is_joint && (vd < jlo || vd > jhi);
+    if (__ballot(viol) != 0ull) {
+      for (int r = 0; r < A; r++)
+        for (int j = 0; j < 12; j++) {
+          const int src = r * MQE_RD + 6 + j;
+          const float vj = __shfl(vd, src, 64), lo = __shfl(jlo, src, 64), hi = __shfl(jhi, src, 64);
+          float vio = 0.0f;
+          if (vj < lo) vio = lo - vj; else if (vj > hi) vio = hi - vj;
+          if (vio != 0.0f) {
+            const float mjj = lds[L.minv + r * MQE_RD * MQE_RD + (6 + j) * MQE_RD + 6 + j];
+            const float lam = vio / mjj;
+            if (is_rdof && dact == r) vd += lds[L.minv + r * MQE_RD * MQE_RD + (6 + j) * MQE_RD + dk] * lam;
+          }
+        }
+    }
+  }
+
+  if (dbg.minv != nullptr) {
+    for (int i = lane; i < MQE_RD * MQE_RD; i += 64) dbg.minv[i] = lds[L.minv + dbg.robot * MQE_RD * MQE_RD + i];
+    if (lane == 0) *dbg.nc = nc;
+    for (int c = lane; c < nc; c += 64) {
+      const float* cr = lds + L.con + c * CON_STRIDE;
+      float* o8 = dbg.contacts + c * 8;
+      o8[0] = (float)__float_as_int(cr[C_IDS]); o8[1] = (float)__float_as_int(cr[C_IDS + 1]);
+      o8[2] = (float)__float_as_int(cr[C_IDS + 2]); o8[3] = (float)__float_as_int(cr[C_IDS + 3]);
+      o8[4] = cr[C_SD]; o8[5] = cr[C_N]; o8[6] = cr[C_N + 1]; o8[7] = cr[C_N + 2];
+    }
+  }
+  if (no_write) return;
+
+  // ---- net contact force per reported body (deterministic: contact order) ---------------------------------------------------
+  {
+    const float idt = 1.0f / dt;
+    float* g_cf = st.cf + (size_t)e * m->NBR * 3;
+    for (int rb = lane; rb < m->NBR; rb += 64) {
+      V3 F = v3(0, 0, 0);
+      for (int c = 0; c < nc; c++) {
+        const float* cr = lds + L.con + c * CON_STRIDE;
+        const int ra = __float_as_int(cr[C_REP]), rb2 = __float_as_int(cr[C_REP + 1]);
+        if (ra == rb || rb2 == rb) {
+          const V3 f = idt * (cr[C_LAM] * ld3(cr + C_N) + cr[C_LAM + 1] * ld3(cr + C_T1) + cr[C_LAM + 2] * ld3(cr + C_T2));
+          F = (ra == rb) ? F + f : F - f;
+        }
+      }
+      g_cf[rb * 3] = F.x; g_cf[rb * 3 + 1] = F.y; g_cf[rb * 3 + 2] = F.z;
+    }
+  }
+  // ---- integrate: semi-implicit Euler; quaternion first-order update + renormalisation -----------------------------------------
+  __syncthreads();
+  lds[L.rhs + lane] = vd;
+  __syncthreads();
+  if (is_rdof && dk >= 6) {
+    const int j = dk - 6;
+    const float q = lds[L.dof + (dact * 12 + j) * 2];
+    g_dof[(dact * 12 + j) * 2] = q + dt * vd;
+    g_dof[(dact * 12 + j) * 2 + 1] = vd;
+  }
+  if (lane < A + PD) {
+    const int act = lane;
+    const float* rs = lds + L.root + act * 13;
+    const float* v = lds + L.rhs + (act < A ? act * MQE_RD : A * MQE_RD + (act - A) * npcdof);
+    float* gr = g_root + act * 13;
+    for (int k = 0; k < 3; k++) { gr[k] = rs[k] + dt * v[k]; gr[7 + k] = v[k]; }
+    const bool has_ang = act < A || npcdof == 6;
+    const float wx = has_ang ? v[3] : rs[10], wy = has_ang ? v[4] : rs[11], wz = has_ang ? v[5] : rs[12];
+    if (has_ang) { gr[10] = wx; gr[11] = wy; gr[12] = wz; }
+    if (has_ang) {
+      float q0 = rs[3], q1 = rs[4], q2 = rs[5], q3 = rs[6];
+      const float d0 = 0.5f * (wx * q3 + wy * q2 - wz * q1);
+      const float d1 = 0.5f * (-wx * q2 + wy * q3 + wz * q0);
+      const float d2 = 0.5f * (wx * q1 - wy * q0 + wz * q3);
+      const float d3 = 0.5f * (-wx * q0 - wy * q1 - wz * q2);
+      q0 += dt * d0; q1 += dt * d1; q2 += dt * d2; q3 += dt * d3;
+      const float nq = sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
+      gr[3] = q0 / nq; gr[4] = q1 / nq; gr[5] = q2 / nq; gr[6] = q3 / nq;
+    }
+  }
+}

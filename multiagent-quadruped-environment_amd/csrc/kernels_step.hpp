@@ -1,0 +1,552 @@
+// kernels_step.hpp -- the streaming kernels around the physics: command/history write (row B), post-policy
+// bookkeeping, actuator-net torques (rows E/F/G), post-physics step (rows J,K,L,S,M,N) and the task wrappers (W1-W4).
+// Each kernel cites the reference lines it replaces; arithmetic order follows the reference / the CPU oracle so that
+// integer and flag results are identical and float results agree to the last bits where libm allows.
+#pragma once
+#include "mqe_common.hpp"
+
+// ----------------------------------------------------------------------------------------------------------------
+// small float helpers with the exact operation order of isaacgym.torch_utils (see oracle/mqe_oracle.c)
+__device__ __forceinline__ void quat_rotate_inverse_f(const float* q, const float* v, float* o) {
+  float qw = q[3];
+  float s = 2.0f * qw * qw - 1.0f;
+  float cx = q[1] * v[2] - q[2] * v[1], cy = q[2] * v[0] - q[0] * v[2], cz = q[0] * v[1] - q[1] * v[0];
+  float dt = q[0] * v[0] + q[1] * v[1] + q[2] * v[2];
+  o[0] = v[0] * s - cx * qw * 2.0f + q[0] * dt * 2.0f;
+  o[1] = v[1] * s - cy * qw * 2.0f + q[1] * dt * 2.0f;
+  o[2] = v[2] * s - cz * qw * 2.0f + q[2] * dt * 2.0f;
+}
+__device__ __forceinline__ float wrap2pi(float a) {
+  const float T = 6.2831855f;
+  float r = fmodf(a, T);
+  if (r < 0) r += T;
+  return r;
+}
+__device__ __forceinline__ void euler_xyz_f(const float* q, float* rpy) {
+  float x = q[0], y = q[1], z = q[2], w = q[3];
+  float sinr = 2.0f * (w * x + y * z), cosr = w * w - x * x - y * y + z * z;
+  float sinp = 2.0f * (w * y - z * x);
+  float siny = 2.0f * (w * z + x * y), cosy = w * w + x * x - y * y - z * z;
+  float roll = atan2f(sinr, cosr);
+  float pitch = fabsf(sinp) >= 1.0f ? copysignf(1.5707964f, sinp) : asinf(sinp);
+  float yaw = atan2f(siny, cosy);
+  rpy[0] = wrap2pi(roll); rpy[1] = wrap2pi(pitch); rpy[2] = wrap2pi(yaw);
+}
+
+__device__ __forceinline__ uint32_t mqe_hash(uint32_t seed, uint32_t genv, uint32_t count, uint32_t k) {
+  uint32_t x = seed * 0x9E3779B1u ^ genv * 0x85EBCA77u ^ count * 0xC2B2AE3Du ^ k * 0x27D4EB2Fu;
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ float mqe_rand(const DevModel* m, int env, int count, uint32_t k, float lo, float hi) {
+  float u = (float)(mqe_hash((uint32_t)m->seed, (uint32_t)(env + m->env_id_offset), (uint32_t)count, k) >> 8) * (1.0f / 16777216.0f);
+  return (hi - lo) * u + lo;
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// wrapper.step head: clip(action,-1,1) * action_scale (go1_sheep_wrapper.py:55-56) -> per-robot command; the scripted
+// defender command of go1football-defender (go1_football_defender.py:56-80) fills agent 2.  One thread per env.
+__device__ __forceinline__ void defender_command_dev(const DevModel* m, const DevState& st, int e, float* cmd3) {
+  int A = m->A, P = m->P;
+  const float* root = st.root + (size_t)e * (A + P) * 13;
+  const float* dp = root + 2 * 13;
+  const float* bp = root + A * 13;
+  float gate[3] = {m->gate_pos[e * 2], m->gate_pos[e * 2 + 1], m->env_origins[e * 3 + 2]};
+  float tp[3];
+  for (int k = 0; k < 3; k++) tp[k] = 0.6f * bp[k] + 0.4f * gate[k];
+  float yaw = st.obs_bag[(size_t)(e * A + 2) * MQE_OBS_BAG + 5];
+  float yaw_to_gate = 3.1415927f + atanf((gate[1] - dp[1]) / (gate[0] - dp[0]));
+  float yc = clampf(yaw_to_gate - yaw, -0.3f, 0.3f) / 0.3f;
+  float tdg = sqrtf((tp[0] - gate[0]) * (tp[0] - gate[0]) + (tp[1] - gate[1]) * (tp[1] - gate[1]));
+  float ddg = sqrtf((dp[0] - gate[0]) * (dp[0] - gate[0]) + (dp[1] - gate[1]) * (dp[1] - gate[1]));
+  float xc = clampf(tdg - ddg, -0.5f, 0.5f);
+  float yy = -clampf(gate[1] + (tp[1] - gate[1]) * (dp[0] - gate[0]) / (tp[0] - gate[0]) - dp[1], -0.5f, 0.5f);
+  cmd3[0] = xc; cmd3[1] = yy; cmd3[2] = yc;
+}
+
+__global__ void k_defender_command(const DevModel* m, DevState st, float* out) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= m->N) return;
+  float c[3];
+  defender_command_dev(m, st, e, c);
+  out[e * 3] = c[0]; out[e * 3 + 1] = c[1]; out[e * 3 + 2] = c[2];
+}
+
+__global__ void k_wrapper_command(const DevModel* m, DevState st, const float* __restrict__ actions) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= m->N) return;
+  int A = m->A, Aw = m->Aw;
+  const float scale[3] = {2.0f, 0.5f, 0.5f};
+  for (int a = 0; a < Aw; a++)
+    for (int k = 0; k < 3; k++) {
+      float v = clampf(actions[((size_t)e * Aw + a) * 3 + k], -1.0f, 1.0f);
+      st.cmd[((size_t)e * A + a) * 3 + k] = m->task == MQE_TASK_PLAIN ? v : v * scale[k];
+    }
+  if (m->task == MQE_TASK_FOOTBALL_DEFENDER) defender_command_dev(m, st, e, st.cmd + ((size_t)e * A + 2) * 3);
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Go1.preprocess_action up to the history update (go1.py:64-102).  One thread per (robot, frame element): the 70-float
+// frame is assembled and written once to the robot's ring slot (280 B) instead of re-concatenating 2100 floats.
+__global__ void k_pre_policy(const DevModel* m, DevState st, const float* __restrict__ command, int hist_slot) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  int i = idx / MQE_FRAME, c = idx - i * MQE_FRAME;
+  if (i >= m->R) return;
+  float* lo = st.loco_obs + (size_t)i * MQE_FRAME;
+  const float* ob = st.obs_bag + (size_t)i * MQE_OBS_BAG;
+  float v;
+  if (c < 3) v = ob[60 + c];                                   // projected gravity      :95
+  else if (c < 6) {                                            // velocity command       :67-68 (+ clip :38)
+    float x = command[i * 3 + (c - 3)];
+    if (m->clip_command) x = clampf(x, -1.0f, 1.0f);
+    v = x * (c < 5 ? m->cmd_lin_scale : m->cmd_ang_scale);
+  } else if (c < 18) v = lo[c];                                // fixed gait parameters (set at construction)
+  else if (c < 30) v = ob[6 + (c - 18)];                       // dof_pos                :96
+  else if (c < 42) v = ob[18 + (c - 30)];                      // dof_vel                :97
+  else if (c < 54) v = st.last_loco[i * 12 + (c - 42)];        //                        :98
+  else if (c < 66) v = st.last_two_loco[i * 12 + (c - 54)];    //                        :99
+  else if (c < 70) v = ob[63 + (c - 66)];                      // clock inputs           :100
+  else v = 0.0f;
+  lo[c] = v;
+  st.hist[((size_t)i * MQE_HIST + hist_slot) * MQE_FRAME + c] = v;   // :102
+}
+
+// go1.py:106-107 + :40-41: shift the last-action registers and clip the new joint targets.  act: [R, ld]
+__global__ void k_post_policy(const DevModel* m, DevState st, const float* __restrict__ act, int ld) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= m->R * 12) return;
+  int i = idx / 12, k = idx - i * 12;
+  float a = act[(size_t)i * ld + k];
+  st.last_two_loco[idx] = st.last_loco[idx];
+  st.last_loco[idx] = a;
+  st.actions[idx] = clampf(a, -m->clip_actions, m->clip_actions);
+}
+
+// body layer 0 finish: v = (hist . W + b) + lat0*w0 + lat1*w1 ; ELU   (go1.py:404: body(cat(history, latent)))
+__global__ void k_body_l0_finish(float* __restrict__ P1, int ldp, int col0, int ncols, const float* __restrict__ lat, int ldl,
+                                 const float* __restrict__ w_lat0, const float* __restrict__ w_lat1, int R) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= R * ncols) return;
+  int i = idx / ncols, c = idx - i * ncols;
+  float v = P1[(size_t)i * ldp + col0 + c];
+  v = fmaf(lat[(size_t)i * ldl], w_lat0[c], v);
+  v = fmaf(lat[(size_t)i * ldl + 1], w_lat1[c], v);
+  P1[(size_t)i * ldp + col0 + c] = v > 0 ? v : expm1f(v);
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Go1._compute_torques (go1.py:315-354) incl. the actuator network (go1.py:367-382): one thread per joint; the 1313
+// weights are wave-uniform, so they arrive through the scalar cache and every FMA is v_fmac(vgpr, sgpr).
+__device__ __forceinline__ float softsign_f(float x) { return x / (1.0f + fabsf(x)); }
+
+__global__ void __launch_bounds__(256) k_compute_torques(const DevModel* m, DevState st, int dec_i) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  int R = m->R, A = m->A;
+  if (idx >= R * 12) return;
+  int i = idx / 12, j = idx - i * 12;
+  int env = i / A, a = i - env * A;
+  const float* ds = st.dof + ((size_t)env * m->ND + a * 12 + j) * 2;
+  float q = ds[0], qd = ds[1];
+  float as = st.actions[idx] * m->action_scale;
+  float tau;
+  if (m->control_type == MQE_CTRL_C) {
+    if (j % 3 == 0) as *= m->hip_scale_reduction;
+    float target = as + m->default_dof_pos[j];
+    float err = q - target;
+    float* e1 = st.act_hist; float* e2 = e1 + (size_t)R * 12; float* v1 = e2 + (size_t)R * 12; float* v2 = v1 + (size_t)R * 12;
+    float x[6] = {err, e1[idx], e2[idx], qd, v1[idx], v2[idx]};
+    const float* W0 = m->actuator.W[0]; const float* b0 = m->actuator.b[0];
+    const float* W1 = m->actuator.W[1]; const float* b1 = m->actuator.b[1];
+    const float* W2 = m->actuator.W[2]; const float* b2 = m->actuator.b[2];
+    float h1[32], h2[32];
+#pragma unroll
+    for (int o = 0; o < 32; o++) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 6; k++) acc = fmaf(W0[o * 6 + k], x[k], acc);
+      h1[o] = softsign_f(acc + b0[o]);
+    }
+#pragma unroll
+    for (int o = 0; o < 32; o++) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 32; k++) acc = fmaf(W1[o * 32 + k], h1[k], acc);
+      h2[o] = softsign_f(acc + b1[o]);
+    }
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 32; k++) acc = fmaf(W2[k], h2[k], acc);
+    tau = acc + b2[0];
+    e2[idx] = e1[idx]; e1[idx] = err;
+    v2[idx] = v1[idx]; v1[idx] = qd;
+  } else if (m->control_type == MQE_CTRL_P) {
+    tau = m->kp * (as + m->default_dof_pos[j] - q) - m->kd * qd;       // legged_robot.py:385
+  } else if (m->control_type == MQE_CTRL_T) {
+    tau = as;
+  } else {
+    tau = 0.0f;
+  }
+  float lim = m->torque_limits[j];
+  tau = clampf(tau, -lim, lim);
+  st.torques[idx] = tau;
+  if (dec_i >= 0) st.sub_tau[((size_t)env * 4 + dec_i) * 12 * A + a * 12 + j] = tau;   // post_decimation_step :113
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// post_physics_step (legged_robot.py:117-157, legged_robot_field.py:117-146, go1.py:153-279,110-145, go1_sheep.py:35-64)
+// One thread per env (a few hundred flops each; ~10 kB/env of traffic only when the env resets).
+__device__ __forceinline__ void compute_observations_env(const DevModel* m, const DevState& st, int e, int in_step) {
+  int A = m->A;
+  for (int a = 0; a < A; a++) {
+    int i = e * A + a;
+    float* ob = st.obs_bag + (size_t)i * MQE_OBS_BAG;
+    const float* rs = st.root + ((size_t)e * (A + m->P) + a) * 13;
+    for (int k = 0; k < 3; k++) ob[k] = rs[k] - m->env_origins[e * 3 + k];
+    euler_xyz_f(st.bquat + i * 4, ob + 3);
+    for (int j = 0; j < 12; j++) {
+      const float* ds = st.dof + ((size_t)e * m->ND + a * 12 + j) * 2;
+      ob[6 + j] = (ds[0] - m->default_dof_pos[j]) * 1.0f;
+      ob[18 + j] = ds[1] * 0.05f;
+      float act = st.actions[i * 12 + j];
+      ob[36 + j] = act;
+      ob[48 + j] = in_step ? act : st.last_actions[i * 12 + j];    // view aliasing, see oracle
+    }
+    for (int k = 0; k < 3; k++) {
+      ob[30 + k] = st.blv[i * 3 + k] * 2.0f;
+      ob[33 + k] = st.bav[i * 3 + k] * 0.25f;
+      ob[60 + k] = st.pg[i * 3 + k];
+    }
+    for (int k = 0; k < 4; k++) { ob[63 + k] = st.clock[i * 4 + k]; ob[67 + k] = st.bquat[i * 4 + k]; }
+  }
+}
+
+__device__ __forceinline__ void reset_env_dev(const DevModel* m, const DevState& st, int e) {
+  int A = m->A, P = m->P;
+  float* root = st.root + (size_t)e * (A + P) * 13;
+  float* dofs = st.dof + (size_t)e * m->ND * 2;
+  int cnt = st.reset_count[e];
+  for (int a = 0; a < A; a++)
+    for (int j = 0; j < 12; j++) {
+      float ratio = mqe_rand(m, e, cnt, (uint32_t)(a * 12 + j), m->dof_ratio_lo, m->dof_ratio_hi);
+      dofs[(a * 12 + j) * 2] = m->default_dof_pos[j] * ratio;
+      dofs[(a * 12 + j) * 2 + 1] = 0.0f;
+    }
+  for (int k = 12 * A; k < m->ND; k++) { dofs[k * 2] = m->seesaw_default_angle; dofs[k * 2 + 1] *= 0.0f; }
+  for (int a = 0; a < A; a++) {
+    float* rs = root + a * 13;
+    for (int k = 0; k < 13; k++) rs[k] = m->base_init[a * 13 + k];
+    for (int k = 0; k < 3; k++) rs[k] += m->agent_origins[((size_t)e * A + a) * 3 + k];
+  }
+  for (int p = 0; p < P; p++) {
+    float* rs = root + (A + p) * 13;
+    for (int k = 0; k < 13; k++) rs[k] = m->npc_init[p * 13 + k];
+    for (int k = 0; k < 3; k++) rs[k] += m->env_origins[e * 3 + k];
+  }
+  if (m->has_base_pos_range)
+    for (int a = 0; a < A; a++) {
+      root[a * 13 + 0] += mqe_rand(m, e, cnt, (uint32_t)(64 + a), m->base_pos_x_lo, m->base_pos_x_hi);
+      root[a * 13 + 1] += mqe_rand(m, e, cnt, (uint32_t)(72 + a), m->base_pos_y_lo, m->base_pos_y_hi);
+    }
+  if (m->has_npc_pos_range)
+    for (int p = 0; p < P; p++) {
+      root[(A + p) * 13 + 0] += mqe_rand(m, e, cnt, (uint32_t)(128 + p), m->npc_pos_x_lo, m->npc_pos_x_hi);
+      root[(A + p) * 13 + 1] += mqe_rand(m, e, cnt, (uint32_t)(160 + p), m->npc_pos_y_lo, m->npc_pos_y_hi);
+    }
+  for (int a = 0; a < A; a++)
+    for (int c = 0; c < 6; c++) root[a * 13 + 7 + c] = mqe_rand(m, e, cnt, (uint32_t)(80 + a * 6 + c), m->base_vel_lo, m->base_vel_hi);
+  for (int k = 0; k < 12 * A; k++) st.last_actions[(size_t)e * 12 * A + k] = 0.0f;
+  st.ep_len[e] = 0;
+  st.reset_buf[e] = 1;
+  for (int a = 0; a < A; a++) st.gait[e * A + a] = 0.0f;
+  // history zeroing (go1.py:145) is done by k_reset_history, 16 B per thread
+  st.reset_count[e] = cnt + 1;
+}
+
+__device__ __forceinline__ void step_sheep_env(const DevModel* m, const DevState& st, int e) {
+  int A = m->A, P = m->P;
+  float* root = st.root + (size_t)e * (A + P) * 13;
+  float avg[3] = {0, 0, 0};
+  for (int p = 0; p < P; p++) for (int k = 0; k < 3; k++) avg[k] += root[(A + p) * 13 + k];
+  for (int k = 0; k < 3; k++) avg[k] /= (float)P;
+  st.sheep_avg[e * 2] = avg[0]; st.sheep_avg[e * 2 + 1] = avg[1];
+  float var = 0;
+  for (int k = 0; k < 2; k++) {
+    float acc = 0;
+    for (int p = 0; p < P; p++) { float t = root[(A + p) * 13 + k] - avg[k]; acc += t * t; }
+    var += acc / (float)P;
+  }
+  st.sheep_var[e] = var;
+  float dvs[MQE_MAX_NPCS][3];
+  for (int p = 0; p < P; p++) {
+    const float* sp = root + (A + p) * 13;
+    float dv[3];
+    for (int k = 0; k < 3; k++) dv[k] = m->sheep_rand * st.npc_noise[((size_t)e * P + p) * 3 + k] * 2.0f;
+    if (P != 1) {
+      float rel[3] = {avg[0] - sp[0], avg[1] - sp[1], avg[2] - sp[2]};
+      float nr = sqrtf(rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2]);
+      for (int k = 0; k < 3; k++) dv[k] += m->sheep_rand * rel[k] / nr / 1.5f;
+    }
+    for (int a = 0; a < A; a++) {
+      const float* dp = root + a * 13;
+      float rel[3] = {sp[0] - dp[0], sp[1] - dp[1], sp[2] - dp[2]};
+      float sq[3] = {rel[0] * rel[0], rel[1] * rel[1], rel[2] * rel[2]};
+      float dis = sqrtf(sq[0] * sq[0] + sq[1] * sq[1] + sq[2] * sq[2]);
+      float den = powf(dis, 1.4f);
+      for (int k = 0; k < 3; k++) { float t = rel[k] / den; if (dis > 9.0f) t = 0.0f; dv[k] += m->sheep_scale * t; }
+    }
+    dv[2] = 0.0f;
+    for (int k = 0; k < 3; k++) dvs[p][k] = dv[k];
+  }
+  for (int p = 0; p < P; p++) {
+    float* sp = root + (A + p) * 13;
+    for (int k = 0; k < 3; k++) sp[7 + k] += dvs[p][k];
+    for (int k = 0; k < 2; k++) sp[7 + k] = clampf(sp[7 + k], -2.0f, 2.0f);
+    sp[2] = clampf(sp[2], 0.0f, 0.3f);
+    sp[3] = 0.0f; sp[4] = 0.0f;
+  }
+}
+
+// wrapper observation + reward for env e.  npc = the `root_states_npc` rows the wrapper sees ([P][13]); see oracle.
+__device__ void wrapper_env_dev(const DevModel* m, const DevState& st, int e, int is_reset_call, const float* npc) {
+  int A = m->A, P = m->P, Aw = m->Aw, D = m->D;
+  float* obs = st.wobs + (size_t)e * Aw * D;
+  float* rew = st.wrew + (size_t)e * Aw;
+  float* rs = st.rsum + (size_t)e * MQE_MAX_REWARD_TERMS;
+  const float* sc = m->reward_scale;
+  for (int a = 0; a < Aw; a++) {
+    float* o = obs + a * D;
+    int c = 0;
+    for (int k = 0; k < Aw; k++) o[c++] = (k == a) ? 1.0f : 0.0f;
+    const float* ob = st.obs_bag + (size_t)(e * A + a) * MQE_OBS_BAG;
+    for (int k = 0; k < 6; k++) o[c++] = ob[k];
+    if (m->task != MQE_TASK_PLAIN) {
+      const float* ob2 = st.obs_bag + (size_t)(e * A + (Aw - 1 - a)) * MQE_OBS_BAG;
+      for (int k = 0; k < 6; k++) o[c++] = ob2[k];
+    }
+    if (m->task == MQE_TASK_GATE || m->task == MQE_TASK_SHEEP) { o[c++] = m->gate_pos[e * 2]; o[c++] = m->gate_pos[e * 2 + 1]; }
+    if (m->task == MQE_TASK_SHEEP)
+      for (int p = 0; p < P; p++) { o[c++] = npc[p * 13] - m->env_origins[e * 3]; o[c++] = npc[p * 13 + 1] - m->env_origins[e * 3 + 1]; }
+    if (m->task == MQE_TASK_FOOTBALL_DEFENDER) {
+      for (int k = 0; k < 3; k++) o[c++] = npc[k] - m->env_origins[e * 3 + k];
+      for (int k = 0; k < 3; k++) o[c++] = npc[7 + k];
+    }
+  }
+  if (is_reset_call) { for (int a = 0; a < Aw; a++) rew[a] = 0; return; }
+  float r_env = 0.0f;
+  uint8_t was_reset = st.reset_buf[e];
+  if (m->task == MQE_TASK_GATE) {
+    float r_ag[MQE_MAX_AGENTS] = {0, 0, 0, 0};
+    float tsum = 0;
+    for (int a = 0; a < A; a++) {
+      const float* ob = st.obs_bag + (size_t)(e * A + a) * MQE_OBS_BAG;
+      float tx = m->wrapper_param[0], ty = (a == 0 ? 1.0f : -1.0f) * m->wrapper_param[1];
+      float dist = sqrtf((ob[0] - tx) * (ob[0] - tx) + (ob[1] - ty) * (ob[1] - ty));
+      if (!st.w_have_last[e]) st.w_last[e * MQE_MAX_AGENTS + a] = dist;
+      tsum += st.w_last[e * MQE_MAX_AGENTS + a] - dist;
+      st.w_last[e * MQE_MAX_AGENTS + a] = dist;
+    }
+    st.w_have_last[e] = 1;
+    if (was_reset) tsum = 0;
+    tsum *= sc[0];
+    for (int a = 0; a < A; a++) r_ag[a] += tsum;
+    rs[0] += tsum;
+    float col = sc[1] * (float)st.collide_buf[e];
+    for (int a = 0; a < A; a++) r_ag[a] += col;
+    rs[1] += col;
+    for (int a = 0; a < A; a++) {
+      const float* ob = st.obs_bag + (size_t)(e * A + a) * MQE_OBS_BAG;
+      if (ob[0] > m->gate_pos[e * 2] + 0.25f) { r_ag[a] += sc[2]; rs[2] += sc[2]; }
+      const float* ob2 = st.obs_bag + (size_t)(e * A + (A - 1 - a)) * MQE_OBS_BAG;
+      float d2 = (ob[0] - ob2[0]) * (ob[0] - ob2[0]) + (ob[1] - ob2[1]) * (ob[1] - ob2[1]);
+      if (d2 < 0.25f) { float pn = sc[3] / d2; r_ag[a] += pn; rs[3] += pn; }
+    }
+    float tot = 0;
+    for (int a = 0; a < A; a++) tot += r_ag[a];
+    for (int a = 0; a < A; a++) rew[a] = tot;
+    return;
+  }
+  if (m->task == MQE_TASK_SHEEP) {
+    float gate_x = m->gate_pos[e * 2];
+    if (sc[0] != 0) {
+      int cnt = 0;
+      for (int p = 0; p < P; p++) if ((npc[p * 13] - m->env_origins[e * 3]) - gate_x > 0) cnt++;
+      r_env = (float)cnt;
+      rs[0] += (float)cnt;
+    }
+    if (sc[1] != 0) { float c = sc[1] * (float)st.collide_buf[e]; r_env += c; rs[1] += c; }
+    if (sc[2] != 0) {
+      if (st.w_have_last[e]) {
+        float xm = st.sheep_avg[e * 2] - st.w_last2[e * 2];
+        if (st.w_delayed_reset[e]) xm = 0;
+        float v = sc[2] * xm;
+        r_env += v; rs[2] += v;
+      }
+      st.w_last2[e * 2] = st.sheep_avg[e * 2]; st.w_last2[e * 2 + 1] = st.sheep_avg[e * 2 + 1];
+      st.w_have_last[e] = 1;
+    }
+    if (sc[3] != 0) {
+      float acc = 0;
+      for (int p = 0; p < P; p++) {
+        float x = npc[p * 13] - m->env_origins[e * 3], y = npc[p * 13 + 1] - m->env_origins[e * 3 + 1];
+        float dg = sqrtf((x - gate_x) * (x - gate_x) + (y - m->gate_pos[e * 2 + 1]) * (y - m->gate_pos[e * 2 + 1]));
+        float v = expf(-dg / 2.0f) * sc[3];
+        if (x >= gate_x) v = sc[3];
+        acc += v;
+      }
+      r_env += acc; rs[3] += acc;
+    }
+    if (sc[4] != 0 || sc[5] != 0) {
+      float v = sc[5] * (st.sheep_var[e] - 1.0f) + sc[4] * expf(st.sheep_var[e] / 2.0f - 1.0f);
+      r_env += v; rs[4] += v;
+    }
+    st.w_delayed_reset[e] = was_reset;
+    for (int a = 0; a < Aw; a++) rew[a] = r_env;
+    return;
+  }
+  if (m->task == MQE_TASK_SEESAW) {
+    float xs = 0, zs = 0, y2 = 0;
+    for (int a = 0; a < A; a++) {
+      const float* ob = st.obs_bag + (size_t)(e * A + a) * MQE_OBS_BAG;
+      if (!st.w_have_last[e]) st.w_last[e * MQE_MAX_AGENTS + a] = ob[0];
+      xs += ob[0] - st.w_last[e * MQE_MAX_AGENTS + a];
+      st.w_last[e * MQE_MAX_AGENTS + a] = ob[0];
+      zs += ob[2]; y2 += ob[1] * ob[1];
+    }
+    st.w_have_last[e] = 1;
+    if (sc[0] != 0) { if (was_reset) xs = 0; xs *= sc[0]; r_env += xs; rs[0] += xs; }
+    if (sc[1] != 0) { float v = sc[1] * (zs - 0.56f); r_env += v; rs[1] += v; }
+    if (sc[2] != 0) { float v = sc[2] * (y2 - 0.5f); r_env += v; rs[2] += v; }
+    if (sc[3] != 0) { float v = sc[3] * (float)st.collide_buf[e]; r_env += v; rs[3] += v; }
+    if (sc[4] != 0) {
+      const float* o0 = st.obs_bag + (size_t)(e * A) * MQE_OBS_BAG; const float* o1 = st.obs_bag + (size_t)(e * A + A - 1) * MQE_OBS_BAG;
+      float d2 = (o0[0] - o1[0]) * (o0[0] - o1[0]) + (o0[1] - o1[1]) * (o0[1] - o1[1]);
+      if (d2 < 0.25f) { float v = sc[4] / d2; r_env += v; rs[4] += v; }
+    }
+    if (sc[5] != 0) {
+      int cnt = 0;
+      for (int a = 0; a < A; a++) { const float* ob = st.obs_bag + (size_t)(e * A + a) * MQE_OBS_BAG; if (ob[0] > 7.7f && ob[2] > 1.3f) cnt++; }
+      float v = sc[5] * (float)cnt; r_env += v; rs[5] += v;
+    }
+    if (sc[6] != 0) { if (st.r_term[e] | st.p_term[e]) { r_env += sc[6]; rs[6] += sc[6]; } }
+    for (int a = 0; a < Aw; a++) rew[a] = r_env;
+    return;
+  }
+  if (m->task == MQE_TASK_FOOTBALL_DEFENDER) {
+    float bx = npc[0] - m->env_origins[e * 3], by = npc[1] - m->env_origins[e * 3 + 1];
+    if (sc[0] != 0) { if (bx > m->gate_pos[e * 2]) { r_env += sc[0]; rs[0] += sc[0]; } }
+    if (sc[1] != 0) {
+      float dg = sqrtf((bx - m->gate_pos[e * 2]) * (bx - m->gate_pos[e * 2]) + (by - m->gate_pos[e * 2 + 1]) * (by - m->gate_pos[e * 2 + 1]));
+      float v = sc[1] * expf(-dg / 3.0f);
+      r_env += v; rs[1] += v;
+    }
+    for (int a = 0; a < Aw; a++) rew[a] = r_env;
+    return;
+  }
+  for (int a = 0; a < Aw; a++) rew[a] = 0;
+}
+
+__global__ void __launch_bounds__(64) k_post_physics(const DevModel* m, DevState st, int first_steps_done) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= m->N) return;
+  int A = m->A, P = m->P;
+  float dtp = m->dt * (float)m->decimation;
+  float* root = st.root + (size_t)e * (A + P) * 13;
+  int ep = st.ep_len[e] + 1;
+  st.ep_len[e] = ep;
+  for (int a = 0; a < A; a++) {
+    int i = e * A + a;
+    const float* rs = root + a * 13;
+    float q[4] = {rs[3], rs[4], rs[5], rs[6]}, v[3] = {rs[7], rs[8], rs[9]}, w[3] = {rs[10], rs[11], rs[12]};
+    float g3[3] = {0.0f, 0.0f, -1.0f}, o[3];
+    for (int k = 0; k < 4; k++) st.bquat[i * 4 + k] = q[k];
+    quat_rotate_inverse_f(q, v, o);  for (int k = 0; k < 3; k++) st.blv[i * 3 + k] = o[k];
+    quat_rotate_inverse_f(q, w, o);  for (int k = 0; k < 3; k++) st.bav[i * 3 + k] = o[k];
+    quat_rotate_inverse_f(q, g3, o); for (int k = 0; k < 3; k++) st.pg[i * 3 + k] = o[k];
+    const float* lo = st.loco_obs + (size_t)i * MQE_FRAME;
+    float f = lo[7], ph = lo[8], off = lo[9], bnd = lo[10], dur = lo[11];
+    float gi = st.gait[i] + dtp * f;
+    gi = gi - floorf(gi);
+    st.gait[i] = gi;
+    float fi[4] = {gi + ph + off + bnd, gi + off, gi + bnd, gi + ph};
+    for (int k = 0; k < 4; k++) {
+      float r = fi[k] - floorf(fi[k]);
+      if (r < dur) fi[k] = r * (0.5f / dur);
+      else if (r > dur) fi[k] = 0.5f + (r - dur) * (0.5f / (1.0f - dur));
+      st.clock[i * 4 + k] = sinf(6.2831855f * fi[k]);
+    }
+  }
+  uint8_t reset = 0, collide = 0, rterm = 0, pterm = 0, zh = 0;
+  if (m->terminate_on_base_contact) {
+    for (int a = 0; a < A; a++) {
+      const float* f3 = st.cf + ((size_t)e * m->NBR + a * MQE_NREP) * 3;
+      if (sqrtf(f3[0] * f3[0] + f3[1] * f3[1] + f3[2] * f3[2]) > 1.0f) collide = 1;
+    }
+    reset = collide;
+  }
+  uint8_t to = ep > m->max_episode_length;
+  st.time_out[e] = to;
+  reset |= to;
+  for (int a = 0; a < A; a++) {
+    int i = e * A + a;
+    float rpy[3];
+    euler_xyz_f(st.bquat + i * 4, rpy);
+    float r = rpy[0], p = rpy[1];
+    if (r > 3.1415927f) r -= 6.2831855f;
+    if (p > 3.1415927f) p -= 6.2831855f;
+    float z = root[a * 13 + 2] - m->agent_origins[((size_t)e * A + a) * 3 + 2];
+    if ((m->termination_flags & MQE_TERM_ROLL) && fabsf(r) > m->roll_thr) rterm = 1;
+    if ((m->termination_flags & MQE_TERM_PITCH) && fabsf(p) > m->pitch_thr) pterm = 1;
+    if ((m->termination_flags & MQE_TERM_Z_LOW) && z < m->zlow_thr) reset = 1;
+    if ((m->termination_flags & MQE_TERM_Z_HIGH) && z > m->zhigh_thr) zh = 1;
+  }
+  if (m->termination_flags & MQE_TERM_ROLL) st.r_term[e] = rterm;
+  if (m->termination_flags & MQE_TERM_PITCH) st.p_term[e] = pterm;
+  if (m->termination_flags & MQE_TERM_Z_HIGH) st.zh_term[e] = zh;
+  reset |= rterm | pterm | zh;
+  st.reset_buf[e] = reset;
+  if (m->terminate_on_base_contact) st.collide_buf[e] = reset;
+  // wrapper's view of root_states_npc: copy taken before the NPC script (legged_robot.py:136); xy/vel only are read
+  float npc_pre[MQE_MAX_NPCS * 13];
+  for (int k = 0; k < P * 13; k++) npc_pre[k] = root[A * 13 + k];
+  if (m->npc_kind == MQE_NPC_SHEEP) step_sheep_env(m, st, e);
+  if (reset) {
+    reset_env_dev(m, st, e);
+    for (int k = 0; k < P * 13; k++) npc_pre[k] = root[A * 13 + k];
+    if (P == 0)
+      for (int a = 0; a < A; a++) for (int k = 0; k < 4; k++) st.bquat[(e * A + a) * 4 + k] = root[a * 13 + 3 + k];
+  }
+  compute_observations_env(m, st, e, 1);
+  for (int k = 0; k < 12 * A; k++) st.last_actions[(size_t)e * 12 * A + k] = st.actions[(size_t)e * 12 * A + k];
+  wrapper_env_dev(m, st, e, 0, npc_pre);
+}
+
+// go1.py:145: history[agent_ids] = 0 for envs that reset this step.  One float4 per thread, R*540 threads.
+__global__ void k_reset_history(const DevModel* m, DevState st) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int per = MQE_HIST * MQE_FRAME / 4;
+  int i = idx / per;
+  if (i >= m->R) return;
+  if (!st.reset_buf[i / m->A]) return;
+  reinterpret_cast<float4*>(st.hist)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+__global__ void __launch_bounds__(64) k_reset_all(const DevModel* m, DevState st, int no_post_step_yet) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= m->N) return;
+  int A = m->A, P = m->P;
+  reset_env_dev(m, st, e);
+  const float* root = st.root + (size_t)e * (A + P) * 13;
+  if (P == 0 || no_post_step_yet)
+    for (int a = 0; a < A; a++) for (int k = 0; k < 4; k++) st.bquat[(e * A + a) * 4 + k] = root[a * 13 + 3 + k];
+  compute_observations_env(m, st, e, 0);
+  st.w_have_last[e] = 0;
+  st.w_delayed_reset[e] = 0;
+  wrapper_env_dev(m, st, e, 1, root + A * 13);
+}
+
+__global__ void __launch_bounds__(64) k_wrapper_eval(const DevModel* m, DevState st, int is_reset_call) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= m->N) return;
+  if (is_reset_call) { st.w_have_last[e] = 0; st.w_delayed_reset[e] = 0; }
+  wrapper_env_dev(m, st, e, is_reset_call, st.root + ((size_t)e * (m->A + m->P) + m->A) * 13);
+}

@@ -1,0 +1,59 @@
+// mqe_common.hpp -- device-side data model of the MI355X MQE engine (gfx950 only).
+//
+// One environment = one 64-lane wavefront in the physics kernel; everything else is thread-per-robot /
+// thread-per-joint / thread-per-env streaming work.  All state lives in HBM between kernels in the env-major layout
+// of include/mqe_hip.h (the Isaac Gym tensor contract of the reference, legged_robot.py:549-645), which is already
+// the coalesced layout for a wave that owns one env: its root/dof/contact rows are contiguous.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mqe_hip.h"
+
+#define MQE_RD 18          // generalized velocities of one robot: 3 lin + 3 ang + 12 joints
+#define MQE_OBS_BAG 74
+#define MQE_WAVE 64
+
+struct DevMlp {
+  int n_layers;
+  int dims[MQE_MAX_LAYERS + 1];
+  const float* W[MQE_MAX_LAYERS];   // device, (out,in) row-major as given
+  const float* b[MQE_MAX_LAYERS];
+};
+
+// constants of one simulation, resident in device memory; every kernel receives a pointer to it (uniform loads)
+struct DevModel {
+  int N, A, P, R, ND, NBR, Aw, D;          // envs, agents, npcs, robots, dofs/env, reported bodies/env, wrapper dims
+  int npc_kind, task, npc_dofs_each, npc_lin_only, n_npc_dyn;   // dynamic NPC bodies (ball/sheep) handled by the solver
+  int env_id_offset, seed;
+  float dt; int decimation; float gravity_z; int solver_iterations;
+  float contact_offset, max_depen, friction, erp;
+  mqe_robot_model robot;
+  float npc_mass, npc_inertia; int npc_n_spheres; float npc_sphere_center[2][3]; float npc_sphere_radius[2];
+  float seesaw_default_angle;
+  int control_type; float action_scale, hip_scale_reduction, clip_actions; float torque_limits[12]; float kp, kd;
+  float default_dof_pos[12]; float command_obs[70]; float cmd_lin_scale, cmd_ang_scale; int clip_command;
+  const float* wall_sdf; int sdf_nx, sdf_ny; float hs, wall_height, ground_z;
+  const float *env_origins, *agent_origins, *base_init, *npc_init, *gate_pos;
+  int termination_flags, terminate_on_base_contact, max_episode_length;
+  float roll_thr, pitch_thr, zlow_thr, zhigh_thr;
+  float dof_ratio_lo, dof_ratio_hi; int has_base_pos_range, has_npc_pos_range;
+  float base_pos_x_lo, base_pos_x_hi, base_pos_y_lo, base_pos_y_hi, npc_pos_x_lo, npc_pos_x_hi, npc_pos_y_lo, npc_pos_y_hi;
+  float base_vel_lo, base_vel_hi;
+  float sheep_scale, sheep_rand;
+  float reward_scale[MQE_MAX_REWARD_TERMS]; float wrapper_param[8];
+  DevMlp actuator;
+  // physics kernel geometry
+  int nbody_env, ndof_env, nsph_env, maxc, ldsB_stride;
+};
+
+// device pointers of all state tensors (kernel argument by value)
+struct DevState {
+  float *root, *dof, *cf, *torques, *actions, *last_actions, *loco_obs, *hist, *last_loco, *last_two_loco, *act_hist;
+  float *gait, *clock, *blv, *bav, *pg, *bquat, *obs_bag, *wobs, *wrew, *rsum, *sheep_avg, *sheep_var, *sub_tau, *npc_noise;
+  float *w_last, *w_last2, *cmd;
+  int32_t *ep_len, *reset_count;
+  uint8_t *reset_buf, *collide_buf, *time_out, *r_term, *p_term, *zh_term, *w_have_last, *w_delayed_reset;
+};
+
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }

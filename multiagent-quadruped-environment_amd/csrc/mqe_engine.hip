@@ -1,0 +1,498 @@
+// mqe_engine.hip -- C ABI (include/mqe_hip.h) of the MI355X-native MQE rollout engine: handle, device memory,
+// kernel launches.  gfx950 only; built in-tree by __graft_entry__.build():
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC mqe_engine.hip -o libmqe_hip.so
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mqe_common.hpp"
+#include "kernels_step.hpp"
+#include "kernels_gemm.hpp"
+#include "kernels_physics.hpp"
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, const char* a = "") {
+  snprintf(g_err, sizeof g_err, fmt, a);
+  return code;
+}
+#define HIPCHK(x)                                                        \
+  do {                                                                   \
+    hipError_t _e = (x);                                                 \
+    if (_e != hipSuccess) return fail(-100, "HIP error: %s", hipGetErrorString(_e)); \
+  } while (0)
+
+struct GemmLayer {
+  float* Wt;      // device [Kpad][Npad]
+  float* bias;    // device [Npad]
+  int K, N, Kpad, Npad;
+};
+
+enum { PROF_GEMM_L0 = 0, PROF_GEMM_REST, PROF_TORQUES, PROF_SIMULATE, PROF_POST, PROF_MISC, PROF_N };
+
+struct mqe_sim {
+  mqe_sim_desc d;
+  DevModel hm;            // host copy
+  DevModel* dm = nullptr; // device copy
+  DevState st;
+  std::vector<void*> allocs;
+  void* tens[MQE_T_COUNT];
+  int N, A, P, R, ND, NBR, Aw, D;
+  int hist_pos = 0, n_post_steps = 0;
+  // policy network (fused first layer: [adaptation L0 | body L0 history part])
+  GemmLayer l0;                       // K = 30*72 (ring), N = ada_h0 + body_h0
+  std::vector<GemmLayer> ada_rest, body_rest;
+  float *w_lat0 = nullptr, *w_lat1 = nullptr;   // body L0 rows for the two latent inputs
+  int ada_h0, body_h0;
+  float *P1 = nullptr, *bufA = nullptr, *bufB = nullptr, *lat = nullptr, *act_out = nullptr;
+  int ldP1, ldbuf, ldlat, ldact;
+  size_t phys_lds_bytes = 0;
+  // profiling
+  bool prof = false;
+  std::vector<hipEvent_t> ev0[PROF_N], ev1[PROF_N];
+  float prof_ms[PROF_N];
+  int prof_cnt[PROF_N];
+};
+
+extern "C" const char* mqe_last_error(void) { return g_err; }
+extern "C" int mqe_abi_version(void) { return MQE_ABI_VERSION; }
+
+template <typename T>
+static int dalloc(mqe_sim* s, T** p, size_t n, int fill_zero = 1) {
+  void* q = nullptr;
+  size_t bytes = (n ? n : 1) * sizeof(T);
+  if (hipMalloc(&q, bytes) != hipSuccess) return -1;
+  if (fill_zero && hipMemset(q, 0, bytes) != hipSuccess) return -1;
+  s->allocs.push_back(q);
+  *p = (T*)q;
+  return 0;
+}
+static int upload(mqe_sim* s, const float** dst, const float* src, size_t n) {
+  if (!src || !n) { *dst = nullptr; return 0; }
+  float* q;
+  if (dalloc(s, &q, n, 0)) return -1;
+  if (hipMemcpy(q, src, n * 4, hipMemcpyHostToDevice) != hipSuccess) return -1;
+  *dst = q;
+  return 0;
+}
+static inline int rup(int v, int m) { return (v + m - 1) / m * m; }
+
+// W (out,in) row-major host -> Wt [Kpad][Npad] device at column offset; rows remapped by `rowmap` (-1 = zero row)
+static int make_layer(mqe_sim* s, GemmLayer* L, int K, int N) {
+  L->K = K; L->N = N; L->Kpad = rup(K, GB_K); L->Npad = rup(N, GB_N);
+  if (dalloc(s, &L->Wt, (size_t)L->Kpad * L->Npad)) return -1;
+  if (dalloc(s, &L->bias, L->Npad)) return -1;
+  return 0;
+}
+static int fill_layer(GemmLayer* L, int col0, const float* W, const float* b, int out, int in_used, int ldw_in,
+                      const std::vector<int>* krow = nullptr) {
+  std::vector<float> tmp((size_t)L->Kpad * out, 0.0f);
+  for (int o = 0; o < out; o++)
+    for (int k = 0; k < in_used; k++) {
+      int kr = krow ? (*krow)[k] : k;
+      tmp[(size_t)kr * out + o] = W[(size_t)o * ldw_in + k];
+    }
+  if (hipMemcpy2D(L->Wt + col0, (size_t)L->Npad * 4, tmp.data(), (size_t)out * 4, (size_t)out * 4, L->Kpad, hipMemcpyHostToDevice) != hipSuccess) return -1;
+  if (b && hipMemcpy(L->bias + col0, b, (size_t)out * 4, hipMemcpyHostToDevice) != hipSuccess) return -1;
+  return 0;
+}
+
+static int wrapper_dims(const mqe_sim_desc* d, int* Aw, int* D) {
+  int A = d->num_agents, P = d->num_npcs;
+  switch (d->task) {
+    case MQE_TASK_GATE: *Aw = A; *D = 14 + A; break;
+    case MQE_TASK_SHEEP: *Aw = A; *D = 14 + 2 * P + A; break;
+    case MQE_TASK_SEESAW: *Aw = A; *D = 12 + A; break;
+    case MQE_TASK_FOOTBALL_DEFENDER: *Aw = 2; *D = 20; break;
+    default: *Aw = A; *D = 6 + A; break;
+  }
+  return 0;
+}
+
+extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
+  if (!d || !out) return fail(-1, "null argument");
+  if (d->abi_version != MQE_ABI_VERSION) return fail(-1, "abi version mismatch");
+  if (d->num_agents < 1 || d->num_agents > MQE_MAX_AGENTS || d->num_npcs > MQE_MAX_NPCS) return fail(-2, "unsupported agent/npc count");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(-3, "no HIP device: the engine has no CPU path");
+  mqe_sim* s = new mqe_sim();
+  s->d = *d;
+  const int N = s->N = d->num_envs, A = s->A = d->num_agents, P = s->P = d->num_npcs;
+  const int R = s->R = N * A;
+  const int seesaw = d->npc_kind == MQE_NPC_SEESAW;
+  s->ND = 12 * A + (seesaw ? P : 0);
+  s->NBR = MQE_NREP * A + (seesaw ? 2 * P : P);
+  wrapper_dims(d, &s->Aw, &s->D);
+  memset(s->tens, 0, sizeof s->tens);
+  memset(s->prof_ms, 0, sizeof s->prof_ms);
+  memset(s->prof_cnt, 0, sizeof s->prof_cnt);
+  DevModel& m = s->hm;
+  memset(&m, 0, sizeof m);
+  m.N = N; m.A = A; m.P = P; m.R = R; m.ND = s->ND; m.NBR = s->NBR; m.Aw = s->Aw; m.D = s->D;
+  m.npc_kind = d->npc_kind; m.task = d->task;
+  m.n_npc_dyn = (d->npc_kind == MQE_NPC_BALL || d->npc_kind == MQE_NPC_SHEEP) ? P : 0;
+  m.npc_lin_only = d->npc_kind == MQE_NPC_SHEEP;
+  m.npc_dofs_each = m.npc_lin_only ? 3 : 6;
+  m.env_id_offset = d->env_id_offset; m.seed = d->seed;
+  m.dt = d->dt; m.decimation = d->decimation; m.gravity_z = d->gravity_z; m.solver_iterations = d->solver_iterations;
+  m.contact_offset = d->contact_offset; m.max_depen = d->max_depenetration_velocity; m.friction = d->friction; m.erp = d->erp;
+  m.robot = d->robot;
+  m.npc_mass = d->npc_mass; m.npc_inertia = d->npc_inertia; m.npc_n_spheres = d->npc_n_spheres;
+  memcpy(m.npc_sphere_center, d->npc_sphere_center, sizeof m.npc_sphere_center);
+  memcpy(m.npc_sphere_radius, d->npc_sphere_radius, sizeof m.npc_sphere_radius);
+  m.seesaw_default_angle = d->seesaw_default_angle;
+  m.control_type = d->control_type; m.action_scale = d->action_scale; m.hip_scale_reduction = d->hip_scale_reduction;
+  m.clip_actions = d->clip_actions; memcpy(m.torque_limits, d->torque_limits, sizeof m.torque_limits);
+  m.kp = d->kp; m.kd = d->kd; memcpy(m.default_dof_pos, d->default_dof_pos, sizeof m.default_dof_pos);
+  memcpy(m.command_obs, d->command_obs, sizeof m.command_obs);
+  m.cmd_lin_scale = d->cmd_lin_scale; m.cmd_ang_scale = d->cmd_ang_scale; m.clip_command = d->clip_command;
+  m.sdf_nx = d->sdf_nx; m.sdf_ny = d->sdf_ny; m.hs = d->horizontal_scale; m.wall_height = d->wall_height; m.ground_z = d->ground_z;
+  m.termination_flags = d->termination_flags; m.terminate_on_base_contact = d->terminate_on_base_contact; m.max_episode_length = d->max_episode_length;
+  m.roll_thr = d->roll_threshold; m.pitch_thr = d->pitch_threshold; m.zlow_thr = d->z_low_threshold; m.zhigh_thr = d->z_high_threshold;
+  m.dof_ratio_lo = d->dof_ratio_lo; m.dof_ratio_hi = d->dof_ratio_hi; m.has_base_pos_range = d->has_base_pos_range; m.has_npc_pos_range = d->has_npc_pos_range;
+  m.base_pos_x_lo = d->base_pos_x_lo; m.base_pos_x_hi = d->base_pos_x_hi; m.base_pos_y_lo = d->base_pos_y_lo; m.base_pos_y_hi = d->base_pos_y_hi;
+  m.npc_pos_x_lo = d->npc_pos_x_lo; m.npc_pos_x_hi = d->npc_pos_x_hi; m.npc_pos_y_lo = d->npc_pos_y_lo; m.npc_pos_y_hi = d->npc_pos_y_hi;
+  m.base_vel_lo = d->base_vel_lo; m.base_vel_hi = d->base_vel_hi;
+  m.sheep_scale = d->sheep_movement_scale; m.sheep_rand = d->sheep_movement_randomness;
+  memcpy(m.reward_scale, d->reward_scale, sizeof m.reward_scale); memcpy(m.wrapper_param, d->wrapper_param, sizeof m.wrapper_param);
+  // physics kernel geometry
+  m.nbody_env = A * MQE_NBODY + m.n_npc_dyn;
+  m.ndof_env = A * MQE_RD + m.n_npc_dyn * m.npc_dofs_each;
+  m.nsph_env = A * d->robot.n_spheres + m.n_npc_dyn * d->npc_n_spheres;
+  m.maxc = mqe_maxc(A, P);
+  m.ldsB_stride = m.ndof_env;
+  if (m.ndof_env > 64 || m.nbody_env > 64) { delete s; return fail(-4, "env has more than 64 bodies or generalized velocities: does not fit one wavefront"); }
+  PhysLds L = phys_lds_layout(A, P, s->ND, m.nbody_env, m.ndof_env, m.nsph_env, m.maxc, m.ldsB_stride);
+  s->phys_lds_bytes = (size_t)L.total * 4;
+  if (s->phys_lds_bytes > 160 * 1024) { delete s; return fail(-4, "physics LDS footprint exceeds 160 KiB"); }
+  if (s->phys_lds_bytes > 48 * 1024)
+    if (hipFuncSetAttribute((const void*)k_simulate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->phys_lds_bytes) != hipSuccess) {
+      delete s; return fail(-4, "cannot raise dynamic LDS limit");
+    }
+#define UP(dst, src, n) if (upload(s, &(dst), (src), (n))) { return fail(-5, "device upload failed"); }
+  UP(m.wall_sdf, d->wall_sdf, (size_t)d->sdf_nx * d->sdf_ny);
+  UP(m.env_origins, d->env_origins, (size_t)N * 3);
+  UP(m.agent_origins, d->agent_origins, (size_t)N * A * 3);
+  UP(m.base_init, d->base_init_state, (size_t)A * 13);
+  UP(m.npc_init, d->npc_init_state, (size_t)P * 13);
+  UP(m.gate_pos, d->gate_pos, (size_t)N * 2);
+  m.actuator.n_layers = d->actuator.n_layers;
+  memcpy(m.actuator.dims, d->actuator.dims, sizeof m.actuator.dims);
+  if (d->actuator.n_layers != 3 || d->actuator.dims[0] != 6 || d->actuator.dims[1] != 32 || d->actuator.dims[2] != 32 || d->actuator.dims[3] != 1)
+    return fail(-6, "actuator network must be 6-32-32-1 (unitree_go1.pt)");
+  for (int l = 0; l < 3; l++) {
+    UP(m.actuator.W[l], d->actuator.W[l], (size_t)d->actuator.dims[l] * d->actuator.dims[l + 1]);
+    UP(m.actuator.b[l], d->actuator.b[l], (size_t)d->actuator.dims[l + 1]);
+  }
+  // ---- policy network: fused layer 0 over the ring-buffer history ------------------------------------------------
+  const mqe_mlp& ad = d->adaptation; const mqe_mlp& bd = d->body;
+  if (ad.dims[0] != 2100 || bd.dims[0] != 2102 || bd.dims[bd.n_layers] != 12 || ad.dims[ad.n_layers] != 2)
+    return fail(-6, "policy I/O must be adaptation 2100->2, body 2102->12 (go1.py:395,404,29)");
+  s->ada_h0 = ad.dims[1]; s->body_h0 = bd.dims[1];
+  if (s->ada_h0 % GB_N || s->body_h0 % GB_N) return fail(-6, "first hidden sizes must be multiples of 64");
+  std::vector<int> krow(2100);
+  for (int k = 0; k < 2100; k++) krow[k] = (k / 70) * MQE_FRAME + (k % 70);
+  if (make_layer(s, &s->l0, MQE_HIST * MQE_FRAME, s->ada_h0 + s->body_h0)) return fail(-5, "alloc");
+  if (fill_layer(&s->l0, 0, ad.W[0], ad.b[0], s->ada_h0, 2100, 2100, &krow)) return fail(-5, "upload");
+  if (fill_layer(&s->l0, s->ada_h0, bd.W[0], bd.b[0], s->body_h0, 2100, 2102, &krow)) return fail(-5, "upload");
+  {
+    std::vector<float> w0(s->body_h0), w1(s->body_h0);
+    for (int o = 0; o < s->body_h0; o++) { w0[o] = bd.W[0][(size_t)o * 2102 + 2100]; w1[o] = bd.W[0][(size_t)o * 2102 + 2101]; }
+    const float* t;
+    UP(t, w0.data(), w0.size()); s->w_lat0 = (float*)t;
+    UP(t, w1.data(), w1.size()); s->w_lat1 = (float*)t;
+  }
+  for (int l = 1; l < ad.n_layers; l++) {
+    GemmLayer g;
+    if (make_layer(s, &g, ad.dims[l], ad.dims[l + 1]) || fill_layer(&g, 0, ad.W[l], ad.b[l], ad.dims[l + 1], ad.dims[l], ad.dims[l])) return fail(-5, "upload");
+    s->ada_rest.push_back(g);
+  }
+  for (int l = 1; l < bd.n_layers; l++) {
+    GemmLayer g;
+    if (make_layer(s, &g, bd.dims[l], bd.dims[l + 1]) || fill_layer(&g, 0, bd.W[l], bd.b[l], bd.dims[l + 1], bd.dims[l], bd.dims[l])) return fail(-5, "upload");
+    s->body_rest.push_back(g);
+  }
+  int maxw = 64;
+  for (auto& g : s->ada_rest) maxw = std::max(maxw, g.Npad);
+  for (auto& g : s->body_rest) maxw = std::max(maxw, g.Npad);
+  s->ldP1 = s->l0.Npad; s->ldbuf = maxw; s->ldlat = 64; s->ldact = 64;
+#define DA(p, n) if (dalloc(s, &(p), (n))) return fail(-5, "device alloc failed");
+  DA(s->P1, (size_t)R * s->ldP1); DA(s->bufA, (size_t)R * s->ldbuf); DA(s->bufB, (size_t)R * s->ldbuf);
+  DA(s->lat, (size_t)R * s->ldlat); DA(s->act_out, (size_t)R * s->ldact);
+  // ---- state ---------------------------------------------------------------------------------------------------------
+  DevState& st = s->st;
+  DA(st.root, (size_t)N * (A + P) * 13); DA(st.dof, (size_t)N * s->ND * 2); DA(st.cf, (size_t)N * s->NBR * 3);
+  DA(st.torques, (size_t)N * 12 * A); DA(st.actions, (size_t)N * 12 * A); DA(st.last_actions, (size_t)N * 12 * A);
+  DA(st.loco_obs, (size_t)R * MQE_FRAME); DA(st.hist, (size_t)R * MQE_HIST * MQE_FRAME);
+  DA(st.last_loco, (size_t)R * 12); DA(st.last_two_loco, (size_t)R * 12); DA(st.act_hist, (size_t)4 * R * 12);
+  DA(st.gait, R); DA(st.clock, (size_t)R * 4); DA(st.blv, (size_t)R * 3); DA(st.bav, (size_t)R * 3); DA(st.pg, (size_t)R * 3);
+  DA(st.bquat, (size_t)R * 4); DA(st.obs_bag, (size_t)R * MQE_OBS_BAG); DA(st.wobs, (size_t)N * s->Aw * s->D); DA(st.wrew, (size_t)N * s->Aw);
+  DA(st.rsum, (size_t)N * MQE_MAX_REWARD_TERMS); DA(st.sheep_avg, (size_t)N * 2); DA(st.sheep_var, N);
+  DA(st.sub_tau, (size_t)N * 4 * 12 * A); DA(st.npc_noise, (size_t)N * (P ? P : 1) * 3);
+  DA(st.w_last, (size_t)N * MQE_MAX_AGENTS); DA(st.w_last2, (size_t)N * 2); DA(st.cmd, (size_t)R * 3);
+  DA(st.ep_len, N); DA(st.reset_count, N);
+  DA(st.reset_buf, N); DA(st.collide_buf, N); DA(st.time_out, N); DA(st.r_term, N); DA(st.p_term, N); DA(st.zh_term, N);
+  DA(st.w_have_last, N); DA(st.w_delayed_reset, N);
+  {
+    // initial values the reference's buffers start from (base_task.py:77-84, legged_robot.py:567-622)
+    std::vector<float> h((size_t)N * (A + P) * 13, 0.0f);
+    for (size_t i = 0; i < (size_t)N * (A + P); i++) h[i * 13 + 6] = 1.0f;
+    HIPCHK(hipMemcpy(st.root, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    std::vector<float> lo((size_t)R * MQE_FRAME, 0.0f), pg((size_t)R * 3, 0.0f), bq((size_t)R * 4, 0.0f);
+    for (int i = 0; i < R; i++) { memcpy(&lo[(size_t)i * MQE_FRAME], d->command_obs, 70 * 4); pg[i * 3 + 2] = -1.0f; bq[i * 4 + 3] = 1.0f; }
+    HIPCHK(hipMemcpy(st.loco_obs, lo.data(), lo.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(st.pg, pg.data(), pg.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(st.bquat, bq.data(), bq.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(st.reset_buf, 1, N));
+  }
+  DevModel* dmp;
+  if (dalloc(s, &dmp, 1)) return fail(-5, "alloc");
+  HIPCHK(hipMemcpy(dmp, &m, sizeof m, hipMemcpyHostToDevice));
+  s->dm = dmp;
+  void** t = s->tens;
+  t[MQE_T_ROOT_STATE] = st.root; t[MQE_T_DOF_STATE] = st.dof; t[MQE_T_CONTACT_FORCE] = st.cf; t[MQE_T_TORQUES] = st.torques;
+  t[MQE_T_ACTIONS] = st.actions; t[MQE_T_LAST_ACTIONS] = st.last_actions; t[MQE_T_LOCOMOTION_OBS] = st.loco_obs;
+  t[MQE_T_HISTORY] = st.hist; t[MQE_T_LAST_LOCO_ACTION] = st.last_loco; t[MQE_T_LAST_TWO_LOCO_ACTION] = st.last_two_loco;
+  t[MQE_T_ACT_HIST] = st.act_hist; t[MQE_T_GAIT_INDICES] = st.gait; t[MQE_T_CLOCK_INPUTS] = st.clock;
+  t[MQE_T_BASE_LIN_VEL] = st.blv; t[MQE_T_BASE_ANG_VEL] = st.bav; t[MQE_T_PROJECTED_GRAVITY] = st.pg; t[MQE_T_BASE_QUAT] = st.bquat;
+  t[MQE_T_EPISODE_LENGTH] = st.ep_len; t[MQE_T_RESET_BUF] = st.reset_buf; t[MQE_T_COLLIDE_BUF] = st.collide_buf;
+  t[MQE_T_TIME_OUT_BUF] = st.time_out; t[MQE_T_R_TERM] = st.r_term; t[MQE_T_P_TERM] = st.p_term; t[MQE_T_Z_HIGH_TERM] = st.zh_term;
+  t[MQE_T_OBS_BAG] = st.obs_bag; t[MQE_T_WRAPPER_OBS] = st.wobs; t[MQE_T_WRAPPER_REWARD] = st.wrew; t[MQE_T_REWARD_SUMS] = st.rsum;
+  t[MQE_T_SHEEP_POS_AVG] = st.sheep_avg; t[MQE_T_SHEEP_POS_VAR] = st.sheep_var; t[MQE_T_RESET_COUNT] = st.reset_count;
+  t[MQE_T_SUBSTEP_TORQUES] = st.sub_tau; t[MQE_T_NPC_NOISE] = st.npc_noise;
+  HIPCHK(hipDeviceSynchronize());
+  *out = s;
+  return 0;
+}
+
+extern "C" int mqe_sim_destroy(mqe_sim* s) {
+  if (!s) return 0;
+  hipDeviceSynchronize();
+  for (void* p : s->allocs) hipFree(p);
+  for (int k = 0; k < PROF_N; k++) {
+    for (auto e : s->ev0[k]) hipEventDestroy(e);
+    for (auto e : s->ev1[k]) hipEventDestroy(e);
+  }
+  delete s;
+  return 0;
+}
+
+extern "C" int mqe_sim_tensor(mqe_sim* s, int kind, mqe_tensor_view* v) {
+  if (!s || !v || kind < 0 || kind >= MQE_T_COUNT) return fail(-1, "bad tensor kind");
+  memset(v, 0, sizeof *v);
+  v->ptr = s->tens[kind];
+  const int N = s->N, A = s->A, P = s->P, R = s->R;
+#define SH(nd, a, b, c, e, dt_) do { v->ndim = nd; v->shape[0] = a; v->shape[1] = b; v->shape[2] = c; v->shape[3] = e; v->dtype = dt_; } while (0)
+  switch (kind) {
+    case MQE_T_ROOT_STATE: SH(3, N, A + P, 13, 0, 0); break;
+    case MQE_T_DOF_STATE: SH(3, N, s->ND, 2, 0, 0); break;
+    case MQE_T_CONTACT_FORCE: SH(3, N, s->NBR, 3, 0, 0); break;
+    case MQE_T_TORQUES: case MQE_T_ACTIONS: case MQE_T_LAST_ACTIONS: SH(2, N, 12 * A, 0, 0, 0); break;
+    case MQE_T_LOCOMOTION_OBS: SH(2, R, MQE_FRAME, 0, 0, 0); break;
+    case MQE_T_HISTORY: SH(3, R, MQE_HIST, MQE_FRAME, 0, 0); break;
+    case MQE_T_LAST_LOCO_ACTION: case MQE_T_LAST_TWO_LOCO_ACTION: SH(2, R, 12, 0, 0, 0); break;
+    case MQE_T_ACT_HIST: SH(3, 4, R, 12, 0, 0); break;
+    case MQE_T_GAIT_INDICES: SH(1, R, 0, 0, 0, 0); break;
+    case MQE_T_CLOCK_INPUTS: case MQE_T_BASE_QUAT: SH(2, R, 4, 0, 0, 0); break;
+    case MQE_T_BASE_LIN_VEL: case MQE_T_BASE_ANG_VEL: case MQE_T_PROJECTED_GRAVITY: SH(2, R, 3, 0, 0, 0); break;
+    case MQE_T_EPISODE_LENGTH: case MQE_T_RESET_COUNT: SH(1, N, 0, 0, 0, 1); break;
+    case MQE_T_RESET_BUF: case MQE_T_COLLIDE_BUF: case MQE_T_TIME_OUT_BUF: case MQE_T_R_TERM: case MQE_T_P_TERM:
+    case MQE_T_Z_HIGH_TERM: SH(1, N, 0, 0, 0, 2); break;
+    case MQE_T_OBS_BAG: SH(2, R, MQE_OBS_BAG, 0, 0, 0); break;
+    case MQE_T_WRAPPER_OBS: SH(3, N, s->Aw, s->D, 0, 0); break;
+    case MQE_T_WRAPPER_REWARD: SH(2, N, s->Aw, 0, 0, 0); break;
+    case MQE_T_REWARD_SUMS: SH(2, N, MQE_MAX_REWARD_TERMS, 0, 0, 0); break;
+    case MQE_T_SHEEP_POS_AVG: SH(2, N, 2, 0, 0, 0); break;
+    case MQE_T_SHEEP_POS_VAR: SH(1, N, 0, 0, 0, 0); break;
+    case MQE_T_SUBSTEP_TORQUES: SH(3, N, 4, 12 * A, 0, 0); break;
+    case MQE_T_NPC_NOISE: SH(3, N, P, 3, 0, 0); break;
+  }
+  return 0;
+}
+
+// ---- profiling helpers ---------------------------------------------------------------------------------------------------
+struct ProfScope {
+  mqe_sim* s; int k; hipStream_t q; hipEvent_t e1;
+  ProfScope(mqe_sim* s_, int k_, hipStream_t q_) : s(s_), k(k_), q(q_), e1(nullptr) {
+    if (!s->prof) return;
+    hipEvent_t e0;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0, q);
+    s->ev0[k].push_back(e0); s->ev1[k].push_back(e1);
+  }
+  ~ProfScope() { if (s->prof) hipEventRecord(e1, q); }
+};
+
+extern "C" int mqe_profile_enable(mqe_sim* s, int on) {
+  s->prof = on != 0;
+  return 0;
+}
+extern "C" int mqe_profile_read(mqe_sim* s, float* ms, int n, int* n_launches) {
+  HIPCHK(hipDeviceSynchronize());
+  for (int k = 0; k < PROF_N; k++) {
+    for (size_t i = 0; i < s->ev0[k].size(); i++) {
+      float t = 0;
+      hipEventElapsedTime(&t, s->ev0[k][i], s->ev1[k][i]);
+      s->prof_ms[k] += t; s->prof_cnt[k] += 1;
+      hipEventDestroy(s->ev0[k][i]); hipEventDestroy(s->ev1[k][i]);
+    }
+    s->ev0[k].clear(); s->ev1[k].clear();
+  }
+  for (int k = 0; k < PROF_N && k < n; k++) ms[k] = s->prof_ms[k];
+  for (int k = 0; k < PROF_N && PROF_N + k < n; k++) ms[PROF_N + k] = (float)s->prof_cnt[k];
+  if (n_launches) *n_launches = s->prof_cnt[PROF_GEMM_L0];
+  memset(s->prof_ms, 0, sizeof s->prof_ms);
+  memset(s->prof_cnt, 0, sizeof s->prof_cnt);
+  return 0;
+}
+
+// ---- launches ---------------------------------------------------------------------------------------------------------------
+static void launch_gemm(hipStream_t q, const float* A, int lda, int rot4, int ring4, const GemmLayer& L, float* C, int ldc, int M, int act_cols) {
+  GemmArgs g;
+  g.A = A; g.lda = lda; g.a_rot4 = rot4; g.a_ring4 = ring4; g.Wt = L.Wt; g.ldw = L.Npad; g.bias = L.bias;
+  g.C = C; g.ldc = ldc; g.M = M; g.N = L.Npad; g.K = L.Kpad; g.act_cols = act_cols;
+  int grid = ((M + GB_M - 1) / GB_M) * (L.Npad / GB_N);
+  hipLaunchKernelGGL(k_gemm_f32, dim3(grid), dim3(256), 0, q, g);
+}
+
+static int policy_step(mqe_sim* s, const float* command, hipStream_t q) {
+  const int R = s->R;
+  {
+    ProfScope ps(s, PROF_MISC, q);
+    int n = R * MQE_FRAME;
+    hipLaunchKernelGGL(k_pre_policy, dim3((n + 255) / 256), dim3(256), 0, q, s->dm, s->st, command, s->hist_pos);
+  }
+  s->hist_pos = (s->hist_pos + 1) % MQE_HIST;     // ring slot of the oldest frame
+  {
+    ProfScope ps(s, PROF_GEMM_L0, q);
+    // fused layer 0 of both networks over the ring: ELU on the adaptation columns only
+    launch_gemm(q, s->st.hist, MQE_HIST * MQE_FRAME, s->hist_pos * (MQE_FRAME / 4), MQE_HIST * MQE_FRAME / 4, s->l0, s->P1, s->ldP1, R, s->ada_h0);
+  }
+  ProfScope ps(s, PROF_GEMM_REST, q);
+  // adaptation tail -> latent
+  const float* x = s->P1; int ldx = s->ldP1;
+  for (size_t l = 0; l < s->ada_rest.size(); l++) {
+    const bool last = l + 1 == s->ada_rest.size();
+    float* y = last ? s->lat : ((l & 1) ? s->bufB : s->bufA);
+    int ldy = last ? s->ldlat : s->ldbuf;
+    launch_gemm(q, x, ldx, 0, 0, s->ada_rest[l], y, ldy, R, last ? 0 : s->ada_rest[l].Npad);
+    x = y; ldx = ldy;
+  }
+  {
+    int n = R * s->body_h0;
+    hipLaunchKernelGGL(k_body_l0_finish, dim3((n + 255) / 256), dim3(256), 0, q, s->P1, s->ldP1, s->ada_h0, s->body_h0,
+                       (const float*)s->lat, s->ldlat, (const float*)s->w_lat0, (const float*)s->w_lat1, R);
+  }
+  x = s->P1 + s->ada_h0; ldx = s->ldP1;
+  for (size_t l = 0; l < s->body_rest.size(); l++) {
+    const bool last = l + 1 == s->body_rest.size();
+    float* y = last ? s->act_out : ((l & 1) ? s->bufB : s->bufA);
+    int ldy = last ? s->ldact : s->ldbuf;
+    launch_gemm(q, x, ldx, 0, 0, s->body_rest[l], y, ldy, R, last ? 0 : s->body_rest[l].Npad);
+    x = y; ldx = ldy;
+  }
+  int n = R * 12;
+  hipLaunchKernelGGL(k_post_policy, dim3((n + 255) / 256), dim3(256), 0, q, s->dm, s->st, (const float*)s->act_out, s->ldact);
+  return 0;
+}
+
+static void launch_torques(mqe_sim* s, int dec_i, hipStream_t q) {
+  ProfScope ps(s, PROF_TORQUES, q);
+  int n = s->R * 12;
+  hipLaunchKernelGGL(k_compute_torques, dim3((n + 255) / 256), dim3(256), 0, q, s->dm, s->st, dec_i);
+}
+static void launch_simulate(mqe_sim* s, hipStream_t q) {
+  ProfScope ps(s, PROF_SIMULATE, q);
+  PhysDebug dbg = {nullptr, nullptr, nullptr, 0};
+  hipLaunchKernelGGL(k_simulate, dim3(s->N), dim3(64), s->phys_lds_bytes, q, s->dm, s->st, 0, 0, dbg);
+}
+static void launch_post(mqe_sim* s, hipStream_t q) {
+  ProfScope ps(s, PROF_POST, q);
+  hipLaunchKernelGGL(k_post_physics, dim3((s->N + 63) / 64), dim3(64), 0, q, s->dm, s->st, s->n_post_steps);
+  int n = s->R * (MQE_HIST * MQE_FRAME / 4);
+  hipLaunchKernelGGL(k_reset_history, dim3((n + 255) / 256), dim3(256), 0, q, s->dm, s->st);
+  s->n_post_steps++;
+}
+
+extern "C" int mqe_policy_step(mqe_sim* s, const float* command, void* stream) {
+  policy_step(s, command, (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+extern "C" int mqe_defender_command(mqe_sim* s, float* out_dev, void* stream) {
+  if (s->d.task != MQE_TASK_FOOTBALL_DEFENDER) return fail(-7, "defender command needs the football-defender task");
+  hipLaunchKernelGGL(k_defender_command, dim3((s->N + 63) / 64), dim3(64), 0, (hipStream_t)stream, s->dm, s->st, out_dev);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+extern "C" int mqe_compute_torques(mqe_sim* s, void* stream) {
+  launch_torques(s, -1, (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+extern "C" int mqe_simulate(mqe_sim* s, void* stream) {
+  launch_simulate(s, (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+extern "C" int mqe_post_decimation_step(mqe_sim* s, int dec_i, void* stream) {
+  if (dec_i < 0 || dec_i >= 4) return fail(-1, "dec_i out of range");
+  size_t n = (size_t)12 * s->A;
+  HIPCHK(hipMemcpy2DAsync(s->st.sub_tau + (size_t)dec_i * n, 4 * n * 4, s->st.torques, n * 4, n * 4, s->N, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int mqe_post_physics_step(mqe_sim* s, void* stream) {
+  launch_post(s, (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+extern "C" int mqe_wrapper_eval(mqe_sim* s, int is_reset_call, void* stream) {
+  hipLaunchKernelGGL(k_wrapper_eval, dim3((s->N + 63) / 64), dim3(64), 0, (hipStream_t)stream, s->dm, s->st, is_reset_call);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+extern "C" int mqe_set_actor_root_state_indexed(mqe_sim*, const int32_t*, int, void*) { return 0; }
+extern "C" int mqe_set_dof_state_indexed(mqe_sim*, const int32_t*, int, void*) { return 0; }
+
+extern "C" int mqe_reset_all(mqe_sim* s, void* stream) {
+  hipStream_t q = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_reset_all, dim3((s->N + 63) / 64), dim3(64), 0, q, s->dm, s->st, s->n_post_steps == 0 ? 1 : 0);
+  int n = s->R * (MQE_HIST * MQE_FRAME / 4);
+  hipLaunchKernelGGL(k_reset_history, dim3((n + 255) / 256), dim3(256), 0, q, s->dm, s->st);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int mqe_step(mqe_sim* s, const float* actions, void* stream) {
+  hipStream_t q = (hipStream_t)stream;
+  {
+    ProfScope ps(s, PROF_MISC, q);
+    hipLaunchKernelGGL(k_wrapper_command, dim3((s->N + 63) / 64), dim3(64), 0, q, s->dm, s->st, actions);
+  }
+  policy_step(s, s->st.cmd, q);
+  for (int k = 0; k < s->d.decimation; k++) {
+    launch_torques(s, k < 4 ? k : 3, q);
+    launch_simulate(s, q);
+  }
+  launch_post(s, q);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// debug: M^-1 of one robot and the contact list of one env from the current state, without advancing it
+extern "C" int mqe_debug_dynamics(mqe_sim* s, int env, int robot, float* minv_out_host, int* nc_out_host, float* contacts_out_host) {
+  float *dm_, *dc; int* dn;
+  HIPCHK(hipMalloc(&dm_, 324 * 4)); HIPCHK(hipMalloc(&dc, 64 * 8 * 4)); HIPCHK(hipMalloc(&dn, 4));
+  PhysDebug dbg = {dm_, dn, dc, robot};
+  hipLaunchKernelGGL(k_simulate, dim3(1), dim3(64), s->phys_lds_bytes, 0, s->dm, s->st, env, 1, dbg);
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(minv_out_host, dm_, 324 * 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(nc_out_host, dn, 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(contacts_out_host, dc, 64 * 8 * 4, hipMemcpyDeviceToHost));
+  hipFree(dm_); hipFree(dc); hipFree(dn);
+  return 0;
+}

@@ -36,7 +36,9 @@ class HipEngine(EngineBase):
         vp = C.c_void_p
         for name, args in (("policy_step", [vp, vp, vp]), ("compute_torques", [vp, vp]), ("simulate", [vp, vp]),
                            ("post_decimation_step", [vp, C.c_int, vp]), ("post_physics_step", [vp, vp]),
-                           ("reset_all", [vp, vp]), ("step", [vp, vp, vp]),
+                           ("reset_all", [vp, vp]), ("step", [vp, vp, vp]), ("defender_command", [vp, vp, vp]),
+                           ("wrapper_eval", [vp, C.c_int, vp]),
+                           ("debug_dynamics", [vp, C.c_int, C.c_int, vp, C.POINTER(C.c_int), vp]),
                            ("profile_enable", [vp, C.c_int]),
                            ("profile_read", [vp, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)])):
             f = getattr(lib, "mqe_" + name)
@@ -52,6 +54,7 @@ class HipEngine(EngineBase):
     def policy_step(self, command):
         assert command.is_cuda and command.dtype == torch.float32 and command.is_contiguous()
         self._call("policy_step", C.c_void_p(command.data_ptr()), self._stream())
+        self._n_policy = getattr(self, "_n_policy", 0) + 1
 
     def compute_torques(self):
         self._call("compute_torques", self._stream())
@@ -71,6 +74,28 @@ class HipEngine(EngineBase):
     def step(self, actions):
         assert actions.is_cuda and actions.dtype == torch.float32 and actions.is_contiguous()
         self._call("step", C.c_void_p(actions.data_ptr()), self._stream())
+        self._n_policy = getattr(self, "_n_policy", 0) + 1
+
+    def defender_command(self, out):
+        self._call("defender_command", C.c_void_p(out.data_ptr()), self._stream())
+
+    def wrapper_eval(self, is_reset):
+        self._call("wrapper_eval", int(is_reset), self._stream())
+
+    def history(self):
+        """(R, 2100) time-ordered locomotion history gathered from the ring (host-side bookkeeping of the slot)."""
+        h = self.tensor(abi.T_HISTORY)
+        pos = getattr(self, "_n_policy", 0) % abi.HIST
+        idx = (torch.arange(abi.HIST, device=h.device) + pos) % abi.HIST
+        return h[:, idx, :70].reshape(h.shape[0], -1)
+
+    def debug_dynamics(self, env, robot):
+        minv = np.zeros((18, 18), np.float32)
+        nc = C.c_int(0)
+        con = np.zeros((64, 8), np.float32)
+        torch.cuda.synchronize()
+        self._call("debug_dynamics", int(env), int(robot), C.c_void_p(minv.ctypes.data), C.byref(nc), C.c_void_p(con.ctypes.data))
+        return minv, con[:nc.value]
 
     def profile_enable(self, on=True):
         self._call("profile_enable", int(bool(on)))

@@ -35,7 +35,8 @@ typedef REAL real;
 #define NB MQE_NBODY
 #define RD 18                       /* dofs of one robot: 3 lin + 3 ang + 12 joints */
 #define MAXDOF (MAXA * RD + MAXP * 6 + 1)
-#define MAXC 64                     /* contacts per env */
+#define MAXC 64                     /* storage; the active bound is env_maxc() */
+static inline int env_maxc(int A, int P) { int v = 16 * A + 4 * P; return v > 48 ? 48 : v; } /* = mqe_maxc() of the engine */
 #define FR MQE_FRAME
 #define OBS_BAG 74
 
@@ -532,6 +533,7 @@ static const int g_parent[NB] = {-1, 0, 1, 2, 0, 4, 5, 0, 7, 8, 0, 10, 11};
 static void fill_jac(const mqo_sim* s, const envwork_t* w, int act, int body, const real* p, real sign, const real dirs[3][3],
                      real J[3][MAXDOF], const real npc_pos[][3]) {
   int A = s->A;
+  const int lin_only = s->d.npc_kind == MQE_NPC_SHEEP;
   if (act < A) {
     int o = act * RD;
     const bodyk_t* bk = w->bk[act];
@@ -553,7 +555,7 @@ static void fill_jac(const mqo_sim* s, const envwork_t* w, int act, int body, co
       real e[3] = {0, 0, 0}; e[k] = 1;
       real r[3] = {p[0] - npc_pos[pi][0], p[1] - npc_pos[pi][1], p[2] - npc_pos[pi][2]};
       real wv[3]; cross3(e, r, wv);
-      for (int q = 0; q < 3; q++) { J[q][o + k] += sign * dirs[q][k]; J[q][o + 3 + k] += sign * dot3(dirs[q], wv); }
+      for (int q = 0; q < 3; q++) { J[q][o + k] += sign * dirs[q][k]; if (!lin_only) J[q][o + 3 + k] += sign * dot3(dirs[q], wv); }
     }
   }
 }
@@ -562,6 +564,9 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
   const mqe_sim_desc* d = &s->d;
   const mqe_robot_model* m = &d->robot;
   int A = s->A, P = (d->npc_kind == MQE_NPC_BALL || d->npc_kind == MQE_NPC_SHEEP) ? s->P : 0;
+  const int maxc = env_maxc(A, s->P);
+  /* sheep: translation-only bodies (orientation is scripted: go1_sheep.py:61 zeroes quat x,y every step) */
+  const int lin_only = d->npc_kind == MQE_NPC_SHEEP;
   real dt = d->dt;
   float* root = s->root + (size_t)env * (A + s->P) * 13;
   float* dofs = s->dof + (size_t)env * s->ND * 2;
@@ -702,7 +707,7 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
             sd = dist - r; n[0] = gx * sh / dist; n[1] = gy * sh / dist; n[2] = dz / dist;
           }
         }
-        if (sd < d->contact_offset && w->nc < MAXC) {
+        if (sd < d->contact_offset && w->nc < maxc) {
           contact_t* ct = &w->con[w->nc++];
           memset(ct, 0, sizeof *ct);
           ct->kind = 0; ct->actA = act; ct->sphA = si; ct->actB = -1; ct->sd = sd;
@@ -723,7 +728,7 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
           real e[3] = {ca[0] - cb[0], ca[1] - cb[1], ca[2] - cb[2]};
           real dist = (real)sqrt((double)dot3(e, e));
           real sd = dist - w->sph_r[a][sa] - w->sph_r[b][sb];
-          if (sd < d->contact_offset && w->nc < MAXC && dist > (real)1e-9) {
+          if (sd < d->contact_offset && w->nc < maxc && dist > (real)1e-9) {
             contact_t* ct = &w->con[w->nc++];
             memset(ct, 0, sizeof *ct);
             ct->kind = 1; ct->actA = a; ct->sphA = sa; ct->actB = b; ct->sphB = sb; ct->sd = sd;
@@ -828,6 +833,7 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
     float* rs = root + act * 13;
     real* v = act < A ? w->v + act * RD : w->v + A * RD + (act - A) * 6;
     for (int k = 0; k < 3; k++) { rs[k] = (float)(rs[k] + dt * v[k]); rs[7 + k] = (float)v[k]; rs[10 + k] = (float)v[3 + k]; }
+    if (act >= A && lin_only) { for (int k = 0; k < 3; k++) rs[10 + k] = (float)w->v[A * RD + (act - A) * 6 + 3 + k]; continue; }
     real q[4] = {rs[3], rs[4], rs[5], rs[6]}, wq[3] = {v[3], v[4], v[5]};
     /* qdot = 0.5 * (w,0) * q */
     real dq[4];

@@ -83,6 +83,16 @@ class OracleEngine(EngineBase):
         self.lib.mqo_defender_command(self.h, C.c_void_p(o.ctypes.data))
         out.copy_(torch.from_numpy(o))
 
+    def debug_dynamics(self, env, robot):
+        M = np.zeros((18, 18), np.float32)
+        minv = np.zeros((18, 18), np.float32)
+        nc = C.c_int(0)
+        con = np.zeros((64, 8), np.float32)
+        f = self.lib.mqo_debug_dynamics
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]
+        f(self.h, int(env), int(robot), C.c_void_p(M.ctypes.data), C.c_void_p(minv.ctypes.data), C.byref(nc), C.c_void_p(con.ctypes.data))
+        return M, minv, con[:nc.value]
+
     def history(self):
         R = self.desc.num_envs * self.desc.num_agents
         out = np.zeros((R, 2100), np.float32)

@@ -1,0 +1,127 @@
+"""-m gpu: the HIP engine (through the C ABI) against (1) the reference's golden traces for everything around the
+physics and (2) the CPU oracle for the physics, on identical seeded states."""
+import numpy as np
+import pytest
+import torch
+
+from mqe.engine import abi
+from helpers import hip_engine, oracle_engine, make_desc, to_dev, close
+from replay import replay
+from wrapper_replay import wrapper_replay
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["gate", "seesaw", "football", "sheep"])
+def test_hip_matches_reference_trace(name):
+    assert replay(name, hip_engine)
+
+
+@pytest.mark.parametrize("name", ["sheep_hard", "sheep_easy", "seesaw", "football_defender"])
+def test_hip_wrappers_match_reference(name):
+    assert wrapper_replay(name, hip_engine)
+
+
+def _pair(task, N, **kw):
+    d1, k1, ctx = make_desc(task, N, **kw)
+    d2, k2, _ = make_desc(task, N, **kw)
+    return hip_engine(d1, k1), oracle_engine(d2, k2), d1
+
+
+def _randomize(eh, eo, seed, drop=0.0, spread=1.0):
+    """identical perturbed states in both engines: reset, then jitter poses / velocities"""
+    eh.reset_all(); eo.reset_all()
+    torch.cuda.synchronize()
+    g = torch.Generator().manual_seed(seed)
+    ro, do = eo.tensor(abi.T_ROOT_STATE), eo.tensor(abi.T_DOF_STATE)
+    ro[:, :, 2] -= drop
+    ro[:, :, 0:2] += (torch.rand(ro[:, :, 0:2].shape, generator=g) - 0.5) * 0.2 * spread
+    q = ro[:, :, 3:7] + torch.randn(ro[:, :, 3:7].shape, generator=g) * 0.08 * spread
+    ro[:, :, 3:7] = q / q.norm(dim=-1, keepdim=True)
+    ro[:, :, 7:13] = torch.randn(ro[:, :, 7:13].shape, generator=g) * 0.3 * spread
+    do[:, :, 1] = torch.randn(do[:, :, 1].shape, generator=g) * 1.0 * spread
+    eh.tensor(abi.T_ROOT_STATE).copy_(ro.cuda()); eh.tensor(abi.T_DOF_STATE).copy_(do.cuda())
+    tau = (torch.rand(eo.tensor(abi.T_TORQUES).shape, generator=g) - 0.5) * 10
+    eo.tensor(abi.T_TORQUES).copy_(tau); eh.tensor(abi.T_TORQUES).copy_(tau.cuda())
+
+
+@pytest.mark.parametrize("task,N", [("go1gate", 64), ("go1football-defender", 16), ("go1sheep-hard", 14)])
+def test_mass_matrix_inverse_and_contacts(task, N):
+    eh, eo, d = _pair(task, N)
+    _randomize(eh, eo, 3, drop=0.12)
+    for env in (0, N // 2, N - 1):
+        for robot in range(d.num_agents):
+            mh, ch = eh.debug_dynamics(env, robot)
+            _, mo, co = eo.debug_dynamics(env, robot)
+            close(mh, mo, atol=2e-4, rtol=2e-3, what=f"Minv env {env} robot {robot}")
+            assert ch.shape == co.shape, (ch.shape, co.shape)
+            assert (ch[:, :4] == co[:, :4]).all(), "contact list (actor, body/sphere ids) must be identical and ordered"
+            close(ch[:, 4:], co[:, 4:], atol=2e-5, what="contact separation / normal")
+
+
+@pytest.mark.parametrize("task,N", [("go1gate", 256), ("go1football-defender", 32), ("go1sheep-hard", 21)])
+def test_single_substep_matches_oracle(task, N):
+    """one 5 ms simulate() from identical states: tolerance 2e-4 abs on positions/velocities (float32 both sides;
+    the HIP kernel sums in a different order: CRBA + Schur complement vs per-body Jacobian sums + Cholesky)"""
+    eh, eo, d = _pair(task, N)
+    for seed, drop in ((1, 0.0), (2, 0.11), (3, 0.2)):
+        _randomize(eh, eo, seed, drop=drop)
+        eh.simulate(); eo.simulate()
+        torch.cuda.synchronize()
+        close(eh.tensor(abi.T_DOF_STATE)[..., 0], eo.tensor(abi.T_DOF_STATE)[..., 0], atol=2e-5, what="dof pos")
+        close(eh.tensor(abi.T_DOF_STATE)[..., 1], eo.tensor(abi.T_DOF_STATE)[..., 1], atol=5e-3, rtol=1e-3, what="dof vel")
+        close(eh.tensor(abi.T_ROOT_STATE)[..., :7], eo.tensor(abi.T_ROOT_STATE)[..., :7], atol=2e-5, what="root pose")
+        close(eh.tensor(abi.T_ROOT_STATE)[..., 7:], eo.tensor(abi.T_ROOT_STATE)[..., 7:], atol=2e-3, rtol=1e-3, what="root vel")
+        close(eh.tensor(abi.T_CONTACT_FORCE), eo.tensor(abi.T_CONTACT_FORCE), atol=0.5, rtol=2e-2, what="net contact force")
+
+
+@pytest.mark.parametrize("task,N", [("go1gate", 128), ("go1football-defender", 16), ("go1sheep-hard", 14), ("go1seesaw", 16)])
+def test_fused_rollout_matches_oracle(task, N):
+    """20 fused step() calls (policy + 4 substeps + post-step + wrapper) from the seeded reset distribution.
+    Contact dynamics amplify rounding differences, so the bound is on the typical (median) deviation and flags."""
+    eh, eo, d = _pair(task, N)
+    eh.reset_all(); eo.reset_all()
+    g = torch.Generator().manual_seed(11)
+    Aw = eo.tensor(abi.T_WRAPPER_OBS).shape[1]
+    dev_pos, mism = [], 0
+    for t in range(20):
+        a = torch.rand(N, Aw, 3, generator=g) * 2 - 1
+        eh.step(a.cuda().contiguous()); eo.step(a)
+        torch.cuda.synchronize()
+        rh, ro = eh.tensor(abi.T_ROOT_STATE).cpu(), eo.tensor(abi.T_ROOT_STATE)
+        dev_pos.append((rh[..., :3] - ro[..., :3]).abs().max(dim=-1).values.flatten())
+        mism += int((eh.tensor(abi.T_RESET_BUF).cpu() != eo.tensor(abi.T_RESET_BUF)).sum())
+        if t == 0:
+            close(eh.tensor(abi.T_WRAPPER_OBS), eo.tensor(abi.T_WRAPPER_OBS), atol=2e-4, what="wrapper obs after 1 step")
+            close(eh.tensor(abi.T_ACTIONS), eo.tensor(abi.T_ACTIONS), atol=5e-5, what="policy actions step 0")
+    dev = torch.stack(dev_pos)
+    assert torch.isfinite(dev).all()
+    assert dev[4].median() < 1e-4, dev[4].median()
+    assert dev[-1].median() < 5e-3, dev[-1].median()
+    assert mism <= max(2, N // 16), f"{mism} reset-flag mismatches"
+
+
+def test_full_size_invariants():
+    """BASELINE config 1 (go1gate, 4096 envs x 2 agents): properties that do not need the oracle."""
+    d, k, ctx = make_desc("go1gate", 4096)
+    e = hip_engine(d, k)
+    e.reset_all()
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    for t in range(30):
+        a = torch.rand(4096, 2, 3, device="cuda", generator=g) * 2 - 1
+        e.step(a)
+    torch.cuda.synchronize()
+    root = e.tensor(abi.T_ROOT_STATE)
+    assert torch.isfinite(root).all() and torch.isfinite(e.tensor(abi.T_DOF_STATE)).all()
+    qn = root[..., 3:7].norm(dim=-1)
+    assert (qn - 1).abs().max() < 1e-4                                # unit quaternions
+    z = root[..., 2]
+    assert z.min() > 0.0 and z.max() < 1.0                             # nobody fell through the ground / flew away
+    obs = e.tensor(abi.T_WRAPPER_OBS)
+    assert obs.shape == (4096, 2, 16) and torch.isfinite(obs).all()
+    assert (obs[:, 0, 0] == 1).all() and (obs[:, 1, 1] == 1).all()     # one-hot ids
+    # joint limits hold (to solver tolerance)
+    q = e.tensor(abi.T_DOF_STATE)[..., 0].reshape(4096, 2, 12)
+    lo = torch.tensor([d.robot.dof_lower[j] for j in range(12)], device="cuda")
+    hi = torch.tensor([d.robot.dof_upper[j] for j in range(12)], device="cuda")
+    assert (q > lo - 0.05).all() and (q < hi + 0.05).all()
