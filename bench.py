@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/s of the go1gate step() hot path (BASELINE.json metric) on N MI355X GPUs.
+
+  python bench.py --gpus 1 --steps 500 --warmup 50
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one wrapper-level env.step(): task action scaling -> locomotion policy (adaptation + body MLP over the
+30-frame history) -> 4 x (actuator-net torques + 5 ms of rigid-body dynamics with contact) -> post-physics step
+(termination, in-kernel resets, observations) -> task observation/reward, for `num_envs` envs x 2 agents with
+fresh U(-1,1) actions every step (generator seed 1234).  Environments shard across ranks (weak scaling: 4096 envs
+per GPU); the only collective is the RCCL all-gather of the returned (obs, reward, done) batch.
+
+Prints ONE JSON line (rank 0).  value = agents x envs(all ranks) x steps / max-over-ranks wall time.
+`roofline`: dominant kernel (largest share of GPU time, HIP events on the launch stream over the timed region).
+`cpu_baseline`: the build's CPU restatement (oracle/, kind "port") timed on this box's host cores on a bounded sample.
+NOTE: body_latest.jit is missing from the reference snapshot, so the locomotion-policy body is the deterministic
+synthetic 2102-512-256-128-12 ELU MLP (mqe/utils/policy_weights.py); the adaptation module and actuator net are real.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "multiagent-quadruped-environment_amd"))
+
+import torch  # noqa: E402
+
+PROF_NAMES = ["gemm_layer0(k_gemm_f32)", "gemm_rest(k_gemm_f32+k_body_l0_finish+k_post_policy)", "torques(k_compute_torques)",
+              "simulate(k_simulate)", "post(k_post_physics+k_reset_history)", "misc(k_wrapper_command+k_pre_policy)"]
+PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak
+PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec peak
+
+
+def make_args(task, num_envs, seed, device):
+    from mqe.utils.helpers import finish_args
+    a = types.SimpleNamespace(task=task, num_envs=num_envs, seed=seed, headless=True, record_video=False,
+                              sim_device=device, pipeline="gpu", subscenes=0, num_threads=0)
+    return finish_args(a)
+
+
+def cpu_baseline(task, sample_envs, sample_steps):
+    """Time the CPU oracle (OpenMP over envs/robots) on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import make_desc
+    from oracle_engine import OracleEngine
+    from mqe.engine import abi
+    d, keep, _ = make_desc(task, sample_envs)
+    e = OracleEngine(d, keep)
+    e.reset_all()
+    g = torch.Generator().manual_seed(1234)
+    Aw = e.tensor(abi.T_WRAPPER_OBS).shape[1]
+    acts = [torch.rand(sample_envs, Aw, 3, generator=g) * 2 - 1 for _ in range(sample_steps + 2)]
+    e.step(acts[0]); e.step(acts[1])
+    t0 = time.perf_counter()
+    for t in range(sample_steps):
+        e.step(acts[2 + t])
+    dt = time.perf_counter() - t0
+    return d.num_agents * sample_envs * sample_steps / dt, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--task", type=str, default="go1gate")
+    ap.add_argument("--num_envs", type=int, default=4096, help="envs PER GPU (weak scaling)")
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--cpu_sample_envs", type=int, default=128)
+    ap.add_argument("--cpu_sample_steps", type=int, default=20)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+
+    from mqe.envs.utils import make_mqe_env, custom_cfg, ENV_DICT
+    from mqe.envs.go1.go1 import Go1
+    N = args.num_envs
+    Go1.shard = (N * world, N * rank)           # global env ids -> identical scene regardless of the GPU count
+    margs = make_args(args.task, N, 0, dev)
+    env, cfg = make_mqe_env(args.task, margs, custom_cfg(margs))
+    A = env.num_agents
+    eng = env.env.engine
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    obs = env.reset()
+    gather = None
+    if world > 1:
+        packed_dim = obs.shape[1] * obs.shape[2] + A + 1
+        gather = torch.empty(world * N, packed_dim, device=dev)
+
+    def one_step():
+        a = torch.rand(N, A, 3, device=dev, generator=gen) * 2 - 1
+        o, r, d, info = env.step(a)
+        if world > 1:   # the one collective of the path: all-gather the returned batch (packed: obs | reward | done)
+            packed = torch.cat([o.reshape(N, -1), r.reshape(N, -1), d.reshape(N, 1).float()], dim=1)
+            dist.all_gather_into_tensor(gather, packed)
+        return o
+
+    for _ in range(args.warmup):
+        one_step()
+    eng.profile_enable(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ms, _ = eng.profile_read(12)
+    eng.profile_enable(False)
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    value = A * N * world * args.steps / elapsed
+
+    if rank == 0:
+        kms = ms[:6]
+        cnt = ms[6:12]
+        tot = sum(kms) or 1.0
+        dom = max(range(6), key=lambda i: kms[i])
+        R = N * A
+        roof = None
+        if dom in (0, 1):
+            d = eng.desc
+            h_a, h_b = d.adaptation.dims[1], d.body.dims[1]
+            flops = 2.0 * R * 2100 * (h_a + h_b)                      # algorithmic: unpadded K = 30 x 70
+            avg_ms = kms[0] / max(cnt[0], 1)
+            ach = flops / (avg_ms * 1e-3) / 1e12
+            roof = {"kernel": "k_gemm_f32 (fused layer 0 of adaptation+body MLP over the history ring)", "bound": "mfma",
+                    "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                    "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": int(cnt[0])}
+        else:
+            avg_ms = kms[dom] / max(cnt[dom], 1)
+            per_launch = {3: 4, 2: 4}.get(dom, 1)
+            byts = 10128.0 * R / per_launch                           # 10128 B per agent-step, 4 launches/step
+            ach = byts / (avg_ms * 1e-3) / 1e9
+            roof = {"kernel": PROF_NAMES[dom], "bound": "hbm", "achieved": round(ach, 3), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": round(ach / PEAK_HBM_GBS, 6), "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": int(cnt[dom])}
+        step_bytes = 10128.0 * R
+        out = {
+            "metric": "env-steps/sec (agents x envs x steps/s), go1gate 4096 envs x 2 agents per GPU",
+            "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic (U(-1,1) actions seed 1234; synthetic body MLP: body_latest.jit missing upstream)",
+            "config": {"workload": f"{args.task}, {A} agents, num_envs={N} per GPU ({N * world} total), 4 substeps x 5 ms per step",
+                       "parallelism": f"env-sharded x{world}, all-gather of the returned batch" if world > 1 else "single GPU"},
+            "target_env_steps_per_s": 1.0e6,
+            "roofline": roof,
+            "hbm_step_algorithmic_GBps": round(step_bytes * args.steps / elapsed / 1e9, 3),
+            "kernel_time_share": {PROF_NAMES[i]: round(kms[i] / tot, 4) for i in range(6)},
+            "gpu_busy_ms_per_step": round(tot / args.steps, 4),
+        }
+        if not args.no_cpu_baseline and world == 1:
+            torch.set_num_threads(os.cpu_count() or 1)
+            v, secs = cpu_baseline(args.task, args.cpu_sample_envs, args.cpu_sample_steps)
+            out["cpu_baseline"] = {"value": round(v, 1), "unit": "env-steps/s", "cores": int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)),
+                                   "kind": "port", "sample": f"{args.task} {args.cpu_sample_envs} envs x {args.cpu_sample_steps} steps, build's CPU restatement (oracle/), {secs:.1f} s"}
+        print(json.dumps(out))
+    env.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

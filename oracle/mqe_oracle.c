@@ -891,7 +891,9 @@ int mqo_debug_dynamics(mqo_sim* s, int env, int robot, float* M_out /*18x18*/, f
   *nc_out = w->nc;
   for (int c = 0; c < w->nc; c++) {
     float* o = contacts_out + c * 8;
-    o[0] = (float)w->con[c].actA; o[1] = (float)w->con[c].sphA; o[2] = (float)w->con[c].actB; o[3] = (float)w->con[c].sphB;
+    const contact_t* ct = &w->con[c];   /* (actor, dynamic body) pairs, -1/0 for static geometry */
+    o[0] = (float)ct->actA; o[1] = (float)(ct->actA < A ? s->d.robot.sphere_body[ct->sphA] : 0);
+    o[2] = (float)ct->actB; o[3] = (float)((ct->actB >= 0 && ct->actB < A) ? s->d.robot.sphere_body[ct->sphB] : 0);
     o[4] = (float)w->con[c].sd; o[5] = (float)w->con[c].n[0]; o[6] = (float)w->con[c].n[1]; o[7] = (float)w->con[c].n[2];
   }
   free(w);
