@@ -163,6 +163,7 @@ typedef struct mqe_sim mqe_sim;
 
 const char* mqe_last_error(void);
 int mqe_abi_version(void);
+int mqe_sizeof_desc(void);   /* sizeof(mqe_sim_desc): lets a foreign-language binding verify its struct mirror */
 
 /* gym.create_sim + load_asset + create_env/create_actor + add_triangle_mesh + prepare_sim
  * (reference legged_robot.py:255-261,754-923; barrier_track.py:395-410; base_task.py:91) */

@@ -42,13 +42,15 @@ __device__ __forceinline__ float wave_sum(float x) {
 
 #define BODY_STRIDE 32
 #define CON_STRIDE 32
+#define JS_MAXNZ 18                 // nonzero Jacobian columns of one contact: 9 per articulated side
+#define JS_STRIDE (4 + 4 * JS_MAXNZ) // [0] = count, then (j_n, j_t1, j_t2, dof index) per nonzero column
 enum { B_R = 0, B_P = 9, B_W = 12, B_VP = 15, B_A = 18, B_AL = 21, B_AP = 24, B_C = 27, B_M = 30 };
 enum { C_IDS = 0, C_P = 4, C_N = 7, C_T1 = 10, C_T2 = 13, C_SD = 16, C_BIAS = 17, C_K = 18, C_LAM = 24, C_REP = 27 };
 
-__host__ __device__ inline int mqe_maxc(int A, int P) { int v = 16 * A + 4 * P; return v > 48 ? 48 : v; }
+__host__ __device__ inline int mqe_maxc(int A, int P) { int v = 12 * A + P; return v > 32 ? 32 : v; }
 
 struct PhysLds {   // float offsets into dynamic LDS
-  int root, dof, tau, body, minv, rhs, fcol, leg, basei, sinv, sph, con, B, W, cfacc, total;
+  int root, dof, tau, body, minv, rhs, fcol, leg, basei, sinv, sph, con, B, W, js, kk, total;
 };
 __host__ __device__ inline PhysLds phys_lds_layout(int A, int P, int ND, int nbody, int ndof, int nsph, int maxc, int bstride) {
   PhysLds L; int o = 0;
@@ -68,11 +70,14 @@ __host__ __device__ inline PhysLds phys_lds_layout(int A, int P, int ND, int nbo
   L.con = o; o += maxc * CON_STRIDE;
   L.B = o; o += maxc * 3 * bstride;
   L.W = o; o += 64 * 4;
+  L.js = o; o += maxc * JS_STRIDE;
+  L.kk = o; o += maxc * maxc * 9;
   L.total = o;
   return L;
 }
 
-struct PhysDebug { float* minv; int* nc; float* contacts; int robot; };
+struct PhysDebug { float* minv; int* nc; float* contacts; int robot; long long* times; };
+#define TSTAMP(i) do { if (dbg.times != nullptr && lane == 0) dbg.times[i] = clock64(); } while (0)
 
 __global__ void __launch_bounds__(64) k_simulate(const DevModel* __restrict__ m, DevState st, int env_base, int no_write, PhysDebug dbg) {
   extern __shared__ float lds[];
@@ -86,12 +91,14 @@ __global__ void __launch_bounds__(64) k_simulate(const DevModel* __restrict__ m,
   float* g_root = st.root + (size_t)e * (A + P) * 13;
   float* g_dof = st.dof + (size_t)e * m->ND * 2;
 
+  TSTAMP(0);
   // ---- coalesced state load -------------------------------------------------------------------------------
   for (int i = lane; i < (A + P) * 13; i += 64) lds[L.root + i] = g_root[i];
   for (int i = lane; i < m->ND * 2; i += 64) lds[L.dof + i] = g_dof[i];
   for (int i = lane; i < 12 * A; i += 64) lds[L.tau + i] = st.torques[(size_t)e * 12 * A + i];
   __syncthreads();
 
+  TSTAMP(1);
   // ---- forward kinematics by tree level (body lanes) ---------------------------------------------------------
   const bool is_body = lane < nbody;
   const bool is_rbody = lane < A * MQE_NBODY;
@@ -162,6 +169,7 @@ __global__ void __launch_bounds__(64) k_simulate(const DevModel* __restrict__ m,
     myrec[B_M] = bmass;
   }
 
+  TSTAMP(2);
   // ---- spatial inertia + bias wrench about o = base origin; composite sums up each leg ------------------------
   // X[0]=m, X[1:4]=h=m*(c-o), X[4:10]=Ibar (sym6), X[10:13]=moment about o, X[13:16]=force
   float X[16];
@@ -224,6 +232,7 @@ __global__ void __launch_bounds__(64) k_simulate(const DevModel* __restrict__ m,
     }
   }
   __syncthreads();
+  TSTAMP(3);
   // ---- leg blocks: Mi = Mll^-1, G = Mbl Mi (6x3), C = G Mbl^T (6x6 sym) ----------------------------------------
   if (lane < A * 4) {
     float* Ml = lds + L.leg + lane * 54;
@@ -243,6 +252,7 @@ __global__ void __launch_bounds__(64) k_simulate(const DevModel* __restrict__ m,
       for (int n = mm; n < 6; n++) Ml[30 + q++] = G[mm * 3] * fc[n] + G[mm * 3 + 1] * fc[6 + n] + G[mm * 3 + 2] * fc[12 + n];
   }
   __syncthreads();
+  TSTAMP(4);
   // ---- 6x6 Schur complement inverse: lane (robot, column) --------------------------------------------------------
   if (lane < A * 6) {
     const int r = lane / 6, col = lane - r * 6;
@@ -297,6 +307,7 @@ __global__ void __launch_bounds__(64) k_simulate(const DevModel* __restrict__ m,
     for (int i = 0; i < 6; i++) Si[i * 6 + col] = x[i];
   }
   __syncthreads();
+  TSTAMP(5);
   // ---- rows of M^-1 (18 x 18 per robot) ---------------------------------------------------------------------------
   for (int d = lane; d < A * MQE_RD; d += 64) {
     const int r = d / MQE_RD, k = d - r * MQE_RD;
@@ -332,6 +343,7 @@ __global__ void __launch_bounds__(64) k_simulate(const DevModel* __restrict__ m,
   }
   __syncthreads();
 
+  TSTAMP(6);
   // ---- dof-lane constants + unconstrained velocity ------------------------------------------------------------------
   const bool is_dof = lane < ndof;
   const bool is_rdof = lane < A * MQE_RD;
@@ -372,6 +384,7 @@ __global__ void __launch_bounds__(64) k_simulate(const DevModel* __restrict__ m,
     if (dk == 2) vd += dt * m->gravity_z;
   }
 
+  TSTAMP(7);
   // ---- collision spheres ----------------------------------------------------------------------------------------------
   const int nsr = rm.n_spheres;
   for (int s = lane; s < nsph; s += 64) {
@@ -392,6 +405,7 @@ __global__ void __launch_bounds__(64) k_simulate(const DevModel* __restrict__ m,
   }
   __syncthreads();
 
+  TSTAMP(8);
   // ---- contact generation: terrain (ground plane, wall SDF), canonical order --------------------------------------------
   int nc = 0;
   for (int s0 = 0; s0 < nsph; s0 += 64) {
@@ -458,6 +472,7 @@ __global__ void __launch_bounds__(64) k_simulate(const DevModel* __restrict__ m,
     nc += __popcll(bg) + __popcll(bw2);
     if (nc > maxc) nc = maxc;
   }
+  TSTAMP(9);
   // ---- sphere-sphere contacts between different actors (a < b; outer loop over b's spheres, lanes = a's spheres) -------
   {
     const int nact = A + PD;
@@ -503,6 +518,7 @@ __global__ void __launch_bounds__(64) k_simulate(const DevModel* __restrict__ m,
   }
   __syncthreads();
 
+  TSTAMP(10);
   // ---- per contact: tangents, B = M^-1 J^T rows, K = J B, bias ---------------------------------------------------------------
   float* Wx = lds + L.W;
   for (int c = 0; c < nc; c++) {
@@ -539,15 +555,25 @@ __global__ void __launch_bounds__(64) k_simulate(const DevModel* __restrict__ m,
       float* Bc = lds + L.B + c * 3 * bs;
       Bc[lane] = b0; Bc[bs + lane] = b1; Bc[2 * bs + lane] = b2;
     }
-    const float k00 = wave_sum(j0 * b0), k11 = wave_sum(j1 * b1), k22 = wave_sum(j2 * b2);
-    const float k10 = wave_sum(j1 * b0), k20 = wave_sum(j2 * b0), k21 = wave_sum(j2 * b1);
+    // sparse Jacobian rows: only the dofs on the kinematic chain(s) of the touching bodies are nonzero (<= 9 per side)
+    float* js = lds + L.js + c * JS_STRIDE;
+    const bool nz = sgn != 0.0f;
+    const unsigned long long bnz = __ballot(nz);
+    {
+      const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+      const int slot = __popcll(bnz & lower);
+      if (nz && slot < JS_MAXNZ) { float* en = js + 4 + slot * 4; en[0] = j0; en[1] = j1; en[2] = j2; en[3] = __int_as_float(lane); }
+    }
+    int nnz = __popcll(bnz);
+    if (nnz > JS_MAXNZ) nnz = JS_MAXNZ;
     if (lane == 0) {
+      js[0] = __int_as_float(nnz);
       st3(cr + C_T1, t1); st3(cr + C_T2, t2);
       const float sd = cr[C_SD];
       cr[C_BIAS] = sd >= 0 ? -sd / dt : fminf(-sd * m->erp / dt, m->max_depen);
-      cr[C_K] = k00; cr[C_K + 1] = k11; cr[C_K + 2] = k22; cr[C_K + 3] = k10; cr[C_K + 4] = k20; cr[C_K + 5] = k21;
       cr[C_LAM] = 0; cr[C_LAM + 1] = 0; cr[C_LAM + 2] = 0;
     }
+    __syncthreads();
     __syncthreads();
   }
 
@@ -559,40 +585,94 @@ __global__ void __launch_bounds__(64) k_simulate(const DevModel* __restrict__ m,
     const float q = lds[L.dof + (dact * 12 + dk - 6) * 2];
     jlo = (rm.dof_lower[dk - 6] - q) / dt; jhi = (rm.dof_upper[dk - 6] - q) / dt;
   }
-  for (int it = 0; it < m->solver_iterations; it++) {
-    for (int c = 0; c < nc; c++) {
-      float* cr = lds + L.con + c * CON_STRIDE;
-      const int actA = __float_as_int(cr[C_IDS]), bodyA = __float_as_int(cr[C_IDS + 1]);
-      const int actB = __float_as_int(cr[C_IDS + 2]), bodyB = __float_as_int(cr[C_IDS + 3]);
-      const V3 p = ld3(cr + C_P), n = ld3(cr + C_N), t1 = ld3(cr + C_T1), t2 = ld3(cr + C_T2);
-      float sgn = 0.0f;
-      if (is_dof) {
-        if (dact == actA && ((dmask >> bodyA) & 1u)) sgn = 1.0f;
-        else if (dact == actB && ((dmask >> bodyB) & 1u)) sgn = -1.0f;
-      }
-      const V3 wv = (sgn * vd) * (dlin ? dax : cross(dax, p - danc));
-      const V3 uw = v3(wave_sum(wv.x), wave_sum(wv.y), wave_sum(wv.z));
-      float u0 = dot(n, uw), u1 = dot(t1, uw), u2 = dot(t2, uw);
-      const float l0o = cr[C_LAM], l1o = cr[C_LAM + 1], l2o = cr[C_LAM + 2];
-      float ln = l0o - (u0 - cr[C_BIAS]) / cr[C_K];
-      ln = fmaxf(ln, 0.0f);
-      const float d0 = ln - l0o;
-      u1 += cr[C_K + 3] * d0; u2 += cr[C_K + 4] * d0;
-      const float lim = mu * ln;
-      float l1 = clampf(l1o - u1 / cr[C_K + 1], -lim, lim);
-      const float d1 = l1 - l1o;
-      u2 += cr[C_K + 5] * d1;
-      float l2 = clampf(l2o - u2 / cr[C_K + 2], -lim, lim);
-      const float d2 = l2 - l2o;
-      __syncthreads();
-      if (lane == 0) { cr[C_LAM] = ln; cr[C_LAM + 1] = l1; cr[C_LAM + 2] = l2; }
-      if (is_dof) {
-        const float* Bc = lds + L.B + c * 3 * bs;
-        vd += Bc[lane] * d0 + Bc[bs + lane] * d1 + Bc[2 * bs + lane] * d2;
-      }
-      __syncthreads();
+  TSTAMP(11);
+  // ---- projected Gauss-Seidel in CONTACT space, lane = contact ------------------------------------------------------------
+  // Each lane owns one contact: relative velocity u (3), impulse lambda (3).  One GS step = the owning lane's impulse
+  // increment (row-wise: normal, then the two friction rows with box limits mu*lambda_n), broadcast with v_readlane, and
+  // every lane adds its 3x3 coupling block KK[c'][c] = J_c M^-1 J_c'^T times the increment.  No LDS round trip or wave
+  // reduction sits on the serial chain.  Mathematically identical to the velocity-space sweep of the CPU oracle.
+  float* Vm = lds + L.rhs + 64;      // v* (unconstrained velocity), read through the sparse Jacobian rows
+  Vm[lane] = vd;
+  __syncthreads();
+  float cu0 = 0, cu1 = 0, cu2 = 0, cl0 = 0, cl1 = 0, cl2 = 0, cbias = 0;
+  float ik00 = 0, ik11 = 0, ik22 = 0, ck10 = 0, ck20 = 0, ck21 = 0;
+  const bool is_con = lane < nc;
+  if (is_con) {
+    const float* js = lds + L.js + lane * JS_STRIDE;
+    const int nnz = __float_as_int(js[0]);
+    for (int i = 0; i < nnz; i++) {
+      const float4 en = *reinterpret_cast<const float4*>(js + 4 + i * 4);
+      const float vv = Vm[__float_as_int(en.w)];
+      cu0 += en.x * vv; cu1 += en.y * vv; cu2 += en.z * vv;
     }
-    // joint limits: sequential over joints in (robot, joint) order, only when some lane violates
+    cbias = lds[L.con + lane * CON_STRIDE + C_BIAS];
+    for (int c2 = 0; c2 < nc; c2++) {
+      const float* Bc = lds + L.B + c2 * 3 * bs;
+      float k[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      for (int i = 0; i < nnz; i++) {
+        const float4 en = *reinterpret_cast<const float4*>(js + 4 + i * 4);
+        const int idx = __float_as_int(en.w);
+        const float b0 = Bc[idx], b1 = Bc[bs + idx], b2 = Bc[2 * bs + idx];
+        k[0] += en.x * b0; k[1] += en.x * b1; k[2] += en.x * b2;
+        k[3] += en.y * b0; k[4] += en.y * b1; k[5] += en.y * b2;
+        k[6] += en.z * b0; k[7] += en.z * b1; k[8] += en.z * b2;
+      }
+      float* kk = lds + L.kk + (c2 * maxc + lane) * 9;
+#pragma unroll
+      for (int q = 0; q < 9; q++) kk[q] = k[q];
+      if (c2 == lane) { ik00 = 1.0f / k[0]; ik11 = 1.0f / k[4]; ik22 = 1.0f / k[8]; ck10 = k[3]; ck20 = k[6]; ck21 = k[7]; }
+    }
+  }
+  __syncthreads();
+  TSTAMP(12);
+  {
+    // software-pipelined: the coupling block for the NEXT step is fetched while the current step's scalar chain runs
+    float kn[9];
+    const float* kbase = lds + L.kk + lane * 9;
+#pragma unroll
+    for (int q = 0; q < 9; q++) kn[q] = (is_con && nc > 0) ? kbase[q] : 0.0f;
+    const int total = m->solver_iterations * nc;
+    int c = 0;
+    for (int stp = 0; stp < total; stp++) {
+      float kk[9];
+#pragma unroll
+      for (int q = 0; q < 9; q++) kk[q] = kn[q];
+      const int cnext = (c + 1 == nc) ? 0 : c + 1;
+      {
+        const float* kp = kbase + cnext * maxc * 9;
+#pragma unroll
+        for (int q = 0; q < 9; q++) kn[q] = is_con ? kp[q] : 0.0f;
+      }
+      // every lane evaluates the update for its own contact; only lane c's result is used
+      const float ln = fmaxf(cl0 - (cu0 - cbias) * ik00, 0.0f);
+      const float d0 = ln - cl0;
+      const float lim = mu * ln;
+      const float l1 = clampf(cl1 - (cu1 + ck10 * d0) * ik11, -lim, lim);
+      const float d1 = l1 - cl1;
+      const float l2 = clampf(cl2 - (cu2 + ck20 * d0 + ck21 * d1) * ik22, -lim, lim);
+      const float d2 = l2 - cl2;
+      const float e0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d0), c));
+      const float e1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d1), c));
+      const float e2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d2), c));
+      if (lane == c) { cl0 = ln; cl1 = l1; cl2 = l2; }
+      cu0 += kk[0] * e0 + kk[1] * e1 + kk[2] * e2;
+      cu1 += kk[3] * e0 + kk[4] * e1 + kk[5] * e2;
+      cu2 += kk[6] * e0 + kk[7] * e1 + kk[8] * e2;
+      c = cnext;
+    }
+  }
+  TSTAMP(13);
+  if (is_con) { float* cr = lds + L.con + lane * CON_STRIDE; cr[C_LAM] = cl0; cr[C_LAM + 1] = cl1; cr[C_LAM + 2] = cl2; }
+  __syncthreads();
+  if (is_dof) {
+    for (int c = 0; c < nc; c++) {
+      const float* cr = lds + L.con + c * CON_STRIDE;
+      const float* Bc = lds + L.B + c * 3 * bs;
+      vd += Bc[lane] * cr[C_LAM] + Bc[bs + lane] * cr[C_LAM + 1] + Bc[2 * bs + lane] * cr[C_LAM + 2];
+    }
+  }
+  // joint limits: one sequential pass in (robot, joint) order after the contact solve, only when some lane violates
+  {
     bool viol = is_joint && (vd < jlo || vd > jhi);
     if (__ballot(viol) != 0ull) {
       for (int r = 0; r < A; r++)
@@ -610,6 +690,7 @@ __global__ void __launch_bounds__(64) k_simulate(const DevModel* __restrict__ m,
     }
   }
 
+  TSTAMP(14);
   if (dbg.minv != nullptr) {
     for (int i = lane; i < MQE_RD * MQE_RD; i += 64) dbg.minv[i] = lds[L.minv + dbg.robot * MQE_RD * MQE_RD + i];
     if (lane == 0) *dbg.nc = nc;

@@ -60,6 +60,7 @@ struct mqe_sim {
 
 extern "C" const char* mqe_last_error(void) { return g_err; }
 extern "C" int mqe_abi_version(void) { return MQE_ABI_VERSION; }
+extern "C" int mqe_sizeof_desc(void) { return (int)sizeof(mqe_sim_desc); }
 
 template <typename T>
 static int dalloc(mqe_sim* s, T** p, size_t n, int fill_zero = 1) {
@@ -407,7 +408,7 @@ static void launch_torques(mqe_sim* s, int dec_i, hipStream_t q) {
 }
 static void launch_simulate(mqe_sim* s, hipStream_t q) {
   ProfScope ps(s, PROF_SIMULATE, q);
-  PhysDebug dbg = {nullptr, nullptr, nullptr, 0};
+  PhysDebug dbg = {nullptr, nullptr, nullptr, 0, nullptr};
   hipLaunchKernelGGL(k_simulate, dim3(s->N), dim3(64), s->phys_lds_bytes, q, s->dm, s->st, 0, 0, dbg);
 }
 static void launch_post(mqe_sim* s, hipStream_t q) {
@@ -484,15 +485,20 @@ extern "C" int mqe_step(mqe_sim* s, const float* actions, void* stream) {
 }
 
 // debug: M^-1 of one robot and the contact list of one env from the current state, without advancing it
+static long long g_dbg_times[16];
+extern "C" int mqe_debug_times(long long* out16) { memcpy(out16, g_dbg_times, sizeof g_dbg_times); return 0; }
 extern "C" int mqe_debug_dynamics(mqe_sim* s, int env, int robot, float* minv_out_host, int* nc_out_host, float* contacts_out_host) {
-  float *dm_, *dc; int* dn;
-  HIPCHK(hipMalloc(&dm_, 324 * 4)); HIPCHK(hipMalloc(&dc, 64 * 8 * 4)); HIPCHK(hipMalloc(&dn, 4));
-  PhysDebug dbg = {dm_, dn, dc, robot};
+  float *dm_, *dc; int* dn; long long* dtm;
+  HIPCHK(hipMalloc(&dm_, 324 * 4)); HIPCHK(hipMalloc(&dc, 64 * 8 * 4)); HIPCHK(hipMalloc(&dn, 4)); HIPCHK(hipMalloc(&dtm, 16 * 8));
+  HIPCHK(hipMemset(dtm, 0, 16 * 8));
+  PhysDebug dbg = {dm_, dn, dc, robot, dtm};
   hipLaunchKernelGGL(k_simulate, dim3(1), dim3(64), s->phys_lds_bytes, 0, s->dm, s->st, env, 1, dbg);
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(minv_out_host, dm_, 324 * 4, hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(nc_out_host, dn, 4, hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(contacts_out_host, dc, 64 * 8 * 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(g_dbg_times, dtm, 16 * 8, hipMemcpyDeviceToHost));
+  hipFree(dtm);
   hipFree(dm_); hipFree(dc); hipFree(dn);
   return 0;
 }

@@ -92,7 +92,7 @@ def task_kind(cfg):
 
 
 def build_desc(cfg, num_envs, terrain, env_origins, agent_origins, gate_pos=None, env_id_offset=0, seed=0,
-               task=None, body=None, resources_root=None, solver_iterations=8, erp=0.2, noise_mode=0):
+               task=None, body=None, resources_root=None, solver_iterations=None, erp=0.2, noise_mode=0):
     """Returns (SimDesc, keepalive) -- keepalive holds the numpy arrays the struct points into."""
     keep = []
     d = abi.SimDesc()
@@ -106,7 +106,8 @@ def build_desc(cfg, num_envs, terrain, env_origins, agent_origins, gate_pos=None
     d.env_id_offset, d.seed = env_id_offset, seed
     px = cfg.sim.physx
     d.dt, d.decimation, d.gravity_z = cfg.sim.dt, cfg.control.decimation, cfg.sim.gravity[2]
-    d.solver_iterations = solver_iterations
+    # PhysX TGS position iterations (legged_robot_config.py:221) -> projected Gauss-Seidel sweeps of the engine
+    d.solver_iterations = int(solver_iterations if solver_iterations is not None else px.num_position_iterations)
     d.contact_offset, d.max_depenetration_velocity = px.contact_offset, px.max_depenetration_velocity
     d.friction = 0.5 * (cfg.terrain.static_friction + 1.0)   # average of terrain and (default 1.0) shape friction
     d.erp = erp

@@ -36,12 +36,14 @@ typedef REAL real;
 #define RD 18                       /* dofs of one robot: 3 lin + 3 ang + 12 joints */
 #define MAXDOF (MAXA * RD + MAXP * 6 + 1)
 #define MAXC 64                     /* storage; the active bound is env_maxc() */
-static inline int env_maxc(int A, int P) { int v = 16 * A + 4 * P; return v > 48 ? 48 : v; } /* = mqe_maxc() of the engine */
+static inline int env_maxc(int A, int P) { int v = 12 * A + P; return v > 32 ? 32 : v; } /* = mqe_maxc() of the engine */
 #define FR MQE_FRAME
 #define OBS_BAG 74
 
 static char g_err[512];
 const char* mqo_last_error(void) { return g_err; }
+int mqo_sizeof_desc(void) { return (int)sizeof(mqe_sim_desc); }
+int mqo_num_threads(void);
 
 typedef struct {
   int n_layers;
@@ -793,7 +795,9 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
       dl[2] = l2 - ct->lam[2]; ct->lam[2] = l2;
       for (int i = 0; i < ndof; i++) w->v[i] += ct->B[0][i] * dl[0] + ct->B[1][i] * dl[1] + ct->B[2][i] * dl[2];
     }
-    /* joint limits: q + dt*qd within [lower, upper] */
+  }
+  {
+    /* joint limits: q + dt*qd within [lower, upper]; one pass after the contact iterations */
     for (int r = 0; r < A; r++)
       for (int j = 0; j < 12; j++) {
         real q = dofs[(r * 12 + j) * 2];
@@ -1323,3 +1327,10 @@ int mqo_step(mqo_sim* s, const float* actions) {
   mqo_post_physics_step(s);
   return 0;
 }
+
+#ifdef _OPENMP
+#include <omp.h>
+int mqo_num_threads(void) { return omp_get_max_threads(); }
+#else
+int mqo_num_threads(void) { return 1; }
+#endif

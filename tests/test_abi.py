@@ -1,0 +1,45 @@
+"""The C-ABI library loads on a CPU-only host and exports every entry point include/mqe_hip.h declares; the ctypes
+mirror of the descriptor has the size the C compiler gives it.  No compute calls (no GPU here)."""
+import ctypes as C
+import os
+import re
+
+from mqe.engine import abi
+from mqe.engine.hip_engine import LIB_PATH
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    h = open(os.path.join(ROOT, "include", "mqe_hip.h")).read()
+    h = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
+    return sorted(set(re.findall(r"\b(mqe_[a-z_0-9]+)\s*\(", h)))
+
+
+def test_header_symbols_exported():
+    assert os.path.isfile(LIB_PATH), "run __graft_entry__.build() first"
+    lib = C.CDLL(LIB_PATH)
+    syms = declared_symbols()
+    assert len(syms) >= 18
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/mqe_hip.h but not exported by libmqe_hip.so"
+
+
+def test_struct_mirror_size():
+    lib = C.CDLL(LIB_PATH)
+    assert lib.mqe_abi_version() == abi.ABI_VERSION
+    assert lib.mqe_sizeof_desc() == C.sizeof(abi.SimDesc)
+    import oracle_engine
+    assert oracle_engine.load_library().mqo_sizeof_desc() == C.sizeof(abi.SimDesc)
+
+
+def test_product_refuses_without_gpu():
+    import pytest
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from helpers import make_desc
+    from mqe.engine.hip_engine import HipEngine
+    d, k, _ = make_desc("go1gate", 2)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        HipEngine(d, k)

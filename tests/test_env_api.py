@@ -1,0 +1,128 @@
+"""The Python plugin surface (make_mqe_env / ENV_DICT / wrappers / OpenRL adapter, SURVEY 8b outer boundary), driven on
+CPU by injecting the oracle engine through Go1.engine_factory (tests only; the product default is the HIP engine)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import golden
+from mqe.envs.go1.go1 import Go1
+from mqe.envs.utils import ENV_DICT, make_mqe_env, custom_cfg
+from mqe.utils.helpers import finish_args
+
+
+def _oracle_factory(desc, keep, device):
+    from oracle_engine import OracleEngine
+    return OracleEngine(desc, keep)
+
+
+@pytest.fixture
+def oracle_backed(monkeypatch):
+    monkeypatch.setattr(Go1, "engine_factory", staticmethod(_oracle_factory))
+    monkeypatch.setattr(Go1, "shard", None)
+    saved = {k: v["config"].env.num_envs for k, v in ENV_DICT.items()}
+    yield
+    for k, v in ENV_DICT.items():
+        v["config"].env.num_envs = saved[k]
+
+
+def args_for(task, n):
+    return finish_args(types.SimpleNamespace(task=task, num_envs=n, seed=0, headless=True, record_video=False,
+                                             sim_device="cpu", pipeline="cpu", subscenes=0, num_threads=0))
+
+
+@pytest.mark.parametrize("task,A,Aw,D", [("go1gate", 2, 2, 16), ("go1sheep-hard", 2, 2, 34), ("go1seesaw", 2, 2, 14),
+                                         ("go1football-defender", 3, 2, 20)])
+def test_make_mqe_env_surface(oracle_backed, task, A, Aw, D):
+    a = args_for(task, 4)
+    env, cfg = make_mqe_env(task, a, custom_cfg(a))
+    assert cfg is ENV_DICT[task]["config"] and cfg.env.num_envs == 4
+    assert env.num_envs == 4 and env.env.num_agents == A and env.num_agents == Aw
+    assert env.observation_space.shape == (D,) and env.action_space.shape == (3,)
+    assert env.dt == pytest.approx(0.02) and env.max_episode_length == np.ceil(cfg.env.episode_length_s / 0.02)
+    obs = env.reset()
+    assert obs.shape == (4, Aw, D) and obs.dtype == torch.float32
+    assert torch.equal(obs[:, :, :Aw], torch.eye(Aw).expand(4, Aw, Aw))
+    for t in range(3):
+        obs, rew, done, info = env.step(torch.rand(4, Aw, 3) * 2 - 1)
+    assert obs.shape == (4, Aw, D) and rew.shape == (4, Aw) and done.shape == (4,) and done.dtype == torch.bool
+    assert isinstance(info, dict) and "time_outs" in info
+    assert env.reward_buffer["step count"] == 3
+    # attributes the reference's wrappers reach through the env
+    for name in ("root_states_npc", "env_origins", "collide_buf", "reset_ids", "r_term_buff", "p_term_buff", "base_init_state",
+                 "BarrierTrack_kwargs", "all_dof_states", "npc_indices", "env_agent_indices", "agent_origins", "obs_buf"):
+        assert getattr(env, name) is not None
+    assert env.obs_buf.base_pos.shape == (4 * A, 3) and env.obs_buf.base_rpy.shape == (4 * A, 3)
+    assert env.root_states.shape == (4 * A, 13) and env.dof_pos.shape == (4, 12 * A)
+    assert env.history_locomotion_obs.shape == (4 * A, 2100)
+    env.close()
+
+
+def test_unfused_step_equals_fused(oracle_backed):
+    a = args_for("go1gate", 3)
+    e1, _ = make_mqe_env("go1gate", a, custom_cfg(a))
+    e2, _ = make_mqe_env("go1gate", a, custom_cfg(a))
+    e1.reset(); e2.reset()
+    g = torch.Generator().manual_seed(3)
+    for t in range(4):
+        act = torch.rand(3, 2, 3, generator=g) * 3 - 1.5
+        o1, r1, d1, _ = e1.step(act)
+        # the reference's call pattern: wrapper clips, scales, hands (N*A,3) commands to Go1.step (go1_sheep_wrapper.py:55-56)
+        cmd = (act.clip(-1, 1) * e2.action_scale).reshape(-1, 3)
+        ob, rew, reset, extras = e2.env.step(cmd)
+        assert torch.allclose(e1.env.root_states, e2.env.root_states, atol=1e-6)
+        assert torch.equal(d1, reset)
+        assert torch.allclose(ob.base_pos, e1.env.obs_buf.base_pos, atol=1e-6)
+        assert (rew == 0).all()                      # Go1 registers no reward functions (go1.py:198-219)
+
+
+def test_openrl_adapter_matches_reference_vectors(oracle_backed):
+    from openrl_ws.utils import mqe_openrl_wrapper
+    z = golden("openrl_adapter")
+    obs, rew, done = z["obs"], z["rew"], z["done"]
+
+    class E:
+        num_envs, num_agents, device = 4, 2, "cpu"
+        action_space = types.SimpleNamespace(shape=(3,))
+        observation_space = types.SimpleNamespace(shape=(7,))
+        reward_buffer = {"x reward": torch.tensor(3.0), "y punishment": torch.tensor(-1.0), "other": 2.0, "step count": 5}
+
+        def reset(self):
+            return torch.tensor(obs[0])
+
+        def step(self, a):
+            self.a = a.clone()
+            return torch.tensor(obs[1]), torch.tensor(rew), torch.tensor(done), {}
+
+    e = E()
+    w = mqe_openrl_wrapper(e)
+    w.num_envs = 4
+    assert np.array_equal(w.reset(), z["o0"])
+    o1, r1, d1, infos = w.step(z["act"])
+    assert np.allclose(e.a.numpy(), z["env_action"]) and np.array_equal(o1, z["o1"]) and np.array_equal(r1, z["r1"])
+    assert np.array_equal(d1, z["d1"]) and len(infos) == int(z["n_infos"]) and w.use_monitor is False
+    br = w.batch_rewards(None)
+    want = dict(zip([str(k) for k in z["br_keys"]], z["br_vals"]))
+    assert set(br) == set(want)
+    for k in want:
+        assert float(br[k]) == pytest.approx(want[k], rel=1e-6)
+    assert e.reward_buffer["step count"] == 0
+
+
+def test_openrl_adapter_on_real_env(oracle_backed):
+    from openrl_ws.utils import make_env
+    a = args_for("go1gate", 2)
+    env, cfg = make_env(a, custom_cfg(a))
+    assert env.agent_num == 2 and env.parallel_env_num == 2
+    o = env.reset()
+    assert isinstance(o, np.ndarray) and o.shape == (2, 2, 16)
+    o, r, d, infos = env.step(np.random.RandomState(0).uniform(-2, 2, (2, 2, 3)))
+    assert o.shape == (2, 2, 16) and r.shape == (2, 2, 1) and d.shape == (2, 2) and d.dtype == bool and len(infos) == 2
+    br = env.batch_rewards(None)
+    assert "average step reward" in br and "target reward" in br
+
+
+def test_unregistered_tasks_fail_loudly():
+    with pytest.raises(NotImplementedError):
+        make_mqe_env("go1pushbox", args_for("go1pushbox", 1))

@@ -1,0 +1,110 @@
+"""Known-answer tests of the rigid-body step (row H).  The reference has no physics of its own to compare with
+(Isaac Gym), so these pin the build's CPU specification physically; the HIP kernel is then held to it (-m gpu)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import make_desc, oracle_engine
+from mqe.engine import abi
+
+G = 9.81
+
+
+def fresh(task="go1gate", N=2, f64=False, **kw):
+    d, k, ctx = make_desc(task, N, **kw)
+    e = oracle_engine(d, k, f64=f64)
+    e.reset_all()
+    root, dof = e.tensor(abi.T_ROOT_STATE), e.tensor(abi.T_DOF_STATE)
+    q0 = torch.tensor([d.default_dof_pos[j] for j in range(12)] * d.num_agents)
+    dof[:, :12 * d.num_agents, 0] = q0
+    dof[..., 1] = 0
+    root[..., 7:] = 0
+    e.tensor(abi.T_TORQUES).zero_()
+    return e, d, root, dof
+
+
+def test_free_fall_is_rigid():
+    """no contacts, no torques, zero velocity: every link accelerates with g => base dv = g dt, joint dv = 0"""
+    e, d, root, dof = fresh()
+    root[:, :, 2] = 2.0
+    e.simulate()
+    assert torch.allclose(root[:, :, 9], torch.full((2, 2), -G * d.dt), atol=2e-6)
+    assert root[:, :, 7:9].abs().max() < 1e-6 and root[:, :, 10:13].abs().max() < 2e-5
+    assert dof[..., 1].abs().max() < 2e-4
+    assert torch.allclose(root[:, :, 2], torch.full((2, 2), 2.0 - G * d.dt * d.dt), atol=1e-6)   # semi-implicit Euler
+
+
+def test_mass_matrix_base_block_and_symmetry():
+    e, d, root, dof = fresh()
+    M, Minv, _ = e.debug_dynamics(0, 0)
+    mt = sum(d.robot.mass[b] for b in range(13))
+    np.testing.assert_allclose(M[:3, :3], mt * np.eye(3), atol=1e-4)
+    np.testing.assert_allclose(M, M.T, atol=1e-5)
+    assert np.all(np.linalg.eigvalsh(M.astype(np.float64)) > 0)
+    np.testing.assert_allclose(M.astype(np.float64) @ Minv.astype(np.float64), np.eye(18), atol=2e-3)
+
+
+def test_static_stand_supports_weight():
+    e, d, root, dof = fresh()
+    a = torch.zeros(2, 2, 3)
+    for t in range(120):
+        e.step(a)
+    cf = e.tensor(abi.T_CONTACT_FORCE).reshape(2, 2, 17, 3)
+    mt = sum(d.robot.mass[b] for b in range(13))
+    fz = cf[:, :, [4, 8, 12, 16], 2].sum(-1)
+    assert torch.allclose(fz, torch.full((2, 2), mt * G), rtol=0.08)          # feet carry the weight
+    assert (cf[:, :, 0].norm(dim=-1) < 1e-6).all()                             # trunk does not touch
+    z = root[:, :, 2]
+    assert ((z > 0.27) & (z < 0.34)).all()
+    assert (e.tensor(abi.T_RESET_COUNT) == 1).all()                            # nobody terminated
+    # spheres do not sink: foot centre height >= ground + r - small penetration
+    assert root[:, :, 7:10].abs().max() < 0.15
+
+
+def test_ball_comes_to_rest_on_the_ground():
+    e, d, root, dof = fresh("go1football-defender", 2)
+    A = d.num_agents
+    root[:, A, 2] = 0.5
+    for t in range(150):
+        e.simulate()
+    r = d.npc_sphere_radius[0]
+    assert torch.allclose(root[:, A, 2], torch.full((2,), d.ground_z + r), atol=3e-3)
+    assert root[:, A, 7:10].abs().max() < 0.05
+
+
+def test_sliding_ball_decelerates_with_mu_g():
+    e, d, root, dof = fresh("go1football-defender", 1)
+    A = d.num_agents
+    root[0, A, 2] = d.ground_z + d.npc_sphere_radius[0]
+    root[0, A, 7] = 3.0
+    root[0, A, 10:13] = 0
+    v = []
+    for t in range(10):
+        e.simulate()
+        v.append(root[0, A, 7].item())
+    # sliding (not yet rolling): dv/dt = -mu g until the contact point sticks
+    dec = (v[0] - v[4]) / (4 * d.dt)
+    assert dec == pytest.approx(d.friction * G, rel=0.1)
+
+
+def test_float32_and_float64_oracles_agree():
+    outs = []
+    for f64 in (False, True):
+        e, d, root, dof = fresh(N=3, f64=f64)
+        g = torch.Generator().manual_seed(0)
+        for t in range(10):
+            e.step(torch.rand(3, 2, 3, generator=g) * 2 - 1)
+        outs.append((root.clone(), dof.clone()))
+    assert (outs[0][0][..., :3] - outs[1][0][..., :3]).abs().max() < 2e-3
+    assert (outs[0][1][..., 0] - outs[1][1][..., 0]).abs().max() < 2e-2
+
+
+def test_robots_collide_with_walls_and_each_other():
+    e, d, root, dof = fresh(N=1)
+    # drive robot 0 sideways into robot 1 and the side wall: positions must stay separated / inside the track
+    for t in range(60):
+        root[0, 0, 8] = 1.0
+        e.simulate()
+    dxy = (root[0, 0, :2] - root[0, 1, :2]).norm()
+    assert dxy > 0.12, "trunk spheres (r=0.057) may not interpenetrate"
+    assert torch.isfinite(root).all()
