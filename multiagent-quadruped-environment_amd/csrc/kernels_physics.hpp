@@ -42,12 +42,11 @@ __device__ __forceinline__ float wave_sum(float x) {
 
 #define BODY_STRIDE 32
 #define CON_STRIDE 32
-#define JS_MAXNZ 18                 // nonzero Jacobian columns of one contact: 9 per articulated side
-#define JS_STRIDE (4 + 4 * JS_MAXNZ) // [0] = count, then (j_n, j_t1, j_t2, dof index) per nonzero column
+#define JS_STRIDE 72                // 2 sides x 9 columns x (j_n, j_t1, j_t2, local dof index)
 enum { B_R = 0, B_P = 9, B_W = 12, B_VP = 15, B_A = 18, B_AL = 21, B_AP = 24, B_C = 27, B_M = 30 };
 enum { C_IDS = 0, C_P = 4, C_N = 7, C_T1 = 10, C_T2 = 13, C_SD = 16, C_BIAS = 17, C_K = 18, C_LAM = 24, C_REP = 27 };
 
-__host__ __device__ inline int mqe_maxc(int A, int P) { int v = 12 * A + P; return v > 32 ? 32 : v; }
+__host__ __device__ inline int mqe_maxc(int A, int P) { int v = 8 * A + P; return v > 32 ? 32 : v; }
 
 struct PhysLds {   // float offsets into dynamic LDS
   int root, dof, tau, body, minv, rhs, fcol, leg, basei, sinv, sph, con, B, W, js, kk, total;
@@ -68,10 +67,10 @@ __host__ __device__ inline PhysLds phys_lds_layout(int A, int P, int ND, int nbo
   o = (o + 3) & ~3;
   L.sph = o; o += nsph * 4;
   L.con = o; o += maxc * CON_STRIDE;
-  L.B = o; o += maxc * 3 * bstride;
-  L.W = o; o += 64 * 4;
+  L.B = o; o += maxc * 2 * 54;          // per contact and side: 3 rows x 18 local dofs of M^-1 J^T
+  L.W = o;
   L.js = o; o += maxc * JS_STRIDE;
-  L.kk = o; o += maxc * maxc * 9;
+  L.kk = o; o += maxc * (maxc * 9 + 1);     // row = receiving contact (lane), padded to an odd stride (bank conflicts)
   L.total = o;
   return L;
 }
@@ -519,65 +518,9 @@ __global__ void __launch_bounds__(64) k_simulate(const DevModel* __restrict__ m,
   __syncthreads();
 
   TSTAMP(10);
-  // ---- per contact: tangents, B = M^-1 J^T rows, K = J B, bias ---------------------------------------------------------------
-  float* Wx = lds + L.W;
-  for (int c = 0; c < nc; c++) {
-    float* cr = lds + L.con + c * CON_STRIDE;
-    const int actA = __float_as_int(cr[C_IDS]), bodyA = __float_as_int(cr[C_IDS + 1]);
-    const int actB = __float_as_int(cr[C_IDS + 2]), bodyB = __float_as_int(cr[C_IDS + 3]);
-    const V3 p = ld3(cr + C_P), n = ld3(cr + C_N);
-    V3 aa = fabsf(n.z) > 0.7f ? v3(1, 0, 0) : v3(0, 0, 1);
-    V3 t1 = cross(aa, n);
-    t1 = (1.0f / sqrtf(dot(t1, t1))) * t1;
-    const V3 t2 = cross(n, t1);
-    float sgn = 0.0f;
-    if (is_dof) {
-      if (dact == actA && ((dmask >> bodyA) & 1u)) sgn = 1.0f;
-      else if (dact == actB && ((dmask >> bodyB) & 1u)) sgn = -1.0f;
-    }
-    const V3 wv = sgn * (dlin ? dax : cross(dax, p - danc));
-    Wx[lane * 4] = wv.x; Wx[lane * 4 + 1] = wv.y; Wx[lane * 4 + 2] = wv.z;
-    __syncthreads();
-    V3 bwv = v3(0, 0, 0);
-    if (is_rdof) {
-      const float* Mc = lds + L.minv + dact * MQE_RD * MQE_RD + dk;
-      const float* Wr = Wx + dact * MQE_RD * 4;
-      for (int ee = 0; ee < MQE_RD; ee++) {
-        const float mv = Mc[ee * MQE_RD];
-        bwv.x += mv * Wr[ee * 4]; bwv.y += mv * Wr[ee * 4 + 1]; bwv.z += mv * Wr[ee * 4 + 2];
-      }
-    } else if (is_dof) {
-      bwv = dinvm * wv;
-    }
-    const float j0 = dot(n, wv), j1 = dot(t1, wv), j2 = dot(t2, wv);
-    const float b0 = dot(n, bwv), b1 = dot(t1, bwv), b2 = dot(t2, bwv);
-    if (is_dof) {
-      float* Bc = lds + L.B + c * 3 * bs;
-      Bc[lane] = b0; Bc[bs + lane] = b1; Bc[2 * bs + lane] = b2;
-    }
-    // sparse Jacobian rows: only the dofs on the kinematic chain(s) of the touching bodies are nonzero (<= 9 per side)
-    float* js = lds + L.js + c * JS_STRIDE;
-    const bool nz = sgn != 0.0f;
-    const unsigned long long bnz = __ballot(nz);
-    {
-      const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-      const int slot = __popcll(bnz & lower);
-      if (nz && slot < JS_MAXNZ) { float* en = js + 4 + slot * 4; en[0] = j0; en[1] = j1; en[2] = j2; en[3] = __int_as_float(lane); }
-    }
-    int nnz = __popcll(bnz);
-    if (nnz > JS_MAXNZ) nnz = JS_MAXNZ;
-    if (lane == 0) {
-      js[0] = __int_as_float(nnz);
-      st3(cr + C_T1, t1); st3(cr + C_T2, t2);
-      const float sd = cr[C_SD];
-      cr[C_BIAS] = sd >= 0 ? -sd / dt : fminf(-sd * m->erp / dt, m->max_depen);
-      cr[C_LAM] = 0; cr[C_LAM + 1] = 0; cr[C_LAM + 2] = 0;
-    }
-    __syncthreads();
-    __syncthreads();
-  }
-
-  // ---- projected Gauss-Seidel in velocity space -----------------------------------------------------------------------------
+  // ---- contact rows, lane = contact: sparse Jacobian (<= 9 columns per articulated side), B = M^-1 J^T, bias --------------------
+  // Per side the columns are [base lin xyz, base ang xyz, the <=3 joints of the chain to the touching link] (robot) or
+  // [lin xyz, (ang xyz)] (ball / sheep).  Column value in the contact frame: dirs . (axis x (p - anchor)) = (r x dirs) . axis.
   const float mu = m->friction;
   float jlo = 0, jhi = 0;
   const bool is_joint = is_rdof && dk >= 6;
@@ -585,90 +528,213 @@ __global__ void __launch_bounds__(64) k_simulate(const DevModel* __restrict__ m,
     const float q = lds[L.dof + (dact * 12 + dk - 6) * 2];
     jlo = (rm.dof_lower[dk - 6] - q) / dt; jhi = (rm.dof_upper[dk - 6] - q) / dt;
   }
-  TSTAMP(11);
-  // ---- projected Gauss-Seidel in CONTACT space, lane = contact ------------------------------------------------------------
-  // Each lane owns one contact: relative velocity u (3), impulse lambda (3).  One GS step = the owning lane's impulse
-  // increment (row-wise: normal, then the two friction rows with box limits mu*lambda_n), broadcast with v_readlane, and
-  // every lane adds its 3x3 coupling block KK[c'][c] = J_c M^-1 J_c'^T times the increment.  No LDS round trip or wave
-  // reduction sits on the serial chain.  Mathematically identical to the velocity-space sweep of the CPU oracle.
   float* Vm = lds + L.rhs + 64;      // v* (unconstrained velocity), read through the sparse Jacobian rows
   Vm[lane] = vd;
   __syncthreads();
+  const bool is_con = lane < nc;
   float cu0 = 0, cu1 = 0, cu2 = 0, cl0 = 0, cl1 = 0, cl2 = 0, cbias = 0;
   float ik00 = 0, ik11 = 0, ik22 = 0, ck10 = 0, ck20 = 0, ck21 = 0;
-  const bool is_con = lane < nc;
+  int myA = -2, myB = -2;
   if (is_con) {
-    const float* js = lds + L.js + lane * JS_STRIDE;
-    const int nnz = __float_as_int(js[0]);
-    for (int i = 0; i < nnz; i++) {
-      const float4 en = *reinterpret_cast<const float4*>(js + 4 + i * 4);
-      const float vv = Vm[__float_as_int(en.w)];
-      cu0 += en.x * vv; cu1 += en.y * vv; cu2 += en.z * vv;
-    }
-    cbias = lds[L.con + lane * CON_STRIDE + C_BIAS];
-    for (int c2 = 0; c2 < nc; c2++) {
-      const float* Bc = lds + L.B + c2 * 3 * bs;
-      float k[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-      for (int i = 0; i < nnz; i++) {
-        const float4 en = *reinterpret_cast<const float4*>(js + 4 + i * 4);
-        const int idx = __float_as_int(en.w);
-        const float b0 = Bc[idx], b1 = Bc[bs + idx], b2 = Bc[2 * bs + idx];
-        k[0] += en.x * b0; k[1] += en.x * b1; k[2] += en.x * b2;
-        k[3] += en.y * b0; k[4] += en.y * b1; k[5] += en.y * b2;
-        k[6] += en.z * b0; k[7] += en.z * b1; k[8] += en.z * b2;
-      }
-      float* kk = lds + L.kk + (c2 * maxc + lane) * 9;
+    float* cr = lds + L.con + lane * CON_STRIDE;
+    myA = __float_as_int(cr[C_IDS]); myB = __float_as_int(cr[C_IDS + 2]);
+    const int bodyA = __float_as_int(cr[C_IDS + 1]), bodyB = __float_as_int(cr[C_IDS + 3]);
+    const V3 p = ld3(cr + C_P), n = ld3(cr + C_N);
+    const V3 aa = fabsf(n.z) > 0.7f ? v3(1, 0, 0) : v3(0, 0, 1);
+    V3 t1 = cross(aa, n);
+    t1 = (1.0f / sqrtf(dot(t1, t1))) * t1;
+    const V3 t2 = cross(n, t1);
+    st3(cr + C_T1, t1); st3(cr + C_T2, t2);
+    const float sd = cr[C_SD];
+    cbias = sd >= 0 ? -sd / dt : fminf(-sd * m->erp / dt, m->max_depen);
+    for (int side = 0; side < 2; side++) {
+      const int act = side == 0 ? myA : myB, body = side == 0 ? bodyA : bodyB;
+      const float sg = side == 0 ? 1.0f : -1.0f;
+      float* js = lds + L.js + lane * JS_STRIDE + side * 36;
+      float* Bs = lds + L.B + (lane * 2 + side) * 54;
+      if (act < 0) continue;
+      if (act < A) {
+        const float* brec = lds + L.body + act * MQE_NBODY * BODY_STRIDE;
+        const V3 r0 = p - ld3(brec + B_P);
+        const V3 cn = cross(r0, n), c1 = cross(r0, t1), c2 = cross(r0, t2);
+        float J[9][3];
+        J[0][0] = sg * n.x; J[0][1] = sg * t1.x; J[0][2] = sg * t2.x;
+        J[1][0] = sg * n.y; J[1][1] = sg * t1.y; J[1][2] = sg * t2.y;
+        J[2][0] = sg * n.z; J[2][1] = sg * t1.z; J[2][2] = sg * t2.z;
+        J[3][0] = sg * cn.x; J[3][1] = sg * c1.x; J[3][2] = sg * c2.x;
+        J[4][0] = sg * cn.y; J[4][1] = sg * c1.y; J[4][2] = sg * c2.y;
+        J[5][0] = sg * cn.z; J[5][1] = sg * c1.z; J[5][2] = sg * c2.z;
+        const int leg = body > 0 ? (body - 1) / 3 : 0, dep = body > 0 ? (body - 1) % 3 + 1 : 0;
 #pragma unroll
-      for (int q = 0; q < 9; q++) kk[q] = k[q];
+        for (int t = 0; t < 3; t++) {
+          const float* jrec = brec + (1 + leg * 3 + t) * BODY_STRIDE;
+          const V3 ax = ld3(jrec + B_A), rr = p - ld3(jrec + B_P);
+          const float on = t < dep ? sg : 0.0f;
+          J[6 + t][0] = on * dot(cross(rr, n), ax); J[6 + t][1] = on * dot(cross(rr, t1), ax); J[6 + t][2] = on * dot(cross(rr, t2), ax);
+        }
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+          const int li = i < 6 ? i : 6 + leg * 3 + (i - 6);
+          js[i * 4] = J[i][0]; js[i * 4 + 1] = J[i][1]; js[i * 4 + 2] = J[i][2]; js[i * 4 + 3] = __int_as_float(li);
+          const float vv = Vm[act * MQE_RD + li];
+          cu0 += J[i][0] * vv; cu1 += J[i][1] * vv; cu2 += J[i][2] * vv;
+        }
+        const float* Mi = lds + L.minv + act * MQE_RD * MQE_RD;
+        for (int d = 0; d < MQE_RD; d++) {
+          float b0 = 0, b1 = 0, b2 = 0;
+#pragma unroll
+          for (int i = 0; i < 9; i++) {
+            const int li = i < 6 ? i : 6 + leg * 3 + (i - 6);
+            const float mv = Mi[li * MQE_RD + d];
+            b0 += mv * J[i][0]; b1 += mv * J[i][1]; b2 += mv * J[i][2];
+          }
+          Bs[d] = b0; Bs[18 + d] = b1; Bs[36 + d] = b2;
+        }
+      } else {
+        const int pi = act - A;
+        const V3 r0 = p - ld3(lds + L.root + (A + pi) * 13);
+        const V3 cn = cross(r0, n), c1 = cross(r0, t1), c2 = cross(r0, t2);
+        const float im = 1.0f / m->npc_mass, ii = 1.0f / m->npc_inertia;
+        float J[6][3] = {{sg * n.x, sg * t1.x, sg * t2.x}, {sg * n.y, sg * t1.y, sg * t2.y}, {sg * n.z, sg * t1.z, sg * t2.z},
+                         {sg * cn.x, sg * c1.x, sg * c2.x}, {sg * cn.y, sg * c1.y, sg * c2.y}, {sg * cn.z, sg * c1.z, sg * c2.z}};
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+          const bool on = i < npcdof;
+          const float j0 = on ? J[i < 6 ? i : 0][0] : 0.0f, j1 = on ? J[i < 6 ? i : 0][1] : 0.0f, j2 = on ? J[i < 6 ? i : 0][2] : 0.0f;
+          js[i * 4] = j0; js[i * 4 + 1] = j1; js[i * 4 + 2] = j2; js[i * 4 + 3] = __int_as_float(on ? i : 0);
+          if (on) {
+            const float vv = Vm[A * MQE_RD + pi * npcdof + i];
+            cu0 += j0 * vv; cu1 += j1 * vv; cu2 += j2 * vv;
+            const float w = i < 3 ? im : ii;
+            Bs[i] = w * j0; Bs[18 + i] = w * j1; Bs[36 + i] = w * j2;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  TSTAMP(11);
+  // ---- 3x3 coupling blocks K(c, c2) = J_c M^-1 J_c2^T for c2 <= c (lower triangle; the upper one is its transpose) -------------
+  const int kstride = maxc * 9 + 1;
+  if (is_con) {
+    const float* jsA = lds + L.js + lane * JS_STRIDE;
+    for (int c2 = 0; c2 <= lane; c2++) {
+      const float* cr2 = lds + L.con + c2 * CON_STRIDE;
+      const int a2 = __float_as_int(cr2[C_IDS]), b2 = __float_as_int(cr2[C_IDS + 2]);
+      float k[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      for (int s1 = 0; s1 < 2; s1++) {
+        const int act = s1 == 0 ? myA : myB;
+        if (act < 0) continue;
+        for (int s2 = 0; s2 < 2; s2++) {
+          if ((s2 == 0 ? a2 : b2) != act) continue;
+          const float* js = jsA + s1 * 36;
+          const float* Bc = lds + L.B + (c2 * 2 + s2) * 54;
+#pragma unroll
+          for (int i = 0; i < 9; i++) {
+            const float4 en = *reinterpret_cast<const float4*>(js + i * 4);
+            const int li = __float_as_int(en.w);
+            const float b0 = Bc[li], b1 = Bc[18 + li], b2v = Bc[36 + li];
+            k[0] += en.x * b0; k[1] += en.x * b1; k[2] += en.x * b2v;
+            k[3] += en.y * b0; k[4] += en.y * b1; k[5] += en.y * b2v;
+            k[6] += en.z * b0; k[7] += en.z * b1; k[8] += en.z * b2v;
+          }
+        }
+      }
+      float* kk = lds + L.kk + lane * kstride + c2 * 9;
+      float* kt = lds + L.kk + c2 * kstride + lane * 9;
+#pragma unroll
+      for (int q = 0; q < 9; q++) { kk[q] = k[q]; kt[(q % 3) * 3 + q / 3] = k[q]; }
       if (c2 == lane) { ik00 = 1.0f / k[0]; ik11 = 1.0f / k[4]; ik22 = 1.0f / k[8]; ck10 = k[3]; ck20 = k[6]; ck21 = k[7]; }
     }
   }
   __syncthreads();
   TSTAMP(12);
+  // ---- projected Gauss-Seidel in CONTACT space, lane = contact ------------------------------------------------------------
+  // Each lane owns one contact: relative velocity u (3), impulse lambda (3).  One GS step = the owning lane's impulse
+  // increment (row-wise: normal, then the two friction rows with box limits mu*lambda_n), broadcast with v_readlane, and
+  // every lane adds its 3x3 coupling block with the owner times the increment.  No LDS round trip or wave reduction
+  // sits on the serial chain.  Mathematically identical to the velocity-space sweep of the CPU oracle.
   {
-    // software-pipelined: the coupling block for the NEXT step is fetched while the current step's scalar chain runs
-    float kn[9];
-    const float* kbase = lds + L.kk + lane * 9;
+    // groups: the terrain contacts of one actor are contiguous in the list and coupled only among themselves, so the
+    // s-th contact of EVERY actor is updated in the same step (owner index per lane -> ds_bpermute broadcast);
+    // contacts between two actors (at the end of the list) couple two groups and are swept one by one afterwards.
+    const bool is_terr = is_con && myB < 0, is_pair = is_con && myB >= 0;
+    int gstartA = 0, glenA = 0, gstartB = 0, glenB = 0, maxlen = 0;
+    const int nact = A + PD;
+    for (int a = 0; a < nact; a++) {
+      const unsigned long long bm = __ballot(is_terr && myA == a);
+      const int len = __popcll(bm), start = bm ? __ffsll((long long)bm) - 1 : 0;
+      maxlen = len > maxlen ? len : maxlen;
+      if (is_con && myA == a) { gstartA = start; glenA = len; }
+      if (is_pair && myB == a) { gstartB = start; glenB = len; }
+    }
+    const int npair = __popcll(__ballot(is_pair));
+    const int pair0 = nc - npair;
+    const float* krow = lds + L.kk + lane * kstride;
+    for (int it = 0; it < m->solver_iterations; it++) {
+      for (int sidx = 0; sidx < maxlen; sidx++) {
+        const int ownA = (gstartA + sidx) & 63;
+        const bool vA = sidx < glenA;
+        float kk[9];
 #pragma unroll
-    for (int q = 0; q < 9; q++) kn[q] = (is_con && nc > 0) ? kbase[q] : 0.0f;
-    const int total = m->solver_iterations * nc;
-    int c = 0;
-    for (int stp = 0; stp < total; stp++) {
-      float kk[9];
+        for (int q = 0; q < 9; q++) kk[q] = krow[ownA * 9 + q];
+        const float ln = fmaxf(cl0 - (cu0 - cbias) * ik00, 0.0f);
+        const float d0 = ln - cl0;
+        const float lim = mu * ln;
+        const float l1 = clampf(cl1 - (cu1 + ck10 * d0) * ik11, -lim, lim);
+        const float d1 = l1 - cl1;
+        const float l2 = clampf(cl2 - (cu2 + ck20 * d0 + ck21 * d1) * ik22, -lim, lim);
+        const float d2 = l2 - cl2;
+        float e0 = __shfl(d0, ownA, 64), e1 = __shfl(d1, ownA, 64), e2 = __shfl(d2, ownA, 64);
+        if (!vA) { e0 = 0.0f; e1 = 0.0f; e2 = 0.0f; }
+        if (is_terr && lane == ownA && vA) { cl0 = ln; cl1 = l1; cl2 = l2; }
+        cu0 += kk[0] * e0 + kk[1] * e1 + kk[2] * e2;
+        cu1 += kk[3] * e0 + kk[4] * e1 + kk[5] * e2;
+        cu2 += kk[6] * e0 + kk[7] * e1 + kk[8] * e2;
+        if (npair > 0) {           // two-actor contacts also feel the owner of their second actor's group
+          const int ownB = (gstartB + sidx) & 63;
+          const bool vB = is_pair && sidx < glenB;
+          float f0 = __shfl(d0, ownB, 64), f1 = __shfl(d1, ownB, 64), f2 = __shfl(d2, ownB, 64);
+          if (!vB) { f0 = 0.0f; f1 = 0.0f; f2 = 0.0f; }
 #pragma unroll
-      for (int q = 0; q < 9; q++) kk[q] = kn[q];
-      const int cnext = (c + 1 == nc) ? 0 : c + 1;
-      {
-        const float* kp = kbase + cnext * maxc * 9;
-#pragma unroll
-        for (int q = 0; q < 9; q++) kn[q] = is_con ? kp[q] : 0.0f;
+          for (int q = 0; q < 9; q++) kk[q] = krow[ownB * 9 + q];
+          cu0 += kk[0] * f0 + kk[1] * f1 + kk[2] * f2;
+          cu1 += kk[3] * f0 + kk[4] * f1 + kk[5] * f2;
+          cu2 += kk[6] * f0 + kk[7] * f1 + kk[8] * f2;
+        }
       }
-      // every lane evaluates the update for its own contact; only lane c's result is used
-      const float ln = fmaxf(cl0 - (cu0 - cbias) * ik00, 0.0f);
-      const float d0 = ln - cl0;
-      const float lim = mu * ln;
-      const float l1 = clampf(cl1 - (cu1 + ck10 * d0) * ik11, -lim, lim);
-      const float d1 = l1 - cl1;
-      const float l2 = clampf(cl2 - (cu2 + ck20 * d0 + ck21 * d1) * ik22, -lim, lim);
-      const float d2 = l2 - cl2;
-      const float e0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d0), c));
-      const float e1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d1), c));
-      const float e2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d2), c));
-      if (lane == c) { cl0 = ln; cl1 = l1; cl2 = l2; }
-      cu0 += kk[0] * e0 + kk[1] * e1 + kk[2] * e2;
-      cu1 += kk[3] * e0 + kk[4] * e1 + kk[5] * e2;
-      cu2 += kk[6] * e0 + kk[7] * e1 + kk[8] * e2;
-      c = cnext;
+      for (int c = pair0; c < nc; c++) {
+        float kk[9];
+#pragma unroll
+        for (int q = 0; q < 9; q++) kk[q] = krow[c * 9 + q];
+        const float ln = fmaxf(cl0 - (cu0 - cbias) * ik00, 0.0f);
+        const float d0 = ln - cl0;
+        const float lim = mu * ln;
+        const float l1 = clampf(cl1 - (cu1 + ck10 * d0) * ik11, -lim, lim);
+        const float d1 = l1 - cl1;
+        const float l2 = clampf(cl2 - (cu2 + ck20 * d0 + ck21 * d1) * ik22, -lim, lim);
+        const float d2 = l2 - cl2;
+        const float e0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d0), c));
+        const float e1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d1), c));
+        const float e2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d2), c));
+        if (lane == c) { cl0 = ln; cl1 = l1; cl2 = l2; }
+        cu0 += kk[0] * e0 + kk[1] * e1 + kk[2] * e2;
+        cu1 += kk[3] * e0 + kk[4] * e1 + kk[5] * e2;
+        cu2 += kk[6] * e0 + kk[7] * e1 + kk[8] * e2;
+      }
     }
   }
   TSTAMP(13);
   if (is_con) { float* cr = lds + L.con + lane * CON_STRIDE; cr[C_LAM] = cl0; cr[C_LAM + 1] = cl1; cr[C_LAM + 2] = cl2; }
   __syncthreads();
   if (is_dof) {
+    const int dloc = is_rdof ? dk : dk;
     for (int c = 0; c < nc; c++) {
       const float* cr = lds + L.con + c * CON_STRIDE;
-      const float* Bc = lds + L.B + c * 3 * bs;
-      vd += Bc[lane] * cr[C_LAM] + Bc[bs + lane] * cr[C_LAM + 1] + Bc[2 * bs + lane] * cr[C_LAM + 2];
+      const int a2 = __float_as_int(cr[C_IDS]), b2 = __float_as_int(cr[C_IDS + 2]);
+      if (a2 != dact && b2 != dact) continue;
+      const float* Bc = lds + L.B + (c * 2 + (a2 == dact ? 0 : 1)) * 54;
+      vd += Bc[dloc] * cr[C_LAM] + Bc[18 + dloc] * cr[C_LAM + 1] + Bc[36 + dloc] * cr[C_LAM + 2];
     }
   }
   // joint limits: one sequential pass in (robot, joint) order after the contact solve, only when some lane violates

@@ -36,7 +36,7 @@ typedef REAL real;
 #define RD 18                       /* dofs of one robot: 3 lin + 3 ang + 12 joints */
 #define MAXDOF (MAXA * RD + MAXP * 6 + 1)
 #define MAXC 64                     /* storage; the active bound is env_maxc() */
-static inline int env_maxc(int A, int P) { int v = 12 * A + P; return v > 32 ? 32 : v; } /* = mqe_maxc() of the engine */
+static inline int env_maxc(int A, int P) { int v = 8 * A + P; return v > 32 ? 32 : v; } /* = mqe_maxc() of the engine */
 #define FR MQE_FRAME
 #define OBS_BAG 74
 
