@@ -49,7 +49,7 @@ enum { C_IDS = 0, C_P = 4, C_N = 7, C_T1 = 10, C_T2 = 13, C_SD = 16, C_BIAS = 17
 __host__ __device__ inline int mqe_maxc(int A, int P) { int v = 8 * A + P; return v > 32 ? 32 : v; }
 
 struct PhysLds {   // float offsets into dynamic LDS
-  int root, dof, tau, body, minv, rhs, fcol, leg, basei, sinv, sph, con, B, W, js, kk, total;
+  int root, dof, tau, body, minv, rhs, fcol, leg, basei, sinv, tt, sph, con, B, W, js, kk, total;
 };
 __host__ __device__ inline PhysLds phys_lds_layout(int A, int P, int ND, int nbody, int ndof, int nsph, int maxc, int bstride) {
   PhysLds L; int o = 0;
@@ -64,6 +64,7 @@ __host__ __device__ inline PhysLds phys_lds_layout(int A, int P, int ND, int nbo
   L.leg = o; o += A * 4 * 54;
   L.basei = o; o += A * 10;
   L.sinv = o; o += A * 36;
+  L.tt = o; o += A * MQE_RD * 6;
   o = (o + 3) & ~3;
   L.sph = o; o += nsph * 4;
   L.con = o; o += maxc * CON_STRIDE;
@@ -307,34 +308,48 @@ __global__ void __launch_bounds__(64) k_simulate(const DevModel* __restrict__ m,
   }
   __syncthreads();
   TSTAMP(5);
-  // ---- rows of M^-1 (18 x 18 per robot) ---------------------------------------------------------------------------
-  for (int d = lane; d < A * MQE_RD; d += 64) {
+  // ---- rows of M^-1 (18 x 18 per robot), two stages of small independent tasks -------------------------------------------
+  // stage 1: T[d][:] = row d of [S^-1 ; G^T S^-1]  (task = (row, column m): 6 FMAs)
+  for (int t = lane; t < A * MQE_RD * 6; t += 64) {
+    const int d = t / 6, mm = t - d * 6;
     const int r = d / MQE_RD, k = d - r * MQE_RD;
     const float* Si = lds + L.sinv + r * 36;
-    float* row = lds + L.minv + (r * MQE_RD + k) * MQE_RD;
-    float T[6];
-    int legk = -1, li = 0;
-    if (k < 6) {
-      for (int mm = 0; mm < 6; mm++) { T[mm] = Si[k * 6 + mm]; row[mm] = T[mm]; }
-    } else {
-      legk = (k - 6) / 3; li = (k - 6) - legk * 3;
+    float acc;
+    if (k < 6) acc = Si[k * 6 + mm];
+    else {
+      const int legk = (k - 6) / 3, li = (k - 6) - legk * 3;
       const float* G = lds + L.leg + (r * 4 + legk) * 54 + 12;
-      for (int mm = 0; mm < 6; mm++) {
-        float acc = 0.0f;
-        for (int n = 0; n < 6; n++) acc += G[n * 3 + li] * Si[n * 6 + mm];
-        T[mm] = acc; row[mm] = -acc;
-      }
+      acc = 0.0f;
+#pragma unroll
+      for (int n = 0; n < 6; n++) acc += G[n * 3 + li] * Si[n * 6 + mm];
     }
-    for (int kk = 0; kk < 4; kk++) {
+    lds[L.tt + t] = acc;
+  }
+  __syncthreads();
+  // stage 2: task = (row d, block): block 0 = the 6 base columns, block 1..4 = the 3 columns of one leg
+  for (int t = lane; t < A * MQE_RD * 5; t += 64) {
+    const int d = t / 5, blk = t - d * 5;
+    const int r = d / MQE_RD, k = d - r * MQE_RD;
+    const float* T = lds + L.tt + d * 6;
+    float* row = lds + L.minv + (r * MQE_RD + k) * MQE_RD;
+    if (blk == 0) {
+      const float sg = k < 6 ? 1.0f : -1.0f;
+#pragma unroll
+      for (int mm = 0; mm < 6; mm++) row[mm] = sg * T[mm];
+    } else {
+      const int kk = blk - 1;
       const float* G = lds + L.leg + (r * 4 + kk) * 54 + 12;
+      const int legk = k < 6 ? -1 : (k - 6) / 3, li = k < 6 ? 0 : (k - 6) - legk * 3;
+#pragma unroll
       for (int i = 0; i < 3; i++) {
         float acc = 0.0f;
+#pragma unroll
         for (int mm = 0; mm < 6; mm++) acc += T[mm] * G[mm * 3 + i];
         if (k < 6) acc = -acc;
         else if (kk == legk) {
           const float* Mi = lds + L.leg + (r * 4 + kk) * 54 + 6;   // sym6 00,11,22,01,02,12
-          const int a = li < i ? li : i, b = li < i ? i : li;
-          acc += (a == b) ? Mi[a] : (a == 0 ? (b == 1 ? Mi[3] : Mi[4]) : Mi[5]);
+          const int a2 = li < i ? li : i, b2 = li < i ? i : li;
+          acc += (a2 == b2) ? Mi[a2] : (a2 == 0 ? (b2 == 1 ? Mi[3] : Mi[4]) : Mi[5]);
         }
         row[6 + kk * 3 + i] = acc;
       }
@@ -579,17 +594,6 @@ __global__ void __launch_bounds__(64) k_simulate(const DevModel* __restrict__ m,
           const float vv = Vm[act * MQE_RD + li];
           cu0 += J[i][0] * vv; cu1 += J[i][1] * vv; cu2 += J[i][2] * vv;
         }
-        const float* Mi = lds + L.minv + act * MQE_RD * MQE_RD;
-        for (int d = 0; d < MQE_RD; d++) {
-          float b0 = 0, b1 = 0, b2 = 0;
-#pragma unroll
-          for (int i = 0; i < 9; i++) {
-            const int li = i < 6 ? i : 6 + leg * 3 + (i - 6);
-            const float mv = Mi[li * MQE_RD + d];
-            b0 += mv * J[i][0]; b1 += mv * J[i][1]; b2 += mv * J[i][2];
-          }
-          Bs[d] = b0; Bs[18 + d] = b1; Bs[36 + d] = b2;
-        }
       } else {
         const int pi = act - A;
         const V3 r0 = p - ld3(lds + L.root + (A + pi) * 13);
@@ -613,39 +617,70 @@ __global__ void __launch_bounds__(64) k_simulate(const DevModel* __restrict__ m,
     }
   }
   __syncthreads();
-  TSTAMP(11);
-  // ---- 3x3 coupling blocks K(c, c2) = J_c M^-1 J_c2^T for c2 <= c (lower triangle; the upper one is its transpose) -------------
-  const int kstride = maxc * 9 + 1;
-  if (is_con) {
-    const float* jsA = lds + L.js + lane * JS_STRIDE;
-    for (int c2 = 0; c2 <= lane; c2++) {
-      const float* cr2 = lds + L.con + c2 * CON_STRIDE;
-      const int a2 = __float_as_int(cr2[C_IDS]), b2 = __float_as_int(cr2[C_IDS + 2]);
-      float k[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-      for (int s1 = 0; s1 < 2; s1++) {
-        const int act = s1 == 0 ? myA : myB;
-        if (act < 0) continue;
-        for (int s2 = 0; s2 < 2; s2++) {
-          if ((s2 == 0 ? a2 : b2) != act) continue;
-          const float* js = jsA + s1 * 36;
-          const float* Bc = lds + L.B + (c2 * 2 + s2) * 54;
+  // B = M^-1 J^T for the articulated sides: task = (contact, side, local dof): 9 x 3 FMAs over the side's sparse columns
+  for (int t = lane; t < nc * 2 * MQE_RD; t += 64) {
+    const int cs = t / MQE_RD, d = t - cs * MQE_RD, c = cs >> 1, side = cs & 1;
+    if (c >= nc) continue;
+    const float* cr = lds + L.con + c * CON_STRIDE;
+    const int act = __float_as_int(cr[C_IDS + 2 * side]);
+    if (act < 0 || act >= A) continue;
+    const float* js = lds + L.js + c * JS_STRIDE + side * 36;
+    const float* Mi = lds + L.minv + act * MQE_RD * MQE_RD + d;
+    float b0 = 0, b1 = 0, b2 = 0;
 #pragma unroll
-          for (int i = 0; i < 9; i++) {
-            const float4 en = *reinterpret_cast<const float4*>(js + i * 4);
-            const int li = __float_as_int(en.w);
-            const float b0 = Bc[li], b1 = Bc[18 + li], b2v = Bc[36 + li];
-            k[0] += en.x * b0; k[1] += en.x * b1; k[2] += en.x * b2v;
-            k[3] += en.y * b0; k[4] += en.y * b1; k[5] += en.y * b2v;
-            k[6] += en.z * b0; k[7] += en.z * b1; k[8] += en.z * b2v;
-          }
+    for (int i = 0; i < 9; i++) {
+      const float4 en = *reinterpret_cast<const float4*>(js + i * 4);
+      const float mv = Mi[__float_as_int(en.w) * MQE_RD];
+      b0 += mv * en.x; b1 += mv * en.y; b2 += mv * en.z;
+    }
+    float* Bs = lds + L.B + cs * 54;
+    Bs[d] = b0; Bs[18 + d] = b1; Bs[36 + d] = b2;
+  }
+  __syncthreads();
+  TSTAMP(11);
+  // ---- 3x3 coupling blocks K(c, c2) = J_c M^-1 J_c2^T: one task per pair c2 <= c, transpose mirrored ---------------------------
+  const int kstride = maxc * 9 + 1;
+  for (int t = lane; t < (nc * (nc + 1)) / 2; t += 64) {
+    int c = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+    while ((c * (c + 1)) / 2 > t) c--;
+    while (((c + 1) * (c + 2)) / 2 <= t) c++;
+    const int c2 = t - (c * (c + 1)) / 2;
+    const float* cr1 = lds + L.con + c * CON_STRIDE;
+    const float* cr2 = lds + L.con + c2 * CON_STRIDE;
+    const int a1 = __float_as_int(cr1[C_IDS]), b1 = __float_as_int(cr1[C_IDS + 2]);
+    const int a2 = __float_as_int(cr2[C_IDS]), b2 = __float_as_int(cr2[C_IDS + 2]);
+    float k[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int s1 = 0; s1 < 2; s1++) {
+      const int act = s1 == 0 ? a1 : b1;
+      if (act < 0) continue;
+      for (int s2 = 0; s2 < 2; s2++) {
+        if ((s2 == 0 ? a2 : b2) != act) continue;
+        const float* js = lds + L.js + c * JS_STRIDE + s1 * 36;
+        const float* Bc = lds + L.B + (c2 * 2 + s2) * 54;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+          const float4 en = *reinterpret_cast<const float4*>(js + i * 4);
+          const int li = __float_as_int(en.w);
+          const float q0 = Bc[li], q1 = Bc[18 + li], q2 = Bc[36 + li];
+          k[0] += en.x * q0; k[1] += en.x * q1; k[2] += en.x * q2;
+          k[3] += en.y * q0; k[4] += en.y * q1; k[5] += en.y * q2;
+          k[6] += en.z * q0; k[7] += en.z * q1; k[8] += en.z * q2;
         }
       }
-      float* kk = lds + L.kk + lane * kstride + c2 * 9;
-      float* kt = lds + L.kk + c2 * kstride + lane * 9;
-#pragma unroll
-      for (int q = 0; q < 9; q++) { kk[q] = k[q]; kt[(q % 3) * 3 + q / 3] = k[q]; }
-      if (c2 == lane) { ik00 = 1.0f / k[0]; ik11 = 1.0f / k[4]; ik22 = 1.0f / k[8]; ck10 = k[3]; ck20 = k[6]; ck21 = k[7]; }
     }
+    float* kk = lds + L.kk + c * kstride + c2 * 9;
+    float* kt = lds + L.kk + c2 * kstride + c * 9;
+#pragma unroll
+    for (int q = 0; q < 9; q++) kk[q] = k[q];
+    if (c != c2) {
+#pragma unroll
+      for (int q = 0; q < 9; q++) kt[(q % 3) * 3 + q / 3] = k[q];
+    }
+  }
+  __syncthreads();
+  if (is_con) {
+    const float* kd = lds + L.kk + lane * kstride + lane * 9;
+    ik00 = 1.0f / kd[0]; ik11 = 1.0f / kd[4]; ik22 = 1.0f / kd[8]; ck10 = kd[3]; ck20 = kd[6]; ck21 = kd[7];
   }
   __syncthreads();
   TSTAMP(12);
