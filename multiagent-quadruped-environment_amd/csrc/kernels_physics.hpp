@@ -708,8 +708,8 @@ __global__ void __launch_bounds__(64) k_simulate(const DevModel* __restrict__ m,
     const float* krow = lds + L.kk + lane * kstride;
     for (int it = 0; it < m->solver_iterations; it++) {
       for (int sidx = 0; sidx < maxlen; sidx++) {
-        const int ownA = (gstartA + sidx) & 63;
         const bool vA = sidx < glenA;
+        const int ownA = vA ? (gstartA + sidx) : (is_con ? lane : 0);   // never index an unwritten block (0 * NaN)
         float kk[9];
 #pragma unroll
         for (int q = 0; q < 9; q++) kk[q] = krow[ownA * 9 + q];
@@ -727,8 +727,8 @@ __global__ void __launch_bounds__(64) k_simulate(const DevModel* __restrict__ m,
         cu1 += kk[3] * e0 + kk[4] * e1 + kk[5] * e2;
         cu2 += kk[6] * e0 + kk[7] * e1 + kk[8] * e2;
         if (npair > 0) {           // two-actor contacts also feel the owner of their second actor's group
-          const int ownB = (gstartB + sidx) & 63;
           const bool vB = is_pair && sidx < glenB;
+          const int ownB = vB ? (gstartB + sidx) : (is_con ? lane : 0);
           float f0 = __shfl(d0, ownB, 64), f1 = __shfl(d1, ownB, 64), f2 = __shfl(d2, ownB, 64);
           if (!vB) { f0 = 0.0f; f1 = 0.0f; f2 = 0.0f; }
 #pragma unroll

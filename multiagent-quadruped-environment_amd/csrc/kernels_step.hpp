@@ -192,6 +192,70 @@ __global__ void __launch_bounds__(256) k_compute_torques(const DevModel* m, DevS
   if (dec_i >= 0) st.sub_tau[((size_t)env * 4 + dec_i) * 12 * A + a * 12 + j] = tau;   // post_decimation_step :113
 }
 
+// MFMA form of the same computation for control type "C" (the batched actuator-MLP GEMM of the north star):
+// one wavefront = 32 joints.  All three layers are evaluated TRANSPOSED (units x joints) with v_mfma_f32_32x32x2_f32,
+// so the accumulator layout of one layer (lane = joint column, 16 registers = 16 hidden units, split over the two
+// half-waves) is exactly the B-operand layout of the next: step r of layer 2 consumes hidden unit u(r,h) =
+// (r&3)+8(r>>2)+4h from register r of lane (joint, h) -- no LDS transpose, no shuffles; the weights are the A operand,
+// pre-permuted per lane into 3 + 16 VGPRs.  The 32->1 output layer is 16 FMAs per lane + one cross-half add.
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+__global__ void __launch_bounds__(256) k_compute_torques_mfma(const DevModel* m, DevState st, int dec_i) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j32 = lane & 31, h = lane >> 5;
+  const int R = m->R, A = m->A;
+  const int nj = R * 12;
+  const int idx = (blockIdx.x * 4 + wave) * 32 + j32;          // joint handled by this lane pair
+  const bool valid = idx < nj;
+  const int ii = valid ? idx : nj - 1;
+  const int i = ii / 12, j = ii - i * 12;
+  const int env = i / A, a = i - env * A;
+  const float* W0 = m->actuator.W[0]; const float* b0 = m->actuator.b[0];
+  const float* W1 = m->actuator.W[1]; const float* b1 = m->actuator.b[1];
+  const float* W2 = m->actuator.W[2]; const float* b2 = m->actuator.b[2];
+  // per-lane weight fragments (A operands): row = hidden unit j32, k = the half-wave's element of each k-pair
+  float a1[3], a2[16], w3[16];
+  f32x16_t acc1, acc2;
+#pragma unroll
+  for (int s2 = 0; s2 < 3; s2++) a1[s2] = W0[j32 * 6 + 2 * s2 + h];
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    const int u = (r & 3) + 8 * (r >> 2) + 4 * h;
+    a2[r] = W1[j32 * 32 + u];
+    w3[r] = W2[u];
+    acc1[r] = b0[u];
+    acc2[r] = b1[u];
+  }
+  float* e1 = st.act_hist; float* e2 = e1 + (size_t)R * 12; float* v1 = e2 + (size_t)R * 12; float* v2 = v1 + (size_t)R * 12;
+  const float* ds = st.dof + ((size_t)env * m->ND + a * 12 + j) * 2;
+  const float q = ds[0], qd = ds[1];
+  float as = st.actions[ii] * m->action_scale;
+  if (j % 3 == 0) as *= m->hip_scale_reduction;
+  const float err = q - (as + m->default_dof_pos[j]);
+  const float x0 = err, x1 = e1[ii], x2 = e2[ii], x3 = qd, x4 = v1[ii], x5 = v2[ii];
+  // layer 1 (K = 6): B operand = input (2s + h) of this lane's joint
+  acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[0], h ? x1 : x0, acc1, 0, 0, 0);
+  acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[1], h ? x3 : x2, acc1, 0, 0, 0);
+  acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[2], h ? x5 : x4, acc1, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 16; r++) acc1[r] = softsign_f(acc1[r]);
+  // layer 2 (K = 32): step r consumes hidden units u(r,0), u(r,1)
+#pragma unroll
+  for (int r = 0; r < 16; r++) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[r], acc1[r], acc2, 0, 0, 0);
+  float part = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 16; r++) part = fmaf(w3[r], softsign_f(acc2[r]), part);
+  float tau = part + __shfl_xor(part, 32, 64) + b2[0];
+  if (valid && h == 0) {
+    e2[idx] = x1; e1[idx] = err;
+    v2[idx] = x4; v1[idx] = qd;
+    const float lim = m->torque_limits[j];
+    tau = clampf(tau, -lim, lim);
+    st.torques[idx] = tau;
+    if (dec_i >= 0) st.sub_tau[((size_t)env * 4 + dec_i) * 12 * A + a * 12 + j] = tau;
+  }
+}
+
 // ----------------------------------------------------------------------------------------------------------------
 // post_physics_step (legged_robot.py:117-157, legged_robot_field.py:117-146, go1.py:153-279,110-145, go1_sheep.py:35-64)
 // One thread per env (a few hundred flops each; ~10 kB/env of traffic only when the env resets).

@@ -404,7 +404,10 @@ static int policy_step(mqe_sim* s, const float* command, hipStream_t q) {
 static void launch_torques(mqe_sim* s, int dec_i, hipStream_t q) {
   ProfScope ps(s, PROF_TORQUES, q);
   int n = s->R * 12;
-  hipLaunchKernelGGL(k_compute_torques, dim3((n + 255) / 256), dim3(256), 0, q, s->dm, s->st, dec_i);
+  if (s->d.control_type == MQE_CTRL_C)
+    hipLaunchKernelGGL(k_compute_torques_mfma, dim3((n + 127) / 128), dim3(256), 0, q, s->dm, s->st, dec_i);
+  else
+    hipLaunchKernelGGL(k_compute_torques, dim3((n + 255) / 256), dim3(256), 0, q, s->dm, s->st, dec_i);
 }
 static void launch_simulate(mqe_sim* s, hipStream_t q) {
   ProfScope ps(s, PROF_SIMULATE, q);
