@@ -52,14 +52,22 @@ struct PhysLds {   // float offsets into dynamic LDS
   int root, dof, tau, body, minv, rhs, fcol, leg, basei, sinv, tt, sph, con, B, W, js, kk, total;
 };
 __host__ __device__ inline PhysLds phys_lds_layout(int A, int P, int ND, int nbody, int ndof, int nsph, int maxc, int bstride) {
+  // Regions that live to the end of the kernel first; then an ARENA shared by (a) everything that is dead once the
+  // contact rows exist (link records, CRBA/Schur scratch, collision spheres) and (b) the coupling blocks, which are
+  // only written after (a) has been consumed.  This is what keeps the footprint under 160 KiB / 6 per wave.
   PhysLds L; int o = 0;
   L.root = o; o += (A + P) * 13;
   L.dof = o; o += ND * 2;
   L.tau = o; o += 12 * A;
   o = (o + 3) & ~3;
-  L.body = o; o += nbody * BODY_STRIDE;
   L.minv = o; o += A * MQE_RD * MQE_RD;
   L.rhs = o; o += 128;
+  L.con = o; o += maxc * CON_STRIDE;
+  L.B = o; o += maxc * 2 * 54;          // per contact and side: 3 rows x 18 local dofs of M^-1 J^T
+  L.W = o;
+  L.js = o; o += maxc * JS_STRIDE;
+  const int arena = o;
+  L.body = o; o += nbody * BODY_STRIDE;
   L.fcol = o; o += A * 12 * 6;
   L.leg = o; o += A * 4 * 54;
   L.basei = o; o += A * 10;
@@ -67,11 +75,9 @@ __host__ __device__ inline PhysLds phys_lds_layout(int A, int P, int ND, int nbo
   L.tt = o; o += A * MQE_RD * 6;
   o = (o + 3) & ~3;
   L.sph = o; o += nsph * 4;
-  L.con = o; o += maxc * CON_STRIDE;
-  L.B = o; o += maxc * 2 * 54;          // per contact and side: 3 rows x 18 local dofs of M^-1 J^T
-  L.W = o;
-  L.js = o; o += maxc * JS_STRIDE;
-  L.kk = o; o += maxc * (maxc * 9 + 1);     // row = receiving contact (lane), padded to an odd stride (bank conflicts)
+  L.kk = arena;                                    // row = receiving contact, odd stride (bank conflicts)
+  const int kk_end = arena + maxc * (maxc * 9 + 1);
+  if (kk_end > o) o = kk_end;
   L.total = o;
   return L;
 }
