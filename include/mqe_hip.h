@@ -93,6 +93,8 @@ typedef struct {
   /* seesaw (fixed base + revolute plank), reference resources/objects/seesaw.urdf */
   float seesaw_joint_offset[3], seesaw_plank_center[3], seesaw_plank_half[3], seesaw_base_half[3];
   float seesaw_plank_mass, seesaw_plank_inertia_yy, seesaw_vel_limit, seesaw_default_angle;
+  float seesaw_column_radius, seesaw_column_length;   /* static column under the platform (seesaw.urdf:90-108) */
+  float seesaw_theta_lo, seesaw_theta_hi;             /* plank angles at which an end touches the ground slab */
   /* control (reference go1_config.py:108-155) */
   int32_t control_type;
   float action_scale, hip_scale_reduction, clip_actions;

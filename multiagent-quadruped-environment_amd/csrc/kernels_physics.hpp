@@ -34,6 +34,35 @@ __device__ __forceinline__ V3 sym_vec(const float* S, V3 v) {
   return v3(S[0] * v.x + S[3] * v.y + S[4] * v.z, S[3] * v.x + S[1] * v.y + S[5] * v.z, S[4] * v.x + S[5] * v.y + S[2] * v.z);
 }
 
+// sphere (centre c, radius r) vs box (centre bc, rotation R, half extents h): signed distance, world normal box->sphere
+__device__ __forceinline__ float sphere_box(V3 c, float r, V3 bc, const float* R, V3 h, V3& n) {
+  const V3 d = c - bc;
+  const float pl[3] = {R[0] * d.x + R[3] * d.y + R[6] * d.z, R[1] * d.x + R[4] * d.y + R[7] * d.z, R[2] * d.x + R[5] * d.y + R[8] * d.z};
+  const float hh[3] = {h.x, h.y, h.z};
+  float dl[3], nl[3] = {0, 0, 0};
+  bool inside = true;
+  for (int k = 0; k < 3; k++) {
+    const float q = fminf(fmaxf(pl[k], -hh[k]), hh[k]);
+    dl[k] = pl[k] - q;
+    if (dl[k] != 0.0f) inside = false;
+  }
+  float sd;
+  if (!inside) {
+    const float dist = sqrtf(dl[0] * dl[0] + dl[1] * dl[1] + dl[2] * dl[2]);
+    nl[0] = dl[0] / dist; nl[1] = dl[1] / dist; nl[2] = dl[2] / dist;
+    sd = dist - r;
+  } else {
+    int ax = 0; float best = hh[0] - fabsf(pl[0]);
+    for (int k = 1; k < 3; k++) { const float mm = hh[k] - fabsf(pl[k]); if (mm < best) { best = mm; ax = k; } }
+    nl[0] = ax == 0 ? (pl[0] >= 0 ? 1.0f : -1.0f) : 0.0f;
+    nl[1] = ax == 1 ? (pl[1] >= 0 ? 1.0f : -1.0f) : 0.0f;
+    nl[2] = ax == 2 ? (pl[2] >= 0 ? 1.0f : -1.0f) : 0.0f;
+    sd = -best - r;
+  }
+  n = mat_vec(R, v3(nl[0], nl[1], nl[2]));
+  return sd;
+}
+
 __device__ __forceinline__ float wave_sum(float x) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
@@ -46,7 +75,9 @@ __device__ __forceinline__ float wave_sum(float x) {
 enum { B_R = 0, B_P = 9, B_W = 12, B_VP = 15, B_A = 18, B_AL = 21, B_AP = 24, B_C = 27, B_M = 30 };
 enum { C_IDS = 0, C_P = 4, C_N = 7, C_T1 = 10, C_T2 = 13, C_SD = 16, C_BIAS = 17, C_K = 18, C_LAM = 24, C_REP = 27 };
 
-__host__ __device__ inline int mqe_maxc(int A, int P) { int v = 8 * A + P; return v > 32 ? 32 : v; }
+__host__ __device__ inline int mqe_maxc(int A, int P) { int v = 8 * A + 2 * P; return v > 40 ? 40 : v; }
+#define CAP_ROBOT 8     // terrain / static-object contacts kept per robot (spheres are priority ordered: feet first)
+#define CAP_NPC 2       // per ball / sheep; per-actor caps so that no actor starves the ones after it in the list
 
 struct PhysLds {   // float offsets into dynamic LDS
   int root, dof, tau, body, minv, rhs, fcol, leg, basei, sinv, tt, sph, con, B, W, js, kk, total;
@@ -392,6 +423,12 @@ __global__ void __launch_bounds__(64) k_simulate(const DevModel* __restrict__ m,
     const float* rh = lds + L.rhs + dact * MQE_RD;
     for (int ee = 0; ee < MQE_RD; ee++) acc += Mc[ee * MQE_RD] * rh[ee];
     vd += dt * acc;
+  } else if (is_dof && m->has_seesaw) {     // the plank's hinge: one angular dof about +y through the hinge point
+    dact = A; dk = 0; dmask = 1u; dlin = false;
+    dax = v3(0, 1, 0);
+    danc = ld3(lds + L.root + A * 13) + v3(m->ss_joint_offset[0], m->ss_joint_offset[1], m->ss_joint_offset[2]);
+    vd = lds[L.dof + (12 * A) * 2 + 1];
+    dinvm = 1.0f / m->ss_inertia;
   } else if (is_dof) {
     const int q = lane - A * MQE_RD;
     const int p = q / npcdof; dk = q - p * npcdof;
@@ -426,12 +463,26 @@ __global__ void __launch_bounds__(64) k_simulate(const DevModel* __restrict__ m,
   __syncthreads();
 
   TSTAMP(8);
+  // seesaw geometry (uniform): platform centre, hinge, plank rotation about +y and centre
+  const bool SS = m->has_seesaw != 0;
+  V3 ssB = v3(0, 0, 0), ssPiv = v3(0, 0, 0), ssC = v3(0, 0, 0);
+  float ssR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, ssTheta = 0.0f;
+  if (SS) {
+    ssB = ld3(lds + L.root + A * 13);
+    ssPiv = ssB + v3(m->ss_joint_offset[0], m->ss_joint_offset[1], m->ss_joint_offset[2]);
+    ssTheta = lds[L.dof + (12 * A) * 2];
+    const float cth = cosf(ssTheta), sth = sinf(ssTheta);
+    ssR[0] = cth; ssR[2] = sth; ssR[6] = -sth; ssR[8] = cth;
+    ssC = ssPiv + mat_vec(ssR, v3(m->ss_plank_center[0], m->ss_plank_center[1], m->ss_plank_center[2]));
+  }
   // ---- contact generation: terrain (ground plane, wall SDF), canonical order --------------------------------------------
   int nc = 0;
-  for (int s0 = 0; s0 < nsph; s0 += 64) {
-    const int s = s0 + lane;
-    bool gflag = false, wflag = false;
-    float gsd = 0, wsd = 0; V3 wn = v3(0, 0, 1); V3 c = v3(0, 0, 0); float rad = 0;
+  for (int actu = 0; actu < A + PD; actu++) {        // one actor per iteration: lanes = its spheres
+    const int nsa = actu < A ? nsr : m->npc_n_spheres;
+    const int s = lane < nsa ? (actu < A ? actu * nsr + lane : A * nsr + (actu - A) * m->npc_n_spheres + lane) : nsph;
+    const int cap = actu < A ? CAP_ROBOT : CAP_NPC;
+    bool gflag = false, wflag = false, bflag = false, cflag = false;   // ground, wall, seesaw platform, seesaw column
+    float gsd = 0, wsd = 0, bsd = 0, csd = 0; V3 wn = v3(0, 0, 1), bn = v3(0, 0, 1), cn3 = v3(0, 0, 1); V3 c = v3(0, 0, 0); float rad = 0;
     int act = 0, body = 0, rep = 0;
     if (s < nsph) {
       const float* sp = lds + L.sph + s * 4;
@@ -465,13 +516,20 @@ __global__ void __launch_bounds__(64) k_simulate(const DevModel* __restrict__ m,
       } else if (sh <= 0) { wsd = dz - rad; wn = v3(0, 0, 1); }
       else { const float dist = sqrtf(sh * sh + dz * dz); wsd = dist - rad; wn = v3(gx * sh / dist, gy * sh / dist, dz / dist); }
       wflag = wsd < m->contact_offset;
+      if (SS && act < A) {
+        const float I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        bsd = sphere_box(c, rad, ssB, I3, v3(m->ss_base_half[0], m->ss_base_half[1], m->ss_base_half[2]), bn);
+        bflag = bsd < m->contact_offset;
+        const float dx = c.x - ssB.x, dy = c.y - ssB.y, rho = sqrtf(dx * dx + dy * dy);
+        if (c.z < ssB.z && c.z > ssB.z - m->ss_col_length && rho > 1e-6f) { csd = rho - m->ss_col_radius - rad; cn3 = v3(dx / rho, dy / rho, 0); cflag = csd < m->contact_offset; }
+      }
     }
-    const unsigned long long bg = __ballot(gflag), bw2 = __ballot(wflag);
+    const unsigned long long bg = __ballot(gflag), bw2 = __ballot(wflag), bb2 = __ballot(bflag), bc2 = __ballot(cflag);
     const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const int pre = __popcll(bg & lower) + __popcll(bw2 & lower);
+    const int pre = __popcll(bg & lower) + __popcll(bw2 & lower) + __popcll(bb2 & lower) + __popcll(bc2 & lower);
     if (gflag) {
       const int slot = nc + pre;
-      if (slot < maxc) {
+      if (slot < maxc && pre < cap) {
         float* cr = lds + L.con + slot * CON_STRIDE;
         cr[C_IDS] = __int_as_float(act); cr[C_IDS + 1] = __int_as_float(body); cr[C_IDS + 2] = __int_as_float(-1); cr[C_IDS + 3] = __int_as_float(0);
         cr[C_P] = c.x; cr[C_P + 1] = c.y; cr[C_P + 2] = c.z - rad;
@@ -480,8 +538,8 @@ __global__ void __launch_bounds__(64) k_simulate(const DevModel* __restrict__ m,
       }
     }
     if (wflag) {
-      const int slot = nc + pre + (gflag ? 1 : 0);
-      if (slot < maxc) {
+      const int rk = pre + (gflag ? 1 : 0), slot = nc + rk;
+      if (slot < maxc && rk < cap) {
         float* cr = lds + L.con + slot * CON_STRIDE;
         cr[C_IDS] = __int_as_float(act); cr[C_IDS + 1] = __int_as_float(body); cr[C_IDS + 2] = __int_as_float(-1); cr[C_IDS + 3] = __int_as_float(0);
         cr[C_P] = c.x - rad * wn.x; cr[C_P + 1] = c.y - rad * wn.y; cr[C_P + 2] = c.z - rad * wn.z;
@@ -489,8 +547,52 @@ __global__ void __launch_bounds__(64) k_simulate(const DevModel* __restrict__ m,
         cr[C_REP] = __int_as_float(rep); cr[C_REP + 1] = __int_as_float(-1);
       }
     }
-    nc += __popcll(bg) + __popcll(bw2);
-    if (nc > maxc) nc = maxc;
+    if (bflag || cflag) {
+      for (int which = 0; which < 2; which++) {
+        if (which == 0 ? !bflag : !cflag) continue;
+        const int rk = pre + (gflag ? 1 : 0) + (wflag ? 1 : 0) + (which == 1 && bflag ? 1 : 0), slot = nc + rk;
+        if (slot < maxc && rk < cap) {
+          const V3 nn = which == 0 ? bn : cn3;
+          float* cr = lds + L.con + slot * CON_STRIDE;
+          cr[C_IDS] = __int_as_float(act); cr[C_IDS + 1] = __int_as_float(body); cr[C_IDS + 2] = __int_as_float(-1); cr[C_IDS + 3] = __int_as_float(0);
+          cr[C_P] = c.x - rad * nn.x; cr[C_P + 1] = c.y - rad * nn.y; cr[C_P + 2] = c.z - rad * nn.z;
+          cr[C_N] = nn.x; cr[C_N + 1] = nn.y; cr[C_N + 2] = nn.z; cr[C_SD] = which == 0 ? bsd : csd;
+          cr[C_REP] = __int_as_float(rep); cr[C_REP + 1] = __int_as_float(-1);
+        }
+      }
+    }
+    {
+      int tot = __popcll(bg) + __popcll(bw2) + __popcll(bb2) + __popcll(bc2);
+      if (tot > cap) tot = cap;
+      nc += tot;
+      if (nc > maxc) nc = maxc;
+    }
+  }
+  // robot spheres vs the seesaw plank (dynamic: couples the robots through the hinge); after all terrain contacts
+  if (SS) {
+    for (int s0 = 0; s0 < A * nsr; s0 += 64) {
+      const int s = s0 + lane;
+      bool hit = false; float sd = 0; V3 n = v3(0, 0, 1), c = v3(0, 0, 0); float rad = 0; int act = 0, body = 0, rep = 0;
+      if (s < A * nsr) {
+        const float* sp = lds + L.sph + s * 4;
+        c = ld3(sp); rad = sp[3];
+        act = s / nsr; const int si = s - act * nsr; body = rm.sphere_body[si]; rep = act * MQE_NREP + rm.sphere_reported[si];
+        sd = sphere_box(c, rad, ssC, ssR, v3(m->ss_plank_half[0], m->ss_plank_half[1], m->ss_plank_half[2]), n);
+        hit = sd < m->contact_offset;
+      }
+      const unsigned long long bh = __ballot(hit);
+      const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+      const int slot = nc + __popcll(bh & lower);
+      if (hit && slot < maxc) {
+        float* cr = lds + L.con + slot * CON_STRIDE;
+        cr[C_IDS] = __int_as_float(act); cr[C_IDS + 1] = __int_as_float(body); cr[C_IDS + 2] = __int_as_float(A); cr[C_IDS + 3] = __int_as_float(0);
+        cr[C_P] = c.x - rad * n.x; cr[C_P + 1] = c.y - rad * n.y; cr[C_P + 2] = c.z - rad * n.z;
+        cr[C_N] = n.x; cr[C_N + 1] = n.y; cr[C_N + 2] = n.z; cr[C_SD] = sd;
+        cr[C_REP] = __int_as_float(rep); cr[C_REP + 1] = __int_as_float(A * MQE_NREP + 1);
+      }
+      nc += __popcll(bh);
+      if (nc > maxc) nc = maxc;
+    }
   }
   TSTAMP(9);
   // ---- sphere-sphere contacts between different actors (a < b; outer loop over b's spheres, lanes = a's spheres) -------
@@ -600,6 +702,19 @@ __global__ void __launch_bounds__(64) k_simulate(const DevModel* __restrict__ m,
           const float vv = Vm[act * MQE_RD + li];
           cu0 += J[i][0] * vv; cu1 += J[i][1] * vv; cu2 += J[i][2] * vv;
         }
+      } else if (SS) {
+        const V3 r0 = p - ssPiv;
+        const V3 wy = cross(v3(0, 1, 0), r0);
+        const float j0 = sg * dot(n, wy), j1 = sg * dot(t1, wy), j2 = sg * dot(t2, wy);
+        const float ii = 1.0f / m->ss_inertia;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+          const bool on = i == 0;
+          js[i * 4] = on ? j0 : 0.0f; js[i * 4 + 1] = on ? j1 : 0.0f; js[i * 4 + 2] = on ? j2 : 0.0f; js[i * 4 + 3] = __int_as_float(0);
+        }
+        const float vv = Vm[A * MQE_RD];
+        cu0 += j0 * vv; cu1 += j1 * vv; cu2 += j2 * vv;
+        Bs[0] = ii * j0; Bs[18] = ii * j1; Bs[36] = ii * j2;
       } else {
         const int pi = act - A;
         const V3 r0 = p - ld3(lds + L.root + (A + pi) * 13);
@@ -797,6 +912,10 @@ __global__ void __launch_bounds__(64) k_simulate(const DevModel* __restrict__ m,
     }
   }
 
+  if (SS && lane == A * MQE_RD) {     // hinge: velocity limit, then the geometric end stops
+    vd = clampf(vd, -m->ss_vel_limit, m->ss_vel_limit);
+    vd = clampf(vd, (m->ss_theta_lo - ssTheta) / dt, (m->ss_theta_hi - ssTheta) / dt);
+  }
   TSTAMP(14);
   if (dbg.minv != nullptr) {
     for (int i = lane; i < MQE_RD * MQE_RD; i += 64) dbg.minv[i] = lds[L.minv + dbg.robot * MQE_RD * MQE_RD + i];
@@ -837,6 +956,10 @@ __global__ void __launch_bounds__(64) k_simulate(const DevModel* __restrict__ m,
     const float q = lds[L.dof + (dact * 12 + j) * 2];
     g_dof[(dact * 12 + j) * 2] = q + dt * vd;
     g_dof[(dact * 12 + j) * 2 + 1] = vd;
+  }
+  if (SS && lane == A * MQE_RD) {
+    g_dof[(12 * A) * 2] = ssTheta + dt * vd;
+    g_dof[(12 * A) * 2 + 1] = vd;
   }
   if (lane < A + PD) {
     const int act = lane;

@@ -137,7 +137,7 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   m.npc_kind = d->npc_kind; m.task = d->task;
   m.n_npc_dyn = (d->npc_kind == MQE_NPC_BALL || d->npc_kind == MQE_NPC_SHEEP) ? P : 0;
   m.npc_lin_only = d->npc_kind == MQE_NPC_SHEEP;
-  m.npc_dofs_each = m.npc_lin_only ? 3 : 6;
+  m.npc_dofs_each = seesaw ? 1 : (m.npc_lin_only ? 3 : 6);
   m.env_id_offset = d->env_id_offset; m.seed = d->seed;
   m.dt = d->dt; m.decimation = d->decimation; m.gravity_z = d->gravity_z; m.solver_iterations = d->solver_iterations;
   m.contact_offset = d->contact_offset; m.max_depen = d->max_depenetration_velocity; m.friction = d->friction; m.erp = d->erp;
@@ -146,6 +146,12 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   memcpy(m.npc_sphere_center, d->npc_sphere_center, sizeof m.npc_sphere_center);
   memcpy(m.npc_sphere_radius, d->npc_sphere_radius, sizeof m.npc_sphere_radius);
   m.seesaw_default_angle = d->seesaw_default_angle;
+  m.has_seesaw = seesaw;
+  memcpy(m.ss_joint_offset, d->seesaw_joint_offset, 12); memcpy(m.ss_plank_center, d->seesaw_plank_center, 12);
+  memcpy(m.ss_plank_half, d->seesaw_plank_half, 12); memcpy(m.ss_base_half, d->seesaw_base_half, 12);
+  m.ss_inertia = d->seesaw_plank_inertia_yy; m.ss_vel_limit = d->seesaw_vel_limit;
+  m.ss_col_radius = d->seesaw_column_radius; m.ss_col_length = d->seesaw_column_length;
+  m.ss_theta_lo = d->seesaw_theta_lo; m.ss_theta_hi = d->seesaw_theta_hi;
   m.control_type = d->control_type; m.action_scale = d->action_scale; m.hip_scale_reduction = d->hip_scale_reduction;
   m.clip_actions = d->clip_actions; memcpy(m.torque_limits, d->torque_limits, sizeof m.torque_limits);
   m.kp = d->kp; m.kd = d->kd; memcpy(m.default_dof_pos, d->default_dof_pos, sizeof m.default_dof_pos);
@@ -162,7 +168,7 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   memcpy(m.reward_scale, d->reward_scale, sizeof m.reward_scale); memcpy(m.wrapper_param, d->wrapper_param, sizeof m.wrapper_param);
   // physics kernel geometry
   m.nbody_env = A * MQE_NBODY + m.n_npc_dyn;
-  m.ndof_env = A * MQE_RD + m.n_npc_dyn * m.npc_dofs_each;
+  m.ndof_env = A * MQE_RD + m.n_npc_dyn * m.npc_dofs_each + (seesaw ? 1 : 0);
   m.nsph_env = A * d->robot.n_spheres + m.n_npc_dyn * d->npc_n_spheres;
   m.maxc = mqe_maxc(A, P);
   m.ldsB_stride = m.ndof_env;

@@ -53,6 +53,7 @@ class SimDesc(C.Structure):
         ("seesaw_joint_offset", f32 * 3), ("seesaw_plank_center", f32 * 3), ("seesaw_plank_half", f32 * 3),
         ("seesaw_base_half", f32 * 3),
         ("seesaw_plank_mass", f32), ("seesaw_plank_inertia_yy", f32), ("seesaw_vel_limit", f32), ("seesaw_default_angle", f32),
+        ("seesaw_column_radius", f32), ("seesaw_column_length", f32), ("seesaw_theta_lo", f32), ("seesaw_theta_hi", f32),
         ("control_type", i32), ("action_scale", f32), ("hip_scale_reduction", f32), ("clip_actions", f32),
         ("torque_limits", f32 * NDOF), ("kp", f32), ("kd", f32), ("default_dof_pos", f32 * NDOF),
         ("command_obs", f32 * 70), ("cmd_lin_scale", f32), ("cmd_ang_scale", f32), ("clip_command", i32),

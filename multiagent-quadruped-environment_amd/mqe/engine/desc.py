@@ -158,6 +158,16 @@ def build_desc(cfg, num_envs, terrain, env_origins, agent_origins, gate_pos=None
         d.seesaw_plank_mass, d.seesaw_plank_inertia_yy = plank["mass"], plank["inertia"][1][1]
         d.seesaw_vel_limit = plank["velocity"]
         d.seesaw_default_angle = getattr(cfg.init_state, "default_npc_joint_angles", [0.0])[0]
+        col = base["shapes"][1]                       # ("cylinder", (radius, length), R, t)
+        d.seesaw_column_radius, d.seesaw_column_length = col[1][0], col[1][1]
+        # The plank's COM sits on the hinge (seesaw.urdf:41-47) so gravity exerts no torque; what bounds its swing is an
+        # end touching the ground slab.  The URDF gives no joint range (lower = upper = 0 by omission, while the task
+        # starts it at -0.2 rad), so the engine uses the geometric stops.
+        pivot_z = cfg.init_state.init_states_npc[0].pos[2] + plank["joint_offset"][2]
+        cx, hx, hz = plank["shapes"][0][3][0], plank["shapes"][0][1][0], plank["shapes"][0][1][2]
+        clear = pivot_z - hz - terrain.ground_z
+        d.seesaw_theta_lo = -math.asin(min(1.0, clear / (hx - cx)))    # -x end (longer arm) down
+        d.seesaw_theta_hi = math.asin(min(1.0, clear / (hx + cx)))     # +x end down
     # control
     ctl = cfg.control
     d.control_type = abi.CTRL[ctl.control_type]

@@ -36,7 +36,9 @@ typedef REAL real;
 #define RD 18                       /* dofs of one robot: 3 lin + 3 ang + 12 joints */
 #define MAXDOF (MAXA * RD + MAXP * 6 + 1)
 #define MAXC 64                     /* storage; the active bound is env_maxc() */
-static inline int env_maxc(int A, int P) { int v = 8 * A + P; return v > 32 ? 32 : v; } /* = mqe_maxc() of the engine */
+static inline int env_maxc(int A, int P) { int v = 8 * A + 2 * P; return v > 40 ? 40 : v; } /* = mqe_maxc() of the engine */
+#define CAP_ROBOT 8   /* terrain / static-object contacts kept per robot (spheres are priority ordered: feet first) */
+#define CAP_NPC 2
 #define FR MQE_FRAME
 #define OBS_BAG 74
 
@@ -476,6 +478,32 @@ static real sdf_sample(const mqo_sim* s, real x, real y, real* gx, real* gy) {
   return a0 + (a1 - a0) * tx;
 }
 
+/* sphere (centre c, radius r) vs box (centre bc, rotation R row-major, half extents h): signed distance and world
+ * normal pointing from the box to the sphere */
+static real sphere_box(const real* c, real r, const real* bc, const real* R, const real* h, real* n) {
+  real d[3] = {c[0] - bc[0], c[1] - bc[1], c[2] - bc[2]}, pl[3], q[3], dl[3];
+  for (int k = 0; k < 3; k++) pl[k] = R[k] * d[0] + R[3 + k] * d[1] + R[6 + k] * d[2];     /* R^T d */
+  int inside = 1;
+  for (int k = 0; k < 3; k++) {
+    q[k] = pl[k] < -h[k] ? -h[k] : (pl[k] > h[k] ? h[k] : pl[k]);
+    dl[k] = pl[k] - q[k];
+    if (dl[k] != 0) inside = 0;
+  }
+  real nl[3] = {0, 0, 0}, sd;
+  if (!inside) {
+    real dist = (real)sqrt((double)(dl[0] * dl[0] + dl[1] * dl[1] + dl[2] * dl[2]));
+    for (int k = 0; k < 3; k++) nl[k] = dl[k] / dist;
+    sd = dist - r;
+  } else {
+    int ax = 0; real best = h[0] - (real)fabs((double)pl[0]);
+    for (int k = 1; k < 3; k++) { real m = h[k] - (real)fabs((double)pl[k]); if (m < best) { best = m; ax = k; } }
+    nl[ax] = pl[ax] >= 0 ? (real)1 : (real)-1;
+    sd = -best - r;
+  }
+  mat3_vec(R, nl, n);
+  return sd;
+}
+
 static void make_tangents(const real* n, real* t1, real* t2) {
   real a[3] = {0, 0, 1};
   if (fabs((double)n[2]) > 0.7) { a[0] = 1; a[2] = 0; }
@@ -551,6 +579,11 @@ static void fill_jac(const mqo_sim* s, const envwork_t* w, int act, int body, co
       real wv[3]; cross3(bk[j].a, r, wv);
       for (int q = 0; q < 3; q++) J[q][o + 6 + (j - 1)] += sign * dot3(dirs[q], wv);
     }
+  } else if (s->d.npc_kind == MQE_NPC_SEESAW) {
+    real ay[3] = {0, 1, 0};
+    real r[3] = {p[0] - npc_pos[0][0], p[1] - npc_pos[0][1], p[2] - npc_pos[0][2]};
+    real wv[3]; cross3(ay, r, wv);
+    for (int q = 0; q < 3; q++) J[q][A * RD] += sign * dot3(dirs[q], wv);
   } else {
     int pi = act - A, o = A * RD + pi * 6;
     for (int k = 0; k < 3; k++) {
@@ -572,8 +605,11 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
   real dt = d->dt;
   float* root = s->root + (size_t)env * (A + s->P) * 13;
   float* dofs = s->dof + (size_t)env * s->ND * 2;
-  int ndof = A * RD + P * 6;
+  const int SS = d->npc_kind == MQE_NPC_SEESAW;   /* fixed base + 1-dof plank (seesaw.urdf) */
+  const int sdof = A * RD;
+  int ndof = A * RD + P * 6 + SS;
   real g[3] = {0, 0, d->gravity_z};
+  real ssR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, ssC[3] = {0, 0, 0}, ssB[3] = {0, 0, 0}, ssTheta = 0;
   real npc_pos[MAXP][3];
 
   /* ---- forward kinematics, mass matrix, bias, unconstrained velocity per robot */
@@ -681,17 +717,40 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
     }
   }
 
+  if (SS) {
+    const float* rs = root + A * 13;
+    for (int k = 0; k < 3; k++) { ssB[k] = rs[k]; npc_pos[0][k] = rs[k] + d->seesaw_joint_offset[k]; }   /* npc_pos[0] = hinge */
+    ssTheta = dofs[(12 * A) * 2];
+    real c = (real)cos((double)ssTheta), sn = (real)sin((double)ssTheta);
+    ssR[0] = c; ssR[2] = sn; ssR[6] = -sn; ssR[8] = c;                  /* rotation about +y */
+    real pc[3] = {d->seesaw_plank_center[0], d->seesaw_plank_center[1], d->seesaw_plank_center[2]}, pw[3];
+    mat3_vec(ssR, pc, pw);
+    for (int k = 0; k < 3; k++) ssC[k] = npc_pos[0][k] + pw[k];
+    w->v[sdof] = dofs[(12 * A) * 2 + 1];                               /* COM on the hinge: no gravity torque, no drive */
+  }
+
   /* ---- contact generation (canonical order: terrain contacts actor by actor, sphere by sphere, ground before
    * wall; then sphere pairs for actor pairs (a<b), outer loop over b's spheres, inner over a's) */
   int nact = A + P;
   w->nc = 0;
   for (int act = 0; act < nact; act++) {
+    int mine = 0;                       /* no actor may starve the ones after it */
+    const int cap = act < A ? CAP_ROBOT : CAP_NPC;
     for (int si = 0; si < w->sph_n[act]; si++) {
       const real* c = w->sph_c[act][si];
       real r = w->sph_r[act][si];
-      for (int pass = 0; pass < 2; pass++) {
+      for (int pass = 0; pass < (SS && act < A ? 4 : 2); pass++) {
         real n[3], sd;
         if (pass == 0) { sd = c[2] - d->ground_z - r; n[0] = 0; n[1] = 0; n[2] = 1; }
+        else if (pass == 2) {      /* seesaw platform: static axis-aligned box */
+          real I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, hb[3] = {d->seesaw_base_half[0], d->seesaw_base_half[1], d->seesaw_base_half[2]};
+          sd = sphere_box(c, r, ssB, I3, hb, n);
+        } else if (pass == 3) {    /* column under the platform: static vertical cylinder, lateral surface only */
+          real dx = c[0] - ssB[0], dy = c[1] - ssB[1];
+          real rho = (real)sqrt((double)(dx * dx + dy * dy));
+          if (c[2] < ssB[2] && c[2] > ssB[2] - d->seesaw_column_length && rho > (real)1e-6) { sd = rho - d->seesaw_column_radius - r; n[0] = dx / rho; n[1] = dy / rho; n[2] = 0; }
+          else { sd = (real)1e3; n[0] = 0; n[1] = 0; n[2] = 1; }
+        }
         else {
           real gx, gy;
           real sh = sdf_sample(s, c[0], c[1], &gx, &gy);
@@ -709,7 +768,8 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
             sd = dist - r; n[0] = gx * sh / dist; n[1] = gy * sh / dist; n[2] = dz / dist;
           }
         }
-        if (sd < d->contact_offset && w->nc < maxc) {
+        if (sd < d->contact_offset && w->nc < maxc && mine < cap) {
+          mine++;
           contact_t* ct = &w->con[w->nc++];
           memset(ct, 0, sizeof *ct);
           ct->kind = 0; ct->actA = act; ct->sphA = si; ct->actB = -1; ct->sd = sd;
@@ -718,6 +778,20 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
       }
     }
   }
+  if (SS)   /* robot spheres vs the plank (dynamic: couples the robots through the hinge) */
+    for (int act = 0; act < A; act++)
+      for (int si = 0; si < w->sph_n[act]; si++) {
+        const real* c = w->sph_c[act][si];
+        real r = w->sph_r[act][si], n[3];
+        real hp[3] = {d->seesaw_plank_half[0], d->seesaw_plank_half[1], d->seesaw_plank_half[2]};
+        real sd = sphere_box(c, r, ssC, ssR, hp, n);
+        if (sd < d->contact_offset && w->nc < maxc) {
+          contact_t* ct = &w->con[w->nc++];
+          memset(ct, 0, sizeof *ct);
+          ct->kind = 2; ct->actA = act; ct->sphA = si; ct->actB = A; ct->sphB = 0; ct->sd = sd;
+          for (int k = 0; k < 3; k++) { ct->n[k] = n[k]; ct->p[k] = c[k] - r * n[k]; }
+        }
+      }
   for (int a = 0; a < nact; a++)
     for (int b = a + 1; b < nact; b++) {
       const real* pa = a < A ? w->bk[a][0].p : npc_pos[a - A];
@@ -762,6 +836,7 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
         int o = A * RD + p * 6;
         for (int k = 0; k < 3; k++) { ct->B[q][o + k] = ct->J[q][o + k] / d->npc_mass; ct->B[q][o + 3 + k] = ct->J[q][o + 3 + k] / d->npc_inertia; }
       }
+      if (SS) ct->B[q][sdof] = ct->J[q][sdof] / d->seesaw_plank_inertia_yy;
     }
     for (int q = 0; q < 3; q++) for (int r2 = 0; r2 < 3; r2++) {
       real acc = 0;
@@ -815,6 +890,13 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
           for (int i = 0; i < RD; i++) v[i] += col[i] * lam;
         }
       }
+    if (SS) {   /* hinge: velocity limit (seesaw.urdf:65), then the geometric end stops */
+      real vv = w->v[sdof], vl = d->seesaw_vel_limit;
+      if (vv > vl) vv = vl; if (vv < -vl) vv = -vl;
+      real lo = (d->seesaw_theta_lo - ssTheta) / dt, hi = (d->seesaw_theta_hi - ssTheta) / dt;
+      if (vv < lo) vv = lo; if (vv > hi) vv = hi;
+      w->v[sdof] = vv;
+    }
   }
 
   /* ---- net contact forces per reported body (gym.refresh_net_contact_force_tensor analogue) */
@@ -827,12 +909,13 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
     int ra = ct->actA < A ? ct->actA * MQE_NREP + m->sphere_reported[ct->sphA] : A * MQE_NREP + (ct->actA - A);
     for (int k = 0; k < 3; k++) cf[ra * 3 + k] += (float)F[k];
     if (ct->actB >= 0) {
-      int rb = ct->actB < A ? ct->actB * MQE_NREP + m->sphere_reported[ct->sphB] : A * MQE_NREP + (ct->actB - A);
+      int rb = ct->actB < A ? ct->actB * MQE_NREP + m->sphere_reported[ct->sphB] : (SS ? A * MQE_NREP + 1 : A * MQE_NREP + (ct->actB - A));
       for (int k = 0; k < 3; k++) cf[rb * 3 + k] -= (float)F[k];
     }
   }
 
   /* ---- integrate (semi-implicit Euler; quaternion: first-order update + renormalise) */
+  if (SS) { float* ds = dofs + (12 * A) * 2; ds[0] = (float)(ds[0] + dt * w->v[sdof]); ds[1] = (float)w->v[sdof]; }
   for (int act = 0; act < nact; act++) {
     float* rs = root + act * 13;
     real* v = act < A ? w->v + act * RD : w->v + A * RD + (act - A) * 6;

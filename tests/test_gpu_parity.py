@@ -101,6 +101,44 @@ def test_fused_rollout_matches_oracle(task, N):
     assert mism <= max(2, N // 16), f"{mism} reset-flag mismatches"
 
 
+def test_seesaw_plank_matches_oracle():
+    """go1seesaw: robots dropped onto the plank / the platform / next to the column: contact lists identical, then
+    110 substeps of coupled robot-plank dynamics (hinge angle tracked to 2e-4 rad)."""
+    N = 24
+    eh, eo, d = _pair("go1seesaw", N)
+    eh.reset_all(); eo.reset_all()
+    torch.cuda.synchronize()
+    ro, do = eo.tensor(abi.T_ROOT_STATE), eo.tensor(abi.T_DOF_STATE)
+    g = torch.Generator().manual_seed(2)
+    base = ro[:, 2, :3].clone()                                    # seesaw platform centre
+    xs = torch.rand(N, 2, generator=g) * 4.5 - 4.2                  # along the plank ... up to the platform
+    ro[:, :2, 0] = base[:, None, 0] + xs
+    ro[:, :2, 1] = base[:, None, 1] + (torch.rand(N, 2, generator=g) - 0.5) * 0.9
+    ro[:, :2, 2] = 1.35
+    ro[:, :2, 7:] = 0
+    do[:, :24, 1] = 0
+    do[:, 24, 0] = (torch.rand(N, generator=g) - 0.5) * 0.3
+    theta0 = do[:, 24, 0].clone()
+    eh.tensor(abi.T_ROOT_STATE).copy_(ro.cuda()); eh.tensor(abi.T_DOF_STATE).copy_(do.cuda())
+    eh.tensor(abi.T_TORQUES).zero_(); eo.tensor(abi.T_TORQUES).zero_()
+    saw_plank = False
+    for k in range(110):
+        if k in (70, 100):
+            for env in range(N):
+                _, ch = eh.debug_dynamics(env, 0)
+                _, _, co = eo.debug_dynamics(env, 0)
+                assert ch.shape == co.shape and (ch[:, :4] == co[:, :4]).all()
+                saw_plank |= bool((co[:, 2] == 2).any())
+        eh.simulate(); eo.simulate()
+    torch.cuda.synchronize()
+    assert saw_plank, "test must exercise plank contacts"
+    th_h, th_o = eh.tensor(abi.T_DOF_STATE)[:, 24, 0].cpu(), eo.tensor(abi.T_DOF_STATE)[:, 24, 0]
+    assert (th_o - theta0).abs().max() > 0.01, "plank must have moved"
+    close(th_h, th_o, atol=2e-4, what="hinge angle after 110 substeps")
+    dz = (eh.tensor(abi.T_ROOT_STATE)[:, :2, 2].cpu() - eo.tensor(abi.T_ROOT_STATE)[:, :2, 2]).abs()
+    assert dz.median() < 1e-4 and dz.max() < 5e-2
+
+
 def test_full_size_invariants():
     """BASELINE config 1 (go1gate, 4096 envs x 2 agents): properties that do not need the oracle."""
     d, k, ctx = make_desc("go1gate", 4096)

@@ -108,3 +108,35 @@ def test_robots_collide_with_walls_and_each_other():
     dxy = (root[0, 0, :2] - root[0, 1, :2]).norm()
     assert dxy > 0.12, "trunk spheres (r=0.057) may not interpenetrate"
     assert torch.isfinite(root).all()
+
+
+def test_seesaw_plank_carries_robots_and_obeys_hinge_limits():
+    """go1seesaw: two robots standing on the right arm: the plank takes their weight and turns at the URDF velocity
+    limit (0.2 rad/s, seesaw.urdf:65); an unloaded spinning plank stops where its end meets the ground slab."""
+    e, d, root, dof = fresh("go1seesaw", 2)
+    base = root[:, 2, :3].clone()
+    for r, (dx, dy) in enumerate(((-1.2, -0.2), (-0.8, 0.25))):
+        root[:, r, 0] = base[:, 0] + dx
+        root[:, r, 1] = base[:, 1] + dy
+        root[:, r, 2] = 1.25
+    a = torch.zeros(2, 2, 3)
+    thetas, fz = [], []
+    for t in range(70):
+        e.step(a)
+        thetas.append(dof[0, 24, 0].item())
+        fz.append(e.tensor(abi.T_CONTACT_FORCE)[0, 2 * 17 + 1, 2].item())
+        assert abs(dof[:, 24, 1]).max() <= d.seesaw_vel_limit + 1e-6
+    assert (e.tensor(abi.T_RESET_COUNT) == 1).all()
+    mt = sum(d.robot.mass[b] for b in range(13))
+    rate = (thetas[60] - thetas[30]) / (30 * 0.02)
+    assert rate == pytest.approx(d.seesaw_vel_limit, rel=0.02)                 # loaded arm goes down at the limit
+    assert np.mean(fz[30:60]) == pytest.approx(-2 * mt * G, rel=0.1)           # plank carries both robots
+    # end stops: plank alone, spinning either way
+    for sign, stop in ((1.0, d.seesaw_theta_hi), (-1.0, d.seesaw_theta_lo)):
+        e2, d2, root2, dof2 = fresh("go1seesaw", 1)
+        root2[:, :2, 0] -= 5.0        # robots far away from the plank
+        dof2[0, 24, 0] = 0.0
+        for k in range(400):
+            dof2[0, 24, 1] = sign * 0.2
+            e2.simulate()
+        assert dof2[0, 24, 0].item() == pytest.approx(stop, abs=1e-5)

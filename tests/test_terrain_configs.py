@@ -49,6 +49,10 @@ def test_instances_do_not_leak_state():
 def test_config_tree_matches_reference(task):
     gold = json.load(open(os.path.join(GOLD, "configs.json")))[task]
     mine = json.loads(json.dumps(class_to_dict(task_cfg(task)), default=lambda o: class_to_dict(o) if hasattr(o, "__dict__") else str(o)))
+    # fields the factory itself mutates on the config CLASS at construction (mqe/envs/utils.py:127, legged_robot.py:1022)
+    for vol in ("num_envs", "max_episode_length"):
+        mine["env"].pop(vol, None)
+        gold["env"].pop(vol, None)
     assert mine == gold
 
 
