@@ -59,7 +59,8 @@ def cpu_baseline(task, sample_envs, sample_steps):
     for t in range(sample_steps):
         e.step(acts[2 + t])
     dt = time.perf_counter() - t0
-    return d.num_agents * sample_envs * sample_steps / dt, dt
+    e.lib.mqo_num_threads.restype = int
+    return d.num_agents * sample_envs * sample_steps / dt, dt, int(e.lib.mqo_num_threads())
 
 
 def main():
@@ -162,6 +163,7 @@ def main():
             "config": {"workload": f"{args.task}, {A} agents, num_envs={N} per GPU ({N * world} total), 4 substeps x 5 ms per step",
                        "parallelism": f"env-sharded x{world}, all-gather of the returned batch" if world > 1 else "single GPU"},
             "target_env_steps_per_s": 1.0e6,
+            "physical_robot_steps_per_s": round(value * env.env.num_agents / A, 1),
             "roofline": roof,
             "hbm_step_algorithmic_GBps": round(step_bytes * args.steps / elapsed / 1e9, 3),
             "kernel_time_share": {PROF_NAMES[i]: round(kms[i] / tot, 4) for i in range(6)},
@@ -169,8 +171,8 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             torch.set_num_threads(os.cpu_count() or 1)
-            v, secs = cpu_baseline(args.task, args.cpu_sample_envs, args.cpu_sample_steps)
-            out["cpu_baseline"] = {"value": round(v, 1), "unit": "env-steps/s", "cores": int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)),
+            v, secs, nthr = cpu_baseline(args.task, args.cpu_sample_envs, args.cpu_sample_steps)
+            out["cpu_baseline"] = {"value": round(v, 1), "unit": "env-steps/s", "cores": nthr,
                                    "kind": "port", "sample": f"{args.task} {args.cpu_sample_envs} envs x {args.cpu_sample_steps} steps, build's CPU restatement (oracle/), {secs:.1f} s"}
         print(json.dumps(out))
     env.close()
