@@ -154,6 +154,15 @@ def main():
             ach = byts / (avg_ms * 1e-3) / 1e9
             roof = {"kernel": PROF_NAMES[dom], "bound": "hbm", "achieved": round(ach, 3), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(ach / PEAK_HBM_GBS, 6), "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": int(cnt[dom])}
+        # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (separate runs; profiles/*pmc_summary.json)
+        try:
+            import glob
+            pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.json")))[-1]))
+            if N == 4096 and args.task == "go1gate":
+                roof["traffic"] = pmc["k_gemm_f32"]["layer0_hbm_bytes_est"] if dom in (0, 1) else pmc.get({3: "k_simulate", 2: "k_compute_torques_mfma", 4: "k_post_physics", 5: "k_pre_policy"}[dom], {}).get("hbm_bytes_raw")
+                roof["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch, see profiles/"
+        except Exception:
+            pass
         step_bytes = 10128.0 * R
         out = {
             "metric": "env-steps/sec (agents x envs x steps/s), go1gate 4096 envs x 2 agents per GPU",

@@ -169,6 +169,23 @@ static inline float dot_chain(const float* w, const float* x, int K) {
   for (int k = 0; k < K; k++) acc = fmaf(w[k], x[k], acc);
   return acc;
 }
+/* y[o] = chain(W[o,:], x) for O outputs: identical per-output k-ordered chains, eight outputs interleaved so that the
+ * CPU pipelines them (the dependency chain of one output is the bottleneck otherwise) */
+static void matvec_chain(const float* W, const float* x, int K, int O, int ldw, float* y) {
+  int o = 0;
+  for (; o + 8 <= O; o += 8) {
+    float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;
+    const float *w0 = W + (size_t)o * ldw, *w1 = w0 + ldw, *w2 = w1 + ldw, *w3 = w2 + ldw, *w4 = w3 + ldw, *w5 = w4 + ldw, *w6 = w5 + ldw, *w7 = w6 + ldw;
+    for (int k = 0; k < K; k++) {
+      float xv = x[k];
+      a0 = fmaf(w0[k], xv, a0); a1 = fmaf(w1[k], xv, a1); a2 = fmaf(w2[k], xv, a2); a3 = fmaf(w3[k], xv, a3);
+      a4 = fmaf(w4[k], xv, a4); a5 = fmaf(w5[k], xv, a5); a6 = fmaf(w6[k], xv, a6); a7 = fmaf(w7[k], xv, a7);
+    }
+    y[o] = a0; y[o + 1] = a1; y[o + 2] = a2; y[o + 3] = a3; y[o + 4] = a4; y[o + 5] = a5; y[o + 6] = a6; y[o + 7] = a7;
+  }
+  for (; o < O; o++) y[o] = dot_chain(W + (size_t)o * ldw, x, K);
+}
+
 /* actuator net, reference go1.py:367-382 (unitree_go1.pt: Linear(6,32) softsign Linear(32,32) softsign Linear(32,1)) */
 static float actuator_net(const mlp_t* m, const float* x6) {
   float h1[32], h2[32];
@@ -197,8 +214,9 @@ static void policy_forward(const mqo_sim* s, const float* h2100, float* latent2,
   for (int l = 0; l < a->n_layers; l++) {
     float* y = (l & 1) ? buf1 : buf0;
     int O = a->dims[l + 1];
+    matvec_chain(a->W[l], x, K, O, K, y);
     for (int o = 0; o < O; o++) {
-      float v = dot_chain(a->W[l] + (size_t)o * K, x, K) + a->b[l][o];
+      float v = y[o] + a->b[l][o];
       y[o] = (l < a->n_layers - 1) ? elu(v) : v;
     }
     x = y; K = O;
@@ -208,9 +226,10 @@ static void policy_forward(const mqo_sim* s, const float* h2100, float* latent2,
   /* layer 0: 2100 history columns as a chain, + bias, then the two latent columns */
   int O = b->dims[1], K0 = b->dims[0];
   float* y = buf0;
+  matvec_chain(b->W[0], h2100, 2100, O, K0, y);
   for (int o = 0; o < O; o++) {
     const float* w = b->W[0] + (size_t)o * K0;
-    float v = dot_chain(w, h2100, 2100) + b->b[0][o];
+    float v = y[o] + b->b[0][o];
     v = fmaf(latent2[0], w[2100], v);
     v = fmaf(latent2[1], w[2101], v);
     y[o] = elu(v);
@@ -219,8 +238,9 @@ static void policy_forward(const mqo_sim* s, const float* h2100, float* latent2,
   for (int l = 1; l < b->n_layers; l++) {
     float* yy = (l & 1) ? buf1 : buf0;
     int OO = b->dims[l + 1];
+    matvec_chain(b->W[l], x, K, OO, K, yy);
     for (int o = 0; o < OO; o++) {
-      float v = dot_chain(b->W[l] + (size_t)o * K, x, K) + b->b[l][o];
+      float v = yy[o] + b->b[l][o];
       yy[o] = (l < b->n_layers - 1) ? elu(v) : v;
     }
     x = yy; K = OO;
