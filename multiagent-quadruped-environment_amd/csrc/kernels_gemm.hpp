@@ -55,18 +55,24 @@ __global__ void __launch_bounds__(256) k_gemm_f32(GemmArgs g) {
   const int bk = tid >> 4, bnq = (tid & 15) * 4;         // B: row bk, 4 consecutive n
   const bool a_ok = (m0 + am) < g.M;
   const float* Arow = g.A + (size_t)(m0 + am) * g.lda;
-  for (int k0 = 0; k0 < g.K; k0 += GB_K) {
-    float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
+  // register prefetch: the global loads of tile t+1 are issued before the MFMAs of tile t, so their latency hides
+  // behind 8 x 64 cycles of matrix work instead of being exposed at the LDS store
+  float4 av = make_float4(0.f, 0.f, 0.f, 0.f), bv;
+  auto load_tile = [&](int k0) {
     if (a_ok) {
       int k4 = (k0 + akq) >> 2;
       if (g.a_ring4) { k4 += g.a_rot4; if (k4 >= g.a_ring4) k4 -= g.a_ring4; }
       av = *reinterpret_cast<const float4*>(Arow + (size_t)k4 * 4);
     }
-    float4 bv = *reinterpret_cast<const float4*>(g.Wt + (size_t)(k0 + bk) * g.ldw + n0 + bnq);
+    bv = *reinterpret_cast<const float4*>(g.Wt + (size_t)(k0 + bk) * g.ldw + n0 + bnq);
+  };
+  load_tile(0);
+  for (int k0 = 0; k0 < g.K; k0 += GB_K) {
     __syncthreads();                     // previous tile fully consumed
     As[akq + 0][am] = av.x; As[akq + 1][am] = av.y; As[akq + 2][am] = av.z; As[akq + 3][am] = av.w;
     *reinterpret_cast<float4*>(&Bs[bk][bnq]) = bv;
     __syncthreads();
+    if (k0 + GB_K < g.K) load_tile(k0 + GB_K);
 #pragma unroll
     for (int kk = 0; kk < GB_K; kk += 2) {
       float a = As[kk + (lane >> 5)][wm * 32 + (lane & 31)];
