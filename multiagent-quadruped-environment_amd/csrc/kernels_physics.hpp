@@ -116,10 +116,11 @@ __host__ __device__ inline PhysLds phys_lds_layout(int A, int P, int ND, int nbo
 struct PhysDebug { float* minv; int* nc; float* contacts; int robot; long long* times; };
 #define TSTAMP(i) do { if (dbg.times != nullptr && lane == 0) dbg.times[i] = clock64(); } while (0)
 
-__global__ void __launch_bounds__(64) k_simulate(const DevModel* __restrict__ m, DevState st, int env_base, int no_write, PhysDebug dbg) {
-  extern __shared__ float lds[];
-  const int lane = threadIdx.x;
-  const int e = env_base + blockIdx.x;
+// flags of one physics substep executed by a wavefront
+enum { PS_LOAD_STATE = 1, PS_LOAD_TAU = 2, PS_STORE_STATE = 4, PS_WRITE_CF = 8 };
+
+__device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, const DevState& st, float* lds, const int e, const int lane,
+                                             const int flags, const int no_write, const PhysDebug& dbg) {
   const int A = m->A, P = m->P, PD = m->n_npc_dyn, npcdof = m->npc_dofs_each;
   const int nbody = m->nbody_env, ndof = m->ndof_env, nsph = m->nsph_env, maxc = m->maxc, bs = m->ldsB_stride;
   const PhysLds L = phys_lds_layout(A, P, m->ND, nbody, ndof, nsph, maxc, bs);
@@ -129,10 +130,13 @@ __global__ void __launch_bounds__(64) k_simulate(const DevModel* __restrict__ m,
   float* g_dof = st.dof + (size_t)e * m->ND * 2;
 
   TSTAMP(0);
-  // ---- coalesced state load -------------------------------------------------------------------------------
-  for (int i = lane; i < (A + P) * 13; i += 64) lds[L.root + i] = g_root[i];
-  for (int i = lane; i < m->ND * 2; i += 64) lds[L.dof + i] = g_dof[i];
-  for (int i = lane; i < 12 * A; i += 64) lds[L.tau + i] = st.torques[(size_t)e * 12 * A + i];
+  // ---- coalesced state load (first substep of a launch only; afterwards the state stays in LDS) -----------------
+  if (flags & PS_LOAD_STATE) {
+    for (int i = lane; i < (A + P) * 13; i += 64) lds[L.root + i] = g_root[i];
+    for (int i = lane; i < m->ND * 2; i += 64) lds[L.dof + i] = g_dof[i];
+  }
+  if (flags & PS_LOAD_TAU)
+    for (int i = lane; i < 12 * A; i += 64) lds[L.tau + i] = st.torques[(size_t)e * 12 * A + i];
   __syncthreads();
 
   TSTAMP(1);
@@ -931,7 +935,7 @@ __global__ void __launch_bounds__(64) k_simulate(const DevModel* __restrict__ m,
   if (no_write) return;
 
   // ---- net contact force per reported body (deterministic: contact order) ---------------------------------------------------
-  {
+  if (flags & PS_WRITE_CF) {
     const float idt = 1.0f / dt;
     float* g_cf = st.cf + (size_t)e * m->NBR * 3;
     for (int rb = lane; rb < m->NBR; rb += 64) {
@@ -953,24 +957,23 @@ __global__ void __launch_bounds__(64) k_simulate(const DevModel* __restrict__ m,
   __syncthreads();
   if (is_rdof && dk >= 6) {
     const int j = dk - 6;
-    const float q = lds[L.dof + (dact * 12 + j) * 2];
-    g_dof[(dact * 12 + j) * 2] = q + dt * vd;
-    g_dof[(dact * 12 + j) * 2 + 1] = vd;
+    float* ds = lds + L.dof + (dact * 12 + j) * 2;
+    ds[0] = ds[0] + dt * vd;
+    ds[1] = vd;
   }
   if (SS && lane == A * MQE_RD) {
-    g_dof[(12 * A) * 2] = ssTheta + dt * vd;
-    g_dof[(12 * A) * 2 + 1] = vd;
+    lds[L.dof + (12 * A) * 2] = ssTheta + dt * vd;
+    lds[L.dof + (12 * A) * 2 + 1] = vd;
   }
   if (lane < A + PD) {
     const int act = lane;
-    const float* rs = lds + L.root + act * 13;
+    float* rs = lds + L.root + act * 13;
     const float* v = lds + L.rhs + (act < A ? act * MQE_RD : A * MQE_RD + (act - A) * npcdof);
-    float* gr = g_root + act * 13;
-    for (int k = 0; k < 3; k++) { gr[k] = rs[k] + dt * v[k]; gr[7 + k] = v[k]; }
     const bool has_ang = act < A || npcdof == 6;
     const float wx = has_ang ? v[3] : rs[10], wy = has_ang ? v[4] : rs[11], wz = has_ang ? v[5] : rs[12];
-    if (has_ang) { gr[10] = wx; gr[11] = wy; gr[12] = wz; }
+    for (int k = 0; k < 3; k++) { rs[k] = rs[k] + dt * v[k]; rs[7 + k] = v[k]; }
     if (has_ang) {
+      rs[10] = wx; rs[11] = wy; rs[12] = wz;
       float q0 = rs[3], q1 = rs[4], q2 = rs[5], q3 = rs[6];
       const float d0 = 0.5f * (wx * q3 + wy * q2 - wz * q1);
       const float d1 = 0.5f * (-wx * q2 + wy * q3 + wz * q0);
@@ -978,7 +981,17 @@ __global__ void __launch_bounds__(64) k_simulate(const DevModel* __restrict__ m,
       const float d3 = 0.5f * (-wx * q0 - wy * q1 - wz * q2);
       q0 += dt * d0; q1 += dt * d1; q2 += dt * d2; q3 += dt * d3;
       const float nq = sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
-      gr[3] = q0 / nq; gr[4] = q1 / nq; gr[5] = q2 / nq; gr[6] = q3 / nq;
+      rs[3] = q0 / nq; rs[4] = q1 / nq; rs[5] = q2 / nq; rs[6] = q3 / nq;
     }
   }
+  __syncthreads();
+  if (flags & PS_STORE_STATE) {       // coalesced write-back
+    for (int i = lane; i < (A + P) * 13; i += 64) g_root[i] = lds[L.root + i];
+    for (int i = lane; i < m->ND * 2; i += 64) g_dof[i] = lds[L.dof + i];
+  }
+}
+
+__global__ void __launch_bounds__(64) k_simulate(const DevModel* __restrict__ m, DevState st, int env_base, int no_write, PhysDebug dbg) {
+  extern __shared__ float lds[];
+  phys_substep(m, st, lds, env_base + blockIdx.x, threadIdx.x, PS_LOAD_STATE | PS_LOAD_TAU | PS_STORE_STATE | PS_WRITE_CF, no_write, dbg);
 }

@@ -124,6 +124,11 @@ def test_seesaw_plank_matches_oracle():
     saw_plank = False
     for k in range(110):
         if k in (70, 100):
+            # contact lists are compared from IDENTICAL states (a sphere sitting exactly at the contact margin would
+            # otherwise flip on a 1e-7 state difference): hinge angle first, then re-synchronise
+            torch.cuda.synchronize()
+            close(eh.tensor(abi.T_DOF_STATE)[:, 24, 0], eo.tensor(abi.T_DOF_STATE)[:, 24, 0], atol=2e-4, what=f"hinge angle at substep {k}")
+            eh.tensor(abi.T_ROOT_STATE).copy_(eo.tensor(abi.T_ROOT_STATE).cuda()); eh.tensor(abi.T_DOF_STATE).copy_(eo.tensor(abi.T_DOF_STATE).cuda())
             for env in range(N):
                 _, ch = eh.debug_dynamics(env, 0)
                 _, _, co = eo.debug_dynamics(env, 0)
