@@ -149,8 +149,8 @@ def main():
                     "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": int(cnt[0])}
         else:
             avg_ms = kms[dom] / max(cnt[dom], 1)
-            per_launch = {3: 4, 2: 4}.get(dom, 1)
-            byts = 10128.0 * R / per_launch                           # 10128 B per agent-step, 4 launches/step
+            per_launch = max(1.0, cnt[dom] / args.steps)              # launches of this kernel class per env step
+            byts = 10128.0 * R / per_launch                           # 10128 B per agent-step
             ach = byts / (avg_ms * 1e-3) / 1e9
             roof = {"kernel": PROF_NAMES[dom], "bound": "hbm", "achieved": round(ach, 3), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(ach / PEAK_HBM_GBS, 6), "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": int(cnt[dom])}

@@ -995,3 +995,103 @@ __global__ void __launch_bounds__(64) k_simulate(const DevModel* __restrict__ m,
   extern __shared__ float lds[];
   phys_substep(m, st, lds, env_base + blockIdx.x, threadIdx.x, PS_LOAD_STATE | PS_LOAD_TAU | PS_STORE_STATE | PS_WRITE_CF, no_write, dbg);
 }
+
+// ----------------------------------------------------------------------------------------------------------------------
+// k_substeps: the whole decimation loop of Go1.step (go1.py:48-58) for one env in one wavefront:
+//   nsub x { actuator-net torques on MFMA (32 joints per tile, see k_compute_torques_mfma) -> physics substep }
+// Root/dof state is loaded once, stays in LDS across the substeps and is written back once; the actuator history
+// (two past position errors and velocities per joint) lives in registers for the whole launch; torques go straight
+// into the LDS slot the physics reads.  Control type "C" only (the reference's hierarchical controller).
+typedef float f32x16_p __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ float softsign_p(float x) { return x / (1.0f + fabsf(x)); }
+
+#define ACT_TILES 2       // 2 x 32 joints >= 12 * MQE_MAX_AGENTS(=4)... agents <= 4 need 48 joints
+
+__global__ void __launch_bounds__(64, 2) k_substeps(const DevModel* __restrict__ m, DevState st, int nsub) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x, e = blockIdx.x;
+  const int A = m->A, P = m->P;
+  const PhysLds L = phys_lds_layout(A, P, m->ND, m->nbody_env, m->ndof_env, m->nsph_env, m->maxc, m->ldsB_stride);
+  const int j32 = lane & 31, h = lane >> 5;
+  const int nj = 12 * A;
+  const float* W0 = m->actuator.W[0]; const float* b0 = m->actuator.b[0];
+  const float* W1 = m->actuator.W[1]; const float* b1 = m->actuator.b[1];
+  const float* W2 = m->actuator.W[2]; const float* b2 = m->actuator.b[2];
+  // per-tile joint state in registers
+  float tgt[ACT_TILES], h_e1[ACT_TILES], h_e2[ACT_TILES], h_v1[ACT_TILES], h_v2[ACT_TILES], lim[ACT_TILES];
+  const size_t R12 = (size_t)m->R * 12;
+#pragma unroll
+  for (int t = 0; t < ACT_TILES; t++) {
+    const int jt = t * 32 + j32;
+    const bool ok = jt < nj;
+    const size_t gi = (size_t)e * nj + (ok ? jt : 0);
+    const int j = (ok ? jt : 0) % 12;
+    float as = st.actions[gi] * m->action_scale;
+    if (j % 3 == 0) as *= m->hip_scale_reduction;
+    tgt[t] = as + m->default_dof_pos[j];
+    h_e1[t] = st.act_hist[gi]; h_e2[t] = st.act_hist[R12 + gi]; h_v1[t] = st.act_hist[2 * R12 + gi]; h_v2[t] = st.act_hist[3 * R12 + gi];
+    lim[t] = m->torque_limits[j];
+  }
+  float* g_root = st.root + (size_t)e * (A + P) * 13;
+  float* g_dof = st.dof + (size_t)e * m->ND * 2;
+  for (int i = lane; i < (A + P) * 13; i += 64) lds[L.root + i] = g_root[i];
+  for (int i = lane; i < m->ND * 2; i += 64) lds[L.dof + i] = g_dof[i];
+  __syncthreads();
+  const PhysDebug nodbg = {nullptr, nullptr, nullptr, 0, nullptr};
+  for (int k = 0; k < nsub; k++) {
+    const bool last = k + 1 == nsub;
+    // weight fragments (A operands): row = hidden unit j32, k = this half-wave's element of each k pair.  They are
+    // re-read (L1/L2 resident, 5 kB shared by every wave) each substep behind an optimisation barrier: keeping 70 VGPRs
+    // live across the 50 k-cycle physics body would spill and halve the occupancy.
+    const float *w0p = W0, *w1p = W1, *w2p = W2, *b0p = b0, *b1p = b1;
+    asm volatile("" : "+s"(w0p), "+s"(w1p), "+s"(w2p), "+s"(b0p), "+s"(b1p));
+    float a1[3], a2[16], w3[16], bb0[16], bb1[16];
+#pragma unroll
+    for (int s2 = 0; s2 < 3; s2++) a1[s2] = w0p[j32 * 6 + 2 * s2 + h];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int u = (r & 3) + 8 * (r >> 2) + 4 * h;
+      a2[r] = w1p[j32 * 32 + u]; w3[r] = w2p[u]; bb0[r] = b0p[u]; bb1[r] = b1p[u];
+    }
+    const float bout = b2[0];
+#pragma unroll
+    for (int t = 0; t < ACT_TILES; t++) {
+      if (t * 32 >= nj) break;                           // wave-uniform
+      const int jt = t * 32 + j32;
+      const bool ok = jt < nj;
+      const float q = lds[L.dof + (ok ? jt : 0) * 2], qd = lds[L.dof + (ok ? jt : 0) * 2 + 1];
+      const float err = q - tgt[t];
+      f32x16_p acc1, acc2;
+#pragma unroll
+      for (int r = 0; r < 16; r++) { acc1[r] = bb0[r]; acc2[r] = bb1[r]; }
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[0], h ? h_e1[t] : err, acc1, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[1], h ? qd : h_e2[t], acc1, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[2], h ? h_v2[t] : h_v1[t], acc1, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc1[r] = softsign_p(acc1[r]);
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[r], acc1[r], acc2, 0, 0, 0);
+      float part = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; r++) part = fmaf(w3[r], softsign_p(acc2[r]), part);
+      float tau = part + __shfl_xor(part, 32, 64) + bout;
+      tau = clampf(tau, -lim[t], lim[t]);
+      h_e2[t] = h_e1[t]; h_e1[t] = err; h_v2[t] = h_v1[t]; h_v1[t] = qd;      // go1.py:347-350
+      if (ok && h == 0) {
+        lds[L.tau + jt] = tau;
+        st.sub_tau[((size_t)e * 4 + (k < 4 ? k : 3)) * nj + jt] = tau;          // post_decimation_step (legged_robot.py:113)
+        if (last) st.torques[(size_t)e * nj + jt] = tau;
+      }
+    }
+    __syncthreads();
+    phys_substep(m, st, lds, e, lane, last ? (PS_STORE_STATE | PS_WRITE_CF) : 0, 0, nodbg);
+  }
+#pragma unroll
+  for (int t = 0; t < ACT_TILES; t++) {
+    const int jt = t * 32 + j32;
+    if (jt < nj && h == 0) {
+      const size_t gi = (size_t)e * nj + jt;
+      st.act_hist[gi] = h_e1[t]; st.act_hist[R12 + gi] = h_e2[t]; st.act_hist[2 * R12 + gi] = h_v1[t]; st.act_hist[3 * R12 + gi] = h_v2[t];
+    }
+  }
+}

@@ -509,8 +509,14 @@ __device__ void wrapper_env_dev(const DevModel* m, const DevState& st, int e, in
   for (int a = 0; a < Aw; a++) rew[a] = 0;
 }
 
+// Launch geometry: the body is scalar per env with row-strided (uncoalesced) accesses, so it is latency-bound; POST_EPW
+// envs per 64-lane wavefront (the other lanes idle) trades issue slots for 64/POST_EPW times more waves in flight.
+#ifndef POST_EPW
+#define POST_EPW 8
+#endif
 __global__ void __launch_bounds__(64) k_post_physics(const DevModel* m, DevState st, int first_steps_done) {
-  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (threadIdx.x >= POST_EPW) return;
+  int e = blockIdx.x * POST_EPW + threadIdx.x;
   if (e >= m->N) return;
   int A = m->A, P = m->P;
   float dtp = m->dt * (float)m->decimation;

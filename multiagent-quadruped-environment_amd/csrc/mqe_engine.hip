@@ -51,6 +51,7 @@ struct mqe_sim {
   float *P1 = nullptr, *bufA = nullptr, *bufB = nullptr, *lat = nullptr, *act_out = nullptr;
   int ldP1, ldbuf, ldlat, ldact;
   size_t phys_lds_bytes = 0;
+  bool fuse_substeps = true;
   // profiling
   bool prof = false;
   std::vector<hipEvent_t> ev0[PROF_N], ev1[PROF_N];
@@ -177,9 +178,11 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   s->phys_lds_bytes = (size_t)L.total * 4;
   if (s->phys_lds_bytes > 160 * 1024) { delete s; return fail(-4, "physics LDS footprint exceeds 160 KiB"); }
   if (s->phys_lds_bytes > 48 * 1024)
-    if (hipFuncSetAttribute((const void*)k_simulate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->phys_lds_bytes) != hipSuccess) {
+    if (hipFuncSetAttribute((const void*)k_simulate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->phys_lds_bytes) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_substeps, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->phys_lds_bytes) != hipSuccess) {
       delete s; return fail(-4, "cannot raise dynamic LDS limit");
     }
+  s->fuse_substeps = getenv("MQE_NO_FUSE_SUBSTEPS") == nullptr && d->decimation <= 4;
 #define UP(dst, src, n) if (upload(s, &(dst), (src), (n))) { return fail(-5, "device upload failed"); }
   UP(m.wall_sdf, d->wall_sdf, (size_t)d->sdf_nx * d->sdf_ny);
   UP(m.env_origins, d->env_origins, (size_t)N * 3);
@@ -422,7 +425,7 @@ static void launch_simulate(mqe_sim* s, hipStream_t q) {
 }
 static void launch_post(mqe_sim* s, hipStream_t q) {
   ProfScope ps(s, PROF_POST, q);
-  hipLaunchKernelGGL(k_post_physics, dim3((s->N + 63) / 64), dim3(64), 0, q, s->dm, s->st, s->n_post_steps);
+  hipLaunchKernelGGL(k_post_physics, dim3((s->N + POST_EPW - 1) / POST_EPW), dim3(64), 0, q, s->dm, s->st, s->n_post_steps);
   int n = s->R * (MQE_HIST * MQE_FRAME / 4);
   hipLaunchKernelGGL(k_reset_history, dim3((n + 255) / 256), dim3(256), 0, q, s->dm, s->st);
   s->n_post_steps++;
@@ -484,9 +487,15 @@ extern "C" int mqe_step(mqe_sim* s, const float* actions, void* stream) {
     hipLaunchKernelGGL(k_wrapper_command, dim3((s->N + 63) / 64), dim3(64), 0, q, s->dm, s->st, actions);
   }
   policy_step(s, s->st.cmd, q);
-  for (int k = 0; k < s->d.decimation; k++) {
-    launch_torques(s, k < 4 ? k : 3, q);
-    launch_simulate(s, q);
+  if (s->d.control_type == MQE_CTRL_C && s->fuse_substeps) {
+    // decimation loop in one launch: state stays in LDS, actuator net on MFMA inside the physics wavefront
+    ProfScope ps(s, PROF_SIMULATE, q);
+    hipLaunchKernelGGL(k_substeps, dim3(s->N), dim3(64), s->phys_lds_bytes, q, s->dm, s->st, s->d.decimation);
+  } else {
+    for (int k = 0; k < s->d.decimation; k++) {
+      launch_torques(s, k < 4 ? k : 3, q);
+      launch_simulate(s, q);
+    }
   }
   launch_post(s, q);
   HIPCHK(hipGetLastError());
