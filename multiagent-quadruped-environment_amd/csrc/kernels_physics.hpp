@@ -71,7 +71,7 @@ __device__ __forceinline__ float wave_sum(float x) {
 
 #define BODY_STRIDE 32
 #define CON_STRIDE 32
-#define JS_STRIDE 72                // 2 sides x 9 columns x (j_n, j_t1, j_t2, local dof index)
+#define JS_STRIDE 36                // per contact side: 9 columns x (j_n, j_t1, j_t2, local dof index)
 enum { B_R = 0, B_P = 9, B_W = 12, B_VP = 15, B_A = 18, B_AL = 21, B_AP = 24, B_C = 27, B_M = 30 };
 enum { C_IDS = 0, C_P = 4, C_N = 7, C_T1 = 10, C_T2 = 13, C_SD = 16, C_BIAS = 17, C_K = 18, C_LAM = 24, C_REP = 27 };
 
@@ -80,34 +80,39 @@ __host__ __device__ inline int mqe_maxc(int A, int P) { int v = 8 * A + 2 * P; r
 #define CAP_NPC 2       // per ball / sheep; per-actor caps so that no actor starves the ones after it in the list
 
 struct PhysLds {   // float offsets into dynamic LDS
-  int root, dof, tau, body, minv, rhs, fcol, leg, basei, sinv, tt, sph, con, B, W, js, kk, total;
+  int root, dof, tau, body, minv, rhs, fcol, leg, basei, sinv, tt, sph, con, B, js, kk, total;
 };
+__host__ __device__ inline int mqe_maxpair(int maxc) { return maxc / 2; }    // two-actor contacts kept per env
 __host__ __device__ inline PhysLds phys_lds_layout(int A, int P, int ND, int nbody, int ndof, int nsph, int maxc, int bstride) {
-  // Regions that live to the end of the kernel first; then an ARENA shared by (a) everything that is dead once the
+  // Regions that live to the end of the substep first; then an ARENA shared by (a) everything that is dead once the
   // contact rows exist (link records, CRBA/Schur scratch, collision spheres) and (b) the coupling blocks, which are
-  // only written after (a) has been consumed.  This is what keeps the footprint under 160 KiB / 6 per wave.
+  // only written after (a) has been consumed.  Inside (a) the spheres overlay the CRBA/Schur scratch (dead once M^-1
+  // exists) and T overlays the joint force columns (dead after the leg blocks).  Contact sides are slot-allocated:
+  // side A of contact c -> slot c, side B of the k-th two-actor contact -> slot maxc + k (terrain contacts have no B).
+  // Together this keeps go1gate at 19 KiB per wave = 8 waves per CU (160 KiB LDS), 2 per SIMD.
   PhysLds L; int o = 0;
   L.root = o; o += (A + P) * 13;
   L.dof = o; o += ND * 2;
   L.tau = o; o += 12 * A;
   o = (o + 3) & ~3;
   L.minv = o; o += A * MQE_RD * MQE_RD;
-  L.rhs = o; o += 128;
+  L.rhs = o; o += (A * MQE_RD > 64 ? A * MQE_RD : 64);      // generalized bias, later v* / the solved velocity (64 lanes)
+  o = (o + 3) & ~3;
   L.con = o; o += maxc * CON_STRIDE;
-  L.B = o; o += maxc * 2 * 54;          // per contact and side: 3 rows x 18 local dofs of M^-1 J^T
-  L.W = o;
-  L.js = o; o += maxc * JS_STRIDE;
+  const int nslot = maxc + mqe_maxpair(maxc);
+  L.B = o; o += nslot * 54;             // per contact side: 3 rows x 18 local dofs of M^-1 J^T
+  L.js = o; o += nslot * JS_STRIDE;
   const int arena = o;
   L.body = o; o += nbody * BODY_STRIDE;
-  L.fcol = o; o += A * 12 * 6;
+  const int scratch = o;
+  L.tt = o; L.fcol = o; o += A * MQE_RD * 6;               // fcol (A*72) is consumed before tt is written
   L.leg = o; o += A * 4 * 54;
   L.basei = o; o += A * 10;
   L.sinv = o; o += A * 36;
-  L.tt = o; o += A * MQE_RD * 6;
-  o = (o + 3) & ~3;
-  L.sph = o; o += nsph * 4;
-  L.kk = arena;                                    // row = receiving contact, odd stride (bank conflicts)
-  const int kk_end = arena + maxc * (maxc * 9 + 1);
+  L.sph = scratch;
+  if (scratch + nsph * 4 > o) o = scratch + nsph * 4;
+  L.kk = arena;                                    // lower-triangular 3x3 blocks, block (c, c2 <= c) at (c(c+1)/2 + c2) * 9
+  const int kk_end = arena + (maxc * (maxc + 1) / 2) * 9;
   if (kk_end > o) o = kk_end;
   L.total = o;
   return L;
@@ -573,29 +578,34 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     }
   }
   // robot spheres vs the seesaw plank (dynamic: couples the robots through the hinge); after all terrain contacts
+  const int nc_terr = nc;                                   // one-sided contacts end here; two-actor contacts follow
+  const int pair_lim = nc_terr + mqe_maxpair(maxc) < maxc ? nc_terr + mqe_maxpair(maxc) : maxc;
   if (SS) {
-    for (int s0 = 0; s0 < A * nsr; s0 += 64) {
-      const int s = s0 + lane;
-      bool hit = false; float sd = 0; V3 n = v3(0, 0, 1), c = v3(0, 0, 0); float rad = 0; int act = 0, body = 0, rep = 0;
-      if (s < A * nsr) {
+    const int capP = mqe_maxpair(maxc) / A;              // per robot, so that the first robot cannot starve the others
+    for (int a = 0; a < A; a++) {                        // one robot per iteration: lanes = its spheres
+      const int s = a * nsr + lane;
+      bool hit = false; float sd = 0; V3 n = v3(0, 0, 1), c = v3(0, 0, 0); float rad = 0; int body = 0, rep = 0;
+      if (lane < nsr) {
         const float* sp = lds + L.sph + s * 4;
         c = ld3(sp); rad = sp[3];
-        act = s / nsr; const int si = s - act * nsr; body = rm.sphere_body[si]; rep = act * MQE_NREP + rm.sphere_reported[si];
+        body = rm.sphere_body[lane]; rep = a * MQE_NREP + rm.sphere_reported[lane];
         sd = sphere_box(c, rad, ssC, ssR, v3(m->ss_plank_half[0], m->ss_plank_half[1], m->ss_plank_half[2]), n);
         hit = sd < m->contact_offset;
       }
       const unsigned long long bh = __ballot(hit);
       const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-      const int slot = nc + __popcll(bh & lower);
-      if (hit && slot < maxc) {
+      const int rk = __popcll(bh & lower), slot = nc + rk;
+      if (hit && rk < capP && slot < pair_lim) {
         float* cr = lds + L.con + slot * CON_STRIDE;
-        cr[C_IDS] = __int_as_float(act); cr[C_IDS + 1] = __int_as_float(body); cr[C_IDS + 2] = __int_as_float(A); cr[C_IDS + 3] = __int_as_float(0);
+        cr[C_IDS] = __int_as_float(a); cr[C_IDS + 1] = __int_as_float(body); cr[C_IDS + 2] = __int_as_float(A); cr[C_IDS + 3] = __int_as_float(0);
         cr[C_P] = c.x - rad * n.x; cr[C_P + 1] = c.y - rad * n.y; cr[C_P + 2] = c.z - rad * n.z;
         cr[C_N] = n.x; cr[C_N + 1] = n.y; cr[C_N + 2] = n.z; cr[C_SD] = sd;
         cr[C_REP] = __int_as_float(rep); cr[C_REP + 1] = __int_as_float(A * MQE_NREP + 1);
       }
-      nc += __popcll(bh);
-      if (nc > maxc) nc = maxc;
+      int tot = __popcll(bh);
+      if (tot > capP) tot = capP;
+      nc += tot;
+      if (nc > pair_lim) nc = pair_lim;
     }
   }
   TSTAMP(9);
@@ -626,7 +636,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
           if (bh == 0ull) continue;
           const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
           const int slot = nc + __popcll(bh & lower);
-          if (hit && slot < maxc) {
+          if (hit && slot < pair_lim) {
             float* cr = lds + L.con + slot * CON_STRIDE;
             const int bodyA = a < A ? rm.sphere_body[lane] : 0, bodyB = b < A ? rm.sphere_body[sb] : 0;
             const int repA = a < A ? a * MQE_NREP + rm.sphere_reported[lane] : A * MQE_NREP + (a - A);
@@ -638,7 +648,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
             cr[C_REP] = __int_as_float(repA); cr[C_REP + 1] = __int_as_float(repB);
           }
           nc += __popcll(bh);
-          if (nc > maxc) nc = maxc;
+          if (nc > pair_lim) nc = pair_lim;
         }
       }
   }
@@ -655,7 +665,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     const float q = lds[L.dof + (dact * 12 + dk - 6) * 2];
     jlo = (rm.dof_lower[dk - 6] - q) / dt; jhi = (rm.dof_upper[dk - 6] - q) / dt;
   }
-  float* Vm = lds + L.rhs + 64;      // v* (unconstrained velocity), read through the sparse Jacobian rows
+  float* Vm = lds + L.rhs;           // v* (unconstrained velocity) over the consumed bias vector, read through the sparse Jacobian rows
   Vm[lane] = vd;
   __syncthreads();
   const bool is_con = lane < nc;
@@ -677,9 +687,10 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     for (int side = 0; side < 2; side++) {
       const int act = side == 0 ? myA : myB, body = side == 0 ? bodyA : bodyB;
       const float sg = side == 0 ? 1.0f : -1.0f;
-      float* js = lds + L.js + lane * JS_STRIDE + side * 36;
-      float* Bs = lds + L.B + (lane * 2 + side) * 54;
       if (act < 0) continue;
+      const int slot = side == 0 ? lane : maxc + (lane - nc_terr);
+      float* js = lds + L.js + slot * JS_STRIDE;
+      float* Bs = lds + L.B + slot * 54;
       if (act < A) {
         const float* brec = lds + L.body + act * MQE_NBODY * BODY_STRIDE;
         const V3 r0 = p - ld3(brec + B_P);
@@ -743,13 +754,14 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   }
   __syncthreads();
   // B = M^-1 J^T for the articulated sides: task = (contact, side, local dof): 9 x 3 FMAs over the side's sparse columns
-  for (int t = lane; t < nc * 2 * MQE_RD; t += 64) {
-    const int cs = t / MQE_RD, d = t - cs * MQE_RD, c = cs >> 1, side = cs & 1;
-    if (c >= nc) continue;
+  for (int t = lane; t < (nc + (nc - nc_terr)) * MQE_RD; t += 64) {
+    const int cs = t / MQE_RD, d = t - cs * MQE_RD;
+    const int side = cs < nc ? 0 : 1, c = cs < nc ? cs : nc_terr + (cs - nc);
+    const int slot = side == 0 ? c : maxc + (c - nc_terr);
     const float* cr = lds + L.con + c * CON_STRIDE;
     const int act = __float_as_int(cr[C_IDS + 2 * side]);
     if (act < 0 || act >= A) continue;
-    const float* js = lds + L.js + c * JS_STRIDE + side * 36;
+    const float* js = lds + L.js + slot * JS_STRIDE;
     const float* Mi = lds + L.minv + act * MQE_RD * MQE_RD + d;
     float b0 = 0, b1 = 0, b2 = 0;
 #pragma unroll
@@ -758,13 +770,12 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       const float mv = Mi[__float_as_int(en.w) * MQE_RD];
       b0 += mv * en.x; b1 += mv * en.y; b2 += mv * en.z;
     }
-    float* Bs = lds + L.B + cs * 54;
+    float* Bs = lds + L.B + slot * 54;
     Bs[d] = b0; Bs[18 + d] = b1; Bs[36 + d] = b2;
   }
   __syncthreads();
   TSTAMP(11);
   // ---- 3x3 coupling blocks K(c, c2) = J_c M^-1 J_c2^T: one task per pair c2 <= c, transpose mirrored ---------------------------
-  const int kstride = maxc * 9 + 1;
   for (int t = lane; t < (nc * (nc + 1)) / 2; t += 64) {
     int c = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
     while ((c * (c + 1)) / 2 > t) c--;
@@ -780,8 +791,8 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       if (act < 0) continue;
       for (int s2 = 0; s2 < 2; s2++) {
         if ((s2 == 0 ? a2 : b2) != act) continue;
-        const float* js = lds + L.js + c * JS_STRIDE + s1 * 36;
-        const float* Bc = lds + L.B + (c2 * 2 + s2) * 54;
+        const float* js = lds + L.js + (s1 == 0 ? c : maxc + (c - nc_terr)) * JS_STRIDE;
+        const float* Bc = lds + L.B + (s2 == 0 ? c2 : maxc + (c2 - nc_terr)) * 54;
 #pragma unroll
         for (int i = 0; i < 9; i++) {
           const float4 en = *reinterpret_cast<const float4*>(js + i * 4);
@@ -793,18 +804,13 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
         }
       }
     }
-    float* kk = lds + L.kk + c * kstride + c2 * 9;
-    float* kt = lds + L.kk + c2 * kstride + c * 9;
+    float* kk = lds + L.kk + t * 9;            // t == c (c + 1) / 2 + c2: lower-triangular block storage
 #pragma unroll
     for (int q = 0; q < 9; q++) kk[q] = k[q];
-    if (c != c2) {
-#pragma unroll
-      for (int q = 0; q < 9; q++) kt[(q % 3) * 3 + q / 3] = k[q];
-    }
   }
   __syncthreads();
   if (is_con) {
-    const float* kd = lds + L.kk + lane * kstride + lane * 9;
+    const float* kd = lds + L.kk + ((lane * (lane + 1)) / 2 + lane) * 9;
     ik00 = 1.0f / kd[0]; ik11 = 1.0f / kd[4]; ik22 = 1.0f / kd[8]; ck10 = kd[3]; ck20 = kd[6]; ck21 = kd[7];
   }
   __syncthreads();
@@ -830,14 +836,26 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     }
     const int npair = __popcll(__ballot(is_pair));
     const int pair0 = nc - npair;
-    const float* krow = lds + L.kk + lane * kstride;
+    // K(lane, own): stored block (max, min); the mirrored half is the transpose (K is symmetric)
+    const int kc = is_con ? lane : 0;
+    const float* kbase = lds + L.kk;
+#define LOAD_KK(own)                                                                                      \
+    {                                                                                                     \
+      const int o_ = (own);                                                                               \
+      const bool tr_ = o_ > kc;                                                                           \
+      const int hi_ = tr_ ? o_ : kc, lo_ = tr_ ? kc : o_;                                                 \
+      const float* b_ = kbase + ((hi_ * (hi_ + 1)) / 2 + lo_) * 9;                                        \
+      kk[0] = b_[0]; kk[4] = b_[4]; kk[8] = b_[8];                                                        \
+      const float x1 = b_[1], x3 = b_[3], x2 = b_[2], x6 = b_[6], x5 = b_[5], x7 = b_[7];                \
+      kk[1] = tr_ ? x3 : x1; kk[3] = tr_ ? x1 : x3; kk[2] = tr_ ? x6 : x2; kk[6] = tr_ ? x2 : x6;         \
+      kk[5] = tr_ ? x7 : x5; kk[7] = tr_ ? x5 : x7;                                                       \
+    }
     for (int it = 0; it < m->solver_iterations; it++) {
       for (int sidx = 0; sidx < maxlen; sidx++) {
         const bool vA = sidx < glenA;
         const int ownA = vA ? (gstartA + sidx) : (is_con ? lane : 0);   // never index an unwritten block (0 * NaN)
         float kk[9];
-#pragma unroll
-        for (int q = 0; q < 9; q++) kk[q] = krow[ownA * 9 + q];
+        LOAD_KK(ownA);
         const float ln = fmaxf(cl0 - (cu0 - cbias) * ik00, 0.0f);
         const float d0 = ln - cl0;
         const float lim = mu * ln;
@@ -856,8 +874,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
           const int ownB = vB ? (gstartB + sidx) : (is_con ? lane : 0);
           float f0 = __shfl(d0, ownB, 64), f1 = __shfl(d1, ownB, 64), f2 = __shfl(d2, ownB, 64);
           if (!vB) { f0 = 0.0f; f1 = 0.0f; f2 = 0.0f; }
-#pragma unroll
-          for (int q = 0; q < 9; q++) kk[q] = krow[ownB * 9 + q];
+          LOAD_KK(ownB);
           cu0 += kk[0] * f0 + kk[1] * f1 + kk[2] * f2;
           cu1 += kk[3] * f0 + kk[4] * f1 + kk[5] * f2;
           cu2 += kk[6] * f0 + kk[7] * f1 + kk[8] * f2;
@@ -865,8 +882,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       }
       for (int c = pair0; c < nc; c++) {
         float kk[9];
-#pragma unroll
-        for (int q = 0; q < 9; q++) kk[q] = krow[c * 9 + q];
+        LOAD_KK(c);
         const float ln = fmaxf(cl0 - (cu0 - cbias) * ik00, 0.0f);
         const float d0 = ln - cl0;
         const float lim = mu * ln;
@@ -884,6 +900,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       }
     }
   }
+#undef LOAD_KK
   TSTAMP(13);
   if (is_con) { float* cr = lds + L.con + lane * CON_STRIDE; cr[C_LAM] = cl0; cr[C_LAM + 1] = cl1; cr[C_LAM + 2] = cl2; }
   __syncthreads();
@@ -893,7 +910,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       const float* cr = lds + L.con + c * CON_STRIDE;
       const int a2 = __float_as_int(cr[C_IDS]), b2 = __float_as_int(cr[C_IDS + 2]);
       if (a2 != dact && b2 != dact) continue;
-      const float* Bc = lds + L.B + (c * 2 + (a2 == dact ? 0 : 1)) * 54;
+      const float* Bc = lds + L.B + (a2 == dact ? c : maxc + (c - nc_terr)) * 54;
       vd += Bc[dloc] * cr[C_LAM] + Bc[18 + dloc] * cr[C_LAM + 1] + Bc[36 + dloc] * cr[C_LAM + 2];
     }
   }

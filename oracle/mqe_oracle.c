@@ -798,20 +798,25 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
       }
     }
   }
+  /* two-actor contacts (plank, sphere pairs): at most maxc/2 of them (the engine slot-allocates their second side) */
+  const int pair_lim = w->nc + maxc / 2 < maxc ? w->nc + maxc / 2 : maxc;
   if (SS)   /* robot spheres vs the plank (dynamic: couples the robots through the hinge) */
-    for (int act = 0; act < A; act++)
+    for (int act = 0; act < A; act++) {
+      int mine = 0;                     /* per-robot share of the two-actor budget */
       for (int si = 0; si < w->sph_n[act]; si++) {
         const real* c = w->sph_c[act][si];
         real r = w->sph_r[act][si], n[3];
         real hp[3] = {d->seesaw_plank_half[0], d->seesaw_plank_half[1], d->seesaw_plank_half[2]};
         real sd = sphere_box(c, r, ssC, ssR, hp, n);
-        if (sd < d->contact_offset && w->nc < maxc) {
+        if (sd < d->contact_offset && w->nc < pair_lim && mine < (maxc / 2) / A) {
+          mine++;
           contact_t* ct = &w->con[w->nc++];
           memset(ct, 0, sizeof *ct);
           ct->kind = 2; ct->actA = act; ct->sphA = si; ct->actB = A; ct->sphB = 0; ct->sd = sd;
           for (int k = 0; k < 3; k++) { ct->n[k] = n[k]; ct->p[k] = c[k] - r * n[k]; }
         }
       }
+    }
   for (int a = 0; a < nact; a++)
     for (int b = a + 1; b < nact; b++) {
       const real* pa = a < A ? w->bk[a][0].p : npc_pos[a - A];
@@ -824,7 +829,7 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
           real e[3] = {ca[0] - cb[0], ca[1] - cb[1], ca[2] - cb[2]};
           real dist = (real)sqrt((double)dot3(e, e));
           real sd = dist - w->sph_r[a][sa] - w->sph_r[b][sb];
-          if (sd < d->contact_offset && w->nc < maxc && dist > (real)1e-9) {
+          if (sd < d->contact_offset && w->nc < pair_lim && dist > (real)1e-9) {
             contact_t* ct = &w->con[w->nc++];
             memset(ct, 0, sizeof *ct);
             ct->kind = 1; ct->actA = a; ct->sphA = sa; ct->actB = b; ct->sphB = sb; ct->sd = sd;
