@@ -166,6 +166,22 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     for (int k = 0; k < 9; k++) myrec[B_R + k] = Rm[k];
     st3(myrec + B_P, bp); st3(myrec + B_W, bw); st3(myrec + B_VP, bvp); st3(myrec + B_A, bax); st3(myrec + B_AL, bal); st3(myrec + B_AP, bap);
   }
+  // joint-local quantities do not depend on the parent: computed once for all joint lanes, outside the level loop
+  // (whose divergent body would otherwise run the sin/cos code three times)
+  float Rj[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, qdj = 0.0f;
+  V3 joff = v3(0, 0, 0), jax = v3(0, 0, 0);
+  if (depth > 0) {
+    const int j = bb - 1;
+    const float qj = lds[L.dof + (br * 12 + j) * 2];
+    qdj = lds[L.dof + (br * 12 + j) * 2 + 1];
+    joff = v3(rm.joint_offset[bb][0], rm.joint_offset[bb][1], rm.joint_offset[bb][2]);
+    jax = v3(rm.joint_axis[bb][0], rm.joint_axis[bb][1], rm.joint_axis[bb][2]);
+    const V3 ax = jax;
+    const float c = cosf(qj), s = sinf(qj), t = 1 - c;
+    Rj[0] = t * ax.x * ax.x + c; Rj[1] = t * ax.x * ax.y - s * ax.z; Rj[2] = t * ax.x * ax.z + s * ax.y;
+    Rj[3] = t * ax.x * ax.y + s * ax.z; Rj[4] = t * ax.y * ax.y + c; Rj[5] = t * ax.y * ax.z - s * ax.x;
+    Rj[6] = t * ax.x * ax.z - s * ax.y; Rj[7] = t * ax.y * ax.z + s * ax.x; Rj[8] = t * ax.z * ax.z + c;
+  }
   __syncthreads();
   for (int lev = 1; lev <= 3; lev++) {
     if (depth == lev) {
@@ -174,19 +190,11 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       float PR[9];
       for (int k = 0; k < 9; k++) PR[k] = pr[B_R + k];
       V3 pp = ld3(pr + B_P), pw = ld3(pr + B_W), pvp = ld3(pr + B_VP), pal = ld3(pr + B_AL), pap = ld3(pr + B_AP);
-      const int j = bb - 1;
-      float qj = lds[L.dof + (br * 12 + j) * 2], qdj = lds[L.dof + (br * 12 + j) * 2 + 1];
-      V3 off = v3(rm.joint_offset[bb][0], rm.joint_offset[bb][1], rm.joint_offset[bb][2]);
-      V3 ax = v3(rm.joint_axis[bb][0], rm.joint_axis[bb][1], rm.joint_axis[bb][2]);
-      V3 dd = mat_vec(PR, off);
+      V3 dd = mat_vec(PR, joff);
       bp = pp + dd;
-      float c = cosf(qj), s = sinf(qj), t = 1 - c;
-      float Rj[9] = {t * ax.x * ax.x + c, t * ax.x * ax.y - s * ax.z, t * ax.x * ax.z + s * ax.y,
-                     t * ax.x * ax.y + s * ax.z, t * ax.y * ax.y + c, t * ax.y * ax.z - s * ax.x,
-                     t * ax.x * ax.z - s * ax.y, t * ax.y * ax.z + s * ax.x, t * ax.z * ax.z + c};
       for (int r = 0; r < 3; r++)
         for (int cc = 0; cc < 3; cc++) Rm[r * 3 + cc] = PR[r * 3] * Rj[cc] + PR[r * 3 + 1] * Rj[3 + cc] + PR[r * 3 + 2] * Rj[6 + cc];
-      bax = mat_vec(PR, ax);
+      bax = mat_vec(PR, jax);
       bw = pw + qdj * bax;
       bvp = pvp + cross(pw, dd);
       bal = pal + cross(pw, qdj * bax);
@@ -486,18 +494,39 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   }
   // ---- contact generation: terrain (ground plane, wall SDF), canonical order --------------------------------------------
   int nc = 0;
-  for (int actu = 0; actu < A + PD; actu++) {        // one actor per iteration: lanes = its spheres
-    const int nsa = actu < A ? nsr : m->npc_n_spheres;
-    const int s = lane < nsa ? (actu < A ? actu * nsr + lane : A * nsr + (actu - A) * m->npc_n_spheres + lane) : nsph;
-    const int cap = actu < A ? CAP_ROBOT : CAP_NPC;
+  // Passes over whole actors, lane = sphere: two robots per pass (2 x 27 spheres), all single-sphere NPCs in one pass
+  // (multi-sphere NPCs: one per pass).  The list order stays canonical -- actor by actor, sphere by sphere, ground /
+  // wall / platform / column -- because a lane's slot = contacts of earlier groups (capped) + its rank in its group.
+  const int rpp = (2 * nsr <= 64) ? 2 : 1;
+  const int n_rpass = (A + rpp - 1) / rpp;
+  const bool npc_fast = m->npc_n_spheres == 1;
+  const int n_pass = n_rpass + (PD > 0 ? (npc_fast ? 1 : PD) : 0);
+  for (int pass = 0; pass < n_pass; pass++) {
+    int act = -1, sidx = 0, s = nsph, sub = 0;
+    unsigned long long gm = ~0ull;                         // lanes of my group (= my actor)
+    const bool rob = pass < n_rpass;
+    const int cap = rob ? CAP_ROBOT : CAP_NPC;
+    const unsigned long long m0 = (nsr < 64) ? ((1ull << nsr) - 1ull) : ~0ull;
+    if (rob) {
+      sub = (rpp == 2 && lane >= nsr) ? 1 : 0;
+      const int l = lane - sub * nsr, r = pass * rpp + sub;
+      if (l < nsr && r < A) { act = r; sidx = l; s = r * nsr + l; }
+      gm = sub ? (m0 << nsr) : m0;
+    } else if (npc_fast) {
+      if (lane < PD) { act = A + lane; s = A * nsr + lane; }
+      gm = 1ull << lane;
+    } else {
+      const int p = pass - n_rpass;
+      if (lane < m->npc_n_spheres) { act = A + p; sidx = lane; s = A * nsr + p * m->npc_n_spheres + lane; }
+    }
     bool gflag = false, wflag = false, bflag = false, cflag = false;   // ground, wall, seesaw platform, seesaw column
     float gsd = 0, wsd = 0, bsd = 0, csd = 0; V3 wn = v3(0, 0, 1), bn = v3(0, 0, 1), cn3 = v3(0, 0, 1); V3 c = v3(0, 0, 0); float rad = 0;
-    int act = 0, body = 0, rep = 0;
-    if (s < nsph) {
+    int body = 0, rep = 0;
+    if (act >= 0) {
       const float* sp = lds + L.sph + s * 4;
       c = ld3(sp); rad = sp[3];
-      if (s < A * nsr) { act = s / nsr; const int si = s - act * nsr; body = rm.sphere_body[si]; rep = act * MQE_NREP + rm.sphere_reported[si]; }
-      else { const int p = (s - A * nsr) / m->npc_n_spheres; act = A + p; body = 0; rep = A * MQE_NREP + p; }
+      if (act < A) { body = rm.sphere_body[sidx]; rep = act * MQE_NREP + rm.sphere_reported[sidx]; }
+      else { body = 0; rep = A * MQE_NREP + (act - A); }
       gsd = c.z - m->ground_z - rad;
       gflag = gsd < m->contact_offset;
       // wall prism set: bilinear SDF sample at cell centres
@@ -535,9 +564,25 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     }
     const unsigned long long bg = __ballot(gflag), bw2 = __ballot(wflag), bb2 = __ballot(bflag), bc2 = __ballot(cflag);
     const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const int pre = __popcll(bg & lower) + __popcll(bw2 & lower) + __popcll(bb2 & lower) + __popcll(bc2 & lower);
+    const unsigned long long gl = gm & lower;
+    const int pre = __popcll(bg & gl) + __popcll(bw2 & gl) + __popcll(bb2 & gl) + __popcll(bc2 & gl);   // rank in my actor
+    int tot0 = __popcll(bg & m0) + __popcll(bw2 & m0) + __popcll(bb2 & m0) + __popcll(bc2 & m0);          // first robot of the pass
+    int tot1 = 0;
+    if (tot0 > cap) tot0 = cap;
+    int base = nc;
+    if (rob) {
+      if (rpp == 2) {
+        const unsigned long long m1 = m0 << nsr;
+        tot1 = __popcll(bg & m1) + __popcll(bw2 & m1) + __popcll(bb2 & m1) + __popcll(bc2 & m1);
+        if (tot1 > cap) tot1 = cap;
+      }
+      base = nc + (sub ? tot0 : 0);
+    } else if (npc_fast) {                 // one sphere per actor: <= 2 contacts each, the cap never binds
+      base = nc + __popcll(bg & lower) + __popcll(bw2 & lower);
+      tot0 = __popcll(bg) + __popcll(bw2);
+    }
     if (gflag) {
-      const int slot = nc + pre;
+      const int slot = base + pre;
       if (slot < maxc && pre < cap) {
         float* cr = lds + L.con + slot * CON_STRIDE;
         cr[C_IDS] = __int_as_float(act); cr[C_IDS + 1] = __int_as_float(body); cr[C_IDS + 2] = __int_as_float(-1); cr[C_IDS + 3] = __int_as_float(0);
@@ -547,7 +592,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       }
     }
     if (wflag) {
-      const int rk = pre + (gflag ? 1 : 0), slot = nc + rk;
+      const int rk = pre + (gflag ? 1 : 0), slot = base + rk;
       if (slot < maxc && rk < cap) {
         float* cr = lds + L.con + slot * CON_STRIDE;
         cr[C_IDS] = __int_as_float(act); cr[C_IDS + 1] = __int_as_float(body); cr[C_IDS + 2] = __int_as_float(-1); cr[C_IDS + 3] = __int_as_float(0);
@@ -559,7 +604,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     if (bflag || cflag) {
       for (int which = 0; which < 2; which++) {
         if (which == 0 ? !bflag : !cflag) continue;
-        const int rk = pre + (gflag ? 1 : 0) + (wflag ? 1 : 0) + (which == 1 && bflag ? 1 : 0), slot = nc + rk;
+        const int rk = pre + (gflag ? 1 : 0) + (wflag ? 1 : 0) + (which == 1 && bflag ? 1 : 0), slot = base + rk;
         if (slot < maxc && rk < cap) {
           const V3 nn = which == 0 ? bn : cn3;
           float* cr = lds + L.con + slot * CON_STRIDE;
@@ -570,12 +615,8 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
         }
       }
     }
-    {
-      int tot = __popcll(bg) + __popcll(bw2) + __popcll(bb2) + __popcll(bc2);
-      if (tot > cap) tot = cap;
-      nc += tot;
-      if (nc > maxc) nc = maxc;
-    }
+    nc += tot0 + tot1;
+    if (nc > maxc) nc = maxc;
   }
   // robot spheres vs the seesaw plank (dynamic: couples the robots through the hinge); after all terrain contacts
   const int nc_terr = nc;                                   // one-sided contacts end here; two-actor contacts follow

@@ -108,7 +108,13 @@ __global__ void k_pre_policy(const DevModel* m, DevState st, const float* __rest
   else if (c < 70) v = ob[63 + (c - 66)];                      // clock inputs           :100
   else v = 0.0f;
   lo[c] = v;
-  st.hist[((size_t)i * MQE_HIST + hist_slot) * MQE_FRAME + c] = v;   // :102
+  const size_t hidx = ((size_t)i * MQE_HIST + hist_slot) * MQE_FRAME + c;
+  st.hist[hidx] = v;   // :102
+  if (st.hist3) {      // the split-bf16 GEMM's operand copy: three bf16 planes (kernels_gemm.hpp)
+    uint16_t h, l, sm;
+    split3(v, h, l, sm);
+    st.hist3[hidx] = h; st.hist3[st.hist3_plane + hidx] = l; st.hist3[2 * st.hist3_plane + hidx] = sm;
+  }
 }
 
 // go1.py:106-107 + :40-41: shift the last-action registers and clip the new joint targets.  act: [R, ld]
@@ -124,14 +130,22 @@ __global__ void k_post_policy(const DevModel* m, DevState st, const float* __res
 
 // body layer 0 finish: v = (hist . W + b) + lat0*w0 + lat1*w1 ; ELU   (go1.py:404: body(cat(history, latent)))
 __global__ void k_body_l0_finish(float* __restrict__ P1, int ldp, int col0, int ncols, const float* __restrict__ lat, int ldl,
-                                 const float* __restrict__ w_lat0, const float* __restrict__ w_lat1, int R) {
+                                 const float* __restrict__ w_lat0, const float* __restrict__ w_lat1, int R,
+                                 uint16_t* __restrict__ P3, size_t plane) {
   int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= R * ncols) return;
   int i = idx / ncols, c = idx - i * ncols;
   float v = P1[(size_t)i * ldp + col0 + c];
   v = fmaf(lat[(size_t)i * ldl], w_lat0[c], v);
   v = fmaf(lat[(size_t)i * ldl + 1], w_lat1[c], v);
-  P1[(size_t)i * ldp + col0 + c] = v > 0 ? v : expm1f(v);
+  v = v > 0 ? v : expm1f(v);
+  P1[(size_t)i * ldp + col0 + c] = v;
+  if (P3) {
+    uint16_t h, l, sm;
+    split3(v, h, l, sm);
+    uint16_t* o = P3 + (size_t)i * ldp + col0 + c;
+    o[0] = h; o[plane] = l; o[2 * plane] = sm;
+  }
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -598,6 +612,10 @@ __global__ void k_reset_history(const DevModel* m, DevState st) {
   if (i >= m->R) return;
   if (!st.reset_buf[i / m->A]) return;
   reinterpret_cast<float4*>(st.hist)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (st.hist3) {
+#pragma unroll
+    for (int p = 0; p < 3; p++) reinterpret_cast<uint2*>(st.hist3 + p * st.hist3_plane)[idx] = make_uint2(0u, 0u);
+  }
 }
 
 __global__ void __launch_bounds__(64) k_reset_all(const DevModel* m, DevState st, int no_post_step_yet) {

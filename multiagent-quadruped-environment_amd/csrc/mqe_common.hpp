@@ -54,8 +54,24 @@ struct DevState {
   float *root, *dof, *cf, *torques, *actions, *last_actions, *loco_obs, *hist, *last_loco, *last_two_loco, *act_hist;
   float *gait, *clock, *blv, *bav, *pg, *bquat, *obs_bag, *wobs, *wrew, *rsum, *sheep_avg, *sheep_var, *sub_tau, *npc_noise;
   float *w_last, *w_last2, *cmd;
+  uint16_t* hist3; size_t hist3_plane;      // split-bf16 copy of the history ring (3 planes, same [R][30][72] layout)
   int32_t *ep_len, *reset_count;
   uint8_t *reset_buf, *collide_buf, *time_out, *r_term, *p_term, *zh_term, *w_have_last, *w_delayed_reset;
 };
 
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+
+// f32 -> three bf16 planes (h + l + s == x to 24 significand bits); see k_gemm_b3 in kernels_gemm.hpp
+__host__ __device__ __forceinline__ uint16_t bf16_rne(float x) {
+  union { float f; uint32_t u; } v; v.f = x;
+  v.u += 0x7fffu + ((v.u >> 16) & 1u);
+  return (uint16_t)(v.u >> 16);
+}
+__host__ __device__ __forceinline__ float bf16_f32(uint16_t h) { union { float f; uint32_t u; } v; v.u = (uint32_t)h << 16; return v.f; }
+__host__ __device__ __forceinline__ void split3(float x, uint16_t& h, uint16_t& l, uint16_t& s) {
+  h = bf16_rne(x);
+  const float r1 = x - bf16_f32(h);
+  l = bf16_rne(r1);
+  s = bf16_rne(r1 - bf16_f32(l));
+}
+

@@ -75,6 +75,25 @@ def test_single_substep_matches_oracle(task, N):
         close(eh.tensor(abi.T_CONTACT_FORCE), eo.tensor(abi.T_CONTACT_FORCE), atol=0.5, rtol=2e-2, what="net contact force")
 
 
+def test_split_bf16_layer0_is_f32_equivalent(monkeypatch):
+    """MQE_GEMM_B3=1 runs layer 0 of the locomotion policy on the bf16 matrix cores with three-plane split operands
+    (k_gemm_b3).  Its joint targets must agree with the CPU oracle's f32 fmaf chain as tightly as the exact-f32 MFMA
+    path does: |diff| <= 5e-5 on O(1) outputs after a history of 12 random steps (tolerance = f32 accumulation noise)."""
+    monkeypatch.setenv("MQE_GEMM_B3", "1")
+    eh, eo, d = _pair("go1gate", 64)
+    monkeypatch.delenv("MQE_GEMM_B3")
+    eh.reset_all(); eo.reset_all()
+    g = torch.Generator().manual_seed(5)
+    for t in range(12):
+        a = torch.rand(64, 2, 3, generator=g) * 2 - 1
+        eh.step(a.cuda().contiguous()); eo.step(a)
+        # keep both engines on the same trajectory so that step t compares the policy on identical histories
+        for k in (abi.T_ROOT_STATE, abi.T_DOF_STATE):
+            eh.tensor(k).copy_(eo.tensor(k).cuda())
+        if t in (0, 3, 11):
+            close(eh.tensor(abi.T_ACTIONS), eo.tensor(abi.T_ACTIONS), atol=5e-5, what=f"policy actions step {t}")
+
+
 @pytest.mark.parametrize("task,N", [("go1gate", 128), ("go1football-defender", 16), ("go1sheep-hard", 14), ("go1seesaw", 16)])
 def test_fused_rollout_matches_oracle(task, N):
     """20 fused step() calls (policy + 4 substeps + post-step + wrapper) from the seeded reset distribution.
