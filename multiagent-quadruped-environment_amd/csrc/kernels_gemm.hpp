@@ -103,32 +103,44 @@ __global__ void __launch_bounds__(256) k_gemm_f32(GemmArgs g) {
 // A product a*b is the six bf16 x bf16 terms down to 2^-24 relative (hh, hl, lh, ll, hs, sh; the dropped ls, sl, ss are
 // <= 2^-24 |ab|), each exact in the MFMA and accumulated in f32.  Six v_mfma_f32_32x32x16_bf16 replace eight
 // v_mfma_f32_32x32x2_f32 per 16 k: 16x the rate per instruction, 2.7x net of the extra terms.
-//   * the producers write the planes: k_pre_policy (new history frame), this kernel's epilogue (hidden activations),
-//     k_body_l0_finish (body layer 0 after the latent columns); weights are split once on the host.
-//   * block 128 x 64, 4 waves as 2 x 2, wave tile 64 x 32 = 2 accumulators; K step 32 through LDS (row = 32 k of one
-//     plane, padded to 80 B so that the 16 B fragment reads of 32 rows spread over the banks).
+//   * producers write the planes (interleaved per 8-element unit, see Gemm3Args): k_pre_policy (new history frame);
+//     weights are split once on the host.
+//   * with 2.7x less matrix time the LDS becomes the critical resource (a 64 x 32 wave tile reads 0.75 fragments per
+//     MFMA and measured LDS-bound), so the tile is large: block 128 x 192, 4 waves as 2 x 2, wave tile 64 x 96 = 6
+//     accumulators (0.42 fragment reads per MFMA).  M = 8192, N = 768 gives exactly 256 blocks = one per CU, so the
+//     pipeline is explicit instead of relying on other resident blocks: LDS double buffer (2 x 77 KB), k-tile t+2 in
+//     flight from global while tile t is multiplied and tile t+1 is written to the other buffer; one barrier per tile.
+//   * LDS row = 32 k of one plane padded to 80 B, so the 16 B fragment reads of 16 consecutive rows tile all banks.
 //   * A may be the history ring: 8-element units, logical unit u -> (u + rot) mod ring (frames are 72 = 9 units).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// explicit global address space: pointers selected between two kernel-argument buffers degrade to flat loads, whose
+// completion is also counted by lgkmcnt, i.e. every LDS wait would wait for the prefetch as well
+typedef unsigned int g3_u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) g3_u32x4 g3_gvec;
 
 #define G3_M 128
-#define G3_N 64
+#define G3_N 192
 #define G3_K 32
-#define G3_ROWB 80          // bytes per LDS row (64 B of data + 16 B pad)
+#define G3_ROWB 80                                  // bytes per LDS row (64 B of data + 16 B pad)
+#define G3_ROWS (G3_M + G3_N)
+#define G3_BUF (3 * G3_ROWS * G3_ROWB)              // one LDS buffer: [plane][A rows | W rows][80 B]
+#define G3_LDS_BYTES (2 * G3_BUF)
+#define G3_NLD ((3 * G3_ROWS * 4) / 256)            // 16 B units per thread per k-tile (= 15)
 
 struct Gemm3Args {
-  const uint16_t* A; int lda; size_t a_plane; int a_rot8, a_ring8;
-  const uint16_t* W; int ldw; size_t w_plane;          // W [Npad][Kpad] per plane (K contiguous: the (out,in) layout)
+  // operands are plane-interleaved per 8-element unit: row r, element k of plane p at r * ld + ((k / 8) * 3 + p) * 8 + k % 8
+  // (ld = 3 * K elements), so the 32 k x 3 planes a row contributes to a k-tile are 192 contiguous bytes: whole 128 B
+  // lines are consumed at once (separate planes half-used every line and fetched it twice through the 32 KB L1)
+  const uint16_t* A; int lda; int a_rot8, a_ring8;
+  const uint16_t* W; int ldw;                          // W rows = output units (the (out,in) layout), same interleaving
   const float* bias;
-  float* C; int ldc;                                   // f32 result (nullable)
-  uint16_t* C3; int ldc3; size_t c_plane; int c3_cols;  // split result for the next layer, columns [0, c3_cols)
-  int M, N, K;                                         // N multiple of 64, K multiple of 32
+  float* C; int ldc;
+  int M, N, K;                                         // N multiple of 192, K multiple of 64
   int act_cols;
 };
 
-__global__ void __launch_bounds__(256) k_gemm_b3(Gemm3Args g) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[3 * (G3_M + G3_N) * G3_ROWB];
-  unsigned char* As = lds;                                   // [plane][row 0..127][80 B]
-  unsigned char* Bs = lds + 3 * G3_M * G3_ROWB;              // [plane][row 0..63][80 B]
+__global__ void __launch_bounds__(256, 1) k_gemm_b3(Gemm3Args g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int ntn = g.N / G3_N, ntm = (g.M + G3_M - 1) / G3_M;
@@ -137,99 +149,76 @@ __global__ void __launch_bounds__(256) k_gemm_b3(Gemm3Args g) {
   if ((total & 7) == 0) { const int xcd = bid & 7, slot = bid >> 3; bid = xcd * (total >> 3) + slot; }
   const int tm = bid / ntn, tn = bid - tm * ntn;
   const int m0 = tm * G3_M, n0 = tn * G3_N;
-  f32x16 acc[2];
+  f32x16 acc00, acc01, acc02, acc10, acc11, acc12;
 #pragma unroll
-  for (int t = 0; t < 2; t++)
-#pragma unroll
-    for (int i = 0; i < 16; i++) acc[t][i] = 0.0f;
-  // staging assignment: 16 B units; A rows tid>>2 and 64 + tid>>2, unit tid&3; B row tid>>2, unit tid&3
+  for (int i = 0; i < 16; i++) { acc00[i] = 0.0f; acc01[i] = 0.0f; acc02[i] = 0.0f; acc10[i] = 0.0f; acc11[i] = 0.0f; acc12[i] = 0.0f; }
+  // staging: per plane this thread moves A rows srow, 64 + srow and W rows srow, 64 + srow, 128 + srow, one 16 B unit
+  // (8 k) each.  Everything but two per-thread byte offsets (A side with the ring rotation, W side) is wave-uniform, so
+  // the 15 loads of a k-tile are SGPR base + VGPR offset.
   const int srow = tid >> 2, sunit = tid & 3;
   const bool a_ok0 = (m0 + srow) < g.M, a_ok1 = (m0 + 64 + srow) < g.M;
-  const uint16_t* Ar0 = g.A + (size_t)(m0 + srow) * g.lda;
-  const uint16_t* Ar1 = g.A + (size_t)(m0 + 64 + srow) * g.lda;
-  const uint16_t* Wr = g.W + (size_t)(n0 + srow) * g.ldw;
-  // prefetch registers (plain scalars: arrays here end up in scratch): tile t+1 is requested before tile t is multiplied.
-  // (A second register set for t+2 was measured slower: 188 registers drop the CU to 2 resident blocks.)
-  uint4 pa00, pa01, pa10, pa11, pa20, pa21, pb0, pb1, pb2;
-  const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
-#define G3_LOAD_TILE(P, k0_)                                                                                    \
-  {                                                                                                             \
-    const int u_ = ((k0_) >> 3) + sunit;                                                                        \
-    int ua_ = u_;                                                                                               \
-    if (g.a_ring8) { ua_ += g.a_rot8; if (ua_ >= g.a_ring8) ua_ -= g.a_ring8; if (ua_ >= g.a_ring8) ua_ -= g.a_ring8; } \
-    const size_t oa_ = (size_t)ua_ * 8, ow_ = (size_t)u_ * 8;                                                    \
-    P##a00 = a_ok0 ? *reinterpret_cast<const uint4*>(Ar0 + oa_) : z4;                                           \
-    P##a01 = a_ok1 ? *reinterpret_cast<const uint4*>(Ar1 + oa_) : z4;                                           \
-    P##a10 = a_ok0 ? *reinterpret_cast<const uint4*>(Ar0 + g.a_plane + oa_) : z4;                               \
-    P##a11 = a_ok1 ? *reinterpret_cast<const uint4*>(Ar1 + g.a_plane + oa_) : z4;                               \
-    P##a20 = a_ok0 ? *reinterpret_cast<const uint4*>(Ar0 + 2 * g.a_plane + oa_) : z4;                           \
-    P##a21 = a_ok1 ? *reinterpret_cast<const uint4*>(Ar1 + 2 * g.a_plane + oa_) : z4;                           \
-    P##b0 = *reinterpret_cast<const uint4*>(Wr + ow_);                                                          \
-    P##b1 = *reinterpret_cast<const uint4*>(Wr + g.w_plane + ow_);                                              \
-    P##b2 = *reinterpret_cast<const uint4*>(Wr + 2 * g.w_plane + ow_);                                          \
-  }
-#define G3_STORE_TILE(P)                                                                                        \
-  {                                                                                                             \
-    unsigned char* wa = As + srow * G3_ROWB + sunit * 16;                                                       \
-    unsigned char* wb = Bs + srow * G3_ROWB + sunit * 16;                                                       \
-    *reinterpret_cast<uint4*>(wa) = P##a00;                                                                     \
-    *reinterpret_cast<uint4*>(wa + 64 * G3_ROWB) = P##a01;                                                      \
-    *reinterpret_cast<uint4*>(wa + G3_M * G3_ROWB) = P##a10;                                                    \
-    *reinterpret_cast<uint4*>(wa + (G3_M + 64) * G3_ROWB) = P##a11;                                             \
-    *reinterpret_cast<uint4*>(wa + 2 * G3_M * G3_ROWB) = P##a20;                                                \
-    *reinterpret_cast<uint4*>(wa + (2 * G3_M + 64) * G3_ROWB) = P##a21;                                         \
-    *reinterpret_cast<uint4*>(wb) = P##b0;                                                                      \
-    *reinterpret_cast<uint4*>(wb + G3_N * G3_ROWB) = P##b1;                                                     \
-    *reinterpret_cast<uint4*>(wb + 2 * G3_N * G3_ROWB) = P##b2;                                                 \
-  }
-#define G3_COMPUTE()                                                                                            \
-  _Pragma("unroll") for (int ks = 0; ks < 2; ks++) {                                                            \
-    bf16x8 b[3], a[2][3];                                                                                       \
-    _Pragma("unroll") for (int p = 0; p < 3; p++) {                                                             \
-      b[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Bs + (p * G3_N + wn * 32 + frow) * G3_ROWB + ks * 32 + fk)); \
-      _Pragma("unroll") for (int t = 0; t < 2; t++)                                                             \
-        a[t][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(As + (p * G3_M + wm * 64 + t * 32 + frow) * G3_ROWB + ks * 32 + fk)); \
-    }                                                                                                           \
-    _Pragma("unroll") for (int t = 0; t < 2; t++) { /* small terms first */                                     \
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][2], b[0], acc[t], 0, 0, 0);                         \
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][0], b[2], acc[t], 0, 0, 0);                         \
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][1], b[1], acc[t], 0, 0, 0);                         \
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][1], b[0], acc[t], 0, 0, 0);                         \
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][0], b[1], acc[t], 0, 0, 0);                         \
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][0], b[0], acc[t], 0, 0, 0);                         \
-    }                                                                                                           \
-  }
+  const char* Abase = reinterpret_cast<const char*>(g.A) + (size_t)m0 * g.lda * 2;
+  const char* Wbase = reinterpret_cast<const char*>(g.W) + (size_t)n0 * g.ldw * 2;
+  const unsigned a_row = (unsigned)srow * g.lda * 2, a_row64 = 64u * g.lda * 2;
+  const unsigned w_row = (unsigned)srow * g.ldw * 2, w_row64 = 64u * g.ldw * 2;
+  // load q (0..2) of a row moves bytes [64 q, 64 q + 64) of the row's 192 B: chunk c = 4 q + sunit = (unit c / 3, plane c % 3)
+  const int c0 = sunit, c1 = 4 + sunit, c2 = 8 + sunit;
+  const int j0 = c0 / 3, j1 = c1 / 3, j2 = c2 / 3;
+  const unsigned st_q0 = ((c0 % 3) * G3_ROWS + srow) * G3_ROWB + j0 * 16;
+  const unsigned st_q1 = ((c1 % 3) * G3_ROWS + srow) * G3_ROWB + j1 * 16;
+  const unsigned st_q2 = ((c2 % 3) * G3_ROWS + srow) * G3_ROWB + j2 * 16;
   const int frow = lane & 31, fk = (lane >> 5) * 16;           // fragment: row, byte offset of its 8 k inside a 16-k step
-  G3_LOAD_TILE(p, 0);
-  for (int k0 = 0; k0 < g.K; k0 += G3_K) {
-    __syncthreads();
-    G3_STORE_TILE(p);
-    __syncthreads();
-    if (k0 + G3_K < g.K) G3_LOAD_TILE(p, k0 + G3_K);
-    G3_COMPUTE();
+  const unsigned fa_ofs = (wm * 64 + frow) * G3_ROWB + fk, fb_ofs = (G3_M + wn * 96 + frow) * G3_ROWB + fk;
+  const int nkt = g.K / G3_K;                                   // even (K is a multiple of 64)
+  unsigned char* buf0 = lds3;
+  unsigned char* buf1 = lds3 + G3_BUF;
+  const g3_u32x4 z4 = {0u, 0u, 0u, 0u};
+  // two prefetch register sets [load q][row block] and two fragment sets [tile][plane]; all named scalars
+  g3_u32x4 Pa00, Pa01, Pa10, Pa11, Pa20, Pa21, Pw00, Pw01, Pw02, Pw10, Pw11, Pw12, Pw20, Pw21, Pw22;
+  g3_u32x4 Qa00, Qa01, Qa10, Qa11, Qa20, Qa21, Qw00, Qw01, Qw02, Qw10, Qw11, Qw12, Qw20, Qw21, Qw22;
+  g3_u32x4 f0a00, f0a01, f0a02, f0a10, f0a11, f0a12, f0b00, f0b01, f0b02, f0b10, f0b11, f0b12, f0b20, f0b21, f0b22;
+  g3_u32x4 f1a00, f1a01, f1a02, f1a10, f1a11, f1a12, f1b00, f1b01, f1b02, f1b10, f1b11, f1b12, f1b20, f1b21, f1b22;
+  unsigned aoff0, aoff1, aoff2, woff;
+#define G3_WRAP(u_) { if (u_ >= g.a_ring8) u_ -= g.a_ring8; if (u_ >= g.a_ring8) u_ -= g.a_ring8; }
+#define G3_ADDR(kt_)                                                                                            \
+  {                                                                                                             \
+    int kc_ = (kt_); if (kc_ > nkt - 1) kc_ = nkt - 1;      /* the last trips re-request the final tile */     \
+    woff = w_row + (unsigned)kc_ * 192u + (unsigned)sunit * 16u;                                                \
+    int u0_ = kc_ * 4 + j0, u1_ = kc_ * 4 + j1, u2_ = kc_ * 4 + j2;                                              \
+    if (g.a_ring8) { u0_ += g.a_rot8; u1_ += g.a_rot8; u2_ += g.a_rot8; G3_WRAP(u0_) G3_WRAP(u1_) G3_WRAP(u2_) } \
+    aoff0 = a_row + (unsigned)(u0_ * 3 + c0 % 3) * 16u;                                                         \
+    aoff1 = a_row + (unsigned)(u1_ * 3 + c1 % 3) * 16u;                                                         \
+    aoff2 = a_row + (unsigned)(u2_ * 3 + c2 % 3) * 16u;                                                         \
   }
-#undef G3_COMPUTE
-#undef G3_STORE_TILE
-#undef G3_LOAD_TILE
-  const int col = n0 + wn * 32 + (lane & 31);
-  const float bias = g.bias ? g.bias[col] : 0.0f;
-  const bool do_act = col < g.act_cols;
-  const bool do_c3 = g.C3 != nullptr && col < g.c3_cols;
-#pragma unroll
-  for (int t = 0; t < 2; t++)
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int row = m0 + wm * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (row < g.M) {
-        float v = acc[t][r] + bias;
-        if (do_act) v = v > 0 ? v : expm1f(v);
-        if (g.C) g.C[(size_t)row * g.ldc + col] = v;
-        if (do_c3) {
-          uint16_t h, l, s;
-          split3(v, h, l, s);
-          uint16_t* o = g.C3 + (size_t)row * g.ldc3 + col;
-          o[0] = h; o[g.c_plane] = l; o[2 * g.c_plane] = s;
-        }
-      }
-    }
+#define G3_LDA(dst, ok_, q_, i_) dst = (ok_) ? *(const g3_gvec*)(Abase + (size_t)(i_) * a_row64 + aoff##q_) : z4;
+#define G3_LDW(dst, q_, i_) dst = *(const g3_gvec*)(Wbase + (size_t)(i_) * w_row64 + (q_) * 64 + woff);
+#define G3_ST(buf_, src_, q_, r_) *reinterpret_cast<g3_u32x4*>((buf_) + st_q##q_ + (r_) * G3_ROWB) = src_;
+#define G3_RDA(buf_, p_, t_, ks_) *reinterpret_cast<const g3_u32x4*>((buf_) + fa_ofs + ((p_) * G3_ROWS + (t_) * 32) * G3_ROWB + (ks_) * 32)
+#define G3_RDB(buf_, p_, u_, ks_) *reinterpret_cast<const g3_u32x4*>((buf_) + fb_ofs + ((p_) * G3_ROWS + (u_) * 32) * G3_ROWB + (ks_) * 32)
+#define G3_BF(x_) __builtin_bit_cast(bf16x8, x_)
+#include "kernels_gemm_b3_loop.inc"
+#undef G3_ADDR
+#undef G3_WRAP
+#undef G3_LDA
+#undef G3_LDW
+#undef G3_ST
+#undef G3_RDA
+#undef G3_RDB
+#undef G3_BF
+#define G3_EPI(acc_, t_, u_)                                                                                    \
+  {                                                                                                             \
+    const int col = n0 + wn * 96 + (u_) * 32 + (lane & 31);                                                     \
+    const float bias = g.bias ? g.bias[col] : 0.0f;                                                             \
+    const bool do_act = col < g.act_cols;                                                                       \
+    _Pragma("unroll") for (int r = 0; r < 16; r++) {                                                            \
+      const int row = m0 + wm * 64 + (t_) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);                      \
+      if (row < g.M) {                                                                                          \
+        float v = acc_[r] + bias;                                                                               \
+        if (do_act) v = v > 0 ? v : expm1f(v);                                                                  \
+        g.C[(size_t)row * g.ldc + col] = v;                                                                     \
+      }                                                                                                         \
+    }                                                                                                           \
+  }
+  G3_EPI(acc00, 0, 0) G3_EPI(acc01, 0, 1) G3_EPI(acc02, 0, 2) G3_EPI(acc10, 1, 0) G3_EPI(acc11, 1, 1) G3_EPI(acc12, 1, 2)
+#undef G3_EPI
 }

@@ -113,7 +113,9 @@ __global__ void k_pre_policy(const DevModel* m, DevState st, const float* __rest
   if (st.hist3) {      // the split-bf16 GEMM's operand copy: three bf16 planes (kernels_gemm.hpp)
     uint16_t h, l, sm;
     split3(v, h, l, sm);
-    st.hist3[hidx] = h; st.hist3[st.hist3_plane + hidx] = l; st.hist3[2 * st.hist3_plane + hidx] = sm;
+    uint16_t* row3 = st.hist3 + (size_t)i * (3 * MQE_HIST * MQE_FRAME);
+    const size_t k = (size_t)hist_slot * MQE_FRAME + c;
+    row3[b3_index(k, 0)] = h; row3[b3_index(k, 1)] = l; row3[b3_index(k, 2)] = sm;
   }
 }
 
@@ -612,9 +614,11 @@ __global__ void k_reset_history(const DevModel* m, DevState st) {
   if (i >= m->R) return;
   if (!st.reset_buf[i / m->A]) return;
   reinterpret_cast<float4*>(st.hist)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (st.hist3) {
+  if (st.hist3) {      // the same 4 elements in each of the three planes
+    const size_t k = (size_t)(idx - i * per) * 4;
+    uint16_t* row3 = st.hist3 + (size_t)i * (3 * MQE_HIST * MQE_FRAME);
 #pragma unroll
-    for (int p = 0; p < 3; p++) reinterpret_cast<uint2*>(st.hist3 + p * st.hist3_plane)[idx] = make_uint2(0u, 0u);
+    for (int p = 0; p < 3; p++) *reinterpret_cast<uint2*>(row3 + b3_index(k, p)) = make_uint2(0u, 0u);
   }
 }
 

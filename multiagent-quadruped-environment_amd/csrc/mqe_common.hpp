@@ -54,7 +54,7 @@ struct DevState {
   float *root, *dof, *cf, *torques, *actions, *last_actions, *loco_obs, *hist, *last_loco, *last_two_loco, *act_hist;
   float *gait, *clock, *blv, *bav, *pg, *bquat, *obs_bag, *wobs, *wrew, *rsum, *sheep_avg, *sheep_var, *sub_tau, *npc_noise;
   float *w_last, *w_last2, *cmd;
-  uint16_t* hist3; size_t hist3_plane;      // split-bf16 copy of the history ring (3 planes, same [R][30][72] layout)
+  uint16_t* hist3;                          // split-bf16 copy of the history ring: [R][270 units][3 planes][8] (k_gemm_b3)
   int32_t *ep_len, *reset_count;
   uint8_t *reset_buf, *collide_buf, *time_out, *r_term, *p_term, *zh_term, *w_have_last, *w_delayed_reset;
 };
@@ -74,4 +74,5 @@ __host__ __device__ __forceinline__ void split3(float x, uint16_t& h, uint16_t& 
   l = bf16_rne(r1);
   s = bf16_rne(r1 - bf16_f32(l));
 }
-
+// element offset of (row-local element k, plane p) in the plane-interleaved layout of k_gemm_b3
+__host__ __device__ __forceinline__ size_t b3_index(size_t k, int p) { return ((k >> 3) * 3 + p) * 8 + (k & 7); }

@@ -89,7 +89,7 @@ static inline int rup(int v, int m) { return (v + m - 1) / m * m; }
 
 // W (out,in) row-major host -> Wt [Kpad][Npad] device at column offset; rows remapped by `rowmap` (-1 = zero row)
 static int make_layer(mqe_sim* s, GemmLayer* L, int K, int N) {
-  L->K = K; L->N = N; L->Kpad = rup(K, GB_K); L->Npad = rup(N, GB_N); L->Kpad3 = rup(K, G3_K);
+  L->K = K; L->N = N; L->Kpad = rup(K, GB_K); L->Npad = rup(N, GB_N); L->Kpad3 = rup(K, 2 * G3_K);
   L->hW.assign((size_t)L->Npad * L->Kpad3, 0.0f);
   if (dalloc(s, &L->Wt, (size_t)L->Kpad * L->Npad)) return -1;
   if (dalloc(s, &L->bias, L->Npad)) return -1;
@@ -113,7 +113,11 @@ static int fill_layer(GemmLayer* L, int col0, const float* W, const float* b, in
 static int finalize_layer(mqe_sim* s, GemmLayer* L) {
   const size_t n = (size_t)L->Npad * L->Kpad3;
   std::vector<uint16_t> pl(3 * n);
-  for (size_t i = 0; i < n; i++) split3(L->hW[i], pl[i], pl[n + i], pl[2 * n + i]);
+  for (int r = 0; r < L->Npad; r++)
+    for (int k = 0; k < L->Kpad3; k++) {
+      uint16_t* row = pl.data() + (size_t)r * 3 * L->Kpad3;
+      split3(L->hW[(size_t)r * L->Kpad3 + k], row[b3_index(k, 0)], row[b3_index(k, 1)], row[b3_index(k, 2)]);
+    }
   if (dalloc(s, &L->W3, 3 * n, 0)) return -1;
   if (hipMemcpy(L->W3, pl.data(), 3 * n * 2, hipMemcpyHostToDevice) != hipSuccess) return -1;
   L->hW.clear(); L->hW.shrink_to_fit();
@@ -233,8 +237,14 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
     UP(t, w0.data(), w0.size()); s->w_lat0 = (float*)t;
     UP(t, w1.data(), w1.size()); s->w_lat1 = (float*)t;
   }
-  s->gemm_split = getenv("MQE_GEMM_B3") != nullptr && atoi(getenv("MQE_GEMM_B3")) != 0;
-  if (s->gemm_split && finalize_layer(s, &s->l0)) return fail(-5, "upload");
+  // Layer 0 runs on the bf16 matrix cores with three-plane split operands (f32-equivalent accuracy, k_gemm_b3) whenever
+  // its width tiles by 192; MQE_GEMM_B3=0 selects the exact-f32 MFMA kernel instead (0.255 ms vs 0.157 ms at 8192 rows).
+  s->gemm_split = !(getenv("MQE_GEMM_B3") != nullptr && atoi(getenv("MQE_GEMM_B3")) == 0) && s->l0.Npad % G3_N == 0;
+  if (s->gemm_split) {
+    if (finalize_layer(s, &s->l0)) return fail(-5, "upload");
+    if (hipFuncSetAttribute((const void*)k_gemm_b3, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES) != hipSuccess)
+      return fail(-4, "cannot raise dynamic LDS limit");
+  }
   for (int l = 1; l < ad.n_layers; l++) {
     GemmLayer g;
     if (make_layer(s, &g, ad.dims[l], ad.dims[l + 1]) || fill_layer(&g, 0, ad.W[l], ad.b[l], ad.dims[l + 1], ad.dims[l], ad.dims[l])) return fail(-5, "upload");
@@ -252,15 +262,13 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
 #define DA(p, n) if (dalloc(s, &(p), (n))) return fail(-5, "device alloc failed");
   DA(s->P1, (size_t)R * s->ldP1); DA(s->bufA, (size_t)R * s->ldbuf); DA(s->bufB, (size_t)R * s->ldbuf);
   DA(s->lat, (size_t)R * s->ldlat); DA(s->act_out, (size_t)R * s->ldact);
-  // MQE_GEMM_B3=1: layer 0 on the bf16 matrix cores with three-plane split operands (f32-equivalent accuracy, see
-  // k_gemm_b3).  Off by default: it measures 0.20 ms vs 0.255 ms exact-f32, not yet worth 3x the history footprint.
   // ---- state ---------------------------------------------------------------------------------------------------------
   DevState& st = s->st;
   DA(st.root, (size_t)N * (A + P) * 13); DA(st.dof, (size_t)N * s->ND * 2); DA(st.cf, (size_t)N * s->NBR * 3);
   DA(st.torques, (size_t)N * 12 * A); DA(st.actions, (size_t)N * 12 * A); DA(st.last_actions, (size_t)N * 12 * A);
   DA(st.loco_obs, (size_t)R * MQE_FRAME); DA(st.hist, (size_t)R * MQE_HIST * MQE_FRAME);
-  st.hist3 = nullptr; st.hist3_plane = (size_t)R * MQE_HIST * MQE_FRAME;
-  if (getenv("MQE_GEMM_B3") != nullptr && atoi(getenv("MQE_GEMM_B3")) != 0) { DA(st.hist3, (size_t)3 * R * MQE_HIST * MQE_FRAME); }
+  st.hist3 = nullptr;
+  if (s->gemm_split) { DA(st.hist3, (size_t)3 * R * MQE_HIST * MQE_FRAME); }
   DA(st.last_loco, (size_t)R * 12); DA(st.last_two_loco, (size_t)R * 12); DA(st.act_hist, (size_t)4 * R * 12);
   DA(st.gait, R); DA(st.clock, (size_t)R * 4); DA(st.blv, (size_t)R * 3); DA(st.bav, (size_t)R * 3); DA(st.pg, (size_t)R * 3);
   DA(st.bquat, (size_t)R * 4); DA(st.obs_bag, (size_t)R * MQE_OBS_BAG); DA(st.wobs, (size_t)N * s->Aw * s->D); DA(st.wrew, (size_t)N * s->Aw);
@@ -392,15 +400,14 @@ static void launch_gemm(hipStream_t q, const float* A, int lda, int rot4, int ri
   hipLaunchKernelGGL(k_gemm_f32, dim3(grid), dim3(256), 0, q, g);
 }
 
-static void launch_gemm3(hipStream_t q, const uint16_t* A, int lda, size_t a_plane, int rot8, int ring8, const GemmLayer& L,
-                         float* C, int ldc, uint16_t* C3, int ldc3, size_t c_plane, int c3_cols, int M, int act_cols) {
+static void launch_gemm3(hipStream_t q, const uint16_t* A, int lda, int rot8, int ring8, const GemmLayer& L,
+                         float* C, int ldc, int M, int act_cols) {
   Gemm3Args g;
-  g.A = A; g.lda = lda; g.a_plane = a_plane; g.a_rot8 = rot8; g.a_ring8 = ring8;
-  g.W = L.W3; g.ldw = L.Kpad3; g.w_plane = (size_t)L.Npad * L.Kpad3; g.bias = L.bias;
-  g.C = C; g.ldc = ldc; g.C3 = C3; g.ldc3 = ldc3; g.c_plane = c_plane; g.c3_cols = c3_cols;
-  g.M = M; g.N = L.Npad; g.K = L.Kpad3; g.act_cols = act_cols;
+  g.A = A; g.lda = lda; g.a_rot8 = rot8; g.a_ring8 = ring8;
+  g.W = L.W3; g.ldw = 3 * L.Kpad3; g.bias = L.bias;
+  g.C = C; g.ldc = ldc; g.M = M; g.N = L.Npad; g.K = L.Kpad3; g.act_cols = act_cols;
   int grid = ((M + G3_M - 1) / G3_M) * (L.Npad / G3_N);
-  hipLaunchKernelGGL(k_gemm_b3, dim3(grid), dim3(256), 0, q, g);
+  hipLaunchKernelGGL(k_gemm_b3, dim3(grid), dim3(256), G3_LDS_BYTES, q, g);
 }
 
 static int policy_step(mqe_sim* s, const float* command, hipStream_t q) {
@@ -415,8 +422,8 @@ static int policy_step(mqe_sim* s, const float* command, hipStream_t q) {
     ProfScope ps(s, PROF_GEMM_L0, q);
     // fused layer 0 of both networks over the ring: ELU on the adaptation columns only
     if (s->gemm_split)
-      launch_gemm3(q, s->st.hist3, MQE_HIST * MQE_FRAME, s->st.hist3_plane, s->hist_pos * (MQE_FRAME / 8), MQE_HIST * MQE_FRAME / 8, s->l0,
-                   s->P1, s->ldP1, nullptr, 0, 0, 0, R, s->ada_h0);
+      launch_gemm3(q, s->st.hist3, 3 * MQE_HIST * MQE_FRAME, s->hist_pos * (MQE_FRAME / 8), MQE_HIST * MQE_FRAME / 8, s->l0,
+                   s->P1, s->ldP1, R, s->ada_h0);
     else
       launch_gemm(q, s->st.hist, MQE_HIST * MQE_FRAME, s->hist_pos * (MQE_FRAME / 4), MQE_HIST * MQE_FRAME / 4, s->l0, s->P1, s->ldP1, R, s->ada_h0);
   }

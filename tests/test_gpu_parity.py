@@ -75,11 +75,13 @@ def test_single_substep_matches_oracle(task, N):
         close(eh.tensor(abi.T_CONTACT_FORCE), eo.tensor(abi.T_CONTACT_FORCE), atol=0.5, rtol=2e-2, what="net contact force")
 
 
-def test_split_bf16_layer0_is_f32_equivalent(monkeypatch):
-    """MQE_GEMM_B3=1 runs layer 0 of the locomotion policy on the bf16 matrix cores with three-plane split operands
-    (k_gemm_b3).  Its joint targets must agree with the CPU oracle's f32 fmaf chain as tightly as the exact-f32 MFMA
-    path does: |diff| <= 5e-5 on O(1) outputs after a history of 12 random steps (tolerance = f32 accumulation noise)."""
-    monkeypatch.setenv("MQE_GEMM_B3", "1")
+@pytest.mark.parametrize("b3", ["1", "0"])
+def test_policy_layer0_paths_are_f32_equivalent(monkeypatch, b3):
+    """Layer 0 of the locomotion policy runs on the bf16 matrix cores with three-plane split operands (k_gemm_b3,
+    default) or on the exact-f32 MFMA kernel (MQE_GEMM_B3=0).  Either way the joint targets must agree with the CPU
+    oracle's f32 fmaf chain to |diff| <= 5e-5 on O(1) outputs after a history of 12 random steps (tolerance = f32
+    accumulation-order noise; a plain bf16 or TF32 product would miss it by two orders of magnitude)."""
+    monkeypatch.setenv("MQE_GEMM_B3", b3)
     eh, eo, d = _pair("go1gate", 64)
     monkeypatch.delenv("MQE_GEMM_B3")
     eh.reset_all(); eo.reset_all()
