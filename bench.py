@@ -28,9 +28,12 @@ sys.path.insert(0, os.path.join(ROOT, "multiagent-quadruped-environment_amd"))
 
 import torch  # noqa: E402
 
-PROF_NAMES = ["gemm_layer0(k_gemm_f32)", "gemm_rest(k_gemm_f32+k_body_l0_finish+k_post_policy)", "torques(k_compute_torques)",
-              "simulate(k_simulate)", "post(k_post_physics+k_reset_history)", "misc(k_wrapper_command+k_pre_policy)"]
+PROF_NAMES = ["policy_layer0(k_gemm_b3 | k_gemm_f32)", "policy_tail(k_gemm_f32 x5 + k_body_l0_finish + k_post_policy)",
+              "torques(unfused path only)", "substeps(k_substeps: 4 x {actuator-net MFMA + physics substep})",
+              "post(k_post_physics + k_reset_history)", "misc(k_wrapper_command + k_pre_policy)"]
+PROF_KERNEL = ["k_gemm_b3", "k_gemm_f32", "k_compute_torques_mfma", "k_substeps", "k_post_physics", "k_pre_policy"]
 PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec peak
 
 
@@ -138,28 +141,41 @@ def main():
         dom = max(range(6), key=lambda i: kms[i])
         R = N * A
         roof = None
-        if dom in (0, 1):
-            d = eng.desc
-            h_a, h_b = d.adaptation.dims[1], d.body.dims[1]
-            flops = 2.0 * R * 2100 * (h_a + h_b)                      # algorithmic: unpadded K = 30 x 70
-            avg_ms = kms[0] / max(cnt[0], 1)
-            ach = flops / (avg_ms * 1e-3) / 1e12
-            roof = {"kernel": "k_gemm_f32 (fused layer 0 of adaptation+body MLP over the history ring)", "bound": "mfma",
-                    "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                    "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": int(cnt[0])}
+        split = os.environ.get("MQE_GEMM_B3", "1") != "0"
+        d = eng.desc
+        h_a, h_b = d.adaptation.dims[1], d.body.dims[1]
+        l0_ms = kms[0] / max(cnt[0], 1)
+        flops32 = 2.0 * R * 2100 * (h_a + h_b)                        # algorithmic: unpadded K = 30 x 70, f32 products
+        if split:   # every f32 product = six bf16 x bf16 terms on the matrix cores, K padded to 2176
+            l0 = {"kernel": "k_gemm_b3 (fused layer 0 of adaptation+body MLP over the history ring; 3-plane split-bf16 operands, f32-equivalent)",
+                  "bound": "mfma", "achieved": round(6 * 2.0 * R * 2176 * (h_a + h_b) / (l0_ms * 1e-3) / 1e12, 2), "peak": PEAK_BF16_MFMA_TFLOPS,
+                  "unit": "TFLOP/s", "f32_equivalent_TFLOPs": round(flops32 / (l0_ms * 1e-3) / 1e12, 2)}
+        else:
+            l0 = {"kernel": "k_gemm_f32 (fused layer 0, exact f32 MFMA)", "bound": "mfma", "achieved": round(flops32 / (l0_ms * 1e-3) / 1e12, 3),
+                  "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s"}
+        l0.update({"frac": round(l0["achieved"] / l0["peak"], 4), "traffic": None, "avg_launch_ms": round(l0_ms, 4), "launches": int(cnt[0])})
+        if dom == 0:
+            roof = l0
         else:
             avg_ms = kms[dom] / max(cnt[dom], 1)
             per_launch = max(1.0, cnt[dom] / args.steps)              # launches of this kernel class per env step
             byts = 10128.0 * R / per_launch                           # 10128 B per agent-step
             ach = byts / (avg_ms * 1e-3) / 1e9
             roof = {"kernel": PROF_NAMES[dom], "bound": "hbm", "achieved": round(ach, 3), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": round(ach / PEAK_HBM_GBS, 6), "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": int(cnt[dom])}
+                    "frac": round(ach / PEAK_HBM_GBS, 6), "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": int(cnt[dom]),
+                    "note": "not HBM-bound by construction: one env per wavefront, state LDS-resident for the 4 substeps; the limiter is "
+                            "dependent-instruction latency at 2 waves/SIMD (see profiles/*pmc_summary.json: issue / wait fractions)"}
         # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (separate runs; profiles/*pmc_summary.json)
         try:
             import glob
             pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.json")))[-1]))
             if N == 4096 and args.task == "go1gate":
-                roof["traffic"] = pmc["k_gemm_f32"]["layer0_hbm_bytes_est"] if dom in (0, 1) else pmc.get({3: "k_simulate", 2: "k_compute_torques_mfma", 4: "k_post_physics", 5: "k_pre_policy"}[dom], {}).get("hbm_bytes_raw")
+                kname = ("k_gemm_b3" if split else "k_gemm_f32") if dom == 0 else PROF_KERNEL[dom]
+                e = pmc.get(kname, {})
+                roof["traffic"] = (e.get("fetch_bytes_x2", 0) + e.get("write_bytes_raw", 0)) if dom == 0 else e.get("hbm_bytes_raw")
+                for k in ("frac_wave_time_issuing", "frac_wave_time_issue_stalled", "frac_wave_time_waiting_on_waitcnt_or_barrier"):
+                    if k in e:
+                        roof[k] = e[k]
                 roof["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch, see profiles/"
         except Exception:
             pass
@@ -174,6 +190,7 @@ def main():
             "target_env_steps_per_s": 1.0e6,
             "physical_robot_steps_per_s": round(value * env.env.num_agents / A, 1),
             "roofline": roof,
+            "roofline_policy_layer0": l0,
             "hbm_step_algorithmic_GBps": round(step_bytes * args.steps / elapsed / 1e9, 3),
             "kernel_time_share": {PROF_NAMES[i]: round(kms[i] / tot, 4) for i in range(6)},
             "gpu_busy_ms_per_step": round(tot / args.steps, 4),
