@@ -53,6 +53,9 @@ def cpu_baseline(task, sample_envs, sample_steps):
     from mqe.engine import abi
     d, keep, _ = make_desc(task, sample_envs)
     e = OracleEngine(d, keep)
+    # the oracle's OpenMP loops (over envs / robots) peak around 32 threads on the box's 256 hardware threads and
+    # collapse when oversubscribed, so the baseline is timed at its best setting, which is reported as `cores`
+    e.lib.mqo_set_num_threads(int(os.environ.get("MQE_CPU_THREADS", min(32, os.cpu_count() or 1))))
     e.reset_all()
     g = torch.Generator().manual_seed(1234)
     Aw = e.tensor(abi.T_WRAPPER_OBS).shape[1]
@@ -74,8 +77,8 @@ def main():
     ap.add_argument("--task", type=str, default="go1gate")
     ap.add_argument("--num_envs", type=int, default=4096, help="envs PER GPU (weak scaling)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
-    ap.add_argument("--cpu_sample_envs", type=int, default=128)
-    ap.add_argument("--cpu_sample_steps", type=int, default=20)
+    ap.add_argument("--cpu_sample_envs", type=int, default=512)
+    ap.add_argument("--cpu_sample_steps", type=int, default=100)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -170,6 +170,10 @@ __global__ void __launch_bounds__(256, 1) k_gemm_b3(Gemm3Args g) {
   const int frow = lane & 31, fk = (lane >> 5) * 16;           // fragment: row, byte offset of its 8 k inside a 16-k step
   const unsigned fa_ofs = (wm * 64 + frow) * G3_ROWB + fk, fb_ofs = (G3_M + wn * 96 + frow) * G3_ROWB + fk;
   const int nkt = g.K / G3_K;                                   // even (K is a multiple of 64)
+  // The 64 blocks that share a W tile would otherwise walk K in lockstep and pull the very same cache lines through one
+  // L2 channel at the same moment (measured: the load phase, not the MFMAs, set the pace).  Each M-tile starts its k loop
+  // at a different tile and wraps; a sum over k does not care about the starting point.
+  const int koff = (tm * 5) % nkt;
   unsigned char* buf0 = lds3;
   unsigned char* buf1 = lds3 + G3_BUF;
   const g3_u32x4 z4 = {0u, 0u, 0u, 0u};
@@ -183,6 +187,7 @@ __global__ void __launch_bounds__(256, 1) k_gemm_b3(Gemm3Args g) {
 #define G3_ADDR(kt_)                                                                                            \
   {                                                                                                             \
     int kc_ = (kt_); if (kc_ > nkt - 1) kc_ = nkt - 1;      /* the last trips re-request the final tile */     \
+    kc_ += koff; if (kc_ >= nkt) kc_ -= nkt;                /* per-block rotation of the k order, see koff */   \
     woff = w_row + (unsigned)kc_ * 192u + (unsigned)sunit * 16u;                                                \
     int u0_ = kc_ * 4 + j0, u1_ = kc_ * 4 + j1, u2_ = kc_ * 4 + j2;                                              \
     if (g.a_ring8) { u0_ += g.a_rot8; u1_ += g.a_rot8; u2_ += g.a_rot8; G3_WRAP(u0_) G3_WRAP(u1_) G3_WRAP(u2_) } \

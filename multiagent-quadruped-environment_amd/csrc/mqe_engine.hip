@@ -12,6 +12,7 @@
 
 #include "mqe_common.hpp"
 #include "kernels_step.hpp"
+#include "kernels_tail.hpp"
 #include "kernels_gemm.hpp"
 #include "kernels_physics.hpp"
 
@@ -54,6 +55,7 @@ struct mqe_sim {
   float *P1 = nullptr, *bufA = nullptr, *bufB = nullptr, *lat = nullptr, *act_out = nullptr;
   int ldP1, ldbuf, ldlat, ldact;
   bool gemm_split = false;
+  bool tail_fused = false;            // k_policy_tail: the reference network shapes (256-128-2 / 512-256-128-12 after layer 0)
   size_t phys_lds_bytes = 0;
   bool fuse_substeps = true;
   // profiling
@@ -255,6 +257,10 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
     if (make_layer(s, &g, bd.dims[l], bd.dims[l + 1]) || fill_layer(&g, 0, bd.W[l], bd.b[l], bd.dims[l + 1], bd.dims[l], bd.dims[l])) return fail(-5, "upload");
     s->body_rest.push_back(g);
   }
+  s->tail_fused = getenv("MQE_NO_FUSED_TAIL") == nullptr && ad.n_layers == 3 && bd.n_layers == 4 && ad.dims[1] == 256 && ad.dims[2] == 128 &&
+                  bd.dims[1] == 512 && bd.dims[2] == 256 && bd.dims[3] == 128;
+  if (s->tail_fused && hipFuncSetAttribute((const void*)k_policy_tail, hipFuncAttributeMaxDynamicSharedMemorySize, TL_LDS_BYTES) != hipSuccess)
+    return fail(-4, "cannot raise dynamic LDS limit");
   int maxw = 64;
   for (auto& g : s->ada_rest) maxw = std::max(maxw, g.Npad);
   for (auto& g : s->body_rest) maxw = std::max(maxw, g.Npad);
@@ -428,6 +434,21 @@ static int policy_step(mqe_sim* s, const float* command, hipStream_t q) {
       launch_gemm(q, s->st.hist, MQE_HIST * MQE_FRAME, s->hist_pos * (MQE_FRAME / 4), MQE_HIST * MQE_FRAME / 4, s->l0, s->P1, s->ldP1, R, s->ada_h0);
   }
   ProfScope ps(s, PROF_GEMM_REST, q);
+  if (s->tail_fused) {
+    TailArgs t;
+    t.P1 = s->P1; t.ldp = s->ldP1; t.ada_h0 = s->ada_h0;
+    t.Wa1 = s->ada_rest[0].Wt; t.ba1 = s->ada_rest[0].bias; t.ldwa1 = s->ada_rest[0].Npad;
+    t.Wa2 = s->ada_rest[1].Wt; t.ba2 = s->ada_rest[1].bias; t.ldwa2 = s->ada_rest[1].Npad;
+    t.wl0 = s->w_lat0; t.wl1 = s->w_lat1;
+    t.Wb1 = s->body_rest[0].Wt; t.bb1 = s->body_rest[0].bias; t.ldwb1 = s->body_rest[0].Npad;
+    t.Wb2 = s->body_rest[1].Wt; t.bb2 = s->body_rest[1].bias; t.ldwb2 = s->body_rest[1].Npad;
+    t.Wb3 = s->body_rest[2].Wt; t.bb3 = s->body_rest[2].bias; t.ldwb3 = s->body_rest[2].Npad;
+    t.lat = s->lat; t.ldl = s->ldlat; t.act = s->act_out; t.lda = s->ldact;
+    t.last_loco = s->st.last_loco; t.last_two_loco = s->st.last_two_loco; t.actions = s->st.actions; t.clip_actions = s->hm.clip_actions;
+    t.R = R;
+    hipLaunchKernelGGL(k_policy_tail, dim3((R + TL_ROWS - 1) / TL_ROWS), dim3(256), TL_LDS_BYTES, q, t);
+    return 0;
+  }
   // adaptation tail -> latent
   const float* x = s->P1; int ldx = s->ldP1;
   for (size_t l = 0; l < s->ada_rest.size(); l++) {

@@ -46,6 +46,7 @@ static char g_err[512];
 const char* mqo_last_error(void) { return g_err; }
 int mqo_sizeof_desc(void) { return (int)sizeof(mqe_sim_desc); }
 int mqo_num_threads(void);
+void mqo_set_num_threads(int n);
 
 typedef struct {
   int n_layers;
@@ -1439,6 +1440,8 @@ int mqo_step(mqo_sim* s, const float* actions) {
 #ifdef _OPENMP
 #include <omp.h>
 int mqo_num_threads(void) { return omp_get_max_threads(); }
+void mqo_set_num_threads(int n) { if (n > 0) omp_set_num_threads(n); }
 #else
 int mqo_num_threads(void) { return 1; }
+void mqo_set_num_threads(int n) { (void)n; }
 #endif
