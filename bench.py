@@ -184,7 +184,7 @@ def main():
             pass
         step_bytes = 10128.0 * R
         out = {
-            "metric": "env-steps/sec (agents x envs x steps/s), go1gate 4096 envs x 2 agents per GPU",
+            "metric": f"env-steps/sec (agents x envs x steps/s), {args.task} {N} envs x {A} agents per GPU",
             "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic (U(-1,1) actions seed 1234; synthetic body MLP: body_latest.jit missing upstream)",

@@ -96,7 +96,7 @@ __host__ __device__ inline PhysLds phys_lds_layout(int A, int P, int ND, int nbo
   L.tau = o; o += 12 * A;
   o = (o + 3) & ~3;
   L.minv = o; o += A * MQE_RD * MQE_RD;
-  L.rhs = o; o += (A * MQE_RD > 64 ? A * MQE_RD : 64);      // generalized bias, later v* / the solved velocity (64 lanes)
+  L.rhs = o; o += (ndof > 64 ? ndof : 64);                  // generalized bias, later v* / the solved velocity (one per dof)
   o = (o + 3) & ~3;
   L.con = o; o += maxc * CON_STRIDE;
   const int nslot = maxc + mqe_maxpair(maxc);
@@ -412,51 +412,26 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   __syncthreads();
 
   TSTAMP(6);
-  // ---- dof-lane constants + unconstrained velocity ------------------------------------------------------------------
-  const bool is_dof = lane < ndof;
-  const bool is_rdof = lane < A * MQE_RD;
-  int dact = -1, dk = 0;        // actor and local dof index
-  uint32_t dmask = 0;           // robot bodies moved by this dof
-  bool dlin = false;
-  V3 dax = v3(0, 0, 0), danc = v3(0, 0, 0);
-  float vd = 0.0f, dinvm = 0.0f;
-  if (is_rdof) {
-    dact = lane / MQE_RD; dk = lane - dact * MQE_RD;
-    if (dk < 6) {
-      dmask = 0x1FFFu; dlin = dk < 3;
-      const int ax = dk % 3;
-      dax = v3(ax == 0, ax == 1, ax == 2);
-      danc = ld3(lds + L.body + dact * MQE_NBODY * BODY_STRIDE + B_P);
-      vd = lds[L.root + dact * 13 + 7 + dk];
-    } else {
-      const int j = dk - 6, i3 = j % 3, b = 1 + j;
-      dmask = ((i3 == 0 ? 7u : (i3 == 1 ? 6u : 4u)) << (1 + (j / 3) * 3));
-      const float* rec = lds + L.body + (dact * MQE_NBODY + b) * BODY_STRIDE;
-      dax = ld3(rec + B_A); danc = ld3(rec + B_P);
-      vd = lds[L.dof + (dact * 12 + j) * 2 + 1];
+  // ---- unconstrained velocity v* = v + dt M^-1 (tau - h) per generalized velocity; a lane owns dofs lane and lane + 64
+  // (4 robots + ball = 78).  Kept in registers until the bias vector it overwrites has been consumed by every lane.
+  auto vstar = [&](int d) -> float {
+    if (d < A * MQE_RD) {
+      const int r = d / MQE_RD, k = d - r * MQE_RD;
+      float v = k < 6 ? lds[L.root + r * 13 + 7 + k] : lds[L.dof + (r * 12 + k - 6) * 2 + 1];
+      float acc = 0.0f;
+      const float* Mc = lds + L.minv + r * MQE_RD * MQE_RD + k;     // column k == row k (symmetric)
+      const float* rh = lds + L.rhs + r * MQE_RD;
+      for (int ee = 0; ee < MQE_RD; ee++) acc += Mc[ee * MQE_RD] * rh[ee];
+      return v + dt * acc;
     }
-    float acc = 0.0f;
-    const float* Mc = lds + L.minv + dact * MQE_RD * MQE_RD + dk;     // column dk == row dk (symmetric)
-    const float* rh = lds + L.rhs + dact * MQE_RD;
-    for (int ee = 0; ee < MQE_RD; ee++) acc += Mc[ee * MQE_RD] * rh[ee];
-    vd += dt * acc;
-  } else if (is_dof && m->has_seesaw) {     // the plank's hinge: one angular dof about +y through the hinge point
-    dact = A; dk = 0; dmask = 1u; dlin = false;
-    dax = v3(0, 1, 0);
-    danc = ld3(lds + L.root + A * 13) + v3(m->ss_joint_offset[0], m->ss_joint_offset[1], m->ss_joint_offset[2]);
-    vd = lds[L.dof + (12 * A) * 2 + 1];
-    dinvm = 1.0f / m->ss_inertia;
-  } else if (is_dof) {
-    const int q = lane - A * MQE_RD;
-    const int p = q / npcdof; dk = q - p * npcdof;
-    dact = A + p; dmask = 1u; dlin = dk < 3;
-    const int ax = dk % 3;
-    dax = v3(ax == 0, ax == 1, ax == 2);
-    danc = ld3(lds + L.root + (A + p) * 13);
-    vd = lds[L.root + (A + p) * 13 + 7 + dk];
-    dinvm = dk < 3 ? 1.0f / m->npc_mass : 1.0f / m->npc_inertia;
-    if (dk == 2) vd += dt * m->gravity_z;
-  }
+    if (m->has_seesaw) return lds[L.dof + (12 * A) * 2 + 1];       // the plank's hinge: COM on the axis, no drive
+    const int q = d - A * MQE_RD, p = q / npcdof, k = q - p * npcdof;
+    float v = lds[L.root + (A + p) * 13 + 7 + k];
+    if (k == 2) v += dt * m->gravity_z;
+    return v;
+  };
+  const float vs0 = lane < ndof ? vstar(lane) : 0.0f;
+  const float vs1 = lane + 64 < ndof ? vstar(lane + 64) : 0.0f;
 
   TSTAMP(7);
   // ---- collision spheres ----------------------------------------------------------------------------------------------
@@ -700,14 +675,9 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   // Per side the columns are [base lin xyz, base ang xyz, the <=3 joints of the chain to the touching link] (robot) or
   // [lin xyz, (ang xyz)] (ball / sheep).  Column value in the contact frame: dirs . (axis x (p - anchor)) = (r x dirs) . axis.
   const float mu = m->friction;
-  float jlo = 0, jhi = 0;
-  const bool is_joint = is_rdof && dk >= 6;
-  if (is_joint) {
-    const float q = lds[L.dof + (dact * 12 + dk - 6) * 2];
-    jlo = (rm.dof_lower[dk - 6] - q) / dt; jhi = (rm.dof_upper[dk - 6] - q) / dt;
-  }
   float* Vm = lds + L.rhs;           // v* (unconstrained velocity) over the consumed bias vector, read through the sparse Jacobian rows
-  Vm[lane] = vd;
+  if (lane < ndof) Vm[lane] = vs0;
+  if (lane + 64 < ndof) Vm[lane + 64] = vs1;
   __syncthreads();
   const bool is_con = lane < nc;
   float cu0 = 0, cu1 = 0, cu2 = 0, cl0 = 0, cl1 = 0, cl2 = 0, cbias = 0;
@@ -945,38 +915,52 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   TSTAMP(13);
   if (is_con) { float* cr = lds + L.con + lane * CON_STRIDE; cr[C_LAM] = cl0; cr[C_LAM + 1] = cl1; cr[C_LAM + 2] = cl2; }
   __syncthreads();
-  if (is_dof) {
-    const int dloc = is_rdof ? dk : dk;
+  for (int d = lane; d < ndof; d += 64) {           // impulses -> velocities, each lane its own entries of Vm
+    int dact, dloc;
+    if (d < A * MQE_RD) { dact = d / MQE_RD; dloc = d - dact * MQE_RD; }
+    else if (m->has_seesaw) { dact = A; dloc = 0; }
+    else { const int q = d - A * MQE_RD; dact = A + q / npcdof; dloc = q - (q / npcdof) * npcdof; }
+    float v = Vm[d];
     for (int c = 0; c < nc; c++) {
       const float* cr = lds + L.con + c * CON_STRIDE;
       const int a2 = __float_as_int(cr[C_IDS]), b2 = __float_as_int(cr[C_IDS + 2]);
       if (a2 != dact && b2 != dact) continue;
       const float* Bc = lds + L.B + (a2 == dact ? c : maxc + (c - nc_terr)) * 54;
-      vd += Bc[dloc] * cr[C_LAM] + Bc[18 + dloc] * cr[C_LAM + 1] + Bc[36 + dloc] * cr[C_LAM + 2];
+      v += Bc[dloc] * cr[C_LAM] + Bc[18 + dloc] * cr[C_LAM + 1] + Bc[36 + dloc] * cr[C_LAM + 2];
     }
+    Vm[d] = v;
   }
-  // joint limits: one sequential pass in (robot, joint) order after the contact solve, only when some lane violates
+  __syncthreads();
+  // joint limits: one sequential pass in (robot, joint) order after the contact solve, only when some joint violates
   {
-    bool viol = is_joint && (vd < jlo || vd > jhi);
+    bool viol = false;
+    for (int d = lane; d < A * 12; d += 64) {
+      const int r = d / 12, j = d - r * 12;
+      const float q = lds[L.dof + d * 2], v = Vm[r * MQE_RD + 6 + j];
+      viol = viol || v < (rm.dof_lower[j] - q) / dt || v > (rm.dof_upper[j] - q) / dt;
+    }
     if (__ballot(viol) != 0ull) {
       for (int r = 0; r < A; r++)
         for (int j = 0; j < 12; j++) {
-          const int src = r * MQE_RD + 6 + j;
-          const float vj = __shfl(vd, src, 64), lo = __shfl(jlo, src, 64), hi = __shfl(jhi, src, 64);
+          const float q = lds[L.dof + (r * 12 + j) * 2], vj = Vm[r * MQE_RD + 6 + j];
+          const float lo = (rm.dof_lower[j] - q) / dt, hi = (rm.dof_upper[j] - q) / dt;
           float vio = 0.0f;
           if (vj < lo) vio = lo - vj; else if (vj > hi) vio = hi - vj;
-          if (vio != 0.0f) {
-            const float mjj = lds[L.minv + r * MQE_RD * MQE_RD + (6 + j) * MQE_RD + 6 + j];
-            const float lam = vio / mjj;
-            if (is_rdof && dact == r) vd += lds[L.minv + r * MQE_RD * MQE_RD + (6 + j) * MQE_RD + dk] * lam;
+          if (vio != 0.0f) {                          // wave-uniform
+            const float* mrow = lds + L.minv + r * MQE_RD * MQE_RD + (6 + j) * MQE_RD;
+            const float lam = vio / mrow[6 + j];
+            __syncthreads();
+            if (lane < MQE_RD) Vm[r * MQE_RD + lane] += mrow[lane] * lam;
+            __syncthreads();
           }
         }
     }
   }
-
-  if (SS && lane == A * MQE_RD) {     // hinge: velocity limit, then the geometric end stops
-    vd = clampf(vd, -m->ss_vel_limit, m->ss_vel_limit);
-    vd = clampf(vd, (m->ss_theta_lo - ssTheta) / dt, (m->ss_theta_hi - ssTheta) / dt);
+  if (SS && lane == 0) {              // hinge: velocity limit, then the geometric end stops
+    float v = Vm[A * MQE_RD];
+    v = clampf(v, -m->ss_vel_limit, m->ss_vel_limit);
+    v = clampf(v, (m->ss_theta_lo - ssTheta) / dt, (m->ss_theta_hi - ssTheta) / dt);
+    Vm[A * MQE_RD] = v;
   }
   TSTAMP(14);
   if (dbg.minv != nullptr) {
@@ -1011,17 +995,17 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   }
   // ---- integrate: semi-implicit Euler; quaternion first-order update + renormalisation -----------------------------------------
   __syncthreads();
-  lds[L.rhs + lane] = vd;
-  __syncthreads();
-  if (is_rdof && dk >= 6) {
-    const int j = dk - 6;
-    float* ds = lds + L.dof + (dact * 12 + j) * 2;
-    ds[0] = ds[0] + dt * vd;
-    ds[1] = vd;
+  for (int d = lane; d < A * 12; d += 64) {
+    const int r = d / 12, j = d - r * 12;
+    const float v = Vm[r * MQE_RD + 6 + j];
+    float* ds = lds + L.dof + d * 2;
+    ds[0] = ds[0] + dt * v;
+    ds[1] = v;
   }
-  if (SS && lane == A * MQE_RD) {
-    lds[L.dof + (12 * A) * 2] = ssTheta + dt * vd;
-    lds[L.dof + (12 * A) * 2 + 1] = vd;
+  if (SS && lane == 0) {
+    const float v = Vm[A * MQE_RD];
+    lds[L.dof + (12 * A) * 2] = ssTheta + dt * v;
+    lds[L.dof + (12 * A) * 2 + 1] = v;
   }
   if (lane < A + PD) {
     const int act = lane;

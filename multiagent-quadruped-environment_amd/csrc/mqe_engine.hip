@@ -196,7 +196,7 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   m.nsph_env = A * d->robot.n_spheres + m.n_npc_dyn * d->npc_n_spheres;
   m.maxc = mqe_maxc(A, P);
   m.ldsB_stride = m.ndof_env;
-  if (m.ndof_env > 64 || m.nbody_env > 64) { delete s; return fail(-4, "env has more than 64 bodies or generalized velocities: does not fit one wavefront"); }
+  if (m.ndof_env > 128 || m.nbody_env > 64) { delete s; return fail(-4, "env has more than 64 bodies or 128 generalized velocities: does not fit one wavefront"); }
   PhysLds L = phys_lds_layout(A, P, s->ND, m.nbody_env, m.ndof_env, m.nsph_env, m.maxc, m.ldsB_stride);
   s->phys_lds_bytes = (size_t)L.total * 4;
   if (s->phys_lds_bytes > 160 * 1024) { delete s; return fail(-4, "physics LDS footprint exceeds 160 KiB"); }

@@ -126,3 +126,31 @@ def test_openrl_adapter_on_real_env(oracle_backed):
 def test_unregistered_tasks_fail_loudly():
     with pytest.raises(NotImplementedError):
         make_mqe_env("go1pushbox", args_for("go1pushbox", 1))
+
+
+@pytest.mark.parametrize("task,key,A", [("go1football-1vs1", "football_game_1v1", 2), ("go1football-2vs2", "football_game_2v2", 4)])
+def test_football_game_tasks_mirror_the_upstream_stub(oracle_backed, task, key, A):
+    """go1football-1vs1 / -2vs2 (reference utils.py:64-73): Go1Object + free ball; the upstream wrapper returns None
+    observations and a zero (N, 4) reward (go1_football_wrapper.py:136,156) but clips and scales the actions it hands to
+    Go1.step (:139-140) -- checked against vectors recorded from the reference wrapper."""
+    z = golden("wrapper_" + key)
+    N = z["actions"].shape[1]
+    a = args_for(task, N)
+    env, cfg = make_mqe_env(task, a, custom_cfg(a))
+    assert env.env.num_agents == A and env.env.num_npcs == 1 and env.observation_space.shape == (int(z["obs_dim"]),)
+    assert env.max_episode_length == np.ceil(cfg.env.episode_length_s / 0.02)
+    assert env.reset() is None
+    ball0 = env.root_states_npc.clone()
+    for t in range(z["actions"].shape[0]):
+        obs, rew, done, info = env.step(torch.from_numpy(z["actions"][t]))
+        assert obs is None and rew.shape == tuple(z["reward"][t].shape) and (rew == 0).all() and done.shape == (N,)
+        # the command the locomotion policy saw = clip(action) * [2, .5, .5] (columns 3:6 of the locomotion obs carry it
+        # times the command scales); compare with the action the reference wrapper passed down
+        cmd = torch.from_numpy(z["env_action"][t]).reshape(N * A, 3)
+        lo = env.env.engine.tensor(__import__("mqe.engine.abi", fromlist=["abi"]).T_LOCOMOTION_OBS)[:, 3:6]
+        d = env.env.engine.desc
+        want = cmd.clip(-1, 1) * torch.tensor([d.cmd_lin_scale, d.cmd_lin_scale, d.cmd_ang_scale])
+        assert torch.allclose(lo, want, atol=1e-6)
+    assert env.reward_buffer["step count"] == int(z["step_count"])
+    assert torch.isfinite(env.root_states_npc).all() and not torch.equal(env.root_states_npc, ball0)   # the ball is simulated
+    env.close()

@@ -659,6 +659,38 @@ def gen_wrappers():
 # --------------------------------------------------------------------------------------------
 # 10/11. BarrierTrack terrain + config dump
 # --------------------------------------------------------------------------------------------
+def gen_game_wrapper():
+    """Go1FootballGameWrapper (go1_football_wrapper.py:93-156) is a stub upstream: None observations, zero reward (N, 4);
+    what it does define is the action clip + scale handed to Go1.step."""
+    from mqe.envs.configs.go1_football_config import Go1Football1vs1Cfg, Go1Football2vs2Cfg
+    from mqe.envs.wrappers.go1_football_wrapper import Go1FootballGameWrapper
+    rng = np.random.RandomState(23)
+    T, N = 4, 3
+    for name, cfg in (("football_game_1v1", Go1Football1vs1Cfg), ("football_game_2v2", Go1Football2vs2Cfg)):
+        A, P = cfg.env.num_agents, cfg.env.num_npcs
+        fe = FakeEnvForWrapper(cfg, N, A, P)
+        fe.env_origins = torch.zeros(N, 3)
+        script = []
+        for t in range(T + 1):
+            ob = types.SimpleNamespace()
+            ob.base_pos = torch.tensor(rng.uniform(-1, 9, (N * A, 3)).astype(np.float32))
+            ob.base_rpy = torch.tensor(rng.uniform(0, 6.28, (N * A, 3)).astype(np.float32))
+            script.append(dict(obs_buf=ob, root_states_npc=torch.tensor(rng.uniform(-1, 12, (N * P, 13)).astype(np.float32)),
+                               reset_buf=torch.tensor(rng.rand(N) < 0.3)))
+        fe.script = script
+        w = Go1FootballGameWrapper(fe)
+        obs0 = w.reset()
+        assert obs0 is None
+        acts = rng.uniform(-1.5, 1.5, (T, N, A, 3)).astype(np.float32)
+        rew_l, act_l, term_l = [], [], []
+        for t in range(T):
+            o, r, term, info = w.step(torch.from_numpy(acts[t]))
+            assert o is None
+            rew_l.append(r.clone()); act_l.append(fe.last_action_in); term_l.append(term.clone())
+        save("wrapper_" + name, reward=torch.stack(rew_l), env_action=torch.stack(act_l), actions=acts, termination=torch.stack(term_l),
+             obs_dim=np.int64(w.observation_space.shape[0]), step_count=np.int64(w.reward_buffer["step count"]))
+
+
 def rle_rows(hf):
     """two-level heightfield -> per-row run-length list (value, start, stop)"""
     runs = []
@@ -675,7 +707,7 @@ def rle_rows(hf):
 
 def gen_terrain_and_configs():
     cfgd = {}
-    for task in ("go1gate", "go1sheep-easy", "go1sheep-hard", "go1seesaw", "go1football-defender"):
+    for task in ("go1gate", "go1sheep-easy", "go1sheep-hard", "go1seesaw", "go1football-defender", "go1football-1vs1", "go1football-2vs2"):
         cfg = ref_utils.ENV_DICT[task]["config"]
         t = barrier_track_for(cfg, 8)
         hf = t.heightfield_raw
@@ -750,8 +782,14 @@ def main():
         gen_fullstep("fullstep_seesaw", Go1Object, Go1SeesawCfg, N=3, T=12, act=act, ada=ada)
         gen_fullstep("fullstep_football", Go1FootballDefender, Go1FootballDefenderCfg, N=3, T=12, act=act, ada=ada)
         gen_fullstep("fullstep_sheep", Go1Sheep, NineSheepCfg, N=3, T=12, act=act, ada=ada)
+    if want("fullstep_game"):     # the two free-play football tasks (Go1Object + ball, 2 and 4 robots)
+        from mqe.envs.configs.go1_football_config import Go1Football1vs1Cfg, Go1Football2vs2Cfg
+        gen_fullstep("fullstep_football1v1", Go1Object, Go1Football1vs1Cfg, N=3, T=12, act=act, ada=ada)
+        gen_fullstep("fullstep_football2v2", Go1Object, Go1Football2vs2Cfg, N=2, T=10, act=act, ada=ada)
     if want("wrappers"):
         gen_wrappers()
+    if want("wrapper_game"):
+        gen_game_wrapper()
     if want("terrain"):
         gen_terrain_and_configs()
     if want("adapter"):
