@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MQE_ABI_VERSION 1
+#define MQE_ABI_VERSION 2
 #define MQE_MAX_SPHERES 32
 #define MQE_NBODY 13      /* dynamic bodies of one Go1 after fixed-joint collapsing */
 #define MQE_NREP 17       /* reported rigid bodies of one Go1 (feet kept, go1.urdf dont_collapse) */
@@ -38,9 +38,9 @@ extern "C" {
 #define MQE_MAX_REWARD_TERMS 12
 
 /* tasks whose wrapper observation / reward are evaluated in-kernel (reference mqe/envs/wrappers) */
-enum { MQE_TASK_PLAIN = 0, MQE_TASK_GATE = 1, MQE_TASK_SHEEP = 2, MQE_TASK_SEESAW = 3, MQE_TASK_FOOTBALL_DEFENDER = 4 };
+enum { MQE_TASK_PLAIN = 0, MQE_TASK_GATE = 1, MQE_TASK_SHEEP = 2, MQE_TASK_SEESAW = 3, MQE_TASK_FOOTBALL_DEFENDER = 4, MQE_TASK_PUSHBOX = 5 };
 /* NPC kinds (reference resources/objects/{ball,sheep,seesaw}.urdf) */
-enum { MQE_NPC_NONE = 0, MQE_NPC_BALL = 1, MQE_NPC_SHEEP = 2, MQE_NPC_SEESAW = 3 };
+enum { MQE_NPC_NONE = 0, MQE_NPC_BALL = 1, MQE_NPC_SHEEP = 2, MQE_NPC_SEESAW = 3, MQE_NPC_BOX = 4 };
 /* control types (reference legged_robot.py:368-392 "P","V","T"; go1.py:315-354 "C") */
 enum { MQE_CTRL_C = 0, MQE_CTRL_P = 1, MQE_CTRL_V = 2, MQE_CTRL_T = 3 };
 /* termination terms (reference legged_robot_field.py:121-146) */
@@ -88,8 +88,10 @@ typedef struct {
   /* NPC free bodies (ball / sheep): mass, isotropic inertia, spheres in the body frame */
   float npc_mass, npc_inertia;
   int32_t npc_n_spheres;
-  float npc_sphere_center[2][3];
-  float npc_sphere_radius[2];
+  float npc_sphere_center[8][3];   /* vs terrain; a box (MQE_NPC_BOX) carries its 8 corners here */
+  float npc_sphere_radius[8];
+  float npc_box_half[3];           /* MQE_NPC_BOX: half extents of the oriented box the robots' spheres collide with */
+  int32_t npc_contact_cap;         /* one-sided (terrain) contacts kept per NPC: 2, a box resting on its face needs 4 */
   /* seesaw (fixed base + revolute plank), reference resources/objects/seesaw.urdf */
   float seesaw_joint_offset[3], seesaw_plank_center[3], seesaw_plank_half[3], seesaw_base_half[3];
   float seesaw_plank_mass, seesaw_plank_inertia_yy, seesaw_vel_limit, seesaw_default_angle;

@@ -75,9 +75,9 @@ __device__ __forceinline__ float wave_sum(float x) {
 enum { B_R = 0, B_P = 9, B_W = 12, B_VP = 15, B_A = 18, B_AL = 21, B_AP = 24, B_C = 27, B_M = 30 };
 enum { C_IDS = 0, C_P = 4, C_N = 7, C_T1 = 10, C_T2 = 13, C_SD = 16, C_BIAS = 17, C_K = 18, C_LAM = 24, C_REP = 27 };
 
-__host__ __device__ inline int mqe_maxc(int A, int P) { int v = 8 * A + 2 * P; return v > 40 ? 40 : v; }
+__host__ __device__ inline int mqe_maxc(int A, int P, int cap_npc) { int v = 8 * A + cap_npc * P; return v > 40 ? 40 : v; }
 #define CAP_ROBOT 8     // terrain / static-object contacts kept per robot (spheres are priority ordered: feet first)
-#define CAP_NPC 2       // per ball / sheep; per-actor caps so that no actor starves the ones after it in the list
+// NPCs keep m->cap_npc one-sided contacts each (2; a box resting on a face 4): per-actor caps so that no actor starves the ones after it
 
 struct PhysLds {   // float offsets into dynamic LDS
   int root, dof, tau, body, minv, rhs, fcol, leg, basei, sinv, tt, sph, con, B, js, kk, total;
@@ -480,7 +480,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     int act = -1, sidx = 0, s = nsph, sub = 0;
     unsigned long long gm = ~0ull;                         // lanes of my group (= my actor)
     const bool rob = pass < n_rpass;
-    const int cap = rob ? CAP_ROBOT : CAP_NPC;
+    const int cap = rob ? CAP_ROBOT : m->cap_npc;
     const unsigned long long m0 = (nsr < 64) ? ((1ull << nsr) - 1ull) : ~0ull;
     if (rob) {
       sub = (rpp == 2 && lane >= nsr) ? 1 : 0;
@@ -633,6 +633,30 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
         const V3 pa = ld3(lds + L.body + (a < A ? a * MQE_NBODY : A * MQE_NBODY + (a - A)) * BODY_STRIDE + B_P);
         const V3 pb = ld3(lds + L.body + (b < A ? b * MQE_NBODY : A * MQE_NBODY + (b - A)) * BODY_STRIDE + B_P);
         const V3 dd = pa - pb;
+        if (m->has_box && b >= A) {                           // robot spheres vs the oriented box (NPC body record = its pose)
+          if (a >= A || dot(dd, dd) > 1.8f * 1.8f) continue;
+          const float* brec = lds + L.body + (A * MQE_NBODY + (b - A)) * BODY_STRIDE;
+          bool hit = false; float sd = 0; V3 n = v3(0, 0, 1), c = v3(0, 0, 0); float ra = 0;
+          if (lane < nsr) {
+            const float* spa = lds + L.sph + (a * nsr + lane) * 4;
+            c = ld3(spa); ra = spa[3];
+            sd = sphere_box(c, ra, pb, brec + B_R, v3(m->npc_box_half[0], m->npc_box_half[1], m->npc_box_half[2]), n);
+            hit = sd < m->contact_offset;
+          }
+          const unsigned long long bh = __ballot(hit);
+          const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+          const int slot = nc + __popcll(bh & lower);
+          if (hit && slot < pair_lim) {
+            float* cr = lds + L.con + slot * CON_STRIDE;
+            cr[C_IDS] = __int_as_float(a); cr[C_IDS + 1] = __int_as_float(rm.sphere_body[lane]); cr[C_IDS + 2] = __int_as_float(b); cr[C_IDS + 3] = __int_as_float(0);
+            const V3 p = c - (ra + 0.5f * sd) * n;
+            cr[C_P] = p.x; cr[C_P + 1] = p.y; cr[C_P + 2] = p.z; cr[C_N] = n.x; cr[C_N + 1] = n.y; cr[C_N + 2] = n.z; cr[C_SD] = sd;
+            cr[C_REP] = __int_as_float(a * MQE_NREP + rm.sphere_reported[lane]); cr[C_REP + 1] = __int_as_float(A * MQE_NREP + (b - A));
+          }
+          nc += __popcll(bh);
+          if (nc > pair_lim) nc = pair_lim;
+          continue;
+        }
         if (dot(dd, dd) > 1.2f * 1.2f) continue;              // wave-uniform broad phase
         const int na = a < A ? nsr : m->npc_n_spheres, nb = b < A ? nsr : m->npc_n_spheres;
         const int oa = a < A ? a * nsr : A * nsr + (a - A) * m->npc_n_spheres;

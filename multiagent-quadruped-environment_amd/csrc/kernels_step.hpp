@@ -403,7 +403,11 @@ __device__ void wrapper_env_dev(const DevModel* m, const DevState& st, int e, in
       const float* ob2 = st.obs_bag + (size_t)(e * A + (Aw - 1 - a)) * MQE_OBS_BAG;
       for (int k = 0; k < 6; k++) o[c++] = ob2[k];
     }
-    if (m->task == MQE_TASK_GATE || m->task == MQE_TASK_SHEEP) { o[c++] = m->gate_pos[e * 2]; o[c++] = m->gate_pos[e * 2 + 1]; }
+    if (m->task == MQE_TASK_GATE || m->task == MQE_TASK_SHEEP || m->task == MQE_TASK_PUSHBOX) { o[c++] = m->gate_pos[e * 2]; o[c++] = m->gate_pos[e * 2 + 1]; }
+    if (m->task == MQE_TASK_PUSHBOX) {              // go1_pushbox_wrapper.py:44-48: box xy rel. env origin, box quaternion
+      o[c++] = npc[0] - m->env_origins[e * 3]; o[c++] = npc[1] - m->env_origins[e * 3 + 1];
+      for (int k = 0; k < 4; k++) o[c++] = npc[3 + k];
+    }
     if (m->task == MQE_TASK_SHEEP)
       for (int p = 0; p < P; p++) { o[c++] = npc[p * 13] - m->env_origins[e * 3]; o[c++] = npc[p * 13 + 1] - m->env_origins[e * 3 + 1]; }
     if (m->task == MQE_TASK_FOOTBALL_DEFENDER) {
@@ -508,6 +512,19 @@ __device__ void wrapper_env_dev(const DevModel* m, const DevState& st, int e, in
       float v = sc[5] * (float)cnt; r_env += v; rs[5] += v;
     }
     if (sc[6] != 0) { if (st.r_term[e] | st.p_term[e]) { r_env += sc[6]; rs[6] += sc[6]; } }
+    for (int a = 0; a < Aw; a++) rew[a] = r_env;
+    return;
+  }
+  if (m->task == MQE_TASK_PUSHBOX) {                // go1_pushbox_wrapper.py:52-88
+    const float bx = npc[0] - m->env_origins[e * 3];
+    if (sc[0] != 0 && st.w_have_last[e]) {
+      float xm = bx - st.w_last2[e * 2];
+      if (was_reset) xm = 0;                        // x_movement[reset_ids] = 0
+      const float v = sc[0] * xm;
+      r_env += v; rs[0] += v;
+    }
+    st.w_last2[e * 2] = bx;
+    st.w_have_last[e] = 1;
     for (int a = 0; a < Aw; a++) rew[a] = r_env;
     return;
   }

@@ -29,7 +29,8 @@ struct DevModel {
   float dt; int decimation; float gravity_z; int solver_iterations;
   float contact_offset, max_depen, friction, erp;
   mqe_robot_model robot;
-  float npc_mass, npc_inertia; int npc_n_spheres; float npc_sphere_center[2][3]; float npc_sphere_radius[2];
+  float npc_mass, npc_inertia; int npc_n_spheres; float npc_sphere_center[8][3]; float npc_sphere_radius[8];
+  int has_box, cap_npc; float npc_box_half[3];     // MQE_NPC_BOX: robots' spheres vs the oriented box; terrain contacts kept per NPC
   float seesaw_default_angle;
   int has_seesaw; float ss_joint_offset[3], ss_plank_center[3], ss_plank_half[3], ss_base_half[3];
   float ss_inertia, ss_vel_limit, ss_col_radius, ss_col_length, ss_theta_lo, ss_theta_hi;

@@ -133,6 +133,7 @@ static int wrapper_dims(const mqe_sim_desc* d, int* Aw, int* D) {
     case MQE_TASK_SHEEP: *Aw = A; *D = 14 + 2 * P + A; break;
     case MQE_TASK_SEESAW: *Aw = A; *D = 12 + A; break;
     case MQE_TASK_FOOTBALL_DEFENDER: *Aw = 2; *D = 20; break;
+    case MQE_TASK_PUSHBOX: *Aw = A; *D = 20 + A; break;
     default: *Aw = A; *D = 6 + A; break;
   }
   return 0;
@@ -159,7 +160,9 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   memset(&m, 0, sizeof m);
   m.N = N; m.A = A; m.P = P; m.R = R; m.ND = s->ND; m.NBR = s->NBR; m.Aw = s->Aw; m.D = s->D;
   m.npc_kind = d->npc_kind; m.task = d->task;
-  m.n_npc_dyn = (d->npc_kind == MQE_NPC_BALL || d->npc_kind == MQE_NPC_SHEEP) ? P : 0;
+  m.n_npc_dyn = (d->npc_kind == MQE_NPC_BALL || d->npc_kind == MQE_NPC_SHEEP || d->npc_kind == MQE_NPC_BOX) ? P : 0;
+  m.has_box = d->npc_kind == MQE_NPC_BOX; m.cap_npc = d->npc_contact_cap > 0 ? d->npc_contact_cap : 2;
+  memcpy(m.npc_box_half, d->npc_box_half, sizeof m.npc_box_half);
   m.npc_lin_only = d->npc_kind == MQE_NPC_SHEEP;
   m.npc_dofs_each = seesaw ? 1 : (m.npc_lin_only ? 3 : 6);
   m.env_id_offset = d->env_id_offset; m.seed = d->seed;
@@ -194,7 +197,7 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   m.nbody_env = A * MQE_NBODY + m.n_npc_dyn;
   m.ndof_env = A * MQE_RD + m.n_npc_dyn * m.npc_dofs_each + (seesaw ? 1 : 0);
   m.nsph_env = A * d->robot.n_spheres + m.n_npc_dyn * d->npc_n_spheres;
-  m.maxc = mqe_maxc(A, P);
+  m.maxc = mqe_maxc(A, P, m.cap_npc);
   m.ldsB_stride = m.ndof_env;
   if (m.ndof_env > 128 || m.nbody_env > 64) { delete s; return fail(-4, "env has more than 64 bodies or 128 generalized velocities: does not fit one wavefront"); }
   PhysLds L = phys_lds_layout(A, P, s->ND, m.nbody_env, m.ndof_env, m.nsph_env, m.maxc, m.ldsB_stride);

@@ -1,13 +1,13 @@
 """ctypes mirror of include/mqe_hip.h (keep in sync; tests/test_abi.py checks sizes against the built library)."""
 import ctypes as C
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_SPHERES, NBODY, NREP, NDOF = 32, 13, 17, 12
 MAX_AGENTS, MAX_NPCS, FRAME, HIST, MAX_LAYERS, MAX_REWARD_TERMS = 4, 9, 72, 30, 6, 12
 OBS_BAG = 74
 
-TASK = dict(plain=0, gate=1, sheep=2, seesaw=3, football_defender=4)
-NPC = dict(none=0, ball=1, sheep=2, seesaw=3)
+TASK = dict(plain=0, gate=1, sheep=2, seesaw=3, football_defender=4, pushbox=5)
+NPC = dict(none=0, ball=1, sheep=2, seesaw=3, box=4)
 CTRL = dict(C=0, P=1, V=2, T=3)
 TERM = dict(roll=1, pitch=2, z_low=4, z_high=8)
 
@@ -49,7 +49,7 @@ class SimDesc(C.Structure):
         ("contact_offset", f32), ("max_depenetration_velocity", f32), ("friction", f32), ("erp", f32),
         ("robot", RobotModel),
         ("npc_mass", f32), ("npc_inertia", f32), ("npc_n_spheres", i32),
-        ("npc_sphere_center", (f32 * 3) * 2), ("npc_sphere_radius", f32 * 2),
+        ("npc_sphere_center", (f32 * 3) * 8), ("npc_sphere_radius", f32 * 8), ("npc_box_half", f32 * 3), ("npc_contact_cap", i32),
         ("seesaw_joint_offset", f32 * 3), ("seesaw_plank_center", f32 * 3), ("seesaw_plank_half", f32 * 3),
         ("seesaw_base_half", f32 * 3),
         ("seesaw_plank_mass", f32), ("seesaw_plank_inertia_yy", f32), ("seesaw_vel_limit", f32), ("seesaw_default_angle", f32),

@@ -20,6 +20,8 @@ REWARD_TERMS = {
                ("agent_distance_punishment_scale", "agent distance punishment"), ("success_reward_scale", "success reward"),
                ("fall_punishment_scale", "fall punishment")],
     "football_defender": [("goal_reward_scale", "goal reward"), ("ball_gate_distance_reward_scale", "ball gate distance reward")],
+    # the wrapper overwrites the configured scale with 1 after reading it (go1_pushbox_wrapper.py:20), see build_desc
+    "pushbox": [("box_x_movement_reward_scale", "box movement reward")],
     "plain": [],
 }
 
@@ -86,6 +88,8 @@ def task_kind(cfg):
         return "sheep"
     if name == "go1seesaw":
         return "seesaw"
+    if name == "go1pushbox":
+        return "pushbox"
     if name == "go1football" and cfg.env.num_agents == 3 and npc == "ball":
         return "football_defender"
     return "plain"
@@ -147,6 +151,23 @@ def build_desc(cfg, num_envs, terrain, env_origins, agent_origins, gate_pos=None
                 d.npc_sphere_radius[i] = rad
                 d.npc_sphere_center[i][0], d.npc_sphere_center[i][1] = t[0], t[1]
                 d.npc_sphere_center[i][2] = t[2] + sgn * max(0.0, length / 2 - rad)
+    d.npc_contact_cap = 2
+    if d.npc_kind == abi.NPC["box"]:
+        # free box (box.urdf: 1 x 1 x 1 m, 6 kg): the robots' spheres collide with the oriented box itself; against the
+        # terrain it is represented by its 8 corners (spheres of radius 2 cm inset by their radius)
+        om = urdf_model.load_model("box", resources_root)["bodies"][0]
+        d.npc_mass, d.npc_inertia = om["mass"], om["inertia"][0][0]
+        kind, half, _, t = om["shapes"][0]
+        assert kind == "box"
+        rc = 0.02
+        d.npc_n_spheres = 8
+        for i in range(8):
+            d.npc_sphere_radius[i] = rc
+            for k in range(3):
+                d.npc_sphere_center[i][k] = t[k] + (1.0 if (i >> k) & 1 else -1.0) * (half[k] - rc)
+        for k in range(3):
+            d.npc_box_half[k] = half[k]
+        d.npc_contact_cap = 4
     if d.npc_kind == abi.NPC["seesaw"]:
         bodies = urdf_model.load_model("seesaw", resources_root)["bodies"]
         base, plank = bodies[0], bodies[1]
@@ -237,6 +258,8 @@ def build_desc(cfg, num_envs, terrain, env_origins, agent_origins, gate_pos=None
     for i, (attr, _) in enumerate(REWARD_TERMS[task]):
         d.reward_scale[i] = float(getattr(cfg.rewards.scales, attr, 0.0))
     kw = cfg.terrain.BarrierTrack_kwargs
+    if task == "pushbox":
+        d.reward_scale[0] = 1.0       # hard-set in the wrapper's constructor after the cfg value was copied (:20)
     if task == "gate":
         d.wrapper_param[0] = kw["init"]["block_length"] + kw["gate"]["block_length"] + kw["plane"]["block_length"] / 2
         d.wrapper_param[1] = kw["track_width"] / 4

@@ -36,9 +36,8 @@ typedef REAL real;
 #define RD 18                       /* dofs of one robot: 3 lin + 3 ang + 12 joints */
 #define MAXDOF (MAXA * RD + MAXP * 6 + 1)
 #define MAXC 64                     /* storage; the active bound is env_maxc() */
-static inline int env_maxc(int A, int P) { int v = 8 * A + 2 * P; return v > 40 ? 40 : v; } /* = mqe_maxc() of the engine */
+static inline int env_maxc(int A, int P, int cap_npc) { int v = 8 * A + cap_npc * P; return v > 40 ? 40 : v; } /* = mqe_maxc() of the engine */
 #define CAP_ROBOT 8   /* terrain / static-object contacts kept per robot (spheres are priority ordered: feet first) */
-#define CAP_NPC 2
 #define FR MQE_FRAME
 #define OBS_BAG 74
 
@@ -265,6 +264,7 @@ static int wrapper_dims(const mqe_sim_desc* d, int* Aw, int* D) {
     case MQE_TASK_SHEEP: *Aw = A; *D = 14 + 2 * P + A; break;
     case MQE_TASK_SEESAW: *Aw = A; *D = 12 + A; break;
     case MQE_TASK_FOOTBALL_DEFENDER: *Aw = 2; *D = 20; break;
+    case MQE_TASK_PUSHBOX: *Aw = A; *D = 20 + A; break;
     default: *Aw = A; *D = 6 + A; break; /* plain: [id, base_pos, base_rpy] */
   }
   return 0;
@@ -619,8 +619,10 @@ static void fill_jac(const mqo_sim* s, const envwork_t* w, int act, int body, co
 static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
   const mqe_sim_desc* d = &s->d;
   const mqe_robot_model* m = &d->robot;
-  int A = s->A, P = (d->npc_kind == MQE_NPC_BALL || d->npc_kind == MQE_NPC_SHEEP) ? s->P : 0;
-  const int maxc = env_maxc(A, s->P);
+  int A = s->A, P = (d->npc_kind == MQE_NPC_BALL || d->npc_kind == MQE_NPC_SHEEP || d->npc_kind == MQE_NPC_BOX) ? s->P : 0;
+  const int cap_npc = d->npc_contact_cap > 0 ? d->npc_contact_cap : 2;
+  const int maxc = env_maxc(A, s->P, cap_npc);
+  const int BOX = d->npc_kind == MQE_NPC_BOX;     /* robots' spheres vs the oriented box; its corners vs the terrain */
   /* sheep: translation-only bodies (orientation is scripted: go1_sheep.py:61 zeroes quat x,y every step) */
   const int lin_only = d->npc_kind == MQE_NPC_SHEEP;
   real dt = d->dt;
@@ -756,7 +758,7 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
   w->nc = 0;
   for (int act = 0; act < nact; act++) {
     int mine = 0;                       /* no actor may starve the ones after it */
-    const int cap = act < A ? CAP_ROBOT : CAP_NPC;
+    const int cap = act < A ? CAP_ROBOT : cap_npc;
     for (int si = 0; si < w->sph_n[act]; si++) {
       const real* c = w->sph_c[act][si];
       real r = w->sph_r[act][si];
@@ -823,6 +825,22 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
       const real* pa = a < A ? w->bk[a][0].p : npc_pos[a - A];
       const real* pb = b < A ? w->bk[b][0].p : npc_pos[b - A];
       real dd[3] = {pa[0] - pb[0], pa[1] - pb[1], pa[2] - pb[2]};
+      if (BOX && b >= A) {                              /* robot spheres vs the box (sphere_box narrow phase) */
+        if (a >= A || dot3(dd, dd) > (real)(1.8 * 1.8)) continue;
+        real hb[3] = {d->npc_box_half[0], d->npc_box_half[1], d->npc_box_half[2]};
+        for (int sa = 0; sa < w->sph_n[a]; sa++) {
+          const real* ca = w->sph_c[a][sa];
+          real n[3];
+          real sd = sphere_box(ca, w->sph_r[a][sa], npc_pos[b - A], w->npcR[b - A], hb, n);
+          if (sd < d->contact_offset && w->nc < pair_lim) {
+            contact_t* ct = &w->con[w->nc++];
+            memset(ct, 0, sizeof *ct);
+            ct->kind = 1; ct->actA = a; ct->sphA = sa; ct->actB = b; ct->sphB = 0; ct->sd = sd;
+            for (int k = 0; k < 3; k++) { ct->n[k] = n[k]; ct->p[k] = ca[k] - n[k] * (w->sph_r[a][sa] + (real)0.5 * sd); }
+          }
+        }
+        continue;
+      }
       if (dot3(dd, dd) > (real)(1.2 * 1.2)) continue;   /* broad phase: actors farther apart than 1.2 m cannot touch */
       for (int sb = 0; sb < w->sph_n[b]; sb++)
         for (int sa = 0; sa < w->sph_n[a]; sa++) {
@@ -1259,7 +1277,11 @@ static void wrapper_env(mqo_sim* s, int e, int is_reset_call, const float* npc) 
     for (int k = 0; k < Aw; k++) o[c++] = (k == a) ? 1.0f : 0.0f;             /* obs_ids (empty_wrapper.py:18) */
     base_info(s, e * A + a, o + c); c += 6;
     if (d->task != MQE_TASK_PLAIN) { base_info(s, e * A + (Aw - 1 - a), o + c); c += 6; }  /* torch.flip(base_info,[1]) */
-    if (d->task == MQE_TASK_GATE || d->task == MQE_TASK_SHEEP) { o[c++] = s->gate_pos[e * 2]; o[c++] = s->gate_pos[e * 2 + 1]; }
+    if (d->task == MQE_TASK_GATE || d->task == MQE_TASK_SHEEP || d->task == MQE_TASK_PUSHBOX) { o[c++] = s->gate_pos[e * 2]; o[c++] = s->gate_pos[e * 2 + 1]; }
+    if (d->task == MQE_TASK_PUSHBOX) {              /* go1_pushbox_wrapper.py:44-48: box xy (rel. env origin), box quaternion */
+      o[c++] = npc[0] - s->env_origins[e * 3]; o[c++] = npc[1] - s->env_origins[e * 3 + 1];
+      for (int k = 0; k < 4; k++) o[c++] = npc[3 + k];
+    }
     if (d->task == MQE_TASK_SHEEP)
       for (int p = 0; p < P; p++) { o[c++] = npc[p * 13] - s->env_origins[e * 3]; o[c++] = npc[p * 13 + 1] - s->env_origins[e * 3 + 1]; }
     if (d->task == MQE_TASK_FOOTBALL_DEFENDER) {
@@ -1365,6 +1387,19 @@ static void wrapper_env(mqo_sim* s, int e, int is_reset_call, const float* npc) 
       float v = sc[5] * (float)cnt; r_env += v; rs[5] += v;
     }
     if (sc[6] != 0) { if (s->r_term[e] | s->p_term[e]) { r_env += sc[6]; rs[6] += sc[6]; } }
+    for (int a = 0; a < Aw; a++) rew[a] = r_env;
+    return;
+  }
+  if (d->task == MQE_TASK_PUSHBOX) {              /* go1_pushbox_wrapper.py:52-88 */
+    float bx = npc[0] - s->env_origins[e * 3];
+    if (sc[0] != 0 && s->w_have_last[e]) {
+      float xm = bx - s->w_last2[e * 2];
+      if (was_reset) xm = 0;                      /* x_movement[reset_ids] = 0 */
+      float v = sc[0] * xm;
+      r_env += v; rs[0] += v;
+    }
+    s->w_last2[e * 2] = bx;
+    s->w_have_last[e] = 1;
     for (int a = 0; a < Aw; a++) rew[a] = r_env;
     return;
   }

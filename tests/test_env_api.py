@@ -33,7 +33,7 @@ def args_for(task, n):
 
 
 @pytest.mark.parametrize("task,A,Aw,D", [("go1gate", 2, 2, 16), ("go1sheep-hard", 2, 2, 34), ("go1seesaw", 2, 2, 14),
-                                         ("go1football-defender", 3, 2, 20)])
+                                         ("go1football-defender", 3, 2, 20), ("go1pushbox", 2, 2, 22)])
 def test_make_mqe_env_surface(oracle_backed, task, A, Aw, D):
     a = args_for(task, 4)
     env, cfg = make_mqe_env(task, a, custom_cfg(a))
@@ -125,7 +125,7 @@ def test_openrl_adapter_on_real_env(oracle_backed):
 
 def test_unregistered_tasks_fail_loudly():
     with pytest.raises(NotImplementedError):
-        make_mqe_env("go1pushbox", args_for("go1pushbox", 1))
+        make_mqe_env("go1tug", args_for("go1tug", 1))
 
 
 @pytest.mark.parametrize("task,key,A", [("go1football-1vs1", "football_game_1v1", 2), ("go1football-2vs2", "football_game_2v2", 4)])

@@ -12,12 +12,12 @@ from wrapper_replay import wrapper_replay
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", ["gate", "seesaw", "football", "sheep", "football1v1", "football2v2"])
+@pytest.mark.parametrize("name", ["gate", "seesaw", "football", "sheep", "football1v1", "football2v2", "pushbox"])
 def test_hip_matches_reference_trace(name):
     assert replay(name, hip_engine)
 
 
-@pytest.mark.parametrize("name", ["sheep_hard", "sheep_easy", "seesaw", "football_defender"])
+@pytest.mark.parametrize("name", ["sheep_hard", "sheep_easy", "seesaw", "football_defender", "pushbox"])
 def test_hip_wrappers_match_reference(name):
     assert wrapper_replay(name, hip_engine)
 
@@ -59,7 +59,7 @@ def test_mass_matrix_inverse_and_contacts(task, N):
             close(ch[:, 4:], co[:, 4:], atol=2e-5, what="contact separation / normal")
 
 
-@pytest.mark.parametrize("task,N", [("go1gate", 256), ("go1football-defender", 32), ("go1sheep-hard", 21), ("go1football-2vs2", 12)])
+@pytest.mark.parametrize("task,N", [("go1gate", 256), ("go1football-defender", 32), ("go1sheep-hard", 21), ("go1football-2vs2", 12), ("go1pushbox", 32)])
 def test_single_substep_matches_oracle(task, N):
     """one 5 ms simulate() from identical states: tolerance 2e-4 abs on positions/velocities (float32 both sides;
     the HIP kernel sums in a different order: CRBA + Schur complement vs per-body Jacobian sums + Cholesky)"""
@@ -96,7 +96,7 @@ def test_policy_layer0_paths_are_f32_equivalent(monkeypatch, b3):
             close(eh.tensor(abi.T_ACTIONS), eo.tensor(abi.T_ACTIONS), atol=5e-5, what=f"policy actions step {t}")
 
 
-@pytest.mark.parametrize("task,N", [("go1gate", 128), ("go1football-defender", 16), ("go1sheep-hard", 14), ("go1seesaw", 16), ("go1football-2vs2", 8), ("go1football-1vs1", 16)])
+@pytest.mark.parametrize("task,N", [("go1gate", 128), ("go1football-defender", 16), ("go1sheep-hard", 14), ("go1seesaw", 16), ("go1football-2vs2", 8), ("go1football-1vs1", 16), ("go1pushbox", 16)])
 def test_fused_rollout_matches_oracle(task, N):
     """20 fused step() calls (policy + 4 substeps + post-step + wrapper) from the seeded reset distribution.
     Contact dynamics amplify rounding differences, so the bound is on the typical (median) deviation and flags."""
@@ -120,6 +120,47 @@ def test_fused_rollout_matches_oracle(task, N):
     assert dev[4].median() < 1e-4, dev[4].median()
     assert dev[-1].median() < 5e-3, dev[-1].median()
     assert mism <= max(2, N // 16), f"{mism} reset-flag mismatches"
+
+
+def test_box_contacts_match_oracle():
+    """go1pushbox: robots dropped onto / against the free box (sphere vs oriented box narrow phase, box corners vs the
+    ground): identical contact lists from identical states, then 60 substeps tracked by the box pose."""
+    N = 16
+    eh, eo, d = _pair("go1pushbox", N)
+    eh.reset_all(); eo.reset_all()
+    torch.cuda.synchronize()
+    ro, do = eo.tensor(abi.T_ROOT_STATE), eo.tensor(abi.T_DOF_STATE)
+    g = torch.Generator().manual_seed(4)
+    A = 2
+    box = ro[:, A, :3].clone()
+    ro[:, A, 2] = d.ground_z + d.npc_box_half[2] + 0.002
+    # robot 0 on the lid, robot 1 leaning against a side face
+    ro[:, 0, :2] = box[:, :2] + (torch.rand(N, 2, generator=g) - 0.5) * 0.3
+    ro[:, 0, 2] = d.ground_z + 2 * d.npc_box_half[2] + 0.34
+    ro[:, 1, 0] = box[:, 0] - d.npc_box_half[0] - 0.30 + (torch.rand(N, generator=g) - 0.5) * 0.1
+    ro[:, 1, 1] = box[:, 1] + (torch.rand(N, generator=g) - 0.5) * 0.4
+    ro[:, 1, 2] = 0.34
+    ro[:, :, 7:] = 0
+    ro[:, 1, 7] = 0.8                                               # walking into the box
+    do[..., 1] = 0
+    eh.tensor(abi.T_ROOT_STATE).copy_(ro.cuda()); eh.tensor(abi.T_DOF_STATE).copy_(do.cuda())
+    eh.tensor(abi.T_TORQUES).zero_(); eo.tensor(abi.T_TORQUES).zero_()
+    saw_box = False
+    for k in range(60):
+        if k in (0, 20, 45):
+            torch.cuda.synchronize()
+            close(eh.tensor(abi.T_ROOT_STATE)[:, A, :7], eo.tensor(abi.T_ROOT_STATE)[:, A, :7], atol=5e-4, what=f"box pose at substep {k}")
+            eh.tensor(abi.T_ROOT_STATE).copy_(eo.tensor(abi.T_ROOT_STATE).cuda()); eh.tensor(abi.T_DOF_STATE).copy_(eo.tensor(abi.T_DOF_STATE).cuda())
+            for env in range(N):
+                _, ch = eh.debug_dynamics(env, 0)
+                _, _, co = eo.debug_dynamics(env, 0)
+                assert ch.shape == co.shape and (ch[:, :4] == co[:, :4]).all()
+                close(ch[:, 4:], co[:, 4:], atol=2e-5, what="contact separation / normal")
+                saw_box |= bool((co[:, 2] == A).any())
+        eh.simulate(); eo.simulate()
+    torch.cuda.synchronize()
+    assert saw_box, "test must exercise robot-box contacts"
+    assert torch.isfinite(eh.tensor(abi.T_ROOT_STATE)).all()
 
 
 def test_seesaw_plank_matches_oracle():

@@ -140,3 +140,36 @@ def test_seesaw_plank_carries_robots_and_obeys_hinge_limits():
             dof2[0, 24, 1] = sign * 0.2
             e2.simulate()
         assert dof2[0, 24, 0].item() == pytest.approx(stop, abs=1e-5)
+
+
+def test_box_rests_on_its_face_and_carries_a_robot():
+    """go1pushbox: the 6 kg unit box (box.urdf) dropped from its spawn height settles upright on four corner contacts
+    carrying m g; a robot set down on top of it (sphere vs oriented box) stands there and its weight reaches the ground
+    through the box."""
+    e, d, root, dof = fresh("go1pushbox", 2)
+    A = d.num_agents
+    for t in range(200):
+        e.simulate()
+    hz = d.npc_box_half[2]
+    assert torch.allclose(root[:, A, 2], torch.full((2,), d.ground_z + hz), atol=4e-3)
+    assert root[:, A, 3:6].abs().max() < 2e-3 and root[:, A, 7:13].abs().max() < 0.05          # upright, at rest
+    fz = e.tensor(abi.T_CONTACT_FORCE)[:, A * 17, 2]
+    assert torch.allclose(fz, torch.full((2,), d.npc_mass * G), rtol=0.05)
+    root[:, 0, :2] = root[:, A, :2]
+    root[:, 0, 2] = d.ground_z + 2 * hz + 0.36
+    root[:, 1, 1] = root[:, A, 1] + 3.0                                                        # the other robot out of the way
+    a = torch.zeros(2, 2, 3)
+    for t in range(40):                     # ~2x the settling time; the stand-in body network is not a balance controller
+        e.step(a)
+    assert (e.tensor(abi.T_RESET_COUNT) == 1).all()
+    top = d.ground_z + 2 * hz
+    assert ((root[:, 0, 2] > top + 0.25) & (root[:, 0, 2] < top + 0.36)).all(), root[:, 0, 2]   # standing on the lid
+    assert torch.allclose(root[:, A, 2], torch.full((2,), d.ground_z + hz), atol=6e-3)         # the box neither sinks nor tips
+    assert root[:, A, 3:5].abs().max() < 5e-3                                                  # no tip (yaw is free)
+    mt = sum(d.robot.mass[b] for b in range(13))
+    fz = e.tensor(abi.T_CONTACT_FORCE)[:, A * 17, 2]
+    # net CONTACT force on the box balances its own weight only: ground pushes up with (m_box + m_robot) g, the feet down with m_robot g
+    assert torch.allclose(fz, torch.full((2,), d.npc_mass * G), atol=0.15 * mt * G)
+    feet = e.tensor(abi.T_CONTACT_FORCE).reshape(2, -1, 3)[:, [4, 8, 12, 16], 2].sum(-1)
+    assert torch.allclose(feet, torch.full((2,), mt * G), rtol=0.15)                           # ... which is what the feet report
+    assert torch.isfinite(root).all()

@@ -256,7 +256,7 @@ def make_env(cls, cfg, N, seed=0, P_dofs=0):
 
 def P_bodies(cfg):
     name = getattr(cfg.asset, "name_npc", "")
-    per = {"": 0, "ball": 1, "sheep": 1, "seesaw": 2}[name]
+    per = {"": 0, "ball": 1, "sheep": 1, "seesaw": 2, "box": 1}[name]
     return per * getattr(cfg.env, "num_npcs", 0)
 
 
@@ -589,8 +589,10 @@ class FakeEnvForWrapper:
         return self.obs_buf, None, self.reset_buf, {}
 
 
-def gen_wrappers():
+def gen_wrappers(only_pushbox=False):
     from mqe.envs.configs.go1_sheep_config import NineSheepCfg, SingleSheepCfg
+    from mqe.envs.configs.go1_pushbox_config import Go1PushboxCfg
+    from mqe.envs.wrappers.go1_pushbox_wrapper import Go1PushboxWrapper
     from mqe.envs.configs.go1_seesaw_config import Go1SeesawCfg
     from mqe.envs.configs.go1_football_config import Go1FootballDefenderCfg
     from mqe.envs.wrappers.go1_sheep_wrapper import Go1SheepWrapper
@@ -598,8 +600,12 @@ def gen_wrappers():
     from mqe.envs.wrappers.go1_football_wrapper import Go1FootballDefenderWrapper
     rng = np.random.RandomState(11)
     T, N = 6, 5
-    for name, cfg, W in (("sheep_hard", NineSheepCfg, Go1SheepWrapper), ("sheep_easy", SingleSheepCfg, Go1SheepWrapper),
-                         ("seesaw", Go1SeesawCfg, Go1SeesawWrapper), ("football_defender", Go1FootballDefenderCfg, Go1FootballDefenderWrapper)):
+    tasks = (("sheep_hard", NineSheepCfg, Go1SheepWrapper), ("sheep_easy", SingleSheepCfg, Go1SheepWrapper),
+             ("seesaw", Go1SeesawCfg, Go1SeesawWrapper), ("football_defender", Go1FootballDefenderCfg, Go1FootballDefenderWrapper))
+    if only_pushbox:   # own random stream so that the older fixtures stay byte-identical
+        tasks = (("pushbox", Go1PushboxCfg, Go1PushboxWrapper),)
+        rng = np.random.RandomState(31)
+    for name, cfg, W in tasks:
         A, P = cfg.env.num_agents, cfg.env.num_npcs
         fe = FakeEnvForWrapper(cfg, N, A, P)
         eo = torch.tensor(rng.uniform(0, 3, (N, 3)).astype(np.float32))
@@ -707,7 +713,7 @@ def rle_rows(hf):
 
 def gen_terrain_and_configs():
     cfgd = {}
-    for task in ("go1gate", "go1sheep-easy", "go1sheep-hard", "go1seesaw", "go1football-defender", "go1football-1vs1", "go1football-2vs2"):
+    for task in ("go1gate", "go1sheep-easy", "go1sheep-hard", "go1seesaw", "go1football-defender", "go1football-1vs1", "go1football-2vs2", "go1pushbox"):
         cfg = ref_utils.ENV_DICT[task]["config"]
         t = barrier_track_for(cfg, 8)
         hf = t.heightfield_raw
@@ -786,10 +792,15 @@ def main():
         from mqe.envs.configs.go1_football_config import Go1Football1vs1Cfg, Go1Football2vs2Cfg
         gen_fullstep("fullstep_football1v1", Go1Object, Go1Football1vs1Cfg, N=3, T=12, act=act, ada=ada)
         gen_fullstep("fullstep_football2v2", Go1Object, Go1Football2vs2Cfg, N=2, T=10, act=act, ada=ada)
+    if want("fullstep_pushbox"):
+        from mqe.envs.configs.go1_pushbox_config import Go1PushboxCfg
+        gen_fullstep("fullstep_pushbox", Go1Object, Go1PushboxCfg, N=3, T=12, act=act, ada=ada)
     if want("wrappers"):
         gen_wrappers()
     if want("wrapper_game"):
         gen_game_wrapper()
+    if want("wrapper_pushbox"):
+        gen_wrappers(only_pushbox=True)
     if want("terrain"):
         gen_terrain_and_configs()
     if want("adapter"):
