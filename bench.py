@@ -28,7 +28,7 @@ sys.path.insert(0, os.path.join(ROOT, "multiagent-quadruped-environment_amd"))
 
 import torch  # noqa: E402
 
-PROF_NAMES = ["policy_layer0(k_gemm_b3 | k_gemm_f32)", "policy_tail(k_gemm_f32 x5 + k_body_l0_finish + k_post_policy)",
+PROF_NAMES = ["policy_layer0(k_gemm_b3 | k_gemm_f32)", "policy_tail(k_policy_tail | k_gemm_f32 x5 + k_body_l0_finish + k_post_policy)",
               "torques(unfused path only)", "substeps(k_substeps: 4 x {actuator-net MFMA + physics substep})",
               "post(k_post_physics + k_reset_history)", "misc(k_wrapper_command + k_pre_policy)"]
 PROF_KERNEL = ["k_gemm_b3", "k_gemm_f32", "k_compute_torques_mfma", "k_substeps", "k_post_physics", "k_pre_policy"]
@@ -101,10 +101,12 @@ def main():
     eng = env.env.engine
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     obs = env.reset()
-    gather = None
+    gather = packed = None
+    pending = [None, None]
     if world > 1:
         packed_dim = obs.shape[1] * obs.shape[2] + A + 1
-        gather = torch.empty(world * N, packed_dim, device=dev)
+        gather = [torch.empty(world * N, packed_dim, device=dev) for _ in range(2)]     # double buffer: the all-gather of
+        packed = [torch.empty(N, packed_dim, device=dev) for _ in range(2)]            # step t overlaps step t+1
 
     # synthetic inputs: one fresh U(-1,1) action tensor per step, generated before the clock starts (the contract times the
     # hot path with its inputs already resident in HBM; 98 kB per step)
@@ -112,16 +114,31 @@ def main():
     step_no = [0]
 
     def one_step():
-        a = actions[step_no[0]]
+        t = step_no[0]
+        a = actions[t]
         step_no[0] += 1
         o, r, d, info = env.step(a)
-        if world > 1:   # the one collective of the path: all-gather the returned batch (packed: obs | reward | done)
-            packed = torch.cat([o.reshape(N, -1), r.reshape(N, -1), d.reshape(N, 1).float()], dim=1)
-            dist.all_gather_into_tensor(gather, packed)
+        if world > 1:   # the one collective of the path: all-gather the returned batch (packed: obs | reward | done), asynchronous
+            b = t & 1
+            if pending[b] is not None:
+                pending[b].wait()                     # the gather that used this buffer two steps ago (stream-side wait)
+            pk = packed[b]
+            no = o.shape[1] * o.shape[2]
+            pk[:, :no] = o.reshape(N, -1)
+            pk[:, no:no + A] = r.reshape(N, -1)
+            pk[:, no + A] = d
+            pending[b] = dist.all_gather_into_tensor(gather[b], pk, async_op=True)
         return o
+
+    def drain():
+        for b in range(2):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
 
     for _ in range(args.warmup):
         one_step()
+    drain()
     eng.profile_enable(True)
     torch.cuda.synchronize()
     if world > 1:
@@ -130,6 +147,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -170,10 +170,10 @@ __global__ void __launch_bounds__(256, 1) k_gemm_b3(Gemm3Args g) {
   const int frow = lane & 31, fk = (lane >> 5) * 16;           // fragment: row, byte offset of its 8 k inside a 16-k step
   const unsigned fa_ofs = (wm * 64 + frow) * G3_ROWB + fk, fb_ofs = (G3_M + wn * 96 + frow) * G3_ROWB + fk;
   const int nkt = g.K / G3_K;                                   // even (K is a multiple of 64)
-  // The 64 blocks that share a W tile would otherwise walk K in lockstep and pull the very same cache lines through one
-  // L2 channel at the same moment (measured: the load phase, not the MFMAs, set the pace).  Each M-tile starts its k loop
-  // at a different tile and wraps; a sum over k does not care about the starting point.
-  const int koff = (tm * 5) % nkt;
+  // All blocks walk K in the same order on purpose: the 64 blocks that share a W tile then touch the same 37 kB window of
+  // W at about the same time and it stays L2-resident.  (Rotating the k order per M-tile, which cured an L2-channel hot
+  // spot in k_policy_tail, was measured here: same kernel time, 4x the HBM-side fetch traffic -- W no longer fits in L2.)
+  const int koff = 0;
   unsigned char* buf0 = lds3;
   unsigned char* buf1 = lds3 + G3_BUF;
   const g3_u32x4 z4 = {0u, 0u, 0u, 0u};

@@ -11,7 +11,7 @@ P = os.path.join(ROOT, "profiles")
 
 
 def one(pattern):
-    f = sorted(glob.glob(os.path.join(G, pattern), recursive=True))
+    f = sorted(glob.glob(os.path.join(G, pattern), recursive=True), key=os.path.getmtime)     # newest run wins
     return f[-1] if f else None
 
 
