@@ -419,33 +419,50 @@ __device__ void wrapper_env_dev(const DevModel* m, const DevState& st, int e, in
   float r_env = 0.0f;
   uint8_t was_reset = st.reset_buf[e];
   if (m->task == MQE_TASK_GATE) {
-    float r_ag[MQE_MAX_AGENTS] = {0, 0, 0, 0};
+    // loads first (see k_post_physics), then the same sums in the same order as the straightforward loop nest
+    float r_ag[MQE_MAX_AGENTS] = {0, 0, 0, 0}, bx[MQE_MAX_AGENTS] = {0, 0, 0, 0}, by[MQE_MAX_AGENTS] = {0, 0, 0, 0}, wl[MQE_MAX_AGENTS] = {0, 0, 0, 0};
+    const uint8_t have = st.w_have_last[e];
+    const float gx = m->gate_pos[e * 2], colf = (float)st.collide_buf[e];
+    float rs0 = rs[0], rs1 = rs[1], rs2 = rs[2], rs3 = rs[3];
+#pragma unroll
+    for (int a = 0; a < MQE_MAX_AGENTS; a++)
+      if (a < A) {
+        const float* ob = st.obs_bag + (size_t)(e * A + a) * MQE_OBS_BAG;
+        bx[a] = ob[0]; by[a] = ob[1];
+        wl[a] = st.w_last[e * MQE_MAX_AGENTS + a];
+      }
     float tsum = 0;
-    for (int a = 0; a < A; a++) {
-      const float* ob = st.obs_bag + (size_t)(e * A + a) * MQE_OBS_BAG;
-      float tx = m->wrapper_param[0], ty = (a == 0 ? 1.0f : -1.0f) * m->wrapper_param[1];
-      float dist = sqrtf((ob[0] - tx) * (ob[0] - tx) + (ob[1] - ty) * (ob[1] - ty));
-      if (!st.w_have_last[e]) st.w_last[e * MQE_MAX_AGENTS + a] = dist;
-      tsum += st.w_last[e * MQE_MAX_AGENTS + a] - dist;
-      st.w_last[e * MQE_MAX_AGENTS + a] = dist;
-    }
+#pragma unroll
+    for (int a = 0; a < MQE_MAX_AGENTS; a++)
+      if (a < A) {
+        const float tx = m->wrapper_param[0], ty = (a == 0 ? 1.0f : -1.0f) * m->wrapper_param[1];
+        const float dist = sqrtf((bx[a] - tx) * (bx[a] - tx) + (by[a] - ty) * (by[a] - ty));
+        const float last = have ? wl[a] : dist;
+        tsum += last - dist;
+        st.w_last[e * MQE_MAX_AGENTS + a] = dist;
+      }
     st.w_have_last[e] = 1;
     if (was_reset) tsum = 0;
     tsum *= sc[0];
-    for (int a = 0; a < A; a++) r_ag[a] += tsum;
-    rs[0] += tsum;
-    float col = sc[1] * (float)st.collide_buf[e];
-    for (int a = 0; a < A; a++) r_ag[a] += col;
-    rs[1] += col;
-    for (int a = 0; a < A; a++) {
-      const float* ob = st.obs_bag + (size_t)(e * A + a) * MQE_OBS_BAG;
-      if (ob[0] > m->gate_pos[e * 2] + 0.25f) { r_ag[a] += sc[2]; rs[2] += sc[2]; }
-      const float* ob2 = st.obs_bag + (size_t)(e * A + (A - 1 - a)) * MQE_OBS_BAG;
-      float d2 = (ob[0] - ob2[0]) * (ob[0] - ob2[0]) + (ob[1] - ob2[1]) * (ob[1] - ob2[1]);
-      if (d2 < 0.25f) { float pn = sc[3] / d2; r_ag[a] += pn; rs[3] += pn; }
-    }
+    const float col = sc[1] * colf;
+    rs0 += tsum;
+    rs1 += col;
+#pragma unroll
+    for (int a = 0; a < MQE_MAX_AGENTS; a++)
+      if (a < A) {
+        r_ag[a] += tsum;
+        r_ag[a] += col;
+        if (bx[a] > gx + 0.25f) { r_ag[a] += sc[2]; rs2 += sc[2]; }
+        const int pa = A - 1 - a;
+        const float px = pa == 0 ? bx[0] : (pa == 1 ? bx[1] : (pa == 2 ? bx[2] : bx[3]));
+        const float py = pa == 0 ? by[0] : (pa == 1 ? by[1] : (pa == 2 ? by[2] : by[3]));
+        const float d2 = (bx[a] - px) * (bx[a] - px) + (by[a] - py) * (by[a] - py);
+        if (d2 < 0.25f) { const float pn = sc[3] / d2; r_ag[a] += pn; rs3 += pn; }
+      }
+    rs[0] = rs0; rs[1] = rs1; rs[2] = rs2; rs[3] = rs3;
     float tot = 0;
-    for (int a = 0; a < A; a++) tot += r_ag[a];
+#pragma unroll
+    for (int a = 0; a < MQE_MAX_AGENTS; a++) if (a < A) tot += r_ag[a];
     for (int a = 0; a < A; a++) rew[a] = tot;
     return;
   }
@@ -544,82 +561,150 @@ __device__ void wrapper_env_dev(const DevModel* m, const DevState& st, int e, in
 
 // Launch geometry: the body is scalar per env with row-strided (uncoalesced) accesses, so it is latency-bound; POST_EPW
 // envs per 64-lane wavefront (the other lanes idle) trades issue slots for 64/POST_EPW times more waves in flight.
+// Within a thread the global accesses are ordered LOADS FIRST: every input of the step (robot root rows, joint states,
+// actions, gait parameters, contact forces, origins) is requested before the first store, because a load behind a store
+// that may alias cannot be hoisted by the compiler and each such load costs a full memory round trip (the first version
+// interleaved them per robot and per buffer: 37 us of s_waitcnt).  Per-robot values live in registers (loops unrolled to
+// MQE_MAX_AGENTS with a guard, so that every array index is a constant).
 #ifndef POST_EPW
 #define POST_EPW 8
 #endif
 __global__ void __launch_bounds__(64) k_post_physics(const DevModel* m, DevState st, int first_steps_done) {
   if (threadIdx.x >= POST_EPW) return;
-  int e = blockIdx.x * POST_EPW + threadIdx.x;
+  const int e = blockIdx.x * POST_EPW + threadIdx.x;
   if (e >= m->N) return;
-  int A = m->A, P = m->P;
-  float dtp = m->dt * (float)m->decimation;
+  const int A = m->A, P = m->P;
+  const float dtp = m->dt * (float)m->decimation;
   float* root = st.root + (size_t)e * (A + P) * 13;
-  int ep = st.ep_len[e] + 1;
-  st.ep_len[e] = ep;
-  for (int a = 0; a < A; a++) {
-    int i = e * A + a;
-    const float* rs = root + a * 13;
-    float q[4] = {rs[3], rs[4], rs[5], rs[6]}, v[3] = {rs[7], rs[8], rs[9]}, w[3] = {rs[10], rs[11], rs[12]};
-    float g3[3] = {0.0f, 0.0f, -1.0f}, o[3];
-    for (int k = 0; k < 4; k++) st.bquat[i * 4 + k] = q[k];
-    quat_rotate_inverse_f(q, v, o);  for (int k = 0; k < 3; k++) st.blv[i * 3 + k] = o[k];
-    quat_rotate_inverse_f(q, w, o);  for (int k = 0; k < 3; k++) st.bav[i * 3 + k] = o[k];
-    quat_rotate_inverse_f(q, g3, o); for (int k = 0; k < 3; k++) st.pg[i * 3 + k] = o[k];
-    const float* lo = st.loco_obs + (size_t)i * MQE_FRAME;
-    float f = lo[7], ph = lo[8], off = lo[9], bnd = lo[10], dur = lo[11];
-    float gi = st.gait[i] + dtp * f;
-    gi = gi - floorf(gi);
-    st.gait[i] = gi;
-    float fi[4] = {gi + ph + off + bnd, gi + off, gi + bnd, gi + ph};
-    for (int k = 0; k < 4; k++) {
-      float r = fi[k] - floorf(fi[k]);
-      if (r < dur) fi[k] = r * (0.5f / dur);
-      else if (r > dur) fi[k] = 0.5f + (r - dur) * (0.5f / (1.0f - dur));
-      st.clock[i * 4 + k] = sinf(6.2831855f * fi[k]);
+  // ---- loads --------------------------------------------------------------------------------------------------------------
+  float rs[MQE_MAX_AGENTS][13], gpar[MQE_MAX_AGENTS][5], gi0[MQE_MAX_AGENTS], f3[MQE_MAX_AGENTS][3], aoz[MQE_MAX_AGENTS];
+  float dq[MQE_MAX_AGENTS][24], act[MQE_MAX_AGENTS][12];
+  const int ep = st.ep_len[e] + 1;
+  float eo[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) eo[k] = m->env_origins[e * 3 + k];
+#pragma unroll
+  for (int a = 0; a < MQE_MAX_AGENTS; a++)
+    if (a < A) {
+      const int i = e * A + a;
+#pragma unroll
+      for (int k = 0; k < 13; k++) rs[a][k] = root[a * 13 + k];
+      const float* lo = st.loco_obs + (size_t)i * MQE_FRAME;
+#pragma unroll
+      for (int k = 0; k < 5; k++) gpar[a][k] = lo[7 + k];
+      gi0[a] = st.gait[i];
+      const float* cf3 = st.cf + ((size_t)e * m->NBR + a * MQE_NREP) * 3;
+#pragma unroll
+      for (int k = 0; k < 3; k++) f3[a][k] = cf3[k];
+      aoz[a] = m->agent_origins[((size_t)e * A + a) * 3 + 2];
+      const float* ds = st.dof + ((size_t)e * m->ND + a * 12) * 2;
+#pragma unroll
+      for (int k = 0; k < 24; k++) dq[a][k] = ds[k];
+#pragma unroll
+      for (int k = 0; k < 12; k++) act[a][k] = st.actions[(size_t)i * 12 + k];
     }
-  }
+  // ---- body-frame quantities, gait clock, termination (registers only) ------------------------------------------------------
+  float bq[MQE_MAX_AGENTS][4], lv[MQE_MAX_AGENTS][3], av[MQE_MAX_AGENTS][3], pgr[MQE_MAX_AGENTS][3], clk[MQE_MAX_AGENTS][4], gi1[MQE_MAX_AGENTS];
   uint8_t reset = 0, collide = 0, rterm = 0, pterm = 0, zh = 0;
-  if (m->terminate_on_base_contact) {
-    for (int a = 0; a < A; a++) {
-      const float* f3 = st.cf + ((size_t)e * m->NBR + a * MQE_NREP) * 3;
-      if (sqrtf(f3[0] * f3[0] + f3[1] * f3[1] + f3[2] * f3[2]) > 1.0f) collide = 1;
+#pragma unroll
+  for (int a = 0; a < MQE_MAX_AGENTS; a++)
+    if (a < A) {
+      const float q[4] = {rs[a][3], rs[a][4], rs[a][5], rs[a][6]}, v[3] = {rs[a][7], rs[a][8], rs[a][9]}, w[3] = {rs[a][10], rs[a][11], rs[a][12]};
+      const float g3[3] = {0.0f, 0.0f, -1.0f};
+#pragma unroll
+      for (int k = 0; k < 4; k++) bq[a][k] = q[k];
+      quat_rotate_inverse_f(q, v, lv[a]);
+      quat_rotate_inverse_f(q, w, av[a]);
+      quat_rotate_inverse_f(q, g3, pgr[a]);
+      const float f = gpar[a][0], ph = gpar[a][1], off = gpar[a][2], bnd = gpar[a][3], dur = gpar[a][4];
+      float gi = gi0[a] + dtp * f;
+      gi = gi - floorf(gi);
+      gi1[a] = gi;
+      float fi[4] = {gi + ph + off + bnd, gi + off, gi + bnd, gi + ph};
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const float r = fi[k] - floorf(fi[k]);
+        if (r < dur) fi[k] = r * (0.5f / dur);
+        else if (r > dur) fi[k] = 0.5f + (r - dur) * (0.5f / (1.0f - dur));
+        clk[a][k] = sinf(6.2831855f * fi[k]);
+      }
+      if (m->terminate_on_base_contact && sqrtf(f3[a][0] * f3[a][0] + f3[a][1] * f3[a][1] + f3[a][2] * f3[a][2]) > 1.0f) collide = 1;
+      float rpy[3];
+      euler_xyz_f(q, rpy);
+      float r = rpy[0], p = rpy[1];
+      if (r > 3.1415927f) r -= 6.2831855f;
+      if (p > 3.1415927f) p -= 6.2831855f;
+      const float z = rs[a][2] - aoz[a];
+      if ((m->termination_flags & MQE_TERM_ROLL) && fabsf(r) > m->roll_thr) rterm = 1;
+      if ((m->termination_flags & MQE_TERM_PITCH) && fabsf(p) > m->pitch_thr) pterm = 1;
+      if ((m->termination_flags & MQE_TERM_Z_LOW) && z < m->zlow_thr) reset = 1;
+      if ((m->termination_flags & MQE_TERM_Z_HIGH) && z > m->zhigh_thr) zh = 1;
     }
-    reset = collide;
-  }
-  uint8_t to = ep > m->max_episode_length;
+  if (m->terminate_on_base_contact) reset |= collide;
+  const uint8_t to = ep > m->max_episode_length;
+  reset |= to | rterm | pterm | zh;
+  // ---- stores of the frame quantities and flags ------------------------------------------------------------------------------
+  st.ep_len[e] = ep;
   st.time_out[e] = to;
-  reset |= to;
-  for (int a = 0; a < A; a++) {
-    int i = e * A + a;
-    float rpy[3];
-    euler_xyz_f(st.bquat + i * 4, rpy);
-    float r = rpy[0], p = rpy[1];
-    if (r > 3.1415927f) r -= 6.2831855f;
-    if (p > 3.1415927f) p -= 6.2831855f;
-    float z = root[a * 13 + 2] - m->agent_origins[((size_t)e * A + a) * 3 + 2];
-    if ((m->termination_flags & MQE_TERM_ROLL) && fabsf(r) > m->roll_thr) rterm = 1;
-    if ((m->termination_flags & MQE_TERM_PITCH) && fabsf(p) > m->pitch_thr) pterm = 1;
-    if ((m->termination_flags & MQE_TERM_Z_LOW) && z < m->zlow_thr) reset = 1;
-    if ((m->termination_flags & MQE_TERM_Z_HIGH) && z > m->zhigh_thr) zh = 1;
-  }
   if (m->termination_flags & MQE_TERM_ROLL) st.r_term[e] = rterm;
   if (m->termination_flags & MQE_TERM_PITCH) st.p_term[e] = pterm;
   if (m->termination_flags & MQE_TERM_Z_HIGH) st.zh_term[e] = zh;
-  reset |= rterm | pterm | zh;
   st.reset_buf[e] = reset;
   if (m->terminate_on_base_contact) st.collide_buf[e] = reset;
+#pragma unroll
+  for (int a = 0; a < MQE_MAX_AGENTS; a++)
+    if (a < A) {
+      const int i = e * A + a;
+#pragma unroll
+      for (int k = 0; k < 3; k++) { st.blv[i * 3 + k] = lv[a][k]; st.bav[i * 3 + k] = av[a][k]; st.pg[i * 3 + k] = pgr[a][k]; }
+#pragma unroll
+      for (int k = 0; k < 4; k++) { st.bquat[i * 4 + k] = bq[a][k]; st.clock[i * 4 + k] = clk[a][k]; }
+      st.gait[i] = gi1[a];
+    }
   // wrapper's view of root_states_npc: copy taken before the NPC script (legged_robot.py:136); xy/vel only are read
   float npc_pre[MQE_MAX_NPCS * 13];
   for (int k = 0; k < P * 13; k++) npc_pre[k] = root[A * 13 + k];
   if (m->npc_kind == MQE_NPC_SHEEP) step_sheep_env(m, st, e);
-  if (reset) {
+  if (reset) {                                  // rare: the reset writes memory, the registers are refreshed from it
     reset_env_dev(m, st, e);
     for (int k = 0; k < P * 13; k++) npc_pre[k] = root[A * 13 + k];
-    if (P == 0)
-      for (int a = 0; a < A; a++) for (int k = 0; k < 4; k++) st.bquat[(e * A + a) * 4 + k] = root[a * 13 + 3 + k];
+#pragma unroll
+    for (int a = 0; a < MQE_MAX_AGENTS; a++)
+      if (a < A) {
+#pragma unroll
+        for (int k = 0; k < 13; k++) rs[a][k] = root[a * 13 + k];
+        const float* ds = st.dof + ((size_t)e * m->ND + a * 12) * 2;
+#pragma unroll
+        for (int k = 0; k < 24; k++) dq[a][k] = ds[k];
+        if (P == 0) {
+#pragma unroll
+          for (int k = 0; k < 4; k++) { bq[a][k] = rs[a][3 + k]; st.bquat[(e * A + a) * 4 + k] = bq[a][k]; }
+        }
+      }
   }
-  compute_observations_env(m, st, e, 1);
-  for (int k = 0; k < 12 * A; k++) st.last_actions[(size_t)e * 12 * A + k] = st.actions[(size_t)e * 12 * A + k];
+  // ---- compute_observations (legged_robot_field.py:117-146) from registers; obs.last_last_action aliases the current action
+#pragma unroll
+  for (int a = 0; a < MQE_MAX_AGENTS; a++)
+    if (a < A) {
+      const int i = e * A + a;
+      float* ob = st.obs_bag + (size_t)i * MQE_OBS_BAG;
+      float rpy[3];
+      euler_xyz_f(bq[a], rpy);
+#pragma unroll
+      for (int k = 0; k < 3; k++) { ob[k] = rs[a][k] - eo[k]; ob[3 + k] = rpy[k]; }
+#pragma unroll
+      for (int j = 0; j < 12; j++) {
+        ob[6 + j] = (dq[a][2 * j] - m->default_dof_pos[j]) * 1.0f;
+        ob[18 + j] = dq[a][2 * j + 1] * 0.05f;
+        ob[36 + j] = act[a][j];
+        ob[48 + j] = act[a][j];
+        st.last_actions[(size_t)i * 12 + j] = act[a][j];
+      }
+#pragma unroll
+      for (int k = 0; k < 3; k++) { ob[30 + k] = lv[a][k] * 2.0f; ob[33 + k] = av[a][k] * 0.25f; ob[60 + k] = pgr[a][k]; }
+#pragma unroll
+      for (int k = 0; k < 4; k++) { ob[63 + k] = clk[a][k]; ob[67 + k] = bq[a][k]; }
+    }
   wrapper_env_dev(m, st, e, 0, npc_pre);
 }
 
