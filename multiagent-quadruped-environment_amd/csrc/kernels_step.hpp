@@ -569,10 +569,31 @@ __device__ void wrapper_env_dev(const DevModel* m, const DevState& st, int e, in
 #ifndef POST_EPW
 #define POST_EPW 8
 #endif
+__device__ __forceinline__ uint8_t post_physics_env(const DevModel* m, const DevState& st, const int e);
+
 __global__ void __launch_bounds__(64) k_post_physics(const DevModel* m, DevState st, int first_steps_done) {
-  if (threadIdx.x >= POST_EPW) return;
   const int e = blockIdx.x * POST_EPW + threadIdx.x;
-  if (e >= m->N) return;
+  uint8_t reset = 0;
+  if (threadIdx.x < POST_EPW && e < m->N) reset = post_physics_env(m, st, e);
+  // go1.py:145: history[agent_ids] = 0 for the envs that reset this step -- rare, so the whole wavefront (the lanes that
+  // idled above included) zeroes them, 16 B per lane per request: the f32 ring and, when present, its three bf16 planes
+  unsigned long long rm = __ballot(reset != 0);
+  while (rm) {
+    const int l = __ffsll((long long)rm) - 1;
+    rm &= rm - 1;
+    const int er = blockIdx.x * POST_EPW + l;
+    const int per = m->A * (MQE_HIST * MQE_FRAME / 4);                 // float4 units of this env's robots (contiguous)
+    float4* h4 = reinterpret_cast<float4*>(st.hist) + (size_t)er * per;
+    for (int i = threadIdx.x; i < per; i += 64) h4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (st.hist3) {                                                    // same robots, 3 planes interleaved: 3x the bytes / 2
+      uint4* p4 = reinterpret_cast<uint4*>(st.hist3 + (size_t)er * m->A * (3 * MQE_HIST * MQE_FRAME));
+      const int per3 = m->A * (3 * MQE_HIST * MQE_FRAME / 8);
+      for (int i = threadIdx.x; i < per3; i += 64) p4[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+  }
+}
+
+__device__ __forceinline__ uint8_t post_physics_env(const DevModel* m, const DevState& st, const int e) {
   const int A = m->A, P = m->P;
   const float dtp = m->dt * (float)m->decimation;
   float* root = st.root + (size_t)e * (A + P) * 13;
@@ -706,6 +727,7 @@ __global__ void __launch_bounds__(64) k_post_physics(const DevModel* m, DevState
       for (int k = 0; k < 4; k++) { ob[63 + k] = clk[a][k]; ob[67 + k] = bq[a][k]; }
     }
   wrapper_env_dev(m, st, e, 0, npc_pre);
+  return reset;
 }
 
 // go1.py:145: history[agent_ids] = 0 for envs that reset this step.  One float4 per thread, R*540 threads.

@@ -494,9 +494,7 @@ static void launch_simulate(mqe_sim* s, hipStream_t q) {
 }
 static void launch_post(mqe_sim* s, hipStream_t q) {
   ProfScope ps(s, PROF_POST, q);
-  hipLaunchKernelGGL(k_post_physics, dim3((s->N + POST_EPW - 1) / POST_EPW), dim3(64), 0, q, s->dm, s->st, s->n_post_steps);
-  int n = s->R * (MQE_HIST * MQE_FRAME / 4);
-  hipLaunchKernelGGL(k_reset_history, dim3((n + 255) / 256), dim3(256), 0, q, s->dm, s->st);
+  hipLaunchKernelGGL(k_post_physics, dim3((s->N + POST_EPW - 1) / POST_EPW), dim3(64), 0, q, s->dm, s->st, s->n_post_steps);   // incl. history zeroing
   s->n_post_steps++;
 }
 
