@@ -88,7 +88,10 @@ __global__ void k_wrapper_command(const DevModel* m, DevState st, const float* _
 // ----------------------------------------------------------------------------------------------------------------
 // Go1.preprocess_action up to the history update (go1.py:64-102).  One thread per (robot, frame element): the 70-float
 // frame is assembled and written once to the robot's ring slot (280 B) instead of re-concatenating 2100 floats.
-__global__ void k_pre_policy(const DevModel* m, DevState st, const float* __restrict__ command, int hist_slot) {
+// `wrapper_actions` != nullptr (fused mqe_step): the wrapper head (k_wrapper_command) is evaluated here for the three
+// command columns instead of in a launch of its own; `command` is then ignored.
+__global__ void k_pre_policy(const DevModel* m, DevState st, const float* __restrict__ command, int hist_slot,
+                             const float* __restrict__ wrapper_actions) {
   int idx = blockIdx.x * blockDim.x + threadIdx.x;
   int i = idx / MQE_FRAME, c = idx - i * MQE_FRAME;
   if (i >= m->R) return;
@@ -97,7 +100,19 @@ __global__ void k_pre_policy(const DevModel* m, DevState st, const float* __rest
   float v;
   if (c < 3) v = ob[60 + c];                                   // projected gravity      :95
   else if (c < 6) {                                            // velocity command       :67-68 (+ clip :38)
-    float x = command[i * 3 + (c - 3)];
+    float x;
+    if (wrapper_actions) {
+      const int A = m->A, Aw = m->Aw, e = i / A, a = i - e * A, k = c - 3;
+      if (m->task == MQE_TASK_FOOTBALL_DEFENDER && a == 2) {
+        float c3[3];
+        defender_command_dev(m, st, e, c3);
+        x = c3[k];
+      } else if (a < Aw) {
+        const float v = clampf(wrapper_actions[((size_t)e * Aw + a) * 3 + k], -1.0f, 1.0f);
+        x = m->task == MQE_TASK_PLAIN ? v : v * (k == 0 ? 2.0f : 0.5f);
+      } else x = st.cmd[i * 3 + k];
+      st.cmd[i * 3 + k] = x;
+    } else x = command[i * 3 + (c - 3)];
     if (m->clip_command) x = clampf(x, -1.0f, 1.0f);
     v = x * (c < 5 ? m->cmd_lin_scale : m->cmd_ang_scale);
   } else if (c < 18) v = lo[c];                                // fixed gait parameters (set at construction)

@@ -419,12 +419,12 @@ static void launch_gemm3(hipStream_t q, const uint16_t* A, int lda, int rot8, in
   hipLaunchKernelGGL(k_gemm_b3, dim3(grid), dim3(256), G3_LDS_BYTES, q, g);
 }
 
-static int policy_step(mqe_sim* s, const float* command, hipStream_t q) {
+static int policy_step(mqe_sim* s, const float* command, hipStream_t q, const float* wrapper_actions = nullptr) {
   const int R = s->R;
   {
     ProfScope ps(s, PROF_MISC, q);
     int n = R * MQE_FRAME;
-    hipLaunchKernelGGL(k_pre_policy, dim3((n + 255) / 256), dim3(256), 0, q, s->dm, s->st, command, s->hist_pos);
+    hipLaunchKernelGGL(k_pre_policy, dim3((n + 255) / 256), dim3(256), 0, q, s->dm, s->st, command, s->hist_pos, wrapper_actions);
   }
   s->hist_pos = (s->hist_pos + 1) % MQE_HIST;     // ring slot of the oldest frame
   {
@@ -549,11 +549,7 @@ extern "C" int mqe_reset_all(mqe_sim* s, void* stream) {
 
 extern "C" int mqe_step(mqe_sim* s, const float* actions, void* stream) {
   hipStream_t q = (hipStream_t)stream;
-  {
-    ProfScope ps(s, PROF_MISC, q);
-    hipLaunchKernelGGL(k_wrapper_command, dim3((s->N + 63) / 64), dim3(64), 0, q, s->dm, s->st, actions);
-  }
-  policy_step(s, s->st.cmd, q);
+  policy_step(s, s->st.cmd, q, actions);         // wrapper head (clip, task action scale, scripted defender) inside k_pre_policy
   if (s->d.control_type == MQE_CTRL_C && s->fuse_substeps) {
     // decimation loop in one launch: state stays in LDS, actuator net on MFMA inside the physics wavefront
     ProfScope ps(s, PROF_SIMULATE, q);
