@@ -153,6 +153,8 @@ enum {
   MQE_T_RESET_COUNT,       /* int32 [N] */
   MQE_T_SUBSTEP_TORQUES,   /* [N,4,12A] (legged_robot.py:112-115) */
   MQE_T_NPC_NOISE,         /* [N,P,3] injected N(0,1) for the sheep script when noise_mode is SCRIPTED */
+  MQE_T_WRAPPER_PACKED,    /* [N*Aw*D + N*Aw] the wrapper observation and reward as ONE contiguous buffer (obs first): the
+                              returned batch can be snapshotted with a single copy */
   MQE_T_COUNT
 };
 

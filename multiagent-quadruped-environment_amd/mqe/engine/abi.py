@@ -15,7 +15,7 @@ TERM = dict(roll=1, pitch=2, z_low=4, z_high=8)
  T_LAST_LOCO_ACTION, T_LAST_TWO_LOCO_ACTION, T_ACT_HIST, T_GAIT_INDICES, T_CLOCK_INPUTS, T_BASE_LIN_VEL,
  T_BASE_ANG_VEL, T_PROJECTED_GRAVITY, T_BASE_QUAT, T_EPISODE_LENGTH, T_RESET_BUF, T_COLLIDE_BUF, T_TIME_OUT_BUF,
  T_R_TERM, T_P_TERM, T_Z_HIGH_TERM, T_OBS_BAG, T_WRAPPER_OBS, T_WRAPPER_REWARD, T_REWARD_SUMS, T_SHEEP_POS_AVG,
- T_SHEEP_POS_VAR, T_RESET_COUNT, T_SUBSTEP_TORQUES, T_NPC_NOISE, T_COUNT) = range(34)
+ T_SHEEP_POS_VAR, T_RESET_COUNT, T_SUBSTEP_TORQUES, T_NPC_NOISE, T_WRAPPER_PACKED, T_COUNT) = range(35)
 
 # slices of one OBS_BAG row (compute_observations, reference go1.py:153-196)
 BAG = dict(base_pos=(0, 3), base_rpy=(3, 6), dof_pos=(6, 18), dof_vel=(18, 30), lin_vel=(30, 33), ang_vel=(33, 36),

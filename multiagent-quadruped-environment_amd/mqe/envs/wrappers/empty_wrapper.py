@@ -69,6 +69,7 @@ class FusedTaskWrapper(EmptyWrapper):
         self.action_scale = torch.tensor([[[2, 0.5, 0.5]]], device=env.device).repeat(self.num_envs, self.num_agents, 1)
         self._wobs = env.engine.tensor(abi.T_WRAPPER_OBS)
         self._wrew = env.engine.tensor(abi.T_WRAPPER_REWARD)
+        self._wpack = env.engine.tensor(abi.T_WRAPPER_PACKED)        # obs | reward in one buffer: one snapshot copy per step
         assert self._wobs.shape[-1] == self.observation_space.shape[0]
         self.reward_buffer = RewardBuffer([n for _, n in REWARD_TERMS[self.task]], env.engine.tensor(abi.T_REWARD_SUMS))
 
@@ -82,4 +83,6 @@ class FusedTaskWrapper(EmptyWrapper):
     def step(self, action):
         self.env.step_fused(action.reshape(self.num_envs, self.num_agents, 3))
         dict.__setitem__(self.reward_buffer, "step count", dict.__getitem__(self.reward_buffer, "step count") + 1)
-        return self._wobs.clone(), self._wrew.clone(), self.env.reset_buf, self.env.extras
+        snap = self._wpack.clone()                                     # fresh tensors every step, like the reference
+        n = self._wobs.numel()
+        return snap[:n].view(self._wobs.shape), snap[n:].view(self._wrew.shape), self.env.reset_buf, self.env.extras

@@ -314,8 +314,8 @@ int mqo_sim_create(const mqe_sim_desc* d, mqo_sim** out) {
   s->bquat = ALLOCF((size_t)R * 4);
   for (int i = 0; i < R; i++) s->bquat[i * 4 + 3] = 1.0f;
   s->obs_bag = ALLOCF((size_t)R * OBS_BAG);
-  s->wobs = ALLOCF((size_t)N * s->Aw * s->D);
-  s->wrew = ALLOCF((size_t)N * s->Aw);
+  s->wobs = ALLOCF((size_t)N * s->Aw * s->D + (size_t)N * s->Aw);
+  s->wrew = s->wobs + (size_t)N * s->Aw * s->D;        /* one buffer, as in the engine (MQE_T_WRAPPER_PACKED) */
   s->rsum = ALLOCF((size_t)N * MQE_MAX_REWARD_TERMS);
   s->sheep_avg = ALLOCF((size_t)N * 2);
   s->sheep_var = ALLOCF(N);
@@ -345,7 +345,7 @@ int mqo_sim_create(const mqe_sim_desc* d, mqo_sim** out) {
   t[MQE_T_TIME_OUT_BUF] = s->time_out; t[MQE_T_R_TERM] = s->r_term; t[MQE_T_P_TERM] = s->p_term; t[MQE_T_Z_HIGH_TERM] = s->zh_term;
   t[MQE_T_OBS_BAG] = s->obs_bag; t[MQE_T_WRAPPER_OBS] = s->wobs; t[MQE_T_WRAPPER_REWARD] = s->wrew; t[MQE_T_REWARD_SUMS] = s->rsum;
   t[MQE_T_SHEEP_POS_AVG] = s->sheep_avg; t[MQE_T_SHEEP_POS_VAR] = s->sheep_var; t[MQE_T_RESET_COUNT] = s->reset_count;
-  t[MQE_T_SUBSTEP_TORQUES] = s->sub_tau; t[MQE_T_NPC_NOISE] = s->npc_noise;
+  t[MQE_T_SUBSTEP_TORQUES] = s->sub_tau; t[MQE_T_NPC_NOISE] = s->npc_noise; t[MQE_T_WRAPPER_PACKED] = s->wobs;
   *out = s;
   return 0;
 }
@@ -381,6 +381,7 @@ int mqo_sim_tensor(mqo_sim* s, int kind, mqe_tensor_view* v) {
     case MQE_T_SHEEP_POS_VAR: SH(1, N, 0, 0, 0, 0); break;
     case MQE_T_SUBSTEP_TORQUES: SH(3, N, 4, 12 * A, 0, 0); break;
     case MQE_T_NPC_NOISE: SH(3, N, P, 3, 0, 0); break;
+    case MQE_T_WRAPPER_PACKED: SH(1, N * s->Aw * s->D + N * s->Aw, 0, 0, 0, 0); break;
   }
   return 0;
 }
