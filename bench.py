@@ -87,7 +87,11 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if os.environ.get("MQE_BENCH_SELFTEST_GLOO"):      # logic check of the sharded path on a 1-GPU box: all ranks on cuda:0, gloo
+            local_rank = 0
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
 

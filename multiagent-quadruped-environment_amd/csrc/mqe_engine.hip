@@ -244,7 +244,15 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   }
   // Layer 0 runs on the bf16 matrix cores with three-plane split operands (f32-equivalent accuracy, k_gemm_b3) whenever
   // its width tiles by 192; MQE_GEMM_B3=0 selects the exact-f32 MFMA kernel instead (0.255 ms vs 0.157 ms at 8192 rows).
-  s->gemm_split = !(getenv("MQE_GEMM_B3") != nullptr && atoi(getenv("MQE_GEMM_B3")) == 0) && s->l0.Npad % G3_N == 0;
+  {
+    // Which kernel for layer 0?  k_gemm_b3 owns a whole CU per 128 x 192 tile: its time is a staircase in R (157 us per
+    // started round of 256 tiles), the exact-f32 kernel scales linearly (255 us at R = 8192).  Pick the faster one for this
+    // batch unless MQE_GEMM_B3 forces a choice.
+    const char* f = getenv("MQE_GEMM_B3");
+    const double rounds = std::ceil(((R + G3_M - 1) / G3_M) * (double)(s->l0.Npad / G3_N) / 256.0);
+    const bool faster = rounds * 157.0 < 255.0 * R / 8192.0;
+    s->gemm_split = s->l0.Npad % G3_N == 0 && (f ? atoi(f) != 0 : faster);
+  }
   if (s->gemm_split) {
     if (finalize_layer(s, &s->l0)) return fail(-5, "upload");
     if (hipFuncSetAttribute((const void*)k_gemm_b3, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES) != hipSuccess)
