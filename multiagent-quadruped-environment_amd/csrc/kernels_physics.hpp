@@ -464,7 +464,8 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     ssPiv = ssB + v3(m->ss_joint_offset[0], m->ss_joint_offset[1], m->ss_joint_offset[2]);
     ssTheta = lds[L.dof + (12 * A) * 2];
     const float cth = cosf(ssTheta), sth = sinf(ssTheta);
-    ssR[0] = cth; ssR[2] = sth; ssR[6] = -sth; ssR[8] = cth;
+    if (m->ss_axis == 2) { ssR[0] = cth; ssR[1] = -sth; ssR[3] = sth; ssR[4] = cth; }      // door: rotation about +z
+    else { ssR[0] = cth; ssR[2] = sth; ssR[6] = -sth; ssR[8] = cth; }                       // plank: rotation about +y
     ssC = ssPiv + mat_vec(ssR, v3(m->ss_plank_center[0], m->ss_plank_center[1], m->ss_plank_center[2]));
   }
   // ---- contact generation: terrain (ground plane, wall SDF), canonical order --------------------------------------------
@@ -754,7 +755,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
         }
       } else if (SS) {
         const V3 r0 = p - ssPiv;
-        const V3 wy = cross(v3(0, 1, 0), r0);
+        const V3 wy = cross(m->ss_axis == 2 ? v3(0, 0, 1) : v3(0, 1, 0), r0);
         const float j0 = sg * dot(n, wy), j1 = sg * dot(t1, wy), j2 = sg * dot(t2, wy);
         const float ii = 1.0f / m->ss_inertia;
 #pragma unroll

@@ -411,7 +411,8 @@ __device__ void wrapper_env_dev(const DevModel* m, const DevState& st, int e, in
   for (int a = 0; a < Aw; a++) {
     float* o = obs + a * D;
     int c = 0;
-    for (int k = 0; k < Aw; k++) o[c++] = (k == a) ? 1.0f : 0.0f;
+    if (m->task != MQE_TASK_ROTATION)
+      for (int k = 0; k < Aw; k++) o[c++] = (k == a) ? 1.0f : 0.0f;
     const float* ob = st.obs_bag + (size_t)(e * A + a) * MQE_OBS_BAG;
     for (int k = 0; k < 6; k++) o[c++] = ob[k];
     if (m->task != MQE_TASK_PLAIN) {
@@ -429,6 +430,30 @@ __device__ void wrapper_env_dev(const DevModel* m, const DevState& st, int e, in
       for (int k = 0; k < 3; k++) o[c++] = npc[k] - m->env_origins[e * 3 + k];
       for (int k = 0; k < 3; k++) o[c++] = npc[7 + k];
     }
+  }
+  if (m->task == MQE_TASK_ROTATION) {             // go1_rotation_wrapper.py:46-50,90-93: agent 1 sees the mirrored scene
+    float* o1 = obs + 1 * D;
+    o1[1] = -o1[1]; o1[4] = -o1[4]; o1[7] = -o1[7]; o1[10] = -o1[10];
+    const float tgt = m->wrapper_param[0];
+    const float* ob0 = st.obs_bag + (size_t)(e * A) * MQE_OBS_BAG;
+    const float* ob1 = st.obs_bag + (size_t)(e * A + 1) * MQE_OBS_BAG;
+    const float x0 = ob0[0], y0 = ob0[1], x1 = ob1[0];
+    if (is_reset_call) {                          // _init_extras (:30-38): only x is shifted by the target here
+      st.w_last[e * MQE_MAX_AGENTS] = sqrtf((x0 - tgt) * (x0 - tgt) + y0 * y0);
+      for (int a = 0; a < Aw; a++) rew[a] = 0;
+      return;
+    }
+    float r0 = 0.0f;
+    if (sc[0] != 0 && x0 > tgt) { r0 += sc[0]; rs[0] += sc[0]; }
+    if (sc[1] != 0 && x1 > tgt) { r0 -= sc[1]; rs[1] += sc[1]; }
+    if (sc[2] != 0) {     // the upstream broadcast subtracts the target from x AND y (:74); kept, see the oracle
+      const float dis = sqrtf((x0 - tgt) * (x0 - tgt) + (y0 - tgt) * (y0 - tgt));
+      if (dis < st.w_last[e * MQE_MAX_AGENTS]) { r0 += sc[2]; rs[2] += sc[2]; }
+      st.w_last[e * MQE_MAX_AGENTS] = dis;
+    }
+    rew[0] = r0;
+    for (int a = 1; a < Aw; a++) rew[a] = 0;
+    return;
   }
   if (is_reset_call) { for (int a = 0; a < Aw; a++) rew[a] = 0; return; }
   float r_env = 0.0f;

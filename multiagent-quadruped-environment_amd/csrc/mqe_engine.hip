@@ -134,6 +134,7 @@ static int wrapper_dims(const mqe_sim_desc* d, int* Aw, int* D) {
     case MQE_TASK_SEESAW: *Aw = A; *D = 12 + A; break;
     case MQE_TASK_FOOTBALL_DEFENDER: *Aw = 2; *D = 20; break;
     case MQE_TASK_PUSHBOX: *Aw = A; *D = 20 + A; break;
+    case MQE_TASK_ROTATION: *Aw = A; *D = 12; break;
     default: *Aw = A; *D = 6 + A; break;
   }
   return 0;
@@ -173,7 +174,7 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   memcpy(m.npc_sphere_center, d->npc_sphere_center, sizeof m.npc_sphere_center);
   memcpy(m.npc_sphere_radius, d->npc_sphere_radius, sizeof m.npc_sphere_radius);
   m.seesaw_default_angle = d->seesaw_default_angle;
-  m.has_seesaw = seesaw;
+  m.has_seesaw = seesaw; m.ss_axis = d->seesaw_axis == 2 ? 2 : 1;
   memcpy(m.ss_joint_offset, d->seesaw_joint_offset, 12); memcpy(m.ss_plank_center, d->seesaw_plank_center, 12);
   memcpy(m.ss_plank_half, d->seesaw_plank_half, 12); memcpy(m.ss_base_half, d->seesaw_base_half, 12);
   m.ss_inertia = d->seesaw_plank_inertia_yy; m.ss_vel_limit = d->seesaw_vel_limit;

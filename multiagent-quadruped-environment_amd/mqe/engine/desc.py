@@ -22,6 +22,8 @@ REWARD_TERMS = {
     "football_defender": [("goal_reward_scale", "goal reward"), ("ball_gate_distance_reward_scale", "ball gate distance reward")],
     # the wrapper overwrites the configured scale with 1 after reading it (go1_pushbox_wrapper.py:20), see build_desc
     "pushbox": [("box_x_movement_reward_scale", "box movement reward")],
+    # hard-set in the wrapper's constructor (go1_rotation_wrapper.py:18-20): 5 / 1 / 1, see build_desc
+    "rotation": [("success_reward_scale", "success reward"), ("punishment_scale", "punishment"), ("distance_reward_scale", "distance reward")],
     "plain": [],
 }
 
@@ -90,6 +92,8 @@ def task_kind(cfg):
         return "seesaw"
     if name == "go1pushbox":
         return "pushbox"
+    if name == "go1rotationCfg":
+        return "rotation"
     if name == "go1football" and cfg.env.num_agents == 3 and npc == "ball":
         return "football_defender"
     return "plain"
@@ -168,7 +172,27 @@ def build_desc(cfg, num_envs, terrain, env_origins, agent_origins, gate_pos=None
         for k in range(3):
             d.npc_box_half[k] = half[k]
         d.npc_contact_cap = 4
-    if d.npc_kind == abi.NPC["seesaw"]:
+    d.seesaw_axis = 1
+    if getattr(cfg.asset, "name_npc", "") == "rotation":
+        # revolving door (rotation_door.urdf): fixed base disk + one box link on a vertical hinge, no joint range, no drive.
+        # It runs on the seesaw code path (same articulation) with the hinge axis switched to +z; the 4 cm base disk is
+        # represented by its inscribed square as the static "platform" box, there is no column.
+        bodies = urdf_model.load_model("rotation", resources_root)["bodies"]
+        base, door = bodies[0], bodies[1]
+        for k in range(3):
+            d.seesaw_joint_offset[k] = door["joint_offset"][k]
+            d.seesaw_plank_center[k] = door["shapes"][0][3][k]
+            d.seesaw_plank_half[k] = door["shapes"][0][1][k]
+        rad, length = base["shapes"][0][1]
+        d.seesaw_base_half[0] = d.seesaw_base_half[1] = rad / math.sqrt(2.0)
+        d.seesaw_base_half[2] = length / 2
+        d.seesaw_plank_mass, d.seesaw_plank_inertia_yy = door["mass"], door["inertia"][2][2]
+        d.seesaw_vel_limit = door["velocity"]
+        d.seesaw_default_angle = 0.0
+        d.seesaw_column_radius = d.seesaw_column_length = 0.0
+        d.seesaw_theta_lo, d.seesaw_theta_hi = -1e9, 1e9
+        d.seesaw_axis = 2
+    elif d.npc_kind == abi.NPC["seesaw"]:
         bodies = urdf_model.load_model("seesaw", resources_root)["bodies"]
         base, plank = bodies[0], bodies[1]
         for k in range(3):
@@ -260,6 +284,9 @@ def build_desc(cfg, num_envs, terrain, env_origins, agent_origins, gate_pos=None
     kw = cfg.terrain.BarrierTrack_kwargs
     if task == "pushbox":
         d.reward_scale[0] = 1.0       # hard-set in the wrapper's constructor after the cfg value was copied (:20)
+    if task == "rotation":            # likewise (go1_rotation_wrapper.py:18-20); the target x = 0.75 * rotation block + wall (:32-35)
+        d.reward_scale[0], d.reward_scale[1], d.reward_scale[2] = 5.0, 1.0, 1.0
+        d.wrapper_param[0] = kw["rotation"]["block_length"] * 0.75 + kw["wall"]["block_length"]
     if task == "gate":
         d.wrapper_param[0] = kw["init"]["block_length"] + kw["gate"]["block_length"] + kw["plane"]["block_length"] / 2
         d.wrapper_param[1] = kw["track_width"] / 4

@@ -14,12 +14,14 @@ from mqe.envs.configs.go1_sheep_config import SingleSheepCfg, NineSheepCfg
 from mqe.envs.configs.go1_football_config import Go1FootballDefenderCfg, Go1Football1vs1Cfg, Go1Football2vs2Cfg
 from mqe.envs.configs.go1_seesaw_config import Go1SeesawCfg
 from mqe.envs.configs.go1_pushbox_config import Go1PushboxCfg
+from mqe.envs.configs.go1_rotation_config import Go1RotationCfg
 
 from mqe.envs.wrappers.empty_wrapper import EmptyWrapper
 from mqe.envs.wrappers.go1_gate_wrapper import Go1GateWrapper
 from mqe.envs.wrappers.go1_sheep_wrapper import Go1SheepWrapper
 from mqe.envs.wrappers.go1_seesaw_wrapper import Go1SeesawWrapper
 from mqe.envs.wrappers.go1_pushbox_wrapper import Go1PushboxWrapper
+from mqe.envs.wrappers.go1_rotation_wrapper import Go1RotationWrapper
 from mqe.envs.wrappers.go1_football_wrapper import Go1FootballDefenderWrapper, Go1FootballGameWrapper
 
 from mqe.utils import get_args, make_env  # noqa: F401
@@ -34,10 +36,11 @@ ENV_DICT = {
     "go1football-2vs2": {"class": Go1Object, "config": Go1Football2vs2Cfg, "wrapper": Go1FootballGameWrapper},
     "go1seesaw": {"class": Go1Object, "config": Go1SeesawCfg, "wrapper": Go1SeesawWrapper},
     "go1pushbox": {"class": Go1Object, "config": Go1PushboxCfg, "wrapper": Go1PushboxWrapper},
+    "go1revolvingdoor": {"class": Go1Object, "config": Go1RotationCfg, "wrapper": Go1RotationWrapper},
 }
 
 # registered by the reference but not built yet
-NOT_YET = ( "go1tug", "go1wrestling", "go1revolvingdoor", "go1bridge")
+NOT_YET = ("go1tug", "go1wrestling", "go1bridge")
 
 
 def make_mqe_env(env_name: str, args=None, custom_cfg=None) -> Tuple[LeggedRobotField, LeggedRobotFieldCfg]:

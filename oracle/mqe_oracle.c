@@ -265,6 +265,7 @@ static int wrapper_dims(const mqe_sim_desc* d, int* Aw, int* D) {
     case MQE_TASK_SEESAW: *Aw = A; *D = 12 + A; break;
     case MQE_TASK_FOOTBALL_DEFENDER: *Aw = 2; *D = 20; break;
     case MQE_TASK_PUSHBOX: *Aw = A; *D = 20 + A; break;
+    case MQE_TASK_ROTATION: *Aw = A; *D = 12; break;
     default: *Aw = A; *D = 6 + A; break; /* plain: [id, base_pos, base_rpy] */
   }
   return 0;
@@ -602,7 +603,7 @@ static void fill_jac(const mqo_sim* s, const envwork_t* w, int act, int body, co
       for (int q = 0; q < 3; q++) J[q][o + 6 + (j - 1)] += sign * dot3(dirs[q], wv);
     }
   } else if (s->d.npc_kind == MQE_NPC_SEESAW) {
-    real ay[3] = {0, 1, 0};
+    real ay[3] = {0, s->d.seesaw_axis == 2 ? 0 : 1, s->d.seesaw_axis == 2 ? 1 : 0};     /* hinge axis: +y plank, +z door */
     real r[3] = {p[0] - npc_pos[0][0], p[1] - npc_pos[0][1], p[2] - npc_pos[0][2]};
     real wv[3]; cross3(ay, r, wv);
     for (int q = 0; q < 3; q++) J[q][A * RD] += sign * dot3(dirs[q], wv);
@@ -746,7 +747,8 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
     for (int k = 0; k < 3; k++) { ssB[k] = rs[k]; npc_pos[0][k] = rs[k] + d->seesaw_joint_offset[k]; }   /* npc_pos[0] = hinge */
     ssTheta = dofs[(12 * A) * 2];
     real c = (real)cos((double)ssTheta), sn = (real)sin((double)ssTheta);
-    ssR[0] = c; ssR[2] = sn; ssR[6] = -sn; ssR[8] = c;                  /* rotation about +y */
+    if (d->seesaw_axis == 2) { ssR[0] = c; ssR[1] = -sn; ssR[3] = sn; ssR[4] = c; }   /* door: rotation about +z */
+    else { ssR[0] = c; ssR[2] = sn; ssR[6] = -sn; ssR[8] = c; }                      /* plank: rotation about +y */
     real pc[3] = {d->seesaw_plank_center[0], d->seesaw_plank_center[1], d->seesaw_plank_center[2]}, pw[3];
     mat3_vec(ssR, pc, pw);
     for (int k = 0; k < 3; k++) ssC[k] = npc_pos[0][k] + pw[k];
@@ -1275,7 +1277,8 @@ static void wrapper_env(mqo_sim* s, int e, int is_reset_call, const float* npc) 
   for (int a = 0; a < Aw; a++) {
     float* o = obs + a * D;
     int c = 0;
-    for (int k = 0; k < Aw; k++) o[c++] = (k == a) ? 1.0f : 0.0f;             /* obs_ids (empty_wrapper.py:18) */
+    if (d->task != MQE_TASK_ROTATION)
+      for (int k = 0; k < Aw; k++) o[c++] = (k == a) ? 1.0f : 0.0f;           /* obs_ids (empty_wrapper.py:18) */
     base_info(s, e * A + a, o + c); c += 6;
     if (d->task != MQE_TASK_PLAIN) { base_info(s, e * A + (Aw - 1 - a), o + c); c += 6; }  /* torch.flip(base_info,[1]) */
     if (d->task == MQE_TASK_GATE || d->task == MQE_TASK_SHEEP || d->task == MQE_TASK_PUSHBOX) { o[c++] = s->gate_pos[e * 2]; o[c++] = s->gate_pos[e * 2 + 1]; }
@@ -1289,6 +1292,31 @@ static void wrapper_env(mqo_sim* s, int e, int is_reset_call, const float* npc) 
       for (int k = 0; k < 3; k++) o[c++] = npc[k] - s->env_origins[e * 3 + k];
       for (int k = 0; k < 3; k++) o[c++] = npc[7 + k];
     }
+  }
+  if (d->task == MQE_TASK_ROTATION) {             /* go1_rotation_wrapper.py:46-50,90-93: agent 1 sees the mirrored scene */
+    float* o1 = obs + 1 * D;
+    o1[1] = -o1[1]; o1[4] = -o1[4]; o1[7] = -o1[7]; o1[10] = -o1[10];
+    const float tgt = d->wrapper_param[0];
+    const float* ob0 = s->obs_bag + (size_t)(e * A) * OBS_BAG;
+    const float* ob1 = s->obs_bag + (size_t)(e * A + 1) * OBS_BAG;
+    if (is_reset_call) {                          /* _init_extras (:30-38): only x is shifted by the target here */
+      s->w_last[e * MAXA] = sqrtf((ob0[0] - tgt) * (ob0[0] - tgt) + ob0[1] * ob0[1]);
+      for (int a = 0; a < Aw; a++) rew[a] = 0;
+      return;
+    }
+    float r0 = 0.0f;
+    if (sc[0] != 0 && ob0[0] > tgt) { r0 += sc[0]; rs[0] += sc[0]; }          /* success: agent 0 past the door line */
+    if (sc[1] != 0 && ob1[0] > tgt) { r0 -= sc[1]; rs[1] += sc[1]; }          /* punishment: the opponent got there */
+    if (sc[2] != 0) {
+      /* `dis[:, :] -= self.target_pos` (:74) broadcasts the (num_envs,) target over the LAST axis, i.e. it is subtracted
+       * from x AND y (and only runs for num_envs in {1, 2} upstream); kept */
+      const float dis = sqrtf((ob0[0] - tgt) * (ob0[0] - tgt) + (ob0[1] - tgt) * (ob0[1] - tgt));
+      if (dis < s->w_last[e * MAXA]) { r0 += sc[2]; rs[2] += sc[2]; }
+      s->w_last[e * MAXA] = dis;
+    }
+    rew[0] = r0;
+    for (int a = 1; a < Aw; a++) rew[a] = 0;
+    return;
   }
   if (is_reset_call) { for (int a = 0; a < Aw; a++) rew[a] = 0; return; }
   float r_env = 0.0f;            /* the (N,1) reward column */

@@ -154,3 +154,21 @@ def test_football_game_tasks_mirror_the_upstream_stub(oracle_backed, task, key, 
     assert env.reward_buffer["step count"] == int(z["step_count"])
     assert torch.isfinite(env.root_states_npc).all() and not torch.equal(env.root_states_npc, ball0)   # the ball is simulated
     env.close()
+
+
+def test_revolving_door_task_surface(oracle_backed):
+    """go1revolvingdoor (reference utils.py:94-98): obs (N,A,12) without one-hot ids, reward (N,A,1) with agent 1's column
+    zero, and the caller's action tensor mirrored in place for agent 1 (go1_rotation_wrapper.py:54)."""
+    a = args_for("go1revolvingdoor", 3)
+    env, cfg = make_mqe_env("go1revolvingdoor", a, custom_cfg(a))
+    assert env.env.num_agents == 2 and env.env.num_npcs == 1 and env.observation_space.shape == (12,)
+    obs = env.reset()
+    assert obs.shape == (3, 2, 12)
+    assert torch.allclose(obs[:, 0, 0:6], obs[:, 1, 6:12] * torch.tensor([1, -1, 1, 1, -1, 1.0]))      # agent 1 sees agent 0 mirrored
+    act = torch.rand(3, 2, 3) * 2 - 1
+    before = act.clone()
+    obs, rew, done, info = env.step(act)
+    assert obs.shape == (3, 2, 12) and rew.shape == (3, 2, 1) and (rew[:, 1] == 0).all() and done.shape == (3,)
+    assert torch.equal(act[:, 0], before[:, 0]) and torch.equal(act[:, 1, 0], before[:, 1, 0]) and torch.equal(act[:, 1, 1:], -before[:, 1, 1:])
+    assert env.dof_state_npc.shape[:2] == (3, 1)                                                        # the door hinge state is exposed
+    env.close()

@@ -12,12 +12,12 @@ from wrapper_replay import wrapper_replay
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", ["gate", "seesaw", "football", "sheep", "football1v1", "football2v2", "pushbox"])
+@pytest.mark.parametrize("name", ["gate", "seesaw", "football", "sheep", "football1v1", "football2v2", "pushbox", "rotation"])
 def test_hip_matches_reference_trace(name):
     assert replay(name, hip_engine)
 
 
-@pytest.mark.parametrize("name", ["sheep_hard", "sheep_easy", "seesaw", "football_defender", "pushbox"])
+@pytest.mark.parametrize("name", ["sheep_hard", "sheep_easy", "seesaw", "football_defender", "pushbox", "rotation"])
 def test_hip_wrappers_match_reference(name):
     assert wrapper_replay(name, hip_engine)
 
@@ -96,7 +96,7 @@ def test_policy_layer0_paths_are_f32_equivalent(monkeypatch, b3, N):
             close(eh.tensor(abi.T_ACTIONS), eo.tensor(abi.T_ACTIONS), atol=5e-5, what=f"policy actions step {t}")
 
 
-@pytest.mark.parametrize("task,N", [("go1gate", 128), ("go1football-defender", 16), ("go1sheep-hard", 14), ("go1seesaw", 16), ("go1football-2vs2", 8), ("go1football-1vs1", 16), ("go1pushbox", 16)])
+@pytest.mark.parametrize("task,N", [("go1gate", 128), ("go1football-defender", 16), ("go1sheep-hard", 14), ("go1seesaw", 16), ("go1football-2vs2", 8), ("go1football-1vs1", 16), ("go1pushbox", 16), ("go1revolvingdoor", 16)])
 def test_fused_rollout_matches_oracle(task, N):
     """20 fused step() calls (policy + 4 substeps + post-step + wrapper) from the seeded reset distribution.
     Contact dynamics amplify rounding differences, so the bound is on the typical (median) deviation and flags."""
@@ -161,6 +161,44 @@ def test_box_contacts_match_oracle():
     torch.cuda.synchronize()
     assert saw_box, "test must exercise robot-box contacts"
     assert torch.isfinite(eh.tensor(abi.T_ROOT_STATE)).all()
+
+
+def test_revolving_door_matches_oracle():
+    """go1revolvingdoor: robots in the sweep of the spinning door (vertical hinge): identical contact lists from identical
+    states, hinge angle tracked over 70 substeps."""
+    N = 16
+    eh, eo, d = _pair("go1revolvingdoor", N)
+    eh.reset_all(); eo.reset_all()
+    torch.cuda.synchronize()
+    ro, do = eo.tensor(abi.T_ROOT_STATE), eo.tensor(abi.T_DOF_STATE)
+    g = torch.Generator().manual_seed(9)
+    A = 2
+    hinge = ro[:, A, :3].clone()
+    do[:, 24, 0] = (torch.rand(N, generator=g) - 0.5) * 1.0
+    do[:, 24, 1] = 1.0 + torch.rand(N, generator=g) * 2.0
+    for r, sy in ((0, 1.0), (1, -1.0)):
+        ro[:, r, 0] = hinge[:, 0] + (torch.rand(N, generator=g) - 0.5) * 0.9
+        ro[:, r, 1] = hinge[:, 1] + sy * (0.35 + torch.rand(N, generator=g) * 0.5)
+        ro[:, r, 2] = 0.33
+    ro[:, :, 7:] = 0
+    do[:, :24, 1] = 0
+    eh.tensor(abi.T_ROOT_STATE).copy_(ro.cuda()); eh.tensor(abi.T_DOF_STATE).copy_(do.cuda())
+    eh.tensor(abi.T_TORQUES).zero_(); eo.tensor(abi.T_TORQUES).zero_()
+    saw_door = False
+    for k in range(70):
+        if k in (0, 30, 60):
+            torch.cuda.synchronize()
+            close(eh.tensor(abi.T_DOF_STATE)[:, 24, 0], eo.tensor(abi.T_DOF_STATE)[:, 24, 0], atol=5e-4, what=f"door angle at substep {k}")
+            eh.tensor(abi.T_ROOT_STATE).copy_(eo.tensor(abi.T_ROOT_STATE).cuda()); eh.tensor(abi.T_DOF_STATE).copy_(eo.tensor(abi.T_DOF_STATE).cuda())
+            for env in range(N):
+                _, ch = eh.debug_dynamics(env, 0)
+                _, _, co = eo.debug_dynamics(env, 0)
+                assert ch.shape == co.shape and (ch[:, :4] == co[:, :4]).all()
+                saw_door |= bool((co[:, 2] == A).any())
+        eh.simulate(); eo.simulate()
+    torch.cuda.synchronize()
+    assert saw_door, "test must exercise door contacts"
+    assert torch.isfinite(eh.tensor(abi.T_ROOT_STATE)).all() and torch.isfinite(eh.tensor(abi.T_DOF_STATE)).all()
 
 
 def test_seesaw_plank_matches_oracle():

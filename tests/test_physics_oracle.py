@@ -173,3 +173,32 @@ def test_box_rests_on_its_face_and_carries_a_robot():
     feet = e.tensor(abi.T_CONTACT_FORCE).reshape(2, -1, 3)[:, [4, 8, 12, 16], 2].sum(-1)
     assert torch.allclose(feet, torch.full((2,), mt * G), rtol=0.15)                           # ... which is what the feet report
     assert torch.isfinite(root).all()
+
+
+def test_revolving_door_spins_freely_and_is_stopped_by_a_robot():
+    """go1revolvingdoor: the door (rotation_door.urdf) is a 1-dof link on a vertical hinge without drive, damping or range:
+    it keeps its angular velocity; a robot standing in its sweep takes the hit through sphere-vs-oriented-box contacts and
+    the door loses (most of) its spin."""
+    e, d, root, dof = fresh("go1revolvingdoor", 2)
+    A = d.num_agents
+    assert d.seesaw_axis == 2 and d.num_npcs == 1
+    root[:, :A, 0] += 5.0                                   # both robots far away
+    dof[:, 12 * A, 1] = 1.0
+    for t in range(50):
+        e.simulate()
+    assert torch.allclose(dof[:, 12 * A, 1], torch.full((2,), 1.0), atol=1e-5)
+    assert torch.allclose(dof[:, 12 * A, 0], torch.full((2,), 50 * d.dt), atol=1e-4)
+    # robot 0 in the path of the +y half of the door (hinge at the NPC base, door half width 0.975 along y at angle 0)
+    hinge = root[:, A, :3].clone()
+    dof[:, 12 * A, 0] = 0.0
+    dof[:, 12 * A, 1] = 2.0                                 # +z spin: the +y half moves towards -x
+    root[:, 0, 0] = hinge[:, 0] - 0.45
+    root[:, 0, 1] = hinge[:, 1] + 0.6
+    root[:, 0, 2] = 0.32
+    root[:, :, 7:] = 0
+    x0 = root[:, 0, 0].clone()
+    for t in range(80):
+        e.simulate()
+    assert torch.isfinite(root).all() and torch.isfinite(dof).all()
+    assert (dof[:, 12 * A, 1] < 1.0).all(), dof[:, 12 * A, 1]                  # the door was braked by the impact
+    assert (root[:, 0, 0] < x0 - 0.02).all(), root[:, 0, 0] - x0              # and the robot was pushed along -x

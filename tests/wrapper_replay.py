@@ -8,7 +8,40 @@ from mqe.engine.desc import REWARD_TERMS
 from helpers import golden, make_desc, to_dev, close
 
 TASK_OF = {"sheep_hard": "go1sheep-hard", "sheep_easy": "go1sheep-easy", "seesaw": "go1seesaw", "football_defender": "go1football-defender",
-           "pushbox": "go1pushbox"}
+           "pushbox": "go1pushbox", "rotation": "go1revolvingdoor"}
+
+
+def _rotation_replay(z, d, keep, make_engine):
+    """go1revolvingdoor: the fixture scripts only base pos / rpy (the wrapper reads nothing else)."""
+    T, N = z["obs"].shape[0], z["obs"].shape[1]
+    A = d.num_agents
+    e = make_engine(d, keep)
+    Tn = e.tensor
+    bagt = Tn(abi.T_OBS_BAG)
+
+    def load(t):
+        bagt[:, 0:3] = to_dev(e, z["base_pos"][t])
+        bagt[:, 3:6] = to_dev(e, z["base_rpy"][t])
+        Tn(abi.T_RESET_BUF).copy_(to_dev(e, z["reset_buf"][t].astype(np.uint8), torch.uint8))
+    load(0)
+    e.wrapper_eval(1)
+    close(Tn(abi.T_WRAPPER_OBS), z["obs_reset"], what="reset obs", atol=1e-6)
+    for t in range(T):
+        load(t + 1)
+        e.wrapper_eval(0)
+        close(Tn(abi.T_WRAPPER_OBS), z["obs"][t], what=f"t{t} obs", atol=1e-6)
+        close(Tn(abi.T_WRAPPER_REWARD), z["reward"][t].reshape(N, A), what=f"t{t} reward", atol=1e-6)
+    sums = Tn(abi.T_REWARD_SUMS).double().sum(0).cpu().numpy()
+    want = dict(zip([str(k) for k in z["reward_buffer_keys"]], z["reward_buffer_vals"]))
+    for i, (_, n) in enumerate(REWARD_TERMS["rotation"]):
+        assert abs(sums[i] - want[n]) <= 1e-4, (n, sums[i], want[n])
+    # the action the reference wrapper handed down: agent 1 mirrored in y / yaw, clipped, scaled
+    act = torch.from_numpy(z["actions"][0].copy())
+    act[:, 1, 1:] = -act[:, 1, 1:]
+    ref = (act.clip(-1, 1) * torch.tensor([2.0, 0.5, 0.5])).reshape(-1, 3)
+    assert torch.allclose(ref, torch.from_numpy(z["env_action"][0]), atol=1e-6)
+    e.close()
+    return True
 
 
 def wrapper_replay(name, make_engine):
@@ -17,8 +50,10 @@ def wrapper_replay(name, make_engine):
     d, keep, ctx = make_desc(TASK_OF[name], N)
     A, P = d.num_agents, d.num_npcs
     # the fixture uses synthetic origins / gate positions: patch the descriptor's per-env constants
-    eo = np.ascontiguousarray(z["env_origins"], np.float32)
     kw = ctx["cfg"].terrain.BarrierTrack_kwargs
+    if name == "rotation":
+        return _rotation_replay(z, d, keep, make_engine)
+    eo = np.ascontiguousarray(z["env_origins"], np.float32)
     gate = np.ascontiguousarray(z["gate_deviation"], np.float32).copy()
     if name.startswith("sheep"):
         gate[:, 0] += kw["init"]["block_length"] + kw["plane"]["block_length"] + kw["gate"]["block_length"] / 2

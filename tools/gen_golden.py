@@ -256,7 +256,7 @@ def make_env(cls, cfg, N, seed=0, P_dofs=0):
 
 def P_bodies(cfg):
     name = getattr(cfg.asset, "name_npc", "")
-    per = {"": 0, "ball": 1, "sheep": 1, "seesaw": 2, "box": 1}[name]
+    per = {"": 0, "ball": 1, "sheep": 1, "seesaw": 2, "box": 1, "rotation": 2}[name]
     return per * getattr(cfg.env, "num_npcs", 0)
 
 
@@ -697,6 +697,39 @@ def gen_game_wrapper():
              obs_dim=np.int64(w.observation_space.shape[0]), step_count=np.int64(w.reward_buffer["step count"]))
 
 
+def gen_rotation_wrapper():
+    """Go1RotationWrapper (go1_rotation_wrapper.py).  Its distance term only broadcasts for num_envs in {1, 2}: N = 2."""
+    from mqe.envs.configs.go1_rotation_config import Go1RotationCfg
+    from mqe.envs.wrappers.go1_rotation_wrapper import Go1RotationWrapper
+    rng = np.random.RandomState(41)
+    T, N = 8, 2
+    cfg = Go1RotationCfg
+    A, P = cfg.env.num_agents, cfg.env.num_npcs
+    fe = FakeEnvForWrapper(cfg, N, A, P)
+    script, rec = [], {}
+    for t in range(T + 1):
+        ob = types.SimpleNamespace()
+        ob.base_pos = torch.tensor(rng.uniform(0, 6, (N * A, 3)).astype(np.float32))
+        ob.base_pos[:, 2] = torch.tensor(rng.uniform(0.2, 0.5, N * A).astype(np.float32))
+        ob.base_rpy = torch.tensor(rng.uniform(0, 6.28, (N * A, 3)).astype(np.float32))
+        script.append(dict(obs_buf=ob, reset_buf=torch.tensor(rng.rand(N) < 0.3)))
+        rec.setdefault("base_pos", []).append(ob.base_pos); rec.setdefault("base_rpy", []).append(ob.base_rpy)
+        rec.setdefault("reset_buf", []).append(script[-1]["reset_buf"])
+    fe.script = script
+    w = Go1RotationWrapper(fe)
+    obs0 = w.reset()
+    acts = rng.uniform(-1.5, 1.5, (T, N, A, 3)).astype(np.float32)
+    obs_l, rew_l, act_l = [], [], []
+    for t in range(T):
+        a_in = torch.from_numpy(acts[t].copy())
+        o, r, term, info = w.step(a_in)
+        obs_l.append(o.clone()); rew_l.append(r.clone()); act_l.append(fe.last_action_in)
+    rb = {k: float(v) for k, v in w.reward_buffer.items()}
+    save("wrapper_rotation", obs_reset=obs0, obs=torch.stack(obs_l), reward=torch.stack(rew_l), env_action=torch.stack(act_l), actions=acts,
+         reward_buffer_keys=np.array(list(rb.keys())), reward_buffer_vals=np.array(list(rb.values()), np.float64),
+         obs_dim=np.int64(w.observation_space.shape[0]), **{k: torch.stack(v, 0) for k, v in rec.items()})
+
+
 def rle_rows(hf):
     """two-level heightfield -> per-row run-length list (value, start, stop)"""
     runs = []
@@ -713,7 +746,7 @@ def rle_rows(hf):
 
 def gen_terrain_and_configs():
     cfgd = {}
-    for task in ("go1gate", "go1sheep-easy", "go1sheep-hard", "go1seesaw", "go1football-defender", "go1football-1vs1", "go1football-2vs2", "go1pushbox"):
+    for task in ("go1gate", "go1sheep-easy", "go1sheep-hard", "go1seesaw", "go1football-defender", "go1football-1vs1", "go1football-2vs2", "go1pushbox", "go1revolvingdoor"):
         cfg = ref_utils.ENV_DICT[task]["config"]
         t = barrier_track_for(cfg, 8)
         hf = t.heightfield_raw
@@ -801,6 +834,11 @@ def main():
         gen_game_wrapper()
     if want("wrapper_pushbox"):
         gen_wrappers(only_pushbox=True)
+    if want("fullstep_rotation"):
+        from mqe.envs.configs.go1_rotation_config import Go1RotationCfg
+        gen_fullstep("fullstep_rotation", Go1Object, Go1RotationCfg, N=2, T=12, act=act, ada=ada)
+    if want("wrapper_rotation"):
+        gen_rotation_wrapper()
     if want("terrain"):
         gen_terrain_and_configs()
     if want("adapter"):
