@@ -159,6 +159,10 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   if (is_body && depth == 0) {
     const float* rs = lds + L.root + (is_rbody ? br : (A + (lane - A * MQE_NBODY))) * 13;
     float x = rs[3], y = rs[4], z = rs[5], w = rs[6];
+    {   // a reset copies the configured quaternion verbatim and go1_wrestling_config.py:68,74 gives (0,0,-+1,1): read it normalised
+      const float inq = 1.0f / sqrtf(x * x + y * y + z * z + w * w);
+      x *= inq; y *= inq; z *= inq; w *= inq;
+    }
     Rm[0] = 1 - 2 * (y * y + z * z); Rm[1] = 2 * (x * y - z * w); Rm[2] = 2 * (x * z + y * w);
     Rm[3] = 2 * (x * y + z * w); Rm[4] = 1 - 2 * (x * x + z * z); Rm[5] = 2 * (y * z - x * w);
     Rm[6] = 2 * (x * z - y * w); Rm[7] = 2 * (y * z + x * w); Rm[8] = 1 - 2 * (x * x + y * y);
@@ -530,6 +534,18 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       } else if (sh <= 0) { wsd = dz - rad; wn = v3(0, 0, 1); }
       else { const float dist = sqrtf(sh * sh + dz * dz); wsd = dist - rad; wn = v3(gx * sh / dist, gy * sh / dist, dz / dist); }
       wflag = wsd < m->contact_offset;
+      if (m->n_static > 0 && act < A) {     // static scenery: the world-aligned box with the smallest signed distance
+        const float I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        const V3 nb = ld3(lds + L.root + A * 13);
+        bsd = 1e3f;
+        for (int bx = 0; bx < m->n_static; bx++) {
+          V3 nn;
+          const float sdb = sphere_box(c, rad, nb + v3(m->sb_center[bx][0], m->sb_center[bx][1], m->sb_center[bx][2]), I3,
+                                       v3(m->sb_half[bx][0], m->sb_half[bx][1], m->sb_half[bx][2]), nn);
+          if (sdb < bsd) { bsd = sdb; bn = nn; }
+        }
+        bflag = bsd < m->contact_offset;
+      }
       if (SS && act < A) {
         const float I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
         bsd = sphere_box(c, rad, ssB, I3, v3(m->ss_base_half[0], m->ss_base_half[1], m->ss_base_half[2]), bn);

@@ -411,7 +411,7 @@ __device__ void wrapper_env_dev(const DevModel* m, const DevState& st, int e, in
   for (int a = 0; a < Aw; a++) {
     float* o = obs + a * D;
     int c = 0;
-    if (m->task != MQE_TASK_ROTATION)
+    if (m->task != MQE_TASK_ROTATION && m->task != MQE_TASK_BRIDGE && m->task != MQE_TASK_WRESTLING)
       for (int k = 0; k < Aw; k++) o[c++] = (k == a) ? 1.0f : 0.0f;
     const float* ob = st.obs_bag + (size_t)(e * A + a) * MQE_OBS_BAG;
     for (int k = 0; k < 6; k++) o[c++] = ob[k];
@@ -430,6 +430,50 @@ __device__ void wrapper_env_dev(const DevModel* m, const DevState& st, int e, in
       for (int k = 0; k < 3; k++) o[c++] = npc[k] - m->env_origins[e * 3 + k];
       for (int k = 0; k < 3; k++) o[c++] = npc[7 + k];
     }
+  }
+  if (m->task == MQE_TASK_BRIDGE) {               // go1_bridge_wrapper.py
+    const float* ob0 = st.obs_bag + (size_t)(e * A) * MQE_OBS_BAG;
+    const float* ob1 = st.obs_bag + (size_t)(e * A + 1) * MQE_OBS_BAG;
+    const float x0 = ob0[0], z0 = ob0[2], x1 = ob1[0], z1 = ob1[2];
+    float S = st.w_last[e * MQE_MAX_AGENTS], tgt = st.w_last[e * MQE_MAX_AGENTS + 1];
+    if (is_reset_call) {                          // _init_extras (:27-29): target_pos = flip(base_pos at reset)
+      S = fabsf(x1 + x0); tgt = x1;
+      st.w_last[e * MQE_MAX_AGENTS] = S; st.w_last[e * MQE_MAX_AGENTS + 1] = tgt;
+    }
+    float* o1 = obs + 1 * D;                      // agent 1 walks the bridge the other way (:37-40, :76-79)
+    o1[0] = S - o1[0]; o1[4] = -o1[4]; o1[6] = S - o1[6]; o1[10] = -o1[10];
+    if (is_reset_call) { for (int a = 0; a < Aw; a++) rew[a] = 0; return; }
+    float r0 = 0.0f;
+    if (sc[0] != 0 && z1 < 0.5f) { r0 += sc[0]; rs[0] += sc[0]; }
+    if (sc[1] != 0 && z0 < 0.5f) { r0 -= sc[1]; rs[1] += sc[1]; }
+    if (sc[2] != 0 && x0 > tgt) { r0 += sc[2]; rs[2] += sc[2]; }
+    rew[0] = r0;
+    for (int a = 1; a < Aw; a++) rew[a] = 0;
+    return;
+  }
+  if (m->task == MQE_TASK_WRESTLING) {            // go1_wrestling_wrapper.py
+    float* o1 = obs + 1 * D;
+    o1[1] = -o1[1]; o1[4] = -o1[4]; o1[7] = -o1[7]; o1[10] = -o1[10];
+    if (is_reset_call) { for (int a = 0; a < Aw; a++) rew[a] = 0; return; }
+    float r0 = 0.0f;
+    bool down0, down1;
+    {
+      const float* ob = st.obs_bag + (size_t)(e * A) * MQE_OBS_BAG;
+      float r = ob[3], p = ob[4];
+      if (r > 3.1415927f) r -= 6.2831855f;
+      if (p > 3.1415927f) p -= 6.2831855f;
+      down0 = fabsf(p) > 3.1415927f * 0.9f || fabsf(r) >= 3.1415927f * 0.4f;
+      ob += MQE_OBS_BAG;
+      r = ob[3]; p = ob[4];
+      if (r > 3.1415927f) r -= 6.2831855f;
+      if (p > 3.1415927f) p -= 6.2831855f;
+      down1 = fabsf(p) > 3.1415927f * 0.9f || fabsf(r) >= 3.1415927f * 0.4f;
+    }
+    if (sc[0] != 0 && down1) { r0 += sc[0]; rs[0] += sc[0]; }
+    if (sc[1] != 0 && down0) { r0 -= sc[1]; rs[1] += sc[1]; }
+    rew[0] = r0;
+    for (int a = 1; a < Aw; a++) rew[a] = 0;
+    return;
   }
   if (m->task == MQE_TASK_ROTATION) {             // go1_rotation_wrapper.py:46-50,90-93: agent 1 sees the mirrored scene
     float* o1 = obs + 1 * D;

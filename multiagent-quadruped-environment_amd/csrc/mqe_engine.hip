@@ -134,7 +134,7 @@ static int wrapper_dims(const mqe_sim_desc* d, int* Aw, int* D) {
     case MQE_TASK_SEESAW: *Aw = A; *D = 12 + A; break;
     case MQE_TASK_FOOTBALL_DEFENDER: *Aw = 2; *D = 20; break;
     case MQE_TASK_PUSHBOX: *Aw = A; *D = 20 + A; break;
-    case MQE_TASK_ROTATION: *Aw = A; *D = 12; break;
+    case MQE_TASK_ROTATION: case MQE_TASK_BRIDGE: case MQE_TASK_WRESTLING: *Aw = A; *D = 12; break;
     default: *Aw = A; *D = 6 + A; break;
   }
   return 0;
@@ -152,7 +152,7 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   const int R = s->R = N * A;
   const int seesaw = d->npc_kind == MQE_NPC_SEESAW;
   s->ND = 12 * A + (seesaw ? P : 0);
-  s->NBR = MQE_NREP * A + (seesaw ? 2 * P : P);
+  s->NBR = MQE_NREP * A + (seesaw ? 2 * P : (d->npc_kind == MQE_NPC_STATIC ? d->npc_reported_bodies * P : P));
   wrapper_dims(d, &s->Aw, &s->D);
   memset(s->tens, 0, sizeof s->tens);
   memset(s->prof_ms, 0, sizeof s->prof_ms);
@@ -174,6 +174,8 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   memcpy(m.npc_sphere_center, d->npc_sphere_center, sizeof m.npc_sphere_center);
   memcpy(m.npc_sphere_radius, d->npc_sphere_radius, sizeof m.npc_sphere_radius);
   m.seesaw_default_angle = d->seesaw_default_angle;
+  m.n_static = d->npc_kind == MQE_NPC_STATIC ? d->n_static_boxes : 0;
+  memcpy(m.sb_center, d->static_box_center, sizeof m.sb_center); memcpy(m.sb_half, d->static_box_half, sizeof m.sb_half);
   m.has_seesaw = seesaw; m.ss_axis = d->seesaw_axis == 2 ? 2 : 1;
   memcpy(m.ss_joint_offset, d->seesaw_joint_offset, 12); memcpy(m.ss_plank_center, d->seesaw_plank_center, 12);
   memcpy(m.ss_plank_half, d->seesaw_plank_half, 12); memcpy(m.ss_base_half, d->seesaw_base_half, 12);

@@ -24,6 +24,8 @@ REWARD_TERMS = {
     "pushbox": [("box_x_movement_reward_scale", "box movement reward")],
     # hard-set in the wrapper's constructor (go1_rotation_wrapper.py:18-20): 5 / 1 / 1, see build_desc
     "rotation": [("success_reward_scale", "success reward"), ("punishment_scale", "punishment"), ("distance_reward_scale", "distance reward")],
+    "bridge": [("success_reward_scale", "success reward"), ("punishment_scale", "punishment"), ("target_reward_scale", "target reward")],
+    "wrestling": [("success_reward_scale", "success reward"), ("punishment_scale", "punishment")],
     "plain": [],
 }
 
@@ -94,6 +96,10 @@ def task_kind(cfg):
         return "pushbox"
     if name == "go1rotationCfg":
         return "rotation"
+    if name == "go1bridge":
+        return "bridge"
+    if name == "go1wrestling":
+        return "wrestling"
     if name == "go1football" and cfg.env.num_agents == 3 and npc == "ball":
         return "football_defender"
     return "plain"
@@ -173,6 +179,26 @@ def build_desc(cfg, num_envs, terrain, env_origins, agent_origins, gate_pos=None
             d.npc_box_half[k] = half[k]
         d.npc_contact_cap = 4
     d.seesaw_axis = 1
+    d.n_static_boxes, d.npc_reported_bodies = 0, 1
+    if d.npc_kind == abi.NPC["bridge"]:
+        # fixed-base scenery (bridge.urdf: deck + two end blocks; wrestling.urdf: the raised field): the collision meshes
+        # are SolidWorks boxes and, after the 90-degree joint rotations, world-aligned; the 3 cm painted rings of the
+        # wrestling field (half height < 2 cm) are left out
+        name = cfg.asset.name_npc
+        scenery = urdf_model.load_model(name, resources_root)["bodies"][0]
+        d.npc_reported_bodies = len(scenery["shapes"])           # one rigid body per URDF link (fixed joints are not merged)
+        n = 0
+        for kind, half, R, t in scenery["shapes"]:
+            Rm = np.abs(np.asarray(R, np.float64))
+            assert kind == "box" and np.allclose(Rm, np.round(Rm), atol=1e-3), "scenery boxes must be world-aligned"
+            hw = Rm @ np.asarray(half, np.float64)
+            if hw[2] < 0.02:
+                continue
+            for k in range(3):
+                d.static_box_center[n][k], d.static_box_half[n][k] = t[k], hw[k]
+            n += 1
+        assert 1 <= n <= 4
+        d.n_static_boxes = n
     if getattr(cfg.asset, "name_npc", "") == "rotation":
         # revolving door (rotation_door.urdf): fixed base disk + one box link on a vertical hinge, no joint range, no drive.
         # It runs on the seesaw code path (same articulation) with the hinge axis switched to +z; the 4 cm base disk is

@@ -51,8 +51,19 @@ def _origin(el):
     return _rpy_to_mat(rpy), xyz
 
 
+def _stl_aabb(path):
+    """(half extents, centre, n_triangles) of a binary STL's bounding box.  The bridge / wrestling scenery ships as
+    SolidWorks STL exports that are plain boxes (12 triangles) plus thin painted rings; the box is what collides."""
+    import struct
+    b = open(path, "rb").read()
+    n = struct.unpack("<I", b[80:84])[0]
+    v = np.frombuffer(b, dtype=np.uint8, count=n * 50, offset=84).reshape(n, 50)[:, 12:48].copy().view(np.float32).reshape(n * 3, 3)
+    lo, hi = v.min(0).astype(np.float64), v.max(0).astype(np.float64)
+    return (hi - lo) / 2, (hi + lo) / 2, n
+
+
 class Link:
-    def __init__(self, el):
+    def __init__(self, el, base_dir=None):
         self.name = el.get("name")
         self.mass = 0.0
         self.com = np.zeros(3)
@@ -77,6 +88,9 @@ class Link:
                 self.shapes.append(("sphere", float(ch.get("radius")), R, t))
             elif ch.tag == "cylinder":
                 self.shapes.append(("cylinder", (float(ch.get("radius")), float(ch.get("length"))), R, t))
+            elif ch.tag == "mesh" and base_dir is not None:
+                half, ctr, ntri = _stl_aabb(os.path.normpath(os.path.join(base_dir, ch.get("filename"))))
+                self.shapes.append(("box", half, R, R @ ctr + t))          # bounding box of the mesh, in the link frame
 
 
 class Joint:
@@ -98,7 +112,7 @@ class Joint:
 
 def parse_urdf(path):
     root = ET.parse(path).getroot()
-    links = {l.get("name"): Link(l) for l in root.findall("link")}
+    links = {l.get("name"): Link(l, os.path.dirname(path)) for l in root.findall("link")}
     joints = [Joint(j) for j in root.findall("joint")]
     children = {j.child for j in joints}
     roots = [n for n in links if n not in children]
@@ -291,7 +305,8 @@ def load_model(name, resources_root=None):
         with open(p) as f:
             return json.load(f)
     rel = {"go1": "robots/go1/urdf/go1.urdf", "ball": "objects/ball.urdf", "sheep": "objects/sheep.urdf",
-           "seesaw": "objects/seesaw.urdf", "box": "objects/box.urdf", "rotation": "objects/rotation_door.urdf"}[name]
+           "seesaw": "objects/seesaw.urdf", "box": "objects/box.urdf", "rotation": "objects/rotation_door.urdf",
+           "bridge": "objects/bridge/urdf/bridge.urdf", "wrestling": "objects/wrestling_field/urdf/wrestling.urdf"}[name]
     path = os.path.join(resources_root, rel)
     return build_go1_model(path) if name == "go1" else build_object_model(path)
 
@@ -300,7 +315,7 @@ if __name__ == "__main__":  # regenerate the json assets from an MQE checkout:  
     import sys
     res = sys.argv[1]
     os.makedirs(ASSET_DIR, exist_ok=True)
-    for nm in ("go1", "ball", "sheep", "seesaw", "box", "rotation"):
+    for nm in ("go1", "ball", "sheep", "seesaw", "box", "rotation", "bridge", "wrestling"):
         mdl = load_model(nm, res)
         with open(os.path.join(ASSET_DIR, f"{nm}_model.json"), "w") as f:
             json.dump(mdl, f, indent=1)

@@ -265,7 +265,7 @@ static int wrapper_dims(const mqe_sim_desc* d, int* Aw, int* D) {
     case MQE_TASK_SEESAW: *Aw = A; *D = 12 + A; break;
     case MQE_TASK_FOOTBALL_DEFENDER: *Aw = 2; *D = 20; break;
     case MQE_TASK_PUSHBOX: *Aw = A; *D = 20 + A; break;
-    case MQE_TASK_ROTATION: *Aw = A; *D = 12; break;
+    case MQE_TASK_ROTATION: case MQE_TASK_BRIDGE: case MQE_TASK_WRESTLING: *Aw = A; *D = 12; break;
     default: *Aw = A; *D = 6 + A; break; /* plain: [id, base_pos, base_rpy] */
   }
   return 0;
@@ -279,7 +279,7 @@ int mqo_sim_create(const mqe_sim_desc* d, mqo_sim** out) {
   int N = s->N = d->num_envs, A = s->A = d->num_agents, P = s->P = d->num_npcs;
   s->R = N * A;
   s->npc_dofs = d->npc_kind == MQE_NPC_SEESAW ? 1 : 0;
-  s->npc_bodies = d->npc_kind == MQE_NPC_SEESAW ? 2 * P : P;
+  s->npc_bodies = d->npc_kind == MQE_NPC_SEESAW ? 2 * P : (d->npc_kind == MQE_NPC_STATIC ? d->npc_reported_bodies * P : P);
   s->ND = 12 * A + s->npc_dofs;
   s->NBR = MQE_NREP * A + s->npc_bodies;
   wrapper_dims(d, &s->Aw, &s->D);
@@ -642,6 +642,11 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
     bodyk_t* bk = w->bk[r];
     const float* rs = root + r * 13;
     real q[4] = {rs[3], rs[4], rs[5], rs[6]};
+    {  /* a reset copies the configured quaternion verbatim and go1_wrestling_config.py:68,74 gives (0,0,-+1,1): the physics
+        * reads it normalised (the integrator writes unit quaternions from then on) */
+      real nq = (real)sqrt((double)(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]));
+      for (int k = 0; k < 4; k++) q[k] /= nq;
+    }
     quat_to_mat(q, bk[0].R);
     for (int k = 0; k < 3; k++) { bk[0].p[k] = rs[k]; bk[0].vp[k] = rs[7 + k]; bk[0].w[k] = rs[10 + k]; bk[0].al[k] = 0; bk[0].ap[k] = 0; bk[0].a[k] = 0; }
     for (int b = 1; b < NB; b++) {
@@ -765,9 +770,21 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
     for (int si = 0; si < w->sph_n[act]; si++) {
       const real* c = w->sph_c[act][si];
       real r = w->sph_r[act][si];
-      for (int pass = 0; pass < (SS && act < A ? 4 : 2); pass++) {
+      const int npass = act < A ? (SS ? 4 : (d->n_static_boxes > 0 ? 3 : 2)) : 2;
+      for (int pass = 0; pass < npass; pass++) {
         real n[3], sd;
         if (pass == 0) { sd = c[2] - d->ground_z - r; n[0] = 0; n[1] = 0; n[2] = 1; }
+        else if (pass == 2 && !SS) { /* static scenery: the world-aligned box with the smallest signed distance */
+          real I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+          const float* nb = root + A * 13;
+          sd = (real)1e3; n[0] = 0; n[1] = 0; n[2] = 1;
+          for (int bx = 0; bx < d->n_static_boxes; bx++) {
+            real bc[3] = {nb[0] + d->static_box_center[bx][0], nb[1] + d->static_box_center[bx][1], nb[2] + d->static_box_center[bx][2]};
+            real hb[3] = {d->static_box_half[bx][0], d->static_box_half[bx][1], d->static_box_half[bx][2]}, nn[3];
+            real sdb = sphere_box(c, r, bc, I3, hb, nn);
+            if (sdb < sd) { sd = sdb; n[0] = nn[0]; n[1] = nn[1]; n[2] = nn[2]; }
+          }
+        }
         else if (pass == 2) {      /* seesaw platform: static axis-aligned box */
           real I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, hb[3] = {d->seesaw_base_half[0], d->seesaw_base_half[1], d->seesaw_base_half[2]};
           sd = sphere_box(c, r, ssB, I3, hb, n);
@@ -1277,7 +1294,7 @@ static void wrapper_env(mqo_sim* s, int e, int is_reset_call, const float* npc) 
   for (int a = 0; a < Aw; a++) {
     float* o = obs + a * D;
     int c = 0;
-    if (d->task != MQE_TASK_ROTATION)
+    if (d->task != MQE_TASK_ROTATION && d->task != MQE_TASK_BRIDGE && d->task != MQE_TASK_WRESTLING)
       for (int k = 0; k < Aw; k++) o[c++] = (k == a) ? 1.0f : 0.0f;           /* obs_ids (empty_wrapper.py:18) */
     base_info(s, e * A + a, o + c); c += 6;
     if (d->task != MQE_TASK_PLAIN) { base_info(s, e * A + (Aw - 1 - a), o + c); c += 6; }  /* torch.flip(base_info,[1]) */
@@ -1292,6 +1309,44 @@ static void wrapper_env(mqo_sim* s, int e, int is_reset_call, const float* npc) 
       for (int k = 0; k < 3; k++) o[c++] = npc[k] - s->env_origins[e * 3 + k];
       for (int k = 0; k < 3; k++) o[c++] = npc[7 + k];
     }
+  }
+  if (d->task == MQE_TASK_BRIDGE) {               /* go1_bridge_wrapper.py */
+    const float* ob0 = s->obs_bag + (size_t)(e * A) * OBS_BAG;
+    const float* ob1 = s->obs_bag + (size_t)(e * A + 1) * OBS_BAG;
+    if (is_reset_call) {                          /* _init_extras (:27-29): target_pos = flip(base_pos at reset) */
+      s->w_last[e * MAXA] = fabsf(ob1[0] + ob0[0]);     /* |target_pos[:,0,0] + target_pos[:,1,0]| */
+      s->w_last[e * MAXA + 1] = ob1[0];                 /* target_pos[:,0,0]: where the opponent started */
+    }
+    const float S = s->w_last[e * MAXA];
+    float* o1 = obs + 1 * D;                      /* agent 1 walks the bridge the other way (:37-40, :76-79) */
+    o1[0] = S - o1[0]; o1[4] = -o1[4]; o1[6] = S - o1[6]; o1[10] = -o1[10];
+    if (is_reset_call) { for (int a = 0; a < Aw; a++) rew[a] = 0; return; }
+    float r0 = 0.0f;
+    if (sc[0] != 0 && ob1[2] < 0.5f) { r0 += sc[0]; rs[0] += sc[0]; }          /* the opponent fell off */
+    if (sc[1] != 0 && ob0[2] < 0.5f) { r0 -= sc[1]; rs[1] += sc[1]; }          /* agent 0 fell off */
+    if (sc[2] != 0 && ob0[0] > s->w_last[e * MAXA + 1]) { r0 += sc[2]; rs[2] += sc[2]; }   /* reached the other side */
+    rew[0] = r0;
+    for (int a = 1; a < Aw; a++) rew[a] = 0;
+    return;
+  }
+  if (d->task == MQE_TASK_WRESTLING) {            /* go1_wrestling_wrapper.py */
+    float* o1 = obs + 1 * D;
+    o1[1] = -o1[1]; o1[4] = -o1[4]; o1[7] = -o1[7]; o1[10] = -o1[10];
+    if (is_reset_call) { for (int a = 0; a < Aw; a++) rew[a] = 0; return; }
+    float r0 = 0.0f;
+    int down[2];
+    for (int a = 0; a < 2; a++) {                 /* roll / pitch of base_quat, wrapped to (-pi, pi] (:58-62) */
+      const float* ob = s->obs_bag + (size_t)(e * A + a) * OBS_BAG;
+      float r = ob[3], p = ob[4];
+      if (r > 3.14159265358979f) r -= 6.28318530717959f;
+      if (p > 3.14159265358979f) p -= 6.28318530717959f;
+      down[a] = fabsf(p) > 3.14159265358979f * 0.9f || fabsf(r) >= 3.14159265358979f * 0.4f;
+    }
+    if (sc[0] != 0 && down[1]) { r0 += sc[0]; rs[0] += sc[0]; }                /* the opponent is on its side / back */
+    if (sc[1] != 0 && down[0]) { r0 -= sc[1]; rs[1] += sc[1]; }
+    rew[0] = r0;
+    for (int a = 1; a < Aw; a++) rew[a] = 0;
+    return;
   }
   if (d->task == MQE_TASK_ROTATION) {             /* go1_rotation_wrapper.py:46-50,90-93: agent 1 sees the mirrored scene */
     float* o1 = obs + 1 * D;

@@ -172,3 +172,20 @@ def test_revolving_door_task_surface(oracle_backed):
     assert torch.equal(act[:, 0], before[:, 0]) and torch.equal(act[:, 1, 0], before[:, 1, 0]) and torch.equal(act[:, 1, 1:], -before[:, 1, 1:])
     assert env.dof_state_npc.shape[:2] == (3, 1)                                                        # the door hinge state is exposed
     env.close()
+
+
+@pytest.mark.parametrize("task,rew_shape", [("go1bridge", (3, 2)), ("go1wrestling", (3, 2, 1))])
+def test_scenery_task_surface(oracle_backed, task, rew_shape):
+    """go1bridge / go1wrestling (reference utils.py:89-103): obs (N,A,12) without ids, agent 0 carries the reward, the caller's
+    action tensor is mirrored in place for agent 1; the two wrappers return differently shaped rewards upstream."""
+    a = args_for(task, 3)
+    env, cfg = make_mqe_env(task, a, custom_cfg(a))
+    assert env.env.num_agents == 2 and env.env.num_npcs == 1 and env.observation_space.shape == (12,)
+    obs = env.reset()
+    assert obs.shape == (3, 2, 12) and torch.isfinite(obs).all()
+    act = torch.rand(3, 2, 3) * 2 - 1
+    before = act.clone()
+    obs, rew, done, info = env.step(act)
+    assert obs.shape == (3, 2, 12) and rew.shape == rew_shape and (rew.reshape(3, 2)[:, 1] == 0).all() and done.shape == (3,)
+    assert torch.equal(act[:, 1, 1:], -before[:, 1, 1:]) and torch.equal(act[:, 0], before[:, 0])
+    env.close()

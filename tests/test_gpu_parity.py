@@ -12,12 +12,12 @@ from wrapper_replay import wrapper_replay
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", ["gate", "seesaw", "football", "sheep", "football1v1", "football2v2", "pushbox", "rotation"])
+@pytest.mark.parametrize("name", ["gate", "seesaw", "football", "sheep", "football1v1", "football2v2", "pushbox", "rotation", "bridge", "wrestling"])
 def test_hip_matches_reference_trace(name):
     assert replay(name, hip_engine)
 
 
-@pytest.mark.parametrize("name", ["sheep_hard", "sheep_easy", "seesaw", "football_defender", "pushbox", "rotation"])
+@pytest.mark.parametrize("name", ["sheep_hard", "sheep_easy", "seesaw", "football_defender", "pushbox", "rotation", "bridge", "wrestling"])
 def test_hip_wrappers_match_reference(name):
     assert wrapper_replay(name, hip_engine)
 
@@ -59,7 +59,7 @@ def test_mass_matrix_inverse_and_contacts(task, N):
             close(ch[:, 4:], co[:, 4:], atol=2e-5, what="contact separation / normal")
 
 
-@pytest.mark.parametrize("task,N", [("go1gate", 256), ("go1football-defender", 32), ("go1sheep-hard", 21), ("go1football-2vs2", 12), ("go1pushbox", 32)])
+@pytest.mark.parametrize("task,N", [("go1gate", 256), ("go1football-defender", 32), ("go1sheep-hard", 21), ("go1football-2vs2", 12), ("go1pushbox", 32), ("go1bridge", 24), ("go1wrestling", 24)])
 def test_single_substep_matches_oracle(task, N):
     """one 5 ms simulate() from identical states: tolerance 2e-4 abs on positions/velocities (float32 both sides;
     the HIP kernel sums in a different order: CRBA + Schur complement vs per-body Jacobian sums + Cholesky)"""
@@ -96,7 +96,7 @@ def test_policy_layer0_paths_are_f32_equivalent(monkeypatch, b3, N):
             close(eh.tensor(abi.T_ACTIONS), eo.tensor(abi.T_ACTIONS), atol=5e-5, what=f"policy actions step {t}")
 
 
-@pytest.mark.parametrize("task,N", [("go1gate", 128), ("go1football-defender", 16), ("go1sheep-hard", 14), ("go1seesaw", 16), ("go1football-2vs2", 8), ("go1football-1vs1", 16), ("go1pushbox", 16), ("go1revolvingdoor", 16)])
+@pytest.mark.parametrize("task,N", [("go1gate", 128), ("go1football-defender", 16), ("go1sheep-hard", 14), ("go1seesaw", 16), ("go1football-2vs2", 8), ("go1football-1vs1", 16), ("go1pushbox", 16), ("go1revolvingdoor", 16), ("go1bridge", 16), ("go1wrestling", 16)])
 def test_fused_rollout_matches_oracle(task, N):
     """20 fused step() calls (policy + 4 substeps + post-step + wrapper) from the seeded reset distribution.
     Contact dynamics amplify rounding differences, so the bound is on the typical (median) deviation and flags."""

@@ -202,3 +202,29 @@ def test_revolving_door_spins_freely_and_is_stopped_by_a_robot():
     assert torch.isfinite(root).all() and torch.isfinite(dof).all()
     assert (dof[:, 12 * A, 1] < 1.0).all(), dof[:, 12 * A, 1]                  # the door was braked by the impact
     assert (root[:, 0, 0] < x0 - 0.02).all(), root[:, 0, 0] - x0              # and the robot was pushed along -x
+
+
+def test_robots_stand_on_the_bridge_and_fall_beside_it():
+    """go1bridge / go1wrestling: fixed scenery = world-aligned boxes (the STL collision meshes are boxes).  Robots dropped at
+    their spawn points come to rest on the end blocks (top 1.02 m) / the field (top 0.5 m); one set down beside the 0.7 m
+    wide deck has nothing under its feet and ends on the ground."""
+    e, d, root, dof = fresh("go1bridge", 2)
+    assert d.n_static_boxes == 3 and d.npc_reported_bodies == 3
+    top = root[0, 2, 2].item() + d.static_box_center[0][2] + d.static_box_half[0][2]
+    assert abs(top - 1.02) < 1e-5
+    a = torch.zeros(2, 2, 3)
+    root[1, 0, 0] = root[1, 2, 0]                                   # env 1: robot 0 next to the middle of the deck
+    root[1, 0, 1] = root[1, 2, 1] + 1.0
+    for t in range(60):
+        e.step(a)
+    assert ((root[0, :2, 2] > top + 0.24) & (root[0, :2, 2] < top + 0.36)).all(), root[0, :2, 2]   # standing on the end blocks
+    assert abs(root[1, 1, 2] - root[0, 1, 2]) < 0.02
+    assert e.tensor(abi.T_RESET_COUNT)[0] == 1 and e.tensor(abi.T_RESET_COUNT)[1] >= 2           # the one beside the deck fell (z_low)
+    e2, d2, root2, dof2 = fresh("go1wrestling", 2)
+    assert d2.n_static_boxes == 1 and d2.npc_reported_bodies == 9
+    for t in range(60):
+        e2.step(a)
+    assert ((root2[:, :2, 2] > 0.5 + 0.24) & (root2[:, :2, 2] < 0.5 + 0.36)).all(), root2[:, :2, 2]
+    q = root2[:, :2, 3:7]
+    assert torch.allclose(q.norm(dim=-1), torch.ones(2, 2), atol=1e-5)                           # (0,0,-+1,1) start quaternions are normalised by the integrator
+    assert (e2.tensor(abi.T_RESET_COUNT) == 1).all()

@@ -8,11 +8,13 @@ from mqe.engine.desc import REWARD_TERMS
 from helpers import golden, make_desc, to_dev, close
 
 TASK_OF = {"sheep_hard": "go1sheep-hard", "sheep_easy": "go1sheep-easy", "seesaw": "go1seesaw", "football_defender": "go1football-defender",
-           "pushbox": "go1pushbox", "rotation": "go1revolvingdoor"}
+           "pushbox": "go1pushbox", "rotation": "go1revolvingdoor",
+           "bridge": "go1bridge", "wrestling": "go1wrestling"}
 
 
-def _rotation_replay(z, d, keep, make_engine):
-    """go1revolvingdoor: the fixture scripts only base pos / rpy (the wrapper reads nothing else)."""
+def _rotation_replay(z, d, keep, make_engine, name="rotation"):
+    """go1revolvingdoor / go1bridge / go1wrestling: the fixtures script only base pos / rpy (the wrappers read nothing else;
+    wrestling's roll / pitch come from base_quat, of which base_rpy is the Euler form)."""
     T, N = z["obs"].shape[0], z["obs"].shape[1]
     A = d.num_agents
     e = make_engine(d, keep)
@@ -33,7 +35,7 @@ def _rotation_replay(z, d, keep, make_engine):
         close(Tn(abi.T_WRAPPER_REWARD), z["reward"][t].reshape(N, A), what=f"t{t} reward", atol=1e-6)
     sums = Tn(abi.T_REWARD_SUMS).double().sum(0).cpu().numpy()
     want = dict(zip([str(k) for k in z["reward_buffer_keys"]], z["reward_buffer_vals"]))
-    for i, (_, n) in enumerate(REWARD_TERMS["rotation"]):
+    for i, (_, n) in enumerate(REWARD_TERMS[name]):
         assert abs(sums[i] - want[n]) <= 1e-4, (n, sums[i], want[n])
     # the action the reference wrapper handed down: agent 1 mirrored in y / yaw, clipped, scaled
     act = torch.from_numpy(z["actions"][0].copy())
@@ -51,8 +53,8 @@ def wrapper_replay(name, make_engine):
     A, P = d.num_agents, d.num_npcs
     # the fixture uses synthetic origins / gate positions: patch the descriptor's per-env constants
     kw = ctx["cfg"].terrain.BarrierTrack_kwargs
-    if name == "rotation":
-        return _rotation_replay(z, d, keep, make_engine)
+    if name in ("rotation", "bridge", "wrestling"):
+        return _rotation_replay(z, d, keep, make_engine, name)
     eo = np.ascontiguousarray(z["env_origins"], np.float32)
     gate = np.ascontiguousarray(z["gate_deviation"], np.float32).copy()
     if name.startswith("sheep"):

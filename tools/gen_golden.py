@@ -256,7 +256,7 @@ def make_env(cls, cfg, N, seed=0, P_dofs=0):
 
 def P_bodies(cfg):
     name = getattr(cfg.asset, "name_npc", "")
-    per = {"": 0, "ball": 1, "sheep": 1, "seesaw": 2, "box": 1, "rotation": 2}[name]
+    per = {"": 0, "ball": 1, "sheep": 1, "seesaw": 2, "box": 1, "rotation": 2, "bridge": 3, "wrestling": 9}[name]
     return per * getattr(cfg.env, "num_npcs", 0)
 
 
@@ -730,6 +730,50 @@ def gen_rotation_wrapper():
          obs_dim=np.int64(w.observation_space.shape[0]), **{k: torch.stack(v, 0) for k, v in rec.items()})
 
 
+def gen_scenery_wrappers():
+    """Go1BridgeWrapper / Go1WrestlingWrapper (fixed scenery tasks): the wrappers read base pos / rpy / quat only."""
+    from isaacgym.torch_utils import quat_from_euler_xyz
+    from mqe.envs.configs.go1_bridge_config import Go1BridgeCfg
+    from mqe.envs.configs.go1_wrestling_config import Go1WrestlingCfg
+    from mqe.envs.wrappers.go1_bridge_wrapper import Go1BridgeWrapper
+    from mqe.envs.wrappers.go1_wrestling_wrapper import Go1WrestlingWrapper
+    T, N = 8, 3
+    for name, cfg, W, seed in (("bridge", Go1BridgeCfg, Go1BridgeWrapper, 51), ("wrestling", Go1WrestlingCfg, Go1WrestlingWrapper, 52)):
+        rng = np.random.RandomState(seed)
+        A, P = cfg.env.num_agents, cfg.env.num_npcs
+        fe = FakeEnvForWrapper(cfg, N, A, P)
+        fe.env_agent_indices = torch.arange(N * A).reshape(N, A)
+        fe.base_init_state = torch.tensor(rng.uniform(0, 2, (N * A, 13)).astype(np.float32))
+        script, rec = [], {}
+        for t in range(T + 1):
+            ob = types.SimpleNamespace()
+            ob.base_pos = torch.tensor(rng.uniform(0, 9, (N * A, 3)).astype(np.float32))
+            ob.base_pos[:, 2] = torch.tensor(rng.uniform(0.2, 1.5, N * A).astype(np.float32))
+            rpy = rng.uniform(-3.1, 3.1, (N * A, 3)).astype(np.float32)
+            rpy[rng.rand(N * A) < 0.5, :2] *= 0.1                      # half of the robots upright
+            q = quat_from_euler_xyz(torch.tensor(rpy[:, 0]), torch.tensor(rpy[:, 1]), torch.tensor(rpy[:, 2]))
+            ob.base_quat = q
+            from isaacgym.torch_utils import get_euler_xyz
+            r_, p_, y_ = get_euler_xyz(q)
+            ob.base_rpy = torch.stack([r_, p_, y_], dim=-1)
+            script.append(dict(obs_buf=ob, reset_buf=torch.tensor(rng.rand(N) < 0.3)))
+            for k in ("base_pos", "base_rpy", "base_quat"):
+                rec.setdefault(k, []).append(getattr(ob, k))
+            rec.setdefault("reset_buf", []).append(script[-1]["reset_buf"])
+        fe.script = script
+        w = W(fe)
+        obs0 = w.reset()
+        acts = rng.uniform(-1.5, 1.5, (T, N, A, 3)).astype(np.float32)
+        obs_l, rew_l, act_l = [], [], []
+        for t in range(T):
+            o, r, term, info = w.step(torch.from_numpy(acts[t].copy()))
+            obs_l.append(o.clone()); rew_l.append(r.clone()); act_l.append(fe.last_action_in)
+        rb = {k: float(v) for k, v in w.reward_buffer.items()}
+        save("wrapper_" + name, obs_reset=obs0, obs=torch.stack(obs_l), reward=torch.stack(rew_l), env_action=torch.stack(act_l), actions=acts,
+             reward_buffer_keys=np.array(list(rb.keys())), reward_buffer_vals=np.array(list(rb.values()), np.float64),
+             obs_dim=np.int64(w.observation_space.shape[0]), **{k: torch.stack(v, 0) for k, v in rec.items()})
+
+
 def rle_rows(hf):
     """two-level heightfield -> per-row run-length list (value, start, stop)"""
     runs = []
@@ -746,7 +790,7 @@ def rle_rows(hf):
 
 def gen_terrain_and_configs():
     cfgd = {}
-    for task in ("go1gate", "go1sheep-easy", "go1sheep-hard", "go1seesaw", "go1football-defender", "go1football-1vs1", "go1football-2vs2", "go1pushbox", "go1revolvingdoor"):
+    for task in ("go1gate", "go1sheep-easy", "go1sheep-hard", "go1seesaw", "go1football-defender", "go1football-1vs1", "go1football-2vs2", "go1pushbox", "go1revolvingdoor", "go1bridge", "go1wrestling"):
         cfg = ref_utils.ENV_DICT[task]["config"]
         t = barrier_track_for(cfg, 8)
         hf = t.heightfield_raw
@@ -839,6 +883,13 @@ def main():
         gen_fullstep("fullstep_rotation", Go1Object, Go1RotationCfg, N=2, T=12, act=act, ada=ada)
     if want("wrapper_rotation"):
         gen_rotation_wrapper()
+    if want("fullstep_scenery"):
+        from mqe.envs.configs.go1_bridge_config import Go1BridgeCfg
+        from mqe.envs.configs.go1_wrestling_config import Go1WrestlingCfg
+        gen_fullstep("fullstep_bridge", Go1Object, Go1BridgeCfg, N=2, T=12, act=act, ada=ada)
+        gen_fullstep("fullstep_wrestling", Go1Object, Go1WrestlingCfg, N=2, T=12, act=act, ada=ada)
+    if want("wrapper_scenery"):
+        gen_scenery_wrappers()
     if want("terrain"):
         gen_terrain_and_configs()
     if want("adapter"):
