@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MQE_ABI_VERSION 4
+#define MQE_ABI_VERSION 5
 #define MQE_MAX_SPHERES 32
 #define MQE_NBODY 13      /* dynamic bodies of one Go1 after fixed-joint collapsing */
 #define MQE_NREP 17       /* reported rigid bodies of one Go1 (feet kept, go1.urdf dont_collapse) */
@@ -39,7 +39,7 @@ extern "C" {
 
 /* tasks whose wrapper observation / reward are evaluated in-kernel (reference mqe/envs/wrappers) */
 enum { MQE_TASK_PLAIN = 0, MQE_TASK_GATE = 1, MQE_TASK_SHEEP = 2, MQE_TASK_SEESAW = 3, MQE_TASK_FOOTBALL_DEFENDER = 4, MQE_TASK_PUSHBOX = 5,
-       MQE_TASK_ROTATION = 6, MQE_TASK_BRIDGE = 7, MQE_TASK_WRESTLING = 8 };
+       MQE_TASK_ROTATION = 6, MQE_TASK_BRIDGE = 7, MQE_TASK_WRESTLING = 8, MQE_TASK_TUG = 9 };
 /* NPC kinds (reference resources/objects/{ball,sheep,seesaw}.urdf) */
 enum { MQE_NPC_NONE = 0, MQE_NPC_BALL = 1, MQE_NPC_SHEEP = 2, MQE_NPC_SEESAW = 3, MQE_NPC_BOX = 4, MQE_NPC_STATIC = 5 };
 /* control types (reference legged_robot.py:368-392 "P","V","T"; go1.py:315-354 "C") */
@@ -102,8 +102,11 @@ typedef struct {
      static boxes, centres relative to the NPC root position; the actor reports `npc_reported_bodies` rigid bodies */
   int32_t n_static_boxes, npc_reported_bodies;
   float static_box_center[4][3], static_box_half[4][3];
-  int32_t seesaw_axis;   /* hinge axis of the 1-dof link: 1 = +y (seesaw plank), 2 = +z (revolving door, rotation_door.urdf:44-50:
-                            same fixed-base + one-link structure, `seesaw_plank_inertia_yy` then holds the inertia about z) */
+  int32_t seesaw_axis;   /* joint of the 1-dof link: 1 = revolute +y (seesaw plank), 2 = revolute +z (revolving door,
+                            rotation_door.urdf:44-50), 3 = prismatic +y (the tug-of-war cylinder, cylinder.urdf:37-43); same
+                            fixed-base + one-link structure, `seesaw_plank_inertia_yy` holds the inertia about the axis resp.
+                            the link mass */
+  int32_t seesaw_link_cylinder;   /* 1: the link is an upright cylinder, radius = seesaw_plank_half[0], half height = [2] */
   /* control (reference go1_config.py:108-155) */
   int32_t control_type;
   float action_scale, hip_scale_reduction, clip_actions;

@@ -63,6 +63,22 @@ __device__ __forceinline__ float sphere_box(V3 c, float r, V3 bc, const float* R
   return sd;
 }
 
+// sphere (centre c, radius r) vs upright solid cylinder (centre bc, radius rc, half height hh): signed distance, normal cylinder->sphere
+__device__ __forceinline__ float sphere_vcyl(V3 c, float r, V3 bc, float rc, float hh, V3& n) {
+  const float dx = c.x - bc.x, dy = c.y - bc.y, dz = c.z - bc.z;
+  const float rho = sqrtf(dx * dx + dy * dy);
+  const float ux = rho > 1e-9f ? dx / rho : 1.0f, uy = rho > 1e-9f ? dy / rho : 0.0f;
+  const float er = rho - rc, ez = fabsf(dz) - hh, sz = dz < 0 ? -1.0f : 1.0f;
+  if (er <= 0 && ez <= 0) {                // centre inside: leave through the nearer surface
+    if (er > ez) { n = v3(ux, uy, 0); return er - r; }
+    n = v3(0, 0, sz); return ez - r;
+  }
+  const float pr = er > 0 ? er : 0.0f, pz = ez > 0 ? ez : 0.0f;
+  const float dist = sqrtf(pr * pr + pz * pz);
+  n = v3(ux * pr / dist, uy * pr / dist, sz * pz / dist);
+  return dist - r;
+}
+
 __device__ __forceinline__ float wave_sum(float x) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
@@ -468,7 +484,8 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     ssPiv = ssB + v3(m->ss_joint_offset[0], m->ss_joint_offset[1], m->ss_joint_offset[2]);
     ssTheta = lds[L.dof + (12 * A) * 2];
     const float cth = cosf(ssTheta), sth = sinf(ssTheta);
-    if (m->ss_axis == 2) { ssR[0] = cth; ssR[1] = -sth; ssR[3] = sth; ssR[4] = cth; }      // door: rotation about +z
+    if (m->ss_axis == 3) ssPiv.y += ssTheta;                                                // slider: translation along +y, no rotation
+    else if (m->ss_axis == 2) { ssR[0] = cth; ssR[1] = -sth; ssR[3] = sth; ssR[4] = cth; }  // door: rotation about +z
     else { ssR[0] = cth; ssR[2] = sth; ssR[6] = -sth; ssR[8] = cth; }                       // plank: rotation about +y
     ssC = ssPiv + mat_vec(ssR, v3(m->ss_plank_center[0], m->ss_plank_center[1], m->ss_plank_center[2]));
   }
@@ -549,7 +566,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       if (SS && act < A) {
         const float I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
         bsd = sphere_box(c, rad, ssB, I3, v3(m->ss_base_half[0], m->ss_base_half[1], m->ss_base_half[2]), bn);
-        bflag = bsd < m->contact_offset;
+        bflag = bsd < m->contact_offset && m->ss_base_half[0] > 0.0f;       // no platform: tug-of-war slider
         const float dx = c.x - ssB.x, dy = c.y - ssB.y, rho = sqrtf(dx * dx + dy * dy);
         if (c.z < ssB.z && c.z > ssB.z - m->ss_col_length && rho > 1e-6f) { csd = rho - m->ss_col_radius - rad; cn3 = v3(dx / rho, dy / rho, 0); cflag = csd < m->contact_offset; }
       }
@@ -622,7 +639,8 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
         const float* sp = lds + L.sph + s * 4;
         c = ld3(sp); rad = sp[3];
         body = rm.sphere_body[lane]; rep = a * MQE_NREP + rm.sphere_reported[lane];
-        sd = sphere_box(c, rad, ssC, ssR, v3(m->ss_plank_half[0], m->ss_plank_half[1], m->ss_plank_half[2]), n);
+        sd = m->ss_link_cyl ? sphere_vcyl(c, rad, ssC, m->ss_plank_half[0], m->ss_plank_half[2], n)
+                            : sphere_box(c, rad, ssC, ssR, v3(m->ss_plank_half[0], m->ss_plank_half[1], m->ss_plank_half[2]), n);
         hit = sd < m->contact_offset;
       }
       const unsigned long long bh = __ballot(hit);
@@ -771,7 +789,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
         }
       } else if (SS) {
         const V3 r0 = p - ssPiv;
-        const V3 wy = cross(m->ss_axis == 2 ? v3(0, 0, 1) : v3(0, 1, 0), r0);
+        const V3 wy = m->ss_axis == 3 ? v3(0, 1, 0) : cross(m->ss_axis == 2 ? v3(0, 0, 1) : v3(0, 1, 0), r0);   // prismatic: the axis itself
         const float j0 = sg * dot(n, wy), j1 = sg * dot(t1, wy), j2 = sg * dot(t2, wy);
         const float ii = 1.0f / m->ss_inertia;
 #pragma unroll

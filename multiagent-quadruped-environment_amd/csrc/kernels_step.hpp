@@ -79,7 +79,8 @@ __global__ void k_wrapper_command(const DevModel* m, DevState st, const float* _
   const float scale[3] = {2.0f, 0.5f, 0.5f};
   for (int a = 0; a < Aw; a++)
     for (int k = 0; k < 3; k++) {
-      float v = clampf(actions[((size_t)e * Aw + a) * 3 + k], -1.0f, 1.0f);
+      float v = actions[((size_t)e * Aw + a) * 3 + k];
+      if (m->task != MQE_TASK_TUG) v = clampf(v, -1.0f, 1.0f);          // the tug wrapper does not clip before scaling
       st.cmd[((size_t)e * A + a) * 3 + k] = m->task == MQE_TASK_PLAIN ? v : v * scale[k];
     }
   if (m->task == MQE_TASK_FOOTBALL_DEFENDER) defender_command_dev(m, st, e, st.cmd + ((size_t)e * A + 2) * 3);
@@ -108,7 +109,8 @@ __global__ void k_pre_policy(const DevModel* m, DevState st, const float* __rest
         defender_command_dev(m, st, e, c3);
         x = c3[k];
       } else if (a < Aw) {
-        const float v = clampf(wrapper_actions[((size_t)e * Aw + a) * 3 + k], -1.0f, 1.0f);
+        float v = wrapper_actions[((size_t)e * Aw + a) * 3 + k];
+        if (m->task != MQE_TASK_TUG) v = clampf(v, -1.0f, 1.0f);        // the tug wrapper does not clip before scaling
         x = m->task == MQE_TASK_PLAIN ? v : v * (k == 0 ? 2.0f : 0.5f);
       } else x = st.cmd[i * 3 + k];
       st.cmd[i * 3 + k] = x;
@@ -402,7 +404,9 @@ __device__ __forceinline__ void step_sheep_env(const DevModel* m, const DevState
 }
 
 // wrapper observation + reward for env e.  npc = the `root_states_npc` rows the wrapper sees ([P][13]); see oracle.
-__device__ void wrapper_env_dev(const DevModel* m, const DevState& st, int e, int is_reset_call, const float* npc) {
+// side_effects: 1 on the wrapper-level paths (mqe_step, mqe_wrapper_eval); the Go1-level mqe_post_physics_step passes 0 so that the
+// state stays exactly what Go1.step leaves (go1tug re-poses its slider from the wrapper)
+__device__ void wrapper_env_dev(const DevModel* m, const DevState& st, int e, int is_reset_call, const float* npc, int side_effects = 1) {
   int A = m->A, P = m->P, Aw = m->Aw, D = m->D;
   float* obs = st.wobs + (size_t)e * Aw * D;
   float* rew = st.wrew + (size_t)e * Aw;
@@ -411,6 +415,16 @@ __device__ void wrapper_env_dev(const DevModel* m, const DevState& st, int e, in
   for (int a = 0; a < Aw; a++) {
     float* o = obs + a * D;
     int c = 0;
+    if (m->task == MQE_TASK_TUG) {                // go1_tug_wrapper.py:47-57: [base info, slider (pos, vel), distance to it, slider pos]
+      const float npos = st.dof[((size_t)e * m->ND + 12 * A) * 2], nvel = st.dof[((size_t)e * m->ND + 12 * A) * 2 + 1];
+      const float sgn = a == 1 ? -1.0f : 1.0f;    // agent 1 sees the mirrored scene: entries 1, 4, 6, 9 negated
+      const float* ob = st.obs_bag + (size_t)(e * A + a) * MQE_OBS_BAG;
+      for (int k = 0; k < 6; k++) o[k] = ob[k];
+      const float dx = o[0] - 1.6f, dy = o[1] - npos;
+      o[1] *= sgn; o[4] *= sgn;
+      o[6] = sgn * npos; o[7] = nvel; o[8] = sqrtf(dx * dx + dy * dy); o[9] = sgn * npos;
+      continue;
+    }
     if (m->task != MQE_TASK_ROTATION && m->task != MQE_TASK_BRIDGE && m->task != MQE_TASK_WRESTLING)
       for (int k = 0; k < Aw; k++) o[c++] = (k == a) ? 1.0f : 0.0f;
     const float* ob = st.obs_bag + (size_t)(e * A + a) * MQE_OBS_BAG;
@@ -430,6 +444,41 @@ __device__ void wrapper_env_dev(const DevModel* m, const DevState& st, int e, in
       for (int k = 0; k < 3; k++) o[c++] = npc[k] - m->env_origins[e * 3 + k];
       for (int k = 0; k < 3; k++) o[c++] = npc[7 + k];
     }
+  }
+  if (m->task == MQE_TASK_TUG) {                  // go1_tug_wrapper.py:59-136
+    float* nd = st.dof + ((size_t)e * m->ND + 12 * A) * 2;
+    const float npos = nd[0];
+    const float* ob0 = st.obs_bag + (size_t)(e * A) * MQE_OBS_BAG;
+    const float* ob1 = st.obs_bag + (size_t)(e * A + 1) * MQE_OBS_BAG;
+    const float x0 = ob0[0], y0 = ob0[1], x1 = ob1[0], y1 = ob1[1];
+    if (is_reset_call) {                          // _init_extras (:37-40)
+      st.w_last[e * MQE_MAX_AGENTS] = x0; st.w_last[e * MQE_MAX_AGENTS + 1] = y0;
+      st.w_last2[e * 2] = npos;
+      st.w_delayed_reset[e] = 0;
+      for (int a = 0; a < Aw; a++) rew[a] = 0;
+      return;
+    }
+    const float last_npc = st.w_last2[e * 2];
+    const float lx = st.w_last[e * MQE_MAX_AGENTS] - 1.6f, ly = st.w_last[e * MQE_MAX_AGENTS + 1] - npos;
+    const float cx = x0 - 1.6f, cy = y0 - npos;
+    const float last_dis = sqrtf(lx * lx + ly * ly), dis = sqrtf(cx * cx + cy * cy);
+    float r0 = 0.0f, sr = 0.0f, pu = 0.0f, pr = 0.0f, pp = 0.0f;
+    if (sc[0] != 0) { if (npos < 0) sr = sc[0] * -npos; if (last_npc <= npos) sr /= 2; r0 += sr; rs[0] += sr; }
+    if (sc[1] != 0) { if (npos > 0) pu = sc[1] * npos; if (last_npc > npos) pu /= 2; r0 -= pu; rs[1] += pu; }
+    if (sc[2] != 0) { if (dis < last_dis) pr = (last_dis - dis) * sc[2]; r0 += pr; rs[2] += pr; }
+    if (sc[3] != 0) { if (dis >= last_dis) pp = powf(2.0f, dis) * sc[3]; r0 -= pp; rs[3] += pp; }
+    rs[4] += npos; rs[5] += pr + sr - pu; rs[6] += x0; rs[7] += y0; rs[8] += x1; rs[9] += y1;
+    st.w_last[e * MQE_MAX_AGENTS] = x0; st.w_last[e * MQE_MAX_AGENTS + 1] = y0;
+    st.w_last2[e * 2] = npos;
+    rew[0] = r0;
+    for (int a = 1; a < Aw; a++) rew[a] = 0;
+    // slider re-zeroed for the two steps that follow an env reset (reset_dic, :61-71), see the oracle
+    if (side_effects) {
+      uint8_t cnt = st.reset_buf[e] ? 2 : st.w_delayed_reset[e];
+      if (cnt > 0) { nd[0] = 0.0f; nd[1] = 0.0f; cnt--; }
+      st.w_delayed_reset[e] = cnt;
+    }
+    return;
   }
   if (m->task == MQE_TASK_BRIDGE) {               // go1_bridge_wrapper.py
     const float* ob0 = st.obs_bag + (size_t)(e * A) * MQE_OBS_BAG;
@@ -653,12 +702,12 @@ __device__ void wrapper_env_dev(const DevModel* m, const DevState& st, int e, in
 #ifndef POST_EPW
 #define POST_EPW 8
 #endif
-__device__ __forceinline__ uint8_t post_physics_env(const DevModel* m, const DevState& st, const int e);
+__device__ __forceinline__ uint8_t post_physics_env(const DevModel* m, const DevState& st, const int e, const int wrapper_level);
 
-__global__ void __launch_bounds__(64) k_post_physics(const DevModel* m, DevState st, int first_steps_done) {
+__global__ void __launch_bounds__(64) k_post_physics(const DevModel* m, DevState st, int wrapper_level) {
   const int e = blockIdx.x * POST_EPW + threadIdx.x;
   uint8_t reset = 0;
-  if (threadIdx.x < POST_EPW && e < m->N) reset = post_physics_env(m, st, e);
+  if (threadIdx.x < POST_EPW && e < m->N) reset = post_physics_env(m, st, e, wrapper_level);
   // go1.py:145: history[agent_ids] = 0 for the envs that reset this step -- rare, so the whole wavefront (the lanes that
   // idled above included) zeroes them, 16 B per lane per request: the f32 ring and, when present, its three bf16 planes
   unsigned long long rm = __ballot(reset != 0);
@@ -677,7 +726,7 @@ __global__ void __launch_bounds__(64) k_post_physics(const DevModel* m, DevState
   }
 }
 
-__device__ __forceinline__ uint8_t post_physics_env(const DevModel* m, const DevState& st, const int e) {
+__device__ __forceinline__ uint8_t post_physics_env(const DevModel* m, const DevState& st, const int e, const int wrapper_level) {
   const int A = m->A, P = m->P;
   const float dtp = m->dt * (float)m->decimation;
   float* root = st.root + (size_t)e * (A + P) * 13;
@@ -810,7 +859,7 @@ __device__ __forceinline__ uint8_t post_physics_env(const DevModel* m, const Dev
 #pragma unroll
       for (int k = 0; k < 4; k++) { ob[63 + k] = clk[a][k]; ob[67 + k] = bq[a][k]; }
     }
-  wrapper_env_dev(m, st, e, 0, npc_pre);
+  wrapper_env_dev(m, st, e, 0, npc_pre, wrapper_level);
   return reset;
 }
 

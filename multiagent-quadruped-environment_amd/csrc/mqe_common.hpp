@@ -33,7 +33,7 @@ struct DevModel {
   int has_box, cap_npc; float npc_box_half[3];     // MQE_NPC_BOX: robots' spheres vs the oriented box; terrain contacts kept per NPC
   float seesaw_default_angle;
   int n_static; float sb_center[4][3], sb_half[4][3];     // MQE_NPC_STATIC: world-aligned scenery boxes on the NPC root
-  int has_seesaw, ss_axis; float ss_joint_offset[3], ss_plank_center[3], ss_plank_half[3], ss_base_half[3];
+  int has_seesaw, ss_axis, ss_link_cyl; float ss_joint_offset[3], ss_plank_center[3], ss_plank_half[3], ss_base_half[3];
   float ss_inertia, ss_vel_limit, ss_col_radius, ss_col_length, ss_theta_lo, ss_theta_hi;
   int control_type; float action_scale, hip_scale_reduction, clip_actions; float torque_limits[12]; float kp, kd;
   float default_dof_pos[12]; float command_obs[70]; float cmd_lin_scale, cmd_ang_scale; int clip_command;

@@ -135,6 +135,7 @@ static int wrapper_dims(const mqe_sim_desc* d, int* Aw, int* D) {
     case MQE_TASK_FOOTBALL_DEFENDER: *Aw = 2; *D = 20; break;
     case MQE_TASK_PUSHBOX: *Aw = A; *D = 20 + A; break;
     case MQE_TASK_ROTATION: case MQE_TASK_BRIDGE: case MQE_TASK_WRESTLING: *Aw = A; *D = 12; break;
+    case MQE_TASK_TUG: *Aw = A; *D = 10; break;
     default: *Aw = A; *D = 6 + A; break;
   }
   return 0;
@@ -176,7 +177,7 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   m.seesaw_default_angle = d->seesaw_default_angle;
   m.n_static = d->npc_kind == MQE_NPC_STATIC ? d->n_static_boxes : 0;
   memcpy(m.sb_center, d->static_box_center, sizeof m.sb_center); memcpy(m.sb_half, d->static_box_half, sizeof m.sb_half);
-  m.has_seesaw = seesaw; m.ss_axis = d->seesaw_axis == 2 ? 2 : 1;
+  m.has_seesaw = seesaw; m.ss_axis = (d->seesaw_axis == 2 || d->seesaw_axis == 3) ? d->seesaw_axis : 1; m.ss_link_cyl = d->seesaw_link_cylinder;
   memcpy(m.ss_joint_offset, d->seesaw_joint_offset, 12); memcpy(m.ss_plank_center, d->seesaw_plank_center, 12);
   memcpy(m.ss_plank_half, d->seesaw_plank_half, 12); memcpy(m.ss_base_half, d->seesaw_base_half, 12);
   m.ss_inertia = d->seesaw_plank_inertia_yy; m.ss_vel_limit = d->seesaw_vel_limit;
@@ -504,9 +505,9 @@ static void launch_simulate(mqe_sim* s, hipStream_t q) {
   PhysDebug dbg = {nullptr, nullptr, nullptr, 0, nullptr};
   hipLaunchKernelGGL(k_simulate, dim3(s->N), dim3(64), s->phys_lds_bytes, q, s->dm, s->st, 0, 0, dbg);
 }
-static void launch_post(mqe_sim* s, hipStream_t q) {
+static void launch_post(mqe_sim* s, hipStream_t q, int wrapper_level) {
   ProfScope ps(s, PROF_POST, q);
-  hipLaunchKernelGGL(k_post_physics, dim3((s->N + POST_EPW - 1) / POST_EPW), dim3(64), 0, q, s->dm, s->st, s->n_post_steps);   // incl. history zeroing
+  hipLaunchKernelGGL(k_post_physics, dim3((s->N + POST_EPW - 1) / POST_EPW), dim3(64), 0, q, s->dm, s->st, wrapper_level);   // incl. history zeroing
   s->n_post_steps++;
 }
 
@@ -538,7 +539,7 @@ extern "C" int mqe_post_decimation_step(mqe_sim* s, int dec_i, void* stream) {
   return 0;
 }
 extern "C" int mqe_post_physics_step(mqe_sim* s, void* stream) {
-  launch_post(s, (hipStream_t)stream);
+  launch_post(s, (hipStream_t)stream, 0);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -572,7 +573,7 @@ extern "C" int mqe_step(mqe_sim* s, const float* actions, void* stream) {
       launch_simulate(s, q);
     }
   }
-  launch_post(s, q);
+  launch_post(s, q, 1);
   HIPCHK(hipGetLastError());
   return 0;
 }

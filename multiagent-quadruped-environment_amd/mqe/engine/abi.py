@@ -1,13 +1,13 @@
 """ctypes mirror of include/mqe_hip.h (keep in sync; tests/test_abi.py checks sizes against the built library)."""
 import ctypes as C
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_SPHERES, NBODY, NREP, NDOF = 32, 13, 17, 12
 MAX_AGENTS, MAX_NPCS, FRAME, HIST, MAX_LAYERS, MAX_REWARD_TERMS = 4, 9, 72, 30, 6, 12
 OBS_BAG = 74
 
-TASK = dict(plain=0, gate=1, sheep=2, seesaw=3, football_defender=4, pushbox=5, rotation=6, bridge=7, wrestling=8)
-NPC = dict(none=0, ball=1, sheep=2, seesaw=3, box=4, rotation=3, bridge=5, wrestling=5)     # the revolving door shares the seesaw's fixed-base + 1-dof-link structure
+TASK = dict(plain=0, gate=1, sheep=2, seesaw=3, football_defender=4, pushbox=5, rotation=6, bridge=7, wrestling=8, tug=9)
+NPC = dict(none=0, ball=1, sheep=2, seesaw=3, box=4, rotation=3, bridge=5, wrestling=5, circular=3)     # the revolving door shares the seesaw's fixed-base + 1-dof-link structure
 CTRL = dict(C=0, P=1, V=2, T=3)
 TERM = dict(roll=1, pitch=2, z_low=4, z_high=8)
 
@@ -55,7 +55,7 @@ class SimDesc(C.Structure):
         ("seesaw_plank_mass", f32), ("seesaw_plank_inertia_yy", f32), ("seesaw_vel_limit", f32), ("seesaw_default_angle", f32),
         ("seesaw_column_radius", f32), ("seesaw_column_length", f32), ("seesaw_theta_lo", f32), ("seesaw_theta_hi", f32),
         ("n_static_boxes", i32), ("npc_reported_bodies", i32), ("static_box_center", (f32 * 3) * 4), ("static_box_half", (f32 * 3) * 4),
-        ("seesaw_axis", i32),
+        ("seesaw_axis", i32), ("seesaw_link_cylinder", i32),
         ("control_type", i32), ("action_scale", f32), ("hip_scale_reduction", f32), ("clip_actions", f32),
         ("torque_limits", f32 * NDOF), ("kp", f32), ("kd", f32), ("default_dof_pos", f32 * NDOF),
         ("command_obs", f32 * 70), ("cmd_lin_scale", f32), ("cmd_ang_scale", f32), ("clip_command", i32),

@@ -26,6 +26,10 @@ REWARD_TERMS = {
     "rotation": [("success_reward_scale", "success reward"), ("punishment_scale", "punishment"), ("distance_reward_scale", "distance reward")],
     "bridge": [("success_reward_scale", "success reward"), ("punishment_scale", "punishment"), ("target_reward_scale", "target reward")],
     "wrestling": [("success_reward_scale", "success reward"), ("punishment_scale", "punishment")],
+    # go1_tug_wrapper.py:21-33: four reward terms and six running logs of positions share the reward_buffer
+    "tug": [("success_reward_scale", "success reward"), ("punishment_reward_scale", "punishment"), ("pos_reward_scale", "pos reward"),
+            ("pos_punishment_scale", "pos punishment"), (None, "npc pos"), (None, "total reward"), (None, "pos"), (None, "pos_y"),
+            (None, "opponet pos"), (None, "opponet pos_y")],
     "plain": [],
 }
 
@@ -96,6 +100,8 @@ def task_kind(cfg):
         return "pushbox"
     if name == "go1rotationCfg":
         return "rotation"
+    if name == "go1tug":
+        return "tug"
     if name == "go1bridge":
         return "bridge"
     if name == "go1wrestling":
@@ -218,6 +224,25 @@ def build_desc(cfg, num_envs, terrain, env_origins, agent_origins, gate_pos=None
         d.seesaw_column_radius = d.seesaw_column_length = 0.0
         d.seesaw_theta_lo, d.seesaw_theta_hi = -1e9, 1e9
         d.seesaw_axis = 2
+    elif getattr(cfg.asset, "name_npc", "") == "circular":
+        # tug-of-war disc (cylinder.urdf): fixed 1 mm base + an upright cylinder (r 1.2, collision height 0.5) on a prismatic
+        # +y joint, range +-10 m, velocity limit 1 m/s, no drive: the 1-dof link path again, with a translating link
+        bodies = urdf_model.load_model("circular", resources_root)["bodies"]
+        disc = bodies[1]
+        kind, (rad, length), _, tc = disc["shapes"][0]
+        assert kind == "cylinder"
+        for k in range(3):
+            d.seesaw_joint_offset[k] = disc["joint_offset"][k]
+            d.seesaw_plank_center[k] = tc[k]
+            d.seesaw_base_half[k] = 0.0
+        d.seesaw_plank_half[0] = d.seesaw_plank_half[1] = rad
+        d.seesaw_plank_half[2] = length / 2
+        d.seesaw_plank_mass = d.seesaw_plank_inertia_yy = disc["mass"]      # generalized inertia of a slider = its mass
+        d.seesaw_vel_limit = disc["velocity"]
+        d.seesaw_default_angle = 0.0
+        d.seesaw_column_radius = d.seesaw_column_length = 0.0
+        d.seesaw_theta_lo, d.seesaw_theta_hi = disc["lower"], disc["upper"]
+        d.seesaw_axis, d.seesaw_link_cylinder = 3, 1
     elif d.npc_kind == abi.NPC["seesaw"]:
         bodies = urdf_model.load_model("seesaw", resources_root)["bodies"]
         base, plank = bodies[0], bodies[1]
@@ -306,7 +331,8 @@ def build_desc(cfg, num_envs, terrain, env_origins, agent_origins, gate_pos=None
     d.sheep_movement_scale = getattr(cfg.asset, "sheep_movement_scale", 0.0)
     d.sheep_movement_randomness = getattr(cfg.asset, "sheep_movement_randomness", 0.0)
     for i, (attr, _) in enumerate(REWARD_TERMS[task]):
-        d.reward_scale[i] = float(getattr(cfg.rewards.scales, attr, 0.0))
+        if attr is not None:
+            d.reward_scale[i] = float(getattr(cfg.rewards.scales, attr, 0.0))
     kw = cfg.terrain.BarrierTrack_kwargs
     if task == "pushbox":
         d.reward_scale[0] = 1.0       # hard-set in the wrapper's constructor after the cfg value was copied (:20)

@@ -16,6 +16,7 @@ from mqe.envs.configs.go1_seesaw_config import Go1SeesawCfg
 from mqe.envs.configs.go1_pushbox_config import Go1PushboxCfg
 from mqe.envs.configs.go1_rotation_config import Go1RotationCfg
 from mqe.envs.configs.go1_bridge_config import Go1BridgeCfg
+from mqe.envs.configs.go1_tug_config import Go1TugCfg
 from mqe.envs.configs.go1_wrestling_config import Go1WrestlingCfg
 
 from mqe.envs.wrappers.empty_wrapper import EmptyWrapper
@@ -25,6 +26,7 @@ from mqe.envs.wrappers.go1_seesaw_wrapper import Go1SeesawWrapper
 from mqe.envs.wrappers.go1_pushbox_wrapper import Go1PushboxWrapper
 from mqe.envs.wrappers.go1_rotation_wrapper import Go1RotationWrapper
 from mqe.envs.wrappers.go1_bridge_wrapper import Go1BridgeWrapper
+from mqe.envs.wrappers.go1_tug_wrapper import Go1TugWrapper
 from mqe.envs.wrappers.go1_wrestling_wrapper import Go1WrestlingWrapper
 from mqe.envs.wrappers.go1_football_wrapper import Go1FootballDefenderWrapper, Go1FootballGameWrapper
 
@@ -41,12 +43,13 @@ ENV_DICT = {
     "go1seesaw": {"class": Go1Object, "config": Go1SeesawCfg, "wrapper": Go1SeesawWrapper},
     "go1pushbox": {"class": Go1Object, "config": Go1PushboxCfg, "wrapper": Go1PushboxWrapper},
     "go1revolvingdoor": {"class": Go1Object, "config": Go1RotationCfg, "wrapper": Go1RotationWrapper},
+    "go1tug": {"class": Go1Object, "config": Go1TugCfg, "wrapper": Go1TugWrapper},
     "go1bridge": {"class": Go1Object, "config": Go1BridgeCfg, "wrapper": Go1BridgeWrapper},
     "go1wrestling": {"class": Go1Object, "config": Go1WrestlingCfg, "wrapper": Go1WrestlingWrapper},
 }
 
 # registered by the reference but not built yet
-NOT_YET = ("go1tug",)
+NOT_YET = ()
 
 
 def make_mqe_env(env_name: str, args=None, custom_cfg=None) -> Tuple[LeggedRobotField, LeggedRobotFieldCfg]:

@@ -306,7 +306,7 @@ def load_model(name, resources_root=None):
             return json.load(f)
     rel = {"go1": "robots/go1/urdf/go1.urdf", "ball": "objects/ball.urdf", "sheep": "objects/sheep.urdf",
            "seesaw": "objects/seesaw.urdf", "box": "objects/box.urdf", "rotation": "objects/rotation_door.urdf",
-           "bridge": "objects/bridge/urdf/bridge.urdf", "wrestling": "objects/wrestling_field/urdf/wrestling.urdf"}[name]
+           "bridge": "objects/bridge/urdf/bridge.urdf", "circular": "objects/cylinder.urdf", "wrestling": "objects/wrestling_field/urdf/wrestling.urdf"}[name]
     path = os.path.join(resources_root, rel)
     return build_go1_model(path) if name == "go1" else build_object_model(path)
 
@@ -315,7 +315,7 @@ if __name__ == "__main__":  # regenerate the json assets from an MQE checkout:  
     import sys
     res = sys.argv[1]
     os.makedirs(ASSET_DIR, exist_ok=True)
-    for nm in ("go1", "ball", "sheep", "seesaw", "box", "rotation", "bridge", "wrestling"):
+    for nm in ("go1", "ball", "sheep", "seesaw", "box", "rotation", "bridge", "wrestling", "circular"):
         mdl = load_model(nm, res)
         with open(os.path.join(ASSET_DIR, f"{nm}_model.json"), "w") as f:
             json.dump(mdl, f, indent=1)

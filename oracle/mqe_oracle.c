@@ -58,6 +58,7 @@ typedef struct mqo_sim {
   mqe_sim_desc d;
   int N, A, P, R, ND, NBR, Aw, D;   /* ND dofs per env in DOF_STATE, NBR reported bodies per env, Aw wrapper agents */
   int npc_dofs, npc_bodies;
+  int wrapper_side_effects;   /* 1 while a wrapper-level call runs (mqo_step / mqo_wrapper_eval): go1tug re-poses its slider */
   mlp_t act, ada, body;
   float* sdf;
   float *env_origins, *agent_origins, *base_init, *npc_init, *gate_pos;
@@ -266,6 +267,7 @@ static int wrapper_dims(const mqe_sim_desc* d, int* Aw, int* D) {
     case MQE_TASK_FOOTBALL_DEFENDER: *Aw = 2; *D = 20; break;
     case MQE_TASK_PUSHBOX: *Aw = A; *D = 20 + A; break;
     case MQE_TASK_ROTATION: case MQE_TASK_BRIDGE: case MQE_TASK_WRESTLING: *Aw = A; *D = 12; break;
+    case MQE_TASK_TUG: *Aw = A; *D = 10; break;
     default: *Aw = A; *D = 6 + A; break; /* plain: [id, base_pos, base_rpy] */
   }
   return 0;
@@ -503,6 +505,21 @@ static real sdf_sample(const mqo_sim* s, real x, real y, real* gx, real* gy) {
 
 /* sphere (centre c, radius r) vs box (centre bc, rotation R row-major, half extents h): signed distance and world
  * normal pointing from the box to the sphere */
+/* sphere (centre c, radius r) vs upright solid cylinder (centre bc, radius rc, half height hh): signed distance, normal cylinder->sphere */
+static real sphere_vcyl(const real* c, real r, const real* bc, real rc, real hh, real* n) {
+  real dx = c[0] - bc[0], dy = c[1] - bc[1], dz = c[2] - bc[2];
+  real rho = (real)sqrt((double)(dx * dx + dy * dy));
+  real ux = rho > (real)1e-9 ? dx / rho : 1, uy = rho > (real)1e-9 ? dy / rho : 0;
+  real er = rho - rc, ez = (dz < 0 ? -dz : dz) - hh, sz = dz < 0 ? (real)-1 : (real)1;
+  if (er <= 0 && ez <= 0) {                /* centre inside: leave through the nearer surface */
+    if (er > ez) { n[0] = ux; n[1] = uy; n[2] = 0; return er - r; }
+    n[0] = 0; n[1] = 0; n[2] = sz; return ez - r;
+  }
+  real pr = er > 0 ? er : 0, pz = ez > 0 ? ez : 0;
+  real dist = (real)sqrt((double)(pr * pr + pz * pz));
+  n[0] = ux * pr / dist; n[1] = uy * pr / dist; n[2] = sz * pz / dist;
+  return dist - r;
+}
 static real sphere_box(const real* c, real r, const real* bc, const real* R, const real* h, real* n) {
   real d[3] = {c[0] - bc[0], c[1] - bc[1], c[2] - bc[2]}, pl[3], q[3], dl[3];
   for (int k = 0; k < 3; k++) pl[k] = R[k] * d[0] + R[3 + k] * d[1] + R[6 + k] * d[2];     /* R^T d */
@@ -603,9 +620,10 @@ static void fill_jac(const mqo_sim* s, const envwork_t* w, int act, int body, co
       for (int q = 0; q < 3; q++) J[q][o + 6 + (j - 1)] += sign * dot3(dirs[q], wv);
     }
   } else if (s->d.npc_kind == MQE_NPC_SEESAW) {
-    real ay[3] = {0, s->d.seesaw_axis == 2 ? 0 : 1, s->d.seesaw_axis == 2 ? 1 : 0};     /* hinge axis: +y plank, +z door */
+    real ay[3] = {0, s->d.seesaw_axis == 2 ? 0 : 1, s->d.seesaw_axis == 2 ? 1 : 0};     /* joint axis: +y plank / slider, +z door */
     real r[3] = {p[0] - npc_pos[0][0], p[1] - npc_pos[0][1], p[2] - npc_pos[0][2]};
     real wv[3]; cross3(ay, r, wv);
+    if (s->d.seesaw_axis == 3) { wv[0] = ay[0]; wv[1] = ay[1]; wv[2] = ay[2]; }         /* prismatic: the point moves with the axis */
     for (int q = 0; q < 3; q++) J[q][A * RD] += sign * dot3(dirs[q], wv);
   } else {
     int pi = act - A, o = A * RD + pi * 6;
@@ -752,6 +770,7 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
     for (int k = 0; k < 3; k++) { ssB[k] = rs[k]; npc_pos[0][k] = rs[k] + d->seesaw_joint_offset[k]; }   /* npc_pos[0] = hinge */
     ssTheta = dofs[(12 * A) * 2];
     real c = (real)cos((double)ssTheta), sn = (real)sin((double)ssTheta);
+    if (d->seesaw_axis == 3) { c = 1; sn = 0; npc_pos[0][1] += ssTheta; }             /* slider: translation along +y, no rotation */
     if (d->seesaw_axis == 2) { ssR[0] = c; ssR[1] = -sn; ssR[3] = sn; ssR[4] = c; }   /* door: rotation about +z */
     else { ssR[0] = c; ssR[2] = sn; ssR[6] = -sn; ssR[8] = c; }                      /* plank: rotation about +y */
     real pc[3] = {d->seesaw_plank_center[0], d->seesaw_plank_center[1], d->seesaw_plank_center[2]}, pw[3];
@@ -787,7 +806,7 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
         }
         else if (pass == 2) {      /* seesaw platform: static axis-aligned box */
           real I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, hb[3] = {d->seesaw_base_half[0], d->seesaw_base_half[1], d->seesaw_base_half[2]};
-          sd = sphere_box(c, r, ssB, I3, hb, n);
+          sd = hb[0] > 0 ? sphere_box(c, r, ssB, I3, hb, n) : (real)1e3;     /* no platform: tug-of-war slider */
         } else if (pass == 3) {    /* column under the platform: static vertical cylinder, lateral surface only */
           real dx = c[0] - ssB[0], dy = c[1] - ssB[1];
           real rho = (real)sqrt((double)(dx * dx + dy * dy));
@@ -830,7 +849,7 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
         const real* c = w->sph_c[act][si];
         real r = w->sph_r[act][si], n[3];
         real hp[3] = {d->seesaw_plank_half[0], d->seesaw_plank_half[1], d->seesaw_plank_half[2]};
-        real sd = sphere_box(c, r, ssC, ssR, hp, n);
+        real sd = d->seesaw_link_cylinder ? sphere_vcyl(c, r, ssC, hp[0], hp[2], n) : sphere_box(c, r, ssC, ssR, hp, n);
         if (sd < d->contact_offset && w->nc < pair_lim && mine < (maxc / 2) / A) {
           mine++;
           contact_t* ct = &w->con[w->nc++];
@@ -1294,6 +1313,15 @@ static void wrapper_env(mqo_sim* s, int e, int is_reset_call, const float* npc) 
   for (int a = 0; a < Aw; a++) {
     float* o = obs + a * D;
     int c = 0;
+    if (d->task == MQE_TASK_TUG) {                /* go1_tug_wrapper.py:47-53: [base info, slider (pos, vel), distance to it, slider pos] */
+      const float npos = s->dof[((size_t)e * s->ND + 12 * A) * 2], nvel = s->dof[((size_t)e * s->ND + 12 * A) * 2 + 1];
+      const float sgn = a == 1 ? -1.0f : 1.0f;    /* agent 1 sees the mirrored scene: entries 1, 4, 6, 9 negated (:54-57) */
+      base_info(s, e * A + a, o);
+      const float dx = o[0] - 1.6f, dy = o[1] - npos;
+      o[1] *= sgn; o[4] *= sgn;
+      o[6] = sgn * npos; o[7] = nvel; o[8] = sqrtf(dx * dx + dy * dy); o[9] = sgn * npos;   /* last_npc_pos was just refreshed (:120) */
+      continue;
+    }
     if (d->task != MQE_TASK_ROTATION && d->task != MQE_TASK_BRIDGE && d->task != MQE_TASK_WRESTLING)
       for (int k = 0; k < Aw; k++) o[c++] = (k == a) ? 1.0f : 0.0f;           /* obs_ids (empty_wrapper.py:18) */
     base_info(s, e * A + a, o + c); c += 6;
@@ -1309,6 +1337,40 @@ static void wrapper_env(mqo_sim* s, int e, int is_reset_call, const float* npc) 
       for (int k = 0; k < 3; k++) o[c++] = npc[k] - s->env_origins[e * 3 + k];
       for (int k = 0; k < 3; k++) o[c++] = npc[7 + k];
     }
+  }
+  if (d->task == MQE_TASK_TUG) {                  /* go1_tug_wrapper.py:59-136 */
+    float* nd = s->dof + ((size_t)e * s->ND + 12 * A) * 2;
+    const float npos = nd[0];
+    const float* ob0 = s->obs_bag + (size_t)(e * A) * OBS_BAG;
+    const float* ob1 = s->obs_bag + (size_t)(e * A + 1) * OBS_BAG;
+    if (is_reset_call) {                          /* _init_extras (:37-40) */
+      s->w_last[e * MAXA] = ob0[0]; s->w_last[e * MAXA + 1] = ob0[1];
+      s->w_last2[e * 2] = npos;
+      s->w_delayed_reset[e] = 0;
+      for (int a = 0; a < Aw; a++) rew[a] = 0;
+      return;
+    }
+    const float last_npc = s->w_last2[e * 2];
+    const float lx = s->w_last[e * MAXA] - 1.6f, ly = s->w_last[e * MAXA + 1] - npos;      /* last base pos vs the CURRENT slider pos (:74-77) */
+    const float cx = ob0[0] - 1.6f, cy = ob0[1] - npos;
+    const float last_dis = sqrtf(lx * lx + ly * ly), dis = sqrtf(cx * cx + cy * cy);
+    float r0 = 0.0f, sr = 0.0f, pu = 0.0f, pr = 0.0f, pp = 0.0f;
+    if (sc[0] != 0) { if (npos < 0) sr = sc[0] * -npos; if (last_npc <= npos) sr /= 2; r0 += sr; rs[0] += sr; }
+    if (sc[1] != 0) { if (npos > 0) pu = sc[1] * npos; if (last_npc > npos) pu /= 2; r0 -= pu; rs[1] += pu; }
+    if (sc[2] != 0) { if (dis < last_dis) pr = (last_dis - dis) * sc[2]; r0 += pr; rs[2] += pr; }
+    if (sc[3] != 0) { if (dis >= last_dis) pp = powf(2.0f, dis) * sc[3]; r0 -= pp; rs[3] += pp; }
+    rs[4] += npos; rs[5] += pr + sr - pu; rs[6] += ob0[0]; rs[7] += ob0[1]; rs[8] += ob1[0]; rs[9] += ob1[1];   /* running logs (:122-127) */
+    s->w_last[e * MAXA] = ob0[0]; s->w_last[e * MAXA + 1] = ob0[1];
+    s->w_last2[e * 2] = npos;
+    rew[0] = r0;
+    for (int a = 1; a < Aw; a++) rew[a] = 0;
+    /* the wrapper re-zeroes the slider at the start of the two steps that follow an env reset (reset_dic, :61-69, :71);
+     * done here, right after the observation of this step, which is the same instant as far as the simulation goes */
+    if (s->wrapper_side_effects) {               /* not part of Go1.step (mqo_post_physics_step alone leaves the state as simulated) */
+      if (s->reset_buf[e]) s->w_delayed_reset[e] = 2;
+      if (s->w_delayed_reset[e] > 0) { nd[0] = 0.0f; nd[1] = 0.0f; s->w_delayed_reset[e]--; }
+    }
+    return;
   }
   if (d->task == MQE_TASK_BRIDGE) {               /* go1_bridge_wrapper.py */
     const float* ob0 = s->obs_bag + (size_t)(e * A) * OBS_BAG;
@@ -1502,10 +1564,12 @@ static void wrapper_env(mqo_sim* s, int e, int is_reset_call, const float* npc) 
 }
 
 int mqo_wrapper_eval(mqo_sim* s, int is_reset_call) {
+  s->wrapper_side_effects = 1;
   for (int e = 0; e < s->N; e++) {
     if (is_reset_call) { s->w_have_last[e] = 0; s->w_delayed_reset[e] = 0; }
     wrapper_env(s, e, is_reset_call, s->P ? s->root + ((size_t)e * (s->A + s->P) + s->A) * 13 : NULL);
   }
+  s->wrapper_side_effects = 0;
   return 0;
 }
 
@@ -1540,7 +1604,7 @@ int mqo_step(mqo_sim* s, const float* actions) {
     for (int a = 0; a < Aw; a++)
       for (int k = 0; k < 3; k++) {
         float v = actions[((size_t)e * Aw + a) * 3 + k];
-        v = fminf(fmaxf(v, -1.0f), 1.0f);                   /* wrapper clip (go1_sheep_wrapper.py:55) */
+        if (d->task != MQE_TASK_TUG) v = fminf(fmaxf(v, -1.0f), 1.0f);   /* wrapper clip (go1_sheep_wrapper.py:55); the tug wrapper has none */
         cmd[((size_t)e * A + a) * 3 + k] = d->task == MQE_TASK_PLAIN ? v : v * scale[k];
       }
     if (d->task == MQE_TASK_FOOTBALL_DEFENDER) defender_command(s, e, cmd + ((size_t)e * A + 2) * 3);
@@ -1552,7 +1616,9 @@ int mqo_step(mqo_sim* s, const float* actions) {
     mqo_simulate(s);
     mqo_post_decimation_step(s, k);
   }
+  s->wrapper_side_effects = 1;
   mqo_post_physics_step(s);
+  s->wrapper_side_effects = 0;
   return 0;
 }
 

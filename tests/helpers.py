@@ -26,11 +26,13 @@ def task_cfg(task):
     from mqe.envs.configs.go1_pushbox_config import Go1PushboxCfg
     from mqe.envs.configs.go1_rotation_config import Go1RotationCfg
     from mqe.envs.configs.go1_bridge_config import Go1BridgeCfg
+    from mqe.envs.configs.go1_tug_config import Go1TugCfg
     from mqe.envs.configs.go1_wrestling_config import Go1WrestlingCfg
     return {"go1gate": Go1GateCfg, "go1sheep-easy": SingleSheepCfg, "go1sheep-hard": NineSheepCfg,
             "go1seesaw": Go1SeesawCfg, "go1football-defender": Go1FootballDefenderCfg, "go1plane": Go1PlaneCfg,
             "go1football-1vs1": Go1Football1vs1Cfg, "go1football-2vs2": Go1Football2vs2Cfg, "go1pushbox": Go1PushboxCfg,
-            "go1revolvingdoor": Go1RotationCfg, "go1bridge": Go1BridgeCfg, "go1wrestling": Go1WrestlingCfg}[task]
+            "go1revolvingdoor": Go1RotationCfg, "go1bridge": Go1BridgeCfg, "go1wrestling": Go1WrestlingCfg,
+            "go1tug": Go1TugCfg}[task]
 
 
 def make_desc(task, N, seed=0, levels=None, types=None, max_episode_length=None, npc_init=None, env_id_offset=0, **kw):

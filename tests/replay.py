@@ -8,7 +8,7 @@ from helpers import golden, make_desc, bag, to_dev, close
 
 TASK_OF = {"gate": "go1gate", "seesaw": "go1seesaw", "football": "go1football-defender", "sheep": "go1sheep-hard",
            "football1v1": "go1football-1vs1", "football2v2": "go1football-2vs2", "pushbox": "go1pushbox", "rotation": "go1revolvingdoor",
-           "bridge": "go1bridge", "wrestling": "go1wrestling"}
+           "bridge": "go1bridge", "wrestling": "go1wrestling", "tug": "go1tug"}
 
 # tolerances: MLP outputs go through libm expm1/ELU and a different accumulation order than torch's GEMM
 TOL_POLICY = dict(atol=2e-5, rtol=1e-4)

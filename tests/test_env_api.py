@@ -123,9 +123,12 @@ def test_openrl_adapter_on_real_env(oracle_backed):
     assert "average step reward" in br and "target reward" in br
 
 
-def test_unregistered_tasks_fail_loudly():
-    with pytest.raises(NotImplementedError):
-        make_mqe_env("go1tug", args_for("go1tug", 1))
+def test_every_reference_task_is_registered():
+    """all 13 entries of the reference's ENV_DICT (mqe/envs/utils.py:38-103); an unknown name fails like upstream (KeyError)"""
+    assert set(ENV_DICT) == {"go1plane", "go1gate", "go1sheep-easy", "go1sheep-hard", "go1football-defender", "go1football-1vs1",
+                             "go1football-2vs2", "go1seesaw", "go1pushbox", "go1tug", "go1wrestling", "go1revolvingdoor", "go1bridge"}
+    with pytest.raises(KeyError):
+        make_mqe_env("go1door", args_for("go1gate", 1))
 
 
 @pytest.mark.parametrize("task,key,A", [("go1football-1vs1", "football_game_1v1", 2), ("go1football-2vs2", "football_game_2v2", 4)])
@@ -174,18 +177,19 @@ def test_revolving_door_task_surface(oracle_backed):
     env.close()
 
 
-@pytest.mark.parametrize("task,rew_shape", [("go1bridge", (3, 2)), ("go1wrestling", (3, 2, 1))])
+@pytest.mark.parametrize("task,rew_shape", [("go1bridge", (3, 2)), ("go1wrestling", (3, 2, 1)), ("go1tug", (3, 2, 1))])
 def test_scenery_task_surface(oracle_backed, task, rew_shape):
     """go1bridge / go1wrestling (reference utils.py:89-103): obs (N,A,12) without ids, agent 0 carries the reward, the caller's
     action tensor is mirrored in place for agent 1; the two wrappers return differently shaped rewards upstream."""
     a = args_for(task, 3)
     env, cfg = make_mqe_env(task, a, custom_cfg(a))
-    assert env.env.num_agents == 2 and env.env.num_npcs == 1 and env.observation_space.shape == (12,)
+    D = 10 if task == "go1tug" else 12
+    assert env.env.num_agents == 2 and env.env.num_npcs == 1 and env.observation_space.shape == (D,)
     obs = env.reset()
-    assert obs.shape == (3, 2, 12) and torch.isfinite(obs).all()
+    assert obs.shape == (3, 2, D) and torch.isfinite(obs).all()
     act = torch.rand(3, 2, 3) * 2 - 1
     before = act.clone()
     obs, rew, done, info = env.step(act)
-    assert obs.shape == (3, 2, 12) and rew.shape == rew_shape and (rew.reshape(3, 2)[:, 1] == 0).all() and done.shape == (3,)
+    assert obs.shape == (3, 2, D) and rew.shape == rew_shape and (rew.reshape(3, 2)[:, 1] == 0).all() and done.shape == (3,)
     assert torch.equal(act[:, 1, 1:], -before[:, 1, 1:]) and torch.equal(act[:, 0], before[:, 0])
     env.close()

@@ -12,12 +12,12 @@ from wrapper_replay import wrapper_replay
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", ["gate", "seesaw", "football", "sheep", "football1v1", "football2v2", "pushbox", "rotation", "bridge", "wrestling"])
+@pytest.mark.parametrize("name", ["gate", "seesaw", "football", "sheep", "football1v1", "football2v2", "pushbox", "rotation", "bridge", "wrestling", "tug"])
 def test_hip_matches_reference_trace(name):
     assert replay(name, hip_engine)
 
 
-@pytest.mark.parametrize("name", ["sheep_hard", "sheep_easy", "seesaw", "football_defender", "pushbox", "rotation", "bridge", "wrestling"])
+@pytest.mark.parametrize("name", ["sheep_hard", "sheep_easy", "seesaw", "football_defender", "pushbox", "rotation", "bridge", "wrestling", "tug"])
 def test_hip_wrappers_match_reference(name):
     assert wrapper_replay(name, hip_engine)
 
@@ -96,7 +96,7 @@ def test_policy_layer0_paths_are_f32_equivalent(monkeypatch, b3, N):
             close(eh.tensor(abi.T_ACTIONS), eo.tensor(abi.T_ACTIONS), atol=5e-5, what=f"policy actions step {t}")
 
 
-@pytest.mark.parametrize("task,N", [("go1gate", 128), ("go1football-defender", 16), ("go1sheep-hard", 14), ("go1seesaw", 16), ("go1football-2vs2", 8), ("go1football-1vs1", 16), ("go1pushbox", 16), ("go1revolvingdoor", 16), ("go1bridge", 16), ("go1wrestling", 16)])
+@pytest.mark.parametrize("task,N", [("go1gate", 128), ("go1football-defender", 16), ("go1sheep-hard", 14), ("go1seesaw", 16), ("go1football-2vs2", 8), ("go1football-1vs1", 16), ("go1pushbox", 16), ("go1revolvingdoor", 16), ("go1bridge", 16), ("go1wrestling", 16), ("go1tug", 16)])
 def test_fused_rollout_matches_oracle(task, N):
     """20 fused step() calls (policy + 4 substeps + post-step + wrapper) from the seeded reset distribution.
     Contact dynamics amplify rounding differences, so the bound is on the typical (median) deviation and flags."""
@@ -198,6 +198,46 @@ def test_revolving_door_matches_oracle():
         eh.simulate(); eo.simulate()
     torch.cuda.synchronize()
     assert saw_door, "test must exercise door contacts"
+    assert torch.isfinite(eh.tensor(abi.T_ROOT_STATE)).all() and torch.isfinite(eh.tensor(abi.T_DOF_STATE)).all()
+
+
+def test_tug_slider_matches_oracle():
+    """go1tug: robots at the rim of the sliding disc (prismatic joint, sphere vs upright cylinder): identical contact lists
+    from identical states, slider position tracked over 70 substeps."""
+    N = 16
+    eh, eo, d = _pair("go1tug", N)
+    eh.reset_all(); eo.reset_all()
+    torch.cuda.synchronize()
+    ro, do = eo.tensor(abi.T_ROOT_STATE), eo.tensor(abi.T_DOF_STATE)
+    g = torch.Generator().manual_seed(12)
+    A = 2
+    hinge = ro[:, A, :3].clone()
+    do[:, 24, 0] = (torch.rand(N, generator=g) - 0.5) * 0.6
+    do[:, 24, 1] = (torch.rand(N, generator=g) - 0.5) * 1.6
+    R = d.seesaw_plank_half[0]
+    for r, sy in ((0, 1.0), (1, -1.0)):
+        ro[:, r, 0] = hinge[:, 0] + (torch.rand(N, generator=g) - 0.5) * 1.0
+        ro[:, r, 1] = hinge[:, 1] + do[:, 24, 0] + sy * (R + 0.25 + torch.rand(N, generator=g) * 0.15)
+        ro[:, r, 2] = 0.32
+        ro[:, r, 3:7] = torch.tensor([0.0, 0.0, 0.0, 1.0])
+    ro[:, :, 7:] = 0
+    do[:, :24, 1] = 0
+    eh.tensor(abi.T_ROOT_STATE).copy_(ro.cuda()); eh.tensor(abi.T_DOF_STATE).copy_(do.cuda())
+    eh.tensor(abi.T_TORQUES).zero_(); eo.tensor(abi.T_TORQUES).zero_()
+    saw = False
+    for k in range(70):
+        if k in (0, 30, 60):
+            torch.cuda.synchronize()
+            close(eh.tensor(abi.T_DOF_STATE)[:, 24, 0], eo.tensor(abi.T_DOF_STATE)[:, 24, 0], atol=5e-4, what=f"slider position at substep {k}")
+            eh.tensor(abi.T_ROOT_STATE).copy_(eo.tensor(abi.T_ROOT_STATE).cuda()); eh.tensor(abi.T_DOF_STATE).copy_(eo.tensor(abi.T_DOF_STATE).cuda())
+            for env in range(N):
+                _, ch = eh.debug_dynamics(env, 0)
+                _, _, co = eo.debug_dynamics(env, 0)
+                assert ch.shape == co.shape and (ch[:, :4] == co[:, :4]).all()
+                saw |= bool((co[:, 2] == A).any())
+        eh.simulate(); eo.simulate()
+    torch.cuda.synchronize()
+    assert saw, "test must exercise disc contacts"
     assert torch.isfinite(eh.tensor(abi.T_ROOT_STATE)).all() and torch.isfinite(eh.tensor(abi.T_DOF_STATE)).all()
 
 

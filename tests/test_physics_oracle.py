@@ -228,3 +228,33 @@ def test_robots_stand_on_the_bridge_and_fall_beside_it():
     q = root2[:, :2, 3:7]
     assert torch.allclose(q.norm(dim=-1), torch.ones(2, 2), atol=1e-5)                           # (0,0,-+1,1) start quaternions are normalised by the integrator
     assert (e2.tensor(abi.T_RESET_COUNT) == 1).all()
+
+
+def test_tug_slider_translates_and_pushes_a_robot():
+    """go1tug: the 3 kg disc (cylinder.urdf) slides along +y without friction or drive, capped at the joint's 1 m/s; a robot
+    standing at its rim is shoved along (sphere vs upright cylinder) and the disc gives up momentum."""
+    e, d, root, dof = fresh("go1tug", 2)
+    A = d.num_agents
+    assert d.seesaw_axis == 3 and d.seesaw_link_cylinder == 1
+    root[:, :A, 0] += 6.0                                   # robots out of the way
+    dof[0, 12 * A, 1] = 0.5
+    dof[1, 12 * A, 1] = 3.0                                 # above the velocity limit
+    for t in range(40):
+        e.simulate()
+    assert abs(dof[0, 12 * A, 1] - 0.5) < 1e-6 and abs(dof[0, 12 * A, 0] - 40 * d.dt * 0.5) < 1e-5
+    assert abs(dof[1, 12 * A, 1] - d.seesaw_vel_limit) < 1e-6
+    hinge = root[:, A, :3].clone()
+    dof[:, 12 * A, 0] = 0.0
+    dof[:, 12 * A, 1] = 0.9
+    root[:, 0, 0] = hinge[:, 0]
+    root[:, 0, 1] = hinge[:, 1] + d.seesaw_plank_half[0] + 0.32
+    root[:, 0, 2] = 0.32
+    root[:, 0, 3:7] = torch.tensor([0.0, 0.0, 0.0, 1.0])
+    root[:, :, 7:] = 0
+    y0 = root[:, 0, 1].clone()
+    for t in range(80):
+        e.simulate()
+    assert torch.isfinite(root).all() and torch.isfinite(dof).all()
+    assert (dof[:, 12 * A, 1] < 0.8).all(), dof[:, 12 * A, 1]                  # momentum went into the robot
+    assert (root[:, 0, 1] > y0 + 0.005).all(), root[:, 0, 1] - y0             # which was shoved along +y (12 kg on mu = 1 feet: not far)
+    assert (root[:, 0, 1] - (hinge[:, 1] + dof[:, 12 * A, 0]) > d.seesaw_plank_half[0] - 0.05).all()   # and never ended up inside the disc

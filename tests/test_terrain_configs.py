@@ -9,7 +9,7 @@ from helpers import GOLD, golden, task_cfg
 from mqe.utils.helpers import class_to_dict
 from mqe.utils.terrain import BarrierTrack
 
-TASKS = ["go1gate", "go1sheep-easy", "go1sheep-hard", "go1seesaw", "go1football-defender", "go1football-1vs1", "go1football-2vs2", "go1pushbox", "go1revolvingdoor", "go1bridge", "go1wrestling"]
+TASKS = ["go1gate", "go1sheep-easy", "go1sheep-hard", "go1seesaw", "go1football-defender", "go1football-1vs1", "go1football-2vs2", "go1pushbox", "go1revolvingdoor", "go1bridge", "go1wrestling", "go1tug"]
 
 
 def unrle(runs, shape):

@@ -256,7 +256,7 @@ def make_env(cls, cfg, N, seed=0, P_dofs=0):
 
 def P_bodies(cfg):
     name = getattr(cfg.asset, "name_npc", "")
-    per = {"": 0, "ball": 1, "sheep": 1, "seesaw": 2, "box": 1, "rotation": 2, "bridge": 3, "wrestling": 9}[name]
+    per = {"": 0, "ball": 1, "sheep": 1, "seesaw": 2, "box": 1, "rotation": 2, "bridge": 3, "wrestling": 9, "circular": 2}[name]
     return per * getattr(cfg.env, "num_npcs", 0)
 
 
@@ -774,6 +774,47 @@ def gen_scenery_wrappers():
              obs_dim=np.int64(w.observation_space.shape[0]), **{k: torch.stack(v, 0) for k, v in rec.items()})
 
 
+def gen_tug_wrapper():
+    """Go1TugWrapper: scripted base pos / rpy, slider dof state, env resets; the gym call it makes is stubbed."""
+    from mqe.envs.configs.go1_tug_config import Go1TugCfg
+    from mqe.envs.wrappers.go1_tug_wrapper import Go1TugWrapper
+    rng = np.random.RandomState(61)
+    T, N = 24, 1          # upstream `reward[:, 0] += success_reward[:, 0]` ((N,1) += (N,)) only broadcasts for num_envs = 1
+    cfg = Go1TugCfg
+    A, P = cfg.env.num_agents, cfg.env.num_npcs
+    fe = FakeEnvForWrapper(cfg, N, A, P)
+    fe.npc_indices = torch.arange(N).reshape(N, 1)
+    fe.all_dof_states = torch.zeros(N * (12 * A + 1), 2)
+    fe.sim = None
+    zero_log = []
+    fe.gym = types.SimpleNamespace(set_dof_state_tensor_indexed=lambda *a: zero_log.append(fe.dof_state_npc[:, 0, :].clone()))
+    script, rec = [], {}
+    for t in range(T + 1):
+        ob = types.SimpleNamespace()
+        ob.base_pos = torch.tensor(rng.uniform(0, 3, (N * A, 3)).astype(np.float32))
+        ob.base_pos[:, 1] = torch.tensor(rng.uniform(-3, 3, N * A).astype(np.float32))
+        ob.base_rpy = torch.tensor(rng.uniform(0, 6.28, (N * A, 3)).astype(np.float32))
+        npc = torch.tensor(rng.uniform(-1.5, 1.5, (N, 1, 2)).astype(np.float32))
+        rb = torch.tensor(rng.rand(N) < 0.25)
+        dct = dict(obs_buf=ob, dof_state_npc=npc, reset_buf=rb)
+        dct["reset_ids"] = rb.nonzero(as_tuple=False).flatten()
+        script.append(dct)
+        rec.setdefault("base_pos", []).append(ob.base_pos); rec.setdefault("base_rpy", []).append(ob.base_rpy)
+        rec.setdefault("dof_state_npc", []).append(npc.clone()); rec.setdefault("reset_buf", []).append(rb)
+    fe.script = script
+    w = Go1TugWrapper(fe)
+    obs0 = w.reset()
+    acts = rng.uniform(-1.5, 1.5, (T, N, A, 3)).astype(np.float32)
+    obs_l, rew_l, act_l, dic_l, npc_after = [], [], [], [], []
+    for t in range(T):
+        o, r, term, info = w.step(torch.from_numpy(acts[t].copy()))
+        obs_l.append(o.clone()); rew_l.append(r.clone()); act_l.append(fe.last_action_in); dic_l.append(w.reset_dic.clone())
+    rb = {k: float(v) for k, v in w.reward_buffer.items()}
+    save("wrapper_tug", obs_reset=obs0, obs=torch.stack(obs_l), reward=torch.stack(rew_l), env_action=torch.stack(act_l), actions=acts,
+         reset_dic=torch.stack(dic_l), reward_buffer_keys=np.array(list(rb.keys())), reward_buffer_vals=np.array(list(rb.values()), np.float64),
+         obs_dim=np.int64(w.observation_space.shape[0]), **{k: torch.stack(v, 0) for k, v in rec.items()})
+
+
 def rle_rows(hf):
     """two-level heightfield -> per-row run-length list (value, start, stop)"""
     runs = []
@@ -790,7 +831,7 @@ def rle_rows(hf):
 
 def gen_terrain_and_configs():
     cfgd = {}
-    for task in ("go1gate", "go1sheep-easy", "go1sheep-hard", "go1seesaw", "go1football-defender", "go1football-1vs1", "go1football-2vs2", "go1pushbox", "go1revolvingdoor", "go1bridge", "go1wrestling"):
+    for task in ("go1gate", "go1sheep-easy", "go1sheep-hard", "go1seesaw", "go1football-defender", "go1football-1vs1", "go1football-2vs2", "go1pushbox", "go1revolvingdoor", "go1bridge", "go1wrestling", "go1tug"):
         cfg = ref_utils.ENV_DICT[task]["config"]
         t = barrier_track_for(cfg, 8)
         hf = t.heightfield_raw
@@ -890,6 +931,11 @@ def main():
         gen_fullstep("fullstep_wrestling", Go1Object, Go1WrestlingCfg, N=2, T=12, act=act, ada=ada)
     if want("wrapper_scenery"):
         gen_scenery_wrappers()
+    if want("fullstep_tug"):
+        from mqe.envs.configs.go1_tug_config import Go1TugCfg
+        gen_fullstep("fullstep_tug", Go1Object, Go1TugCfg, N=2, T=12, act=act, ada=ada)
+    if want("wrapper_tug"):
+        gen_tug_wrapper()
     if want("terrain"):
         gen_terrain_and_configs()
     if want("adapter"):
