@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MQE_ABI_VERSION 5
+#define MQE_ABI_VERSION 6
 #define MQE_MAX_SPHERES 32
 #define MQE_NBODY 13      /* dynamic bodies of one Go1 after fixed-joint collapsing */
 #define MQE_NREP 17       /* reported rigid bodies of one Go1 (feet kept, go1.urdf dont_collapse) */
@@ -220,6 +220,11 @@ int mqe_reset_all(mqe_sim* s, void* stream);
  * actions: [N, A', 3] raw policy actions in [-1,1] (the wrapper's clip and action_scale are applied inside);
  * results land in MQE_T_WRAPPER_OBS / MQE_T_WRAPPER_REWARD / MQE_T_RESET_BUF. */
 int mqe_step(mqe_sim* s, const float* actions, void* stream);
+/* The same for the low-level control types "P" / "V" / "T" (Go1.step's else branch, go1.py:42-44 -> pre_physics_step,
+ * legged_robot.py:108-110, and the PD / torque laws of legged_robot.py:380-392): actions [R, 12] joint-space actions, clipped
+ * to clip_actions inside; no locomotion policy runs.  The decimation loop, post-physics step and (plain) wrapper are the
+ * fused ones. */
+int mqe_step_joint(mqe_sim* s, const float* actions12, void* stream);
 
 /* bookkeeping for benchmarks: time of the dominant kernel measured with HIP events on `stream` */
 int mqe_profile_enable(mqe_sim* s, int on);

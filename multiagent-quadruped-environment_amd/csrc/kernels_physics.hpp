@@ -1120,6 +1120,8 @@ __global__ void __launch_bounds__(64, 2) k_substeps(const DevModel* __restrict__
   const float* W2 = m->actuator.W[2]; const float* b2 = m->actuator.b[2];
   // per-tile joint state in registers
   float tgt[ACT_TILES], h_e1[ACT_TILES], h_e2[ACT_TILES], h_v1[ACT_TILES], h_v2[ACT_TILES], lim[ACT_TILES];
+  float asc[ACT_TILES], dfl[ACT_TILES], lqd[ACT_TILES];          // low-level control types: scaled action, default pose, last-step velocity
+  const int ctrl = m->control_type;
   const size_t R12 = (size_t)m->R * 12;
 #pragma unroll
   for (int t = 0; t < ACT_TILES; t++) {
@@ -1129,6 +1131,9 @@ __global__ void __launch_bounds__(64, 2) k_substeps(const DevModel* __restrict__
     const int j = (ok ? jt : 0) % 12;
     float as = st.actions[gi] * m->action_scale;
     if (j % 3 == 0) as *= m->hip_scale_reduction;
+    asc[t] = st.actions[gi] * m->action_scale;                   // P / V / T: no hip reduction (legged_robot.py:380)
+    dfl[t] = m->default_dof_pos[j];
+    lqd[t] = ctrl == MQE_CTRL_V ? st.last_dof_vel[gi] : 0.0f;
     tgt[t] = as + m->default_dof_pos[j];
     h_e1[t] = st.act_hist[gi]; h_e2[t] = st.act_hist[R12 + gi]; h_v1[t] = st.act_hist[2 * R12 + gi]; h_v2[t] = st.act_hist[3 * R12 + gi];
     lim[t] = m->torque_limits[j];
@@ -1144,6 +1149,27 @@ __global__ void __launch_bounds__(64, 2) k_substeps(const DevModel* __restrict__
     // weight fragments (A operands): row = hidden unit j32, k = this half-wave's element of each k pair.  They are
     // re-read (L1/L2 resident, 5 kB shared by every wave) each substep behind an optimisation barrier: keeping 70 VGPRs
     // live across the 50 k-cycle physics body would spill and halve the occupancy.
+    if (ctrl != MQE_CTRL_C) {          // P / V / T (legged_robot.py:384-390): a few FMAs per joint lane instead of the actuator network
+#pragma unroll
+      for (int t = 0; t < ACT_TILES; t++) {
+        if (t * 32 >= nj) break;
+        const int jt = t * 32 + j32;
+        const bool ok = jt < nj;
+        const float q = lds[L.dof + (ok ? jt : 0) * 2], qd = lds[L.dof + (ok ? jt : 0) * 2 + 1];
+        float tau = asc[t];
+        if (ctrl == MQE_CTRL_P) tau = m->kp * (asc[t] + dfl[t] - q) - m->kd * qd;
+        else if (ctrl == MQE_CTRL_V) tau = m->kp * (asc[t] - qd) - m->kd * (qd - lqd[t]) / m->dt;
+        tau = clampf(tau, -lim[t], lim[t]);
+        if (ok && h == 0) {
+          lds[L.tau + jt] = tau;
+          st.sub_tau[((size_t)e * 4 + (k < 4 ? k : 3)) * nj + jt] = tau;
+          if (last) st.torques[(size_t)e * nj + jt] = tau;
+        }
+      }
+      __syncthreads();
+      phys_substep(m, st, lds, e, lane, last ? (PS_STORE_STATE | PS_WRITE_CF) : 0, 0, nodbg);
+      continue;
+    }
     const float *w0p = W0, *w1p = W1, *w2p = W2, *b0p = b0, *b1p = b1;
     asm volatile("" : "+s"(w0p), "+s"(w1p), "+s"(w2p), "+s"(b0p), "+s"(b1p));
     float a1[3], a2[16], w3[16], bb0[16], bb1[16];

@@ -212,6 +212,8 @@ __global__ void __launch_bounds__(256) k_compute_torques(const DevModel* m, DevS
     tau = acc + b2[0];
     e2[idx] = e1[idx]; e1[idx] = err;
     v2[idx] = v1[idx]; v1[idx] = qd;
+  } else if (m->control_type == MQE_CTRL_V) {       // legged_robot.py:387: velocity targets, D term on the change per policy step
+    tau = m->kp * (as - qd) - m->kd * (qd - st.last_dof_vel[idx]) / m->dt;
   } else if (m->control_type == MQE_CTRL_P) {
     tau = m->kp * (as + m->default_dof_pos[j] - q) - m->kd * qd;       // legged_robot.py:385
   } else if (m->control_type == MQE_CTRL_T) {
@@ -853,6 +855,7 @@ __device__ __forceinline__ uint8_t post_physics_env(const DevModel* m, const Dev
         ob[36 + j] = act[a][j];
         ob[48 + j] = act[a][j];
         st.last_actions[(size_t)i * 12 + j] = act[a][j];
+        st.last_dof_vel[(size_t)i * 12 + j] = dq[a][2 * j + 1];        // legged_robot.py:152
       }
 #pragma unroll
       for (int k = 0; k < 3; k++) { ob[30 + k] = lv[a][k] * 2.0f; ob[33 + k] = av[a][k] * 0.25f; ob[60 + k] = pgr[a][k]; }

@@ -55,7 +55,7 @@ struct DevModel {
 struct DevState {
   float *root, *dof, *cf, *torques, *actions, *last_actions, *loco_obs, *hist, *last_loco, *last_two_loco, *act_hist;
   float *gait, *clock, *blv, *bav, *pg, *bquat, *obs_bag, *wobs, *wrew, *rsum, *sheep_avg, *sheep_var, *sub_tau, *npc_noise;
-  float *w_last, *w_last2, *cmd;
+  float *w_last, *w_last2, *cmd, *last_dof_vel;
   uint16_t* hist3;                          // split-bf16 copy of the history ring: [R][270 units][3 planes][8] (k_gemm_b3)
   int32_t *ep_len, *reset_count;
   uint8_t *reset_buf, *collide_buf, *time_out, *r_term, *p_term, *zh_term, *w_have_last, *w_delayed_reset;

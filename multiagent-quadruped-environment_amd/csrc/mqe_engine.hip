@@ -296,7 +296,7 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   DA(st.rsum, (size_t)N * MQE_MAX_REWARD_TERMS); DA(st.sheep_avg, (size_t)N * 2); DA(st.sheep_var, N);
   DA(st.sub_tau, (size_t)N * 4 * 12 * A); DA(st.npc_noise, (size_t)N * (P ? P : 1) * 3);
   DA(st.w_last, (size_t)N * MQE_MAX_AGENTS); DA(st.w_last2, (size_t)N * 2); DA(st.cmd, (size_t)R * 3);
-  DA(st.ep_len, N); DA(st.reset_count, N);
+  DA(st.ep_len, N); DA(st.reset_count, N); DA(st.last_dof_vel, (size_t)R * 12);
   DA(st.reset_buf, N); DA(st.collide_buf, N); DA(st.time_out, N); DA(st.r_term, N); DA(st.p_term, N); DA(st.zh_term, N);
   DA(st.w_have_last, N); DA(st.w_delayed_reset, N);
   {
@@ -560,11 +560,35 @@ extern "C" int mqe_reset_all(mqe_sim* s, void* stream) {
   return 0;
 }
 
+static int run_substeps_and_post(mqe_sim* s, hipStream_t q);
+
+// clip to clip_actions (legged_robot.py:108-110) -> st.actions
+__global__ void k_set_joint_actions(const DevModel* m, DevState st, const float* __restrict__ a12) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < m->R * 12) st.actions[idx] = clampf(a12[idx], -m->clip_actions, m->clip_actions);
+}
+
+extern "C" int mqe_step_joint(mqe_sim* s, const float* actions12, void* stream) {
+  if (s->d.control_type == MQE_CTRL_C) return fail(-7, "mqe_step_joint drives control types P / V / T; use mqe_step for the hierarchical controller");
+  hipStream_t q = (hipStream_t)stream;
+  {
+    ProfScope ps(s, PROF_MISC, q);
+    const int n = s->R * 12;
+    hipLaunchKernelGGL(k_set_joint_actions, dim3((n + 255) / 256), dim3(256), 0, q, s->dm, s->st, actions12);
+  }
+  return run_substeps_and_post(s, q);
+}
+
 extern "C" int mqe_step(mqe_sim* s, const float* actions, void* stream) {
   hipStream_t q = (hipStream_t)stream;
+  if (s->d.control_type != MQE_CTRL_C) return fail(-7, "mqe_step drives the hierarchical controller (control type C); use mqe_step_joint for P / V / T");
   policy_step(s, s->st.cmd, q, actions);         // wrapper head (clip, task action scale, scripted defender) inside k_pre_policy
-  if (s->d.control_type == MQE_CTRL_C && s->fuse_substeps) {
-    // decimation loop in one launch: state stays in LDS, actuator net on MFMA inside the physics wavefront
+  return run_substeps_and_post(s, q);
+}
+
+static int run_substeps_and_post(mqe_sim* s, hipStream_t q) {
+  if (s->fuse_substeps) {
+    // decimation loop in one launch: state stays in LDS; actuator net on MFMA (C) or the PD / torque law (P, V, T) inside the wavefront
     ProfScope ps(s, PROF_SIMULATE, q);
     hipLaunchKernelGGL(k_substeps, dim3(s->N), dim3(64), s->phys_lds_bytes, q, s->dm, s->st, s->d.decimation);
   } else {

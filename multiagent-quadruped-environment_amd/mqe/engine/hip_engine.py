@@ -36,7 +36,7 @@ class HipEngine(EngineBase):
         vp = C.c_void_p
         for name, args in (("policy_step", [vp, vp, vp]), ("compute_torques", [vp, vp]), ("simulate", [vp, vp]),
                            ("post_decimation_step", [vp, C.c_int, vp]), ("post_physics_step", [vp, vp]),
-                           ("reset_all", [vp, vp]), ("step", [vp, vp, vp]), ("defender_command", [vp, vp, vp]),
+                           ("reset_all", [vp, vp]), ("step", [vp, vp, vp]), ("step_joint", [vp, vp, vp]), ("defender_command", [vp, vp, vp]),
                            ("wrapper_eval", [vp, C.c_int, vp]),
                            ("debug_dynamics", [vp, C.c_int, C.c_int, vp, C.POINTER(C.c_int), vp]),
                            ("profile_enable", [vp, C.c_int]),
@@ -70,6 +70,11 @@ class HipEngine(EngineBase):
 
     def reset_all(self):
         self._call("reset_all", self._stream())
+
+    def step_joint(self, actions12):
+        """Fused step for control types P / V / T: (R, 12) joint-space actions on the device."""
+        assert actions12.is_cuda and actions12.dtype == torch.float32 and actions12.is_contiguous()
+        self._call("step_joint", C.c_void_p(actions12.data_ptr()), self._stream())
 
     def step(self, actions):
         assert actions.is_cuda and actions.dtype == torch.float32 and actions.is_contiguous()

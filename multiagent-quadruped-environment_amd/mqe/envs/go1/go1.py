@@ -232,7 +232,12 @@ class Go1:
     def step(self, action):
         """One policy step from already-scaled commands (go1.py:35-62); action: (N*A, 3) or (N, A, 3)."""
         if self.cfg.control.control_type != "C":
-            raise NotImplementedError("this entry point drives control_type 'C'; P/V/T torques are engine modes set at construction")
+            # low-level control (go1.py:42-44): joint-space actions (N*A, 12) / (N, A*12), clipped to clip_actions inside
+            # the engine (legged_robot.py:108-110); PD / torque law, 4 substeps and the post-physics step are one fused call
+            a = action.reshape(-1, 12).to(self.engine.torch_device, torch.float32).contiguous()
+            self.engine.step_joint(a)
+            self.common_step_counter += 1
+            return self.obs_buf, self.rew_buf, self.reset_buf, self.extras
         cmd = action.reshape(-1, 3).to(self.engine.torch_device, torch.float32).contiguous()
         if self.task == "football_defender" and cmd.shape[0] == self.num_envs * 2:
             raise NotImplementedError("call the task wrapper (fused path) for go1football-defender; the scripted "

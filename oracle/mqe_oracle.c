@@ -65,7 +65,7 @@ typedef struct mqo_sim {
   /* state */
   float *root, *dof, *cf, *torques, *actions, *last_actions, *loco_obs, *hist, *last_loco, *last_two_loco;
   float *act_hist, *gait, *clock, *blv, *bav, *pg, *bquat, *obs_bag, *wobs, *wrew, *rsum, *sheep_avg, *sheep_var;
-  float *sub_tau, *npc_noise;
+  float *sub_tau, *npc_noise, *last_dof_vel;
   int32_t *ep_len, *reset_count;
   uint8_t *reset_buf, *collide_buf, *time_out, *r_term, *p_term, *zh_term;
   /* wrapper memory */
@@ -324,6 +324,7 @@ int mqo_sim_create(const mqe_sim_desc* d, mqo_sim** out) {
   s->sheep_var = ALLOCF(N);
   s->sub_tau = ALLOCF((size_t)N * 4 * 12 * A);
   s->npc_noise = ALLOCF((size_t)N * (P ? P : 1) * 3);
+  s->last_dof_vel = ALLOCF((size_t)s->R * 12);
   s->ep_len = (int32_t*)calloc(N, 4);
   s->reset_count = (int32_t*)calloc(N, 4);
   s->reset_buf = (uint8_t*)calloc(N, 1);
@@ -450,6 +451,8 @@ int mqo_compute_torques(mqo_sim* s) {
         v2[i * 12 + j] = v1[i * 12 + j]; v1[i * 12 + j] = qd;              /* :349-350 */
       } else if (d->control_type == MQE_CTRL_P) {
         tau = d->kp * (as + d->default_dof_pos[j] - q) - d->kd * qd;       /* legged_robot.py:385 */
+      } else if (d->control_type == MQE_CTRL_V) {                          /* :387: velocity targets, D term on the change per policy step */
+        tau = d->kp * (as - qd) - d->kd * (qd - s->last_dof_vel[i * 12 + j]) / d->dt;
       } else if (d->control_type == MQE_CTRL_T) {
         tau = as;                                                          /* :389 */
       } else {
@@ -1273,6 +1276,7 @@ int mqo_post_physics_step(mqo_sim* s) {
     }
     compute_observations_env(s, e, 1);                                            /* :149 */
     for (int k = 0; k < 12 * A; k++) s->last_actions[(size_t)e * 12 * A + k] = s->actions[(size_t)e * 12 * A + k];  /* :151 */
+    for (int k = 0; k < 12 * A; k++) s->last_dof_vel[(size_t)e * 12 * A + k] = s->dof[((size_t)e * s->ND + k) * 2 + 1];    /* :152 */
     wrapper_env(s, e, 0, pre_npc ? pre_npc + (size_t)e * P * 13 : NULL);
   }
   free(pre_npc);
@@ -1611,6 +1615,21 @@ int mqo_step(mqo_sim* s, const float* actions) {
   }
   mqo_policy_step(s, cmd);
   free(cmd);
+  for (int k = 0; k < d->decimation; k++) {
+    mqo_compute_torques(s);
+    mqo_simulate(s);
+    mqo_post_decimation_step(s, k);
+  }
+  s->wrapper_side_effects = 1;
+  mqo_post_physics_step(s);
+  s->wrapper_side_effects = 0;
+  return 0;
+}
+
+/* Go1.step for control types P / V / T (go1.py:42-44): clip to clip_actions (legged_robot.py:108-110), no policy */
+int mqo_step_joint(mqo_sim* s, const float* actions12) {
+  const mqe_sim_desc* d = &s->d;
+  for (size_t i = 0; i < (size_t)s->R * 12; i++) s->actions[i] = fminf(fmaxf(actions12[i], -d->clip_actions), d->clip_actions);
   for (int k = 0; k < d->decimation; k++) {
     mqo_compute_torques(s);
     mqo_simulate(s);

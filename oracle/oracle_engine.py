@@ -41,7 +41,7 @@ class OracleEngine(EngineBase):
         vp = C.c_void_p
         for name, args in (("policy_step", [vp, vp]), ("compute_torques", [vp]), ("simulate", [vp]),
                            ("post_decimation_step", [vp, C.c_int]), ("post_physics_step", [vp]),
-                           ("reset_all", [vp]), ("step", [vp, vp]), ("hist_pos", [vp]), ("wrapper_eval", [vp, C.c_int])):
+                           ("reset_all", [vp]), ("step", [vp, vp]), ("step_joint", [vp, vp]), ("hist_pos", [vp]), ("wrapper_eval", [vp, C.c_int])):
             f = getattr(self.lib, "mqo_" + name)
             f.argtypes, f.restype = args, C.c_int
 
@@ -69,6 +69,10 @@ class OracleEngine(EngineBase):
 
     def reset_all(self):
         self._call("reset_all")
+
+    def step_joint(self, actions12):
+        a = np.ascontiguousarray(actions12.detach().cpu().numpy() if hasattr(actions12, "detach") else actions12, np.float32)
+        self._call("step_joint", C.c_void_p(a.ctypes.data))
 
     def step(self, actions):
         a = np.ascontiguousarray(actions.detach().cpu().numpy(), np.float32)

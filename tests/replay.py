@@ -80,3 +80,41 @@ def replay(name, make_engine):
             close(Tn(abi.T_SHEEP_POS_VAR), z["sheep_pos_var"][t], what=f"t{t} sheep var", atol=1e-4, rtol=1e-5)
     e.close()
     return True
+
+
+def replay_joint(ctrl, make_engine):
+    """`fullstep_gate_{P,V,T}`: the reference's Go1.step else-branch (go1.py:42-44; PD / velocity / torque laws of
+    legged_robot.py:380-392) on the gate scene with a scripted simulator, replayed through the unfused entry points."""
+    z = golden("fullstep_gate_" + ctrl)
+    N, A, P = int(z["N"]), int(z["A"]), int(z["P"])
+    T = z["actions"].shape[0]
+    d, keep, ctx = make_desc("go1gate", N, levels=z["terrain_levels"], types=z["terrain_types"], max_episode_length=int(z["max_episode_length"]))
+    d.control_type = abi.CTRL[ctrl]
+    e = make_engine(d, keep)
+    Tn = e.tensor
+    e.reset_all()
+    close(Tn(abi.T_ROOT_STATE).reshape(-1, 13), z["reset_all_root"], what="reset root", **TOL_EXACT)
+    root, dof, cf, act = Tn(abi.T_ROOT_STATE), Tn(abi.T_DOF_STATE), Tn(abi.T_CONTACT_FORCE), Tn(abi.T_ACTIONS)
+    clip = d.clip_actions
+    for t in range(T):
+        a = np.clip(z["actions"][t].reshape(N, A * 12), -clip, clip)               # pre_physics_step (legged_robot.py:108-110)
+        act.copy_(to_dev(e, a))
+        close(act, z["actions_clipped"][t], what=f"t{t} clipped actions", **TOL_EXACT)
+        for k in range(4):
+            e.compute_torques()
+            close(Tn(abi.T_TORQUES), z["torques"][t, k][:, :12 * A], what=f"t{t} substep {k} torques", atol=2e-5, rtol=1e-5)
+            dof.copy_(to_dev(e, z["dof_script"][t, k]))
+            e.post_decimation_step(k)
+        root.copy_(to_dev(e, z["root_script"][t].reshape(N, A + P, 13)))
+        cf.copy_(to_dev(e, z["contact_script"][t]))
+        e.post_physics_step()
+        for key, kind in (("reset_buf", abi.T_RESET_BUF), ("time_out", abi.T_TIME_OUT_BUF), ("r_term", abi.T_R_TERM), ("p_term", abi.T_P_TERM)):
+            assert (Tn(kind).cpu().numpy().astype(bool) == z[key][t]).all(), (t, key)
+        assert (Tn(abi.T_EPISODE_LENGTH).cpu().numpy() == z["episode_length"][t]).all(), (t, "episode_length")
+        close(root.reshape(-1, 13), z["post_all_root"][t], what=f"t{t} root after post-step", **TOL_EXACT)
+        close(dof.reshape(-1, 2), z["post_all_dof"][t], what=f"t{t} dof after post-step", **TOL_EXACT)
+        for k in ("base_pos", "base_quat", "dof_pos", "dof_vel", "lin_vel", "ang_vel", "last_action", "last_last_action", "projected_gravity", "base_rpy"):
+            if "obs_" + k in z.files:
+                close(bag(e, k), z["obs_" + k][t], what=f"t{t} obs {k}", atol=3e-6, rtol=1e-5)
+    e.close()
+    return True

@@ -193,3 +193,24 @@ def test_scenery_task_surface(oracle_backed, task, rew_shape):
     assert obs.shape == (3, 2, D) and rew.shape == rew_shape and (rew.reshape(3, 2)[:, 1] == 0).all() and done.shape == (3,)
     assert torch.equal(act[:, 1, 1:], -before[:, 1, 1:]) and torch.equal(act[:, 0], before[:, 0])
     env.close()
+
+
+def test_low_level_control_types_through_go1_step(oracle_backed):
+    """control_type "P" (PD on joint targets): Go1.step takes (N*A, 12) joint-space actions (go1.py:42-44) -- the plugin
+    surface a locomotion-level trainer uses; run on the gate scene, restored afterwards."""
+    from mqe.envs.configs.go1_gate_config import Go1GateCfg
+    old = Go1GateCfg.control.control_type
+    Go1GateCfg.control.control_type = "P"
+    try:
+        a = args_for("go1gate", 3)
+        env, cfg = make_mqe_env("go1gate", a, custom_cfg(a))
+        env.reset()
+        ob, rew, done, info = env.env.step(torch.zeros(3 * 2, 12))
+        assert ob.dof_pos.shape == (6, 12) and done.shape == (3,) and (rew == 0).all()
+        q0 = env.env.dof_pos.clone()
+        for t in range(20):
+            env.env.step(torch.zeros(3 * 2, 12))                       # PD holds the default pose
+        assert (env.env.dof_pos - q0).abs().max() < 0.6 and torch.isfinite(env.env.root_states).all()
+        env.close()
+    finally:
+        Go1GateCfg.control.control_type = old

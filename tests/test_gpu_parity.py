@@ -241,6 +241,31 @@ def test_tug_slider_matches_oracle():
     assert torch.isfinite(eh.tensor(abi.T_ROOT_STATE)).all() and torch.isfinite(eh.tensor(abi.T_DOF_STATE)).all()
 
 
+@pytest.mark.parametrize("ctrl", ["P", "V", "T"])
+def test_low_level_control_matches_reference_and_oracle(ctrl):
+    """Control types P / V / T: (1) the reference's trace through the unfused entry points; (2) 12 fused mqe_step_joint calls
+    (PD / torque law inside k_substeps) against the oracle from the seeded reset distribution."""
+    from replay import replay_joint
+    assert replay_joint(ctrl, hip_engine)
+    N = 64
+    d1, k1, _ = make_desc("go1gate", N); d2, k2, _ = make_desc("go1gate", N)
+    d1.control_type = d2.control_type = abi.CTRL[ctrl]
+    eh, eo = hip_engine(d1, k1), oracle_engine(d2, k2)
+    eh.reset_all(); eo.reset_all()
+    g = torch.Generator().manual_seed(3)
+    dev = []
+    for t in range(12):
+        a = (torch.rand(N * 2, 12, generator=g) * 2 - 1) * (1.0 if ctrl != "T" else 8.0)
+        eh.step_joint(a.cuda().contiguous()); eo.step_joint(a)
+        torch.cuda.synchronize()
+        if t == 0:
+            close(eh.tensor(abi.T_SUBSTEP_TORQUES)[:, 0], eo.tensor(abi.T_SUBSTEP_TORQUES)[:, 0], atol=2e-4, rtol=1e-4, what="first substep torques")
+        dev.append((eh.tensor(abi.T_ROOT_STATE).cpu()[..., :3] - eo.tensor(abi.T_ROOT_STATE)[..., :3]).abs().max(dim=-1).values.flatten())
+    dev = torch.stack(dev)
+    assert torch.isfinite(dev).all() and dev[3].median() < 1e-4 and dev[-1].median() < 5e-3, (dev[3].median(), dev[-1].median())
+    assert int((eh.tensor(abi.T_RESET_BUF).cpu() != eo.tensor(abi.T_RESET_BUF)).sum()) <= 4
+
+
 def test_seesaw_plank_matches_oracle():
     """go1seesaw: robots dropped onto the plank / the platform / next to the column: contact lists identical, then
     110 substeps of coupled robot-plank dynamics (hinge angle tracked to 2e-4 rad)."""

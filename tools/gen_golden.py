@@ -401,7 +401,7 @@ def obs_fields(ob):
     return d
 
 
-def gen_fullstep(name, cls, cfg, N, T, act, ada, action_gain=1.0, seed=0):
+def gen_fullstep(name, cls, cfg, N, T, act, ada, action_gain=1.0, seed=0, ctrl="C"):
     """Drive the reference's own step() (go1.py:35-62 / go1_football_defender.py:25-54) for T steps with the
     scripted simulator; record everything a replay needs and everything it must reproduce."""
     A = cfg.env.num_agents
@@ -475,6 +475,8 @@ def gen_fullstep(name, cls, cfg, N, T, act, ada, action_gain=1.0, seed=0):
         if ti == 7 and len(cfg.asset.terminate_after_contacts_on):
             contact_script[ti, 2 % N, 17 * (A - 1), :] = [0.5, 0.2, 3.0]  # base of last agent touches: collide
     actions = (rng.uniform(-1.3, 1.3, (T, N * (A if cls is not Go1FootballDefender else A - 1), 3)) * action_gain).astype(np.float32)
+    if ctrl != "C":     # low-level control types: joint-space actions, some beyond clip_actions
+        actions = rng.uniform(-1.0, 1.0, (T, N * A, 12)).astype(np.float32) * np.where(rng.rand(T, N * A, 12) < 0.02, 150.0, 1.0).astype(np.float32)
 
     g = env.gym
     g.dof_script = torch.from_numpy(dof_script.reshape(T * 4, N * ndof_env, 2))
@@ -931,6 +933,12 @@ def main():
         gen_fullstep("fullstep_wrestling", Go1Object, Go1WrestlingCfg, N=2, T=12, act=act, ada=ada)
     if want("wrapper_scenery"):
         gen_scenery_wrappers()
+    if want("fullstep_pvt"):       # Go1.step's else-branch (go1.py:42-44): control types P / V / T on the gate scene
+        from mqe.envs.configs.go1_gate_config import Go1GateCfg
+        for c in ("P", "V", "T"):
+            ctl = type("control", (Go1GateCfg.control,), {"control_type": c})
+            cfg_c = type("Go1Gate" + c + "Cfg", (Go1GateCfg,), {"control": ctl})
+            gen_fullstep("fullstep_gate_" + c, Go1, cfg_c, N=3, T=10, act=act, ada=ada, ctrl=c)
     if want("fullstep_tug"):
         from mqe.envs.configs.go1_tug_config import Go1TugCfg
         gen_fullstep("fullstep_tug", Go1Object, Go1TugCfg, N=2, T=12, act=act, ada=ada)
