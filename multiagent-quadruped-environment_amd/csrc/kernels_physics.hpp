@@ -1,19 +1,21 @@
-// kernels_physics.hpp -- k_simulate: one 5 ms step of articulated rigid-body dynamics with contact for every env.
+// kernels_physics.hpp -- k_substeps / k_simulate: articulated rigid-body dynamics with contact, one 5 ms substep at a time.
 // Replaces gym.set_dof_actuation_force_tensor + gym.simulate + refresh_* (reference go1.py:52-56, legged_robot.py:
-// 122-124); the reference delegates this to Isaac Gym / PhysX, so the algorithm is this build's own (DESIGN.md).
+// 122-124); the reference delegates this to Isaac Gym / PhysX, so the algorithm is this build's own (DESIGN.md section 4).
 //
 // Mapping: ONE ENVIRONMENT PER 64-LANE WAVEFRONT (one wave per workgroup).  Lanes take different roles per phase:
-//   body lanes   (A*13 + P)   forward kinematics by tree level, spatial inertia / bias wrench about the base origin,
-//                             composite sums up the 3-link leg chains with lane shuffles
-//   leg lanes    (A*4)        3x3 leg block inverse, Schur terms;   (A*6) lanes: 6x6 base Schur complement inverse
-//   dof lanes    (A*18 + P*k) rows of M^-1, unconstrained velocity, and the velocity-space projected Gauss-Seidel
-//                             sweep: per contact every dof lane forms its Jacobian column on the fly, three wave
-//                             reductions give the contact-point velocity, the impulse update is uniform, and each lane
-//                             applies its own row of B = M^-1 J^T from LDS
-//   sphere lanes (A*27 + ..)  collision spheres vs ground plane / wall signed-distance field / other actors' spheres,
-//                             compacted with ballots into a bounded, canonically ordered contact list
-// Link transforms, M^-1 (18x18 per robot), B rows and the contact list live in LDS; state is read from and written to
-// HBM exactly once per launch, coalesced (the env-major rows of one env are contiguous).
+//   body lanes    (A*13 + P)   forward kinematics by tree level, spatial inertia / bias wrench about the base origin,
+//                              composite sums up the 3-link leg chains with lane shuffles
+//   leg lanes     (A*4)        3x3 leg block inverse, Schur terms;   (A*6) lanes: 6x6 base Schur complement inverse
+//   task lanes                 rows of M^-1, B = M^-1 J^T per (contact side, dof), 3x3 coupling blocks per contact pair
+//   sphere lanes  (2*27 / P)   collision spheres vs ground plane / wall signed-distance field / static scenery boxes /
+//                              1-dof link (plank, door, disc) / free box / other actors' spheres, compacted with ballots
+//                              into a bounded, canonically ordered contact list
+//   contact lanes (<= maxc)    sparse Jacobian rows, then projected Gauss-Seidel in CONTACT space: a lane owns its contact's
+//                              relative velocity and impulse, increments travel by ds_bpermute / v_readlane
+//   dof lanes     (<= 2 x 64)  unconstrained velocity, impulses -> velocities, joint limits, integration (velocities in LDS)
+// Link transforms, M^-1 (18x18 per robot), contact rows and coupling blocks live in LDS (layout: phys_lds_layout); with
+// k_substeps the state is read from and written to HBM once per env.step(), coalesced (the env-major rows of one env are
+// contiguous), and the actuator network / PD law of every substep runs inside the same wavefront.
 #pragma once
 #include "mqe_common.hpp"
 
@@ -99,7 +101,7 @@ struct PhysLds {   // float offsets into dynamic LDS
   int root, dof, tau, body, minv, rhs, fcol, leg, basei, sinv, tt, sph, con, B, js, kk, total;
 };
 __host__ __device__ inline int mqe_maxpair(int maxc) { return maxc / 2; }    // two-actor contacts kept per env
-__host__ __device__ inline PhysLds phys_lds_layout(int A, int P, int ND, int nbody, int ndof, int nsph, int maxc, int bstride) {
+__host__ __device__ inline PhysLds phys_lds_layout(int A, int P, int ND, int nbody, int ndof, int nsph, int maxc) {
   // Regions that live to the end of the substep first; then an ARENA shared by (a) everything that is dead once the
   // contact rows exist (link records, CRBA/Schur scratch, collision spheres) and (b) the coupling blocks, which are
   // only written after (a) has been consumed.  Inside (a) the spheres overlay the CRBA/Schur scratch (dead once M^-1
@@ -143,8 +145,8 @@ enum { PS_LOAD_STATE = 1, PS_LOAD_TAU = 2, PS_STORE_STATE = 4, PS_WRITE_CF = 8 }
 __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, const DevState& st, float* lds, const int e, const int lane,
                                              const int flags, const int no_write, const PhysDebug& dbg) {
   const int A = m->A, P = m->P, PD = m->n_npc_dyn, npcdof = m->npc_dofs_each;
-  const int nbody = m->nbody_env, ndof = m->ndof_env, nsph = m->nsph_env, maxc = m->maxc, bs = m->ldsB_stride;
-  const PhysLds L = phys_lds_layout(A, P, m->ND, nbody, ndof, nsph, maxc, bs);
+  const int nbody = m->nbody_env, ndof = m->ndof_env, nsph = m->nsph_env, maxc = m->maxc;
+  const PhysLds L = phys_lds_layout(A, P, m->ND, nbody, ndof, nsph, maxc);
   const float dt = m->dt;
   const mqe_robot_model& rm = m->robot;
   float* g_root = st.root + (size_t)e * (A + P) * 13;
@@ -1112,7 +1114,7 @@ __global__ void __launch_bounds__(64, 2) k_substeps(const DevModel* __restrict__
   extern __shared__ float lds[];
   const int lane = threadIdx.x, e = blockIdx.x;
   const int A = m->A, P = m->P;
-  const PhysLds L = phys_lds_layout(A, P, m->ND, m->nbody_env, m->ndof_env, m->nsph_env, m->maxc, m->ldsB_stride);
+  const PhysLds L = phys_lds_layout(A, P, m->ND, m->nbody_env, m->ndof_env, m->nsph_env, m->maxc);
   const int j32 = lane & 31, h = lane >> 5;
   const int nj = 12 * A;
   const float* W0 = m->actuator.W[0]; const float* b0 = m->actuator.b[0];

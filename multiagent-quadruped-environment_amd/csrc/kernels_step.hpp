@@ -149,22 +149,14 @@ __global__ void k_post_policy(const DevModel* m, DevState st, const float* __res
 
 // body layer 0 finish: v = (hist . W + b) + lat0*w0 + lat1*w1 ; ELU   (go1.py:404: body(cat(history, latent)))
 __global__ void k_body_l0_finish(float* __restrict__ P1, int ldp, int col0, int ncols, const float* __restrict__ lat, int ldl,
-                                 const float* __restrict__ w_lat0, const float* __restrict__ w_lat1, int R,
-                                 uint16_t* __restrict__ P3, size_t plane) {
+                                 const float* __restrict__ w_lat0, const float* __restrict__ w_lat1, int R) {
   int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= R * ncols) return;
   int i = idx / ncols, c = idx - i * ncols;
   float v = P1[(size_t)i * ldp + col0 + c];
   v = fmaf(lat[(size_t)i * ldl], w_lat0[c], v);
   v = fmaf(lat[(size_t)i * ldl + 1], w_lat1[c], v);
-  v = v > 0 ? v : expm1f(v);
-  P1[(size_t)i * ldp + col0 + c] = v;
-  if (P3) {
-    uint16_t h, l, sm;
-    split3(v, h, l, sm);
-    uint16_t* o = P3 + (size_t)i * ldp + col0 + c;
-    o[0] = h; o[plane] = l; o[2 * plane] = sm;
-  }
+  P1[(size_t)i * ldp + col0 + c] = v > 0 ? v : expm1f(v);
 }
 
 // ----------------------------------------------------------------------------------------------------------------

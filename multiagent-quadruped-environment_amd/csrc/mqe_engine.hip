@@ -202,9 +202,8 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   m.ndof_env = A * MQE_RD + m.n_npc_dyn * m.npc_dofs_each + (seesaw ? 1 : 0);
   m.nsph_env = A * d->robot.n_spheres + m.n_npc_dyn * d->npc_n_spheres;
   m.maxc = mqe_maxc(A, P, m.cap_npc);
-  m.ldsB_stride = m.ndof_env;
   if (m.ndof_env > 128 || m.nbody_env > 64) { delete s; return fail(-4, "env has more than 64 bodies or 128 generalized velocities: does not fit one wavefront"); }
-  PhysLds L = phys_lds_layout(A, P, s->ND, m.nbody_env, m.ndof_env, m.nsph_env, m.maxc, m.ldsB_stride);
+  PhysLds L = phys_lds_layout(A, P, s->ND, m.nbody_env, m.ndof_env, m.nsph_env, m.maxc);
   s->phys_lds_bytes = (size_t)L.total * 4;
   if (s->phys_lds_bytes > 160 * 1024) { delete s; return fail(-4, "physics LDS footprint exceeds 160 KiB"); }
   if (s->phys_lds_bytes > 48 * 1024)
@@ -477,7 +476,7 @@ static int policy_step(mqe_sim* s, const float* command, hipStream_t q, const fl
   {
     int n = R * s->body_h0;
     hipLaunchKernelGGL(k_body_l0_finish, dim3((n + 255) / 256), dim3(256), 0, q, s->P1, s->ldP1, s->ada_h0, s->body_h0,
-                       (const float*)s->lat, s->ldlat, (const float*)s->w_lat0, (const float*)s->w_lat1, R, (uint16_t*)nullptr, (size_t)0);
+                       (const float*)s->lat, s->ldlat, (const float*)s->w_lat0, (const float*)s->w_lat1, R);
   }
   x = s->P1 + s->ada_h0; ldx = s->ldP1;
   for (size_t l = 0; l < s->body_rest.size(); l++) {
