@@ -143,7 +143,10 @@ def main():
     for _ in range(args.warmup):
         one_step()
     drain()
-    eng.profile_enable(True)
+    # HIP events around each kernel class on the launch stream, on every PROF_EVERY-th step of the timed region (an event
+    # pair costs ~4 us of GPU timeline; bracketing all 5 classes of every step would inflate ms_per_step by 7 %)
+    prof_every = 0 if os.environ.get("MQE_BENCH_NOPROF") else max(1, int(os.environ.get("MQE_BENCH_PROF_EVERY", "8")))
+    eng.profile_enable(prof_every)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -175,7 +178,7 @@ def main():
         split = os.environ.get("MQE_GEMM_B3", "1") != "0"
         d = eng.desc
         h_a, h_b = d.adaptation.dims[1], d.body.dims[1]
-        l0_ms = kms[0] / max(cnt[0], 1)
+        l0_ms = max(kms[0] / max(cnt[0], 1), 1e-9)
         flops32 = 2.0 * R * 2100 * (h_a + h_b)                        # algorithmic: unpadded K = 30 x 70, f32 products
         if split:   # every f32 product = six bf16 x bf16 terms on the matrix cores, K padded to 2176
             l0 = {"kernel": "k_gemm_b3 (fused layer 0 of adaptation+body MLP over the history ring; 3-plane split-bf16 operands, f32-equivalent)",
@@ -189,7 +192,8 @@ def main():
             roof = l0
         else:
             avg_ms = kms[dom] / max(cnt[dom], 1)
-            per_launch = max(1.0, cnt[dom] / args.steps)              # launches of this kernel class per env step
+            sampled = max(1, -(-args.steps // max(prof_every, 1)))     # env steps whose launches were bracketed
+            per_launch = max(1.0, cnt[dom] / sampled)                 # launches of this kernel class per env step
             byts = 10128.0 * R / per_launch                           # 10128 B per agent-step
             ach = byts / (avg_ms * 1e-3) / 1e9
             roof = {"kernel": PROF_NAMES[dom], "bound": "hbm", "achieved": round(ach, 3), "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -224,7 +228,8 @@ def main():
             "roofline_policy_layer0": l0,
             "hbm_step_algorithmic_GBps": round(step_bytes * args.steps / elapsed / 1e9, 3),
             "kernel_time_share": {PROF_NAMES[i]: round(kms[i] / tot, 4) for i in range(6)},
-            "gpu_busy_ms_per_step": round(tot / args.steps, 4),
+            "gpu_busy_ms_per_step": round(tot / max(1, -(-args.steps // max(prof_every, 1))), 4),
+            "hip_event_sampling": f"kernel classes of every {prof_every}-th timed step bracketed" if prof_every else "off",
         }
         if not args.no_cpu_baseline and world == 1:
             torch.set_num_threads(os.cpu_count() or 1)

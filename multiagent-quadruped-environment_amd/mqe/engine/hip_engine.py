@@ -103,7 +103,8 @@ class HipEngine(EngineBase):
         return minv, con[:nc.value]
 
     def profile_enable(self, on=True):
-        self._call("profile_enable", int(bool(on)))
+        """on: False/0 = off, True/1 = bracket every fused step with HIP events, k > 1 = every k-th fused step."""
+        self._call("profile_enable", int(on))
 
     def profile_read(self, n=16):
         buf = (C.c_float * n)()
