@@ -28,12 +28,12 @@ sys.path.insert(0, os.path.join(ROOT, "multiagent-quadruped-environment_amd"))
 
 import torch  # noqa: E402
 
-PROF_NAMES = ["policy_layer0(k_gemm_b3 | k_gemm_f32)", "policy_tail(k_policy_tail | k_gemm_f32 x5 + k_body_l0_finish + k_post_policy)",
+PROF_NAMES = ["policy_layer0(k_gemm_h2 | k_gemm_f32)", "policy_tail(k_policy_tail | k_gemm_f32 x5 + k_body_l0_finish + k_post_policy)",
               "torques(unfused path only)", "substeps(k_substeps: 4 x {actuator-net MFMA + physics substep})",
               "post(k_post_physics + k_reset_history)", "misc(k_wrapper_command + k_pre_policy)"]
-PROF_KERNEL = ["k_gemm_b3", "k_gemm_f32", "k_compute_torques_mfma", "k_substeps", "k_post_physics", "k_pre_policy"]
+PROF_KERNEL = ["k_gemm_h2", "k_gemm_f32", "k_compute_torques_mfma", "k_substeps", "k_post_physics", "k_pre_policy"]
 PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak
-PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
+PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16 / bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec peak
 
 
@@ -175,14 +175,14 @@ def main():
         dom = max(range(6), key=lambda i: kms[i])
         R = N * A
         roof = None
-        split = os.environ.get("MQE_GEMM_B3", "1") != "0"
+        split = os.environ.get("MQE_GEMM_SPLIT", "1") != "0"
         d = eng.desc
         h_a, h_b = d.adaptation.dims[1], d.body.dims[1]
         l0_ms = max(kms[0] / max(cnt[0], 1), 1e-9)
         flops32 = 2.0 * R * 2100 * (h_a + h_b)                        # algorithmic: unpadded K = 30 x 70, f32 products
-        if split:   # every f32 product = six bf16 x bf16 terms on the matrix cores, K padded to 2176
-            l0 = {"kernel": "k_gemm_b3 (fused layer 0 of adaptation+body MLP over the history ring; 3-plane split-bf16 operands, f32-equivalent)",
-                  "bound": "mfma", "achieved": round(6 * 2.0 * R * 2176 * (h_a + h_b) / (l0_ms * 1e-3) / 1e12, 2), "peak": PEAK_BF16_MFMA_TFLOPS,
+        if split:   # every f32 product = three f16 x f16 terms on the matrix cores, K padded to 2176
+            l0 = {"kernel": "k_gemm_h2 (fused layer 0 of adaptation+body MLP over the history ring; 2-plane split-f16 operands, 3 MFMA terms per product, f32-class accuracy)",
+                  "bound": "mfma", "achieved": round(3 * 2.0 * R * 2176 * (h_a + h_b) / (l0_ms * 1e-3) / 1e12, 2), "peak": PEAK_F16_MFMA_TFLOPS,
                   "unit": "TFLOP/s", "f32_equivalent_TFLOPs": round(flops32 / (l0_ms * 1e-3) / 1e12, 2)}
         else:
             l0 = {"kernel": "k_gemm_f32 (fused layer 0, exact f32 MFMA)", "bound": "mfma", "achieved": round(flops32 / (l0_ms * 1e-3) / 1e12, 3),
@@ -205,7 +205,7 @@ def main():
             import glob
             pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.json")))[-1]))
             if N == 4096 and args.task == "go1gate":
-                kname = ("k_gemm_b3" if split else "k_gemm_f32") if dom == 0 else PROF_KERNEL[dom]
+                kname = ("k_gemm_h2" if split else "k_gemm_f32") if dom == 0 else PROF_KERNEL[dom]
                 e = pmc.get(kname, {})
                 roof["traffic"] = (e.get("fetch_bytes_x2", 0) + e.get("write_bytes_raw", 0)) if dom == 0 else e.get("hbm_bytes_raw")
                 for k in ("frac_wave_time_issuing", "frac_wave_time_issue_stalled", "frac_wave_time_waiting_on_waitcnt_or_barrier"):

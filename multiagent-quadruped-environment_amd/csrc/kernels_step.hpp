@@ -127,12 +127,12 @@ __global__ void k_pre_policy(const DevModel* m, DevState st, const float* __rest
   lo[c] = v;
   const size_t hidx = ((size_t)i * MQE_HIST + hist_slot) * MQE_FRAME + c;
   st.hist[hidx] = v;   // :102
-  if (st.hist3) {      // the split-bf16 GEMM's operand copy: three bf16 planes (kernels_gemm.hpp)
-    uint16_t h, l, sm;
-    split3(v, h, l, sm);
-    uint16_t* row3 = st.hist3 + (size_t)i * (3 * MQE_HIST * MQE_FRAME);
+  if (st.hist2) {      // the split-f16 GEMM's operand copy: two f16 planes (kernels_gemm.hpp)
+    uint16_t h, l;
+    split2(v, MQE_H2_ASCALE, h, l);
+    uint16_t* row2 = st.hist2 + (size_t)i * (2 * MQE_HIST * MQE_FRAME);
     const size_t k = (size_t)hist_slot * MQE_FRAME + c;
-    row3[b3_index(k, 0)] = h; row3[b3_index(k, 1)] = l; row3[b3_index(k, 2)] = sm;
+    row2[h2_index(k, 0)] = h; row2[h2_index(k, 1)] = l;
   }
 }
 
@@ -703,7 +703,7 @@ __global__ void __launch_bounds__(64) k_post_physics(const DevModel* m, DevState
   uint8_t reset = 0;
   if (threadIdx.x < POST_EPW && e < m->N) reset = post_physics_env(m, st, e, wrapper_level);
   // go1.py:145: history[agent_ids] = 0 for the envs that reset this step -- rare, so the whole wavefront (the lanes that
-  // idled above included) zeroes them, 16 B per lane per request: the f32 ring and, when present, its three bf16 planes
+  // idled above included) zeroes them, 16 B per lane per request: the f32 ring and, when present, its two f16 planes
   unsigned long long rm = __ballot(reset != 0);
   while (rm) {
     const int l = __ffsll((long long)rm) - 1;
@@ -712,10 +712,10 @@ __global__ void __launch_bounds__(64) k_post_physics(const DevModel* m, DevState
     const int per = m->A * (MQE_HIST * MQE_FRAME / 4);                 // float4 units of this env's robots (contiguous)
     float4* h4 = reinterpret_cast<float4*>(st.hist) + (size_t)er * per;
     for (int i = threadIdx.x; i < per; i += 64) h4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (st.hist3) {                                                    // same robots, 3 planes interleaved: 3x the bytes / 2
-      uint4* p4 = reinterpret_cast<uint4*>(st.hist3 + (size_t)er * m->A * (3 * MQE_HIST * MQE_FRAME));
-      const int per3 = m->A * (3 * MQE_HIST * MQE_FRAME / 8);
-      for (int i = threadIdx.x; i < per3; i += 64) p4[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (st.hist2) {                                                    // same robots, 2 planes interleaved: the same bytes
+      uint4* p4 = reinterpret_cast<uint4*>(st.hist2 + (size_t)er * m->A * (2 * MQE_HIST * MQE_FRAME));
+      const int per2 = m->A * (2 * MQE_HIST * MQE_FRAME / 8);
+      for (int i = threadIdx.x; i < per2; i += 64) p4[i] = make_uint4(0u, 0u, 0u, 0u);
     }
   }
 }
@@ -866,11 +866,11 @@ __global__ void k_reset_history(const DevModel* m, DevState st) {
   if (i >= m->R) return;
   if (!st.reset_buf[i / m->A]) return;
   reinterpret_cast<float4*>(st.hist)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (st.hist3) {      // the same 4 elements in each of the three planes
+  if (st.hist2) {      // the same 4 elements in both planes
     const size_t k = (size_t)(idx - i * per) * 4;
-    uint16_t* row3 = st.hist3 + (size_t)i * (3 * MQE_HIST * MQE_FRAME);
+    uint16_t* row2 = st.hist2 + (size_t)i * (2 * MQE_HIST * MQE_FRAME);
 #pragma unroll
-    for (int p = 0; p < 3; p++) *reinterpret_cast<uint2*>(row3 + b3_index(k, p)) = make_uint2(0u, 0u);
+    for (int p = 0; p < 2; p++) *reinterpret_cast<uint2*>(row2 + h2_index(k, p)) = make_uint2(0u, 0u);
   }
 }
 

@@ -56,25 +56,22 @@ struct DevState {
   float *root, *dof, *cf, *torques, *actions, *last_actions, *loco_obs, *hist, *last_loco, *last_two_loco, *act_hist;
   float *gait, *clock, *blv, *bav, *pg, *bquat, *obs_bag, *wobs, *wrew, *rsum, *sheep_avg, *sheep_var, *sub_tau, *npc_noise;
   float *w_last, *w_last2, *cmd, *last_dof_vel;
-  uint16_t* hist3;                          // split-bf16 copy of the history ring: [R][270 units][3 planes][8] (k_gemm_b3)
+  uint16_t* hist2;                          // split-f16 copy of the history ring: [R][270 units][2 planes][8] (k_gemm_h2)
   int32_t *ep_len, *reset_count;
   uint8_t *reset_buf, *collide_buf, *time_out, *r_term, *p_term, *zh_term, *w_have_last, *w_delayed_reset;
 };
 
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
 
-// f32 -> three bf16 planes (h + l + s == x to 24 significand bits); see k_gemm_b3 in kernels_gemm.hpp
-__host__ __device__ __forceinline__ uint16_t bf16_rne(float x) {
-  union { float f; uint32_t u; } v; v.f = x;
-  v.u += 0x7fffu + ((v.u >> 16) & 1u);
-  return (uint16_t)(v.u >> 16);
+// f32 -> two f16 planes of scale * x (h + l == scale * x to 22 significand bits); see k_gemm_h2 in kernels_gemm.hpp
+#define MQE_H2_ASCALE 64.0f                 // activation scale c_a: |x| <= 1023 representable, beyond that the value saturates
+__host__ __device__ __forceinline__ uint16_t f16_bits(_Float16 h) { union { _Float16 f; uint16_t u; } v; v.f = h; return v.u; }
+__host__ __device__ __forceinline__ void split2(float x, float scale, uint16_t& h, uint16_t& l) {
+  float y = x * scale;
+  y = y > 65504.0f ? 65504.0f : (y < -65504.0f ? -65504.0f : y);       // NaN falls through (and propagates, as in f32)
+  const _Float16 hh = (_Float16)y;                                      // round to nearest even
+  h = f16_bits(hh);
+  l = f16_bits((_Float16)(y - (float)hh));
 }
-__host__ __device__ __forceinline__ float bf16_f32(uint16_t h) { union { float f; uint32_t u; } v; v.u = (uint32_t)h << 16; return v.f; }
-__host__ __device__ __forceinline__ void split3(float x, uint16_t& h, uint16_t& l, uint16_t& s) {
-  h = bf16_rne(x);
-  const float r1 = x - bf16_f32(h);
-  l = bf16_rne(r1);
-  s = bf16_rne(r1 - bf16_f32(l));
-}
-// element offset of (row-local element k, plane p) in the plane-interleaved layout of k_gemm_b3
-__host__ __device__ __forceinline__ size_t b3_index(size_t k, int p) { return ((k >> 3) * 3 + p) * 8 + (k & 7); }
+// element offset of (row-local element k, plane p) in the plane-interleaved layout of k_gemm_h2
+__host__ __device__ __forceinline__ size_t h2_index(size_t k, int p) { return ((k >> 3) * 2 + p) * 8 + (k & 7); }

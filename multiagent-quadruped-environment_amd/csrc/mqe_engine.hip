@@ -31,7 +31,8 @@ struct GemmLayer {
   float* Wt;      // device [Kpad][Npad]            (exact-f32 path, k_gemm_f32)
   float* bias;    // device [Npad]
   int K, N, Kpad, Npad;
-  uint16_t* W3 = nullptr;   // device, 3 bf16 planes of [Npad][Kpad3] (split-bf16 path, k_gemm_b3)
+  uint16_t* W2 = nullptr;   // device, 2 f16 planes of wscale * [Npad][Kpad3] (split-f16 path, k_gemm_h2)
+  float wscale = 1.0f;
   int Kpad3 = 0;
   std::vector<float> hW;    // host staging [Npad][Kpad3] until finalize_layer
 };
@@ -92,7 +93,7 @@ static inline int rup(int v, int m) { return (v + m - 1) / m * m; }
 
 // W (out,in) row-major host -> Wt [Kpad][Npad] device at column offset; rows remapped by `rowmap` (-1 = zero row)
 static int make_layer(mqe_sim* s, GemmLayer* L, int K, int N) {
-  L->K = K; L->N = N; L->Kpad = rup(K, GB_K); L->Npad = rup(N, GB_N); L->Kpad3 = rup(K, 2 * G3_K);
+  L->K = K; L->N = N; L->Kpad = rup(K, GB_K); L->Npad = rup(N, GB_N); L->Kpad3 = rup(K, 2 * H2_K);
   L->hW.assign((size_t)L->Npad * L->Kpad3, 0.0f);
   if (dalloc(s, &L->Wt, (size_t)L->Kpad * L->Npad)) return -1;
   if (dalloc(s, &L->bias, L->Npad)) return -1;
@@ -112,17 +113,23 @@ static int fill_layer(GemmLayer* L, int col0, const float* W, const float* b, in
   return 0;
 }
 
-// split the staged weights into the three bf16 planes and upload them
+// split the staged weights into the two f16 planes (scaled by a power of two that puts max|w| in [16384, 32768]) and upload them
 static int finalize_layer(mqe_sim* s, GemmLayer* L) {
   const size_t n = (size_t)L->Npad * L->Kpad3;
-  std::vector<uint16_t> pl(3 * n);
+  float wmax = 0.0f;
+  for (size_t i = 0; i < n; i++) wmax = std::max(wmax, std::fabs(L->hW[i]));
+  if (!(wmax < 1e30f)) return -1;
+  int e = wmax > 0.0f ? (int)std::floor(std::log2(32768.0f / wmax)) : 0;
+  e = std::min(std::max(e, -100), 100);
+  L->wscale = std::ldexp(1.0f, e);
+  std::vector<uint16_t> pl(2 * n);
   for (int r = 0; r < L->Npad; r++)
     for (int k = 0; k < L->Kpad3; k++) {
-      uint16_t* row = pl.data() + (size_t)r * 3 * L->Kpad3;
-      split3(L->hW[(size_t)r * L->Kpad3 + k], row[b3_index(k, 0)], row[b3_index(k, 1)], row[b3_index(k, 2)]);
+      uint16_t* row = pl.data() + (size_t)r * 2 * L->Kpad3;
+      split2(L->hW[(size_t)r * L->Kpad3 + k], L->wscale, row[h2_index(k, 0)], row[h2_index(k, 1)]);
     }
-  if (dalloc(s, &L->W3, 3 * n, 0)) return -1;
-  if (hipMemcpy(L->W3, pl.data(), 3 * n * 2, hipMemcpyHostToDevice) != hipSuccess) return -1;
+  if (dalloc(s, &L->W2, 2 * n, 0)) return -1;
+  if (hipMemcpy(L->W2, pl.data(), 2 * n * 2, hipMemcpyHostToDevice) != hipSuccess) return -1;
   L->hW.clear(); L->hW.shrink_to_fit();
   return 0;
 }
@@ -246,20 +253,20 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
     UP(t, w0.data(), w0.size()); s->w_lat0 = (float*)t;
     UP(t, w1.data(), w1.size()); s->w_lat1 = (float*)t;
   }
-  // Layer 0 runs on the bf16 matrix cores with three-plane split operands (f32-equivalent accuracy, k_gemm_b3) whenever
-  // its width tiles by 192; MQE_GEMM_B3=0 selects the exact-f32 MFMA kernel instead (0.255 ms vs 0.157 ms at 8192 rows).
+  // Layer 0 runs on the f16 matrix cores with two-plane split operands (f32-class accuracy, k_gemm_h2) whenever
+  // its width tiles by 192; MQE_GEMM_SPLIT=0 selects the exact-f32 MFMA kernel instead (0.255 ms vs 0.104 ms at 8192 rows).
   {
-    // Which kernel for layer 0?  k_gemm_b3 owns a whole CU per 128 x 192 tile: its time is a staircase in R (157 us per
+    // Which kernel for layer 0?  k_gemm_h2 owns a whole CU per 128 x 192 tile: its time is a staircase in R (104 us per
     // started round of 256 tiles), the exact-f32 kernel scales linearly (255 us at R = 8192).  Pick the faster one for this
-    // batch unless MQE_GEMM_B3 forces a choice.
-    const char* f = getenv("MQE_GEMM_B3");
-    const double rounds = std::ceil(((R + G3_M - 1) / G3_M) * (double)(s->l0.Npad / G3_N) / 256.0);
-    const bool faster = rounds * 157.0 < 255.0 * R / 8192.0;
-    s->gemm_split = s->l0.Npad % G3_N == 0 && (f ? atoi(f) != 0 : faster);
+    // batch unless MQE_GEMM_SPLIT forces a choice.
+    const char* f = getenv("MQE_GEMM_SPLIT");
+    const double rounds = std::ceil(((R + H2_M - 1) / H2_M) * (double)(s->l0.Npad / H2_N) / 256.0);
+    const bool faster = rounds * 104.0 < 255.0 * R / 8192.0;
+    s->gemm_split = s->l0.Npad % H2_N == 0 && (f ? atoi(f) != 0 : faster);
   }
   if (s->gemm_split) {
     if (finalize_layer(s, &s->l0)) return fail(-5, "upload");
-    if (hipFuncSetAttribute((const void*)k_gemm_b3, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)k_gemm_h2, hipFuncAttributeMaxDynamicSharedMemorySize, H2_LDS_BYTES) != hipSuccess)
       return fail(-4, "cannot raise dynamic LDS limit");
   }
   for (int l = 1; l < ad.n_layers; l++) {
@@ -288,8 +295,8 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   DA(st.root, (size_t)N * (A + P) * 13); DA(st.dof, (size_t)N * s->ND * 2); DA(st.cf, (size_t)N * s->NBR * 3);
   DA(st.torques, (size_t)N * 12 * A); DA(st.actions, (size_t)N * 12 * A); DA(st.last_actions, (size_t)N * 12 * A);
   DA(st.loco_obs, (size_t)R * MQE_FRAME); DA(st.hist, (size_t)R * MQE_HIST * MQE_FRAME);
-  st.hist3 = nullptr;
-  if (s->gemm_split) { DA(st.hist3, (size_t)3 * R * MQE_HIST * MQE_FRAME); }
+  st.hist2 = nullptr;
+  if (s->gemm_split) { DA(st.hist2, (size_t)2 * R * MQE_HIST * MQE_FRAME); }
   DA(st.last_loco, (size_t)R * 12); DA(st.last_two_loco, (size_t)R * 12); DA(st.act_hist, (size_t)4 * R * 12);
   DA(st.gait, R); DA(st.clock, (size_t)R * 4); DA(st.blv, (size_t)R * 3); DA(st.bav, (size_t)R * 3); DA(st.pg, (size_t)R * 3);
   DA(st.bquat, (size_t)R * 4); DA(st.obs_bag, (size_t)R * MQE_OBS_BAG); DA(st.wobs, (size_t)N * s->Aw * s->D + (size_t)N * s->Aw); st.wrew = st.wobs + (size_t)N * s->Aw * s->D;   // one buffer
@@ -427,14 +434,15 @@ static void launch_gemm(hipStream_t q, const float* A, int lda, int rot4, int ri
   hipLaunchKernelGGL(k_gemm_f32, dim3(grid), dim3(256), 0, q, g);
 }
 
-static void launch_gemm3(hipStream_t q, const uint16_t* A, int lda, int rot8, int ring8, const GemmLayer& L,
+static void launch_gemm2(hipStream_t q, const uint16_t* A, int lda, int rot8, int ring8, const GemmLayer& L,
                          float* C, int ldc, int M, int act_cols) {
-  Gemm3Args g;
+  Gemm2Args g;
   g.A = A; g.lda = lda; g.a_rot8 = rot8; g.a_ring8 = ring8;
-  g.W = L.W3; g.ldw = 3 * L.Kpad3; g.bias = L.bias;
+  g.W = L.W2; g.ldw = 2 * L.Kpad3; g.bias = L.bias;
   g.C = C; g.ldc = ldc; g.M = M; g.N = L.Npad; g.K = L.Kpad3; g.act_cols = act_cols;
-  int grid = ((M + G3_M - 1) / G3_M) * (L.Npad / G3_N);
-  hipLaunchKernelGGL(k_gemm_b3, dim3(grid), dim3(256), G3_LDS_BYTES, q, g);
+  g.descale = 1.0f / (MQE_H2_ASCALE * L.wscale);
+  int grid = ((M + H2_M - 1) / H2_M) * (L.Npad / H2_N);
+  hipLaunchKernelGGL(k_gemm_h2, dim3(grid), dim3(256), H2_LDS_BYTES, q, g);
 }
 
 static int policy_step(mqe_sim* s, const float* command, hipStream_t q, const float* wrapper_actions = nullptr) {
@@ -449,7 +457,7 @@ static int policy_step(mqe_sim* s, const float* command, hipStream_t q, const fl
     ProfScope ps(s, PROF_GEMM_L0, q);
     // fused layer 0 of both networks over the ring: ELU on the adaptation columns only
     if (s->gemm_split)
-      launch_gemm3(q, s->st.hist3, 3 * MQE_HIST * MQE_FRAME, s->hist_pos * (MQE_FRAME / 8), MQE_HIST * MQE_FRAME / 8, s->l0,
+      launch_gemm2(q, s->st.hist2, 2 * MQE_HIST * MQE_FRAME, s->hist_pos * (MQE_FRAME / 8), MQE_HIST * MQE_FRAME / 8, s->l0,
                    s->P1, s->ldP1, R, s->ada_h0);
     else
       launch_gemm(q, s->st.hist, MQE_HIST * MQE_FRAME, s->hist_pos * (MQE_FRAME / 4), MQE_HIST * MQE_FRAME / 4, s->l0, s->P1, s->ldP1, R, s->ada_h0);

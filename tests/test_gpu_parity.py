@@ -75,15 +75,15 @@ def test_single_substep_matches_oracle(task, N):
         close(eh.tensor(abi.T_CONTACT_FORCE), eo.tensor(abi.T_CONTACT_FORCE), atol=0.5, rtol=2e-2, what="net contact force")
 
 
-@pytest.mark.parametrize("b3,N", [("1", 64), ("0", 64), ("1", 101)])     # 101 envs: 202 rows = one full + one ragged 128-row tile
-def test_policy_layer0_paths_are_f32_equivalent(monkeypatch, b3, N):
-    """Layer 0 of the locomotion policy runs on the bf16 matrix cores with three-plane split operands (k_gemm_b3,
-    large batches by default) or on the exact-f32 MFMA kernel (MQE_GEMM_B3=0; the engine picks by batch size otherwise).  Either way the joint targets must agree with the CPU
+@pytest.mark.parametrize("split,N", [("1", 64), ("0", 64), ("1", 101)])     # 101 envs: 202 rows = one full + one ragged 128-row tile
+def test_policy_layer0_paths_are_f32_equivalent(monkeypatch, split, N):
+    """Layer 0 of the locomotion policy runs on the f16 matrix cores with two-plane split operands (k_gemm_h2: hh + hl + lh,
+    large batches by default) or on the exact-f32 MFMA kernel (MQE_GEMM_SPLIT=0; the engine picks by batch size otherwise).  Either way the joint targets must agree with the CPU
     oracle's f32 fmaf chain to |diff| <= 5e-5 on O(1) outputs after a history of 12 random steps (tolerance = f32
-    accumulation-order noise; a plain bf16 or TF32 product would miss it by two orders of magnitude)."""
-    monkeypatch.setenv("MQE_GEMM_B3", b3)
+    accumulation-order noise; a plain f16, bf16 or TF32 product would miss it by two orders of magnitude)."""
+    monkeypatch.setenv("MQE_GEMM_SPLIT", split)
     eh, eo, d = _pair("go1gate", N)
-    monkeypatch.delenv("MQE_GEMM_B3")
+    monkeypatch.delenv("MQE_GEMM_SPLIT")
     eh.reset_all(); eo.reset_all()
     g = torch.Generator().manual_seed(5)
     for t in range(12):
