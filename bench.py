@@ -180,9 +180,9 @@ def main():
         h_a, h_b = d.adaptation.dims[1], d.body.dims[1]
         l0_ms = max(kms[0] / max(cnt[0], 1), 1e-9)
         flops32 = 2.0 * R * 2100 * (h_a + h_b)                        # algorithmic: unpadded K = 30 x 70, f32 products
-        if split:   # every f32 product = three f16 x f16 terms on the matrix cores, K padded to 2176
+        if split:   # every f32 product = three f16 x f16 terms on the matrix cores, K padded to 2208 (a multiple of three 32-k tiles)
             l0 = {"kernel": "k_gemm_h2 (fused layer 0 of adaptation+body MLP over the history ring; 2-plane split-f16 operands, 3 MFMA terms per product, f32-class accuracy)",
-                  "bound": "mfma", "achieved": round(3 * 2.0 * R * 2176 * (h_a + h_b) / (l0_ms * 1e-3) / 1e12, 2), "peak": PEAK_F16_MFMA_TFLOPS,
+                  "bound": "mfma", "achieved": round(3 * 2.0 * R * 2208 * (h_a + h_b) / (l0_ms * 1e-3) / 1e12, 2), "peak": PEAK_F16_MFMA_TFLOPS,
                   "unit": "TFLOP/s", "f32_equivalent_TFLOPs": round(flops32 / (l0_ms * 1e-3) / 1e12, 2)}
         else:
             l0 = {"kernel": "k_gemm_f32 (fused layer 0, exact f32 MFMA)", "bound": "mfma", "achieved": round(flops32 / (l0_ms * 1e-3) / 1e12, 3),

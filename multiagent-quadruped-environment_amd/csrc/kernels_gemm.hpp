@@ -109,10 +109,18 @@ __global__ void __launch_bounds__(256) k_gemm_f32(GemmArgs g) {
 //     (|c x| < 6e-5 * 2^11) keep an absolute error of 2^-25 / c, far below the terms' own rounding.
 //   * producers write the planes (interleaved per 8-element unit, see Gemm2Args): k_pre_policy (new history frame);
 //     weights are split once on the host.
-//   * block 128 x 192, 4 waves as 2 x 2, wave tile 64 x 96 = 6 accumulators (0.55 fragment reads per MFMA).  M = 8192,
-//     N = 768 gives exactly 256 blocks = one per CU, so the pipeline is explicit instead of relying on other resident
-//     blocks: LDS double buffer (2 x 50 KB), k-tile t+2 in flight from global while tile t is multiplied and tile t+1 is
-//     written to the other buffer; one barrier per tile (tools/gen_gemm_h2.py emits the loop).
+//   * block 128 x 192 (M = 8192, N = 768: exactly 256 blocks = one per CU), 8 waves = 2 per SIMD with separate roles
+//     (tools/gen_gemm_h2.py emits the loop): waves 0-3 multiply (wave tile 64 x 96 = 6 accumulators, 0.55 fragment reads
+//     per MFMA, no vmcnt wait anywhere in their stream), waves 4-7 stage (global loads 3 k-tiles ahead into registers,
+//     LDS stores 2 tiles ahead into a ring of three 50 KB buffers); one barrier per k-tile.
+//   * what bounds it (standalone harness tools/dev/gemm_bench.hip, R = 8192, per launch): MFMAs alone 33 us + 12 us of
+//     prologue / epilogue; the global -> register stream alone 35 us (2.8 MB per CU = 80 GB/s per CU, the tile shape
+//     already minimises it); LDS stores and fragment reads slow each other down (1.6x the cycles of either alone); and
+//     with the loads running the shader clock drops from 2.4 to ~1.65 GHz (same cycle count, 1.5x the time).  Measured
+//     structures: every wave staging and multiplying, 4 waves 111 us (= the sum of the parts: each wait of the single
+//     instruction stream idles the SIMD's matrix pipe), 8 waves 94 us; roles split 93 us; roles split with direct
+//     global -> LDS loads (global_load_lds_dwordx4, 4 x 40 KB ring, XOR-swizzled rows) 101 us: the LDS-DMA path took
+//     ~200 cycles per instruction, 20 B/clk per CU.
 //   * LDS row = 32 k of one plane padded to 80 B, so the 16 B fragment reads of a ds_read_b128 lane group (16 rows)
 //     tile all 64 banks; the planes are 64 B apart modulo the 128 B store banking, so the 8 lanes that stage one row's
 //     128 contiguous global bytes (4 units x 2 planes) store conflict-free as well.
@@ -126,11 +134,15 @@ typedef __attribute__((address_space(1))) h2_u32x4 h2_gvec;
 #define H2_M 128
 #define H2_N 192
 #define H2_K 32
+#define H2_KMULT 96                                 // K must be a multiple of three k-tiles (the loop is unrolled over the ring)
+#define H2_THREADS 512
 #define H2_ROWB 80                                  // bytes per LDS row (64 B of data + 16 B pad)
 #define H2_ROWS (H2_M + H2_N)
 #define H2_PLANE (H2_ROWS * H2_ROWB + 64)           // one plane of a buffer: [A rows | W rows][80 B] (+ 64 B: see above)
 #define H2_BUF (2 * H2_PLANE)
-#define H2_LDS_BYTES (2 * H2_BUF)
+#define H2_LDS_BYTES (3 * H2_BUF)
+#define H2_EPS 196                                  // epilogue staging: floats per row of the 128 x 192 block tile (192 + 4)
+static_assert(H2_M * H2_EPS * 4 <= H2_LDS_BYTES, "epilogue staging");
 
 struct Gemm2Args {
   // operands are plane-interleaved per 8-element unit: row r, element k of plane p at r * ld + ((k / 8) * 2 + p) * 8 + k % 8
@@ -139,15 +151,15 @@ struct Gemm2Args {
   const uint16_t* W; int ldw;                          // W rows = output units (the (out,in) layout), same interleaving
   const float* bias;
   float* C; int ldc;
-  int M, N, K;                                         // N multiple of 192, K multiple of 64
-  int act_cols;
+  int M, N, K;                                         // N multiple of 192, K multiple of 96
+  int act_cols;                                        // multiple of 4
   float descale;                                       // 1 / (c_a c_w)
 };
 
-__global__ void __launch_bounds__(256, 1) k_gemm_h2(Gemm2Args g) {
+__global__ void __launch_bounds__(H2_THREADS, 1) k_gemm_h2(Gemm2Args g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds2[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = (wave >> 1) & 1, wn = wave & 1;               // multiplier waves 0..3 as 2 x 2
   const int ntn = g.N / H2_N, ntm = (g.M + H2_M - 1) / H2_M;
   int bid = blockIdx.x;
   const int total = ntn * ntm;
@@ -157,28 +169,30 @@ __global__ void __launch_bounds__(256, 1) k_gemm_h2(Gemm2Args g) {
   f32x16 acc00, acc01, acc02, acc10, acc11, acc12;
 #pragma unroll
   for (int i = 0; i < 16; i++) { acc00[i] = 0.0f; acc01[i] = 0.0f; acc02[i] = 0.0f; acc10[i] = 0.0f; acc11[i] = 0.0f; acc12[i] = 0.0f; }
-  // staging: 8 consecutive threads move the 128 B a row contributes to a k-tile (chunk c = tid & 7 = unit c / 2, plane
-  // c % 2), 32 rows per instruction: 4 instructions for the A tile, 6 for the W tile.  Everything but two per-thread byte
-  // offsets (A side with the ring rotation, W side) is wave-uniform, so the loads are SGPR base + VGPR offset.
-  const int srow = tid >> 3, sc = tid & 7, sj = sc >> 1, sp = sc & 1;
-  const bool a_ok0 = (m0 + srow) < g.M, a_ok1 = (m0 + 32 + srow) < g.M, a_ok2 = (m0 + 64 + srow) < g.M, a_ok3 = (m0 + 96 + srow) < g.M;
-  const char* Abase = reinterpret_cast<const char*>(g.A) + (size_t)m0 * g.lda * 2;
+  // staging (waves 4..7, 256 threads): 8 consecutive threads move the 128 B a row contributes to a k-tile (chunk c = unit
+  // c / 2, plane c % 2), 32 rows per instruction: 4 instructions for the A tile, 6 for the W tile.  Rows past M re-read
+  // row M - 1 (never stored) so that the loads are unconditional.
+  const int stid = tid & 255, srow = stid >> 3, sc = stid & 7, sj = sc >> 1, sp = sc & 1;
+  const char* Abase = reinterpret_cast<const char*>(g.A);
   const char* Wbase = reinterpret_cast<const char*>(g.W) + (size_t)n0 * g.ldw * 2;
-  const unsigned a_row = (unsigned)srow * g.lda * 2, a_row32 = 32u * g.lda * 2;
+  const unsigned a_row0 = (unsigned)min(m0 + srow, g.M - 1) * g.lda * 2, a_row1 = (unsigned)min(m0 + 32 + srow, g.M - 1) * g.lda * 2,
+                 a_row2 = (unsigned)min(m0 + 64 + srow, g.M - 1) * g.lda * 2, a_row3 = (unsigned)min(m0 + 96 + srow, g.M - 1) * g.lda * 2;
   const unsigned w_row = (unsigned)srow * g.ldw * 2, w_row32 = 32u * g.ldw * 2;
   const unsigned st_ofs = sp * H2_PLANE + srow * H2_ROWB + sj * 16;
   const int frow = lane & 31, fk = (lane >> 5) * 16;           // fragment: row, byte offset of its 8 k inside a 16-k step
   const unsigned fa_ofs = (wm * 64 + frow) * H2_ROWB + fk, fb_ofs = (H2_M + wn * 96 + frow) * H2_ROWB + fk;
-  const int nkt = g.K / H2_K;                                   // even (K is a multiple of 64)
+  const int nkt = g.K / H2_K;                                   // multiple of 3
   // All blocks walk K in the same order on purpose: the 64 blocks that share a W tile then touch the same window of W at
   // about the same time and it stays L2-resident.  (Rotating the k order per M-tile, which cured an L2-channel hot spot
   // in k_policy_tail, was measured here: same kernel time, 4x the HBM-side fetch traffic -- W no longer fits in L2.)
   unsigned char* buf0 = lds2;
   unsigned char* buf1 = lds2 + H2_BUF;
-  const h2_u32x4 z4 = {0u, 0u, 0u, 0u};
-  // two prefetch register sets [row block] and two fragment sets [tile][plane]; all named scalars
+  unsigned char* buf2 = lds2 + 2 * H2_BUF;
+  // three prefetch register sets [row block] (staging waves) and two fragment sets [tile][plane] (multiplier waves); all
+  // named scalars: arrays carried across the loop end up in scratch memory
   h2_u32x4 Pa0, Pa1, Pa2, Pa3, Pw0, Pw1, Pw2, Pw3, Pw4, Pw5;
   h2_u32x4 Qa0, Qa1, Qa2, Qa3, Qw0, Qw1, Qw2, Qw3, Qw4, Qw5;
+  h2_u32x4 Ra0, Ra1, Ra2, Ra3, Rw0, Rw1, Rw2, Rw3, Rw4, Rw5;
   h2_u32x4 f0a00, f0a01, f0a10, f0a11, f0b00, f0b01, f0b10, f0b11, f0b20, f0b21;
   h2_u32x4 f1a00, f1a01, f1a10, f1a11, f1b00, f1b01, f1b10, f1b11, f1b20, f1b21;
   unsigned aoff, woff;
@@ -188,14 +202,16 @@ __global__ void __launch_bounds__(256, 1) k_gemm_h2(Gemm2Args g) {
     woff = w_row + (unsigned)kc_ * 128u + (unsigned)sc * 16u;                                                   \
     int u_ = kc_ * 4 + sj;                                                                                      \
     if (g.a_ring8) { u_ += g.a_rot8; if (u_ >= g.a_ring8) u_ -= g.a_ring8; if (u_ >= g.a_ring8) u_ -= g.a_ring8; } \
-    aoff = a_row + (unsigned)(u_ * 2 + sp) * 16u;                                                               \
+    aoff = (unsigned)(u_ * 2 + sp) * 16u;                                                                       \
   }
-#define H2_LDA(dst, ok_, i_) dst = (ok_) ? *(const h2_gvec*)(Abase + (size_t)(i_) * a_row32 + aoff) : z4;
+#define H2_LDA(dst, i_) dst = *(const h2_gvec*)(Abase + a_row##i_ + aoff);
 #define H2_LDW(dst, i_) dst = *(const h2_gvec*)(Wbase + (size_t)(i_) * w_row32 + woff);
 #define H2_ST(buf_, src_, r_) *reinterpret_cast<h2_u32x4*>((buf_) + st_ofs + (r_) * H2_ROWB) = src_;
 #define H2_RDA(buf_, p_, t_, ks_) *reinterpret_cast<const h2_u32x4*>((buf_) + fa_ofs + (p_) * H2_PLANE + (t_) * 32 * H2_ROWB + (ks_) * 32)
 #define H2_RDB(buf_, p_, u_, ks_) *reinterpret_cast<const h2_u32x4*>((buf_) + fb_ofs + (p_) * H2_PLANE + (u_) * 32 * H2_ROWB + (ks_) * 32)
 #define H2_F16(x_) __builtin_bit_cast(f16x8, x_)
+#define H2_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x16_f16(H2_F16(a_), H2_F16(b_), c_, 0, 0, 0)
+#define H2_PIN() __builtin_amdgcn_sched_barrier(0)
 #include "kernels_gemm_h2_loop.inc"
 #undef H2_ADDR
 #undef H2_LDA
@@ -204,20 +220,29 @@ __global__ void __launch_bounds__(256, 1) k_gemm_h2(Gemm2Args g) {
 #undef H2_RDA
 #undef H2_RDB
 #undef H2_F16
-#define H2_EPI(acc_, t_, u_)                                                                                    \
-  {                                                                                                             \
-    const int col = n0 + wn * 96 + (u_) * 32 + (lane & 31);                                                     \
-    const float bias = g.bias ? g.bias[col] : 0.0f;                                                             \
-    const bool do_act = col < g.act_cols;                                                                       \
-    _Pragma("unroll") for (int r = 0; r < 16; r++) {                                                            \
-      const int row = m0 + wm * 64 + (t_) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);                      \
-      if (row < g.M) {                                                                                          \
-        float v = fmaf(acc_[r], g.descale, bias);                                                               \
-        if (do_act) v = v > 0 ? v : expm1f(v);                                                                  \
-        g.C[(size_t)row * g.ldc + col] = v;                                                                     \
-      }                                                                                                         \
-    }                                                                                                           \
+#undef H2_MFMA
+#undef H2_PIN
+  // epilogue: the accumulators hold 4-row column slivers, so they go through the (now idle) LDS once and leave as 16 B per
+  // lane = whole row segments, stored by all 8 waves (dword stores of 128 B half-rows measured 13 us for the 25 MB)
+  __syncthreads();
+  float* ep = reinterpret_cast<float*>(lds2);
+#define H2_EPW(acc_, t_, u_)                                                                                    \
+  _Pragma("unroll") for (int r = 0; r < 16; r++)                                                                \
+    ep[(wm * 64 + (t_) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * H2_EPS + wn * 96 + (u_) * 32 + (lane & 31)] = acc_[r];
+  if (wave < 4) { H2_EPW(acc00, 0, 0) H2_EPW(acc01, 0, 1) H2_EPW(acc02, 0, 2) H2_EPW(acc10, 1, 0) H2_EPW(acc11, 1, 1) H2_EPW(acc12, 1, 2) }
+#undef H2_EPW
+  __syncthreads();
+#pragma unroll 4
+  for (int it = 0; it < (H2_M * H2_N / 4) / H2_THREADS; it++) {
+    const int i = it * H2_THREADS + tid, row = i / (H2_N / 4), c4 = i - row * (H2_N / 4);
+    const int col = n0 + c4 * 4, grow = m0 + row;
+    float4 v = *reinterpret_cast<const float4*>(ep + row * H2_EPS + c4 * 4);
+    float4 bb = g.bias ? *reinterpret_cast<const float4*>(g.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    v.x = fmaf(v.x, g.descale, bb.x); v.y = fmaf(v.y, g.descale, bb.y); v.z = fmaf(v.z, g.descale, bb.z); v.w = fmaf(v.w, g.descale, bb.w);
+    if (col < g.act_cols) {       // ELU
+      v.x = v.x > 0 ? v.x : __expf(v.x) - 1.0f; v.y = v.y > 0 ? v.y : __expf(v.y) - 1.0f;
+      v.z = v.z > 0 ? v.z : __expf(v.z) - 1.0f; v.w = v.w > 0 ? v.w : __expf(v.w) - 1.0f;
+    }
+    if (grow < g.M) *reinterpret_cast<float4*>(g.C + (size_t)grow * g.ldc + col) = v;
   }
-  H2_EPI(acc00, 0, 0) H2_EPI(acc01, 0, 1) H2_EPI(acc02, 0, 2) H2_EPI(acc10, 1, 0) H2_EPI(acc11, 1, 1) H2_EPI(acc12, 1, 2)
-#undef H2_EPI
 }

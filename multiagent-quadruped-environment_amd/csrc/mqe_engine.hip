@@ -93,7 +93,7 @@ static inline int rup(int v, int m) { return (v + m - 1) / m * m; }
 
 // W (out,in) row-major host -> Wt [Kpad][Npad] device at column offset; rows remapped by `rowmap` (-1 = zero row)
 static int make_layer(mqe_sim* s, GemmLayer* L, int K, int N) {
-  L->K = K; L->N = N; L->Kpad = rup(K, GB_K); L->Npad = rup(N, GB_N); L->Kpad3 = rup(K, 2 * H2_K);
+  L->K = K; L->N = N; L->Kpad = rup(K, GB_K); L->Npad = rup(N, GB_N); L->Kpad3 = rup(K, H2_KMULT);
   L->hW.assign((size_t)L->Npad * L->Kpad3, 0.0f);
   if (dalloc(s, &L->Wt, (size_t)L->Kpad * L->Npad)) return -1;
   if (dalloc(s, &L->bias, L->Npad)) return -1;
@@ -254,14 +254,14 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
     UP(t, w1.data(), w1.size()); s->w_lat1 = (float*)t;
   }
   // Layer 0 runs on the f16 matrix cores with two-plane split operands (f32-class accuracy, k_gemm_h2) whenever
-  // its width tiles by 192; MQE_GEMM_SPLIT=0 selects the exact-f32 MFMA kernel instead (0.255 ms vs 0.104 ms at 8192 rows).
+  // its width tiles by 192; MQE_GEMM_SPLIT=0 selects the exact-f32 MFMA kernel instead (0.255 ms vs 0.080 ms at 8192 rows).
   {
-    // Which kernel for layer 0?  k_gemm_h2 owns a whole CU per 128 x 192 tile: its time is a staircase in R (104 us per
+    // Which kernel for layer 0?  k_gemm_h2 owns a whole CU per 128 x 192 tile: its time is a staircase in R (80 us per
     // started round of 256 tiles), the exact-f32 kernel scales linearly (255 us at R = 8192).  Pick the faster one for this
     // batch unless MQE_GEMM_SPLIT forces a choice.
     const char* f = getenv("MQE_GEMM_SPLIT");
     const double rounds = std::ceil(((R + H2_M - 1) / H2_M) * (double)(s->l0.Npad / H2_N) / 256.0);
-    const bool faster = rounds * 104.0 < 255.0 * R / 8192.0;
+    const bool faster = rounds * 80.0 < 255.0 * R / 8192.0;
     s->gemm_split = s->l0.Npad % H2_N == 0 && (f ? atoi(f) != 0 : faster);
   }
   if (s->gemm_split) {
@@ -442,7 +442,7 @@ static void launch_gemm2(hipStream_t q, const uint16_t* A, int lda, int rot8, in
   g.C = C; g.ldc = ldc; g.M = M; g.N = L.Npad; g.K = L.Kpad3; g.act_cols = act_cols;
   g.descale = 1.0f / (MQE_H2_ASCALE * L.wscale);
   int grid = ((M + H2_M - 1) / H2_M) * (L.Npad / H2_N);
-  hipLaunchKernelGGL(k_gemm_h2, dim3(grid), dim3(256), H2_LDS_BYTES, q, g);
+  hipLaunchKernelGGL(k_gemm_h2, dim3(grid), dim3(H2_THREADS), H2_LDS_BYTES, q, g);
 }
 
 static int policy_step(mqe_sim* s, const float* command, hipStream_t q, const float* wrapper_actions = nullptr) {

@@ -1,0 +1,70 @@
+// Standalone timing / correctness harness for k_gemm_h2 (development tool, not part of the product or the tests).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DH2_...] tools/dev/gemm_bench.hip -o gemm_bench && ./gemm_bench
+#include "../../multiagent-quadruped-environment_amd/csrc/kernels_gemm.hpp"
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <vector>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+int main(int argc, char** argv) {
+  const int M = argc > 1 ? atoi(argv[1]) : 8192, N = 768, K = 2208, ring8 = 270, rot8 = 9 * 7;
+  const int reps = argc > 2 ? atoi(argv[2]) : 200;
+  const int lda = argc > 3 ? atoi(argv[3]) : 2 * K;
+  const int ldc = argc > 5 ? atoi(argv[5]) : N;
+  const int ldw = argc > 6 ? atoi(argv[6]) : 2 * K;
+  std::vector<float> A((size_t)M * K), W((size_t)N * K), bias(N);
+  srand(1);
+  auto rnd = []() { return (float)rand() / RAND_MAX * 2.0f - 1.0f; };
+  for (auto& v : A) v = rnd() * 3.0f;
+  for (auto& v : W) v = rnd() * 0.05f;
+  for (auto& v : bias) v = rnd();
+  for (int r = 0; r < M; r++) for (int k = 2160; k < K; k++) A[(size_t)r * K + k] = 0.0f;
+  for (int r = 0; r < N; r++) for (int k = 2160; k < K; k++) W[(size_t)r * K + k] = 0.0f;
+  const float wscale = 262144.0f;      // 32768 / 0.05 -> 2^18 = 262144 (0.05 * 2^18 = 13107)
+  std::vector<uint16_t> A2((size_t)M * lda), W2((size_t)N * ldw);
+  // ring: logical unit u lives at physical unit (u + rot) % ring for u < ring; pad units stay in place
+  for (int r = 0; r < M; r++) for (int k = 0; k < K; k++) {
+    int u = k / 8, pu = u < ring8 ? (u + rot8) % ring8 : u;
+    size_t pk = (size_t)pu * 8 + k % 8;
+    uint16_t h, l; split2(A[(size_t)r * K + k], MQE_H2_ASCALE, h, l);
+    if (u >= ring8) continue;   // the pad units alias ring data (zero weights)
+    A2[(size_t)r * lda + h2_index(pk, 0)] = h; A2[(size_t)r * lda + h2_index(pk, 1)] = l;
+  }
+  for (int r = 0; r < N; r++) for (int k = 0; k < K; k++) {
+    uint16_t h, l; split2(W[(size_t)r * K + k], wscale, h, l);
+    W2[(size_t)r * ldw + h2_index(k, 0)] = h; W2[(size_t)r * ldw + h2_index(k, 1)] = l;
+  }
+  uint16_t *dA, *dW; float *dB, *dC;
+  CK(hipMalloc(&dA, A2.size() * 2)); CK(hipMalloc(&dW, W2.size() * 2)); CK(hipMalloc(&dB, N * 4)); CK(hipMalloc(&dC, (size_t)M * ldc * 4));
+  CK(hipMemcpy(dA, A2.data(), A2.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dW, W2.data(), W2.size() * 2, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dB, bias.data(), N * 4, hipMemcpyHostToDevice));
+  Gemm2Args g;
+  g.A = dA; g.lda = lda; g.a_rot8 = rot8; g.a_ring8 = ring8; g.W = dW; g.ldw = ldw; g.bias = dB; g.C = dC; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+  g.act_cols = argc > 4 ? atoi(argv[4]) : 256; g.descale = 1.0f / (MQE_H2_ASCALE * wscale);
+  CK(hipFuncSetAttribute((const void*)k_gemm_h2, hipFuncAttributeMaxDynamicSharedMemorySize, H2_LDS_BYTES));
+  const int grid = ((M + H2_M - 1) / H2_M) * (N / H2_N);
+  hipLaunchKernelGGL(k_gemm_h2, dim3(grid), dim3(H2_THREADS), H2_LDS_BYTES, 0, g);
+  CK(hipDeviceSynchronize());
+  std::vector<float> C((size_t)M * ldc);
+  CK(hipMemcpy(C.data(), dC, C.size() * 4, hipMemcpyDeviceToHost));
+  double maxerr = 0;
+  for (int t = 0; t < 4000; t++) {
+    int r = rand() % M, c = rand() % N;
+    if (t < 8) { r = t < 4 ? t * 37 % M : M - 1 - t; c = (t * 101) % N; }
+    double acc = 0;
+    for (int k = 0; k < 2160; k++) acc += (double)A[(size_t)r * K + k] * (double)W[(size_t)c * K + k];
+    acc += bias[c];
+    if (c < 256) acc = acc > 0 ? acc : std::expm1(acc);
+    maxerr = std::max(maxerr, std::fabs(acc - (double)C[(size_t)r * ldc + c]));
+  }
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 20; i++) hipLaunchKernelGGL(k_gemm_h2, dim3(grid), dim3(H2_THREADS), H2_LDS_BYTES, 0, g);
+  CK(hipEventRecord(e0, 0));
+  for (int i = 0; i < reps; i++) hipLaunchKernelGGL(k_gemm_h2, dim3(grid), dim3(H2_THREADS), H2_LDS_BYTES, 0, g);
+  CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  const double us = ms * 1e3 / reps;
+  printf("ldw=%d lda=%d M=%d grid=%d  %.2f us/launch  %.1f TF (3-term f16)  %.1f TF f32-equivalent  max|err| = %.3e\n", ldw, lda, M, grid, us,
+         3 * 2.0 * M * N * K / us * 1e-6, 2.0 * M * N * 2100.0 / us * 1e-6, maxerr);
+  return 0;
+}
