@@ -6,31 +6,43 @@
 //   post        last-action registers shifted, targets clipped into `actions`
 // Replaces five k_gemm_f32 launches + k_body_l0_finish + k_post_policy, which were launch/latency-bound (84 us for
 // 3.3 GFLOP at R = 8192).  One 256-thread workgroup owns 32 robots (R = 8192 -> 256 workgroups = one per CU) and walks
-// the six dependent stages with the activations in LDS (k-major, row stride 33: the MFMA A operand is one conflict-free
-// ds_read_b32).  Weights stream from L2 straight into the B operand: a lane loads float4 = 4 consecutive output
-// columns of one k, i.e. the B values of FOUR interleaved 32-column tiles (tile t = columns 4 j + t), so one 1 KiB load
-// feeds four v_mfma_f32_32x32x2_f32.  The four waves split (column group) x (K range); K-partials are summed through
-// LDS in a fixed order (deterministic).  Exact f32 (f32 MFMA == fmaf chain per partial).
+// the six dependent stages with the activations in LDS.
+//
+// Arithmetic: the same two-plane split-f16 scheme as k_gemm_h2 (x = h + l in f16 after a power-of-two scale, products
+// hh + hl + lh on v_mfma_f32_32x32x16_f16, f32 accumulation, exact rescale): f32-class accuracy at 3/16 of the f32-MFMA
+// instruction cost -- the exact-f32 form of this kernel spent 21 of its 54 us in the matrix pipe alone.
+//   * activations: two f16 planes [32 rows][K] in LDS (row stride 2 K + 16 B: the 16 B fragment reads of a ds_read_b128
+//     lane group tile all banks), written by the previous stage's epilogue straight from the accumulators.
+//   * weights: split once on the host into MFMA-fragment order -- block (column tile ct, 16-k step s, plane p) = 1 KiB,
+//     lane l holds the 8 k of column ct * 32 + l % 32, k half l / 32 -- so a wave streams its column tiles from L2 with
+//     fully coalesced 16 B per lane loads, straight into the B operand, through a ring of registers that runs 8-16 k
+//     steps ahead (a CU hosts a single workgroup: memory-level parallelism has to come from the wave itself).
+//   * no K split: wave w owns column tile(s) w (two for the 256-wide layer) over the whole K, so there are no partial
+//     sums to reduce through LDS; the two narrow layers (2 and 12 outputs, padded to one column tile) run on wave 0 with
+//     their weights prefetched at kernel start.
+//   * every CU streams the same weights: each workgroup starts its k loop at a different step so that the 32 CUs of an
+//     XCD do not pull the same cache line through the same L2 channel at the same moment (a sum over k does not care).
 #pragma once
 #include "mqe_common.hpp"
 #include "kernels_gemm.hpp"
 
 #define TL_ROWS 32
-#define TL_AS 33                         // row stride of the k-major activation arrays
-#define TL_X (512 * TL_AS)               // floats: b0, and the K-partial buffers
-#define TL_Y (256 * TL_AS)               // h0 -> b1
-#define TL_Z (128 * TL_AS)               // h1 -> b2
-#define TL_C (64 + 640 + 1024)             // latent [32][2], biases (128 + 64 + 256 + 128 + 64), latent weight columns 2 x 512
-#define TL_LDS_BYTES ((TL_X + TL_Y + TL_Z + TL_C) * 4)
+#define TL_SX (2 * 512 + 16)             // row strides in bytes of the activation planes: b0 (K = 512)
+#define TL_SY (2 * 256 + 16)             // h0, b1 (K = 256)
+#define TL_SZ (2 * 128 + 16)             // h1, b2 (K = 128)
+#define TL_PX (TL_ROWS * TL_SX)          // one plane
+#define TL_PY (TL_ROWS * TL_SY)
+#define TL_PZ (TL_ROWS * TL_SZ)
+#define TL_C (64 + 640 + 1024 + 32 * 33)   // floats: latent [32][2], biases (128 + 64 + 256 + 128 + 64), latent weight columns 2 x 512, narrow-stage output [32][33]
+#define TL_LDS_BYTES (2 * TL_PX + 2 * TL_PY + 2 * TL_PZ + TL_C * 4)
+#define TL_ASCALE 64.0f                  // activation scale (|x| <= 1023 representable)
+
+struct TailLayer { const uint16_t* W; const float* bias; float descale; };   // fragment-ordered planes, see above
 
 struct TailArgs {
   const float* P1; int ldp; int ada_h0;       // [R][ldp]: cols [0, 256) = ELU(adaptation h0); [256, 768) = body layer-0 pre-activation
-  const float *Wa1, *ba1; int ldwa1;          // [256][128]
-  const float *Wa2, *ba2; int ldwa2;          // [128][64] (2 used)
+  TailLayer a1, a2, b1, b2, b3;               // 256->128, 128->2, 512->256, 256->128, 128->12
   const float *wl0, *wl1;                     // [512] body layer-0 weights of the two latent inputs
-  const float *Wb1, *bb1; int ldwb1;          // [512][256]
-  const float *Wb2, *bb2; int ldwb2;          // [256][128]
-  const float *Wb3, *bb3; int ldwb3;          // [128][64] (12 used)
   float* lat; int ldl;                        // out: latent [R][ldl]
   float* act; int lda;                        // out: raw joint targets [R][lda]
   float *last_loco, *last_two_loco, *actions; float clip_actions;   // post-policy registers [R][12]
@@ -38,197 +50,175 @@ struct TailArgs {
 };
 
 // ELU with exp(v) - 1 on the hardware exponential: absolute error <= 1.2e-7 (the branchy expm1f polynomial costs more than
-// the reductions around it and keeps the loops from being pipelined); the result feeds f32 GEMMs with ~1e-6 noise.
+// the matrix work around it)
 __device__ __forceinline__ float elu_f(float v) { return v > 0 ? v : __expf(v) - 1.0f; }
 
-// acc[t] += A[32 x K-range] * Wt[K-range][group columns 4 j + t]; wave = (column group cg of 128, K part kp of KS).
-// The weights are not cache-resident when the kernel starts (layer 0 streams 190 MB through L2 every step) and a CU
-// hosts a single workgroup, so memory-level parallelism has to come from the wave itself: the weight stream runs 32
-// k-pairs (32 KiB per wave, 128 KiB per CU) ahead of the MFMAs through a ring of named registers (an array carried
-// around the loop would be spilled).
-template <int K, int KS>
-__device__ __forceinline__ void tl_wide(const float* __restrict__ As, const float* __restrict__ Wt, int ldw, int cg, int kp, int lane, f32x16 (&acc)[4]) {
+// acc[t] += A[32 x K] * W[K x 32 columns of tile t], K = 16 S.  Ahi: this lane's fragment address in plane 0 at step 0
+// (row lane % 32, k half lane / 32), plane 1 `plane` bytes further; Wf: this lane's 16 B in block (tile 0, step 0, plane 0),
+// tiles `tile_u4` uint4 apart.  D k-steps of weights in flight; the step order is rotated by krot (< S).
+template <int S, int NT, int D>
+__device__ __forceinline__ void tl_mm(const unsigned char* Ahi, int plane, const h2_gvec* Wf, int tile_u4, int krot, f32x16* acc) {
+  h2_u32x4 wq[D][NT][2], aq[2][2];
 #pragma unroll
-  for (int t = 0; t < 4; t++)
+  for (int i = 0; i < D; i++) {
+    const int sr = (i + krot) & (S - 1);
 #pragma unroll
-    for (int i = 0; i < 16; i++) acc[t][i] = 0.0f;
-  constexpr int KR = K / KS;                 // k range of this wave, multiple of 64
-  const int kh = lane >> 5, j = lane & 31;
-  const int kb = kp * KR;
-  const float* ap = As + (kb + kh) * TL_AS + j;
-  const float* wp = Wt + (size_t)(kb + kh) * ldw + cg * 128 + 4 * j;
-  // every CU streams the same weights: rotate the k order per workgroup so that the 32 CUs of an XCD do not pull the same
-  // cache line through the same L2 channel at the same moment (a sum over k does not care where it starts)
-  const int krot = ((blockIdx.x * 7) & 31) * (KR / 32);            // even, < KR
-  float4 W0, W1, W2, W3, W4, W5, W6, W7, W8, W9, W10, W11, W12, W13, W14, W15, W16, W17, W18, W19, W20, W21, W22, W23, W24, W25, W26, W27, W28, W29, W30, W31;
-#define TL_ROT(c_) { c_ += krot; if (c_ >= KR) c_ -= KR; }
-#define TL_LD(i_, kk_) { int c_ = (kk_); if (c_ > KR - 2) c_ = KR - 2; TL_ROT(c_) W##i_ = *reinterpret_cast<const float4*>(wp + (size_t)c_ * ldw); }
-#define TL_STEP(i_, kk_)                                                                 \
-  {                                                                                      \
-    int ca_ = (kk_); TL_ROT(ca_)                                                         \
-    const float a_ = ap[ca_ * TL_AS];                                                    \
-    const float4 w_ = W##i_;                                                             \
-    if (KR > 64) TL_LD(i_, (kk_) + 64)                                                   \
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_, w_.x, acc[0], 0, 0, 0);            \
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_, w_.y, acc[1], 0, 0, 0);            \
-    acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_, w_.z, acc[2], 0, 0, 0);            \
-    acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_, w_.w, acc[3], 0, 0, 0);            \
+    for (int t = 0; t < NT; t++) { wq[i][t][0] = Wf[t * tile_u4 + sr * 128]; wq[i][t][1] = Wf[t * tile_u4 + sr * 128 + 64]; }
   }
-  TL_LD(0, 0) TL_LD(1, 2) TL_LD(2, 4) TL_LD(3, 6) TL_LD(4, 8) TL_LD(5, 10) TL_LD(6, 12) TL_LD(7, 14) TL_LD(8, 16) TL_LD(9, 18) TL_LD(10, 20) TL_LD(11, 22) TL_LD(12, 24) TL_LD(13, 26) TL_LD(14, 28) TL_LD(15, 30) TL_LD(16, 32) TL_LD(17, 34) TL_LD(18, 36) TL_LD(19, 38) TL_LD(20, 40) TL_LD(21, 42) TL_LD(22, 44) TL_LD(23, 46) TL_LD(24, 48) TL_LD(25, 50) TL_LD(26, 52) TL_LD(27, 54) TL_LD(28, 56) TL_LD(29, 58) TL_LD(30, 60) TL_LD(31, 62)
-  for (int k2 = 0; k2 < KR; k2 += 64) {
-    TL_STEP(0, k2 + 0) TL_STEP(1, k2 + 2) TL_STEP(2, k2 + 4) TL_STEP(3, k2 + 6)
-    TL_STEP(4, k2 + 8) TL_STEP(5, k2 + 10) TL_STEP(6, k2 + 12) TL_STEP(7, k2 + 14)
-    TL_STEP(8, k2 + 16) TL_STEP(9, k2 + 18) TL_STEP(10, k2 + 20) TL_STEP(11, k2 + 22)
-    TL_STEP(12, k2 + 24) TL_STEP(13, k2 + 26) TL_STEP(14, k2 + 28) TL_STEP(15, k2 + 30)
-    TL_STEP(16, k2 + 32) TL_STEP(17, k2 + 34) TL_STEP(18, k2 + 36) TL_STEP(19, k2 + 38)
-    TL_STEP(20, k2 + 40) TL_STEP(21, k2 + 42) TL_STEP(22, k2 + 44) TL_STEP(23, k2 + 46)
-    TL_STEP(24, k2 + 48) TL_STEP(25, k2 + 50) TL_STEP(26, k2 + 52) TL_STEP(27, k2 + 54)
-    TL_STEP(28, k2 + 56) TL_STEP(29, k2 + 58) TL_STEP(30, k2 + 60) TL_STEP(31, k2 + 62)
+  {
+    const int sr = krot & (S - 1);
+    aq[0][0] = *reinterpret_cast<const h2_u32x4*>(Ahi + sr * 32); aq[0][1] = *reinterpret_cast<const h2_u32x4*>(Ahi + plane + sr * 32);
   }
-#undef TL_STEP
-#undef TL_LD
-#undef TL_ROT
+#pragma unroll
+  for (int s = 0; s < S; s++) {
+    if (s + 1 < S) {
+      const int sr = (s + 1 + krot) & (S - 1);
+      aq[(s + 1) & 1][0] = *reinterpret_cast<const h2_u32x4*>(Ahi + sr * 32);
+      aq[(s + 1) & 1][1] = *reinterpret_cast<const h2_u32x4*>(Ahi + plane + sr * 32);
+    }
+    const f16x8 ah = __builtin_bit_cast(f16x8, aq[s & 1][0]), al = __builtin_bit_cast(f16x8, aq[s & 1][1]);
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      const f16x8 wh = __builtin_bit_cast(f16x8, wq[s % D][t][0]), wl = __builtin_bit_cast(f16x8, wq[s % D][t][1]);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh, acc[t], 0, 0, 0);
+    }
+    if (s + D < S) {
+      const int sr = (s + D + krot) & (S - 1);
+#pragma unroll
+      for (int t = 0; t < NT; t++) { wq[s % D][t][0] = Wf[t * tile_u4 + sr * 128]; wq[s % D][t][1] = Wf[t * tile_u4 + sr * 128 + 64]; }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
 }
-// partial tile -> red[kp][row][N + 1]
-template <int N>
-__device__ __forceinline__ void tl_store_partial(float* red, int cg, int kp, int lane, const f32x16 (&acc)[4]) {
-  float* base = red + kp * (TL_ROWS * (N + 1)) + cg * 128 + 4 * (lane & 31);
+
+// accumulator tile (columns col0 .. col0 + 31 of the layer) -> ELU(acc * descale + bias) as two f16 planes [row][k = column]
+__device__ __forceinline__ void tl_store_act(const f32x16& acc, float descale, const float* bias, int col0, unsigned char* out, int stride, int plane, int lane) {
+  const int col = col0 + (lane & 31);
+  const float b = bias[col];
 #pragma unroll
   for (int r = 0; r < 16; r++) {
     const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-#pragma unroll
-    for (int t = 0; t < 4; t++) base[row * (N + 1) + t] = acc[t][r];
-  }
-}
-// out[col][row] (k-major) = ELU(sum_kp red + bias)
-template <int N, int KS>
-__device__ __forceinline__ void tl_reduce_act(const float* red, const float* bias, float* out, int tid) {
-#pragma unroll 4
-  for (int idx = tid; idx < TL_ROWS * N; idx += 256) {
-    const int col = idx >> 5, row = idx & 31;
-    float v = red[row * (N + 1) + col];
-#pragma unroll
-    for (int p = 1; p < KS; p++) v += red[p * (TL_ROWS * (N + 1)) + row * (N + 1) + col];
-    out[col * TL_AS + row] = elu_f(v + bias[col]);
-  }
-}
-// narrow stage (<= 32 output columns, Wt [128][ldw]): every wave one K quarter; partial -> red[wave][32][33]
-__device__ __forceinline__ void tl_narrow(const float* __restrict__ As, const float* __restrict__ Wt, int ldw, int wave, int lane, float* red) {
-  f32x16 acc;
-#pragma unroll
-  for (int i = 0; i < 16; i++) acc[i] = 0.0f;
-  const int kh = lane >> 5, j = lane & 31;
-  const int kb = wave * 32;
-  float b[16];
-#pragma unroll
-  for (int q = 0; q < 16; q++) b[q] = Wt[(size_t)(kb + 2 * q + kh) * ldw + j];      // all 16 requests first
-#pragma unroll
-  for (int q = 0; q < 16; q++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[(kb + 2 * q + kh) * TL_AS + j], b[q], acc, 0, 0, 0);
-#pragma unroll
-  for (int r = 0; r < 16; r++) {
-    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    red[wave * (TL_ROWS * 33) + row * 33 + j] = acc[r];
+    uint16_t h, l;
+    split2(elu_f(fmaf(acc[r], descale, b)), TL_ASCALE, h, l);
+    *reinterpret_cast<uint16_t*>(out + row * stride + col * 2) = h;
+    *reinterpret_cast<uint16_t*>(out + plane + row * stride + col * 2) = l;
   }
 }
 
 __global__ void __launch_bounds__(256, 1) k_policy_tail(TailArgs g) {
-  extern __shared__ float tl_lds[];
-  float* X = tl_lds;
-  float* Y = X + TL_X;
-  float* Z = Y + TL_Y;
-  float* latS = Z + TL_Z;                    // [32][2]
+  extern __shared__ __attribute__((aligned(16))) unsigned char tl_lds[];
+  unsigned char* X = tl_lds;                  // b0 planes
+  unsigned char* Y = X + 2 * TL_PX;           // h0, later b1
+  unsigned char* Z = Y + 2 * TL_PY;           // h1, later b2
+  float* latS = reinterpret_cast<float*>(Z + 2 * TL_PZ);     // [32][2]
   float* bA1 = latS + 64;  float* bA2 = bA1 + 128;  float* bB1 = bA2 + 64;  float* bB2 = bB1 + 256;  float* bB3 = bB2 + 128;
-  float* wL0 = bB3 + 64;   float* wL1 = wL0 + 512;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* wL0 = bB3 + 64;   float* wL1 = wL0 + 512;  float* nar = wL1 + 512;   // nar: [32][33] raw output of a narrow stage
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r0 = blockIdx.x * TL_ROWS;
+  const int krot = (blockIdx.x * 7) & 31;
+  const int frow = lane & 31, fhalf = lane >> 5;
+  const h2_gvec* Wa1 = (const h2_gvec*)(g.a1.W) + lane;
+  const h2_gvec* Wa2 = (const h2_gvec*)(g.a2.W) + lane;
+  const h2_gvec* Wb1 = (const h2_gvec*)(g.b1.W) + lane;
+  const h2_gvec* Wb2 = (const h2_gvec*)(g.b2.W) + lane;
+  const h2_gvec* Wb3 = (const h2_gvec*)(g.b3.W) + lane;
+  // ---- all of this workgroup's P1 rows are requested before anything else (P1 was written by the previous launch:
+  // far-memory latency); h0 is consumed right away, the body pre-activations after the latent exists (stage 3)
+  float4 vh[8], vb[16];
+#pragma unroll
+  for (int q = 0; q < 8; q++) {
+    const int idx = tid + 256 * q, row = idx >> 6, k4 = idx & 63;
+    vh[q] = *reinterpret_cast<const float4*>(g.P1 + (size_t)min(r0 + row, g.R - 1) * g.ldp + k4 * 4);
+  }
+#pragma unroll
+  for (int q = 0; q < 16; q++) {
+    const int idx = tid + 256 * q, row = idx >> 7, k4 = idx & 127;
+    vb[q] = *reinterpret_cast<const float4*>(g.P1 + (size_t)min(r0 + row, g.R - 1) * g.ldp + g.ada_h0 + k4 * 4);
+  }
   // ---- the small vectors (biases, latent weight columns) -> LDS
   {
-    for (int i = tid; i < 128; i += 256) { bA1[i] = g.ba1[i]; bB2[i] = g.bb2[i]; }
-    for (int i = tid; i < 64; i += 256) { bA2[i] = g.ba2[i]; bB3[i] = g.bb3[i]; }
-    for (int i = tid; i < 256; i += 256) bB1[i] = g.bb1[i];
+    for (int i = tid; i < 128; i += 256) { bA1[i] = g.a1.bias[i]; bB2[i] = g.b2.bias[i]; }
+    for (int i = tid; i < 64; i += 256) { bA2[i] = g.a2.bias[i]; bB3[i] = g.b3.bias[i]; }
+    for (int i = tid; i < 256; i += 256) bB1[i] = g.b1.bias[i];
     for (int i = tid; i < 512; i += 256) { wL0[i] = g.wl0[i]; wL1[i] = g.wl1[i]; }
   }
-  // ---- stage 0: h0 (adaptation layer-0 activations) -> Y, k-major.  All eight 16 B requests of a thread go out before
-  // the first is used (P1 was written by the previous launch: far-memory latency); a wave reads 1 KiB of one row.
-  {
-    float4 v[8];
+  // ---- stage 0: h0 (adaptation layer-0 activations) -> Y as split planes [row][k]
 #pragma unroll
-    for (int q = 0; q < 8; q++) {
-      const int idx = tid + 256 * q, row = idx >> 6, k4 = idx & 63;
-      v[q] = (r0 + row < g.R) ? *reinterpret_cast<const float4*>(g.P1 + (size_t)(r0 + row) * g.ldp + k4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int q = 0; q < 8; q++) {
-      const int idx = tid + 256 * q, row = idx >> 6, k4 = idx & 63;
-      float* o = Y + (k4 * 4) * TL_AS + row;
-      o[0] = v[q].x; o[TL_AS] = v[q].y; o[2 * TL_AS] = v[q].z; o[3 * TL_AS] = v[q].w;
-    }
+  for (int q = 0; q < 8; q++) {
+    const int idx = tid + 256 * q, row = idx >> 6, k4 = idx & 63;
+    uint16_t h0, l0, h1, l1, h2, l2, h3, l3;
+    split2(vh[q].x, TL_ASCALE, h0, l0); split2(vh[q].y, TL_ASCALE, h1, l1); split2(vh[q].z, TL_ASCALE, h2, l2); split2(vh[q].w, TL_ASCALE, h3, l3);
+    *reinterpret_cast<uint2*>(Y + row * TL_SY + k4 * 8) = make_uint2(h0 | ((unsigned)h1 << 16), h2 | ((unsigned)h3 << 16));
+    *reinterpret_cast<uint2*>(Y + TL_PY + row * TL_SY + k4 * 8) = make_uint2(l0 | ((unsigned)l1 << 16), l2 | ((unsigned)l3 << 16));
   }
   __syncthreads();
-  f32x16 acc[4];
-  // ---- stage 1: h1 = ELU(h0 Wa1 + b): 256 -> 128, one column group, K split four ways
-  tl_wide<256, 4>(Y, g.Wa1, g.ldwa1, 0, wave, lane, acc);
-  tl_store_partial<128>(X, 0, wave, lane, acc);
+  f32x16 acc[2];
+#define TL_ZERO(n_) _Pragma("unroll") for (int t_ = 0; t_ < (n_); t_++) _Pragma("unroll") for (int i_ = 0; i_ < 16; i_++) acc[t_][i_] = 0.0f;
+  // ---- stage 1: h1 = ELU(h0 Wa1 + b): 256 -> 128, wave w = column tile w
+  {
+    TL_ZERO(1)
+    tl_mm<16, 1, 16>(Y + frow * TL_SY + fhalf * 16, TL_PY, Wa1 + wave * (16 * 128), 0, krot, acc);
+    tl_store_act(acc[0], g.a1.descale, bA1, wave * 32, Z, TL_SZ, TL_PZ, lane);
+  }
   __syncthreads();
-  tl_reduce_act<128, 4>(X, bA1, Z, tid);
-  __syncthreads();
-  // ---- stage 2: latent = h1 Wa2 + b: 128 -> 2
-  tl_narrow(Z, g.Wa2, g.ldwa2, wave, lane, X);
+  // ---- stage 2: latent = h1 Wa2 + b: 128 -> 2 (one column tile, wave 0)
+  if (wave == 0) {
+    TL_ZERO(1)
+    tl_mm<8, 1, 8>(Z + frow * TL_SZ + fhalf * 16, TL_PZ, Wa2, 0, 0, acc);
+#pragma unroll
+    for (int r = 0; r < 16; r++) nar[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 33 + (lane & 31)] = acc[0][r];
+  }
   __syncthreads();
   if (tid < TL_ROWS * 2) {
     const int row = tid >> 1, c = tid & 1;
-    float v = X[row * 33 + c];
-#pragma unroll
-    for (int p = 1; p < 4; p++) v += X[p * (TL_ROWS * 33) + row * 33 + c];
-    v += bA2[c];
+    const float v = fmaf(nar[row * 33 + c], g.a2.descale, bA2[c]);
     latS[row * 2 + c] = v;
     if (r0 + row < g.R) g.lat[(size_t)(r0 + row) * g.ldl + c] = v;
   }
   __syncthreads();
-  // ---- stage 3: b0 = ELU(pre0 + latent . w_lat) -> X (k-major)
-  {
-    float4 v[16];
+  // ---- stage 3: b0 = ELU(pre0 + latent . w_lat) -> X
 #pragma unroll
-    for (int q = 0; q < 16; q++) {
-      const int idx = tid + 256 * q, row = idx >> 7, k4 = idx & 127;
-      v[q] = (r0 + row < g.R) ? *reinterpret_cast<const float4*>(g.P1 + (size_t)(r0 + row) * g.ldp + g.ada_h0 + k4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int q = 0; q < 16; q++) {
-      const int idx = tid + 256 * q, row = idx >> 7, k4 = idx & 127;
-      const float4 w0 = *reinterpret_cast<const float4*>(wL0 + k4 * 4), w1 = *reinterpret_cast<const float4*>(wL1 + k4 * 4);
-      const float l0 = latS[row * 2], l1 = latS[row * 2 + 1];
-      float* o = X + (k4 * 4) * TL_AS + row;
-      o[0] = elu_f(fmaf(l1, w1.x, fmaf(l0, w0.x, v[q].x)));
-      o[TL_AS] = elu_f(fmaf(l1, w1.y, fmaf(l0, w0.y, v[q].y)));
-      o[2 * TL_AS] = elu_f(fmaf(l1, w1.z, fmaf(l0, w0.z, v[q].z)));
-      o[3 * TL_AS] = elu_f(fmaf(l1, w1.w, fmaf(l0, w0.w, v[q].w)));
-    }
+  for (int q = 0; q < 16; q++) {
+    const int idx = tid + 256 * q, row = idx >> 7, k4 = idx & 127;
+    const float4 w0 = *reinterpret_cast<const float4*>(wL0 + k4 * 4), w1 = *reinterpret_cast<const float4*>(wL1 + k4 * 4);
+    const float l0 = latS[row * 2], l1 = latS[row * 2 + 1];
+    uint16_t h0, q0, h1, q1, h2, q2, h3, q3;
+    split2(elu_f(fmaf(l1, w1.x, fmaf(l0, w0.x, vb[q].x))), TL_ASCALE, h0, q0);
+    split2(elu_f(fmaf(l1, w1.y, fmaf(l0, w0.y, vb[q].y))), TL_ASCALE, h1, q1);
+    split2(elu_f(fmaf(l1, w1.z, fmaf(l0, w0.z, vb[q].z))), TL_ASCALE, h2, q2);
+    split2(elu_f(fmaf(l1, w1.w, fmaf(l0, w0.w, vb[q].w))), TL_ASCALE, h3, q3);
+    *reinterpret_cast<uint2*>(X + row * TL_SX + k4 * 8) = make_uint2(h0 | ((unsigned)h1 << 16), h2 | ((unsigned)h3 << 16));
+    *reinterpret_cast<uint2*>(X + TL_PX + row * TL_SX + k4 * 8) = make_uint2(q0 | ((unsigned)q1 << 16), q2 | ((unsigned)q3 << 16));
   }
   __syncthreads();
-  // ---- stage 4: b1 = ELU(b0 Wb1 + b): 512 -> 256, two column groups x two K halves
-  tl_wide<512, 2>(X, g.Wb1, g.ldwb1, wave & 1, wave >> 1, lane, acc);
-  __syncthreads();                                   // every wave is done reading b0 before the partials overwrite it
-  tl_store_partial<256>(X, wave & 1, wave >> 1, lane, acc);
-  __syncthreads();
-  tl_reduce_act<256, 2>(X, bB1, Y, tid);
+  // ---- stage 4: b1 = ELU(b0 Wb1 + b): 512 -> 256, wave w = column tiles 2 w, 2 w + 1
+  TL_ZERO(2)
+  tl_mm<32, 2, 8>(X + frow * TL_SX + fhalf * 16, TL_PX, Wb1 + (2 * wave) * (32 * 128), 32 * 128, krot, acc);
+  tl_store_act(acc[0], g.b1.descale, bB1, (2 * wave) * 32, Y, TL_SY, TL_PY, lane);     // h0 is dead since stage 1
+  tl_store_act(acc[1], g.b1.descale, bB1, (2 * wave + 1) * 32, Y, TL_SY, TL_PY, lane);
   __syncthreads();
   // ---- stage 5: b2 = ELU(b1 Wb2 + b): 256 -> 128
-  tl_wide<256, 4>(Y, g.Wb2, g.ldwb2, 0, wave, lane, acc);
-  tl_store_partial<128>(X, 0, wave, lane, acc);
+  {
+    TL_ZERO(1)
+    tl_mm<16, 1, 16>(Y + frow * TL_SY + fhalf * 16, TL_PY, Wb2 + wave * (16 * 128), 0, krot, acc);
+    tl_store_act(acc[0], g.b2.descale, bB2, wave * 32, Z, TL_SZ, TL_PZ, lane);           // h1 is dead since stage 2
+  }
   __syncthreads();
-  tl_reduce_act<128, 4>(X, bB2, Z, tid);
-  __syncthreads();
-  // ---- stage 6: joint targets = b2 Wb3 + b: 128 -> 12; post-policy registers (go1.py:106-107, :40-41)
-  tl_narrow(Z, g.Wb3, g.ldwb3, wave, lane, X);
+  // ---- stage 6: joint targets = b2 Wb3 + b: 128 -> 12 (wave 0); post-policy registers (go1.py:106-107, :40-41)
+  if (wave == 0) {
+    TL_ZERO(1)
+    tl_mm<8, 1, 8>(Z + frow * TL_SZ + fhalf * 16, TL_PZ, Wb3, 0, 0, acc);
+#pragma unroll
+    for (int r = 0; r < 16; r++) nar[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 33 + (lane & 31)] = acc[0][r];
+  }
+#undef TL_ZERO
   __syncthreads();
   for (int idx = tid; idx < TL_ROWS * 12; idx += 256) {
     const int row = idx / 12, c = idx - row * 12;
     if (r0 + row >= g.R) continue;
-    float v = X[row * 33 + c];
-#pragma unroll
-    for (int p = 1; p < 4; p++) v += X[p * (TL_ROWS * 33) + row * 33 + c];
-    v += bB3[c];
+    const float v = fmaf(nar[row * 33 + c], g.b3.descale, bB3[c]);
     const size_t i = (size_t)(r0 + row);
     g.act[i * g.lda + c] = v;
     g.last_two_loco[i * 12 + c] = g.last_loco[i * 12 + c];

@@ -33,6 +33,8 @@ struct GemmLayer {
   int K, N, Kpad, Npad;
   uint16_t* W2 = nullptr;   // device, 2 f16 planes of wscale * [Npad][Kpad3] (split-f16 path, k_gemm_h2)
   float wscale = 1.0f;
+  uint16_t* Wfrag = nullptr;   // device, the same two planes in MFMA-fragment order (k_policy_tail), scaled by fscale
+  float fscale = 1.0f;
   int Kpad3 = 0;
   std::vector<float> hW;    // host staging [Npad][Kpad3] until finalize_layer
 };
@@ -131,6 +133,34 @@ static int finalize_layer(mqe_sim* s, GemmLayer* L) {
   if (dalloc(s, &L->W2, 2 * n, 0)) return -1;
   if (hipMemcpy(L->W2, pl.data(), 2 * n * 2, hipMemcpyHostToDevice) != hipSuccess) return -1;
   L->hW.clear(); L->hW.shrink_to_fit();
+  return 0;
+}
+
+// weights of a tail layer -> two f16 planes in MFMA-fragment order: block (column tile ct, 16-k step s, plane p) = 512 values,
+// lane l holds the 8 k = 16 s + 8 (l / 32) .. of column 32 ct + l % 32 (kernels_tail.hpp)
+static int finalize_frag(mqe_sim* s, GemmLayer* L) {
+  if (L->K % 16 || L->Npad % 32) return -1;
+  float wmax = 0.0f;
+  for (float v : L->hW) wmax = std::max(wmax, std::fabs(v));
+  if (!(wmax < 1e30f)) return -1;
+  int e = wmax > 0.0f ? (int)std::floor(std::log2(32768.0f / wmax)) : 0;
+  e = std::min(std::max(e, -100), 100);
+  L->fscale = std::ldexp(1.0f, e);
+  const int S = L->K / 16, CT = L->Npad / 32;
+  std::vector<uint16_t> pl((size_t)CT * S * 2 * 512);
+  for (int ct = 0; ct < CT; ct++)
+    for (int st = 0; st < S; st++)
+      for (int l = 0; l < 64; l++)
+        for (int q = 0; q < 8; q++) {
+          const int col = ct * 32 + (l & 31), k = st * 16 + (l >> 5) * 8 + q;
+          uint16_t h, lo;
+          split2(L->hW[(size_t)col * L->Kpad3 + k], L->fscale, h, lo);
+          const size_t blk = ((size_t)ct * S + st) * 2;
+          pl[(blk + 0) * 512 + l * 8 + q] = h;
+          pl[(blk + 1) * 512 + l * 8 + q] = lo;
+        }
+  if (dalloc(s, &L->Wfrag, pl.size(), 0)) return -1;
+  if (hipMemcpy(L->Wfrag, pl.data(), pl.size() * 2, hipMemcpyHostToDevice) != hipSuccess) return -1;
   return 0;
 }
 
@@ -281,8 +311,12 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   }
   s->tail_fused = getenv("MQE_NO_FUSED_TAIL") == nullptr && ad.n_layers == 3 && bd.n_layers == 4 && ad.dims[1] == 256 && ad.dims[2] == 128 &&
                   bd.dims[1] == 512 && bd.dims[2] == 256 && bd.dims[3] == 128;
-  if (s->tail_fused && hipFuncSetAttribute((const void*)k_policy_tail, hipFuncAttributeMaxDynamicSharedMemorySize, TL_LDS_BYTES) != hipSuccess)
-    return fail(-4, "cannot raise dynamic LDS limit");
+  if (s->tail_fused) {
+    if (hipFuncSetAttribute((const void*)k_policy_tail, hipFuncAttributeMaxDynamicSharedMemorySize, TL_LDS_BYTES) != hipSuccess)
+      return fail(-4, "cannot raise dynamic LDS limit");
+    for (auto& g : s->ada_rest) if (finalize_frag(s, &g)) return fail(-5, "upload");
+    for (auto& g : s->body_rest) if (finalize_frag(s, &g)) return fail(-5, "upload");
+  }
   int maxw = 64;
   for (auto& g : s->ada_rest) maxw = std::max(maxw, g.Npad);
   for (auto& g : s->body_rest) maxw = std::max(maxw, g.Npad);
@@ -466,12 +500,10 @@ static int policy_step(mqe_sim* s, const float* command, hipStream_t q, const fl
   if (s->tail_fused) {
     TailArgs t;
     t.P1 = s->P1; t.ldp = s->ldP1; t.ada_h0 = s->ada_h0;
-    t.Wa1 = s->ada_rest[0].Wt; t.ba1 = s->ada_rest[0].bias; t.ldwa1 = s->ada_rest[0].Npad;
-    t.Wa2 = s->ada_rest[1].Wt; t.ba2 = s->ada_rest[1].bias; t.ldwa2 = s->ada_rest[1].Npad;
+    auto tl = [](const GemmLayer& L) { TailLayer r; r.W = L.Wfrag; r.bias = L.bias; r.descale = 1.0f / (TL_ASCALE * L.fscale); return r; };
+    t.a1 = tl(s->ada_rest[0]); t.a2 = tl(s->ada_rest[1]);
     t.wl0 = s->w_lat0; t.wl1 = s->w_lat1;
-    t.Wb1 = s->body_rest[0].Wt; t.bb1 = s->body_rest[0].bias; t.ldwb1 = s->body_rest[0].Npad;
-    t.Wb2 = s->body_rest[1].Wt; t.bb2 = s->body_rest[1].bias; t.ldwb2 = s->body_rest[1].Npad;
-    t.Wb3 = s->body_rest[2].Wt; t.bb3 = s->body_rest[2].bias; t.ldwb3 = s->body_rest[2].Npad;
+    t.b1 = tl(s->body_rest[0]); t.b2 = tl(s->body_rest[1]); t.b3 = tl(s->body_rest[2]);
     t.lat = s->lat; t.ldl = s->ldlat; t.act = s->act_out; t.lda = s->ldact;
     t.last_loco = s->st.last_loco; t.last_two_loco = s->st.last_two_loco; t.actions = s->st.actions; t.clip_actions = s->hm.clip_actions;
     t.R = R;
