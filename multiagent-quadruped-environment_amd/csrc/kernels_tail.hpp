@@ -18,8 +18,8 @@
 //     fully coalesced 16 B per lane loads, straight into the B operand, through a ring of registers that runs 8-16 k
 //     steps ahead (a CU hosts a single workgroup: memory-level parallelism has to come from the wave itself).
 //   * no K split: wave w owns column tile(s) w (two for the 256-wide layer) over the whole K, so there are no partial
-//     sums to reduce through LDS; the two narrow layers (2 and 12 outputs, padded to one column tile) run on wave 0 with
-//     their weights prefetched at kernel start.
+//     sums to reduce through LDS; the two narrow layers (2 and 12 outputs, padded to one column tile) run on wave 0.
+//     The first ring fill of every stage is issued one stage early, so no stage starts by waiting for L2.
 //   * every CU streams the same weights: each workgroup starts its k loop at a different step so that the 32 CUs of an
 //     XCD do not pull the same cache line through the same L2 channel at the same moment (a sum over k does not care).
 #pragma once
@@ -57,14 +57,21 @@ __device__ __forceinline__ float elu_f(float v) { return v > 0 ? v : __expf(v) -
 // (row lane % 32, k half lane / 32), plane 1 `plane` bytes further; Wf: this lane's 16 B in block (tile 0, step 0, plane 0),
 // tiles `tile_u4` uint4 apart.  D k-steps of weights in flight; the step order is rotated by krot (< S).
 template <int S, int NT, int D>
-__device__ __forceinline__ void tl_mm(const unsigned char* Ahi, int plane, const h2_gvec* Wf, int tile_u4, int krot, f32x16* acc) {
-  h2_u32x4 wq[D][NT][2], aq[2][2];
+struct TlRing { h2_u32x4 w[D][NT][2]; };
+// request the first D k-steps of a stage's weights; issued before the barrier / the work that precedes the stage, so that
+// the L2 latency of every stage start is off the critical path
+template <int S, int NT, int D>
+__device__ __forceinline__ void tl_fill(const h2_gvec* Wf, int tile_u4, int krot, TlRing<S, NT, D>& q) {
 #pragma unroll
   for (int i = 0; i < D; i++) {
     const int sr = (i + krot) & (S - 1);
 #pragma unroll
-    for (int t = 0; t < NT; t++) { wq[i][t][0] = Wf[t * tile_u4 + sr * 128]; wq[i][t][1] = Wf[t * tile_u4 + sr * 128 + 64]; }
+    for (int t = 0; t < NT; t++) { q.w[i][t][0] = Wf[t * tile_u4 + sr * 128]; q.w[i][t][1] = Wf[t * tile_u4 + sr * 128 + 64]; }
   }
+}
+template <int S, int NT, int D>
+__device__ __forceinline__ void tl_mm(const unsigned char* Ahi, int plane, const h2_gvec* Wf, int tile_u4, int krot, TlRing<S, NT, D>& q, f32x16* acc) {
+  h2_u32x4 aq[2][2];
   {
     const int sr = krot & (S - 1);
     aq[0][0] = *reinterpret_cast<const h2_u32x4*>(Ahi + sr * 32); aq[0][1] = *reinterpret_cast<const h2_u32x4*>(Ahi + plane + sr * 32);
@@ -79,7 +86,7 @@ __device__ __forceinline__ void tl_mm(const unsigned char* Ahi, int plane, const
     const f16x8 ah = __builtin_bit_cast(f16x8, aq[s & 1][0]), al = __builtin_bit_cast(f16x8, aq[s & 1][1]);
 #pragma unroll
     for (int t = 0; t < NT; t++) {
-      const f16x8 wh = __builtin_bit_cast(f16x8, wq[s % D][t][0]), wl = __builtin_bit_cast(f16x8, wq[s % D][t][1]);
+      const f16x8 wh = __builtin_bit_cast(f16x8, q.w[s % D][t][0]), wl = __builtin_bit_cast(f16x8, q.w[s % D][t][1]);
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh, acc[t], 0, 0, 0);
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl, acc[t], 0, 0, 0);
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh, acc[t], 0, 0, 0);
@@ -87,7 +94,7 @@ __device__ __forceinline__ void tl_mm(const unsigned char* Ahi, int plane, const
     if (s + D < S) {
       const int sr = (s + D + krot) & (S - 1);
 #pragma unroll
-      for (int t = 0; t < NT; t++) { wq[s % D][t][0] = Wf[t * tile_u4 + sr * 128]; wq[s % D][t][1] = Wf[t * tile_u4 + sr * 128 + 64]; }
+      for (int t = 0; t < NT; t++) { q.w[s % D][t][0] = Wf[t * tile_u4 + sr * 128]; q.w[s % D][t][1] = Wf[t * tile_u4 + sr * 128 + 64]; }
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -124,7 +131,11 @@ __global__ void __launch_bounds__(256, 1) k_policy_tail(TailArgs g) {
   const h2_gvec* Wb1 = (const h2_gvec*)(g.b1.W) + lane;
   const h2_gvec* Wb2 = (const h2_gvec*)(g.b2.W) + lane;
   const h2_gvec* Wb3 = (const h2_gvec*)(g.b3.W) + lane;
-  // ---- all of this workgroup's P1 rows are requested before anything else (P1 was written by the previous launch:
+  // ---- weights of the first two stages, then all of this workgroup's P1 rows, are requested before anything else
+  TlRing<16, 1, 16> q1;  TlRing<8, 1, 8> q2;
+  tl_fill(Wa1 + wave * (16 * 128), 0, krot, q1);
+  if (wave == 0) tl_fill(Wa2, 0, 0, q2);
+  // ---- all of this workgroup's P1 rows (P1 was written by the previous launch:
   // far-memory latency); h0 is consumed right away, the body pre-activations after the latent exists (stage 3)
   float4 vh[8], vb[16];
 #pragma unroll
@@ -159,14 +170,16 @@ __global__ void __launch_bounds__(256, 1) k_policy_tail(TailArgs g) {
   // ---- stage 1: h1 = ELU(h0 Wa1 + b): 256 -> 128, wave w = column tile w
   {
     TL_ZERO(1)
-    tl_mm<16, 1, 16>(Y + frow * TL_SY + fhalf * 16, TL_PY, Wa1 + wave * (16 * 128), 0, krot, acc);
+    tl_mm(Y + frow * TL_SY + fhalf * 16, TL_PY, Wa1 + wave * (16 * 128), 0, krot, q1, acc);
     tl_store_act(acc[0], g.a1.descale, bA1, wave * 32, Z, TL_SZ, TL_PZ, lane);
   }
+  TlRing<32, 2, 8> q4;                          // stage 4's first weights travel during stages 2 and 3
+  tl_fill(Wb1 + (2 * wave) * (32 * 128), 32 * 128, krot, q4);
   __syncthreads();
   // ---- stage 2: latent = h1 Wa2 + b: 128 -> 2 (one column tile, wave 0)
   if (wave == 0) {
     TL_ZERO(1)
-    tl_mm<8, 1, 8>(Z + frow * TL_SZ + fhalf * 16, TL_PZ, Wa2, 0, 0, acc);
+    tl_mm(Z + frow * TL_SZ + fhalf * 16, TL_PZ, Wa2, 0, 0, q2, acc);
 #pragma unroll
     for (int r = 0; r < 16; r++) nar[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 33 + (lane & 31)] = acc[0][r];
   }
@@ -195,21 +208,24 @@ __global__ void __launch_bounds__(256, 1) k_policy_tail(TailArgs g) {
   __syncthreads();
   // ---- stage 4: b1 = ELU(b0 Wb1 + b): 512 -> 256, wave w = column tiles 2 w, 2 w + 1
   TL_ZERO(2)
-  tl_mm<32, 2, 8>(X + frow * TL_SX + fhalf * 16, TL_PX, Wb1 + (2 * wave) * (32 * 128), 32 * 128, krot, acc);
+  tl_mm(X + frow * TL_SX + fhalf * 16, TL_PX, Wb1 + (2 * wave) * (32 * 128), 32 * 128, krot, q4, acc);
+  TlRing<16, 1, 16> q5;  TlRing<8, 1, 8> q6;
+  tl_fill(Wb2 + wave * (16 * 128), 0, krot, q5);
+  if (wave == 0) tl_fill(Wb3, 0, 0, q6);
   tl_store_act(acc[0], g.b1.descale, bB1, (2 * wave) * 32, Y, TL_SY, TL_PY, lane);     // h0 is dead since stage 1
   tl_store_act(acc[1], g.b1.descale, bB1, (2 * wave + 1) * 32, Y, TL_SY, TL_PY, lane);
   __syncthreads();
   // ---- stage 5: b2 = ELU(b1 Wb2 + b): 256 -> 128
   {
     TL_ZERO(1)
-    tl_mm<16, 1, 16>(Y + frow * TL_SY + fhalf * 16, TL_PY, Wb2 + wave * (16 * 128), 0, krot, acc);
+    tl_mm(Y + frow * TL_SY + fhalf * 16, TL_PY, Wb2 + wave * (16 * 128), 0, krot, q5, acc);
     tl_store_act(acc[0], g.b2.descale, bB2, wave * 32, Z, TL_SZ, TL_PZ, lane);           // h1 is dead since stage 2
   }
   __syncthreads();
   // ---- stage 6: joint targets = b2 Wb3 + b: 128 -> 12 (wave 0); post-policy registers (go1.py:106-107, :40-41)
   if (wave == 0) {
     TL_ZERO(1)
-    tl_mm<8, 1, 8>(Z + frow * TL_SZ + fhalf * 16, TL_PZ, Wb3, 0, 0, acc);
+    tl_mm(Z + frow * TL_SZ + fhalf * 16, TL_PZ, Wb3, 0, 0, q6, acc);
 #pragma unroll
     for (int r = 0; r < 16; r++) nar[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 33 + (lane & 31)] = acc[0][r];
   }
