@@ -25,8 +25,9 @@
 extern "C" {
 #endif
 
-#define MQE_ABI_VERSION 6
+#define MQE_ABI_VERSION 7
 #define MQE_MAX_SPHERES 32
+#define MQE_MAX_SELF_PAIRS 384
 #define MQE_NBODY 13      /* dynamic bodies of one Go1 after fixed-joint collapsing */
 #define MQE_NREP 17       /* reported rigid bodies of one Go1 (feet kept, go1.urdf dont_collapse) */
 #define MQE_NDOF 12
@@ -70,6 +71,10 @@ typedef struct {
   int32_t sphere_reported[MQE_MAX_SPHERES];
   float sphere_center[MQE_MAX_SPHERES][3];
   float sphere_radius[MQE_MAX_SPHERES];
+  /* self-collision candidates (asset.self_collisions = 0, go1_config.py:73 / legged_robot.py:874): every pair of collision
+   * spheres whose links are neither the same nor parent and child, lower sphere index first, ascending; entry = i | j << 8 */
+  int32_t n_self_pairs;
+  uint16_t self_pair[MQE_MAX_SELF_PAIRS];
 } mqe_robot_model;
 
 typedef struct {
@@ -101,6 +106,7 @@ typedef struct {
   /* MQE_NPC_STATIC (bridge.urdf, wrestling.urdf: fixed-base scenery whose collision meshes are boxes): up to 4 world-aligned
      static boxes, centres relative to the NPC root position; the actor reports `npc_reported_bodies` rigid bodies */
   int32_t n_static_boxes, npc_reported_bodies;
+  int32_t self_collision;                 /* 1: contacts between the links of one robot (the self_pair list) */
   float static_box_center[4][3], static_box_half[4][3];
   int32_t seesaw_axis;   /* joint of the 1-dof link: 1 = revolute +y (seesaw plank), 2 = revolute +z (revolving door,
                             rotation_door.urdf:44-50), 3 = prismatic +y (the tug-of-war cylinder, cylinder.urdf:37-43); same

@@ -122,6 +122,7 @@ __host__ __device__ inline PhysLds phys_lds_layout(int A, int P, int ND, int nbo
   L.js = o; o += nslot * JS_STRIDE;
   const int arena = o;
   L.body = o; o += nbody * BODY_STRIDE;
+  o = (o + 3) & ~3;                                         // the sphere records are read as float4
   const int scratch = o;
   L.tt = o; L.fcol = o; o += A * MQE_RD * 6;               // fcol (A*72) is consumed before tt is written
   L.leg = o; o += A * 4 * 54;
@@ -152,6 +153,12 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   float* g_root = st.root + (size_t)e * (A + P) * 13;
   float* g_dof = st.dof + (size_t)e * m->ND * 2;
 
+  // this lane's self-collision candidates, one per pass of 64 (requested here, consumed after the terrain contacts: the
+  // table sits in global memory and a load inside the pass loop put its full latency on every pass)
+  constexpr int NSP = (MQE_MAX_SELF_PAIRS + 63) / 64;
+  int selfp[NSP];
+#pragma unroll
+  for (int k = 0; k < NSP; k++) selfp[k] = (m->self_collision && k * 64 + lane < rm.n_self_pairs) ? (int)rm.self_pair[k * 64 + lane] : -1;
   TSTAMP(0);
   // ---- coalesced state load (first substep of a launch only; afterwards the state stays in LDS) -----------------
   if (flags & PS_LOAD_STATE) {
@@ -728,6 +735,61 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
           if (nc > pair_lim) nc = pair_lim;
         }
       }
+    // links of one robot against each other (asset.self_collisions = 0): lanes = candidate sphere pairs (same link and
+    // parent-child pairs are not in the list), 64 per pass; both contact sides belong to the same actor.  Last in the list:
+    // they only take the two-actor slots that the contacts with other actors left over.
+    if (m->self_collision) {
+      const int npairs = rm.n_self_pairs;
+      for (int a = 0; a < A; a++) {
+        // screen: all passes at once (independent 16 B loads, one ballot); robots rarely touch themselves, so the per-pass
+        // compaction below normally does not run at all
+        const float* sp0 = lds + L.sph + a * nsr * 4;
+        float4 si4[NSP], sj4[NSP];
+#pragma unroll
+        for (int k = 0; k < NSP; k++) {                          // beyond the list: sphere 0 against itself, masked below
+          const int pr = selfp[k] < 0 ? 0 : selfp[k];
+          si4[k] = *reinterpret_cast<const float4*>(sp0 + (pr & 255) * 4);
+          sj4[k] = *reinterpret_cast<const float4*>(sp0 + (pr >> 8) * 4);
+        }
+        int any = 0;
+#pragma unroll
+        for (int k = 0; k < NSP; k++) {
+          const float ex = si4[k].x - sj4[k].x, ey = si4[k].y - sj4[k].y, ez = si4[k].z - sj4[k].z, lim = si4[k].w + sj4[k].w + m->contact_offset;
+          any |= (int)(selfp[k] >= 0) & (int)(ex * ex + ey * ey + ez * ez < lim * lim);
+        }
+        if (__ballot(any != 0) == 0ull) continue;
+#pragma unroll
+        for (int k = 0; k < NSP; k++) {
+          if (k * 64 >= npairs) continue;
+          bool hit = false; float sd = 0, dist = 1, rj = 0; V3 ev = v3(0, 0, 0), cj = v3(0, 0, 0); int si = 0, sj = 0;
+          if (selfp[k] >= 0) {
+            const int pr = selfp[k];
+            si = pr & 255; sj = pr >> 8;
+            const float* spi = lds + L.sph + (a * nsr + si) * 4;
+            const float* spj = lds + L.sph + (a * nsr + sj) * 4;
+            cj = ld3(spj); rj = spj[3];
+            ev = ld3(spi) - cj;
+            dist = sqrtf(dot(ev, ev));
+            sd = dist - spi[3] - rj;
+            hit = sd < m->contact_offset && dist > 1e-9f;
+          }
+          const unsigned long long bh = __ballot(hit);
+          if (bh == 0ull) continue;
+          const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+          const int slot = nc + __popcll(bh & lower);
+          if (hit && slot < pair_lim) {
+            float* cr = lds + L.con + slot * CON_STRIDE;
+            cr[C_IDS] = __int_as_float(a); cr[C_IDS + 1] = __int_as_float(rm.sphere_body[si]); cr[C_IDS + 2] = __int_as_float(a); cr[C_IDS + 3] = __int_as_float(rm.sphere_body[sj]);
+            const V3 n = (1.0f / dist) * ev;
+            const V3 p = cj + (rj + 0.5f * sd) * n;
+            cr[C_P] = p.x; cr[C_P + 1] = p.y; cr[C_P + 2] = p.z; cr[C_N] = n.x; cr[C_N + 1] = n.y; cr[C_N + 2] = n.z; cr[C_SD] = sd;
+            cr[C_REP] = __int_as_float(a * MQE_NREP + rm.sphere_reported[si]); cr[C_REP + 1] = __int_as_float(a * MQE_NREP + rm.sphere_reported[sj]);
+          }
+          nc += __popcll(bh);
+          if (nc > pair_lim) nc = pair_lim;
+        }
+      }
+    }
   }
   __syncthreads();
 
@@ -904,7 +966,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       const int len = __popcll(bm), start = bm ? __ffsll((long long)bm) - 1 : 0;
       maxlen = len > maxlen ? len : maxlen;
       if (is_con && myA == a) { gstartA = start; glenA = len; }
-      if (is_pair && myB == a) { gstartB = start; glenB = len; }
+      if (is_pair && myB == a && myB != myA) { gstartB = start; glenB = len; }   // a self-contact has one group: its block with the owner already holds both sides
     }
     const int npair = __popcll(__ballot(is_pair));
     const int pair0 = nc - npair;
@@ -985,9 +1047,14 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     for (int c = 0; c < nc; c++) {
       const float* cr = lds + L.con + c * CON_STRIDE;
       const int a2 = __float_as_int(cr[C_IDS]), b2 = __float_as_int(cr[C_IDS + 2]);
-      if (a2 != dact && b2 != dact) continue;
-      const float* Bc = lds + L.B + (a2 == dact ? c : maxc + (c - nc_terr)) * 54;
-      v += Bc[dloc] * cr[C_LAM] + Bc[18 + dloc] * cr[C_LAM + 1] + Bc[36 + dloc] * cr[C_LAM + 2];
+      if (a2 == dact) {
+        const float* Bc = lds + L.B + c * 54;
+        v += Bc[dloc] * cr[C_LAM] + Bc[18 + dloc] * cr[C_LAM + 1] + Bc[36 + dloc] * cr[C_LAM + 2];
+      }
+      if (b2 == dact) {                               // both for a contact between two links of this actor
+        const float* Bc = lds + L.B + (maxc + (c - nc_terr)) * 54;
+        v += Bc[dloc] * cr[C_LAM] + Bc[18 + dloc] * cr[C_LAM + 1] + Bc[36 + dloc] * cr[C_LAM + 2];
+      }
     }
     Vm[d] = v;
   }

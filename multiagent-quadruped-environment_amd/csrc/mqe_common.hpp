@@ -30,6 +30,7 @@ struct DevModel {
   float contact_offset, max_depen, friction, erp;
   mqe_robot_model robot;
   float npc_mass, npc_inertia; int npc_n_spheres; float npc_sphere_center[8][3]; float npc_sphere_radius[8];
+  int self_collision;                              // contacts between the links of one robot (rm.self_pair)
   int has_box, cap_npc; float npc_box_half[3];     // MQE_NPC_BOX: robots' spheres vs the oriented box; terrain contacts kept per NPC
   float seesaw_default_angle;
   int n_static; float sb_center[4][3], sb_half[4][3];     // MQE_NPC_STATIC: world-aligned scenery boxes on the NPC root

@@ -201,6 +201,7 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   m.N = N; m.A = A; m.P = P; m.R = R; m.ND = s->ND; m.NBR = s->NBR; m.Aw = s->Aw; m.D = s->D;
   m.npc_kind = d->npc_kind; m.task = d->task;
   m.n_npc_dyn = (d->npc_kind == MQE_NPC_BALL || d->npc_kind == MQE_NPC_SHEEP || d->npc_kind == MQE_NPC_BOX) ? P : 0;
+  m.self_collision = d->self_collision != 0 && d->robot.n_self_pairs > 0;
   m.has_box = d->npc_kind == MQE_NPC_BOX; m.cap_npc = d->npc_contact_cap > 0 ? d->npc_contact_cap : 2;
   memcpy(m.npc_box_half, d->npc_box_half, sizeof m.npc_box_half);
   m.npc_lin_only = d->npc_kind == MQE_NPC_SHEEP;

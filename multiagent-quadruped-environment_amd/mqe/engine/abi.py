@@ -1,8 +1,9 @@
 """ctypes mirror of include/mqe_hip.h (keep in sync; tests/test_abi.py checks sizes against the built library)."""
 import ctypes as C
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_SPHERES, NBODY, NREP, NDOF = 32, 13, 17, 12
+MAX_SELF_PAIRS = 384
 MAX_AGENTS, MAX_NPCS, FRAME, HIST, MAX_LAYERS, MAX_REWARD_TERMS = 4, 9, 72, 30, 6, 12
 OBS_BAG = 74
 
@@ -37,6 +38,7 @@ class RobotModel(C.Structure):
         ("dof_lower", f32 * NDOF), ("dof_upper", f32 * NDOF),
         ("n_spheres", i32), ("sphere_body", i32 * MAX_SPHERES), ("sphere_reported", i32 * MAX_SPHERES),
         ("sphere_center", (f32 * 3) * MAX_SPHERES), ("sphere_radius", f32 * MAX_SPHERES),
+        ("n_self_pairs", i32), ("self_pair", C.c_uint16 * MAX_SELF_PAIRS),
     ]
 
 
@@ -54,7 +56,7 @@ class SimDesc(C.Structure):
         ("seesaw_base_half", f32 * 3),
         ("seesaw_plank_mass", f32), ("seesaw_plank_inertia_yy", f32), ("seesaw_vel_limit", f32), ("seesaw_default_angle", f32),
         ("seesaw_column_radius", f32), ("seesaw_column_length", f32), ("seesaw_theta_lo", f32), ("seesaw_theta_hi", f32),
-        ("n_static_boxes", i32), ("npc_reported_bodies", i32), ("static_box_center", (f32 * 3) * 4), ("static_box_half", (f32 * 3) * 4),
+        ("n_static_boxes", i32), ("npc_reported_bodies", i32), ("self_collision", i32), ("static_box_center", (f32 * 3) * 4), ("static_box_half", (f32 * 3) * 4),
         ("seesaw_axis", i32), ("seesaw_link_cylinder", i32),
         ("control_type", i32), ("action_scale", f32), ("hip_scale_reduction", f32), ("clip_actions", f32),
         ("torque_limits", f32 * NDOF), ("kp", f32), ("kd", f32), ("default_dof_pos", f32 * NDOF),

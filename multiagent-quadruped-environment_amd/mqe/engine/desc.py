@@ -150,6 +150,16 @@ def build_desc(cfg, num_envs, terrain, env_origins, agent_origins, gate_pos=None
         r.sphere_body[s], r.sphere_reported[s], r.sphere_radius[s] = m["sphere_body"][s], m["sphere_reported"][s], m["sphere_radius"][s]
         for k in range(3):
             r.sphere_center[s][k] = m["sphere_center"][s][k]
+    # self-collision (asset.self_collisions is Isaac Gym's filter mask: 0 = links of one robot collide, go1_config.py:73):
+    # every sphere pair whose links are neither the same nor parent and child, lower sphere index first
+    par, sb = m["parent"], m["sphere_body"]
+    pairs = [(i, j) for i in range(r.n_spheres) for j in range(i + 1, r.n_spheres)
+             if sb[i] != sb[j] and par[sb[i]] != sb[j] and par[sb[j]] != sb[i]]
+    assert len(pairs) <= abi.MAX_SELF_PAIRS, len(pairs)
+    r.n_self_pairs = len(pairs)
+    for k, (i, j) in enumerate(pairs):
+        r.self_pair[k] = i | (j << 8)
+    d.self_collision = 1 if int(getattr(cfg.asset, "self_collisions", 1)) == 0 else 0
     # NPC objects
     if d.npc_kind in (abi.NPC["ball"], abi.NPC["sheep"]):
         om = urdf_model.load_model("ball" if d.npc_kind == abi.NPC["ball"] else "sheep", resources_root)["bodies"][0]

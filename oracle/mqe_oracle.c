@@ -898,6 +898,23 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
           }
         }
     }
+  /* links of one robot against each other (asset.self_collisions = 0, go1_config.py:73): the candidate list of the robot
+   * model in order; both sides of such a contact are the same actor (fill_jac adds the two Jacobians into one row) */
+  if (d->self_collision)
+    for (int a = 0; a < A; a++)
+      for (int pi = 0; pi < m->n_self_pairs; pi++) {
+        int si = m->self_pair[pi] & 255, sj = m->self_pair[pi] >> 8;
+        const real* ci = w->sph_c[a][si]; const real* cj = w->sph_c[a][sj];
+        real e[3] = {ci[0] - cj[0], ci[1] - cj[1], ci[2] - cj[2]};
+        real dist = (real)sqrt((double)dot3(e, e));
+        real sd = dist - w->sph_r[a][si] - w->sph_r[a][sj];
+        if (sd < d->contact_offset && w->nc < pair_lim && dist > (real)1e-9) {
+          contact_t* ct = &w->con[w->nc++];
+          memset(ct, 0, sizeof *ct);
+          ct->kind = 1; ct->actA = a; ct->sphA = si; ct->actB = a; ct->sphB = sj; ct->sd = sd;
+          for (int k = 0; k < 3; k++) { ct->n[k] = e[k] / dist; ct->p[k] = cj[k] + ct->n[k] * (w->sph_r[a][sj] + (real)0.5 * sd); }
+        }
+      }
 
   /* ---- contact rows: J, B = Minv J^T, K = J B */
   for (int ci = 0; ci < w->nc; ci++) {

@@ -122,6 +122,45 @@ def test_fused_rollout_matches_oracle(task, N):
     assert mism <= max(2, N // 16), f"{mism} reset-flag mismatches"
 
 
+def test_self_contacts_match_oracle():
+    """asset.self_collisions = 0: contacts between two links of one robot (both contact sides on the same actor: one
+    Jacobian row over one set of dofs, coupling blocks with all four side pairings).  Robots in free fall with crossed /
+    folded legs, perturbed per env: identical contact lists, then 40 substeps tracked in joint space."""
+    N = 16
+    eh, eo, d = _pair("go1gate", N)
+    assert d.self_collision == 1 and d.robot.n_self_pairs == 270
+    eh.reset_all(); eo.reset_all()
+    torch.cuda.synchronize()
+    ro, do = eo.tensor(abi.T_ROOT_STATE), eo.tensor(abi.T_DOF_STATE)
+    g = torch.Generator().manual_seed(9)
+    crossed = torch.tensor([-0.6, 0.8, -2.2, 0.6, 0.8, -2.2, 0.1, 1.0, -1.5, -0.1, 1.0, -1.5])       # front feet 23 mm into each other
+    folded = torch.tensor([-0.8, 0.8, -1.5, 0.8, 0.8, -1.5, -0.6, 1.0, -2.2, 0.6, 1.0, -2.2])        # front thighs + hind feet
+    do[:, :12, 0] = crossed + (torch.rand(N, 12, generator=g) - 0.5) * 0.06
+    do[:, 12:24, 0] = folded + (torch.rand(N, 12, generator=g) - 0.5) * 0.06
+    do[..., 1] = (torch.rand(do[..., 1].shape, generator=g) - 0.5) * 0.5
+    ro[:, :, 2] = 2.0; ro[:, 1, 1] += 1.0                                  # free fall, far from each other
+    ro[:, :, 7:] = 0
+    eh.tensor(abi.T_ROOT_STATE).copy_(ro.cuda()); eh.tensor(abi.T_DOF_STATE).copy_(do.cuda())
+    eh.tensor(abi.T_TORQUES).zero_(); eo.tensor(abi.T_TORQUES).zero_()
+    nself = 0
+    for k in range(40):
+        if k in (0, 10, 25):
+            torch.cuda.synchronize()
+            close(eh.tensor(abi.T_DOF_STATE)[..., 0], eo.tensor(abi.T_DOF_STATE)[..., 0], atol=2e-4, what=f"joint angles at substep {k}")
+            eh.tensor(abi.T_ROOT_STATE).copy_(eo.tensor(abi.T_ROOT_STATE).cuda()); eh.tensor(abi.T_DOF_STATE).copy_(eo.tensor(abi.T_DOF_STATE).cuda())
+            for env in range(N):
+                _, ch = eh.debug_dynamics(env, 0)
+                _, _, co = eo.debug_dynamics(env, 0)
+                assert ch.shape == co.shape and (ch[:, :4] == co[:, :4]).all()
+                close(ch[:, 4:], co[:, 4:], atol=1e-4, what="contact separation / normal")     # centres 1-2 cm apart at z = 2 m: the unit normal carries ~1e-5 of f32 rounding
+                nself += int((co[:, 0] == co[:, 2]).sum())
+        eh.simulate(); eo.simulate()
+    torch.cuda.synchronize()
+    assert nself >= 2 * N, "test must exercise self-contacts on both robots"
+    close(eh.tensor(abi.T_CONTACT_FORCE), eo.tensor(abi.T_CONTACT_FORCE), atol=0.5, rtol=2e-2, what="net contact force")
+    assert torch.isfinite(eh.tensor(abi.T_ROOT_STATE)).all() and torch.isfinite(eh.tensor(abi.T_DOF_STATE)).all()
+
+
 def test_box_contacts_match_oracle():
     """go1pushbox: robots dropped onto / against the free box (sphere vs oriented box narrow phase, box corners vs the
     ground): identical contact lists from identical states, then 60 substeps tracked by the box pose."""

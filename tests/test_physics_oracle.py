@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import make_desc, oracle_engine
+from helpers import make_desc, oracle_engine, self_gap
 from mqe.engine import abi
 
 G = 9.81
@@ -258,3 +258,41 @@ def test_tug_slider_translates_and_pushes_a_robot():
     assert (dof[:, 12 * A, 1] < 0.8).all(), dof[:, 12 * A, 1]                  # momentum went into the robot
     assert (root[:, 0, 1] > y0 + 0.005).all(), root[:, 0, 1] - y0             # which was shoved along +y (12 kg on mu = 1 feet: not far)
     assert (root[:, 0, 1] - (hinge[:, 1] + dof[:, 12 * A, 0]) > d.seesaw_plank_half[0] - 0.05).all()   # and never ended up inside the disc
+
+
+CROSSED_FRONT_FEET = [-0.6, 0.8, -2.2, 0.6, 0.8, -2.2, 0.1, 1.0, -1.5, -0.1, 1.0, -1.5]      # spheres 0 / 1 (FL / FR foot) overlap by 23 mm
+
+
+def _crossed(self_collision):
+    d, k, ctx = make_desc("go1gate", 1)
+    d.self_collision = self_collision
+    e = oracle_engine(d, k)
+    e.reset_all()
+    root, dof = e.tensor(abi.T_ROOT_STATE), e.tensor(abi.T_DOF_STATE)
+    dof[0, :12, 0] = torch.tensor(CROSSED_FRONT_FEET)
+    dof[..., 1] = 0
+    root[..., 7:] = 0
+    root[0, 0, 2] = 2.0                     # free fall: no other contact, and without contact forces the pose would not change
+    e.tensor(abi.T_TORQUES).zero_()
+    return e, d, root, dof
+
+
+def test_links_of_one_robot_collide():
+    """asset.self_collisions = 0 (go1_config.py:73): the front feet, posed 23 mm into each other, are pushed apart by a contact
+    whose two sides are the same actor; with the flag off nothing happens.  The contact force is internal: the robot's
+    momentum is not changed (the base keeps falling with g up to the reaction of the legs' relative motion)."""
+    assert self_gap(CROSSED_FRONT_FEET, 0, 1) < -0.02
+    e, d, root, dof = _crossed(1)
+    _, _, con = e.debug_dynamics(0, 0)
+    assert len(con) == 1 and con[0, 0] == 0 and con[0, 2] == 0 and con[0, 1] != con[0, 3], con     # one contact, robot 0 on both sides, two different links
+    assert abs(float(con[0, 4]) - self_gap(CROSSED_FRONT_FEET, 0, 1)) < 1e-5
+    for _ in range(40):
+        e.simulate()
+    assert self_gap(dof[0, :12, 0].numpy(), 0, 1) > -1e-3, "the penetration must be resolved"
+    assert torch.isfinite(root).all() and torch.isfinite(dof).all()
+    assert abs(float(root[0, 0, 9]) + G * d.dt * 40) < 0.5, "an internal force cannot stop the fall"
+    e2, d2, root2, dof2 = _crossed(0)
+    assert len(e2.debug_dynamics(0, 0)[2]) == 0
+    for _ in range(40):
+        e2.simulate()
+    assert abs(self_gap(dof2[0, :12, 0].numpy(), 0, 1) - self_gap(CROSSED_FRONT_FEET, 0, 1)) < 1e-4, "free fall keeps the pose"
