@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MQE_ABI_VERSION 7
+#define MQE_ABI_VERSION 8
 #define MQE_MAX_SPHERES 32
 #define MQE_MAX_SELF_PAIRS 384
 #define MQE_NBODY 13      /* dynamic bodies of one Go1 after fixed-joint collapsing */
@@ -142,6 +142,20 @@ typedef struct {
   float base_pos_x_lo, base_pos_x_hi, base_pos_y_lo, base_pos_y_hi;
   float npc_pos_x_lo, npc_pos_x_hi, npc_pos_y_lo, npc_pos_y_hi;
   float base_vel_lo, base_vel_hi;
+  /* domain randomisation -- every switch is off in the reference's task configs (go1_config.py:216-247).  Values are drawn
+   * once per handle from the hash RNG keyed by the GLOBAL env id and exposed as MQE_T_DOMAIN_PARAMS:
+   *   friction (legged_robot.py:283-294): 64 buckets U(lo, hi), one bucket per env, applied to the robots' shapes; a contact
+   *     uses the average of the robot's coefficient and `friction` (PhysX combine mode average with terrain / objects);
+   *   added base mass (legged_robot.py:332-334) and base CoM shift (legged_robot_field.py:324-334): per robot, body 0;
+   *   lag_timesteps (go1.py:337-339, control type C): the joint targets are delayed by this many SUBSTEPS (the reference
+   *     shifts its lag buffer in every _compute_torques call); the buffer is never reset;
+   *   push_interval / max_push_vel_xy (go1.py:237, legged_robot.py:470-476): every push_interval-th step the base linear
+   *     velocity x, y of every robot is re-drawn from U(-max, max) after the step's observations were taken. */
+  int32_t rand_friction; float friction_lo, friction_hi;
+  int32_t rand_base_mass; float added_mass_lo, added_mass_hi;
+  int32_t rand_com; float com_lo[3], com_hi[3];
+  int32_t lag_timesteps;
+  int32_t push_interval; float max_push_vel_xy;
   /* sheep script (reference go1_sheep.py:35-64) */
   float sheep_movement_scale, sheep_movement_randomness;
   /* wrapper parameters: reward scales in the order documented in mqe/envs/wrappers of this package */
@@ -171,6 +185,8 @@ enum {
   MQE_T_NPC_NOISE,         /* [N,P,3] injected N(0,1) for the sheep script when noise_mode is SCRIPTED */
   MQE_T_WRAPPER_PACKED,    /* [N*Aw*D + N*Aw] the wrapper observation and reward as ONE contiguous buffer (obs first): the
                               returned batch can be snapshotted with a single copy */
+  MQE_T_DOMAIN_PARAMS,     /* [R][8]: shape friction of the robot's env, added base mass, base CoM shift xyz, 3 unused; read by every
+                              physics step, writable (tests / curricula) */
   MQE_T_COUNT
 };
 

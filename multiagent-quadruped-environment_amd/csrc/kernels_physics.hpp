@@ -235,8 +235,12 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   }
   // world COM / inertia of robot bodies
   if (is_rbody) {
-    bmass = rm.mass[bb];
-    bc = bp + mat_vec(Rm, v3(rm.com[bb][0], rm.com[bb][1], rm.com[bb][2]));
+    // domain parameters of this robot (MQE_T_DOMAIN_PARAMS): added base mass, base CoM shift -- body 0 only, inertia about
+    // the CoM unchanged (legged_robot.py:332-334, legged_robot_field.py:324-334 edit mass and com of props[0] only)
+    const float* dp = st.dparams + ((size_t)e * A + br) * 8;
+    const bool base = bb == 0;
+    bmass = rm.mass[bb] + (base ? dp[1] : 0.0f);
+    bc = bp + mat_vec(Rm, v3(rm.com[bb][0] + (base ? dp[2] : 0.0f), rm.com[bb][1] + (base ? dp[3] : 0.0f), rm.com[bb][2] + (base ? dp[4] : 0.0f)));
     const float* S = rm.inertia[bb];
     float Il[9] = {S[0], S[3], S[4], S[3], S[1], S[5], S[4], S[5], S[2]}, T[9];
     for (int r = 0; r < 3; r++)
@@ -797,7 +801,9 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   // ---- contact rows, lane = contact: sparse Jacobian (<= 9 columns per articulated side), B = M^-1 J^T, bias --------------------
   // Per side the columns are [base lin xyz, base ang xyz, the <=3 joints of the chain to the touching link] (robot) or
   // [lin xyz, (ang xyz)] (ball / sheep).  Column value in the contact frame: dirs . (axis x (p - anchor)) = (r x dirs) . axis.
-  const float mu = m->friction;
+  // friction of a contact: the shapes of a robot carry the env's (randomised) coefficient, averaged with the other shape's
+  // (terrain / objects: m->friction) as PhysX does; contacts without a robot keep m->friction
+  const float mu_robot = 0.5f * (st.dparams[(size_t)e * A * 8] + m->friction);
   float* Vm = lds + L.rhs;           // v* (unconstrained velocity) over the consumed bias vector, read through the sparse Jacobian rows
   if (lane < ndof) Vm[lane] = vs0;
   if (lane + 64 < ndof) Vm[lane + 64] = vs1;
@@ -806,9 +812,11 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   float cu0 = 0, cu1 = 0, cu2 = 0, cl0 = 0, cl1 = 0, cl2 = 0, cbias = 0;
   float ik00 = 0, ik11 = 0, ik22 = 0, ck10 = 0, ck20 = 0, ck21 = 0;
   int myA = -2, myB = -2;
+  float mu = m->friction;
   if (is_con) {
     float* cr = lds + L.con + lane * CON_STRIDE;
     myA = __float_as_int(cr[C_IDS]); myB = __float_as_int(cr[C_IDS + 2]);
+    if (myA < A || (myB >= 0 && myB < A)) mu = mu_robot;
     const int bodyA = __float_as_int(cr[C_IDS + 1]), bodyB = __float_as_int(cr[C_IDS + 3]);
     const V3 p = ld3(cr + C_P), n = ld3(cr + C_N);
     const V3 aa = fabsf(n.z) > 0.7f ? v3(1, 0, 0) : v3(0, 0, 1);
@@ -1177,7 +1185,7 @@ __device__ __forceinline__ float softsign_p(float x) { return x / (1.0f + fabsf(
 
 #define ACT_TILES 2       // 2 x 32 joints >= 12 * MQE_MAX_AGENTS(=4)... agents <= 4 need 48 joints
 
-__global__ void __launch_bounds__(64, 2) k_substeps(const DevModel* __restrict__ m, DevState st, int nsub) {
+__global__ void __launch_bounds__(64, 2) k_substeps(const DevModel* __restrict__ m, DevState st, int nsub, int lag_pos) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x, e = blockIdx.x;
   const int A = m->A, P = m->P;
@@ -1188,6 +1196,7 @@ __global__ void __launch_bounds__(64, 2) k_substeps(const DevModel* __restrict__
   const float* W1 = m->actuator.W[1]; const float* b1 = m->actuator.b[1];
   const float* W2 = m->actuator.W[2]; const float* b2 = m->actuator.b[2];
   // per-tile joint state in registers
+  float asl[ACT_TILES];                                           // scaled action incl. hip reduction (the lagged target's input)
   float tgt[ACT_TILES], h_e1[ACT_TILES], h_e2[ACT_TILES], h_v1[ACT_TILES], h_v2[ACT_TILES], lim[ACT_TILES];
   float asc[ACT_TILES], dfl[ACT_TILES], lqd[ACT_TILES];          // low-level control types: scaled action, default pose, last-step velocity
   const int ctrl = m->control_type;
@@ -1203,6 +1212,7 @@ __global__ void __launch_bounds__(64, 2) k_substeps(const DevModel* __restrict__
     asc[t] = st.actions[gi] * m->action_scale;                   // P / V / T: no hip reduction (legged_robot.py:380)
     dfl[t] = m->default_dof_pos[j];
     lqd[t] = ctrl == MQE_CTRL_V ? st.last_dof_vel[gi] : 0.0f;
+    asl[t] = as;
     tgt[t] = as + m->default_dof_pos[j];
     h_e1[t] = st.act_hist[gi]; h_e2[t] = st.act_hist[R12 + gi]; h_v1[t] = st.act_hist[2 * R12 + gi]; h_v2[t] = st.act_hist[3 * R12 + gi];
     lim[t] = m->torque_limits[j];
@@ -1238,6 +1248,15 @@ __global__ void __launch_bounds__(64, 2) k_substeps(const DevModel* __restrict__
       __syncthreads();
       phys_substep(m, st, lds, e, lane, last ? (PS_STORE_STATE | PS_WRITE_CF) : 0, 0, nodbg);
       continue;
+    }
+    if (m->lag_steps > 0) {            // go1.py:337-339: the lag buffer shifts in every _compute_torques call, i.e. per substep
+      const int n = m->lag_steps + 1;
+      int pos = lag_pos + k; pos -= (pos / n) * n;
+#pragma unroll
+      for (int t = 0; t < ACT_TILES; t++) {
+        const int jt = t * 32 + j32;
+        if (jt < nj) tgt[t] = lag_target(m, st, (size_t)e * nj + jt, asl[t], pos) + dfl[t];
+      }
     }
     const float *w0p = W0, *w1p = W1, *w2p = W2, *b0p = b0, *b1p = b1;
     asm volatile("" : "+s"(w0p), "+s"(w1p), "+s"(w2p), "+s"(b0p), "+s"(b1p));

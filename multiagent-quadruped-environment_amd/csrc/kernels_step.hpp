@@ -33,14 +33,19 @@ __device__ __forceinline__ void euler_xyz_f(const float* q, float* rpy) {
   rpy[0] = wrap2pi(roll); rpy[1] = wrap2pi(pitch); rpy[2] = wrap2pi(yaw);
 }
 
-__device__ __forceinline__ uint32_t mqe_hash(uint32_t seed, uint32_t genv, uint32_t count, uint32_t k) {
-  uint32_t x = seed * 0x9E3779B1u ^ genv * 0x85EBCA77u ^ count * 0xC2B2AE3Du ^ k * 0x27D4EB2Fu;
-  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
-  return x;
-}
 __device__ __forceinline__ float mqe_rand(const DevModel* m, int env, int count, uint32_t k, float lo, float hi) {
-  float u = (float)(mqe_hash((uint32_t)m->seed, (uint32_t)(env + m->env_id_offset), (uint32_t)count, k) >> 8) * (1.0f / 16777216.0f);
+  float u = mqe_u01((uint32_t)m->seed, (uint32_t)(env + m->env_id_offset), (uint32_t)count, k);
   return (hi - lo) * u + lo;
+}
+// joint target delayed by m->lag_steps substeps (go1.py:337-339): ring [(L + 1)][R * 12] of scaled actions, slot `pos` is
+// written, the oldest slot (pos + 1) mod (L + 1) is read.  Both half-waves of an MFMA lane pair write the same value.
+__device__ __forceinline__ float lag_target(const DevModel* m, const DevState& st, size_t idx, float as, int pos) {
+  if (m->lag_steps <= 0) return as;
+  const int n = m->lag_steps + 1;
+  const size_t R12 = (size_t)m->R * 12;
+  st.lag_buf[(size_t)pos * R12 + idx] = as;
+  const int rd = pos + 1 >= n ? 0 : pos + 1;
+  return st.lag_buf[(size_t)rd * R12 + idx];
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -164,7 +169,7 @@ __global__ void k_body_l0_finish(float* __restrict__ P1, int ldp, int col0, int 
 // weights are wave-uniform, so they arrive through the scalar cache and every FMA is v_fmac(vgpr, sgpr).
 __device__ __forceinline__ float softsign_f(float x) { return x / (1.0f + fabsf(x)); }
 
-__global__ void __launch_bounds__(256) k_compute_torques(const DevModel* m, DevState st, int dec_i) {
+__global__ void __launch_bounds__(256) k_compute_torques(const DevModel* m, DevState st, int dec_i, int lag_pos) {
   int idx = blockIdx.x * blockDim.x + threadIdx.x;
   int R = m->R, A = m->A;
   if (idx >= R * 12) return;
@@ -176,7 +181,7 @@ __global__ void __launch_bounds__(256) k_compute_torques(const DevModel* m, DevS
   float tau;
   if (m->control_type == MQE_CTRL_C) {
     if (j % 3 == 0) as *= m->hip_scale_reduction;
-    float target = as + m->default_dof_pos[j];
+    float target = lag_target(m, st, (size_t)idx, as, lag_pos) + m->default_dof_pos[j];
     float err = q - target;
     float* e1 = st.act_hist; float* e2 = e1 + (size_t)R * 12; float* v1 = e2 + (size_t)R * 12; float* v2 = v1 + (size_t)R * 12;
     float x[6] = {err, e1[idx], e2[idx], qd, v1[idx], v2[idx]};
@@ -227,7 +232,7 @@ __global__ void __launch_bounds__(256) k_compute_torques(const DevModel* m, DevS
 // pre-permuted per lane into 3 + 16 VGPRs.  The 32->1 output layer is 16 FMAs per lane + one cross-half add.
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
-__global__ void __launch_bounds__(256) k_compute_torques_mfma(const DevModel* m, DevState st, int dec_i) {
+__global__ void __launch_bounds__(256) k_compute_torques_mfma(const DevModel* m, DevState st, int dec_i, int lag_pos) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j32 = lane & 31, h = lane >> 5;
   const int R = m->R, A = m->A;
@@ -258,7 +263,7 @@ __global__ void __launch_bounds__(256) k_compute_torques_mfma(const DevModel* m,
   const float q = ds[0], qd = ds[1];
   float as = st.actions[ii] * m->action_scale;
   if (j % 3 == 0) as *= m->hip_scale_reduction;
-  const float err = q - (as + m->default_dof_pos[j]);
+  const float err = q - (lag_target(m, st, (size_t)ii, as, lag_pos) + m->default_dof_pos[j]);
   const float x0 = err, x1 = e1[ii], x2 = e2[ii], x3 = qd, x4 = v1[ii], x5 = v2[ii];
   // layer 1 (K = 6): B operand = input (2s + h) of this lane's joint
   acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[0], h ? x1 : x0, acc1, 0, 0, 0);
@@ -696,12 +701,12 @@ __device__ void wrapper_env_dev(const DevModel* m, const DevState& st, int e, in
 #ifndef POST_EPW
 #define POST_EPW 8
 #endif
-__device__ __forceinline__ uint8_t post_physics_env(const DevModel* m, const DevState& st, const int e, const int wrapper_level);
+__device__ __forceinline__ uint8_t post_physics_env(const DevModel* m, const DevState& st, const int e, const int wrapper_level, const int push_count);
 
-__global__ void __launch_bounds__(64) k_post_physics(const DevModel* m, DevState st, int wrapper_level) {
+__global__ void __launch_bounds__(64) k_post_physics(const DevModel* m, DevState st, int wrapper_level, int push_count) {
   const int e = blockIdx.x * POST_EPW + threadIdx.x;
   uint8_t reset = 0;
-  if (threadIdx.x < POST_EPW && e < m->N) reset = post_physics_env(m, st, e, wrapper_level);
+  if (threadIdx.x < POST_EPW && e < m->N) reset = post_physics_env(m, st, e, wrapper_level, push_count);
   // go1.py:145: history[agent_ids] = 0 for the envs that reset this step -- rare, so the whole wavefront (the lanes that
   // idled above included) zeroes them, 16 B per lane per request: the f32 ring and, when present, its two f16 planes
   unsigned long long rm = __ballot(reset != 0);
@@ -720,7 +725,7 @@ __global__ void __launch_bounds__(64) k_post_physics(const DevModel* m, DevState
   }
 }
 
-__device__ __forceinline__ uint8_t post_physics_env(const DevModel* m, const DevState& st, const int e, const int wrapper_level) {
+__device__ __forceinline__ uint8_t post_physics_env(const DevModel* m, const DevState& st, const int e, const int wrapper_level, const int push_count) {
   const int A = m->A, P = m->P;
   const float dtp = m->dt * (float)m->decimation;
   float* root = st.root + (size_t)e * (A + P) * 13;
@@ -855,6 +860,15 @@ __device__ __forceinline__ uint8_t post_physics_env(const DevModel* m, const Dev
       for (int k = 0; k < 4; k++) { ob[63 + k] = clk[a][k]; ob[67 + k] = bq[a][k]; }
     }
   wrapper_env_dev(m, st, e, 0, npc_pre, wrapper_level);
+  // _push_robots (go1.py:237, legged_robot.py:470-476): after this step's frame quantities were taken, before reset_idx --
+  // whose U(-0.5, 0.5) base velocities replace the push in the envs that reset.  One draw per robot (the reference draws
+  // (num_envs, 2) for a (num_envs * num_agents, 2) slice, which only broadcasts for a single agent).
+  if (push_count > 0 && !reset)
+    for (int a = 0; a < A; a++) {
+      float* rv = st.root + ((size_t)e * (A + P) + a) * 13 + 7;
+      rv[0] = mqe_rand(m, e, (int)(MQE_RNG_PUSH + (uint32_t)push_count), (uint32_t)(2 * a), -m->max_push, m->max_push);
+      rv[1] = mqe_rand(m, e, (int)(MQE_RNG_PUSH + (uint32_t)push_count), (uint32_t)(2 * a + 1), -m->max_push, m->max_push);
+    }
   return reset;
 }
 

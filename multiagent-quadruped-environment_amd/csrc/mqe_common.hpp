@@ -31,6 +31,7 @@ struct DevModel {
   mqe_robot_model robot;
   float npc_mass, npc_inertia; int npc_n_spheres; float npc_sphere_center[8][3]; float npc_sphere_radius[8];
   int self_collision;                              // contacts between the links of one robot (rm.self_pair)
+  int lag_steps; float max_push;                   // domain randomisation: action lag in substeps (0 = off), push velocity bound
   int has_box, cap_npc; float npc_box_half[3];     // MQE_NPC_BOX: robots' spheres vs the oriented box; terrain contacts kept per NPC
   float seesaw_default_angle;
   int n_static; float sb_center[4][3], sb_half[4][3];     // MQE_NPC_STATIC: world-aligned scenery boxes on the NPC root
@@ -57,12 +58,26 @@ struct DevState {
   float *root, *dof, *cf, *torques, *actions, *last_actions, *loco_obs, *hist, *last_loco, *last_two_loco, *act_hist;
   float *gait, *clock, *blv, *bav, *pg, *bquat, *obs_bag, *wobs, *wrew, *rsum, *sheep_avg, *sheep_var, *sub_tau, *npc_noise;
   float *w_last, *w_last2, *cmd, *last_dof_vel;
+  float *dparams, *lag_buf;                 // [R][8] friction / added mass / CoM shift (MQE_T_DOMAIN_PARAMS); [(lag + 1)][R][12] scaled actions
   uint16_t* hist2;                          // split-f16 copy of the history ring: [R][270 units][2 planes][8] (k_gemm_h2)
   int32_t *ep_len, *reset_count;
   uint8_t *reset_buf, *collide_buf, *time_out, *r_term, *p_term, *zh_term, *w_have_last, *w_delayed_reset;
 };
 
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+
+// counter-based RNG of the reset distribution and the domain randomisation: keyed by (seed, GLOBAL env id, count, stream)
+__host__ __device__ __forceinline__ uint32_t mqe_hash(uint32_t seed, uint32_t genv, uint32_t count, uint32_t k) {
+  uint32_t x = seed * 0x9E3779B1u ^ genv * 0x85EBCA77u ^ count * 0xC2B2AE3Du ^ k * 0x27D4EB2Fu;
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  return x;
+}
+__host__ __device__ __forceinline__ float mqe_u01(uint32_t seed, uint32_t genv, uint32_t count, uint32_t k) {
+  return (float)(mqe_hash(seed, genv, count, k) >> 8) * (1.0f / 16777216.0f);
+}
+#define MQE_RNG_CREATE 0xD0D0D0D0u         // `count` of the draws made once per handle (domain parameters)
+#define MQE_RNG_PUSH 0x50000000u           // + ordinal of the push
+
 
 // f32 -> two f16 planes of scale * x (h + l == scale * x to 22 significand bits); see k_gemm_h2 in kernels_gemm.hpp
 #define MQE_H2_ASCALE 64.0f                 // activation scale c_a: |x| <= 1023 representable, beyond that the value saturates

@@ -50,6 +50,7 @@ struct mqe_sim {
   void* tens[MQE_T_COUNT];
   int N, A, P, R, ND, NBR, Aw, D;
   int hist_pos = 0, n_post_steps = 0;
+  int lag_pos = 0;                    // write slot of the action-lag ring (domain randomisation), advances per substep
   // policy network (fused first layer: [adaptation L0 | body L0 history part])
   GemmLayer l0;                       // K = 30*72 (ring), N = ada_h0 + body_h0
   std::vector<GemmLayer> ada_rest, body_rest;
@@ -202,6 +203,7 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   m.npc_kind = d->npc_kind; m.task = d->task;
   m.n_npc_dyn = (d->npc_kind == MQE_NPC_BALL || d->npc_kind == MQE_NPC_SHEEP || d->npc_kind == MQE_NPC_BOX) ? P : 0;
   m.self_collision = d->self_collision != 0 && d->robot.n_self_pairs > 0;
+  m.lag_steps = (d->control_type == MQE_CTRL_C && d->lag_timesteps > 0) ? d->lag_timesteps : 0; m.max_push = d->max_push_vel_xy;
   m.has_box = d->npc_kind == MQE_NPC_BOX; m.cap_npc = d->npc_contact_cap > 0 ? d->npc_contact_cap : 2;
   memcpy(m.npc_box_half, d->npc_box_half, sizeof m.npc_box_half);
   m.npc_lin_only = d->npc_kind == MQE_NPC_SHEEP;
@@ -339,6 +341,30 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   DA(st.sub_tau, (size_t)N * 4 * 12 * A); DA(st.npc_noise, (size_t)N * (P ? P : 1) * 3);
   DA(st.w_last, (size_t)N * MQE_MAX_AGENTS); DA(st.w_last2, (size_t)N * 2); DA(st.cmd, (size_t)R * 3);
   DA(st.ep_len, N); DA(st.reset_count, N); DA(st.last_dof_vel, (size_t)R * 12);
+  // domain parameters (include/mqe_hip.h): drawn once, keyed by the global env id so that a sharded run sees the same robots
+  {
+    std::vector<float> dp((size_t)R * 8, 0.0f);
+    const uint32_t seed = (uint32_t)d->seed;
+    for (int e = 0; e < N; e++) {
+      const uint32_t genv = (uint32_t)(e + d->env_id_offset);
+      float mu = d->friction;
+      if (d->rand_friction) {            // legged_robot.py:283-294: 64 buckets, one per env
+        const uint32_t bucket = mqe_hash(seed, genv, MQE_RNG_CREATE, 0) % 64u;
+        mu = d->friction_lo + (d->friction_hi - d->friction_lo) * mqe_u01(seed, bucket, MQE_RNG_CREATE + 1u, 0);
+      }
+      for (int a = 0; a < A; a++) {
+        float* p = dp.data() + ((size_t)e * A + a) * 8;
+        p[0] = mu;
+        if (d->rand_base_mass) p[1] = d->added_mass_lo + (d->added_mass_hi - d->added_mass_lo) * mqe_u01(seed, genv, MQE_RNG_CREATE, 16u + (uint32_t)a);
+        if (d->rand_com)
+          for (int k = 0; k < 3; k++) p[2 + k] = d->com_lo[k] + (d->com_hi[k] - d->com_lo[k]) * mqe_u01(seed, genv, MQE_RNG_CREATE, 32u + (uint32_t)(a * 3 + k));
+      }
+    }
+    DA(st.dparams, (size_t)R * 8);
+    if (hipMemcpy(st.dparams, dp.data(), dp.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return fail(-5, "upload");
+  }
+  st.lag_buf = nullptr;
+  if (s->hm.lag_steps > 0) { DA(st.lag_buf, (size_t)(s->hm.lag_steps + 1) * R * 12); }
   DA(st.reset_buf, N); DA(st.collide_buf, N); DA(st.time_out, N); DA(st.r_term, N); DA(st.p_term, N); DA(st.zh_term, N);
   DA(st.w_have_last, N); DA(st.w_delayed_reset, N);
   {
@@ -368,6 +394,7 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   t[MQE_T_OBS_BAG] = st.obs_bag; t[MQE_T_WRAPPER_OBS] = st.wobs; t[MQE_T_WRAPPER_REWARD] = st.wrew; t[MQE_T_REWARD_SUMS] = st.rsum;
   t[MQE_T_SHEEP_POS_AVG] = st.sheep_avg; t[MQE_T_SHEEP_POS_VAR] = st.sheep_var; t[MQE_T_RESET_COUNT] = st.reset_count;
   t[MQE_T_SUBSTEP_TORQUES] = st.sub_tau; t[MQE_T_NPC_NOISE] = st.npc_noise; t[MQE_T_WRAPPER_PACKED] = st.wobs;
+  t[MQE_T_DOMAIN_PARAMS] = st.dparams;
   HIPCHK(hipDeviceSynchronize());
   *out = s;
   return 0;
@@ -415,6 +442,7 @@ extern "C" int mqe_sim_tensor(mqe_sim* s, int kind, mqe_tensor_view* v) {
     case MQE_T_SUBSTEP_TORQUES: SH(3, N, 4, 12 * A, 0, 0); break;
     case MQE_T_NPC_NOISE: SH(3, N, P, 3, 0, 0); break;
     case MQE_T_WRAPPER_PACKED: SH(1, N * s->Aw * s->D + N * s->Aw, 0, 0, 0, 0); break;
+    case MQE_T_DOMAIN_PARAMS: SH(2, s->R, 8, 0, 0, 0); break;
   }
   return 0;
 }
@@ -538,13 +566,15 @@ static int policy_step(mqe_sim* s, const float* command, hipStream_t q, const fl
   return 0;
 }
 
+static void advance_lag(mqe_sim* s, int n) { if (s->d.lag_timesteps > 0) s->lag_pos = (s->lag_pos + n) % (s->d.lag_timesteps + 1); }
 static void launch_torques(mqe_sim* s, int dec_i, hipStream_t q) {
   ProfScope ps(s, PROF_TORQUES, q);
   int n = s->R * 12;
   if (s->d.control_type == MQE_CTRL_C)
-    hipLaunchKernelGGL(k_compute_torques_mfma, dim3((n + 127) / 128), dim3(256), 0, q, s->dm, s->st, dec_i);
+    hipLaunchKernelGGL(k_compute_torques_mfma, dim3((n + 127) / 128), dim3(256), 0, q, s->dm, s->st, dec_i, s->lag_pos);
   else
-    hipLaunchKernelGGL(k_compute_torques, dim3((n + 255) / 256), dim3(256), 0, q, s->dm, s->st, dec_i);
+    hipLaunchKernelGGL(k_compute_torques, dim3((n + 255) / 256), dim3(256), 0, q, s->dm, s->st, dec_i, s->lag_pos);
+  advance_lag(s, 1);
 }
 static void launch_simulate(mqe_sim* s, hipStream_t q) {
   ProfScope ps(s, PROF_SIMULATE, q);
@@ -553,8 +583,9 @@ static void launch_simulate(mqe_sim* s, hipStream_t q) {
 }
 static void launch_post(mqe_sim* s, hipStream_t q, int wrapper_level) {
   ProfScope ps(s, PROF_POST, q);
-  hipLaunchKernelGGL(k_post_physics, dim3((s->N + POST_EPW - 1) / POST_EPW), dim3(64), 0, q, s->dm, s->st, wrapper_level);   // incl. history zeroing
-  s->n_post_steps++;
+  s->n_post_steps++;                          // = common_step_counter after its increment (legged_robot.py:127)
+  const int push = (s->d.push_interval > 0 && s->n_post_steps % s->d.push_interval == 0) ? (int)(s->n_post_steps / s->d.push_interval) : 0;
+  hipLaunchKernelGGL(k_post_physics, dim3((s->N + POST_EPW - 1) / POST_EPW), dim3(64), 0, q, s->dm, s->st, wrapper_level, push);   // incl. history zeroing
 }
 
 extern "C" int mqe_policy_step(mqe_sim* s, const float* command, void* stream) {
@@ -638,7 +669,8 @@ static int run_substeps_and_post(mqe_sim* s, hipStream_t q) {
   if (s->fuse_substeps) {
     // decimation loop in one launch: state stays in LDS; actuator net on MFMA (C) or the PD / torque law (P, V, T) inside the wavefront
     ProfScope ps(s, PROF_SIMULATE, q);
-    hipLaunchKernelGGL(k_substeps, dim3(s->N), dim3(64), s->phys_lds_bytes, q, s->dm, s->st, s->d.decimation);
+    hipLaunchKernelGGL(k_substeps, dim3(s->N), dim3(64), s->phys_lds_bytes, q, s->dm, s->st, s->d.decimation, s->lag_pos);
+    advance_lag(s, s->d.decimation);
   } else {
     for (int k = 0; k < s->d.decimation; k++) {
       launch_torques(s, k < 4 ? k : 3, q);

@@ -1,7 +1,7 @@
 """ctypes mirror of include/mqe_hip.h (keep in sync; tests/test_abi.py checks sizes against the built library)."""
 import ctypes as C
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_SPHERES, NBODY, NREP, NDOF = 32, 13, 17, 12
 MAX_SELF_PAIRS = 384
 MAX_AGENTS, MAX_NPCS, FRAME, HIST, MAX_LAYERS, MAX_REWARD_TERMS = 4, 9, 72, 30, 6, 12
@@ -16,7 +16,7 @@ TERM = dict(roll=1, pitch=2, z_low=4, z_high=8)
  T_LAST_LOCO_ACTION, T_LAST_TWO_LOCO_ACTION, T_ACT_HIST, T_GAIT_INDICES, T_CLOCK_INPUTS, T_BASE_LIN_VEL,
  T_BASE_ANG_VEL, T_PROJECTED_GRAVITY, T_BASE_QUAT, T_EPISODE_LENGTH, T_RESET_BUF, T_COLLIDE_BUF, T_TIME_OUT_BUF,
  T_R_TERM, T_P_TERM, T_Z_HIGH_TERM, T_OBS_BAG, T_WRAPPER_OBS, T_WRAPPER_REWARD, T_REWARD_SUMS, T_SHEEP_POS_AVG,
- T_SHEEP_POS_VAR, T_RESET_COUNT, T_SUBSTEP_TORQUES, T_NPC_NOISE, T_WRAPPER_PACKED, T_COUNT) = range(35)
+ T_SHEEP_POS_VAR, T_RESET_COUNT, T_SUBSTEP_TORQUES, T_NPC_NOISE, T_WRAPPER_PACKED, T_DOMAIN_PARAMS, T_COUNT) = range(36)
 
 # slices of one OBS_BAG row (compute_observations, reference go1.py:153-196)
 BAG = dict(base_pos=(0, 3), base_rpy=(3, 6), dof_pos=(6, 18), dof_vel=(18, 30), lin_vel=(30, 33), ang_vel=(33, 36),
@@ -71,6 +71,10 @@ class SimDesc(C.Structure):
         ("base_pos_x_lo", f32), ("base_pos_x_hi", f32), ("base_pos_y_lo", f32), ("base_pos_y_hi", f32),
         ("npc_pos_x_lo", f32), ("npc_pos_x_hi", f32), ("npc_pos_y_lo", f32), ("npc_pos_y_hi", f32),
         ("base_vel_lo", f32), ("base_vel_hi", f32),
+        ("rand_friction", i32), ("friction_lo", f32), ("friction_hi", f32),
+        ("rand_base_mass", i32), ("added_mass_lo", f32), ("added_mass_hi", f32),
+        ("rand_com", i32), ("com_lo", f32 * 3), ("com_hi", f32 * 3),
+        ("lag_timesteps", i32), ("push_interval", i32), ("max_push_vel_xy", f32),
         ("sheep_movement_scale", f32), ("sheep_movement_randomness", f32),
         ("reward_scale", f32 * MAX_REWARD_TERMS), ("wrapper_param", f32 * 8),
         ("actuator", Mlp), ("adaptation", Mlp), ("body", Mlp),

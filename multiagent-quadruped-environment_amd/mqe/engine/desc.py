@@ -338,6 +338,22 @@ def build_desc(cfg, num_envs, terrain, env_origins, agent_origins, gate_pos=None
         d.npc_pos_y_lo, d.npc_pos_y_hi = npr["y"]
     bv = getattr(dr, "init_base_vel_range", None) or (-0.5, 0.5)
     d.base_vel_lo, d.base_vel_hi = bv
+    # domain randomisation switches (legged_robot.py:283-336, legged_robot_field.py:324-334, go1.py:237,337)
+    if getattr(dr, "randomize_friction", False):
+        d.rand_friction = 1
+        d.friction_lo, d.friction_hi = dr.friction_range
+    if getattr(dr, "randomize_base_mass", False):
+        d.rand_base_mass = 1
+        d.added_mass_lo, d.added_mass_hi = dr.added_mass_range
+    if getattr(dr, "randomize_com", False):
+        d.rand_com = 1
+        for k, ax in enumerate("xyz"):
+            d.com_lo[k], d.com_hi[k] = getattr(dr.com_range, ax)
+    if getattr(dr, "randomize_lag_timesteps", False):
+        d.lag_timesteps = int(dr.lag_timesteps)
+    if getattr(dr, "push_robots", False):
+        d.push_interval = int(np.ceil(dr.push_interval_s / (cfg.sim.dt * cfg.control.decimation)))     # legged_robot.py:1024
+        d.max_push_vel_xy = float(dr.max_push_vel_xy)
     d.sheep_movement_scale = getattr(cfg.asset, "sheep_movement_scale", 0.0)
     d.sheep_movement_randomness = getattr(cfg.asset, "sheep_movement_randomness", 0.0)
     for i, (attr, _) in enumerate(REWARD_TERMS[task]):

@@ -66,6 +66,8 @@ typedef struct mqo_sim {
   float *root, *dof, *cf, *torques, *actions, *last_actions, *loco_obs, *hist, *last_loco, *last_two_loco;
   float *act_hist, *gait, *clock, *blv, *bav, *pg, *bquat, *obs_bag, *wobs, *wrew, *rsum, *sheep_avg, *sheep_var;
   float *sub_tau, *npc_noise, *last_dof_vel;
+  float *dparams, *lag_buf;         /* [R][8] MQE_T_DOMAIN_PARAMS; [(lag + 1)][R][12] scaled actions (domain randomisation, include/mqe_hip.h) */
+  int lag_pos;
   int32_t *ep_len, *reset_count;
   uint8_t *reset_buf, *collide_buf, *time_out, *r_term, *p_term, *zh_term;
   /* wrapper memory */
@@ -323,6 +325,24 @@ int mqo_sim_create(const mqe_sim_desc* d, mqo_sim** out) {
   s->sheep_avg = ALLOCF((size_t)N * 2);
   s->sheep_var = ALLOCF(N);
   s->sub_tau = ALLOCF((size_t)N * 4 * 12 * A);
+  /* domain parameters: drawn once, keyed by the global env id (the engine makes the same draws on its host side) */
+  s->dparams = ALLOCF((size_t)R * 8);
+  for (int e = 0; e < N; e++) {
+    uint32_t genv = (uint32_t)(e + d->env_id_offset), seed = (uint32_t)d->seed;
+    float mu = d->friction;
+    if (d->rand_friction) {                  /* legged_robot.py:283-294: 64 buckets, one per env */
+      uint32_t bucket = mqo_hash(seed, genv, 0xD0D0D0D0u, 0) % 64u;
+      mu = d->friction_lo + (d->friction_hi - d->friction_lo) * mqo_u01(seed, bucket, 0xD0D0D0D1u, 0);
+    }
+    for (int a = 0; a < A; a++) {
+      float* p = s->dparams + ((size_t)e * A + a) * 8;
+      p[0] = mu;
+      if (d->rand_base_mass) p[1] = d->added_mass_lo + (d->added_mass_hi - d->added_mass_lo) * mqo_u01(seed, genv, 0xD0D0D0D0u, 16u + (uint32_t)a);
+      if (d->rand_com)
+        for (int k = 0; k < 3; k++) p[2 + k] = d->com_lo[k] + (d->com_hi[k] - d->com_lo[k]) * mqo_u01(seed, genv, 0xD0D0D0D0u, 32u + (uint32_t)(a * 3 + k));
+    }
+  }
+  s->lag_buf = (d->control_type == MQE_CTRL_C && d->lag_timesteps > 0) ? ALLOCF((size_t)(d->lag_timesteps + 1) * R * 12) : NULL;
   s->npc_noise = ALLOCF((size_t)N * (P ? P : 1) * 3);
   s->last_dof_vel = ALLOCF((size_t)s->R * 12);
   s->ep_len = (int32_t*)calloc(N, 4);
@@ -350,6 +370,7 @@ int mqo_sim_create(const mqe_sim_desc* d, mqo_sim** out) {
   t[MQE_T_OBS_BAG] = s->obs_bag; t[MQE_T_WRAPPER_OBS] = s->wobs; t[MQE_T_WRAPPER_REWARD] = s->wrew; t[MQE_T_REWARD_SUMS] = s->rsum;
   t[MQE_T_SHEEP_POS_AVG] = s->sheep_avg; t[MQE_T_SHEEP_POS_VAR] = s->sheep_var; t[MQE_T_RESET_COUNT] = s->reset_count;
   t[MQE_T_SUBSTEP_TORQUES] = s->sub_tau; t[MQE_T_NPC_NOISE] = s->npc_noise; t[MQE_T_WRAPPER_PACKED] = s->wobs;
+  t[MQE_T_DOMAIN_PARAMS] = s->dparams;
   *out = s;
   return 0;
 }
@@ -386,6 +407,7 @@ int mqo_sim_tensor(mqo_sim* s, int kind, mqe_tensor_view* v) {
     case MQE_T_SUBSTEP_TORQUES: SH(3, N, 4, 12 * A, 0, 0); break;
     case MQE_T_NPC_NOISE: SH(3, N, P, 3, 0, 0); break;
     case MQE_T_WRAPPER_PACKED: SH(1, N * s->Aw * s->D + N * s->Aw, 0, 0, 0, 0); break;
+    case MQE_T_DOMAIN_PARAMS: SH(2, s->R, 8, 0, 0, 0); break;
   }
   return 0;
 }
@@ -443,6 +465,11 @@ int mqo_compute_torques(mqo_sim* s) {
       float tau;
       if (d->control_type == MQE_CTRL_C) {
         if (j % 3 == 0) as *= d->hip_scale_reduction;                     /* :331 */
+        if (s->lag_buf) {                                                  /* :337-339: buffer = buffer[1:] + [as]; target from buffer[0] */
+          int n = d->lag_timesteps + 1, rd = s->lag_pos + 1 >= n ? 0 : s->lag_pos + 1;
+          s->lag_buf[(size_t)s->lag_pos * R * 12 + i * 12 + j] = as;
+          as = s->lag_buf[(size_t)rd * R * 12 + i * 12 + j];
+        }
         float target = as + d->default_dof_pos[j];                         /* :341 */
         float err = q - target;                                            /* :343 */
         float x[6] = {err, e1[i * 12 + j], e2[i * 12 + j], qd, v1[i * 12 + j], v2[i * 12 + j]};
@@ -462,6 +489,7 @@ int mqo_compute_torques(mqo_sim* s) {
       s->torques[i * 12 + j] = fminf(fmaxf(tau, -lim), lim);               /* go1.py:352 */
     }
   }
+  if (s->lag_buf) s->lag_pos = (s->lag_pos + 1) % (d->lag_timesteps + 1);
   return 0;
 }
 
@@ -693,7 +721,9 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
       for (int k = 0; k < 3; k++) bk[b].ap[k] = bk[pb].ap[k] + t[k] + t2[k];
     }
     for (int b = 0; b < NB; b++) {
-      real cl[3] = {m->com[b][0], m->com[b][1], m->com[b][2]}, cw[3], Il[9], T[9], Rt[9];
+      /* domain parameters: added base mass and base CoM shift act on body 0 only, inertia about the CoM unchanged */
+      const float* dp = s->dparams + ((size_t)env * A + r) * 8;
+      real cl[3] = {m->com[b][0] + (b == 0 ? dp[2] : 0), m->com[b][1] + (b == 0 ? dp[3] : 0), m->com[b][2] + (b == 0 ? dp[4] : 0)}, cw[3], Il[9], T[9], Rt[9];
       mat3_vec(bk[b].R, cl, cw);
       for (int k = 0; k < 3; k++) bk[b].c[k] = bk[b].p[k] + cw[k];
       sym6_to_mat(m->inertia[b], Il);
@@ -720,7 +750,7 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
         for (int k = 0; k < 3; k++) Jw[6 + j - 1][k] = bk[j].a[k];
         cross3(bk[j].a, rr, Jv[6 + j - 1]);
       }
-      real mb = m->mass[b];
+      real mb = m->mass[b] + (b == 0 ? s->dparams[((size_t)env * A + r) * 8 + 1] : 0);
       for (int i = 0; i < RD; i++) {
         real IJ[3]; mat3_vec(bk[b].Iw, Jw[i], IJ);
         for (int j = 0; j < RD; j++) M[i * RD + j] += mb * dot3(Jv[i], Jv[j]) + dot3(IJ, Jw[j]);
@@ -949,10 +979,13 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
   }
 
   /* ---- projected Gauss-Seidel on velocities */
-  real mu = d->friction;
+  /* the shapes of a robot carry the env's (randomised) coefficient, averaged with the other shape's (PhysX combine mode);
+   * contacts without a robot keep d->friction */
+  real mu_robot = (real)0.5 * (s->dparams[(size_t)env * A * 8] + d->friction);
   for (int it = 0; it < d->solver_iterations; it++) {
     for (int ci = 0; ci < w->nc; ci++) {
       contact_t* ct = &w->con[ci];
+      real mu = (ct->actA < A || (ct->actB >= 0 && ct->actB < A)) ? mu_robot : (real)d->friction;
       real u[3];
       for (int q = 0; q < 3; q++) { real acc = 0; for (int i = 0; i < ndof; i++) acc += ct->J[q][i] * w->v[i]; u[q] = acc; }
       real bias = ct->sd >= 0 ? -ct->sd / dt : fminf((float)(-ct->sd * d->erp / dt), d->max_depenetration_velocity);
@@ -1295,6 +1328,15 @@ int mqo_post_physics_step(mqo_sim* s) {
     for (int k = 0; k < 12 * A; k++) s->last_actions[(size_t)e * 12 * A + k] = s->actions[(size_t)e * 12 * A + k];  /* :151 */
     for (int k = 0; k < 12 * A; k++) s->last_dof_vel[(size_t)e * 12 * A + k] = s->dof[((size_t)e * s->ND + k) * 2 + 1];    /* :152 */
     wrapper_env(s, e, 0, pre_npc ? pre_npc + (size_t)e * P * 13 : NULL);
+    /* _push_robots (go1.py:237, legged_robot.py:470-476): after this step's frame quantities were taken, before reset_idx,
+     * whose base velocities replace the push in the envs that reset; one draw per robot */
+    if (d->push_interval > 0 && (s->n_post_steps + 1) % d->push_interval == 0 && !s->reset_buf[e]) {
+      uint32_t cnt = 0x50000000u + (uint32_t)((s->n_post_steps + 1) / d->push_interval);
+      for (int a = 0; a < A; a++)
+        for (int c = 0; c < 2; c++)
+          s->root[((size_t)e * (A + P) + a) * 13 + 7 + c] =
+              2 * d->max_push_vel_xy * mqo_u01((uint32_t)d->seed, (uint32_t)(e + d->env_id_offset), cnt, (uint32_t)(2 * a + c)) + -d->max_push_vel_xy;
+    }
   }
   free(pre_npc);
   s->n_post_steps++;

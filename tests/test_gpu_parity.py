@@ -122,6 +122,46 @@ def test_fused_rollout_matches_oracle(task, N):
     assert mism <= max(2, N // 16), f"{mism} reset-flag mismatches"
 
 
+def test_domain_randomisation_matches_oracle():
+    """every hook of tests/test_domain_rand.py switched on at once (friction buckets, added mass, CoM shift, 6 substeps of action
+    lag, a push every 3rd step): same draws in both engines (hash RNG keyed by the global env id), fused rollout within the
+    bounds of test_fused_rollout_matches_oracle, pushed velocities identical."""
+    N = 32
+
+    def mk():
+        d, k, _ = make_desc("go1gate", N)
+        d.rand_friction, d.friction_lo, d.friction_hi = 1, 0.3, 1.5
+        d.rand_base_mass, d.added_mass_lo, d.added_mass_hi = 1, -1.0, 3.0
+        d.rand_com = 1
+        for c, (lo, hi) in enumerate(((-0.05, 0.15), (-0.1, 0.1), (-0.05, 0.05))):
+            d.com_lo[c], d.com_hi[c] = lo, hi
+        d.lag_timesteps, d.push_interval, d.max_push_vel_xy = 6, 3, 1.0
+        return d, k
+    eh, eo = hip_engine(*mk()), oracle_engine(*mk())
+    assert torch.equal(eh.tensor(abi.T_DOMAIN_PARAMS).cpu(), eo.tensor(abi.T_DOMAIN_PARAMS))
+    assert eo.tensor(abi.T_DOMAIN_PARAMS)[:, 1].std() > 0.5
+    eh.reset_all(); eo.reset_all()
+    g = torch.Generator().manual_seed(21)
+    dev_pos, mism = [], 0
+    for t in range(1, 13):
+        a = torch.rand(N, 2, 3, generator=g) * 2 - 1
+        eh.step(a.cuda().contiguous()); eo.step(a)
+        torch.cuda.synchronize()
+        rh, ro = eh.tensor(abi.T_ROOT_STATE).cpu(), eo.tensor(abi.T_ROOT_STATE)
+        dev_pos.append((rh[..., :3] - ro[..., :3]).abs().max(dim=-1).values.flatten())
+        mism += int((eh.tensor(abi.T_RESET_BUF).cpu() != eo.tensor(abi.T_RESET_BUF)).sum())
+        if t == 1:
+            close(eh.tensor(abi.T_SUBSTEP_TORQUES), eo.tensor(abi.T_SUBSTEP_TORQUES), atol=2e-2, rtol=1e-3, what="substep torques under lag")
+        if t % 3 == 0:
+            keep = (eo.tensor(abi.T_RESET_BUF) == 0) & (eh.tensor(abi.T_RESET_BUF).cpu() == 0)
+            assert torch.equal(rh[keep][:, :, 7:9], ro[keep][:, :, 7:9]), "pushed base velocities"
+            assert ro[keep][:, :, 7:9].abs().max() <= 1.0 and ro[keep][:, :, 7:9].abs().mean() > 0.3
+    dev = torch.stack(dev_pos)
+    assert torch.isfinite(dev).all()
+    assert dev[4].median() < 1e-4 and dev[-1].median() < 5e-3, (dev[4].median(), dev[-1].median())
+    assert mism <= 2, f"{mism} reset-flag mismatches"
+
+
 def test_self_contacts_match_oracle():
     """asset.self_collisions = 0: contacts between two links of one robot (both contact sides on the same actor: one
     Jacobian row over one set of dofs, coupling blocks with all four side pairings).  Robots in free fall with crossed /
