@@ -1052,16 +1052,18 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     else if (m->has_seesaw) { dact = A; dloc = 0; }
     else { const int q = d - A * MQE_RD; dact = A + q / npcdof; dloc = q - (q / npcdof) * npcdof; }
     float v = Vm[d];
-    for (int c = 0; c < nc; c++) {
-      const float* cr = lds + L.con + c * CON_STRIDE;
-      const int a2 = __float_as_int(cr[C_IDS]), b2 = __float_as_int(cr[C_IDS + 2]);
+    for (int c = 0; c < nc; c++) {                    // contact c's actors and impulse live in lane c's registers
+      const int a2 = __builtin_amdgcn_readlane(myA, c), b2 = __builtin_amdgcn_readlane(myB, c);
+      const float l0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cl0), c));
+      const float l1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cl1), c));
+      const float l2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cl2), c));
       if (a2 == dact) {
         const float* Bc = lds + L.B + c * 54;
-        v += Bc[dloc] * cr[C_LAM] + Bc[18 + dloc] * cr[C_LAM + 1] + Bc[36 + dloc] * cr[C_LAM + 2];
+        v += Bc[dloc] * l0 + Bc[18 + dloc] * l1 + Bc[36 + dloc] * l2;
       }
       if (b2 == dact) {                               // both for a contact between two links of this actor
         const float* Bc = lds + L.B + (maxc + (c - nc_terr)) * 54;
-        v += Bc[dloc] * cr[C_LAM] + Bc[18 + dloc] * cr[C_LAM + 1] + Bc[36 + dloc] * cr[C_LAM + 2];
+        v += Bc[dloc] * l0 + Bc[18 + dloc] * l1 + Bc[36 + dloc] * l2;
       }
     }
     Vm[d] = v;
