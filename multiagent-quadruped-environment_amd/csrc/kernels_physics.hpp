@@ -143,15 +143,37 @@ struct PhysDebug { float* minv; int* nc; float* contacts; int robot; long long* 
 // flags of one physics substep executed by a wavefront
 enum { PS_LOAD_STATE = 1, PS_LOAD_TAU = 2, PS_STORE_STATE = 4, PS_WRITE_CF = 8 };
 
+// Compile-time shape of an env (specialisations of the runtime values below; measured on go1gate: -8 % kernel time --
+// loops over the agents unroll, the NPC / seesaw / box / scenery branches disappear, the LDS layout becomes constants):
+//   TA > 0: number of agents, TA = 0: m->A;
+//   TP >= 0: which kinds of non-robot objects the scene has -- PS_F_LINK (fixed base + 1-dof link: seesaw, door, tug),
+//            PS_F_NPC (free bodies: ball, sheep, box), PS_F_BOX (the free body is the oriented box), PS_F_STATIC (scenery
+//            boxes); 0 = robots only.  TP = -1: everything read from the model at run time.
+enum { PS_F_LINK = 1, PS_F_NPC = 2, PS_F_BOX = 4, PS_F_STATIC = 8 };
+template <int TA, int TP>
+struct PhysShape {
+  const int A, P, PD, npcdof, ND, nbody, ndof, maxc, n_static;
+  const bool has_seesaw, has_box;
+  __device__ __forceinline__ explicit PhysShape(const DevModel* m)
+      : A(TA > 0 ? TA : m->A), P(TP == 0 ? 0 : m->P), PD((TP < 0 || (TP & PS_F_NPC)) ? m->n_npc_dyn : 0),
+        npcdof((TP < 0 || (TP & PS_F_NPC)) ? m->npc_dofs_each : 0),
+        ND((TA > 0 && TP == 0) ? 12 * TA : m->ND), nbody((TA > 0 && TP == 0) ? TA * MQE_NBODY : m->nbody_env),
+        ndof((TA > 0 && TP == 0) ? TA * MQE_RD : m->ndof_env), maxc((TA > 0 && TP == 0) ? mqe_maxc(TA, 0, 2) : m->maxc),
+        n_static((TP < 0 || (TP & PS_F_STATIC)) ? m->n_static : 0),
+        has_seesaw(TP < 0 ? m->has_seesaw != 0 : (TP & PS_F_LINK) != 0), has_box(TP < 0 ? m->has_box != 0 : (TP & PS_F_BOX) != 0) {}
+};
+
+template <int TA, int TP>
 __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, const DevState& st, float* lds, const int e, const int lane,
                                              const int flags, const int no_write, const PhysDebug& dbg) {
-  const int A = m->A, P = m->P, PD = m->n_npc_dyn, npcdof = m->npc_dofs_each;
-  const int nbody = m->nbody_env, ndof = m->ndof_env, nsph = m->nsph_env, maxc = m->maxc;
-  const PhysLds L = phys_lds_layout(A, P, m->ND, nbody, ndof, nsph, maxc);
+  const PhysShape<TA, TP> shp(m);
+  const int A = shp.A, P = shp.P, PD = shp.PD, npcdof = shp.npcdof;
+  const int nbody = shp.nbody, ndof = shp.ndof, nsph = m->nsph_env, maxc = shp.maxc;
+  const PhysLds L = phys_lds_layout(A, P, shp.ND, nbody, ndof, nsph, maxc);
   const float dt = m->dt;
   const mqe_robot_model& rm = m->robot;
   float* g_root = st.root + (size_t)e * (A + P) * 13;
-  float* g_dof = st.dof + (size_t)e * m->ND * 2;
+  float* g_dof = st.dof + (size_t)e * shp.ND * 2;
 
   // this lane's self-collision candidates, one per pass of 64 (requested here, consumed after the terrain contacts: the
   // table sits in global memory and a load inside the pass loop put its full latency on every pass)
@@ -163,7 +185,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   // ---- coalesced state load (first substep of a launch only; afterwards the state stays in LDS) -----------------
   if (flags & PS_LOAD_STATE) {
     for (int i = lane; i < (A + P) * 13; i += 64) lds[L.root + i] = g_root[i];
-    for (int i = lane; i < m->ND * 2; i += 64) lds[L.dof + i] = g_dof[i];
+    for (int i = lane; i < shp.ND * 2; i += 64) lds[L.dof + i] = g_dof[i];
   }
   if (flags & PS_LOAD_TAU)
     for (int i = lane; i < 12 * A; i += 64) lds[L.tau + i] = st.torques[(size_t)e * 12 * A + i];
@@ -457,7 +479,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       for (int ee = 0; ee < MQE_RD; ee++) acc += Mc[ee * MQE_RD] * rh[ee];
       return v + dt * acc;
     }
-    if (m->has_seesaw) return lds[L.dof + (12 * A) * 2 + 1];       // the plank's hinge: COM on the axis, no drive
+    if (shp.has_seesaw) return lds[L.dof + (12 * A) * 2 + 1];       // the plank's hinge: COM on the axis, no drive
     const int q = d - A * MQE_RD, p = q / npcdof, k = q - p * npcdof;
     float v = lds[L.root + (A + p) * 13 + 7 + k];
     if (k == 2) v += dt * m->gravity_z;
@@ -489,7 +511,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
 
   TSTAMP(8);
   // seesaw geometry (uniform): platform centre, hinge, plank rotation about +y and centre
-  const bool SS = m->has_seesaw != 0;
+  const bool SS = shp.has_seesaw;
   V3 ssB = v3(0, 0, 0), ssPiv = v3(0, 0, 0), ssC = v3(0, 0, 0);
   float ssR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, ssTheta = 0.0f;
   if (SS) {
@@ -564,11 +586,11 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       } else if (sh <= 0) { wsd = dz - rad; wn = v3(0, 0, 1); }
       else { const float dist = sqrtf(sh * sh + dz * dz); wsd = dist - rad; wn = v3(gx * sh / dist, gy * sh / dist, dz / dist); }
       wflag = wsd < m->contact_offset;
-      if (m->n_static > 0 && act < A) {     // static scenery: the world-aligned box with the smallest signed distance
+      if (shp.n_static > 0 && act < A) {     // static scenery: the world-aligned box with the smallest signed distance
         const float I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
         const V3 nb = ld3(lds + L.root + A * 13);
         bsd = 1e3f;
-        for (int bx = 0; bx < m->n_static; bx++) {
+        for (int bx = 0; bx < shp.n_static; bx++) {
           V3 nn;
           const float sdb = sphere_box(c, rad, nb + v3(m->sb_center[bx][0], m->sb_center[bx][1], m->sb_center[bx][2]), I3,
                                        v3(m->sb_half[bx][0], m->sb_half[bx][1], m->sb_half[bx][2]), nn);
@@ -681,7 +703,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
         const V3 pa = ld3(lds + L.body + (a < A ? a * MQE_NBODY : A * MQE_NBODY + (a - A)) * BODY_STRIDE + B_P);
         const V3 pb = ld3(lds + L.body + (b < A ? b * MQE_NBODY : A * MQE_NBODY + (b - A)) * BODY_STRIDE + B_P);
         const V3 dd = pa - pb;
-        if (m->has_box && b >= A) {                           // robot spheres vs the oriented box (NPC body record = its pose)
+        if (shp.has_box && b >= A) {                           // robot spheres vs the oriented box (NPC body record = its pose)
           if (a >= A || dot(dd, dd) > 1.8f * 1.8f) continue;
           const float* brec = lds + L.body + (A * MQE_NBODY + (b - A)) * BODY_STRIDE;
           bool hit = false; float sd = 0; V3 n = v3(0, 0, 1), c = v3(0, 0, 0); float ra = 0;
@@ -1049,7 +1071,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   for (int d = lane; d < ndof; d += 64) {           // impulses -> velocities, each lane its own entries of Vm
     int dact, dloc;
     if (d < A * MQE_RD) { dact = d / MQE_RD; dloc = d - dact * MQE_RD; }
-    else if (m->has_seesaw) { dact = A; dloc = 0; }
+    else if (shp.has_seesaw) { dact = A; dloc = 0; }
     else { const int q = d - A * MQE_RD; dact = A + q / npcdof; dloc = q - (q / npcdof) * npcdof; }
     float v = Vm[d];
     for (int c = 0; c < nc; c++) {                    // contact c's actors and impulse live in lane c's registers
@@ -1167,13 +1189,13 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   __syncthreads();
   if (flags & PS_STORE_STATE) {       // coalesced write-back
     for (int i = lane; i < (A + P) * 13; i += 64) g_root[i] = lds[L.root + i];
-    for (int i = lane; i < m->ND * 2; i += 64) g_dof[i] = lds[L.dof + i];
+    for (int i = lane; i < shp.ND * 2; i += 64) g_dof[i] = lds[L.dof + i];
   }
 }
 
 __global__ void __launch_bounds__(64) k_simulate(const DevModel* __restrict__ m, DevState st, int env_base, int no_write, PhysDebug dbg) {
   extern __shared__ float lds[];
-  phys_substep(m, st, lds, env_base + blockIdx.x, threadIdx.x, PS_LOAD_STATE | PS_LOAD_TAU | PS_STORE_STATE | PS_WRITE_CF, no_write, dbg);
+  phys_substep<0, -1>(m, st, lds, env_base + blockIdx.x, threadIdx.x, PS_LOAD_STATE | PS_LOAD_TAU | PS_STORE_STATE | PS_WRITE_CF, no_write, dbg);
 }
 
 // ----------------------------------------------------------------------------------------------------------------------
@@ -1187,11 +1209,13 @@ __device__ __forceinline__ float softsign_p(float x) { return x / (1.0f + fabsf(
 
 #define ACT_TILES 2       // 2 x 32 joints >= 12 * MQE_MAX_AGENTS(=4)... agents <= 4 need 48 joints
 
+template <int TA, int TP>
 __global__ void __launch_bounds__(64, 2) k_substeps(const DevModel* __restrict__ m, DevState st, int nsub, int lag_pos) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x, e = blockIdx.x;
-  const int A = m->A, P = m->P;
-  const PhysLds L = phys_lds_layout(A, P, m->ND, m->nbody_env, m->ndof_env, m->nsph_env, m->maxc);
+  const PhysShape<TA, TP> shp(m);
+  const int A = shp.A, P = shp.P;
+  const PhysLds L = phys_lds_layout(A, P, shp.ND, shp.nbody, shp.ndof, m->nsph_env, shp.maxc);
   const int j32 = lane & 31, h = lane >> 5;
   const int nj = 12 * A;
   const float* W0 = m->actuator.W[0]; const float* b0 = m->actuator.b[0];
@@ -1220,9 +1244,9 @@ __global__ void __launch_bounds__(64, 2) k_substeps(const DevModel* __restrict__
     lim[t] = m->torque_limits[j];
   }
   float* g_root = st.root + (size_t)e * (A + P) * 13;
-  float* g_dof = st.dof + (size_t)e * m->ND * 2;
+  float* g_dof = st.dof + (size_t)e * shp.ND * 2;
   for (int i = lane; i < (A + P) * 13; i += 64) lds[L.root + i] = g_root[i];
-  for (int i = lane; i < m->ND * 2; i += 64) lds[L.dof + i] = g_dof[i];
+  for (int i = lane; i < shp.ND * 2; i += 64) lds[L.dof + i] = g_dof[i];
   __syncthreads();
   const PhysDebug nodbg = {nullptr, nullptr, nullptr, 0, nullptr};
   for (int k = 0; k < nsub; k++) {
@@ -1248,7 +1272,7 @@ __global__ void __launch_bounds__(64, 2) k_substeps(const DevModel* __restrict__
         }
       }
       __syncthreads();
-      phys_substep(m, st, lds, e, lane, last ? (PS_STORE_STATE | PS_WRITE_CF) : 0, 0, nodbg);
+      phys_substep<TA, TP>(m, st, lds, e, lane, last ? (PS_STORE_STATE | PS_WRITE_CF) : 0, 0, nodbg);
       continue;
     }
     if (m->lag_steps > 0) {            // go1.py:337-339: the lag buffer shifts in every _compute_torques call, i.e. per substep
@@ -1301,7 +1325,7 @@ __global__ void __launch_bounds__(64, 2) k_substeps(const DevModel* __restrict__
       }
     }
     __syncthreads();
-    phys_substep(m, st, lds, e, lane, last ? (PS_STORE_STATE | PS_WRITE_CF) : 0, 0, nodbg);
+    phys_substep<TA, TP>(m, st, lds, e, lane, last ? (PS_STORE_STATE | PS_WRITE_CF) : 0, 0, nodbg);
   }
 #pragma unroll
   for (int t = 0; t < ACT_TILES; t++) {

@@ -50,6 +50,7 @@ struct mqe_sim {
   void* tens[MQE_T_COUNT];
   int N, A, P, R, ND, NBR, Aw, D;
   int hist_pos = 0, n_post_steps = 0;
+  void (*substeps_fn)(const DevModel*, DevState, int, int) = nullptr;    // the k_substeps specialisation of this scene
   int lag_pos = 0;                    // write slot of the action-lag ring (domain randomisation), advances per substep
   // policy network (fused first layer: [adaptation L0 | body L0 history part])
   GemmLayer l0;                       // K = 30*72 (ring), N = ada_h0 + body_h0
@@ -165,6 +166,21 @@ static int finalize_frag(mqe_sim* s, GemmLayer* L) {
   return 0;
 }
 
+// k_substeps is compiled for the env shapes of the shipped tasks (kernels_physics.hpp: PhysShape); everything else takes the
+// runtime form
+static void (*pick_substeps(const DevModel& m))(const DevModel*, DevState, int, int) {
+  const int feat = (m.has_seesaw ? PS_F_LINK : 0) | (m.n_npc_dyn > 0 ? PS_F_NPC : 0) | (m.has_box ? PS_F_BOX : 0) | (m.n_static > 0 ? PS_F_STATIC : 0);
+  if (feat == 0 && m.P == 0) {
+    if (m.A == 2) return k_substeps<2, 0>;                                   // go1gate
+    if (m.A == 1) return k_substeps<1, 0>;                                   // go1plane
+  }
+  if (m.A == 2 && feat == PS_F_LINK) return k_substeps<2, PS_F_LINK>;        // go1seesaw, go1revolvingdoor, go1tug
+  if (m.A == 2 && feat == PS_F_NPC) return k_substeps<2, PS_F_NPC>;          // go1sheep-*, go1football-1vs1
+  if (m.A == 3 && feat == PS_F_NPC) return k_substeps<3, PS_F_NPC>;          // go1football-defender
+  if (m.A == 2) return k_substeps<2, -1>;
+  return k_substeps<0, -1>;
+}
+
 static int wrapper_dims(const mqe_sim_desc* d, int* Aw, int* D) {
   int A = d->num_agents, P = d->num_npcs;
   switch (d->task) {
@@ -247,9 +263,10 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   PhysLds L = phys_lds_layout(A, P, s->ND, m.nbody_env, m.ndof_env, m.nsph_env, m.maxc);
   s->phys_lds_bytes = (size_t)L.total * 4;
   if (s->phys_lds_bytes > 160 * 1024) { delete s; return fail(-4, "physics LDS footprint exceeds 160 KiB"); }
+  s->substeps_fn = pick_substeps(m);
   if (s->phys_lds_bytes > 48 * 1024)
     if (hipFuncSetAttribute((const void*)k_simulate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->phys_lds_bytes) != hipSuccess ||
-        hipFuncSetAttribute((const void*)k_substeps, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->phys_lds_bytes) != hipSuccess) {
+        hipFuncSetAttribute((const void*)s->substeps_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->phys_lds_bytes) != hipSuccess) {
       delete s; return fail(-4, "cannot raise dynamic LDS limit");
     }
   s->fuse_substeps = getenv("MQE_NO_FUSE_SUBSTEPS") == nullptr && d->decimation <= 4;
@@ -669,7 +686,7 @@ static int run_substeps_and_post(mqe_sim* s, hipStream_t q) {
   if (s->fuse_substeps) {
     // decimation loop in one launch: state stays in LDS; actuator net on MFMA (C) or the PD / torque law (P, V, T) inside the wavefront
     ProfScope ps(s, PROF_SIMULATE, q);
-    hipLaunchKernelGGL(k_substeps, dim3(s->N), dim3(64), s->phys_lds_bytes, q, s->dm, s->st, s->d.decimation, s->lag_pos);
+    hipLaunchKernelGGL(s->substeps_fn, dim3(s->N), dim3(64), s->phys_lds_bytes, q, s->dm, s->st, s->d.decimation, s->lag_pos);
     advance_lag(s, s->d.decimation);
   } else {
     for (int k = 0; k < s->d.decimation; k++) {
