@@ -16,7 +16,13 @@ def one(pattern):
 
 
 def short(name):
-    return name.split("(")[0].strip()
+    """kernel name without signature, return type and template arguments: `void k_substeps<2, 0>(...)` -> `k_substeps`"""
+    n = name.split("(")[0].strip()
+    if n.startswith("void "):
+        n = n[5:]
+    if n.startswith("k_"):
+        n = n.split("<")[0]
+    return n
 
 
 summary = {"_note": ("rocprofv3 on `bench.py --steps 60 --warmup 10` (go1gate 4096 envs x 2 agents, 1 MI355X), separate runs: "
