@@ -122,6 +122,26 @@ def test_fused_rollout_matches_oracle(task, N):
     assert mism <= max(2, N // 16), f"{mism} reset-flag mismatches"
 
 
+@pytest.mark.parametrize("N,split", [(1, "0"), (1, "1"), (3, "1"), (37, "0"), (37, "1")])
+def test_tiny_and_ragged_batches(monkeypatch, N, split):
+    """batch sizes far below a tile of any kernel (1 env = 2 robots: 2 of the 128 GEMM rows, 2 of the tail's 32, one physics
+    wave) and not a multiple of anything, with either layer-0 kernel: 6 fused steps against the oracle"""
+    monkeypatch.setenv("MQE_GEMM_SPLIT", split)
+    eh, eo, d = _pair("go1gate", N)
+    monkeypatch.delenv("MQE_GEMM_SPLIT")
+    eh.reset_all(); eo.reset_all()
+    g = torch.Generator().manual_seed(31 + N)
+    for t in range(6):
+        a = torch.rand(N, 2, 3, generator=g) * 2 - 1
+        eh.step(a.cuda().contiguous()); eo.step(a)
+        torch.cuda.synchronize()
+        if t == 0:
+            close(eh.tensor(abi.T_ACTIONS), eo.tensor(abi.T_ACTIONS), atol=5e-5, what="policy actions step 0")
+            close(eh.tensor(abi.T_WRAPPER_OBS), eo.tensor(abi.T_WRAPPER_OBS), atol=2e-4, what="wrapper obs step 0")
+    close(eh.tensor(abi.T_ROOT_STATE)[..., :3], eo.tensor(abi.T_ROOT_STATE)[..., :3], atol=2e-3, what="root position after 6 steps")
+    assert (eh.tensor(abi.T_RESET_BUF).cpu() == eo.tensor(abi.T_RESET_BUF)).all()
+
+
 def test_domain_randomisation_matches_oracle():
     """every hook of tests/test_domain_rand.py switched on at once (friction buckets, added mass, CoM shift, 6 substeps of action
     lag, a push every 3rd step): same draws in both engines (hash RNG keyed by the global env id), fused rollout within the
