@@ -1,71 +1,61 @@
-"""Task registry and factory: the drop-in boundary of the package (reference mqe/envs/utils.py:38-134)."""
+"""Task registry and factory: the drop-in boundary of the package (same names and call signatures as the reference's
+mqe/envs/utils.py:38-134: `ENV_DICT[task] = {"class", "config", "wrapper"}`, `make_mqe_env(task, args, custom_cfg)`,
+`custom_cfg(args)`).  The registry itself is a table of names resolved on import."""
+from importlib import import_module
 from typing import Tuple
 
-from mqe.envs.go1.go1 import Go1
-from mqe.envs.npc.go1_sheep import Go1Sheep
-from mqe.envs.npc.go1_object import Go1Object
-from mqe.envs.npc.go1_football_defender import Go1FootballDefender
+from mqe.envs.configs._build import cfg
 from mqe.envs.field.legged_robot_field import LeggedRobotField
 from mqe.envs.field.legged_robot_field_config import LeggedRobotFieldCfg
-
-from mqe.envs.configs.go1_plane_config import Go1PlaneCfg
-from mqe.envs.configs.go1_gate_config import Go1GateCfg
-from mqe.envs.configs.go1_sheep_config import SingleSheepCfg, NineSheepCfg
-from mqe.envs.configs.go1_football_config import Go1FootballDefenderCfg, Go1Football1vs1Cfg, Go1Football2vs2Cfg
-from mqe.envs.configs.go1_seesaw_config import Go1SeesawCfg
-from mqe.envs.configs.go1_pushbox_config import Go1PushboxCfg
-from mqe.envs.configs.go1_rotation_config import Go1RotationCfg
-from mqe.envs.configs.go1_bridge_config import Go1BridgeCfg
-from mqe.envs.configs.go1_tug_config import Go1TugCfg
-from mqe.envs.configs.go1_wrestling_config import Go1WrestlingCfg
-
-from mqe.envs.wrappers.empty_wrapper import EmptyWrapper
-from mqe.envs.wrappers.go1_gate_wrapper import Go1GateWrapper
-from mqe.envs.wrappers.go1_sheep_wrapper import Go1SheepWrapper
-from mqe.envs.wrappers.go1_seesaw_wrapper import Go1SeesawWrapper
-from mqe.envs.wrappers.go1_pushbox_wrapper import Go1PushboxWrapper
-from mqe.envs.wrappers.go1_rotation_wrapper import Go1RotationWrapper
-from mqe.envs.wrappers.go1_bridge_wrapper import Go1BridgeWrapper
-from mqe.envs.wrappers.go1_tug_wrapper import Go1TugWrapper
-from mqe.envs.wrappers.go1_wrestling_wrapper import Go1WrestlingWrapper
-from mqe.envs.wrappers.go1_football_wrapper import Go1FootballDefenderWrapper, Go1FootballGameWrapper
-
 from mqe.utils import get_args, make_env  # noqa: F401
 
-ENV_DICT = {
-    "go1plane": {"class": Go1, "config": Go1PlaneCfg, "wrapper": EmptyWrapper},
-    "go1gate": {"class": Go1, "config": Go1GateCfg, "wrapper": Go1GateWrapper},
-    "go1sheep-easy": {"class": Go1Sheep, "config": SingleSheepCfg, "wrapper": Go1SheepWrapper},
-    "go1sheep-hard": {"class": Go1Sheep, "config": NineSheepCfg, "wrapper": Go1SheepWrapper},
-    "go1football-defender": {"class": Go1FootballDefender, "config": Go1FootballDefenderCfg, "wrapper": Go1FootballDefenderWrapper},
-    "go1football-1vs1": {"class": Go1Object, "config": Go1Football1vs1Cfg, "wrapper": Go1FootballGameWrapper},
-    "go1football-2vs2": {"class": Go1Object, "config": Go1Football2vs2Cfg, "wrapper": Go1FootballGameWrapper},
-    "go1seesaw": {"class": Go1Object, "config": Go1SeesawCfg, "wrapper": Go1SeesawWrapper},
-    "go1pushbox": {"class": Go1Object, "config": Go1PushboxCfg, "wrapper": Go1PushboxWrapper},
-    "go1revolvingdoor": {"class": Go1Object, "config": Go1RotationCfg, "wrapper": Go1RotationWrapper},
-    "go1tug": {"class": Go1Object, "config": Go1TugCfg, "wrapper": Go1TugWrapper},
-    "go1bridge": {"class": Go1Object, "config": Go1BridgeCfg, "wrapper": Go1BridgeWrapper},
-    "go1wrestling": {"class": Go1Object, "config": Go1WrestlingCfg, "wrapper": Go1WrestlingWrapper},
-}
+#        task                      environment class (module:name)                   config entry              wrapper (module:name)
+_TASKS = (
+    ("go1plane",             "go1.go1:Go1",                                    "Go1PlaneCfg",            "empty_wrapper:EmptyWrapper"),
+    ("go1gate",              "go1.go1:Go1",                                    "Go1GateCfg",             "go1_gate_wrapper:Go1GateWrapper"),
+    ("go1sheep-easy",        "npc.go1_sheep:Go1Sheep",                         "SingleSheepCfg",         "go1_sheep_wrapper:Go1SheepWrapper"),
+    ("go1sheep-hard",        "npc.go1_sheep:Go1Sheep",                         "NineSheepCfg",           "go1_sheep_wrapper:Go1SheepWrapper"),
+    ("go1football-defender", "npc.go1_football_defender:Go1FootballDefender",  "Go1FootballDefenderCfg", "go1_football_wrapper:Go1FootballDefenderWrapper"),
+    ("go1football-1vs1",     "npc.go1_object:Go1Object",                       "Go1Football1vs1Cfg",     "go1_football_wrapper:Go1FootballGameWrapper"),
+    ("go1football-2vs2",     "npc.go1_object:Go1Object",                       "Go1Football2vs2Cfg",     "go1_football_wrapper:Go1FootballGameWrapper"),
+    ("go1seesaw",            "npc.go1_object:Go1Object",                       "Go1SeesawCfg",           "go1_seesaw_wrapper:Go1SeesawWrapper"),
+    ("go1pushbox",           "npc.go1_object:Go1Object",                       "Go1PushboxCfg",          "go1_pushbox_wrapper:Go1PushboxWrapper"),
+    ("go1revolvingdoor",     "npc.go1_object:Go1Object",                       "Go1RotationCfg",         "go1_rotation_wrapper:Go1RotationWrapper"),
+    ("go1tug",               "npc.go1_object:Go1Object",                       "Go1TugCfg",              "go1_tug_wrapper:Go1TugWrapper"),
+    ("go1bridge",            "npc.go1_object:Go1Object",                       "Go1BridgeCfg",           "go1_bridge_wrapper:Go1BridgeWrapper"),
+    ("go1wrestling",         "npc.go1_object:Go1Object",                       "Go1WrestlingCfg",        "go1_wrestling_wrapper:Go1WrestlingWrapper"),
+)
 
-# registered by the reference but not built yet
+
+def _resolve(package, spec):
+    module, name = spec.split(":")
+    return getattr(import_module(f"{package}.{module}"), name)
+
+
+ENV_DICT = {task: {"class": _resolve("mqe.envs", env), "config": cfg(entry), "wrapper": _resolve("mqe.envs.wrappers", wrapper)}
+            for task, env, entry, wrapper in _TASKS}
+
+# tasks the reference registers that this build does not run: none
 NOT_YET = ()
 
 
 def make_mqe_env(env_name: str, args=None, custom_cfg=None) -> Tuple[LeggedRobotField, LeggedRobotFieldCfg]:
+    """environment of task `env_name` inside its task wrapper, and the config it was built from"""
     if env_name in NOT_YET:
         raise NotImplementedError(f"task '{env_name}' is registered by the reference but outside this build's hot-path scope so far")
-    entry = ENV_DICT[env_name]
+    task = ENV_DICT[env_name]
     if callable(custom_cfg):
-        entry["config"] = custom_cfg(entry["config"])
-    env, env_cfg = make_env(entry["class"], entry["config"], args)
-    return entry["wrapper"](env), env_cfg
+        task["config"] = custom_cfg(task["config"])
+    env, env_cfg = make_env(task["class"], task["config"], args)
+    return task["wrapper"](env), env_cfg
 
 
 def custom_cfg(args):
-    def fn(cfg: LeggedRobotFieldCfg):
-        if getattr(args, "num_envs", None) is not None:
-            cfg.env.num_envs = args.num_envs
-        cfg.env.record_video = getattr(args, "record_video", False)
-        return cfg
-    return fn
+    """config hook of the training scripts: --num_envs and --record_video override the task defaults"""
+    def apply(cfg_cls: LeggedRobotFieldCfg):
+        n = getattr(args, "num_envs", None)
+        if n is not None:
+            cfg_cls.env.num_envs = n
+        cfg_cls.env.record_video = getattr(args, "record_video", False)
+        return cfg_cls
+    return apply
