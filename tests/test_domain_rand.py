@@ -136,3 +136,29 @@ def test_pushes_redraw_the_base_velocity_after_the_observation():
             assert (va.abs() <= 1.0).all() and not torch.allclose(va, first), "a fresh draw per push"
         else:
             assert torch.allclose(va, vb)
+
+
+def test_config_switches_reach_the_engine_descriptor():
+    """cfg.domain_rand / cfg.asset of a task config -> mqe_sim_desc (mqe/engine/desc.py), as the reference reads them at env creation"""
+    from helpers import task_cfg
+    cfg = task_cfg("go1gate")
+    d0, _, _ = make_desc("go1gate", 4)
+    assert (d0.rand_friction, d0.rand_base_mass, d0.rand_com, d0.lag_timesteps, d0.push_interval) == (0, 0, 0, 0, 0)   # go1_config.py:216-247: all off
+    assert d0.self_collision == 1                                                                                        # go1_config.py:73
+    dr, asset = cfg.domain_rand, cfg.asset
+    saved = {k: getattr(dr, k) for k in ("randomize_friction", "randomize_base_mass", "randomize_com", "randomize_lag_timesteps", "push_robots")}
+    saved_sc = asset.self_collisions
+    try:
+        dr.randomize_friction = dr.randomize_base_mass = dr.randomize_com = dr.randomize_lag_timesteps = dr.push_robots = True
+        asset.self_collisions = 1
+        d1, _, _ = make_desc("go1gate", 4)
+    finally:
+        for k, v in saved.items():
+            setattr(dr, k, v)
+        asset.self_collisions = saved_sc
+    assert d1.rand_friction == 1 and (round(d1.friction_lo, 3), round(d1.friction_hi, 3)) == (0.05, 4.5)
+    assert d1.rand_base_mass == 1 and (d1.added_mass_lo, d1.added_mass_hi) == (-1.0, 3.0)
+    assert d1.rand_com == 1 and [round(d1.com_lo[k], 3) for k in range(3)] == [-0.05, -0.1, -0.05] and [round(d1.com_hi[k], 3) for k in range(3)] == [0.15, 0.1, 0.05]
+    assert d1.lag_timesteps == 6
+    assert d1.push_interval == 750 and d1.max_push_vel_xy == 1.0                  # 15 s / (4 x 5 ms), legged_robot.py:1024
+    assert d1.self_collision == 0
