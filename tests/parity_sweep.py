@@ -3,7 +3,7 @@
 random actions; prints / writes per task the deviation of the robots' base positions (median and 99th percentile over envs)
 after 5, 20 and 50 steps, the reset-flag mismatches and the largest policy-action difference at step 0.  Contact dynamics
 amplify rounding differences, so the late numbers measure trajectory divergence, not arithmetic error (tests/ pin the
-arithmetic on single steps).  Usage (GPU box): python tools/parity_sweep.py [N] [out.json]"""
+arithmetic on single steps).  Usage (GPU box): python tests/parity_sweep.py [N] [out.json]"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "multiagent-quadruped-environment_amd")]
