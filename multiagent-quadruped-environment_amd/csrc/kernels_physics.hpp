@@ -1271,10 +1271,8 @@ __global__ void __launch_bounds__(64, 2) k_substeps(const DevModel* __restrict__
           if (last) st.torques[(size_t)e * nj + jt] = tau;
         }
       }
-      __syncthreads();
-      phys_substep<TA, TP>(m, st, lds, e, lane, last ? (PS_STORE_STATE | PS_WRITE_CF) : 0, 0, nodbg);
-      continue;
-    }
+    } else {                           // control type C: actuator network (one call site of the physics body below: it is
+                                       // inlined, and two copies of its ~9 k instructions would not fit the instruction cache)
     if (m->lag_steps > 0) {            // go1.py:337-339: the lag buffer shifts in every _compute_torques call, i.e. per substep
       const int n = m->lag_steps + 1;
       int pos = lag_pos + k; pos -= (pos / n) * n;
@@ -1323,6 +1321,7 @@ __global__ void __launch_bounds__(64, 2) k_substeps(const DevModel* __restrict__
         st.sub_tau[((size_t)e * 4 + (k < 4 ? k : 3)) * nj + jt] = tau;          // post_decimation_step (legged_robot.py:113)
         if (last) st.torques[(size_t)e * nj + jt] = tau;
       }
+    }
     }
     __syncthreads();
     phys_substep<TA, TP>(m, st, lds, e, lane, last ? (PS_STORE_STATE | PS_WRITE_CF) : 0, 0, nodbg);
