@@ -177,6 +177,9 @@ static void (*pick_substeps(const DevModel& m))(const DevModel*, DevState, int, 
   if (m.A == 2 && feat == PS_F_LINK) return k_substeps<2, PS_F_LINK>;        // go1seesaw, go1revolvingdoor, go1tug
   if (m.A == 2 && feat == PS_F_NPC) return k_substeps<2, PS_F_NPC>;          // go1sheep-*, go1football-1vs1
   if (m.A == 3 && feat == PS_F_NPC) return k_substeps<3, PS_F_NPC>;          // go1football-defender
+  if (m.A == 4 && feat == PS_F_NPC) return k_substeps<4, PS_F_NPC>;          // go1football-2vs2
+  if (m.A == 2 && feat == (PS_F_NPC | PS_F_BOX)) return k_substeps<2, PS_F_NPC | PS_F_BOX>;   // go1pushbox
+  if (m.A == 2 && feat == PS_F_STATIC) return k_substeps<2, PS_F_STATIC>;    // go1bridge, go1wrestling
   if (m.A == 2) return k_substeps<2, -1>;
   return k_substeps<0, -1>;
 }
