@@ -701,12 +701,14 @@ __device__ void wrapper_env_dev(const DevModel* m, const DevState& st, int e, in
 #ifndef POST_EPW
 #define POST_EPW 8
 #endif
+template <int AM>
 __device__ __forceinline__ uint8_t post_physics_env(const DevModel* m, const DevState& st, const int e, const int wrapper_level, const int push_count);
 
+template <int AM>
 __global__ void __launch_bounds__(64) k_post_physics(const DevModel* m, DevState st, int wrapper_level, int push_count) {
   const int e = blockIdx.x * POST_EPW + threadIdx.x;
   uint8_t reset = 0;
-  if (threadIdx.x < POST_EPW && e < m->N) reset = post_physics_env(m, st, e, wrapper_level, push_count);
+  if (threadIdx.x < POST_EPW && e < m->N) reset = post_physics_env<AM>(m, st, e, wrapper_level, push_count);
   // go1.py:145: history[agent_ids] = 0 for the envs that reset this step -- rare, so the whole wavefront (the lanes that
   // idled above included) zeroes them, 16 B per lane per request: the f32 ring and, when present, its two f16 planes
   unsigned long long rm = __ballot(reset != 0);
@@ -725,19 +727,21 @@ __global__ void __launch_bounds__(64) k_post_physics(const DevModel* m, DevState
   }
 }
 
+// AM: compile-time bound of the agent loops (>= m->A; 2 for the two-robot tasks, MQE_MAX_AGENTS otherwise)
+template <int AM>
 __device__ __forceinline__ uint8_t post_physics_env(const DevModel* m, const DevState& st, const int e, const int wrapper_level, const int push_count) {
   const int A = m->A, P = m->P;
   const float dtp = m->dt * (float)m->decimation;
   float* root = st.root + (size_t)e * (A + P) * 13;
   // ---- loads --------------------------------------------------------------------------------------------------------------
-  float rs[MQE_MAX_AGENTS][13], gpar[MQE_MAX_AGENTS][5], gi0[MQE_MAX_AGENTS], f3[MQE_MAX_AGENTS][3], aoz[MQE_MAX_AGENTS];
-  float dq[MQE_MAX_AGENTS][24], act[MQE_MAX_AGENTS][12];
+  float rs[AM][13], gpar[AM][5], gi0[AM], f3[AM][3], aoz[AM];
+  float dq[AM][24], act[AM][12];
   const int ep = st.ep_len[e] + 1;
   float eo[3];
 #pragma unroll
   for (int k = 0; k < 3; k++) eo[k] = m->env_origins[e * 3 + k];
 #pragma unroll
-  for (int a = 0; a < MQE_MAX_AGENTS; a++)
+  for (int a = 0; a < AM; a++)
     if (a < A) {
       const int i = e * A + a;
 #pragma unroll
@@ -757,10 +761,10 @@ __device__ __forceinline__ uint8_t post_physics_env(const DevModel* m, const Dev
       for (int k = 0; k < 12; k++) act[a][k] = st.actions[(size_t)i * 12 + k];
     }
   // ---- body-frame quantities, gait clock, termination (registers only) ------------------------------------------------------
-  float bq[MQE_MAX_AGENTS][4], lv[MQE_MAX_AGENTS][3], av[MQE_MAX_AGENTS][3], pgr[MQE_MAX_AGENTS][3], clk[MQE_MAX_AGENTS][4], gi1[MQE_MAX_AGENTS];
+  float bq[AM][4], lv[AM][3], av[AM][3], pgr[AM][3], clk[AM][4], gi1[AM];
   uint8_t reset = 0, collide = 0, rterm = 0, pterm = 0, zh = 0;
 #pragma unroll
-  for (int a = 0; a < MQE_MAX_AGENTS; a++)
+  for (int a = 0; a < AM; a++)
     if (a < A) {
       const float q[4] = {rs[a][3], rs[a][4], rs[a][5], rs[a][6]}, v[3] = {rs[a][7], rs[a][8], rs[a][9]}, w[3] = {rs[a][10], rs[a][11], rs[a][12]};
       const float g3[3] = {0.0f, 0.0f, -1.0f};
@@ -805,7 +809,7 @@ __device__ __forceinline__ uint8_t post_physics_env(const DevModel* m, const Dev
   st.reset_buf[e] = reset;
   if (m->terminate_on_base_contact) st.collide_buf[e] = reset;
 #pragma unroll
-  for (int a = 0; a < MQE_MAX_AGENTS; a++)
+  for (int a = 0; a < AM; a++)
     if (a < A) {
       const int i = e * A + a;
 #pragma unroll
@@ -822,7 +826,7 @@ __device__ __forceinline__ uint8_t post_physics_env(const DevModel* m, const Dev
     reset_env_dev(m, st, e);
     for (int k = 0; k < P * 13; k++) npc_pre[k] = root[A * 13 + k];
 #pragma unroll
-    for (int a = 0; a < MQE_MAX_AGENTS; a++)
+    for (int a = 0; a < AM; a++)
       if (a < A) {
 #pragma unroll
         for (int k = 0; k < 13; k++) rs[a][k] = root[a * 13 + k];
@@ -837,7 +841,7 @@ __device__ __forceinline__ uint8_t post_physics_env(const DevModel* m, const Dev
   }
   // ---- compute_observations (legged_robot_field.py:117-146) from registers; obs.last_last_action aliases the current action
 #pragma unroll
-  for (int a = 0; a < MQE_MAX_AGENTS; a++)
+  for (int a = 0; a < AM; a++)
     if (a < A) {
       const int i = e * A + a;
       float* ob = st.obs_bag + (size_t)i * MQE_OBS_BAG;

@@ -605,7 +605,10 @@ static void launch_post(mqe_sim* s, hipStream_t q, int wrapper_level) {
   ProfScope ps(s, PROF_POST, q);
   s->n_post_steps++;                          // = common_step_counter after its increment (legged_robot.py:127)
   const int push = (s->d.push_interval > 0 && s->n_post_steps % s->d.push_interval == 0) ? (int)(s->n_post_steps / s->d.push_interval) : 0;
-  hipLaunchKernelGGL(k_post_physics, dim3((s->N + POST_EPW - 1) / POST_EPW), dim3(64), 0, q, s->dm, s->st, wrapper_level, push);   // incl. history zeroing
+  if (s->hm.A <= 2)
+    hipLaunchKernelGGL(k_post_physics<2>, dim3((s->N + POST_EPW - 1) / POST_EPW), dim3(64), 0, q, s->dm, s->st, wrapper_level, push);
+  else
+    hipLaunchKernelGGL(k_post_physics<MQE_MAX_AGENTS>, dim3((s->N + POST_EPW - 1) / POST_EPW), dim3(64), 0, q, s->dm, s->st, wrapper_level, push);   // incl. history zeroing
 }
 
 extern "C" int mqe_policy_step(mqe_sim* s, const float* command, void* stream) {
