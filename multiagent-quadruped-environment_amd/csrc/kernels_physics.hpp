@@ -417,38 +417,34 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   }
   __syncthreads();
   TSTAMP(5);
-  // ---- rows of M^-1 (18 x 18 per robot), two stages of small independent tasks -------------------------------------------
-  // stage 1: T[d][:] = row d of [S^-1 ; G^T S^-1]  (task = (row, column m): 6 FMAs)
-  for (int t = lane; t < A * MQE_RD * 6; t += 64) {
-    const int d = t / 6, mm = t - d * 6;
+  // ---- rows of M^-1 (18 x 18 per robot): lane = row.  Row k = [ T | (+-) T G_0 | ... | T G_3 (+ M_ll^-1 on its own leg) ] with
+  // T = row k of [S^-1 ; G^T S^-1] (6 values, registers).  One pass of ~150 broadcast-friendly LDS reads and ~110 FMAs per lane
+  // (the earlier form -- (row, column) tasks for T through LDS, then (row, block) tasks -- took 7 passes and 7.4 k cycles).
+  for (int d = lane; d < A * MQE_RD; d += 64) {
     const int r = d / MQE_RD, k = d - r * MQE_RD;
     const float* Si = lds + L.sinv + r * 36;
-    float acc;
-    if (k < 6) acc = Si[k * 6 + mm];
-    else {
-      const int legk = (k - 6) / 3, li = (k - 6) - legk * 3;
-      const float* G = lds + L.leg + (r * 4 + legk) * 54 + 12;
-      acc = 0.0f;
+    const int legk = k < 6 ? -1 : (k - 6) / 3, li = k < 6 ? 0 : (k - 6) - legk * 3;
+    float T[6];
+    if (k < 6) {
 #pragma unroll
-      for (int n = 0; n < 6; n++) acc += G[n * 3 + li] * Si[n * 6 + mm];
-    }
-    lds[L.tt + t] = acc;
-  }
-  __syncthreads();
-  // stage 2: task = (row d, block): block 0 = the 6 base columns, block 1..4 = the 3 columns of one leg
-  for (int t = lane; t < A * MQE_RD * 5; t += 64) {
-    const int d = t / 5, blk = t - d * 5;
-    const int r = d / MQE_RD, k = d - r * MQE_RD;
-    const float* T = lds + L.tt + d * 6;
-    float* row = lds + L.minv + (r * MQE_RD + k) * MQE_RD;
-    if (blk == 0) {
-      const float sg = k < 6 ? 1.0f : -1.0f;
-#pragma unroll
-      for (int mm = 0; mm < 6; mm++) row[mm] = sg * T[mm];
+      for (int mm = 0; mm < 6; mm++) T[mm] = Si[k * 6 + mm];
     } else {
-      const int kk = blk - 1;
+      const float* G = lds + L.leg + (r * 4 + legk) * 54 + 12;
+#pragma unroll
+      for (int mm = 0; mm < 6; mm++) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int n = 0; n < 6; n++) acc += G[n * 3 + li] * Si[n * 6 + mm];
+        T[mm] = acc;
+      }
+    }
+    float* row = lds + L.minv + (r * MQE_RD + k) * MQE_RD;
+    const float sg = k < 6 ? 1.0f : -1.0f;
+#pragma unroll
+    for (int mm = 0; mm < 6; mm++) row[mm] = sg * T[mm];
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
       const float* G = lds + L.leg + (r * 4 + kk) * 54 + 12;
-      const int legk = k < 6 ? -1 : (k - 6) / 3, li = k < 6 ? 0 : (k - 6) - legk * 3;
 #pragma unroll
       for (int i = 0; i < 3; i++) {
         float acc = 0.0f;
