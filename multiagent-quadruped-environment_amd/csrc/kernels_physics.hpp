@@ -198,6 +198,14 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   const int br = is_rbody ? lane / MQE_NBODY : 0;              // robot of this body lane
   const int bb = is_rbody ? lane - br * MQE_NBODY : 0;         // body index in the robot
   const int depth = (is_rbody && bb > 0) ? ((bb - 1) % 3 + 1) : 0;
+  // domain parameters (MQE_T_DOMAIN_PARAMS, global memory) are requested here and consumed after the kinematics / in the
+  // contact solver, so that their latency is off the critical path: added base mass and base CoM shift of this lane's robot --
+  // body 0 only, inertia about the CoM unchanged (legged_robot.py:332-334, legged_robot_field.py:324-334 edit mass and com of
+  // props[0] only) -- and the env's shape friction
+  const float* dp = st.dparams + ((size_t)e * A + br) * 8;
+  const bool dbase = is_rbody && bb == 0;
+  const float dp_mass = dbase ? dp[1] : 0.0f, dp_cx = dbase ? dp[2] : 0.0f, dp_cy = dbase ? dp[3] : 0.0f, dp_cz = dbase ? dp[4] : 0.0f;
+  const float mu_env = st.dparams[(size_t)e * A * 8];
   float Rm[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   V3 bp = v3(0, 0, 0), bw = bp, bvp = bp, bax = bp, bal = bp, bap = bp, bc = bp;
   float Iw[6] = {0, 0, 0, 0, 0, 0};
@@ -257,12 +265,8 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   }
   // world COM / inertia of robot bodies
   if (is_rbody) {
-    // domain parameters of this robot (MQE_T_DOMAIN_PARAMS): added base mass, base CoM shift -- body 0 only, inertia about
-    // the CoM unchanged (legged_robot.py:332-334, legged_robot_field.py:324-334 edit mass and com of props[0] only)
-    const float* dp = st.dparams + ((size_t)e * A + br) * 8;
-    const bool base = bb == 0;
-    bmass = rm.mass[bb] + (base ? dp[1] : 0.0f);
-    bc = bp + mat_vec(Rm, v3(rm.com[bb][0] + (base ? dp[2] : 0.0f), rm.com[bb][1] + (base ? dp[3] : 0.0f), rm.com[bb][2] + (base ? dp[4] : 0.0f)));
+    bmass = rm.mass[bb] + dp_mass;
+    bc = bp + mat_vec(Rm, v3(rm.com[bb][0] + dp_cx, rm.com[bb][1] + dp_cy, rm.com[bb][2] + dp_cz));
     const float* S = rm.inertia[bb];
     float Il[9] = {S[0], S[3], S[4], S[3], S[1], S[5], S[4], S[5], S[2]}, T[9];
     for (int r = 0; r < 3; r++)
@@ -821,7 +825,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   // [lin xyz, (ang xyz)] (ball / sheep).  Column value in the contact frame: dirs . (axis x (p - anchor)) = (r x dirs) . axis.
   // friction of a contact: the shapes of a robot carry the env's (randomised) coefficient, averaged with the other shape's
   // (terrain / objects: m->friction) as PhysX does; contacts without a robot keep m->friction
-  const float mu_robot = 0.5f * (st.dparams[(size_t)e * A * 8] + m->friction);
+  const float mu_robot = 0.5f * (mu_env + m->friction);
   float* Vm = lds + L.rhs;           // v* (unconstrained velocity) over the consumed bias vector, read through the sparse Jacobian rows
   if (lane < ndof) Vm[lane] = vs0;
   if (lane + 64 < ndof) Vm[lane + 64] = vs1;
