@@ -308,12 +308,25 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
 #pragma unroll
   for (int k = 0; k < 16; k++) { float t = __shfl_down(X[k], 1, 64); if (depth == 1) X[k] += t; }
   {
-    const int basel = br * MQE_NBODY;
+    // the four hip composites of a robot -> its base lane, through LDS (4 x 16 B stores per hip lane, 16 x 16 B loads per base
+    // lane, in the joint-force-column area that is written further down): 20 LDS instructions instead of 64 ds_bpermute
+    float* hx = lds + L.fcol;
+    if (depth == 1) {
+      float4* w = reinterpret_cast<float4*>(hx + (br * 4 + (bb - 1) / 3) * 16);
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-      float t = __shfl(X[k], basel + 1, 64) + __shfl(X[k], basel + 4, 64) + __shfl(X[k], basel + 7, 64) + __shfl(X[k], basel + 10, 64);
-      if (is_rbody && bb == 0) X[k] += t;
+      for (int k = 0; k < 4; k++) w[k] = make_float4(X[4 * k], X[4 * k + 1], X[4 * k + 2], X[4 * k + 3]);
     }
+    __syncthreads();
+    if (is_rbody && bb == 0) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const float4* rd = reinterpret_cast<const float4*>(hx + br * 64) + k;
+        const float4 h0 = rd[0], h1 = rd[4], h2 = rd[8], h3 = rd[12];
+        X[4 * k] += h0.x + h1.x + h2.x + h3.x; X[4 * k + 1] += h0.y + h1.y + h2.y + h3.y;
+        X[4 * k + 2] += h0.z + h1.z + h2.z + h3.z; X[4 * k + 3] += h0.w + h1.w + h2.w + h3.w;
+      }
+    }
+    __syncthreads();
   }
   // ---- mass-matrix columns (CRBA in the common frame) and generalized bias ------------------------------------
   // joint lane: S = (w: a, v_o: (p - o) x a);  F = Ic S = (f, n)
