@@ -36,6 +36,15 @@ __device__ __forceinline__ V3 sym_vec(const float* S, V3 v) {
   return v3(S[0] * v.x + S[3] * v.y + S[4] * v.z, S[3] * v.x + S[1] * v.y + S[5] * v.z, S[4] * v.x + S[5] * v.y + S[2] * v.z);
 }
 
+// value of the neighbouring lane through the DPP wave shifts of the VALU (a modifier of v_mov, no LDS crossbar round trip as
+// in ds_bpermute / __shfl): lane i reads lane i + 1 (wave_shl:1) resp. lane i - 1 (wave_shr:1); the end lanes keep their own value
+__device__ __forceinline__ float lane_next(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x130, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float lane_prev(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x138, 0xF, 0xF, false));
+}
+
 // sphere (centre c, radius r) vs box (centre bc, rotation R, half extents h): signed distance, world normal box->sphere
 __device__ __forceinline__ float sphere_box(V3 c, float r, V3 bc, const float* R, V3 h, V3& n) {
   const V3 d = c - bc;
@@ -304,9 +313,9 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     X[10] = no.x; X[11] = no.y; X[12] = no.z; X[13] = f.x; X[14] = f.y; X[15] = f.z;
   }
 #pragma unroll
-  for (int k = 0; k < 16; k++) { float t = __shfl_down(X[k], 1, 64); if (depth == 2) X[k] += t; }
+  for (int k = 0; k < 16; k++) { float t = lane_next(X[k]); if (depth == 2) X[k] += t; }
 #pragma unroll
-  for (int k = 0; k < 16; k++) { float t = __shfl_down(X[k], 1, 64); if (depth == 1) X[k] += t; }
+  for (int k = 0; k < 16; k++) { float t = lane_next(X[k]); if (depth == 1) X[k] += t; }
   {
     // the four hip composites of a robot -> its base lane, through LDS (4 x 16 B stores per hip lane, 16 x 16 B loads per base
     // lane, in the joint-force-column area that is written further down): 20 LDS instructions instead of 64 ds_bpermute
@@ -335,10 +344,10 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   V3 Fn = sym_vec(X + 4, Sa) + cross(v3(X[1], X[2], X[3]), Sv);
   {
     // ancestors' S through shuffles (lane-1: parent joint if depth>=2, lane-2: grandparent if depth==3)
-    V3 Sa1 = v3(__shfl_up(Sa.x, 1, 64), __shfl_up(Sa.y, 1, 64), __shfl_up(Sa.z, 1, 64));
-    V3 Sv1 = v3(__shfl_up(Sv.x, 1, 64), __shfl_up(Sv.y, 1, 64), __shfl_up(Sv.z, 1, 64));
-    V3 Sa2 = v3(__shfl_up(Sa.x, 2, 64), __shfl_up(Sa.y, 2, 64), __shfl_up(Sa.z, 2, 64));
-    V3 Sv2 = v3(__shfl_up(Sv.x, 2, 64), __shfl_up(Sv.y, 2, 64), __shfl_up(Sv.z, 2, 64));
+    V3 Sa1 = v3(lane_prev(Sa.x), lane_prev(Sa.y), lane_prev(Sa.z));
+    V3 Sv1 = v3(lane_prev(Sv.x), lane_prev(Sv.y), lane_prev(Sv.z));
+    V3 Sa2 = v3(lane_prev(Sa1.x), lane_prev(Sa1.y), lane_prev(Sa1.z));
+    V3 Sv2 = v3(lane_prev(Sv1.x), lane_prev(Sv1.y), lane_prev(Sv1.z));
     if (depth >= 1) {
       const int j = bb - 1, leg = j / 3;
       float* Ml = lds + L.leg + (br * 4 + leg) * 54;     // Mll: [hh, tt, cc, ht, hc, tc]
