@@ -251,13 +251,31 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     Rj[6] = t * ax.x * ax.z - s * ax.y; Rj[7] = t * ax.y * ax.z + s * ax.x; Rj[8] = t * ax.z * ax.z + c;
   }
   __syncthreads();
+#pragma unroll
   for (int lev = 1; lev <= 3; lev++) {
+    // the parent of a thigh / calf lane is lane - 1, which computed its frame in the previous level: its registers arrive through
+    // DPP wave shifts (executed by every lane: a DPP read needs an active source lane); hips read the base record from LDS
+    float QR[9];
+    V3 qp, qw, qvp, qal, qap;
+    if (lev >= 2) {
+#pragma unroll
+      for (int k = 0; k < 9; k++) QR[k] = lane_prev(Rm[k]);
+      qp = v3(lane_prev(bp.x), lane_prev(bp.y), lane_prev(bp.z)); qw = v3(lane_prev(bw.x), lane_prev(bw.y), lane_prev(bw.z));
+      qvp = v3(lane_prev(bvp.x), lane_prev(bvp.y), lane_prev(bvp.z)); qal = v3(lane_prev(bal.x), lane_prev(bal.y), lane_prev(bal.z));
+      qap = v3(lane_prev(bap.x), lane_prev(bap.y), lane_prev(bap.z));
+    }
     if (depth == lev) {
-      const int pl = (lev == 1) ? br * MQE_NBODY : lane - 1;
-      const float* pr = lds + L.body + pl * BODY_STRIDE;
       float PR[9];
-      for (int k = 0; k < 9; k++) PR[k] = pr[B_R + k];
-      V3 pp = ld3(pr + B_P), pw = ld3(pr + B_W), pvp = ld3(pr + B_VP), pal = ld3(pr + B_AL), pap = ld3(pr + B_AP);
+      V3 pp, pw, pvp, pal, pap;
+      if (lev == 1) {
+        const float* pr = lds + L.body + br * MQE_NBODY * BODY_STRIDE;
+        for (int k = 0; k < 9; k++) PR[k] = pr[B_R + k];
+        pp = ld3(pr + B_P); pw = ld3(pr + B_W); pvp = ld3(pr + B_VP); pal = ld3(pr + B_AL); pap = ld3(pr + B_AP);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 9; k++) PR[k] = QR[k];
+        pp = qp; pw = qw; pvp = qvp; pal = qal; pap = qap;
+      }
       V3 dd = mat_vec(PR, joff);
       bp = pp + dd;
       for (int r = 0; r < 3; r++)
@@ -270,8 +288,8 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       for (int k = 0; k < 9; k++) myrec[B_R + k] = Rm[k];
       st3(myrec + B_P, bp); st3(myrec + B_W, bw); st3(myrec + B_VP, bvp); st3(myrec + B_A, bax); st3(myrec + B_AL, bal); st3(myrec + B_AP, bap);
     }
-    __syncthreads();
   }
+  __syncthreads();
   // world COM / inertia of robot bodies
   if (is_rbody) {
     bmass = rm.mass[bb] + dp_mass;
