@@ -1245,7 +1245,8 @@ __global__ void __launch_bounds__(64) k_simulate(const DevModel* __restrict__ m,
 // (two past position errors and velocities per joint) lives in registers for the whole launch; torques go straight
 // into the LDS slot the physics reads.  Control type "C" only (the reference's hierarchical controller).
 typedef float f32x16_p __attribute__((ext_vector_type(16)));
-__device__ __forceinline__ float softsign_p(float x) { return x / (1.0f + fabsf(x)); }
+// 1 + |x| >= 1: the hardware reciprocal (1 ulp) needs none of the range scaling a general division carries
+__device__ __forceinline__ float softsign_p(float x) { return x * __builtin_amdgcn_rcpf(1.0f + fabsf(x)); }
 
 #define ACT_TILES 2       // 2 x 32 joints >= 12 * MQE_MAX_AGENTS(=4)... agents <= 4 need 48 joints
 
