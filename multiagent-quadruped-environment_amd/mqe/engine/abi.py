@@ -3,7 +3,7 @@ import ctypes as C
 
 ABI_VERSION = 8
 MAX_SPHERES, NBODY, NREP, NDOF = 32, 13, 17, 12
-MAX_SELF_PAIRS = 384
+MAX_SELF_PAIRS = 320
 MAX_AGENTS, MAX_NPCS, FRAME, HIST, MAX_LAYERS, MAX_REWARD_TERMS = 4, 9, 72, 30, 6, 12
 OBS_BAG = 74
 
