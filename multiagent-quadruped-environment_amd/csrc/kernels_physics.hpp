@@ -366,16 +366,14 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     V3 Sv1 = v3(lane_prev(Sv.x), lane_prev(Sv.y), lane_prev(Sv.z));
     V3 Sa2 = v3(lane_prev(Sa1.x), lane_prev(Sa1.y), lane_prev(Sa1.z));
     V3 Sv2 = v3(lane_prev(Sv1.x), lane_prev(Sv1.y), lane_prev(Sv1.z));
+    // joint lane: own diagonal entry, couplings with the parent (thigh, calf) and the grandparent (calf), bias force
+    float mjj = 0.0f, cpl1 = 0.0f, cpl2 = 0.0f;
     if (depth >= 1) {
-      const int j = bb - 1, leg = j / 3;
-      float* Ml = lds + L.leg + (br * 4 + leg) * 54;     // Mll: [hh, tt, cc, ht, hc, tc]
-      float mjj = dot(Sa, Fn) + dot(Sv, Ff);
-      float hj = dot(Sa, v3(X[10], X[11], X[12])) + dot(Sv, v3(X[13], X[14], X[15]));
-      Ml[depth - 1] = mjj;
-      if (depth == 2) Ml[3] = dot(Sa1, Fn) + dot(Sv1, Ff);
-      if (depth == 3) { Ml[5] = dot(Sa1, Fn) + dot(Sv1, Ff); Ml[4] = dot(Sa2, Fn) + dot(Sv2, Ff); }
-      float* fc = lds + L.fcol + (br * 12 + j) * 6;
-      fc[0] = Ff.x; fc[1] = Ff.y; fc[2] = Ff.z; fc[3] = Fn.x; fc[4] = Fn.y; fc[5] = Fn.z;
+      const int j = bb - 1;
+      mjj = dot(Sa, Fn) + dot(Sv, Ff);
+      const float hj = dot(Sa, v3(X[10], X[11], X[12])) + dot(Sv, v3(X[13], X[14], X[15]));
+      if (depth >= 2) cpl1 = dot(Sa1, Fn) + dot(Sv1, Ff);
+      if (depth == 3) cpl2 = dot(Sa2, Fn) + dot(Sv2, Ff);
       lds[L.rhs + br * MQE_RD + 6 + j] = lds[L.tau + br * 12 + j] - hj;
     } else if (is_rbody) {
       float* bi = lds + L.basei + br * 10;
@@ -383,28 +381,37 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       float* rh = lds + L.rhs + br * MQE_RD;
       rh[0] = -X[13]; rh[1] = -X[14]; rh[2] = -X[15]; rh[3] = -X[10]; rh[4] = -X[11]; rh[5] = -X[12];
     }
+    // ---- leg blocks on the hip lanes: Mi = Mll^-1, G = Mbl Mi (6x3), C = G Mbl^T (6x6 sym).  The thigh's and the calf's
+    // force columns and matrix entries come from lanes + 1 and + 2 through DPP wave shifts (every lane executes the shifts: a DPP
+    // read needs an active source lane) -- no LDS round trip between the CRBA columns and the block inverse.
+    float fc[18], t1v[9], t2v[9];
+    {
+      const float mine[9] = {Ff.x, Ff.y, Ff.z, Fn.x, Fn.y, Fn.z, mjj, cpl1, cpl2};
+#pragma unroll
+      for (int k = 0; k < 9; k++) { t1v[k] = lane_next(mine[k]); t2v[k] = lane_next(t1v[k]); }
+#pragma unroll
+      for (int k = 0; k < 6; k++) { fc[k] = mine[k]; fc[6 + k] = t1v[k]; fc[12 + k] = t2v[k]; }
+    }
+    if (depth == 1) {
+      const int leg = (bb - 1) / 3;
+      float* Ml = lds + L.leg + (br * 4 + leg) * 54;     // [6..11] Mll^-1 (sym6), [12..29] G, [30..50] C (upper triangle)
+      const float a = mjj, b = t1v[6], c = t2v[6], d = t1v[7], ee = t2v[8], f = t2v[7];   // Mll = [[a,d,ee],[d,b,f],[ee,f,c]]
+      float c00 = b * c - f * f, c01 = ee * f - d * c, c02 = d * f - ee * b;
+      float c11 = a * c - ee * ee, c12 = d * ee - a * f, c22 = a * b - d * d;
+      float idet = 1.0f / (a * c00 + d * c01 + ee * c02);
+      float Mi[9] = {c00 * idet, c01 * idet, c02 * idet, c01 * idet, c11 * idet, c12 * idet, c02 * idet, c12 * idet, c22 * idet};
+      float G[18];
+      for (int mm = 0; mm < 6; mm++)
+        for (int i = 0; i < 3; i++) G[mm * 3 + i] = fc[mm] * Mi[i] + fc[6 + mm] * Mi[3 + i] + fc[12 + mm] * Mi[6 + i];
+      Ml[6] = Mi[0]; Ml[7] = Mi[4]; Ml[8] = Mi[8]; Ml[9] = Mi[1]; Ml[10] = Mi[2]; Ml[11] = Mi[5];   // sym6: 00,11,22,01,02,12
+      for (int k = 0; k < 18; k++) Ml[12 + k] = G[k];
+      int q = 0;
+      for (int mm = 0; mm < 6; mm++)
+        for (int n = mm; n < 6; n++) Ml[30 + q++] = G[mm * 3] * fc[n] + G[mm * 3 + 1] * fc[6 + n] + G[mm * 3 + 2] * fc[12 + n];
+    }
   }
   __syncthreads();
   TSTAMP(3);
-  // ---- leg blocks: Mi = Mll^-1, G = Mbl Mi (6x3), C = G Mbl^T (6x6 sym) ----------------------------------------
-  if (lane < A * 4) {
-    float* Ml = lds + L.leg + lane * 54;
-    const float* fc = lds + L.fcol + lane * 18;     // three consecutive joints x 6
-    float a = Ml[0], b = Ml[1], c = Ml[2], d = Ml[3], ee = Ml[4], f = Ml[5];   // [[a,d,ee],[d,b,f],[ee,f,c]]
-    float c00 = b * c - f * f, c01 = ee * f - d * c, c02 = d * f - ee * b;
-    float c11 = a * c - ee * ee, c12 = d * ee - a * f, c22 = a * b - d * d;
-    float idet = 1.0f / (a * c00 + d * c01 + ee * c02);
-    float Mi[9] = {c00 * idet, c01 * idet, c02 * idet, c01 * idet, c11 * idet, c12 * idet, c02 * idet, c12 * idet, c22 * idet};
-    float G[18];
-    for (int mm = 0; mm < 6; mm++)
-      for (int i = 0; i < 3; i++) G[mm * 3 + i] = fc[mm] * Mi[i] + fc[6 + mm] * Mi[3 + i] + fc[12 + mm] * Mi[6 + i];
-    Ml[6] = Mi[0]; Ml[7] = Mi[4]; Ml[8] = Mi[8]; Ml[9] = Mi[1]; Ml[10] = Mi[2]; Ml[11] = Mi[5];   // sym6: 00,11,22,01,02,12
-    for (int k = 0; k < 18; k++) Ml[12 + k] = G[k];
-    int q = 0;
-    for (int mm = 0; mm < 6; mm++)
-      for (int n = mm; n < 6; n++) Ml[30 + q++] = G[mm * 3] * fc[n] + G[mm * 3 + 1] * fc[6 + n] + G[mm * 3 + 2] * fc[12 + n];
-  }
-  __syncthreads();
   TSTAMP(4);
   // ---- 6x6 Schur complement inverse: lane (robot, column) --------------------------------------------------------
   if (lane < A * 6) {
