@@ -99,7 +99,15 @@ __device__ __forceinline__ float wave_sum(float x) {
 #define BODY_STRIDE 32
 #define CON_STRIDE 32
 #define JS_STRIDE 36                // per contact side: 9 columns x (j_n, j_t1, j_t2, local dof index)
-enum { B_R = 0, B_P = 9, B_W = 12, B_VP = 15, B_A = 18, B_AL = 21, B_AP = 24, B_C = 27, B_M = 30 };
+// link record: rotation (9), origin (3), joint axis (3) = four 16 B words, what the collision and Jacobian phases read back; the
+// base records also carry angular velocity, origin velocity and the two bias accelerations for their hips (the other links
+// hand those to their children through registers)
+enum { B_R = 0, B_P = 9, B_A = 12, B_W = 16, B_VP = 19, B_AL = 22, B_AP = 25 };
+__device__ __forceinline__ void body_store(float* rec, const float* R, V3 p, V3 a) {
+  float4* r4 = reinterpret_cast<float4*>(rec);
+  r4[0] = make_float4(R[0], R[1], R[2], R[3]); r4[1] = make_float4(R[4], R[5], R[6], R[7]);
+  r4[2] = make_float4(R[8], p.x, p.y, p.z); r4[3] = make_float4(a.x, a.y, a.z, 0.0f);
+}
 enum { C_IDS = 0, C_P = 4, C_N = 7, C_T1 = 10, C_T2 = 13, C_SD = 16, C_BIAS = 17, C_K = 18, C_LAM = 24, C_REP = 27 };
 
 __host__ __device__ inline int mqe_maxc(int A, int P, int cap_npc) { int v = 8 * A + cap_npc * P; return v > 40 ? 40 : v; }
@@ -129,6 +137,7 @@ __host__ __device__ inline PhysLds phys_lds_layout(int A, int P, int ND, int nbo
   const int nslot = maxc + mqe_maxpair(maxc);
   L.B = o; o += nslot * 54;             // per contact side: 3 rows x 18 local dofs of M^-1 J^T
   L.js = o; o += nslot * JS_STRIDE;
+  o = (o + 3) & ~3;                                         // the link records are accessed as 16 B words
   const int arena = o;
   L.body = o; o += nbody * BODY_STRIDE;
   o = (o + 3) & ~3;                                         // the sphere records are read as float4
@@ -231,8 +240,8 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     Rm[3] = 2 * (x * y + z * w); Rm[4] = 1 - 2 * (x * x + z * z); Rm[5] = 2 * (y * z - x * w);
     Rm[6] = 2 * (x * z - y * w); Rm[7] = 2 * (y * z + x * w); Rm[8] = 1 - 2 * (x * x + y * y);
     bp = ld3(rs); bvp = ld3(rs + 7); bw = ld3(rs + 10);
-    for (int k = 0; k < 9; k++) myrec[B_R + k] = Rm[k];
-    st3(myrec + B_P, bp); st3(myrec + B_W, bw); st3(myrec + B_VP, bvp); st3(myrec + B_A, bax); st3(myrec + B_AL, bal); st3(myrec + B_AP, bap);
+    body_store(myrec, Rm, bp, bax);
+    st3(myrec + B_W, bw); st3(myrec + B_VP, bvp); st3(myrec + B_AL, bal); st3(myrec + B_AP, bap);
   }
   // joint-local quantities do not depend on the parent: computed once for all joint lanes, outside the level loop
   // (whose divergent body would otherwise run the sin/cos code three times)
@@ -285,8 +294,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       bvp = pvp + cross(pw, dd);
       bal = pal + cross(pw, qdj * bax);
       bap = pap + cross(pal, dd) + cross(pw, cross(pw, dd));
-      for (int k = 0; k < 9; k++) myrec[B_R + k] = Rm[k];
-      st3(myrec + B_P, bp); st3(myrec + B_W, bw); st3(myrec + B_VP, bvp); st3(myrec + B_A, bax); st3(myrec + B_AL, bal); st3(myrec + B_AP, bap);
+      body_store(myrec, Rm, bp, bax);
     }
   }
   __syncthreads();
@@ -305,8 +313,6 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     Iw[3] = T[0] * Rm[3] + T[1] * Rm[4] + T[2] * Rm[5];
     Iw[4] = T[0] * Rm[6] + T[1] * Rm[7] + T[2] * Rm[8];
     Iw[5] = T[3] * Rm[6] + T[4] * Rm[7] + T[5] * Rm[8];
-    st3(myrec + B_C, bc);
-    myrec[B_M] = bmass;
   }
 
   TSTAMP(2);
@@ -543,7 +549,9 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     if (s < A * nsr) {
       const int r = s / nsr, si = s - r * nsr;
       const float* rec = lds + L.body + (r * MQE_NBODY + rm.sphere_body[si]) * BODY_STRIDE;
-      c = ld3(rec + B_P) + mat_vec(rec + B_R, v3(rm.sphere_center[si][0], rm.sphere_center[si][1], rm.sphere_center[si][2]));
+      const float4 q0 = reinterpret_cast<const float4*>(rec)[0], q1 = reinterpret_cast<const float4*>(rec)[1], q2 = reinterpret_cast<const float4*>(rec)[2];
+      const float Rr[9] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x};
+      c = v3(q2.y, q2.z, q2.w) + mat_vec(Rr, v3(rm.sphere_center[si][0], rm.sphere_center[si][1], rm.sphere_center[si][2]));
       rad = rm.sphere_radius[si];
     } else {
       const int q = s - A * nsr, p = q / m->npc_n_spheres, si = q - p * m->npc_n_spheres;
@@ -917,7 +925,8 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
 #pragma unroll
         for (int t = 0; t < 3; t++) {
           const float* jrec = brec + (1 + leg * 3 + t) * BODY_STRIDE;
-          const V3 ax = ld3(jrec + B_A), rr = p - ld3(jrec + B_P);
+          const float4 jq2 = reinterpret_cast<const float4*>(jrec)[2], jq3 = reinterpret_cast<const float4*>(jrec)[3];
+          const V3 ax = v3(jq3.x, jq3.y, jq3.z), rr = p - v3(jq2.y, jq2.z, jq2.w);
           const float on = t < dep ? sg : 0.0f;
           J[6 + t][0] = on * dot(cross(rr, n), ax); J[6 + t][1] = on * dot(cross(rr, t1), ax); J[6 + t][2] = on * dot(cross(rr, t2), ax);
         }
