@@ -560,7 +560,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       rad = m->npc_sphere_radius[si];
     }
     float* sp = lds + L.sph + s * 4;
-    sp[0] = c.x; sp[1] = c.y; sp[2] = c.z; sp[3] = rad;
+    *reinterpret_cast<float4*>(sp) = make_float4(c.x, c.y, c.z, rad);
   }
   __syncthreads();
 
@@ -611,7 +611,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     int body = 0, rep = 0;
     if (act >= 0) {
       const float* sp = lds + L.sph + s * 4;
-      c = ld3(sp); rad = sp[3];
+      { const float4 q = *reinterpret_cast<const float4*>(sp); c = v3(q.x, q.y, q.z); rad = q.w; }
       if (act < A) { body = rm.sphere_body[sidx]; rep = act * MQE_NREP + rm.sphere_reported[sidx]; }
       else { body = 0; rep = A * MQE_NREP + (act - A); }
       gsd = c.z - m->ground_z - rad;
@@ -727,7 +727,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       bool hit = false; float sd = 0; V3 n = v3(0, 0, 1), c = v3(0, 0, 0); float rad = 0; int body = 0, rep = 0;
       if (lane < nsr) {
         const float* sp = lds + L.sph + s * 4;
-        c = ld3(sp); rad = sp[3];
+        { const float4 q = *reinterpret_cast<const float4*>(sp); c = v3(q.x, q.y, q.z); rad = q.w; }
         body = rm.sphere_body[lane]; rep = a * MQE_NREP + rm.sphere_reported[lane];
         sd = m->ss_link_cyl ? sphere_vcyl(c, rad, ssC, m->ss_plank_half[0], m->ss_plank_half[2], n)
                             : sphere_box(c, rad, ssC, ssR, v3(m->ss_plank_half[0], m->ss_plank_half[1], m->ss_plank_half[2]), n);
@@ -764,7 +764,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
           bool hit = false; float sd = 0; V3 n = v3(0, 0, 1), c = v3(0, 0, 0); float ra = 0;
           if (lane < nsr) {
             const float* spa = lds + L.sph + (a * nsr + lane) * 4;
-            c = ld3(spa); ra = spa[3];
+            { const float4 q = *reinterpret_cast<const float4*>(spa); c = v3(q.x, q.y, q.z); ra = q.w; }
             sd = sphere_box(c, ra, pb, brec + B_R, v3(m->npc_box_half[0], m->npc_box_half[1], m->npc_box_half[2]), n);
             hit = sd < m->contact_offset;
           }
@@ -788,11 +788,12 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
         const int ob = b < A ? b * nsr : A * nsr + (b - A) * m->npc_n_spheres;
         for (int sb = 0; sb < nb; sb++) {
           const float* spb = lds + L.sph + (ob + sb) * 4;
-          const V3 cb = ld3(spb); const float rb = spb[3];
+          const float4 qb = *reinterpret_cast<const float4*>(spb);
+          const V3 cb = v3(qb.x, qb.y, qb.z); const float rb = qb.w;
           bool hit = false; float sd = 0, dist = 1; V3 ev = v3(0, 0, 0); float ra = 0;
           if (lane < na) {
             const float* spa = lds + L.sph + (oa + lane) * 4;
-            ev = ld3(spa) - cb; ra = spa[3];
+            { const float4 q = *reinterpret_cast<const float4*>(spa); ev = v3(q.x, q.y, q.z) - cb; ra = q.w; }
             dist = sqrtf(dot(ev, ev));
             sd = dist - ra - rb;
             hit = sd < m->contact_offset && dist > 1e-9f;
