@@ -108,7 +108,16 @@ __device__ __forceinline__ void body_store(float* rec, const float* R, V3 p, V3 
   r4[0] = make_float4(R[0], R[1], R[2], R[3]); r4[1] = make_float4(R[4], R[5], R[6], R[7]);
   r4[2] = make_float4(R[8], p.x, p.y, p.z); r4[3] = make_float4(a.x, a.y, a.z, 0.0f);
 }
-enum { C_IDS = 0, C_P = 4, C_N = 7, C_T1 = 10, C_T2 = 13, C_SD = 16, C_BIAS = 17, C_K = 18, C_LAM = 24, C_REP = 27 };
+// contact record in 16 B words: [actor A, link A, actor B (-1: static), link B] [point, separation] [normal, reported body A]
+// [tangent 1, -] [tangent 2, -] [impulse, reported body B]
+enum { C_IDS = 0, C_P = 4, C_SD = 7, C_N = 8, C_REPA = 11, C_T1 = 12, C_T2 = 16, C_LAM = 20, C_REPB = 23 };
+__device__ __forceinline__ void con_store(float* cr, int a, int linkA, int b, int linkB, V3 p, V3 n, float sd, int repA, int repB) {
+  float4* c4 = reinterpret_cast<float4*>(cr);
+  c4[0] = make_float4(__int_as_float(a), __int_as_float(linkA), __int_as_float(b), __int_as_float(linkB));
+  c4[1] = make_float4(p.x, p.y, p.z, sd);
+  c4[2] = make_float4(n.x, n.y, n.z, __int_as_float(repA));
+  c4[5] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(repB));
+}
 
 __host__ __device__ inline int mqe_maxc(int A, int P, int cap_npc) { int v = 8 * A + cap_npc * P; return v > 40 ? 40 : v; }
 #define CAP_ROBOT 8     // terrain / static-object contacts kept per robot (spheres are priority ordered: feet first)
@@ -684,20 +693,14 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       const int slot = base + pre;
       if (slot < maxc && pre < cap) {
         float* cr = lds + L.con + slot * CON_STRIDE;
-        cr[C_IDS] = __int_as_float(act); cr[C_IDS + 1] = __int_as_float(body); cr[C_IDS + 2] = __int_as_float(-1); cr[C_IDS + 3] = __int_as_float(0);
-        cr[C_P] = c.x; cr[C_P + 1] = c.y; cr[C_P + 2] = c.z - rad;
-        cr[C_N] = 0; cr[C_N + 1] = 0; cr[C_N + 2] = 1; cr[C_SD] = gsd;
-        cr[C_REP] = __int_as_float(rep); cr[C_REP + 1] = __int_as_float(-1);
+        con_store(cr, act, body, -1, 0, v3(c.x, c.y, c.z - rad), v3(0, 0, 1), gsd, rep, -1);
       }
     }
     if (wflag) {
       const int rk = pre + (gflag ? 1 : 0), slot = base + rk;
       if (slot < maxc && rk < cap) {
         float* cr = lds + L.con + slot * CON_STRIDE;
-        cr[C_IDS] = __int_as_float(act); cr[C_IDS + 1] = __int_as_float(body); cr[C_IDS + 2] = __int_as_float(-1); cr[C_IDS + 3] = __int_as_float(0);
-        cr[C_P] = c.x - rad * wn.x; cr[C_P + 1] = c.y - rad * wn.y; cr[C_P + 2] = c.z - rad * wn.z;
-        cr[C_N] = wn.x; cr[C_N + 1] = wn.y; cr[C_N + 2] = wn.z; cr[C_SD] = wsd;
-        cr[C_REP] = __int_as_float(rep); cr[C_REP + 1] = __int_as_float(-1);
+        con_store(cr, act, body, -1, 0, c - rad * wn, wn, wsd, rep, -1);
       }
     }
     if (bflag || cflag) {
@@ -707,10 +710,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
         if (slot < maxc && rk < cap) {
           const V3 nn = which == 0 ? bn : cn3;
           float* cr = lds + L.con + slot * CON_STRIDE;
-          cr[C_IDS] = __int_as_float(act); cr[C_IDS + 1] = __int_as_float(body); cr[C_IDS + 2] = __int_as_float(-1); cr[C_IDS + 3] = __int_as_float(0);
-          cr[C_P] = c.x - rad * nn.x; cr[C_P + 1] = c.y - rad * nn.y; cr[C_P + 2] = c.z - rad * nn.z;
-          cr[C_N] = nn.x; cr[C_N + 1] = nn.y; cr[C_N + 2] = nn.z; cr[C_SD] = which == 0 ? bsd : csd;
-          cr[C_REP] = __int_as_float(rep); cr[C_REP + 1] = __int_as_float(-1);
+          con_store(cr, act, body, -1, 0, c - rad * nn, nn, which == 0 ? bsd : csd, rep, -1);
         }
       }
     }
@@ -738,10 +738,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       const int rk = __popcll(bh & lower), slot = nc + rk;
       if (hit && rk < capP && slot < pair_lim) {
         float* cr = lds + L.con + slot * CON_STRIDE;
-        cr[C_IDS] = __int_as_float(a); cr[C_IDS + 1] = __int_as_float(body); cr[C_IDS + 2] = __int_as_float(A); cr[C_IDS + 3] = __int_as_float(0);
-        cr[C_P] = c.x - rad * n.x; cr[C_P + 1] = c.y - rad * n.y; cr[C_P + 2] = c.z - rad * n.z;
-        cr[C_N] = n.x; cr[C_N + 1] = n.y; cr[C_N + 2] = n.z; cr[C_SD] = sd;
-        cr[C_REP] = __int_as_float(rep); cr[C_REP + 1] = __int_as_float(A * MQE_NREP + 1);
+        con_store(cr, a, body, A, 0, c - rad * n, n, sd, rep, A * MQE_NREP + 1);
       }
       int tot = __popcll(bh);
       if (tot > capP) tot = capP;
@@ -773,10 +770,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
           const int slot = nc + __popcll(bh & lower);
           if (hit && slot < pair_lim) {
             float* cr = lds + L.con + slot * CON_STRIDE;
-            cr[C_IDS] = __int_as_float(a); cr[C_IDS + 1] = __int_as_float(rm.sphere_body[lane]); cr[C_IDS + 2] = __int_as_float(b); cr[C_IDS + 3] = __int_as_float(0);
-            const V3 p = c - (ra + 0.5f * sd) * n;
-            cr[C_P] = p.x; cr[C_P + 1] = p.y; cr[C_P + 2] = p.z; cr[C_N] = n.x; cr[C_N + 1] = n.y; cr[C_N + 2] = n.z; cr[C_SD] = sd;
-            cr[C_REP] = __int_as_float(a * MQE_NREP + rm.sphere_reported[lane]); cr[C_REP + 1] = __int_as_float(A * MQE_NREP + (b - A));
+            con_store(cr, a, rm.sphere_body[lane], b, 0, c - (ra + 0.5f * sd) * n, n, sd, a * MQE_NREP + rm.sphere_reported[lane], A * MQE_NREP + (b - A));
           }
           nc += __popcll(bh);
           if (nc > pair_lim) nc = pair_lim;
@@ -807,11 +801,8 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
             const int bodyA = a < A ? rm.sphere_body[lane] : 0, bodyB = b < A ? rm.sphere_body[sb] : 0;
             const int repA = a < A ? a * MQE_NREP + rm.sphere_reported[lane] : A * MQE_NREP + (a - A);
             const int repB = b < A ? b * MQE_NREP + rm.sphere_reported[sb] : A * MQE_NREP + (b - A);
-            cr[C_IDS] = __int_as_float(a); cr[C_IDS + 1] = __int_as_float(bodyA); cr[C_IDS + 2] = __int_as_float(b); cr[C_IDS + 3] = __int_as_float(bodyB);
             const V3 n = (1.0f / dist) * ev;
-            const V3 p = cb + (rb + 0.5f * sd) * n;
-            cr[C_P] = p.x; cr[C_P + 1] = p.y; cr[C_P + 2] = p.z; cr[C_N] = n.x; cr[C_N + 1] = n.y; cr[C_N + 2] = n.z; cr[C_SD] = sd;
-            cr[C_REP] = __int_as_float(repA); cr[C_REP + 1] = __int_as_float(repB);
+            con_store(cr, a, bodyA, b, bodyB, cb + (rb + 0.5f * sd) * n, n, sd, repA, repB);
           }
           nc += __popcll(bh);
           if (nc > pair_lim) nc = pair_lim;
@@ -861,11 +852,9 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
           const int slot = nc + __popcll(bh & lower);
           if (hit && slot < pair_lim) {
             float* cr = lds + L.con + slot * CON_STRIDE;
-            cr[C_IDS] = __int_as_float(a); cr[C_IDS + 1] = __int_as_float(rm.sphere_body[si]); cr[C_IDS + 2] = __int_as_float(a); cr[C_IDS + 3] = __int_as_float(rm.sphere_body[sj]);
             const V3 n = (1.0f / dist) * ev;
-            const V3 p = cj + (rj + 0.5f * sd) * n;
-            cr[C_P] = p.x; cr[C_P + 1] = p.y; cr[C_P + 2] = p.z; cr[C_N] = n.x; cr[C_N + 1] = n.y; cr[C_N + 2] = n.z; cr[C_SD] = sd;
-            cr[C_REP] = __int_as_float(a * MQE_NREP + rm.sphere_reported[si]); cr[C_REP + 1] = __int_as_float(a * MQE_NREP + rm.sphere_reported[sj]);
+            con_store(cr, a, rm.sphere_body[si], a, rm.sphere_body[sj], cj + (rj + 0.5f * sd) * n, n, sd, a * MQE_NREP + rm.sphere_reported[si],
+                      a * MQE_NREP + rm.sphere_reported[sj]);
           }
           nc += __popcll(bh);
           if (nc > pair_lim) nc = pair_lim;
@@ -893,16 +882,18 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   float mu = m->friction;
   if (is_con) {
     float* cr = lds + L.con + lane * CON_STRIDE;
-    myA = __float_as_int(cr[C_IDS]); myB = __float_as_int(cr[C_IDS + 2]);
+    const float4 w0 = reinterpret_cast<const float4*>(cr)[0], w1 = reinterpret_cast<const float4*>(cr)[1], w2 = reinterpret_cast<const float4*>(cr)[2];
+    myA = __float_as_int(w0.x); myB = __float_as_int(w0.z);
     if (myA < A || (myB >= 0 && myB < A)) mu = mu_robot;
-    const int bodyA = __float_as_int(cr[C_IDS + 1]), bodyB = __float_as_int(cr[C_IDS + 3]);
-    const V3 p = ld3(cr + C_P), n = ld3(cr + C_N);
+    const int bodyA = __float_as_int(w0.y), bodyB = __float_as_int(w0.w);
+    const V3 p = v3(w1.x, w1.y, w1.z), n = v3(w2.x, w2.y, w2.z);
     const V3 aa = fabsf(n.z) > 0.7f ? v3(1, 0, 0) : v3(0, 0, 1);
     V3 t1 = cross(aa, n);
     t1 = (1.0f / sqrtf(dot(t1, t1))) * t1;
     const V3 t2 = cross(n, t1);
-    st3(cr + C_T1, t1); st3(cr + C_T2, t2);
-    const float sd = cr[C_SD];
+    reinterpret_cast<float4*>(cr)[3] = make_float4(t1.x, t1.y, t1.z, 0.0f);
+    reinterpret_cast<float4*>(cr)[4] = make_float4(t2.x, t2.y, t2.z, 0.0f);
+    const float sd = w1.w;
     cbias = sd >= 0 ? -sd / dt : fminf(-sd * m->erp / dt, m->max_depen);
     for (int side = 0; side < 2; side++) {
       const int act = side == 0 ? myA : myB, body = side == 0 ? bodyA : bodyB;
@@ -1201,7 +1192,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       V3 F = v3(0, 0, 0);
       for (int c = 0; c < nc; c++) {
         const float* cr = lds + L.con + c * CON_STRIDE;
-        const int ra = __float_as_int(cr[C_REP]), rb2 = __float_as_int(cr[C_REP + 1]);
+        const int ra = __float_as_int(cr[C_REPA]), rb2 = __float_as_int(cr[C_REPB]);
         if (ra == rb || rb2 == rb) {
           const V3 f = idt * (cr[C_LAM] * ld3(cr + C_N) + cr[C_LAM + 1] * ld3(cr + C_T1) + cr[C_LAM + 2] * ld3(cr + C_T2));
           F = (ra == rb) ? F + f : F - f;
