@@ -97,6 +97,11 @@ __device__ __forceinline__ float wave_sum(float x) {
 }
 
 #define BODY_STRIDE 32
+// leg block record in 16 B words: Mll^-1 (sym6) at 0, G = Mbl Mll^-1 (6 x 3) at 8, C = G Mbl^T (upper triangle, 21) at 28
+#define LEG_STRIDE 52
+#define LEG_MI 0
+#define LEG_G 8
+#define LEG_C 28
 #define CON_STRIDE 32
 #define JS_STRIDE 36                // per contact side: 9 columns x (j_n, j_t1, j_t2, local dof index)
 // link record: rotation (9), origin (3), joint axis (3) = four 16 B words, what the collision and Jacobian phases read back; the
@@ -152,7 +157,7 @@ __host__ __device__ inline PhysLds phys_lds_layout(int A, int P, int ND, int nbo
   o = (o + 3) & ~3;                                         // the sphere records are read as float4
   const int scratch = o;
   L.tt = o; L.fcol = o; o += A * MQE_RD * 6;               // fcol (A*72) is consumed before tt is written
-  L.leg = o; o += A * 4 * 54;
+  L.leg = o; o += A * 4 * LEG_STRIDE;
   L.basei = o; o += A * 10;
   L.sinv = o; o += A * 36;
   L.sph = scratch;
@@ -409,7 +414,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     }
     if (depth == 1) {
       const int leg = (bb - 1) / 3;
-      float* Ml = lds + L.leg + (br * 4 + leg) * 54;     // [6..11] Mll^-1 (sym6), [12..29] G, [30..50] C (upper triangle)
+      float* Ml = lds + L.leg + (br * 4 + leg) * LEG_STRIDE;
       const float a = mjj, b = t1v[6], c = t2v[6], d = t1v[7], ee = t2v[8], f = t2v[7];   // Mll = [[a,d,ee],[d,b,f],[ee,f,c]]
       float c00 = b * c - f * f, c01 = ee * f - d * c, c02 = d * f - ee * b;
       float c11 = a * c - ee * ee, c12 = d * ee - a * f, c22 = a * b - d * d;
@@ -418,11 +423,18 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       float G[18];
       for (int mm = 0; mm < 6; mm++)
         for (int i = 0; i < 3; i++) G[mm * 3 + i] = fc[mm] * Mi[i] + fc[6 + mm] * Mi[3 + i] + fc[12 + mm] * Mi[6 + i];
-      Ml[6] = Mi[0]; Ml[7] = Mi[4]; Ml[8] = Mi[8]; Ml[9] = Mi[1]; Ml[10] = Mi[2]; Ml[11] = Mi[5];   // sym6: 00,11,22,01,02,12
-      for (int k = 0; k < 18; k++) Ml[12 + k] = G[k];
+      float Cv[24];
       int q = 0;
       for (int mm = 0; mm < 6; mm++)
-        for (int n = mm; n < 6; n++) Ml[30 + q++] = G[mm * 3] * fc[n] + G[mm * 3 + 1] * fc[6 + n] + G[mm * 3 + 2] * fc[12 + n];
+        for (int n = mm; n < 6; n++) Cv[q++] = G[mm * 3] * fc[n] + G[mm * 3 + 1] * fc[6 + n] + G[mm * 3 + 2] * fc[12 + n];
+      Cv[21] = 0.0f; Cv[22] = 0.0f; Cv[23] = 0.0f;
+      float4* M4 = reinterpret_cast<float4*>(Ml);
+      M4[0] = make_float4(Mi[0], Mi[4], Mi[8], Mi[1]); M4[1] = make_float4(Mi[2], Mi[5], 0.0f, 0.0f);   // sym6: 00,11,22,01,02,12
+#pragma unroll
+      for (int k = 0; k < 4; k++) M4[2 + k] = make_float4(G[4 * k], G[4 * k + 1], G[4 * k + 2], G[4 * k + 3]);
+      M4[6] = make_float4(G[16], G[17], 0.0f, 0.0f);
+#pragma unroll
+      for (int k = 0; k < 6; k++) M4[7 + k] = make_float4(Cv[4 * k], Cv[4 * k + 1], Cv[4 * k + 2], Cv[4 * k + 3]);
     }
   }
   __syncthreads();
@@ -440,7 +452,10 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     S[0][4] = hz; S[0][5] = -hy; S[1][3] = -hz; S[1][5] = hx; S[2][3] = hy; S[2][4] = -hx;
     S[3][3] = bi[4]; S[4][4] = bi[5]; S[5][5] = bi[6]; S[3][4] = bi[7]; S[3][5] = bi[8]; S[4][5] = bi[9];
     for (int k = 0; k < 4; k++) {
-      const float* Cc = lds + L.leg + (r * 4 + k) * 54 + 30;
+      const float4* C4 = reinterpret_cast<const float4*>(lds + L.leg + (r * 4 + k) * LEG_STRIDE + LEG_C);
+      float Cc[24];
+#pragma unroll
+      for (int w = 0; w < 6; w++) { const float4 t = C4[w]; Cc[4 * w] = t.x; Cc[4 * w + 1] = t.y; Cc[4 * w + 2] = t.z; Cc[4 * w + 3] = t.w; }
       int q = 0;
       for (int i = 0; i < 6; i++) for (int j = i; j < 6; j++) S[i][j] -= Cc[q++];
     }
@@ -495,7 +510,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
 #pragma unroll
       for (int mm = 0; mm < 6; mm++) T[mm] = Si[k * 6 + mm];
     } else {
-      const float* G = lds + L.leg + (r * 4 + legk) * 54 + 12;
+      const float* G = lds + L.leg + (r * 4 + legk) * LEG_STRIDE + LEG_G;
 #pragma unroll
       for (int mm = 0; mm < 6; mm++) {
         float acc = 0.0f;
@@ -510,7 +525,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     for (int mm = 0; mm < 6; mm++) row[mm] = sg * T[mm];
 #pragma unroll
     for (int kk = 0; kk < 4; kk++) {
-      const float* G = lds + L.leg + (r * 4 + kk) * 54 + 12;
+      const float* G = lds + L.leg + (r * 4 + kk) * LEG_STRIDE + LEG_G;
 #pragma unroll
       for (int i = 0; i < 3; i++) {
         float acc = 0.0f;
@@ -518,7 +533,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
         for (int mm = 0; mm < 6; mm++) acc += T[mm] * G[mm * 3 + i];
         if (k < 6) acc = -acc;
         else if (kk == legk) {
-          const float* Mi = lds + L.leg + (r * 4 + kk) * 54 + 6;   // sym6 00,11,22,01,02,12
+          const float* Mi = lds + L.leg + (r * 4 + kk) * LEG_STRIDE + LEG_MI;   // sym6 00,11,22,01,02,12
           const int a2 = li < i ? li : i, b2 = li < i ? i : li;
           acc += (a2 == b2) ? Mi[a2] : (a2 == 0 ? (b2 == 1 ? Mi[3] : Mi[4]) : Mi[5]);
         }
