@@ -150,6 +150,7 @@ __host__ __device__ inline PhysLds phys_lds_layout(int A, int P, int ND, int nbo
   L.con = o; o += maxc * CON_STRIDE;
   const int nslot = maxc + mqe_maxpair(maxc);
   L.B = o; o += nslot * 54;             // per contact side: 3 rows x 18 local dofs of M^-1 J^T
+  o = (o + 3) & ~3;                     // the Jacobian rows are 16 B words
   L.js = o; o += nslot * JS_STRIDE;
   o = (o + 3) & ~3;                                         // the link records are accessed as 16 B words
   const int arena = o;
@@ -525,7 +526,12 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     for (int mm = 0; mm < 6; mm++) row[mm] = sg * T[mm];
 #pragma unroll
     for (int kk = 0; kk < 4; kk++) {
-      const float* G = lds + L.leg + (r * 4 + kk) * LEG_STRIDE + LEG_G;
+      float G[20];                                   // the leg's G block: five 16 B loads
+      {
+        const float4* G4 = reinterpret_cast<const float4*>(lds + L.leg + (r * 4 + kk) * LEG_STRIDE + LEG_G);
+#pragma unroll
+        for (int w = 0; w < 5; w++) { const float4 t = G4[w]; G[4 * w] = t.x; G[4 * w + 1] = t.y; G[4 * w + 2] = t.z; G[4 * w + 3] = t.w; }
+      }
 #pragma unroll
       for (int i = 0; i < 3; i++) {
         float acc = 0.0f;
@@ -940,7 +946,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
 #pragma unroll
         for (int i = 0; i < 9; i++) {
           const int li = i < 6 ? i : 6 + leg * 3 + (i - 6);
-          js[i * 4] = J[i][0]; js[i * 4 + 1] = J[i][1]; js[i * 4 + 2] = J[i][2]; js[i * 4 + 3] = __int_as_float(li);
+          reinterpret_cast<float4*>(js)[i] = make_float4(J[i][0], J[i][1], J[i][2], __int_as_float(li));
           const float vv = Vm[act * MQE_RD + li];
           cu0 += J[i][0] * vv; cu1 += J[i][1] * vv; cu2 += J[i][2] * vv;
         }
@@ -952,7 +958,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
 #pragma unroll
         for (int i = 0; i < 9; i++) {
           const bool on = i == 0;
-          js[i * 4] = on ? j0 : 0.0f; js[i * 4 + 1] = on ? j1 : 0.0f; js[i * 4 + 2] = on ? j2 : 0.0f; js[i * 4 + 3] = __int_as_float(0);
+          reinterpret_cast<float4*>(js)[i] = make_float4(on ? j0 : 0.0f, on ? j1 : 0.0f, on ? j2 : 0.0f, __int_as_float(0));
         }
         const float vv = Vm[A * MQE_RD];
         cu0 += j0 * vv; cu1 += j1 * vv; cu2 += j2 * vv;
@@ -968,7 +974,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
         for (int i = 0; i < 9; i++) {
           const bool on = i < npcdof;
           const float j0 = on ? J[i < 6 ? i : 0][0] : 0.0f, j1 = on ? J[i < 6 ? i : 0][1] : 0.0f, j2 = on ? J[i < 6 ? i : 0][2] : 0.0f;
-          js[i * 4] = j0; js[i * 4 + 1] = j1; js[i * 4 + 2] = j2; js[i * 4 + 3] = __int_as_float(on ? i : 0);
+          reinterpret_cast<float4*>(js)[i] = make_float4(j0, j1, j2, __int_as_float(on ? i : 0));
           if (on) {
             const float vv = Vm[A * MQE_RD + pi * npcdof + i];
             cu0 += j0 * vv; cu1 += j1 * vv; cu2 += j2 * vv;
