@@ -256,7 +256,9 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     Rm[6] = 2 * (x * z - y * w); Rm[7] = 2 * (y * z + x * w); Rm[8] = 1 - 2 * (x * x + y * y);
     bp = ld3(rs); bvp = ld3(rs + 7); bw = ld3(rs + 10);
     body_store(myrec, Rm, bp, bax);
-    st3(myrec + B_W, bw); st3(myrec + B_VP, bvp); st3(myrec + B_AL, bal); st3(myrec + B_AP, bap);
+    reinterpret_cast<float4*>(myrec)[4] = make_float4(bw.x, bw.y, bw.z, bvp.x);
+    reinterpret_cast<float4*>(myrec)[5] = make_float4(bvp.y, bvp.z, bal.x, bal.y);
+    reinterpret_cast<float4*>(myrec)[6] = make_float4(bal.z, bap.x, bap.y, bap.z);
   }
   // joint-local quantities do not depend on the parent: computed once for all joint lanes, outside the level loop
   // (whose divergent body would otherwise run the sin/cos code three times)
@@ -293,8 +295,10 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       V3 pp, pw, pvp, pal, pap;
       if (lev == 1) {
         const float* pr = lds + L.body + br * MQE_NBODY * BODY_STRIDE;
-        for (int k = 0; k < 9; k++) PR[k] = pr[B_R + k];
-        pp = ld3(pr + B_P); pw = ld3(pr + B_W); pvp = ld3(pr + B_VP); pal = ld3(pr + B_AL); pap = ld3(pr + B_AP);
+        const float4* p4 = reinterpret_cast<const float4*>(pr);
+        const float4 b0 = p4[0], b1 = p4[1], b2 = p4[2], b4 = p4[4], b5 = p4[5], b6 = p4[6];     // words 0-2: R, origin; 4-6: w, vp, al, ap
+        PR[0] = b0.x; PR[1] = b0.y; PR[2] = b0.z; PR[3] = b0.w; PR[4] = b1.x; PR[5] = b1.y; PR[6] = b1.z; PR[7] = b1.w; PR[8] = b2.x;
+        pp = v3(b2.y, b2.z, b2.w); pw = v3(b4.x, b4.y, b4.z); pvp = v3(b4.w, b5.x, b5.y); pal = v3(b5.z, b5.w, b6.x); pap = v3(b6.y, b6.z, b6.w);
       } else {
 #pragma unroll
         for (int k = 0; k < 9; k++) PR[k] = QR[k];
