@@ -4,16 +4,19 @@
 //
 // Mapping: ONE ENVIRONMENT PER 64-LANE WAVEFRONT (one wave per workgroup).  Lanes take different roles per phase:
 //   body lanes    (A*13 + P)   forward kinematics by tree level, spatial inertia / bias wrench about the base origin,
-//                              composite sums up the 3-link leg chains with lane shuffles
-//   leg lanes     (A*4)        3x3 leg block inverse, Schur terms;   (A*6) lanes: 6x6 base Schur complement inverse
-//   task lanes                 rows of M^-1, B = M^-1 J^T per (contact side, dof), 3x3 coupling blocks per contact pair
+//                              composite sums up the 3-link leg chains; a child's parent is the neighbouring lane, so frames,
+//                              composites and joint axes travel through DPP wave shifts, not LDS
+//   hip lanes     (A*4)        3x3 leg block inverse, Schur terms;   (A*6) lanes: 6x6 base Schur complement inverse
+//   row / task lanes           rows of M^-1 (lane = row), B = M^-1 J^T per (contact side, dof), 3x3 coupling blocks per contact pair
 //   sphere lanes  (2*27 / P)   collision spheres vs ground plane / wall signed-distance field / static scenery boxes /
 //                              1-dof link (plank, door, disc) / free box / other actors' spheres, compacted with ballots
 //                              into a bounded, canonically ordered contact list
 //   contact lanes (<= maxc)    sparse Jacobian rows, then projected Gauss-Seidel in CONTACT space: a lane owns its contact's
 //                              relative velocity and impulse, increments travel by ds_bpermute / v_readlane
 //   dof lanes     (<= 2 x 64)  unconstrained velocity, impulses -> velocities, joint limits, integration (velocities in LDS)
-// Link transforms, M^-1 (18x18 per robot), contact rows and coupling blocks live in LDS (layout: phys_lds_layout); with
+// Link frames, M^-1 (18x18 per robot), contact rows and coupling blocks live in LDS (layout: phys_lds_layout); the records
+// that are moved whole (link frames, spheres, contacts, leg blocks, Jacobian rows) are laid out in 16 B words and accessed
+// with ds_read_b128 / ds_write_b128 -- a quarter of the LDS instructions and of the waits in front of them.  With
 // k_substeps the state is read from and written to HBM once per env.step(), coalesced (the env-major rows of one env are
 // contiguous), and the actuator network / PD law of every substep runs inside the same wavefront.
 #pragma once
