@@ -15,5 +15,5 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_write -- $BENCH > $OUT/${TAG}_pmc_write.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_sq -- $BENCH > $OUT/${TAG}_pmc_sq.log 2>&1
 cd $R
-python bench.py --steps 500 --warmup 50 $* > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+python bench.py --steps 500 --warmup 50 $* 2> $OUT/${TAG}_bench.err | grep "^{" > $OUT/${TAG}_bench.json
 tail -1 $OUT/${TAG}_bench.json
