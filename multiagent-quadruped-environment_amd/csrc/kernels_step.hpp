@@ -405,7 +405,8 @@ __device__ __forceinline__ void step_sheep_env(const DevModel* m, const DevState
 // wrapper observation + reward for env e.  npc = the `root_states_npc` rows the wrapper sees ([P][13]); see oracle.
 // side_effects: 1 on the wrapper-level paths (mqe_step, mqe_wrapper_eval); the Go1-level mqe_post_physics_step passes 0 so that the
 // state stays exactly what Go1.step leaves (go1tug re-poses its slider from the wrapper)
-__device__ void wrapper_env_dev(const DevModel* m, const DevState& st, int e, int is_reset_call, const float* npc, int side_effects = 1) {
+__device__ void wrapper_env_dev(const DevModel* m, const DevState& st, int e, int is_reset_call, const float* npc, int side_effects = 1, const float* bag = nullptr) {
+  if (!bag) bag = st.obs_bag + (size_t)e * m->A * MQE_OBS_BAG;   // this env's rows (k_post_physics passes its LDS copy)
   int A = m->A, P = m->P, Aw = m->Aw, D = m->D;
   float* obs = st.wobs + (size_t)e * Aw * D;
   float* rew = st.wrew + (size_t)e * Aw;
@@ -417,7 +418,7 @@ __device__ void wrapper_env_dev(const DevModel* m, const DevState& st, int e, in
     if (m->task == MQE_TASK_TUG) {                // go1_tug_wrapper.py:47-57: [base info, slider (pos, vel), distance to it, slider pos]
       const float npos = st.dof[((size_t)e * m->ND + 12 * A) * 2], nvel = st.dof[((size_t)e * m->ND + 12 * A) * 2 + 1];
       const float sgn = a == 1 ? -1.0f : 1.0f;    // agent 1 sees the mirrored scene: entries 1, 4, 6, 9 negated
-      const float* ob = st.obs_bag + (size_t)(e * A + a) * MQE_OBS_BAG;
+      const float* ob = bag + (a) * MQE_OBS_BAG;
       for (int k = 0; k < 6; k++) o[k] = ob[k];
       const float dx = o[0] - 1.6f, dy = o[1] - npos;
       o[1] *= sgn; o[4] *= sgn;
@@ -426,10 +427,10 @@ __device__ void wrapper_env_dev(const DevModel* m, const DevState& st, int e, in
     }
     if (m->task != MQE_TASK_ROTATION && m->task != MQE_TASK_BRIDGE && m->task != MQE_TASK_WRESTLING)
       for (int k = 0; k < Aw; k++) o[c++] = (k == a) ? 1.0f : 0.0f;
-    const float* ob = st.obs_bag + (size_t)(e * A + a) * MQE_OBS_BAG;
+    const float* ob = bag + (a) * MQE_OBS_BAG;
     for (int k = 0; k < 6; k++) o[c++] = ob[k];
     if (m->task != MQE_TASK_PLAIN) {
-      const float* ob2 = st.obs_bag + (size_t)(e * A + (Aw - 1 - a)) * MQE_OBS_BAG;
+      const float* ob2 = bag + ((Aw - 1 - a)) * MQE_OBS_BAG;
       for (int k = 0; k < 6; k++) o[c++] = ob2[k];
     }
     if (m->task == MQE_TASK_GATE || m->task == MQE_TASK_SHEEP || m->task == MQE_TASK_PUSHBOX) { o[c++] = m->gate_pos[e * 2]; o[c++] = m->gate_pos[e * 2 + 1]; }
@@ -447,8 +448,8 @@ __device__ void wrapper_env_dev(const DevModel* m, const DevState& st, int e, in
   if (m->task == MQE_TASK_TUG) {                  // go1_tug_wrapper.py:59-136
     float* nd = st.dof + ((size_t)e * m->ND + 12 * A) * 2;
     const float npos = nd[0];
-    const float* ob0 = st.obs_bag + (size_t)(e * A) * MQE_OBS_BAG;
-    const float* ob1 = st.obs_bag + (size_t)(e * A + 1) * MQE_OBS_BAG;
+    const float* ob0 = bag;
+    const float* ob1 = bag + (1) * MQE_OBS_BAG;
     const float x0 = ob0[0], y0 = ob0[1], x1 = ob1[0], y1 = ob1[1];
     if (is_reset_call) {                          // _init_extras (:37-40)
       st.w_last[e * MQE_MAX_AGENTS] = x0; st.w_last[e * MQE_MAX_AGENTS + 1] = y0;
@@ -480,8 +481,8 @@ __device__ void wrapper_env_dev(const DevModel* m, const DevState& st, int e, in
     return;
   }
   if (m->task == MQE_TASK_BRIDGE) {               // go1_bridge_wrapper.py
-    const float* ob0 = st.obs_bag + (size_t)(e * A) * MQE_OBS_BAG;
-    const float* ob1 = st.obs_bag + (size_t)(e * A + 1) * MQE_OBS_BAG;
+    const float* ob0 = bag;
+    const float* ob1 = bag + (1) * MQE_OBS_BAG;
     const float x0 = ob0[0], z0 = ob0[2], x1 = ob1[0], z1 = ob1[2];
     float S = st.w_last[e * MQE_MAX_AGENTS], tgt = st.w_last[e * MQE_MAX_AGENTS + 1];
     if (is_reset_call) {                          // _init_extras (:27-29): target_pos = flip(base_pos at reset)
@@ -506,7 +507,7 @@ __device__ void wrapper_env_dev(const DevModel* m, const DevState& st, int e, in
     float r0 = 0.0f;
     bool down0, down1;
     {
-      const float* ob = st.obs_bag + (size_t)(e * A) * MQE_OBS_BAG;
+      const float* ob = bag;
       float r = ob[3], p = ob[4];
       if (r > 3.1415927f) r -= 6.2831855f;
       if (p > 3.1415927f) p -= 6.2831855f;
@@ -527,8 +528,8 @@ __device__ void wrapper_env_dev(const DevModel* m, const DevState& st, int e, in
     float* o1 = obs + 1 * D;
     o1[1] = -o1[1]; o1[4] = -o1[4]; o1[7] = -o1[7]; o1[10] = -o1[10];
     const float tgt = m->wrapper_param[0];
-    const float* ob0 = st.obs_bag + (size_t)(e * A) * MQE_OBS_BAG;
-    const float* ob1 = st.obs_bag + (size_t)(e * A + 1) * MQE_OBS_BAG;
+    const float* ob0 = bag;
+    const float* ob1 = bag + (1) * MQE_OBS_BAG;
     const float x0 = ob0[0], y0 = ob0[1], x1 = ob1[0];
     if (is_reset_call) {                          // _init_extras (:30-38): only x is shifted by the target here
       st.w_last[e * MQE_MAX_AGENTS] = sqrtf((x0 - tgt) * (x0 - tgt) + y0 * y0);
@@ -559,7 +560,7 @@ __device__ void wrapper_env_dev(const DevModel* m, const DevState& st, int e, in
 #pragma unroll
     for (int a = 0; a < MQE_MAX_AGENTS; a++)
       if (a < A) {
-        const float* ob = st.obs_bag + (size_t)(e * A + a) * MQE_OBS_BAG;
+        const float* ob = bag + (a) * MQE_OBS_BAG;
         bx[a] = ob[0]; by[a] = ob[1];
         wl[a] = st.w_last[e * MQE_MAX_AGENTS + a];
       }
@@ -639,7 +640,7 @@ __device__ void wrapper_env_dev(const DevModel* m, const DevState& st, int e, in
   if (m->task == MQE_TASK_SEESAW) {
     float xs = 0, zs = 0, y2 = 0;
     for (int a = 0; a < A; a++) {
-      const float* ob = st.obs_bag + (size_t)(e * A + a) * MQE_OBS_BAG;
+      const float* ob = bag + (a) * MQE_OBS_BAG;
       if (!st.w_have_last[e]) st.w_last[e * MQE_MAX_AGENTS + a] = ob[0];
       xs += ob[0] - st.w_last[e * MQE_MAX_AGENTS + a];
       st.w_last[e * MQE_MAX_AGENTS + a] = ob[0];
@@ -651,13 +652,13 @@ __device__ void wrapper_env_dev(const DevModel* m, const DevState& st, int e, in
     if (sc[2] != 0) { float v = sc[2] * (y2 - 0.5f); r_env += v; rs[2] += v; }
     if (sc[3] != 0) { float v = sc[3] * (float)st.collide_buf[e]; r_env += v; rs[3] += v; }
     if (sc[4] != 0) {
-      const float* o0 = st.obs_bag + (size_t)(e * A) * MQE_OBS_BAG; const float* o1 = st.obs_bag + (size_t)(e * A + A - 1) * MQE_OBS_BAG;
+      const float* o0 = bag; const float* o1 = bag + (A - 1) * MQE_OBS_BAG;
       float d2 = (o0[0] - o1[0]) * (o0[0] - o1[0]) + (o0[1] - o1[1]) * (o0[1] - o1[1]);
       if (d2 < 0.25f) { float v = sc[4] / d2; r_env += v; rs[4] += v; }
     }
     if (sc[5] != 0) {
       int cnt = 0;
-      for (int a = 0; a < A; a++) { const float* ob = st.obs_bag + (size_t)(e * A + a) * MQE_OBS_BAG; if (ob[0] > 7.7f && ob[2] > 1.3f) cnt++; }
+      for (int a = 0; a < A; a++) { const float* ob = bag + (a) * MQE_OBS_BAG; if (ob[0] > 7.7f && ob[2] > 1.3f) cnt++; }
       float v = sc[5] * (float)cnt; r_env += v; rs[5] += v;
     }
     if (sc[6] != 0) { if (st.r_term[e] | st.p_term[e]) { r_env += sc[6]; rs[6] += sc[6]; } }
@@ -702,13 +703,35 @@ __device__ void wrapper_env_dev(const DevModel* m, const DevState& st, int e, in
 #define POST_EPW 8
 #endif
 template <int AM>
-__device__ __forceinline__ uint8_t post_physics_env(const DevModel* m, const DevState& st, const int e, const int wrapper_level, const int push_count);
+__device__ __forceinline__ uint8_t post_physics_env(const DevModel* m, const DevState& st, const int e, const int wrapper_level, const int push_count, float* bag, float* la);
+
+// One block's rows of a [R][W] tensor (contiguous for the block's consecutive envs) from LDS to HBM, 16 B per lane.
+__device__ __forceinline__ void post_flush_rows(float* __restrict__ g, const float* lds, const int n) {
+  const int n4 = n >> 2;
+  for (int i = threadIdx.x; i < n4; i += 64) reinterpret_cast<float4*>(g)[i] = reinterpret_cast<const float4*>(lds)[i];
+  for (int i = (n4 << 2) + threadIdx.x; i < n; i += 64) g[i] = lds[i];
+}
 
 template <int AM>
 __global__ void __launch_bounds__(64) k_post_physics(const DevModel* m, DevState st, int wrapper_level, int push_count) {
   const int e = blockIdx.x * POST_EPW + threadIdx.x;
+  // The per-robot rows this block produces (obs bag 74, last action 12, last dof velocity 12) are contiguous in HBM over
+  // the block's envs: the 8 working lanes write them to LDS (the wrapper reads the obs rows back from there, not through
+  // L2) and the whole wavefront stores them 16 B per lane: ~300 scattered dword stores per lane become 12.
+  __shared__ float4 s_bag4[POST_EPW * AM * MQE_OBS_BAG / 4], s_la4[POST_EPW * AM * 24 / 4];
+  float* s_bag = reinterpret_cast<float*>(s_bag4);
+  float* s_la = reinterpret_cast<float*>(s_la4);
+  const int A = m->A, nrow = min(POST_EPW, m->N - blockIdx.x * POST_EPW) * A;   // robots of this block
   uint8_t reset = 0;
-  if (threadIdx.x < POST_EPW && e < m->N) reset = post_physics_env<AM>(m, st, e, wrapper_level, push_count);
+  if (threadIdx.x < POST_EPW && e < m->N)
+    reset = post_physics_env<AM>(m, st, e, wrapper_level, push_count, s_bag + threadIdx.x * A * MQE_OBS_BAG, s_la + threadIdx.x * A * 12);
+  __syncthreads();
+  {
+    const size_t r0 = (size_t)blockIdx.x * POST_EPW * A;
+    post_flush_rows(st.obs_bag + r0 * MQE_OBS_BAG, s_bag, nrow * MQE_OBS_BAG);
+    post_flush_rows(st.last_actions + r0 * 12, s_la, nrow * 12);
+    post_flush_rows(st.last_dof_vel + r0 * 12, s_la + POST_EPW * AM * 12, nrow * 12);
+  }
   // go1.py:145: history[agent_ids] = 0 for the envs that reset this step -- rare, so the whole wavefront (the lanes that
   // idled above included) zeroes them, 16 B per lane per request: the f32 ring and, when present, its two f16 planes
   unsigned long long rm = __ballot(reset != 0);
@@ -729,7 +752,7 @@ __global__ void __launch_bounds__(64) k_post_physics(const DevModel* m, DevState
 
 // AM: compile-time bound of the agent loops (>= m->A; 2 for the two-robot tasks, MQE_MAX_AGENTS otherwise)
 template <int AM>
-__device__ __forceinline__ uint8_t post_physics_env(const DevModel* m, const DevState& st, const int e, const int wrapper_level, const int push_count) {
+__device__ __forceinline__ uint8_t post_physics_env(const DevModel* m, const DevState& st, const int e, const int wrapper_level, const int push_count, float* bag, float* la) {
   const int A = m->A, P = m->P;
   const float dtp = m->dt * (float)m->decimation;
   float* root = st.root + (size_t)e * (A + P) * 13;
@@ -844,7 +867,7 @@ __device__ __forceinline__ uint8_t post_physics_env(const DevModel* m, const Dev
   for (int a = 0; a < AM; a++)
     if (a < A) {
       const int i = e * A + a;
-      float* ob = st.obs_bag + (size_t)i * MQE_OBS_BAG;
+      float* ob = bag + a * MQE_OBS_BAG;
       float rpy[3];
       euler_xyz_f(bq[a], rpy);
 #pragma unroll
@@ -855,15 +878,17 @@ __device__ __forceinline__ uint8_t post_physics_env(const DevModel* m, const Dev
         ob[18 + j] = dq[a][2 * j + 1] * 0.05f;
         ob[36 + j] = act[a][j];
         ob[48 + j] = act[a][j];
-        st.last_actions[(size_t)i * 12 + j] = act[a][j];
-        st.last_dof_vel[(size_t)i * 12 + j] = dq[a][2 * j + 1];        // legged_robot.py:152
+        la[a * 12 + j] = act[a][j];
+        la[POST_EPW * AM * 12 + a * 12 + j] = dq[a][2 * j + 1];        // legged_robot.py:152
       }
 #pragma unroll
       for (int k = 0; k < 3; k++) { ob[30 + k] = lv[a][k] * 2.0f; ob[33 + k] = av[a][k] * 0.25f; ob[60 + k] = pgr[a][k]; }
 #pragma unroll
       for (int k = 0; k < 4; k++) { ob[63 + k] = clk[a][k]; ob[67 + k] = bq[a][k]; }
+#pragma unroll
+      for (int k = 71; k < MQE_OBS_BAG; k++) ob[k] = 0.0f;             // row padding (the LDS copy is stored whole)
     }
-  wrapper_env_dev(m, st, e, 0, npc_pre, wrapper_level);
+  wrapper_env_dev(m, st, e, 0, npc_pre, wrapper_level, bag);
   // _push_robots (go1.py:237, legged_robot.py:470-476): after this step's frame quantities were taken, before reset_idx --
   // whose U(-0.5, 0.5) base velocities replace the push in the envs that reset.  One draw per robot (the reference draws
   // (num_envs, 2) for a (num_envs * num_agents, 2) slice, which only broadcasts for a single agent).
