@@ -692,18 +692,18 @@ __device__ void wrapper_env_dev(const DevModel* m, const DevState& st, int e, in
   for (int a = 0; a < Aw; a++) rew[a] = 0;
 }
 
-// Launch geometry: the body is scalar per env with row-strided (uncoalesced) accesses, so it is latency-bound; POST_EPW
-// envs per 64-lane wavefront (the other lanes idle) trades issue slots for 64/POST_EPW times more waves in flight.
-// Within a thread the global accesses are ordered LOADS FIRST: every input of the step (robot root rows, joint states,
-// actions, gait parameters, contact forces, origins) is requested before the first store, because a load behind a store
-// that may alias cannot be hoisted by the compiler and each such load costs a full memory round trip (the first version
-// interleaved them per robot and per buffer: 37 us of s_waitcnt).  Per-robot values live in registers (loops unrolled to
-// MQE_MAX_AGENTS with a guard, so that every array index is a constant).
+// Launch geometry: POST_EPW envs per 64-lane wavefront, lane = (agent, env): lane a * POST_EPW + le holds robot a of the
+// block's env le, so the per-robot work (state loads, body-frame quantities, gait clock, termination tests, observation
+// row) runs once per lane instead of A times per env lane; the env-level work (flags, NPC script, reset, wrapper, push)
+// stays on the agent-0 lane, which collects the other robots' termination bits with wave shuffles.  The body is latency-
+// bound (row-strided accesses, one wave per SIMD), so what counts is the length of the per-lane instruction chain.
+// Within a lane the global accesses are ordered LOADS FIRST: every input of the step (root row, joint states, actions,
+// gait parameters, contact force, origins) is requested before the first store, because a load behind a store that may
+// alias cannot be hoisted by the compiler and each such load costs a full memory round trip (the first version
+// interleaved them per robot and per buffer: 37 us of s_waitcnt).
 #ifndef POST_EPW
 #define POST_EPW 8
 #endif
-template <int AM>
-__device__ __forceinline__ uint8_t post_physics_env(const DevModel* m, const DevState& st, const int e, const int wrapper_level, const int push_count, float* bag, float* la);
 
 // One block's rows of a [R][W] tensor (contiguous for the block's consecutive envs) from LDS to HBM, 16 B per lane.
 __device__ __forceinline__ void post_flush_rows(float* __restrict__ g, const float* lds, const int n) {
@@ -712,193 +712,190 @@ __device__ __forceinline__ void post_flush_rows(float* __restrict__ g, const flo
   for (int i = (n4 << 2) + threadIdx.x; i < n; i += 64) g[i] = lds[i];
 }
 
+// AM: compile-time bound of the agent lanes (>= m->A; 2 for the two-robot tasks, MQE_MAX_AGENTS otherwise)
 template <int AM>
 __global__ void __launch_bounds__(64) k_post_physics(const DevModel* m, DevState st, int wrapper_level, int push_count) {
-  const int e = blockIdx.x * POST_EPW + threadIdx.x;
+  static_assert(POST_EPW * AM <= 64 && (POST_EPW & (POST_EPW - 1)) == 0, "agent lanes of POST_EPW envs must fit one wavefront");
   // The per-robot rows this block produces (obs bag 74, last action 12, last dof velocity 12) are contiguous in HBM over
-  // the block's envs: the 8 working lanes write them to LDS (the wrapper reads the obs rows back from there, not through
-  // L2) and the whole wavefront stores them 16 B per lane: ~300 scattered dword stores per lane become 12.
+  // the block's envs: the robot lanes write them to LDS (the wrapper reads the obs rows back from there, not through L2)
+  // and the whole wavefront stores them 16 B per lane.
   __shared__ float4 s_bag4[POST_EPW * AM * MQE_OBS_BAG / 4], s_la4[POST_EPW * AM * 24 / 4];
   float* s_bag = reinterpret_cast<float*>(s_bag4);
   float* s_la = reinterpret_cast<float*>(s_la4);
-  const int A = m->A, nrow = min(POST_EPW, m->N - blockIdx.x * POST_EPW) * A;   // robots of this block
-  uint8_t reset = 0;
-  if (threadIdx.x < POST_EPW && e < m->N)
-    reset = post_physics_env<AM>(m, st, e, wrapper_level, push_count, s_bag + threadIdx.x * A * MQE_OBS_BAG, s_la + threadIdx.x * A * 12);
+  const int A = m->A, P = m->P;
+  const int le = threadIdx.x & (POST_EPW - 1), a = threadIdx.x / POST_EPW;
+  const int e = blockIdx.x * POST_EPW + le;
+  const bool mine = e < m->N && a < A;          // this lane's robot exists
+  const bool lead = e < m->N && a == 0;         // this lane does its env's env-level work
+  const int i = e * A + a;
+  const int nrow = min(POST_EPW, m->N - blockIdx.x * POST_EPW) * A;   // robots of this block
+  const float dtp = m->dt * (float)m->decimation;
+  float* root = st.root + (size_t)e * (A + P) * 13;
+  float* bag = s_bag + le * A * MQE_OBS_BAG;    // this env's rows, agent-major like the tensor
+  float* la = s_la + le * A * 12;
+  // ---- loads --------------------------------------------------------------------------------------------------------------
+  float rs[13], gpar[5], gi0 = 0.f, f3[3], aoz = 0.f, dq[24], act[12], eo[3];
+  int ep = 0;
+  if (mine) {
+    ep = st.ep_len[e] + 1;
+#pragma unroll
+    for (int k = 0; k < 3; k++) eo[k] = m->env_origins[e * 3 + k];
+#pragma unroll
+    for (int k = 0; k < 13; k++) rs[k] = root[a * 13 + k];
+    const float* lo = st.loco_obs + (size_t)i * MQE_FRAME;
+#pragma unroll
+    for (int k = 0; k < 5; k++) gpar[k] = lo[7 + k];
+    gi0 = st.gait[i];
+    const float* cf3 = st.cf + ((size_t)e * m->NBR + a * MQE_NREP) * 3;
+#pragma unroll
+    for (int k = 0; k < 3; k++) f3[k] = cf3[k];
+    aoz = m->agent_origins[(size_t)i * 3 + 2];
+    const float* ds = st.dof + ((size_t)e * m->ND + a * 12) * 2;
+#pragma unroll
+    for (int k = 0; k < 24; k++) dq[k] = ds[k];
+#pragma unroll
+    for (int k = 0; k < 12; k++) act[k] = st.actions[(size_t)i * 12 + k];
+  }
+  // ---- body-frame quantities, gait clock, termination (registers only) ------------------------------------------------------
+  float bq[4], lv[3], av[3], pgr[3], clk[4], gi1 = 0.f;
+  unsigned fl = 0;                              // bit 0 base contact, 1 roll, 2 pitch, 3 z high, 4 z low
+  if (mine) {
+    const float q[4] = {rs[3], rs[4], rs[5], rs[6]}, v[3] = {rs[7], rs[8], rs[9]}, w[3] = {rs[10], rs[11], rs[12]};
+    const float g3[3] = {0.0f, 0.0f, -1.0f};
+#pragma unroll
+    for (int k = 0; k < 4; k++) bq[k] = q[k];
+    quat_rotate_inverse_f(q, v, lv);
+    quat_rotate_inverse_f(q, w, av);
+    quat_rotate_inverse_f(q, g3, pgr);
+    const float f = gpar[0], ph = gpar[1], off = gpar[2], bnd = gpar[3], dur = gpar[4];
+    float gi = gi0 + dtp * f;
+    gi = gi - floorf(gi);
+    gi1 = gi;
+    float fi[4] = {gi + ph + off + bnd, gi + off, gi + bnd, gi + ph};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const float r = fi[k] - floorf(fi[k]);
+      if (r < dur) fi[k] = r * (0.5f / dur);
+      else if (r > dur) fi[k] = 0.5f + (r - dur) * (0.5f / (1.0f - dur));
+      clk[k] = sinf(6.2831855f * fi[k]);
+    }
+    if (m->terminate_on_base_contact && sqrtf(f3[0] * f3[0] + f3[1] * f3[1] + f3[2] * f3[2]) > 1.0f) fl |= 1u;
+    float rpy[3];
+    euler_xyz_f(q, rpy);
+    float r = rpy[0], p = rpy[1];
+    if (r > 3.1415927f) r -= 6.2831855f;
+    if (p > 3.1415927f) p -= 6.2831855f;
+    const float z = rs[2] - aoz;
+    if ((m->termination_flags & MQE_TERM_ROLL) && fabsf(r) > m->roll_thr) fl |= 2u;
+    if ((m->termination_flags & MQE_TERM_PITCH) && fabsf(p) > m->pitch_thr) fl |= 4u;
+    if ((m->termination_flags & MQE_TERM_Z_HIGH) && z > m->zhigh_thr) fl |= 8u;
+    if ((m->termination_flags & MQE_TERM_Z_LOW) && z < m->zlow_thr) fl |= 16u;
+  }
+  // any robot of the env: OR over the agent lanes (lane ^ POST_EPW, ^ 2 POST_EPW stay inside the POST_EPW * AM robot lanes)
+#pragma unroll
+  for (int d = POST_EPW; d < POST_EPW * AM; d <<= 1) fl |= (unsigned)__shfl_xor((int)fl, d);
+  const uint8_t to = ep > m->max_episode_length, rterm = (fl >> 1) & 1, pterm = (fl >> 2) & 1, zh = (fl >> 3) & 1;
+  const uint8_t reset = (uint8_t)(mine && (fl != 0 || to));       // the same value on all robot lanes of the env
+  // ---- stores of the frame quantities and flags ------------------------------------------------------------------------------
+  if (lead) {
+    st.ep_len[e] = ep;
+    st.time_out[e] = to;
+    if (m->termination_flags & MQE_TERM_ROLL) st.r_term[e] = rterm;
+    if (m->termination_flags & MQE_TERM_PITCH) st.p_term[e] = pterm;
+    if (m->termination_flags & MQE_TERM_Z_HIGH) st.zh_term[e] = zh;
+    st.reset_buf[e] = reset;
+    if (m->terminate_on_base_contact) st.collide_buf[e] = reset;
+  }
+  if (mine) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) { st.blv[i * 3 + k] = lv[k]; st.bav[i * 3 + k] = av[k]; st.pg[i * 3 + k] = pgr[k]; }
+#pragma unroll
+    for (int k = 0; k < 4; k++) { st.bquat[i * 4 + k] = bq[k]; st.clock[i * 4 + k] = clk[k]; }
+    st.gait[i] = gi1;
+  }
+  // wrapper's view of root_states_npc: copy taken before the NPC script (legged_robot.py:136); xy/vel only are read
+  float npc_pre[MQE_MAX_NPCS * 13];
+  if (lead) {
+    for (int k = 0; k < P * 13; k++) npc_pre[k] = root[A * 13 + k];
+    if (m->npc_kind == MQE_NPC_SHEEP) step_sheep_env(m, st, e);
+    if (reset) {                                // rare: the reset writes memory, the robot lanes refresh their registers from it
+      reset_env_dev(m, st, e);
+      for (int k = 0; k < P * 13; k++) npc_pre[k] = root[A * 13 + k];
+    }
+  }
+  if (__ballot(reset != 0)) {                   // wave-uniform
+    __threadfence();                            // the lead lane's stores, then no stale L1 lines for the other robot lanes
+    __syncthreads();
+    if (reset) {
+#pragma unroll
+      for (int k = 0; k < 13; k++) rs[k] = root[a * 13 + k];
+      const float* ds = st.dof + ((size_t)e * m->ND + a * 12) * 2;
+#pragma unroll
+      for (int k = 0; k < 24; k++) dq[k] = ds[k];
+      if (P == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) { bq[k] = rs[3 + k]; st.bquat[i * 4 + k] = bq[k]; }
+      }
+    }
+  }
+  // ---- compute_observations (legged_robot_field.py:117-146) from registers; obs.last_last_action aliases the current action
+  if (mine) {
+    float* ob = bag + a * MQE_OBS_BAG;
+    float rpy[3];
+    euler_xyz_f(bq, rpy);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { ob[k] = rs[k] - eo[k]; ob[3 + k] = rpy[k]; }
+#pragma unroll
+    for (int j = 0; j < 12; j++) {
+      ob[6 + j] = (dq[2 * j] - m->default_dof_pos[j]) * 1.0f;
+      ob[18 + j] = dq[2 * j + 1] * 0.05f;
+      ob[36 + j] = act[j];
+      ob[48 + j] = act[j];
+      la[a * 12 + j] = act[j];
+      la[POST_EPW * AM * 12 + a * 12 + j] = dq[2 * j + 1];             // legged_robot.py:152
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) { ob[30 + k] = lv[k] * 2.0f; ob[33 + k] = av[k] * 0.25f; ob[60 + k] = pgr[k]; }
+#pragma unroll
+    for (int k = 0; k < 4; k++) { ob[63 + k] = clk[k]; ob[67 + k] = bq[k]; }
+#pragma unroll
+    for (int k = 71; k < MQE_OBS_BAG; k++) ob[k] = 0.0f;               // row padding (the LDS copy is stored whole)
+  }
   __syncthreads();
+  if (lead) {
+    wrapper_env_dev(m, st, e, 0, npc_pre, wrapper_level, bag);
+    // _push_robots (go1.py:237, legged_robot.py:470-476): after this step's frame quantities were taken, before reset_idx --
+    // whose U(-0.5, 0.5) base velocities replace the push in the envs that reset.  One draw per robot (the reference draws
+    // (num_envs, 2) for a (num_envs * num_agents, 2) slice, which only broadcasts for a single agent).
+    if (push_count > 0 && !reset)
+      for (int b = 0; b < A; b++) {
+        float* rv = root + b * 13 + 7;
+        rv[0] = mqe_rand(m, e, (int)(MQE_RNG_PUSH + (uint32_t)push_count), (uint32_t)(2 * b), -m->max_push, m->max_push);
+        rv[1] = mqe_rand(m, e, (int)(MQE_RNG_PUSH + (uint32_t)push_count), (uint32_t)(2 * b + 1), -m->max_push, m->max_push);
+      }
+  }
   {
     const size_t r0 = (size_t)blockIdx.x * POST_EPW * A;
     post_flush_rows(st.obs_bag + r0 * MQE_OBS_BAG, s_bag, nrow * MQE_OBS_BAG);
     post_flush_rows(st.last_actions + r0 * 12, s_la, nrow * 12);
     post_flush_rows(st.last_dof_vel + r0 * 12, s_la + POST_EPW * AM * 12, nrow * 12);
   }
-  // go1.py:145: history[agent_ids] = 0 for the envs that reset this step -- rare, so the whole wavefront (the lanes that
-  // idled above included) zeroes them, 16 B per lane per request: the f32 ring and, when present, its two f16 planes
-  unsigned long long rm = __ballot(reset != 0);
+  // go1.py:145: history[agent_ids] = 0 for the envs that reset this step -- rare, so the whole wavefront zeroes them,
+  // 16 B per lane per request: the f32 ring and, when present, its two f16 planes
+  unsigned long long rm = __ballot(lead && reset != 0);
   while (rm) {
     const int l = __ffsll((long long)rm) - 1;
     rm &= rm - 1;
     const int er = blockIdx.x * POST_EPW + l;
     const int per = m->A * (MQE_HIST * MQE_FRAME / 4);                 // float4 units of this env's robots (contiguous)
     float4* h4 = reinterpret_cast<float4*>(st.hist) + (size_t)er * per;
-    for (int i = threadIdx.x; i < per; i += 64) h4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = threadIdx.x; k < per; k += 64) h4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (st.hist2) {                                                    // same robots, 2 planes interleaved: the same bytes
       uint4* p4 = reinterpret_cast<uint4*>(st.hist2 + (size_t)er * m->A * (2 * MQE_HIST * MQE_FRAME));
       const int per2 = m->A * (2 * MQE_HIST * MQE_FRAME / 8);
-      for (int i = threadIdx.x; i < per2; i += 64) p4[i] = make_uint4(0u, 0u, 0u, 0u);
+      for (int k = threadIdx.x; k < per2; k += 64) p4[k] = make_uint4(0u, 0u, 0u, 0u);
     }
   }
-}
-
-// AM: compile-time bound of the agent loops (>= m->A; 2 for the two-robot tasks, MQE_MAX_AGENTS otherwise)
-template <int AM>
-__device__ __forceinline__ uint8_t post_physics_env(const DevModel* m, const DevState& st, const int e, const int wrapper_level, const int push_count, float* bag, float* la) {
-  const int A = m->A, P = m->P;
-  const float dtp = m->dt * (float)m->decimation;
-  float* root = st.root + (size_t)e * (A + P) * 13;
-  // ---- loads --------------------------------------------------------------------------------------------------------------
-  float rs[AM][13], gpar[AM][5], gi0[AM], f3[AM][3], aoz[AM];
-  float dq[AM][24], act[AM][12];
-  const int ep = st.ep_len[e] + 1;
-  float eo[3];
-#pragma unroll
-  for (int k = 0; k < 3; k++) eo[k] = m->env_origins[e * 3 + k];
-#pragma unroll
-  for (int a = 0; a < AM; a++)
-    if (a < A) {
-      const int i = e * A + a;
-#pragma unroll
-      for (int k = 0; k < 13; k++) rs[a][k] = root[a * 13 + k];
-      const float* lo = st.loco_obs + (size_t)i * MQE_FRAME;
-#pragma unroll
-      for (int k = 0; k < 5; k++) gpar[a][k] = lo[7 + k];
-      gi0[a] = st.gait[i];
-      const float* cf3 = st.cf + ((size_t)e * m->NBR + a * MQE_NREP) * 3;
-#pragma unroll
-      for (int k = 0; k < 3; k++) f3[a][k] = cf3[k];
-      aoz[a] = m->agent_origins[((size_t)e * A + a) * 3 + 2];
-      const float* ds = st.dof + ((size_t)e * m->ND + a * 12) * 2;
-#pragma unroll
-      for (int k = 0; k < 24; k++) dq[a][k] = ds[k];
-#pragma unroll
-      for (int k = 0; k < 12; k++) act[a][k] = st.actions[(size_t)i * 12 + k];
-    }
-  // ---- body-frame quantities, gait clock, termination (registers only) ------------------------------------------------------
-  float bq[AM][4], lv[AM][3], av[AM][3], pgr[AM][3], clk[AM][4], gi1[AM];
-  uint8_t reset = 0, collide = 0, rterm = 0, pterm = 0, zh = 0;
-#pragma unroll
-  for (int a = 0; a < AM; a++)
-    if (a < A) {
-      const float q[4] = {rs[a][3], rs[a][4], rs[a][5], rs[a][6]}, v[3] = {rs[a][7], rs[a][8], rs[a][9]}, w[3] = {rs[a][10], rs[a][11], rs[a][12]};
-      const float g3[3] = {0.0f, 0.0f, -1.0f};
-#pragma unroll
-      for (int k = 0; k < 4; k++) bq[a][k] = q[k];
-      quat_rotate_inverse_f(q, v, lv[a]);
-      quat_rotate_inverse_f(q, w, av[a]);
-      quat_rotate_inverse_f(q, g3, pgr[a]);
-      const float f = gpar[a][0], ph = gpar[a][1], off = gpar[a][2], bnd = gpar[a][3], dur = gpar[a][4];
-      float gi = gi0[a] + dtp * f;
-      gi = gi - floorf(gi);
-      gi1[a] = gi;
-      float fi[4] = {gi + ph + off + bnd, gi + off, gi + bnd, gi + ph};
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const float r = fi[k] - floorf(fi[k]);
-        if (r < dur) fi[k] = r * (0.5f / dur);
-        else if (r > dur) fi[k] = 0.5f + (r - dur) * (0.5f / (1.0f - dur));
-        clk[a][k] = sinf(6.2831855f * fi[k]);
-      }
-      if (m->terminate_on_base_contact && sqrtf(f3[a][0] * f3[a][0] + f3[a][1] * f3[a][1] + f3[a][2] * f3[a][2]) > 1.0f) collide = 1;
-      float rpy[3];
-      euler_xyz_f(q, rpy);
-      float r = rpy[0], p = rpy[1];
-      if (r > 3.1415927f) r -= 6.2831855f;
-      if (p > 3.1415927f) p -= 6.2831855f;
-      const float z = rs[a][2] - aoz[a];
-      if ((m->termination_flags & MQE_TERM_ROLL) && fabsf(r) > m->roll_thr) rterm = 1;
-      if ((m->termination_flags & MQE_TERM_PITCH) && fabsf(p) > m->pitch_thr) pterm = 1;
-      if ((m->termination_flags & MQE_TERM_Z_LOW) && z < m->zlow_thr) reset = 1;
-      if ((m->termination_flags & MQE_TERM_Z_HIGH) && z > m->zhigh_thr) zh = 1;
-    }
-  if (m->terminate_on_base_contact) reset |= collide;
-  const uint8_t to = ep > m->max_episode_length;
-  reset |= to | rterm | pterm | zh;
-  // ---- stores of the frame quantities and flags ------------------------------------------------------------------------------
-  st.ep_len[e] = ep;
-  st.time_out[e] = to;
-  if (m->termination_flags & MQE_TERM_ROLL) st.r_term[e] = rterm;
-  if (m->termination_flags & MQE_TERM_PITCH) st.p_term[e] = pterm;
-  if (m->termination_flags & MQE_TERM_Z_HIGH) st.zh_term[e] = zh;
-  st.reset_buf[e] = reset;
-  if (m->terminate_on_base_contact) st.collide_buf[e] = reset;
-#pragma unroll
-  for (int a = 0; a < AM; a++)
-    if (a < A) {
-      const int i = e * A + a;
-#pragma unroll
-      for (int k = 0; k < 3; k++) { st.blv[i * 3 + k] = lv[a][k]; st.bav[i * 3 + k] = av[a][k]; st.pg[i * 3 + k] = pgr[a][k]; }
-#pragma unroll
-      for (int k = 0; k < 4; k++) { st.bquat[i * 4 + k] = bq[a][k]; st.clock[i * 4 + k] = clk[a][k]; }
-      st.gait[i] = gi1[a];
-    }
-  // wrapper's view of root_states_npc: copy taken before the NPC script (legged_robot.py:136); xy/vel only are read
-  float npc_pre[MQE_MAX_NPCS * 13];
-  for (int k = 0; k < P * 13; k++) npc_pre[k] = root[A * 13 + k];
-  if (m->npc_kind == MQE_NPC_SHEEP) step_sheep_env(m, st, e);
-  if (reset) {                                  // rare: the reset writes memory, the registers are refreshed from it
-    reset_env_dev(m, st, e);
-    for (int k = 0; k < P * 13; k++) npc_pre[k] = root[A * 13 + k];
-#pragma unroll
-    for (int a = 0; a < AM; a++)
-      if (a < A) {
-#pragma unroll
-        for (int k = 0; k < 13; k++) rs[a][k] = root[a * 13 + k];
-        const float* ds = st.dof + ((size_t)e * m->ND + a * 12) * 2;
-#pragma unroll
-        for (int k = 0; k < 24; k++) dq[a][k] = ds[k];
-        if (P == 0) {
-#pragma unroll
-          for (int k = 0; k < 4; k++) { bq[a][k] = rs[a][3 + k]; st.bquat[(e * A + a) * 4 + k] = bq[a][k]; }
-        }
-      }
-  }
-  // ---- compute_observations (legged_robot_field.py:117-146) from registers; obs.last_last_action aliases the current action
-#pragma unroll
-  for (int a = 0; a < AM; a++)
-    if (a < A) {
-      const int i = e * A + a;
-      float* ob = bag + a * MQE_OBS_BAG;
-      float rpy[3];
-      euler_xyz_f(bq[a], rpy);
-#pragma unroll
-      for (int k = 0; k < 3; k++) { ob[k] = rs[a][k] - eo[k]; ob[3 + k] = rpy[k]; }
-#pragma unroll
-      for (int j = 0; j < 12; j++) {
-        ob[6 + j] = (dq[a][2 * j] - m->default_dof_pos[j]) * 1.0f;
-        ob[18 + j] = dq[a][2 * j + 1] * 0.05f;
-        ob[36 + j] = act[a][j];
-        ob[48 + j] = act[a][j];
-        la[a * 12 + j] = act[a][j];
-        la[POST_EPW * AM * 12 + a * 12 + j] = dq[a][2 * j + 1];        // legged_robot.py:152
-      }
-#pragma unroll
-      for (int k = 0; k < 3; k++) { ob[30 + k] = lv[a][k] * 2.0f; ob[33 + k] = av[a][k] * 0.25f; ob[60 + k] = pgr[a][k]; }
-#pragma unroll
-      for (int k = 0; k < 4; k++) { ob[63 + k] = clk[a][k]; ob[67 + k] = bq[a][k]; }
-#pragma unroll
-      for (int k = 71; k < MQE_OBS_BAG; k++) ob[k] = 0.0f;             // row padding (the LDS copy is stored whole)
-    }
-  wrapper_env_dev(m, st, e, 0, npc_pre, wrapper_level, bag);
-  // _push_robots (go1.py:237, legged_robot.py:470-476): after this step's frame quantities were taken, before reset_idx --
-  // whose U(-0.5, 0.5) base velocities replace the push in the envs that reset.  One draw per robot (the reference draws
-  // (num_envs, 2) for a (num_envs * num_agents, 2) slice, which only broadcasts for a single agent).
-  if (push_count > 0 && !reset)
-    for (int a = 0; a < A; a++) {
-      float* rv = st.root + ((size_t)e * (A + P) + a) * 13 + 7;
-      rv[0] = mqe_rand(m, e, (int)(MQE_RNG_PUSH + (uint32_t)push_count), (uint32_t)(2 * a), -m->max_push, m->max_push);
-      rv[1] = mqe_rand(m, e, (int)(MQE_RNG_PUSH + (uint32_t)push_count), (uint32_t)(2 * a + 1), -m->max_push, m->max_push);
-    }
-  return reset;
 }
 
 // go1.py:145: history[agent_ids] = 0 for envs that reset this step.  One float4 per thread, R*540 threads.
