@@ -91,7 +91,12 @@ def main():
             local_rank = 0
             dist.init_process_group(backend="gloo")
         else:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            opts = None
+            try:      # RCCL kernels on a high-priority HIP stream: they take their few CUs as soon as they are runnable
+                opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+            except Exception:
+                pass
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), pg_options=opts)
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
 
@@ -117,24 +122,45 @@ def main():
     actions = [torch.rand(N, A, 3, device=dev, generator=gen) * 2 - 1 for _ in range(args.warmup + args.steps)]
     step_no = [0]
 
+    # The one collective of the path: all-gather of the returned batch (packed: obs | reward | done), asynchronous and
+    # double-buffered.  The gather of step t is ISSUED inside step t+1, between the policy kernels and the physics kernel
+    # (Go1.between_policy_and_physics -> mqe_step_begin / mqe_step_end): the comm stream then waits for the policy of step
+    # t+1 and the RCCL kernel shares the GPU with k_substeps (thousands of independent waves: a few displaced CUs cost
+    # their share of 0.2 ms) instead of with the layer-0 GEMM (one workgroup per CU: one displaced workgroup = a second round).
+    ready = [None]                # buffer index packed by the previous step, not gathered yet
+    n_gathers = [0]
+
+    def issue_gather():
+        b = ready[0]
+        if b is not None:
+            pending[b] = dist.all_gather_into_tensor(gather[b], packed[b], async_op=True)
+            ready[0] = None
+            n_gathers[0] += 1
+
+    if world > 1:
+        env.env.between_policy_and_physics = issue_gather
+
     def one_step():
         t = step_no[0]
         a = actions[t]
         step_no[0] += 1
         o, r, d, info = env.step(a)
-        if world > 1:   # the one collective of the path: all-gather the returned batch (packed: obs | reward | done), asynchronous
+        if world > 1:
             b = t & 1
             if pending[b] is not None:
-                pending[b].wait()                     # the gather that used this buffer two steps ago (stream-side wait)
+                pending[b].wait()                     # the gather that read this buffer two steps ago (stream-side wait)
+                pending[b] = None
             pk = packed[b]
             no = o.shape[1] * o.shape[2]
             pk[:, :no] = o.reshape(N, -1)
             pk[:, no:no + A] = r.reshape(N, -1)
             pk[:, no + A] = d
-            pending[b] = dist.all_gather_into_tensor(gather[b], pk, async_op=True)
+            ready[0] = b
         return o
 
     def drain():
+        if world > 1:
+            issue_gather()                            # the last step's batch
         for b in range(2):
             if pending[b] is not None:
                 pending[b].wait()
@@ -160,6 +186,10 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if world > 1:   # every step's batch was gathered, and the last one arrived whole: this rank's slice is its own packed batch
+        b = (args.warmup + args.steps - 1) & 1
+        assert n_gathers[0] == args.warmup + args.steps, (n_gathers[0], args.warmup + args.steps)
+        assert torch.equal(gather[b][rank * N:(rank + 1) * N], packed[b]), "all-gather: own slice differs from the packed batch"
     ms, _ = eng.profile_read(12)
     eng.profile_enable(False)
     if world > 1:

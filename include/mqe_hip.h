@@ -242,6 +242,13 @@ int mqe_reset_all(mqe_sim* s, void* stream);
  * actions: [N, A', 3] raw policy actions in [-1,1] (the wrapper's clip and action_scale are applied inside);
  * results land in MQE_T_WRAPPER_OBS / MQE_T_WRAPPER_REWARD / MQE_T_RESET_BUF. */
 int mqe_step(mqe_sim* s, const float* actions, void* stream);
+/* mqe_step in two halves, for a host that has launches of its own to place between them: _begin enqueues the wrapper head
+ * and the locomotion policy (Go1.step up to go1.py:41), _end the decimation loop, post-physics step and wrapper
+ * (go1.py:46-62).  mqe_step == _begin; _end.  The env-sharded runner issues the all-gather of the PREVIOUS batch between
+ * the two, so that the collective shares the GPU with the physics kernel (wave-granular, tolerant of a few displaced
+ * CUs) and not with the policy GEMM (one workgroup per CU: any displaced workgroup costs a whole extra round). */
+int mqe_step_begin(mqe_sim* s, const float* actions, void* stream);
+int mqe_step_end(mqe_sim* s, void* stream);
 /* The same for the low-level control types "P" / "V" / "T" (Go1.step's else branch, go1.py:42-44 -> pre_physics_step,
  * legged_robot.py:108-110, and the PD / torque laws of legged_robot.py:380-392): actions [R, 12] joint-space actions, clipped
  * to clip_actions inside; no locomotion policy runs.  The decimation loop, post-physics step and (plain) wrapper are the

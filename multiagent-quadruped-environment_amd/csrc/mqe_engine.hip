@@ -65,6 +65,7 @@ struct mqe_sim {
   bool fuse_substeps = true;
   // profiling
   bool prof = false, prof_now = false;   // prof_now: this call is one of the sampled ones
+  bool step_open = false;                // between mqe_step_begin and mqe_step_end
   int prof_every = 1; long prof_step = 0;
   std::vector<hipEvent_t> ev0[PROF_N], ev1[PROF_N];
   float prof_ms[PROF_N];
@@ -688,6 +689,23 @@ extern "C" int mqe_step(mqe_sim* s, const float* actions, void* stream) {
   s->prof_now = s->prof && (s->prof_step++ % s->prof_every == 0);
   policy_step(s, s->st.cmd, q, actions);         // wrapper head (clip, task action scale, scripted defender) inside k_pre_policy
   return run_substeps_and_post(s, q);
+}
+
+extern "C" int mqe_step_begin(mqe_sim* s, const float* actions, void* stream) {
+  hipStream_t q = (hipStream_t)stream;
+  if (s->d.control_type != MQE_CTRL_C) return fail(-7, "mqe_step_begin drives the hierarchical controller (control type C)");
+  if (s->step_open) return fail(-8, "mqe_step_begin: the previous step was not closed with mqe_step_end");
+  s->prof_now = s->prof && (s->prof_step++ % s->prof_every == 0);
+  policy_step(s, s->st.cmd, q, actions);
+  s->step_open = true;
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int mqe_step_end(mqe_sim* s, void* stream) {
+  if (!s->step_open) return fail(-8, "mqe_step_end without mqe_step_begin");
+  s->step_open = false;
+  return run_substeps_and_post(s, (hipStream_t)stream);
 }
 
 static int run_substeps_and_post(mqe_sim* s, hipStream_t q) {

@@ -36,7 +36,7 @@ class HipEngine(EngineBase):
         vp = C.c_void_p
         for name, args in (("policy_step", [vp, vp, vp]), ("compute_torques", [vp, vp]), ("simulate", [vp, vp]),
                            ("post_decimation_step", [vp, C.c_int, vp]), ("post_physics_step", [vp, vp]),
-                           ("reset_all", [vp, vp]), ("step", [vp, vp, vp]), ("step_joint", [vp, vp, vp]), ("defender_command", [vp, vp, vp]),
+                           ("reset_all", [vp, vp]), ("step", [vp, vp, vp]), ("step_begin", [vp, vp, vp]), ("step_end", [vp, vp]), ("step_joint", [vp, vp, vp]), ("defender_command", [vp, vp, vp]),
                            ("wrapper_eval", [vp, C.c_int, vp]),
                            ("debug_dynamics", [vp, C.c_int, C.c_int, vp, C.POINTER(C.c_int), vp]),
                            ("profile_enable", [vp, C.c_int]),
@@ -76,9 +76,18 @@ class HipEngine(EngineBase):
         assert actions12.is_cuda and actions12.dtype == torch.float32 and actions12.is_contiguous()
         self._call("step_joint", C.c_void_p(actions12.data_ptr()), self._stream())
 
-    def step(self, actions):
+    def step(self, actions, between=None):
+        """mqe_step; with `between` (a callable) the two halves mqe_step_begin / mqe_step_end with the callable's own
+        launches placed after the policy kernels and before the physics kernel (see include/mqe_hip.h)."""
         assert actions.is_cuda and actions.dtype == torch.float32 and actions.is_contiguous()
-        self._call("step", C.c_void_p(actions.data_ptr()), self._stream())
+        if between is None:
+            self._call("step", C.c_void_p(actions.data_ptr()), self._stream())
+        else:
+            self._call("step_begin", C.c_void_p(actions.data_ptr()), self._stream())
+            try:
+                between()
+            finally:
+                self._call("step_end", self._stream())
         self._n_policy = getattr(self, "_n_policy", 0) + 1
 
     def defender_command(self, out):

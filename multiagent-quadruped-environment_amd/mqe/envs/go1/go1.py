@@ -257,7 +257,7 @@ class Go1:
         """Wrapper-level step: raw actions (N, A', 3) in [-1,1]; clip, task action scale, policy, 4 substeps,
         post-step, task observation and reward all inside the engine (mqe_step)."""
         a = actions.to(self.engine.torch_device, torch.float32).contiguous()
-        self.engine.step(a)
+        self.engine.step(a, getattr(self, "between_policy_and_physics", None))   # hook of the env-sharded runner (bench.py)
         self._steps_policy = getattr(self, "_steps_policy", 0) + 1
         self.common_step_counter += 1
 

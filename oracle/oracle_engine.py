@@ -74,8 +74,10 @@ class OracleEngine(EngineBase):
         a = np.ascontiguousarray(actions12.detach().cpu().numpy() if hasattr(actions12, "detach") else actions12, np.float32)
         self._call("step_joint", C.c_void_p(a.ctypes.data))
 
-    def step(self, actions):
+    def step(self, actions, between=None):
         a = np.ascontiguousarray(actions.detach().cpu().numpy(), np.float32)
+        if between is not None:      # the HIP engine runs this between its policy and physics launches; here order is all there is
+            between()
         self._call("step", C.c_void_p(a.ctypes.data))
 
     def wrapper_eval(self, is_reset):

@@ -1,0 +1,96 @@
+"""The two-half step of the env-sharded runner (include/mqe_hip.h: mqe_step_begin / mqe_step_end) and bench.py's sharded
+path with the delayed all-gather, on the one GPU of the test box (two ranks on cuda:0 over gloo: the schedule and the
+buffers are the ones of the RCCL run, the transport is not)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from helpers import make_desc, hip_engine
+from mqe.engine import abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def test_step_halves_equal_step():
+    """mqe_step == mqe_step_begin; <host launches>; mqe_step_end -- bit for bit, with work of the host's own in between"""
+    N = 64
+    d0, k0, _ = make_desc("go1gate", N)
+    d1, k1, _ = make_desc("go1gate", N)
+    e0, e1 = hip_engine(d0, k0), hip_engine(d1, k1)
+    e0.reset_all(); e1.reset_all()
+    g = torch.Generator().manual_seed(77)
+    scratch = torch.zeros(1 << 16, device="cuda")
+    calls = []
+
+    def between():
+        calls.append(1)
+        scratch.add_(1.0)          # a launch of the host's own between the policy and the physics kernels
+
+    for t in range(8):
+        a = (torch.rand(N, 2, 3, generator=g) * 2 - 1).cuda().contiguous()
+        e0.step(a)
+        e1.step(a, between)
+    torch.cuda.synchronize()
+    assert len(calls) == 8 and float(scratch[0]) == 8.0
+    for kind in (abi.T_ROOT_STATE, abi.T_DOF_STATE, abi.T_WRAPPER_OBS, abi.T_WRAPPER_REWARD, abi.T_RESET_BUF, abi.T_ACTIONS):
+        assert torch.equal(e0.tensor(kind), e1.tensor(kind)), kind
+
+
+def test_step_end_without_begin_is_an_error():
+    d, k, _ = make_desc("go1gate", 4)
+    e = hip_engine(d, k)
+    e.reset_all()
+    with pytest.raises(RuntimeError):
+        e._call("step_end", e._stream())
+    a = torch.zeros(4, 2, 3, device="cuda")
+    e._call("step_begin", a.data_ptr(), e._stream())
+    with pytest.raises(RuntimeError):          # a second begin before the end
+        e._call("step_begin", a.data_ptr(), e._stream())
+    e._call("step_end", e._stream())
+    torch.cuda.synchronize()
+
+
+def test_bench_two_ranks_delayed_gather():
+    """bench.py --gpus 2 as the driver launches it, both ranks on cuda:0 over gloo: every step's batch is gathered (issued
+    from inside the next step) and arrives whole -- bench.py asserts both"""
+    env = dict(os.environ, MQE_BENCH_SELFTEST_GLOO="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29617", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "3",
+           "--num_envs", "128", "--no_cpu_baseline"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    r = json.loads(line)
+    assert r["n_gpus"] == 2 and r["steps"] == 12 and r["value"] > 0 and r["scaling"] == "weak"
+    assert "128 per GPU (256 total)" in r["config"]["workload"]
+
+
+def test_rccl_process_group_options_single_rank():
+    """the RCCL process group exactly as bench.py creates it for N > 1 (device_id, high-priority stream), world size 1: init,
+    an asynchronous all_gather_into_tensor, wait, barrier, destroy"""
+    code = r'''
+import os, torch, torch.distributed as dist
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29633", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+dist.init_process_group(backend="nccl", device_id=torch.device("cuda", 0), pg_options=opts)
+torch.cuda.set_device(0)
+x = torch.arange(1024, device="cuda", dtype=torch.float32).reshape(32, 32)
+y = torch.empty(32, 32, device="cuda")
+w = dist.all_gather_into_tensor(y, x, async_op=True)
+w.wait()
+dist.barrier()
+torch.cuda.synchronize()
+assert torch.equal(x, y)
+t = torch.tensor([1.5], device="cuda", dtype=torch.float64)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+assert float(t.item()) == 1.5
+dist.destroy_process_group()
+print("rccl ok")
+'''
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 0 and "rccl ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
