@@ -110,30 +110,35 @@ def main():
     eng = env.env.engine
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     obs = env.reset()
-    gather = packed = None
+    gather = None
     pending = [None, None]
+    sent = [None, None]                          # the snapshot each in-flight gather reads (kept alive until it is waited for)
     if world > 1:
-        packed_dim = obs.shape[1] * obs.shape[2] + A + 1
-        gather = [torch.empty(world * N, packed_dim, device=dev) for _ in range(2)]     # double buffer: the all-gather of
-        packed = [torch.empty(N, packed_dim, device=dev) for _ in range(2)]            # step t overlaps step t+1
+        from mqe.engine import abi
+        gather = [torch.empty(world * eng.tensor(abi.T_WRAPPER_PACKED).numel(), device=dev) for _ in range(2)]   # double buffer, [world][L]
 
     # synthetic inputs: one fresh U(-1,1) action tensor per step, generated before the clock starts (the contract times the
     # hot path with its inputs already resident in HBM; 98 kB per step)
     actions = [torch.rand(N, A, 3, device=dev, generator=gen) * 2 - 1 for _ in range(args.warmup + args.steps)]
     step_no = [0]
 
-    # The one collective of the path: all-gather of the returned batch (packed: obs | reward | done), asynchronous and
-    # double-buffered.  The gather of step t is ISSUED inside step t+1, between the policy kernels and the physics kernel
-    # (Go1.between_policy_and_physics -> mqe_step_begin / mqe_step_end): the comm stream then waits for the policy of step
-    # t+1 and the RCCL kernel shares the GPU with k_substeps (thousands of independent waves: a few displaced CUs cost
-    # their share of 0.2 ms) instead of with the layer-0 GEMM (one workgroup per CU: one displaced workgroup = a second round).
-    ready = [None]                # buffer index packed by the previous step, not gathered yet
+    # The one collective of the path: all-gather of the returned batch, asynchronous and double-buffered.  What is gathered
+    # is the snapshot env.step() makes anyway (MQE_T_WRAPPER_PACKED: obs | reward | done, one copy), so the sharded step has
+    # no kernels of its own on the compute stream.  The gather of step t is ISSUED inside step t+1, between the policy
+    # kernels and the physics kernel (Go1.between_policy_and_physics -> mqe_step_begin / mqe_step_end): the comm stream then
+    # waits for the policy of step t+1 and the RCCL kernel shares the GPU with k_substeps (thousands of independent waves:
+    # a few displaced CUs cost their share of 0.2 ms) instead of with the layer-0 GEMM (one workgroup per CU: one displaced
+    # workgroup = a second round).
+    ready = [None]                # (buffer index, snapshot) of the previous step, not gathered yet
     n_gathers = [0]
 
     def issue_gather():
-        b = ready[0]
-        if b is not None:
-            pending[b] = dist.all_gather_into_tensor(gather[b], packed[b], async_op=True)
+        if ready[0] is not None:
+            b, snap = ready[0]
+            if pending[b] is not None:
+                pending[b].wait()                     # the gather that filled this buffer two steps ago (stream-side wait)
+            sent[b] = snap
+            pending[b] = dist.all_gather_into_tensor(gather[b], snap, async_op=True)
             ready[0] = None
             n_gathers[0] += 1
 
@@ -146,16 +151,7 @@ def main():
         step_no[0] += 1
         o, r, d, info = env.step(a)
         if world > 1:
-            b = t & 1
-            if pending[b] is not None:
-                pending[b].wait()                     # the gather that read this buffer two steps ago (stream-side wait)
-                pending[b] = None
-            pk = packed[b]
-            no = o.shape[1] * o.shape[2]
-            pk[:, :no] = o.reshape(N, -1)
-            pk[:, no:no + A] = r.reshape(N, -1)
-            pk[:, no + A] = d
-            ready[0] = b
+            ready[0] = (t & 1, env.returned_batch)
         return o
 
     def drain():
@@ -186,10 +182,12 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:   # every step's batch was gathered, and the last one arrived whole: this rank's slice is its own packed batch
+    if world > 1:   # every step's batch was gathered, and the last one arrived whole: this rank's slice is its own snapshot
         b = (args.warmup + args.steps - 1) & 1
         assert n_gathers[0] == args.warmup + args.steps, (n_gathers[0], args.warmup + args.steps)
-        assert torch.equal(gather[b][rank * N:(rank + 1) * N], packed[b]), "all-gather: own slice differs from the packed batch"
+        mine = gather[b].view(world, -1)[rank]
+        assert torch.equal(mine, env.returned_batch), "all-gather: own slice differs from the returned batch"
+        assert torch.equal(mine[obs.numel() + N * A:] != 0, env.env.reset_buf), "all-gather: done flags"
     ms, _ = eng.profile_read(12)
     eng.profile_enable(False)
     if world > 1:

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MQE_ABI_VERSION 8
+#define MQE_ABI_VERSION 9
 #define MQE_MAX_SPHERES 32
 #define MQE_MAX_SELF_PAIRS 320
 #define MQE_NBODY 13      /* dynamic bodies of one Go1 after fixed-joint collapsing */
@@ -183,8 +183,9 @@ enum {
   MQE_T_RESET_COUNT,       /* int32 [N] */
   MQE_T_SUBSTEP_TORQUES,   /* [N,4,12A] (legged_robot.py:112-115) */
   MQE_T_NPC_NOISE,         /* [N,P,3] injected N(0,1) for the sheep script when noise_mode is SCRIPTED */
-  MQE_T_WRAPPER_PACKED,    /* [N*Aw*D + N*Aw] the wrapper observation and reward as ONE contiguous buffer (obs first): the
-                              returned batch can be snapshotted with a single copy */
+  MQE_T_WRAPPER_PACKED,    /* [N*Aw*D + N*Aw + N] everything a step returns as ONE contiguous buffer: wrapper observation, reward,
+                              then MQE_T_RESET_BUF once more as 0.0 / 1.0 -- snapshotted with a single copy, and that copy is what
+                              the env-sharded runner all-gathers */
   MQE_T_DOMAIN_PARAMS,     /* [R][8]: shape friction of the robot's env, added base mass, base CoM shift xyz, 3 unused; read by every
                               physics step, writable (tests / curricula) */
   MQE_T_COUNT

@@ -56,7 +56,7 @@ struct DevModel {
 // device pointers of all state tensors (kernel argument by value)
 struct DevState {
   float *root, *dof, *cf, *torques, *actions, *last_actions, *loco_obs, *hist, *last_loco, *last_two_loco, *act_hist;
-  float *gait, *clock, *blv, *bav, *pg, *bquat, *obs_bag, *wobs, *wrew, *rsum, *sheep_avg, *sheep_var, *sub_tau, *npc_noise;
+  float *gait, *clock, *blv, *bav, *pg, *bquat, *obs_bag, *wobs, *wrew, *wdone, *rsum, *sheep_avg, *sheep_var, *sub_tau, *npc_noise;
   float *w_last, *w_last2, *cmd, *last_dof_vel;
   float *dparams, *lag_buf;                 // [R][8] friction / added mass / CoM shift (MQE_T_DOMAIN_PARAMS); [(lag + 1)][R][12] scaled actions
   uint16_t* hist2;                          // split-f16 copy of the history ring: [R][270 units][2 planes][8] (k_gemm_h2)

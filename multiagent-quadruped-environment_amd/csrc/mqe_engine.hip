@@ -359,7 +359,7 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   if (s->gemm_split) { DA(st.hist2, (size_t)2 * R * MQE_HIST * MQE_FRAME); }
   DA(st.last_loco, (size_t)R * 12); DA(st.last_two_loco, (size_t)R * 12); DA(st.act_hist, (size_t)4 * R * 12);
   DA(st.gait, R); DA(st.clock, (size_t)R * 4); DA(st.blv, (size_t)R * 3); DA(st.bav, (size_t)R * 3); DA(st.pg, (size_t)R * 3);
-  DA(st.bquat, (size_t)R * 4); DA(st.obs_bag, (size_t)R * MQE_OBS_BAG); DA(st.wobs, (size_t)N * s->Aw * s->D + (size_t)N * s->Aw); st.wrew = st.wobs + (size_t)N * s->Aw * s->D;   // one buffer
+  DA(st.bquat, (size_t)R * 4); DA(st.obs_bag, (size_t)R * MQE_OBS_BAG); DA(st.wobs, (size_t)N * s->Aw * s->D + (size_t)N * s->Aw + N); st.wrew = st.wobs + (size_t)N * s->Aw * s->D; st.wdone = st.wrew + (size_t)N * s->Aw;   // one buffer: obs | reward | done
   DA(st.rsum, (size_t)N * MQE_MAX_REWARD_TERMS); DA(st.sheep_avg, (size_t)N * 2); DA(st.sheep_var, N);
   DA(st.sub_tau, (size_t)N * 4 * 12 * A); DA(st.npc_noise, (size_t)N * (P ? P : 1) * 3);
   DA(st.w_last, (size_t)N * MQE_MAX_AGENTS); DA(st.w_last2, (size_t)N * 2); DA(st.cmd, (size_t)R * 3);
@@ -464,7 +464,7 @@ extern "C" int mqe_sim_tensor(mqe_sim* s, int kind, mqe_tensor_view* v) {
     case MQE_T_SHEEP_POS_VAR: SH(1, N, 0, 0, 0, 0); break;
     case MQE_T_SUBSTEP_TORQUES: SH(3, N, 4, 12 * A, 0, 0); break;
     case MQE_T_NPC_NOISE: SH(3, N, P, 3, 0, 0); break;
-    case MQE_T_WRAPPER_PACKED: SH(1, N * s->Aw * s->D + N * s->Aw, 0, 0, 0, 0); break;
+    case MQE_T_WRAPPER_PACKED: SH(1, N * s->Aw * s->D + N * s->Aw + N, 0, 0, 0, 0); break;
     case MQE_T_DOMAIN_PARAMS: SH(2, s->R, 8, 0, 0, 0); break;
   }
   return 0;

@@ -1,7 +1,7 @@
 """ctypes mirror of include/mqe_hip.h (keep in sync; tests/test_abi.py checks sizes against the built library)."""
 import ctypes as C
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 MAX_SPHERES, NBODY, NREP, NDOF = 32, 13, 17, 12
 MAX_SELF_PAIRS = 320
 MAX_AGENTS, MAX_NPCS, FRAME, HIST, MAX_LAYERS, MAX_REWARD_TERMS = 4, 9, 72, 30, 6, 12

@@ -69,7 +69,7 @@ class FusedTaskWrapper(EmptyWrapper):
         self.action_scale = torch.tensor([[[2, 0.5, 0.5]]], device=env.device).repeat(self.num_envs, self.num_agents, 1)
         self._wobs = env.engine.tensor(abi.T_WRAPPER_OBS)
         self._wrew = env.engine.tensor(abi.T_WRAPPER_REWARD)
-        self._wpack = env.engine.tensor(abi.T_WRAPPER_PACKED)        # obs | reward in one buffer: one snapshot copy per step
+        self._wpack = env.engine.tensor(abi.T_WRAPPER_PACKED)        # obs | reward | done in one buffer: one snapshot copy per step
         assert self._wobs.shape[-1] == self.observation_space.shape[0]
         self.reward_buffer = RewardBuffer([n for _, n in REWARD_TERMS[self.task]], env.engine.tensor(abi.T_REWARD_SUMS))
 
@@ -84,5 +84,6 @@ class FusedTaskWrapper(EmptyWrapper):
         self.env.step_fused(action.reshape(self.num_envs, self.num_agents, 3))
         dict.__setitem__(self.reward_buffer, "step count", dict.__getitem__(self.reward_buffer, "step count") + 1)
         snap = self._wpack.clone()                                     # fresh tensors every step, like the reference
-        n = self._wobs.numel()
-        return snap[:n].view(self._wobs.shape), snap[n:].view(self._wrew.shape), self.env.reset_buf, self.env.extras
+        n, nr = self._wobs.numel(), self._wrew.numel()
+        self.returned_batch = snap                                     # obs | reward | done (0/1): what a sharded runner all-gathers
+        return snap[:n].view(self._wobs.shape), snap[n:n + nr].view(self._wrew.shape), self.env.reset_buf, self.env.extras

@@ -64,7 +64,7 @@ typedef struct mqo_sim {
   float *env_origins, *agent_origins, *base_init, *npc_init, *gate_pos;
   /* state */
   float *root, *dof, *cf, *torques, *actions, *last_actions, *loco_obs, *hist, *last_loco, *last_two_loco;
-  float *act_hist, *gait, *clock, *blv, *bav, *pg, *bquat, *obs_bag, *wobs, *wrew, *rsum, *sheep_avg, *sheep_var;
+  float *act_hist, *gait, *clock, *blv, *bav, *pg, *bquat, *obs_bag, *wobs, *wrew, *wdone, *rsum, *sheep_avg, *sheep_var;
   float *sub_tau, *npc_noise, *last_dof_vel;
   float *dparams, *lag_buf;         /* [R][8] MQE_T_DOMAIN_PARAMS; [(lag + 1)][R][12] scaled actions (domain randomisation, include/mqe_hip.h) */
   int lag_pos;
@@ -319,8 +319,9 @@ int mqo_sim_create(const mqe_sim_desc* d, mqo_sim** out) {
   s->bquat = ALLOCF((size_t)R * 4);
   for (int i = 0; i < R; i++) s->bquat[i * 4 + 3] = 1.0f;
   s->obs_bag = ALLOCF((size_t)R * OBS_BAG);
-  s->wobs = ALLOCF((size_t)N * s->Aw * s->D + (size_t)N * s->Aw);
-  s->wrew = s->wobs + (size_t)N * s->Aw * s->D;        /* one buffer, as in the engine (MQE_T_WRAPPER_PACKED) */
+  s->wobs = ALLOCF((size_t)N * s->Aw * s->D + (size_t)N * s->Aw + N);
+  s->wrew = s->wobs + (size_t)N * s->Aw * s->D;        /* one buffer, as in the engine (MQE_T_WRAPPER_PACKED): obs | reward | done */
+  s->wdone = s->wrew + (size_t)N * s->Aw;
   s->rsum = ALLOCF((size_t)N * MQE_MAX_REWARD_TERMS);
   s->sheep_avg = ALLOCF((size_t)N * 2);
   s->sheep_var = ALLOCF(N);
@@ -406,7 +407,7 @@ int mqo_sim_tensor(mqo_sim* s, int kind, mqe_tensor_view* v) {
     case MQE_T_SHEEP_POS_VAR: SH(1, N, 0, 0, 0, 0); break;
     case MQE_T_SUBSTEP_TORQUES: SH(3, N, 4, 12 * A, 0, 0); break;
     case MQE_T_NPC_NOISE: SH(3, N, P, 3, 0, 0); break;
-    case MQE_T_WRAPPER_PACKED: SH(1, N * s->Aw * s->D + N * s->Aw, 0, 0, 0, 0); break;
+    case MQE_T_WRAPPER_PACKED: SH(1, N * s->Aw * s->D + N * s->Aw + N, 0, 0, 0, 0); break;
     case MQE_T_DOMAIN_PARAMS: SH(2, s->R, 8, 0, 0, 0); break;
   }
   return 0;
@@ -1192,6 +1193,7 @@ static void reset_env(mqo_sim* s, int e) { /* go1.py:110-145, legged_robot.py:39
   for (int k = 0; k < 12 * A; k++) s->last_actions[(size_t)e * 12 * A + k] = 0.0f;
   s->ep_len[e] = 0;
   s->reset_buf[e] = 1;
+  s->wdone[e] = 1.0f;
   for (int a = 0; a < A; a++) {
     int i = e * A + a;
     s->gait[i] = 0.0f;
@@ -1307,6 +1309,7 @@ int mqo_post_physics_step(mqo_sim* s) {
     if (d->termination_flags & MQE_TERM_Z_HIGH) s->zh_term[e] = zh;
     reset |= rterm | pterm | zh;
     s->reset_buf[e] = reset;
+    s->wdone[e] = (float)reset;
     /* reset_buf aliases collide_buf when contact termination is on (legged_robot.py:165) */
     if (d->terminate_on_base_contact) s->collide_buf[e] = reset;
   }

@@ -41,6 +41,35 @@ def test_step_halves_equal_step():
         assert torch.equal(e0.tensor(kind), e1.tensor(kind)), kind
 
 
+def test_packed_return_batch_is_obs_reward_done():
+    """MQE_T_WRAPPER_PACKED = wrapper obs | reward | reset flags as 0/1 floats, in the HIP engine and in the oracle: after
+    reset_all (all flags 1) and along a rollout in which envs do reset (robots dropped from 3 m terminate on base contact)"""
+    from helpers import oracle_engine
+    N = 16
+    d0, k0, _ = make_desc("go1gate", N)
+    d1, k1, _ = make_desc("go1gate", N)
+    eh, eo = hip_engine(d0, k0), oracle_engine(d1, k1)
+    for e in (eh, eo):
+        e.reset_all()
+    seen = 0
+    for t in range(40):
+        a = torch.zeros(N, 2, 3)
+        if t == 3:
+            for e in (eh, eo):
+                r = e.tensor(abi.T_ROOT_STATE)
+                r[:4, 0, 2] += 3.0
+        eh.step(a.cuda()); eo.step(a)
+        torch.cuda.synchronize()
+        for e in (eh, eo):
+            o, r, f = e.tensor(abi.T_WRAPPER_OBS), e.tensor(abi.T_WRAPPER_REWARD), e.tensor(abi.T_RESET_BUF)
+            pk = e.tensor(abi.T_WRAPPER_PACKED)
+            assert pk.numel() == o.numel() + r.numel() + N
+            assert torch.equal(pk[:o.numel()], o.reshape(-1)) and torch.equal(pk[o.numel():o.numel() + r.numel()], r.reshape(-1))
+            assert torch.equal(pk[o.numel() + r.numel():] != 0, f.reshape(-1) != 0)
+        seen += int(eh.tensor(abi.T_RESET_BUF).sum())
+    assert seen > 0, "no env reset in this rollout: the done half of the check did not run"
+
+
 def test_step_end_without_begin_is_an_error():
     d, k, _ = make_desc("go1gate", 4)
     e = hip_engine(d, k)
