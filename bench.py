@@ -167,7 +167,7 @@ def main():
     drain()
     # HIP events around each kernel class on the launch stream, on every PROF_EVERY-th step of the timed region (an event
     # pair costs ~4 us of GPU timeline; bracketing all 5 classes of every step would inflate ms_per_step by 7 %)
-    prof_every = 0 if os.environ.get("MQE_BENCH_NOPROF") else max(1, int(os.environ.get("MQE_BENCH_PROF_EVERY", "8")))
+    prof_every = 0 if os.environ.get("MQE_BENCH_NOPROF") else max(1, int(os.environ.get("MQE_BENCH_PROF_EVERY", "16")))
     eng.profile_enable(prof_every)
     torch.cuda.synchronize()
     if world > 1:
