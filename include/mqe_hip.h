@@ -250,6 +250,11 @@ int mqe_step(mqe_sim* s, const float* actions, void* stream);
  * CUs) and not with the policy GEMM (one workgroup per CU: any displaced workgroup costs a whole extra round). */
 int mqe_step_begin(mqe_sim* s, const float* actions, void* stream);
 int mqe_step_end(mqe_sim* s, void* stream);
+/* Where the following launches write what a step returns (the MQE_T_WRAPPER_PACKED layout: obs | reward | done): a device
+ * buffer of the caller, at least as large as MQE_T_WRAPPER_PACKED, or NULL for the engine's own buffer (the one the
+ * MQE_T_WRAPPER_* views show).  Host-side switch only; a launch uses the buffer that was set when it was enqueued.  The
+ * wrappers hand every step a fresh tensor this way (the reference returns new tensors each step) instead of copying. */
+int mqe_set_return_buffer(mqe_sim* s, float* packed_dev);
 /* The same for the low-level control types "P" / "V" / "T" (Go1.step's else branch, go1.py:42-44 -> pre_physics_step,
  * legged_robot.py:108-110, and the PD / torque laws of legged_robot.py:380-392): actions [R, 12] joint-space actions, clipped
  * to clip_actions inside; no locomotion policy runs.  The decimation loop, post-physics step and (plain) wrapper are the

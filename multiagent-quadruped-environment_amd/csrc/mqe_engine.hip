@@ -702,6 +702,15 @@ extern "C" int mqe_step_begin(mqe_sim* s, const float* actions, void* stream) {
   return 0;
 }
 
+extern "C" int mqe_set_return_buffer(mqe_sim* s, float* packed_dev) {
+  if (!s) return fail(-1, "mqe_set_return_buffer: no engine");
+  float* base = packed_dev ? packed_dev : (float*)s->tens[MQE_T_WRAPPER_PACKED];
+  s->st.wobs = base;
+  s->st.wrew = base + (size_t)s->N * s->Aw * s->D;
+  s->st.wdone = s->st.wrew + (size_t)s->N * s->Aw;
+  return 0;
+}
+
 extern "C" int mqe_step_end(mqe_sim* s, void* stream) {
   if (!s->step_open) return fail(-8, "mqe_step_end without mqe_step_begin");
   s->step_open = false;

@@ -36,7 +36,7 @@ class HipEngine(EngineBase):
         vp = C.c_void_p
         for name, args in (("policy_step", [vp, vp, vp]), ("compute_torques", [vp, vp]), ("simulate", [vp, vp]),
                            ("post_decimation_step", [vp, C.c_int, vp]), ("post_physics_step", [vp, vp]),
-                           ("reset_all", [vp, vp]), ("step", [vp, vp, vp]), ("step_begin", [vp, vp, vp]), ("step_end", [vp, vp]), ("step_joint", [vp, vp, vp]), ("defender_command", [vp, vp, vp]),
+                           ("reset_all", [vp, vp]), ("step", [vp, vp, vp]), ("step_begin", [vp, vp, vp]), ("step_end", [vp, vp]), ("set_return_buffer", [vp, vp]), ("step_joint", [vp, vp, vp]), ("defender_command", [vp, vp, vp]),
                            ("wrapper_eval", [vp, C.c_int, vp]),
                            ("debug_dynamics", [vp, C.c_int, C.c_int, vp, C.POINTER(C.c_int), vp]),
                            ("profile_enable", [vp, C.c_int]),
@@ -89,6 +89,13 @@ class HipEngine(EngineBase):
             finally:
                 self._call("step_end", self._stream())
         self._n_policy = getattr(self, "_n_policy", 0) + 1
+
+    def set_return_buffer(self, packed):
+        """mqe_set_return_buffer: the following launches write obs | reward | done into `packed` (None: the engine's own buffer)"""
+        if packed is not None:
+            assert packed.is_cuda and packed.dtype == torch.float32 and packed.is_contiguous()
+            assert packed.numel() >= self.tensor(abi.T_WRAPPER_PACKED).numel()
+        self._call("set_return_buffer", C.c_void_p(packed.data_ptr() if packed is not None else None))
 
     def defender_command(self, out):
         self._call("defender_command", C.c_void_p(out.data_ptr()), self._stream())

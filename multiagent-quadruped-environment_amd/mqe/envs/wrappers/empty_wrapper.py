@@ -81,9 +81,22 @@ class FusedTaskWrapper(EmptyWrapper):
         return self._wobs.clone()
 
     def step(self, action):
-        self.env.step_fused(action.reshape(self.num_envs, self.num_agents, 3))
+        # fresh tensors every step, like the reference: the HIP engine writes obs | reward | done of this step straight into a
+        # new tensor (mqe_set_return_buffer; the engine's own MQE_T_WRAPPER_* buffer then keeps the previous contents); an
+        # engine without that entry point is snapshotted with one copy
+        eng = self.env.engine
+        direct = hasattr(eng, "set_return_buffer")
+        if direct:
+            snap = torch.empty_like(self._wpack)
+            eng.set_return_buffer(snap)
+        try:
+            self.env.step_fused(action.reshape(self.num_envs, self.num_agents, 3))
+        finally:
+            if direct:
+                eng.set_return_buffer(None)
         dict.__setitem__(self.reward_buffer, "step count", dict.__getitem__(self.reward_buffer, "step count") + 1)
-        snap = self._wpack.clone()                                     # fresh tensors every step, like the reference
+        if not direct:
+            snap = self._wpack.clone()
         n, nr = self._wobs.numel(), self._wrew.numel()
         self.returned_batch = snap                                     # obs | reward | done (0/1): what a sharded runner all-gathers
         return snap[:n].view(self._wobs.shape), snap[n:n + nr].view(self._wrew.shape), self.env.reset_buf, self.env.extras

@@ -123,3 +123,32 @@ print("rccl ok")
 '''
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert out.returncode == 0 and "rccl ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+def test_return_buffer_receives_the_step_outputs():
+    """mqe_set_return_buffer: the step writes obs | reward | done into the caller's tensor (what the wrappers hand out as the
+    step's fresh tensors) and leaves the engine's own buffer alone; NULL switches back"""
+    N = 32
+    d0, k0, _ = make_desc("go1gate", N)
+    d1, k1, _ = make_desc("go1gate", N)
+    e0, e1 = hip_engine(d0, k0), hip_engine(d1, k1)
+    e0.reset_all(); e1.reset_all()
+    g = torch.Generator().manual_seed(3)
+    own_before = e1.tensor(abi.T_WRAPPER_PACKED).clone()
+    bufs = []
+    for t in range(5):
+        a = (torch.rand(N, 2, 3, generator=g) * 2 - 1).cuda().contiguous()
+        e0.step(a)
+        buf = torch.full_like(e1.tensor(abi.T_WRAPPER_PACKED), float("nan"))
+        e1.set_return_buffer(buf)
+        e1.step(a)
+        e1.set_return_buffer(None)
+        torch.cuda.synchronize()
+        assert torch.equal(buf, e0.tensor(abi.T_WRAPPER_PACKED)), t
+        bufs.append(buf)
+    assert torch.equal(e1.tensor(abi.T_WRAPPER_PACKED), own_before)
+    assert not torch.equal(bufs[0], bufs[-1])
+    a = torch.zeros(N, 2, 3, device="cuda")
+    e0.step(a); e1.step(a)                     # back on the engine's own buffer
+    torch.cuda.synchronize()
+    assert torch.equal(e1.tensor(abi.T_WRAPPER_PACKED), e0.tensor(abi.T_WRAPPER_PACKED))
