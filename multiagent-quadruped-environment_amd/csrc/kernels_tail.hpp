@@ -47,6 +47,7 @@ struct TailArgs {
   float* act; int lda;                        // out: raw joint targets [R][lda]
   float *last_loco, *last_two_loco, *actions; float clip_actions;   // post-policy registers [R][12]
   int R;
+  int block0;                                 // index of this batch's first row block among the GLOBAL rows (env_id_offset * A / TL_ROWS)
 };
 
 // ELU with exp(v) - 1 on the hardware exponential: absolute error <= 1.2e-7 (the branchy expm1f polynomial costs more than
@@ -124,7 +125,9 @@ __global__ void __launch_bounds__(256, 1) k_policy_tail(TailArgs g) {
   float* wL0 = bB3 + 64;   float* wL1 = wL0 + 512;  float* nar = wL1 + 512;   // nar: [32][33] raw output of a narrow stage
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r0 = blockIdx.x * TL_ROWS;
-  const int krot = (blockIdx.x * 7) & 31;
+  // k order rotated per row block to spread the L2 requests for the weights; keyed by the GLOBAL row block, so that an env's
+  // summation order (hence its bits) does not depend on which shard of the batch it is computed in
+  const int krot = ((blockIdx.x + g.block0) * 7) & 31;
   const int frow = lane & 31, fhalf = lane >> 5;
   const h2_gvec* Wa1 = (const h2_gvec*)(g.a1.W) + lane;
   const h2_gvec* Wa2 = (const h2_gvec*)(g.a2.W) + lane;

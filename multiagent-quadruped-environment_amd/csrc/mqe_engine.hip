@@ -559,6 +559,7 @@ static int policy_step(mqe_sim* s, const float* command, hipStream_t q, const fl
     t.lat = s->lat; t.ldl = s->ldlat; t.act = s->act_out; t.lda = s->ldact;
     t.last_loco = s->st.last_loco; t.last_two_loco = s->st.last_two_loco; t.actions = s->st.actions; t.clip_actions = s->hm.clip_actions;
     t.R = R;
+    t.block0 = (int)(((long long)s->d.env_id_offset * s->A) / TL_ROWS);
     hipLaunchKernelGGL(k_policy_tail, dim3((R + TL_ROWS - 1) / TL_ROWS), dim3(256), TL_LDS_BYTES, q, t);
     return 0;
   }

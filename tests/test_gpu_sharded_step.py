@@ -152,3 +152,35 @@ def test_return_buffer_receives_the_step_outputs():
     e0.step(a); e1.step(a)                     # back on the engine's own buffer
     torch.cuda.synchronize()
     assert torch.equal(e1.tensor(abi.T_WRAPPER_PACKED), e0.tensor(abi.T_WRAPPER_PACKED))
+
+
+def test_full_size_batch_is_the_union_of_its_shards(monkeypatch):
+    """BASELINE config 1 (4096 envs x 2 agents) against small batches that the oracle tests cover: envs [g0, g0+32) of the full
+    batch and the same global env ids run alone (env_id_offset) go through identical kernels row by row / wave by wave, so 20
+    fused steps must agree BIT FOR BIT -- state, returned batch, reset flags (the layer-0 kernel is pinned to the split-f16
+    one, which the small batch would not pick by itself)."""
+    monkeypatch.setenv("MQE_GEMM_SPLIT", "1")
+    NF, NS = 4096, 32
+    df, kf, _ = make_desc("go1gate", NF)
+    ef = hip_engine(df, kf)
+    ef.reset_all()
+    small = []
+    for g0 in (0, 2016, NF - NS):
+        d, k, _ = make_desc("go1gate", NS, env_id_offset=g0)
+        e = hip_engine(d, k)
+        e.reset_all()
+        small.append((g0, e))
+    g = torch.Generator().manual_seed(11)
+    kinds = (abi.T_ROOT_STATE, abi.T_DOF_STATE, abi.T_WRAPPER_OBS, abi.T_WRAPPER_REWARD, abi.T_RESET_BUF, abi.T_EPISODE_LENGTH)
+    for t in range(-1, 20):
+        if t >= 0:
+            a = torch.rand(NF, 2, 3, generator=g) * 2 - 1
+            ef.step(a.cuda().contiguous())
+            for g0, e in small:
+                e.step(a[g0:g0 + NS].cuda().contiguous())
+        torch.cuda.synchronize()
+        for g0, e in small:
+            for kind in kinds:
+                full = ef.tensor(kind)
+                per = full.shape[0] // NF
+                assert torch.equal(full[g0 * per:(g0 + NS) * per], e.tensor(kind)), f"step {t}, envs from {g0}, tensor kind {kind}"
