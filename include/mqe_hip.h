@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MQE_ABI_VERSION 9
+#define MQE_ABI_VERSION 10
 #define MQE_MAX_SPHERES 32
 #define MQE_MAX_SELF_PAIRS 320
 #define MQE_NBODY 13      /* dynamic bodies of one Go1 after fixed-joint collapsing */
@@ -66,6 +66,8 @@ typedef struct {
   float joint_offset[MQE_NBODY][3];       /* joint origin in the parent frame (entry 0 unused) */
   float joint_axis[MQE_NBODY][3];         /* in the child (= parent at q=0) frame */
   float dof_lower[MQE_NDOF], dof_upper[MQE_NDOF];
+  float dof_vel_limit[MQE_NDOF];          /* URDF <limit velocity> (go1.urdf:115,157,185: 50 / 28 / 28 rad/s; props["velocity"],
+                                             legged_robot.py:315): the solver keeps |joint speed| below it; <= 0 = unlimited */
   int32_t n_spheres;
   int32_t sphere_body[MQE_MAX_SPHERES];
   int32_t sphere_reported[MQE_MAX_SPHERES];
@@ -126,6 +128,11 @@ typedef struct {
   const float* wall_sdf;                  /* host pointer, [sdf_nx][sdf_ny] */
   int32_t sdf_nx, sdf_ny;
   float horizontal_scale, wall_height, ground_z;
+  /* low relief of the walkable surface (Perlin noise, barrier_track.py:372-393,421-439; perlin.py:33-72): height [m] above
+   * ground_z at the same cell centres as wall_sdf, [sdf_nx][sdf_ny] host pointer, or NULL for the flat slab */
+  const float* ground_height;
+  float soft_dof_pos_limit;               /* rewards.soft_dof_pos_limit (legged_robot.py:317-321): fraction of the URDF joint range
+                                             outside of which MQE_T_SUBSTEP_EXCEED_DOF_POS_LIMITS flags a joint; 0 = 1.0 */
   /* per-env constants, host pointers */
   const float* env_origins;               /* [N,3] */
   const float* agent_origins;             /* [N,A,3] */
@@ -188,6 +195,10 @@ enum {
                               the env-sharded runner all-gathers */
   MQE_T_DOMAIN_PARAMS,     /* [R][8]: shape friction of the robot's env, added base mass, base CoM shift xyz, 3 unused; read by every
                               physics step, writable (tests / curricula) */
+  MQE_T_SUBSTEP_DOF_VEL,   /* [N,4,12A] joint velocities after each substep (legged_robot.py:114) */
+  MQE_T_SUBSTEP_EXCEED_DOF_POS_LIMITS,   /* uint8 [N,4,12A] joint outside its soft position limits after each substep (legged_robot.py:115) */
+  MQE_T_CONTACT_OVERFLOW,  /* int32 [N]: substeps so far in which the bounded contact list of the env dropped a touching pair (per-actor
+                              cap or list end); 0 everywhere = no contact was ever truncated */
   MQE_T_COUNT
 };
 
@@ -260,6 +271,11 @@ int mqe_set_return_buffer(mqe_sim* s, float* packed_dev);
  * to clip_actions inside; no locomotion policy runs.  The decimation loop, post-physics step and (plain) wrapper are the
  * fused ones. */
 int mqe_step_joint(mqe_sim* s, const float* actions12, void* stream);
+
+/* debug taps (tests): M^-1 (18 x 18) of one robot and the contact list of one env ([<= 64][8]: actor A, link A, actor B (-1 static),
+ * link B, separation, normal xyz) from the CURRENT state, without advancing it; outputs are host pointers */
+int mqe_debug_dynamics(mqe_sim* s, int env, int robot, float* minv_out_host, int* nc_out_host, float* contacts_out_host);
+int mqe_debug_times(long long* out16);   /* clock64 stamps of the phases of the last mqe_debug_dynamics launch */
 
 /* bookkeeping for benchmarks: time of the dominant kernel measured with HIP events on `stream` */
 int mqe_profile_enable(mqe_sim* s, int on);

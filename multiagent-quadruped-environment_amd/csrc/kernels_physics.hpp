@@ -618,6 +618,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   }
   // ---- contact generation: terrain (ground plane, wall SDF), canonical order --------------------------------------------
   int nc = 0;
+  int ovf = 0;                      // wave-uniform: a touching pair did not fit the bounded list (per-actor cap or list end)
   // Passes over whole actors, lane = sphere: two robots per pass (2 x 27 spheres), all single-sphere NPCs in one pass
   // (multi-sphere NPCs: one per pass).  The list order stays canonical -- actor by actor, sphere by sphere, ground /
   // wall / platform / column -- because a lane's slot = contacts of earlier groups (capped) + its rank in its group.
@@ -704,13 +705,13 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     const int pre = __popcll(bg & gl) + __popcll(bw2 & gl) + __popcll(bb2 & gl) + __popcll(bc2 & gl);   // rank in my actor
     int tot0 = __popcll(bg & m0) + __popcll(bw2 & m0) + __popcll(bb2 & m0) + __popcll(bc2 & m0);          // first robot of the pass
     int tot1 = 0;
-    if (tot0 > cap) tot0 = cap;
+    if (tot0 > cap) { tot0 = cap; if (rob || !npc_fast) ovf = 1; }      // (the single-sphere NPC pass recounts below: its cap never binds)
     int base = nc;
     if (rob) {
       if (rpp == 2) {
         const unsigned long long m1 = m0 << nsr;
         tot1 = __popcll(bg & m1) + __popcll(bw2 & m1) + __popcll(bb2 & m1) + __popcll(bc2 & m1);
-        if (tot1 > cap) tot1 = cap;
+        if (tot1 > cap) { tot1 = cap; ovf = 1; }
       }
       base = nc + (sub ? tot0 : 0);
     } else if (npc_fast) {                 // one sphere per actor: <= 2 contacts each, the cap never binds
@@ -743,7 +744,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       }
     }
     nc += tot0 + tot1;
-    if (nc > maxc) nc = maxc;
+    if (nc > maxc) { nc = maxc; ovf = 1; }
   }
   // robot spheres vs the seesaw plank (dynamic: couples the robots through the hinge); after all terrain contacts
   const int nc_terr = nc;                                   // one-sided contacts end here; two-actor contacts follow
@@ -769,9 +770,9 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
         con_store(cr, a, body, A, 0, c - rad * n, n, sd, rep, A * MQE_NREP + 1);
       }
       int tot = __popcll(bh);
-      if (tot > capP) tot = capP;
+      if (tot > capP) { tot = capP; ovf = 1; }
       nc += tot;
-      if (nc > pair_lim) nc = pair_lim;
+      if (nc > pair_lim) { nc = pair_lim; ovf = 1; }
     }
   }
   TSTAMP(9);
@@ -801,7 +802,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
             con_store(cr, a, rm.sphere_body[lane], b, 0, c - (ra + 0.5f * sd) * n, n, sd, a * MQE_NREP + rm.sphere_reported[lane], A * MQE_NREP + (b - A));
           }
           nc += __popcll(bh);
-          if (nc > pair_lim) nc = pair_lim;
+          if (nc > pair_lim) { nc = pair_lim; ovf = 1; }
           continue;
         }
         if (dot(dd, dd) > 1.2f * 1.2f) continue;              // wave-uniform broad phase
@@ -833,7 +834,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
             con_store(cr, a, bodyA, b, bodyB, cb + (rb + 0.5f * sd) * n, n, sd, repA, repB);
           }
           nc += __popcll(bh);
-          if (nc > pair_lim) nc = pair_lim;
+          if (nc > pair_lim) { nc = pair_lim; ovf = 1; }
         }
       }
     // links of one robot against each other (asset.self_collisions = 0): lanes = candidate sphere pairs (same link and
@@ -885,7 +886,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
                       a * MQE_NREP + rm.sphere_reported[sj]);
           }
           nc += __popcll(bh);
-          if (nc > pair_lim) nc = pair_lim;
+          if (nc > pair_lim) { nc = pair_lim; ovf = 1; }
         }
       }
     }
@@ -1167,19 +1168,30 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     Vm[d] = v;
   }
   __syncthreads();
-  // joint limits: one sequential pass in (robot, joint) order after the contact solve, only when some joint violates
+  // joint limits: one sequential pass in (robot, joint) order after the contact solve, only when some joint violates.  The bound
+  // of a joint's speed is the tighter of its position stops ((limit - q) / dt) and the URDF velocity limit (go1.urdf:115,157,185;
+  // PhysX maxJointVelocity); a violation is removed by an impulse along the joint coordinate, so momentum is exchanged with the
+  // rest of the robot instead of disappearing.
   {
+    auto jbound = [&](int j, float q, float& lo, float& hi) {
+      lo = (rm.dof_lower[j] - q) / dt; hi = (rm.dof_upper[j] - q) / dt;
+      const float vl = rm.dof_vel_limit[j];
+      if (vl > 0.0f) { lo = fmaxf(lo, -vl); hi = fminf(hi, vl); }
+    };
     bool viol = false;
     for (int d = lane; d < A * 12; d += 64) {
       const int r = d / 12, j = d - r * 12;
       const float q = lds[L.dof + d * 2], v = Vm[r * MQE_RD + 6 + j];
-      viol = viol || v < (rm.dof_lower[j] - q) / dt || v > (rm.dof_upper[j] - q) / dt;
+      float lo, hi;
+      jbound(j, q, lo, hi);
+      viol = viol || v < lo || v > hi;
     }
     if (__ballot(viol) != 0ull) {
       for (int r = 0; r < A; r++)
         for (int j = 0; j < 12; j++) {
           const float q = lds[L.dof + (r * 12 + j) * 2], vj = Vm[r * MQE_RD + 6 + j];
-          const float lo = (rm.dof_lower[j] - q) / dt, hi = (rm.dof_upper[j] - q) / dt;
+          float lo, hi;
+          jbound(j, q, lo, hi);
           float vio = 0.0f;
           if (vj < lo) vio = lo - vj; else if (vj > hi) vio = hi - vj;
           if (vio != 0.0f) {                          // wave-uniform
@@ -1211,6 +1223,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     }
   }
   if (no_write) return;
+  if (ovf && lane == 0) st.overflow[e] += 1;          // MQE_T_CONTACT_OVERFLOW: this substep's list was truncated
 
   // ---- net contact force per reported body (deterministic: contact order) ---------------------------------------------------
   if (flags & PS_WRITE_CF) {
@@ -1402,6 +1415,14 @@ __global__ void __launch_bounds__(64, 2) k_substeps(const DevModel* __restrict__
     }
     __syncthreads();
     phys_substep<TA, TP>(m, st, lds, e, lane, last ? (PS_STORE_STATE | PS_WRITE_CF) : 0, 0, nodbg);
+    // post_decimation_step (legged_robot.py:114-115): joint velocities and soft-limit flags after this substep, from the LDS state
+    for (int jt = lane; jt < nj; jt += 64) {
+      const float q = lds[L.dof + jt * 2], qd = lds[L.dof + jt * 2 + 1];
+      const int j = jt % 12;
+      const size_t o = ((size_t)e * 4 + (k < 4 ? k : 3)) * nj + jt;
+      st.sub_dof_vel[o] = qd;
+      st.sub_exceed[o] = (uint8_t)((q < m->soft_lo[j]) | (q > m->soft_hi[j]));
+    }
   }
 #pragma unroll
   for (int t = 0; t < ACT_TILES; t++) {

@@ -51,6 +51,11 @@ __device__ __forceinline__ float lag_target(const DevModel* m, const DevState& s
 // ----------------------------------------------------------------------------------------------------------------
 // wrapper.step head: clip(action,-1,1) * action_scale (go1_sheep_wrapper.py:55-56) -> per-robot command; the scripted
 // defender command of go1football-defender (go1_football_defender.py:56-80) fills agent 2.  One thread per env.
+// a / b and atan(a / b) with the IEEE results of the reference's torch expressions spelt out for b == 0 (the engine is built with
+// -fno-honor-infinities / -fno-honor-nans, under which a division by zero is undefined): +-inf resp. +-pi/2; 0 / 0 (NaN in torch) -> 0
+__device__ __forceinline__ float div_ieee(float a, float b) { return b != 0.0f ? a / b : (a > 0.0f ? 3.0e38f : (a < 0.0f ? -3.0e38f : 0.0f)); }
+__device__ __forceinline__ float atan_ratio(float a, float b) { return b != 0.0f ? atanf(a / b) : (a > 0.0f ? 1.5707964f : (a < 0.0f ? -1.5707964f : 0.0f)); }
+
 __device__ __forceinline__ void defender_command_dev(const DevModel* m, const DevState& st, int e, float* cmd3) {
   int A = m->A, P = m->P;
   const float* root = st.root + (size_t)e * (A + P) * 13;
@@ -60,12 +65,12 @@ __device__ __forceinline__ void defender_command_dev(const DevModel* m, const De
   float tp[3];
   for (int k = 0; k < 3; k++) tp[k] = 0.6f * bp[k] + 0.4f * gate[k];
   float yaw = st.obs_bag[(size_t)(e * A + 2) * MQE_OBS_BAG + 5];
-  float yaw_to_gate = 3.1415927f + atanf((gate[1] - dp[1]) / (gate[0] - dp[0]));
+  float yaw_to_gate = 3.1415927f + atan_ratio(gate[1] - dp[1], gate[0] - dp[0]);
   float yc = clampf(yaw_to_gate - yaw, -0.3f, 0.3f) / 0.3f;
   float tdg = sqrtf((tp[0] - gate[0]) * (tp[0] - gate[0]) + (tp[1] - gate[1]) * (tp[1] - gate[1]));
   float ddg = sqrtf((dp[0] - gate[0]) * (dp[0] - gate[0]) + (dp[1] - gate[1]) * (dp[1] - gate[1]));
   float xc = clampf(tdg - ddg, -0.5f, 0.5f);
-  float yy = -clampf(gate[1] + (tp[1] - gate[1]) * (dp[0] - gate[0]) / (tp[0] - gate[0]) - dp[1], -0.5f, 0.5f);
+  float yy = -clampf(gate[1] + div_ieee((tp[1] - gate[1]) * (dp[0] - gate[0]), tp[0] - gate[0]) - dp[1], -0.5f, 0.5f);
   cmd3[0] = xc; cmd3[1] = yy; cmd3[2] = yc;
 }
 
@@ -359,7 +364,15 @@ __device__ __forceinline__ void reset_env_dev(const DevModel* m, const DevState&
   st.reset_count[e] = cnt + 1;
 }
 
-__device__ __forceinline__ void step_sheep_env(const DevModel* m, const DevState& st, int e) {
+// N(0,1) of the sheep's random walk (go1_sheep.py:43: randn_like per step) in MQE_NOISE_HASH mode: Box-Muller over the counter
+// RNG keyed by (seed, GLOBAL env id, ordinal of the post-physics step, sheep * 3 + axis) -- independent of the GPU count
+__device__ __forceinline__ float mqe_randn(const DevModel* m, int e, int step_no, uint32_t k) {
+  const uint32_t cnt = MQE_RNG_NPC + (uint32_t)step_no, genv = (uint32_t)(e + m->env_id_offset);
+  const float u1 = mqe_u01((uint32_t)m->seed, genv, cnt, 2u * k), u2 = mqe_u01((uint32_t)m->seed, genv, cnt, 2u * k + 1u);
+  return sqrtf(-2.0f * logf(1.0f - u1)) * cosf(6.2831855f * u2);
+}
+
+__device__ __forceinline__ void step_sheep_env(const DevModel* m, const DevState& st, int e, int step_no) {
   int A = m->A, P = m->P;
   float* root = st.root + (size_t)e * (A + P) * 13;
   float avg[3] = {0, 0, 0};
@@ -377,11 +390,18 @@ __device__ __forceinline__ void step_sheep_env(const DevModel* m, const DevState
   for (int p = 0; p < P; p++) {
     const float* sp = root + (A + p) * 13;
     float dv[3];
-    for (int k = 0; k < 3; k++) dv[k] = m->sheep_rand * st.npc_noise[((size_t)e * P + p) * 3 + k] * 2.0f;
+    for (int k = 0; k < 3; k++) {
+      // MQE_NOISE_SCRIPTED: the injected sequence (golden traces); otherwise a fresh draw every step, as the reference's randn_like
+      const float z = m->noise_mode == MQE_NOISE_SCRIPTED ? st.npc_noise[((size_t)e * P + p) * 3 + k]
+                                                          : (m->sheep_rand != 0.0f ? mqe_randn(m, e, step_no, (uint32_t)(p * 3 + k)) : 0.0f);
+      dv[k] = m->sheep_rand * z * 2.0f;
+    }
     if (P != 1) {
       float rel[3] = {avg[0] - sp[0], avg[1] - sp[1], avg[2] - sp[2]};
       float nr = sqrtf(rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2]);
-      for (int k = 0; k < 3; k++) dv[k] += m->sheep_rand * rel[k] / nr / 1.5f;
+      // a sheep exactly on the flock mean (the centre of the 3 x 3 grid at reset): torch gives 0 / 0 = NaN, which the clip of
+      // go1_sheep.py:59 passes on; the engine is built with -fno-honor-nans, so the cohesion term is dropped there instead
+      if (nr > 0.0f) for (int k = 0; k < 3; k++) dv[k] += m->sheep_rand * rel[k] / nr / 1.5f;
     }
     for (int a = 0; a < A; a++) {
       const float* dp = root + a * 13;
@@ -591,7 +611,7 @@ __device__ void wrapper_env_dev(const DevModel* m, const DevState& st, int e, in
         const float px = pa == 0 ? bx[0] : (pa == 1 ? bx[1] : (pa == 2 ? bx[2] : bx[3]));
         const float py = pa == 0 ? by[0] : (pa == 1 ? by[1] : (pa == 2 ? by[2] : by[3]));
         const float d2 = (bx[a] - px) * (bx[a] - px) + (by[a] - py) * (by[a] - py);
-        if (d2 < 0.25f) { const float pn = sc[3] / d2; r_ag[a] += pn; rs3 += pn; }
+        if (d2 < 0.25f) { const float pn = div_ieee(sc[3], d2); r_ag[a] += pn; rs3 += pn; }
       }
     rs[0] = rs0; rs[1] = rs1; rs[2] = rs2; rs[3] = rs3;
     float tot = 0;
@@ -655,7 +675,7 @@ __device__ void wrapper_env_dev(const DevModel* m, const DevState& st, int e, in
     if (sc[4] != 0) {
       const float* o0 = bag; const float* o1 = bag + (A - 1) * MQE_OBS_BAG;
       float d2 = (o0[0] - o1[0]) * (o0[0] - o1[0]) + (o0[1] - o1[1]) * (o0[1] - o1[1]);
-      if (d2 < 0.25f) { float v = sc[4] / d2; r_env += v; rs[4] += v; }
+      if (d2 < 0.25f) { float v = div_ieee(sc[4], d2); r_env += v; rs[4] += v; }
     }
     if (sc[5] != 0) {
       int cnt = 0;
@@ -715,7 +735,7 @@ __device__ __forceinline__ void post_flush_rows(float* __restrict__ g, const flo
 
 // AM: compile-time bound of the agent lanes (>= m->A; 2 for the two-robot tasks, MQE_MAX_AGENTS otherwise)
 template <int AM>
-__global__ void __launch_bounds__(64) k_post_physics(const DevModel* m, DevState st, int wrapper_level, int push_count) {
+__global__ void __launch_bounds__(64) k_post_physics(const DevModel* m, DevState st, int wrapper_level, int push_count, int step_no) {
   static_assert(POST_EPW * AM <= 64 && (POST_EPW & (POST_EPW - 1)) == 0, "agent lanes of POST_EPW envs must fit one wavefront");
   // The per-robot rows this block produces (obs bag 74, last action 12, last dof velocity 12) are contiguous in HBM over
   // the block's envs: the robot lanes write them to LDS (the wrapper reads the obs rows back from there, not through L2)
@@ -819,7 +839,7 @@ __global__ void __launch_bounds__(64) k_post_physics(const DevModel* m, DevState
   float npc_pre[MQE_MAX_NPCS * 13];
   if (lead) {
     for (int k = 0; k < P * 13; k++) npc_pre[k] = root[A * 13 + k];
-    if (m->npc_kind == MQE_NPC_SHEEP) step_sheep_env(m, st, e);
+    if (m->npc_kind == MQE_NPC_SHEEP) step_sheep_env(m, st, e, step_no);
     if (reset) {                                // rare: the reset writes memory, the robot lanes refresh their registers from it
       reset_env_dev(m, st, e);
       for (int k = 0; k < P * 13; k++) npc_pre[k] = root[A * 13 + k];

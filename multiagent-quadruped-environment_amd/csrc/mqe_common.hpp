@@ -25,7 +25,7 @@ struct DevMlp {
 struct DevModel {
   int N, A, P, R, ND, NBR, Aw, D;          // envs, agents, npcs, robots, dofs/env, reported bodies/env, wrapper dims
   int npc_kind, task, npc_dofs_each, npc_lin_only, n_npc_dyn;   // dynamic NPC bodies (ball/sheep) handled by the solver
-  int env_id_offset, seed;
+  int env_id_offset, seed, noise_mode;
   float dt; int decimation; float gravity_z; int solver_iterations;
   float contact_offset, max_depen, friction, erp;
   mqe_robot_model robot;
@@ -40,6 +40,8 @@ struct DevModel {
   int control_type; float action_scale, hip_scale_reduction, clip_actions; float torque_limits[12]; float kp, kd;
   float default_dof_pos[12]; float command_obs[70]; float cmd_lin_scale, cmd_ang_scale; int clip_command;
   const float* wall_sdf; int sdf_nx, sdf_ny; float hs, wall_height, ground_z;
+  const float* ground_height;                      // relief of the walkable surface above ground_z at the SDF's cell centres, or nullptr
+  float soft_lo[12], soft_hi[12];                  // soft joint position limits (legged_robot.py:317-321) of MQE_T_SUBSTEP_EXCEED_DOF_POS_LIMITS
   const float *env_origins, *agent_origins, *base_init, *npc_init, *gate_pos;
   int termination_flags, terminate_on_base_contact, max_episode_length;
   float roll_thr, pitch_thr, zlow_thr, zhigh_thr;
@@ -58,6 +60,7 @@ struct DevState {
   float *root, *dof, *cf, *torques, *actions, *last_actions, *loco_obs, *hist, *last_loco, *last_two_loco, *act_hist;
   float *gait, *clock, *blv, *bav, *pg, *bquat, *obs_bag, *wobs, *wrew, *wdone, *rsum, *sheep_avg, *sheep_var, *sub_tau, *npc_noise;
   float *w_last, *w_last2, *cmd, *last_dof_vel;
+  float* sub_dof_vel; uint8_t* sub_exceed; int32_t* overflow;   // per-substep logs (legged_robot.py:114-115); truncated-contact-list counter
   float *dparams, *lag_buf;                 // [R][8] friction / added mass / CoM shift (MQE_T_DOMAIN_PARAMS); [(lag + 1)][R][12] scaled actions
   uint16_t* hist2;                          // split-f16 copy of the history ring: [R][270 units][2 planes][8] (k_gemm_h2)
   int32_t *ep_len, *reset_count;
@@ -77,6 +80,7 @@ __host__ __device__ __forceinline__ float mqe_u01(uint32_t seed, uint32_t genv, 
 }
 #define MQE_RNG_CREATE 0xD0D0D0D0u         // `count` of the draws made once per handle (domain parameters)
 #define MQE_RNG_PUSH 0x50000000u           // + ordinal of the push
+#define MQE_RNG_NPC 0x60000000u            // + ordinal of the post-physics step: the sheep's per-step N(0,1) draws
 
 
 // f32 -> two f16 planes of scale * x (h + l == scale * x to 22 significand bits); see k_gemm_h2 in kernels_gemm.hpp

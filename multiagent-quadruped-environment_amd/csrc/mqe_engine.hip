@@ -207,6 +207,8 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(-3, "no HIP device: the engine has no CPU path");
   mqe_sim* s = new mqe_sim();
+  // every error exit below releases the handle and whatever it has allocated so far; success disarms the guard
+  struct Guard { mqe_sim* s; ~Guard() { if (s) mqe_sim_destroy(s); } } guard{s};
   s->d = *d;
   const int N = s->N = d->num_envs, A = s->A = d->num_agents, P = s->P = d->num_npcs;
   const int R = s->R = N * A;
@@ -228,7 +230,7 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   memcpy(m.npc_box_half, d->npc_box_half, sizeof m.npc_box_half);
   m.npc_lin_only = d->npc_kind == MQE_NPC_SHEEP;
   m.npc_dofs_each = seesaw ? 1 : (m.npc_lin_only ? 3 : 6);
-  m.env_id_offset = d->env_id_offset; m.seed = d->seed;
+  m.env_id_offset = d->env_id_offset; m.seed = d->seed; m.noise_mode = d->noise_mode;
   m.dt = d->dt; m.decimation = d->decimation; m.gravity_z = d->gravity_z; m.solver_iterations = d->solver_iterations;
   m.contact_offset = d->contact_offset; m.max_depen = d->max_depenetration_velocity; m.friction = d->friction; m.erp = d->erp;
   m.robot = d->robot;
@@ -263,21 +265,29 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   m.ndof_env = A * MQE_RD + m.n_npc_dyn * m.npc_dofs_each + (seesaw ? 1 : 0);
   m.nsph_env = A * d->robot.n_spheres + m.n_npc_dyn * d->npc_n_spheres;
   m.maxc = mqe_maxc(A, P, m.cap_npc);
-  if (m.ndof_env > 128 || m.nbody_env > 64) { delete s; return fail(-4, "env has more than 64 bodies or 128 generalized velocities: does not fit one wavefront"); }
+  if (m.ndof_env > 128 || m.nbody_env > 64) { return fail(-4, "env has more than 64 bodies or 128 generalized velocities: does not fit one wavefront"); }
   PhysLds L = phys_lds_layout(A, P, s->ND, m.nbody_env, m.ndof_env, m.nsph_env, m.maxc);
   s->phys_lds_bytes = (size_t)L.total * 4;
   // the records the physics kernel moves as 16 B words must start on 16 B (kernels_physics.hpp)
-  if ((L.body | L.sph | L.con | L.js | L.leg | L.fcol) & 3) { delete s; return fail(-4, "physics LDS layout: a 16 B record area is misaligned"); }
-  if (s->phys_lds_bytes > 160 * 1024) { delete s; return fail(-4, "physics LDS footprint exceeds 160 KiB"); }
+  if ((L.body | L.sph | L.con | L.js | L.leg | L.fcol) & 3) { return fail(-4, "physics LDS layout: a 16 B record area is misaligned"); }
+  if (s->phys_lds_bytes > 160 * 1024) { return fail(-4, "physics LDS footprint exceeds 160 KiB"); }
   s->substeps_fn = pick_substeps(m);
   if (s->phys_lds_bytes > 48 * 1024)
     if (hipFuncSetAttribute((const void*)k_simulate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->phys_lds_bytes) != hipSuccess ||
         hipFuncSetAttribute((const void*)s->substeps_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->phys_lds_bytes) != hipSuccess) {
-      delete s; return fail(-4, "cannot raise dynamic LDS limit");
+      return fail(-4, "cannot raise dynamic LDS limit");
     }
   s->fuse_substeps = getenv("MQE_NO_FUSE_SUBSTEPS") == nullptr && d->decimation <= 4;
 #define UP(dst, src, n) if (upload(s, &(dst), (src), (n))) { return fail(-5, "device upload failed"); }
   UP(m.wall_sdf, d->wall_sdf, (size_t)d->sdf_nx * d->sdf_ny);
+  UP(m.ground_height, d->ground_height, (size_t)d->sdf_nx * d->sdf_ny);
+  {
+    const float soft = d->soft_dof_pos_limit > 0.0f ? d->soft_dof_pos_limit : 1.0f;
+    for (int j = 0; j < MQE_NDOF; j++) {          // legged_robot.py:317-321
+      const float mid = (d->robot.dof_lower[j] + d->robot.dof_upper[j]) / 2, r = d->robot.dof_upper[j] - d->robot.dof_lower[j];
+      m.soft_lo[j] = mid - 0.5f * r * soft; m.soft_hi[j] = mid + 0.5f * r * soft;
+    }
+  }
   UP(m.env_origins, d->env_origins, (size_t)N * 3);
   UP(m.agent_origins, d->agent_origins, (size_t)N * A * 3);
   UP(m.base_init, d->base_init_state, (size_t)A * 13);
@@ -361,6 +371,7 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   DA(st.gait, R); DA(st.clock, (size_t)R * 4); DA(st.blv, (size_t)R * 3); DA(st.bav, (size_t)R * 3); DA(st.pg, (size_t)R * 3);
   DA(st.bquat, (size_t)R * 4); DA(st.obs_bag, (size_t)R * MQE_OBS_BAG); DA(st.wobs, (size_t)N * s->Aw * s->D + (size_t)N * s->Aw + N); st.wrew = st.wobs + (size_t)N * s->Aw * s->D; st.wdone = st.wrew + (size_t)N * s->Aw;   // one buffer: obs | reward | done
   DA(st.rsum, (size_t)N * MQE_MAX_REWARD_TERMS); DA(st.sheep_avg, (size_t)N * 2); DA(st.sheep_var, N);
+  DA(st.sub_dof_vel, (size_t)N * 4 * 12 * A); DA(st.sub_exceed, (size_t)N * 4 * 12 * A); DA(st.overflow, N);
   DA(st.sub_tau, (size_t)N * 4 * 12 * A); DA(st.npc_noise, (size_t)N * (P ? P : 1) * 3);
   DA(st.w_last, (size_t)N * MQE_MAX_AGENTS); DA(st.w_last2, (size_t)N * 2); DA(st.cmd, (size_t)R * 3);
   DA(st.ep_len, N); DA(st.reset_count, N); DA(st.last_dof_vel, (size_t)R * 12);
@@ -418,7 +429,9 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   t[MQE_T_SHEEP_POS_AVG] = st.sheep_avg; t[MQE_T_SHEEP_POS_VAR] = st.sheep_var; t[MQE_T_RESET_COUNT] = st.reset_count;
   t[MQE_T_SUBSTEP_TORQUES] = st.sub_tau; t[MQE_T_NPC_NOISE] = st.npc_noise; t[MQE_T_WRAPPER_PACKED] = st.wobs;
   t[MQE_T_DOMAIN_PARAMS] = st.dparams;
+  t[MQE_T_SUBSTEP_DOF_VEL] = st.sub_dof_vel; t[MQE_T_SUBSTEP_EXCEED_DOF_POS_LIMITS] = st.sub_exceed; t[MQE_T_CONTACT_OVERFLOW] = st.overflow;
   HIPCHK(hipDeviceSynchronize());
+  guard.s = nullptr;
   *out = s;
   return 0;
 }
@@ -462,7 +475,9 @@ extern "C" int mqe_sim_tensor(mqe_sim* s, int kind, mqe_tensor_view* v) {
     case MQE_T_REWARD_SUMS: SH(2, N, MQE_MAX_REWARD_TERMS, 0, 0, 0); break;
     case MQE_T_SHEEP_POS_AVG: SH(2, N, 2, 0, 0, 0); break;
     case MQE_T_SHEEP_POS_VAR: SH(1, N, 0, 0, 0, 0); break;
-    case MQE_T_SUBSTEP_TORQUES: SH(3, N, 4, 12 * A, 0, 0); break;
+    case MQE_T_SUBSTEP_TORQUES: case MQE_T_SUBSTEP_DOF_VEL: SH(3, N, 4, 12 * A, 0, 0); break;
+    case MQE_T_SUBSTEP_EXCEED_DOF_POS_LIMITS: SH(3, N, 4, 12 * A, 0, 2); break;
+    case MQE_T_CONTACT_OVERFLOW: SH(1, N, 0, 0, 0, 1); break;
     case MQE_T_NPC_NOISE: SH(3, N, P, 3, 0, 0); break;
     case MQE_T_WRAPPER_PACKED: SH(1, N * s->Aw * s->D + N * s->Aw + N, 0, 0, 0, 0); break;
     case MQE_T_DOMAIN_PARAMS: SH(2, s->R, 8, 0, 0, 0); break;
@@ -486,6 +501,7 @@ struct ProfScope {
 // on = 0: off; on = k > 0: the kernel classes of every k-th fused step are bracketed with HIP events on the launch stream (an
 // event pair costs ~4 us of GPU timeline, 5 classes = 7 % of a 0.5 ms step: sampling keeps the measurement out of the result)
 extern "C" int mqe_profile_enable(mqe_sim* s, int on) {
+  if (!s) return fail(-1, "null engine handle");
   s->prof = on != 0;
   s->prof_every = on > 0 ? on : 1;
   s->prof_step = 0;
@@ -493,6 +509,7 @@ extern "C" int mqe_profile_enable(mqe_sim* s, int on) {
   return 0;
 }
 extern "C" int mqe_profile_read(mqe_sim* s, float* ms, int n, int* n_launches) {
+  if (!s) return fail(-1, "null engine handle");
   HIPCHK(hipDeviceSynchronize());
   for (int k = 0; k < PROF_N; k++) {
     for (size_t i = 0; i < s->ev0[k].size(); i++) {
@@ -610,44 +627,65 @@ static void launch_post(mqe_sim* s, hipStream_t q, int wrapper_level) {
   s->n_post_steps++;                          // = common_step_counter after its increment (legged_robot.py:127)
   const int push = (s->d.push_interval > 0 && s->n_post_steps % s->d.push_interval == 0) ? (int)(s->n_post_steps / s->d.push_interval) : 0;
   if (s->hm.A <= 2)
-    hipLaunchKernelGGL(k_post_physics<2>, dim3((s->N + POST_EPW - 1) / POST_EPW), dim3(64), 0, q, s->dm, s->st, wrapper_level, push);
+    hipLaunchKernelGGL(k_post_physics<2>, dim3((s->N + POST_EPW - 1) / POST_EPW), dim3(64), 0, q, s->dm, s->st, wrapper_level, push, s->n_post_steps);
   else
-    hipLaunchKernelGGL(k_post_physics<MQE_MAX_AGENTS>, dim3((s->N + POST_EPW - 1) / POST_EPW), dim3(64), 0, q, s->dm, s->st, wrapper_level, push);   // incl. history zeroing
+    hipLaunchKernelGGL(k_post_physics<MQE_MAX_AGENTS>, dim3((s->N + POST_EPW - 1) / POST_EPW), dim3(64), 0, q, s->dm, s->st, wrapper_level, push, s->n_post_steps);   // incl. history zeroing
 }
 
 extern "C" int mqe_policy_step(mqe_sim* s, const float* command, void* stream) {
+  if (!s) return fail(-1, "null engine handle");
   policy_step(s, command, (hipStream_t)stream);
   HIPCHK(hipGetLastError());
   return 0;
 }
 extern "C" int mqe_defender_command(mqe_sim* s, float* out_dev, void* stream) {
+  if (!s) return fail(-1, "null engine handle");
   if (s->d.task != MQE_TASK_FOOTBALL_DEFENDER) return fail(-7, "defender command needs the football-defender task");
   hipLaunchKernelGGL(k_defender_command, dim3((s->N + 63) / 64), dim3(64), 0, (hipStream_t)stream, s->dm, s->st, out_dev);
   HIPCHK(hipGetLastError());
   return 0;
 }
 extern "C" int mqe_compute_torques(mqe_sim* s, void* stream) {
+  if (!s) return fail(-1, "null engine handle");
   launch_torques(s, -1, (hipStream_t)stream);
   HIPCHK(hipGetLastError());
   return 0;
 }
 extern "C" int mqe_simulate(mqe_sim* s, void* stream) {
+  if (!s) return fail(-1, "null engine handle");
   launch_simulate(s, (hipStream_t)stream);
   HIPCHK(hipGetLastError());
   return 0;
 }
+// post_decimation_step (legged_robot.py:112-115) of the unfused path: torques, joint velocities and soft-limit flags of substep dec_i
+__global__ void k_post_decimation(const DevModel* m, DevState st, int dec_i) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nj = 12 * m->A;
+  if (idx >= m->N * nj) return;
+  const int e = idx / nj, jt = idx - e * nj, j = jt % 12;
+  const size_t o = ((size_t)e * 4 + dec_i) * nj + jt;
+  const float q = st.dof[((size_t)e * m->ND + jt) * 2], qd = st.dof[((size_t)e * m->ND + jt) * 2 + 1];
+  st.sub_tau[o] = st.torques[idx];
+  st.sub_dof_vel[o] = qd;
+  st.sub_exceed[o] = (q < m->soft_lo[j]) | (q > m->soft_hi[j]);
+}
+
 extern "C" int mqe_post_decimation_step(mqe_sim* s, int dec_i, void* stream) {
+  if (!s) return fail(-1, "null engine handle");
   if (dec_i < 0 || dec_i >= 4) return fail(-1, "dec_i out of range");
-  size_t n = (size_t)12 * s->A;
-  HIPCHK(hipMemcpy2DAsync(s->st.sub_tau + (size_t)dec_i * n, 4 * n * 4, s->st.torques, n * 4, n * 4, s->N, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  const int n = s->N * 12 * s->A;
+  hipLaunchKernelGGL(k_post_decimation, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, s->dm, s->st, dec_i);
+  HIPCHK(hipGetLastError());
   return 0;
 }
 extern "C" int mqe_post_physics_step(mqe_sim* s, void* stream) {
+  if (!s) return fail(-1, "null engine handle");
   launch_post(s, (hipStream_t)stream, 0);
   HIPCHK(hipGetLastError());
   return 0;
 }
 extern "C" int mqe_wrapper_eval(mqe_sim* s, int is_reset_call, void* stream) {
+  if (!s) return fail(-1, "null engine handle");
   hipLaunchKernelGGL(k_wrapper_eval, dim3((s->N + 63) / 64), dim3(64), 0, (hipStream_t)stream, s->dm, s->st, is_reset_call);
   HIPCHK(hipGetLastError());
   return 0;
@@ -656,6 +694,7 @@ extern "C" int mqe_set_actor_root_state_indexed(mqe_sim*, const int32_t*, int, v
 extern "C" int mqe_set_dof_state_indexed(mqe_sim*, const int32_t*, int, void*) { return 0; }
 
 extern "C" int mqe_reset_all(mqe_sim* s, void* stream) {
+  if (!s) return fail(-1, "null engine handle");
   hipStream_t q = (hipStream_t)stream;
   hipLaunchKernelGGL(k_reset_all, dim3((s->N + 63) / 64), dim3(64), 0, q, s->dm, s->st, s->n_post_steps == 0 ? 1 : 0);
   int n = s->R * (MQE_HIST * MQE_FRAME / 4);
@@ -665,6 +704,7 @@ extern "C" int mqe_reset_all(mqe_sim* s, void* stream) {
 }
 
 static int run_substeps_and_post(mqe_sim* s, hipStream_t q);
+__global__ void k_post_decimation(const DevModel* m, DevState st, int dec_i);
 
 // clip to clip_actions (legged_robot.py:108-110) -> st.actions
 __global__ void k_set_joint_actions(const DevModel* m, DevState st, const float* __restrict__ a12) {
@@ -673,6 +713,7 @@ __global__ void k_set_joint_actions(const DevModel* m, DevState st, const float*
 }
 
 extern "C" int mqe_step_joint(mqe_sim* s, const float* actions12, void* stream) {
+  if (!s) return fail(-1, "null engine handle");
   if (s->d.control_type == MQE_CTRL_C) return fail(-7, "mqe_step_joint drives control types P / V / T; use mqe_step for the hierarchical controller");
   hipStream_t q = (hipStream_t)stream;
   s->prof_now = s->prof && (s->prof_step++ % s->prof_every == 0);
@@ -685,6 +726,7 @@ extern "C" int mqe_step_joint(mqe_sim* s, const float* actions12, void* stream) 
 }
 
 extern "C" int mqe_step(mqe_sim* s, const float* actions, void* stream) {
+  if (!s) return fail(-1, "null engine handle");
   hipStream_t q = (hipStream_t)stream;
   if (s->d.control_type != MQE_CTRL_C) return fail(-7, "mqe_step drives the hierarchical controller (control type C); use mqe_step_joint for P / V / T");
   s->prof_now = s->prof && (s->prof_step++ % s->prof_every == 0);
@@ -693,6 +735,7 @@ extern "C" int mqe_step(mqe_sim* s, const float* actions, void* stream) {
 }
 
 extern "C" int mqe_step_begin(mqe_sim* s, const float* actions, void* stream) {
+  if (!s) return fail(-1, "null engine handle");
   hipStream_t q = (hipStream_t)stream;
   if (s->d.control_type != MQE_CTRL_C) return fail(-7, "mqe_step_begin drives the hierarchical controller (control type C)");
   if (s->step_open) return fail(-8, "mqe_step_begin: the previous step was not closed with mqe_step_end");
@@ -713,6 +756,7 @@ extern "C" int mqe_set_return_buffer(mqe_sim* s, float* packed_dev) {
 }
 
 extern "C" int mqe_step_end(mqe_sim* s, void* stream) {
+  if (!s) return fail(-1, "null engine handle");
   if (!s->step_open) return fail(-8, "mqe_step_end without mqe_step_begin");
   s->step_open = false;
   return run_substeps_and_post(s, (hipStream_t)stream);
@@ -728,6 +772,8 @@ static int run_substeps_and_post(mqe_sim* s, hipStream_t q) {
     for (int k = 0; k < s->d.decimation; k++) {
       launch_torques(s, k < 4 ? k : 3, q);
       launch_simulate(s, q);
+      const int n = s->N * 12 * s->A;
+      hipLaunchKernelGGL(k_post_decimation, dim3((n + 255) / 256), dim3(256), 0, q, s->dm, s->st, k < 4 ? k : 3);
     }
   }
   launch_post(s, q, 1);
@@ -740,6 +786,7 @@ static int run_substeps_and_post(mqe_sim* s, hipStream_t q) {
 static long long g_dbg_times[16];
 extern "C" int mqe_debug_times(long long* out16) { memcpy(out16, g_dbg_times, sizeof g_dbg_times); return 0; }
 extern "C" int mqe_debug_dynamics(mqe_sim* s, int env, int robot, float* minv_out_host, int* nc_out_host, float* contacts_out_host) {
+  if (!s) return fail(-1, "null engine handle");
   float *dm_, *dc; int* dn; long long* dtm;
   HIPCHK(hipMalloc(&dm_, 324 * 4)); HIPCHK(hipMalloc(&dc, 64 * 8 * 4)); HIPCHK(hipMalloc(&dn, 4)); HIPCHK(hipMalloc(&dtm, 16 * 8));
   HIPCHK(hipMemset(dtm, 0, 16 * 8));

@@ -1,7 +1,7 @@
 """ctypes mirror of include/mqe_hip.h (keep in sync; tests/test_abi.py checks sizes against the built library)."""
 import ctypes as C
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 MAX_SPHERES, NBODY, NREP, NDOF = 32, 13, 17, 12
 MAX_SELF_PAIRS = 320
 MAX_AGENTS, MAX_NPCS, FRAME, HIST, MAX_LAYERS, MAX_REWARD_TERMS = 4, 9, 72, 30, 6, 12
@@ -16,7 +16,8 @@ TERM = dict(roll=1, pitch=2, z_low=4, z_high=8)
  T_LAST_LOCO_ACTION, T_LAST_TWO_LOCO_ACTION, T_ACT_HIST, T_GAIT_INDICES, T_CLOCK_INPUTS, T_BASE_LIN_VEL,
  T_BASE_ANG_VEL, T_PROJECTED_GRAVITY, T_BASE_QUAT, T_EPISODE_LENGTH, T_RESET_BUF, T_COLLIDE_BUF, T_TIME_OUT_BUF,
  T_R_TERM, T_P_TERM, T_Z_HIGH_TERM, T_OBS_BAG, T_WRAPPER_OBS, T_WRAPPER_REWARD, T_REWARD_SUMS, T_SHEEP_POS_AVG,
- T_SHEEP_POS_VAR, T_RESET_COUNT, T_SUBSTEP_TORQUES, T_NPC_NOISE, T_WRAPPER_PACKED, T_DOMAIN_PARAMS, T_COUNT) = range(36)
+ T_SHEEP_POS_VAR, T_RESET_COUNT, T_SUBSTEP_TORQUES, T_NPC_NOISE, T_WRAPPER_PACKED, T_DOMAIN_PARAMS, T_SUBSTEP_DOF_VEL,
+ T_SUBSTEP_EXCEED_DOF_POS_LIMITS, T_CONTACT_OVERFLOW, T_COUNT) = range(39)
 
 # slices of one OBS_BAG row (compute_observations, reference go1.py:153-196)
 BAG = dict(base_pos=(0, 3), base_rpy=(3, 6), dof_pos=(6, 18), dof_vel=(18, 30), lin_vel=(30, 33), ang_vel=(33, 36),
@@ -35,7 +36,7 @@ class RobotModel(C.Structure):
     _fields_ = [
         ("mass", f32 * NBODY), ("com", (f32 * 3) * NBODY), ("inertia", (f32 * 6) * NBODY),
         ("joint_offset", (f32 * 3) * NBODY), ("joint_axis", (f32 * 3) * NBODY),
-        ("dof_lower", f32 * NDOF), ("dof_upper", f32 * NDOF),
+        ("dof_lower", f32 * NDOF), ("dof_upper", f32 * NDOF), ("dof_vel_limit", f32 * NDOF),
         ("n_spheres", i32), ("sphere_body", i32 * MAX_SPHERES), ("sphere_reported", i32 * MAX_SPHERES),
         ("sphere_center", (f32 * 3) * MAX_SPHERES), ("sphere_radius", f32 * MAX_SPHERES),
         ("n_self_pairs", i32), ("self_pair", C.c_uint16 * MAX_SELF_PAIRS),
@@ -62,7 +63,7 @@ class SimDesc(C.Structure):
         ("torque_limits", f32 * NDOF), ("kp", f32), ("kd", f32), ("default_dof_pos", f32 * NDOF),
         ("command_obs", f32 * 70), ("cmd_lin_scale", f32), ("cmd_ang_scale", f32), ("clip_command", i32),
         ("wall_sdf", FP), ("sdf_nx", i32), ("sdf_ny", i32),
-        ("horizontal_scale", f32), ("wall_height", f32), ("ground_z", f32),
+        ("horizontal_scale", f32), ("wall_height", f32), ("ground_z", f32), ("ground_height", FP), ("soft_dof_pos_limit", f32),
         ("env_origins", FP), ("agent_origins", FP), ("base_init_state", FP), ("npc_init_state", FP), ("gate_pos", FP),
         ("termination_flags", i32), ("terminate_on_base_contact", i32), ("max_episode_length", i32),
         ("roll_threshold", f32), ("pitch_threshold", f32), ("z_low_threshold", f32), ("z_high_threshold", f32),

@@ -145,6 +145,7 @@ def build_desc(cfg, num_envs, terrain, env_origins, agent_origins, gate_pos=None
             r.joint_axis[b][k] = m["joint_axis"][b][k]
     for j in range(abi.NDOF):
         r.dof_lower[j], r.dof_upper[j] = m["dof_lower"][j], m["dof_upper"][j]
+        r.dof_vel_limit[j] = m["dof_velocity"][j]          # props["velocity"] (legged_robot.py:315): enforced by the solver
     r.n_spheres = len(m["sphere_body"])
     for s in range(r.n_spheres):
         r.sphere_body[s], r.sphere_reported[s], r.sphere_radius[s] = m["sphere_body"][s], m["sphere_reported"][s], m["sphere_radius"][s]
@@ -295,6 +296,11 @@ def build_desc(cfg, num_envs, terrain, env_origins, agent_origins, gate_pos=None
     d.wall_sdf = _fp(terrain.wall_sdf, keep)
     d.sdf_nx, d.sdf_ny = terrain.wall_sdf.shape
     d.horizontal_scale, d.wall_height, d.ground_z = cfg.terrain.horizontal_scale, terrain.wall_height, terrain.ground_z
+    gh = getattr(terrain, "ground_height", None)              # Perlin relief of the walkable surface (None: flat slab)
+    if gh is not None:
+        assert gh.shape == terrain.wall_sdf.shape
+        d.ground_height = _fp(gh, keep)
+    d.soft_dof_pos_limit = float(getattr(cfg.rewards, "soft_dof_pos_limit", 1.0))
     d.env_origins = _fp(env_origins, keep)
     d.agent_origins = _fp(agent_origins, keep)
     st = cfg.init_state

@@ -66,6 +66,8 @@ typedef struct mqo_sim {
   float *root, *dof, *cf, *torques, *actions, *last_actions, *loco_obs, *hist, *last_loco, *last_two_loco;
   float *act_hist, *gait, *clock, *blv, *bav, *pg, *bquat, *obs_bag, *wobs, *wrew, *wdone, *rsum, *sheep_avg, *sheep_var;
   float *sub_tau, *npc_noise, *last_dof_vel;
+  float* sub_dof_vel; uint8_t* sub_exceed; int32_t* overflow;   /* legged_robot.py:114-115 logs; truncated-contact-list counter */
+  float soft_lo[12], soft_hi[12];
   float *dparams, *lag_buf;         /* [R][8] MQE_T_DOMAIN_PARAMS; [(lag + 1)][R][12] scaled actions (domain randomisation, include/mqe_hip.h) */
   int lag_pos;
   int32_t *ep_len, *reset_count;
@@ -326,6 +328,16 @@ int mqo_sim_create(const mqe_sim_desc* d, mqo_sim** out) {
   s->sheep_avg = ALLOCF((size_t)N * 2);
   s->sheep_var = ALLOCF(N);
   s->sub_tau = ALLOCF((size_t)N * 4 * 12 * A);
+  s->sub_dof_vel = ALLOCF((size_t)N * 4 * 12 * A);
+  s->sub_exceed = (uint8_t*)calloc((size_t)N * 4 * 12 * A, 1);
+  s->overflow = (int32_t*)calloc(N, 4);
+  {
+    const float soft = d->soft_dof_pos_limit > 0.0f ? d->soft_dof_pos_limit : 1.0f;
+    for (int j = 0; j < 12; j++) {                           /* legged_robot.py:317-321 */
+      const float mid = (d->robot.dof_lower[j] + d->robot.dof_upper[j]) / 2, r = d->robot.dof_upper[j] - d->robot.dof_lower[j];
+      s->soft_lo[j] = mid - 0.5f * r * soft; s->soft_hi[j] = mid + 0.5f * r * soft;
+    }
+  }
   /* domain parameters: drawn once, keyed by the global env id (the engine makes the same draws on its host side) */
   s->dparams = ALLOCF((size_t)R * 8);
   for (int e = 0; e < N; e++) {
@@ -372,6 +384,7 @@ int mqo_sim_create(const mqe_sim_desc* d, mqo_sim** out) {
   t[MQE_T_SHEEP_POS_AVG] = s->sheep_avg; t[MQE_T_SHEEP_POS_VAR] = s->sheep_var; t[MQE_T_RESET_COUNT] = s->reset_count;
   t[MQE_T_SUBSTEP_TORQUES] = s->sub_tau; t[MQE_T_NPC_NOISE] = s->npc_noise; t[MQE_T_WRAPPER_PACKED] = s->wobs;
   t[MQE_T_DOMAIN_PARAMS] = s->dparams;
+  t[MQE_T_SUBSTEP_DOF_VEL] = s->sub_dof_vel; t[MQE_T_SUBSTEP_EXCEED_DOF_POS_LIMITS] = s->sub_exceed; t[MQE_T_CONTACT_OVERFLOW] = s->overflow;
   *out = s;
   return 0;
 }
@@ -405,7 +418,9 @@ int mqo_sim_tensor(mqo_sim* s, int kind, mqe_tensor_view* v) {
     case MQE_T_REWARD_SUMS: SH(2, N, MQE_MAX_REWARD_TERMS, 0, 0, 0); break;
     case MQE_T_SHEEP_POS_AVG: SH(2, N, 2, 0, 0, 0); break;
     case MQE_T_SHEEP_POS_VAR: SH(1, N, 0, 0, 0, 0); break;
-    case MQE_T_SUBSTEP_TORQUES: SH(3, N, 4, 12 * A, 0, 0); break;
+    case MQE_T_SUBSTEP_TORQUES: case MQE_T_SUBSTEP_DOF_VEL: SH(3, N, 4, 12 * A, 0, 0); break;
+    case MQE_T_SUBSTEP_EXCEED_DOF_POS_LIMITS: SH(3, N, 4, 12 * A, 0, 2); break;
+    case MQE_T_CONTACT_OVERFLOW: SH(1, N, 0, 0, 0, 1); break;
     case MQE_T_NPC_NOISE: SH(3, N, P, 3, 0, 0); break;
     case MQE_T_WRAPPER_PACKED: SH(1, N * s->Aw * s->D + N * s->Aw + N, 0, 0, 0, 0); break;
     case MQE_T_DOMAIN_PARAMS: SH(2, s->R, 8, 0, 0, 0); break;
@@ -496,7 +511,14 @@ int mqo_compute_torques(mqo_sim* s) {
 
 int mqo_post_decimation_step(mqo_sim* s, int dec_i) { /* legged_robot.py:112-115 */
   int n = 12 * s->A;
-  for (int e = 0; e < s->N; e++) memcpy(s->sub_tau + ((size_t)e * 4 + dec_i) * n, s->torques + (size_t)e * n, n * 4);
+  for (int e = 0; e < s->N; e++) {
+    memcpy(s->sub_tau + ((size_t)e * 4 + dec_i) * n, s->torques + (size_t)e * n, n * 4);                     /* :113 */
+    for (int jt = 0; jt < n; jt++) {
+      const float q = s->dof[((size_t)e * s->ND + jt) * 2], qd = s->dof[((size_t)e * s->ND + jt) * 2 + 1];
+      s->sub_dof_vel[((size_t)e * 4 + dec_i) * n + jt] = qd;                                                  /* :114 */
+      s->sub_exceed[((size_t)e * 4 + dec_i) * n + jt] = (q < s->soft_lo[jt % 12]) | (q > s->soft_hi[jt % 12]);  /* :115 */
+    }
+  }
   return 0;
 }
 
@@ -816,6 +838,7 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
   /* ---- contact generation (canonical order: terrain contacts actor by actor, sphere by sphere, ground before
    * wall; then sphere pairs for actor pairs (a<b), outer loop over b's spheres, inner over a's) */
   int nact = A + P;
+  int ovf = 0;                          /* a touching pair did not fit the bounded list (MQE_T_CONTACT_OVERFLOW) */
   w->nc = 0;
   for (int act = 0; act < nact; act++) {
     int mine = 0;                       /* no actor may starve the ones after it */
@@ -864,6 +887,7 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
             sd = dist - r; n[0] = gx * sh / dist; n[1] = gy * sh / dist; n[2] = dz / dist;
           }
         }
+        if (sd < d->contact_offset && !(w->nc < maxc && mine < cap)) ovf = 1;
         if (sd < d->contact_offset && w->nc < maxc && mine < cap) {
           mine++;
           contact_t* ct = &w->con[w->nc++];
@@ -884,6 +908,7 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
         real r = w->sph_r[act][si], n[3];
         real hp[3] = {d->seesaw_plank_half[0], d->seesaw_plank_half[1], d->seesaw_plank_half[2]};
         real sd = d->seesaw_link_cylinder ? sphere_vcyl(c, r, ssC, hp[0], hp[2], n) : sphere_box(c, r, ssC, ssR, hp, n);
+        if (sd < d->contact_offset && !(w->nc < pair_lim && mine < (maxc / 2) / A)) ovf = 1;
         if (sd < d->contact_offset && w->nc < pair_lim && mine < (maxc / 2) / A) {
           mine++;
           contact_t* ct = &w->con[w->nc++];
@@ -905,6 +930,7 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
           const real* ca = w->sph_c[a][sa];
           real n[3];
           real sd = sphere_box(ca, w->sph_r[a][sa], npc_pos[b - A], w->npcR[b - A], hb, n);
+          if (sd < d->contact_offset && !(w->nc < pair_lim)) ovf = 1;
           if (sd < d->contact_offset && w->nc < pair_lim) {
             contact_t* ct = &w->con[w->nc++];
             memset(ct, 0, sizeof *ct);
@@ -921,6 +947,7 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
           real e[3] = {ca[0] - cb[0], ca[1] - cb[1], ca[2] - cb[2]};
           real dist = (real)sqrt((double)dot3(e, e));
           real sd = dist - w->sph_r[a][sa] - w->sph_r[b][sb];
+          if (sd < d->contact_offset && dist > (real)1e-9 && !(w->nc < pair_lim)) ovf = 1;
           if (sd < d->contact_offset && w->nc < pair_lim && dist > (real)1e-9) {
             contact_t* ct = &w->con[w->nc++];
             memset(ct, 0, sizeof *ct);
@@ -939,6 +966,7 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
         real e[3] = {ci[0] - cj[0], ci[1] - cj[1], ci[2] - cj[2]};
         real dist = (real)sqrt((double)dot3(e, e));
         real sd = dist - w->sph_r[a][si] - w->sph_r[a][sj];
+        if (sd < d->contact_offset && dist > (real)1e-9 && !(w->nc < pair_lim)) ovf = 1;
         if (sd < d->contact_offset && w->nc < pair_lim && dist > (real)1e-9) {
           contact_t* ct = &w->con[w->nc++];
           memset(ct, 0, sizeof *ct);
@@ -1009,12 +1037,14 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
     }
   }
   {
-    /* joint limits: q + dt*qd within [lower, upper]; one pass after the contact iterations */
+    /* joint limits: q + dt*qd within [lower, upper] and |qd| <= the URDF velocity limit (go1.urdf:115,157,185; legged_robot.py:315;
+     * PhysX maxJointVelocity); one pass after the contact iterations, violations removed by an impulse along the joint */
     for (int r = 0; r < A; r++)
       for (int j = 0; j < 12; j++) {
         real q = dofs[(r * 12 + j) * 2];
         real* v = w->v + r * RD;
         real lo = (m->dof_lower[j] - q) / dt, hi = (m->dof_upper[j] - q) / dt;
+        if (m->dof_vel_limit[j] > 0) { real vl = m->dof_vel_limit[j]; if (lo < -vl) lo = -vl; if (hi > vl) hi = vl; }
         real viol = 0;
         if (v[6 + j] < lo) viol = lo - v[6 + j];
         else if (v[6 + j] > hi) viol = hi - v[6 + j];
@@ -1036,6 +1066,7 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
     }
   }
 
+  if (ovf) s->overflow[env] += 1;
   /* ---- net contact forces per reported body (gym.refresh_net_contact_force_tensor analogue) */
   float* cf = s->cf + (size_t)env * s->NBR * 3;
   memset(cf, 0, (size_t)s->NBR * 3 * 4);
@@ -1098,7 +1129,9 @@ int mqo_debug_dynamics(mqo_sim* s, int env, int robot, float* M_out /*18x18*/, f
   float* r0 = (float*)dupmem(s->root + env * nr, nr * 4);
   float* d0 = (float*)dupmem(s->dof + env * ndf, ndf * 4);
   float* c0 = (float*)dupmem(s->cf + env * ncf, ncf * 4);
+  const int32_t ov0 = s->overflow[env];
   simulate_env(s, env, w);
+  s->overflow[env] = ov0;
   memcpy(s->root + env * nr, r0, nr * 4); memcpy(s->dof + env * ndf, d0, ndf * 4); memcpy(s->cf + env * ncf, c0, ncf * 4);
   free(r0); free(d0); free(c0);
   const real* L = w->L[robot];
@@ -1203,6 +1236,15 @@ static void reset_env(mqo_sim* s, int e) { /* go1.py:110-145, legged_robot.py:39
 }
 
 /* sheep flocking script, go1_sheep.py:14-18,35-64.  noise: injected N(0,1) [P][3] */
+/* MQE_NOISE_HASH: N(0,1) by Box-Muller over the counter RNG, keyed by (seed, global env id, post-step ordinal, sheep * 3 + axis);
+ * same formula as mqe_randn() of the engine (kernels_step.hpp) */
+static float mqo_randn(const mqo_sim* s, int e, uint32_t k) {
+  const mqe_sim_desc* d = &s->d;
+  const uint32_t cnt = 0x60000000u + (uint32_t)(s->n_post_steps + 1), genv = (uint32_t)(e + d->env_id_offset);
+  const float u1 = mqo_u01((uint32_t)d->seed, genv, cnt, 2u * k), u2 = mqo_u01((uint32_t)d->seed, genv, cnt, 2u * k + 1u);
+  return sqrtf(-2.0f * logf(1.0f - u1)) * cosf(6.2831855f * u2);
+}
+
 static void step_sheep_env(mqo_sim* s, int e) {
   const mqe_sim_desc* d = &s->d;
   int A = s->A, P = s->P;
@@ -1222,11 +1264,16 @@ static void step_sheep_env(mqo_sim* s, int e) {
   for (int p = 0; p < P; p++) {
     const float* sp = root + (A + p) * 13;
     float dv[3];
-    for (int k = 0; k < 3; k++) dv[k] = d->sheep_movement_randomness * s->npc_noise[((size_t)e * P + p) * 3 + k] * 2.0f;  /* :43 */
+    for (int k = 0; k < 3; k++) {                                               /* :43 randn_like: scripted (fixtures) or a fresh draw per step */
+      float z = d->noise_mode == MQE_NOISE_SCRIPTED ? s->npc_noise[((size_t)e * P + p) * 3 + k]
+                                                    : (d->sheep_movement_randomness != 0.0f ? mqo_randn(s, e, (uint32_t)(p * 3 + k)) : 0.0f);
+      dv[k] = d->sheep_movement_randomness * z * 2.0f;
+    }
     if (P != 1) {
       float rel[3] = {avg[0] - sp[0], avg[1] - sp[1], avg[2] - sp[2]};
       float nr = sqrtf(rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2]);
-      for (int k = 0; k < 3; k++) dv[k] += d->sheep_movement_randomness * rel[k] / nr / 1.5f;   /* :47 */
+      /* :47; a sheep exactly on the flock mean would be 0 / 0 in torch: the cohesion term is dropped there (engine: no-NaN math) */
+      if (nr > 0.0f) for (int k = 0; k < 3; k++) dv[k] += d->sheep_movement_randomness * rel[k] / nr / 1.5f;
     }
     for (int a = 0; a < A; a++) {
       const float* dp = root + a * 13;
@@ -1249,6 +1296,10 @@ static void step_sheep_env(mqo_sim* s, int e) {
 }
 
 static void wrapper_env(mqo_sim* s, int e, int is_reset_call, const float* pre_npc);
+/* a / b and atan(a / b) as the engine evaluates them (kernels_step.hpp: div_ieee / atan_ratio): torch's IEEE results for b == 0
+ * spelt out with a large finite value in place of +-inf, 0 / 0 -> 0 */
+static inline float div_ieee(float a, float b) { return b != 0.0f ? a / b : (a > 0.0f ? 3.0e38f : (a < 0.0f ? -3.0e38f : 0.0f)); }
+static inline float atan_ratio(float a, float b) { return b != 0.0f ? atanf(a / b) : (a > 0.0f ? 1.5707964f : (a < 0.0f ? -1.5707964f : 0.0f)); }
 
 int mqo_post_physics_step(mqo_sim* s) {
   const mqe_sim_desc* d = &s->d;
@@ -1529,7 +1580,7 @@ static void wrapper_env(mqo_sim* s, int e, int is_reset_call, const float* npc) 
       if (ob[0] > s->gate_pos[e * 2] + 0.25f) { r_ag[a] += sc[2]; rs[2] += sc[2]; }
       const float* ob2 = s->obs_bag + (size_t)(e * A + (A - 1 - a)) * OBS_BAG;
       float d2 = (ob[0] - ob2[0]) * (ob[0] - ob2[0]) + (ob[1] - ob2[1]) * (ob[1] - ob2[1]);
-      if (d2 < 0.25f) { float pn = sc[3] / d2; r_ag[a] += pn; rs[3] += pn; }
+      if (d2 < 0.25f) { float pn = div_ieee(sc[3], d2); r_ag[a] += pn; rs[3] += pn; }
     }
     float tot = 0;
     for (int a = 0; a < A; a++) tot += r_ag[a];
@@ -1591,7 +1642,7 @@ static void wrapper_env(mqo_sim* s, int e, int is_reset_call, const float* npc) 
     if (sc[4] != 0) {
       const float* o0 = s->obs_bag + (size_t)(e * A) * OBS_BAG; const float* o1 = s->obs_bag + (size_t)(e * A + A - 1) * OBS_BAG;
       float d2 = (o0[0] - o1[0]) * (o0[0] - o1[0]) + (o0[1] - o1[1]) * (o0[1] - o1[1]);
-      if (d2 < 0.25f) { float v = sc[4] / d2; r_env += v; rs[4] += v; }
+      if (d2 < 0.25f) { float v = div_ieee(sc[4], d2); r_env += v; rs[4] += v; }
     }
     if (sc[5] != 0) {
       int cnt = 0;
@@ -1649,12 +1700,12 @@ static void defender_command(const mqo_sim* s, int e, float* cmd3) {
   float tp[3];
   for (int k = 0; k < 3; k++) tp[k] = 0.6f * bp[k] + 0.4f * gate[k];
   float yaw = s->obs_bag[(size_t)(e * A + 2) * OBS_BAG + 5];
-  float yaw_to_gate = 3.1415927f + atanf((gate[1] - dp[1]) / (gate[0] - dp[0]));
+  float yaw_to_gate = 3.1415927f + atan_ratio(gate[1] - dp[1], gate[0] - dp[0]);
   float yc = fminf(fmaxf(yaw_to_gate - yaw, -0.3f), 0.3f) / 0.3f;
   float tdg = sqrtf((tp[0] - gate[0]) * (tp[0] - gate[0]) + (tp[1] - gate[1]) * (tp[1] - gate[1]));
   float ddg = sqrtf((dp[0] - gate[0]) * (dp[0] - gate[0]) + (dp[1] - gate[1]) * (dp[1] - gate[1]));
   float xc = fminf(fmaxf(tdg - ddg, -0.5f), 0.5f);
-  float yy = -fminf(fmaxf(gate[1] + (tp[1] - gate[1]) * (dp[0] - gate[0]) / (tp[0] - gate[0]) - dp[1], -0.5f), 0.5f);
+  float yy = -fminf(fmaxf(gate[1] + div_ieee((tp[1] - gate[1]) * (dp[0] - gate[0]), tp[0] - gate[0]) - dp[1], -0.5f), 0.5f);
   cmd3[0] = xc; cmd3[1] = yy; cmd3[2] = yc;
 }
 int mqo_defender_command(mqo_sim* s, float* out /*[N,3]*/) { for (int e = 0; e < s->N; e++) defender_command(s, e, out + e * 3); return 0; }

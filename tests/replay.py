@@ -22,7 +22,8 @@ def replay(name, make_engine):
     T = z["actions"].shape[0]
     d, keep, ctx = make_desc(TASK_OF[name], N, levels=z["terrain_levels"], types=z["terrain_types"],
                              max_episode_length=int(z["max_episode_length"]),
-                             npc_init=z["base_init_state_npc"][:P] if P else None)
+                             npc_init=z["base_init_state_npc"][:P] if P else None,
+                             noise_mode=1 if name == "sheep" else 0)      # MQE_NOISE_SCRIPTED: the recorded randn sequence is injected
     np.testing.assert_allclose(ctx["env_origins"], z["env_origins"], atol=0)
     np.testing.assert_allclose(ctx["agent_origins"], z["agent_origins"], atol=0)
     e = make_engine(d, keep)
