@@ -104,7 +104,7 @@ class Go1:
         self.task = task_kind(cfg)
         gate_pos = self._task_gate_pos()
         desc, keep = build_desc(cfg, N, t, self._env_origins_np, self._agent_origins_np, gate_pos=gate_pos,
-                                env_id_offset=g0, seed=int(getattr(self, "seed", 0)), task=self.task)
+                                env_id_offset=g0, seed=int(getattr(cfg, "seed", 0) or 0), task=self.task)
         self.body_is_synthetic = dict(k for k in keep if isinstance(k, tuple)).get("body_is_synthetic", True)
         self.engine = type(self).engine_factory(desc, keep, self.device)
         self.device = str(self.engine.torch_device) if hasattr(self.engine, "torch_device") else self.device
@@ -239,10 +239,13 @@ class Go1:
             self.common_step_counter += 1
             return self.obs_buf, self.rew_buf, self.reset_buf, self.extras
         cmd = action.reshape(-1, 3).to(self.engine.torch_device, torch.float32).contiguous()
-        if self.task == "football_defender" and cmd.shape[0] == self.num_envs * 2:
-            raise NotImplementedError("call the task wrapper (fused path) for go1football-defender; the scripted "
-                                      "defender command is generated inside the engine")
         e = self.engine
+        if self.task == "football_defender" and cmd.shape[0] == self.num_envs * 2:
+            # Go1FootballDefender.step (go1_football_defender.py:25-31): the scripted defender's command is appended to the two
+            # learners' commands (mqe_defender_command evaluates _get_defender_action, :56-80, from the current state)
+            dc = torch.empty(self.num_envs, 3, device=cmd.device)
+            e.defender_command(dc)
+            cmd = torch.cat([cmd.view(self.num_envs, 2, 3), dc.unsqueeze(1)], dim=1).reshape(-1, 3).contiguous()
         e.policy_step(cmd)
         self._steps_policy = getattr(self, "_steps_policy", 0) + 1
         for dec_i in range(self.decimation):

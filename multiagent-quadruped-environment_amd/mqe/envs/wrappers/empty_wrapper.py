@@ -99,4 +99,6 @@ class FusedTaskWrapper(EmptyWrapper):
             snap = self._wpack.clone()
         n, nr = self._wobs.numel(), self._wrew.numel()
         self.returned_batch = snap                                     # obs | reward | done (0/1): what a sharded runner all-gathers
-        return snap[:n].view(self._wobs.shape), snap[n:n + nr].view(self._wrew.shape), self.env.reset_buf, self.env.extras
+        # all three returned tensors belong to this step alone (the reference builds a new reset_buf every step; env.reset_buf
+        # is a live view of engine memory that the next step overwrites)
+        return snap[:n].view(self._wobs.shape), snap[n:n + nr].view(self._wrew.shape), snap[n + nr:] != 0, self.env.extras

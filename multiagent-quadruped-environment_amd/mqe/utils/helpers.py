@@ -104,7 +104,9 @@ def make_env(task_class, env_cfg, args=None):
     if args is None:
         args = get_args()
     env_cfg, _ = update_cfg_from_args(env_cfg, None, args)
-    set_seed(args.seed)
+    # the seed also keys every in-engine draw (reset noise, domain parameters, pushes, the sheep's random walk): one value per
+    # run, the same on every rank of an env-sharded run (draws are keyed by the GLOBAL env id, so shards then agree)
+    env_cfg.seed = set_seed(args.seed)
     sim_params = parse_sim_params(args, {"sim": class_to_dict(env_cfg.sim)})
     env = task_class(cfg=env_cfg, sim_params=sim_params, physics_engine=args.physics_engine,
                      sim_device=args.sim_device, headless=args.headless)

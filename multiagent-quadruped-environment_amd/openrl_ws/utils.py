@@ -40,9 +40,18 @@ class mqe_openrl_wrapper(Wrapper):
         return obs, rewards, dones, [{} for _ in range(dones.shape[0])]
 
     def step_torch(self, actions: torch.Tensor):
-        """Same transform, tensors stay on the device: (obs (N,A,D), reward (N,A,1), done (N,A) bool)."""
+        """Same transform, tensors stay on the device: (obs (N,A,D), reward (N,A,1), done (N,A) bool).  Every returned tensor
+        is fresh memory of this step (the engine writes the batch straight into it), so a rollout buffer may keep references."""
         obs, reward, termination, info = self.env.step((0.5 * actions).clip(-1, 1))
         return obs, reward.unsqueeze(-1), termination.unsqueeze(-1).repeat(1, self.agent_num)
+
+    def step_dlpack(self, actions):
+        """Device-resident hand-off for trainers that do not speak torch (replaces the numpy round trip of
+        openrl_ws/utils.py:53-67): `actions` is any object with `__dlpack__` living on the env's device; returns objects with
+        `__dlpack__` / `__dlpack_device__` (consume with `xp.from_dlpack(...)`), zero-copy both ways."""
+        a = actions if isinstance(actions, torch.Tensor) else torch.from_dlpack(actions)
+        obs, rew, done = self.step_torch(a.to(torch.float32))
+        return obs, rew, done.to(torch.uint8)            # DLPack has no portable bool before v1.0: flags travel as uint8
 
     def close(self, **kwargs):
         return self.env.close()
@@ -95,29 +104,52 @@ class SingleAgentWrapper(Wrapper):
         return obs.reshape(self.num_envs, 1, -1), reward.reshape(self.num_envs, 1), term, info
 
 
+def _base_parser():
+    """OpenRL's own parser when the trainer is installed (the reference builds its CLI on `create_config_parser()`,
+    openrl_ws/utils.py:230-232, so that `PPONet(env, cfg=args)` finds OpenRL's keys in the namespace, train.py:47-49);
+    a bare parser with the one OpenRL flag the env side reads (--seed) otherwise."""
+    try:
+        from openrl.configs.config import create_config_parser
+        return create_config_parser(), True
+    except ImportError:
+        return argparse.ArgumentParser(), False
+
+
 def get_args(argv=None):
-    """CLI of the reference's train/test scripts (openrl_ws/utils.py:230-264) minus OpenRL's own parser."""
-    p = argparse.ArgumentParser()
-    p.add_argument("--sim_device", type=str, default="cuda:0")
-    p.add_argument("--pipeline", type=str, default="gpu")
-    p.add_argument("--graphics_device_id", type=int, default=0)
-    p.add_argument("--num_threads", type=int, default=0)
-    p.add_argument("--subscenes", type=int, default=0)
-    p.add_argument("--task", type=str, default="go1gate")
-    p.add_argument("--algo", type=str, default="ppo")
-    p.add_argument("--resume", action="store_true", default=False)
-    p.add_argument("--run_name", type=str)
-    p.add_argument("--load_run", type=str)
-    p.add_argument("--checkpoint", type=str)
-    p.add_argument("--headless", action="store_true", default=True)
-    p.add_argument("--horovod", action="store_true", default=False)
-    p.add_argument("--rl_device", type=str, default="cuda:0")
-    p.add_argument("--num_envs", type=int)
-    p.add_argument("--seed", type=int, default=0)
-    p.add_argument("--max_iterations", type=int)
-    p.add_argument("--train_timesteps", type=int)
-    p.add_argument("--use_wandb", action="store_true", default=False)
-    p.add_argument("--use_tensorboard", action="store_true", default=False)
-    p.add_argument("--exp_name", type=str, default="default")
-    p.add_argument("--record_video", action="store_true", default=False)
-    return finish_args(p.parse_args(argv))
+    """CLI of the reference's train/test scripts (openrl_ws/utils.py:157-264): OpenRL's parser + gymutil's simulation flags +
+    the MQE flags, then the same derived fields."""
+    p, have_openrl = _base_parser()
+    taken = {o for a in p._actions for o in a.option_strings}
+
+    def add(name, **kw):
+        if name not in taken:               # OpenRL owns e.g. --seed; never redefine one of its flags
+            p.add_argument(name, **kw)
+    add("--sim_device", type=str, default="cuda:0")
+    add("--pipeline", type=str, default="gpu")
+    add("--graphics_device_id", type=int, default=0)
+    add("--flex", action="store_true")
+    add("--physx", action="store_true")
+    add("--num_threads", type=int, default=0)
+    add("--subscenes", type=int, default=0)
+    add("--slices", type=int)
+    add("--task", type=str, default="go1gate")
+    add("--algo", type=str, default="ppo")
+    add("--resume", action="store_true", default=False)
+    add("--run_name", type=str)
+    add("--load_run", type=str)
+    add("--checkpoint", type=str)
+    add("--headless", action="store_true", default=True)
+    add("--horovod", action="store_true", default=False)
+    add("--rl_device", type=str, default="cuda:0")
+    add("--num_envs", type=int)
+    add("--seed", type=int, default=0)
+    add("--max_iterations", type=int)
+    add("--train_timesteps", type=int)
+    add("--use_wandb", action="store_true", default=False)
+    add("--use_tensorboard", action="store_true", default=False)
+    add("--exp_name", type=str, default="default")
+    add("--record_video", action="store_true", default=False)
+    args = finish_args(p.parse_args(argv))
+    if args.slices is None:
+        args.slices = args.subscenes
+    return args

@@ -1,5 +1,6 @@
 import os, sys, time
-sys.path[:0] = ["/root/repo", "/root/repo/multiagent-quadruped-environment_amd"]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "multiagent-quadruped-environment_amd")]
 import torch
 import bench
 for envs in (64, 256):

@@ -35,8 +35,9 @@ for task in ENV_DICT:
             rec["max_policy_action_diff_step0"] = float((eh.tensor(abi.T_ACTIONS).cpu() - eo.tensor(abi.T_ACTIONS)).abs().max())
         if t in (5, 20, 50):
             dev = (eh.tensor(abi.T_ROOT_STATE).cpu()[:, :A, :3] - eo.tensor(abi.T_ROOT_STATE)[:, :A, :3]).abs().amax(dim=(1, 2))
-            rec[f"pos_dev_m_step{t}"] = {"median": float(dev.median()), "p99": float(dev.quantile(0.99)), "finite": bool(torch.isfinite(dev).all())}
+            rec[f"pos_dev_m_step{t}"] = {"median": float(dev.median()), "p99": float(dev.quantile(0.99)), "max": float(dev.max()), "finite": bool(torch.isfinite(dev).all())}
     rec["reset_flag_mismatches_in_50_steps"] = mism
+    rec["contact_list_overflows_hip_oracle"] = [int(eh.tensor(abi.T_CONTACT_OVERFLOW).sum()), int(eo.tensor(abi.T_CONTACT_OVERFLOW).sum())]
     rec["seconds"] = round(time.time() - t0, 1)
     out[task] = rec
     print(task, json.dumps(rec))

@@ -214,3 +214,86 @@ def test_low_level_control_types_through_go1_step(oracle_backed):
         env.close()
     finally:
         Go1GateCfg.control.control_type = old
+
+
+def test_get_args_composes_with_the_openrl_parser(monkeypatch):
+    """openrl_ws.utils.get_args builds on OpenRL's create_config_parser() when the trainer is importable (reference
+    openrl_ws/utils.py:230-264), so that train.py's `PPONet(env, cfg=args)` finds OpenRL's keys; without it the CLI still parses"""
+    import argparse
+    import sys
+    from openrl_ws import utils as U
+    a = U.get_args(["--task", "go1seesaw", "--num_envs", "7", "--seed", "3"])
+    assert (a.task, a.num_envs, a.seed, a.sim_device, a.use_gpu_pipeline, a.slices) == ("go1seesaw", 7, 3, "cuda:0", True, 0)
+    fake = types.ModuleType("openrl.configs.config")
+
+    def create_config_parser():
+        p = argparse.ArgumentParser()
+        p.add_argument("--seed", type=int, default=11)          # OpenRL owns --seed
+        p.add_argument("--lr", type=float, default=5e-4)
+        p.add_argument("--episode_length", type=int, default=200)
+        return p
+    fake.create_config_parser = create_config_parser
+    for name in ("openrl", "openrl.configs"):
+        monkeypatch.setitem(sys.modules, name, types.ModuleType(name))
+    monkeypatch.setitem(sys.modules, "openrl.configs.config", fake)
+    a = U.get_args(["--task", "go1gate", "--lr", "1e-3"])
+    assert a.lr == 1e-3 and a.episode_length == 200 and a.seed == 11 and a.task == "go1gate" and a.headless is True
+    assert a.sim_device == "cuda:0" and a.sim_device_id == 0 and a.physics_engine == 1
+
+
+def test_seed_reaches_the_engine(oracle_backed):
+    def reset_state(seed):
+        a = args_for("go1gate", 6)
+        a.seed = seed
+        env, _ = make_mqe_env("go1gate", a, custom_cfg(a))
+        assert env.env.engine.desc.seed == seed
+        env.reset()
+        st = (env.env.dof_pos.clone(), env.env.root_states.clone())
+        env.close()
+        return st
+    q0, r0 = reset_state(0)
+    q0b, r0b = reset_state(0)
+    q7, r7 = reset_state(7)
+    assert torch.equal(q0, q0b) and torch.equal(r0, r0b)
+    assert not torch.equal(q0, q7) and not torch.equal(r0[:, 7:], r7[:, 7:])
+
+
+def test_step_returns_tensors_of_its_own(oracle_backed):
+    """obs, reward and done of a step are that step's alone (`done` used to be a live view of engine memory)"""
+    a = args_for("go1gate", 4)
+    env, _ = make_mqe_env("go1gate", a, custom_cfg(a))
+    env.reset()
+    o1, r1, d1, _ = env.step(torch.zeros(4, 2, 3))
+    keep = (o1.clone(), r1.clone(), d1.clone())
+    env.env.engine.tensor(__import__("mqe.engine.abi", fromlist=["abi"]).T_ROOT_STATE)[:, 0, 2] += 3.0      # robots dropped: the next steps reset
+    for t in range(30):
+        o2, r2, d2, _ = env.step(torch.zeros(4, 2, 3))
+        if d2.any():
+            break
+    assert d2.any() and not d1.any()
+    assert torch.equal(o1, keep[0]) and torch.equal(r1, keep[1]) and torch.equal(d1, keep[2])
+    env.close()
+
+
+def test_defender_task_through_go1_step(oracle_backed):
+    """Go1FootballDefender.step (go1_football_defender.py:25-31): two learner commands in, the scripted defender's appended
+    (mqe_defender_command): identical to the fused wrapper step"""
+    a = args_for("go1football-defender", 5)
+    e1, _ = make_mqe_env("go1football-defender", a, custom_cfg(a))
+    e2, _ = make_mqe_env("go1football-defender", a, custom_cfg(a))
+    e1.reset(); e2.reset()
+    g = torch.Generator().manual_seed(8)
+    for t in range(4):
+        act = torch.rand(5, 2, 3, generator=g) * 2 - 1
+        o1, r1, d1, _ = e1.step(act)
+        ob, rew, reset, _ = e2.env.step((act.clip(-1, 1) * e2.action_scale).reshape(-1, 3))
+        assert torch.allclose(e1.env.root_states, e2.env.root_states, atol=1e-6) and torch.equal(d1, reset)
+    e1.close(); e2.close()
+
+
+def test_sheep_random_walk_draws_oracle():
+    from test_env_api_gpu import _sheep_draws
+    from helpers import oracle_engine
+    a, b, c = _sheep_draws(oracle_engine, 0, N=32), _sheep_draws(oracle_engine, 0, N=32), _sheep_draws(oracle_engine, 1, N=32)
+    assert torch.equal(a, b) and (a[0] - a[1]).abs().mean() > 0.5 and (a[0] - c[0]).abs().mean() > 0.5
+    assert abs(float(a.mean())) < 0.15 and 0.85 < float(a.std()) < 1.15

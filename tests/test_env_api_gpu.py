@@ -1,0 +1,206 @@
+"""-m gpu: the outer Python boundary (make_mqe_env / ENV_DICT / task wrappers / OpenRL adapter) on the DEFAULT engine
+-- the HIP one behind the C ABI -- i.e. exactly what `openrl_ws/train.py` would drive.  tests/test_env_api.py holds the same
+checks on the oracle-backed engine (CPU)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from mqe.engine import abi
+from mqe.envs.go1.go1 import Go1
+from mqe.envs.utils import ENV_DICT, make_mqe_env, custom_cfg
+from mqe.utils.helpers import finish_args
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _restore_registry(monkeypatch):
+    monkeypatch.setattr(Go1, "shard", None)
+    saved = {k: (v["config"].env.num_envs, getattr(v["config"], "seed", None)) for k, v in ENV_DICT.items()}
+    yield
+    for k, v in ENV_DICT.items():
+        v["config"].env.num_envs = saved[k][0]
+
+
+def args_for(task, n, seed=0):
+    return finish_args(types.SimpleNamespace(task=task, num_envs=n, seed=seed, headless=True, record_video=False,
+                                             sim_device="cuda:0", pipeline="gpu", subscenes=0, num_threads=0))
+
+
+@pytest.mark.parametrize("task,A,Aw,D", [("go1gate", 2, 2, 16), ("go1sheep-hard", 2, 2, 34), ("go1seesaw", 2, 2, 14),
+                                         ("go1football-defender", 3, 2, 20), ("go1pushbox", 2, 2, 22)])
+def test_make_mqe_env_surface_on_the_hip_engine(task, A, Aw, D):
+    a = args_for(task, 8)
+    env, cfg = make_mqe_env(task, a, custom_cfg(a))
+    from mqe.engine.hip_engine import HipEngine
+    assert isinstance(env.env.engine, HipEngine) and str(env.device).startswith("cuda")
+    assert cfg is ENV_DICT[task]["config"] and cfg.env.num_envs == 8
+    assert env.num_envs == 8 and env.env.num_agents == A and env.num_agents == Aw
+    assert env.observation_space.shape == (D,) and env.action_space.shape == (3,)
+    assert env.dt == pytest.approx(0.02) and env.max_episode_length == np.ceil(cfg.env.episode_length_s / 0.02)
+    obs = env.reset()
+    assert obs.is_cuda and obs.shape == (8, Aw, D) and obs.dtype == torch.float32
+    assert torch.equal(obs[:, :, :Aw].cpu(), torch.eye(Aw).expand(8, Aw, Aw))
+    kept = []
+    for t in range(3):
+        obs, rew, done, info = env.step(torch.rand(8, Aw, 3, device="cuda") * 2 - 1)
+        kept.append((obs, rew, done, obs.clone(), rew.clone(), done.clone()))
+    assert obs.shape == (8, Aw, D) and rew.shape == (8, Aw) and done.shape == (8,) and done.dtype == torch.bool
+    # every step hands out fresh tensors (the reference builds new ones per step): nothing a caller kept was overwritten
+    torch.cuda.synchronize()
+    for o, r, d, oc, rc, dc in kept:
+        assert torch.equal(o, oc) and torch.equal(r, rc) and torch.equal(d, dc)
+    assert len({k[0].data_ptr() for k in kept}) == 3 and len({k[2].data_ptr() for k in kept}) == 3
+    assert isinstance(info, dict) and "time_outs" in info
+    assert env.reward_buffer["step count"] == 3
+    for name in ("root_states_npc", "env_origins", "collide_buf", "reset_ids", "r_term_buff", "p_term_buff", "base_init_state",
+                 "BarrierTrack_kwargs", "all_dof_states", "npc_indices", "env_agent_indices", "agent_origins", "obs_buf"):
+        assert getattr(env, name) is not None
+    assert env.obs_buf.base_pos.shape == (8 * A, 3) and env.obs_buf.base_rpy.shape == (8 * A, 3)
+    assert env.root_states.shape == (8 * A, 13) and env.dof_pos.shape == (8, 12 * A)
+    assert env.history_locomotion_obs.shape == (8 * A, 2100)
+    assert env.reset_ids.dtype == torch.int64
+    sums = env.env.engine.tensor(abi.T_REWARD_SUMS)
+    assert sums.is_cuda and torch.isfinite(sums).all()
+    env.close()
+
+
+@pytest.mark.parametrize("task", ["go1gate", "go1football-defender"])
+def test_unfused_step_equals_fused_on_the_hip_engine(task):
+    """wrapper.step (one fused mqe_step) == the reference's call pattern: the wrapper clips and scales, Go1.step runs policy,
+    4 x (torques, simulate, post_decimation_step) and the post-physics step through the Isaac-Gym-shaped entry points; for the
+    defender task Go1.step also appends the scripted command (mqe_defender_command, go1_football_defender.py:25-31)."""
+    N = 16
+    a = args_for(task, N)
+    e1, _ = make_mqe_env(task, a, custom_cfg(a))
+    e2, _ = make_mqe_env(task, a, custom_cfg(a))
+    e1.reset(); e2.reset()
+    Aw = e1.num_agents
+    g = torch.Generator().manual_seed(3)
+    for t in range(4):
+        act = (torch.rand(N, Aw, 3, generator=g) * 3 - 1.5).cuda()
+        o1, r1, d1, _ = e1.step(act)
+        cmd = (act.clip(-1, 1) * e2.action_scale).reshape(-1, 3)
+        ob, rew, reset, extras = e2.env.step(cmd)
+        torch.cuda.synchronize()
+        assert torch.allclose(e1.env.root_states, e2.env.root_states, atol=1e-6)
+        assert torch.allclose(e1.env.dof_pos, e2.env.dof_pos, atol=1e-6)
+        assert torch.equal(d1, reset)
+        assert torch.allclose(ob.base_pos, e1.env.obs_buf.base_pos, atol=1e-6)
+        assert (rew == 0).all()
+        # the per-substep logs of post_decimation_step (legged_robot.py:112-115): fused == unfused
+        for kind in (abi.T_SUBSTEP_TORQUES, abi.T_SUBSTEP_DOF_VEL, abi.T_SUBSTEP_EXCEED_DOF_POS_LIMITS):
+            x1, x2 = e1.env.engine.tensor(kind), e2.env.engine.tensor(kind)
+            assert torch.allclose(x1.float(), x2.float(), atol=2e-5), kind
+    e1.close(); e2.close()
+
+
+def test_openrl_adapter_on_the_hip_engine():
+    from openrl_ws.utils import make_env
+    a = args_for("go1gate", 8)
+    env, cfg = make_env(a, custom_cfg(a))
+    assert env.agent_num == 2 and env.parallel_env_num == 8
+    o = env.reset()
+    assert isinstance(o, np.ndarray) and o.shape == (8, 2, 16)
+    o, r, d, infos = env.step(np.random.RandomState(0).uniform(-2, 2, (8, 2, 3)))
+    assert o.shape == (8, 2, 16) and r.shape == (8, 2, 1) and d.shape == (8, 2) and d.dtype == bool and len(infos) == 8
+    br = env.batch_rewards(None)
+    assert "average step reward" in br and "target reward" in br
+    assert float(env.env.reward_buffer["target reward"]) == 0.0 and env.env.reward_buffer["step count"] == 0   # cleared by the read
+    env.close()
+
+
+def test_device_resident_hand_off():
+    """`step_torch` (tensors stay on the GPU, fresh per step) and `step_dlpack` (any `__dlpack__` producer in, DLPack
+    exporters out) against the numpy adapter of the reference (openrl_ws/utils.py:53-67) on a twin env."""
+    from openrl_ws.utils import make_env
+    N = 8
+    a = args_for("go1gate", N)
+    e_np, _ = make_env(a, custom_cfg(a))
+    e_t, _ = make_env(a, custom_cfg(a))
+    e_d, _ = make_env(a, custom_cfg(a))
+    for e in (e_np, e_t, e_d):
+        e.reset()
+    rs = np.random.RandomState(5)
+    held = []
+    for t in range(5):
+        act = rs.uniform(-2, 2, (N, 2, 3)).astype(np.float32)
+        o, r, d, _ = e_np.step(act)
+        ot, rt, dt_ = e_t.step_torch(torch.from_numpy(act).cuda())
+        assert ot.is_cuda and rt.is_cuda and dt_.is_cuda and rt.shape == (N, 2, 1) and dt_.shape == (N, 2) and dt_.dtype == torch.bool
+        assert np.array_equal(ot.cpu().numpy(), o) and np.array_equal(rt.cpu().numpy(), r) and np.array_equal(dt_.cpu().numpy(), d)
+        held.append((ot, ot.clone()))
+
+        class Producer:                     # a foreign array: only the DLPack protocol is visible
+            def __init__(self, t): self._t = t
+            def __dlpack__(self, stream=None): return self._t.__dlpack__(stream=stream) if stream is not None else self._t.__dlpack__()
+            def __dlpack_device__(self): return self._t.__dlpack_device__()
+        od, rd, dd = e_d.step_dlpack(Producer(torch.from_numpy(act).cuda()))
+        for x in (od, rd, dd):
+            assert hasattr(x, "__dlpack__") and x.__dlpack_device__()[0] in (2, 10)          # kDLCUDA / kDLROCM
+        o2 = torch.from_dlpack(od)
+        assert o2.data_ptr() == od.data_ptr()                                                   # zero-copy
+        assert np.array_equal(o2.cpu().numpy(), o) and np.array_equal(torch.from_dlpack(rd).cpu().numpy(), r)
+        assert np.array_equal(torch.from_dlpack(dd).cpu().numpy().astype(bool), d)
+    torch.cuda.synchronize()
+    for kept, copy in held:
+        assert torch.equal(kept, copy)
+    for e in (e_np, e_t, e_d):
+        e.close()
+
+
+def test_seed_reaches_the_engine():
+    """make_env hands --seed to the engine (every in-engine draw is keyed by it): same seed -> identical reset states, another
+    seed -> other joint ratios / base velocities"""
+    def reset_state(seed):
+        a = args_for("go1gate", 16, seed=seed)
+        env, _ = make_mqe_env("go1gate", a, custom_cfg(a))
+        assert env.env.engine.desc.seed == seed
+        env.reset()
+        st = (env.env.dof_pos.clone(), env.env.root_states.clone())
+        env.close()
+        return st
+    q0, r0 = reset_state(0)
+    q0b, r0b = reset_state(0)
+    q7, r7 = reset_state(7)
+    assert torch.equal(q0, q0b) and torch.equal(r0, r0b)
+    assert not torch.equal(q0, q7) and not torch.equal(r0[:, 7:], r7[:, 7:])
+
+
+def _sheep_draws(make_engine, seed, steps=3, N=64):
+    """N(0,1) draws of the sheep script recovered through the unfused entry point: (increment in hash mode - increment with a
+    scripted zero noise) / (2 * randomness), from identical states (velocities zeroed before every call; no physics in between,
+    so the deterministic part -- cohesion + repulsion, functions of positions -- is the same every time)"""
+    from helpers import make_desc
+    d0, k0, _ = make_desc("go1sheep-hard", N, noise_mode=1)
+    d1, k1, _ = make_desc("go1sheep-hard", N)
+    d1.seed = d0.seed = seed
+    assert d1.sheep_movement_randomness == pytest.approx(0.1) and d1.noise_mode == 0 and d0.noise_mode == 1
+    es, eh = make_engine(d0, k0), make_engine(d1, k1)
+    es.reset_all(); eh.reset_all()
+    zs = []
+    for t in range(steps):
+        for e in (es, eh):
+            e.tensor(abi.T_ROOT_STATE)[:, 2:, 7:10] = 0
+            e.post_physics_step()
+        if eh.tensor(abi.T_ROOT_STATE).is_cuda:
+            torch.cuda.synchronize()
+        assert not bool(eh.tensor(abi.T_RESET_BUF).any()) and not bool(es.tensor(abi.T_RESET_BUF).any())
+        zs.append(((eh.tensor(abi.T_ROOT_STATE)[:, 2:, 7:9] - es.tensor(abi.T_ROOT_STATE)[:, 2:, 7:9]) / 0.2).cpu().clone())
+    es.close(); eh.close()
+    return torch.stack(zs)
+
+
+def test_sheep_random_walk_is_drawn_in_the_engine():
+    """go1sheep-hard: `sheep_movement_randomness * randn * 2` is drawn fresh every step (go1_sheep.py:43) -- in MQE_NOISE_HASH mode
+    by the engine itself, keyed by (seed, global env id, step): standard normal, different every step and for every seed, the
+    same again for the same seed, and the same numbers as the CPU oracle draws"""
+    from helpers import hip_engine, oracle_engine
+    a, b, c = _sheep_draws(hip_engine, 0), _sheep_draws(hip_engine, 0), _sheep_draws(hip_engine, 1)
+    assert torch.equal(a, b)
+    assert (a[0] - a[1]).abs().mean() > 0.5 and (a[0] - c[0]).abs().mean() > 0.5
+    assert abs(float(a.mean())) < 0.1 and 0.9 < float(a.std()) < 1.1
+    o = _sheep_draws(oracle_engine, 0)
+    assert (a - o).abs().max() < 1e-4

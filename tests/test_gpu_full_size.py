@@ -1,0 +1,123 @@
+"""-m gpu: the BASELINE.json configurations at their FULL sizes on the HIP engine.
+
+  config 2  go1gate               4096 envs x 2 agents                      (also tests/test_gpu_parity.py::test_full_size_invariants)
+  config 3  go1sheep-hard         2048 envs x (2 agents + 9 sheep), tracks assigned by randint as legged_robot.py:980-993
+  config 4  go1seesaw             4096 envs x (2 agents + articulated seesaw)
+  config 5  go1football-defender  4096 envs x (3 agents + ball) = the per-GPU shard of the 32768-env, 8-GPU configuration
+
+The oracle cannot run these sizes in seconds; what ties them to the small batches it does check is SIZE INDEPENDENCE: envs
+[g0, g0 + NS) of the full batch and the same GLOBAL env ids run alone (env_id_offset, same track assignment) must agree bit for
+bit over a fused rollout -- every kernel treats a row / an env independently of its neighbours and every random draw is keyed by
+the global env id.  Plus invariants that need no oracle: finite state, unit quaternions, bodies inside the arena, joint limits,
+no truncated contact list."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import make_desc, hip_engine, task_cfg
+from mqe.engine import abi
+
+pytestmark = pytest.mark.gpu
+
+FULL = [("go1gate", 4096), ("go1sheep-hard", 2048), ("go1seesaw", 4096), ("go1football-defender", 4096)]
+
+
+def assign_tracks(task, NF, seed=0):
+    """terrain_levels / terrain_types of the GLOBAL batch as Go1._create_scene draws them (reference legged_robot.py:980-993):
+    levels = randint(0, max_init_level + 1), types = env id mod num_cols"""
+    cfg = task_cfg(task)
+    rows, cols = cfg.terrain.num_rows, cfg.terrain.num_cols
+    max_level = cfg.terrain.max_init_terrain_level if cfg.terrain.curriculum else rows - 1
+    g = torch.Generator().manual_seed(seed)
+    levels = torch.randint(0, max_level + 1, (NF,), generator=g).numpy()
+    types = np.arange(NF) % cols
+    return levels, types
+
+
+def shard_desc(task, NF, g0, n, levels, types):
+    return make_desc(task, n, levels=levels[g0:g0 + n], types=types[g0:g0 + n], env_id_offset=g0)
+
+
+@pytest.mark.parametrize("task,NF", FULL)
+def test_full_size_invariants(task, NF):
+    levels, types = assign_tracks(task, NF)
+    d, k, ctx = shard_desc(task, NF, 0, NF, levels, types)
+    if task == "go1sheep-hard":
+        assert len(set(zip(levels.tolist(), types.tolist()))) == 35, "all 5 x 7 tracks must be in use"
+    e = hip_engine(d, k)
+    e.reset_all()
+    A, P = d.num_agents, d.num_npcs
+    Aw = e.tensor(abi.T_WRAPPER_OBS).shape[1]
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    for t in range(40):
+        e.step(torch.rand(NF, Aw, 3, device="cuda", generator=g) * 2 - 1)
+    torch.cuda.synchronize()
+    root, dof = e.tensor(abi.T_ROOT_STATE), e.tensor(abi.T_DOF_STATE)
+    assert torch.isfinite(root).all() and torch.isfinite(dof).all()
+    assert torch.isfinite(e.tensor(abi.T_WRAPPER_OBS)).all() and torch.isfinite(e.tensor(abi.T_WRAPPER_REWARD)).all()
+    assert torch.isfinite(e.tensor(abi.T_CONTACT_FORCE)).all()
+    rob = root[:, :A]
+    assert ((rob[..., 3:7].norm(dim=-1) - 1).abs() < 1e-4).all()                           # unit quaternions
+    zmax = 2.0 if task == "go1seesaw" else 1.0                                             # the seesaw's far end is 1.3 m up
+    assert rob[..., 2].min() > 0.0 and rob[..., 2].max() < zmax                            # nobody fell through the ground / flew away
+    eo = torch.as_tensor(ctx["env_origins"], device="cuda")[:, None, :2]
+    assert (root[:, :, :2] - eo).abs().max() < 30.0                                        # nothing left its track
+    q = dof[:, :12 * A, 0].reshape(NF, A, 12)
+    lo = torch.tensor([d.robot.dof_lower[j] for j in range(12)], device="cuda")
+    hi = torch.tensor([d.robot.dof_upper[j] for j in range(12)], device="cuda")
+    assert (q > lo - 0.05).all() and (q < hi + 0.05).all()                                 # joint limits, to solver tolerance
+    vl = torch.tensor([d.robot.dof_vel_limit[j] for j in range(12)], device="cuda")
+    assert (dof[:, :12 * A, 1].reshape(NF, A, 12).abs() <= vl * 1.0001).all()               # URDF joint velocity limits (go1.urdf:115,157,185)
+    sv = e.tensor(abi.T_SUBSTEP_DOF_VEL).reshape(NF, 4, A, 12)
+    assert (sv.abs() <= vl * 1.0001).all() and torch.equal(sv[:, 3].reshape(NF, -1), dof[:, :12 * A, 1])
+    obs = e.tensor(abi.T_WRAPPER_OBS)
+    assert obs.shape[:2] == (NF, Aw)
+    if task not in ("go1football-defender",):
+        ids = obs[:, :, :Aw]
+        assert torch.equal(ids, torch.eye(Aw, device="cuda").expand(NF, Aw, Aw))            # one-hot agent ids
+    if P and task == "go1sheep-hard":
+        sheep = root[:, A:]
+        assert (sheep[..., 7:9].abs() <= 2.0).all() and (sheep[..., 2] >= 0).all() and (sheep[..., 2] <= 0.3 + 0.05).all()   # go1_sheep.py:59-60
+    # how often did a bounded contact list drop a touching pair?  (per env and substep; 0 expected on these scenes)
+    ov = e.tensor(abi.T_CONTACT_OVERFLOW)
+    assert int(ov.sum()) <= NF * 40 * 4 // 1000, f"contact lists truncated in {int(ov.sum())} env-substeps"
+    assert int(e.tensor(abi.T_RESET_COUNT).min()) >= 1
+    e.close()
+
+
+@pytest.mark.parametrize("task,NF", FULL)
+def test_full_size_batch_is_the_union_of_its_shards(monkeypatch, task, NF):
+    """20 fused steps: envs [g0, g0 + 32) of the full batch == the same global env ids run as a 32-env batch of their own (the size
+    the oracle parity tests cover), BIT FOR BIT -- state, returned batch, reset flags, episode counters.  The layer-0 kernel is
+    pinned to the split-f16 one, which the small batch would not pick by itself."""
+    monkeypatch.setenv("MQE_GEMM_SPLIT", "1")
+    NS = 32
+    levels, types = assign_tracks(task, NF)
+    df, kf, _ = shard_desc(task, NF, 0, NF, levels, types)
+    ef = hip_engine(df, kf)
+    ef.reset_all()
+    small = []
+    for g0 in (0, (NF // 2 // NS) * NS - NS // 2 + 7, NF - NS):     # first, a range straddling tile boundaries, last
+        d, k, _ = shard_desc(task, NF, g0, NS, levels, types)
+        e = hip_engine(d, k)
+        e.reset_all()
+        small.append((g0, e))
+    Aw = ef.tensor(abi.T_WRAPPER_OBS).shape[1]
+    g = torch.Generator().manual_seed(11)
+    kinds = (abi.T_ROOT_STATE, abi.T_DOF_STATE, abi.T_WRAPPER_OBS, abi.T_WRAPPER_REWARD, abi.T_RESET_BUF, abi.T_EPISODE_LENGTH,
+             abi.T_CONTACT_FORCE, abi.T_SUBSTEP_TORQUES)
+    for t in range(-1, 20):
+        if t >= 0:
+            a = torch.rand(NF, Aw, 3, generator=g) * 2 - 1
+            ef.step(a.cuda().contiguous())
+            for g0, e in small:
+                e.step(a[g0:g0 + NS].cuda().contiguous())
+        torch.cuda.synchronize()
+        for g0, e in small:
+            for kind in kinds:
+                full = ef.tensor(kind)
+                per = full.shape[0] // NF
+                assert torch.equal(full[g0 * per:(g0 + NS) * per], e.tensor(kind)), f"{task}: step {t}, envs from {g0}, tensor kind {kind}"
+    ef.close()
+    for _, e in small:
+        e.close()

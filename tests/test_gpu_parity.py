@@ -98,8 +98,10 @@ def test_policy_layer0_paths_are_f32_equivalent(monkeypatch, split, N):
 
 @pytest.mark.parametrize("task,N", [("go1gate", 128), ("go1football-defender", 16), ("go1sheep-hard", 14), ("go1seesaw", 16), ("go1football-2vs2", 8), ("go1football-1vs1", 16), ("go1pushbox", 16), ("go1revolvingdoor", 16), ("go1bridge", 16), ("go1wrestling", 16), ("go1tug", 16)])
 def test_fused_rollout_matches_oracle(task, N):
-    """20 fused step() calls (policy + 4 substeps + post-step + wrapper) from the seeded reset distribution.
-    Contact dynamics amplify rounding differences, so the bound is on the typical (median) deviation and flags."""
+    """20 fused step() calls (policy + 4 substeps + post-step + wrapper) from the seeded reset distribution, nothing re-synchronised.
+    Contact dynamics amplify rounding differences (a contact that closes one substep earlier), so the bound is a distribution
+    over envs -- median, 99th percentile AND maximum of the base-position deviation (the measured values are two to three orders
+    below: profiles/r02_parity_sweep.json) -- and the reset flags must agree in every env at every step."""
     eh, eo, d = _pair(task, N)
     eh.reset_all(); eo.reset_all()
     g = torch.Generator().manual_seed(11)
@@ -117,9 +119,11 @@ def test_fused_rollout_matches_oracle(task, N):
             close(eh.tensor(abi.T_ACTIONS), eo.tensor(abi.T_ACTIONS), atol=5e-5, what="policy actions step 0")
     dev = torch.stack(dev_pos)
     assert torch.isfinite(dev).all()
-    assert dev[4].median() < 1e-4, dev[4].median()
-    assert dev[-1].median() < 5e-3, dev[-1].median()
-    assert mism <= max(2, N // 16), f"{mism} reset-flag mismatches"
+    for step, med, p99, mx in ((4, 1e-5, 1e-4, 1e-3), (19, 1e-4, 1e-3, 2e-2)):
+        got = (float(dev[step].median()), float(dev[step].quantile(0.99)), float(dev[step].max()))
+        assert got[0] < med and got[1] < p99 and got[2] < mx, f"{task}: base position deviation after {step + 1} steps (median, p99, max) = {got}"
+    assert mism == 0, f"{mism} reset-flag mismatches"
+    assert int(eh.tensor(abi.T_CONTACT_OVERFLOW).sum()) == int(eo.tensor(abi.T_CONTACT_OVERFLOW).sum())
 
 
 @pytest.mark.parametrize("N,split", [(1, "0"), (1, "1"), (3, "1"), (37, "0"), (37, "1")])
