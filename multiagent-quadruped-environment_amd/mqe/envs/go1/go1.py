@@ -14,7 +14,7 @@ import torch
 
 from mqe.engine import abi
 from mqe.engine.desc import build_desc, task_kind, REWARD_TERMS
-from mqe.utils.helpers import class_to_dict
+from mqe.utils.helpers import class_to_dict, engine_seed
 from mqe.utils.terrain import get_terrain_cls
 
 
@@ -104,7 +104,7 @@ class Go1:
         self.task = task_kind(cfg)
         gate_pos = self._task_gate_pos()
         desc, keep = build_desc(cfg, N, t, self._env_origins_np, self._agent_origins_np, gate_pos=gate_pos,
-                                env_id_offset=g0, seed=int(getattr(cfg, "seed", 0) or 0), task=self.task)
+                                env_id_offset=g0, seed=engine_seed(), task=self.task)
         self.body_is_synthetic = dict(k for k in keep if isinstance(k, tuple)).get("body_is_synthetic", True)
         self.engine = type(self).engine_factory(desc, keep, self.device)
         self.device = str(self.engine.torch_device) if hasattr(self.engine, "torch_device") else self.device

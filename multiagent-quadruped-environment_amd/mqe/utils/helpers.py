@@ -26,9 +26,21 @@ def merge_dict(this: dict, other: dict):
     return merged
 
 
+_ENGINE_SEED = 0
+
+
+def engine_seed():
+    """Seed of the engine's counter RNG (reset noise, domain parameters, pushes, the sheep's random walk): the value of the last
+    set_seed() call -- the reference's draws follow torch's global generator, which the same call seeds (helpers.py:81-91).  An
+    env-sharded run must use one seed on all ranks; draws are keyed by the GLOBAL env id, so the shards then agree."""
+    return _ENGINE_SEED
+
+
 def set_seed(seed):
+    global _ENGINE_SEED
     if seed == -1:
         seed = np.random.randint(0, 10000)
+    _ENGINE_SEED = int(seed)
     print("Setting seed: {}".format(seed))
     random.seed(seed)
     np.random.seed(seed)
@@ -104,9 +116,7 @@ def make_env(task_class, env_cfg, args=None):
     if args is None:
         args = get_args()
     env_cfg, _ = update_cfg_from_args(env_cfg, None, args)
-    # the seed also keys every in-engine draw (reset noise, domain parameters, pushes, the sheep's random walk): one value per
-    # run, the same on every rank of an env-sharded run (draws are keyed by the GLOBAL env id, so shards then agree)
-    env_cfg.seed = set_seed(args.seed)
+    set_seed(args.seed)          # also the engine's seed: see engine_seed()
     sim_params = parse_sim_params(args, {"sim": class_to_dict(env_cfg.sim)})
     env = task_class(cfg=env_cfg, sim_params=sim_params, physics_engine=args.physics_engine,
                      sim_device=args.sim_device, headless=args.headless)

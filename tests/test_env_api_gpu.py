@@ -18,10 +18,10 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True)
 def _restore_registry(monkeypatch):
     monkeypatch.setattr(Go1, "shard", None)
-    saved = {k: (v["config"].env.num_envs, getattr(v["config"], "seed", None)) for k, v in ENV_DICT.items()}
+    saved = {k: v["config"].env.num_envs for k, v in ENV_DICT.items()}
     yield
     for k, v in ENV_DICT.items():
-        v["config"].env.num_envs = saved[k][0]
+        v["config"].env.num_envs = saved[k]
 
 
 def args_for(task, n, seed=0):
