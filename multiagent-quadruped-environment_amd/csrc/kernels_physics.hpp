@@ -128,6 +128,7 @@ __device__ __forceinline__ void con_store(float* cr, int a, int linkA, int b, in
 }
 
 __host__ __device__ inline int mqe_maxc(int A, int P, int cap_npc) { int v = 8 * A + cap_npc * P; return v > 40 ? 40 : v; }
+#define MQE_LIMIT_PASSES 4   // Gauss-Seidel passes of the joint position / speed limits per substep (oracle: the same constant)
 #define CAP_ROBOT 8     // terrain / static-object contacts kept per robot (spheres are priority ordered: feet first)
 // NPCs keep m->cap_npc one-sided contacts each (2; a box resting on a face 4): per-actor caps so that no actor starves the ones after it
 
@@ -1178,15 +1179,19 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       const float vl = rm.dof_vel_limit[j];
       if (vl > 0.0f) { lo = fmaxf(lo, -vl); hi = fminf(hi, vl); }
     };
-    bool viol = false;
-    for (int d = lane; d < A * 12; d += 64) {
-      const int r = d / 12, j = d - r * 12;
-      const float q = lds[L.dof + d * 2], v = Vm[r * MQE_RD + 6 + j];
-      float lo, hi;
-      jbound(j, q, lo, hi);
-      viol = viol || v < lo || v > hi;
-    }
-    if (__ballot(viol) != 0ull) {
+    // Gauss-Seidel over the violated joints: an impulse on one joint changes its neighbours' speeds, so the pass is repeated while
+    // something still violates (at most MQE_LIMIT_PASSES times; normally none or one runs), then the bound is enforced exactly
+    for (int pass = 0; pass <= MQE_LIMIT_PASSES; pass++) {
+      bool viol = false;
+      for (int d = lane; d < A * 12; d += 64) {
+        const int r = d / 12, j = d - r * 12;
+        const float q = lds[L.dof + d * 2], v = Vm[r * MQE_RD + 6 + j];
+        float lo, hi;
+        jbound(j, q, lo, hi);
+        viol = viol || v < lo || v > hi;
+        if (pass == MQE_LIMIT_PASSES) Vm[r * MQE_RD + 6 + j] = fminf(fmaxf(v, lo), hi);     // residual of the last pass (~1e-3 of the violation)
+      }
+      if (__ballot(viol) == 0ull || pass == MQE_LIMIT_PASSES) break;
       for (int r = 0; r < A; r++)
         for (int j = 0; j < 12; j++) {
           const float q = lds[L.dof + (r * 12 + j) * 2], vj = Vm[r * MQE_RD + 6 + j];
@@ -1203,6 +1208,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
           }
         }
     }
+    __syncthreads();
   }
   if (SS && lane == 0) {              // hinge: velocity limit, then the geometric end stops
     float v = Vm[A * MQE_RD];

@@ -37,6 +37,7 @@ typedef REAL real;
 #define MAXDOF (MAXA * RD + MAXP * 6 + 1)
 #define MAXC 64                     /* storage; the active bound is env_maxc() */
 static inline int env_maxc(int A, int P, int cap_npc) { int v = 8 * A + cap_npc * P; return v > 40 ? 40 : v; } /* = mqe_maxc() of the engine */
+#define LIMIT_PASSES 4 /* Gauss-Seidel passes of the joint position / speed limits per substep (= MQE_LIMIT_PASSES of the engine) */
 #define CAP_ROBOT 8   /* terrain / static-object contacts kept per robot (spheres are priority ordered: feet first) */
 #define FR MQE_FRAME
 #define OBS_BAG 74
@@ -544,7 +545,7 @@ static real sdf_sample(const mqo_sim* s, real x, real y, real* gx, real* gy) {
   real hs = d->horizontal_scale;
   real fx = x / hs - (real)0.5, fy = y / hs - (real)0.5;   /* samples sit at cell centres */
   int nx = d->sdf_nx, ny = d->sdf_ny;
-  if (fx < 0) fx = 0; if (fy < 0) fy = 0;
+  if (!(fx >= 0)) fx = 0; if (!(fy >= 0)) fy = 0;     /* also catches NaN (a diverged state must not index out of the map) */
   if (fx > nx - 1) fx = (real)(nx - 1); if (fy > ny - 1) fy = (real)(ny - 1);
   int ix = (int)fx, iy = (int)fy;
   if (ix > nx - 2) ix = nx - 2; if (iy > ny - 2) iy = ny - 2;
@@ -1039,24 +1040,39 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
   {
     /* joint limits: q + dt*qd within [lower, upper] and |qd| <= the URDF velocity limit (go1.urdf:115,157,185; legged_robot.py:315;
      * PhysX maxJointVelocity); one pass after the contact iterations, violations removed by an impulse along the joint */
-    for (int r = 0; r < A; r++)
-      for (int j = 0; j < 12; j++) {
-        real q = dofs[(r * 12 + j) * 2];
-        real* v = w->v + r * RD;
-        real lo = (m->dof_lower[j] - q) / dt, hi = (m->dof_upper[j] - q) / dt;
-        if (m->dof_vel_limit[j] > 0) { real vl = m->dof_vel_limit[j]; if (lo < -vl) lo = -vl; if (hi > vl) hi = vl; }
-        real viol = 0;
-        if (v[6 + j] < lo) viol = lo - v[6 + j];
-        else if (v[6 + j] > hi) viol = hi - v[6 + j];
-        if (viol != 0) {
-          /* impulse along e_j: dv = Minv e_j * lambda with (Minv)_jj lambda = viol */
-          real col[RD];
-          memset(col, 0, sizeof col); col[6 + j] = 1;
-          chol_solve(w->L[r], RD, RD, col);
-          real lam = viol / col[6 + j];
-          for (int i = 0; i < RD; i++) v[i] += col[i] * lam;
+    /* Gauss-Seidel over the joints, repeated while something still violates (an impulse on one joint changes its neighbours'
+     * speeds), at most LIMIT_PASSES times; then the bound is enforced exactly */
+    for (int pass = 0; pass <= LIMIT_PASSES; pass++) {
+      int any = 0;
+      for (int r = 0; r < A; r++)
+        for (int j = 0; j < 12; j++) {
+          real q = dofs[(r * 12 + j) * 2];
+          real* v = w->v + r * RD;
+          real lo = (m->dof_lower[j] - q) / dt, hi = (m->dof_upper[j] - q) / dt;
+          if (m->dof_vel_limit[j] > 0) { real vl = m->dof_vel_limit[j]; if (lo < -vl) lo = -vl; if (hi > vl) hi = vl; }
+          if (v[6 + j] < lo || v[6 + j] > hi) any = 1;
+          if (pass == LIMIT_PASSES) { if (v[6 + j] < lo) v[6 + j] = lo; if (v[6 + j] > hi) v[6 + j] = hi; }
         }
-      }
+      if (!any || pass == LIMIT_PASSES) break;
+      for (int r = 0; r < A; r++)
+        for (int j = 0; j < 12; j++) {
+          real q = dofs[(r * 12 + j) * 2];
+          real* v = w->v + r * RD;
+          real lo = (m->dof_lower[j] - q) / dt, hi = (m->dof_upper[j] - q) / dt;
+          if (m->dof_vel_limit[j] > 0) { real vl = m->dof_vel_limit[j]; if (lo < -vl) lo = -vl; if (hi > vl) hi = vl; }
+          real viol = 0;
+          if (v[6 + j] < lo) viol = lo - v[6 + j];
+          else if (v[6 + j] > hi) viol = hi - v[6 + j];
+          if (viol != 0) {
+            /* impulse along e_j: dv = Minv e_j * lambda with (Minv)_jj lambda = viol */
+            real col[RD];
+            memset(col, 0, sizeof col); col[6 + j] = 1;
+            chol_solve(w->L[r], RD, RD, col);
+            real lam = viol / col[6 + j];
+            for (int i = 0; i < RD; i++) v[i] += col[i] * lam;
+          }
+        }
+    }
     if (SS) {   /* hinge: velocity limit (seesaw.urdf:65), then the geometric end stops */
       real vv = w->v[sdof], vl = d->seesaw_vel_limit;
       if (vv > vl) vv = vl; if (vv < -vl) vv = -vl;
