@@ -667,6 +667,77 @@ def gen_wrappers(only_pushbox=False):
 # --------------------------------------------------------------------------------------------
 # 10/11. BarrierTrack terrain + config dump
 # --------------------------------------------------------------------------------------------
+def gen_gate_wrapper():
+    """W1: the gate wrapper's observation / reward code is COMMENTED OUT upstream (go1_gate_wrapper.py:40-56,66-69,80-154; the
+    live methods return 0).  The commented block is executable Python: it is activated here IN MEMORY -- '# ' stripped from the
+    code lines of those ranges (prose comments inside it are '# # ...' and stay comments), the two `obs = 0` overrides dropped --
+    compiled as a subclass body under the stub, and driven like the other wrappers.  Nothing of the reference's text is stored:
+    the fixture holds the scripted env attributes and the outputs."""
+    import re
+    from mqe.envs.configs.go1_gate_config import Go1GateCfg
+    src = open(os.path.join(REF, "mqe/envs/wrappers/go1_gate_wrapper.py")).read().split("\n")
+    live = []
+    for ln, line in enumerate(src, 1):
+        in_code = (41 <= ln <= 56) or (66 <= ln <= 69) or (80 <= ln <= 154)
+        mm = re.match(r"^(\s*)# (.*)$", line)
+        if in_code and mm and not mm.group(2).startswith("#"):
+            line = mm.group(1) + mm.group(2)
+        if line.strip() in ("obs = 0", "obs, reward = 0, 0"):
+            continue
+        live.append(line)
+    mod = types.ModuleType("go1_gate_wrapper_live")
+    exec(compile("\n".join(live), "go1_gate_wrapper.py[uncommented]", "exec"), mod.__dict__)
+    W = mod.Go1GateWrapper
+    cfg = Go1GateCfg
+    rng = np.random.RandomState(53)
+    T, N = 7, 6
+    A, P = cfg.env.num_agents, 0
+    fe = FakeEnvForWrapper(cfg, N, A, P)
+    eo = torch.tensor(rng.uniform(0, 3, (N, 3)).astype(np.float32))
+    eo[:, 2] = 0
+    fe.env_origins = eo
+    gate_dev = torch.tensor(rng.uniform(-0.4, 0.4, (N, 2)).astype(np.float32))
+    gate_dev[:, 0] = 0
+    script = []
+    rec = {"env_origins": eo, "gate_deviation": gate_dev.clone()}
+    for t in range(T + 1):
+        ob = types.SimpleNamespace()
+        ob.base_pos = torch.tensor(rng.uniform(-1, 6, (N * A, 3)).astype(np.float32))
+        ob.base_pos[:, 2] = torch.tensor(rng.uniform(0.2, 0.5, N * A).astype(np.float32))
+        if t in (2, 5):
+            ob.base_pos[1 * A + 1, :2] = ob.base_pos[1 * A, :2] + 0.2      # agents close: distance punishment
+            ob.base_pos[4 * A + 1, :2] = ob.base_pos[4 * A, :2] - 0.1
+        ob.base_rpy = torch.tensor(rng.uniform(0, 6.28, (N * A, 3)).astype(np.float32))
+        ob.lin_vel = torch.tensor(rng.uniform(-1, 1, (N * A, 3)).astype(np.float32))
+        ob.env_info = {"gate_deviation": gate_dev.clone()}
+        d = dict(obs_buf=ob, reset_buf=torch.tensor(rng.rand(N) < 0.3), collide_buf=torch.tensor(rng.rand(N) < 0.3),
+                 root_states_npc=torch.zeros(0, 13), r_term_buff=torch.zeros(N, dtype=torch.bool), p_term_buff=torch.zeros(N, dtype=torch.bool),
+                 sheep_pos_avg=torch.zeros(N, 2), sheep_pos_var=torch.zeros(N))
+        d["reset_ids"] = d["reset_buf"].nonzero(as_tuple=False).flatten()
+        script.append(d)
+        for k in ("root_states_npc", "reset_buf", "collide_buf", "r_term_buff", "p_term_buff", "sheep_pos_avg", "sheep_pos_var"):
+            rec.setdefault(k, []).append(d[k])
+        rec.setdefault("base_pos", []).append(ob.base_pos)
+        rec.setdefault("base_rpy", []).append(ob.base_rpy)
+    fe.script = script
+    w = W(fe)
+    obs0 = w.reset()
+    assert isinstance(obs0, torch.Tensor) and obs0.shape == (N, A, 14 + A), "the commented-out observation code did not run"
+    acts = rng.uniform(-1.5, 1.5, (T, N, A, 3)).astype(np.float32)
+    obs_l, rew_l, act_l = [], [], []
+    for t in range(T):
+        o, r, term, info = w.step(torch.from_numpy(acts[t]))
+        obs_l.append(o.clone()); rew_l.append(r.clone()); act_l.append(fe.last_action_in)
+    for k in list(rec.keys()):
+        if isinstance(rec[k], list):
+            rec[k] = torch.stack(rec[k], 0)
+    rb = {k: float(v) for k, v in w.reward_buffer.items()}
+    assert abs(rb["agent distance punishment"]) > 0 and abs(rb["success reward"]) > 0 and abs(rb["contact punishment"]) > 0
+    save("wrapper_gate", obs_reset=obs0, obs=torch.stack(obs_l), reward=torch.stack(rew_l), env_action=torch.stack(act_l),
+         actions=acts, reward_buffer_keys=np.array(list(rb.keys())), reward_buffer_vals=np.array(list(rb.values()), np.float64),
+         obs_dim=np.int64(w.observation_space.shape[0]), **rec)
+
+
 def gen_game_wrapper():
     """Go1FootballGameWrapper (go1_football_wrapper.py:93-156) is a stub upstream: None observations, zero reward (N, 4);
     what it does define is the action clip + scale handed to Go1.step."""
@@ -919,6 +990,8 @@ def main():
         gen_wrappers()
     if want("wrapper_game"):
         gen_game_wrapper()
+    if want("wrapper_gate"):
+        gen_gate_wrapper()
     if want("wrapper_pushbox"):
         gen_wrappers(only_pushbox=True)
     if want("fullstep_rotation"):
