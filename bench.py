@@ -11,8 +11,11 @@ fresh U(-1,1) actions every step (generator seed 1234).  Environments shard acro
 per GPU); the only collective is the RCCL all-gather of the returned (obs, reward, done) batch.
 
 Prints ONE JSON line (rank 0).  value = agents x envs(all ranks) x steps / max-over-ranks wall time.
-`roofline`: dominant kernel (largest share of GPU time, HIP events on the launch stream over the timed region).
-`cpu_baseline`: the build's CPU restatement (oracle/, kind "port") timed on this box's host cores on a bounded sample.
+`roofline`: dominant kernel (largest share of GPU time, HIP events on the launch stream over the timed region) charged with the
+whole step's algorithmic bytes (SURVEY 8d); `roofline_per_kernel`: every kernel class against ITS OWN bytes / flops;
+`strict_f32`: the same workload with every policy GEMM on the exact-f32 kernels (the companion of `dtype: f32`);
+`cpu_baseline` / `cpu_baseline_n4`: the build's CPU restatement (oracle/, kind "port") timed on this box's host cores at the
+GPU run's batch size (8 steps) and at N = 4 (BASELINE config 1).
 NOTE: body_latest.jit is missing from the reference snapshot, so the locomotion-policy body is the deterministic
 synthetic 2102-512-256-128-12 ELU MLP (mqe/utils/policy_weights.py); the adaptation module and actuator net are real.
 """
@@ -44,7 +47,7 @@ def make_args(task, num_envs, seed, device):
     return finish_args(a)
 
 
-def cpu_baseline(task, sample_envs, sample_steps):
+def cpu_baseline(task, sample_envs, sample_steps, threads=None):
     """Time the CPU oracle (OpenMP over envs/robots) on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -55,7 +58,9 @@ def cpu_baseline(task, sample_envs, sample_steps):
     e = OracleEngine(d, keep)
     # the oracle's OpenMP loops (over envs / robots) peak around 32 threads on the box's 256 hardware threads and
     # collapse when oversubscribed, so the baseline is timed at its best setting, which is reported as `cores`
-    e.lib.mqo_set_num_threads(int(os.environ.get("MQE_CPU_THREADS", min(32, os.cpu_count() or 1))))
+    if threads is None:
+        threads = int(os.environ.get("MQE_CPU_THREADS", min(32, os.cpu_count() or 1)))
+    e.lib.mqo_set_num_threads(int(threads))
     e.reset_all()
     g = torch.Generator().manual_seed(1234)
     Aw = e.tensor(abi.T_WRAPPER_OBS).shape[1]
@@ -69,6 +74,36 @@ def cpu_baseline(task, sample_envs, sample_steps):
     return d.num_agents * sample_envs * sample_steps / dt, dt, int(e.lib.mqo_num_threads())
 
 
+def time_variant(task, N, dev, steps, warmup, env_vars):
+    """ms per step of a second engine instance created under `env_vars` (the switches are read at creation), same inputs"""
+    from mqe.envs.utils import make_mqe_env, custom_cfg
+    old = {k: os.environ.get(k) for k in env_vars}
+    os.environ.update(env_vars)
+    try:
+        margs = make_args(task, N, 0, dev)
+        env, _ = make_mqe_env(task, margs, custom_cfg(margs))
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    A = env.num_agents
+    gen = torch.Generator(device=dev).manual_seed(1234)
+    env.reset()
+    acts = [torch.rand(N, A, 3, device=dev, generator=gen) * 2 - 1 for _ in range(warmup + steps)]
+    for t in range(warmup):
+        env.step(acts[t])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(steps):
+        env.step(acts[warmup + t])
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    env.close()
+    return 1e3 * el / steps, A
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -77,8 +112,9 @@ def main():
     ap.add_argument("--task", type=str, default="go1gate")
     ap.add_argument("--num_envs", type=int, default=4096, help="envs PER GPU (weak scaling)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
-    ap.add_argument("--cpu_sample_envs", type=int, default=512)
-    ap.add_argument("--cpu_sample_steps", type=int, default=100)
+    ap.add_argument("--no_strict_f32", action="store_true", help="skip the exact-f32 companion run")
+    ap.add_argument("--cpu_sample_envs", type=int, default=0, help="CPU baseline batch (0 = the GPU run's num_envs, 8 steps)")
+    ap.add_argument("--cpu_sample_steps", type=int, default=8)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -202,11 +238,19 @@ def main():
         tot = sum(kms) or 1.0
         dom = max(range(6), key=lambda i: kms[i])
         R = N * A
-        roof = None
+        P = env.env.num_npcs
         split = os.environ.get("MQE_GEMM_SPLIT", "1") != "0"
         d = eng.desc
         h_a, h_b = d.adaptation.dims[1], d.body.dims[1]
-        l0_ms = max(kms[0] / max(cnt[0], 1), 1e-9)
+        sampled = max(1, -(-args.steps // max(prof_every, 1)))         # env steps whose launches were bracketed
+
+        def avg_ms(i):
+            return kms[i] / max(cnt[i], 1)
+
+        def launches_per_step(i):
+            return max(1.0, cnt[i] / sampled)
+        # ---- policy layer 0: the one MFMA-bound kernel
+        l0_ms = max(avg_ms(0), 1e-9)
         flops32 = 2.0 * R * 2100 * (h_a + h_b)                        # algorithmic: unpadded K = 30 x 70, f32 products
         if split:   # every f32 product = three f16 x f16 terms on the matrix cores, K padded to 2208 (a multiple of three 32-k tiles)
             l0 = {"kernel": "k_gemm_h2 (fused layer 0 of adaptation+body MLP over the history ring; 2-plane split-f16 operands, 3 MFMA terms per product, f32-class accuracy)",
@@ -216,33 +260,65 @@ def main():
             l0 = {"kernel": "k_gemm_f32 (fused layer 0, exact f32 MFMA)", "bound": "mfma", "achieved": round(flops32 / (l0_ms * 1e-3) / 1e12, 3),
                   "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s"}
         l0.update({"frac": round(l0["achieved"] / l0["peak"], 4), "traffic": None, "avg_launch_ms": round(l0_ms, 4), "launches": int(cnt[0])})
+        # ---- headline roofline (prescribed form): the WHOLE step's algorithmic bytes (10128 B per agent-step, + 104 B
+        # read/write per free NPC body and env step) over the dominant kernel's average launch time
+        step_bytes = 10128.0 * R + 2 * 104.0 * N * P
         if dom == 0:
-            roof = l0
+            roof = dict(l0)
         else:
-            avg_ms = kms[dom] / max(cnt[dom], 1)
-            sampled = max(1, -(-args.steps // max(prof_every, 1)))     # env steps whose launches were bracketed
-            per_launch = max(1.0, cnt[dom] / sampled)                 # launches of this kernel class per env step
-            byts = 10128.0 * R / per_launch                           # 10128 B per agent-step
-            ach = byts / (avg_ms * 1e-3) / 1e9
+            byts = step_bytes / launches_per_step(dom)
+            ach = byts / (avg_ms(dom) * 1e-3) / 1e9
             roof = {"kernel": PROF_NAMES[dom], "bound": "hbm", "achieved": round(ach, 3), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": round(ach / PEAK_HBM_GBS, 6), "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": int(cnt[dom]),
+                    "frac": round(ach / PEAK_HBM_GBS, 6), "traffic": None, "avg_launch_ms": round(avg_ms(dom), 4), "launches": int(cnt[dom]),
+                    "bytes_basis": "SURVEY 8(d): the whole step's 10128 B/agent-step charged to the dominant kernel; per-kernel shares in roofline_per_kernel",
                     "note": "not HBM-bound by construction: one env per wavefront, state LDS-resident for the 4 substeps; the limiter is "
-                            "dependent-instruction latency at 2 waves/SIMD (see profiles/*pmc_summary.json: issue / wait fractions)"}
-        # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (separate runs; profiles/*pmc_summary.json)
+                            "dependent-instruction latency at the kernel's waves/SIMD (pmc_from_profile: issue / wait fractions)"}
+        # HBM traffic of the dominant kernel: NOT measured in this run -- copied from the committed rocprofv3 PMC passes (separate
+        # runs of this command, profiles/*pmc_summary.json) and labelled as such
         try:
             import glob
-            pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.json")))[-1]))
+            pfile = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.json")))[-1]
+            pmc = json.load(open(pfile))
             if N == 4096 and args.task == "go1gate":
                 kname = ("k_gemm_h2" if split else "k_gemm_f32") if dom == 0 else PROF_KERNEL[dom]
                 e = pmc.get(kname, {})
                 roof["traffic"] = (e.get("fetch_bytes_x2", 0) + e.get("write_bytes_raw", 0)) if dom == 0 else e.get("hbm_bytes_raw")
-                for k in ("frac_wave_time_issuing", "frac_wave_time_issue_stalled", "frac_wave_time_waiting_on_waitcnt_or_barrier"):
-                    if k in e:
-                        roof[k] = e[k]
-                roof["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch, see profiles/"
+                roof["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, bytes per launch, copied from " + os.path.relpath(pfile, ROOT)
+                roof["pmc_from_profile"] = {"file": os.path.relpath(pfile, ROOT), "measured_in_this_run": False,
+                                            **{k: e[k] for k in ("frac_wave_time_issuing", "frac_wave_time_issue_stalled", "frac_wave_time_waiting_on_waitcnt_or_barrier") if k in e}}
         except Exception:
             pass
-        step_bytes = 10128.0 * R
+        # ---- per-kernel table: every kernel class with ITS OWN share of the algorithmic bytes (the items of SURVEY 8(d) assigned
+        # to the kernel that moves them) resp. its flops, against its own average launch time measured in this run
+        own_bytes = {   # per agent-step: (read, written)
+            5: (12 + 96, 280),                    # k_pre_policy: command, last two actions -> history frame
+            0: (8400, 0),                         # layer 0: the 30 x 70 float history
+            1: (0, 96),                           # policy tail: last actions
+            3: (52 + 96 + 192, 52 + 96 + 192 + 204),   # k_substeps: root, dof, actuator history -> the same + net contact forces
+            4: (4, 4 + 284 + 64 + 4),             # k_post_physics: gait index -> gait, obs bag, wrapper obs, reward
+        }
+        tail_flops = 2.0 * R * (sum(d.adaptation.dims[l] * d.adaptation.dims[l + 1] for l in range(1, d.adaptation.n_layers)) +
+                                sum(d.body.dims[l] * d.body.dims[l + 1] for l in range(1, d.body.n_layers)) + 2 * h_b)
+        act_flops = 2.0 * R * 12 * 4 * 1248
+        table = []
+        for i in (5, 0, 1, 3, 4):
+            if cnt[i] <= 0:
+                continue
+            rd, wr = own_bytes[i]
+            npc = 2 * 104.0 * N * P if i == 3 else 0.0
+            byts = ((rd + wr) * R + npc) / launches_per_step(i)
+            t = avg_ms(i) * 1e-3
+            row = {"kernel": PROF_NAMES[i], "avg_launch_ms": round(avg_ms(i), 4), "launches_per_step": round(launches_per_step(i), 2),
+                   "algorithmic_bytes_per_launch": int(byts), "hbm_GBps": round(byts / t / 1e9, 2), "hbm_frac": round(byts / t / 1e9 / PEAK_HBM_GBS, 5)}
+            if i == 0:
+                row.update({"bound": "mfma", "TFLOPs": l0["achieved"], "mfma_frac": l0["frac"], "peak_TFLOPs": l0["peak"]})
+            elif i == 1:
+                row.update({"bound": "latency (L2 weight stream, 6 dependent stages)", "f32_equivalent_TFLOPs": round(tail_flops / launches_per_step(i) / t / 1e12, 2)})
+            elif i == 3:
+                row.update({"bound": "latency (occupancy-limited, LDS-resident state)", "actuator_mlp_f32_mfma_TFLOPs": round(act_flops / t / 1e12, 2)})
+            else:
+                row.update({"bound": "latency / hbm"})
+            table.append(row)
         out = {
             "metric": f"env-steps/sec (agents x envs x steps/s), {args.task} {N} envs x {A} agents per GPU",
             "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -254,16 +330,30 @@ def main():
             "physical_robot_steps_per_s": round(value * env.env.num_agents / A, 1),
             "roofline": roof,
             "roofline_policy_layer0": l0,
+            "roofline_per_kernel": table,
             "hbm_step_algorithmic_GBps": round(step_bytes * args.steps / elapsed / 1e9, 3),
+            "hbm_step_algorithmic_frac": round(step_bytes * args.steps / elapsed / 1e9 / PEAK_HBM_GBS, 5),
             "kernel_time_share": {PROF_NAMES[i]: round(kms[i] / tot, 4) for i in range(6)},
-            "gpu_busy_ms_per_step": round(tot / max(1, -(-args.steps // max(prof_every, 1))), 4),
+            "gpu_busy_ms_per_step": round(tot / sampled, 4),
             "hip_event_sampling": f"kernel classes of every {prof_every}-th timed step bracketed" if prof_every else "off",
+            "dtype_note": "state, physics, actuator net: f32.  Policy layer 0 + tail: f32 operands carried as two f16 planes (22 significand bits, "
+                          "3 MFMA terms), held to the same 5e-5 bound as exact f32; strict_f32 = the same run on the exact-f32 kernels",
         }
+        if world == 1 and not args.no_strict_f32 and not os.environ.get("MQE_BENCH_NOPROF"):
+            # the dtype claim's companion: identical workload with every policy GEMM on the exact-f32 kernels
+            sms, _ = time_variant(args.task, N, dev, min(args.steps, 100), min(args.warmup, 10), {"MQE_GEMM_SPLIT": "0", "MQE_NO_FUSED_TAIL": "1"})
+            out["strict_f32"] = {"value": round(A * N / (sms * 1e-3), 1), "unit": "env-steps/s", "ms_per_step": round(sms, 4), "steps": min(args.steps, 100),
+                                 "switches": "MQE_GEMM_SPLIT=0 MQE_NO_FUSED_TAIL=1 (k_gemm_f32 for every policy layer)"}
         if not args.no_cpu_baseline and world == 1:
             torch.set_num_threads(os.cpu_count() or 1)
-            v, secs, nthr = cpu_baseline(args.task, args.cpu_sample_envs, args.cpu_sample_steps)
-            out["cpu_baseline"] = {"value": round(v, 1), "unit": "env-steps/s", "cores": nthr,
-                                   "kind": "port", "sample": f"{args.task} {args.cpu_sample_envs} envs x {args.cpu_sample_steps} steps, build's CPU restatement (oracle/), {secs:.1f} s"}
+            # the CPU restatement at the headline size (few steps) and at the reference's own CPU-runnable size (N = 4)
+            big_n, big_steps = (args.cpu_sample_envs, args.cpu_sample_steps) if args.cpu_sample_envs else (N, 8)
+            v, secs, nthr = cpu_baseline(args.task, big_n, big_steps)
+            out["cpu_baseline"] = {"value": round(v, 1), "unit": "env-steps/s", "cores": nthr, "host_threads_available": os.cpu_count(),
+                                   "kind": "port", "sample": f"{args.task} {big_n} envs x {big_steps} steps, build's CPU restatement (oracle/, OpenMP over envs), {secs:.1f} s"}
+            v4, secs4, nthr4 = cpu_baseline(args.task, 4, 200, threads=4)
+            out["cpu_baseline_n4"] = {"value": round(v4, 1), "unit": "env-steps/s", "cores": nthr4, "kind": "port",
+                                      "sample": f"{args.task} 4 envs x 200 steps (BASELINE config 1 size), {secs4:.1f} s"}
         print(json.dumps(out))
     env.close()
     if world > 1:

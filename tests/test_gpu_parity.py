@@ -17,7 +17,7 @@ def test_hip_matches_reference_trace(name):
     assert replay(name, hip_engine)
 
 
-@pytest.mark.parametrize("name", ["sheep_hard", "sheep_easy", "seesaw", "football_defender", "pushbox", "rotation", "bridge", "wrestling", "tug"])
+@pytest.mark.parametrize("name", ["gate", "sheep_hard", "sheep_easy", "seesaw", "football_defender", "pushbox", "rotation", "bridge", "wrestling", "tug"])
 def test_hip_wrappers_match_reference(name):
     assert wrapper_replay(name, hip_engine)
 
@@ -469,3 +469,90 @@ def test_every_task_survives_a_long_random_rollout(task):
             assert (root[:, :, :2] - eo).abs().max() < 40.0                      # nothing left the arena
     assert int(e.tensor(abi.T_RESET_COUNT).min()) >= 1
     e.close()
+
+
+def test_general_shape_policy_tail(tmp_path):
+    """Row D: a body file whose depth / widths are not the stand-in's (2102-128-64-12, TorchScript written and read back through
+    load_body) takes the general k_gemm_f32 chain on the GPU: joint targets == the oracle == the TorchScript module (plain torch
+    fp32) on identical histories, for both layer-0 kernels."""
+    import os
+    from test_models_oracle import scripted_body, torch_adaptation
+    net, Ws, bs = scripted_body(tmp_path)
+    ada = torch_adaptation()
+    N = 48
+    for split in ("1", "0"):
+        os.environ["MQE_GEMM_SPLIT"] = split
+        try:
+            d1, k1, _ = make_desc("go1gate", N, body=(Ws, bs))
+            d2, k2, _ = make_desc("go1gate", N, body=(Ws, bs))
+            eh, eo = hip_engine(d1, k1), oracle_engine(d2, k2)
+        finally:
+            del os.environ["MQE_GEMM_SPLIT"]
+        eh.reset_all(); eo.reset_all()
+        g = torch.Generator().manual_seed(5)
+        for t in range(8):
+            a = torch.rand(N, 2, 3, generator=g) * 2 - 1
+            eh.step(a.cuda().contiguous()); eo.step(a)
+            for k in (abi.T_ROOT_STATE, abi.T_DOF_STATE):
+                eh.tensor(k).copy_(eo.tensor(k).cuda())
+            if t in (0, 7):
+                close(eh.tensor(abi.T_ACTIONS), eo.tensor(abi.T_ACTIONS), atol=5e-5, what=f"policy actions step {t} (split {split})")
+        hist = eh.history().cpu()
+        with torch.no_grad():
+            want = net(torch.cat([hist, ada(hist)], dim=1))
+        close(eh.tensor(abi.T_LAST_LOCO_ACTION), want, atol=1e-4, rtol=1e-4, what="policy output vs the TorchScript module")
+        eh.close()
+
+
+def test_unfused_tail_on_the_default_shape(monkeypatch):
+    """MQE_NO_FUSED_TAIL=1: the reference network shapes through the general chain (five k_gemm_f32 launches + k_body_l0_finish +
+    k_post_policy) instead of k_policy_tail: same joint targets as the oracle, and as the fused tail to f32 rounding"""
+    N = 64
+    monkeypatch.setenv("MQE_NO_FUSED_TAIL", "1")
+    eh, eo, d = _pair("go1gate", N)
+    monkeypatch.delenv("MQE_NO_FUSED_TAIL")
+    d3, k3, _ = make_desc("go1gate", N)
+    ef = hip_engine(d3, k3)
+    for e in (eh, eo, ef):
+        e.reset_all()
+    g = torch.Generator().manual_seed(6)
+    for t in range(6):
+        a = torch.rand(N, 2, 3, generator=g) * 2 - 1
+        eh.step(a.cuda().contiguous()); eo.step(a); ef.step(a.cuda().contiguous())
+        for k in (abi.T_ROOT_STATE, abi.T_DOF_STATE):
+            eh.tensor(k).copy_(eo.tensor(k).cuda()); ef.tensor(k).copy_(eo.tensor(k).cuda())
+        close(eh.tensor(abi.T_ACTIONS), eo.tensor(abi.T_ACTIONS), atol=5e-5, what=f"unfused tail vs oracle, step {t}")
+        close(eh.tensor(abi.T_ACTIONS), ef.tensor(abi.T_ACTIONS), atol=5e-5, what=f"unfused vs fused tail, step {t}")
+
+
+def test_out_of_range_observations_do_not_poison_the_policy():
+    """The split-f16 operands carry 64 x: beyond |x| = 1023 the value saturates (clamped to the f16 range in split2, never inf / NaN).
+    A blown-up joint velocity (1e4 rad/s in the history) must leave the policy output finite and bounded, on the other robots
+    untouched, and the exact-f32 path must agree with the oracle there."""
+    import os
+    N = 32
+    outs = {}
+    for split in ("1", "0"):
+        os.environ["MQE_GEMM_SPLIT"] = split
+        try:
+            d1, k1, _ = make_desc("go1gate", N)
+            e = hip_engine(d1, k1)
+        finally:
+            del os.environ["MQE_GEMM_SPLIT"]
+        e.reset_all()
+        a = torch.zeros(N, 2, 3, device="cuda")
+        e.step(a)
+        dof = e.tensor(abi.T_DOF_STATE)
+        dof[3, :12, 1] = 4.0e5                       # robot 0 of env 3: obs dof_vel = 0.05 * 4e5 = 2e4 >> 1023
+        e.post_physics_step()                        # refreshes the observation bag from the poisoned state
+        dof[3, :12, 1] = 0.0
+        e.step(a)
+        torch.cuda.synchronize()
+        act = e.tensor(abi.T_LAST_LOCO_ACTION).cpu()
+        assert torch.isfinite(act).all() and torch.isfinite(e.tensor(abi.T_ACTIONS)).all()
+        assert act.abs().max() < 1e6
+        outs[split] = act
+        e.close()
+    others = [i for i in range(2 * N) if i != 6]
+    assert (outs["1"][others] - outs["0"][others]).abs().max() < 5e-5          # nobody else noticed
+    assert outs["0"][6].abs().max() > 10 * outs["0"][others].abs().max()        # the exact path sees the full 2e4

@@ -84,13 +84,15 @@ def test_step_end_without_begin_is_an_error():
     torch.cuda.synchronize()
 
 
-def test_bench_two_ranks_delayed_gather():
+@pytest.mark.parametrize("task,port", [("go1gate", "29617"), ("go1football-defender", "29619")])
+def test_bench_two_ranks_delayed_gather(task, port):
     """bench.py --gpus 2 as the driver launches it, both ranks on cuda:0 over gloo: every step's batch is gathered (issued
-    from inside the next step) and arrives whole -- bench.py asserts both"""
+    from inside the next step) and arrives whole -- bench.py asserts both.  go1football-defender = BASELINE config 5's sharded
+    path: 3 robots per env, the scripted defender and the reset draws keyed by the global env id."""
     env = dict(os.environ, MQE_BENCH_SELFTEST_GLOO="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29617", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "3",
-           "--num_envs", "128", "--no_cpu_baseline"]
+           "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "3",
+           "--num_envs", "128", "--no_cpu_baseline", "--task", task]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]

@@ -49,3 +49,65 @@ def test_go1_model_from_urdf_numbers():
     assert len(m["sphere_body"]) == 27 and m["sphere_radius"][0] == 0.02
     for I in m["inertia"]:
         assert np.all(np.linalg.eigvalsh(np.asarray(I)) > 0)
+
+
+def scripted_body(tmp_path, hidden=(128, 64), seed=5):
+    """A TorchScript body as upstream ships it (Sequential of Linear / ELU, go1.py:397) with hidden sizes that are NOT the
+    stand-in's 512-256-128: written to <tmp>/body_latest.jit, read back through the product loader (policy_weights.load_body)."""
+    from mqe.utils import policy_weights as pw
+    torch.manual_seed(seed)
+    dims = (pw.BODY_IN,) + tuple(hidden) + (pw.BODY_OUT,)
+    layers = []
+    for i in range(len(dims) - 1):
+        lin = torch.nn.Linear(dims[i], dims[i + 1])
+        with torch.no_grad():
+            lin.weight.mul_(2.0 if i else 1.0)
+            lin.bias.uniform_(-0.3, 0.3)
+        layers.append(lin)
+        if i < len(dims) - 2:
+            layers.append(torch.nn.ELU())
+    net = torch.nn.Sequential(*layers).eval()
+    torch.jit.script(net).save(str(tmp_path / "body_latest.jit"))
+    Ws, bs, synthetic = pw.load_body(str(tmp_path))
+    assert synthetic is False and [w.shape for w in Ws] == [(dims[i + 1], dims[i]) for i in range(len(dims) - 1)]
+    for w, b, lin in zip(Ws, bs, [l for l in layers if isinstance(l, torch.nn.Linear)]):
+        assert np.array_equal(w, lin.weight.detach().numpy()) and np.array_equal(b, lin.bias.detach().numpy())
+    return net, Ws, bs
+
+
+def torch_adaptation():
+    from mqe.utils import policy_weights as pw
+    Ws, bs = pw.load_adaptation_module()
+    layers = []
+    for i, (w, b) in enumerate(zip(Ws, bs)):
+        lin = torch.nn.Linear(w.shape[1], w.shape[0])
+        with torch.no_grad():
+            lin.weight.copy_(torch.from_numpy(w)); lin.bias.copy_(torch.from_numpy(b))
+        layers.append(lin)
+        if i < len(Ws) - 1:
+            layers.append(torch.nn.ELU())
+    return torch.nn.Sequential(*layers).eval()
+
+
+def test_real_body_file_of_another_shape_runs_through_the_loader(tmp_path):
+    """Row D: body_latest.jit is missing upstream, so what can be pinned is the path a real file takes: TorchScript ->
+    load_body -> descriptor -> oracle forward == the TorchScript module's own output on the same inputs (plain torch fp32),
+    for a network whose depth and widths differ from the synthetic stand-in (2102-128-64-12)."""
+    net, Ws, bs = scripted_body(tmp_path)
+    ada = torch_adaptation()
+    d, k, _ = make_desc("go1gate", 1, body=(Ws, bs))
+    assert [d.body.dims[i] for i in range(d.body.n_layers + 1)] == [2102, 128, 64, 12]
+    e = oracle_engine(d, k)
+    f = e.lib.mqo_policy_forward
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    g = torch.Generator().manual_seed(2)
+    lat, act = np.zeros(2, np.float32), np.zeros(12, np.float32)
+    for i in range(8):
+        x = torch.randn(2100, generator=g) * (0.3 if i else 0.0)
+        with torch.no_grad():
+            lt = ada(x[None])
+            at = net(torch.cat([x[None], lt], dim=1))
+        xi = np.ascontiguousarray(x.numpy(), np.float32)
+        f(e.h, xi.ctypes.data, lat.ctypes.data, act.ctypes.data)
+        np.testing.assert_allclose(lat, lt[0].numpy(), rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(act, at[0].numpy(), rtol=1e-4, atol=5e-5)

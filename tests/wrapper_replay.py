@@ -7,7 +7,7 @@ from mqe.engine import abi
 from mqe.engine.desc import REWARD_TERMS
 from helpers import golden, make_desc, to_dev, close
 
-TASK_OF = {"sheep_hard": "go1sheep-hard", "sheep_easy": "go1sheep-easy", "seesaw": "go1seesaw", "football_defender": "go1football-defender",
+TASK_OF = {"gate": "go1gate", "sheep_hard": "go1sheep-hard", "sheep_easy": "go1sheep-easy", "seesaw": "go1seesaw", "football_defender": "go1football-defender",
            "pushbox": "go1pushbox", "rotation": "go1revolvingdoor",
            "bridge": "go1bridge", "wrestling": "go1wrestling", "tug": "go1tug"}
 
@@ -102,7 +102,7 @@ def wrapper_replay(name, make_engine):
     gate = np.ascontiguousarray(z["gate_deviation"], np.float32).copy()
     if name.startswith("sheep"):
         gate[:, 0] += kw["init"]["block_length"] + kw["plane"]["block_length"] + kw["gate"]["block_length"] / 2
-    elif name == "pushbox":
+    elif name in ("pushbox", "gate"):       # go1_gate_wrapper.py:41-42 (commented upstream), go1_pushbox_wrapper.py:29-30
         gate[:, 0] += kw["init"]["block_length"] + kw["gate"]["block_length"] / 2
     elif name == "football_defender":
         gate = eo[:, :2].copy()

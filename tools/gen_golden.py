@@ -668,7 +668,7 @@ def gen_wrappers(only_pushbox=False):
 # 10/11. BarrierTrack terrain + config dump
 # --------------------------------------------------------------------------------------------
 def gen_gate_wrapper():
-    """W1: the gate wrapper's observation / reward code is COMMENTED OUT upstream (go1_gate_wrapper.py:40-56,66-69,80-154; the
+    """W1: the gate wrapper's observation / reward code is COMMENTED OUT upstream (go1_gate_wrapper.py:41-54,64-67,78-154; the
     live methods return 0).  The commented block is executable Python: it is activated here IN MEMORY -- '# ' stripped from the
     code lines of those ranges (prose comments inside it are '# # ...' and stay comments), the two `obs = 0` overrides dropped --
     compiled as a subclass body under the stub, and driven like the other wrappers.  Nothing of the reference's text is stored:
@@ -678,7 +678,7 @@ def gen_gate_wrapper():
     src = open(os.path.join(REF, "mqe/envs/wrappers/go1_gate_wrapper.py")).read().split("\n")
     live = []
     for ln, line in enumerate(src, 1):
-        in_code = (41 <= ln <= 56) or (66 <= ln <= 69) or (80 <= ln <= 154)
+        in_code = (41 <= ln <= 54) or (64 <= ln <= 67) or (78 <= ln <= 154)
         mm = re.match(r"^(\s*)# (.*)$", line)
         if in_code and mm and not mm.group(2).startswith("#"):
             line = mm.group(1) + mm.group(2)
