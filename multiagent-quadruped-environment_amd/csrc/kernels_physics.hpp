@@ -100,13 +100,26 @@ __device__ __forceinline__ float wave_sum(float x) {
 }
 
 #define BODY_STRIDE 32
-// leg block record in 16 B words: Mll^-1 (sym6) at 0, G = Mbl Mll^-1 (6 x 3) at 8, C = G Mbl^T (upper triangle, 21) at 28
-#define LEG_STRIDE 52
+// leg block record in 16 B words (lives to the end of the substep): Mll^-1 (sym6) at 0, G = Mbl Mll^-1 (6 x 3) at 8; the Schur
+// term C = G Mbl^T (upper triangle, 21 values, 6 words) is scratch of its own (LEGC_STRIDE)
+#define LEG_STRIDE 28
 #define LEG_MI 0
 #define LEG_G 8
-#define LEG_C 28
-#define CON_STRIDE 32
-#define JS_STRIDE 36                // per contact side: 9 columns x (j_n, j_t1, j_t2, local dof index)
+#define LEGC_STRIDE 24
+#define CON_STRIDE 24
+// contact side record: three rows (normal, tangent 1, tangent 2) of four 16 B words:
+//   [ W (6) | V (6) | Z (3) | info ]   W = J_base - J_leg G_leg^T  (the Jacobian row reduced onto the 6 base coordinates)
+//                                      V = W S^-1                   (S = Schur complement of the base block)
+//                                      Z = J_leg                    (the <= 3 joints of the chain to the touching link)
+//   info of row 0 = leg index of a robot side whose link is not the base, else -1.  With these a 3 x 3 coupling block is
+//   K = V W'^T (+ Z Mll^-1 Z'^T for two sides on the same leg) and M^-1 J^T lambda = [V^T lambda ; Mll^-1 Z^T lambda - G^T V^T lambda]:
+//   neither the 18 x 18 inverse nor M^-1 J^T (3 x 18 per side) is ever formed.  Free bodies / the 1-dof link: W = J, V = W M^-1, Z = 0.
+#define SIDE_STRIDE 48
+#define SIDE_ROW 16
+#define SIDE_W 0
+#define SIDE_V 6
+#define SIDE_Z 12
+#define SIDE_INFO 15
 // link record: rotation (9), origin (3), joint axis (3) = four 16 B words, what the collision and Jacobian phases read back; the
 // base records also carry angular velocity, origin velocity and the two bias accelerations for their hips (the other links
 // hand those to their children through registers)
@@ -133,38 +146,36 @@ __host__ __device__ inline int mqe_maxc(int A, int P, int cap_npc) { int v = 8 *
 // NPCs keep m->cap_npc one-sided contacts each (2; a box resting on a face 4): per-actor caps so that no actor starves the ones after it
 
 struct PhysLds {   // float offsets into dynamic LDS
-  int root, dof, tau, body, minv, rhs, fcol, leg, basei, sinv, tt, sph, con, B, js, kk, total;
+  int root, dof, tau, body, rhs, acc, acth, fcol, leg, legc, basei, sinv, sph, con, side, kk, total;
 };
 __host__ __device__ inline int mqe_maxpair(int maxc) { return maxc / 2; }    // two-actor contacts kept per env
 __host__ __device__ inline PhysLds phys_lds_layout(int A, int P, int ND, int nbody, int ndof, int nsph, int maxc) {
   // Regions that live to the end of the substep first; then an ARENA shared by (a) everything that is dead once the
-  // contact rows exist (link records, CRBA/Schur scratch, collision spheres) and (b) the coupling blocks, which are
-  // only written after (a) has been consumed.  Inside (a) the spheres overlay the CRBA/Schur scratch (dead once M^-1
-  // exists) and T overlays the joint force columns (dead after the leg blocks).  Contact sides are slot-allocated:
-  // side A of contact c -> slot c, side B of the k-th two-actor contact -> slot maxc + k (terrain contacts have no B).
-  // Together this keeps go1gate at 19 KiB per wave = 8 waves per CU (160 KiB LDS), 2 per SIMD.
+  // contact side records exist (link records, CRBA/Schur scratch, collision spheres) and (b) the coupling blocks, which are
+  // only written after (a) has been consumed.  Inside (a) the spheres overlay the CRBA/Schur scratch (dead once the Schur
+  // inverse exists).  Contact sides are slot-allocated: side A of contact c -> slot c, side B of the k-th two-actor contact
+  // -> slot maxc + k (terrain contacts have no B).  The mass-matrix inverse is kept in its factored form only (per leg
+  // Mll^-1 and G, per robot S^-1: 184 floats per robot instead of 324) and the contact sides in the reduced form of
+  // SIDE_STRIDE: go1gate needs 12.5 KiB per wave = 12 waves per CU (160 KiB LDS), 3 per SIMD.
   PhysLds L; int o = 0;
   L.root = o; o += (A + P) * 13;
   L.dof = o; o += ND * 2;
   L.tau = o; o += 12 * A;
   o = (o + 3) & ~3;
-  L.minv = o; o += A * MQE_RD * MQE_RD;
-  L.rhs = o; o += (ndof > 64 ? ndof : 64);                  // generalized bias, later v* / the solved velocity (one per dof)
-  o = (o + 3) & ~3;
+  L.rhs = o; o += (ndof + 3) & ~3;                          // generalized bias, later v* / the solved velocity (one per dof)
+  L.acc = o; o += (ndof + 3) & ~3;                          // one scratch float per dof: reduced right-hand sides, J^T lambda sums
+  L.acth = o; o += 4 * 12 * A;                              // k_substeps: actuator-net history of every joint (two past errors, two past velocities)
+  L.leg = o; o += A * 4 * LEG_STRIDE;
+  L.sinv = o; o += A * 36;
   L.con = o; o += maxc * CON_STRIDE;
   const int nslot = maxc + mqe_maxpair(maxc);
-  L.B = o; o += nslot * 54;             // per contact side: 3 rows x 18 local dofs of M^-1 J^T
-  o = (o + 3) & ~3;                     // the Jacobian rows are 16 B words
-  L.js = o; o += nslot * JS_STRIDE;
-  o = (o + 3) & ~3;                                         // the link records are accessed as 16 B words
+  L.side = o; o += nslot * SIDE_STRIDE;
   const int arena = o;
   L.body = o; o += nbody * BODY_STRIDE;
-  o = (o + 3) & ~3;                                         // the sphere records are read as float4
   const int scratch = o;
-  L.tt = o; L.fcol = o; o += A * MQE_RD * 6;               // fcol (A*72) is consumed before tt is written
-  L.leg = o; o += A * 4 * LEG_STRIDE;
-  L.basei = o; o += A * 10;
-  L.sinv = o; o += A * 36;
+  L.fcol = o; o += A * 64;                                  // the four hip composites of every robot on their way to the base lane
+  L.legc = o; o += A * 4 * LEGC_STRIDE;
+  L.basei = o; o += A * 12;
   L.sph = scratch;
   if (scratch + nsph * 4 > o) o = scratch + nsph * 4;
   L.kk = arena;                                    // lower-triangular 3x3 blocks, block (c, c2 <= c) at (c(c+1)/2 + c2) * 9
@@ -405,7 +416,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       if (depth == 3) cpl2 = dot(Sa2, Fn) + dot(Sv2, Ff);
       lds[L.rhs + br * MQE_RD + 6 + j] = lds[L.tau + br * 12 + j] - hj;
     } else if (is_rbody) {
-      float* bi = lds + L.basei + br * 10;
+      float* bi = lds + L.basei + br * 12;
       for (int k = 0; k < 10; k++) bi[k] = X[k];
       float* rh = lds + L.rhs + br * MQE_RD;
       rh[0] = -X[13]; rh[1] = -X[14]; rh[2] = -X[15]; rh[3] = -X[10]; rh[4] = -X[11]; rh[5] = -X[12];
@@ -442,8 +453,9 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
 #pragma unroll
       for (int k = 0; k < 4; k++) M4[2 + k] = make_float4(G[4 * k], G[4 * k + 1], G[4 * k + 2], G[4 * k + 3]);
       M4[6] = make_float4(G[16], G[17], 0.0f, 0.0f);
+      float4* C4w = reinterpret_cast<float4*>(lds + L.legc + (br * 4 + leg) * LEGC_STRIDE);
 #pragma unroll
-      for (int k = 0; k < 6; k++) M4[7 + k] = make_float4(Cv[4 * k], Cv[4 * k + 1], Cv[4 * k + 2], Cv[4 * k + 3]);
+      for (int k = 0; k < 6; k++) C4w[k] = make_float4(Cv[4 * k], Cv[4 * k + 1], Cv[4 * k + 2], Cv[4 * k + 3]);
     }
   }
   __syncthreads();
@@ -452,7 +464,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   // ---- 6x6 Schur complement inverse: lane (robot, column) --------------------------------------------------------
   if (lane < A * 6) {
     const int r = lane / 6, col = lane - r * 6;
-    const float* bi = lds + L.basei + r * 10;
+    const float* bi = lds + L.basei + r * 12;
     float mt = bi[0], hx = bi[1], hy = bi[2], hz = bi[3];
     float S[6][6];
     for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) S[i][j] = 0.0f;
@@ -461,7 +473,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     S[0][4] = hz; S[0][5] = -hy; S[1][3] = -hz; S[1][5] = hx; S[2][3] = hy; S[2][4] = -hx;
     S[3][3] = bi[4]; S[4][4] = bi[5]; S[5][5] = bi[6]; S[3][4] = bi[7]; S[3][5] = bi[8]; S[4][5] = bi[9];
     for (int k = 0; k < 4; k++) {
-      const float4* C4 = reinterpret_cast<const float4*>(lds + L.leg + (r * 4 + k) * LEG_STRIDE + LEG_C);
+      const float4* C4 = reinterpret_cast<const float4*>(lds + L.legc + (r * 4 + k) * LEGC_STRIDE);
       float Cc[24];
 #pragma unroll
       for (int w = 0; w < 6; w++) { const float4 t = C4[w]; Cc[4 * w] = t.x; Cc[4 * w + 1] = t.y; Cc[4 * w + 2] = t.z; Cc[4 * w + 3] = t.w; }
@@ -507,68 +519,78 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   }
   __syncthreads();
   TSTAMP(5);
-  // ---- rows of M^-1 (18 x 18 per robot): lane = row.  Row k = [ T | (+-) T G_0 | ... | T G_3 (+ M_ll^-1 on its own leg) ] with
-  // T = row k of [S^-1 ; G^T S^-1] (6 values, registers).  One pass of ~150 broadcast-friendly LDS reads and ~110 FMAs per lane
-  // (the earlier form -- (row, column) tasks for T through LDS, then (row, block) tasks -- took 7 passes and 7.4 k cycles).
-  for (int d = lane; d < A * MQE_RD; d += 64) {
-    const int r = d / MQE_RD, k = d - r * MQE_RD;
+  // ---- M^-1 in factored form.  With G_k = M_bl,k M_ll,k^-1 (6 x 3 per leg) and S = M_bb - sum_k G_k M_lb,k:
+  //   M^-1 = [ S^-1            -S^-1 G            ]    so   x = M^-1 r  is  x_b = S^-1 (r_b - sum_k G_k r_l,k),
+  //          [ -G^T S^-1   M_ll^-1 + G^T S^-1 G   ]                          x_l,k = M_ll,k^-1 r_l,k - G_k^T x_b
+  // -- three short lane-parallel stages instead of the 18 x 18 inverse (which took 4.7 k cycles and 1.3 kB per robot to build).
+  auto mi_at = [](const float* Mi, int i, int j) -> float {         // sym6 00,11,22,01,02,12: (0,1) -> 3, (0,2) -> 4, (1,2) -> 5
+    return Mi[i == j ? i : 2 + i + j];
+  };
+  // row k of one robot's M^-1, element `e` (both 0..17): only for the joint-limit impulses and the debug tap
+  auto minv_elem = [&](int r, int k, int e) -> float {
     const float* Si = lds + L.sinv + r * 36;
-    const int legk = k < 6 ? -1 : (k - 6) / 3, li = k < 6 ? 0 : (k - 6) - legk * 3;
-    float T[6];
+    const float* lg = lds + L.leg + r * 4 * LEG_STRIDE;
+    float y[6];                                                     // k < 6: row k of S^-1; else S^-1 G_L[:, t]
     if (k < 6) {
 #pragma unroll
-      for (int mm = 0; mm < 6; mm++) T[mm] = Si[k * 6 + mm];
+      for (int mm = 0; mm < 6; mm++) y[mm] = Si[k * 6 + mm];
     } else {
-      const float* G = lds + L.leg + (r * 4 + legk) * LEG_STRIDE + LEG_G;
+      const float* G = lg + ((k - 6) / 3) * LEG_STRIDE + LEG_G;
+      const int t = (k - 6) % 3;
 #pragma unroll
       for (int mm = 0; mm < 6; mm++) {
         float acc = 0.0f;
 #pragma unroll
-        for (int n = 0; n < 6; n++) acc += G[n * 3 + li] * Si[n * 6 + mm];
-        T[mm] = acc;
+        for (int n = 0; n < 6; n++) acc += Si[mm * 6 + n] * G[n * 3 + t];
+        y[mm] = acc;
       }
     }
-    float* row = lds + L.minv + (r * MQE_RD + k) * MQE_RD;
-    const float sg = k < 6 ? 1.0f : -1.0f;
+    if (e < 6) return k < 6 ? y[e] : -y[e];
+    const int L2 = (e - 6) / 3, i = (e - 6) % 3;
+    const float* G2 = lg + L2 * LEG_STRIDE + LEG_G;
+    float acc = 0.0f;
 #pragma unroll
-    for (int mm = 0; mm < 6; mm++) row[mm] = sg * T[mm];
+    for (int mm = 0; mm < 6; mm++) acc += G2[mm * 3 + i] * y[mm];
+    if (k < 6) return -acc;
+    if (L2 == (k - 6) / 3) acc += mi_at(lg + L2 * LEG_STRIDE + LEG_MI, i, (k - 6) % 3);
+    return acc;
+  };
+  float* accv = lds + L.acc;
+  if (lane < A * 6) {                       // stage 1: t = r_b - sum_k G_k r_l,k
+    const int r = lane / 6, mm = lane - r * 6;
+    const float* rh = lds + L.rhs + r * MQE_RD;
+    float t = rh[mm];
 #pragma unroll
-    for (int kk = 0; kk < 4; kk++) {
-      float G[20];                                   // the leg's G block: five 16 B loads
-      {
-        const float4* G4 = reinterpret_cast<const float4*>(lds + L.leg + (r * 4 + kk) * LEG_STRIDE + LEG_G);
-#pragma unroll
-        for (int w = 0; w < 5; w++) { const float4 t = G4[w]; G[4 * w] = t.x; G[4 * w + 1] = t.y; G[4 * w + 2] = t.z; G[4 * w + 3] = t.w; }
-      }
-#pragma unroll
-      for (int i = 0; i < 3; i++) {
-        float acc = 0.0f;
-#pragma unroll
-        for (int mm = 0; mm < 6; mm++) acc += T[mm] * G[mm * 3 + i];
-        if (k < 6) acc = -acc;
-        else if (kk == legk) {
-          const float* Mi = lds + L.leg + (r * 4 + kk) * LEG_STRIDE + LEG_MI;   // sym6 00,11,22,01,02,12
-          const int a2 = li < i ? li : i, b2 = li < i ? i : li;
-          acc += (a2 == b2) ? Mi[a2] : (a2 == 0 ? (b2 == 1 ? Mi[3] : Mi[4]) : Mi[5]);
-        }
-        row[6 + kk * 3 + i] = acc;
-      }
+    for (int k = 0; k < 4; k++) {
+      const float* G = lds + L.leg + (r * 4 + k) * LEG_STRIDE + LEG_G + mm * 3;
+      t -= G[0] * rh[6 + k * 3] + G[1] * rh[7 + k * 3] + G[2] * rh[8 + k * 3];
     }
+    accv[r * MQE_RD + 6 + mm] = t;          // parked in the joint part of the scratch vector
   }
   __syncthreads();
-
+  if (lane < A * 6) {                       // stage 2: x_b = S^-1 t
+    const int r = lane / 6, mm = lane - r * 6;
+    const float* Si = lds + L.sinv + r * 36 + mm * 6;
+    const float* t = accv + r * MQE_RD + 6;
+    accv[r * MQE_RD + mm] = Si[0] * t[0] + Si[1] * t[1] + Si[2] * t[2] + Si[3] * t[3] + Si[4] * t[4] + Si[5] * t[5];
+  }
+  __syncthreads();
   TSTAMP(6);
   // ---- unconstrained velocity v* = v + dt M^-1 (tau - h) per generalized velocity; a lane owns dofs lane and lane + 64
   // (4 robots + ball = 78).  Kept in registers until the bias vector it overwrites has been consumed by every lane.
   auto vstar = [&](int d) -> float {
     if (d < A * MQE_RD) {
       const int r = d / MQE_RD, k = d - r * MQE_RD;
-      float v = k < 6 ? lds[L.root + r * 13 + 7 + k] : lds[L.dof + (r * 12 + k - 6) * 2 + 1];
-      float acc = 0.0f;
-      const float* Mc = lds + L.minv + r * MQE_RD * MQE_RD + k;     // column k == row k (symmetric)
-      const float* rh = lds + L.rhs + r * MQE_RD;
-      for (int ee = 0; ee < MQE_RD; ee++) acc += Mc[ee * MQE_RD] * rh[ee];
-      return v + dt * acc;
+      const float* xb = accv + r * MQE_RD;
+      if (k < 6) return lds[L.root + r * 13 + 7 + k] + dt * xb[k];
+      const int lg = (k - 6) / 3, i = (k - 6) - lg * 3;
+      const float* rec = lds + L.leg + (r * 4 + lg) * LEG_STRIDE;
+      const float* rl = lds + L.rhs + r * MQE_RD + 6 + lg * 3;
+      const float* G = rec + LEG_G + i;
+      float x = mi_at(rec + LEG_MI, i, 0) * rl[0] + mi_at(rec + LEG_MI, i, 1) * rl[1] + mi_at(rec + LEG_MI, i, 2) * rl[2];
+#pragma unroll
+      for (int mm = 0; mm < 6; mm++) x -= G[mm * 3] * xb[mm];
+      return lds[L.dof + (r * 12 + k - 6) * 2 + 1] + dt * x;
     }
     if (shp.has_seesaw) return lds[L.dof + (12 * A) * 2 + 1];       // the plank's hinge: COM on the axis, no drive
     const int q = d - A * MQE_RD, p = q / npcdof, k = q - p * npcdof;
@@ -930,19 +952,20 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       const float sg = side == 0 ? 1.0f : -1.0f;
       if (act < 0) continue;
       const int slot = side == 0 ? lane : maxc + (lane - nc_terr);
-      float* js = lds + L.js + slot * JS_STRIDE;
-      float* Bs = lds + L.B + slot * 54;
+      float4* sr = reinterpret_cast<float4*>(lds + L.side + slot * SIDE_STRIDE);
+      float W[3][6], Z[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, V[3][6];
+      int legi = -1;
+      const V3 dirs[3] = {n, t1, t2};
       if (act < A) {
         const float* brec = lds + L.body + act * MQE_NBODY * BODY_STRIDE;
         const V3 r0 = p - ld3(brec + B_P);
-        const V3 cn = cross(r0, n), c1 = cross(r0, t1), c2 = cross(r0, t2);
-        float J[9][3];
-        J[0][0] = sg * n.x; J[0][1] = sg * t1.x; J[0][2] = sg * t2.x;
-        J[1][0] = sg * n.y; J[1][1] = sg * t1.y; J[1][2] = sg * t2.y;
-        J[2][0] = sg * n.z; J[2][1] = sg * t1.z; J[2][2] = sg * t2.z;
-        J[3][0] = sg * cn.x; J[3][1] = sg * c1.x; J[3][2] = sg * c2.x;
-        J[4][0] = sg * cn.y; J[4][1] = sg * c1.y; J[4][2] = sg * c2.y;
-        J[5][0] = sg * cn.z; J[5][1] = sg * c1.z; J[5][2] = sg * c2.z;
+        const float* vb = Vm + act * MQE_RD;
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+          const V3 cq = cross(r0, dirs[q]);
+          W[q][0] = sg * dirs[q].x; W[q][1] = sg * dirs[q].y; W[q][2] = sg * dirs[q].z;
+          W[q][3] = sg * cq.x; W[q][4] = sg * cq.y; W[q][5] = sg * cq.z;
+        }
         const int leg = body > 0 ? (body - 1) / 3 : 0, dep = body > 0 ? (body - 1) % 3 + 1 : 0;
 #pragma unroll
         for (int t = 0; t < 3; t++) {
@@ -950,70 +973,87 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
           const float4 jq2 = reinterpret_cast<const float4*>(jrec)[2], jq3 = reinterpret_cast<const float4*>(jrec)[3];
           const V3 ax = v3(jq3.x, jq3.y, jq3.z), rr = p - v3(jq2.y, jq2.z, jq2.w);
           const float on = t < dep ? sg : 0.0f;
-          J[6 + t][0] = on * dot(cross(rr, n), ax); J[6 + t][1] = on * dot(cross(rr, t1), ax); J[6 + t][2] = on * dot(cross(rr, t2), ax);
-        }
 #pragma unroll
-        for (int i = 0; i < 9; i++) {
-          const int li = i < 6 ? i : 6 + leg * 3 + (i - 6);
-          reinterpret_cast<float4*>(js)[i] = make_float4(J[i][0], J[i][1], J[i][2], __int_as_float(li));
-          const float vv = Vm[act * MQE_RD + li];
-          cu0 += J[i][0] * vv; cu1 += J[i][1] * vv; cu2 += J[i][2] * vv;
+          for (int q = 0; q < 3; q++) Z[q][t] = on * dot(cross(rr, dirs[q]), ax);
+        }
+        // relative velocity of the unconstrained motion through the FULL Jacobian row: base columns, then the chain's joints
+        {
+          const float* vl = vb + 6 + leg * 3;
+          float uq[3];
+#pragma unroll
+          for (int q = 0; q < 3; q++) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int mm = 0; mm < 6; mm++) acc += W[q][mm] * vb[mm];
+            uq[q] = acc + Z[q][0] * vl[0] + Z[q][1] * vl[1] + Z[q][2] * vl[2];
+          }
+          cu0 += uq[0]; cu1 += uq[1]; cu2 += uq[2];
+        }
+        if (dep > 0) {                       // reduce onto the base coordinates: W = J_b - J_l G^T (five 16 B loads of G)
+          legi = leg;
+          float G[20];
+          const float4* G4 = reinterpret_cast<const float4*>(lds + L.leg + (act * 4 + leg) * LEG_STRIDE + LEG_G);
+#pragma unroll
+          for (int w = 0; w < 5; w++) { const float4 t = G4[w]; G[4 * w] = t.x; G[4 * w + 1] = t.y; G[4 * w + 2] = t.z; G[4 * w + 3] = t.w; }
+#pragma unroll
+          for (int q = 0; q < 3; q++)
+#pragma unroll
+            for (int mm = 0; mm < 6; mm++) W[q][mm] -= Z[q][0] * G[mm * 3] + Z[q][1] * G[mm * 3 + 1] + Z[q][2] * G[mm * 3 + 2];
+        }
+        {                                    // V = W S^-1 (S^-1 symmetric: nine 16 B loads)
+          float Si[36];
+          const float4* S4 = reinterpret_cast<const float4*>(lds + L.sinv + act * 36);
+#pragma unroll
+          for (int w = 0; w < 9; w++) { const float4 t = S4[w]; Si[4 * w] = t.x; Si[4 * w + 1] = t.y; Si[4 * w + 2] = t.z; Si[4 * w + 3] = t.w; }
+#pragma unroll
+          for (int q = 0; q < 3; q++)
+#pragma unroll
+            for (int mm = 0; mm < 6; mm++) {
+              float acc = 0.0f;
+#pragma unroll
+              for (int nn = 0; nn < 6; nn++) acc += W[q][nn] * Si[nn * 6 + mm];
+              V[q][mm] = acc;
+            }
         }
       } else if (SS) {
         const V3 r0 = p - ssPiv;
         const V3 wy = m->ss_axis == 3 ? v3(0, 1, 0) : cross(m->ss_axis == 2 ? v3(0, 0, 1) : v3(0, 1, 0), r0);   // prismatic: the axis itself
-        const float j0 = sg * dot(n, wy), j1 = sg * dot(t1, wy), j2 = sg * dot(t2, wy);
-        const float ii = 1.0f / m->ss_inertia;
+        const float ii = 1.0f / m->ss_inertia, vv = Vm[A * MQE_RD];
 #pragma unroll
-        for (int i = 0; i < 9; i++) {
-          const bool on = i == 0;
-          reinterpret_cast<float4*>(js)[i] = make_float4(on ? j0 : 0.0f, on ? j1 : 0.0f, on ? j2 : 0.0f, __int_as_float(0));
+        for (int q = 0; q < 3; q++) {
+          const float jq = sg * dot(dirs[q], wy);
+#pragma unroll
+          for (int mm = 0; mm < 6; mm++) { W[q][mm] = mm == 0 ? jq : 0.0f; V[q][mm] = mm == 0 ? ii * jq : 0.0f; }
         }
-        const float vv = Vm[A * MQE_RD];
-        cu0 += j0 * vv; cu1 += j1 * vv; cu2 += j2 * vv;
-        Bs[0] = ii * j0; Bs[18] = ii * j1; Bs[36] = ii * j2;
+        cu0 += W[0][0] * vv; cu1 += W[1][0] * vv; cu2 += W[2][0] * vv;
       } else {
         const int pi = act - A;
         const V3 r0 = p - ld3(lds + L.root + (A + pi) * 13);
-        const V3 cn = cross(r0, n), c1 = cross(r0, t1), c2 = cross(r0, t2);
         const float im = 1.0f / m->npc_mass, ii = 1.0f / m->npc_inertia;
-        float J[6][3] = {{sg * n.x, sg * t1.x, sg * t2.x}, {sg * n.y, sg * t1.y, sg * t2.y}, {sg * n.z, sg * t1.z, sg * t2.z},
-                         {sg * cn.x, sg * c1.x, sg * c2.x}, {sg * cn.y, sg * c1.y, sg * c2.y}, {sg * cn.z, sg * c1.z, sg * c2.z}};
+        const float* vn = Vm + A * MQE_RD + pi * npcdof;
 #pragma unroll
-        for (int i = 0; i < 9; i++) {
-          const bool on = i < npcdof;
-          const float j0 = on ? J[i < 6 ? i : 0][0] : 0.0f, j1 = on ? J[i < 6 ? i : 0][1] : 0.0f, j2 = on ? J[i < 6 ? i : 0][2] : 0.0f;
-          reinterpret_cast<float4*>(js)[i] = make_float4(j0, j1, j2, __int_as_float(on ? i : 0));
-          if (on) {
-            const float vv = Vm[A * MQE_RD + pi * npcdof + i];
-            cu0 += j0 * vv; cu1 += j1 * vv; cu2 += j2 * vv;
-            const float w = i < 3 ? im : ii;
-            Bs[i] = w * j0; Bs[18 + i] = w * j1; Bs[36 + i] = w * j2;
+        for (int q = 0; q < 3; q++) {
+          const V3 cq = cross(r0, dirs[q]);
+          const float jr[6] = {sg * dirs[q].x, sg * dirs[q].y, sg * dirs[q].z, sg * cq.x, sg * cq.y, sg * cq.z};
+          float acc = 0.0f;
+#pragma unroll
+          for (int mm = 0; mm < 6; mm++) {
+            const bool on = mm < npcdof;
+            W[q][mm] = on ? jr[mm] : 0.0f;
+            V[q][mm] = on ? (mm < 3 ? im : ii) * jr[mm] : 0.0f;
+            if (on) acc += jr[mm] * vn[mm];
           }
+          if (q == 0) cu0 += acc; else if (q == 1) cu1 += acc; else cu2 += acc;
         }
       }
-    }
-  }
-  __syncthreads();
-  // B = M^-1 J^T for the articulated sides: task = (contact, side, local dof): 9 x 3 FMAs over the side's sparse columns
-  for (int t = lane; t < (nc + (nc - nc_terr)) * MQE_RD; t += 64) {
-    const int cs = t / MQE_RD, d = t - cs * MQE_RD;
-    const int side = cs < nc ? 0 : 1, c = cs < nc ? cs : nc_terr + (cs - nc);
-    const int slot = side == 0 ? c : maxc + (c - nc_terr);
-    const float* cr = lds + L.con + c * CON_STRIDE;
-    const int act = __float_as_int(cr[C_IDS + 2 * side]);
-    if (act < 0 || act >= A) continue;
-    const float* js = lds + L.js + slot * JS_STRIDE;
-    const float* Mi = lds + L.minv + act * MQE_RD * MQE_RD + d;
-    float b0 = 0, b1 = 0, b2 = 0;
 #pragma unroll
-    for (int i = 0; i < 9; i++) {
-      const float4 en = *reinterpret_cast<const float4*>(js + i * 4);
-      const float mv = Mi[__float_as_int(en.w) * MQE_RD];
-      b0 += mv * en.x; b1 += mv * en.y; b2 += mv * en.z;
+      for (int q = 0; q < 3; q++) {
+        sr[q * 4 + 0] = make_float4(W[q][0], W[q][1], W[q][2], W[q][3]);
+        sr[q * 4 + 1] = make_float4(W[q][4], W[q][5], V[q][0], V[q][1]);
+        sr[q * 4 + 2] = make_float4(V[q][2], V[q][3], V[q][4], V[q][5]);
+        sr[q * 4 + 3] = make_float4(Z[q][0], Z[q][1], Z[q][2], __int_as_float(legi));
+      }
     }
-    float* Bs = lds + L.B + slot * 54;
-    Bs[d] = b0; Bs[18 + d] = b1; Bs[36 + d] = b2;
   }
   __syncthreads();
   TSTAMP(11);
@@ -1033,16 +1073,44 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       if (act < 0) continue;
       for (int s2 = 0; s2 < 2; s2++) {
         if ((s2 == 0 ? a2 : b2) != act) continue;
-        const float* js = lds + L.js + (s1 == 0 ? c : maxc + (c - nc_terr)) * JS_STRIDE;
-        const float* Bc = lds + L.B + (s2 == 0 ? c2 : maxc + (c2 - nc_terr)) * 54;
+        const float4* r1 = reinterpret_cast<const float4*>(lds + L.side + (s1 == 0 ? c : maxc + (c - nc_terr)) * SIDE_STRIDE);
+        const float4* r2 = reinterpret_cast<const float4*>(lds + L.side + (s2 == 0 ? c2 : maxc + (c2 - nc_terr)) * SIDE_STRIDE);
+        float W2[3][6], Z2[3][3];
+        int leg2 = -1;
 #pragma unroll
-        for (int i = 0; i < 9; i++) {
-          const float4 en = *reinterpret_cast<const float4*>(js + i * 4);
-          const int li = __float_as_int(en.w);
-          const float q0 = Bc[li], q1 = Bc[18 + li], q2 = Bc[36 + li];
-          k[0] += en.x * q0; k[1] += en.x * q1; k[2] += en.x * q2;
-          k[3] += en.y * q0; k[4] += en.y * q1; k[5] += en.y * q2;
-          k[6] += en.z * q0; k[7] += en.z * q1; k[8] += en.z * q2;
+        for (int q = 0; q < 3; q++) {
+          const float4 x0 = r2[q * 4], x1 = r2[q * 4 + 1], x3 = r2[q * 4 + 3];
+          W2[q][0] = x0.x; W2[q][1] = x0.y; W2[q][2] = x0.z; W2[q][3] = x0.w; W2[q][4] = x1.x; W2[q][5] = x1.y;
+          Z2[q][0] = x3.x; Z2[q][1] = x3.y; Z2[q][2] = x3.z;
+          if (q == 0) leg2 = __float_as_int(x3.w);
+        }
+        float Z1[3][3];
+        int leg1 = -1;
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+          const float4 y1 = r1[q * 4 + 1], y2 = r1[q * 4 + 2], y3 = r1[q * 4 + 3];
+          const float V1[6] = {y1.z, y1.w, y2.x, y2.y, y2.z, y2.w};
+          Z1[q][0] = y3.x; Z1[q][1] = y3.y; Z1[q][2] = y3.z;
+          if (q == 0) leg1 = __float_as_int(y3.w);
+#pragma unroll
+          for (int q2 = 0; q2 < 3; q2++) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int mm = 0; mm < 6; mm++) acc += V1[mm] * W2[q2][mm];
+            k[q * 3 + q2] += acc;
+          }
+        }
+        if (act < A && leg1 >= 0 && leg1 == leg2) {      // both on the same leg: + Z M_ll^-1 Z'^T
+          const float* Mi = lds + L.leg + (act * 4 + leg1) * LEG_STRIDE + LEG_MI;
+          const float m00 = Mi[0], m11 = Mi[1], m22 = Mi[2], m01 = Mi[3], m02 = Mi[4], m12 = Mi[5];
+#pragma unroll
+          for (int q = 0; q < 3; q++) {
+            const float t0 = Z1[q][0] * m00 + Z1[q][1] * m01 + Z1[q][2] * m02;
+            const float t1_ = Z1[q][0] * m01 + Z1[q][1] * m11 + Z1[q][2] * m12;
+            const float t2_ = Z1[q][0] * m02 + Z1[q][1] * m12 + Z1[q][2] * m22;
+#pragma unroll
+            for (int q2 = 0; q2 < 3; q2++) k[q * 3 + q2] += t0 * Z2[q2][0] + t1_ * Z2[q2][1] + t2_ * Z2[q2][2];
+          }
         }
       }
     }
@@ -1146,27 +1214,51 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   TSTAMP(13);
   if (is_con) { float* cr = lds + L.con + lane * CON_STRIDE; cr[C_LAM] = cl0; cr[C_LAM + 1] = cl1; cr[C_LAM + 2] = cl2; }
   __syncthreads();
-  for (int d = lane; d < ndof; d += 64) {           // impulses -> velocities, each lane its own entries of Vm
+  // impulses -> velocities in two stages: (1) per generalized coordinate the reduced sums  a = sum_c V_c^T lambda_c  (base
+  // coordinates / free bodies / the 1-dof link) resp.  b = sum_c Z_c^T lambda_c  (joints, contacts on the joint's own leg only);
+  // (2) dv_base = a, dv_leg = M_ll^-1 b - G^T a
+  for (int d = lane; d < ndof; d += 64) {
     int dact, dloc;
     if (d < A * MQE_RD) { dact = d / MQE_RD; dloc = d - dact * MQE_RD; }
     else if (shp.has_seesaw) { dact = A; dloc = 0; }
     else { const int q = d - A * MQE_RD; dact = A + q / npcdof; dloc = q - (q / npcdof) * npcdof; }
-    float v = Vm[d];
+    const bool jointd = dact < A && dloc >= 6;
+    const int dleg = jointd ? (dloc - 6) / 3 : -1;
+    const int off = jointd ? SIDE_Z + (dloc - 6) - dleg * 3 : SIDE_V + dloc;
+    float acc = 0.0f;
     for (int c = 0; c < nc; c++) {                    // contact c's actors and impulse live in lane c's registers
       const int a2 = __builtin_amdgcn_readlane(myA, c), b2 = __builtin_amdgcn_readlane(myB, c);
       const float l0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cl0), c));
       const float l1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cl1), c));
       const float l2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cl2), c));
       if (a2 == dact) {
-        const float* Bc = lds + L.B + c * 54;
-        v += Bc[dloc] * l0 + Bc[18 + dloc] * l1 + Bc[36 + dloc] * l2;
+        const float* sr = lds + L.side + c * SIDE_STRIDE;
+        if (!jointd || __float_as_int(sr[SIDE_INFO]) == dleg) acc += sr[off] * l0 + sr[SIDE_ROW + off] * l1 + sr[2 * SIDE_ROW + off] * l2;
       }
       if (b2 == dact) {                               // both for a contact between two links of this actor
-        const float* Bc = lds + L.B + (maxc + (c - nc_terr)) * 54;
-        v += Bc[dloc] * l0 + Bc[18 + dloc] * l1 + Bc[36 + dloc] * l2;
+        const float* sr = lds + L.side + (maxc + (c - nc_terr)) * SIDE_STRIDE;
+        if (!jointd || __float_as_int(sr[SIDE_INFO]) == dleg) acc += sr[off] * l0 + sr[SIDE_ROW + off] * l1 + sr[2 * SIDE_ROW + off] * l2;
       }
     }
-    Vm[d] = v;
+    accv[d] = acc;
+  }
+  __syncthreads();
+  for (int d = lane; d < ndof; d += 64) {
+    float dv = accv[d];
+    if (d < A * MQE_RD) {
+      const int r = d / MQE_RD, k = d - r * MQE_RD;
+      if (k >= 6) {
+        const int lg = (k - 6) / 3, i = (k - 6) - lg * 3;
+        const float* rec = lds + L.leg + (r * 4 + lg) * LEG_STRIDE;
+        const float* bl = accv + r * MQE_RD + 6 + lg * 3;
+        const float* ab = accv + r * MQE_RD;
+        const float* G = rec + LEG_G + i;
+        dv = mi_at(rec + LEG_MI, i, 0) * bl[0] + mi_at(rec + LEG_MI, i, 1) * bl[1] + mi_at(rec + LEG_MI, i, 2) * bl[2];
+#pragma unroll
+        for (int mm = 0; mm < 6; mm++) dv -= G[mm * 3] * ab[mm];
+      }
+    }
+    Vm[d] += dv;
   }
   __syncthreads();
   // joint limits: one sequential pass in (robot, joint) order after the contact solve, only when some joint violates.  The bound
@@ -1199,11 +1291,10 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
           jbound(j, q, lo, hi);
           float vio = 0.0f;
           if (vj < lo) vio = lo - vj; else if (vj > hi) vio = hi - vj;
-          if (vio != 0.0f) {                          // wave-uniform
-            const float* mrow = lds + L.minv + r * MQE_RD * MQE_RD + (6 + j) * MQE_RD;
-            const float lam = vio / mrow[6 + j];
+          if (vio != 0.0f) {                          // wave-uniform: impulse along e_j, dv = M^-1 e_j lambda, (M^-1)_jj lambda = vio
+            const float lam = vio / minv_elem(r, 6 + j, 6 + j);
             __syncthreads();
-            if (lane < MQE_RD) Vm[r * MQE_RD + lane] += mrow[lane] * lam;
+            if (lane < MQE_RD) Vm[r * MQE_RD + lane] += minv_elem(r, 6 + j, lane) * lam;
             __syncthreads();
           }
         }
@@ -1218,7 +1309,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   }
   TSTAMP(14);
   if (dbg.minv != nullptr) {
-    for (int i = lane; i < MQE_RD * MQE_RD; i += 64) dbg.minv[i] = lds[L.minv + dbg.robot * MQE_RD * MQE_RD + i];
+    for (int i = lane; i < MQE_RD * MQE_RD; i += 64) dbg.minv[i] = minv_elem(dbg.robot, i / MQE_RD, i % MQE_RD);   // assembled from the factors
     if (lane == 0) *dbg.nc = nc;
     for (int c = lane; c < nc; c += 64) {
       const float* cr = lds + L.con + c * CON_STRIDE;
@@ -1305,39 +1396,26 @@ __device__ __forceinline__ float softsign_p(float x) { return x * __builtin_amdg
 
 #define ACT_TILES 2       // 2 x 32 joints >= 12 * MQE_MAX_AGENTS(=4)... agents <= 4 need 48 joints
 
+#ifndef MQE_SUBSTEPS_WAVES
+#define MQE_SUBSTEPS_WAVES 2
+#endif
 template <int TA, int TP>
-__global__ void __launch_bounds__(64, 2) k_substeps(const DevModel* __restrict__ m, DevState st, int nsub, int lag_pos) {
+__global__ void __launch_bounds__(64, MQE_SUBSTEPS_WAVES) k_substeps(const DevModel* __restrict__ m, DevState st, int nsub, int lag_pos) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x, e = blockIdx.x;
   const PhysShape<TA, TP> shp(m);
   const int A = shp.A, P = shp.P;
   const PhysLds L = phys_lds_layout(A, P, shp.ND, shp.nbody, shp.ndof, m->nsph_env, shp.maxc);
-  const int j32 = lane & 31, h = lane >> 5;
   const int nj = 12 * A;
-  const float* W0 = m->actuator.W[0]; const float* b0 = m->actuator.b[0];
-  const float* W1 = m->actuator.W[1]; const float* b1 = m->actuator.b[1];
-  const float* W2 = m->actuator.W[2]; const float* b2 = m->actuator.b[2];
-  // per-tile joint state in registers
-  float asl[ACT_TILES];                                           // scaled action incl. hip reduction (the lagged target's input)
-  float tgt[ACT_TILES], h_e1[ACT_TILES], h_e2[ACT_TILES], h_v1[ACT_TILES], h_v2[ACT_TILES], lim[ACT_TILES];
-  float asc[ACT_TILES], dfl[ACT_TILES], lqd[ACT_TILES];          // low-level control types: scaled action, default pose, last-step velocity
   const int ctrl = m->control_type;
   const size_t R12 = (size_t)m->R * 12;
-#pragma unroll
-  for (int t = 0; t < ACT_TILES; t++) {
-    const int jt = t * 32 + j32;
-    const bool ok = jt < nj;
-    const size_t gi = (size_t)e * nj + (ok ? jt : 0);
-    const int j = (ok ? jt : 0) % 12;
-    float as = st.actions[gi] * m->action_scale;
-    if (j % 3 == 0) as *= m->hip_scale_reduction;
-    asc[t] = st.actions[gi] * m->action_scale;                   // P / V / T: no hip reduction (legged_robot.py:380)
-    dfl[t] = m->default_dof_pos[j];
-    lqd[t] = ctrl == MQE_CTRL_V ? st.last_dof_vel[gi] : 0.0f;
-    asl[t] = as;
-    tgt[t] = as + m->default_dof_pos[j];
-    h_e1[t] = st.act_hist[gi]; h_e2[t] = st.act_hist[R12 + gi]; h_v1[t] = st.act_hist[2 * R12 + gi]; h_v2[t] = st.act_hist[3 * R12 + gi];
-    lim[t] = m->torque_limits[j];
+  // Nothing of the controller stays in registers across the physics body (it needs every one of the 168 a wave may hold at 3
+  // waves per SIMD): the actuator history of each joint lives in LDS, the per-joint constants and the action are re-read (L1 / L2)
+  // at the head of every substep.
+  float* acth = lds + L.acth;                                    // [4][nj]: e1, e2, v1, v2
+  for (int i = lane; i < 4 * nj; i += 64) {
+    const int w = i / nj, jt = i - w * nj;
+    acth[i] = st.act_hist[(size_t)w * R12 + (size_t)e * nj + jt];
   }
   float* g_root = st.root + (size_t)e * (A + P) * 13;
   float* g_dof = st.dof + (size_t)e * shp.ND * 2;
@@ -1345,84 +1423,107 @@ __global__ void __launch_bounds__(64, 2) k_substeps(const DevModel* __restrict__
   for (int i = lane; i < shp.ND * 2; i += 64) lds[L.dof + i] = g_dof[i];
   __syncthreads();
   const PhysDebug nodbg = {nullptr, nullptr, nullptr, 0, nullptr};
+#pragma clang loop unroll(disable)
   for (int k = 0; k < nsub; k++) {
     const bool last = k + 1 == nsub;
-    // weight fragments (A operands): row = hidden unit j32, k = this half-wave's element of each k pair.  They are
-    // re-read (L1/L2 resident, 5 kB shared by every wave) each substep behind an optimisation barrier: keeping 70 VGPRs
-    // live across the 50 k-cycle physics body would spill and halve the occupancy.
+    // Register budget vs. recomputation (measured, go1gate 4096 envs, MI355X).  Everything the body derives
+    // from the lane id and the model alone (indices, LDS addresses, masks, per-lane model constants: ~100 values) is invariant
+    // over the substeps; the compiler hoists it out of this loop and the kernel then needs ~250 VGPRs = 2 waves per SIMD.
+    // Laundering the model pointer (MQE_LAUNDER >= 1) and the lane id (>= 2) once per substep turns the hoisting off: 154 VGPRs,
+    // no scratch, 3 waves per SIMD with the 12.9 KiB LDS footprint -- but a wave then re-derives all of it four times (+17 %
+    // instructions), and 4096 envs are 16 waves per CU = one round of 12 plus a tail of 4: 219 us against 199 us for the hoisted
+    // form at 2 waves per SIMD (two full rounds of 8).  Forcing 168 VGPRs onto the hoisted form spills (267 us).  So: hoisted.
+    const DevModel* mk = m;
+    int lane_k = lane;
+#ifndef MQE_LAUNDER
+#define MQE_LAUNDER 0
+#endif
+#if MQE_LAUNDER >= 1
+    asm volatile("" : "+s"(mk));
+#endif
+#if MQE_LAUNDER >= 2
+    asm volatile("" : "+v"(lane_k));
+    lane_k &= 63;                                    // gives the value range of threadIdx.x back to the optimiser
+#endif
+    const int j32 = lane_k & 31, h = lane_k >> 5;
     if (ctrl != MQE_CTRL_C) {          // P / V / T (legged_robot.py:384-390): a few FMAs per joint lane instead of the actuator network
-#pragma unroll
-      for (int t = 0; t < ACT_TILES; t++) {
-        if (t * 32 >= nj) break;
-        const int jt = t * 32 + j32;
-        const bool ok = jt < nj;
-        const float q = lds[L.dof + (ok ? jt : 0) * 2], qd = lds[L.dof + (ok ? jt : 0) * 2 + 1];
-        float tau = asc[t];
-        if (ctrl == MQE_CTRL_P) tau = m->kp * (asc[t] + dfl[t] - q) - m->kd * qd;
-        else if (ctrl == MQE_CTRL_V) tau = m->kp * (asc[t] - qd) - m->kd * (qd - lqd[t]) / m->dt;
-        tau = clampf(tau, -lim[t], lim[t]);
-        if (ok && h == 0) {
-          lds[L.tau + jt] = tau;
-          st.sub_tau[((size_t)e * 4 + (k < 4 ? k : 3)) * nj + jt] = tau;
-          if (last) st.torques[(size_t)e * nj + jt] = tau;
-        }
+      for (int jt = lane_k; jt < nj; jt += 64) {
+        const size_t gi = (size_t)e * nj + jt;
+        const int j = jt % 12;
+        const float asc = st.actions[gi] * m->action_scale;          // no hip reduction (legged_robot.py:380)
+        const float q = lds[L.dof + jt * 2], qd = lds[L.dof + jt * 2 + 1], lim = m->torque_limits[j];
+        float tau = asc;
+        if (ctrl == MQE_CTRL_P) tau = m->kp * (asc + m->default_dof_pos[j] - q) - m->kd * qd;
+        else if (ctrl == MQE_CTRL_V) tau = m->kp * (asc - qd) - m->kd * (qd - st.last_dof_vel[gi]) / m->dt;
+        tau = clampf(tau, -lim, lim);
+        lds[L.tau + jt] = tau;
+        st.sub_tau[((size_t)e * 4 + (k < 4 ? k : 3)) * nj + jt] = tau;
+        if (last) st.torques[gi] = tau;
       }
     } else {                           // control type C: actuator network (one call site of the physics body below: it is
                                        // inlined, and two copies of its ~9 k instructions would not fit the instruction cache)
-    if (m->lag_steps > 0) {            // go1.py:337-339: the lag buffer shifts in every _compute_torques call, i.e. per substep
-      const int n = m->lag_steps + 1;
-      int pos = lag_pos + k; pos -= (pos / n) * n;
+      // weight fragments (A operands): row = hidden unit j32, k = this half-wave's element of each k pair; re-read every substep
+      // (L1/L2 resident, 5 kB shared by every wave)
+      const float* W0 = mk->actuator.W[0]; const float* b0 = mk->actuator.b[0];      // through the laundered pointer: the 70 fragment
+      const float* W1 = mk->actuator.W[1]; const float* b1 = mk->actuator.b[1];      // loads below stay inside the substep loop
+      const float* W2 = mk->actuator.W[2]; const float* b2 = mk->actuator.b[2];
+      float a1[3], a2[16], w3[16], bb0[16], bb1[16];
+#pragma unroll
+      for (int s2 = 0; s2 < 3; s2++) a1[s2] = W0[j32 * 6 + 2 * s2 + h];
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int u = (r & 3) + 8 * (r >> 2) + 4 * h;
+        a2[r] = W1[j32 * 32 + u]; w3[r] = W2[u]; bb0[r] = b0[u]; bb1[r] = b1[u];
+      }
+      const float bout = b2[0];
+      int pos = 0;
+      if (m->lag_steps > 0) {          // go1.py:337-339: the lag buffer shifts in every _compute_torques call, i.e. per substep
+        const int n = m->lag_steps + 1;
+        pos = lag_pos + k; pos -= (pos / n) * n;
+      }
 #pragma unroll
       for (int t = 0; t < ACT_TILES; t++) {
+        if (t * 32 >= nj) break;                           // wave-uniform
         const int jt = t * 32 + j32;
-        if (jt < nj) tgt[t] = lag_target(m, st, (size_t)e * nj + jt, asl[t], pos) + dfl[t];
+        const bool ok = jt < nj;
+        const int jc = ok ? jt : 0, j = jc % 12;
+        const size_t gi = (size_t)e * nj + jc;
+        float as = st.actions[gi] * m->action_scale;
+        if (j % 3 == 0) as *= m->hip_scale_reduction;
+        float tgt = as + m->default_dof_pos[j];
+        if (m->lag_steps > 0 && ok) tgt = lag_target(m, st, gi, as, pos) + m->default_dof_pos[j];
+        const float lim = m->torque_limits[j];
+        const float q = lds[L.dof + jc * 2], qd = lds[L.dof + jc * 2 + 1];
+        const float he1 = acth[jc], he2 = acth[nj + jc], hv1 = acth[2 * nj + jc], hv2 = acth[3 * nj + jc];
+        const float err = q - tgt;
+        f32x16_p acc1, acc2;
+#pragma unroll
+        for (int r = 0; r < 16; r++) { acc1[r] = bb0[r]; acc2[r] = bb1[r]; }
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[0], h ? he1 : err, acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[1], h ? qd : he2, acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[2], h ? hv2 : hv1, acc1, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc1[r] = softsign_p(acc1[r]);
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[r], acc1[r], acc2, 0, 0, 0);
+        float part = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) part = fmaf(w3[r], softsign_p(acc2[r]), part);
+        float tau = part + __shfl_xor(part, 32, 64) + bout;
+        tau = clampf(tau, -lim, lim);
+        __syncthreads();                                   // every lane has read the history before it shifts
+        if (ok && h == 0) {
+          acth[nj + jt] = he1; acth[jt] = err; acth[3 * nj + jt] = hv1; acth[2 * nj + jt] = qd;      // go1.py:347-350
+          lds[L.tau + jt] = tau;
+          st.sub_tau[((size_t)e * 4 + (k < 4 ? k : 3)) * nj + jt] = tau;          // post_decimation_step (legged_robot.py:113)
+          if (last) st.torques[gi] = tau;
+        }
       }
-    }
-    const float *w0p = W0, *w1p = W1, *w2p = W2, *b0p = b0, *b1p = b1;
-    asm volatile("" : "+s"(w0p), "+s"(w1p), "+s"(w2p), "+s"(b0p), "+s"(b1p));
-    float a1[3], a2[16], w3[16], bb0[16], bb1[16];
-#pragma unroll
-    for (int s2 = 0; s2 < 3; s2++) a1[s2] = w0p[j32 * 6 + 2 * s2 + h];
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int u = (r & 3) + 8 * (r >> 2) + 4 * h;
-      a2[r] = w1p[j32 * 32 + u]; w3[r] = w2p[u]; bb0[r] = b0p[u]; bb1[r] = b1p[u];
-    }
-    const float bout = b2[0];
-#pragma unroll
-    for (int t = 0; t < ACT_TILES; t++) {
-      if (t * 32 >= nj) break;                           // wave-uniform
-      const int jt = t * 32 + j32;
-      const bool ok = jt < nj;
-      const float q = lds[L.dof + (ok ? jt : 0) * 2], qd = lds[L.dof + (ok ? jt : 0) * 2 + 1];
-      const float err = q - tgt[t];
-      f32x16_p acc1, acc2;
-#pragma unroll
-      for (int r = 0; r < 16; r++) { acc1[r] = bb0[r]; acc2[r] = bb1[r]; }
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[0], h ? h_e1[t] : err, acc1, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[1], h ? qd : h_e2[t], acc1, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[2], h ? h_v2[t] : h_v1[t], acc1, 0, 0, 0);
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc1[r] = softsign_p(acc1[r]);
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[r], acc1[r], acc2, 0, 0, 0);
-      float part = 0.0f;
-#pragma unroll
-      for (int r = 0; r < 16; r++) part = fmaf(w3[r], softsign_p(acc2[r]), part);
-      float tau = part + __shfl_xor(part, 32, 64) + bout;
-      tau = clampf(tau, -lim[t], lim[t]);
-      h_e2[t] = h_e1[t]; h_e1[t] = err; h_v2[t] = h_v1[t]; h_v1[t] = qd;      // go1.py:347-350
-      if (ok && h == 0) {
-        lds[L.tau + jt] = tau;
-        st.sub_tau[((size_t)e * 4 + (k < 4 ? k : 3)) * nj + jt] = tau;          // post_decimation_step (legged_robot.py:113)
-        if (last) st.torques[(size_t)e * nj + jt] = tau;
-      }
-    }
     }
     __syncthreads();
-    phys_substep<TA, TP>(m, st, lds, e, lane, last ? (PS_STORE_STATE | PS_WRITE_CF) : 0, 0, nodbg);
+    phys_substep<TA, TP>(mk, st, lds, e, lane_k, last ? (PS_STORE_STATE | PS_WRITE_CF) : 0, 0, nodbg);
     // post_decimation_step (legged_robot.py:114-115): joint velocities and soft-limit flags after this substep, from the LDS state
-    for (int jt = lane; jt < nj; jt += 64) {
+    for (int jt = lane_k; jt < nj; jt += 64) {
       const float q = lds[L.dof + jt * 2], qd = lds[L.dof + jt * 2 + 1];
       const int j = jt % 12;
       const size_t o = ((size_t)e * 4 + (k < 4 ? k : 3)) * nj + jt;
@@ -1430,12 +1531,9 @@ __global__ void __launch_bounds__(64, 2) k_substeps(const DevModel* __restrict__
       st.sub_exceed[o] = (uint8_t)((q < m->soft_lo[j]) | (q > m->soft_hi[j]));
     }
   }
-#pragma unroll
-  for (int t = 0; t < ACT_TILES; t++) {
-    const int jt = t * 32 + j32;
-    if (jt < nj && h == 0) {
-      const size_t gi = (size_t)e * nj + jt;
-      st.act_hist[gi] = h_e1[t]; st.act_hist[R12 + gi] = h_e2[t]; st.act_hist[2 * R12 + gi] = h_v1[t]; st.act_hist[3 * R12 + gi] = h_v2[t];
-    }
+  __syncthreads();
+  for (int i = lane; i < 4 * nj; i += 64) {
+    const int w = i / nj, jt = i - w * nj;
+    st.act_hist[(size_t)w * R12 + (size_t)e * nj + jt] = acth[i];
   }
 }

@@ -268,8 +268,9 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   if (m.ndof_env > 128 || m.nbody_env > 64) { return fail(-4, "env has more than 64 bodies or 128 generalized velocities: does not fit one wavefront"); }
   PhysLds L = phys_lds_layout(A, P, s->ND, m.nbody_env, m.ndof_env, m.nsph_env, m.maxc);
   s->phys_lds_bytes = (size_t)L.total * 4;
+  if (const char* pad = getenv("MQE_PHYS_LDS_PAD")) s->phys_lds_bytes += (size_t)atoi(pad);   // experiments: caps the physics kernel's waves per CU
   // the records the physics kernel moves as 16 B words must start on 16 B (kernels_physics.hpp)
-  if ((L.body | L.sph | L.con | L.js | L.leg | L.fcol) & 3) { return fail(-4, "physics LDS layout: a 16 B record area is misaligned"); }
+  if ((L.body | L.sph | L.con | L.side | L.leg | L.legc | L.sinv | L.fcol | L.acc | L.rhs) & 3) { return fail(-4, "physics LDS layout: a 16 B record area is misaligned"); }
   if (s->phys_lds_bytes > 160 * 1024) { return fail(-4, "physics LDS footprint exceeds 160 KiB"); }
   s->substeps_fn = pick_substeps(m);
   if (s->phys_lds_bytes > 48 * 1024)

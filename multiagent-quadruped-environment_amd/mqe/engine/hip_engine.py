@@ -16,6 +16,10 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.
 def load_library():
     global _LIB
     if _LIB is None:
+        path = os.environ.get("MQE_HIP_LIB", LIB_PATH)       # experiments: an alternative build of the same ABI
+        if path != LIB_PATH:
+            _LIB = C.CDLL(path)
+            return _LIB
         if not os.path.isfile(LIB_PATH):
             raise RuntimeError(f"HIP engine not built: {LIB_PATH} missing (run `python -c 'import __graft_entry__ as g; g.build()'`)")
         _LIB = C.CDLL(LIB_PATH)

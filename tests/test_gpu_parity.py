@@ -357,16 +357,26 @@ def test_low_level_control_matches_reference_and_oracle(ctrl):
     eh.reset_all(); eo.reset_all()
     g = torch.Generator().manual_seed(3)
     dev = []
+    together = torch.ones(N, dtype=torch.bool)          # envs whose two trajectories still agree to float noise (10 um)
+    early = 0
     for t in range(12):
         a = (torch.rand(N * 2, 12, generator=g) * 2 - 1) * (1.0 if ctrl != "T" else 8.0)
         eh.step_joint(a.cuda().contiguous()); eo.step_joint(a)
         torch.cuda.synchronize()
         if t == 0:
             close(eh.tensor(abi.T_SUBSTEP_TORQUES)[:, 0], eo.tensor(abi.T_SUBSTEP_TORQUES)[:, 0], atol=2e-4, rtol=1e-4, what="first substep torques")
-        dev.append((eh.tensor(abi.T_ROOT_STATE).cpu()[..., :3] - eo.tensor(abi.T_ROOT_STATE)[..., :3]).abs().max(dim=-1).values.flatten())
+        # random joint-space actions throw the robots over within a few steps; a fall is chaotic, so a flag may only differ in an
+        # env whose trajectories had already separated -- in one that is still on the common trajectory only when a termination
+        # test sits exactly on its threshold (base contact force 1 N): at most one such event in the whole rollout
+        flags_h, flags_o = eh.tensor(abi.T_RESET_BUF).cpu() != 0, eo.tensor(abi.T_RESET_BUF) != 0
+        early += int(((flags_h != flags_o) & together).sum())
+        d_now = (eh.tensor(abi.T_ROOT_STATE).cpu()[..., :3] - eo.tensor(abi.T_ROOT_STATE)[..., :3]).abs().max(dim=-1).values
+        dev.append(d_now.flatten())
+        together &= (d_now.max(dim=-1).values < 1e-5) & ~(flags_h | flags_o)
     dev = torch.stack(dev)
     assert torch.isfinite(dev).all() and dev[3].median() < 1e-4 and dev[-1].median() < 5e-3, (dev[3].median(), dev[-1].median())
-    assert int((eh.tensor(abi.T_RESET_BUF).cpu() != eo.tensor(abi.T_RESET_BUF)).sum()) <= 4
+    assert early <= 1, f"{early} reset flags differ in envs that had not diverged"
+    assert int((eh.tensor(abi.T_RESET_BUF).cpu() != eo.tensor(abi.T_RESET_BUF)).sum()) <= N // 8
 
 
 def test_seesaw_plank_matches_oracle():
