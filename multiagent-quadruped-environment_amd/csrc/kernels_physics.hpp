@@ -668,16 +668,15 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       if (lane < m->npc_n_spheres) { act = A + p; sidx = lane; s = A * nsr + p * m->npc_n_spheres + lane; }
     }
     bool gflag = false, wflag = false, bflag = false, cflag = false;   // ground, wall, seesaw platform, seesaw column
-    float gsd = 0, wsd = 0, bsd = 0, csd = 0; V3 wn = v3(0, 0, 1), bn = v3(0, 0, 1), cn3 = v3(0, 0, 1); V3 c = v3(0, 0, 0); float rad = 0;
+    float gsd = 0, wsd = 0, bsd = 0, csd = 0; V3 gn = v3(0, 0, 1), wn = v3(0, 0, 1), bn = v3(0, 0, 1), cn3 = v3(0, 0, 1); V3 c = v3(0, 0, 0); float rad = 0;
     int body = 0, rep = 0;
     if (act >= 0) {
       const float* sp = lds + L.sph + s * 4;
       { const float4 q = *reinterpret_cast<const float4*>(sp); c = v3(q.x, q.y, q.z); rad = q.w; }
       if (act < A) { body = rm.sphere_body[sidx]; rep = act * MQE_NREP + rm.sphere_reported[sidx]; }
       else { body = 0; rep = A * MQE_NREP + (act - A); }
-      gsd = c.z - m->ground_z - rad;
-      gflag = gsd < m->contact_offset;
-      // wall prism set: bilinear SDF sample at cell centres
+      // terrain maps are sampled bilinearly at cell centres: the wall set's signed distance and, when the scene has one, the
+      // relief of the walkable surface (Perlin noise, barrier_track.py:372-393)
       const float hs = m->hs;
       float fx = c.x / hs - 0.5f, fy = c.y / hs - 0.5f;
       const int nx = m->sdf_nx, ny = m->sdf_ny;
@@ -686,6 +685,17 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       if (ix > nx - 2) ix = nx - 2;
       if (iy > ny - 2) iy = ny - 2;
       const float tx = fx - ix, ty = fy - iy;
+      gsd = c.z - m->ground_z - rad;
+      if (m->ground_height != nullptr) {       // heightfield ground: first-order distance to the surface along its normal
+        const float* gh = m->ground_height + (size_t)ix * ny + iy;
+        const float h00 = gh[0], h01 = gh[1], h10 = gh[ny], h11 = gh[ny + 1];
+        const float b0 = h00 + (h01 - h00) * ty, b1 = h10 + (h11 - h10) * ty;
+        const float hx = (b1 - b0) / hs, hy = ((h01 - h00) + ((h11 - h10) - (h01 - h00)) * tx) / hs;
+        const float inl = 1.0f / sqrtf(hx * hx + hy * hy + 1.0f);
+        gn = v3(-hx * inl, -hy * inl, inl);
+        gsd = (c.z - m->ground_z - (b0 + (b1 - b0) * tx)) * inl - rad;
+      }
+      gflag = gsd < m->contact_offset;
       const float* sd = m->wall_sdf + (size_t)ix * ny + iy;
       const float s00 = sd[0], s01 = sd[1], s10 = sd[ny], s11 = sd[ny + 1];
       const float a0 = s00 + (s01 - s00) * ty, a1 = s10 + (s11 - s10) * ty;
@@ -745,7 +755,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       const int slot = base + pre;
       if (slot < maxc && pre < cap) {
         float* cr = lds + L.con + slot * CON_STRIDE;
-        con_store(cr, act, body, -1, 0, v3(c.x, c.y, c.z - rad), v3(0, 0, 1), gsd, rep, -1);
+        con_store(cr, act, body, -1, 0, c - rad * gn, gn, gsd, rep, -1);
       }
     }
     if (wflag) {

@@ -62,6 +62,7 @@ typedef struct mqo_sim {
   int wrapper_side_effects;   /* 1 while a wrapper-level call runs (mqo_step / mqo_wrapper_eval): go1tug re-poses its slider */
   mlp_t act, ada, body;
   float* sdf;
+  float* ground_height;             /* relief of the walkable surface at the SDF's cell centres, or NULL (flat slab) */
   float *env_origins, *agent_origins, *base_init, *npc_init, *gate_pos;
   /* state */
   float *root, *dof, *cf, *torques, *actions, *last_actions, *loco_obs, *hist, *last_loco, *last_two_loco;
@@ -294,6 +295,7 @@ int mqo_sim_create(const mqe_sim_desc* d, mqo_sim** out) {
   mlp_copy(&s->ada, &d->adaptation);
   mlp_copy(&s->body, &d->body);
   s->sdf = (float*)dupmem(d->wall_sdf, (size_t)d->sdf_nx * d->sdf_ny * 4);
+  s->ground_height = d->ground_height ? (float*)dupmem(d->ground_height, (size_t)d->sdf_nx * d->sdf_ny * 4) : NULL;
   s->env_origins = (float*)dupmem(d->env_origins, (size_t)N * 3 * 4);
   s->agent_origins = (float*)dupmem(d->agent_origins, (size_t)N * A * 3 * 4);
   s->base_init = (float*)dupmem(d->base_init_state, (size_t)A * 13 * 4);
@@ -539,8 +541,8 @@ static void sym6_to_mat(const float* s6, real* I) {
   I[0] = s6[0]; I[4] = s6[1]; I[8] = s6[2]; I[1] = I[3] = s6[3]; I[2] = I[6] = s6[4]; I[5] = I[7] = s6[5];
 }
 
-/* bilinear sample of the wall SDF at world (x,y) + gradient */
-static real sdf_sample(const mqo_sim* s, real x, real y, real* gx, real* gy) {
+/* bilinear sample of a terrain map (wall SDF / ground relief, values at cell centres) at world (x,y) + gradient */
+static real map_sample(const mqo_sim* s, const float* map, real x, real y, real* gx, real* gy) {
   const mqe_sim_desc* d = &s->d;
   real hs = d->horizontal_scale;
   real fx = x / hs - (real)0.5, fy = y / hs - (real)0.5;   /* samples sit at cell centres */
@@ -550,13 +552,14 @@ static real sdf_sample(const mqo_sim* s, real x, real y, real* gx, real* gy) {
   int ix = (int)fx, iy = (int)fy;
   if (ix > nx - 2) ix = nx - 2; if (iy > ny - 2) iy = ny - 2;
   real tx = fx - ix, ty = fy - iy;
-  real s00 = s->sdf[(size_t)ix * ny + iy], s01 = s->sdf[(size_t)ix * ny + iy + 1];
-  real s10 = s->sdf[(size_t)(ix + 1) * ny + iy], s11 = s->sdf[(size_t)(ix + 1) * ny + iy + 1];
+  real s00 = map[(size_t)ix * ny + iy], s01 = map[(size_t)ix * ny + iy + 1];
+  real s10 = map[(size_t)(ix + 1) * ny + iy], s11 = map[(size_t)(ix + 1) * ny + iy + 1];
   real a0 = s00 + (s01 - s00) * ty, a1 = s10 + (s11 - s10) * ty;
   *gx = (a1 - a0) / hs;
   *gy = ((s01 - s00) + ((s11 - s10) - (s01 - s00)) * tx) / hs;
   return a0 + (a1 - a0) * tx;
 }
+static real sdf_sample(const mqo_sim* s, real x, real y, real* gx, real* gy) { return map_sample(s, s->sdf, x, y, gx, gy); }
 
 /* sphere (centre c, radius r) vs box (centre bc, rotation R row-major, half extents h): signed distance and world
  * normal pointing from the box to the sphere */
@@ -850,7 +853,16 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
       const int npass = act < A ? (SS ? 4 : (d->n_static_boxes > 0 ? 3 : 2)) : 2;
       for (int pass = 0; pass < npass; pass++) {
         real n[3], sd;
-        if (pass == 0) { sd = c[2] - d->ground_z - r; n[0] = 0; n[1] = 0; n[2] = 1; }
+        if (pass == 0) {
+          sd = c[2] - d->ground_z - r; n[0] = 0; n[1] = 0; n[2] = 1;
+          if (s->ground_height) {      /* heightfield ground (Perlin relief): first-order distance to the surface along its normal */
+            real hx, hy;
+            real h = map_sample(s, s->ground_height, c[0], c[1], &hx, &hy);
+            real inl = 1 / (real)sqrt((double)(hx * hx + hy * hy + 1));
+            n[0] = -hx * inl; n[1] = -hy * inl; n[2] = inl;
+            sd = (c[2] - d->ground_z - h) * inl - r;
+          }
+        }
         else if (pass == 2 && !SS) { /* static scenery: the world-aligned box with the smallest signed distance */
           real I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
           const float* nb = root + A * 13;

@@ -35,9 +35,19 @@ def task_cfg(task):
             "go1tug": Go1TugCfg}[task]
 
 
-def make_desc(task, N, seed=0, levels=None, types=None, max_episode_length=None, npc_init=None, env_id_offset=0, **kw):
+def perlin_terrain(task, zScale=0.12, frequency=10, **cfg_over):
+    """the task's own terrain config with the whole-map Perlin relief switched on (barrier_track.py:372-393)"""
+    base = task_cfg(task).terrain
+    kw = dict(base.BarrierTrack_kwargs)
+    kw.update(add_perlin_noise=True, border_perlin_noise=True)
+    return type("PerlinTerrain", (base,), dict(cfg_over, BarrierTrack_kwargs=kw, TerrainPerlin_kwargs=dict(zScale=zScale, frequency=frequency)))
+
+
+def make_desc(task, N, seed=0, levels=None, types=None, max_episode_length=None, npc_init=None, env_id_offset=0, terrain_cfg=None, **kw):
     """Scene exactly as Go1._create_scene builds it, but with explicit track assignment for replaying fixtures."""
     cfg = task_cfg(task)
+    if terrain_cfg is not None:
+        cfg = type(cfg.__name__ + "OnOtherTerrain", (cfg,), {"terrain": terrain_cfg})
     A = cfg.env.num_agents
     np.random.seed(seed)
     t = BarrierTrack(cfg.terrain, N, A).build()

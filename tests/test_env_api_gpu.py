@@ -204,3 +204,40 @@ def test_sheep_random_walk_is_drawn_in_the_engine():
     assert abs(float(a.mean())) < 0.1 and 0.9 < float(a.std()) < 1.1
     o = _sheep_draws(oracle_engine, 0)
     assert (a - o).abs().max() < 1e-4
+
+
+def test_perlin_track_through_the_plugin_api():
+    """SURVEY 8(f)4 end to end: a user switches the Perlin relief on in `custom_cfg` (BarrierTrack_kwargs of the reference's config
+    tree), make_mqe_env builds the terrain with the reference's generator stream and the HIP engine walks on it"""
+    from mqe.envs.configs.go1_gate_config import Go1GateCfg
+    a = args_for("go1gate", 64)
+    old_kw, had = dict(Go1GateCfg.terrain.BarrierTrack_kwargs), hasattr(Go1GateCfg.terrain, "TerrainPerlin_kwargs")
+    old_tp = getattr(Go1GateCfg.terrain, "TerrainPerlin_kwargs", None)
+
+    def with_perlin(cfg):
+        cfg = custom_cfg(a)(cfg)
+        cfg.terrain.BarrierTrack_kwargs = dict(cfg.terrain.BarrierTrack_kwargs, add_perlin_noise=True, border_perlin_noise=True)
+        cfg.terrain.TerrainPerlin_kwargs = dict(zScale=0.05, frequency=10)
+        return cfg
+    try:
+        env, cfg = make_mqe_env("go1gate", a, with_perlin)
+        t = env.env.terrain
+        assert t.ground_height is not None and t.ground_z == 0.0 and bool(env.env.engine.desc.ground_height)
+        env.reset()
+        for _ in range(40):
+            obs, rew, done, info = env.step(torch.zeros(64, 2, 3, device="cuda"))
+        torch.cuda.synchronize()
+        z = env.env.root_states[:, 2]
+        assert torch.isfinite(env.env.root_states).all() and float(z.min()) > 0.15 and float(z.max()) < 0.6
+        feet = env.env.contact_forces.reshape(64, 2, 17, 3)[:, :, [4, 8, 12, 16], 2].sum(-1)
+        assert float((feet > 30).float().mean()) > 0.8          # standing on the bumps
+        env.close()
+    finally:
+        Go1GateCfg.terrain.BarrierTrack_kwargs = old_kw
+        if had:
+            Go1GateCfg.terrain.TerrainPerlin_kwargs = old_tp
+        else:
+            try:
+                del Go1GateCfg.terrain.TerrainPerlin_kwargs
+            except AttributeError:
+                pass

@@ -566,3 +566,43 @@ def test_out_of_range_observations_do_not_poison_the_policy():
     others = [i for i in range(2 * N) if i != 6]
     assert (outs["1"][others] - outs["0"][others]).abs().max() < 5e-5          # nobody else noticed
     assert outs["0"][6].abs().max() > 10 * outs["0"][others].abs().max()        # the exact path sees the full 2e4
+
+
+@pytest.mark.parametrize("task,N,zs", [("go1gate", 64, 0.06), ("go1football-defender", 16, 0.12)])
+def test_perlin_terrain_matches_oracle(task, N, zs):
+    """heightfield ground (Perlin relief as a second terrain map, no slab): contact lists from identical perturbed
+    states are identical incl. the tilted ground normals, a substep agrees, and a 20-step fused rollout stays within the bounds of
+    the flat scenes"""
+    from helpers import perlin_terrain
+    tc = perlin_terrain(task, zScale=zs)
+    d1, k1, _ = make_desc(task, N, terrain_cfg=tc)
+    d2, k2, _ = make_desc(task, N, terrain_cfg=tc)
+    assert d1.ground_z == 0.0 and bool(d1.ground_height)
+    eh, eo = hip_engine(d1, k1), oracle_engine(d2, k2)
+    _randomize(eh, eo, 5, drop=0.08)
+    tilted = 0
+    for env in (0, N // 2, N - 1):
+        mh, ch = eh.debug_dynamics(env, 0)
+        _, mo, co = eo.debug_dynamics(env, 0)
+        assert ch.shape == co.shape and (ch[:, :4] == co[:, :4]).all()
+        close(ch[:, 4:], co[:, 4:], atol=3e-5, what="contact separation / normal on the relief")
+        tilted += int(((co[:, 2] < 0) & (np.abs(co[:, 7]) < 0.999) & (co[:, 7] > 0.3)).sum())
+    assert tilted > 0, "the test must see ground contacts with tilted normals"
+    eh.simulate(); eo.simulate()
+    torch.cuda.synchronize()
+    close(eh.tensor(abi.T_ROOT_STATE)[..., :7], eo.tensor(abi.T_ROOT_STATE)[..., :7], atol=2e-5, what="root pose after a substep")
+    close(eh.tensor(abi.T_ROOT_STATE)[..., 7:], eo.tensor(abi.T_ROOT_STATE)[..., 7:], atol=2e-3, rtol=1e-3, what="root vel after a substep")
+    close(eh.tensor(abi.T_CONTACT_FORCE), eo.tensor(abi.T_CONTACT_FORCE), atol=0.5, rtol=2e-2, what="net contact force")
+    eh.reset_all(); eo.reset_all()
+    g = torch.Generator().manual_seed(13)
+    Aw = eo.tensor(abi.T_WRAPPER_OBS).shape[1]
+    dev, mism = [], 0
+    for t in range(20):
+        a = torch.rand(N, Aw, 3, generator=g) * 2 - 1
+        eh.step(a.cuda().contiguous()); eo.step(a)
+        torch.cuda.synchronize()
+        dev.append((eh.tensor(abi.T_ROOT_STATE).cpu()[..., :3] - eo.tensor(abi.T_ROOT_STATE)[..., :3]).abs().max(dim=-1).values.flatten())
+        mism += int((eh.tensor(abi.T_RESET_BUF).cpu() != eo.tensor(abi.T_RESET_BUF)).sum())
+    dev = torch.stack(dev)
+    assert torch.isfinite(dev).all() and float(dev[4].median()) < 1e-5 and float(dev[-1].median()) < 1e-4 and float(dev[-1].quantile(0.99)) < 5e-3
+    assert mism <= 1

@@ -296,3 +296,56 @@ def test_links_of_one_robot_collide():
     for _ in range(40):
         e2.simulate()
     assert abs(self_gap(dof2[0, :12, 0].numpy(), 0, 1) - self_gap(CROSSED_FRONT_FEET, 0, 1)) < 1e-4, "free fall keeps the pose"
+
+
+def test_perlin_relief_is_the_ground():
+    """on a Perlin track the walkable surface is the heightfield (no 2 cm slab).  A ball dropped onto it rides ON the
+    relief -- never through it, never gaining energy from it, hugging it once the bounces have died down on gentle bumps --
+    and robots spawned above it settle with their feet on it."""
+    from helpers import perlin_terrain
+    for zs, settle in ((0.12, False), (0.03, True)):
+        d, k, ctx = make_desc("go1football-defender", 3, terrain_cfg=perlin_terrain("go1football-defender", zScale=zs))
+        t = ctx["terrain"]
+        assert d.ground_z == 0.0 and t.ground_height is not None and t.ground_height.max() > 0.6 * zs
+        e = oracle_engine(d, k)
+        e.reset_all()
+        root = e.tensor(abi.T_ROOT_STATE)
+        A, r, hs = d.num_agents, d.npc_sphere_radius[0], d.horizontal_scale
+
+        def relief(xy):
+            fx, fy = xy[0] / hs - 0.5, xy[1] / hs - 0.5
+            ix, iy = int(fx), int(fy)
+            tx, ty = fx - ix, fy - iy
+            g = t.ground_height
+            return float((g[ix, iy] * (1 - ty) + g[ix, iy + 1] * ty) * (1 - tx) + (g[ix + 1, iy] * (1 - ty) + g[ix + 1, iy + 1] * ty) * tx)
+
+        def energy(env):
+            v = root[env, A, 7:10]
+            return 0.5 * d.npc_mass * float(v @ v) + 0.5 * d.npc_inertia * float(root[env, A, 10:13] @ root[env, A, 10:13]) + d.npc_mass * G * float(root[env, A, 2])
+        for env in range(3):
+            root[env, A, 0] += 0.5 + 0.37 * env                  # three different spots of the pitch, clear of the robots
+            root[env, A, 1] += 0.3 * env
+            root[env, A, 2] = relief(root[env, A, :2].tolist()) + r + 0.05
+            root[env, A, 7:13] = 0
+        e0 = [energy(env) for env in range(3)]
+        for step in range(800):
+            e.simulate()
+            if step % 25 == 0:
+                for env in range(3):
+                    gap = float(root[env, A, 2]) - r - relief(root[env, A, :2].tolist())
+                    assert gap > -0.006, (zs, env, step, gap)     # never through the surface (contact margin + first-order distance)
+        for env in range(3):
+            assert energy(env) < e0[env] + 1e-3, "contacts with the relief may only dissipate"
+            if settle:
+                gap = float(root[env, A, 2]) - r - relief(root[env, A, :2].tolist())
+                # gentle bumps: it rolls on (nothing but sliding friction dissipates on this surface), hugging the relief
+                assert gap < 0.006 and root[env, A, 7:10].abs().max() < 0.5, (env, gap, root[env, A, 7:10])
+    # robots dropped from their spawn height stand on the bumps
+    e2 = oracle_engine(*make_desc("go1gate", 2, terrain_cfg=perlin_terrain("go1gate", zScale=0.06))[:2])
+    e2.reset_all()
+    for step in range(60):
+        e2.step(torch.zeros(2, 2, 3))
+    r2 = e2.tensor(abi.T_ROOT_STATE)
+    assert torch.isfinite(r2).all() and ((r2[:, :, 2] > 0.2) & (r2[:, :, 2] < 0.45)).all(), r2[:, :, 2]
+    cf = e2.tensor(abi.T_CONTACT_FORCE).reshape(2, 2, 17, 3)
+    assert (cf[:, :, [4, 8, 12, 16], 2].sum(-1) > 40).all()                                    # feet carry (most of) the 113 N

@@ -64,3 +64,54 @@ def test_custom_cfg_plugin_point():
     out = custom_cfg(types.SimpleNamespace(num_envs=77, record_video=False))(cfg)
     assert out is cfg and cfg.env.num_envs == 77
     cfg.env.num_envs = old
+
+
+def perlin_cfgs():
+    """the terrain variants of tools/gen_golden.py::perlin_terrain_cfgs, on this package's config classes"""
+    base = task_cfg("go1gate").terrain
+    kw = dict(base.BarrierTrack_kwargs)
+
+    def variant(name, cfg_over, kw_over):
+        k2 = dict(kw); k2.update(kw_over)
+        return type(name, (base,), dict(cfg_over, BarrierTrack_kwargs=k2))
+    return {
+        "perlin_map": variant("PerlinMap", dict(num_rows=2, num_cols=2, border_size=1, TerrainPerlin_kwargs=dict(zScale=0.12, frequency=10)),
+                              dict(add_perlin_noise=True, border_perlin_noise=True)),
+        "perlin_curriculum": variant("PerlinCurriculum", dict(num_rows=2, num_cols=1, border_size=1, curriculum=True,
+                                                               TerrainPerlin_kwargs=dict(zScale=[0.05, 0.1], frequency=10)),
+                                     dict(add_perlin_noise=True, border_perlin_noise=True, curriculum_perlin=True, no_perlin_threshold=0.06,
+                                          border_height=0.3)),
+        "perlin_tracks_only": variant("PerlinTracksOnly", dict(num_rows=2, num_cols=1, border_size=1, TerrainPerlin_kwargs=dict(zScale=[0.05, 0.1], frequency=10)),
+                                      dict(add_perlin_noise=True, border_perlin_noise=False)),
+    }
+
+
+@pytest.mark.parametrize("name", ["perlin_map", "perlin_curriculum", "perlin_tracks_only"])
+def test_perlin_and_curriculum_tracks_match_reference(name):
+    """whole-map Perlin relief (barrier_track.py:372-393, perlin.py:33-72), curriculum rows (:421-439,635-638) and the
+    noise masks of the block painters (:449-459) reproduce the reference's heightfield, origins and gate deviations at
+    np.random.seed(0); the engine's view of it is consistent (walls in the SDF, relief in `ground_height`, no slab)"""
+    z = golden("terrain_" + name)
+    tcfg = perlin_cfgs()[name]
+    np.random.seed(0)
+    t = BarrierTrack(tcfg, 4, 2).build()
+    hf = t.heightfield_raw.astype(np.float64)
+    assert hf.shape == tuple(z["shape"])
+    np.testing.assert_allclose(hf[::3, ::3], z["sub"], atol=2e-4, rtol=1e-6)
+    np.testing.assert_allclose(hf.sum(1), z["row_sums"], rtol=1e-6, atol=1e-2)
+    assert abs(hf.sum() - float(z["total"])) <= 1e-6 * abs(float(z["total"])) + 1e-2
+    assert abs((hf ** 2).sum() - float(z["total_sq"])) <= 1e-6 * float(z["total_sq"]) + 1e-2
+    assert np.array_equal(t.env_origins, z["env_origins"]) and np.array_equal(t.agent_origins, z["agent_origins"])
+    assert np.array_equal(t.env_info["gate_deviation"], z["gate_deviation"])
+    vs = tcfg.vertical_scale
+    if name == "perlin_tracks_only":
+        assert t.ground_height is None and t.ground_z == pytest.approx(0.02)
+        assert set(np.unique(hf)) == {0.0, t.wall_height / vs}
+    else:
+        assert t.ground_z == 0.0 and t.ground_height.shape == hf.shape
+        free = ~t.wall
+        # off the walls the heightfield IS the relief wherever a painter's noise mask kept it; nowhere is it anything else
+        keep = free & (np.abs(hf - t.ground_height / vs) < 1e-3)
+        assert keep.sum() > 0.5 * free.sum() and np.all((hf[free & ~keep] == 0.0))
+        assert 0.0 <= t.ground_height.min() and t.ground_height.max() < 0.2          # zScale 0.12 (+ one quarter-weight octave)
+        assert ((t.wall_sdf < 0) == t.wall).all()

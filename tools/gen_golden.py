@@ -902,6 +902,39 @@ def rle_rows(hf):
     return np.array(runs, np.float32).reshape(-1, 4)
 
 
+def perlin_terrain_cfgs():
+    """Terrain configs that switch on what every shipped task leaves off: the whole-map Perlin relief and
+    curriculum rows.  Returns {name: (terrain cfg class, num_agents)}; shared with tests/test_terrain_configs.py by name."""
+    from mqe.envs.configs.go1_gate_config import Go1GateCfg
+    base = Go1GateCfg.terrain
+    kw = dict(base.BarrierTrack_kwargs)
+
+    def variant(name, cfg_over, kw_over):
+        k2 = dict(kw); k2.update(kw_over)
+        return type(name, (base,), dict(cfg_over, BarrierTrack_kwargs=k2))
+    out = {}
+    out["perlin_map"] = (variant("PerlinMap", dict(num_rows=2, num_cols=2, border_size=1, TerrainPerlin_kwargs=dict(zScale=0.12, frequency=10)),
+                                 dict(add_perlin_noise=True, border_perlin_noise=True)), 2)
+    out["perlin_curriculum"] = (variant("PerlinCurriculum", dict(num_rows=2, num_cols=1, border_size=1, curriculum=True,
+                                                                  TerrainPerlin_kwargs=dict(zScale=[0.05, 0.1], frequency=10)),
+                                        dict(add_perlin_noise=True, border_perlin_noise=True, curriculum_perlin=True, no_perlin_threshold=0.06,
+                                             border_height=0.3)), 2)
+    out["perlin_tracks_only"] = (variant("PerlinTracksOnly", dict(num_rows=2, num_cols=1, border_size=1, TerrainPerlin_kwargs=dict(zScale=[0.05, 0.1], frequency=10)),
+                                         dict(add_perlin_noise=True, border_perlin_noise=False)), 2)
+    return out
+
+
+def gen_perlin_terrain():
+    """BarrierTrack with Perlin noise / curriculum at np.random.seed(0): every third heightfield sample + whole-field sums, origins,
+    gate deviations (barrier_track.py:372-393,421-459,635-638; perlin.py:33-72)"""
+    for name, (tcfg, A) in perlin_terrain_cfgs().items():
+        t = barrier_track_for(types.SimpleNamespace(terrain=tcfg, env=types.SimpleNamespace(num_agents=A)), 4)
+        hf = np.asarray(t.heightfield_raw, np.float64)
+        save("terrain_" + name, shape=np.array(hf.shape), sub=hf[::3, ::3].astype(np.float32), total=np.float64(hf.sum()), total_sq=np.float64((hf ** 2).sum()),
+             row_sums=hf.sum(1), env_origins=t.env_origins, agent_origins=t.agent_origins,
+             gate_deviation=np.asarray(t.env_info["gate_deviation"]) if t.env_info else np.zeros(0))
+
+
 def gen_terrain_and_configs():
     cfgd = {}
     for task in ("go1gate", "go1sheep-easy", "go1sheep-hard", "go1seesaw", "go1football-defender", "go1football-1vs1", "go1football-2vs2", "go1pushbox", "go1revolvingdoor", "go1bridge", "go1wrestling", "go1tug"):
@@ -1019,6 +1052,8 @@ def main():
         gen_tug_wrapper()
     if want("terrain"):
         gen_terrain_and_configs()
+    if want("terrain_perlin"):
+        gen_perlin_terrain()
     if want("adapter"):
         gen_adapter()
 
