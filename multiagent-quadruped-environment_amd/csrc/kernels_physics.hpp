@@ -647,8 +647,10 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   // wall / platform / column -- because a lane's slot = contacts of earlier groups (capped) + its rank in its group.
   const int rpp = (2 * nsr <= 64) ? 2 : 1;
   const int n_rpass = (A + rpp - 1) / rpp;
-  const bool npc_fast = m->npc_n_spheres == 1;
-  const int n_pass = n_rpass + (PD > 0 ? (npc_fast ? 1 : PD) : 0);
+  const int nsn = m->npc_n_spheres;
+  const bool npc_one = PD * nsn <= 64;                     // every sphere of every free NPC in ONE pass, lane = (npc, sphere): 9 sheep x 2
+  const int n_pass = n_rpass + (PD > 0 ? (npc_one ? 1 : PD) : 0);
+  const unsigned long long mns = (nsn < 64) ? ((1ull << nsn) - 1ull) : ~0ull;
   for (int pass = 0; pass < n_pass; pass++) {
     int act = -1, sidx = 0, s = nsph, sub = 0;
     unsigned long long gm = ~0ull;                         // lanes of my group (= my actor)
@@ -660,9 +662,10 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       const int l = lane - sub * nsr, r = pass * rpp + sub;
       if (l < nsr && r < A) { act = r; sidx = l; s = r * nsr + l; }
       gm = sub ? (m0 << nsr) : m0;
-    } else if (npc_fast) {
-      if (lane < PD) { act = A + lane; s = A * nsr + lane; }
-      gm = 1ull << lane;
+    } else if (npc_one) {
+      const int pl = lane < PD * nsn ? lane / nsn : 0;
+      if (lane < PD * nsn) { act = A + pl; sidx = lane - pl * nsn; s = A * nsr + lane; }
+      gm = mns << (pl * nsn);
     } else {
       const int p = pass - n_rpass;
       if (lane < m->npc_n_spheres) { act = A + p; sidx = lane; s = A * nsr + p * m->npc_n_spheres + lane; }
@@ -738,7 +741,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     const int pre = __popcll(bg & gl) + __popcll(bw2 & gl) + __popcll(bb2 & gl) + __popcll(bc2 & gl);   // rank in my actor
     int tot0 = __popcll(bg & m0) + __popcll(bw2 & m0) + __popcll(bb2 & m0) + __popcll(bc2 & m0);          // first robot of the pass
     int tot1 = 0;
-    if (tot0 > cap) { tot0 = cap; if (rob || !npc_fast) ovf = 1; }      // (the single-sphere NPC pass recounts below: its cap never binds)
+    if (tot0 > cap) { tot0 = cap; if (rob || !npc_one) ovf = 1; }       // (the all-NPC pass recounts per actor below)
     int base = nc;
     if (rob) {
       if (rpp == 2) {
@@ -747,9 +750,16 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
         if (tot1 > cap) { tot1 = cap; ovf = 1; }
       }
       base = nc + (sub ? tot0 : 0);
-    } else if (npc_fast) {                 // one sphere per actor: <= 2 contacts each, the cap never binds
-      base = nc + __popcll(bg & lower) + __popcll(bw2 & lower);
-      tot0 = __popcll(bg) + __popcll(bw2);
+    } else if (npc_one) {                  // per actor: its (capped) count; a lane's base = the counts of the actors before its own
+      const int myp = act >= 0 ? act - A : PD;
+      tot0 = 0;
+      for (int q = 0; q < PD; q++) {
+        const unsigned long long mq = mns << (q * nsn);
+        int tq = __popcll(bg & mq) + __popcll(bw2 & mq);
+        if (tq > cap) { tq = cap; ovf = 1; }
+        if (q < myp) base += tq;
+        tot0 += tq;
+      }
     }
     if (gflag) {
       const int slot = base + pre;
@@ -812,13 +822,35 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   // ---- sphere-sphere contacts between different actors (a < b; outer loop over b's spheres, lanes = a's spheres) -------
   {
     const int nact = A + PD;
+    // broad phase of ALL actor pairs at once, lane = pair (a < b, row-major): actors farther apart than 1.2 m (robot vs the box: 1.8 m)
+    // cannot touch.  The 55 pairs of the 2 + 9 actors of go1sheep-hard used to cost 55 sequential LDS round trips per substep.
+    unsigned long long near0 = 0ull, near1 = 0ull;
+    {
+      const int npa = (nact * (nact - 1)) / 2;
+      for (int t0 = 0; t0 < npa; t0 += 64) {
+        const int t = t0 + lane;
+        bool nr = false;
+        if (t < npa) {
+          int a = 0, rem = t;
+          while (rem >= nact - 1 - a) { rem -= nact - 1 - a; a++; }
+          const int b = a + 1 + rem;
+          const V3 pa = ld3(lds + L.body + (a < A ? a * MQE_NBODY : A * MQE_NBODY + (a - A)) * BODY_STRIDE + B_P);
+          const V3 pb = ld3(lds + L.body + (b < A ? b * MQE_NBODY : A * MQE_NBODY + (b - A)) * BODY_STRIDE + B_P);
+          const V3 dd = pa - pb;
+          if (shp.has_box && b >= A) nr = a < A && !(dot(dd, dd) > 1.8f * 1.8f);
+          else nr = !(dot(dd, dd) > 1.2f * 1.2f);
+        }
+        const unsigned long long bm = __ballot(nr);
+        if (t0 == 0) near0 = bm; else near1 = bm;
+      }
+    }
+    int tp = -1;
     for (int a = 0; a < nact; a++)
       for (int b = a + 1; b < nact; b++) {
-        const V3 pa = ld3(lds + L.body + (a < A ? a * MQE_NBODY : A * MQE_NBODY + (a - A)) * BODY_STRIDE + B_P);
+        tp++;
+        if (!(((tp < 64 ? near0 >> tp : near1 >> (tp - 64)) & 1ull))) continue;          // wave-uniform
         const V3 pb = ld3(lds + L.body + (b < A ? b * MQE_NBODY : A * MQE_NBODY + (b - A)) * BODY_STRIDE + B_P);
-        const V3 dd = pa - pb;
         if (shp.has_box && b >= A) {                           // robot spheres vs the oriented box (NPC body record = its pose)
-          if (a >= A || dot(dd, dd) > 1.8f * 1.8f) continue;
           const float* brec = lds + L.body + (A * MQE_NBODY + (b - A)) * BODY_STRIDE;
           bool hit = false; float sd = 0; V3 n = v3(0, 0, 1), c = v3(0, 0, 0); float ra = 0;
           if (lane < nsr) {
@@ -838,7 +870,6 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
           if (nc > pair_lim) { nc = pair_lim; ovf = 1; }
           continue;
         }
-        if (dot(dd, dd) > 1.2f * 1.2f) continue;              // wave-uniform broad phase
         const int na = a < A ? nsr : m->npc_n_spheres, nb = b < A ? nsr : m->npc_n_spheres;
         const int oa = a < A ? a * nsr : A * nsr + (a - A) * m->npc_n_spheres;
         const int ob = b < A ? b * nsr : A * nsr + (b - A) * m->npc_n_spheres;
@@ -940,7 +971,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   const bool is_con = lane < nc;
   float cu0 = 0, cu1 = 0, cu2 = 0, cl0 = 0, cl1 = 0, cl2 = 0, cbias = 0;
   float ik00 = 0, ik11 = 0, ik22 = 0, ck10 = 0, ck20 = 0, ck21 = 0;
-  int myA = -2, myB = -2;
+  int myA = -2, myB = -2, myLegA = -1, myLegB = -1;      // actors of my contact's sides; leg of a robot side (-1: base link / not a robot)
   float mu = m->friction;
   if (is_con) {
     float* cr = lds + L.con + lane * CON_STRIDE;
@@ -1063,6 +1094,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
         sr[q * 4 + 2] = make_float4(V[q][2], V[q][3], V[q][4], V[q][5]);
         sr[q * 4 + 3] = make_float4(Z[q][0], Z[q][1], Z[q][2], __int_as_float(legi));
       }
+      if (side == 0) myLegA = legi; else myLegB = legi;
     }
   }
   __syncthreads();
@@ -1241,13 +1273,13 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       const float l0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cl0), c));
       const float l1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cl1), c));
       const float l2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cl2), c));
-      if (a2 == dact) {
+      if (a2 == dact && (!jointd || __builtin_amdgcn_readlane(myLegA, c) == dleg)) {
         const float* sr = lds + L.side + c * SIDE_STRIDE;
-        if (!jointd || __float_as_int(sr[SIDE_INFO]) == dleg) acc += sr[off] * l0 + sr[SIDE_ROW + off] * l1 + sr[2 * SIDE_ROW + off] * l2;
+        acc += sr[off] * l0 + sr[SIDE_ROW + off] * l1 + sr[2 * SIDE_ROW + off] * l2;
       }
-      if (b2 == dact) {                               // both for a contact between two links of this actor
+      if (b2 == dact && (!jointd || __builtin_amdgcn_readlane(myLegB, c) == dleg)) {      // both for a contact between two links of this actor
         const float* sr = lds + L.side + (maxc + (c - nc_terr)) * SIDE_STRIDE;
-        if (!jointd || __float_as_int(sr[SIDE_INFO]) == dleg) acc += sr[off] * l0 + sr[SIDE_ROW + off] * l1 + sr[2 * SIDE_ROW + off] * l2;
+        acc += sr[off] * l0 + sr[SIDE_ROW + off] * l1 + sr[2 * SIDE_ROW + off] * l2;
       }
     }
     accv[d] = acc;
