@@ -935,6 +935,45 @@ def gen_perlin_terrain():
              gate_deviation=np.asarray(t.env_info["gate_deviation"]) if t.env_info else np.zeros(0))
 
 
+def gen_urdf_facts():
+    """go1.urdf read with nothing but xml.etree -- every <inertial>, <collision> and <joint> as plain numbers -- so that the product's
+    own URDF reader (mqe/utils/urdf_model.py, which feeds BOTH engines) is checked against an independent reading
+    (tests/test_models_oracle.py recombines the fixed-joint subtrees itself)."""
+    import xml.etree.ElementTree as ET
+
+    def nums(t, d):
+        return [float(x) for x in (t if t is not None else d).split()]
+    root = ET.parse(os.path.join(REF, "resources/robots/go1/urdf/go1.urdf")).getroot()
+    links, joints = {}, {}
+    for l in root.findall("link"):
+        e = {"collisions": []}
+        ine = l.find("inertial")
+        if ine is not None:
+            o = ine.find("origin")
+            e["mass"] = float(ine.find("mass").get("value"))
+            e["com_xyz"] = nums(o.get("xyz") if o is not None else None, "0 0 0")
+            e["com_rpy"] = nums(o.get("rpy") if o is not None else None, "0 0 0")
+            i = ine.find("inertia")
+            e["inertia"] = [float(i.get(k)) for k in ("ixx", "ixy", "ixz", "iyy", "iyz", "izz")]
+        for c in l.findall("collision"):
+            o, g = c.find("origin"), c.find("geometry")
+            k = list(g)[0]
+            e["collisions"].append({"type": k.tag, "params": {a: nums(v, "0") for a, v in k.attrib.items() if a != "filename"},
+                                    "xyz": nums(o.get("xyz") if o is not None else None, "0 0 0"),
+                                    "rpy": nums(o.get("rpy") if o is not None else None, "0 0 0")})
+        links[l.get("name")] = e
+    for j in root.findall("joint"):
+        o, ax, lim = j.find("origin"), j.find("axis"), j.find("limit")
+        joints[j.get("name")] = {"type": j.get("type"), "parent": j.find("parent").get("link"), "child": j.find("child").get("link"),
+                                 "xyz": nums(o.get("xyz") if o is not None else None, "0 0 0"), "rpy": nums(o.get("rpy") if o is not None else None, "0 0 0"),
+                                 "axis": nums(ax.get("xyz") if ax is not None else None, "1 0 0"),
+                                 "limit": {k: float(v) for k, v in lim.attrib.items()} if lim is not None else {},
+                                 "dont_collapse": j.get("dont_collapse") == "true"}
+    with open(os.path.join(GOLD, "go1_urdf_facts.json"), "w") as f:
+        json.dump({"links": links, "joints": joints}, f, indent=0, sort_keys=True)
+    print("wrote go1_urdf_facts.json", len(links), "links", len(joints), "joints")
+
+
 def gen_terrain_and_configs():
     cfgd = {}
     for task in ("go1gate", "go1sheep-easy", "go1sheep-hard", "go1seesaw", "go1football-defender", "go1football-1vs1", "go1football-2vs2", "go1pushbox", "go1revolvingdoor", "go1bridge", "go1wrestling", "go1tug"):
@@ -1054,6 +1093,8 @@ def main():
         gen_terrain_and_configs()
     if want("terrain_perlin"):
         gen_perlin_terrain()
+    if want("urdf_facts"):
+        gen_urdf_facts()
     if want("adapter"):
         gen_adapter()
 
