@@ -100,26 +100,26 @@ __device__ __forceinline__ float wave_sum(float x) {
 }
 
 #define BODY_STRIDE 32
-// leg block record in 16 B words (lives to the end of the substep): Mll^-1 (sym6) at 0, G = Mbl Mll^-1 (6 x 3) at 8; the Schur
-// term C = G Mbl^T (upper triangle, 21 values, 6 words) is scratch of its own (LEGC_STRIDE)
-#define LEG_STRIDE 28
+// leg block record in 16 B words (lives to the end of the substep): Mll^-1 (sym6: 00,11,22,10,20,21) at 0, its Cholesky factor
+// Lm (Mll^-1 = Lm Lm^T; l00,l10,l11,l20,l21,l22) at 6, G = Mbl Mll^-1 (6 x 3) at 12; the Schur term C = G Mbl^T (upper
+// triangle, 21 values, 6 words) is scratch of its own (LEGC_STRIDE)
+#define LEG_STRIDE 32
 #define LEG_MI 0
-#define LEG_G 8
+#define LEG_LM 6
+#define LEG_G 12
 #define LEGC_STRIDE 24
 #define CON_STRIDE 24
-// contact side record: three rows (normal, tangent 1, tangent 2) of four 16 B words:
-//   [ W (6) | V (6) | Z (3) | info ]   W = J_base - J_leg G_leg^T  (the Jacobian row reduced onto the 6 base coordinates)
-//                                      V = W S^-1                   (S = Schur complement of the base block)
-//                                      Z = J_leg                    (the <= 3 joints of the chain to the touching link)
-//   info of row 0 = leg index of a robot side whose link is not the base, else -1.  With these a 3 x 3 coupling block is
-//   K = V W'^T (+ Z Mll^-1 Z'^T for two sides on the same leg) and M^-1 J^T lambda = [V^T lambda ; Mll^-1 Z^T lambda - G^T V^T lambda]:
-//   neither the 18 x 18 inverse nor M^-1 J^T (3 x 18 per side) is ever formed.  Free bodies / the 1-dof link: W = J, V = W M^-1, Z = 0.
-#define SIDE_STRIDE 48
-#define SIDE_ROW 16
-#define SIDE_W 0
-#define SIDE_V 6
-#define SIDE_Z 12
-#define SIDE_INFO 15
+// Contact side record (7 words): Phi = the side's Jacobian in coordinates in which the actor's inverse mass matrix is the
+// identity.  Robot: M^-1 = [S^-1, -S^-1 G; -G^T S^-1, Mll^-1 + G^T S^-1 G] = T T^T with T = [F 0; -G^T F, Lm] (S^-1 = F F^T, F upper
+// triangular; Mll^-1 = Lm Lm^T per leg), so Phi = J T = [ U | Z' ],  U = (J_base - J_leg G^T) F (3 x 6),  Z' = J_leg Lm (3 x 3, the
+// <= 3 joints of the chain to the touching link).  Free body / 1-dof link: U = J M^-1/2, no Z'.  With these
+//   K(c, c') = Phi_c Phi_c'^T   and   M^-1 J^T lambda = T Phi^T lambda,
+// so the projected Gauss-Seidel sweep runs on  w = sum_c Phi_c^T lambda_c  (one float per generalized coordinate, LDS) and needs
+// neither the coupling blocks K (5 kB on go1gate, 21 kB on go1sheep-hard) nor M^-1 J^T, and  dv = T w  falls out at the end.
+//   floats 0-17: U[q][m] at q * 6 + m;  18-26: Z'[q][i] at 18 + q * 3 + i;  27: (leg + 1) | columns << 4
+#define SIDE_STRIDE 28
+#define SIDE_Z 18
+#define SIDE_INFO 27
 // link record: rotation (9), origin (3), joint axis (3) = four 16 B words, what the collision and Jacobian phases read back; the
 // base records also carry angular velocity, origin velocity and the two bias accelerations for their hips (the other links
 // hand those to their children through registers)
@@ -146,17 +146,15 @@ __host__ __device__ inline int mqe_maxc(int A, int P, int cap_npc) { int v = 8 *
 // NPCs keep m->cap_npc one-sided contacts each (2; a box resting on a face 4): per-actor caps so that no actor starves the ones after it
 
 struct PhysLds {   // float offsets into dynamic LDS
-  int root, dof, tau, body, rhs, acc, acth, fcol, leg, legc, basei, sinv, sph, con, side, kk, total;
+  int root, dof, tau, body, rhs, acc, acth, fcol, leg, legc, basei, sinv, sph, con, side, total;
 };
 __host__ __device__ inline int mqe_maxpair(int maxc) { return maxc / 2; }    // two-actor contacts kept per env
 __host__ __device__ inline PhysLds phys_lds_layout(int A, int P, int ND, int nbody, int ndof, int nsph, int maxc) {
-  // Regions that live to the end of the substep first; then an ARENA shared by (a) everything that is dead once the
-  // contact side records exist (link records, CRBA/Schur scratch, collision spheres) and (b) the coupling blocks, which are
-  // only written after (a) has been consumed.  Inside (a) the spheres overlay the CRBA/Schur scratch (dead once the Schur
-  // inverse exists).  Contact sides are slot-allocated: side A of contact c -> slot c, side B of the k-th two-actor contact
-  // -> slot maxc + k (terrain contacts have no B).  The mass-matrix inverse is kept in its factored form only (per leg
-  // Mll^-1 and G, per robot S^-1: 184 floats per robot instead of 324) and the contact sides in the reduced form of
-  // SIDE_STRIDE: go1gate needs 12.5 KiB per wave = 12 waves per CU (160 KiB LDS), 3 per SIMD.
+  // Regions that live to the end of the substep first; then the scratch of the dynamics phases (link records, CRBA / Schur
+  // scratch; the collision spheres overlay the latter), dead once the contact side records exist.  Contact sides are
+  // slot-allocated: side A of contact c -> slot c, side B of the k-th two-actor contact -> slot maxc + k (terrain contacts have no
+  // B).  The mass-matrix inverse is kept in factored form only (per leg Mll^-1, its Cholesky factor and G; per robot S^-1 and its
+  // factor F) and the contact problem in the Phi form of SIDE_STRIDE -- no coupling blocks: go1gate 9.9 KiB per wave (was 19.7).
   PhysLds L; int o = 0;
   L.root = o; o += (A + P) * 13;
   L.dof = o; o += ND * 2;
@@ -166,11 +164,9 @@ __host__ __device__ inline PhysLds phys_lds_layout(int A, int P, int ND, int nbo
   L.acc = o; o += (ndof + 3) & ~3;                          // one scratch float per dof: reduced right-hand sides, J^T lambda sums
   L.acth = o; o += 4 * 12 * A;                              // k_substeps: actuator-net history of every joint (two past errors, two past velocities)
   L.leg = o; o += A * 4 * LEG_STRIDE;
-  L.sinv = o; o += A * 36;
+  L.sinv = o; o += A * 72;                                  // per robot: S^-1 (36), then F with S^-1 = F F^T (upper triangular, stored 6 x 6)
   L.con = o; o += maxc * CON_STRIDE;
-  const int nslot = maxc + mqe_maxpair(maxc);
-  L.side = o; o += nslot * SIDE_STRIDE;
-  const int arena = o;
+  L.side = o; o += mqe_maxpair(maxc) * SIDE_STRIDE;         // side B of the two-actor contacts only (side A lives in registers)
   L.body = o; o += nbody * BODY_STRIDE;
   const int scratch = o;
   L.fcol = o; o += A * 64;                                  // the four hip composites of every robot on their way to the base lane
@@ -178,15 +174,13 @@ __host__ __device__ inline PhysLds phys_lds_layout(int A, int P, int ND, int nbo
   L.basei = o; o += A * 12;
   L.sph = scratch;
   if (scratch + nsph * 4 > o) o = scratch + nsph * 4;
-  L.kk = arena;                                    // lower-triangular 3x3 blocks, block (c, c2 <= c) at (c(c+1)/2 + c2) * 9
-  const int kk_end = arena + (maxc * (maxc + 1) / 2) * 9;
-  if (kk_end > o) o = kk_end;
   L.total = o;
   return L;
 }
 
-struct PhysDebug { float* minv; int* nc; float* contacts; int robot; long long* times; };
-#define TSTAMP(i) do { if (dbg.times != nullptr && lane == 0) dbg.times[i] = clock64(); } while (0)
+struct PhysDebug { float* minv; int* nc; float* contacts; int robot; long long* times; int stop_after; };
+// phase tap: shader clock of lane 0 and, for per-phase counter runs (tools/phase_counters.py), an early exit of the whole wavefront
+#define TSTAMP(i) do { if (dbg.times != nullptr && lane == 0) dbg.times[i] = clock64(); if (dbg.stop_after == (i)) return; } while (0)
 
 // flags of one physics substep executed by a wavefront
 enum { PS_LOAD_STATE = 1, PS_LOAD_TAU = 2, PS_STORE_STATE = 4, PS_WRITE_CF = 8 };
@@ -449,10 +443,14 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
         for (int n = mm; n < 6; n++) Cv[q++] = G[mm * 3] * fc[n] + G[mm * 3 + 1] * fc[6 + n] + G[mm * 3 + 2] * fc[12 + n];
       Cv[21] = 0.0f; Cv[22] = 0.0f; Cv[23] = 0.0f;
       float4* M4 = reinterpret_cast<float4*>(Ml);
-      M4[0] = make_float4(Mi[0], Mi[4], Mi[8], Mi[1]); M4[1] = make_float4(Mi[2], Mi[5], 0.0f, 0.0f);   // sym6: 00,11,22,01,02,12
+      // Cholesky factor of Mll^-1 (3 x 3, SPD): Mll^-1 = Lm Lm^T
+      const float l00 = sqrtf(Mi[0]), il00 = 1.0f / l00, l10 = Mi[1] * il00, l20 = Mi[2] * il00;
+      const float l11 = sqrtf(Mi[4] - l10 * l10), l21 = (Mi[5] - l20 * l10) / l11, l22 = sqrtf(Mi[8] - l20 * l20 - l21 * l21);
+      M4[0] = make_float4(Mi[0], Mi[4], Mi[8], Mi[1]); M4[1] = make_float4(Mi[2], Mi[5], l00, l10);   // sym6: 00,11,22,01,02,12; then Lm
+      M4[2] = make_float4(l11, l20, l21, l22);
 #pragma unroll
-      for (int k = 0; k < 4; k++) M4[2 + k] = make_float4(G[4 * k], G[4 * k + 1], G[4 * k + 2], G[4 * k + 3]);
-      M4[6] = make_float4(G[16], G[17], 0.0f, 0.0f);
+      for (int k = 0; k < 4; k++) M4[3 + k] = make_float4(G[4 * k], G[4 * k + 1], G[4 * k + 2], G[4 * k + 3]);
+      M4[7] = make_float4(G[16], G[17], 0.0f, 0.0f);
       float4* C4w = reinterpret_cast<float4*>(lds + L.legc + (br * 4 + leg) * LEGC_STRIDE);
 #pragma unroll
       for (int k = 0; k < 6; k++) C4w[k] = make_float4(Cv[4 * k], Cv[4 * k + 1], Cv[4 * k + 2], Cv[4 * k + 3]);
@@ -507,6 +505,10 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       for (int k = 0; k < i; k++) v -= Lc[i][k] * x[k];
       x[i] = v / Lc[i][i];
     }
+    float* Si = lds + L.sinv + r * 72;
+    // after the forward substitution x = Lc^-1 e_col, i.e. row `col` of F = Lc^-T (S^-1 = Lc^-T Lc^-1 = F F^T): zeros left of the diagonal
+#pragma unroll
+    for (int i = 0; i < 6; i++) Si[36 + col * 6 + i] = x[i];
 #pragma unroll
     for (int i = 5; i >= 0; i--) {
       float v = x[i];
@@ -514,7 +516,6 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       for (int k = i + 1; k < 6; k++) v -= Lc[k][i] * x[k];
       x[i] = v / Lc[i][i];
     }
-    float* Si = lds + L.sinv + r * 36;
     for (int i = 0; i < 6; i++) Si[i * 6 + col] = x[i];
   }
   __syncthreads();
@@ -528,7 +529,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   };
   // row k of one robot's M^-1, element `e` (both 0..17): only for the joint-limit impulses and the debug tap
   auto minv_elem = [&](int r, int k, int e) -> float {
-    const float* Si = lds + L.sinv + r * 36;
+    const float* Si = lds + L.sinv + r * 72;
     const float* lg = lds + L.leg + r * 4 * LEG_STRIDE;
     float y[6];                                                     // k < 6: row k of S^-1; else S^-1 G_L[:, t]
     if (k < 6) {
@@ -570,7 +571,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   __syncthreads();
   if (lane < A * 6) {                       // stage 2: x_b = S^-1 t
     const int r = lane / 6, mm = lane - r * 6;
-    const float* Si = lds + L.sinv + r * 36 + mm * 6;
+    const float* Si = lds + L.sinv + r * 72 + mm * 6;
     const float* t = accv + r * MQE_RD + 6;
     accv[r * MQE_RD + mm] = Si[0] * t[0] + Si[1] * t[1] + Si[2] * t[2] + Si[3] * t[3] + Si[4] * t[4] + Si[5] * t[5];
   }
@@ -969,10 +970,15 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   if (lane + 64 < ndof) Vm[lane + 64] = vs1;
   __syncthreads();
   const bool is_con = lane < nc;
-  float cu0 = 0, cu1 = 0, cu2 = 0, cl0 = 0, cl1 = 0, cl2 = 0, cbias = 0;
-  float ik00 = 0, ik11 = 0, ik22 = 0, ck10 = 0, ck20 = 0, ck21 = 0;
-  int myA = -2, myB = -2, myLegA = -1, myLegB = -1;      // actors of my contact's sides; leg of a robot side (-1: base link / not a robot)
+  float us0 = 0, us1 = 0, us2 = 0, cl0 = 0, cl1 = 0, cl2 = 0, cbias = 0;      // relative velocity of the unconstrained motion, impulse, bias
+  float d00 = 0, d10 = 0, d11 = 0, d20 = 0, d21 = 0, d22 = 0;                // my contact's own 3 x 3 block K(c, c) = sum over sides Phi Phi^T
+  int myA = -2, myB = -2;                                                   // actors of my contact's sides
+  int wA = 0, wB = 0, infoA = 0, infoB = 0;                                  // first generalized coordinate of each side's actor; (leg + 1) | columns << 4
   float mu = m->friction;
+  float fA[27];                                                             // Phi of my contact's side A (U 18, Z' 9): registers for the whole sweep
+#pragma unroll
+  for (int i = 0; i < 27; i++) fA[i] = 0.0f;
+  for (int i = lane; i < ((ndof + 3) & ~3); i += 64) accv[i] = 0.0f;          // w = sum_c Phi_c^T lambda_c starts at zero (no warm start)
   if (is_con) {
     float* cr = lds + L.con + lane * CON_STRIDE;
     const float4 w0 = reinterpret_cast<const float4*>(cr)[0], w1 = reinterpret_cast<const float4*>(cr)[1], w2 = reinterpret_cast<const float4*>(cr)[2];
@@ -992,12 +998,14 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       const int act = side == 0 ? myA : myB, body = side == 0 ? bodyA : bodyB;
       const float sg = side == 0 ? 1.0f : -1.0f;
       if (act < 0) continue;
-      const int slot = side == 0 ? lane : maxc + (lane - nc_terr);
-      float4* sr = reinterpret_cast<float4*>(lds + L.side + slot * SIDE_STRIDE);
-      float W[3][6], Z[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, V[3][6];
-      int legi = -1;
+      float W[3][6], Z[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+      float f[SIDE_STRIDE];                                   // the record: U, Z', info
+#pragma unroll
+      for (int i = 0; i < SIDE_STRIDE; i++) f[i] = 0.0f;
+      int legi = -1, ncol = 6, wbase = 0;
       const V3 dirs[3] = {n, t1, t2};
       if (act < A) {
+        wbase = act * MQE_RD;
         const float* brec = lds + L.body + act * MQE_NBODY * BODY_STRIDE;
         const V3 r0 = p - ld3(brec + B_P);
         const float* vb = Vm + act * MQE_RD;
@@ -1028,50 +1036,55 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
             for (int mm = 0; mm < 6; mm++) acc += W[q][mm] * vb[mm];
             uq[q] = acc + Z[q][0] * vl[0] + Z[q][1] * vl[1] + Z[q][2] * vl[2];
           }
-          cu0 += uq[0]; cu1 += uq[1]; cu2 += uq[2];
+          us0 += uq[0]; us1 += uq[1]; us2 += uq[2];
         }
-        if (dep > 0) {                       // reduce onto the base coordinates: W = J_b - J_l G^T (five 16 B loads of G)
+        if (dep > 0) {                       // reduce onto the base coordinates: W = J_b - J_l G^T (five 16 B loads of G), Z' = J_l Lm
           legi = leg;
-          float G[20];
-          const float4* G4 = reinterpret_cast<const float4*>(lds + L.leg + (act * 4 + leg) * LEG_STRIDE + LEG_G);
+          const float* lrec = lds + L.leg + (act * 4 + leg) * LEG_STRIDE;
 #pragma unroll
-          for (int w = 0; w < 5; w++) { const float4 t = G4[w]; G[4 * w] = t.x; G[4 * w + 1] = t.y; G[4 * w + 2] = t.z; G[4 * w + 3] = t.w; }
+          for (int mm = 0; mm < 6; mm++) {   // G streamed row by row (3 floats): few registers live at a time
+            const float g0 = lrec[LEG_G + mm * 3], g1 = lrec[LEG_G + mm * 3 + 1], g2 = lrec[LEG_G + mm * 3 + 2];
 #pragma unroll
-          for (int q = 0; q < 3; q++)
+            for (int q = 0; q < 3; q++) W[q][mm] -= Z[q][0] * g0 + Z[q][1] * g1 + Z[q][2] * g2;
+          }
+          const float4 la = reinterpret_cast<const float4*>(lrec)[1], lb = reinterpret_cast<const float4*>(lrec)[2];   // .., l00, l10 | l11, l20, l21, l22
 #pragma unroll
-            for (int mm = 0; mm < 6; mm++) W[q][mm] -= Z[q][0] * G[mm * 3] + Z[q][1] * G[mm * 3 + 1] + Z[q][2] * G[mm * 3 + 2];
+          for (int q = 0; q < 3; q++) {
+            f[SIDE_Z + q * 3 + 0] = Z[q][0] * la.z + Z[q][1] * la.w + Z[q][2] * lb.y;
+            f[SIDE_Z + q * 3 + 1] = Z[q][1] * lb.x + Z[q][2] * lb.z;
+            f[SIDE_Z + q * 3 + 2] = Z[q][2] * lb.w;
+          }
         }
-        {                                    // V = W S^-1 (S^-1 symmetric: nine 16 B loads)
-          float Si[36];
-          const float4* S4 = reinterpret_cast<const float4*>(lds + L.sinv + act * 36);
+        {                                    // U = W F (F upper triangular: nine 16 B loads)
+          const float* Fm = lds + L.sinv + act * 72 + 36;
 #pragma unroll
-          for (int w = 0; w < 9; w++) { const float4 t = S4[w]; Si[4 * w] = t.x; Si[4 * w + 1] = t.y; Si[4 * w + 2] = t.z; Si[4 * w + 3] = t.w; }
+          for (int nn = 0; nn < 6; nn++) {   // F streamed row by row: row nn feeds the columns mm >= nn
+            float fr[6];
 #pragma unroll
-          for (int q = 0; q < 3; q++)
+            for (int mm = 0; mm < 6; mm++) fr[mm] = mm >= nn ? Fm[nn * 6 + mm] : 0.0f;
 #pragma unroll
-            for (int mm = 0; mm < 6; mm++) {
-              float acc = 0.0f;
+            for (int q = 0; q < 3; q++)
 #pragma unroll
-              for (int nn = 0; nn < 6; nn++) acc += W[q][nn] * Si[nn * 6 + mm];
-              V[q][mm] = acc;
-            }
+              for (int mm = nn; mm < 6; mm++) f[q * 6 + mm] += W[q][nn] * fr[mm];
+          }
         }
       } else if (SS) {
+        wbase = A * MQE_RD; ncol = 1;
         const V3 r0 = p - ssPiv;
         const V3 wy = m->ss_axis == 3 ? v3(0, 1, 0) : cross(m->ss_axis == 2 ? v3(0, 0, 1) : v3(0, 1, 0), r0);   // prismatic: the axis itself
-        const float ii = 1.0f / m->ss_inertia, vv = Vm[A * MQE_RD];
+        const float si = sqrtf(1.0f / m->ss_inertia), vv = Vm[A * MQE_RD];
 #pragma unroll
         for (int q = 0; q < 3; q++) {
           const float jq = sg * dot(dirs[q], wy);
-#pragma unroll
-          for (int mm = 0; mm < 6; mm++) { W[q][mm] = mm == 0 ? jq : 0.0f; V[q][mm] = mm == 0 ? ii * jq : 0.0f; }
+          f[q * 6] = si * jq;
+          if (q == 0) us0 += jq * vv; else if (q == 1) us1 += jq * vv; else us2 += jq * vv;
         }
-        cu0 += W[0][0] * vv; cu1 += W[1][0] * vv; cu2 += W[2][0] * vv;
       } else {
         const int pi = act - A;
+        wbase = A * MQE_RD + pi * npcdof; ncol = npcdof;
         const V3 r0 = p - ld3(lds + L.root + (A + pi) * 13);
-        const float im = 1.0f / m->npc_mass, ii = 1.0f / m->npc_inertia;
-        const float* vn = Vm + A * MQE_RD + pi * npcdof;
+        const float sm = sqrtf(1.0f / m->npc_mass), si = sqrtf(1.0f / m->npc_inertia);
+        const float* vn = Vm + wbase;
 #pragma unroll
         for (int q = 0; q < 3; q++) {
           const V3 cq = cross(r0, dirs[q]);
@@ -1080,225 +1093,183 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
 #pragma unroll
           for (int mm = 0; mm < 6; mm++) {
             const bool on = mm < npcdof;
-            W[q][mm] = on ? jr[mm] : 0.0f;
-            V[q][mm] = on ? (mm < 3 ? im : ii) * jr[mm] : 0.0f;
+            f[q * 6 + mm] = on ? (mm < 3 ? sm : si) * jr[mm] : 0.0f;
             if (on) acc += jr[mm] * vn[mm];
           }
-          if (q == 0) cu0 += acc; else if (q == 1) cu1 += acc; else cu2 += acc;
+          if (q == 0) us0 += acc; else if (q == 1) us1 += acc; else us2 += acc;
         }
       }
+      // this side's share of the contact's own block
+      {
+        float s00 = 0, s10 = 0, s11 = 0, s20 = 0, s21 = 0, s22 = 0;
 #pragma unroll
-      for (int q = 0; q < 3; q++) {
-        sr[q * 4 + 0] = make_float4(W[q][0], W[q][1], W[q][2], W[q][3]);
-        sr[q * 4 + 1] = make_float4(W[q][4], W[q][5], V[q][0], V[q][1]);
-        sr[q * 4 + 2] = make_float4(V[q][2], V[q][3], V[q][4], V[q][5]);
-        sr[q * 4 + 3] = make_float4(Z[q][0], Z[q][1], Z[q][2], __int_as_float(legi));
+        for (int mm = 0; mm < 6; mm++) {
+          s00 += f[mm] * f[mm]; s10 += f[6 + mm] * f[mm]; s11 += f[6 + mm] * f[6 + mm];
+          s20 += f[12 + mm] * f[mm]; s21 += f[12 + mm] * f[6 + mm]; s22 += f[12 + mm] * f[12 + mm];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          s00 += f[SIDE_Z + i] * f[SIDE_Z + i]; s10 += f[SIDE_Z + 3 + i] * f[SIDE_Z + i]; s11 += f[SIDE_Z + 3 + i] * f[SIDE_Z + 3 + i];
+          s20 += f[SIDE_Z + 6 + i] * f[SIDE_Z + i]; s21 += f[SIDE_Z + 6 + i] * f[SIDE_Z + 3 + i]; s22 += f[SIDE_Z + 6 + i] * f[SIDE_Z + 6 + i];
+        }
+        d00 += s00; d10 += s10; d11 += s11; d20 += s20; d21 += s21; d22 += s22;
       }
-      if (side == 0) myLegA = legi; else myLegB = legi;
+      const int info = (legi + 1) | (ncol << 4);
+      if (side == 0) {                       // side A: registers for the whole sweep
+        wA = wbase; infoA = info;
+#pragma unroll
+        for (int i = 0; i < 27; i++) fA[i] = f[i];
+      } else {                               // side B (two-actor contacts only): its slot in LDS
+        wB = wbase; infoB = info;
+        f[SIDE_INFO] = __int_as_float(info);
+        float4* sr = reinterpret_cast<float4*>(lds + L.side + (lane - nc_terr) * SIDE_STRIDE);
+#pragma unroll
+        for (int w = 0; w < SIDE_STRIDE / 4; w++) sr[w] = make_float4(f[4 * w], f[4 * w + 1], f[4 * w + 2], f[4 * w + 3]);
+        if (myB == myA) {                    // both sides on ONE actor (two links of a robot): the sides share coordinates -> cross terms
+          const bool same_leg = (infoA & 15) != 0 && (infoA & 15) == (infoB & 15);
+          float x[3][3];
+#pragma unroll
+          for (int q = 0; q < 3; q++)
+#pragma unroll
+            for (int q2 = 0; q2 < 3; q2++) {
+              float acc = 0.0f;
+#pragma unroll
+              for (int mm = 0; mm < 6; mm++) acc += fA[q * 6 + mm] * f[q2 * 6 + mm];
+              if (same_leg) acc += fA[SIDE_Z + q * 3] * f[SIDE_Z + q2 * 3] + fA[SIDE_Z + q * 3 + 1] * f[SIDE_Z + q2 * 3 + 1] + fA[SIDE_Z + q * 3 + 2] * f[SIDE_Z + q2 * 3 + 2];
+              x[q][q2] = acc;
+            }
+          d00 += 2.0f * x[0][0]; d10 += x[1][0] + x[0][1]; d11 += 2.0f * x[1][1];
+          d20 += x[2][0] + x[0][2]; d21 += x[2][1] + x[1][2]; d22 += 2.0f * x[2][2];
+        }
+      }
     }
   }
+  const float ik00 = is_con ? 1.0f / d00 : 0.0f, ik11 = is_con ? 1.0f / d11 : 0.0f, ik22 = is_con ? 1.0f / d22 : 0.0f;
   __syncthreads();
   TSTAMP(11);
-  // ---- 3x3 coupling blocks K(c, c2) = J_c M^-1 J_c2^T: one task per pair c2 <= c, transpose mirrored ---------------------------
-  for (int t = lane; t < (nc * (nc + 1)) / 2; t += 64) {
-    int c = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-    while ((c * (c + 1)) / 2 > t) c--;
-    while (((c + 1) * (c + 2)) / 2 <= t) c++;
-    const int c2 = t - (c * (c + 1)) / 2;
-    const float* cr1 = lds + L.con + c * CON_STRIDE;
-    const float* cr2 = lds + L.con + c2 * CON_STRIDE;
-    const int a1 = __float_as_int(cr1[C_IDS]), b1 = __float_as_int(cr1[C_IDS + 2]);
-    const int a2 = __float_as_int(cr2[C_IDS]), b2 = __float_as_int(cr2[C_IDS + 2]);
-    float k[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int s1 = 0; s1 < 2; s1++) {
-      const int act = s1 == 0 ? a1 : b1;
-      if (act < 0) continue;
-      for (int s2 = 0; s2 < 2; s2++) {
-        if ((s2 == 0 ? a2 : b2) != act) continue;
-        const float4* r1 = reinterpret_cast<const float4*>(lds + L.side + (s1 == 0 ? c : maxc + (c - nc_terr)) * SIDE_STRIDE);
-        const float4* r2 = reinterpret_cast<const float4*>(lds + L.side + (s2 == 0 ? c2 : maxc + (c2 - nc_terr)) * SIDE_STRIDE);
-        float W2[3][6], Z2[3][3];
-        int leg2 = -1;
-#pragma unroll
-        for (int q = 0; q < 3; q++) {
-          const float4 x0 = r2[q * 4], x1 = r2[q * 4 + 1], x3 = r2[q * 4 + 3];
-          W2[q][0] = x0.x; W2[q][1] = x0.y; W2[q][2] = x0.z; W2[q][3] = x0.w; W2[q][4] = x1.x; W2[q][5] = x1.y;
-          Z2[q][0] = x3.x; Z2[q][1] = x3.y; Z2[q][2] = x3.z;
-          if (q == 0) leg2 = __float_as_int(x3.w);
-        }
-        float Z1[3][3];
-        int leg1 = -1;
-#pragma unroll
-        for (int q = 0; q < 3; q++) {
-          const float4 y1 = r1[q * 4 + 1], y2 = r1[q * 4 + 2], y3 = r1[q * 4 + 3];
-          const float V1[6] = {y1.z, y1.w, y2.x, y2.y, y2.z, y2.w};
-          Z1[q][0] = y3.x; Z1[q][1] = y3.y; Z1[q][2] = y3.z;
-          if (q == 0) leg1 = __float_as_int(y3.w);
-#pragma unroll
-          for (int q2 = 0; q2 < 3; q2++) {
-            float acc = 0.0f;
-#pragma unroll
-            for (int mm = 0; mm < 6; mm++) acc += V1[mm] * W2[q2][mm];
-            k[q * 3 + q2] += acc;
-          }
-        }
-        if (act < A && leg1 >= 0 && leg1 == leg2) {      // both on the same leg: + Z M_ll^-1 Z'^T
-          const float* Mi = lds + L.leg + (act * 4 + leg1) * LEG_STRIDE + LEG_MI;
-          const float m00 = Mi[0], m11 = Mi[1], m22 = Mi[2], m01 = Mi[3], m02 = Mi[4], m12 = Mi[5];
-#pragma unroll
-          for (int q = 0; q < 3; q++) {
-            const float t0 = Z1[q][0] * m00 + Z1[q][1] * m01 + Z1[q][2] * m02;
-            const float t1_ = Z1[q][0] * m01 + Z1[q][1] * m11 + Z1[q][2] * m12;
-            const float t2_ = Z1[q][0] * m02 + Z1[q][1] * m12 + Z1[q][2] * m22;
-#pragma unroll
-            for (int q2 = 0; q2 < 3; q2++) k[q * 3 + q2] += t0 * Z2[q2][0] + t1_ * Z2[q2][1] + t2_ * Z2[q2][2];
-          }
-        }
-      }
-    }
-    float* kk = lds + L.kk + t * 9;            // t == c (c + 1) / 2 + c2: lower-triangular block storage
-#pragma unroll
-    for (int q = 0; q < 9; q++) kk[q] = k[q];
-  }
-  __syncthreads();
-  if (is_con) {
-    const float* kd = lds + L.kk + ((lane * (lane + 1)) / 2 + lane) * 9;
-    ik00 = 1.0f / kd[0]; ik11 = 1.0f / kd[4]; ik22 = 1.0f / kd[8]; ck10 = kd[3]; ck20 = kd[6]; ck21 = kd[7];
-  }
-  __syncthreads();
   TSTAMP(12);
-  // ---- projected Gauss-Seidel in CONTACT space, lane = contact ------------------------------------------------------------
-  // Each lane owns one contact: relative velocity u (3), impulse lambda (3).  One GS step = the owning lane's impulse
-  // increment (row-wise: normal, then the two friction rows with box limits mu*lambda_n), broadcast with v_readlane, and
-  // every lane adds its 3x3 coupling block with the owner times the increment.  No LDS round trip or wave reduction
-  // sits on the serial chain.  Mathematically identical to the velocity-space sweep of the CPU oracle.
+  // ---- projected Gauss-Seidel on  w = sum_c Phi_c^T lambda_c  ---------------------------------------------------------------
+  // A step: the owning lane forms its relative velocity u = u* + Phi w (its actors' coordinates: 6 + 3 per robot side), solves its
+  // three rows (normal >= 0, two friction rows boxed by mu lambda_n, the rows coupled through the contact's own block) and adds
+  // Phi^T d(lambda) to w.  The one-sided contacts of one actor touch that actor's coordinates only, so the s-th contact of EVERY
+  // actor is processed in the same step; contacts between two actors follow one by one.  Mathematically the sweep of the CPU
+  // oracle (velocity space) and of the former coupling-block form (contact space); here w IS M^-1 J^T lambda in disguise: dv = T w.
   {
-    // groups: the terrain contacts of one actor are contiguous in the list and coupled only among themselves, so the
-    // s-th contact of EVERY actor is updated in the same step (owner index per lane -> ds_bpermute broadcast);
-    // contacts between two actors (at the end of the list) couple two groups and are swept one by one afterwards.
     const bool is_terr = is_con && myB < 0, is_pair = is_con && myB >= 0;
-    int gstartA = 0, glenA = 0, gstartB = 0, glenB = 0, maxlen = 0;
-    const int nact = A + PD;
+    int gstartA = 0, glenA = 0, maxlen = 0;
+    const int nact = A + PD + (SS ? 1 : 0);
     for (int a = 0; a < nact; a++) {
       const unsigned long long bm = __ballot(is_terr && myA == a);
       const int len = __popcll(bm), start = bm ? __ffsll((long long)bm) - 1 : 0;
       maxlen = len > maxlen ? len : maxlen;
-      if (is_con && myA == a) { gstartA = start; glenA = len; }
-      if (is_pair && myB == a && myB != myA) { gstartB = start; glenB = len; }   // a self-contact has one group: its block with the owner already holds both sides
+      if (is_terr && myA == a) { gstartA = start; glenA = len; }
     }
     const int npair = __popcll(__ballot(is_pair));
     const int pair0 = nc - npair;
-    // K(lane, own): stored block (max, min); the mirrored half is the transpose (K is symmetric)
-    const int kc = is_con ? lane : 0;
-    const float* kbase = lds + L.kk;
-#define LOAD_KK(own)                                                                                      \
-    {                                                                                                     \
-      const int o_ = (own);                                                                               \
-      const bool tr_ = o_ > kc;                                                                           \
-      const int hi_ = tr_ ? o_ : kc, lo_ = tr_ ? kc : o_;                                                 \
-      const float* b_ = kbase + ((hi_ * (hi_ + 1)) / 2 + lo_) * 9;                                        \
-      kk[0] = b_[0]; kk[4] = b_[4]; kk[8] = b_[8];                                                        \
-      const float x1 = b_[1], x3 = b_[3], x2 = b_[2], x6 = b_[6], x5 = b_[5], x7 = b_[7];                \
-      kk[1] = tr_ ? x3 : x1; kk[3] = tr_ ? x1 : x3; kk[2] = tr_ ? x6 : x2; kk[6] = tr_ ? x2 : x6;         \
-      kk[5] = tr_ ? x7 : x5; kk[7] = tr_ ? x5 : x7;                                                       \
-    }
-    for (int it = 0; it < m->solver_iterations; it++) {
-      for (int sidx = 0; sidx < maxlen; sidx++) {
-        const bool vA = sidx < glenA;
-        const int ownA = vA ? (gstartA + sidx) : (is_con ? lane : 0);   // never index an unwritten block (0 * NaN)
-        float kk[9];
-        LOAD_KK(ownA);
-        const float ln = fmaxf(cl0 - (cu0 - cbias) * ik00, 0.0f);
-        const float d0 = ln - cl0;
-        const float lim = mu * ln;
-        const float l1 = clampf(cl1 - (cu1 + ck10 * d0) * ik11, -lim, lim);
-        const float d1 = l1 - cl1;
-        const float l2 = clampf(cl2 - (cu2 + ck20 * d0 + ck21 * d1) * ik22, -lim, lim);
-        const float d2 = l2 - cl2;
-        float e0 = __shfl(d0, ownA, 64), e1 = __shfl(d1, ownA, 64), e2 = __shfl(d2, ownA, 64);
-        if (!vA) { e0 = 0.0f; e1 = 0.0f; e2 = 0.0f; }
-        if (is_terr && lane == ownA && vA) { cl0 = ln; cl1 = l1; cl2 = l2; }
-        cu0 += kk[0] * e0 + kk[1] * e1 + kk[2] * e2;
-        cu1 += kk[3] * e0 + kk[4] * e1 + kk[5] * e2;
-        cu2 += kk[6] * e0 + kk[7] * e1 + kk[8] * e2;
-        if (npair > 0) {           // two-actor contacts also feel the owner of their second actor's group
-          const bool vB = is_pair && sidx < glenB;
-          const int ownB = vB ? (gstartB + sidx) : (is_con ? lane : 0);
-          float f0 = __shfl(d0, ownB, 64), f1 = __shfl(d1, ownB, 64), f2 = __shfl(d2, ownB, 64);
-          if (!vB) { f0 = 0.0f; f1 = 0.0f; f2 = 0.0f; }
-          LOAD_KK(ownB);
-          cu0 += kk[0] * f0 + kk[1] * f1 + kk[2] * f2;
-          cu1 += kk[3] * f0 + kk[4] * f1 + kk[5] * f2;
-          cu2 += kk[6] * f0 + kk[7] * f1 + kk[8] * f2;
+    const int ncolA = infoA >> 4, legA = (infoA & 15) - 1;
+    float* wbA = accv + wA;
+    float* wlA = accv + wA + 6 + (legA > 0 ? legA : 0) * 3;
+    auto gs_update = [&]() {
+      // side A from registers; its actor's coordinates are read once and written once
+      float wv[9];
+#pragma unroll
+      for (int mm = 0; mm < 6; mm++) wv[mm] = mm < ncolA ? wbA[mm] : 0.0f;
+#pragma unroll
+      for (int i = 0; i < 3; i++) wv[6 + i] = legA >= 0 ? wlA[i] : 0.0f;
+      float u0 = us0, u1 = us1, u2 = us2;
+#pragma unroll
+      for (int mm = 0; mm < 6; mm++) { u0 += fA[mm] * wv[mm]; u1 += fA[6 + mm] * wv[mm]; u2 += fA[12 + mm] * wv[mm]; }
+#pragma unroll
+      for (int i = 0; i < 3; i++) { u0 += fA[SIDE_Z + i] * wv[6 + i]; u1 += fA[SIDE_Z + 3 + i] * wv[6 + i]; u2 += fA[SIDE_Z + 6 + i] * wv[6 + i]; }
+      float fb[SIDE_STRIDE];
+      int ncolB = 0, legB = -1;
+      if (is_pair) {                         // side B: record from its LDS slot, coordinates of the second actor
+        const float4* r4 = reinterpret_cast<const float4*>(lds + L.side + (lane - nc_terr) * SIDE_STRIDE);
+#pragma unroll
+        for (int w = 0; w < SIDE_STRIDE / 4; w++) { const float4 t = r4[w]; fb[4 * w] = t.x; fb[4 * w + 1] = t.y; fb[4 * w + 2] = t.z; fb[4 * w + 3] = t.w; }
+        ncolB = infoB >> 4; legB = (infoB & 15) - 1;
+        const float* wb = accv + wB;
+        const float* wl = accv + wB + 6 + (legB > 0 ? legB : 0) * 3;
+#pragma unroll
+        for (int mm = 0; mm < 6; mm++)
+          if (mm < ncolB) { const float x = wb[mm]; u0 += fb[mm] * x; u1 += fb[6 + mm] * x; u2 += fb[12 + mm] * x; }
+        if (legB >= 0) {
+#pragma unroll
+          for (int i = 0; i < 3; i++) { const float x = wl[i]; u0 += fb[SIDE_Z + i] * x; u1 += fb[SIDE_Z + 3 + i] * x; u2 += fb[SIDE_Z + 6 + i] * x; }
         }
       }
+      const float ln = fmaxf(cl0 - (u0 - cbias) * ik00, 0.0f);
+      const float e0 = ln - cl0;
+      const float lim = mu * ln;
+      const float l1 = clampf(cl1 - (u1 + d10 * e0) * ik11, -lim, lim);
+      const float e1 = l1 - cl1;
+      const float l2 = clampf(cl2 - (u2 + d20 * e0 + d21 * e1) * ik22, -lim, lim);
+      const float e2 = l2 - cl2;
+      cl0 = ln; cl1 = l1; cl2 = l2;
+#pragma unroll
+      for (int mm = 0; mm < 6; mm++)
+        if (mm < ncolA) wbA[mm] = wv[mm] + fA[mm] * e0 + fA[6 + mm] * e1 + fA[12 + mm] * e2;
+      if (legA >= 0) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) wlA[i] = wv[6 + i] + fA[SIDE_Z + i] * e0 + fA[SIDE_Z + 3 + i] * e1 + fA[SIDE_Z + 6 + i] * e2;
+      }
+      if (is_pair) {                         // after side A's stores: the two sides may share coordinates (self-contact)
+        float* wb = accv + wB;
+        float* wl = accv + wB + 6 + (legB > 0 ? legB : 0) * 3;
+#pragma unroll
+        for (int mm = 0; mm < 6; mm++)
+          if (mm < ncolB) wb[mm] += fb[mm] * e0 + fb[6 + mm] * e1 + fb[12 + mm] * e2;
+        if (legB >= 0) {
+#pragma unroll
+          for (int i = 0; i < 3; i++) wl[i] += fb[SIDE_Z + i] * e0 + fb[SIDE_Z + 3 + i] * e1 + fb[SIDE_Z + 6 + i] * e2;
+        }
+      }
+    };
+    for (int it = 0; it < m->solver_iterations; it++) {
+      for (int sidx = 0; sidx < maxlen; sidx++) {
+        if (is_terr && sidx < glenA && lane == gstartA + sidx) gs_update();
+        __syncthreads();
+      }
       for (int c = pair0; c < nc; c++) {
-        float kk[9];
-        LOAD_KK(c);
-        const float ln = fmaxf(cl0 - (cu0 - cbias) * ik00, 0.0f);
-        const float d0 = ln - cl0;
-        const float lim = mu * ln;
-        const float l1 = clampf(cl1 - (cu1 + ck10 * d0) * ik11, -lim, lim);
-        const float d1 = l1 - cl1;
-        const float l2 = clampf(cl2 - (cu2 + ck20 * d0 + ck21 * d1) * ik22, -lim, lim);
-        const float d2 = l2 - cl2;
-        const float e0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d0), c));
-        const float e1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d1), c));
-        const float e2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d2), c));
-        if (lane == c) { cl0 = ln; cl1 = l1; cl2 = l2; }
-        cu0 += kk[0] * e0 + kk[1] * e1 + kk[2] * e2;
-        cu1 += kk[3] * e0 + kk[4] * e1 + kk[5] * e2;
-        cu2 += kk[6] * e0 + kk[7] * e1 + kk[8] * e2;
+        if (lane == c) gs_update();
+        __syncthreads();
       }
     }
   }
-#undef LOAD_KK
   TSTAMP(13);
   if (is_con) { float* cr = lds + L.con + lane * CON_STRIDE; cr[C_LAM] = cl0; cr[C_LAM + 1] = cl1; cr[C_LAM + 2] = cl2; }
-  __syncthreads();
-  // impulses -> velocities in two stages: (1) per generalized coordinate the reduced sums  a = sum_c V_c^T lambda_c  (base
-  // coordinates / free bodies / the 1-dof link) resp.  b = sum_c Z_c^T lambda_c  (joints, contacts on the joint's own leg only);
-  // (2) dv_base = a, dv_leg = M_ll^-1 b - G^T a
+  // impulses -> velocities: dv = T w.  Base: F w_b; leg: Lm w_l - G^T (F w_b); free body / 1-dof link: M^-1/2 w
   for (int d = lane; d < ndof; d += 64) {
-    int dact, dloc;
-    if (d < A * MQE_RD) { dact = d / MQE_RD; dloc = d - dact * MQE_RD; }
-    else if (shp.has_seesaw) { dact = A; dloc = 0; }
-    else { const int q = d - A * MQE_RD; dact = A + q / npcdof; dloc = q - (q / npcdof) * npcdof; }
-    const bool jointd = dact < A && dloc >= 6;
-    const int dleg = jointd ? (dloc - 6) / 3 : -1;
-    const int off = jointd ? SIDE_Z + (dloc - 6) - dleg * 3 : SIDE_V + dloc;
-    float acc = 0.0f;
-    for (int c = 0; c < nc; c++) {                    // contact c's actors and impulse live in lane c's registers
-      const int a2 = __builtin_amdgcn_readlane(myA, c), b2 = __builtin_amdgcn_readlane(myB, c);
-      const float l0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cl0), c));
-      const float l1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cl1), c));
-      const float l2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cl2), c));
-      if (a2 == dact && (!jointd || __builtin_amdgcn_readlane(myLegA, c) == dleg)) {
-        const float* sr = lds + L.side + c * SIDE_STRIDE;
-        acc += sr[off] * l0 + sr[SIDE_ROW + off] * l1 + sr[2 * SIDE_ROW + off] * l2;
-      }
-      if (b2 == dact && (!jointd || __builtin_amdgcn_readlane(myLegB, c) == dleg)) {      // both for a contact between two links of this actor
-        const float* sr = lds + L.side + (maxc + (c - nc_terr)) * SIDE_STRIDE;
-        acc += sr[off] * l0 + sr[SIDE_ROW + off] * l1 + sr[2 * SIDE_ROW + off] * l2;
-      }
-    }
-    accv[d] = acc;
-  }
-  __syncthreads();
-  for (int d = lane; d < ndof; d += 64) {
-    float dv = accv[d];
+    float dv;
     if (d < A * MQE_RD) {
       const int r = d / MQE_RD, k = d - r * MQE_RD;
-      if (k >= 6) {
+      const float* Fm = lds + L.sinv + r * 72 + 36;
+      const float* wb = accv + r * MQE_RD;
+      if (k < 6) {
+        dv = 0.0f;
+#pragma unroll
+        for (int mm = 0; mm < 6; mm++) dv += Fm[k * 6 + mm] * wb[mm];
+      } else {
         const int lg = (k - 6) / 3, i = (k - 6) - lg * 3;
         const float* rec = lds + L.leg + (r * 4 + lg) * LEG_STRIDE;
-        const float* bl = accv + r * MQE_RD + 6 + lg * 3;
-        const float* ab = accv + r * MQE_RD;
+        const float* wl = wb + 6 + lg * 3;
+        const float* Lm = rec + LEG_LM + (i * (i + 1)) / 2;
+        dv = Lm[0] * wl[0];
+        if (i >= 1) dv += Lm[1] * wl[1];
+        if (i >= 2) dv += Lm[2] * wl[2];
         const float* G = rec + LEG_G + i;
-        dv = mi_at(rec + LEG_MI, i, 0) * bl[0] + mi_at(rec + LEG_MI, i, 1) * bl[1] + mi_at(rec + LEG_MI, i, 2) * bl[2];
 #pragma unroll
-        for (int mm = 0; mm < 6; mm++) dv -= G[mm * 3] * ab[mm];
+        for (int nn = 0; nn < 6; nn++) {
+          float dvb = 0.0f;
+#pragma unroll
+          for (int mm = 0; mm < 6; mm++) dvb += Fm[nn * 6 + mm] * wb[mm];
+          dv -= G[nn * 3] * dvb;
+        }
       }
+    } else if (shp.has_seesaw) dv = sqrtf(1.0f / m->ss_inertia) * accv[d];
+    else {
+      const int q = d - A * MQE_RD, k = q - (q / npcdof) * npcdof;
+      dv = sqrtf(1.0f / (k < 3 ? m->npc_mass : m->npc_inertia)) * accv[d];
     }
     Vm[d] += dv;
   }
@@ -1425,6 +1396,11 @@ __global__ void __launch_bounds__(64) k_simulate(const DevModel* __restrict__ m,
   extern __shared__ float lds[];
   phys_substep<0, -1>(m, st, lds, env_base + blockIdx.x, threadIdx.x, PS_LOAD_STATE | PS_LOAD_TAU | PS_STORE_STATE | PS_WRITE_CF, no_write, dbg);
 }
+// the same substep compiled for the two-robot, no-NPC shape (what k_substeps<2,0> runs): only the per-phase counter tool launches it
+__global__ void __launch_bounds__(64) k_simulate_a2(const DevModel* __restrict__ m, DevState st, int env_base, int no_write, PhysDebug dbg) {
+  extern __shared__ float lds[];
+  phys_substep<2, 0>(m, st, lds, env_base + blockIdx.x, threadIdx.x, PS_LOAD_STATE | PS_LOAD_TAU | PS_STORE_STATE | PS_WRITE_CF, no_write, dbg);
+}
 
 // ----------------------------------------------------------------------------------------------------------------------
 // k_substeps: the whole decimation loop of Go1.step (go1.py:48-58) for one env in one wavefront:
@@ -1438,11 +1414,25 @@ __device__ __forceinline__ float softsign_p(float x) { return x * __builtin_amdg
 
 #define ACT_TILES 2       // 2 x 32 joints >= 12 * MQE_MAX_AGENTS(=4)... agents <= 4 need 48 joints
 
-#ifndef MQE_SUBSTEPS_WAVES
-#define MQE_SUBSTEPS_WAVES 2
+// Occupancy class of a scene shape.  Robot-only scenes (with or without the 1-dof link) need < 10 KiB of LDS per env, so 16 waves
+// fit a CU: they are compiled for 128 VGPRs (4 waves per SIMD) and 4096 envs run as ONE round of 16 waves per CU.  Scenes with
+// NPCs / statics need more LDS than that allows and stay at 2 waves per SIMD with the full register file.  (Overrides for
+// experiments: -DMQE_SUBSTEPS_WAVES=n, -DMQE_LAUNDER=0|1|2.)
+template <int TP> struct SubstepsClass {
+  static constexpr bool small = TP == 0 || TP == PS_F_LINK;
+#ifdef MQE_SUBSTEPS_WAVES
+  static constexpr int waves = MQE_SUBSTEPS_WAVES;
+#else
+  static constexpr int waves = small ? 4 : 2;
 #endif
+#ifdef MQE_LAUNDER
+  static constexpr int launder = MQE_LAUNDER;
+#else
+  static constexpr int launder = small ? 2 : 0;
+#endif
+};
 template <int TA, int TP>
-__global__ void __launch_bounds__(64, MQE_SUBSTEPS_WAVES) k_substeps(const DevModel* __restrict__ m, DevState st, int nsub, int lag_pos) {
+__global__ void __launch_bounds__(64, SubstepsClass<TP>::waves) k_substeps(const DevModel* __restrict__ m, DevState st, int nsub, int lag_pos) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x, e = blockIdx.x;
   const PhysShape<TA, TP> shp(m);
@@ -1464,29 +1454,23 @@ __global__ void __launch_bounds__(64, MQE_SUBSTEPS_WAVES) k_substeps(const DevMo
   for (int i = lane; i < (A + P) * 13; i += 64) lds[L.root + i] = g_root[i];
   for (int i = lane; i < shp.ND * 2; i += 64) lds[L.dof + i] = g_dof[i];
   __syncthreads();
-  const PhysDebug nodbg = {nullptr, nullptr, nullptr, 0, nullptr};
+  const PhysDebug nodbg = {nullptr, nullptr, nullptr, 0, nullptr, -1};
 #pragma clang loop unroll(disable)
   for (int k = 0; k < nsub; k++) {
     const bool last = k + 1 == nsub;
-    // Register budget vs. recomputation (measured, go1gate 4096 envs, MI355X).  Everything the body derives
-    // from the lane id and the model alone (indices, LDS addresses, masks, per-lane model constants: ~100 values) is invariant
-    // over the substeps; the compiler hoists it out of this loop and the kernel then needs ~250 VGPRs = 2 waves per SIMD.
-    // Laundering the model pointer (MQE_LAUNDER >= 1) and the lane id (>= 2) once per substep turns the hoisting off: 154 VGPRs,
-    // no scratch, 3 waves per SIMD with the 12.9 KiB LDS footprint -- but a wave then re-derives all of it four times (+17 %
-    // instructions), and 4096 envs are 16 waves per CU = one round of 12 plus a tail of 4: 219 us against 199 us for the hoisted
-    // form at 2 waves per SIMD (two full rounds of 8).  Forcing 168 VGPRs onto the hoisted form spills (267 us).  So: hoisted.
+    // Register budget vs. recomputation (measured, MI355X).  Everything the body derives from the lane id and
+    // the model alone (indices, LDS addresses, masks, per-lane model constants: ~100 values) is invariant over the substeps; left
+    // alone the compiler hoists it out of this loop and the kernel needs ~250 VGPRs = 2 waves per SIMD.  Laundering the model
+    // pointer (launder >= 1) and the lane id (>= 2) once per substep turns the hoisting off: the body then fits 128 VGPRs with a
+    // handful of spills, at the price of re-deriving those values every substep (+17 % instructions).  That pays exactly when the
+    // LDS footprint lets 16 waves sit on a CU (SubstepsClass::small): 4096 envs then run as one round instead of two.
     const DevModel* mk = m;
     int lane_k = lane;
-#ifndef MQE_LAUNDER
-#define MQE_LAUNDER 0
-#endif
-#if MQE_LAUNDER >= 1
-    asm volatile("" : "+s"(mk));
-#endif
-#if MQE_LAUNDER >= 2
-    asm volatile("" : "+v"(lane_k));
-    lane_k &= 63;                                    // gives the value range of threadIdx.x back to the optimiser
-#endif
+    if (SubstepsClass<TP>::launder >= 1) asm volatile("" : "+s"(mk));
+    if (SubstepsClass<TP>::launder >= 2) {
+      asm volatile("" : "+v"(lane_k));
+      lane_k &= 63;                                  // gives the value range of threadIdx.x back to the optimiser
+    }
     const int j32 = lane_k & 31, h = lane_k >> 5;
     if (ctrl != MQE_CTRL_C) {          // P / V / T (legged_robot.py:384-390): a few FMAs per joint lane instead of the actuator network
       for (int jt = lane_k; jt < nj; jt += 64) {

@@ -268,6 +268,7 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   if (m.ndof_env > 128 || m.nbody_env > 64) { return fail(-4, "env has more than 64 bodies or 128 generalized velocities: does not fit one wavefront"); }
   PhysLds L = phys_lds_layout(A, P, s->ND, m.nbody_env, m.ndof_env, m.nsph_env, m.maxc);
   s->phys_lds_bytes = (size_t)L.total * 4;
+  if (getenv("MQE_VERBOSE")) fprintf(stderr, "mqe: physics LDS %zu B per env (wavefront)\n", s->phys_lds_bytes);
   if (const char* pad = getenv("MQE_PHYS_LDS_PAD")) s->phys_lds_bytes += (size_t)atoi(pad);   // experiments: caps the physics kernel's waves per CU
   // the records the physics kernel moves as 16 B words must start on 16 B (kernels_physics.hpp)
   if ((L.body | L.sph | L.con | L.side | L.leg | L.legc | L.sinv | L.fcol | L.acc | L.rhs) & 3) { return fail(-4, "physics LDS layout: a 16 B record area is misaligned"); }
@@ -620,7 +621,14 @@ static void launch_torques(mqe_sim* s, int dec_i, hipStream_t q) {
 }
 static void launch_simulate(mqe_sim* s, hipStream_t q) {
   ProfScope ps(s, PROF_SIMULATE, q);
-  PhysDebug dbg = {nullptr, nullptr, nullptr, 0, nullptr};
+  PhysDebug dbg = {nullptr, nullptr, nullptr, 0, nullptr, -1};
+  if (const char* sp = getenv("MQE_DEBUG_STOP_PHASE")) {     // tools/phase_counters.py: the wavefront leaves after that phase tap
+    dbg.stop_after = atoi(sp);
+    if (s->substeps_fn == (void (*)(const DevModel*, DevState, int, int))k_substeps<2, 0>) {
+      hipLaunchKernelGGL(k_simulate_a2, dim3(s->N), dim3(64), s->phys_lds_bytes, q, s->dm, s->st, 0, dbg.stop_after >= 0 ? 1 : 0, dbg);
+      return;
+    }
+  }
   hipLaunchKernelGGL(k_simulate, dim3(s->N), dim3(64), s->phys_lds_bytes, q, s->dm, s->st, 0, 0, dbg);
 }
 static void launch_post(mqe_sim* s, hipStream_t q, int wrapper_level) {
@@ -791,7 +799,7 @@ extern "C" int mqe_debug_dynamics(mqe_sim* s, int env, int robot, float* minv_ou
   float *dm_, *dc; int* dn; long long* dtm;
   HIPCHK(hipMalloc(&dm_, 324 * 4)); HIPCHK(hipMalloc(&dc, 64 * 8 * 4)); HIPCHK(hipMalloc(&dn, 4)); HIPCHK(hipMalloc(&dtm, 16 * 8));
   HIPCHK(hipMemset(dtm, 0, 16 * 8));
-  PhysDebug dbg = {dm_, dn, dc, robot, dtm};
+  PhysDebug dbg = {dm_, dn, dc, robot, dtm, -1};
   hipLaunchKernelGGL(k_simulate, dim3(1), dim3(64), s->phys_lds_bytes, 0, s->dm, s->st, env, 1, dbg);
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(minv_out_host, dm_, 324 * 4, hipMemcpyDeviceToHost));
