@@ -48,6 +48,24 @@ __device__ __forceinline__ float lane_prev(float x) {
   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x138, 0xF, 0xF, false));
 }
 
+// sum over the 16 lanes of a DPP row, delivered to every lane of the row: four butterfly steps (lane ^ 1, lane ^ 2 as quad
+// permutations, then the mirror inside each half row and inside the row).  Both partners of a step add the same two operands, so
+// all 16 lanes end with bitwise the same sum.
+template <int CTRL> __device__ __forceinline__ float dpp_take(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float row16_sum(float x) {
+  x += dpp_take<0xB1>(x);      // quad_perm [1,0,3,2]
+  x += dpp_take<0x4E>(x);      // quad_perm [2,3,0,1]
+  x += dpp_take<0x141>(x);     // row_half_mirror
+  x += dpp_take<0x140>(x);     // row_mirror
+  return x;
+}
+// value of lane ^ 16 (the same position in the neighbouring row): ds_swizzle in bit-mask mode, xor 0x10 -- no LDS access
+__device__ __forceinline__ float row_partner(float x) {
+  return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), 0x401F));
+}
+
 // sphere (centre c, radius r) vs box (centre bc, rotation R, half extents h): signed distance, world normal box->sphere
 __device__ __forceinline__ float sphere_box(V3 c, float r, V3 bc, const float* R, V3 h, V3& n) {
   const V3 d = c - bc;
@@ -146,10 +164,11 @@ __host__ __device__ inline int mqe_maxc(int A, int P, int cap_npc) { int v = 8 *
 // NPCs keep m->cap_npc one-sided contacts each (2; a box resting on a face 4): per-actor caps so that no actor starves the ones after it
 
 struct PhysLds {   // float offsets into dynamic LDS
-  int root, dof, tau, body, rhs, acc, acth, fcol, leg, legc, basei, sinv, sph, con, side, total;
+  int root, dof, tau, body, rhs, acc, acth, fcol, leg, legc, basei, sinv, sph, con, side, phi, srec, total;
 };
+#define SREC_STRIDE 16    // row sweep: per contact [u* (3), bias] [mu, 1/d00, 1/d11, 1/d22] [d10, d20, d21, -] [lambda (3), -]
 __host__ __device__ inline int mqe_maxpair(int maxc) { return maxc / 2; }    // two-actor contacts kept per env
-__host__ __device__ inline PhysLds phys_lds_layout(int A, int P, int ND, int nbody, int ndof, int nsph, int maxc) {
+__host__ __device__ inline PhysLds phys_lds_layout(int A, int P, int ND, int nbody, int ndof, int nsph, int maxc, int rowgs) {
   // Regions that live to the end of the substep first; then the scratch of the dynamics phases (link records, CRBA / Schur
   // scratch; the collision spheres overlay the latter), dead once the contact side records exist.  Contact sides are
   // slot-allocated: side A of contact c -> slot c, side B of the k-th two-actor contact -> slot maxc + k (terrain contacts have no
@@ -174,6 +193,10 @@ __host__ __device__ inline PhysLds phys_lds_layout(int A, int P, int ND, int nbo
   L.basei = o; o += A * 12;
   L.sph = scratch;
   if (scratch + nsph * 4 > o) o = scratch + nsph * 4;
+  // row sweep (robot-only scenes): side A of every contact and the per-contact solve record, written over the link records once the
+  // last Jacobian row has been read
+  L.phi = L.body; L.srec = L.phi + maxc * SIDE_STRIDE;
+  if (rowgs && L.srec + maxc * SREC_STRIDE > o) o = L.srec + maxc * SREC_STRIDE;
   L.total = o;
   return L;
 }
@@ -196,13 +219,15 @@ template <int TA, int TP>
 struct PhysShape {
   const int A, P, PD, npcdof, ND, nbody, ndof, maxc, n_static;
   const bool has_seesaw, has_box;
+  const bool rowgs;      // contact sweep with one DPP row per actor (scenes of robots and at most the 1-dof link) instead of one lane per contact
   __device__ __forceinline__ explicit PhysShape(const DevModel* m)
       : A(TA > 0 ? TA : m->A), P(TP == 0 ? 0 : m->P), PD((TP < 0 || (TP & PS_F_NPC)) ? m->n_npc_dyn : 0),
         npcdof((TP < 0 || (TP & PS_F_NPC)) ? m->npc_dofs_each : 0),
         ND((TA > 0 && TP == 0) ? 12 * TA : m->ND), nbody((TA > 0 && TP == 0) ? TA * MQE_NBODY : m->nbody_env),
         ndof((TA > 0 && TP == 0) ? TA * MQE_RD : m->ndof_env), maxc((TA > 0 && TP == 0) ? mqe_maxc(TA, 0, 2) : m->maxc),
         n_static((TP < 0 || (TP & PS_F_STATIC)) ? m->n_static : 0),
-        has_seesaw(TP < 0 ? m->has_seesaw != 0 : (TP & PS_F_LINK) != 0), has_box(TP < 0 ? m->has_box != 0 : (TP & PS_F_BOX) != 0) {}
+        has_seesaw(TP < 0 ? m->has_seesaw != 0 : (TP & PS_F_LINK) != 0), has_box(TP < 0 ? m->has_box != 0 : (TP & PS_F_BOX) != 0),
+        rowgs(TP < 0 ? m->rowgs != 0 : (TP == 0 || TP == PS_F_LINK)) {}
 };
 
 template <int TA, int TP>
@@ -211,7 +236,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   const PhysShape<TA, TP> shp(m);
   const int A = shp.A, P = shp.P, PD = shp.PD, npcdof = shp.npcdof;
   const int nbody = shp.nbody, ndof = shp.ndof, nsph = m->nsph_env, maxc = shp.maxc;
-  const PhysLds L = phys_lds_layout(A, P, shp.ND, nbody, ndof, nsph, maxc);
+  const PhysLds L = phys_lds_layout(A, P, shp.ND, nbody, ndof, nsph, maxc, shp.rowgs);
   const float dt = m->dt;
   const mqe_robot_model& rm = m->robot;
   float* g_root = st.root + (size_t)e * (A + P) * 13;
@@ -973,7 +998,8 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   float us0 = 0, us1 = 0, us2 = 0, cl0 = 0, cl1 = 0, cl2 = 0, cbias = 0;      // relative velocity of the unconstrained motion, impulse, bias
   float d00 = 0, d10 = 0, d11 = 0, d20 = 0, d21 = 0, d22 = 0;                // my contact's own 3 x 3 block K(c, c) = sum over sides Phi Phi^T
   int myA = -2, myB = -2;                                                   // actors of my contact's sides
-  int wA = 0, wB = 0, infoA = 0, infoB = 0;                                  // first generalized coordinate of each side's actor; (leg + 1) | columns << 4
+  int wA = 0, wB = 0, infoA = 0, infoB = 0;                                  // first generalized coordinate of each side's actor; the side's info word
+  int lgA = 0, lgB = 0;                                                     // leg + 1 of each side's touching link (0: base / not a robot)
   float mu = m->friction;
   float fA[27];                                                             // Phi of my contact's side A (U 18, Z' 9): registers for the whole sweep
 #pragma unroll
@@ -1114,19 +1140,20 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
         }
         d00 += s00; d10 += s10; d11 += s11; d20 += s20; d21 += s21; d22 += s22;
       }
-      const int info = (legi + 1) | (ncol << 4);
+      // info word: the lane sweep reads (leg + 1) | columns << 4; the row sweep lanes | first joint offset << 4 | first coordinate << 10
+      const int info = shp.rowgs ? ((ncol == 6 && act < A ? 9 : ncol) | ((legi > 0 ? legi * 3 : 0) << 4) | (wbase << 10)) : ((legi + 1) | (ncol << 4));
       if (side == 0) {                       // side A: registers for the whole sweep
-        wA = wbase; infoA = info;
+        wA = wbase; infoA = info; lgA = legi + 1;
 #pragma unroll
         for (int i = 0; i < 27; i++) fA[i] = f[i];
       } else {                               // side B (two-actor contacts only): its slot in LDS
-        wB = wbase; infoB = info;
+        wB = wbase; infoB = info; lgB = legi + 1;
         f[SIDE_INFO] = __int_as_float(info);
         float4* sr = reinterpret_cast<float4*>(lds + L.side + (lane - nc_terr) * SIDE_STRIDE);
 #pragma unroll
         for (int w = 0; w < SIDE_STRIDE / 4; w++) sr[w] = make_float4(f[4 * w], f[4 * w + 1], f[4 * w + 2], f[4 * w + 3]);
         if (myB == myA) {                    // both sides on ONE actor (two links of a robot): the sides share coordinates -> cross terms
-          const bool same_leg = (infoA & 15) != 0 && (infoA & 15) == (infoB & 15);
+          const bool same_leg = lgA != 0 && lgA == lgB;
           float x[3][3];
 #pragma unroll
           for (int q = 0; q < 3; q++)
@@ -1154,88 +1181,183 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   // Phi^T d(lambda) to w.  The one-sided contacts of one actor touch that actor's coordinates only, so the s-th contact of EVERY
   // actor is processed in the same step; contacts between two actors follow one by one.  Mathematically the sweep of the CPU
   // oracle (velocity space) and of the former coupling-block form (contact space); here w IS M^-1 J^T lambda in disguise: dv = T w.
-  {
+  if (shp.rowgs) {
+    // ---- row sweep (scenes of robots and at most the 1-dof link): one DPP row of 16 lanes per ACTOR ---------------------------
+    // The same projected Gauss-Seidel on w = sum Phi^T lambda, but a step is spread over the lanes of a row instead of running on the
+    // contact's one lane: lane k of the row holds coordinate k of the actor (6 base + the 3 joints of the touching leg), multiplies
+    // Phi[:, k] by w[k], the three sums over the row come from four DPP butterfly steps each, every lane solves the three rows
+    // (identical operands -> identical results) and updates its own w[k].  ~40 VALU instructions per step instead of ~90, and the
+    // side records and per-contact constants sit in LDS (over the dead link records) instead of 45 registers of every lane.
+    if (is_con) {
+      float4* pr = reinterpret_cast<float4*>(lds + L.phi + lane * SIDE_STRIDE);
+#pragma unroll
+      for (int w = 0; w < 6; w++) pr[w] = make_float4(fA[4 * w], fA[4 * w + 1], fA[4 * w + 2], fA[4 * w + 3]);
+      pr[6] = make_float4(fA[24], fA[25], fA[26], __int_as_float(infoA));
+      float4* sr = reinterpret_cast<float4*>(lds + L.srec + lane * SREC_STRIDE);
+      sr[0] = make_float4(us0, us1, us2, cbias);
+      sr[1] = make_float4(mu, ik00, ik11, ik22);
+      sr[2] = make_float4(d10, d20, d21, 0.0f);
+      sr[3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
     const bool is_terr = is_con && myB < 0, is_pair = is_con && myB >= 0;
-    int gstartA = 0, glenA = 0, maxlen = 0;
+    const int row = lane >> 4, k = lane & 15;
+    int gstart = 0, glen = 0, maxlen = 0;                    // the one-sided contacts of my row's actor: first list index, count
     const int nact = A + PD + (SS ? 1 : 0);
     for (int a = 0; a < nact; a++) {
       const unsigned long long bm = __ballot(is_terr && myA == a);
       const int len = __popcll(bm), start = bm ? __ffsll((long long)bm) - 1 : 0;
       maxlen = len > maxlen ? len : maxlen;
-      if (is_terr && myA == a) { gstartA = start; glenA = len; }
+      if (row == a) { gstart = start; glen = len; }
     }
     const int npair = __popcll(__ballot(is_pair));
     const int pair0 = nc - npair;
-    const int ncolA = infoA >> 4, legA = (infoA & 15) - 1;
-    float* wbA = accv + wA;
-    float* wlA = accv + wA + 6 + (legA > 0 ? legA : 0) * 3;
-    auto gs_update = [&]() {
-      // side A from registers; its actor's coordinates are read once and written once
-      float wv[9];
-#pragma unroll
-      for (int mm = 0; mm < 6; mm++) wv[mm] = mm < ncolA ? wbA[mm] : 0.0f;
-#pragma unroll
-      for (int i = 0; i < 3; i++) wv[6 + i] = legA >= 0 ? wlA[i] : 0.0f;
-      float u0 = us0, u1 = us1, u2 = us2;
-#pragma unroll
-      for (int mm = 0; mm < 6; mm++) { u0 += fA[mm] * wv[mm]; u1 += fA[6 + mm] * wv[mm]; u2 += fA[12 + mm] * wv[mm]; }
-#pragma unroll
-      for (int i = 0; i < 3; i++) { u0 += fA[SIDE_Z + i] * wv[6 + i]; u1 += fA[SIDE_Z + 3 + i] * wv[6 + i]; u2 += fA[SIDE_Z + 6 + i] * wv[6 + i]; }
-      float fb[SIDE_STRIDE];
-      int ncolB = 0, legB = -1;
-      if (is_pair) {                         // side B: record from its LDS slot, coordinates of the second actor
-        const float4* r4 = reinterpret_cast<const float4*>(lds + L.side + (lane - nc_terr) * SIDE_STRIDE);
-#pragma unroll
-        for (int w = 0; w < SIDE_STRIDE / 4; w++) { const float4 t = r4[w]; fb[4 * w] = t.x; fb[4 * w + 1] = t.y; fb[4 * w + 2] = t.z; fb[4 * w + 3] = t.w; }
-        ncolB = infoB >> 4; legB = (infoB & 15) - 1;
-        const float* wb = accv + wB;
-        const float* wl = accv + wB + 6 + (legB > 0 ? legB : 0) * 3;
-#pragma unroll
-        for (int mm = 0; mm < 6; mm++)
-          if (mm < ncolB) { const float x = wb[mm]; u0 += fb[mm] * x; u1 += fb[6 + mm] * x; u2 += fb[12 + mm] * x; }
-        if (legB >= 0) {
-#pragma unroll
-          for (int i = 0; i < 3; i++) { const float x = wl[i]; u0 += fb[SIDE_Z + i] * x; u1 += fb[SIDE_Z + 3 + i] * x; u2 += fb[SIDE_Z + 6 + i] * x; }
-        }
-      }
-      const float ln = fmaxf(cl0 - (u0 - cbias) * ik00, 0.0f);
-      const float e0 = ln - cl0;
-      const float lim = mu * ln;
-      const float l1 = clampf(cl1 - (u1 + d10 * e0) * ik11, -lim, lim);
-      const float e1 = l1 - cl1;
-      const float l2 = clampf(cl2 - (u2 + d20 * e0 + d21 * e1) * ik22, -lim, lim);
-      const float e2 = l2 - cl2;
-      cl0 = ln; cl1 = l1; cl2 = l2;
-#pragma unroll
-      for (int mm = 0; mm < 6; mm++)
-        if (mm < ncolA) wbA[mm] = wv[mm] + fA[mm] * e0 + fA[6 + mm] * e1 + fA[12 + mm] * e2;
-      if (legA >= 0) {
-#pragma unroll
-        for (int i = 0; i < 3; i++) wlA[i] = wv[6 + i] + fA[SIDE_Z + i] * e0 + fA[SIDE_Z + 3 + i] * e1 + fA[SIDE_Z + 6 + i] * e2;
-      }
-      if (is_pair) {                         // after side A's stores: the two sides may share coordinates (self-contact)
-        float* wb = accv + wB;
-        float* wl = accv + wB + 6 + (legB > 0 ? legB : 0) * 3;
-#pragma unroll
-        for (int mm = 0; mm < 6; mm++)
-          if (mm < ncolB) wb[mm] += fb[mm] * e0 + fb[6 + mm] * e1 + fb[12 + mm] * e2;
-        if (legB >= 0) {
-#pragma unroll
-          for (int i = 0; i < 3; i++) wl[i] += fb[SIDE_Z + i] * e0 + fb[SIDE_Z + 3 + i] * e1 + fb[SIDE_Z + 6 + i] * e2;
-        }
-      }
+    // where lane k finds its column in a side record: U[q][k] at q * 6 + k, Z'[q][k - 6] at 18 + q * 3 + (k - 6)
+    const int koff = k < 6 ? k : (k < 9 ? SIDE_Z + (k - 6) : 0), kstr = k < 6 ? 6 : 3;
+    const int klegmask = (k >= 6 && k < 9) ? -1 : 0;
+    __syncthreads();
+    struct RowStep { float ph0, ph1, ph2, wk, s0, s1, s2; int widx; bool on; };
+    // the row's sums of Phi[q][k] w[k] over the coordinates of the side record `rec` (info word: lanes | first joint << 4 | first
+    // coordinate << 10; columns past the actor's are masked, a robot side without a leg has zero Z' and points at leg 0)
+    auto row_products = [&](const float* rec) {
+      RowStep r;
+      const int info = __float_as_int(rec[SIDE_INFO]);
+      r.on = k < (info & 15);
+      r.widx = (info >> 10) + k + (((info >> 4) & 63) & klegmask);
+      const float r0 = rec[koff], r1 = rec[koff + kstr], r2 = rec[koff + 2 * kstr], ww = accv[r.on ? r.widx : 0];
+      r.ph0 = r.on ? r0 : 0.0f; r.ph1 = r.on ? r1 : 0.0f; r.ph2 = r.on ? r2 : 0.0f; r.wk = r.on ? ww : 0.0f;
+      float a0 = r.ph0 * r.wk, a1 = r.ph1 * r.wk, a2 = r.ph2 * r.wk;       // three independent butterflies, interleaved
+      a0 += dpp_take<0xB1>(a0); a1 += dpp_take<0xB1>(a1); a2 += dpp_take<0xB1>(a2);
+      a0 += dpp_take<0x4E>(a0); a1 += dpp_take<0x4E>(a1); a2 += dpp_take<0x4E>(a2);
+      a0 += dpp_take<0x141>(a0); a1 += dpp_take<0x141>(a1); a2 += dpp_take<0x141>(a2);
+      a0 += dpp_take<0x140>(a0); a1 += dpp_take<0x140>(a1); a2 += dpp_take<0x140>(a2);
+      r.s0 = a0; r.s1 = a1; r.s2 = a2;
+      return r;
+    };
+    // the contact's three rows from its solve record; returns the impulse increments
+    auto row_solve = [&](float* sr, float u0, float u1, float u2, bool writer, float& e0, float& e1, float& e2) {
+      const float4 q0 = reinterpret_cast<const float4*>(sr)[0], q1 = reinterpret_cast<const float4*>(sr)[1];
+      const float4 q2 = reinterpret_cast<const float4*>(sr)[2], q3 = reinterpret_cast<const float4*>(sr)[3];
+      u0 += q0.x; u1 += q0.y; u2 += q0.z;
+      const float ln = fmaxf(q3.x - (u0 - q0.w) * q1.y, 0.0f);
+      e0 = ln - q3.x;
+      const float lim = q1.x * ln;
+      const float l1 = clampf(q3.y - (u1 + q2.x * e0) * q1.z, -lim, lim);
+      e1 = l1 - q3.y;
+      const float l2 = clampf(q3.z - (u2 + q2.y * e0 + q2.z * e1) * q1.w, -lim, lim);
+      e2 = l2 - q3.z;
+      if (writer) reinterpret_cast<float4*>(sr)[3] = make_float4(ln, l1, l2, 0.0f);
     };
     for (int it = 0; it < m->solver_iterations; it++) {
       for (int sidx = 0; sidx < maxlen; sidx++) {
-        if (is_terr && sidx < glenA && lane == gstartA + sidx) gs_update();
+        if (row < nact && sidx < glen) {                     // the s-th one-sided contact of every actor, each in its own row
+          const int c = gstart + sidx;
+          const RowStep r = row_products(lds + L.phi + c * SIDE_STRIDE);
+          float e0, e1, e2;
+          row_solve(lds + L.srec + c * SREC_STRIDE, r.s0, r.s1, r.s2, k == 0, e0, e1, e2);
+          if (r.on) accv[r.widx] = r.wk + r.ph0 * e0 + r.ph1 * e1 + r.ph2 * e2;
+        }
         __syncthreads();
       }
-      for (int c = pair0; c < nc; c++) {
-        if (lane == c) gs_update();
+      for (int c = pair0; c < nc; c++) {                     // two-actor contacts one by one: row 0 = side A, row 1 = side B
+        float e0 = 0.0f, e1 = 0.0f, e2 = 0.0f, fb0 = 0.0f, fb1 = 0.0f, fb2 = 0.0f;
+        int widxB = 0;
+        bool onB = false;
+        if (row < 2) {
+          const RowStep r = row_products(row == 0 ? lds + L.phi + c * SIDE_STRIDE : lds + L.side + (c - nc_terr) * SIDE_STRIDE);
+          const float s0 = r.s0 + row_partner(r.s0), s1 = r.s1 + row_partner(r.s1), s2 = r.s2 + row_partner(r.s2);
+          row_solve(lds + L.srec + c * SREC_STRIDE, s0, s1, s2, lane == 0, e0, e1, e2);     // both rows solve the same numbers; one lane records lambda
+          if (row == 0 && r.on) accv[r.widx] = r.wk + r.ph0 * e0 + r.ph1 * e1 + r.ph2 * e2;
+          onB = row == 1 && r.on; widxB = r.widx; fb0 = r.ph0; fb1 = r.ph1; fb2 = r.ph2;
+        }
+        __syncthreads();
+        if (onB) accv[widxB] += fb0 * e0 + fb1 * e1 + fb2 * e2;                 // after side A's stores: the sides may share coordinates (self-contact)
         __syncthreads();
       }
     }
-  }
+    if (is_con) { const float4 q3 = reinterpret_cast<const float4*>(lds + L.srec + lane * SREC_STRIDE)[3]; cl0 = q3.x; cl1 = q3.y; cl2 = q3.z; }
+  } else
+    {
+      const bool is_terr = is_con && myB < 0, is_pair = is_con && myB >= 0;
+      int gstartA = 0, glenA = 0, maxlen = 0;
+      const int nact = A + PD + (SS ? 1 : 0);
+      for (int a = 0; a < nact; a++) {
+        const unsigned long long bm = __ballot(is_terr && myA == a);
+        const int len = __popcll(bm), start = bm ? __ffsll((long long)bm) - 1 : 0;
+        maxlen = len > maxlen ? len : maxlen;
+        if (is_terr && myA == a) { gstartA = start; glenA = len; }
+      }
+      const int npair = __popcll(__ballot(is_pair));
+      const int pair0 = nc - npair;
+      const int ncolA = (infoA >> 4) & 15, legA = (infoA & 15) - 1;
+      float* wbA = accv + wA;
+      float* wlA = accv + wA + 6 + (legA > 0 ? legA : 0) * 3;
+      auto gs_update = [&]() {
+        // side A from registers; its actor's coordinates are read once and written once
+        float wv[9];
+  #pragma unroll
+        for (int mm = 0; mm < 6; mm++) wv[mm] = mm < ncolA ? wbA[mm] : 0.0f;
+  #pragma unroll
+        for (int i = 0; i < 3; i++) wv[6 + i] = legA >= 0 ? wlA[i] : 0.0f;
+        float u0 = us0, u1 = us1, u2 = us2;
+  #pragma unroll
+        for (int mm = 0; mm < 6; mm++) { u0 += fA[mm] * wv[mm]; u1 += fA[6 + mm] * wv[mm]; u2 += fA[12 + mm] * wv[mm]; }
+  #pragma unroll
+        for (int i = 0; i < 3; i++) { u0 += fA[SIDE_Z + i] * wv[6 + i]; u1 += fA[SIDE_Z + 3 + i] * wv[6 + i]; u2 += fA[SIDE_Z + 6 + i] * wv[6 + i]; }
+        float fb[SIDE_STRIDE];
+        int ncolB = 0, legB = -1;
+        if (is_pair) {                         // side B: record from its LDS slot, coordinates of the second actor
+          const float4* r4 = reinterpret_cast<const float4*>(lds + L.side + (lane - nc_terr) * SIDE_STRIDE);
+  #pragma unroll
+          for (int w = 0; w < SIDE_STRIDE / 4; w++) { const float4 t = r4[w]; fb[4 * w] = t.x; fb[4 * w + 1] = t.y; fb[4 * w + 2] = t.z; fb[4 * w + 3] = t.w; }
+          ncolB = (infoB >> 4) & 15; legB = (infoB & 15) - 1;
+          const float* wb = accv + wB;
+          const float* wl = accv + wB + 6 + (legB > 0 ? legB : 0) * 3;
+  #pragma unroll
+          for (int mm = 0; mm < 6; mm++)
+            if (mm < ncolB) { const float x = wb[mm]; u0 += fb[mm] * x; u1 += fb[6 + mm] * x; u2 += fb[12 + mm] * x; }
+          if (legB >= 0) {
+  #pragma unroll
+            for (int i = 0; i < 3; i++) { const float x = wl[i]; u0 += fb[SIDE_Z + i] * x; u1 += fb[SIDE_Z + 3 + i] * x; u2 += fb[SIDE_Z + 6 + i] * x; }
+          }
+        }
+        const float ln = fmaxf(cl0 - (u0 - cbias) * ik00, 0.0f);
+        const float e0 = ln - cl0;
+        const float lim = mu * ln;
+        const float l1 = clampf(cl1 - (u1 + d10 * e0) * ik11, -lim, lim);
+        const float e1 = l1 - cl1;
+        const float l2 = clampf(cl2 - (u2 + d20 * e0 + d21 * e1) * ik22, -lim, lim);
+        const float e2 = l2 - cl2;
+        cl0 = ln; cl1 = l1; cl2 = l2;
+  #pragma unroll
+        for (int mm = 0; mm < 6; mm++)
+          if (mm < ncolA) wbA[mm] = wv[mm] + fA[mm] * e0 + fA[6 + mm] * e1 + fA[12 + mm] * e2;
+        if (legA >= 0) {
+  #pragma unroll
+          for (int i = 0; i < 3; i++) wlA[i] = wv[6 + i] + fA[SIDE_Z + i] * e0 + fA[SIDE_Z + 3 + i] * e1 + fA[SIDE_Z + 6 + i] * e2;
+        }
+        if (is_pair) {                         // after side A's stores: the two sides may share coordinates (self-contact)
+          float* wb = accv + wB;
+          float* wl = accv + wB + 6 + (legB > 0 ? legB : 0) * 3;
+  #pragma unroll
+          for (int mm = 0; mm < 6; mm++)
+            if (mm < ncolB) wb[mm] += fb[mm] * e0 + fb[6 + mm] * e1 + fb[12 + mm] * e2;
+          if (legB >= 0) {
+  #pragma unroll
+            for (int i = 0; i < 3; i++) wl[i] += fb[SIDE_Z + i] * e0 + fb[SIDE_Z + 3 + i] * e1 + fb[SIDE_Z + 6 + i] * e2;
+          }
+        }
+      };
+      for (int it = 0; it < m->solver_iterations; it++) {
+        for (int sidx = 0; sidx < maxlen; sidx++) {
+          if (is_terr && sidx < glenA && lane == gstartA + sidx) gs_update();
+          __syncthreads();
+        }
+        for (int c = pair0; c < nc; c++) {
+          if (lane == c) gs_update();
+          __syncthreads();
+        }
+      }
+    }
   TSTAMP(13);
   if (is_con) { float* cr = lds + L.con + lane * CON_STRIDE; cr[C_LAM] = cl0; cr[C_LAM + 1] = cl1; cr[C_LAM + 2] = cl2; }
   // impulses -> velocities: dv = T w.  Base: F w_b; leg: Lm w_l - G^T (F w_b); free body / 1-dof link: M^-1/2 w
@@ -1417,7 +1539,7 @@ __device__ __forceinline__ float softsign_p(float x) { return x * __builtin_amdg
 // Occupancy class of a scene shape.  Robot-only scenes (with or without the 1-dof link) need < 10 KiB of LDS per env, so 16 waves
 // fit a CU: they are compiled for 128 VGPRs (4 waves per SIMD) and 4096 envs run as ONE round of 16 waves per CU.  Scenes with
 // NPCs / statics need more LDS than that allows and stay at 2 waves per SIMD with the full register file.  (Overrides for
-// experiments: -DMQE_SUBSTEPS_WAVES=n, -DMQE_LAUNDER=0|1|2.)
+// experiments: -DMQE_SUBSTEPS_WAVES=n, -DMQE_LAUNDER=0..3.)
 template <int TP> struct SubstepsClass {
   static constexpr bool small = TP == 0 || TP == PS_F_LINK;
 #ifdef MQE_SUBSTEPS_WAVES
@@ -1428,7 +1550,7 @@ template <int TP> struct SubstepsClass {
 #ifdef MQE_LAUNDER
   static constexpr int launder = MQE_LAUNDER;
 #else
-  static constexpr int launder = small ? 2 : 0;
+  static constexpr int launder = small ? 2 : 0;       // bit 0: the model pointer, bit 1: the lane id
 #endif
 };
 template <int TA, int TP>
@@ -1437,7 +1559,7 @@ __global__ void __launch_bounds__(64, SubstepsClass<TP>::waves) k_substeps(const
   const int lane = threadIdx.x, e = blockIdx.x;
   const PhysShape<TA, TP> shp(m);
   const int A = shp.A, P = shp.P;
-  const PhysLds L = phys_lds_layout(A, P, shp.ND, shp.nbody, shp.ndof, m->nsph_env, shp.maxc);
+  const PhysLds L = phys_lds_layout(A, P, shp.ND, shp.nbody, shp.ndof, m->nsph_env, shp.maxc, shp.rowgs);
   const int nj = 12 * A;
   const int ctrl = m->control_type;
   const size_t R12 = (size_t)m->R * 12;
@@ -1459,15 +1581,16 @@ __global__ void __launch_bounds__(64, SubstepsClass<TP>::waves) k_substeps(const
   for (int k = 0; k < nsub; k++) {
     const bool last = k + 1 == nsub;
     // Register budget vs. recomputation (measured, MI355X).  Everything the body derives from the lane id and
-    // the model alone (indices, LDS addresses, masks, per-lane model constants: ~100 values) is invariant over the substeps; left
-    // alone the compiler hoists it out of this loop and the kernel needs ~250 VGPRs = 2 waves per SIMD.  Laundering the model
-    // pointer (launder >= 1) and the lane id (>= 2) once per substep turns the hoisting off: the body then fits 128 VGPRs with a
-    // handful of spills, at the price of re-deriving those values every substep (+17 % instructions).  That pays exactly when the
-    // LDS footprint lets 16 waves sit on a CU (SubstepsClass::small): 4096 envs then run as one round instead of two.
+    // the model alone (indices, LDS addresses, masks, per-lane model constants: ~330 VALU instructions, ~100 values) is invariant over
+    // the substeps; left alone the compiler hoists it out of this loop and the kernel needs ~250 VGPRs = 2 waves per SIMD.
+    // Laundering the lane id (bit 1) once per substep keeps everything lane-derived inside the loop: the body then fits 128 VGPRs
+    // with a handful of spills, at the price of re-deriving those values every substep; what depends on the model alone is
+    // wave-uniform, lives in SGPRs and stays hoisted (laundering the model pointer too, bit 0, costs 5-12 %).  That pays exactly when
+    // the LDS footprint lets 16 waves sit on a CU (SubstepsClass::small): 4096 envs then run as one round instead of two.
     const DevModel* mk = m;
     int lane_k = lane;
-    if (SubstepsClass<TP>::launder >= 1) asm volatile("" : "+s"(mk));
-    if (SubstepsClass<TP>::launder >= 2) {
+    if (SubstepsClass<TP>::launder & 1) asm volatile("" : "+s"(mk));
+    if (SubstepsClass<TP>::launder & 2) {
       asm volatile("" : "+v"(lane_k));
       lane_k &= 63;                                  // gives the value range of threadIdx.x back to the optimiser
     }
