@@ -372,12 +372,17 @@ __device__ __forceinline__ float mqe_randn(const DevModel* m, int e, int step_no
   return sqrtf(-2.0f * logf(1.0f - u1)) * cosf(6.2831855f * u2);
 }
 
-__device__ __forceinline__ void step_sheep_env(const DevModel* m, const DevState& st, int e, int step_no) {
-  int A = m->A, P = m->P;
-  float* root = st.root + (size_t)e * (A + P) * 13;
-  float avg[3] = {0, 0, 0};
+// The sheep script (go1_sheep.py:35-64) in three pieces so that k_post_physics can spread an env's sheep over lanes: flock mean
+// (+ the two logged statistics), one sheep's velocity increment from the pre-update state, and its write-back.  All increments are
+// formed before any row is written, as in the reference's vectorised update.
+__device__ __forceinline__ void sheep_flock_mean(const DevModel* m, const float* root, float* avg) {
+  const int A = m->A, P = m->P;
+  avg[0] = 0; avg[1] = 0; avg[2] = 0;
   for (int p = 0; p < P; p++) for (int k = 0; k < 3; k++) avg[k] += root[(A + p) * 13 + k];
   for (int k = 0; k < 3; k++) avg[k] /= (float)P;
+}
+__device__ __forceinline__ void sheep_flock_stats(const DevModel* m, const DevState& st, int e, const float* root, const float* avg) {
+  const int A = m->A, P = m->P;
   st.sheep_avg[e * 2] = avg[0]; st.sheep_avg[e * 2 + 1] = avg[1];
   float var = 0;
   for (int k = 0; k < 2; k++) {
@@ -386,43 +391,40 @@ __device__ __forceinline__ void step_sheep_env(const DevModel* m, const DevState
     var += acc / (float)P;
   }
   st.sheep_var[e] = var;
-  float dvs[MQE_MAX_NPCS][3];
-  for (int p = 0; p < P; p++) {
-    const float* sp = root + (A + p) * 13;
-    float dv[3];
-    for (int k = 0; k < 3; k++) {
-      // MQE_NOISE_SCRIPTED: the injected sequence (golden traces); otherwise a fresh draw every step, as the reference's randn_like
-      const float z = m->noise_mode == MQE_NOISE_SCRIPTED ? st.npc_noise[((size_t)e * P + p) * 3 + k]
-                                                          : (m->sheep_rand != 0.0f ? mqe_randn(m, e, step_no, (uint32_t)(p * 3 + k)) : 0.0f);
-      dv[k] = m->sheep_rand * z * 2.0f;
-    }
-    if (P != 1) {
-      float rel[3] = {avg[0] - sp[0], avg[1] - sp[1], avg[2] - sp[2]};
-      float nr = sqrtf(rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2]);
-      // a sheep exactly on the flock mean (the centre of the 3 x 3 grid at reset): torch gives 0 / 0 = NaN, which the clip of
-      // go1_sheep.py:59 passes on; the engine is built with -fno-honor-nans, so the cohesion term is dropped there instead
-      if (nr > 0.0f) for (int k = 0; k < 3; k++) dv[k] += m->sheep_rand * rel[k] / nr / 1.5f;
-    }
-    for (int a = 0; a < A; a++) {
-      const float* dp = root + a * 13;
-      float rel[3] = {sp[0] - dp[0], sp[1] - dp[1], sp[2] - dp[2]};
-      float sq[3] = {rel[0] * rel[0], rel[1] * rel[1], rel[2] * rel[2]};
-      float dis = sqrtf(sq[0] * sq[0] + sq[1] * sq[1] + sq[2] * sq[2]);
-      float den = powf(dis, 1.4f);
-      for (int k = 0; k < 3; k++) { float t = rel[k] / den; if (dis > 9.0f) t = 0.0f; dv[k] += m->sheep_scale * t; }
-    }
-    dv[2] = 0.0f;
-    for (int k = 0; k < 3; k++) dvs[p][k] = dv[k];
-  }
-  for (int p = 0; p < P; p++) {
-    float* sp = root + (A + p) * 13;
-    for (int k = 0; k < 3; k++) sp[7 + k] += dvs[p][k];
-    for (int k = 0; k < 2; k++) sp[7 + k] = clampf(sp[7 + k], -2.0f, 2.0f);
-    sp[2] = clampf(sp[2], 0.0f, 0.3f);
-    sp[3] = 0.0f; sp[4] = 0.0f;
-  }
 }
-
+__device__ __forceinline__ void sheep_increment(const DevModel* m, const DevState& st, int e, int p, const float* root, const float* avg, int step_no, float* dv) {
+  const int A = m->A, P = m->P;
+  const float* sp = root + (A + p) * 13;
+  for (int k = 0; k < 3; k++) {
+    // MQE_NOISE_SCRIPTED: the injected sequence (golden traces); otherwise a fresh draw every step, as the reference's randn_like
+    const float z = m->noise_mode == MQE_NOISE_SCRIPTED ? st.npc_noise[((size_t)e * P + p) * 3 + k]
+                                                        : (m->sheep_rand != 0.0f ? mqe_randn(m, e, step_no, (uint32_t)(p * 3 + k)) : 0.0f);
+    dv[k] = m->sheep_rand * z * 2.0f;
+  }
+  if (P != 1) {
+    float rel[3] = {avg[0] - sp[0], avg[1] - sp[1], avg[2] - sp[2]};
+    float nr = sqrtf(rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2]);
+    // a sheep exactly on the flock mean (the centre of the 3 x 3 grid at reset): torch gives 0 / 0 = NaN, which the clip of
+    // go1_sheep.py:59 passes on; the engine is built with -fno-honor-nans, so the cohesion term is dropped there instead
+    if (nr > 0.0f) for (int k = 0; k < 3; k++) dv[k] += m->sheep_rand * rel[k] / nr / 1.5f;
+  }
+  for (int a = 0; a < A; a++) {
+    const float* dp = root + a * 13;
+    float rel[3] = {sp[0] - dp[0], sp[1] - dp[1], sp[2] - dp[2]};
+    float sq[3] = {rel[0] * rel[0], rel[1] * rel[1], rel[2] * rel[2]};
+    float dis = sqrtf(sq[0] * sq[0] + sq[1] * sq[1] + sq[2] * sq[2]);
+    float den = powf(dis, 1.4f);
+    for (int k = 0; k < 3; k++) { float t = rel[k] / den; if (dis > 9.0f) t = 0.0f; dv[k] += m->sheep_scale * t; }
+  }
+  dv[2] = 0.0f;
+}
+__device__ __forceinline__ void sheep_apply(float* root, int A, int p, const float* dv) {
+  float* sp = root + (A + p) * 13;
+  for (int k = 0; k < 3; k++) sp[7 + k] += dv[k];
+  for (int k = 0; k < 2; k++) sp[7 + k] = clampf(sp[7 + k], -2.0f, 2.0f);
+  sp[2] = clampf(sp[2], 0.0f, 0.3f);
+  sp[3] = 0.0f; sp[4] = 0.0f;
+}
 // wrapper observation + reward for env e.  npc = the `root_states_npc` rows the wrapper sees ([P][13]); see oracle.
 // side_effects: 1 on the wrapper-level paths (mqe_step, mqe_wrapper_eval); the Go1-level mqe_post_physics_step passes 0 so that the
 // state stays exactly what Go1.step leaves (go1tug re-poses its slider from the wrapper)
@@ -741,6 +743,7 @@ __global__ void __launch_bounds__(64) k_post_physics(const DevModel* m, DevState
   // the block's envs: the robot lanes write them to LDS (the wrapper reads the obs rows back from there, not through L2)
   // and the whole wavefront stores them 16 B per lane.
   __shared__ float4 s_bag4[POST_EPW * AM * MQE_OBS_BAG / 4], s_la4[POST_EPW * AM * 24 / 4];
+  __shared__ float s_npc[POST_EPW * MQE_MAX_NPCS * 13];
   float* s_bag = reinterpret_cast<float*>(s_bag4);
   float* s_la = reinterpret_cast<float*>(s_la4);
   const int A = m->A, P = m->P;
@@ -836,10 +839,37 @@ __global__ void __launch_bounds__(64) k_post_physics(const DevModel* m, DevState
     st.gait[i] = gi1;
   }
   // wrapper's view of root_states_npc: copy taken before the NPC script (legged_robot.py:136); xy/vel only are read
-  float npc_pre[MQE_MAX_NPCS * 13];
+  // (staged in LDS by the whole wavefront: as a per-lane array of P * 13 floats it lived in scratch memory)
+  float* npc_pre = s_npc + le * MQE_MAX_NPCS * 13;
+  {
+    const int e0 = blockIdx.x * POST_EPW, nenv = min(POST_EPW, m->N - e0), per = P * 13;
+    for (int t = threadIdx.x; t < nenv * per; t += 64) {
+      const int sl = t / per, r = t - sl * per;
+      s_npc[sl * MQE_MAX_NPCS * 13 + r] = st.root[((size_t)(e0 + sl) * (A + P) + A) * 13 + r];
+    }
+    __syncthreads();
+  }
+  if (m->npc_kind == MQE_NPC_SHEEP) {           // wave-uniform.  The 64 / POST_EPW lanes of an env share its sheep (lane a: sheep a, a + 8, ..)
+    constexpr int LPE = 64 / POST_EPW, NPASS = (MQE_MAX_NPCS + LPE - 1) / LPE;
+    float dvs[NPASS][3];
+    if (e < m->N) {
+      float avg[3];
+      sheep_flock_mean(m, root, avg);           // every lane of the env, the same loop -> the same bits
+      if (lead) sheep_flock_stats(m, st, e, root, avg);
+#pragma unroll
+      for (int q = 0; q < NPASS; q++)
+        if (a + q * LPE < P) sheep_increment(m, st, e, a + q * LPE, root, avg, step_no, dvs[q]);
+    }
+    __syncthreads();                            // every increment is formed from the pre-update flock
+    if (e < m->N) {
+#pragma unroll
+      for (int q = 0; q < NPASS; q++)
+        if (a + q * LPE < P) sheep_apply(root, A, a + q * LPE, dvs[q]);
+    }
+    __threadfence();
+    __syncthreads();                            // the sheep rows are final before the lead lane's reset / wrapper reads
+  }
   if (lead) {
-    for (int k = 0; k < P * 13; k++) npc_pre[k] = root[A * 13 + k];
-    if (m->npc_kind == MQE_NPC_SHEEP) step_sheep_env(m, st, e, step_no);
     if (reset) {                                // rare: the reset writes memory, the robot lanes refresh their registers from it
       reset_env_dev(m, st, e);
       for (int k = 0; k < P * 13; k++) npc_pre[k] = root[A * 13 + k];
