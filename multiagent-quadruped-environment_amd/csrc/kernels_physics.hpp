@@ -52,7 +52,7 @@ __device__ __forceinline__ float lane_prev(float x) {
 // permutations, then the mirror inside each half row and inside the row).  Both partners of a step add the same two operands, so
 // all 16 lanes end with bitwise the same sum.
 template <int CTRL> __device__ __forceinline__ float dpp_take(float x) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false));
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
 }
 __device__ __forceinline__ float row16_sum(float x) {
   x += dpp_take<0xB1>(x);      // quad_perm [1,0,3,2]
@@ -1223,9 +1223,11 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       const int info = __float_as_int(rec[SIDE_INFO]);
       r.on = k < (info & 15);
       r.widx = (info >> 10) + k + (((info >> 4) & 63) & klegmask);
-      const float r0 = rec[koff], r1 = rec[koff + kstr], r2 = rec[koff + 2 * kstr], ww = accv[r.on ? r.widx : 0];
-      r.ph0 = r.on ? r0 : 0.0f; r.ph1 = r.on ? r1 : 0.0f; r.ph2 = r.on ? r2 : 0.0f; r.wk = r.on ? ww : 0.0f;
+      const float ww = accv[r.on ? r.widx : 0];
+      r.ph0 = rec[koff]; r.ph1 = rec[koff + kstr]; r.ph2 = rec[koff + 2 * kstr];   // lanes past the side's coordinates read finite record words ...
+      r.wk = r.on ? ww : 0.0f;                                                     // ... and multiply them by zero
       float a0 = r.ph0 * r.wk, a1 = r.ph1 * r.wk, a2 = r.ph2 * r.wk;       // three independent butterflies, interleaved
+      asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2));    // products stay products: contracted into the first step they cost mov_dpp + fma each
       a0 += dpp_take<0xB1>(a0); a1 += dpp_take<0xB1>(a1); a2 += dpp_take<0xB1>(a2);
       a0 += dpp_take<0x4E>(a0); a1 += dpp_take<0x4E>(a1); a2 += dpp_take<0x4E>(a2);
       a0 += dpp_take<0x141>(a0); a1 += dpp_take<0x141>(a1); a2 += dpp_take<0x141>(a2);

@@ -171,11 +171,13 @@ static int finalize_frag(mqe_sim* s, GemmLayer* L) {
 // runtime form
 static void (*pick_substeps(const DevModel& m))(const DevModel*, DevState, int, int) {
   const int feat = (m.has_seesaw ? PS_F_LINK : 0) | (m.n_npc_dyn > 0 ? PS_F_NPC : 0) | (m.has_box ? PS_F_BOX : 0) | (m.n_static > 0 ? PS_F_STATIC : 0);
-  if (feat == 0 && m.P == 0) {
-    if (m.A == 2) return k_substeps<2, 0>;                                   // go1gate
-    if (m.A == 1) return k_substeps<1, 0>;                                   // go1plane
+  if (m.rowgs) {                                                             // (MQE_LANE_SWEEP=1 sends these scenes to the generic kernels below)
+    if (feat == 0 && m.P == 0) {
+      if (m.A == 2) return k_substeps<2, 0>;                                 // go1gate
+      if (m.A == 1) return k_substeps<1, 0>;                                 // go1plane
+    }
+    if (m.A == 2 && feat == PS_F_LINK) return k_substeps<2, PS_F_LINK>;      // go1seesaw, go1revolvingdoor, go1tug
   }
-  if (m.A == 2 && feat == PS_F_LINK) return k_substeps<2, PS_F_LINK>;        // go1seesaw, go1revolvingdoor, go1tug
   if (m.A == 2 && feat == PS_F_NPC) return k_substeps<2, PS_F_NPC>;          // go1sheep-*, go1football-1vs1
   if (m.A == 3 && feat == PS_F_NPC) return k_substeps<3, PS_F_NPC>;          // go1football-defender
   if (m.A == 4 && feat == PS_F_NPC) return k_substeps<4, PS_F_NPC>;          // go1football-2vs2
@@ -267,6 +269,7 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   m.maxc = mqe_maxc(A, P, m.cap_npc);
   if (m.ndof_env > 128 || m.nbody_env > 64) { return fail(-4, "env has more than 64 bodies or 128 generalized velocities: does not fit one wavefront"); }
   m.rowgs = (m.n_npc_dyn == 0 && !m.has_box && m.n_static == 0 && (seesaw || P == 0) && A + (seesaw ? 1 : 0) <= 4) ? 1 : 0;   // = what pick_substeps' <A,0> / <2,LINK> assume
+  if (getenv("MQE_LANE_SWEEP")) m.rowgs = 0;      // tests: the other lane mapping of the contact sweep on the same scene (tests/test_gpu_parity.py)
   PhysLds L = phys_lds_layout(A, P, s->ND, m.nbody_env, m.ndof_env, m.nsph_env, m.maxc, m.rowgs);
   s->phys_lds_bytes = (size_t)L.total * 4;
   if (getenv("MQE_VERBOSE")) fprintf(stderr, "mqe: physics LDS %zu B per env (wavefront)\n", s->phys_lds_bytes);

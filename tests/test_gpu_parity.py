@@ -126,6 +126,34 @@ def test_fused_rollout_matches_oracle(task, N):
     assert int(eh.tensor(abi.T_CONTACT_OVERFLOW).sum()) == int(eo.tensor(abi.T_CONTACT_OVERFLOW).sum())
 
 
+@pytest.mark.parametrize("task,N", [("go1gate", 256), ("go1seesaw", 64), ("go1tug", 32)])
+def test_row_sweep_and_lane_sweep_agree(monkeypatch, task, N):
+    """The contact sweep has two lane mappings (kernels_physics.hpp: one DPP row per actor for scenes of robots and the 1-dof link,
+    one lane per contact otherwise).  MQE_LANE_SWEEP=1 sends a robot-only scene down the other one (generic kernels, lane sweep,
+    other LDS layout): same records, same Gauss-Seidel order, different summation trees -> 8 fused steps agree to rounding and
+    every reset flag and contact-overflow count is identical."""
+    d, keep, _ = make_desc(task, N)
+    er = hip_engine(d, keep)
+    monkeypatch.setenv("MQE_LANE_SWEEP", "1")
+    d2, keep2, _ = make_desc(task, N)
+    el = hip_engine(d2, keep2)
+    monkeypatch.delenv("MQE_LANE_SWEEP")
+    er.reset_all(); el.reset_all()
+    g = torch.Generator().manual_seed(5)
+    Aw = er.tensor(abi.T_WRAPPER_OBS).shape[1]
+    for t in range(8):
+        a = (torch.rand(N, Aw, 3, generator=g) * 2 - 1).cuda().contiguous()
+        er.step(a); el.step(a)
+        torch.cuda.synchronize()
+        assert (er.tensor(abi.T_RESET_BUF) == el.tensor(abi.T_RESET_BUF)).all()
+        if t in (0, 3):
+            close(er.tensor(abi.T_ROOT_STATE), el.tensor(abi.T_ROOT_STATE), atol=2e-5 if t == 0 else 2e-4, what=f"root state step {t}")
+            close(er.tensor(abi.T_DOF_STATE), el.tensor(abi.T_DOF_STATE), atol=2e-4 if t == 0 else 5e-3, what=f"dof state step {t}")
+    dev = (er.tensor(abi.T_ROOT_STATE)[..., :3] - el.tensor(abi.T_ROOT_STATE)[..., :3]).abs().max(dim=-1).values.flatten()
+    assert float(dev.median()) < 1e-5 and float(dev.quantile(0.99)) < 1e-4 and float(dev.max()) < 2e-3, (float(dev.median()), float(dev.max()))
+    assert int(er.tensor(abi.T_CONTACT_OVERFLOW).sum()) == int(el.tensor(abi.T_CONTACT_OVERFLOW).sum())
+
+
 @pytest.mark.parametrize("N,split", [(1, "0"), (1, "1"), (3, "1"), (37, "0"), (37, "1")])
 def test_tiny_and_ragged_batches(monkeypatch, N, split):
     """batch sizes far below a tile of any kernel (1 env = 2 robots: 2 of the 128 GEMM rows, 2 of the tail's 32, one physics
