@@ -126,7 +126,7 @@ __device__ __forceinline__ float wave_sum(float x) {
 #define LEG_LM 6
 #define LEG_G 12
 #define LEGC_STRIDE 24
-#define CON_STRIDE 24
+#define CON_STRIDE 16
 // Contact side record (7 words): Phi = the side's Jacobian in coordinates in which the actor's inverse mass matrix is the
 // identity.  Robot: M^-1 = [S^-1, -S^-1 G; -G^T S^-1, Mll^-1 + G^T S^-1 G] = T T^T with T = [F 0; -G^T F, Lm] (S^-1 = F F^T, F upper
 // triangular; Mll^-1 = Lm Lm^T per leg), so Phi = J T = [ U | Z' ],  U = (J_base - J_leg G^T) F (3 x 6),  Z' = J_leg Lm (3 x 3, the
@@ -148,14 +148,20 @@ __device__ __forceinline__ void body_store(float* rec, const float* R, V3 p, V3 
   r4[2] = make_float4(R[8], p.x, p.y, p.z); r4[3] = make_float4(a.x, a.y, a.z, 0.0f);
 }
 // contact record in 16 B words: [actor A, link A, actor B (-1: static), link B] [point, separation] [normal, reported body A]
-// [tangent 1, -] [tangent 2, -] [impulse, reported body B]
-enum { C_IDS = 0, C_P = 4, C_SD = 7, C_N = 8, C_REPA = 11, C_T1 = 12, C_T2 = 16, C_LAM = 20, C_REPB = 23 };
+// [contact force on A (written after the sweep of the last substep), reported body B]; the tangent frame is a function of the normal
+enum { C_IDS = 0, C_P = 4, C_SD = 7, C_N = 8, C_REPA = 11, C_F = 12, C_REPB = 15 };
+__device__ __forceinline__ void contact_tangents(V3 n, V3& t1, V3& t2) {
+  const V3 aa = fabsf(n.z) > 0.7f ? v3(1, 0, 0) : v3(0, 0, 1);
+  t1 = cross(aa, n);
+  t1 = (1.0f / sqrtf(dot(t1, t1))) * t1;
+  t2 = cross(n, t1);
+}
 __device__ __forceinline__ void con_store(float* cr, int a, int linkA, int b, int linkB, V3 p, V3 n, float sd, int repA, int repB) {
   float4* c4 = reinterpret_cast<float4*>(cr);
   c4[0] = make_float4(__int_as_float(a), __int_as_float(linkA), __int_as_float(b), __int_as_float(linkB));
   c4[1] = make_float4(p.x, p.y, p.z, sd);
   c4[2] = make_float4(n.x, n.y, n.z, __int_as_float(repA));
-  c4[5] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(repB));
+  c4[3] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(repB));
 }
 
 __host__ __device__ inline int mqe_maxc(int A, int P, int cap_npc) { int v = 8 * A + cap_npc * P; return v > 40 ? 40 : v; }
@@ -214,7 +220,9 @@ enum { PS_LOAD_STATE = 1, PS_LOAD_TAU = 2, PS_STORE_STATE = 4, PS_WRITE_CF = 8 }
 //   TP >= 0: which kinds of non-robot objects the scene has -- PS_F_LINK (fixed base + 1-dof link: seesaw, door, tug),
 //            PS_F_NPC (free bodies: ball, sheep, box), PS_F_BOX (the free body is the oriented box), PS_F_STATIC (scenery
 //            boxes); 0 = robots only.  TP = -1: everything read from the model at run time.
-enum { PS_F_LINK = 1, PS_F_NPC = 2, PS_F_BOX = 4, PS_F_STATIC = 8 };
+enum { PS_F_LINK = 1, PS_F_NPC = 2, PS_F_BOX = 4, PS_F_STATIC = 8,
+       PS_F_FEW = 16 };   // at most 4 actors and at most 10 KiB of LDS per env: the scene runs the row sweep with all envs resident (SubstepsClass)
+template <int TP> struct ShapeClass { static constexpr bool small = TP == 0 || TP == PS_F_LINK || (TP > 0 && (TP & PS_F_FEW) != 0); };
 template <int TA, int TP>
 struct PhysShape {
   const int A, P, PD, npcdof, ND, nbody, ndof, maxc, n_static;
@@ -227,7 +235,7 @@ struct PhysShape {
         ndof((TA > 0 && TP == 0) ? TA * MQE_RD : m->ndof_env), maxc((TA > 0 && TP == 0) ? mqe_maxc(TA, 0, 2) : m->maxc),
         n_static((TP < 0 || (TP & PS_F_STATIC)) ? m->n_static : 0),
         has_seesaw(TP < 0 ? m->has_seesaw != 0 : (TP & PS_F_LINK) != 0), has_box(TP < 0 ? m->has_box != 0 : (TP & PS_F_BOX) != 0),
-        rowgs(TP < 0 ? m->rowgs != 0 : (TP == 0 || TP == PS_F_LINK)) {}
+        rowgs(ShapeClass<TP>::small ? true : m->rowgs != 0) {}
 };
 
 template <int TA, int TP>
@@ -1012,12 +1020,8 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     if (myA < A || (myB >= 0 && myB < A)) mu = mu_robot;
     const int bodyA = __float_as_int(w0.y), bodyB = __float_as_int(w0.w);
     const V3 p = v3(w1.x, w1.y, w1.z), n = v3(w2.x, w2.y, w2.z);
-    const V3 aa = fabsf(n.z) > 0.7f ? v3(1, 0, 0) : v3(0, 0, 1);
-    V3 t1 = cross(aa, n);
-    t1 = (1.0f / sqrtf(dot(t1, t1))) * t1;
-    const V3 t2 = cross(n, t1);
-    reinterpret_cast<float4*>(cr)[3] = make_float4(t1.x, t1.y, t1.z, 0.0f);
-    reinterpret_cast<float4*>(cr)[4] = make_float4(t2.x, t2.y, t2.z, 0.0f);
+    V3 t1, t2;
+    contact_tangents(n, t1, t2);
     const float sd = w1.w;
     cbias = sd >= 0 ? -sd / dt : fminf(-sd * m->erp / dt, m->max_depen);
     for (int side = 0; side < 2; side++) {
@@ -1361,7 +1365,14 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       }
     }
   TSTAMP(13);
-  if (is_con) { float* cr = lds + L.con + lane * CON_STRIDE; cr[C_LAM] = cl0; cr[C_LAM + 1] = cl1; cr[C_LAM + 2] = cl2; }
+  if (is_con && (flags & PS_WRITE_CF)) {        // the contact's force on its side A, for the per-body sums further down
+    float* cr = lds + L.con + lane * CON_STRIDE;
+    const V3 n = ld3(cr + C_N);
+    V3 t1, t2;
+    contact_tangents(n, t1, t2);
+    const V3 f = (1.0f / dt) * (cl0 * n + cl1 * t1 + cl2 * t2);
+    cr[C_F] = f.x; cr[C_F + 1] = f.y; cr[C_F + 2] = f.z;
+  }
   // impulses -> velocities: dv = T w.  Base: F w_b; leg: Lm w_l - G^T (F w_b); free body / 1-dof link: M^-1/2 w
   for (int d = lane; d < ndof; d += 64) {
     float dv;
@@ -1461,7 +1472,6 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
 
   // ---- net contact force per reported body (deterministic: contact order) ---------------------------------------------------
   if (flags & PS_WRITE_CF) {
-    const float idt = 1.0f / dt;
     float* g_cf = st.cf + (size_t)e * m->NBR * 3;
     for (int rb = lane; rb < m->NBR; rb += 64) {
       V3 F = v3(0, 0, 0);
@@ -1469,7 +1479,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
         const float* cr = lds + L.con + c * CON_STRIDE;
         const int ra = __float_as_int(cr[C_REPA]), rb2 = __float_as_int(cr[C_REPB]);
         if (ra == rb || rb2 == rb) {
-          const V3 f = idt * (cr[C_LAM] * ld3(cr + C_N) + cr[C_LAM + 1] * ld3(cr + C_T1) + cr[C_LAM + 2] * ld3(cr + C_T2));
+          const V3 f = ld3(cr + C_F);
           F = (ra == rb) ? F + f : F - f;
         }
       }
@@ -1538,12 +1548,12 @@ __device__ __forceinline__ float softsign_p(float x) { return x * __builtin_amdg
 
 #define ACT_TILES 2       // 2 x 32 joints >= 12 * MQE_MAX_AGENTS(=4)... agents <= 4 need 48 joints
 
-// Occupancy class of a scene shape.  Robot-only scenes (with or without the 1-dof link) need < 10 KiB of LDS per env, so 16 waves
-// fit a CU: they are compiled for 128 VGPRs (4 waves per SIMD) and 4096 envs run as ONE round of 16 waves per CU.  Scenes with
-// NPCs / statics need more LDS than that allows and stay at 2 waves per SIMD with the full register file.  (Overrides for
+// Occupancy class of a scene shape.  Scenes of two robots and at most one more object (link, ball, box, scenery) need < 10 KiB of LDS
+// per env, so 16 waves fit a CU: they are compiled for 128 VGPRs (4 waves per SIMD) and 4096 envs run as ONE round of 16 waves per
+// CU.  Larger scenes need more LDS than that allows and stay at 2 waves per SIMD with the full register file.  (Overrides for
 // experiments: -DMQE_SUBSTEPS_WAVES=n, -DMQE_LAUNDER=0..3.)
 template <int TP> struct SubstepsClass {
-  static constexpr bool small = TP == 0 || TP == PS_F_LINK;
+  static constexpr bool small = ShapeClass<TP>::small;
 #ifdef MQE_SUBSTEPS_WAVES
   static constexpr int waves = MQE_SUBSTEPS_WAVES;
 #else

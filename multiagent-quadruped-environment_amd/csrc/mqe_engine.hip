@@ -169,20 +169,22 @@ static int finalize_frag(mqe_sim* s, GemmLayer* L) {
 
 // k_substeps is compiled for the env shapes of the shipped tasks (kernels_physics.hpp: PhysShape); everything else takes the
 // runtime form
-static void (*pick_substeps(const DevModel& m))(const DevModel*, DevState, int, int) {
+static void (*pick_substeps(const DevModel& m, size_t lds_bytes))(const DevModel*, DevState, int, int) {
   const int feat = (m.has_seesaw ? PS_F_LINK : 0) | (m.n_npc_dyn > 0 ? PS_F_NPC : 0) | (m.has_box ? PS_F_BOX : 0) | (m.n_static > 0 ? PS_F_STATIC : 0);
-  if (m.rowgs) {                                                             // (MQE_LANE_SWEEP=1 sends these scenes to the generic kernels below)
+  // the small class (row sweep compiled in, 128 VGPRs, every env resident): <= 4 actors and 16 LDS footprints per CU
+  if (m.rowgs && lds_bytes <= 10240) {                                       // (MQE_LANE_SWEEP=1 sends these scenes to the kernels below)
     if (feat == 0 && m.P == 0) {
       if (m.A == 2) return k_substeps<2, 0>;                                 // go1gate
       if (m.A == 1) return k_substeps<1, 0>;                                 // go1plane
     }
     if (m.A == 2 && feat == PS_F_LINK) return k_substeps<2, PS_F_LINK>;      // go1seesaw, go1revolvingdoor, go1tug
+    if (m.A == 2 && feat == PS_F_NPC) return k_substeps<2, PS_F_NPC | PS_F_FEW>;                  // go1football-1vs1, a single sheep
+    if (m.A == 2 && feat == (PS_F_NPC | PS_F_BOX)) return k_substeps<2, PS_F_NPC | PS_F_BOX | PS_F_FEW>;   // go1pushbox
+    if (m.A == 2 && feat == PS_F_STATIC) return k_substeps<2, PS_F_STATIC | PS_F_FEW>;           // go1bridge, go1wrestling
   }
-  if (m.A == 2 && feat == PS_F_NPC) return k_substeps<2, PS_F_NPC>;          // go1sheep-*, go1football-1vs1
+  if (m.A == 2 && feat == PS_F_NPC) return k_substeps<2, PS_F_NPC>;          // go1sheep-*
   if (m.A == 3 && feat == PS_F_NPC) return k_substeps<3, PS_F_NPC>;          // go1football-defender
   if (m.A == 4 && feat == PS_F_NPC) return k_substeps<4, PS_F_NPC>;          // go1football-2vs2
-  if (m.A == 2 && feat == (PS_F_NPC | PS_F_BOX)) return k_substeps<2, PS_F_NPC | PS_F_BOX>;   // go1pushbox
-  if (m.A == 2 && feat == PS_F_STATIC) return k_substeps<2, PS_F_STATIC>;    // go1bridge, go1wrestling
   if (m.A == 2) return k_substeps<2, -1>;
   return k_substeps<0, -1>;
 }
@@ -268,7 +270,7 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   m.nsph_env = A * d->robot.n_spheres + m.n_npc_dyn * d->npc_n_spheres;
   m.maxc = mqe_maxc(A, P, m.cap_npc);
   if (m.ndof_env > 128 || m.nbody_env > 64) { return fail(-4, "env has more than 64 bodies or 128 generalized velocities: does not fit one wavefront"); }
-  m.rowgs = (m.n_npc_dyn == 0 && !m.has_box && m.n_static == 0 && (seesaw || P == 0) && A + (seesaw ? 1 : 0) <= 4) ? 1 : 0;   // = what pick_substeps' <A,0> / <2,LINK> assume
+  m.rowgs = (A + m.n_npc_dyn + (seesaw ? 1 : 0) <= 4) ? 1 : 0;      // one 16-lane row per actor; the <A,0> / <2,LINK> kernels assume it
   if (getenv("MQE_LANE_SWEEP")) m.rowgs = 0;      // tests: the other lane mapping of the contact sweep on the same scene (tests/test_gpu_parity.py)
   PhysLds L = phys_lds_layout(A, P, s->ND, m.nbody_env, m.ndof_env, m.nsph_env, m.maxc, m.rowgs);
   s->phys_lds_bytes = (size_t)L.total * 4;
@@ -277,7 +279,7 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   // the records the physics kernel moves as 16 B words must start on 16 B (kernels_physics.hpp)
   if ((L.body | L.sph | L.con | L.side | L.leg | L.legc | L.sinv | L.fcol | L.acc | L.rhs | L.phi | L.srec) & 3) { return fail(-4, "physics LDS layout: a 16 B record area is misaligned"); }
   if (s->phys_lds_bytes > 160 * 1024) { return fail(-4, "physics LDS footprint exceeds 160 KiB"); }
-  s->substeps_fn = pick_substeps(m);
+  s->substeps_fn = pick_substeps(m, s->phys_lds_bytes);
   if (s->phys_lds_bytes > 48 * 1024)
     if (hipFuncSetAttribute((const void*)k_simulate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->phys_lds_bytes) != hipSuccess ||
         hipFuncSetAttribute((const void*)s->substeps_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->phys_lds_bytes) != hipSuccess) {
