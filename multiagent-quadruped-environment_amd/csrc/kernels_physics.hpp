@@ -221,8 +221,12 @@ enum { PS_LOAD_STATE = 1, PS_LOAD_TAU = 2, PS_STORE_STATE = 4, PS_WRITE_CF = 8 }
 //            PS_F_NPC (free bodies: ball, sheep, box), PS_F_BOX (the free body is the oriented box), PS_F_STATIC (scenery
 //            boxes); 0 = robots only.  TP = -1: everything read from the model at run time.
 enum { PS_F_LINK = 1, PS_F_NPC = 2, PS_F_BOX = 4, PS_F_STATIC = 8,
-       PS_F_FEW = 16 };   // at most 4 actors and at most 10 KiB of LDS per env: the scene runs the row sweep with all envs resident (SubstepsClass)
-template <int TP> struct ShapeClass { static constexpr bool small = TP == 0 || TP == PS_F_LINK || (TP > 0 && (TP & PS_F_FEW) != 0); };
+       PS_F_FEW = 16,     // at most 4 actors and at most 10 KiB of LDS per env: the scene runs the row sweep with all envs resident (SubstepsClass)
+       PS_F_ROW = 32 };   // at most 4 actors: row sweep compiled in (without it a TP >= 0 kernel of a larger scene has the lane sweep only)
+template <int TP> struct ShapeClass {
+  static constexpr bool small = TP == 0 || TP == PS_F_LINK || (TP > 0 && (TP & PS_F_FEW) != 0);
+  static constexpr int sweep = small || (TP > 0 && (TP & PS_F_ROW) != 0) ? 1 : (TP < 0 ? -1 : 0);    // 1 row, 0 lane, -1 the model says (generic kernels)
+};
 template <int TA, int TP>
 struct PhysShape {
   const int A, P, PD, npcdof, ND, nbody, ndof, maxc, n_static;
@@ -235,7 +239,7 @@ struct PhysShape {
         ndof((TA > 0 && TP == 0) ? TA * MQE_RD : m->ndof_env), maxc((TA > 0 && TP == 0) ? mqe_maxc(TA, 0, 2) : m->maxc),
         n_static((TP < 0 || (TP & PS_F_STATIC)) ? m->n_static : 0),
         has_seesaw(TP < 0 ? m->has_seesaw != 0 : (TP & PS_F_LINK) != 0), has_box(TP < 0 ? m->has_box != 0 : (TP & PS_F_BOX) != 0),
-        rowgs(ShapeClass<TP>::small ? true : m->rowgs != 0) {}
+        rowgs(ShapeClass<TP>::sweep >= 0 ? ShapeClass<TP>::sweep == 1 : m->rowgs != 0) {}
 };
 
 template <int TA, int TP>

@@ -182,9 +182,10 @@ static void (*pick_substeps(const DevModel& m, size_t lds_bytes))(const DevModel
     if (m.A == 2 && feat == (PS_F_NPC | PS_F_BOX)) return k_substeps<2, PS_F_NPC | PS_F_BOX | PS_F_FEW>;   // go1pushbox
     if (m.A == 2 && feat == PS_F_STATIC) return k_substeps<2, PS_F_STATIC | PS_F_FEW>;           // go1bridge, go1wrestling
   }
-  if (m.A == 2 && feat == PS_F_NPC) return k_substeps<2, PS_F_NPC>;          // go1sheep-*
-  if (m.A == 3 && feat == PS_F_NPC) return k_substeps<3, PS_F_NPC>;          // go1football-defender
-  if (m.A == 4 && feat == PS_F_NPC) return k_substeps<4, PS_F_NPC>;          // go1football-2vs2
+  // larger scenes: 2 waves per SIMD; the sweep variant is compiled in (the kernel's LDS layout has to be the one computed from m.rowgs)
+  if (m.A == 3 && feat == PS_F_NPC && m.rowgs) return k_substeps<3, PS_F_NPC | PS_F_ROW>;   // go1football-defender
+  if (m.A == 2 && feat == PS_F_NPC && !m.rowgs) return k_substeps<2, PS_F_NPC>;             // go1sheep-* (flocks)
+  if (m.A == 4 && feat == PS_F_NPC && !m.rowgs) return k_substeps<4, PS_F_NPC>;             // go1football-2vs2
   if (m.A == 2) return k_substeps<2, -1>;
   return k_substeps<0, -1>;
 }
