@@ -6,19 +6,19 @@
 //   body lanes    (A*13 + P)   forward kinematics by tree level, spatial inertia / bias wrench about the base origin,
 //                              composite sums up the 3-link leg chains; a child's parent is the neighbouring lane, so frames,
 //                              composites and joint axes travel through DPP wave shifts, not LDS
-//   hip lanes     (A*4)        3x3 leg block inverse, Schur terms;   (A*6) lanes: 6x6 base Schur complement inverse
-//   row / task lanes           rows of M^-1 (lane = row), B = M^-1 J^T per (contact side, dof), 3x3 coupling blocks per contact pair
-//   sphere lanes  (2*27 / P)   collision spheres vs ground plane / wall signed-distance field / static scenery boxes /
+//   hip lanes     (A*4)        3x3 leg block: Mll^-1, its Cholesky factor, G = Mbl Mll^-1;   (A*6) lanes: 6x6 base Schur complement,
+//                              Cholesky-factored -- the inverse mass matrix exists only as these factors (M^-1 = T T^T, see SIDE_STRIDE)
+//   sphere lanes  (2*27 / P)   collision spheres vs ground (plane or relief map) / wall signed-distance field / static scenery boxes /
 //                              1-dof link (plank, door, disc) / free box / other actors' spheres, compacted with ballots
 //                              into a bounded, canonically ordered contact list
-//   contact lanes (<= maxc)    sparse Jacobian rows, then projected Gauss-Seidel in CONTACT space: a lane owns its contact's
-//                              relative velocity and impulse, increments travel by ds_bpermute / v_readlane
-//   dof lanes     (<= 2 x 64)  unconstrained velocity, impulses -> velocities, joint limits, integration (velocities in LDS)
-// Link frames, M^-1 (18x18 per robot), contact rows and coupling blocks live in LDS (layout: phys_lds_layout); the records
-// that are moved whole (link frames, spheres, contacts, leg blocks, Jacobian rows) are laid out in 16 B words and accessed
-// with ds_read_b128 / ds_write_b128 -- a quarter of the LDS instructions and of the waits in front of them.  With
-// k_substeps the state is read from and written to HBM once per env.step(), coalesced (the env-major rows of one env are
-// contiguous), and the actuator network / PD law of every substep runs inside the same wavefront.
+//   contact lanes (<= maxc)    the side records Phi = J T (28 floats) and the contact's own 3x3 block
+//   sweep                      projected Gauss-Seidel on w = sum Phi^T lambda (one float per generalized coordinate): either one
+//                              DPP row of 16 lanes per ACTOR (lane = coordinate; scenes of <= 4 actors) or one lane per contact
+//   dof lanes     (<= 2 x 64)  unconstrained velocity, dv = T w, joint limits, integration (velocities in LDS)
+// Link frames, the factors, contact and side records live in LDS (layout: phys_lds_layout: 9-10 KiB for two robots and one more
+// object = 16 envs per CU); the records that are moved whole are laid out in 16 B words and accessed with ds_read_b128 /
+// ds_write_b128.  With k_substeps the state is read from and written to HBM once per env.step(), coalesced (the env-major rows
+// of one env are contiguous), and the actuator network / PD law of every substep runs inside the same wavefront.
 #pragma once
 #include "mqe_common.hpp"
 

@@ -14,8 +14,8 @@ Aw = e.tensor(abi.T_WRAPPER_OBS).shape[1]
 for t in range(40):
     e.step(torch.zeros(64, Aw, 3, device="cuda"))
 torch.cuda.synchronize()
-names = ["load", "FK", "inertia+shuffles+Mcols", "leg blocks", "schur 6x6", "Minv rows", "v*", "spheres", "terrain contacts",
-         "pair contacts", "per-contact B/J", "KK build", "GS", "lambda->v, limits", "end"]
+names = ["load", "FK", "inertia+shuffles+Mcols", "leg blocks", "schur 6x6", "factor rows", "v*", "spheres", "one-sided contacts",
+         "two-actor contacts", "side records", "-", "sweep", "dv = T w, limits", "end"]
 for rep in range(2):
     minv, con = e.debug_dynamics(3, 0)
     t = (C.c_longlong * 16)()
