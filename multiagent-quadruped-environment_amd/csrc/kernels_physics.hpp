@@ -1017,7 +1017,170 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
 #pragma unroll
   for (int i = 0; i < 27; i++) fA[i] = 0.0f;
   for (int i = lane; i < ((ndof + 3) & ~3); i += 64) accv[i] = 0.0f;          // w = sum_c Phi_c^T lambda_c starts at zero (no warm start)
-  if (is_con) {
+  if (shp.rowgs) {
+    // ---- side records for the row sweep: lane = (contact, direction).  The three rows of a contact (normal, two tangents) are
+    // independent of each other up to the contact's own 3 x 3 block, so four lanes share a contact (lane & 3 = row, the fourth
+    // idles), each builds ONE row of Phi per side, and the block's couplings come from the neighbour's row through a quad
+    // permutation: a third of the instructions of the one-lane-per-contact form below.  Rows of side A wait in registers until
+    // every lane has read the link records (the records go on top of them); side B has its own area.
+    constexpr int NPQ = 2;                       // passes of 16 contacts: scenes of <= 4 actors keep <= 32 contacts
+    const int q = lane & 3;
+    float rowA[NPQ][9], usq[NPQ], dqq[NPQ], dqn[NPQ], cbq[NPQ], muq[NPQ];
+    int infq[NPQ];
+#pragma unroll
+    for (int ps = 0; ps < NPQ; ps++) {
+      usq[ps] = 0.0f; dqq[ps] = 0.0f; dqn[ps] = 0.0f; cbq[ps] = 0.0f; muq[ps] = m->friction; infq[ps] = 0;
+#pragma unroll
+      for (int i = 0; i < 9; i++) rowA[ps][i] = 0.0f;
+      const int c = ps * 16 + (lane >> 2);
+      if (ps * 16 < nc && c < nc) {
+        const float* cr = lds + L.con + c * CON_STRIDE;
+        const float4 w0 = reinterpret_cast<const float4*>(cr)[0], w1 = reinterpret_cast<const float4*>(cr)[1], w2 = reinterpret_cast<const float4*>(cr)[2];
+        const int cA = __float_as_int(w0.x), cB = __float_as_int(w0.z);
+        if (cA < A || (cB >= 0 && cB < A)) muq[ps] = mu_robot;
+        const int bodyA = __float_as_int(w0.y), bodyB = __float_as_int(w0.w);
+        const V3 p = v3(w1.x, w1.y, w1.z), n = v3(w2.x, w2.y, w2.z);
+        V3 t1, t2;
+        contact_tangents(n, t1, t2);
+        const V3 dir = q == 0 ? n : (q == 1 ? t1 : t2);
+        const float sd = w1.w;
+        cbq[ps] = sd >= 0 ? -sd / dt : fminf(-sd * m->erp / dt, m->max_depen);
+        float fan[9];                            // side A's NEXT row (two sides on one actor: cross terms)
+#pragma unroll
+        for (int i = 0; i < 9; i++) fan[i] = 0.0f;
+        int lgA_ = 0;
+        for (int side = 0; side < 2; side++) {
+          const int act = side == 0 ? cA : cB, body = side == 0 ? bodyA : bodyB;
+          const float sg = side == 0 ? 1.0f : -1.0f;
+          if (act < 0) continue;
+          float fq[9];                           // this lane's row of the record: U[q][0..5], Z'[q][0..2]
+#pragma unroll
+          for (int i = 0; i < 9; i++) fq[i] = 0.0f;
+          int legi = -1, ncol = 6, wbase = 0;
+          float uq = 0.0f;
+          if (act < A) {
+            wbase = act * MQE_RD;
+            const float* brec = lds + L.body + act * MQE_NBODY * BODY_STRIDE;
+            const V3 r0 = p - ld3(brec + B_P);
+            const float* vb = Vm + act * MQE_RD;
+            const V3 cq = cross(r0, dir);
+            float Wq[6] = {sg * dir.x, sg * dir.y, sg * dir.z, sg * cq.x, sg * cq.y, sg * cq.z}, Zq[3];
+            const int leg = body > 0 ? (body - 1) / 3 : 0, dep = body > 0 ? (body - 1) % 3 + 1 : 0;
+#pragma unroll
+            for (int t = 0; t < 3; t++) {
+              const float* jrec = brec + (1 + leg * 3 + t) * BODY_STRIDE;
+              const float4 jq2 = reinterpret_cast<const float4*>(jrec)[2], jq3 = reinterpret_cast<const float4*>(jrec)[3];
+              const V3 ax = v3(jq3.x, jq3.y, jq3.z), rr = p - v3(jq2.y, jq2.z, jq2.w);
+              Zq[t] = (t < dep ? sg : 0.0f) * dot(cross(rr, dir), ax);
+            }
+            {                                    // relative velocity of the unconstrained motion through the FULL Jacobian row
+              const float* vl = vb + 6 + leg * 3;
+#pragma unroll
+              for (int mm = 0; mm < 6; mm++) uq += Wq[mm] * vb[mm];
+              uq = uq + Zq[0] * vl[0] + Zq[1] * vl[1] + Zq[2] * vl[2];
+            }
+            if (dep > 0) {                       // reduce onto the base coordinates: W = J_b - J_l G^T, Z' = J_l Lm
+              legi = leg;
+              const float* lrec = lds + L.leg + (act * 4 + leg) * LEG_STRIDE;
+#pragma unroll
+              for (int mm = 0; mm < 6; mm++) Wq[mm] -= Zq[0] * lrec[LEG_G + mm * 3] + Zq[1] * lrec[LEG_G + mm * 3 + 1] + Zq[2] * lrec[LEG_G + mm * 3 + 2];
+              const float4 la = reinterpret_cast<const float4*>(lrec)[1], lb = reinterpret_cast<const float4*>(lrec)[2];   // .., l00, l10 | l11, l20, l21, l22
+              fq[6] = Zq[0] * la.z + Zq[1] * la.w + Zq[2] * lb.y;
+              fq[7] = Zq[1] * lb.x + Zq[2] * lb.z;
+              fq[8] = Zq[2] * lb.w;
+            }
+            const float* Fm = lds + L.sinv + act * 72 + 36;   // U = W F, F upper triangular
+#pragma unroll
+            for (int nn = 0; nn < 6; nn++)
+#pragma unroll
+              for (int mm = nn; mm < 6; mm++) fq[mm] += Wq[nn] * Fm[nn * 6 + mm];
+          } else if (SS) {
+            wbase = A * MQE_RD; ncol = 1;
+            const V3 r0 = p - ssPiv;
+            const V3 wy = m->ss_axis == 3 ? v3(0, 1, 0) : cross(m->ss_axis == 2 ? v3(0, 0, 1) : v3(0, 1, 0), r0);   // prismatic: the axis itself
+            const float jq = sg * dot(dir, wy);
+            fq[0] = sqrtf(1.0f / m->ss_inertia) * jq;
+            uq = jq * Vm[A * MQE_RD];
+          } else {
+            const int pi = act - A;
+            wbase = A * MQE_RD + pi * npcdof; ncol = npcdof;
+            const V3 r0 = p - ld3(lds + L.root + (A + pi) * 13);
+            const float sm = sqrtf(1.0f / m->npc_mass), si = sqrtf(1.0f / m->npc_inertia);
+            const float* vn = Vm + wbase;
+            const V3 cq = cross(r0, dir);
+            const float jr[6] = {sg * dir.x, sg * dir.y, sg * dir.z, sg * cq.x, sg * cq.y, sg * cq.z};
+#pragma unroll
+            for (int mm = 0; mm < 6; mm++) {
+              const bool on = mm < npcdof;
+              fq[mm] = on ? (mm < 3 ? sm : si) * jr[mm] : 0.0f;
+              if (on) uq += jr[mm] * vn[mm];
+            }
+          }
+          usq[ps] += uq;
+          // the contact's own block: |row|^2 and the coupling with the next row (0 -> 1, 1 -> 2, 2 -> 0) fetched from the neighbour lane
+          float fn[9];
+#pragma unroll
+          for (int i = 0; i < 9; i++) fn[i] = dpp_take<0xC9>(fq[i]);          // quad_perm [1,2,0,3]
+          float sqq = 0.0f, sqn = 0.0f;
+#pragma unroll
+          for (int i = 0; i < 9; i++) { sqq += fq[i] * fq[i]; sqn += fq[i] * fn[i]; }
+          dqq[ps] += sqq; dqn[ps] += sqn;
+          const int info = (ncol == 6 && act < A ? 9 : ncol) | ((legi > 0 ? legi * 3 : 0) << 4) | (wbase << 10);   // lanes | first joint offset | first coordinate
+          if (side == 0) {
+            infq[ps] = info; lgA_ = legi + 1;
+#pragma unroll
+            for (int i = 0; i < 9; i++) { rowA[ps][i] = fq[i]; fan[i] = fn[i]; }
+          } else {                               // side B (two-actor contacts only): straight into its slot
+            float* rec = lds + L.side + (c - nc_terr) * SIDE_STRIDE;
+            if (q < 3) {
+#pragma unroll
+              for (int mm = 0; mm < 6; mm++) rec[q * 6 + mm] = fq[mm];
+#pragma unroll
+              for (int i = 0; i < 3; i++) rec[SIDE_Z + q * 3 + i] = fq[6 + i];
+            }
+            if (q == 0) rec[SIDE_INFO] = __int_as_float(info);
+            if (cB == cA) {                      // both sides on ONE actor (two links of a robot): the sides share coordinates -> cross terms
+              const bool same_leg = lgA_ != 0 && lgA_ == legi + 1;
+              float xqq = 0.0f, xqn = 0.0f, xnq = 0.0f;      // A_q . B_q,  A_q . B_next,  A_next . B_q
+#pragma unroll
+              for (int mm = 0; mm < 6; mm++) { xqq += rowA[ps][mm] * fq[mm]; xqn += rowA[ps][mm] * fn[mm]; xnq += fan[mm] * fq[mm]; }
+              if (same_leg) {
+#pragma unroll
+                for (int i = 6; i < 9; i++) { xqq += rowA[ps][i] * fq[i]; xqn += rowA[ps][i] * fn[i]; xnq += fan[i] * fq[i]; }
+              }
+              dqq[ps] += 2.0f * xqq; dqn[ps] += xqn + xnq;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();                             // the link records are dead from here: side A and the solve records go on top of them
+#pragma unroll
+    for (int ps = 0; ps < NPQ; ps++) {
+      const int c = ps * 16 + (lane >> 2);
+      if (ps * 16 < nc && c < nc) {
+        float* rec = lds + L.phi + c * SIDE_STRIDE;
+        float* sr = lds + L.srec + c * SREC_STRIDE;
+        if (q < 3) {
+#pragma unroll
+          for (int mm = 0; mm < 6; mm++) rec[q * 6 + mm] = rowA[ps][mm];
+#pragma unroll
+          for (int i = 0; i < 3; i++) rec[SIDE_Z + q * 3 + i] = rowA[ps][6 + i];
+          sr[q] = usq[ps];
+          sr[5 + q] = 1.0f / dqq[ps];
+          sr[q == 0 ? 8 : (q == 1 ? 10 : 9)] = dqn[ps];          // d10 = row 0 . row 1, d21 = row 1 . row 2, d20 = row 2 . row 0
+        } else {
+          sr[11] = 0.0f;
+          reinterpret_cast<float4*>(sr)[3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // lambda starts at zero
+        }
+        if (q == 0) { rec[SIDE_INFO] = __int_as_float(infq[ps]); sr[3] = cbq[ps]; sr[4] = muq[ps]; }
+      }
+    }
+    if (is_con) {                                // the sweep groups the contacts by actor: lane = contact again
+      const float4 w0 = reinterpret_cast<const float4*>(lds + L.con + lane * CON_STRIDE)[0];
+      myA = __float_as_int(w0.x); myB = __float_as_int(w0.z);
+    }
+  } else if (is_con) {
     float* cr = lds + L.con + lane * CON_STRIDE;
     const float4 w0 = reinterpret_cast<const float4*>(cr)[0], w1 = reinterpret_cast<const float4*>(cr)[1], w2 = reinterpret_cast<const float4*>(cr)[2];
     myA = __float_as_int(w0.x); myB = __float_as_int(w0.z);
@@ -1148,8 +1311,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
         }
         d00 += s00; d10 += s10; d11 += s11; d20 += s20; d21 += s21; d22 += s22;
       }
-      // info word: the lane sweep reads (leg + 1) | columns << 4; the row sweep lanes | first joint offset << 4 | first coordinate << 10
-      const int info = shp.rowgs ? ((ncol == 6 && act < A ? 9 : ncol) | ((legi > 0 ? legi * 3 : 0) << 4) | (wbase << 10)) : ((legi + 1) | (ncol << 4));
+      const int info = (legi + 1) | (ncol << 4);           // the lane sweep's info word (the row sweep has its own: see above)
       if (side == 0) {                       // side A: registers for the whole sweep
         wA = wbase; infoA = info; lgA = legi + 1;
 #pragma unroll
@@ -1196,17 +1358,6 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     // Phi[:, k] by w[k], the three sums over the row come from four DPP butterfly steps each, every lane solves the three rows
     // (identical operands -> identical results) and updates its own w[k].  ~40 VALU instructions per step instead of ~90, and the
     // side records and per-contact constants sit in LDS (over the dead link records) instead of 45 registers of every lane.
-    if (is_con) {
-      float4* pr = reinterpret_cast<float4*>(lds + L.phi + lane * SIDE_STRIDE);
-#pragma unroll
-      for (int w = 0; w < 6; w++) pr[w] = make_float4(fA[4 * w], fA[4 * w + 1], fA[4 * w + 2], fA[4 * w + 3]);
-      pr[6] = make_float4(fA[24], fA[25], fA[26], __int_as_float(infoA));
-      float4* sr = reinterpret_cast<float4*>(lds + L.srec + lane * SREC_STRIDE);
-      sr[0] = make_float4(us0, us1, us2, cbias);
-      sr[1] = make_float4(mu, ik00, ik11, ik22);
-      sr[2] = make_float4(d10, d20, d21, 0.0f);
-      sr[3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    }
     const bool is_terr = is_con && myB < 0, is_pair = is_con && myB >= 0;
     const int row = lane >> 4, k = lane & 15;
     int gstart = 0, glen = 0, maxlen = 0;                    // the one-sided contacts of my row's actor: first list index, count
