@@ -218,6 +218,41 @@ def test_ball_slides_then_rolls_at_the_closed_form_speed():
     assert abs(float(root[0, A, 2]) - (d.ground_z + r)) < 2e-3
 
 
+def test_ball_rolls_down_a_ramp_with_the_closed_form_acceleration():
+    """The relief map as an inclined plane h = s y (exact under the bilinear sampling): a ball released at rest rolls without
+    slipping (mu = 1 >> 2/7 tan(theta)) with a = g sin(theta) / (1 + I / (m r^2)) along the slope -- contact normal from the map's
+    gradient, friction, and the rolling constraint through the contact solver, none of it shared with a flat-ground test."""
+    from helpers import perlin_terrain
+    slope = 0.1
+    d, k, ctx = make_desc("go1football-defender", 1, terrain_cfg=perlin_terrain("go1football-defender", zScale=0.01))
+    hs = d.horizontal_scale
+    ramp = np.ascontiguousarray(np.tile((slope * (np.arange(d.sdf_ny) + 0.5) * hs).astype(np.float32), (d.sdf_nx, 1)))
+    k.append(ramp)
+    d.ground_height = ramp.ctypes.data_as(abi.FP)
+    e = oracle_engine(d, k, f64=True)
+    e.reset_all()
+    root = e.tensor(abi.T_ROOT_STATE)
+    A, r = d.num_agents, d.npc_sphere_radius[0]
+    root[0, :A, 2] += 30.0                       # the robots out of the way (falling, far above)
+    root[0, A, 0] += 1.0
+    th = np.arctan(slope)
+    y0 = float(root[0, A, 1])
+    root[0, A, 2] = d.ground_z + slope * y0 + r / np.cos(th)      # touching: centre r above the plane along its normal
+    root[0, A, 7:13] = 0
+    a = G * np.sin(th) / (1.0 + d.npc_inertia / (d.npc_mass * r * r))
+    T = 100
+    for t in range(T):
+        e.simulate()
+    tt = T * d.dt
+    v = root[0, A, 7:10].numpy()
+    assert float(v[1]) == pytest.approx(-a * tt * np.cos(th), rel=0.03), (v, a * tt)
+    assert float(v[2]) == pytest.approx(-a * tt * np.sin(th), rel=0.05)
+    assert abs(float(v[0])) < 1e-3
+    assert float(root[0, A, 10]) == pytest.approx(a * tt / r, rel=0.04)          # rolling: w_x = +|v| / r for motion along -y
+    gap = float(root[0, A, 2]) - d.ground_z - slope * float(root[0, A, 1]) - r / np.cos(th)
+    assert abs(gap) < 3e-3, gap                  # stays on the plane
+
+
 def test_joint_velocity_limit_is_an_internal_impulse():
     """go1.urdf:115,157,185 (50 / 28 / 28 rad/s): a joint thrown faster than its limit is braked to the limit within the substep,
     by an impulse along the joint -- so the robot's linear and angular momentum do not notice.  (Time step 10 us: the impulse does
