@@ -882,8 +882,13 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
         if (t0 == 0) near0 = bm; else near1 = bm;
       }
     }
+    // pairs of two NPCs of one or two spheres (a flock) are tested lane-parallel, 64 sphere pairs per pass, after the robots' pairs:
+    // in the canonical order (a, b, sphere of b, sphere of a) they come last anyway, and 36 wave-uniform iterations for 9 sheep
+    // were a third of this phase
+    const bool npc_pass = PD > 1 && m->npc_n_spheres <= 2 && !shp.has_box;
+    const int a_end = npc_pass ? A : nact;
     int tp = -1;
-    for (int a = 0; a < nact; a++)
+    for (int a = 0; a < a_end; a++)
       for (int b = a + 1; b < nact; b++) {
         tp++;
         if (!(((tp < 64 ? near0 >> tp : near1 >> (tp - 64)) & 1ull))) continue;          // wave-uniform
@@ -939,6 +944,38 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
           if (nc > pair_lim) { nc = pair_lim; ovf = 1; }
         }
       }
+    if (npc_pass) {
+      const int ns = m->npc_n_spheres, ns2 = ns * ns;
+      const int np2 = ((PD * (PD - 1)) / 2) * ns2;
+      for (int t0 = 0; t0 < np2; t0 += 64) {
+        const int t = t0 + lane;
+        bool hit = false; float sd = 0, dist = 1, rb = 0; V3 ev = v3(0, 0, 0), cb = v3(0, 0, 0); int i = 0, j = 0;
+        if (t < np2) {
+          int rem = t / ns2;
+          const int ss = t - rem * ns2, sb = ss / ns, sa = ss - sb * ns;
+          while (rem >= PD - 1 - i) { rem -= PD - 1 - i; i++; }
+          j = i + 1 + rem;
+          const float4 qa = *reinterpret_cast<const float4*>(lds + L.sph + (A * nsr + i * ns + sa) * 4);
+          const float4 qb = *reinterpret_cast<const float4*>(lds + L.sph + (A * nsr + j * ns + sb) * 4);
+          cb = v3(qb.x, qb.y, qb.z); rb = qb.w;
+          ev = v3(qa.x, qa.y, qa.z) - cb;
+          dist = sqrtf(dot(ev, ev));
+          sd = dist - qa.w - rb;
+          hit = sd < m->contact_offset && dist > 1e-9f;
+        }
+        const unsigned long long bh = __ballot(hit);
+        if (bh == 0ull) continue;
+        const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        const int slot = nc + __popcll(bh & lower);
+        if (hit && slot < pair_lim) {
+          float* cr = lds + L.con + slot * CON_STRIDE;
+          const V3 n = (1.0f / dist) * ev;
+          con_store(cr, A + i, 0, A + j, 0, cb + (rb + 0.5f * sd) * n, n, sd, A * MQE_NREP + i, A * MQE_NREP + j);
+        }
+        nc += __popcll(bh);
+        if (nc > pair_lim) { nc = pair_lim; ovf = 1; }
+      }
+    }
     // links of one robot against each other (asset.self_collisions = 0): lanes = candidate sphere pairs (same link and
     // parent-child pairs are not in the list), 64 per pass; both contact sides belong to the same actor.  Last in the list:
     // they only take the two-actor slots that the contacts with other actors left over.
