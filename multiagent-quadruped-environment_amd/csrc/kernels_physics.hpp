@@ -199,7 +199,7 @@ __host__ __device__ inline PhysLds phys_lds_layout(int A, int P, int ND, int nbo
   L.basei = o; o += A * 12;
   L.sph = scratch;
   if (scratch + nsph * 4 > o) o = scratch + nsph * 4;
-  // row sweep (robot-only scenes): side A of every contact and the per-contact solve record, written over the link records once the
+  // row sweep (scenes of <= 4 actors): side A of every contact and the per-contact solve record, written over the link records once the
   // last Jacobian row has been read
   L.phi = L.body; L.srec = L.phi + maxc * SIDE_STRIDE;
   if (rowgs && L.srec + maxc * SREC_STRIDE > o) o = L.srec + maxc * SREC_STRIDE;
@@ -231,7 +231,7 @@ template <int TA, int TP>
 struct PhysShape {
   const int A, P, PD, npcdof, ND, nbody, ndof, maxc, n_static;
   const bool has_seesaw, has_box;
-  const bool rowgs;      // contact sweep with one DPP row per actor (scenes of robots and at most the 1-dof link) instead of one lane per contact
+  const bool rowgs;      // contact sweep with one DPP row per actor (scenes of <= 4 actors) instead of one lane per contact
   __device__ __forceinline__ explicit PhysShape(const DevModel* m)
       : A(TA > 0 ? TA : m->A), P(TP == 0 ? 0 : m->P), PD((TP < 0 || (TP & PS_F_NPC)) ? m->n_npc_dyn : 0),
         npcdof((TP < 0 || (TP & PS_F_NPC)) ? m->npc_dofs_each : 0),
@@ -1389,11 +1389,11 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   // actor is processed in the same step; contacts between two actors follow one by one.  Mathematically the sweep of the CPU
   // oracle (velocity space) and of the former coupling-block form (contact space); here w IS M^-1 J^T lambda in disguise: dv = T w.
   if (shp.rowgs) {
-    // ---- row sweep (scenes of robots and at most the 1-dof link): one DPP row of 16 lanes per ACTOR ---------------------------
+    // ---- row sweep (scenes of <= 4 actors): one DPP row of 16 lanes per ACTOR -------------------------------------------------
     // The same projected Gauss-Seidel on w = sum Phi^T lambda, but a step is spread over the lanes of a row instead of running on the
     // contact's one lane: lane k of the row holds coordinate k of the actor (6 base + the 3 joints of the touching leg), multiplies
     // Phi[:, k] by w[k], the three sums over the row come from four DPP butterfly steps each, every lane solves the three rows
-    // (identical operands -> identical results) and updates its own w[k].  ~40 VALU instructions per step instead of ~90, and the
+    // (identical operands -> identical results) and updates its own w[k].  ~50 VALU instructions per step instead of ~90, and the
     // side records and per-contact constants sit in LDS (over the dead link records) instead of 45 registers of every lane.
     const bool is_terr = is_con && myB < 0, is_pair = is_con && myB >= 0;
     const int row = lane >> 4, k = lane & 15;

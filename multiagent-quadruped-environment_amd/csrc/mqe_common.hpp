@@ -31,7 +31,7 @@ struct DevModel {
   mqe_robot_model robot;
   float npc_mass, npc_inertia; int npc_n_spheres; float npc_sphere_center[8][3]; float npc_sphere_radius[8];
   int self_collision;                              // contacts between the links of one robot (rm.self_pair)
-  int rowgs;                                       // contact sweep variant of the physics kernel (PhysShape::rowgs): scenes of <= 4 robots and at most the 1-dof link
+  int rowgs;                                       // contact sweep variant of the physics kernel (PhysShape::rowgs): 1 = row sweep, scenes of <= 4 actors
   int lag_steps; float max_push;                   // domain randomisation: action lag in substeps (0 = off), push velocity bound
   int has_box, cap_npc; float npc_box_half[3];     // MQE_NPC_BOX: robots' spheres vs the oriented box; terrain contacts kept per NPC
   float seesaw_default_angle;
