@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MQE_ABI_VERSION 10
+#define MQE_ABI_VERSION 11
 #define MQE_MAX_SPHERES 32
 #define MQE_MAX_SELF_PAIRS 320
 #define MQE_NBODY 13      /* dynamic bodies of one Go1 after fixed-joint collapsing */
@@ -131,6 +131,9 @@ typedef struct {
   /* low relief of the walkable surface (Perlin noise, barrier_track.py:372-393,421-439; perlin.py:33-72): height [m] above
    * ground_z at the same cell centres as wall_sdf, [sdf_nx][sdf_ny] host pointer, or NULL for the flat slab */
   const float* ground_height;
+  /* walls of different heights in one scene (barrier_track.py:167-173,191-199,218-239: a (lo, hi) wall_height draws one height per
+   * block): top [m] of the wall nearest to each cell centre, [sdf_nx][sdf_ny] host pointer, or NULL = wall_height everywhere */
+  const float* wall_top;
   float soft_dof_pos_limit;               /* rewards.soft_dof_pos_limit (legged_robot.py:317-321): fraction of the URDF joint range
                                              outside of which MQE_T_SUBSTEP_EXCEED_DOF_POS_LIMITS flags a joint; 0 = 1.0 */
   /* per-env constants, host pointers */

@@ -746,7 +746,10 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       float gl = sqrtf(gx * gx + gy * gy);
       if (gl < 1e-6f) { gx = 1; gy = 0; gl = 1; }
       gx /= gl; gy /= gl;
-      const float dz = c.z - m->wall_height;
+      // top of the wall this sphere is next to: one height per scene, or (walls of different heights) that of the wall nearest to
+      // the sphere's own cell
+      const float wtop = m->wall_top != nullptr ? m->wall_top[(size_t)(tx < 0.5f ? ix : ix + 1) * ny + (ty < 0.5f ? iy : iy + 1)] : m->wall_height;
+      const float dz = c.z - wtop;
       if (dz <= 0) {
         if (sh <= 0 && -sh > -dz) { wsd = dz - rad; wn = v3(0, 0, 1); }
         else { wsd = sh - rad; wn = v3(gx, gy, 0); }

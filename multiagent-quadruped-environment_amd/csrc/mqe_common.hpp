@@ -41,6 +41,7 @@ struct DevModel {
   int control_type; float action_scale, hip_scale_reduction, clip_actions; float torque_limits[12]; float kp, kd;
   float default_dof_pos[12]; float command_obs[70]; float cmd_lin_scale, cmd_ang_scale; int clip_command;
   const float* wall_sdf; int sdf_nx, sdf_ny; float hs, wall_height, ground_z;
+  const float* wall_top;                           // per-cell wall top [m] (walls of different heights), or nullptr = wall_height
   const float* ground_height;                      // relief of the walkable surface above ground_z at the SDF's cell centres, or nullptr
   float soft_lo[12], soft_hi[12];                  // soft joint position limits (legged_robot.py:317-321) of MQE_T_SUBSTEP_EXCEED_DOF_POS_LIMITS
   const float *env_origins, *agent_origins, *base_init, *npc_init, *gate_pos;

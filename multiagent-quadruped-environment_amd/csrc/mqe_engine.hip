@@ -290,6 +290,7 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
 #define UP(dst, src, n) if (upload(s, &(dst), (src), (n))) { return fail(-5, "device upload failed"); }
   UP(m.wall_sdf, d->wall_sdf, (size_t)d->sdf_nx * d->sdf_ny);
   UP(m.ground_height, d->ground_height, (size_t)d->sdf_nx * d->sdf_ny);
+  UP(m.wall_top, d->wall_top, (size_t)d->sdf_nx * d->sdf_ny);
   {
     const float soft = d->soft_dof_pos_limit > 0.0f ? d->soft_dof_pos_limit : 1.0f;
     for (int j = 0; j < MQE_NDOF; j++) {          // legged_robot.py:317-321

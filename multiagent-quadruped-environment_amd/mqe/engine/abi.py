@@ -1,7 +1,7 @@
 """ctypes mirror of include/mqe_hip.h (keep in sync; tests/test_abi.py checks sizes against the built library)."""
 import ctypes as C
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 MAX_SPHERES, NBODY, NREP, NDOF = 32, 13, 17, 12
 MAX_SELF_PAIRS = 320
 MAX_AGENTS, MAX_NPCS, FRAME, HIST, MAX_LAYERS, MAX_REWARD_TERMS = 4, 9, 72, 30, 6, 12
@@ -63,7 +63,7 @@ class SimDesc(C.Structure):
         ("torque_limits", f32 * NDOF), ("kp", f32), ("kd", f32), ("default_dof_pos", f32 * NDOF),
         ("command_obs", f32 * 70), ("cmd_lin_scale", f32), ("cmd_ang_scale", f32), ("clip_command", i32),
         ("wall_sdf", FP), ("sdf_nx", i32), ("sdf_ny", i32),
-        ("horizontal_scale", f32), ("wall_height", f32), ("ground_z", f32), ("ground_height", FP), ("soft_dof_pos_limit", f32),
+        ("horizontal_scale", f32), ("wall_height", f32), ("ground_z", f32), ("ground_height", FP), ("wall_top", FP), ("soft_dof_pos_limit", f32),
         ("env_origins", FP), ("agent_origins", FP), ("base_init_state", FP), ("npc_init_state", FP), ("gate_pos", FP),
         ("termination_flags", i32), ("terminate_on_base_contact", i32), ("max_episode_length", i32),
         ("roll_threshold", f32), ("pitch_threshold", f32), ("z_low_threshold", f32), ("z_high_threshold", f32),

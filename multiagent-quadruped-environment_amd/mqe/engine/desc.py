@@ -300,6 +300,10 @@ def build_desc(cfg, num_envs, terrain, env_origins, agent_origins, gate_pos=None
     if gh is not None:
         assert gh.shape == terrain.wall_sdf.shape
         d.ground_height = _fp(gh, keep)
+    wt = getattr(terrain, "wall_top", None)                   # per-block wall heights (None: one height, d.wall_height)
+    if wt is not None:
+        assert wt.shape == terrain.wall_sdf.shape
+        d.wall_top = _fp(wt, keep)
     d.soft_dof_pos_limit = float(getattr(cfg.rewards, "soft_dof_pos_limit", 1.0))
     d.env_origins = _fp(env_origins, keep)
     d.agent_origins = _fp(agent_origins, keep)

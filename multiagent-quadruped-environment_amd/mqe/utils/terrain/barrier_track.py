@@ -216,6 +216,7 @@ class BarrierTrack:
         self.track_width_map = np.zeros((cfg.num_rows, cfg.num_cols), dtype=np.float32)
         infos = {}
         heights = set()
+        wall_px = np.zeros_like(hf)                      # height [px units] of the wall standing on each pixel (0: none)
         for c in range(cfg.num_cols):
             for r in range(cfg.num_rows):
                 org = np.array([int(r * self.track_resolution[0]) + self.border, int(c * self.track_resolution[1]) + self.border, 0])
@@ -235,6 +236,7 @@ class BarrierTrack:
                     sl = (slice(x, x + res[0]), slice(org[1], org[1] + res[1]))
                     hf[sl] = h + mask * hf[sl] + org[2]
                     wall[sl] = h > 0
+                    wall_px[sl] = h
                     heights.update(np.unique(h[h > 0]).tolist())
                     x += res[0]
                     if sp is not None:
@@ -249,9 +251,14 @@ class BarrierTrack:
         self.heightfield_raw = hf
         self.heightsamples = hf
         self.env_info = infos
+        # one wall height per scene is a scalar; a (lo, hi) wall_height draws one per block (:167-173,191-199,218-239) and the engine
+        # then gets a map: at every cell centre the top of the wall nearest to it
+        self.wall_height = float(max(heights) * cfg.vertical_scale) if heights else 0.0
+        self.wall_top = None
         if len(heights) > 1:
-            raise NotImplementedError("engine terrain model: one wall height per scene (a (lo, hi) wall_height draws one per block)")
-        self.wall_height = float(heights.pop() * cfg.vertical_scale) if heights else 0.0
+            wall_px[wall & (wall_px <= 0)] = max(kwt["border_height"], 0.0) / cfg.vertical_scale      # raised Perlin borders
+            _, (ii, jj) = ndimage.distance_transform_edt(~(wall_px > 0), return_indices=True)
+            self.wall_top = (wall_px[ii, jj] * cfg.vertical_scale).astype(np.float32)
         # flat scenes lie under the reference's 2 cm ground slab (:628-632); with the Perlin map there is no slab (:567-626): the
         # ground is the heightfield itself
         self.ground_z = 0.0 if perlin_map else GROUND_SLAB_TOP

@@ -63,6 +63,7 @@ typedef struct mqo_sim {
   mlp_t act, ada, body;
   float* sdf;
   float* ground_height;             /* relief of the walkable surface at the SDF's cell centres, or NULL (flat slab) */
+  float* wall_top;                  /* per-cell wall top (walls of different heights), or NULL */
   float *env_origins, *agent_origins, *base_init, *npc_init, *gate_pos;
   /* state */
   float *root, *dof, *cf, *torques, *actions, *last_actions, *loco_obs, *hist, *last_loco, *last_two_loco;
@@ -296,6 +297,7 @@ int mqo_sim_create(const mqe_sim_desc* d, mqo_sim** out) {
   mlp_copy(&s->body, &d->body);
   s->sdf = (float*)dupmem(d->wall_sdf, (size_t)d->sdf_nx * d->sdf_ny * 4);
   s->ground_height = d->ground_height ? (float*)dupmem(d->ground_height, (size_t)d->sdf_nx * d->sdf_ny * 4) : NULL;
+  s->wall_top = d->wall_top ? (float*)dupmem(d->wall_top, (size_t)d->sdf_nx * d->sdf_ny * 4) : NULL;
   s->env_origins = (float*)dupmem(d->env_origins, (size_t)N * 3 * 4);
   s->agent_origins = (float*)dupmem(d->agent_origins, (size_t)N * A * 3 * 4);
   s->base_init = (float*)dupmem(d->base_init_state, (size_t)A * 13 * 4);
@@ -560,6 +562,21 @@ static real map_sample(const mqo_sim* s, const float* map, real x, real y, real*
   return a0 + (a1 - a0) * tx;
 }
 static real sdf_sample(const mqo_sim* s, real x, real y, real* gx, real* gy) { return map_sample(s, s->sdf, x, y, gx, gy); }
+/* top of the wall next to (x, y): one height per scene, or -- walls of different heights (barrier_track.py:167-173: a (lo, hi)
+ * wall_height draws one per block) -- the value stored at the nearest cell centre = the height of the wall nearest to that cell */
+static real wall_top_at(const mqo_sim* s, real x, real y) {
+  const mqe_sim_desc* d = &s->d;
+  if (!s->wall_top) return d->wall_height;
+  real hs = d->horizontal_scale;
+  real fx = x / hs - (real)0.5, fy = y / hs - (real)0.5;
+  int nx = d->sdf_nx, ny = d->sdf_ny;
+  if (!(fx >= 0)) fx = 0; if (!(fy >= 0)) fy = 0;
+  if (fx > nx - 1) fx = (real)(nx - 1); if (fy > ny - 1) fy = (real)(ny - 1);
+  int ix = (int)fx, iy = (int)fy;
+  if (ix > nx - 2) ix = nx - 2; if (iy > ny - 2) iy = ny - 2;
+  real tx = fx - ix, ty = fy - iy;
+  return s->wall_top[(size_t)(tx < (real)0.5 ? ix : ix + 1) * ny + (ty < (real)0.5 ? iy : iy + 1)];
+}
 
 /* sphere (centre c, radius r) vs box (centre bc, rotation R row-major, half extents h): signed distance and world
  * normal pointing from the box to the sphere */
@@ -889,7 +906,7 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
           real gl = (real)sqrt((double)(gx * gx + gy * gy));
           if (gl < (real)1e-6) { gx = 1; gy = 0; gl = 1; }
           gx /= gl; gy /= gl;
-          real dz = c[2] - d->wall_height;
+          real dz = c[2] - wall_top_at(s, c[0], c[1]);
           if (dz <= 0) {               /* beside (or inside) the wall prism: lateral contact */
             if (sh <= 0 && -sh > -dz) { sd = dz - r; n[0] = 0; n[1] = 0; n[2] = 1; }  /* deep inside, closer to the top */
             else { sd = sh - r; n[0] = gx; n[1] = gy; n[2] = 0; }

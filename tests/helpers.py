@@ -43,6 +43,14 @@ def perlin_terrain(task, zScale=0.12, frequency=10, **cfg_over):
     return type("PerlinTerrain", (base,), dict(cfg_over, BarrierTrack_kwargs=kw, TerrainPerlin_kwargs=dict(zScale=zScale, frequency=frequency)))
 
 
+def wall_heights_terrain(task, lo=0.3, hi=0.7, **cfg_over):
+    """the task's own terrain config with a (lo, hi) wall_height: one wall height per block (barrier_track.py:167-173,191-199,218-239)"""
+    base = task_cfg(task).terrain
+    kw = dict(base.BarrierTrack_kwargs)
+    kw.update(wall_height=(lo, hi))
+    return type("WallHeightsTerrain", (base,), dict(cfg_over, BarrierTrack_kwargs=kw))
+
+
 def make_desc(task, N, seed=0, levels=None, types=None, max_episode_length=None, npc_init=None, env_id_offset=0, terrain_cfg=None, **kw):
     """Scene exactly as Go1._create_scene builds it, but with explicit track assignment for replaying fixtures."""
     cfg = task_cfg(task)

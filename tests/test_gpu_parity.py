@@ -634,3 +634,51 @@ def test_perlin_terrain_matches_oracle(task, N, zs):
     dev = torch.stack(dev)
     assert torch.isfinite(dev).all() and float(dev[4].median()) < 1e-5 and float(dev[-1].median()) < 1e-4 and float(dev[-1].quantile(0.99)) < 5e-3
     assert mism <= 1
+
+
+def test_walls_of_different_heights_match_oracle():
+    """a (lo, hi) wall_height: per-cell wall tops (`wall_top`, ABI v11) on the HIP engine == oracle -- contact lists of perturbed
+    states incl. contacts with the top faces and edges of walls of different heights, one substep, and a short fused rollout"""
+    from helpers import wall_heights_terrain
+    task, N = "go1gate", 48
+    np.random.seed(0)
+    d1, k1, c1 = make_desc(task, N, terrain_cfg=wall_heights_terrain(task))
+    np.random.seed(0)
+    d2, k2, _ = make_desc(task, N, terrain_cfg=wall_heights_terrain(task))
+    assert bool(d1.wall_top) and c1["terrain"].wall_top is not None
+    eh, eo = hip_engine(d1, k1), oracle_engine(d2, k2)
+    eh.reset_all(); eo.reset_all()
+    # half of the robots onto / next to walls: base above a wall pixel at a height between the lowest and the tallest top
+    t = c1["terrain"]
+    hs = d1.horizontal_scale
+    wi, wj = np.nonzero(t.wall)
+    g = torch.Generator().manual_seed(21)
+    ro = eo.tensor(abi.T_ROOT_STATE)
+    sel = torch.randint(0, len(wi), (N,), generator=g)
+    for env in range(0, N, 2):
+        ro[env, 0, 0] = float((wi[sel[env]] + 0.5) * hs) + 0.03
+        ro[env, 0, 1] = float((wj[sel[env]] + 0.5) * hs) - 0.02
+        ro[env, 0, 2] = float(t.wall_top[wi[sel[env]], wj[sel[env]]]) + 0.12 + 0.1 * float(torch.rand((), generator=g))
+    eh.tensor(abi.T_ROOT_STATE).copy_(ro.cuda())
+    wall_contacts = 0
+    for env in (0, 2, 10, N - 2):
+        mh, ch = eh.debug_dynamics(env, 0)
+        _, mo, co = eo.debug_dynamics(env, 0)
+        assert ch.shape == co.shape and (ch[:, :4] == co[:, :4]).all()
+        close(ch[:, 4:], co[:, 4:], atol=3e-5, what="contact separation / normal at walls of different heights")
+        wall_contacts += len(co)
+    assert wall_contacts > 0
+    for _ in range(3):
+        eh.simulate(); eo.simulate()
+    torch.cuda.synchronize()
+    close(eh.tensor(abi.T_ROOT_STATE)[..., :7], eo.tensor(abi.T_ROOT_STATE)[..., :7], atol=5e-5, what="root pose after 3 substeps")
+    eh.reset_all(); eo.reset_all()
+    dev = []
+    for s_ in range(10):
+        a = torch.rand(N, 2, 3, generator=g) * 2 - 1
+        eh.step(a.cuda().contiguous()); eo.step(a)
+        torch.cuda.synchronize()
+        dev.append((eh.tensor(abi.T_ROOT_STATE).cpu()[..., :3] - eo.tensor(abi.T_ROOT_STATE)[..., :3]).abs().max(dim=-1).values.flatten())
+        assert (eh.tensor(abi.T_RESET_BUF).cpu() == eo.tensor(abi.T_RESET_BUF)).all()
+    dev = torch.stack(dev)
+    assert float(dev[-1].median()) < 1e-4 and float(dev[-1].quantile(0.99)) < 1e-3

@@ -349,3 +349,36 @@ def test_perlin_relief_is_the_ground():
     assert torch.isfinite(r2).all() and ((r2[:, :, 2] > 0.2) & (r2[:, :, 2] < 0.45)).all(), r2[:, :, 2]
     cf = e2.tensor(abi.T_CONTACT_FORCE).reshape(2, 2, 17, 3)
     assert (cf[:, :, [4, 8, 12, 16], 2].sum(-1) > 40).all()                                    # feet carry (most of) the 113 N
+
+
+def test_walls_of_different_heights_carry_a_ball_at_their_own_top():
+    """a (lo, hi) wall_height (one draw per block): the engine's terrain is the wall SDF plus, per cell, the top of the nearest wall.
+    A ball set down on the middle of the lowest and of the tallest wall rests at THAT wall's top, and a ball beside the tall wall,
+    above the low one's top, is still stopped by it"""
+    from helpers import wall_heights_terrain
+    np.random.seed(0)
+    d, k, ctx = make_desc("go1football-defender", 2, terrain_cfg=wall_heights_terrain("go1football-defender"))
+    t = ctx["terrain"]
+    assert t.wall_top is not None
+    e = oracle_engine(d, k, f64=True)
+    e.reset_all()
+    root = e.tensor(abi.T_ROOT_STATE)
+    A, r, hs = d.num_agents, d.npc_sphere_radius[0], d.horizontal_scale
+    deep = t.wall_sdf < -1.4 * hs                        # well inside a wall: the contact is with the top face only
+    assert deep.any()
+    tops = np.where(deep, t.wall_top, np.nan)
+    lo_ij = np.unravel_index(np.nanargmin(tops), tops.shape)
+    hi_ij = np.unravel_index(np.nanargmax(tops), tops.shape)
+    want = [float(t.wall_top[lo_ij]), float(t.wall_top[hi_ij])]
+    assert want[1] - want[0] > 0.1
+    root[:, :A, 2] += 30.0                               # robots out of the way
+    for env, ij in enumerate((lo_ij, hi_ij)):
+        root[env, A, 0] = (ij[0] + 0.5) * hs
+        root[env, A, 1] = (ij[1] + 0.5) * hs
+        root[env, A, 2] = want[env] + r + 0.01
+        root[env, A, 7:13] = 0
+    for _ in range(120):
+        e.simulate()
+    for env in range(2):
+        assert abs(float(root[env, A, 2]) - (want[env] + r)) < 2e-3, (env, float(root[env, A, 2]), want[env] + r)
+        assert root[env, A, 7:10].abs().max() < 1e-2

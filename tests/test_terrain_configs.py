@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import GOLD, golden, task_cfg
+from helpers import GOLD, golden, task_cfg, make_desc
 from mqe.utils.helpers import class_to_dict
 from mqe.utils.terrain import BarrierTrack
 
@@ -83,7 +83,33 @@ def perlin_cfgs():
                                           border_height=0.3)),
         "perlin_tracks_only": variant("PerlinTracksOnly", dict(num_rows=2, num_cols=1, border_size=1, TerrainPerlin_kwargs=dict(zScale=[0.05, 0.1], frequency=10)),
                                       dict(add_perlin_noise=True, border_perlin_noise=False)),
+        "wall_heights": variant("WallHeights", dict(num_rows=2, num_cols=2, border_size=1), dict(wall_height=(0.3, 0.7))),
     }
+
+
+def test_walls_of_different_heights_match_reference_and_reach_the_engine():
+    """a (lo, hi) wall_height makes every block painter draw its own height (barrier_track.py:167-173,191-199,218-239): the raster is
+    the reference's at np.random.seed(0), and the engine gets, per cell, the top of the wall nearest to it (`wall_top`)"""
+    z = golden("terrain_wall_heights")
+    tcfg = perlin_cfgs()["wall_heights"]
+    np.random.seed(0)
+    t = BarrierTrack(tcfg, 4, 2).build()
+    hf = t.heightfield_raw.astype(np.float64)
+    assert hf.shape == tuple(z["shape"])
+    np.testing.assert_allclose(hf[::3, ::3], z["sub"], atol=2e-4, rtol=1e-6)
+    np.testing.assert_allclose(hf.sum(1), z["row_sums"], rtol=1e-6, atol=1e-2)
+    assert np.array_equal(t.env_origins, z["env_origins"]) and np.array_equal(t.agent_origins, z["agent_origins"])
+    assert np.array_equal(t.env_info["gate_deviation"], z["gate_deviation"])
+    vs = tcfg.vertical_scale
+    tops = np.unique(hf[t.wall]) * vs
+    assert len(tops) > 2 and tops.min() >= 0.3 - vs and tops.max() <= 0.7 + vs             # several heights inside the range
+    assert t.wall_top is not None and t.wall_top.shape == hf.shape and t.wall_height == pytest.approx(tops.max())
+    np.testing.assert_allclose(t.wall_top[t.wall], hf[t.wall] * vs, atol=1e-6)               # on a wall: its own top
+    from scipy import ndimage
+    _, (ii, jj) = ndimage.distance_transform_edt(~t.wall, return_indices=True)
+    np.testing.assert_allclose(t.wall_top, (hf * vs)[ii, jj], atol=1e-6)                      # elsewhere: the nearest wall's
+    d, keep, ctx = make_desc("go1gate", 4, terrain_cfg=tcfg)
+    assert d.wall_top and d.wall_height == pytest.approx(ctx["terrain"].wall_height)
 
 
 @pytest.mark.parametrize("name", ["perlin_map", "perlin_curriculum", "perlin_tracks_only"])

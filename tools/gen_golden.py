@@ -921,6 +921,8 @@ def perlin_terrain_cfgs():
                                              border_height=0.3)), 2)
     out["perlin_tracks_only"] = (variant("PerlinTracksOnly", dict(num_rows=2, num_cols=1, border_size=1, TerrainPerlin_kwargs=dict(zScale=[0.05, 0.1], frequency=10)),
                                          dict(add_perlin_noise=True, border_perlin_noise=False)), 2)
+    # a (lo, hi) wall_height: every block painter draws its own wall height (barrier_track.py:167-173,191-199,218-239)
+    out["wall_heights"] = (variant("WallHeights", dict(num_rows=2, num_cols=2, border_size=1), dict(wall_height=(0.3, 0.7))), 2)
     return out
 
 
