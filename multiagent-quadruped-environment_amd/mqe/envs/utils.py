@@ -35,14 +35,9 @@ def _resolve(package, spec):
 ENV_DICT = {task: {"class": _resolve("mqe.envs", env), "config": cfg(entry), "wrapper": _resolve("mqe.envs.wrappers", wrapper)}
             for task, env, entry, wrapper in _TASKS}
 
-# tasks the reference registers that this build does not run: none
-NOT_YET = ()
-
 
 def make_mqe_env(env_name: str, args=None, custom_cfg=None) -> Tuple[LeggedRobotField, LeggedRobotFieldCfg]:
     """environment of task `env_name` inside its task wrapper, and the config it was built from"""
-    if env_name in NOT_YET:
-        raise NotImplementedError(f"task '{env_name}' is registered by the reference but outside this build's hot-path scope so far")
     task = ENV_DICT[env_name]
     if callable(custom_cfg):
         task["config"] = custom_cfg(task["config"])
