@@ -272,7 +272,7 @@ def main():
                     "frac": round(ach / PEAK_HBM_GBS, 6), "traffic": None, "avg_launch_ms": round(avg_ms(dom), 4), "launches": int(cnt[dom]),
                     "bytes_basis": "SURVEY 8(d): the whole step's 10128 B/agent-step charged to the dominant kernel; per-kernel shares in roofline_per_kernel",
                     "note": "not HBM-bound by construction: one env per wavefront, state LDS-resident for the 4 substeps; the limiter is "
-                            "the kernel's VALU instruction count (robot-only scenes: all envs resident at 4 waves/SIMD, vector ALUs ~74 % busy; "
+                            "the kernel's VALU instruction count (robot-only scenes: all envs resident at 4 waves/SIMD, vector ALUs ~80 % busy; "
                             "pmc_from_profile: issue / wait fractions; DESIGN.md 3.1)"}
         # HBM traffic of the dominant kernel: NOT measured in this run -- copied from the committed rocprofv3 PMC passes (separate
         # runs of this command, profiles/*pmc_summary.json) and labelled as such
