@@ -252,9 +252,9 @@ def main():
         # ---- policy layer 0: the one MFMA-bound kernel
         l0_ms = max(avg_ms(0), 1e-9)
         flops32 = 2.0 * R * 2100 * (h_a + h_b)                        # algorithmic: unpadded K = 30 x 70, f32 products
-        if split:   # every f32 product = three f16 x f16 terms on the matrix cores, K padded to 2208 (a multiple of three 32-k tiles)
+        if split:   # every f32 product = three f16 x f16 terms on the matrix cores, K = 30 compact frames of 64 (58 changing columns + flag + pads)
             l0 = {"kernel": "k_gemm_h2 (fused layer 0 of adaptation+body MLP over the history ring; 2-plane split-f16 operands, 3 MFMA terms per product, f32-class accuracy)",
-                  "bound": "mfma", "achieved": round(3 * 2.0 * R * 2208 * (h_a + h_b) / (l0_ms * 1e-3) / 1e12, 2), "peak": PEAK_F16_MFMA_TFLOPS,
+                  "bound": "mfma", "achieved": round(3 * 2.0 * R * 1920 * (h_a + h_b) / (l0_ms * 1e-3) / 1e12, 2), "peak": PEAK_F16_MFMA_TFLOPS,
                   "unit": "TFLOP/s", "f32_equivalent_TFLOPs": round(flops32 / (l0_ms * 1e-3) / 1e12, 2)}
         else:
             l0 = {"kernel": "k_gemm_f32 (fused layer 0, exact f32 MFMA)", "bound": "mfma", "achieved": round(flops32 / (l0_ms * 1e-3) / 1e12, 3),

@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(256) k_gemm_f32(GemmArgs g) {
 //   * LDS row = 32 k of one plane padded to 80 B, so the 16 B fragment reads of a ds_read_b128 lane group (16 rows)
 //     tile all 64 banks; the planes are 64 B apart modulo the 128 B store banking, so the 8 lanes that stage one row's
 //     128 contiguous global bytes (4 units x 2 planes) store conflict-free as well.
-//   * A may be the history ring: 8-element units, logical unit u -> (u + rot) mod ring (frames are 72 = 9 units).
+//   * A may be the history ring: 8-element units, logical unit u -> (u + rot) mod ring (compact frames of 64 = 8 units, mqe_common.hpp).
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // explicit global address space: pointers selected between two kernel-argument buffers degrade to flat loads, whose
 // completion is also counted by lgkmcnt, i.e. every LDS wait would wait for the prefetch as well

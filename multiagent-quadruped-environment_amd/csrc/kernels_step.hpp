@@ -127,7 +127,7 @@ __global__ void k_pre_policy(const DevModel* m, DevState st, const float* __rest
     } else x = command[i * 3 + (c - 3)];
     if (m->clip_command) x = clampf(x, -1.0f, 1.0f);
     v = x * (c < 5 ? m->cmd_lin_scale : m->cmd_ang_scale);
-  } else if (c < 18) v = lo[c];                                // fixed gait parameters (set at construction)
+  } else if (c < 18) v = m->command_obs[c];                    // fixed gait parameters (constants of the scene: desc.command_obs)
   else if (c < 30) v = ob[6 + (c - 18)];                       // dof_pos                :96
   else if (c < 42) v = ob[18 + (c - 30)];                      // dof_vel                :97
   else if (c < 54) v = st.last_loco[i * 12 + (c - 42)];        //                        :98
@@ -137,12 +137,15 @@ __global__ void k_pre_policy(const DevModel* m, DevState st, const float* __rest
   lo[c] = v;
   const size_t hidx = ((size_t)i * MQE_HIST + hist_slot) * MQE_FRAME + c;
   st.hist[hidx] = v;   // :102
-  if (st.hist2) {      // the split-f16 GEMM's operand copy: two f16 planes (kernels_gemm.hpp)
-    uint16_t h, l;
-    split2(v, MQE_H2_ASCALE, h, l);
-    uint16_t* row2 = st.hist2 + (size_t)i * (2 * MQE_HIST * MQE_FRAME);
-    const size_t k = (size_t)hist_slot * MQE_FRAME + c;
-    row2[h2_index(k, 0)] = h; row2[h2_index(k, 1)] = l;
+  if (st.hist2) {      // the split-f16 GEMM's operand copy: two f16 planes, compact frames (mqe_common.hpp: MQE_H2_FRAME)
+    const int cc = c < 70 ? h2_col(c) : (c == 70 ? MQE_H2_FLAG_COL : -1);      // thread 70 of the frame writes the presence flag
+    if (cc >= 0) {
+      uint16_t h, l;
+      split2(c < 70 ? v : 1.0f, MQE_H2_ASCALE, h, l);
+      uint16_t* row2 = st.hist2 + (size_t)i * (2 * MQE_HIST * MQE_H2_FRAME);
+      const size_t k = (size_t)hist_slot * MQE_H2_FRAME + cc;
+      row2[h2_index(k, 0)] = h; row2[h2_index(k, 1)] = l;
+    }
   }
 }
 
@@ -943,8 +946,8 @@ __global__ void __launch_bounds__(64) k_post_physics(const DevModel* m, DevState
     float4* h4 = reinterpret_cast<float4*>(st.hist) + (size_t)er * per;
     for (int k = threadIdx.x; k < per; k += 64) h4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (st.hist2) {                                                    // same robots, 2 planes interleaved: the same bytes
-      uint4* p4 = reinterpret_cast<uint4*>(st.hist2 + (size_t)er * m->A * (2 * MQE_HIST * MQE_FRAME));
-      const int per2 = m->A * (2 * MQE_HIST * MQE_FRAME / 8);
+      uint4* p4 = reinterpret_cast<uint4*>(st.hist2 + (size_t)er * m->A * (2 * MQE_HIST * MQE_H2_FRAME));
+      const int per2 = m->A * (2 * MQE_HIST * MQE_H2_FRAME / 8);
       for (int k = threadIdx.x; k < per2; k += 64) p4[k] = make_uint4(0u, 0u, 0u, 0u);
     }
   }
@@ -958,11 +961,10 @@ __global__ void k_reset_history(const DevModel* m, DevState st) {
   if (i >= m->R) return;
   if (!st.reset_buf[i / m->A]) return;
   reinterpret_cast<float4*>(st.hist)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (st.hist2) {      // the same 4 elements in both planes
-    const size_t k = (size_t)(idx - i * per) * 4;
-    uint16_t* row2 = st.hist2 + (size_t)i * (2 * MQE_HIST * MQE_FRAME);
-#pragma unroll
-    for (int p = 0; p < 2; p++) *reinterpret_cast<uint2*>(row2 + h2_index(k, p)) = make_uint2(0u, 0u);
+  if (st.hist2) {      // the robot's compact f16 planes: 2 x 30 x 64 values = 480 16-byte words, one per thread of the first 480
+    const int w = idx - i * per;
+    if (w < 2 * MQE_HIST * MQE_H2_FRAME / 8)
+      reinterpret_cast<uint4*>(st.hist2 + (size_t)i * (2 * MQE_HIST * MQE_H2_FRAME))[w] = make_uint4(0u, 0u, 0u, 0u);
   }
 }
 

@@ -64,7 +64,7 @@ struct DevState {
   float *w_last, *w_last2, *cmd, *last_dof_vel;
   float* sub_dof_vel; uint8_t* sub_exceed; int32_t* overflow;   // per-substep logs (legged_robot.py:114-115); truncated-contact-list counter
   float *dparams, *lag_buf;                 // [R][8] friction / added mass / CoM shift (MQE_T_DOMAIN_PARAMS); [(lag + 1)][R][12] scaled actions
-  uint16_t* hist2;                          // split-f16 copy of the history ring: [R][270 units][2 planes][8] (k_gemm_h2)
+  uint16_t* hist2;                          // compact split-f16 copy of the history ring: [R][240 units][2 planes][8] (k_gemm_h2; MQE_H2_FRAME)
   int32_t *ep_len, *reset_count;
   uint8_t *reset_buf, *collide_buf, *time_out, *r_term, *p_term, *zh_term, *w_have_last, *w_delayed_reset;
 };
@@ -86,6 +86,14 @@ __host__ __device__ __forceinline__ float mqe_u01(uint32_t seed, uint32_t genv, 
 
 
 // f32 -> two f16 planes of scale * x (h + l == scale * x to 22 significand bits); see k_gemm_h2 in kernels_gemm.hpp
+// The split-f16 copy of the history (k_gemm_h2's A operand) is COMPACT: per frame 64 columns = the 58 entries of the 70-float frame
+// that change from step to step + one "frame is present" flag + 5 zero pads.  Columns 6..17 of a frame are the gait parameters:
+// constants of the scene (desc.command_obs, go1.py:411-479: only the velocity command is an action), so all twelve ride on the
+// flag column -- its weight is sum_c W[., c] * command_obs[c], it is 1 in a written frame and 0 in a frame zeroed by a reset,
+// exactly like the constants themselves.  K = 30 x 64 = 1920 instead of 30 x 72 padded to 2208.
+#define MQE_H2_FRAME 64
+#define MQE_H2_FLAG_COL 58
+__host__ __device__ __forceinline__ int h2_col(int c) { return c < 6 ? c : (c < 18 ? -1 : c - 12); }   // frame column -> compact column
 #define MQE_H2_ASCALE 64.0f                 // activation scale c_a: |x| <= 1023 representable, beyond that the value saturates
 __host__ __device__ __forceinline__ uint16_t f16_bits(_Float16 h) { union { _Float16 f; uint16_t u; } v; v.f = h; return v.u; }
 __host__ __device__ __forceinline__ void split2(float x, float scale, uint16_t& h, uint16_t& l) {

@@ -104,15 +104,24 @@ static int make_layer(mqe_sim* s, GemmLayer* L, int K, int N) {
   if (dalloc(s, &L->bias, L->Npad)) return -1;
   return 0;
 }
+// krow: input k -> row of the exact-f32 operand (ring-row order).  k2row / k2scale (layer 0 only): input k -> row of the split-f16
+// operand in its own, compact K order; inputs that share a row (the constant columns on the flag column) are accumulated with
+// their constant as the factor.
 static int fill_layer(GemmLayer* L, int col0, const float* W, const float* b, int out, int in_used, int ldw_in,
-                      const std::vector<int>* krow = nullptr) {
+                      const std::vector<int>* krow = nullptr, const std::vector<int>* k2row = nullptr, const std::vector<float>* k2scale = nullptr) {
   std::vector<float> tmp((size_t)L->Kpad * out, 0.0f);
+  std::vector<double> acc;
+  if (k2row) acc.assign((size_t)out * L->Kpad3, 0.0);
   for (int o = 0; o < out; o++)
     for (int k = 0; k < in_used; k++) {
       int kr = krow ? (*krow)[k] : k;
       tmp[(size_t)kr * out + o] = W[(size_t)o * ldw_in + k];
-      L->hW[(size_t)(col0 + o) * L->Kpad3 + kr] = W[(size_t)o * ldw_in + k];
+      if (k2row) acc[(size_t)o * L->Kpad3 + (*k2row)[k]] += (double)W[(size_t)o * ldw_in + k] * (double)(*k2scale)[k];
+      else L->hW[(size_t)(col0 + o) * L->Kpad3 + kr] = W[(size_t)o * ldw_in + k];
     }
+  if (k2row)
+    for (int o = 0; o < out; o++)
+      for (int k = 0; k < L->Kpad3; k++) L->hW[(size_t)(col0 + o) * L->Kpad3 + k] = (float)acc[(size_t)o * L->Kpad3 + k];
   if (hipMemcpy2D(L->Wt + col0, (size_t)L->Npad * 4, tmp.data(), (size_t)out * 4, (size_t)out * 4, L->Kpad, hipMemcpyHostToDevice) != hipSuccess) return -1;
   if (b && hipMemcpy(L->bias + col0, b, (size_t)out * 4, hipMemcpyHostToDevice) != hipSuccess) return -1;
   return 0;
@@ -319,9 +328,20 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   if (s->ada_h0 % GB_N || s->body_h0 % GB_N) return fail(-6, "first hidden sizes must be multiples of 64");
   std::vector<int> krow(2100);
   for (int k = 0; k < 2100; k++) krow[k] = (k / 70) * MQE_FRAME + (k % 70);
+  // the split-f16 operand has its own K order: compact frames of MQE_H2_FRAME columns (mqe_common.hpp), the twelve constant gait
+  // parameters of a frame folded onto its presence-flag column
+  std::vector<int> k2row(2100);
+  std::vector<float> k2scale(2100);
+  for (int k = 0; k < 2100; k++) {
+    const int f = k / 70, c = k % 70, cc = h2_col(c);
+    k2row[k] = f * MQE_H2_FRAME + (cc >= 0 ? cc : MQE_H2_FLAG_COL);
+    k2scale[k] = cc >= 0 ? 1.0f : d->command_obs[c];
+  }
   if (make_layer(s, &s->l0, MQE_HIST * MQE_FRAME, s->ada_h0 + s->body_h0)) return fail(-5, "alloc");
-  if (fill_layer(&s->l0, 0, ad.W[0], ad.b[0], s->ada_h0, 2100, 2100, &krow)) return fail(-5, "upload");
-  if (fill_layer(&s->l0, s->ada_h0, bd.W[0], bd.b[0], s->body_h0, 2100, 2102, &krow)) return fail(-5, "upload");
+  s->l0.Kpad3 = rup(MQE_HIST * MQE_H2_FRAME, H2_KMULT);
+  s->l0.hW.assign((size_t)s->l0.Npad * s->l0.Kpad3, 0.0f);
+  if (fill_layer(&s->l0, 0, ad.W[0], ad.b[0], s->ada_h0, 2100, 2100, &krow, &k2row, &k2scale)) return fail(-5, "upload");
+  if (fill_layer(&s->l0, s->ada_h0, bd.W[0], bd.b[0], s->body_h0, 2100, 2102, &krow, &k2row, &k2scale)) return fail(-5, "upload");
   {
     std::vector<float> w0(s->body_h0), w1(s->body_h0);
     for (int o = 0; o < s->body_h0; o++) { w0[o] = bd.W[0][(size_t)o * 2102 + 2100]; w1[o] = bd.W[0][(size_t)o * 2102 + 2101]; }
@@ -376,7 +396,7 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   DA(st.torques, (size_t)N * 12 * A); DA(st.actions, (size_t)N * 12 * A); DA(st.last_actions, (size_t)N * 12 * A);
   DA(st.loco_obs, (size_t)R * MQE_FRAME); DA(st.hist, (size_t)R * MQE_HIST * MQE_FRAME);
   st.hist2 = nullptr;
-  if (s->gemm_split) { DA(st.hist2, (size_t)2 * R * MQE_HIST * MQE_FRAME); }
+  if (s->gemm_split) { DA(st.hist2, (size_t)2 * R * MQE_HIST * MQE_H2_FRAME); }
   DA(st.last_loco, (size_t)R * 12); DA(st.last_two_loco, (size_t)R * 12); DA(st.act_hist, (size_t)4 * R * 12);
   DA(st.gait, R); DA(st.clock, (size_t)R * 4); DA(st.blv, (size_t)R * 3); DA(st.bav, (size_t)R * 3); DA(st.pg, (size_t)R * 3);
   DA(st.bquat, (size_t)R * 4); DA(st.obs_bag, (size_t)R * MQE_OBS_BAG); DA(st.wobs, (size_t)N * s->Aw * s->D + (size_t)N * s->Aw + N); st.wrew = st.wobs + (size_t)N * s->Aw * s->D; st.wdone = st.wrew + (size_t)N * s->Aw;   // one buffer: obs | reward | done
@@ -570,7 +590,7 @@ static int policy_step(mqe_sim* s, const float* command, hipStream_t q, const fl
     ProfScope ps(s, PROF_GEMM_L0, q);
     // fused layer 0 of both networks over the ring: ELU on the adaptation columns only
     if (s->gemm_split)
-      launch_gemm2(q, s->st.hist2, 2 * MQE_HIST * MQE_FRAME, s->hist_pos * (MQE_FRAME / 8), MQE_HIST * MQE_FRAME / 8, s->l0,
+      launch_gemm2(q, s->st.hist2, 2 * MQE_HIST * MQE_H2_FRAME, s->hist_pos * (MQE_H2_FRAME / 8), MQE_HIST * MQE_H2_FRAME / 8, s->l0,
                    s->P1, s->ldP1, R, s->ada_h0);
     else
       launch_gemm(q, s->st.hist, MQE_HIST * MQE_FRAME, s->hist_pos * (MQE_FRAME / 4), MQE_HIST * MQE_FRAME / 4, s->l0, s->P1, s->ldP1, R, s->ada_h0);
