@@ -196,7 +196,7 @@ __host__ __device__ inline PhysLds phys_lds_layout(int A, int P, int ND, int nbo
   const int scratch = o;
   L.fcol = o; o += A * 64;                                  // the four hip composites of every robot on their way to the base lane
   L.legc = o; o += A * 4 * LEGC_STRIDE;
-  L.basei = o; o += A * 12;
+  L.basei = o; o += A * 24;                                 // per robot: upper triangle of the base block, then of the Schur complement (21 values)
   L.sph = scratch;
   if (scratch + nsph * 4 > o) o = scratch + nsph * 4;
   // row sweep (scenes of <= 4 actors): side A of every contact and the per-contact solve record, written over the link records once the
@@ -447,8 +447,12 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       if (depth == 3) cpl2 = dot(Sa2, Fn) + dot(Sv2, Ff);
       lds[L.rhs + br * MQE_RD + 6 + j] = lds[L.tau + br * 12 + j] - hj;
     } else if (is_rbody) {
-      float* bi = lds + L.basei + br * 12;
-      for (int k = 0; k < 10; k++) bi[k] = X[k];
+      // base block M_bb = [m 1, -[h]x; [h]x, Ibar] as its upper triangle, row-major (00 01 .. 05 11 .. 55): what the leg blocks'
+      // C terms are subtracted from, entry by entry, further down
+      float4* b4 = reinterpret_cast<float4*>(lds + L.basei + br * 24);
+      b4[0] = make_float4(X[0], 0.0f, 0.0f, 0.0f);      b4[1] = make_float4(X[3], -X[2], X[0], 0.0f);
+      b4[2] = make_float4(-X[3], 0.0f, X[1], X[0]);     b4[3] = make_float4(X[2], -X[1], 0.0f, X[4]);
+      b4[4] = make_float4(X[7], X[8], X[5], X[9]);      b4[5] = make_float4(X[6], 0.0f, 0.0f, 0.0f);
       float* rh = lds + L.rhs + br * MQE_RD;
       rh[0] = -X[13]; rh[1] = -X[14]; rh[2] = -X[15]; rh[3] = -X[10]; rh[4] = -X[11]; rh[5] = -X[12];
     }
@@ -496,24 +500,26 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   __syncthreads();
   TSTAMP(3);
   TSTAMP(4);
+  // ---- Schur complement S = M_bb - sum_legs C, one lane per entry of the upper triangle (the six lanes that factor it below would
+  // otherwise each subtract all four C matrices) -----------------------------------------------------------------------------------
+  for (int t = lane; t < A * 21; t += 64) {
+    const int r = t / 21, q = t - r * 21;
+    float* sb = lds + L.basei + r * 24 + q;
+    const float* cq = lds + L.legc + r * 4 * LEGC_STRIDE + q;
+    *sb = (((*sb - cq[0]) - cq[LEGC_STRIDE]) - cq[2 * LEGC_STRIDE]) - cq[3 * LEGC_STRIDE];
+  }
+  __syncthreads();
   // ---- 6x6 Schur complement inverse: lane (robot, column) --------------------------------------------------------
   if (lane < A * 6) {
     const int r = lane / 6, col = lane - r * 6;
-    const float* bi = lds + L.basei + r * 12;
-    float mt = bi[0], hx = bi[1], hy = bi[2], hz = bi[3];
     float S[6][6];
-    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) S[i][j] = 0.0f;
-    S[0][0] = S[1][1] = S[2][2] = mt;
-    // M_lin,ang = -[h]x
-    S[0][4] = hz; S[0][5] = -hy; S[1][3] = -hz; S[1][5] = hx; S[2][3] = hy; S[2][4] = -hx;
-    S[3][3] = bi[4]; S[4][4] = bi[5]; S[5][5] = bi[6]; S[3][4] = bi[7]; S[3][5] = bi[8]; S[4][5] = bi[9];
-    for (int k = 0; k < 4; k++) {
-      const float4* C4 = reinterpret_cast<const float4*>(lds + L.legc + (r * 4 + k) * LEGC_STRIDE);
-      float Cc[24];
+    {
+      const float4* s4 = reinterpret_cast<const float4*>(lds + L.basei + r * 24);
+      float Su[24];
 #pragma unroll
-      for (int w = 0; w < 6; w++) { const float4 t = C4[w]; Cc[4 * w] = t.x; Cc[4 * w + 1] = t.y; Cc[4 * w + 2] = t.z; Cc[4 * w + 3] = t.w; }
+      for (int w = 0; w < 6; w++) { const float4 t = s4[w]; Su[4 * w] = t.x; Su[4 * w + 1] = t.y; Su[4 * w + 2] = t.z; Su[4 * w + 3] = t.w; }
       int q = 0;
-      for (int i = 0; i < 6; i++) for (int j = i; j < 6; j++) S[i][j] -= Cc[q++];
+      for (int i = 0; i < 6; i++) for (int j = i; j < 6; j++) S[i][j] = Su[q++];
     }
     for (int i = 0; i < 6; i++) for (int j = 0; j < i; j++) S[i][j] = S[j][i];
     // Cholesky (lower), then solve S x = e_col

@@ -287,7 +287,7 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   if (getenv("MQE_VERBOSE")) fprintf(stderr, "mqe: physics LDS %zu B per env (wavefront)\n", s->phys_lds_bytes);
   if (const char* pad = getenv("MQE_PHYS_LDS_PAD")) s->phys_lds_bytes += (size_t)atoi(pad);   // experiments: caps the physics kernel's waves per CU
   // the records the physics kernel moves as 16 B words must start on 16 B (kernels_physics.hpp)
-  if ((L.body | L.sph | L.con | L.side | L.leg | L.legc | L.sinv | L.fcol | L.acc | L.rhs | L.phi | L.srec) & 3) { return fail(-4, "physics LDS layout: a 16 B record area is misaligned"); }
+  if ((L.body | L.sph | L.con | L.side | L.leg | L.legc | L.basei | L.sinv | L.fcol | L.acc | L.rhs | L.phi | L.srec) & 3) { return fail(-4, "physics LDS layout: a 16 B record area is misaligned"); }
   if (s->phys_lds_bytes > 160 * 1024) { return fail(-4, "physics LDS footprint exceeds 160 KiB"); }
   s->substeps_fn = pick_substeps(m, s->phys_lds_bytes);
   if (s->phys_lds_bytes > 48 * 1024)
