@@ -9,13 +9,20 @@ BarrierTrack terrain, config tree, OpenRL adapter.  Where the reference needs th
 with a scripted stand-in `FakeGym` whose `simulate()` overwrites the state tensors from arrays that are
 stored in the fixture, so the product can replay exactly the same states.
 
-usage:  python tools/gen_golden.py [--only name,...]
+usage:  python tools/gen_golden.py [--only name,...] [--out DIR]
+
+One invocation regenerates everything.  Every stage runs in a forked child process: the reference's env constructors
+assign tensors onto its config CLASSES (class attributes, shared by every later user of the class), so a stage that ran
+after another one used to see a config tree that `class_to_dict` could not walk any more (RecursionError); a child
+starts from the state right after import and leaves nothing behind.  `--out DIR` writes fixtures and product assets
+under DIR/golden and DIR/assets instead of the committed places (tests/test_golden_regeneration.py compares them).
 """
 import argparse
 import importlib.util
 import json
 import os
 import sys
+import traceback
 import types
 
 import numpy as np
@@ -1031,11 +1038,34 @@ def gen_adapter():
          n_infos=np.int64(len(infos)), br_keys=np.array(list(br.keys())), br_vals=np.array([float(v) for v in br.values()]))
 
 
+def run_stage(fn, *args, **kw):
+    """Run one generator stage in a forked child (see the module docstring); the parent only waits for it."""
+    sys.stdout.flush(); sys.stderr.flush()
+    pid = os.fork()
+    if pid == 0:
+        code = 0
+        try:
+            fn(*args, **kw)
+        except BaseException:
+            traceback.print_exc()
+            code = 1
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(code)
+    _, status = os.waitpid(pid, 0)
+    if status != 0:
+        raise SystemExit(f"gen_golden: stage {fn.__name__}{args[:1]} failed (status {status})")
+
+
 def main():
+    global GOLD, ASSETS
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
+    ap.add_argument("--out", default="", help="write under DIR/golden and DIR/assets instead of tests/golden and the package assets")
     a = ap.parse_args()
     only = set(a.only.split(",")) if a.only else None
+    if a.out:
+        GOLD = os.path.join(os.path.abspath(a.out), "golden")
+        ASSETS = os.path.join(os.path.abspath(a.out), "assets")
     os.makedirs(GOLD, exist_ok=True)
     os.makedirs(ASSETS, exist_ok=True)
     act, ada = gen_mlps()
@@ -1043,62 +1073,62 @@ def main():
     def want(n):
         return only is None or n in only
     if want("gait"):
-        gen_gait_clock()
+        run_stage(gen_gait_clock)
     if want("fullstep"):
         from mqe.envs.configs.go1_gate_config import Go1GateCfg
         from mqe.envs.configs.go1_sheep_config import NineSheepCfg
         from mqe.envs.configs.go1_seesaw_config import Go1SeesawCfg
         from mqe.envs.configs.go1_football_config import Go1FootballDefenderCfg
-        gen_fullstep("fullstep_gate", Go1, Go1GateCfg, N=3, T=12, act=act, ada=ada)
-        gen_fullstep("fullstep_seesaw", Go1Object, Go1SeesawCfg, N=3, T=12, act=act, ada=ada)
-        gen_fullstep("fullstep_football", Go1FootballDefender, Go1FootballDefenderCfg, N=3, T=12, act=act, ada=ada)
-        gen_fullstep("fullstep_sheep", Go1Sheep, NineSheepCfg, N=3, T=12, act=act, ada=ada)
+        run_stage(gen_fullstep, "fullstep_gate", Go1, Go1GateCfg, N=3, T=12, act=act, ada=ada)
+        run_stage(gen_fullstep, "fullstep_seesaw", Go1Object, Go1SeesawCfg, N=3, T=12, act=act, ada=ada)
+        run_stage(gen_fullstep, "fullstep_football", Go1FootballDefender, Go1FootballDefenderCfg, N=3, T=12, act=act, ada=ada)
+        run_stage(gen_fullstep, "fullstep_sheep", Go1Sheep, NineSheepCfg, N=3, T=12, act=act, ada=ada)
     if want("fullstep_game"):     # the two free-play football tasks (Go1Object + ball, 2 and 4 robots)
         from mqe.envs.configs.go1_football_config import Go1Football1vs1Cfg, Go1Football2vs2Cfg
-        gen_fullstep("fullstep_football1v1", Go1Object, Go1Football1vs1Cfg, N=3, T=12, act=act, ada=ada)
-        gen_fullstep("fullstep_football2v2", Go1Object, Go1Football2vs2Cfg, N=2, T=10, act=act, ada=ada)
+        run_stage(gen_fullstep, "fullstep_football1v1", Go1Object, Go1Football1vs1Cfg, N=3, T=12, act=act, ada=ada)
+        run_stage(gen_fullstep, "fullstep_football2v2", Go1Object, Go1Football2vs2Cfg, N=2, T=10, act=act, ada=ada)
     if want("fullstep_pushbox"):
         from mqe.envs.configs.go1_pushbox_config import Go1PushboxCfg
-        gen_fullstep("fullstep_pushbox", Go1Object, Go1PushboxCfg, N=3, T=12, act=act, ada=ada)
+        run_stage(gen_fullstep, "fullstep_pushbox", Go1Object, Go1PushboxCfg, N=3, T=12, act=act, ada=ada)
     if want("wrappers"):
-        gen_wrappers()
+        run_stage(gen_wrappers)
     if want("wrapper_game"):
-        gen_game_wrapper()
+        run_stage(gen_game_wrapper)
     if want("wrapper_gate"):
-        gen_gate_wrapper()
+        run_stage(gen_gate_wrapper)
     if want("wrapper_pushbox"):
-        gen_wrappers(only_pushbox=True)
+        run_stage(gen_wrappers, only_pushbox=True)
     if want("fullstep_rotation"):
         from mqe.envs.configs.go1_rotation_config import Go1RotationCfg
-        gen_fullstep("fullstep_rotation", Go1Object, Go1RotationCfg, N=2, T=12, act=act, ada=ada)
+        run_stage(gen_fullstep, "fullstep_rotation", Go1Object, Go1RotationCfg, N=2, T=12, act=act, ada=ada)
     if want("wrapper_rotation"):
-        gen_rotation_wrapper()
+        run_stage(gen_rotation_wrapper)
     if want("fullstep_scenery"):
         from mqe.envs.configs.go1_bridge_config import Go1BridgeCfg
         from mqe.envs.configs.go1_wrestling_config import Go1WrestlingCfg
-        gen_fullstep("fullstep_bridge", Go1Object, Go1BridgeCfg, N=2, T=12, act=act, ada=ada)
-        gen_fullstep("fullstep_wrestling", Go1Object, Go1WrestlingCfg, N=2, T=12, act=act, ada=ada)
+        run_stage(gen_fullstep, "fullstep_bridge", Go1Object, Go1BridgeCfg, N=2, T=12, act=act, ada=ada)
+        run_stage(gen_fullstep, "fullstep_wrestling", Go1Object, Go1WrestlingCfg, N=2, T=12, act=act, ada=ada)
     if want("wrapper_scenery"):
-        gen_scenery_wrappers()
+        run_stage(gen_scenery_wrappers)
     if want("fullstep_pvt"):       # Go1.step's else-branch (go1.py:42-44): control types P / V / T on the gate scene
         from mqe.envs.configs.go1_gate_config import Go1GateCfg
         for c in ("P", "V", "T"):
             ctl = type("control", (Go1GateCfg.control,), {"control_type": c})
             cfg_c = type("Go1Gate" + c + "Cfg", (Go1GateCfg,), {"control": ctl})
-            gen_fullstep("fullstep_gate_" + c, Go1, cfg_c, N=3, T=10, act=act, ada=ada, ctrl=c)
+            run_stage(gen_fullstep, "fullstep_gate_" + c, Go1, cfg_c, N=3, T=10, act=act, ada=ada, ctrl=c)
     if want("fullstep_tug"):
         from mqe.envs.configs.go1_tug_config import Go1TugCfg
-        gen_fullstep("fullstep_tug", Go1Object, Go1TugCfg, N=2, T=12, act=act, ada=ada)
+        run_stage(gen_fullstep, "fullstep_tug", Go1Object, Go1TugCfg, N=2, T=12, act=act, ada=ada)
     if want("wrapper_tug"):
-        gen_tug_wrapper()
+        run_stage(gen_tug_wrapper)
     if want("terrain"):
-        gen_terrain_and_configs()
+        run_stage(gen_terrain_and_configs)
     if want("terrain_perlin"):
-        gen_perlin_terrain()
+        run_stage(gen_perlin_terrain)
     if want("urdf_facts"):
-        gen_urdf_facts()
+        run_stage(gen_urdf_facts)
     if want("adapter"):
-        gen_adapter()
+        run_stage(gen_adapter)
 
 
 if __name__ == "__main__":
