@@ -20,6 +20,7 @@ NOTE: body_latest.jit is missing from the reference snapshot, so the locomotion-
 synthetic 2102-512-256-128-12 ELU MLP (mqe/utils/policy_weights.py); the adaptation module and actuator net are real.
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -81,7 +82,8 @@ def time_variant(task, N, dev, steps, warmup, env_vars):
     os.environ.update(env_vars)
     try:
         margs = make_args(task, N, 0, dev)
-        env, _ = make_mqe_env(task, margs, custom_cfg(margs))
+        with contextlib.redirect_stdout(sys.stderr):
+            env, _ = make_mqe_env(task, margs, custom_cfg(margs))
     finally:
         for k, v in old.items():
             if v is None:
@@ -141,7 +143,8 @@ def main():
     N = args.num_envs
     Go1.shard = (N * world, N * rank)           # global env ids -> identical scene regardless of the GPU count
     margs = make_args(args.task, N, 0, dev)
-    env, cfg = make_mqe_env(args.task, margs, custom_cfg(margs))
+    with contextlib.redirect_stdout(sys.stderr):     # "Setting seed: 0" (as upstream, helpers.py:82) must not precede the ONE JSON line on stdout
+        env, cfg = make_mqe_env(args.task, margs, custom_cfg(margs))
     A = env.num_agents
     eng = env.env.engine
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -222,9 +225,10 @@ def main():
         b = (args.warmup + args.steps - 1) & 1
         assert n_gathers[0] == args.warmup + args.steps, (n_gathers[0], args.warmup + args.steps)
         mine = gather[b].view(world, -1)[rank]
-        assert torch.equal(mine, env.returned_batch), "all-gather: own slice differs from the returned batch"
-        assert torch.equal(mine[obs.numel() + N * A:] != 0, env.env.reset_buf), "all-gather: done flags"
+        assert torch.equal(mine.view(torch.int32), env.returned_batch.view(torch.int32)), "all-gather: own slice differs from the returned batch"
+        assert torch.equal(mine[obs.numel() + N * A:].view(torch.uint8)[:N].view(torch.bool), env.env.reset_buf), "all-gather: done flags"
     ms, _ = eng.profile_read(12)
+    overflow_substeps = int(env.env.contact_overflow.sum().item())      # truncated contact lists over the whole run (after the clock stopped)
     eng.profile_enable(False)
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -336,6 +340,7 @@ def main():
             "hbm_step_algorithmic_frac": round(step_bytes * args.steps / elapsed / 1e9 / PEAK_HBM_GBS, 5),
             "kernel_time_share": {PROF_NAMES[i]: round(kms[i] / tot, 4) for i in range(6)},
             "gpu_busy_ms_per_step": round(tot / sampled, 4),
+            "contact_overflow_substeps": overflow_substeps,      # env-substeps whose bounded contact list was truncated (of envs x 4 x steps)
             "hip_event_sampling": f"kernel classes of every {prof_every}-th timed step bracketed" if prof_every else "off",
             "dtype_note": "state, physics, actuator net: f32.  Policy layer 0 + tail: f32 operands carried as two f16 planes (22 significand bits, "
                           "3 MFMA terms), held to the same 5e-5 bound as exact f32; strict_f32 = the same run on the exact-f32 kernels",

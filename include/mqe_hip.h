@@ -124,15 +124,15 @@ typedef struct {
   float command_obs[70];                  /* _fill_command_obs (go1.py:411-479) */
   float cmd_lin_scale, cmd_ang_scale;     /* 2.0, 0.25 */
   int32_t clip_command;                   /* 1: Go1.step re-clips to +-1 (go1.py:38); 0: defender variant */
-  /* terrain: 2D signed distance [m] to the wall set, sampled at cell centres of the BarrierTrack heightfield */
+  /* terrain: 2D signed distance [m] to the wall set, raster entry (i, j) at the world point (i hs, j hs) = the vertices of the BarrierTrack heightfield mesh */
   const float* wall_sdf;                  /* host pointer, [sdf_nx][sdf_ny] */
   int32_t sdf_nx, sdf_ny;
   float horizontal_scale, wall_height, ground_z;
   /* low relief of the walkable surface (Perlin noise, barrier_track.py:372-393,421-439; perlin.py:33-72): height [m] above
-   * ground_z at the same cell centres as wall_sdf, [sdf_nx][sdf_ny] host pointer, or NULL for the flat slab */
+   * ground_z at the same raster points as wall_sdf, [sdf_nx][sdf_ny] host pointer, or NULL for the flat slab */
   const float* ground_height;
   /* walls of different heights in one scene (barrier_track.py:167-173,191-199,218-239: a (lo, hi) wall_height draws one height per
-   * block): top [m] of the wall nearest to each cell centre, [sdf_nx][sdf_ny] host pointer, or NULL = wall_height everywhere */
+   * block): top [m] of the wall nearest to each raster point, [sdf_nx][sdf_ny] host pointer, or NULL = wall_height everywhere */
   const float* wall_top;
   float soft_dof_pos_limit;               /* rewards.soft_dof_pos_limit (legged_robot.py:317-321): fraction of the URDF joint range
                                              outside of which MQE_T_SUBSTEP_EXCEED_DOF_POS_LIMITS flags a joint; 0 = 1.0 */
@@ -193,9 +193,9 @@ enum {
   MQE_T_RESET_COUNT,       /* int32 [N] */
   MQE_T_SUBSTEP_TORQUES,   /* [N,4,12A] (legged_robot.py:112-115) */
   MQE_T_NPC_NOISE,         /* [N,P,3] injected N(0,1) for the sheep script when noise_mode is SCRIPTED */
-  MQE_T_WRAPPER_PACKED,    /* [N*Aw*D + N*Aw + N] everything a step returns as ONE contiguous buffer: wrapper observation, reward,
-                              then MQE_T_RESET_BUF once more as 0.0 / 1.0 -- snapshotted with a single copy, and that copy is what
-                              the env-sharded runner all-gathers */
+  MQE_T_WRAPPER_PACKED,    /* f32 [N*Aw*D + N*Aw + ceil(N/4)] everything a step returns as ONE contiguous buffer: wrapper observation,
+                              reward, then MQE_T_RESET_BUF once more as N BYTES (0 / 1; pad bytes of the last word are never written) --
+                              the caller views them as bool in place, and the whole buffer is what the env-sharded runner all-gathers */
   MQE_T_DOMAIN_PARAMS,     /* [R][8]: shape friction of the robot's env, added base mass, base CoM shift xyz, 3 unused; read by every
                               physics step, writable (tests / curricula) */
   MQE_T_SUBSTEP_DOF_VEL,   /* [N,4,12A] joint velocities after each substep (legged_robot.py:114) */
@@ -279,6 +279,10 @@ int mqe_step_joint(mqe_sim* s, const float* actions12, void* stream);
  * link B, separation, normal xyz) from the CURRENT state, without advancing it; outputs are host pointers */
 int mqe_debug_dynamics(mqe_sim* s, int env, int robot, float* minv_out_host, int* nc_out_host, float* contacts_out_host);
 int mqe_debug_times(long long* out16);   /* clock64 stamps of the phases of the last mqe_debug_dynamics launch */
+/* per-phase counter runs (tools/phase_counters.py): the following mqe_simulate launches leave the wavefront after phase tap `tap`
+ * and write nothing back (tap < 0: normal launches again).  Two-robot scenes without objects only; any other scene is refused.
+ * The environment variable MQE_DEBUG_STOP_PHASE sets the same thing when the handle is created. */
+int mqe_debug_stop_phase(mqe_sim* s, int tap);
 
 /* bookkeeping for benchmarks: time of the dominant kernel measured with HIP events on `stream` */
 int mqe_profile_enable(mqe_sim* s, int on);

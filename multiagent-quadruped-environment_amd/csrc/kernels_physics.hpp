@@ -722,10 +722,11 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       { const float4 q = *reinterpret_cast<const float4*>(sp); c = v3(q.x, q.y, q.z); rad = q.w; }
       if (act < A) { body = rm.sphere_body[sidx]; rep = act * MQE_NREP + rm.sphere_reported[sidx]; }
       else { body = 0; rep = A * MQE_NREP + (act - A); }
-      // terrain maps are sampled bilinearly at cell centres: the wall set's signed distance and, when the scene has one, the
-      // relief of the walkable surface (Perlin noise, barrier_track.py:372-393)
+      // terrain maps are sampled bilinearly; raster entry (i, j) sits at the world point (i hs, j hs) -- the vertices of upstream's
+      // convert_heightfield_to_trimesh mesh (barrier_track.py:483-497): the wall set's signed distance and, when the scene has one,
+      // the relief of the walkable surface (Perlin noise, barrier_track.py:372-393)
       const float hs = m->hs;
-      float fx = c.x / hs - 0.5f, fy = c.y / hs - 0.5f;
+      float fx = c.x / hs, fy = c.y / hs;
       const int nx = m->sdf_nx, ny = m->sdf_ny;
       fx = fminf(fmaxf(fx, 0.0f), (float)(nx - 1)); fy = fminf(fmaxf(fy, 0.0f), (float)(ny - 1));
       int ix = (int)fx, iy = (int)fy;

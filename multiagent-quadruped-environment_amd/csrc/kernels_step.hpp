@@ -361,7 +361,7 @@ __device__ __forceinline__ void reset_env_dev(const DevModel* m, const DevState&
   for (int k = 0; k < 12 * A; k++) st.last_actions[(size_t)e * 12 * A + k] = 0.0f;
   st.ep_len[e] = 0;
   st.reset_buf[e] = 1;
-  st.wdone[e] = 1.0f;
+  st.wdone[e] = 1;
   for (int a = 0; a < A; a++) st.gait[e * A + a] = 0.0f;
   // history zeroing (go1.py:145) is done by k_reset_history, 16 B per thread
   st.reset_count[e] = cnt + 1;
@@ -831,7 +831,7 @@ __global__ void __launch_bounds__(64) k_post_physics(const DevModel* m, DevState
     if (m->termination_flags & MQE_TERM_PITCH) st.p_term[e] = pterm;
     if (m->termination_flags & MQE_TERM_Z_HIGH) st.zh_term[e] = zh;
     st.reset_buf[e] = reset;
-    st.wdone[e] = (float)reset;                 // the flag once more, in the packed return batch
+    st.wdone[e] = reset;                        // the flag once more, in the packed return batch (byte tail: a torch.bool view, no kernel)
     if (m->terminate_on_base_contact) st.collide_buf[e] = reset;
   }
   if (mine) {

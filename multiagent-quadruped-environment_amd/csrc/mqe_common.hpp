@@ -42,7 +42,7 @@ struct DevModel {
   float default_dof_pos[12]; float command_obs[70]; float cmd_lin_scale, cmd_ang_scale; int clip_command;
   const float* wall_sdf; int sdf_nx, sdf_ny; float hs, wall_height, ground_z;
   const float* wall_top;                           // per-cell wall top [m] (walls of different heights), or nullptr = wall_height
-  const float* ground_height;                      // relief of the walkable surface above ground_z at the SDF's cell centres, or nullptr
+  const float* ground_height;                      // relief of the walkable surface above ground_z at the SDF's raster points, or nullptr
   float soft_lo[12], soft_hi[12];                  // soft joint position limits (legged_robot.py:317-321) of MQE_T_SUBSTEP_EXCEED_DOF_POS_LIMITS
   const float *env_origins, *agent_origins, *base_init, *npc_init, *gate_pos;
   int termination_flags, terminate_on_base_contact, max_episode_length;
@@ -60,13 +60,14 @@ struct DevModel {
 // device pointers of all state tensors (kernel argument by value)
 struct DevState {
   float *root, *dof, *cf, *torques, *actions, *last_actions, *loco_obs, *hist, *last_loco, *last_two_loco, *act_hist;
-  float *gait, *clock, *blv, *bav, *pg, *bquat, *obs_bag, *wobs, *wrew, *wdone, *rsum, *sheep_avg, *sheep_var, *sub_tau, *npc_noise;
+  float *gait, *clock, *blv, *bav, *pg, *bquat, *obs_bag, *wobs, *wrew, *rsum, *sheep_avg, *sheep_var, *sub_tau, *npc_noise;
   float *w_last, *w_last2, *cmd, *last_dof_vel;
   float* sub_dof_vel; uint8_t* sub_exceed; int32_t* overflow;   // per-substep logs (legged_robot.py:114-115); truncated-contact-list counter
   float *dparams, *lag_buf;                 // [R][8] friction / added mass / CoM shift (MQE_T_DOMAIN_PARAMS); [(lag + 1)][R][12] scaled actions
   uint16_t* hist2;                          // compact split-f16 copy of the history ring: [R][240 units][2 planes][8] (k_gemm_h2; MQE_H2_FRAME)
   int32_t *ep_len, *reset_count;
   uint8_t *reset_buf, *collide_buf, *time_out, *r_term, *p_term, *zh_term, *w_have_last, *w_delayed_reset;
+  uint8_t* wdone;         // the reset flags once more, as the byte tail of the packed return batch (obs | reward | done)
 };
 
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }

@@ -63,6 +63,7 @@ struct mqe_sim {
   bool tail_fused = false;            // k_policy_tail: the reference network shapes (256-128-2 / 512-256-128-12 after layer 0)
   size_t phys_lds_bytes = 0;
   bool fuse_substeps = true;
+  int dbg_stop_phase = -1;            // MQE_DEBUG_STOP_PHASE, read once at creation (tools/phase_counters.py)
   // profiling
   bool prof = false, prof_now = false;   // prof_now: this call is one of the sampled ones
   bool step_open = false;                // between mqe_step_begin and mqe_step_end
@@ -296,6 +297,18 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
       return fail(-4, "cannot raise dynamic LDS limit");
     }
   s->fuse_substeps = getenv("MQE_NO_FUSE_SUBSTEPS") == nullptr && d->decimation <= 4;
+  // Debug / experiment switches are read HERE, once per handle, never on the launch path; MQE_VERBOSE lists the ones in effect.
+  if (const char* sp = getenv("MQE_DEBUG_STOP_PHASE")) {
+    // per-phase counter runs: the wavefront leaves k_simulate_a2 after that phase tap WITHOUT writing the state back, so the
+    // unfused path stops advancing.  Only the two-robot, no-object scene has that kernel: refuse everywhere else.
+    if (s->substeps_fn != (void (*)(const DevModel*, DevState, int, int))k_substeps<2, 0>) { return fail(-4, "MQE_DEBUG_STOP_PHASE applies to two-robot scenes without objects only (k_simulate_a2)"); }
+    s->dbg_stop_phase = atoi(sp);
+  }
+  if (getenv("MQE_VERBOSE")) {
+    const char* names[] = {"MQE_LANE_SWEEP", "MQE_PHYS_LDS_PAD", "MQE_NO_FUSE_SUBSTEPS", "MQE_GEMM_SPLIT", "MQE_NO_FUSED_TAIL", "MQE_DEBUG_STOP_PHASE"};
+    for (const char* n : names)
+      if (const char* v = getenv(n)) fprintf(stderr, "mqe: override in effect: %s=%s\n", n, v);
+  }
 #define UP(dst, src, n) if (upload(s, &(dst), (src), (n))) { return fail(-5, "device upload failed"); }
   UP(m.wall_sdf, d->wall_sdf, (size_t)d->sdf_nx * d->sdf_ny);
   UP(m.ground_height, d->ground_height, (size_t)d->sdf_nx * d->sdf_ny);
@@ -399,7 +412,7 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   if (s->gemm_split) { DA(st.hist2, (size_t)2 * R * MQE_HIST * MQE_H2_FRAME); }
   DA(st.last_loco, (size_t)R * 12); DA(st.last_two_loco, (size_t)R * 12); DA(st.act_hist, (size_t)4 * R * 12);
   DA(st.gait, R); DA(st.clock, (size_t)R * 4); DA(st.blv, (size_t)R * 3); DA(st.bav, (size_t)R * 3); DA(st.pg, (size_t)R * 3);
-  DA(st.bquat, (size_t)R * 4); DA(st.obs_bag, (size_t)R * MQE_OBS_BAG); DA(st.wobs, (size_t)N * s->Aw * s->D + (size_t)N * s->Aw + N); st.wrew = st.wobs + (size_t)N * s->Aw * s->D; st.wdone = st.wrew + (size_t)N * s->Aw;   // one buffer: obs | reward | done
+  DA(st.bquat, (size_t)R * 4); DA(st.obs_bag, (size_t)R * MQE_OBS_BAG); DA(st.wobs, (size_t)N * s->Aw * s->D + (size_t)N * s->Aw + (N + 3) / 4); st.wrew = st.wobs + (size_t)N * s->Aw * s->D; st.wdone = (uint8_t*)(st.wrew + (size_t)N * s->Aw);   // one buffer: obs | reward | done (N bytes)
   DA(st.rsum, (size_t)N * MQE_MAX_REWARD_TERMS); DA(st.sheep_avg, (size_t)N * 2); DA(st.sheep_var, N);
   DA(st.sub_dof_vel, (size_t)N * 4 * 12 * A); DA(st.sub_exceed, (size_t)N * 4 * 12 * A); DA(st.overflow, N);
   DA(st.sub_tau, (size_t)N * 4 * 12 * A); DA(st.npc_noise, (size_t)N * (P ? P : 1) * 3);
@@ -509,7 +522,7 @@ extern "C" int mqe_sim_tensor(mqe_sim* s, int kind, mqe_tensor_view* v) {
     case MQE_T_SUBSTEP_EXCEED_DOF_POS_LIMITS: SH(3, N, 4, 12 * A, 0, 2); break;
     case MQE_T_CONTACT_OVERFLOW: SH(1, N, 0, 0, 0, 1); break;
     case MQE_T_NPC_NOISE: SH(3, N, P, 3, 0, 0); break;
-    case MQE_T_WRAPPER_PACKED: SH(1, N * s->Aw * s->D + N * s->Aw + N, 0, 0, 0, 0); break;
+    case MQE_T_WRAPPER_PACKED: SH(1, N * s->Aw * s->D + N * s->Aw + (N + 3) / 4, 0, 0, 0, 0); break;
     case MQE_T_DOMAIN_PARAMS: SH(2, s->R, 8, 0, 0, 0); break;
   }
   return 0;
@@ -650,12 +663,10 @@ static void launch_torques(mqe_sim* s, int dec_i, hipStream_t q) {
 static void launch_simulate(mqe_sim* s, hipStream_t q) {
   ProfScope ps(s, PROF_SIMULATE, q);
   PhysDebug dbg = {nullptr, nullptr, nullptr, 0, nullptr, -1};
-  if (const char* sp = getenv("MQE_DEBUG_STOP_PHASE")) {     // tools/phase_counters.py: the wavefront leaves after that phase tap
-    dbg.stop_after = atoi(sp);
-    if (s->substeps_fn == (void (*)(const DevModel*, DevState, int, int))k_substeps<2, 0>) {
-      hipLaunchKernelGGL(k_simulate_a2, dim3(s->N), dim3(64), s->phys_lds_bytes, q, s->dm, s->st, 0, dbg.stop_after >= 0 ? 1 : 0, dbg);
-      return;
-    }
+  if (s->dbg_stop_phase >= 0) {             // tools/phase_counters.py: the wavefront leaves after that phase tap (validated at creation)
+    dbg.stop_after = s->dbg_stop_phase;
+    hipLaunchKernelGGL(k_simulate_a2, dim3(s->N), dim3(64), s->phys_lds_bytes, q, s->dm, s->st, 0, 1, dbg);
+    return;
   }
   hipLaunchKernelGGL(k_simulate, dim3(s->N), dim3(64), s->phys_lds_bytes, q, s->dm, s->st, 0, 0, dbg);
 }
@@ -669,6 +680,12 @@ static void launch_post(mqe_sim* s, hipStream_t q, int wrapper_level) {
     hipLaunchKernelGGL(k_post_physics<MQE_MAX_AGENTS>, dim3((s->N + POST_EPW - 1) / POST_EPW), dim3(64), 0, q, s->dm, s->st, wrapper_level, push, s->n_post_steps);   // incl. history zeroing
 }
 
+extern "C" int mqe_debug_stop_phase(mqe_sim* s, int tap) {
+  if (!s) return fail(-1, "null engine handle");
+  if (tap >= 0 && s->substeps_fn != (void (*)(const DevModel*, DevState, int, int))k_substeps<2, 0>) return fail(-4, "phase taps exist for two-robot scenes without objects only (k_simulate_a2)");
+  s->dbg_stop_phase = tap < 0 ? -1 : tap;
+  return 0;
+}
 extern "C" int mqe_policy_step(mqe_sim* s, const float* command, void* stream) {
   if (!s) return fail(-1, "null engine handle");
   policy_step(s, command, (hipStream_t)stream);
@@ -788,7 +805,7 @@ extern "C" int mqe_set_return_buffer(mqe_sim* s, float* packed_dev) {
   float* base = packed_dev ? packed_dev : (float*)s->tens[MQE_T_WRAPPER_PACKED];
   s->st.wobs = base;
   s->st.wrew = base + (size_t)s->N * s->Aw * s->D;
-  s->st.wdone = s->st.wrew + (size_t)s->N * s->Aw;
+  s->st.wdone = (uint8_t*)(s->st.wrew + (size_t)s->N * s->Aw);
   return 0;
 }
 

@@ -287,7 +287,16 @@ def build_desc(cfg, num_envs, terrain, env_origins, agent_origins, gate_pos=None
         d.default_dof_pos[j] = cfg.init_state.default_joint_angles[names[j]]
     d.kp = next((v for k, v in ctl.stiffness.items() if k in names[0]), 0.0)
     d.kd = next((v for k, v in ctl.damping.items() if k in names[0]), 0.0)
-    cmd, _ = fill_command_obs(cfg)
+    cmd, idx = fill_command_obs(cfg)
+    if idx != {"vel": 0}:
+        # go1.py:64-92 lets command.cfg.{body_height, gait_freq, footswing_height, body_pose, stance_width, stance_length, aux_reward}
+        # turn further action columns into live entries 6-17 of the locomotion observation (and vel = False freezes the velocity
+        # command).  The engine's action is the (x, y, yaw) velocity command only: columns 6-17 are constants of the scene, folded into
+        # the layer-0 operand when the handle is created ("compact K").  No shipped task sets these flags and the task
+        # wrappers' (N, A, 3) action scaling could not carry them either; refuse instead of running with the slots silently at 0.
+        extra = sorted(k for k in idx if k != "vel") + ([] if "vel" in idx else ["vel = False"])
+        raise NotImplementedError("command.cfg flags beyond the velocity command are not supported by the HIP engine: " + ", ".join(extra) +
+                                  " (reference go1.py:64-92; the gait parameters are fixed when the engine is created)")
     for k in range(70):
         d.command_obs[k] = cmd[k]
     d.cmd_lin_scale, d.cmd_ang_scale = ctl.obs_scales.lin_vel, ctl.obs_scales.ang_vel

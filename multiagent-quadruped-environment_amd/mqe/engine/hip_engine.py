@@ -43,6 +43,7 @@ class HipEngine(EngineBase):
                            ("reset_all", [vp, vp]), ("step", [vp, vp, vp]), ("step_begin", [vp, vp, vp]), ("step_end", [vp, vp]), ("set_return_buffer", [vp, vp]), ("step_joint", [vp, vp, vp]), ("defender_command", [vp, vp, vp]),
                            ("wrapper_eval", [vp, C.c_int, vp]),
                            ("debug_dynamics", [vp, C.c_int, C.c_int, vp, C.POINTER(C.c_int), vp]),
+                           ("debug_stop_phase", [vp, C.c_int]),
                            ("profile_enable", [vp, C.c_int]),
                            ("profile_read", [vp, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)])):
             f = getattr(lib, "mqe_" + name)

@@ -79,6 +79,17 @@ class Go1:
         self.max_episode_length_s = cfg.env.episode_length_s
         self.max_episode_length = np.ceil(self.max_episode_length_s / self.dt)
         cfg.env.max_episode_length = self.max_episode_length
+        if getattr(cfg.terrain, "curriculum", False) and cfg.terrain.num_rows > 1:
+            # reset_idx -> _update_terrain_curriculum (legged_robot.py:185-186,479-503) moves an env between the rows of the track grid
+            # at run time.  Upstream the rule reads root_states[env_ids] (robot rows indexed by ENV ids), compares with the never
+            # sampled self.commands (all zero: nobody ever moves down), and rewrites env_origins only -- agent_origins, the copy
+            # env_origins_repeat behind obs_buf.base_pos and env_info keep the old track, so the robots stay where they were while
+            # NPCs and the wrappers' relative positions jump.  The engine's in-kernel reset uses fixed per-env origins; rather than
+            # ignore the switch (or reproduce the above) it is refused.  The INITIAL level draw (max_init_terrain_level) and the
+            # per-row difficulty of the generated tracks are supported: with one row the run-time move is the identity.
+            raise NotImplementedError("cfg.terrain.curriculum = True with num_rows > 1: the run-time terrain curriculum "
+                                      "(legged_robot.py:479-503) is not implemented by the HIP engine; set curriculum = False "
+                                      "(tracks of all rows are still generated and assigned as legged_robot.py:980-993 does)")
 
     # ---- scene construction (reference create_sim, legged_robot.py:255-261,754-923,972-997) ---------------------
     def _create_scene(self):
@@ -168,6 +179,9 @@ class Go1:
         self.sheep_pos_avg = T(abi.T_SHEEP_POS_AVG)
         self.sheep_pos_var = T(abi.T_SHEEP_POS_VAR)
         self.npc_noise = T(abi.T_NPC_NOISE)
+        # diagnostic, not in the reference: per env the number of substeps whose bounded contact list was truncated (cumulative
+        # over the handle's life).  A device tensor -- reading it is the caller's sync, the step never does.
+        self.contact_overflow = T(abi.T_CONTACT_OVERFLOW)
         self.rew_buf = torch.zeros(N * A, device=dev)                    # Go1 registers no reward functions (go1.py:198-219)
         self.env_origins = torch.from_numpy(self._env_origins_np).to(dev)
         self.env_origins_repeat = self.env_origins.unsqueeze(1).repeat(1, A, 1).reshape(-1, 3)
@@ -184,7 +198,7 @@ class Go1:
         self.npc_indices = self.actor_indices[:, A:]
         self.obs_buf = ObsBag(self.cfg.obs, T(abi.T_OBS_BAG), self.env_info if self.env_info else None)
         self.privileged_obs_buf = None
-        self.extras = {"time_outs": self.time_out_buf, "episode": {}}
+        self.extras = {"time_outs": self.time_out_buf, "episode": {}, "contact_overflow": self.contact_overflow}
         self.common_step_counter = 0
         if self.task == "football_defender":
             self.gate_pos = torch.zeros(N, 3, device=dev)

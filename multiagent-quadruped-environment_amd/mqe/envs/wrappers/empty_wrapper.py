@@ -69,7 +69,7 @@ class FusedTaskWrapper(EmptyWrapper):
         self.action_scale = torch.tensor([[[2, 0.5, 0.5]]], device=env.device).repeat(self.num_envs, self.num_agents, 1)
         self._wobs = env.engine.tensor(abi.T_WRAPPER_OBS)
         self._wrew = env.engine.tensor(abi.T_WRAPPER_REWARD)
-        self._wpack = env.engine.tensor(abi.T_WRAPPER_PACKED)        # obs | reward | done in one buffer: one snapshot copy per step
+        self._wpack = env.engine.tensor(abi.T_WRAPPER_PACKED)        # obs | reward | done (N bytes) in one buffer
         assert self._wobs.shape[-1] == self.observation_space.shape[0]
         self.reward_buffer = RewardBuffer([n for _, n in REWARD_TERMS[self.task]], env.engine.tensor(abi.T_REWARD_SUMS))
 
@@ -100,5 +100,7 @@ class FusedTaskWrapper(EmptyWrapper):
         n, nr = self._wobs.numel(), self._wrew.numel()
         self.returned_batch = snap                                     # obs | reward | done (0/1): what a sharded runner all-gathers
         # all three returned tensors belong to this step alone (the reference builds a new reset_buf every step; env.reset_buf
-        # is a live view of engine memory that the next step overwrites)
-        return snap[:n].view(self._wobs.shape), snap[n:n + nr].view(self._wrew.shape), snap[n + nr:] != 0, self.env.extras
+        # is a live view of engine memory that the next step overwrites) and all three are VIEWS of the one buffer the step wrote:
+        # the done flags are its byte tail, seen as torch.bool in place -- no torch kernel runs in a step
+        done = snap[n + nr:].view(torch.uint8)[:self.num_envs].view(torch.bool)
+        return snap[:n].view(self._wobs.shape), snap[n:n + nr].view(self._wrew.shape), done, self.env.extras

@@ -14,7 +14,7 @@ Differences by design:
    environments created in one process);
  * Perlin relief (`add_perlin_noise` + `border_perlin_noise`, reference :372-393 with perlin.py:33-72) and curriculum rows
    (`cfg.curriculum`, :421-439,635-638) are generated with the reference's random stream; the engine receives the relief of the
-   walkable surface as a second map, `ground_height` [m] at the SDF's cell centres, next to the wall set.  As upstream, the
+   walkable surface as a second map, `ground_height` [m] at the SDF's raster points (entry (i, j) at the world point (i hs, j hs), the vertices of upstream's trimesh), next to the wall set.  As upstream, the
    per-track noise of `add_track_to_sim` is drawn (it advances `np.random`) but only the whole-map noise of
    `build_heightfield_raw` ever reaches the heightfield: a track keeps it where its noise mask is 1 (:449-459).
 """
@@ -201,6 +201,7 @@ class BarrierTrack:
         wall = np.zeros(hf.shape, dtype=bool)          # pixels raised by a block painter / the border: the engine's wall set
         relief = None                                  # whole-map noise [vertical units], kept unmasked for the engine's ground map
         perlin_map = bool(kwt["add_perlin_noise"] and kwt["border_perlin_noise"])
+        heights = set()                                # distinct wall heights [vertical units]: block walls and the raised border
         if perlin_map:                                 # build_heightfield_raw (:372-393)
             relief = fractal_noise(xSize=self.env_length * cfg.num_rows + 2 * cfg.border_size,
                                    ySize=self.env_width * cfg.num_cols + 2 * cfg.border_size,
@@ -212,10 +213,10 @@ class BarrierTrack:
                 if kwt["border_height"] > 0:
                     wall[:, :self.border] = True
                     wall[:, -self.border:] = True
+                    heights.add(kwt["border_height"] / cfg.vertical_scale)     # the border is a wall of its own height (relief + border_height)
         self.track_origins_px = np.zeros((cfg.num_rows, cfg.num_cols, 3), dtype=int)
         self.track_width_map = np.zeros((cfg.num_rows, cfg.num_cols), dtype=np.float32)
         infos = {}
-        heights = set()
         wall_px = np.zeros_like(hf)                      # height [px units] of the wall standing on each pixel (0: none)
         for c in range(cfg.num_cols):
             for r in range(cfg.num_rows):
@@ -252,7 +253,7 @@ class BarrierTrack:
         self.heightsamples = hf
         self.env_info = infos
         # one wall height per scene is a scalar; a (lo, hi) wall_height draws one per block (:167-173,191-199,218-239) and the engine
-        # then gets a map: at every cell centre the top of the wall nearest to it
+        # then gets a map: at every raster point the top of the wall nearest to it
         self.wall_height = float(max(heights) * cfg.vertical_scale) if heights else 0.0
         self.wall_top = None
         if len(heights) > 1:
@@ -274,7 +275,8 @@ class BarrierTrack:
 
     @staticmethod
     def _signed_distance(wall, hs):
-        """[m] distance from each pixel centre to the wall pixel set (negative inside), exact EDT."""
+        """[m] distance from each raster point to the wall pixel set (negative inside), exact EDT; a pixel is the hs x hs square
+        centred on its raster point (i hs, j hs): see map_sample in oracle/mqe_oracle.c for what that approximates upstream."""
         if not wall.any():
             return np.full(wall.shape, 1e3, np.float32)
         outside = ndimage.distance_transform_edt(~wall) - 0.5

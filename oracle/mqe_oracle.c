@@ -62,12 +62,12 @@ typedef struct mqo_sim {
   int wrapper_side_effects;   /* 1 while a wrapper-level call runs (mqo_step / mqo_wrapper_eval): go1tug re-poses its slider */
   mlp_t act, ada, body;
   float* sdf;
-  float* ground_height;             /* relief of the walkable surface at the SDF's cell centres, or NULL (flat slab) */
+  float* ground_height;             /* relief of the walkable surface at the SDF's raster points, or NULL (flat slab) */
   float* wall_top;                  /* per-cell wall top (walls of different heights), or NULL */
   float *env_origins, *agent_origins, *base_init, *npc_init, *gate_pos;
   /* state */
   float *root, *dof, *cf, *torques, *actions, *last_actions, *loco_obs, *hist, *last_loco, *last_two_loco;
-  float *act_hist, *gait, *clock, *blv, *bav, *pg, *bquat, *obs_bag, *wobs, *wrew, *wdone, *rsum, *sheep_avg, *sheep_var;
+  float *act_hist, *gait, *clock, *blv, *bav, *pg, *bquat, *obs_bag, *wobs, *wrew, *rsum, *sheep_avg, *sheep_var;
   float *sub_tau, *npc_noise, *last_dof_vel;
   float* sub_dof_vel; uint8_t* sub_exceed; int32_t* overflow;   /* legged_robot.py:114-115 logs; truncated-contact-list counter */
   float soft_lo[12], soft_hi[12];
@@ -78,6 +78,7 @@ typedef struct mqo_sim {
   /* wrapper memory */
   float *w_last, *w_last2;          /* per env: previous distances / x positions */
   uint8_t *w_have_last, *w_delayed_reset;
+  uint8_t* wdone;                   /* byte tail of the packed return batch */
   int hist_pos;                     /* ring slot that holds the OLDEST frame == next write slot */
   int n_post_steps;                 /* post_physics_step calls so far (base_quat aliasing, see mqo_reset_all) */
   void* tens[MQE_T_COUNT];
@@ -326,9 +327,9 @@ int mqo_sim_create(const mqe_sim_desc* d, mqo_sim** out) {
   s->bquat = ALLOCF((size_t)R * 4);
   for (int i = 0; i < R; i++) s->bquat[i * 4 + 3] = 1.0f;
   s->obs_bag = ALLOCF((size_t)R * OBS_BAG);
-  s->wobs = ALLOCF((size_t)N * s->Aw * s->D + (size_t)N * s->Aw + N);
+  s->wobs = ALLOCF((size_t)N * s->Aw * s->D + (size_t)N * s->Aw + (size_t)(N + 3) / 4);
   s->wrew = s->wobs + (size_t)N * s->Aw * s->D;        /* one buffer, as in the engine (MQE_T_WRAPPER_PACKED): obs | reward | done */
-  s->wdone = s->wrew + (size_t)N * s->Aw;
+  s->wdone = (uint8_t*)(s->wrew + (size_t)N * s->Aw);
   s->rsum = ALLOCF((size_t)N * MQE_MAX_REWARD_TERMS);
   s->sheep_avg = ALLOCF((size_t)N * 2);
   s->sheep_var = ALLOCF(N);
@@ -427,7 +428,7 @@ int mqo_sim_tensor(mqo_sim* s, int kind, mqe_tensor_view* v) {
     case MQE_T_SUBSTEP_EXCEED_DOF_POS_LIMITS: SH(3, N, 4, 12 * A, 0, 2); break;
     case MQE_T_CONTACT_OVERFLOW: SH(1, N, 0, 0, 0, 1); break;
     case MQE_T_NPC_NOISE: SH(3, N, P, 3, 0, 0); break;
-    case MQE_T_WRAPPER_PACKED: SH(1, N * s->Aw * s->D + N * s->Aw + N, 0, 0, 0, 0); break;
+    case MQE_T_WRAPPER_PACKED: SH(1, N * s->Aw * s->D + N * s->Aw + (N + 3) / 4, 0, 0, 0, 0); break;
     case MQE_T_DOMAIN_PARAMS: SH(2, s->R, 8, 0, 0, 0); break;
   }
   return 0;
@@ -543,11 +544,16 @@ static void sym6_to_mat(const float* s6, real* I) {
   I[0] = s6[0]; I[4] = s6[1]; I[8] = s6[2]; I[1] = I[3] = s6[3]; I[2] = I[6] = s6[4]; I[5] = I[7] = s6[5];
 }
 
-/* bilinear sample of a terrain map (wall SDF / ground relief, values at cell centres) at world (x,y) + gradient */
+/* bilinear sample of a terrain map (wall SDF / ground relief) at world (x,y) + gradient.  Raster entry (i, j) sits at the world point
+ * (i hs, j hs): upstream hands PhysX convert_heightfield_to_trimesh(heightfield, hs, vs, slope_treshold) (barrier_track.py:483-491,
+ * isaacgym.terrain_utils -- third party, not in the snapshot: vertices on linspace(0, (n-1) hs, n)) placed at the track's pixel origin
+ * times hs (:492-497).  With the field configs' slope_treshold = 100 (legged_robot_field_config.py:13) no slope is corrected to a
+ * vertical face, so a raised pixel is a frustum whose flanks run from the neighbouring low vertices to its own: the wall prism of
+ * the signed-distance map (pixel = square centred on its vertex) cuts those flanks at mid height. */
 static real map_sample(const mqo_sim* s, const float* map, real x, real y, real* gx, real* gy) {
   const mqe_sim_desc* d = &s->d;
   real hs = d->horizontal_scale;
-  real fx = x / hs - (real)0.5, fy = y / hs - (real)0.5;   /* samples sit at cell centres */
+  real fx = x / hs, fy = y / hs;                          /* samples sit at the raster's vertices */
   int nx = d->sdf_nx, ny = d->sdf_ny;
   if (!(fx >= 0)) fx = 0; if (!(fy >= 0)) fy = 0;     /* also catches NaN (a diverged state must not index out of the map) */
   if (fx > nx - 1) fx = (real)(nx - 1); if (fy > ny - 1) fy = (real)(ny - 1);
@@ -563,12 +569,12 @@ static real map_sample(const mqo_sim* s, const float* map, real x, real y, real*
 }
 static real sdf_sample(const mqo_sim* s, real x, real y, real* gx, real* gy) { return map_sample(s, s->sdf, x, y, gx, gy); }
 /* top of the wall next to (x, y): one height per scene, or -- walls of different heights (barrier_track.py:167-173: a (lo, hi)
- * wall_height draws one per block) -- the value stored at the nearest cell centre = the height of the wall nearest to that cell */
+ * wall_height draws one per block) -- the value stored at the nearest raster vertex = the height of the wall nearest to it */
 static real wall_top_at(const mqo_sim* s, real x, real y) {
   const mqe_sim_desc* d = &s->d;
   if (!s->wall_top) return d->wall_height;
   real hs = d->horizontal_scale;
-  real fx = x / hs - (real)0.5, fy = y / hs - (real)0.5;
+  real fx = x / hs, fy = y / hs;
   int nx = d->sdf_nx, ny = d->sdf_ny;
   if (!(fx >= 0)) fx = 0; if (!(fy >= 0)) fy = 0;
   if (fx > nx - 1) fx = (real)(nx - 1); if (fy > ny - 1) fy = (real)(ny - 1);
@@ -1271,7 +1277,7 @@ static void reset_env(mqo_sim* s, int e) { /* go1.py:110-145, legged_robot.py:39
   for (int k = 0; k < 12 * A; k++) s->last_actions[(size_t)e * 12 * A + k] = 0.0f;
   s->ep_len[e] = 0;
   s->reset_buf[e] = 1;
-  s->wdone[e] = 1.0f;
+  s->wdone[e] = 1;
   for (int a = 0; a < A; a++) {
     int i = e * A + a;
     s->gait[i] = 0.0f;
@@ -1405,7 +1411,7 @@ int mqo_post_physics_step(mqo_sim* s) {
     if (d->termination_flags & MQE_TERM_Z_HIGH) s->zh_term[e] = zh;
     reset |= rterm | pterm | zh;
     s->reset_buf[e] = reset;
-    s->wdone[e] = (float)reset;
+    s->wdone[e] = (uint8_t)reset;
     /* reset_buf aliases collide_buf when contact termination is on (legged_robot.py:165) */
     if (d->terminate_on_base_contact) s->collide_buf[e] = reset;
   }

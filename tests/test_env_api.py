@@ -297,3 +297,38 @@ def test_sheep_random_walk_draws_oracle():
     a, b, c = _sheep_draws(oracle_engine, 0, N=32), _sheep_draws(oracle_engine, 0, N=32), _sheep_draws(oracle_engine, 1, N=32)
     assert torch.equal(a, b) and (a[0] - a[1]).abs().mean() > 0.5 and (a[0] - c[0]).abs().mean() > 0.5
     assert abs(float(a.mean())) < 0.15 and 0.85 < float(a.std()) < 1.15
+
+
+def test_unsupported_switches_are_refused_not_ignored(oracle_backed):
+    """VERDICT r2 'Missing' 4/5: a config that turns extra command dimensions (go1.py:64-92) or the run-time terrain curriculum
+    (legged_robot.py:479-503) on must not run with the switch silently dropped."""
+    a = args_for("go1gate", 4)
+    base = ENV_DICT["go1gate"]["config"]
+
+    def with_flags(**flags):
+        def edit(cfg):
+            cfg = custom_cfg(a)(cfg)
+            cc = type("cfg", (cfg.command.cfg,), flags)
+            cmd = type("command", (cfg.command,), {"cfg": cc})
+            return type("Go1GateCmdCfg", (cfg,), {"command": cmd})
+        return edit
+    for flags in ({"body_height": True}, {"gait_freq": True, "footswing_height": True}, {"vel": False}, {"stance_width": True}):
+        with pytest.raises(NotImplementedError, match="command.cfg flags"):
+            make_mqe_env("go1gate", a, with_flags(**flags))
+        ENV_DICT["go1gate"]["config"] = base          # make_mqe_env registers what the hook returns (as upstream, utils.py:113-116)
+
+    def curriculum(rows):
+        def edit(cfg):
+            cfg = custom_cfg(a)(cfg)
+            ter = type("terrain", (cfg.terrain,), {"curriculum": True, "num_rows": rows, "max_init_terrain_level": 0})
+            return type("Go1GateCurCfg", (cfg,), {"terrain": ter})
+        return edit
+    with pytest.raises(NotImplementedError, match="terrain curriculum"):
+        make_mqe_env("go1gate", a, curriculum(3))
+    ENV_DICT["go1gate"]["config"] = base
+    env, _ = make_mqe_env("go1gate", a, curriculum(1))        # one row: the run-time move is the identity
+    env.reset()
+    env.step(torch.zeros(4, 2, 3))
+    env.close()
+    ENV_DICT["go1gate"]["config"] = base
+    assert base.command.cfg.vel is True and base.terrain.curriculum is False      # the registered config was not touched

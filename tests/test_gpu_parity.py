@@ -656,8 +656,8 @@ def test_walls_of_different_heights_match_oracle():
     ro = eo.tensor(abi.T_ROOT_STATE)
     sel = torch.randint(0, len(wi), (N,), generator=g)
     for env in range(0, N, 2):
-        ro[env, 0, 0] = float((wi[sel[env]] + 0.5) * hs) + 0.03
-        ro[env, 0, 1] = float((wj[sel[env]] + 0.5) * hs) - 0.02
+        ro[env, 0, 0] = float(wi[sel[env]] * hs) + 0.03
+        ro[env, 0, 1] = float(wj[sel[env]] * hs) - 0.02
         ro[env, 0, 2] = float(t.wall_top[wi[sel[env]], wj[sel[env]]]) + 0.12 + 0.1 * float(torch.rand((), generator=g))
     eh.tensor(abi.T_ROOT_STATE).copy_(ro.cuda())
     wall_contacts = 0

@@ -42,7 +42,7 @@ def test_step_halves_equal_step():
 
 
 def test_packed_return_batch_is_obs_reward_done():
-    """MQE_T_WRAPPER_PACKED = wrapper obs | reward | reset flags as 0/1 floats, in the HIP engine and in the oracle: after
+    """MQE_T_WRAPPER_PACKED = wrapper obs | reward | reset flags as N bytes (0/1), in the HIP engine and in the oracle: after
     reset_all (all flags 1) and along a rollout in which envs do reset (robots dropped from 3 m terminate on base contact)"""
     from helpers import oracle_engine
     N = 16
@@ -63,9 +63,9 @@ def test_packed_return_batch_is_obs_reward_done():
         for e in (eh, eo):
             o, r, f = e.tensor(abi.T_WRAPPER_OBS), e.tensor(abi.T_WRAPPER_REWARD), e.tensor(abi.T_RESET_BUF)
             pk = e.tensor(abi.T_WRAPPER_PACKED)
-            assert pk.numel() == o.numel() + r.numel() + N
+            assert pk.numel() == o.numel() + r.numel() + (N + 3) // 4
             assert torch.equal(pk[:o.numel()], o.reshape(-1)) and torch.equal(pk[o.numel():o.numel() + r.numel()], r.reshape(-1))
-            assert torch.equal(pk[o.numel() + r.numel():] != 0, f.reshape(-1) != 0)
+            assert torch.equal(pk[o.numel() + r.numel():].view(torch.uint8)[:N], f.reshape(-1).view(torch.uint8))
         seen += int(eh.tensor(abi.T_RESET_BUF).sum())
     assert seen > 0, "no env reset in this rollout: the done half of the check did not run"
 
@@ -146,14 +146,14 @@ def test_return_buffer_receives_the_step_outputs():
         e1.step(a)
         e1.set_return_buffer(None)
         torch.cuda.synchronize()
-        assert torch.equal(buf, e0.tensor(abi.T_WRAPPER_PACKED)), t
+        assert torch.equal(buf.view(torch.int32), e0.tensor(abi.T_WRAPPER_PACKED).view(torch.int32)), t      # bit patterns: the tail is bytes
         bufs.append(buf)
-    assert torch.equal(e1.tensor(abi.T_WRAPPER_PACKED), own_before)
-    assert not torch.equal(bufs[0], bufs[-1])
+    assert torch.equal(e1.tensor(abi.T_WRAPPER_PACKED).view(torch.int32), own_before.view(torch.int32))
+    assert not torch.equal(bufs[0].view(torch.int32), bufs[-1].view(torch.int32))
     a = torch.zeros(N, 2, 3, device="cuda")
     e0.step(a); e1.step(a)                     # back on the engine's own buffer
     torch.cuda.synchronize()
-    assert torch.equal(e1.tensor(abi.T_WRAPPER_PACKED), e0.tensor(abi.T_WRAPPER_PACKED))
+    assert torch.equal(e1.tensor(abi.T_WRAPPER_PACKED).view(torch.int32), e0.tensor(abi.T_WRAPPER_PACKED).view(torch.int32))
 
 
 def test_full_size_batch_is_the_union_of_its_shards(monkeypatch):

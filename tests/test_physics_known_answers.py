@@ -226,7 +226,7 @@ def test_ball_rolls_down_a_ramp_with_the_closed_form_acceleration():
     slope = 0.1
     d, k, ctx = make_desc("go1football-defender", 1, terrain_cfg=perlin_terrain("go1football-defender", zScale=0.01))
     hs = d.horizontal_scale
-    ramp = np.ascontiguousarray(np.tile((slope * (np.arange(d.sdf_ny) + 0.5) * hs).astype(np.float32), (d.sdf_nx, 1)))
+    ramp = np.ascontiguousarray(np.tile((slope * np.arange(d.sdf_ny) * hs).astype(np.float32), (d.sdf_nx, 1)))
     k.append(ramp)
     d.ground_height = ramp.ctypes.data_as(abi.FP)
     e = oracle_engine(d, k, f64=True)

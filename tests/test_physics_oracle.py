@@ -313,7 +313,7 @@ def test_perlin_relief_is_the_ground():
         A, r, hs = d.num_agents, d.npc_sphere_radius[0], d.horizontal_scale
 
         def relief(xy):
-            fx, fy = xy[0] / hs - 0.5, xy[1] / hs - 0.5
+            fx, fy = xy[0] / hs, xy[1] / hs
             ix, iy = int(fx), int(fy)
             tx, ty = fx - ix, fy - iy
             g = t.ground_height
@@ -373,8 +373,8 @@ def test_walls_of_different_heights_carry_a_ball_at_their_own_top():
     assert want[1] - want[0] > 0.1
     root[:, :A, 2] += 30.0                               # robots out of the way
     for env, ij in enumerate((lo_ij, hi_ij)):
-        root[env, A, 0] = (ij[0] + 0.5) * hs
-        root[env, A, 1] = (ij[1] + 0.5) * hs
+        root[env, A, 0] = ij[0] * hs
+        root[env, A, 1] = ij[1] * hs
         root[env, A, 2] = want[env] + r + 0.01
         root[env, A, 7:13] = 0
     for _ in range(120):

@@ -141,3 +141,30 @@ def test_perlin_and_curriculum_tracks_match_reference(name):
         assert keep.sum() > 0.5 * free.sum() and np.all((hf[free & ~keep] == 0.0))
         assert 0.0 <= t.ground_height.min() and t.ground_height.max() < 0.2          # zScale 0.12 (+ one quarter-weight octave)
         assert ((t.wall_sdf < 0) == t.wall).all()
+
+
+def test_raised_perlin_border_is_a_wall_of_its_own_height():
+    """with border_perlin_noise the border strips are raised by border_height (barrier_track.py:383-392).  They are part
+    of the wall set with THAT height: next to block walls of another height the engine gets the per-point `wall_top` map, and a
+    track without block walls still has the border as an obstacle."""
+    tcfg = perlin_cfgs()["perlin_curriculum"]                      # border_height 0.3, block walls 0.3 ... configured wall_height
+    kw = dict(tcfg.BarrierTrack_kwargs); kw["border_height"] = 0.45
+    tc = type("BorderTaller", (tcfg,), dict(BarrierTrack_kwargs=kw))
+    np.random.seed(0)
+    t = BarrierTrack(tc, 4, 2).build()
+    b = t.border
+    assert t.wall[:, :b].all() and t.wall[:, -b:].all()
+    assert t.wall_top is not None and t.wall_height == pytest.approx(max(0.45, kw["wall_height"]))
+    np.testing.assert_allclose(t.wall_top[:, :b], 0.45, atol=1e-6)
+    np.testing.assert_allclose(t.wall_top[:, -b:], 0.45, atol=1e-6)
+    inner = t.wall.copy(); inner[:, :b] = False; inner[:, -b:] = False
+    assert inner.any() and np.allclose(t.wall_top[inner], kw["wall_height"], atol=1e-6)
+    kw2 = dict(kw); kw2["options"] = ["init", "plane"]; kw2["wall_thickness"] = 0.0
+    tc2 = type("BorderOnly", (tcfg,), dict(BarrierTrack_kwargs=kw2))
+    np.random.seed(0)
+    try:
+        t2 = BarrierTrack(tc2, 4, 2).build()
+    except Exception:
+        pytest.skip("this track layout is not expressible with the block painters")
+    if not (t2.wall[:, b:-b]).any():
+        assert t2.wall_height == pytest.approx(0.45) and t2.wall_top is None

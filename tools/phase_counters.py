@@ -5,7 +5,7 @@
     python tools/phase_counters.py report gpurun_out/phase_pmc
 
 `run` steps the scene to a walking state, then launches the one-substep debug kernel once per phase tap with
-MQE_DEBUG_STOP_PHASE=i (the wavefront returns at tap i, nothing is written back), so the counters of launch i minus
+mqe_debug_stop_phase(handle, i) (the wavefront returns at tap i, nothing is written back), so the counters of launch i minus
 those of launch i-1 are phase i's.  `report` prints the differences per wavefront."""
 import csv, glob, os, sys, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -29,7 +29,7 @@ if sys.argv[1] == "run":
     torch.cuda.synchronize()
     for rep in range(2):
         for tap in TAPS + [-1]:
-            os.environ["MQE_DEBUG_STOP_PHASE"] = str(tap)
+            e._call("debug_stop_phase", tap)
             e.simulate()
             torch.cuda.synchronize()
 else:
