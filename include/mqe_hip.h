@@ -25,8 +25,9 @@
 extern "C" {
 #endif
 
-#define MQE_ABI_VERSION 11
-#define MQE_MAX_SPHERES 32
+#define MQE_ABI_VERSION 12
+#define MQE_MAX_SPHERES 32    /* feature points of one robot */
+#define MQE_MAX_PRIMS 20      /* collision primitives of one robot (Go1: 18) */
 #define MQE_MAX_SELF_PAIRS 320
 #define MQE_NBODY 13      /* dynamic bodies of one Go1 after fixed-joint collapsing */
 #define MQE_NREP 17       /* reported rigid bodies of one Go1 (feet kept, go1.urdf dont_collapse) */
@@ -43,6 +44,8 @@ enum { MQE_TASK_PLAIN = 0, MQE_TASK_GATE = 1, MQE_TASK_SHEEP = 2, MQE_TASK_SEESA
        MQE_TASK_ROTATION = 6, MQE_TASK_BRIDGE = 7, MQE_TASK_WRESTLING = 8, MQE_TASK_TUG = 9 };
 /* NPC kinds (reference resources/objects/{ball,sheep,seesaw}.urdf) */
 enum { MQE_NPC_NONE = 0, MQE_NPC_BALL = 1, MQE_NPC_SHEEP = 2, MQE_NPC_SEESAW = 3, MQE_NPC_BOX = 4, MQE_NPC_STATIC = 5 };
+/* collision primitive types of mqe_robot_model */
+enum { MQE_PRIM_SPHERE = 0, MQE_PRIM_CAPSULE = 1, MQE_PRIM_BOX = 2 };
 /* control types (reference legged_robot.py:368-392 "P","V","T"; go1.py:315-354 "C") */
 enum { MQE_CTRL_C = 0, MQE_CTRL_P = 1, MQE_CTRL_V = 2, MQE_CTRL_T = 3 };
 /* termination terms (reference legged_robot_field.py:121-146) */
@@ -68,13 +71,30 @@ typedef struct {
   float dof_lower[MQE_NDOF], dof_upper[MQE_NDOF];
   float dof_vel_limit[MQE_NDOF];          /* URDF <limit velocity> (go1.urdf:115,157,185: 50 / 28 / 28 rad/s; props["velocity"],
                                              legged_robot.py:315): the solver keeps |joint speed| below it; <= 0 = unlimited */
+  /* Collision model (go1.urdf <collision> elements; ABI v12).  PRIMITIVES are the URDF's shapes themselves -- what other bodies
+   * collide WITH: sphere (foot), capsule (hip cylinder as `replace_cylinder_with_capsule` makes it, go1_config.py:75; thigh and
+   * calf bars as the best-fitting capsule), box (trunk go1.urdf:56, head :80; aligned with the link frame).  FEATURE POINTS
+   * ("spheres": centre + radius, rigidly on a link) are what is tested AGAINST the terrain maps, the scenery, the 1-dof link,
+   * the free box and the other actors' primitives: the foot spheres, the capsules' end points (capsule radius) and the boxes'
+   * corners (radius 0) -- a convex body's outermost point against a plane is always one of them.  Order = priority in the
+   * bounded contact list (feet, trunk, head, knees, thigh tops, hips). */
   int32_t n_spheres;
   int32_t sphere_body[MQE_MAX_SPHERES];
   int32_t sphere_reported[MQE_MAX_SPHERES];
+  int32_t sphere_prim[MQE_MAX_SPHERES];   /* the primitive the feature point belongs to */
   float sphere_center[MQE_MAX_SPHERES][3];
   float sphere_radius[MQE_MAX_SPHERES];
-  /* self-collision candidates (asset.self_collisions = 0, go1_config.py:73 / legged_robot.py:874): every pair of collision
-   * spheres whose links are neither the same nor parent and child, lower sphere index first, ascending; entry = i | j << 8 */
+  int32_t n_prims;
+  int32_t prim_type[MQE_MAX_PRIMS];       /* MQE_PRIM_SPHERE / _CAPSULE / _BOX */
+  int32_t prim_body[MQE_MAX_PRIMS];
+  int32_t prim_reported[MQE_MAX_PRIMS];
+  float prim_center[MQE_MAX_PRIMS][3];    /* link frame */
+  float prim_axis[MQE_MAX_PRIMS][3];      /* capsule: half of its segment (centre +- axis), link frame; otherwise 0 */
+  float prim_half[MQE_MAX_PRIMS][3];      /* box: half extents along the link axes; sphere / capsule: [0] = radius */
+  float prim_bound[MQE_MAX_PRIMS];        /* radius of the bounding sphere about prim_center */
+  /* self-collision candidates (asset.self_collisions = 0, go1_config.py:73 / legged_robot.py:874): (feature point, primitive)
+   * pairs whose links are neither the same nor parent and child and that some pose inside the joint limits brings within 3 cm
+   * (mqe/utils/urdf_model.py::_self_pair_candidates), ascending; entry = feature | primitive << 8 */
   int32_t n_self_pairs;
   uint16_t self_pair[MQE_MAX_SELF_PAIRS];
 } mqe_robot_model;

@@ -1,9 +1,11 @@
 """ctypes mirror of include/mqe_hip.h (keep in sync; tests/test_abi.py checks sizes against the built library)."""
 import ctypes as C
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 MAX_SPHERES, NBODY, NREP, NDOF = 32, 13, 17, 12
 MAX_SELF_PAIRS = 320
+MAX_PRIMS = 20
+PRIM_SPHERE, PRIM_CAPSULE, PRIM_BOX = 0, 1, 2
 MAX_AGENTS, MAX_NPCS, FRAME, HIST, MAX_LAYERS, MAX_REWARD_TERMS = 4, 9, 72, 30, 6, 12
 OBS_BAG = 74
 
@@ -37,8 +39,11 @@ class RobotModel(C.Structure):
         ("mass", f32 * NBODY), ("com", (f32 * 3) * NBODY), ("inertia", (f32 * 6) * NBODY),
         ("joint_offset", (f32 * 3) * NBODY), ("joint_axis", (f32 * 3) * NBODY),
         ("dof_lower", f32 * NDOF), ("dof_upper", f32 * NDOF), ("dof_vel_limit", f32 * NDOF),
-        ("n_spheres", i32), ("sphere_body", i32 * MAX_SPHERES), ("sphere_reported", i32 * MAX_SPHERES),
+        ("n_spheres", i32), ("sphere_body", i32 * MAX_SPHERES), ("sphere_reported", i32 * MAX_SPHERES), ("sphere_prim", i32 * MAX_SPHERES),
         ("sphere_center", (f32 * 3) * MAX_SPHERES), ("sphere_radius", f32 * MAX_SPHERES),
+        ("n_prims", i32), ("prim_type", i32 * MAX_PRIMS), ("prim_body", i32 * MAX_PRIMS), ("prim_reported", i32 * MAX_PRIMS),
+        ("prim_center", (f32 * 3) * MAX_PRIMS), ("prim_axis", (f32 * 3) * MAX_PRIMS), ("prim_half", (f32 * 3) * MAX_PRIMS),
+        ("prim_bound", f32 * MAX_PRIMS),
         ("n_self_pairs", i32), ("self_pair", C.c_uint16 * MAX_SELF_PAIRS),
     ]
 

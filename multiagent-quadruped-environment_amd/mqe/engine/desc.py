@@ -146,16 +146,21 @@ def build_desc(cfg, num_envs, terrain, env_origins, agent_origins, gate_pos=None
     for j in range(abi.NDOF):
         r.dof_lower[j], r.dof_upper[j] = m["dof_lower"][j], m["dof_upper"][j]
         r.dof_vel_limit[j] = m["dof_velocity"][j]          # props["velocity"] (legged_robot.py:315): enforced by the solver
+    # collision model: feature points + the URDF's primitives (mqe/utils/urdf_model.py::_collision_model_for_go1)
     r.n_spheres = len(m["sphere_body"])
     for s in range(r.n_spheres):
         r.sphere_body[s], r.sphere_reported[s], r.sphere_radius[s] = m["sphere_body"][s], m["sphere_reported"][s], m["sphere_radius"][s]
+        r.sphere_prim[s] = m["sphere_prim"][s]
         for k in range(3):
             r.sphere_center[s][k] = m["sphere_center"][s][k]
+    r.n_prims = len(m["prim_type"])
+    for q in range(r.n_prims):
+        r.prim_type[q], r.prim_body[q], r.prim_reported[q], r.prim_bound[q] = m["prim_type"][q], m["prim_body"][q], m["prim_reported"][q], m["prim_bound"][q]
+        for k in range(3):
+            r.prim_center[q][k], r.prim_axis[q][k], r.prim_half[q][k] = m["prim_center"][q][k], m["prim_axis"][q][k], m["prim_half"][q][k]
     # self-collision (asset.self_collisions is Isaac Gym's filter mask: 0 = links of one robot collide, go1_config.py:73):
-    # every sphere pair whose links are neither the same nor parent and child, lower sphere index first
-    par, sb = m["parent"], m["sphere_body"]
-    pairs = [(i, j) for i in range(r.n_spheres) for j in range(i + 1, r.n_spheres)
-             if sb[i] != sb[j] and par[sb[i]] != sb[j] and par[sb[j]] != sb[i]]
+    # the model file's (feature point, primitive) candidates -- links neither the same nor adjacent, reachable inside the joint limits
+    pairs = [tuple(p) for p in m["self_pairs"]]
     assert len(pairs) <= abi.MAX_SELF_PAIRS, len(pairs)
     r.n_self_pairs = len(pairs)
     for k, (i, j) in enumerate(pairs):

@@ -13,8 +13,8 @@ physics must follow").  What Isaac Gym's importer does with them is restated her
   itself comes from Isaac Gym and is not stated in the reference, so the build fixes this one.
 * `replace_cylinder_with_capsule=True` (go1_config.py:75).
 
-Collision geometry is reduced to spheres rigidly attached to links (sphere-swept approximations of the URDF
-primitives, rule in `_spheres_for_go1`); see DESIGN.md "collision model" for why (one closed-form narrow phase).
+Collision geometry of the Go1: the URDF's own primitives (trunk and head boxes, hip capsules, foot spheres; the thigh and
+calf bars as capsules) plus their feature points -- `_collision_model_for_go1`, DESIGN.md "collision model".
 """
 import json
 import math
@@ -180,51 +180,127 @@ def collapse(links, joints, root):
     return bodies
 
 
-def _spheres_for_go1(bodies, reported_names):
-    """Sphere-swept stand-ins for the Go1 collision primitives (go1.urdf:56,80 boxes on base, hip cylinder,
-    thigh/calf boxes, foot sphere).  Returns list of (dyn_body, centre, radius, reported_body_index)."""
-    out = []
+PRIM_SPHERE, PRIM_CAPSULE, PRIM_BOX = 0, 1, 2
+MAX_PRIMS = 20
+SELF_PAIR_MARGIN = 0.03       # a (feature, primitive) pair is a self-collision candidate if some pose brings it this close [m]
+
+
+def _capsule_for_bar(h):
+    """Sphere-swept segment standing in for a slender URDF box (thigh 213 x 24.5 x 34 mm, calf 213 x 16 x 16 mm; go1.urdf thigh / calf
+    <collision>): the radius that minimises the two-sided deviation of the cross-section (half the sum of the in-circle and the
+    circum-circle radii of the rectangle) and the half-length at which the cap's overshoot along the bar equals its shortfall at the
+    end corners.  Returns (long axis index, half-length of the segment, radius)."""
+    h = np.asarray(h, np.float64)
+    order = np.argsort(h)
+    long_ax = int(order[2])
+    rin, rout = float(h[order[0]]), float(np.hypot(h[order[0]], h[order[1]]))
+    r = 0.5 * (rin + rout)
+    H = float(h[long_ax])
+    lo, hi = max(H - 2 * r, 0.0), H
+    for _ in range(60):                      # bisection on a: overshoot(a) = a + r - H rises, corner shortfall falls
+        a = 0.5 * (lo + hi)
+        if a + r - H > np.hypot(H - a, rout) - r:
+            hi = a
+        else:
+            lo = a
+    return long_ax, 0.5 * (lo + hi), r
+
+
+def _collision_model_for_go1(bodies, reported_names):
+    """The Go1 collision model of the engine: the URDF's 18 primitives themselves (go1.urdf:56 trunk box, :80 head box, hip cylinders
+    -> capsules as `replace_cylinder_with_capsule` does (go1_config.py:75), thigh / calf bars -> capsules (`_capsule_for_bar`), foot
+    spheres) = what OTHER bodies collide with, and their FEATURE POINTS (sphere-swept: capsule end points with the capsule's radius,
+    box corners with radius 0, the foot spheres) = what is tested against the terrain maps, the scenery and the other actors'
+    primitives.  A convex body's lowest / outermost point against a plane is always a feature point, so ground and wall-face
+    contacts are those of the primitives themselves.
+    Returns (prims, feats): prims = [dict(type, body, reported, center, axis (capsule half-segment), half (box) | radius)],
+    feats = [dict(body, reported, center, radius, prim)], both in the link frame of `body`."""
+    prims, feats = [], []
     for bi, b in enumerate(bodies):
         for kind, prm, R, t, rep in b.shapes:
             ri = reported_names.index(rep)
+            R, t = np.asarray(R, np.float64), np.asarray(t, np.float64)
+            pi = len(prims)
             if kind == "sphere":
-                out.append((bi, t, prm, ri))
-            elif kind == "cylinder":
+                prims.append(dict(type=PRIM_SPHERE, body=bi, reported=ri, center=t, axis=np.zeros(3), half=np.array([prm, 0, 0.0]), bound=float(prm)))
+                feats.append(dict(body=bi, reported=ri, center=t, radius=float(prm), prim=pi, tag="foot"))
+            elif kind == "cylinder":        # capsule of the cylinder's radius whose segment is the cylinder's axis (Isaac Gym's replacement)
                 r, L = prm
-                out.append((bi, t, r, ri))           # half-length 0.02 < r/2: one sphere
-            elif kind == "box":
-                h = np.asarray(prm)
-                order = np.argsort(h)
-                r = float(h[order[0]])
-                long_ax = int(order[2])
-                ext = float(h[long_ax]) - r
-                if h[order[1]] > 2.0 * r:          # plate-like (head box 0.02 x 0.05 x 0.05): 2 x 2 grid
-                    a1, a2 = int(order[1]), int(order[2])
-                    for s1 in (-1, 1):
-                        for s2 in (-1, 1):
-                            c = np.zeros(3)
-                            c[a1] = s1 * (h[a1] - r)
-                            c[a2] = s2 * (h[a2] - r)
-                            out.append((bi, R @ c + t, r, ri))
-                elif b.parent < 0:                   # trunk box: three spheres along the long axis
-                    r2 = float(h[order[1]]) if h[order[1]] < 1.3 * r else r
-                    for s in (-1, 0, 1):
-                        c = np.zeros(3)
-                        c[long_ax] = s * (h[long_ax] - r2)
-                        out.append((bi, R @ c + t, r2, ri))
-                else:                                # thigh / calf bars
-                    rr = float(h[order[1]])          # larger of the two short half-extents
-                    is_calf = "calf" in b.name
-                    pts = (0.0,) if is_calf else (0.0, -1.0)   # calf: middle (ends = knee sphere of thigh, foot)
-                    for s in pts:
-                        c = np.zeros(3)
-                        c[long_ax] = s * (h[long_ax] - rr)
-                        # long axis of the bar maps to -z of the link (rpy 0,pi/2,0): "-1" end must be the far end
-                        p = R @ c + t
-                        if s != 0.0 and np.linalg.norm(p) < np.linalg.norm(t):
-                            p = R @ (-c) + t
-                        out.append((bi, p, rr, ri))
-    return out
+                u = R @ np.array([0.0, 0.0, L / 2])
+                prims.append(dict(type=PRIM_CAPSULE, body=bi, reported=ri, center=t, axis=u, half=np.array([r, 0, 0.0]), bound=float(r + L / 2)))
+                for sgn in (-1.0, 1.0):
+                    feats.append(dict(body=bi, reported=ri, center=t + sgn * u, radius=float(r), prim=pi, tag="hip"))
+            elif kind == "box" and b.parent < 0:      # trunk / head: the box itself, corners as feature points
+                h = np.asarray(prm, np.float64)
+                assert np.allclose(np.abs(R), np.round(np.abs(R)), atol=1e-9), "base boxes must be aligned with the base frame"
+                hl = np.abs(R) @ h                     # half extents along the link axes
+                prims.append(dict(type=PRIM_BOX, body=bi, reported=ri, center=t, axis=np.zeros(3), half=hl, bound=float(np.linalg.norm(hl))))
+                corners = [np.array([sx, sy, sz]) * hl for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)]
+                is_head = len([p for p in prims if p["type"] == PRIM_BOX]) > 1
+                for c in corners:
+                    # the head box (4 x 10 x 10 cm in front of the trunk): its four rear corners are never the outermost point of
+                    # the trunk + head pair by more than 3 mm (y: 50 vs 46.75 mm, z: 50 vs 57 mm), so only the front four are kept
+                    if is_head and c[0] < 0:
+                        continue
+                    feats.append(dict(body=bi, reported=ri, center=t + c, radius=0.0, prim=pi, tag="head" if is_head else "trunk"))
+            elif kind == "box":             # thigh / calf bar -> capsule
+                h = np.asarray(prm, np.float64)
+                long_ax, a, r = _capsule_for_bar(h)
+                e = np.zeros(3); e[long_ax] = 1.0
+                u = R @ (a * e)
+                if np.linalg.norm(t + u) < np.linalg.norm(t - u):   # +u points away from the link's own joint (towards the child)
+                    u = -u
+                prims.append(dict(type=PRIM_CAPSULE, body=bi, reported=ri, center=t, axis=u, half=np.array([r, 0, 0.0]), bound=float(r + a)))
+                if "calf" in b.name:
+                    # the calf's lower end lies inside the foot sphere (r 20 mm) and its upper end inside the thigh's lower end cap
+                    # (same point -- the knee -- and the thigh is the thicker bar): the calf contributes the primitive only
+                    continue
+                feats.append(dict(body=bi, reported=ri, center=t + u, radius=float(r), prim=pi, tag="knee"))
+                feats.append(dict(body=bi, reported=ri, center=t - u, radius=float(r), prim=pi, tag="thigh"))
+    return prims, feats
+
+
+def _self_pair_candidates(m, prims, feats, n_samples=200000, seed=0):
+    """(feature, primitive) pairs of one robot that can come within SELF_PAIR_MARGIN of each other somewhere inside the joint limits
+    (links neither the same nor parent and child: PhysX filters exactly the adjacent links of an articulation).  Sampled: uniform
+    joint angles, distance = feature sphere against the primitive's bounding capsule / box (exact for spheres and capsules)."""
+    rng = np.random.RandomState(seed)
+    par = m["parent"]
+    lo, hi = np.asarray(m["dof_lower"]), np.asarray(m["dof_upper"])
+    off, axs = np.asarray(m["joint_offset"], np.float64), np.asarray(m["joint_axis"], np.float64)
+    # (a sphere against a sphere is the same pair from either side: kept once, lower primitive first)
+    cand = [(i, j) for i, f in enumerate(feats) for j, q in enumerate(prims)
+            if f["prim"] != j and f["body"] != q["body"] and par[f["body"]] != q["body"] and par[q["body"]] != f["body"]
+            and not (q["type"] == PRIM_SPHERE and prims[f["prim"]]["type"] == PRIM_SPHERE and f["prim"] > j)]
+    best = np.full(len(cand), np.inf)
+    B = 2000
+    for _ in range(n_samples // B):
+        q = lo + (hi - lo) * rng.rand(B, 12)
+        R = np.zeros((B, N_BODIES_DYN, 3, 3)); R[:, 0] = np.eye(3)
+        p = np.zeros((B, N_BODIES_DYN, 3))
+        for b in range(1, N_BODIES_DYN):
+            ax = axs[b]
+            K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+            ang = q[:, b - 1]
+            Rj = np.eye(3)[None] + np.sin(ang)[:, None, None] * K[None] + (1 - np.cos(ang))[:, None, None] * (K @ K)[None]
+            R[:, b] = R[:, par[b]] @ Rj
+            p[:, b] = p[:, par[b]] + R[:, par[b]] @ off[b]
+        fc = np.stack([p[:, f["body"]] + R[:, f["body"]] @ f["center"] for f in feats], 1)          # (B, F, 3)
+        qc = np.stack([p[:, g["body"]] + R[:, g["body"]] @ g["center"] for g in prims], 1)
+        qu = np.stack([R[:, g["body"]] @ g["axis"] for g in prims], 1)
+        for k, (i, j) in enumerate(cand):
+            g = prims[j]
+            d = fc[:, i] - qc[:, j]
+            if g["type"] == PRIM_BOX:
+                loc = np.einsum("bji,bj->bi", R[:, g["body"]], d)
+                ex = np.maximum(np.abs(loc) - g["half"], 0.0)
+                dist = np.linalg.norm(ex, axis=1)
+            else:
+                uu = max(float(g["axis"] @ g["axis"]), 1e-18)
+                tpar = np.clip(np.einsum("bi,bi->b", d, qu[:, j]) / uu, -1, 1)
+                dist = np.linalg.norm(d - tpar[:, None] * qu[:, j], axis=1) - g["half"][0]
+            best[k] = min(best[k], float((dist - feats[i]["radius"]).min()))
+    return [c for c, b in zip(cand, best) if b < SELF_PAIR_MARGIN], len(cand)
 
 
 def build_go1_model(urdf_path):
@@ -264,17 +340,28 @@ def build_go1_model(urdf_path):
     }
     for b in ordered[1:]:
         assert np.allclose(b.joint_R, np.eye(3)), "engine assumes joint frames are pure translations (true for go1.urdf)"
-    sph = _spheres_for_go1(ordered, reported)
-    # priority order for the bounded contact list: feet first, then knees/legs, then trunk
-    def prio(s):
-        nm = reported[s[3]]
-        return 0 if "foot" in nm else (1 if ("calf" in nm or "thigh" in nm) else (2 if "hip" in nm else 3))
-    sph.sort(key=lambda s: (prio(s), s[0]))
-    assert len(sph) <= MAX_SPHERES, len(sph)
-    m["sphere_body"] = [int(s[0]) for s in sph]
-    m["sphere_center"] = [np.asarray(s[1]).tolist() for s in sph]
-    m["sphere_radius"] = [float(s[2]) for s in sph]
-    m["sphere_reported"] = [int(s[3]) for s in sph]
+    prims, feats = _collision_model_for_go1(ordered, reported)
+    # priority order of the feature points for the bounded contact list: feet first (they carry the robot), then the trunk and head
+    # corners (base contact is what check_termination thresholds), then knees, thigh tops and hips
+    rank = {"foot": 0, "trunk": 1, "head": 2, "knee": 3, "thigh": 4, "hip": 5}
+    feats.sort(key=lambda f: (rank[f["tag"]], f["body"]))
+    assert len(feats) <= MAX_SPHERES and len(prims) <= MAX_PRIMS, (len(feats), len(prims))
+    m["sphere_body"] = [int(f["body"]) for f in feats]
+    m["sphere_center"] = [np.asarray(f["center"]).tolist() for f in feats]
+    m["sphere_radius"] = [float(f["radius"]) for f in feats]
+    m["sphere_reported"] = [int(f["reported"]) for f in feats]
+    m["sphere_prim"] = [int(f["prim"]) for f in feats]
+    m["sphere_tag"] = [f["tag"] for f in feats]
+    m["prim_type"] = [int(g["type"]) for g in prims]
+    m["prim_body"] = [int(g["body"]) for g in prims]
+    m["prim_reported"] = [int(g["reported"]) for g in prims]
+    m["prim_center"] = [np.asarray(g["center"]).tolist() for g in prims]
+    m["prim_axis"] = [np.asarray(g["axis"]).tolist() for g in prims]
+    m["prim_half"] = [np.asarray(g["half"]).tolist() for g in prims]
+    m["prim_bound"] = [float(g["bound"]) for g in prims]
+    pairs, n_all = _self_pair_candidates(m, prims, feats)
+    m["self_pairs"] = [[int(i), int(j)] for i, j in pairs]
+    m["self_pairs_unpruned"] = int(n_all)
     m["total_mass"] = float(sum(m["mass"]))
     return m
 

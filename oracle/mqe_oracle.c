@@ -534,8 +534,10 @@ typedef struct {
 } bodyk_t;
 
 typedef struct {
-  int kind;           /* 0 terrain, 1 sphere-sphere */
-  int actA, sphA, actB, sphB;   /* actor index in env: 0..A-1 robots, A.. npcs; actB=-1 static */
+  int kind;           /* 0 terrain, 1 two actors, 2 plank */
+  int actA, actB;     /* actor index in env: 0..A-1 robots, A.. npcs; actB=-1 static */
+  int bodyA, bodyB;   /* touching link of a robot side (0 = base; 0 for NPC sides) */
+  int repA, repB;     /* reported rigid body of each side (index into the env's net-contact-force rows) */
   real p[3], n[3], t1[3], t2[3], sd;
   real J[3][MAXDOF], B[3][MAXDOF], K[3][3], lam[3];
 } contact_t;
@@ -665,9 +667,10 @@ static void chol_solve(const real* L, int n, int ld, real* b) {
 typedef struct {
   bodyk_t bk[MAXA][NB];
   real L[MAXA][RD * RD];       /* Cholesky factor of each robot's mass matrix */
-  real sph_c[MAXA + MAXP][MQE_MAX_SPHERES][3];
+  real sph_c[MAXA + MAXP][MQE_MAX_SPHERES][3];     /* feature points (robots) / collision spheres (free NPCs), world frame */
   real sph_r[MAXA + MAXP][MQE_MAX_SPHERES];
   int sph_n[MAXA + MAXP];
+  real prim_c[MAXA][MQE_MAX_PRIMS][3], prim_u[MAXA][MQE_MAX_PRIMS][3];   /* robots' primitives: centre, capsule half-segment (world) */
   real npcR[MAXP][9];
   real v[MAXDOF], tau[MAXDOF];
   contact_t con[MAXC];
@@ -715,6 +718,29 @@ static void fill_jac(const mqo_sim* s, const envwork_t* w, int act, int body, co
       for (int q = 0; q < 3; q++) { J[q][o + k] += sign * dirs[q][k]; if (!lin_only) J[q][o + 3 + k] += sign * dot3(dirs[q], wv); }
     }
   }
+}
+
+/* feature point (sphere: centre c, radius r) against primitive q of robot `rob` (go1.urdf <collision> shapes, include/mqe_hip.h):
+ * signed distance and the unit normal from the primitive to the sphere.  Sphere / capsule: the closest point of the capsule's
+ * segment centre +- u (u = 0: a sphere); box: the link-aligned box.  Returns 0 when the centre lies on the segment itself (no
+ * direction), the caller skips the pair. */
+static int feat_vs_prim(const mqe_robot_model* m, const envwork_t* w, int rob, int q, const real* c, real r, real* sd, real* n) {
+  const real* cq = w->prim_c[rob][q];
+  if (m->prim_type[q] == MQE_PRIM_BOX) {
+    real hb[3] = {m->prim_half[q][0], m->prim_half[q][1], m->prim_half[q][2]};
+    *sd = sphere_box(c, r, cq, w->bk[rob][m->prim_body[q]].R, hb, n);
+    return 1;
+  }
+  const real* u = w->prim_u[rob][q];
+  real dq[3] = {c[0] - cq[0], c[1] - cq[1], c[2] - cq[2]};
+  real uu = dot3(u, u), t = 0;
+  if (uu > 0) { t = dot3(dq, u) / uu; if (t < -1) t = -1; if (t > 1) t = 1; }
+  real e[3] = {dq[0] - t * u[0], dq[1] - t * u[1], dq[2] - t * u[2]};
+  real dist = (real)sqrt((double)dot3(e, e));
+  if (!(dist > (real)1e-9)) return 0;
+  *sd = dist - r - m->prim_half[q][0];
+  n[0] = e[0] / dist; n[1] = e[1] / dist; n[2] = e[2] / dist;
+  return 1;
 }
 
 static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
@@ -831,6 +857,13 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
       for (int k = 0; k < 3; k++) w->sph_c[r][si][k] = bk[b].p[k] + cw[k];
       w->sph_r[r][si] = m->sphere_radius[si];
     }
+    for (int q = 0; q < m->n_prims; q++) {
+      int b = m->prim_body[q];
+      real cl[3] = {m->prim_center[q][0], m->prim_center[q][1], m->prim_center[q][2]}, ul[3] = {m->prim_axis[q][0], m->prim_axis[q][1], m->prim_axis[q][2]}, cw[3];
+      mat3_vec(bk[b].R, cl, cw);
+      for (int k = 0; k < 3; k++) w->prim_c[r][q][k] = bk[b].p[k] + cw[k];
+      mat3_vec(bk[b].R, ul, w->prim_u[r][q]);
+    }
   }
   /* ---- free NPC bodies (ball / sheep): isotropic inertia => no gyroscopic term */
   for (int p = 0; p < P; p++) {
@@ -928,7 +961,9 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
           mine++;
           contact_t* ct = &w->con[w->nc++];
           memset(ct, 0, sizeof *ct);
-          ct->kind = 0; ct->actA = act; ct->sphA = si; ct->actB = -1; ct->sd = sd;
+          ct->kind = 0; ct->actA = act; ct->actB = -1; ct->sd = sd; ct->repB = -1;
+          ct->bodyA = act < A ? m->sphere_body[si] : 0;
+          ct->repA = act < A ? act * MQE_NREP + m->sphere_reported[si] : A * MQE_NREP + (act - A);
           for (int k = 0; k < 3; k++) { ct->n[k] = n[k]; ct->p[k] = c[k] - r * n[k]; }
         }
       }
@@ -949,7 +984,8 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
           mine++;
           contact_t* ct = &w->con[w->nc++];
           memset(ct, 0, sizeof *ct);
-          ct->kind = 2; ct->actA = act; ct->sphA = si; ct->actB = A; ct->sphB = 0; ct->sd = sd;
+          ct->kind = 2; ct->actA = act; ct->actB = A; ct->sd = sd;
+          ct->bodyA = m->sphere_body[si]; ct->repA = act * MQE_NREP + m->sphere_reported[si]; ct->bodyB = 0; ct->repB = A * MQE_NREP + 1;
           for (int k = 0; k < 3; k++) { ct->n[k] = n[k]; ct->p[k] = c[k] - r * n[k]; }
         }
       }
@@ -970,14 +1006,55 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
           if (sd < d->contact_offset && w->nc < pair_lim) {
             contact_t* ct = &w->con[w->nc++];
             memset(ct, 0, sizeof *ct);
-            ct->kind = 1; ct->actA = a; ct->sphA = sa; ct->actB = b; ct->sphB = 0; ct->sd = sd;
+            ct->kind = 1; ct->actA = a; ct->actB = b; ct->sd = sd;
+            ct->bodyA = m->sphere_body[sa]; ct->repA = a * MQE_NREP + m->sphere_reported[sa]; ct->bodyB = 0; ct->repB = A * MQE_NREP + (b - A);
             for (int k = 0; k < 3; k++) { ct->n[k] = n[k]; ct->p[k] = ca[k] - n[k] * (w->sph_r[a][sa] + (real)0.5 * sd); }
           }
         }
         continue;
       }
       if (dot3(dd, dd) > (real)(1.2 * 1.2)) continue;   /* broad phase: actors farther apart than 1.2 m cannot touch */
-      for (int sb = 0; sb < w->sph_n[b]; sb++)
+      if (a < A && b < A) {
+        /* two robots: the feature points of one against the primitives of the other, both ways (outer loop over the primitives,
+         * inner over the feature points); a foot against a foot is the same sphere pair both ways and is taken the first time only */
+        for (int dir = 0; dir < 2; dir++) {
+          const int fa = dir == 0 ? a : b, qa = dir == 0 ? b : a;     /* feature points of fa, primitives of qa */
+          for (int q = 0; q < m->n_prims; q++)
+            for (int f = 0; f < m->n_spheres; f++) {
+              if (dir == 1 && m->prim_type[q] == MQE_PRIM_SPHERE && m->prim_type[m->sphere_prim[f]] == MQE_PRIM_SPHERE) continue;
+              real n[3], sd;
+              if (!feat_vs_prim(m, w, qa, q, w->sph_c[fa][f], w->sph_r[fa][f], &sd, n)) continue;
+              if (sd < d->contact_offset && !(w->nc < pair_lim)) ovf = 1;
+              if (sd < d->contact_offset && w->nc < pair_lim) {
+                contact_t* ct = &w->con[w->nc++];
+                memset(ct, 0, sizeof *ct);
+                ct->kind = 1; ct->actA = fa; ct->actB = qa; ct->sd = sd;
+                ct->bodyA = m->sphere_body[f]; ct->repA = fa * MQE_NREP + m->sphere_reported[f];
+                ct->bodyB = m->prim_body[q]; ct->repB = qa * MQE_NREP + m->prim_reported[q];
+                for (int k = 0; k < 3; k++) { ct->n[k] = n[k]; ct->p[k] = w->sph_c[fa][f][k] - n[k] * (w->sph_r[fa][f] + (real)0.5 * sd); }
+              }
+            }
+        }
+        continue;
+      }
+      if (a < A) {
+        /* robot a against the collision spheres of free NPC b (ball, sheep): every sphere of b against the robot's primitives */
+        for (int sb = 0; sb < w->sph_n[b]; sb++)
+          for (int q = 0; q < m->n_prims; q++) {
+            real n[3], sd;
+            if (!feat_vs_prim(m, w, a, q, w->sph_c[b][sb], w->sph_r[b][sb], &sd, n)) continue;     /* n: from the primitive to the sphere */
+            if (sd < d->contact_offset && !(w->nc < pair_lim)) ovf = 1;
+            if (sd < d->contact_offset && w->nc < pair_lim) {
+              contact_t* ct = &w->con[w->nc++];
+              memset(ct, 0, sizeof *ct);
+              ct->kind = 1; ct->actA = a; ct->actB = b; ct->sd = sd;
+              ct->bodyA = m->prim_body[q]; ct->repA = a * MQE_NREP + m->prim_reported[q]; ct->bodyB = 0; ct->repB = A * MQE_NREP + (b - A);
+              for (int k = 0; k < 3; k++) { ct->n[k] = -n[k]; ct->p[k] = w->sph_c[b][sb][k] - n[k] * (w->sph_r[b][sb] + (real)0.5 * sd); }   /* normal from B (the NPC) to A */
+            }
+          }
+        continue;
+      }
+      for (int sb = 0; sb < w->sph_n[b]; sb++)          /* two free NPCs: sphere pairs */
         for (int sa = 0; sa < w->sph_n[a]; sa++) {
           const real* ca = w->sph_c[a][sa]; const real* cb = w->sph_c[b][sb];
           real e[3] = {ca[0] - cb[0], ca[1] - cb[1], ca[2] - cb[2]};
@@ -987,27 +1064,29 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
           if (sd < d->contact_offset && w->nc < pair_lim && dist > (real)1e-9) {
             contact_t* ct = &w->con[w->nc++];
             memset(ct, 0, sizeof *ct);
-            ct->kind = 1; ct->actA = a; ct->sphA = sa; ct->actB = b; ct->sphB = sb; ct->sd = sd;
+            ct->kind = 1; ct->actA = a; ct->actB = b; ct->sd = sd;
+            ct->bodyA = 0; ct->repA = A * MQE_NREP + (a - A); ct->bodyB = 0; ct->repB = A * MQE_NREP + (b - A);
             for (int k = 0; k < 3; k++) { ct->n[k] = e[k] / dist; ct->p[k] = cb[k] + ct->n[k] * (w->sph_r[b][sb] + (real)0.5 * sd); }
           }
         }
     }
-  /* links of one robot against each other (asset.self_collisions = 0, go1_config.py:73): the candidate list of the robot
-   * model in order; both sides of such a contact are the same actor (fill_jac adds the two Jacobians into one row) */
+  /* links of one robot against each other (asset.self_collisions = 0, go1_config.py:73): the candidate (feature point, primitive)
+   * list of the robot model in order; both sides of such a contact are the same actor (fill_jac adds the two Jacobians into one
+   * row) */
   if (d->self_collision)
     for (int a = 0; a < A; a++)
       for (int pi = 0; pi < m->n_self_pairs; pi++) {
-        int si = m->self_pair[pi] & 255, sj = m->self_pair[pi] >> 8;
-        const real* ci = w->sph_c[a][si]; const real* cj = w->sph_c[a][sj];
-        real e[3] = {ci[0] - cj[0], ci[1] - cj[1], ci[2] - cj[2]};
-        real dist = (real)sqrt((double)dot3(e, e));
-        real sd = dist - w->sph_r[a][si] - w->sph_r[a][sj];
-        if (sd < d->contact_offset && dist > (real)1e-9 && !(w->nc < pair_lim)) ovf = 1;
-        if (sd < d->contact_offset && w->nc < pair_lim && dist > (real)1e-9) {
+        int f = m->self_pair[pi] & 255, q = m->self_pair[pi] >> 8;
+        real n[3], sd;
+        if (!feat_vs_prim(m, w, a, q, w->sph_c[a][f], w->sph_r[a][f], &sd, n)) continue;
+        if (sd < d->contact_offset && !(w->nc < pair_lim)) ovf = 1;
+        if (sd < d->contact_offset && w->nc < pair_lim) {
           contact_t* ct = &w->con[w->nc++];
           memset(ct, 0, sizeof *ct);
-          ct->kind = 1; ct->actA = a; ct->sphA = si; ct->actB = a; ct->sphB = sj; ct->sd = sd;
-          for (int k = 0; k < 3; k++) { ct->n[k] = e[k] / dist; ct->p[k] = cj[k] + ct->n[k] * (w->sph_r[a][sj] + (real)0.5 * sd); }
+          ct->kind = 1; ct->actA = a; ct->actB = a; ct->sd = sd;
+          ct->bodyA = m->sphere_body[f]; ct->repA = a * MQE_NREP + m->sphere_reported[f];
+          ct->bodyB = m->prim_body[q]; ct->repB = a * MQE_NREP + m->prim_reported[q];
+          for (int k = 0; k < 3; k++) { ct->n[k] = n[k]; ct->p[k] = w->sph_c[a][f][k] - n[k] * (w->sph_r[a][f] + (real)0.5 * sd); }
         }
       }
 
@@ -1017,11 +1096,9 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
     make_tangents(ct->n, ct->t1, ct->t2);
     real dirs[3][3];
     for (int k = 0; k < 3; k++) { dirs[0][k] = ct->n[k]; dirs[1][k] = ct->t1[k]; dirs[2][k] = ct->t2[k]; }
-    int bodyA = ct->actA < A ? m->sphere_body[ct->sphA] : 0;
-    fill_jac(s, w, ct->actA, bodyA, ct->p, (real)1, dirs, ct->J, npc_pos);
+    fill_jac(s, w, ct->actA, ct->bodyA, ct->p, (real)1, dirs, ct->J, npc_pos);
     if (ct->actB >= 0) {
-      int bodyB = ct->actB < A ? m->sphere_body[ct->sphB] : 0;
-      fill_jac(s, w, ct->actB, bodyB, ct->p, (real)-1, dirs, ct->J, npc_pos);
+      fill_jac(s, w, ct->actB, ct->bodyB, ct->p, (real)-1, dirs, ct->J, npc_pos);
     }
     for (int q = 0; q < 3; q++) {
       for (int r = 0; r < A; r++) {
@@ -1125,11 +1202,9 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
     contact_t* ct = &w->con[ci];
     real F[3];
     for (int k = 0; k < 3; k++) F[k] = (ct->lam[0] * ct->n[k] + ct->lam[1] * ct->t1[k] + ct->lam[2] * ct->t2[k]) / dt;
-    int ra = ct->actA < A ? ct->actA * MQE_NREP + m->sphere_reported[ct->sphA] : A * MQE_NREP + (ct->actA - A);
-    for (int k = 0; k < 3; k++) cf[ra * 3 + k] += (float)F[k];
+    for (int k = 0; k < 3; k++) cf[ct->repA * 3 + k] += (float)F[k];
     if (ct->actB >= 0) {
-      int rb = ct->actB < A ? ct->actB * MQE_NREP + m->sphere_reported[ct->sphB] : (SS ? A * MQE_NREP + 1 : A * MQE_NREP + (ct->actB - A));
-      for (int k = 0; k < 3; k++) cf[rb * 3 + k] -= (float)F[k];
+      for (int k = 0; k < 3; k++) cf[ct->repB * 3 + k] -= (float)F[k];
     }
   }
 
@@ -1200,8 +1275,8 @@ int mqo_debug_dynamics(mqo_sim* s, int env, int robot, float* M_out /*18x18*/, f
   for (int c = 0; c < w->nc; c++) {
     float* o = contacts_out + c * 8;
     const contact_t* ct = &w->con[c];   /* (actor, dynamic body) pairs, -1/0 for static geometry */
-    o[0] = (float)ct->actA; o[1] = (float)(ct->actA < A ? s->d.robot.sphere_body[ct->sphA] : 0);
-    o[2] = (float)ct->actB; o[3] = (float)((ct->actB >= 0 && ct->actB < A) ? s->d.robot.sphere_body[ct->sphB] : 0);
+    o[0] = (float)ct->actA; o[1] = (float)ct->bodyA;
+    o[2] = (float)ct->actB; o[3] = (float)(ct->actB >= 0 ? ct->bodyB : 0);
     o[4] = (float)w->con[c].sd; o[5] = (float)w->con[c].n[0]; o[6] = (float)w->con[c].n[1]; o[7] = (float)w->con[c].n[2];
   }
   free(w);

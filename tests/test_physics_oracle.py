@@ -252,11 +252,15 @@ def test_tug_slider_translates_and_pushes_a_robot():
     root[:, 0, 3:7] = torch.tensor([0.0, 0.0, 0.0, 1.0])
     root[:, :, 7:] = 0
     y0 = root[:, 0, 1].clone()
+    vmax = torch.zeros(2)
     for t in range(80):
         e.simulate()
+        vmax = torch.maximum(vmax, root[:, 0, 8])
     assert torch.isfinite(root).all() and torch.isfinite(dof).all()
     assert (dof[:, 12 * A, 1] < 0.8).all(), dof[:, 12 * A, 1]                  # momentum went into the robot
-    assert (root[:, 0, 1] > y0 + 0.005).all(), root[:, 0, 1] - y0             # which was shoved along +y (12 kg on mu = 1 feet: not far)
+    # which was shoved along +y: 2.7 N s of disc momentum would give its 12.6 kg 0.2 m/s (the unpowered robot is collapsing onto
+    # its belly meanwhile and mu = 1 friction stops it within millimetres, so the base POSITION says little: its roll moves it more)
+    assert (vmax > 0.05).all(), vmax
     assert (root[:, 0, 1] - (hinge[:, 1] + dof[:, 12 * A, 0]) > d.seesaw_plank_half[0] - 0.05).all()   # and never ended up inside the disc
 
 
@@ -284,8 +288,11 @@ def test_links_of_one_robot_collide():
     assert self_gap(CROSSED_FRONT_FEET, 0, 1) < -0.02
     e, d, root, dof = _crossed(1)
     _, _, con = e.debug_dynamics(0, 0)
-    assert len(con) == 1 and con[0, 0] == 0 and con[0, 2] == 0 and con[0, 1] != con[0, 3], con     # one contact, robot 0 on both sides, two different links
-    assert abs(float(con[0, 4]) - self_gap(CROSSED_FRONT_FEET, 0, 1)) < 1e-5
+    # every contact has robot 0 on both sides and joins the two front legs (links 1-3 and 4-6): foot against foot (taken once: the
+    # deepest) and each foot against the other calf's end cap, which ends inside its foot sphere
+    assert len(con) == 3 and (con[:, 0] == 0).all() and (con[:, 2] == 0).all(), con
+    assert all({int(c[1]) <= 3, int(c[3]) <= 3} == {True, False} and 1 <= min(c[1], c[3]) and max(c[1], c[3]) <= 6 for c in con), con
+    assert abs(float(con[:, 4].min()) - self_gap(CROSSED_FRONT_FEET, 0, 1)) < 1e-5
     for _ in range(40):
         e.simulate()
     assert self_gap(dof[0, :12, 0].numpy(), 0, 1) > -1e-3, "the penetration must be resolved"
