@@ -28,7 +28,7 @@ extern "C" {
 #define MQE_ABI_VERSION 12
 #define MQE_MAX_SPHERES 32    /* feature points of one robot */
 #define MQE_MAX_PRIMS 20      /* collision primitives of one robot (Go1: 18) */
-#define MQE_MAX_SELF_PAIRS 320
+#define MQE_MAX_SELF_PAIRS 192
 #define MQE_NBODY 13      /* dynamic bodies of one Go1 after fixed-joint collapsing */
 #define MQE_NREP 17       /* reported rigid bodies of one Go1 (feet kept, go1.urdf dont_collapse) */
 #define MQE_NDOF 12

@@ -111,6 +111,20 @@ __device__ __forceinline__ float sphere_vcyl(V3 c, float r, V3 bc, float rc, flo
   return dist - r;
 }
 
+// sphere (centre c, radius r) vs capsule (centre cq, half-segment u, radius rq; u = 0: a sphere): signed distance and the unit normal
+// from the capsule to the sphere through the closest point of the segment; false when the centre lies on the segment itself
+__device__ __forceinline__ bool sphere_capsule(V3 c, float r, V3 cq, V3 u, float rq, float& sd, V3& n) {
+  const V3 d = c - cq;
+  const float uu = dot(u, u);
+  float t = 0.0f;
+  if (uu > 0.0f) t = fminf(fmaxf(dot(d, u) / uu, -1.0f), 1.0f);
+  const V3 e = d - t * u;
+  const float dist = sqrtf(dot(e, e));
+  sd = dist - r - rq;
+  n = (1.0f / dist) * e;
+  return dist > 1e-9f;
+}
+
 __device__ __forceinline__ float wave_sum(float x) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
@@ -170,16 +184,18 @@ __host__ __device__ inline int mqe_maxc(int A, int P, int cap_npc) { int v = 8 *
 // NPCs keep m->cap_npc one-sided contacts each (2; a box resting on a face 4): per-actor caps so that no actor starves the ones after it
 
 struct PhysLds {   // float offsets into dynamic LDS
-  int root, dof, tau, body, rhs, acc, acth, fcol, leg, legc, basei, sinv, sph, con, side, phi, srec, total;
+  int root, dof, tau, body, rhs, acc, acth, fcol, leg, legc, basei, sinv, sph, prim, con, side, phi, srec, total;
 };
 #define SREC_STRIDE 16    // row sweep: per contact [u* (3), bias] [mu, 1/d00, 1/d11, 1/d22] [d10, d20, d21, -] [lambda (3), -]
 __host__ __device__ inline int mqe_maxpair(int maxc) { return maxc / 2; }    // two-actor contacts kept per env
-__host__ __device__ inline PhysLds phys_lds_layout(int A, int P, int ND, int nbody, int ndof, int nsph, int maxc, int rowgs) {
-  // Regions that live to the end of the substep first; then the scratch of the dynamics phases (link records, CRBA / Schur
-  // scratch; the collision spheres overlay the latter), dead once the contact side records exist.  Contact sides are
-  // slot-allocated: side A of contact c -> slot c, side B of the k-th two-actor contact -> slot maxc + k (terrain contacts have no
-  // B).  The mass-matrix inverse is kept in factored form only (per leg Mll^-1, its Cholesky factor and G; per robot S^-1 and its
-  // factor F) and the contact problem in the Phi form of SIDE_STRIDE -- no coupling blocks: go1gate 9.9 KiB per wave (was 19.7).
+__host__ __device__ inline PhysLds phys_lds_layout(int A, int P, int ND, int nbody, int ndof, int nsph, int nprim, int maxc, int rowgs) {
+  // Regions that live to the end of the substep first; then the link records; then ONE scratch area used three times over: by the
+  // CRBA / Schur scratch (dead once the factors exist), by the collision geometry in world coordinates -- the feature points of the
+  // robots / collision spheres of the NPCs (16 B each) and the robots' primitives (32 B each: centre + bounding radius, capsule
+  // half-segment + radius) -- live during contact generation only, and by side B of the two-actor contacts, written afterwards.
+  // Contact sides are slot-allocated: side A of contact c -> slot c, side B of the k-th two-actor contact -> slot k of its own area
+  // (terrain contacts have no B).  The mass-matrix inverse is kept in factored form only (per leg Mll^-1, its Cholesky factor and G;
+  // per robot S^-1 and its factor F) and the contact problem in the Phi form of SIDE_STRIDE -- no coupling blocks.
   PhysLds L; int o = 0;
   L.root = o; o += (A + P) * 13;
   L.dof = o; o += ND * 2;
@@ -191,18 +207,19 @@ __host__ __device__ inline PhysLds phys_lds_layout(int A, int P, int ND, int nbo
   L.leg = o; o += A * 4 * LEG_STRIDE;
   L.sinv = o; o += A * 72;                                  // per robot: S^-1 (36), then F with S^-1 = F F^T (upper triangular, stored 6 x 6)
   L.con = o; o += maxc * CON_STRIDE;
-  L.side = o; o += mqe_maxpair(maxc) * SIDE_STRIDE;         // side B of the two-actor contacts only (side A lives in registers)
   L.body = o; o += nbody * BODY_STRIDE;
-  const int scratch = o;
-  L.fcol = o; o += A * 64;                                  // the four hip composites of every robot on their way to the base lane
-  L.legc = o; o += A * 4 * LEGC_STRIDE;
-  L.basei = o; o += A * 24;                                 // per robot: upper triangle of the base block, then of the Schur complement (21 values)
-  L.sph = scratch;
-  if (scratch + nsph * 4 > o) o = scratch + nsph * 4;
   // row sweep (scenes of <= 4 actors): side A of every contact and the per-contact solve record, written over the link records once the
   // last Jacobian row has been read
   L.phi = L.body; L.srec = L.phi + maxc * SIDE_STRIDE;
   if (rowgs && L.srec + maxc * SREC_STRIDE > o) o = L.srec + maxc * SREC_STRIDE;
+  const int scratch = o;
+  L.fcol = o; o += A * 64;                                  // the four hip composites of every robot on their way to the base lane
+  L.legc = o; o += A * 4 * LEGC_STRIDE;
+  L.basei = o; o += A * 24;                                 // per robot: upper triangle of the base block, then of the Schur complement (21 values)
+  L.sph = scratch; L.prim = scratch + nsph * 4;
+  if (L.prim + nprim * 8 > o) o = L.prim + nprim * 8;
+  L.side = scratch;                                         // side B of the two-actor contacts only (side A: registers / the phi area)
+  if (scratch + mqe_maxpair(maxc) * SIDE_STRIDE > o) o = scratch + mqe_maxpair(maxc) * SIDE_STRIDE;
   L.total = o;
   return L;
 }
@@ -248,7 +265,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   const PhysShape<TA, TP> shp(m);
   const int A = shp.A, P = shp.P, PD = shp.PD, npcdof = shp.npcdof;
   const int nbody = shp.nbody, ndof = shp.ndof, nsph = m->nsph_env, maxc = shp.maxc;
-  const PhysLds L = phys_lds_layout(A, P, shp.ND, nbody, ndof, nsph, maxc, shp.rowgs);
+  const PhysLds L = phys_lds_layout(A, P, shp.ND, nbody, ndof, nsph, m->nprim_env, maxc, shp.rowgs);
   const float dt = m->dt;
   const mqe_robot_model& rm = m->robot;
   float* g_root = st.root + (size_t)e * (A + P) * 13;
@@ -666,6 +683,20 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     float* sp = lds + L.sph + s * 4;
     *reinterpret_cast<float4*>(sp) = make_float4(c.x, c.y, c.z, rad);
   }
+  // the robots' primitives in world coordinates (what the OTHER actors' feature points and spheres are tested against): centre and
+  // bounding radius, capsule half-segment and radius (a sphere is a capsule with a zero segment; a box keeps its link's rotation)
+  const int npr = rm.n_prims;
+  for (int t = lane; t < A * npr; t += 64) {
+    const int r = t / npr, q = t - r * npr;
+    const float* rec = lds + L.body + (r * MQE_NBODY + rm.prim_body[q]) * BODY_STRIDE;
+    const float4 q0 = reinterpret_cast<const float4*>(rec)[0], q1 = reinterpret_cast<const float4*>(rec)[1], q2 = reinterpret_cast<const float4*>(rec)[2];
+    const float Rr[9] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x};
+    const V3 c = v3(q2.y, q2.z, q2.w) + mat_vec(Rr, v3(rm.prim_center[q][0], rm.prim_center[q][1], rm.prim_center[q][2]));
+    const V3 u = mat_vec(Rr, v3(rm.prim_axis[q][0], rm.prim_axis[q][1], rm.prim_axis[q][2]));
+    float4* pw = reinterpret_cast<float4*>(lds + L.prim + t * 8);
+    pw[0] = make_float4(c.x, c.y, c.z, rm.prim_bound[q]);
+    pw[1] = make_float4(u.x, u.y, u.z, rm.prim_half[q][0]);
+  }
   __syncthreads();
 
   TSTAMP(8);
@@ -923,9 +954,94 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
           if (nc > pair_lim) { nc = pair_lim; ovf = 1; }
           continue;
         }
-        const int na = a < A ? nsr : m->npc_n_spheres, nb = b < A ? nsr : m->npc_n_spheres;
-        const int oa = a < A ? a * nsr : A * nsr + (a - A) * m->npc_n_spheres;
-        const int ob = b < A ? b * nsr : A * nsr + (b - A) * m->npc_n_spheres;
+        if (b < A) {
+          // two robots: the feature points of one (lanes) against the primitives of the other (wave-uniform loop), both ways; a foot
+          // against a foot is the same sphere pair both ways and is taken the first time only.  Every primitive is screened with
+          // its bounding sphere first, so a pair of robots that is merely close costs two compares per primitive.
+          for (int dir = 0; dir < 2; dir++) {
+            const int fa = dir == 0 ? a : b, qa = dir == 0 ? b : a;
+            V3 c = v3(0, 0, 0); float ra = 0; bool foot = false;
+            if (lane < nsr) {
+              const float4 qf = *reinterpret_cast<const float4*>(lds + L.sph + (fa * nsr + lane) * 4);
+              c = v3(qf.x, qf.y, qf.z); ra = qf.w;
+              foot = rm.prim_type[rm.sphere_prim[lane]] == MQE_PRIM_SPHERE;
+            }
+            for (int q = 0; q < npr; q++) {
+              const float4* pw = reinterpret_cast<const float4*>(lds + L.prim + (qa * npr + q) * 8);
+              const float4 w0 = pw[0], w1 = pw[1];
+              const V3 cq = v3(w0.x, w0.y, w0.z);
+              const int ptype = rm.prim_type[q];
+              const V3 dq = c - cq;
+              const float reach = ra + w0.w + m->contact_offset;
+              bool cand = lane < nsr && dot(dq, dq) < reach * reach && !(dir == 1 && foot && ptype == MQE_PRIM_SPHERE);
+              if (__ballot(cand) == 0ull) continue;
+              bool hit = false; float sd = 0; V3 n = v3(0, 0, 1);
+              if (cand) {
+                if (ptype == MQE_PRIM_BOX) {
+                  sd = sphere_box(c, ra, cq, lds + L.body + (qa * MQE_NBODY + rm.prim_body[q]) * BODY_STRIDE + B_R,
+                                  v3(rm.prim_half[q][0], rm.prim_half[q][1], rm.prim_half[q][2]), n);
+                  hit = sd < m->contact_offset;
+                } else {
+                  const bool ok = sphere_capsule(c, ra, cq, v3(w1.x, w1.y, w1.z), w1.w, sd, n);
+                  hit = ok && sd < m->contact_offset;
+                }
+              }
+              const unsigned long long bh = __ballot(hit);
+              if (bh == 0ull) continue;
+              const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+              const int slot = nc + __popcll(bh & lower);
+              if (hit && slot < pair_lim) {
+                float* cr = lds + L.con + slot * CON_STRIDE;
+                con_store(cr, fa, rm.sphere_body[lane], qa, rm.prim_body[q], c - (ra + 0.5f * sd) * n, n, sd, fa * MQE_NREP + rm.sphere_reported[lane],
+                          qa * MQE_NREP + rm.prim_reported[q]);
+              }
+              nc += __popcll(bh);
+              if (nc > pair_lim) { nc = pair_lim; ovf = 1; }
+            }
+          }
+          continue;
+        }
+        if (a < A) {
+          // robot a against the collision spheres of free NPC b (ball, sheep): lanes = the robot's primitives, one sphere of b per
+          // iteration; the contact's normal points from B (the NPC) to A
+          const int nb = m->npc_n_spheres, ob = A * nsr + (b - A) * m->npc_n_spheres;
+          float4 w0 = make_float4(0, 0, 0, 0), w1 = w0; int ptype = MQE_PRIM_SPHERE, pbody = 0, prep = 0; V3 ph = v3(0, 0, 0);
+          if (lane < npr) {
+            const float4* pw = reinterpret_cast<const float4*>(lds + L.prim + (a * npr + lane) * 8);
+            w0 = pw[0]; w1 = pw[1];
+            ptype = rm.prim_type[lane]; pbody = rm.prim_body[lane]; prep = rm.prim_reported[lane];
+            ph = v3(rm.prim_half[lane][0], rm.prim_half[lane][1], rm.prim_half[lane][2]);
+          }
+          for (int sb = 0; sb < nb; sb++) {
+            const float4 qb = *reinterpret_cast<const float4*>(lds + L.sph + (ob + sb) * 4);
+            const V3 cb = v3(qb.x, qb.y, qb.z); const float rb = qb.w;
+            bool hit = false; float sd = 0; V3 n = v3(0, 0, 1);
+            if (lane < npr) {
+              const V3 cq = v3(w0.x, w0.y, w0.z);
+              if (ptype == MQE_PRIM_BOX) {
+                sd = sphere_box(cb, rb, cq, lds + L.body + (a * MQE_NBODY + pbody) * BODY_STRIDE + B_R, ph, n);
+                hit = sd < m->contact_offset;
+              } else {
+                const bool ok = sphere_capsule(cb, rb, cq, v3(w1.x, w1.y, w1.z), w1.w, sd, n);
+                hit = ok && sd < m->contact_offset;
+              }
+            }
+            const unsigned long long bh = __ballot(hit);
+            if (bh == 0ull) continue;
+            const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+            const int slot = nc + __popcll(bh & lower);
+            if (hit && slot < pair_lim) {
+              float* cr = lds + L.con + slot * CON_STRIDE;
+              con_store(cr, a, pbody, b, 0, cb - (rb + 0.5f * sd) * n, v3(-n.x, -n.y, -n.z), sd, a * MQE_NREP + prep, A * MQE_NREP + (b - A));
+            }
+            nc += __popcll(bh);
+            if (nc > pair_lim) { nc = pair_lim; ovf = 1; }
+          }
+          continue;
+        }
+        const int na = m->npc_n_spheres, nb = m->npc_n_spheres;        // two free NPCs: sphere pairs (flocks take the lane-parallel pass below)
+        const int oa = A * nsr + (a - A) * m->npc_n_spheres;
+        const int ob = A * nsr + (b - A) * m->npc_n_spheres;
         for (int sb = 0; sb < nb; sb++) {
           const float* spb = lds + L.sph + (ob + sb) * 4;
           const float4 qb = *reinterpret_cast<const float4*>(spb);
@@ -944,11 +1060,8 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
           const int slot = nc + __popcll(bh & lower);
           if (hit && slot < pair_lim) {
             float* cr = lds + L.con + slot * CON_STRIDE;
-            const int bodyA = a < A ? rm.sphere_body[lane] : 0, bodyB = b < A ? rm.sphere_body[sb] : 0;
-            const int repA = a < A ? a * MQE_NREP + rm.sphere_reported[lane] : A * MQE_NREP + (a - A);
-            const int repB = b < A ? b * MQE_NREP + rm.sphere_reported[sb] : A * MQE_NREP + (b - A);
             const V3 n = (1.0f / dist) * ev;
-            con_store(cr, a, bodyA, b, bodyB, cb + (rb + 0.5f * sd) * n, n, sd, repA, repB);
+            con_store(cr, a, 0, b, 0, cb + (rb + 0.5f * sd) * n, n, sd, A * MQE_NREP + (a - A), A * MQE_NREP + (b - A));
           }
           nc += __popcll(bh);
           if (nc > pair_lim) { nc = pair_lim; ovf = 1; }
@@ -986,21 +1099,22 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
         if (nc > pair_lim) { nc = pair_lim; ovf = 1; }
       }
     }
-    // links of one robot against each other (asset.self_collisions = 0): lanes = candidate sphere pairs (same link and
-    // parent-child pairs are not in the list), 64 per pass; both contact sides belong to the same actor.  Last in the list:
-    // they only take the two-actor slots that the contacts with other actors left over.
+    // links of one robot against each other (asset.self_collisions = 0): lanes = the model's candidate (feature point, primitive)
+    // pairs (links neither the same nor adjacent, reachable inside the joint limits), 64 per pass; both contact sides belong to the
+    // same actor.  Last in the list: they only take the two-actor slots that the contacts with other actors left over.
     if (m->self_collision) {
       const int npairs = rm.n_self_pairs;
       for (int a = 0; a < A; a++) {
-        // screen: all passes at once (independent 16 B loads, one ballot); robots rarely touch themselves, so the per-pass
-        // compaction below normally does not run at all
+        // screen: all passes at once (independent 16 B loads, one ballot) with the primitive's bounding sphere; robots rarely touch
+        // themselves, so the per-pass exact test below normally does not run at all
         const float* sp0 = lds + L.sph + a * nsr * 4;
+        const float* pp0 = lds + L.prim + a * npr * 8;
         float4 si4[NSP], sj4[NSP];
 #pragma unroll
-        for (int k = 0; k < NSP; k++) {                          // beyond the list: sphere 0 against itself, masked below
+        for (int k = 0; k < NSP; k++) {                          // beyond the list: feature 0 against primitive 0, masked below
           const int pr = selfp[k] < 0 ? 0 : selfp[k];
           si4[k] = *reinterpret_cast<const float4*>(sp0 + (pr & 255) * 4);
-          sj4[k] = *reinterpret_cast<const float4*>(sp0 + (pr >> 8) * 4);
+          sj4[k] = *reinterpret_cast<const float4*>(pp0 + (pr >> 8) * 8);
         }
         int any = 0;
 #pragma unroll
@@ -1012,17 +1126,20 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
 #pragma unroll
         for (int k = 0; k < NSP; k++) {
           if (k * 64 >= npairs) continue;
-          bool hit = false; float sd = 0, dist = 1, rj = 0; V3 ev = v3(0, 0, 0), cj = v3(0, 0, 0); int si = 0, sj = 0;
+          bool hit = false; float sd = 0; V3 n = v3(0, 0, 1), c = v3(0, 0, 0); float ra = 0; int f = 0, q = 0;
           if (selfp[k] >= 0) {
-            const int pr = selfp[k];
-            si = pr & 255; sj = pr >> 8;
-            const float* spi = lds + L.sph + (a * nsr + si) * 4;
-            const float* spj = lds + L.sph + (a * nsr + sj) * 4;
-            cj = ld3(spj); rj = spj[3];
-            ev = ld3(spi) - cj;
-            dist = sqrtf(dot(ev, ev));
-            sd = dist - spi[3] - rj;
-            hit = sd < m->contact_offset && dist > 1e-9f;
+            f = selfp[k] & 255; q = selfp[k] >> 8;
+            c = v3(si4[k].x, si4[k].y, si4[k].z); ra = si4[k].w;
+            const V3 cq = v3(sj4[k].x, sj4[k].y, sj4[k].z);
+            if (rm.prim_type[q] == MQE_PRIM_BOX) {
+              sd = sphere_box(c, ra, cq, lds + L.body + (a * MQE_NBODY + rm.prim_body[q]) * BODY_STRIDE + B_R,
+                              v3(rm.prim_half[q][0], rm.prim_half[q][1], rm.prim_half[q][2]), n);
+              hit = sd < m->contact_offset;
+            } else {
+              const float4 w1 = *reinterpret_cast<const float4*>(pp0 + q * 8 + 4);
+              const bool ok = sphere_capsule(c, ra, cq, v3(w1.x, w1.y, w1.z), w1.w, sd, n);
+              hit = ok && sd < m->contact_offset;
+            }
           }
           const unsigned long long bh = __ballot(hit);
           if (bh == 0ull) continue;
@@ -1030,9 +1147,8 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
           const int slot = nc + __popcll(bh & lower);
           if (hit && slot < pair_lim) {
             float* cr = lds + L.con + slot * CON_STRIDE;
-            const V3 n = (1.0f / dist) * ev;
-            con_store(cr, a, rm.sphere_body[si], a, rm.sphere_body[sj], cj + (rj + 0.5f * sd) * n, n, sd, a * MQE_NREP + rm.sphere_reported[si],
-                      a * MQE_NREP + rm.sphere_reported[sj]);
+            con_store(cr, a, rm.sphere_body[f], a, rm.prim_body[q], c - (ra + 0.5f * sd) * n, n, sd, a * MQE_NREP + rm.sphere_reported[f],
+                      a * MQE_NREP + rm.prim_reported[q]);
           }
           nc += __popcll(bh);
           if (nc > pair_lim) { nc = pair_lim; ovf = 1; }
@@ -1773,7 +1889,7 @@ __global__ void __launch_bounds__(64, SubstepsClass<TP>::waves) k_substeps(const
   const int lane = threadIdx.x, e = blockIdx.x;
   const PhysShape<TA, TP> shp(m);
   const int A = shp.A, P = shp.P;
-  const PhysLds L = phys_lds_layout(A, P, shp.ND, shp.nbody, shp.ndof, m->nsph_env, shp.maxc, shp.rowgs);
+  const PhysLds L = phys_lds_layout(A, P, shp.ND, shp.nbody, shp.ndof, m->nsph_env, m->nprim_env, shp.maxc, shp.rowgs);
   const int nj = 12 * A;
   const int ctrl = m->control_type;
   const size_t R12 = (size_t)m->R * 12;

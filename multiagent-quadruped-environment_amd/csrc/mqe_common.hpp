@@ -54,7 +54,7 @@ struct DevModel {
   float reward_scale[MQE_MAX_REWARD_TERMS]; float wrapper_param[8];
   DevMlp actuator;
   // physics kernel geometry
-  int nbody_env, ndof_env, nsph_env, maxc;
+  int nbody_env, ndof_env, nsph_env, nprim_env, maxc;
 };
 
 // device pointers of all state tensors (kernel argument by value)

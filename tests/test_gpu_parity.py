@@ -1,5 +1,7 @@
 """-m gpu: the HIP engine (through the C ABI) against (1) the reference's golden traces for everything around the
 physics and (2) the CPU oracle for the physics, on identical seeded states."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -8,6 +10,8 @@ from mqe.engine import abi
 from helpers import hip_engine, oracle_engine, make_desc, to_dev, close
 from replay import replay
 from wrapper_replay import wrapper_replay
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -96,12 +100,23 @@ def test_policy_layer0_paths_are_f32_equivalent(monkeypatch, split, N):
             close(eh.tensor(abi.T_ACTIONS), eo.tensor(abi.T_ACTIONS), atol=5e-5, what=f"policy actions step {t}")
 
 
+def _record(kind, obj):
+    """measured deviations, appended to gpurun_out/test_measurements.jsonl when that directory exists (what the bounds are set from)"""
+    import json
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "test_measurements.jsonl"), "a") as f:
+            f.write(json.dumps(dict(obj, kind=kind)) + "\n")
+
+
 @pytest.mark.parametrize("task,N", [("go1gate", 128), ("go1football-defender", 16), ("go1sheep-hard", 14), ("go1seesaw", 16), ("go1football-2vs2", 8), ("go1football-1vs1", 16), ("go1pushbox", 16), ("go1revolvingdoor", 16), ("go1bridge", 16), ("go1wrestling", 16), ("go1tug", 16)])
 def test_fused_rollout_matches_oracle(task, N):
     """20 fused step() calls (policy + 4 substeps + post-step + wrapper) from the seeded reset distribution, nothing re-synchronised.
     Contact dynamics amplify rounding differences (a contact that closes one substep earlier), so the bound is a distribution
-    over envs -- median, 99th percentile AND maximum of the base-position deviation (the measured values are two to three orders
-    below: profiles/r02_parity_sweep.json) -- and the reset flags must agree in every env at every step."""
+    over envs -- median, 99th percentile AND maximum of the base-position deviation -- and the reset flags must agree in every env
+    at every step.  The bounds sit about 10 x above what is measured (this test on MI355X, round 3: worst task after 5 steps
+    median 3e-8 / p99 7e-7 / max 1e-6 m, after 20 steps 6e-8 / 1.5e-6 / 2.9e-6 m; the 256-env sweep profiles/r03_parity_sweep.json:
+    worst max 8e-5 m after 20 steps): a regression of one order of magnitude fails (round 2's bounds were 1000 x looser)."""
     eh, eo, d = _pair(task, N)
     eh.reset_all(); eo.reset_all()
     g = torch.Generator().manual_seed(11)
@@ -119,8 +134,14 @@ def test_fused_rollout_matches_oracle(task, N):
             close(eh.tensor(abi.T_ACTIONS), eo.tensor(abi.T_ACTIONS), atol=5e-5, what="policy actions step 0")
     dev = torch.stack(dev_pos)
     assert torch.isfinite(dev).all()
-    for step, med, p99, mx in ((4, 1e-5, 1e-4, 1e-3), (19, 1e-4, 1e-3, 2e-2)):
+    meas = {}
+    BOUNDS = ((4, 5e-7, 1e-5, 2e-5), (19, 2e-6, 5e-5, 5e-4))
+    for step, med, p99, mx in BOUNDS:
         got = (float(dev[step].median()), float(dev[step].quantile(0.99)), float(dev[step].max()))
+        meas[step + 1] = got
+    _record("rollout_dev", {"task": task, "N": N, "dev": meas})
+    for step, med, p99, mx in BOUNDS:
+        got = meas[step + 1]
         assert got[0] < med and got[1] < p99 and got[2] < mx, f"{task}: base position deviation after {step + 1} steps (median, p99, max) = {got}"
     assert mism == 0, f"{mism} reset-flag mismatches"
     assert int(eh.tensor(abi.T_CONTACT_OVERFLOW).sum()) == int(eo.tensor(abi.T_CONTACT_OVERFLOW).sum())
@@ -220,7 +241,7 @@ def test_self_contacts_match_oracle():
     folded legs, perturbed per env: identical contact lists, then 40 substeps tracked in joint space."""
     N = 16
     eh, eo, d = _pair("go1gate", N)
-    assert d.self_collision == 1 and d.robot.n_self_pairs == 270
+    assert d.self_collision == 1 and d.robot.n_self_pairs == 124        # (feature point, primitive) candidates of the model file
     eh.reset_all(); eo.reset_all()
     torch.cuda.synchronize()
     ro, do = eo.tensor(abi.T_ROOT_STATE), eo.tensor(abi.T_DOF_STATE)
