@@ -124,6 +124,9 @@ class Go1:
         """(N,2) per-env gate position the task wrapper / scripted defender uses, or None."""
         kw = self.cfg.terrain.BarrierTrack_kwargs
         gd = self._env_info_np.get("gate_deviation")
+        if gd is None and self.task in ("gate", "pushbox", "sheep"):
+            raise ValueError(f"task '{self.task}' reads the gate position from the terrain's env_info (a BarrierTrack with a gate block); "
+                             f"{type(self.terrain).__name__} has none")
         if self.task in ("gate", "pushbox"):      # go1_gate_wrapper.py:41-42, go1_pushbox_wrapper.py:29-30
             g = gd.copy()
             g[:, 0] += kw["init"]["block_length"] + kw["gate"]["block_length"] / 2

@@ -4,6 +4,7 @@ import os
 
 import numpy as np
 import pytest
+import torch
 
 from helpers import GOLD, golden, task_cfg, make_desc
 from mqe.utils.helpers import class_to_dict
@@ -168,3 +169,101 @@ def test_raised_perlin_border_is_a_wall_of_its_own_height():
         pytest.skip("this track layout is not expressible with the block painters")
     if not (t2.wall[:, b:-b]).any():
         assert t2.wall_height == pytest.approx(0.45) and t2.wall_top is None
+
+
+def _terrain_variant(name, **over):
+    return type(name, (task_cfg("go1gate").terrain,), over)
+
+
+def test_terrain_perlin_class_matches_reference_and_drives_an_env(monkeypatch):
+    """SURVEY 8(f)4 / VERDICT r2 missing 3: `TerrainPerlin` (perlin.py:9-32,95-117) is selectable through the registry
+    (__init__.py:3-13); its int16 samples and env origins are the reference's at np.random.seed(0), and an env built on it walks on
+    the relief (oracle engine: the product path needs a GPU)."""
+    from mqe.utils.terrain import get_terrain_cls, terrain_registry
+    assert sorted(terrain_registry) == ["BarrierTrack", "Terrain", "TerrainPerlin"]
+    z = golden("terrain_perlin_class")
+    tcfg = _terrain_variant("PerlinClassTerrain", selected="TerrainPerlin", num_rows=2, num_cols=2, terrain_length=4.0, terrain_width=4.0,
+                            TerrainPerlin_kwargs=dict(zScale=0.1, frequency=5))
+    np.random.seed(0)
+    t = get_terrain_cls("TerrainPerlin")(tcfg, 4, 2).build()
+    hs = t.heightsamples
+    assert hs.dtype == np.int16 and hs.shape == tuple(z["shape"])
+    assert np.array_equal(hs[::4, ::4], z["sub"]) and int(hs.astype(np.int64).sum()) == int(z["total"])
+    assert np.array_equal(hs.astype(np.int64).sum(1), z["row_sums"])
+    np.testing.assert_allclose(t.env_origins, z["env_origins"], atol=1e-6)
+    assert t.ground_height.shape == hs.shape and not t.wall.any() and t.ground_z == 0.0
+    # an env on it: robots dropped at the origin of their cell stand ON the relief
+    import types as _t
+    from mqe.envs.go1.go1 import Go1
+    from mqe.envs.utils import ENV_DICT, make_mqe_env, custom_cfg
+    from mqe.utils.helpers import finish_args
+    from oracle_engine import OracleEngine
+    monkeypatch.setattr(Go1, "engine_factory", staticmethod(lambda d, k, dev: OracleEngine(d, k)))
+    monkeypatch.setattr(Go1, "shard", None)
+    base = ENV_DICT["go1plane"]["config"]
+    a = finish_args(_t.SimpleNamespace(task="go1plane", num_envs=3, seed=0, headless=True, record_video=False, sim_device="cpu", pipeline="cpu", subscenes=0, num_threads=0))
+    try:
+        with pytest.raises(ValueError, match="gate position"):      # the gate task needs its gate: a clear error, not an AttributeError
+            make_mqe_env("go1gate", a, lambda c: type("Go1GateOnPerlin", (custom_cfg(a)(c),), {"terrain": tcfg}))
+        ENV_DICT["go1gate"]["config"] = task_cfg("go1gate")
+        env, _ = make_mqe_env("go1plane", a, lambda c: type("Go1PlaneOnPerlin", (custom_cfg(a)(c),), {"terrain": tcfg}))
+        assert type(env.env.terrain).__name__ == "TerrainPerlin"
+        env.reset()
+        A = env.env.num_agents
+        for _ in range(25):
+            env.step(torch.zeros(3, A, 3))
+        rs = env.env.root_states
+        gh = env.env.terrain.ground_height
+        hsc = tcfg.horizontal_scale
+        under = np.array([gh[int(round(float(x) / hsc)), int(round(float(y) / hsc))] for x, y in rs[:, :2]])
+        hgt = rs[:, 2].numpy() - under
+        assert np.isfinite(rs.numpy()).all() and (hgt > 0.15).all() and (hgt < 0.45).all(), hgt
+        env.close()
+    finally:
+        ENV_DICT["go1plane"]["config"] = base
+
+
+def test_legacy_terrain_generators():
+    """`Terrain` (terrain.py:38-165) on the restated isaacgym.terrain_utils generators (third party, not in the snapshot: unpinned):
+    deterministic under np.random.seed, right raster size, and every generator does what its name says."""
+    from mqe.utils.terrain import get_terrain_cls
+    from mqe.utils.terrain import terrain as T
+    tcfg = _terrain_variant("LegacyTerrain", selected="Terrain", mesh_type="trimesh", num_rows=3, num_cols=4, terrain_length=8.0, terrain_width=8.0, border_size=2.0,
+                            horizontal_scale=0.1, vertical_scale=0.005, curriculum=True, terrain_proportions=[0.1, 0.1, 0.35, 0.25, 0.2], slope_treshold=0.75)
+    np.random.seed(3)
+    t1 = get_terrain_cls("Terrain")(tcfg, 8, 2).build()
+    np.random.seed(3)
+    t2 = get_terrain_cls("Terrain")(tcfg, 8, 2).build()
+    assert np.array_equal(t1.height_field_raw, t2.height_field_raw) and t1.height_field_raw.dtype == np.int16
+    assert t1.height_field_raw.shape == (3 * 80 + 40, 4 * 80 + 40) and t1.env_origins.shape == (3, 4, 3) and t1.agent_origins.shape == (3, 4, 2, 3)
+    assert (t1.height_field_raw[:20] == 0).all() and (t1.height_field_raw[:, :20] == 0).all()              # flat border
+    assert t1.ground_height.shape == t1.height_field_raw.shape and not t1.wall.any()
+    # curriculum: column = terrain type (slope, rough slope, stairs down, stairs up, obstacles), row = difficulty
+    blocks = lambda i, j: t1.height_field_raw[20 + 80 * i: 100 + 80 * i, 20 + 80 * j: 100 + 80 * j].astype(float) * 0.005
+    assert np.abs(blocks(2, 0)).max() > np.abs(blocks(1, 0)).max() > 0                                      # steeper pyramids in later rows
+    st = blocks(2, 3)                                                                                      # stairs: few distinct levels, multiples of the step height
+    lv = np.unique(st)
+    assert 3 <= len(lv) <= 12 and np.allclose(np.diff(lv), np.diff(lv)[0], atol=0.006)
+
+    s = T.SubTerrain(width=80, length=80, vertical_scale=0.005, horizontal_scale=0.1)
+    T.pyramid_sloped_terrain(s, slope=0.2, platform_size=3.0)
+    c = s.height_field_raw[40, 40]
+    assert c == s.height_field_raw.max() > 0 and (s.height_field_raw[25:55, 25:55] == c).all() and s.height_field_raw[0, 0] == 0
+    s = T.SubTerrain(width=80, length=80, vertical_scale=0.005, horizontal_scale=0.1)
+    T.pit_terrain(s, depth=0.5, platform_size=4.0)
+    assert s.height_field_raw.min() == -100 and (s.height_field_raw[20:60, 20:60] == -100).all() and s.height_field_raw[5, 5] == 0
+    s = T.SubTerrain(width=80, length=80, vertical_scale=0.005, horizontal_scale=0.1)
+    T.gap_terrain(s, gap_size=0.5, platform_size=3.0)
+    assert s.height_field_raw[40, 40] == 0 and s.height_field_raw.min() == -1000 and s.height_field_raw[2, 2] == 0
+    s = T.SubTerrain(width=80, length=80, vertical_scale=0.005, horizontal_scale=0.1)
+    np.random.seed(1)
+    T.random_uniform_terrain(s, -0.05, 0.05, step=0.005, downsampled_scale=0.2)
+    assert -10 <= s.height_field_raw.min() < 0 < s.height_field_raw.max() <= 10
+    s = T.SubTerrain(width=80, length=80, vertical_scale=0.005, horizontal_scale=0.1)
+    np.random.seed(1)
+    T.stepping_stones_terrain(s, stone_size=1.0, stone_distance=0.1, max_height=0.0, platform_size=2.0)
+    assert s.height_field_raw.min() == -2000 and (s.height_field_raw[30:50, 30:50] == 0).all()
+    s = T.SubTerrain(width=80, length=80, vertical_scale=0.005, horizontal_scale=0.1)
+    np.random.seed(1)
+    T.discrete_obstacles_terrain(s, 0.2, 1.0, 2.0, 20, platform_size=3.0)
+    assert set(np.unique(s.height_field_raw)) <= {-40, -20, 0, 20, 40} and (s.height_field_raw[25:55, 25:55] == 0).all()

@@ -944,6 +944,22 @@ def gen_perlin_terrain():
              gate_deviation=np.asarray(t.env_info["gate_deviation"]) if t.env_info else np.zeros(0))
 
 
+def gen_perlin_class():
+    """TerrainPerlin (perlin.py:9-32,95-117; selectable through the registry, __init__.py:6) at np.random.seed(0): the int16 height
+    samples (every fourth + sums) and the env origins of a square 2 x 2 map"""
+    from mqe.utils.terrain import get_terrain_cls
+    from mqe.envs.configs.go1_gate_config import Go1GateCfg
+    base = Go1GateCfg.terrain
+    tcfg = type("PerlinClassTerrain", (base,), dict(selected="TerrainPerlin", num_rows=2, num_cols=2, terrain_length=4.0, terrain_width=4.0,
+                                                    TerrainPerlin_kwargs=dict(zScale=0.1, frequency=5)))
+    np.random.seed(0)
+    t = get_terrain_cls("TerrainPerlin")(tcfg, 4, 1)
+    t.add_terrain_to_sim(types.SimpleNamespace(add_triangle_mesh=lambda *a, **k: None), "sim", "cpu")
+    hs = np.asarray(t.heightsamples)
+    save("terrain_perlin_class", shape=np.array(hs.shape), sub=hs[::4, ::4].astype(np.int16), total=np.int64(hs.astype(np.int64).sum()),
+         row_sums=hs.astype(np.int64).sum(1), env_origins=np.asarray(t.env_origins, np.float64))
+
+
 def gen_urdf_facts():
     """go1.urdf read with nothing but xml.etree -- every <inertial>, <collision> and <joint> as plain numbers -- so that the product's
     own URDF reader (mqe/utils/urdf_model.py, which feeds BOTH engines) is checked against an independent reading
@@ -1125,6 +1141,8 @@ def main():
         run_stage(gen_terrain_and_configs)
     if want("terrain_perlin"):
         run_stage(gen_perlin_terrain)
+    if want("terrain_perlin_class"):
+        run_stage(gen_perlin_class)
     if want("urdf_facts"):
         run_stage(gen_urdf_facts)
     if want("adapter"):
