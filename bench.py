@@ -117,6 +117,12 @@ def main():
     ap.add_argument("--no_strict_f32", action="store_true", help="skip the exact-f32 companion run")
     ap.add_argument("--cpu_sample_envs", type=int, default=0, help="CPU baseline batch (0 = the GPU run's num_envs, 8 steps)")
     ap.add_argument("--cpu_sample_steps", type=int, default=8)
+    ap.add_argument("--gather", choices=["between", "after"], default=os.environ.get("MQE_BENCH_GATHER", "between"),
+                    help="N > 1: where the all-gather of a step's returned batch is issued.  between (default): inside the NEXT step, after its policy "
+                         "kernels and before its physics kernel (overlaps k_substeps; DESIGN.md 8).  after: right behind the step's own k_post_physics, "
+                         "and the next step's first kernel waits for it (no RCCL block is ever resident beside the two machine-filling kernels; "
+                         "costs the gather's latency once per step)")
+    ap.add_argument("--no_gather", action="store_true", help="N > 1: per-GPU learners -- every rank keeps its own batch, no collective at all (SURVEY 8e)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -181,20 +187,30 @@ def main():
             ready[0] = None
             n_gathers[0] += 1
 
-    if world > 1:
+    use_gather = world > 1 and not args.no_gather
+    if use_gather and args.gather == "between":
         env.env.between_policy_and_physics = issue_gather
 
     def one_step():
         t = step_no[0]
         a = actions[t]
         step_no[0] += 1
+        if use_gather and args.gather == "after":
+            # schedule "after": the gather of the previous batch was issued behind that step's last kernel; this step's first
+            # kernel waits for it (stream-side), so the RCCL kernel never shares the GPU with the GEMM or the physics kernel
+            for b in range(2):
+                if pending[b] is not None:
+                    pending[b].wait()
+                    pending[b] = None
         o, r, d, info = env.step(a)
-        if world > 1:
+        if use_gather:
             ready[0] = (t & 1, env.returned_batch)
+            if args.gather == "after":
+                issue_gather()
         return o
 
     def drain():
-        if world > 1:
+        if use_gather:
             issue_gather()                            # the last step's batch
         for b in range(2):
             if pending[b] is not None:
@@ -221,7 +237,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:   # every step's batch was gathered, and the last one arrived whole: this rank's slice is its own snapshot
+    if use_gather:   # every step's batch was gathered, and the last one arrived whole: this rank's slice is its own snapshot
         b = (args.warmup + args.steps - 1) & 1
         assert n_gathers[0] == args.warmup + args.steps, (n_gathers[0], args.warmup + args.steps)
         mine = gather[b].view(world, -1)[rank]
@@ -330,7 +346,11 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic (U(-1,1) actions seed 1234; synthetic body MLP: body_latest.jit missing upstream)",
             "config": {"workload": f"{args.task}, {A} agents, num_envs={N} per GPU ({N * world} total), 4 substeps x 5 ms per step",
-                       "parallelism": f"env-sharded x{world}, all-gather of the returned batch" if world > 1 else "single GPU"},
+                       "parallelism": (f"env-sharded x{world}, " + ("no collective (per-GPU learners)" if args.no_gather else
+                                       f"all-gather of the returned batch issued {'between policy and physics of the next step' if args.gather == 'between' else 'after the step, next step waits'}"))
+                                      if world > 1 else "single GPU"},
+            "collective": None if world == 1 else ("none" if args.no_gather else {"op": "all_gather_into_tensor", "schedule": args.gather, "bytes_per_rank": int(4 * env.returned_batch.numel()),
+                                                                                  "gathers": n_gathers[0]}),
             "target_env_steps_per_s": 1.0e6,
             "physical_robot_steps_per_s": round(value * env.env.num_agents / A, 1),
             "roofline": roof,

@@ -28,7 +28,7 @@ extern "C" {
 #define MQE_ABI_VERSION 12
 #define MQE_MAX_SPHERES 32    /* feature points of one robot */
 #define MQE_MAX_PRIMS 20      /* collision primitives of one robot (Go1: 18) */
-#define MQE_MAX_SELF_PAIRS 192
+#define MQE_MAX_SELF_PAIRS 128
 #define MQE_NBODY 13      /* dynamic bodies of one Go1 after fixed-joint collapsing */
 #define MQE_NREP 17       /* reported rigid bodies of one Go1 (feet kept, go1.urdf dont_collapse) */
 #define MQE_NDOF 12
@@ -92,6 +92,8 @@ typedef struct {
   float prim_axis[MQE_MAX_PRIMS][3];      /* capsule: half of its segment (centre +- axis), link frame; otherwise 0 */
   float prim_half[MQE_MAX_PRIMS][3];      /* box: half extents along the link axes; sphere / capsule: [0] = radius */
   float prim_bound[MQE_MAX_PRIMS];        /* radius of the bounding sphere about prim_center */
+  float feature_reach;                    /* no feature point (its sphere included) is ever farther from the base origin than this,
+                                             whatever the joint angles: the broad phase between two robots */
   /* self-collision candidates (asset.self_collisions = 0, go1_config.py:73 / legged_robot.py:874): (feature point, primitive)
    * pairs whose links are neither the same nor parent and child and that some pose inside the joint limits brings within 3 cm
    * (mqe/utils/urdf_model.py::_self_pair_candidates), ascending; entry = feature | primitive << 8 */
@@ -300,7 +302,7 @@ int mqe_step_joint(mqe_sim* s, const float* actions12, void* stream);
 int mqe_debug_dynamics(mqe_sim* s, int env, int robot, float* minv_out_host, int* nc_out_host, float* contacts_out_host);
 int mqe_debug_times(long long* out16);   /* clock64 stamps of the phases of the last mqe_debug_dynamics launch */
 /* per-phase counter runs (tools/phase_counters.py): the following mqe_simulate launches leave the wavefront after phase tap `tap`
- * and write nothing back (tap < 0: normal launches again).  Two-robot scenes without objects only; any other scene is refused.
+ * and write nothing back (tap < 0: normal launches again; tap >= 100: the same specialised kernel run to the end, state written).  Two-robot scenes without objects only; any other scene is refused.
  * The environment variable MQE_DEBUG_STOP_PHASE sets the same thing when the handle is created. */
 int mqe_debug_stop_phase(mqe_sim* s, int tap);
 

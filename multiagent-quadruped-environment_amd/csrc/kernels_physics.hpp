@@ -61,6 +61,15 @@ __device__ __forceinline__ float row16_sum(float x) {
   x += dpp_take<0x140>(x);     // row_mirror
   return x;
 }
+// maximum over the wave of a non-negative value, delivered to every lane: DPP butterfly inside each row of 16, then the four rows
+// through scalar registers
+__device__ __forceinline__ float wave_max_nonneg(float x) {
+  x = fmaxf(x, dpp_take<0xB1>(x)); x = fmaxf(x, dpp_take<0x4E>(x)); x = fmaxf(x, dpp_take<0x141>(x)); x = fmaxf(x, dpp_take<0x140>(x));
+  const int xi = __float_as_int(x);
+  const float a = __int_as_float(__builtin_amdgcn_readlane(xi, 0)), b = __int_as_float(__builtin_amdgcn_readlane(xi, 16));
+  const float c = __int_as_float(__builtin_amdgcn_readlane(xi, 32)), d = __int_as_float(__builtin_amdgcn_readlane(xi, 48));
+  return fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
 // value of lane ^ 16 (the same position in the neighbouring row): ds_swizzle in bit-mask mode, xor 0x10 -- no LDS access
 __device__ __forceinline__ float row_partner(float x) {
   return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), 0x401F));
@@ -684,7 +693,8 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     *reinterpret_cast<float4*>(sp) = make_float4(c.x, c.y, c.z, rad);
   }
   // the robots' primitives in world coordinates (what the OTHER actors' feature points and spheres are tested against): centre and
-  // bounding radius, capsule half-segment and radius (a sphere is a capsule with a zero segment; a box keeps its link's rotation)
+  // bounding radius, capsule half-segment and radius (a sphere is a capsule with a zero segment; a box keeps its link's rotation
+  // and is marked by a negative radius)
   const int npr = rm.n_prims;
   for (int t = lane; t < A * npr; t += 64) {
     const int r = t / npr, q = t - r * npr;
@@ -695,7 +705,13 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     const V3 u = mat_vec(Rr, v3(rm.prim_axis[q][0], rm.prim_axis[q][1], rm.prim_axis[q][2]));
     float4* pw = reinterpret_cast<float4*>(lds + L.prim + t * 8);
     pw[0] = make_float4(c.x, c.y, c.z, rm.prim_bound[q]);
-    pw[1] = make_float4(u.x, u.y, u.z, rm.prim_half[q][0]);
+    // radius; a box carries MINUS the radius of its bounding capsule about its longest edge (the sign marks it; screens use |.|)
+    float rad = rm.prim_half[q][0];
+    if (rm.prim_type[q] == MQE_PRIM_BOX) {
+      const V3 hb = v3(rm.prim_half[q][0], rm.prim_half[q][1], rm.prim_half[q][2]), al = v3(rm.prim_axis[q][0], rm.prim_axis[q][1], rm.prim_axis[q][2]);
+      rad = -sqrtf(fmaxf(dot(hb, hb) - dot(al, al), 1e-12f));
+    }
+    pw[1] = make_float4(u.x, u.y, u.z, rad);
   }
   __syncthreads();
 
@@ -964,20 +980,39 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
             if (lane < nsr) {
               const float4 qf = *reinterpret_cast<const float4*>(lds + L.sph + (fa * nsr + lane) * 4);
               c = v3(qf.x, qf.y, qf.z); ra = qf.w;
-              foot = rm.prim_type[rm.sphere_prim[lane]] == MQE_PRIM_SPHERE;
+              foot = ((m->feat_sphere_mask >> lane) & 1u) != 0u;
             }
-            for (int q = 0; q < npr; q++) {
+            // which primitives of qa reach into the ball around fa's base that holds all of fa's feature points in THIS pose (its
+            // radius: a maximum over the feature lanes; lane = primitive, one ballot): two robots walking side by side normally
+            // have none, and the loop below does not run at all
+            unsigned long long qmask;
+            {
+              const V3 pbase = ld3(lds + L.body + fa * MQE_NBODY * BODY_STRIDE + B_P);
+              const V3 db = c - pbase;
+              const float rfeat = wave_max_nonneg(lane < nsr ? sqrtf(dot(db, db)) + ra : 0.0f);
+              bool act = false;
+              if (lane < npr) {
+                const float4 w0 = *reinterpret_cast<const float4*>(lds + L.prim + (qa * npr + lane) * 8);
+                const V3 df = v3(w0.x, w0.y, w0.z) - pbase;
+                const float reach = w0.w + rfeat + m->contact_offset;
+                act = dot(df, df) < reach * reach;
+              }
+              qmask = __ballot(act);
+            }
+            while (qmask != 0ull) {
+              const int q = __ffsll((long long)qmask) - 1;
+              qmask &= qmask - 1ull;
               const float4* pw = reinterpret_cast<const float4*>(lds + L.prim + (qa * npr + q) * 8);
               const float4 w0 = pw[0], w1 = pw[1];
               const V3 cq = v3(w0.x, w0.y, w0.z);
-              const int ptype = rm.prim_type[q];
+              const bool qbox = w1.w < 0.0f, qsph = !qbox && w1.x == 0.0f && w1.y == 0.0f && w1.z == 0.0f;      // wave-uniform
               const V3 dq = c - cq;
               const float reach = ra + w0.w + m->contact_offset;
-              bool cand = lane < nsr && dot(dq, dq) < reach * reach && !(dir == 1 && foot && ptype == MQE_PRIM_SPHERE);
+              bool cand = lane < nsr && dot(dq, dq) < reach * reach && !(dir == 1 && foot && qsph);
               if (__ballot(cand) == 0ull) continue;
               bool hit = false; float sd = 0; V3 n = v3(0, 0, 1);
               if (cand) {
-                if (ptype == MQE_PRIM_BOX) {
+                if (qbox) {
                   sd = sphere_box(c, ra, cq, lds + L.body + (qa * MQE_NBODY + rm.prim_body[q]) * BODY_STRIDE + B_R,
                                   v3(rm.prim_half[q][0], rm.prim_half[q][1], rm.prim_half[q][2]), n);
                   hit = sd < m->contact_offset;
@@ -1009,7 +1044,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
           if (lane < npr) {
             const float4* pw = reinterpret_cast<const float4*>(lds + L.prim + (a * npr + lane) * 8);
             w0 = pw[0]; w1 = pw[1];
-            ptype = rm.prim_type[lane]; pbody = rm.prim_body[lane]; prep = rm.prim_reported[lane];
+            ptype = w1.w < 0.0f ? MQE_PRIM_BOX : MQE_PRIM_CAPSULE; pbody = rm.prim_body[lane]; prep = rm.prim_reported[lane];
             ph = v3(rm.prim_half[lane][0], rm.prim_half[lane][1], rm.prim_half[lane][2]);
           }
           for (int sb = 0; sb < nb; sb++) {
@@ -1105,22 +1140,26 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     if (m->self_collision) {
       const int npairs = rm.n_self_pairs;
       for (int a = 0; a < A; a++) {
-        // screen: all passes at once (independent 16 B loads, one ballot) with the primitive's bounding sphere; robots rarely touch
-        // themselves, so the per-pass exact test below normally does not run at all
+        // screen: all passes at once (independent 16 B loads, one ballot).  Bounding SPHERES (11 cm for a thigh or calf, 20 cm for the
+        // trunk) would let the neighbouring legs and the thigh tops through in every substep, so the screen is the distance to the
+        // capsule's segment itself (a box: its bounding capsule); robots rarely touch themselves and the compaction below normally
+        // does not run at all
         const float* sp0 = lds + L.sph + a * nsr * 4;
         const float* pp0 = lds + L.prim + a * npr * 8;
         float4 si4[NSP], sj4[NSP];
+        int any = 0;
 #pragma unroll
         for (int k = 0; k < NSP; k++) {                          // beyond the list: feature 0 against primitive 0, masked below
           const int pr = selfp[k] < 0 ? 0 : selfp[k];
           si4[k] = *reinterpret_cast<const float4*>(sp0 + (pr & 255) * 4);
           sj4[k] = *reinterpret_cast<const float4*>(pp0 + (pr >> 8) * 8);
-        }
-        int any = 0;
-#pragma unroll
-        for (int k = 0; k < NSP; k++) {
-          const float ex = si4[k].x - sj4[k].x, ey = si4[k].y - sj4[k].y, ez = si4[k].z - sj4[k].z, lim = si4[k].w + sj4[k].w + m->contact_offset;
-          any |= (int)(selfp[k] >= 0) & (int)(ex * ex + ey * ey + ez * ez < lim * lim);
+          const float4 uj = *reinterpret_cast<const float4*>(pp0 + (pr >> 8) * 8 + 4);
+          const V3 u = v3(uj.x, uj.y, uj.z), dq = v3(si4[k].x - sj4[k].x, si4[k].y - sj4[k].y, si4[k].z - sj4[k].z);
+          const float uu = dot(u, u);
+          const float t = uu > 0.0f ? fminf(fmaxf(dot(dq, u) * __builtin_amdgcn_rcpf(uu), -1.0f), 1.0f) : 0.0f;
+          const V3 e = dq - t * u;
+          const float lim = si4[k].w + fabsf(uj.w) + m->contact_offset + 1e-5f;                                       // (+ the screen's own rounding)
+          any |= (int)(selfp[k] >= 0) & (int)(dot(e, e) < lim * lim);
         }
         if (__ballot(any != 0) == 0ull) continue;
 #pragma unroll
@@ -1131,12 +1170,12 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
             f = selfp[k] & 255; q = selfp[k] >> 8;
             c = v3(si4[k].x, si4[k].y, si4[k].z); ra = si4[k].w;
             const V3 cq = v3(sj4[k].x, sj4[k].y, sj4[k].z);
-            if (rm.prim_type[q] == MQE_PRIM_BOX) {
+            const float4 w1 = *reinterpret_cast<const float4*>(pp0 + q * 8 + 4);
+            if (w1.w < 0.0f) {
               sd = sphere_box(c, ra, cq, lds + L.body + (a * MQE_NBODY + rm.prim_body[q]) * BODY_STRIDE + B_R,
                               v3(rm.prim_half[q][0], rm.prim_half[q][1], rm.prim_half[q][2]), n);
               hit = sd < m->contact_offset;
             } else {
-              const float4 w1 = *reinterpret_cast<const float4*>(pp0 + q * 8 + 4);
               const bool ok = sphere_capsule(c, ra, cq, v3(w1.x, w1.y, w1.z), w1.w, sd, n);
               hit = ok && sd < m->contact_offset;
             }

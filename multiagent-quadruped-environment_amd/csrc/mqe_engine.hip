@@ -280,6 +280,9 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   m.ndof_env = A * MQE_RD + m.n_npc_dyn * m.npc_dofs_each + (seesaw ? 1 : 0);
   m.nsph_env = A * d->robot.n_spheres + m.n_npc_dyn * d->npc_n_spheres;
   m.nprim_env = A * d->robot.n_prims;
+  m.feat_sphere_mask = 0u;
+  for (int f = 0; f < d->robot.n_spheres; f++)
+    if (d->robot.prim_type[d->robot.sphere_prim[f]] == MQE_PRIM_SPHERE) m.feat_sphere_mask |= 1u << f;
   m.maxc = mqe_maxc(A, P, m.cap_npc);
   if (m.ndof_env > 128 || m.nbody_env > 64) { return fail(-4, "env has more than 64 bodies or 128 generalized velocities: does not fit one wavefront"); }
   m.rowgs = (A + m.n_npc_dyn + (seesaw ? 1 : 0) <= 4) ? 1 : 0;      // one 16-lane row per actor; the <A,0> / <2,LINK> kernels assume it
@@ -665,8 +668,8 @@ static void launch_simulate(mqe_sim* s, hipStream_t q) {
   ProfScope ps(s, PROF_SIMULATE, q);
   PhysDebug dbg = {nullptr, nullptr, nullptr, 0, nullptr, -1};
   if (s->dbg_stop_phase >= 0) {             // tools/phase_counters.py: the wavefront leaves after that phase tap (validated at creation)
-    dbg.stop_after = s->dbg_stop_phase;
-    hipLaunchKernelGGL(k_simulate_a2, dim3(s->N), dim3(64), s->phys_lds_bytes, q, s->dm, s->st, 0, 1, dbg);
+    dbg.stop_after = s->dbg_stop_phase;      // a tap >= 100 never fires: the whole a2 substep, state written back (the "full" launch of the tool)
+    hipLaunchKernelGGL(k_simulate_a2, dim3(s->N), dim3(64), s->phys_lds_bytes, q, s->dm, s->st, 0, s->dbg_stop_phase < 100 ? 1 : 0, dbg);
     return;
   }
   hipLaunchKernelGGL(k_simulate, dim3(s->N), dim3(64), s->phys_lds_bytes, q, s->dm, s->st, 0, 0, dbg);

@@ -3,7 +3,7 @@ import ctypes as C
 
 ABI_VERSION = 12
 MAX_SPHERES, NBODY, NREP, NDOF = 32, 13, 17, 12
-MAX_SELF_PAIRS = 192
+MAX_SELF_PAIRS = 128
 MAX_PRIMS = 20
 PRIM_SPHERE, PRIM_CAPSULE, PRIM_BOX = 0, 1, 2
 MAX_AGENTS, MAX_NPCS, FRAME, HIST, MAX_LAYERS, MAX_REWARD_TERMS = 4, 9, 72, 30, 6, 12
@@ -43,7 +43,7 @@ class RobotModel(C.Structure):
         ("sphere_center", (f32 * 3) * MAX_SPHERES), ("sphere_radius", f32 * MAX_SPHERES),
         ("n_prims", i32), ("prim_type", i32 * MAX_PRIMS), ("prim_body", i32 * MAX_PRIMS), ("prim_reported", i32 * MAX_PRIMS),
         ("prim_center", (f32 * 3) * MAX_PRIMS), ("prim_axis", (f32 * 3) * MAX_PRIMS), ("prim_half", (f32 * 3) * MAX_PRIMS),
-        ("prim_bound", f32 * MAX_PRIMS),
+        ("prim_bound", f32 * MAX_PRIMS), ("feature_reach", f32),
         ("n_self_pairs", i32), ("self_pair", C.c_uint16 * MAX_SELF_PAIRS),
     ]
 

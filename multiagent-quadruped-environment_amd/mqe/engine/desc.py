@@ -153,6 +153,7 @@ def build_desc(cfg, num_envs, terrain, env_origins, agent_origins, gate_pos=None
         r.sphere_prim[s] = m["sphere_prim"][s]
         for k in range(3):
             r.sphere_center[s][k] = m["sphere_center"][s][k]
+    r.feature_reach = m["feature_reach"]
     r.n_prims = len(m["prim_type"])
     for q in range(r.n_prims):
         r.prim_type[q], r.prim_body[q], r.prim_reported[q], r.prim_bound[q] = m["prim_type"][q], m["prim_body"][q], m["prim_reported"][q], m["prim_bound"][q]

@@ -234,7 +234,9 @@ def _collision_model_for_go1(bodies, reported_names):
                 h = np.asarray(prm, np.float64)
                 assert np.allclose(np.abs(R), np.round(np.abs(R)), atol=1e-9), "base boxes must be aligned with the base frame"
                 hl = np.abs(R) @ h                     # half extents along the link axes
-                prims.append(dict(type=PRIM_BOX, body=bi, reported=ri, center=t, axis=np.zeros(3), half=hl, bound=float(np.linalg.norm(hl))))
+                la = int(np.argmax(hl))
+                ax = np.zeros(3); ax[la] = hl[la]          # a box's "axis": half of its longest edge (its bounding capsule, for screens)
+                prims.append(dict(type=PRIM_BOX, body=bi, reported=ri, center=t, axis=ax, half=hl, bound=float(np.linalg.norm(hl))))
                 corners = [np.array([sx, sy, sz]) * hl for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)]
                 is_head = len([p for p in prims if p["type"] == PRIM_BOX]) > 1
                 for c in corners:
@@ -291,7 +293,7 @@ def _self_pair_candidates(m, prims, feats, n_samples=200000, seed=0):
         for k, (i, j) in enumerate(cand):
             g = prims[j]
             d = fc[:, i] - qc[:, j]
-            if g["type"] == PRIM_BOX:
+            if g["type"] == PRIM_BOX:        # (the exact box, not its bounding capsule)
                 loc = np.einsum("bji,bj->bi", R[:, g["body"]], d)
                 ex = np.maximum(np.abs(loc) - g["half"], 0.0)
                 dist = np.linalg.norm(ex, axis=1)
@@ -359,6 +361,10 @@ def build_go1_model(urdf_path):
     m["prim_axis"] = [np.asarray(g["axis"]).tolist() for g in prims]
     m["prim_half"] = [np.asarray(g["half"]).tolist() for g in prims]
     m["prim_bound"] = [float(g["bound"]) for g in prims]
+    # upper bound of |feature point - base origin| + its radius over all joint angles: joint offsets along the chain + the local centre
+    def chain(b):
+        return 0.0 if b == 0 else float(np.linalg.norm(m["joint_offset"][b])) + chain(m["parent"][b])
+    m["feature_reach"] = max(chain(f["body"]) + float(np.linalg.norm(f["center"])) + f["radius"] for f in feats)
     pairs, n_all = _self_pair_candidates(m, prims, feats)
     m["self_pairs"] = [[int(i), int(j)] for i, j in pairs]
     m["self_pairs_unpruned"] = int(n_all)

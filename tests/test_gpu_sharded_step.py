@@ -84,21 +84,31 @@ def test_step_end_without_begin_is_an_error():
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("task,port", [("go1gate", "29617"), ("go1football-defender", "29619")])
-def test_bench_two_ranks_delayed_gather(task, port):
-    """bench.py --gpus 2 as the driver launches it, both ranks on cuda:0 over gloo: every step's batch is gathered (issued
-    from inside the next step) and arrives whole -- bench.py asserts both.  go1football-defender = BASELINE config 5's sharded
-    path: 3 robots per env, the scripted defender and the reset draws keyed by the global env id."""
+@pytest.mark.parametrize("task,port,world,extra", [
+    ("go1gate", "29641", 2, []), ("go1football-defender", "29643", 2, []),
+    ("go1gate", "29645", 8, []), ("go1gate", "29647", 8, ["--gather", "after"]), ("go1football-defender", "29649", 8, ["--gather", "after"]),
+    ("go1gate", "29651", 8, ["--no_gather"])])
+def test_bench_sharded_schedules_over_gloo(task, port, world, extra):
+    """bench.py --gpus N as the driver launches it, all ranks on cuda:0 over gloo (world sizes 2 and 8 = the node the driver
+    measures on): every step's batch is gathered and arrives whole -- bench.py asserts both -- under both schedules of the
+    collective (issued between policy and physics of the next step | issued after the step, next step waits) and without a
+    collective (per-GPU learners).  go1football-defender = BASELINE config 5's sharded path: 3 robots per env, the scripted
+    defender and the reset draws keyed by the global env id."""
     env = dict(os.environ, MQE_BENCH_SELFTEST_GLOO="1", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "3",
-           "--num_envs", "128", "--no_cpu_baseline", "--task", task]
-    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    n = 128 if world == 2 else 32
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "12", "--warmup", "3",
+           "--num_envs", str(n), "--no_cpu_baseline", "--task", task] + extra
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     r = json.loads(line)
-    assert r["n_gpus"] == 2 and r["steps"] == 12 and r["value"] > 0 and r["scaling"] == "weak"
-    assert "128 per GPU (256 total)" in r["config"]["workload"]
+    assert r["n_gpus"] == world and r["steps"] == 12 and r["value"] > 0 and r["scaling"] == "weak"
+    assert f"{n} per GPU ({n * world} total)" in r["config"]["workload"]
+    if "--no_gather" in extra:
+        assert r["collective"] == "none" and "no collective" in r["config"]["parallelism"]
+    else:
+        assert r["collective"]["schedule"] == ("after" if "after" in extra else "between") and r["collective"]["gathers"] == 15
 
 
 def test_rccl_process_group_options_single_rank():

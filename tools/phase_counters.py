@@ -28,7 +28,7 @@ if sys.argv[1] == "run":
         e.step((torch.rand(n, Aw, 3, device="cuda", generator=g) * 2 - 1) * 0.5)
     torch.cuda.synchronize()
     for rep in range(2):
-        for tap in TAPS + [-1]:
+        for tap in TAPS + [100]:
             e._call("debug_stop_phase", tap)
             e.simulate()
             torch.cuda.synchronize()
