@@ -63,8 +63,11 @@ __device__ __forceinline__ float row16_sum(float x) {
 }
 // maximum over the wave of a non-negative value, delivered to every lane: DPP butterfly inside each row of 16, then the four rows
 // through scalar registers
-__device__ __forceinline__ float wave_max_nonneg(float x) {
+// (HALF = true: over each half-wave of 32 lanes separately -- the two rows of a half through the xor-16 swizzle, no lane of the other
+// half is read, so the two halves may sit in different branches)
+template <bool HALF> __device__ __forceinline__ float wave_max_nonneg(float x) {
   x = fmaxf(x, dpp_take<0xB1>(x)); x = fmaxf(x, dpp_take<0x4E>(x)); x = fmaxf(x, dpp_take<0x141>(x)); x = fmaxf(x, dpp_take<0x140>(x));
+  if (HALF) return fmaxf(x, __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), 0x401F)));
   const int xi = __float_as_int(x);
   const float a = __int_as_float(__builtin_amdgcn_readlane(xi, 0)), b = __int_as_float(__builtin_amdgcn_readlane(xi, 16));
   const float c = __int_as_float(__builtin_amdgcn_readlane(xi, 32)), d = __int_as_float(__builtin_amdgcn_readlane(xi, 48));
@@ -140,7 +143,16 @@ __device__ __forceinline__ float wave_sum(float x) {
   return x;
 }
 
-#define BODY_STRIDE 32
+// Record strides are multiples of 4 floats (16 B words) that are NOT multiples of 32: with 32 banks of 4 B a stride of 128 B puts the
+// same word of every lane's record into the same banks (26 body lanes storing a float4 each = a 26-way conflict; PMC, round 3: 31 % of
+// the LDS-busy cycles of k_substeps were bank-conflict stalls, the LDS the busiest unit of the CU at 60 %).  36 / 20 / 28 floats walk
+// through all 32 banks in 8 lanes: 16 B accesses of neighbouring lanes are conflict-free.  The records that live in the scratch
+// union or on top of the link records (LEGC, FCOL, SREC) are padded for free; the link and contact records cost LDS (+ 672 B for two
+// robots), which only robot-only scenes can afford inside the 10 KiB that keep 16 envs on a CU: `pad` in phys_lds_layout /
+// PhysPad<TP> (go1gate k_substeps 127.6 -> 122.2 us).
+template <int TP> struct PhysPad { static constexpr int on = TP == 0 ? 1 : 0; };
+#define BODY_STRIDE_OF(pad) ((pad) ? 36 : 32)
+#define CON_STRIDE_OF(pad) ((pad) ? 20 : 16)
 // leg block record in 16 B words (lives to the end of the substep): Mll^-1 (sym6: 00,11,22,10,20,21) at 0, its Cholesky factor
 // Lm (Mll^-1 = Lm Lm^T; l00,l10,l11,l20,l21,l22) at 6, G = Mbl Mll^-1 (6 x 3) at 12; the Schur term C = G Mbl^T (upper
 // triangle, 21 values, 6 words) is scratch of its own (LEGC_STRIDE)
@@ -148,8 +160,8 @@ __device__ __forceinline__ float wave_sum(float x) {
 #define LEG_MI 0
 #define LEG_LM 6
 #define LEG_G 12
-#define LEGC_STRIDE 24
-#define CON_STRIDE 16
+#define LEGC_STRIDE 28
+#define FCOL_STRIDE 20      // one hip's composite (16 floats) on its way to the base lane
 // Contact side record (7 words): Phi = the side's Jacobian in coordinates in which the actor's inverse mass matrix is the
 // identity.  Robot: M^-1 = [S^-1, -S^-1 G; -G^T S^-1, Mll^-1 + G^T S^-1 G] = T T^T with T = [F 0; -G^T F, Lm] (S^-1 = F F^T, F upper
 // triangular; Mll^-1 = Lm Lm^T per leg), so Phi = J T = [ U | Z' ],  U = (J_base - J_leg G^T) F (3 x 6),  Z' = J_leg Lm (3 x 3, the
@@ -195,9 +207,10 @@ __host__ __device__ inline int mqe_maxc(int A, int P, int cap_npc) { int v = 8 *
 struct PhysLds {   // float offsets into dynamic LDS
   int root, dof, tau, body, rhs, acc, acth, fcol, leg, legc, basei, sinv, sph, prim, con, side, phi, srec, total;
 };
-#define SREC_STRIDE 16    // row sweep: per contact [u* (3), bias] [mu, 1/d00, 1/d11, 1/d22] [d10, d20, d21, -] [lambda (3), -]
+#define SREC_STRIDE 20    // row sweep: per contact [u* (3), bias] [mu, 1/d00, 1/d11, 1/d22] [d10, d20, d21, -] [lambda (3), -]
 __host__ __device__ inline int mqe_maxpair(int maxc) { return maxc / 2; }    // two-actor contacts kept per env
-__host__ __device__ inline PhysLds phys_lds_layout(int A, int P, int ND, int nbody, int ndof, int nsph, int nprim, int maxc, int rowgs) {
+__host__ __device__ inline PhysLds phys_lds_layout(int A, int P, int ND, int nbody, int ndof, int nsph, int nprim, int maxc, int rowgs, int pad) {
+  const int BODY_STRIDE = BODY_STRIDE_OF(pad), CON_STRIDE = CON_STRIDE_OF(pad);
   // Regions that live to the end of the substep first; then the link records; then ONE scratch area used three times over: by the
   // CRBA / Schur scratch (dead once the factors exist), by the collision geometry in world coordinates -- the feature points of the
   // robots / collision spheres of the NPCs (16 B each) and the robots' primitives (32 B each: centre + bounding radius, capsule
@@ -222,11 +235,11 @@ __host__ __device__ inline PhysLds phys_lds_layout(int A, int P, int ND, int nbo
   L.phi = L.body; L.srec = L.phi + maxc * SIDE_STRIDE;
   if (rowgs && L.srec + maxc * SREC_STRIDE > o) o = L.srec + maxc * SREC_STRIDE;
   const int scratch = o;
-  L.fcol = o; o += A * 64;                                  // the four hip composites of every robot on their way to the base lane
+  L.fcol = o; o += A * 4 * FCOL_STRIDE;                                  // the four hip composites of every robot on their way to the base lane
   L.legc = o; o += A * 4 * LEGC_STRIDE;
   L.basei = o; o += A * 24;                                 // per robot: upper triangle of the base block, then of the Schur complement (21 values)
   L.sph = scratch; L.prim = scratch + nsph * 4;
-  if (L.prim + nprim * 8 > o) o = L.prim + nprim * 8;
+  if (L.prim + nprim * 8 > o) o = L.prim + nprim * 8;     // two arrays of 16 B words: [centre, bounding radius] x nprim, then [half-segment, radius] x nprim
   L.side = scratch;                                         // side B of the two-actor contacts only (side A: registers / the phi area)
   if (scratch + mqe_maxpair(maxc) * SIDE_STRIDE > o) o = scratch + mqe_maxpair(maxc) * SIDE_STRIDE;
   L.total = o;
@@ -268,13 +281,34 @@ struct PhysShape {
         rowgs(ShapeClass<TP>::sweep >= 0 ? ShapeClass<TP>::sweep == 1 : m->rowgs != 0) {}
 };
 
-template <int TA, int TP>
-__device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, const DevState& st, float* lds, const int e, const int lane,
+// EPW = environments per wavefront.  1: the 64 lanes work for one env.  2 (two-robot scenes without objects): each half-wave of 32
+// lanes runs its own env -- body lanes 0-25, one 16-lane sweep row per robot, 32 feature points per pass -- so the dynamics and
+// contact phases, which keep a third of 64 lanes busy for one env, do the work of two envs with the same instruction stream.
+// Everything below is written for "the env's lanes": `lane` is the lane WITHIN the group, `lds` the group's own state, ballots are
+// the group's bits; the few places where a wave-wide decision is needed (barriers inside loops whose trip count depends on the
+// env) say so.  The arithmetic per env is the same either way: both forms produce bit-identical states (tests/test_gpu_parity.py).
+template <int TA, int TP, int EPW = 1>
+__device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, const DevState& st, float* lds_wave, const int e_first, const int lane_wave,
                                              const int flags, const int no_write, const PhysDebug& dbg) {
+  static_assert(EPW == 1 || (EPW == 2 && TP == 0 && (TA == 1 || TA == 2)), "two envs per wavefront: robot-only scenes of at most two robots");
+  constexpr int LW = 64 / EPW;                                   // lanes of one env
+  const int grp = EPW == 1 ? 0 : lane_wave / LW;                 // which env of the wavefront this lane works for
+  const int lane = EPW == 1 ? lane_wave : lane_wave - grp * LW;  // lane within the env's group
+  const bool evalid = EPW == 1 || e_first + grp < m->N;          // an odd batch leaves the last wavefront's second half without an env:
+  const int e = evalid ? e_first + grp : m->N - 1;               // it recomputes the last env and stores nothing
+  auto gballot = [&](bool p) -> unsigned long long {             // the group's bits of a ballot, in the low LW bits
+    const unsigned long long b = __ballot(p);
+    return EPW == 1 ? b : ((b >> (grp * LW)) & ((1ull << (LW & 63)) - 1ull));
+  };
+  auto wave_max_of_groups = [&](int x) -> int {                  // a value that is uniform within each group -> its maximum over the wave
+    return EPW == 1 ? x : max(__builtin_amdgcn_readlane(x, 0), __builtin_amdgcn_readlane(x, 32));
+  };
   const PhysShape<TA, TP> shp(m);
   const int A = shp.A, P = shp.P, PD = shp.PD, npcdof = shp.npcdof;
   const int nbody = shp.nbody, ndof = shp.ndof, nsph = m->nsph_env, maxc = shp.maxc;
-  const PhysLds L = phys_lds_layout(A, P, shp.ND, nbody, ndof, nsph, m->nprim_env, maxc, shp.rowgs);
+  constexpr int BODY_STRIDE = BODY_STRIDE_OF(PhysPad<TP>::on), CON_STRIDE = CON_STRIDE_OF(PhysPad<TP>::on);
+  const PhysLds L = phys_lds_layout(A, P, shp.ND, nbody, ndof, nsph, m->nprim_env, maxc, shp.rowgs, PhysPad<TP>::on);
+  float* lds = lds_wave + grp * L.total;
   const float dt = m->dt;
   const mqe_robot_model& rm = m->robot;
   float* g_root = st.root + (size_t)e * (A + P) * 13;
@@ -282,18 +316,18 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
 
   // this lane's self-collision candidates, one per pass of 64 (requested here, consumed after the terrain contacts: the
   // table sits in global memory and a load inside the pass loop put its full latency on every pass)
-  constexpr int NSP = (MQE_MAX_SELF_PAIRS + 63) / 64;
+  constexpr int NSP = (MQE_MAX_SELF_PAIRS + LW - 1) / LW;
   int selfp[NSP];
 #pragma unroll
-  for (int k = 0; k < NSP; k++) selfp[k] = (m->self_collision && k * 64 + lane < rm.n_self_pairs) ? (int)rm.self_pair[k * 64 + lane] : -1;
+  for (int k = 0; k < NSP; k++) selfp[k] = (m->self_collision && k * LW + lane < rm.n_self_pairs) ? (int)rm.self_pair[k * LW + lane] : -1;
   TSTAMP(0);
   // ---- coalesced state load (first substep of a launch only; afterwards the state stays in LDS) -----------------
   if (flags & PS_LOAD_STATE) {
-    for (int i = lane; i < (A + P) * 13; i += 64) lds[L.root + i] = g_root[i];
-    for (int i = lane; i < shp.ND * 2; i += 64) lds[L.dof + i] = g_dof[i];
+    for (int i = lane; i < (A + P) * 13; i += LW) lds[L.root + i] = g_root[i];
+    for (int i = lane; i < shp.ND * 2; i += LW) lds[L.dof + i] = g_dof[i];
   }
   if (flags & PS_LOAD_TAU)
-    for (int i = lane; i < 12 * A; i += 64) lds[L.tau + i] = st.torques[(size_t)e * 12 * A + i];
+    for (int i = lane; i < 12 * A; i += LW) lds[L.tau + i] = st.torques[(size_t)e * 12 * A + i];
   __syncthreads();
 
   TSTAMP(1);
@@ -436,7 +470,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     // lane, in the joint-force-column area that is written further down): 20 LDS instructions instead of 64 ds_bpermute
     float* hx = lds + L.fcol;
     if (depth == 1) {
-      float4* w = reinterpret_cast<float4*>(hx + (br * 4 + (bb - 1) / 3) * 16);
+      float4* w = reinterpret_cast<float4*>(hx + (br * 4 + (bb - 1) / 3) * FCOL_STRIDE);
 #pragma unroll
       for (int k = 0; k < 4; k++) w[k] = make_float4(X[4 * k], X[4 * k + 1], X[4 * k + 2], X[4 * k + 3]);
     }
@@ -444,8 +478,8 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     if (is_rbody && bb == 0) {
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        const float4* rd = reinterpret_cast<const float4*>(hx + br * 64) + k;
-        const float4 h0 = rd[0], h1 = rd[4], h2 = rd[8], h3 = rd[12];
+        const float4* rd = reinterpret_cast<const float4*>(hx + br * 4 * FCOL_STRIDE) + k;
+        const float4 h0 = rd[0], h1 = rd[FCOL_STRIDE / 4], h2 = rd[2 * (FCOL_STRIDE / 4)], h3 = rd[3 * (FCOL_STRIDE / 4)];
         X[4 * k] += h0.x + h1.x + h2.x + h3.x; X[4 * k + 1] += h0.y + h1.y + h2.y + h3.y;
         X[4 * k + 2] += h0.z + h1.z + h2.z + h3.z; X[4 * k + 3] += h0.w + h1.w + h2.w + h3.w;
       }
@@ -528,7 +562,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   TSTAMP(4);
   // ---- Schur complement S = M_bb - sum_legs C, one lane per entry of the upper triangle (the six lanes that factor it below would
   // otherwise each subtract all four C matrices) -----------------------------------------------------------------------------------
-  for (int t = lane; t < A * 21; t += 64) {
+  for (int t = lane; t < A * 21; t += LW) {
     const int r = t / 21, q = t - r * 21;
     float* sb = lds + L.basei + r * 24 + q;
     const float* cq = lds + L.legc + r * 4 * LEGC_STRIDE + q;
@@ -646,7 +680,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   }
   __syncthreads();
   TSTAMP(6);
-  // ---- unconstrained velocity v* = v + dt M^-1 (tau - h) per generalized velocity; a lane owns dofs lane and lane + 64
+  // ---- unconstrained velocity v* = v + dt M^-1 (tau - h) per generalized velocity; a lane owns dofs lane and lane + LW
   // (4 robots + ball = 78).  Kept in registers until the bias vector it overwrites has been consumed by every lane.
   auto vstar = [&](int d) -> float {
     if (d < A * MQE_RD) {
@@ -669,12 +703,12 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     return v;
   };
   const float vs0 = lane < ndof ? vstar(lane) : 0.0f;
-  const float vs1 = lane + 64 < ndof ? vstar(lane + 64) : 0.0f;
+  const float vs1 = lane + LW < ndof ? vstar(lane + LW) : 0.0f;
 
   TSTAMP(7);
   // ---- collision spheres ----------------------------------------------------------------------------------------------
   const int nsr = rm.n_spheres;
-  for (int s = lane; s < nsph; s += 64) {
+  for (int s = lane; s < nsph; s += LW) {
     V3 c; float rad;
     if (s < A * nsr) {
       const int r = s / nsr, si = s - r * nsr;
@@ -696,22 +730,23 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   // bounding radius, capsule half-segment and radius (a sphere is a capsule with a zero segment; a box keeps its link's rotation
   // and is marked by a negative radius)
   const int npr = rm.n_prims;
-  for (int t = lane; t < A * npr; t += 64) {
+  for (int t = lane; t < A * npr; t += LW) {
     const int r = t / npr, q = t - r * npr;
     const float* rec = lds + L.body + (r * MQE_NBODY + rm.prim_body[q]) * BODY_STRIDE;
     const float4 q0 = reinterpret_cast<const float4*>(rec)[0], q1 = reinterpret_cast<const float4*>(rec)[1], q2 = reinterpret_cast<const float4*>(rec)[2];
     const float Rr[9] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x};
     const V3 c = v3(q2.y, q2.z, q2.w) + mat_vec(Rr, v3(rm.prim_center[q][0], rm.prim_center[q][1], rm.prim_center[q][2]));
     const V3 u = mat_vec(Rr, v3(rm.prim_axis[q][0], rm.prim_axis[q][1], rm.prim_axis[q][2]));
-    float4* pw = reinterpret_cast<float4*>(lds + L.prim + t * 8);
-    pw[0] = make_float4(c.x, c.y, c.z, rm.prim_bound[q]);
+    float4* pw0 = reinterpret_cast<float4*>(lds + L.prim) + t;
+    float4* pw1 = pw0 + m->nprim_env;
+    pw0[0] = make_float4(c.x, c.y, c.z, rm.prim_bound[q]);
     // radius; a box carries MINUS the radius of its bounding capsule about its longest edge (the sign marks it; screens use |.|)
     float rad = rm.prim_half[q][0];
     if (rm.prim_type[q] == MQE_PRIM_BOX) {
       const V3 hb = v3(rm.prim_half[q][0], rm.prim_half[q][1], rm.prim_half[q][2]), al = v3(rm.prim_axis[q][0], rm.prim_axis[q][1], rm.prim_axis[q][2]);
       rad = -sqrtf(fmaxf(dot(hb, hb) - dot(al, al), 1e-12f));
     }
-    pw[1] = make_float4(u.x, u.y, u.z, rad);
+    pw1[0] = make_float4(u.x, u.y, u.z, rad);
   }
   __syncthreads();
 
@@ -736,10 +771,10 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   // Passes over whole actors, lane = sphere: two robots per pass (2 x 27 spheres), all single-sphere NPCs in one pass
   // (multi-sphere NPCs: one per pass).  The list order stays canonical -- actor by actor, sphere by sphere, ground /
   // wall / platform / column -- because a lane's slot = contacts of earlier groups (capped) + its rank in its group.
-  const int rpp = (2 * nsr <= 64) ? 2 : 1;
+  const int rpp = (2 * nsr <= LW) ? 2 : 1;
   const int n_rpass = (A + rpp - 1) / rpp;
   const int nsn = m->npc_n_spheres;
-  const bool npc_one = PD * nsn <= 64;                     // every sphere of every free NPC in ONE pass, lane = (npc, sphere): 9 sheep x 2
+  const bool npc_one = PD * nsn <= LW;                     // every sphere of every free NPC in ONE pass, lane = (npc, sphere): 9 sheep x 2
   const int n_pass = n_rpass + (PD > 0 ? (npc_one ? 1 : PD) : 0);
   const unsigned long long mns = (nsn < 64) ? ((1ull << nsn) - 1ull) : ~0ull;
   for (int pass = 0; pass < n_pass; pass++) {
@@ -830,7 +865,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
         if (c.z < ssB.z && c.z > ssB.z - m->ss_col_length && rho > 1e-6f) { csd = rho - m->ss_col_radius - rad; cn3 = v3(dx / rho, dy / rho, 0); cflag = csd < m->contact_offset; }
       }
     }
-    const unsigned long long bg = __ballot(gflag), bw2 = __ballot(wflag), bb2 = __ballot(bflag), bc2 = __ballot(cflag);
+    const unsigned long long bg = gballot(gflag), bw2 = gballot(wflag), bb2 = gballot(bflag), bc2 = gballot(cflag);
     const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const unsigned long long gl = gm & lower;
     const int pre = __popcll(bg & gl) + __popcll(bw2 & gl) + __popcll(bb2 & gl) + __popcll(bc2 & gl);   // rank in my actor
@@ -900,7 +935,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
                             : sphere_box(c, rad, ssC, ssR, v3(m->ss_plank_half[0], m->ss_plank_half[1], m->ss_plank_half[2]), n);
         hit = sd < m->contact_offset;
       }
-      const unsigned long long bh = __ballot(hit);
+      const unsigned long long bh = gballot(hit);
       const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
       const int rk = __popcll(bh & lower), slot = nc + rk;
       if (hit && rk < capP && slot < pair_lim) {
@@ -922,7 +957,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     unsigned long long near0 = 0ull, near1 = 0ull;
     {
       const int npa = (nact * (nact - 1)) / 2;
-      for (int t0 = 0; t0 < npa; t0 += 64) {
+      for (int t0 = 0; t0 < npa; t0 += LW) {
         const int t = t0 + lane;
         bool nr = false;
         if (t < npa) {
@@ -935,7 +970,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
           if (shp.has_box && b >= A) nr = a < A && !(dot(dd, dd) > 1.8f * 1.8f);
           else nr = !(dot(dd, dd) > 1.2f * 1.2f);
         }
-        const unsigned long long bm = __ballot(nr);
+        const unsigned long long bm = gballot(nr);
         if (t0 == 0) near0 = bm; else near1 = bm;
       }
     }
@@ -948,7 +983,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     for (int a = 0; a < a_end; a++)
       for (int b = a + 1; b < nact; b++) {
         tp++;
-        if (!(((tp < 64 ? near0 >> tp : near1 >> (tp - 64)) & 1ull))) continue;          // wave-uniform
+        if (!(((tp < LW ? near0 >> tp : near1 >> (tp - LW)) & 1ull))) continue;          // uniform within the group
         const V3 pb = ld3(lds + L.body + (b < A ? b * MQE_NBODY : A * MQE_NBODY + (b - A)) * BODY_STRIDE + B_P);
         if (shp.has_box && b >= A) {                           // robot spheres vs the oriented box (NPC body record = its pose)
           const float* brec = lds + L.body + (A * MQE_NBODY + (b - A)) * BODY_STRIDE;
@@ -959,7 +994,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
             sd = sphere_box(c, ra, pb, brec + B_R, v3(m->npc_box_half[0], m->npc_box_half[1], m->npc_box_half[2]), n);
             hit = sd < m->contact_offset;
           }
-          const unsigned long long bh = __ballot(hit);
+          const unsigned long long bh = gballot(hit);
           const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
           const int slot = nc + __popcll(bh & lower);
           if (hit && slot < pair_lim) {
@@ -989,27 +1024,27 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
             {
               const V3 pbase = ld3(lds + L.body + fa * MQE_NBODY * BODY_STRIDE + B_P);
               const V3 db = c - pbase;
-              const float rfeat = wave_max_nonneg(lane < nsr ? sqrtf(dot(db, db)) + ra : 0.0f);
+              const float rfeat = wave_max_nonneg<EPW == 2>(lane < nsr ? sqrtf(dot(db, db)) + ra : 0.0f);
               bool act = false;
               if (lane < npr) {
-                const float4 w0 = *reinterpret_cast<const float4*>(lds + L.prim + (qa * npr + lane) * 8);
+                const float4 w0 = reinterpret_cast<const float4*>(lds + L.prim)[qa * npr + lane];
                 const V3 df = v3(w0.x, w0.y, w0.z) - pbase;
                 const float reach = w0.w + rfeat + m->contact_offset;
                 act = dot(df, df) < reach * reach;
               }
-              qmask = __ballot(act);
+              qmask = gballot(act);
             }
             while (qmask != 0ull) {
               const int q = __ffsll((long long)qmask) - 1;
               qmask &= qmask - 1ull;
-              const float4* pw = reinterpret_cast<const float4*>(lds + L.prim + (qa * npr + q) * 8);
-              const float4 w0 = pw[0], w1 = pw[1];
+              const float4* pw = reinterpret_cast<const float4*>(lds + L.prim) + (qa * npr + q);
+              const float4 w0 = pw[0], w1 = pw[m->nprim_env];
               const V3 cq = v3(w0.x, w0.y, w0.z);
               const bool qbox = w1.w < 0.0f, qsph = !qbox && w1.x == 0.0f && w1.y == 0.0f && w1.z == 0.0f;      // wave-uniform
               const V3 dq = c - cq;
               const float reach = ra + w0.w + m->contact_offset;
               bool cand = lane < nsr && dot(dq, dq) < reach * reach && !(dir == 1 && foot && qsph);
-              if (__ballot(cand) == 0ull) continue;
+              if (gballot(cand) == 0ull) continue;
               bool hit = false; float sd = 0; V3 n = v3(0, 0, 1);
               if (cand) {
                 if (qbox) {
@@ -1021,7 +1056,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
                   hit = ok && sd < m->contact_offset;
                 }
               }
-              const unsigned long long bh = __ballot(hit);
+              const unsigned long long bh = gballot(hit);
               if (bh == 0ull) continue;
               const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
               const int slot = nc + __popcll(bh & lower);
@@ -1042,8 +1077,8 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
           const int nb = m->npc_n_spheres, ob = A * nsr + (b - A) * m->npc_n_spheres;
           float4 w0 = make_float4(0, 0, 0, 0), w1 = w0; int ptype = MQE_PRIM_SPHERE, pbody = 0, prep = 0; V3 ph = v3(0, 0, 0);
           if (lane < npr) {
-            const float4* pw = reinterpret_cast<const float4*>(lds + L.prim + (a * npr + lane) * 8);
-            w0 = pw[0]; w1 = pw[1];
+            const float4* pw = reinterpret_cast<const float4*>(lds + L.prim) + (a * npr + lane);
+            w0 = pw[0]; w1 = pw[m->nprim_env];
             ptype = w1.w < 0.0f ? MQE_PRIM_BOX : MQE_PRIM_CAPSULE; pbody = rm.prim_body[lane]; prep = rm.prim_reported[lane];
             ph = v3(rm.prim_half[lane][0], rm.prim_half[lane][1], rm.prim_half[lane][2]);
           }
@@ -1061,7 +1096,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
                 hit = ok && sd < m->contact_offset;
               }
             }
-            const unsigned long long bh = __ballot(hit);
+            const unsigned long long bh = gballot(hit);
             if (bh == 0ull) continue;
             const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
             const int slot = nc + __popcll(bh & lower);
@@ -1089,7 +1124,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
             sd = dist - ra - rb;
             hit = sd < m->contact_offset && dist > 1e-9f;
           }
-          const unsigned long long bh = __ballot(hit);
+          const unsigned long long bh = gballot(hit);
           if (bh == 0ull) continue;
           const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
           const int slot = nc + __popcll(bh & lower);
@@ -1105,7 +1140,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     if (npc_pass) {
       const int ns = m->npc_n_spheres, ns2 = ns * ns;
       const int np2 = ((PD * (PD - 1)) / 2) * ns2;
-      for (int t0 = 0; t0 < np2; t0 += 64) {
+      for (int t0 = 0; t0 < np2; t0 += LW) {
         const int t = t0 + lane;
         bool hit = false; float sd = 0, dist = 1, rb = 0; V3 ev = v3(0, 0, 0), cb = v3(0, 0, 0); int i = 0, j = 0;
         if (t < np2) {
@@ -1121,7 +1156,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
           sd = dist - qa.w - rb;
           hit = sd < m->contact_offset && dist > 1e-9f;
         }
-        const unsigned long long bh = __ballot(hit);
+        const unsigned long long bh = gballot(hit);
         if (bh == 0ull) continue;
         const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
         const int slot = nc + __popcll(bh & lower);
@@ -1145,15 +1180,15 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
         // capsule's segment itself (a box: its bounding capsule); robots rarely touch themselves and the compaction below normally
         // does not run at all
         const float* sp0 = lds + L.sph + a * nsr * 4;
-        const float* pp0 = lds + L.prim + a * npr * 8;
+        const float4* pp0 = reinterpret_cast<const float4*>(lds + L.prim) + a * npr;       // [q]: centre, bound; [nprim_env + q]: half-segment, radius
         float4 si4[NSP], sj4[NSP];
         int any = 0;
 #pragma unroll
         for (int k = 0; k < NSP; k++) {                          // beyond the list: feature 0 against primitive 0, masked below
           const int pr = selfp[k] < 0 ? 0 : selfp[k];
           si4[k] = *reinterpret_cast<const float4*>(sp0 + (pr & 255) * 4);
-          sj4[k] = *reinterpret_cast<const float4*>(pp0 + (pr >> 8) * 8);
-          const float4 uj = *reinterpret_cast<const float4*>(pp0 + (pr >> 8) * 8 + 4);
+          sj4[k] = pp0[pr >> 8];
+          const float4 uj = pp0[m->nprim_env + (pr >> 8)];
           const V3 u = v3(uj.x, uj.y, uj.z), dq = v3(si4[k].x - sj4[k].x, si4[k].y - sj4[k].y, si4[k].z - sj4[k].z);
           const float uu = dot(u, u);
           const float t = uu > 0.0f ? fminf(fmaxf(dot(dq, u) * __builtin_amdgcn_rcpf(uu), -1.0f), 1.0f) : 0.0f;
@@ -1161,16 +1196,16 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
           const float lim = si4[k].w + fabsf(uj.w) + m->contact_offset + 1e-5f;                                       // (+ the screen's own rounding)
           any |= (int)(selfp[k] >= 0) & (int)(dot(e, e) < lim * lim);
         }
-        if (__ballot(any != 0) == 0ull) continue;
+        if (gballot(any != 0) == 0ull) continue;
 #pragma unroll
         for (int k = 0; k < NSP; k++) {
-          if (k * 64 >= npairs) continue;
+          if (k * LW >= npairs) continue;
           bool hit = false; float sd = 0; V3 n = v3(0, 0, 1), c = v3(0, 0, 0); float ra = 0; int f = 0, q = 0;
           if (selfp[k] >= 0) {
             f = selfp[k] & 255; q = selfp[k] >> 8;
             c = v3(si4[k].x, si4[k].y, si4[k].z); ra = si4[k].w;
             const V3 cq = v3(sj4[k].x, sj4[k].y, sj4[k].z);
-            const float4 w1 = *reinterpret_cast<const float4*>(pp0 + q * 8 + 4);
+            const float4 w1 = pp0[m->nprim_env + q];
             if (w1.w < 0.0f) {
               sd = sphere_box(c, ra, cq, lds + L.body + (a * MQE_NBODY + rm.prim_body[q]) * BODY_STRIDE + B_R,
                               v3(rm.prim_half[q][0], rm.prim_half[q][1], rm.prim_half[q][2]), n);
@@ -1180,7 +1215,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
               hit = ok && sd < m->contact_offset;
             }
           }
-          const unsigned long long bh = __ballot(hit);
+          const unsigned long long bh = gballot(hit);
           if (bh == 0ull) continue;
           const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
           const int slot = nc + __popcll(bh & lower);
@@ -1206,7 +1241,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   const float mu_robot = 0.5f * (mu_env + m->friction);
   float* Vm = lds + L.rhs;           // v* (unconstrained velocity) over the consumed bias vector, read through the sparse Jacobian rows
   if (lane < ndof) Vm[lane] = vs0;
-  if (lane + 64 < ndof) Vm[lane + 64] = vs1;
+  if (lane + LW < ndof) Vm[lane + LW] = vs1;
   __syncthreads();
   const bool is_con = lane < nc;
   float us0 = 0, us1 = 0, us2 = 0, cl0 = 0, cl1 = 0, cl2 = 0, cbias = 0;      // relative velocity of the unconstrained motion, impulse, bias
@@ -1218,14 +1253,14 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   float fA[27];                                                             // Phi of my contact's side A (U 18, Z' 9): registers for the whole sweep
 #pragma unroll
   for (int i = 0; i < 27; i++) fA[i] = 0.0f;
-  for (int i = lane; i < ((ndof + 3) & ~3); i += 64) accv[i] = 0.0f;          // w = sum_c Phi_c^T lambda_c starts at zero (no warm start)
+  for (int i = lane; i < ((ndof + 3) & ~3); i += LW) accv[i] = 0.0f;          // w = sum_c Phi_c^T lambda_c starts at zero (no warm start)
   if (shp.rowgs) {
     // ---- side records for the row sweep: lane = (contact, direction).  The three rows of a contact (normal, two tangents) are
     // independent of each other up to the contact's own 3 x 3 block, so four lanes share a contact (lane & 3 = row, the fourth
     // idles), each builds ONE row of Phi per side, and the block's couplings come from the neighbour's row through a quad
     // permutation: a third of the instructions of the one-lane-per-contact form below.  Rows of side A wait in registers until
     // every lane has read the link records (the records go on top of them); side B has its own area.
-    constexpr int NPQ = 2;                       // passes of 16 contacts: scenes of <= 4 actors keep <= 32 contacts
+    constexpr int NPQ = 2;                       // passes of LW / 4 contacts: scenes of <= 4 actors keep <= 32 contacts, two robots alone <= 16
     const int q = lane & 3;
     float rowA[NPQ][9], usq[NPQ], dqq[NPQ], dqn[NPQ], cbq[NPQ], muq[NPQ];
     int infq[NPQ];
@@ -1234,8 +1269,8 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       usq[ps] = 0.0f; dqq[ps] = 0.0f; dqn[ps] = 0.0f; cbq[ps] = 0.0f; muq[ps] = m->friction; infq[ps] = 0;
 #pragma unroll
       for (int i = 0; i < 9; i++) rowA[ps][i] = 0.0f;
-      const int c = ps * 16 + (lane >> 2);
-      if (ps * 16 < nc && c < nc) {
+      const int c = ps * (LW / 4) + (lane >> 2);
+      if (ps * (LW / 4) < nc && c < nc) {
         const float* cr = lds + L.con + c * CON_STRIDE;
         const float4 w0 = reinterpret_cast<const float4*>(cr)[0], w1 = reinterpret_cast<const float4*>(cr)[1], w2 = reinterpret_cast<const float4*>(cr)[2];
         const int cA = __float_as_int(w0.x), cB = __float_as_int(w0.z);
@@ -1359,8 +1394,8 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     __syncthreads();                             // the link records are dead from here: side A and the solve records go on top of them
 #pragma unroll
     for (int ps = 0; ps < NPQ; ps++) {
-      const int c = ps * 16 + (lane >> 2);
-      if (ps * 16 < nc && c < nc) {
+      const int c = ps * (LW / 4) + (lane >> 2);
+      if (ps * (LW / 4) < nc && c < nc) {
         float* rec = lds + L.phi + c * SIDE_STRIDE;
         float* sr = lds + L.srec + c * SREC_STRIDE;
         if (q < 3) {
@@ -1565,12 +1600,12 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     int gstart = 0, glen = 0, maxlen = 0;                    // the one-sided contacts of my row's actor: first list index, count
     const int nact = A + PD + (SS ? 1 : 0);
     for (int a = 0; a < nact; a++) {
-      const unsigned long long bm = __ballot(is_terr && myA == a);
+      const unsigned long long bm = gballot(is_terr && myA == a);
       const int len = __popcll(bm), start = bm ? __ffsll((long long)bm) - 1 : 0;
       maxlen = len > maxlen ? len : maxlen;
       if (row == a) { gstart = start; glen = len; }
     }
-    const int npair = __popcll(__ballot(is_pair));
+    const int npair = __popcll(gballot(is_pair));
     const int pair0 = nc - npair;
     // where lane k finds its column in a side record: U[q][k] at q * 6 + k, Z'[q][k - 6] at 18 + q * 3 + (k - 6)
     const int koff = k < 6 ? k : (k < 9 ? SIDE_Z + (k - 6) : 0), kstr = k < 6 ? 6 : 3;
@@ -1610,8 +1645,10 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       e2 = l2 - q3.z;
       if (writer) reinterpret_cast<float4*>(sr)[3] = make_float4(ln, l1, l2, 0.0f);
     };
+    // (barriers inside: with two envs per wavefront the trip counts are the larger of the two envs'; a row without work idles)
+    const int maxlen_w = wave_max_of_groups(maxlen), npair_w = wave_max_of_groups(npair);
     for (int it = 0; it < m->solver_iterations; it++) {
-      for (int sidx = 0; sidx < maxlen; sidx++) {
+      for (int sidx = 0; sidx < maxlen_w; sidx++) {
         if (row < nact && sidx < glen) {                     // the s-th one-sided contact of every actor, each in its own row
           const int c = gstart + sidx;
           const RowStep r = row_products(lds + L.phi + c * SIDE_STRIDE);
@@ -1621,11 +1658,12 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
         }
         __syncthreads();
       }
-      for (int c = pair0; c < nc; c++) {                     // two-actor contacts one by one: row 0 = side A, row 1 = side B
+      for (int ip = 0; ip < npair_w; ip++) {                 // two-actor contacts one by one: row 0 = side A, row 1 = side B
+        const int c = pair0 + ip;
         float e0 = 0.0f, e1 = 0.0f, e2 = 0.0f, fb0 = 0.0f, fb1 = 0.0f, fb2 = 0.0f;
         int widxB = 0;
         bool onB = false;
-        if (row < 2) {
+        if (row < 2 && c < nc) {
           const RowStep r = row_products(row == 0 ? lds + L.phi + c * SIDE_STRIDE : lds + L.side + (c - nc_terr) * SIDE_STRIDE);
           const float s0 = r.s0 + row_partner(r.s0), s1 = r.s1 + row_partner(r.s1), s2 = r.s2 + row_partner(r.s2);
           row_solve(lds + L.srec + c * SREC_STRIDE, s0, s1, s2, lane == 0, e0, e1, e2);     // both rows solve the same numbers; one lane records lambda
@@ -1644,12 +1682,12 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       int gstartA = 0, glenA = 0, maxlen = 0;
       const int nact = A + PD + (SS ? 1 : 0);
       for (int a = 0; a < nact; a++) {
-        const unsigned long long bm = __ballot(is_terr && myA == a);
+        const unsigned long long bm = gballot(is_terr && myA == a);
         const int len = __popcll(bm), start = bm ? __ffsll((long long)bm) - 1 : 0;
         maxlen = len > maxlen ? len : maxlen;
         if (is_terr && myA == a) { gstartA = start; glenA = len; }
       }
-      const int npair = __popcll(__ballot(is_pair));
+      const int npair = __popcll(gballot(is_pair));
       const int pair0 = nc - npair;
       const int ncolA = (infoA >> 4) & 15, legA = (infoA & 15) - 1;
       float* wbA = accv + wA;
@@ -1731,7 +1769,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     cr[C_F] = f.x; cr[C_F + 1] = f.y; cr[C_F + 2] = f.z;
   }
   // impulses -> velocities: dv = T w.  Base: F w_b; leg: Lm w_l - G^T (F w_b); free body / 1-dof link: M^-1/2 w
-  for (int d = lane; d < ndof; d += 64) {
+  for (int d = lane; d < ndof; d += LW) {
     float dv;
     if (d < A * MQE_RD) {
       const int r = d / MQE_RD, k = d - r * MQE_RD;
@@ -1780,7 +1818,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     // something still violates (at most MQE_LIMIT_PASSES times; normally none or one runs), then the bound is enforced exactly
     for (int pass = 0; pass <= MQE_LIMIT_PASSES; pass++) {
       bool viol = false;
-      for (int d = lane; d < A * 12; d += 64) {
+      for (int d = lane; d < A * 12; d += LW) {
         const int r = d / 12, j = d - r * 12;
         const float q = lds[L.dof + d * 2], v = Vm[r * MQE_RD + 6 + j];
         float lo, hi;
@@ -1788,7 +1826,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
         viol = viol || v < lo || v > hi;
         if (pass == MQE_LIMIT_PASSES) Vm[r * MQE_RD + 6 + j] = fminf(fmaxf(v, lo), hi);     // residual of the last pass (~1e-3 of the violation)
       }
-      if (__ballot(viol) == 0ull || pass == MQE_LIMIT_PASSES) break;
+      if (__ballot(viol) == 0ull || pass == MQE_LIMIT_PASSES) break;       // wave-wide: the passes below hold barriers
       for (int r = 0; r < A; r++)
         for (int j = 0; j < 12; j++) {
           const float q = lds[L.dof + (r * 12 + j) * 2], vj = Vm[r * MQE_RD + 6 + j];
@@ -1796,10 +1834,13 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
           jbound(j, q, lo, hi);
           float vio = 0.0f;
           if (vj < lo) vio = lo - vj; else if (vj > hi) vio = hi - vj;
-          if (vio != 0.0f) {                          // wave-uniform: impulse along e_j, dv = M^-1 e_j lambda, (M^-1)_jj lambda = vio
-            const float lam = vio / minv_elem(r, 6 + j, 6 + j);
+          // uniform within the env's lanes: impulse along e_j, dv = M^-1 e_j lambda, (M^-1)_jj lambda = vio.  The barriers need the
+          // whole wavefront: with two envs per wavefront both halves go through when either has a violation
+          const bool mine = vio != 0.0f;
+          if (EPW == 1 ? mine : (__ballot(mine) != 0ull)) {
+            const float lam = mine ? vio / minv_elem(r, 6 + j, 6 + j) : 0.0f;
             __syncthreads();
-            if (lane < MQE_RD) Vm[r * MQE_RD + lane] += minv_elem(r, 6 + j, lane) * lam;
+            if (mine && lane < MQE_RD) Vm[r * MQE_RD + lane] += minv_elem(r, 6 + j, lane) * lam;
             __syncthreads();
           }
         }
@@ -1814,9 +1855,9 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   }
   TSTAMP(14);
   if (dbg.minv != nullptr) {
-    for (int i = lane; i < MQE_RD * MQE_RD; i += 64) dbg.minv[i] = minv_elem(dbg.robot, i / MQE_RD, i % MQE_RD);   // assembled from the factors
+    for (int i = lane; i < MQE_RD * MQE_RD; i += LW) dbg.minv[i] = minv_elem(dbg.robot, i / MQE_RD, i % MQE_RD);   // assembled from the factors
     if (lane == 0) *dbg.nc = nc;
-    for (int c = lane; c < nc; c += 64) {
+    for (int c = lane; c < nc; c += LW) {
       const float* cr = lds + L.con + c * CON_STRIDE;
       float* o8 = dbg.contacts + c * 8;
       o8[0] = (float)__float_as_int(cr[C_IDS]); o8[1] = (float)__float_as_int(cr[C_IDS + 1]);
@@ -1825,12 +1866,12 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     }
   }
   if (no_write) return;
-  if (ovf && lane == 0) st.overflow[e] += 1;          // MQE_T_CONTACT_OVERFLOW: this substep's list was truncated
+  if (ovf && lane == 0 && evalid) st.overflow[e] += 1;          // MQE_T_CONTACT_OVERFLOW: this substep's list was truncated
 
   // ---- net contact force per reported body (deterministic: contact order) ---------------------------------------------------
-  if (flags & PS_WRITE_CF) {
+  if ((flags & PS_WRITE_CF) && evalid) {
     float* g_cf = st.cf + (size_t)e * m->NBR * 3;
-    for (int rb = lane; rb < m->NBR; rb += 64) {
+    for (int rb = lane; rb < m->NBR; rb += LW) {
       V3 F = v3(0, 0, 0);
       for (int c = 0; c < nc; c++) {
         const float* cr = lds + L.con + c * CON_STRIDE;
@@ -1845,7 +1886,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   }
   // ---- integrate: semi-implicit Euler; quaternion first-order update + renormalisation -----------------------------------------
   __syncthreads();
-  for (int d = lane; d < A * 12; d += 64) {
+  for (int d = lane; d < A * 12; d += LW) {
     const int r = d / 12, j = d - r * 12;
     const float v = Vm[r * MQE_RD + 6 + j];
     float* ds = lds + L.dof + d * 2;
@@ -1877,9 +1918,9 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     }
   }
   __syncthreads();
-  if (flags & PS_STORE_STATE) {       // coalesced write-back
-    for (int i = lane; i < (A + P) * 13; i += 64) g_root[i] = lds[L.root + i];
-    for (int i = lane; i < shp.ND * 2; i += 64) g_dof[i] = lds[L.dof + i];
+  if ((flags & PS_STORE_STATE) && evalid) {       // coalesced write-back
+    for (int i = lane; i < (A + P) * 13; i += LW) g_root[i] = lds[L.root + i];
+    for (int i = lane; i < shp.ND * 2; i += LW) g_dof[i] = lds[L.dof + i];
   }
 }
 
@@ -1922,13 +1963,26 @@ template <int TP> struct SubstepsClass {
   static constexpr int launder = small ? 2 : 0;       // bit 0: the model pointer, bit 1: the lane id
 #endif
 };
-template <int TA, int TP>
-__global__ void __launch_bounds__(64, SubstepsClass<TP>::waves) k_substeps(const DevModel* __restrict__ m, DevState st, int nsub, int lag_pos) {
-  extern __shared__ float lds[];
-  const int lane = threadIdx.x, e = blockIdx.x;
+template <int TA, int TP, int EPW = 1>
+__global__ void __launch_bounds__(64, EPW == 2 ? 2 : SubstepsClass<TP>::waves) k_substeps(const DevModel* __restrict__ m, DevState st, int nsub, int lag_pos) {
+  extern __shared__ float lds_wave[];
+  // EPW = 2 (phys_substep): the two halves of the wavefront run envs 2 b and 2 b + 1; `lane` / `lds` / `e` below are the group's.
+  // 2048 wavefronts for 4096 envs = 2 per SIMD with the whole register file each: nothing is laundered, everything invariant
+  // over the substeps is hoisted.
+  constexpr int LW = 64 / EPW;
+#ifdef MQE_LAUNDER2
+  constexpr int launder = EPW == 2 ? MQE_LAUNDER2 : SubstepsClass<TP>::launder;
+#else
+  constexpr int launder = EPW == 2 ? 2 : SubstepsClass<TP>::launder;     // hoisting everything overflows even 256 VGPRs (43 spilled)
+#endif
+  const int lane_wave = threadIdx.x, e_first = blockIdx.x * EPW;
+  const int grp = EPW == 1 ? 0 : lane_wave / LW, lane = EPW == 1 ? lane_wave : lane_wave - grp * LW;
+  const bool evalid = EPW == 1 || e_first + grp < m->N;
+  const int e = evalid ? e_first + grp : m->N - 1;
   const PhysShape<TA, TP> shp(m);
   const int A = shp.A, P = shp.P;
-  const PhysLds L = phys_lds_layout(A, P, shp.ND, shp.nbody, shp.ndof, m->nsph_env, m->nprim_env, shp.maxc, shp.rowgs);
+  const PhysLds L = phys_lds_layout(A, P, shp.ND, shp.nbody, shp.ndof, m->nsph_env, m->nprim_env, shp.maxc, shp.rowgs, PhysPad<TP>::on);
+  float* lds = lds_wave + grp * L.total;
   const int nj = 12 * A;
   const int ctrl = m->control_type;
   const size_t R12 = (size_t)m->R * 12;
@@ -1936,14 +1990,14 @@ __global__ void __launch_bounds__(64, SubstepsClass<TP>::waves) k_substeps(const
   // waves per SIMD): the actuator history of each joint lives in LDS, the per-joint constants and the action are re-read (L1 / L2)
   // at the head of every substep.
   float* acth = lds + L.acth;                                    // [4][nj]: e1, e2, v1, v2
-  for (int i = lane; i < 4 * nj; i += 64) {
+  for (int i = lane; i < 4 * nj; i += LW) {
     const int w = i / nj, jt = i - w * nj;
     acth[i] = st.act_hist[(size_t)w * R12 + (size_t)e * nj + jt];
   }
   float* g_root = st.root + (size_t)e * (A + P) * 13;
   float* g_dof = st.dof + (size_t)e * shp.ND * 2;
-  for (int i = lane; i < (A + P) * 13; i += 64) lds[L.root + i] = g_root[i];
-  for (int i = lane; i < shp.ND * 2; i += 64) lds[L.dof + i] = g_dof[i];
+  for (int i = lane; i < (A + P) * 13; i += LW) lds[L.root + i] = g_root[i];
+  for (int i = lane; i < shp.ND * 2; i += LW) lds[L.dof + i] = g_dof[i];
   __syncthreads();
   const PhysDebug nodbg = {nullptr, nullptr, nullptr, 0, nullptr, -1};
 #pragma clang loop unroll(disable)
@@ -1961,15 +2015,16 @@ __global__ void __launch_bounds__(64, SubstepsClass<TP>::waves) k_substeps(const
     // wave-uniform, lives in SGPRs and stays hoisted (laundering the model pointer too, bit 0, costs 5-12 %).  That pays exactly when
     // the LDS footprint lets 16 waves sit on a CU (SubstepsClass::small): 4096 envs then run as one round instead of two.
     const DevModel* mk = m;
-    int lane_k = lane;
-    if (SubstepsClass<TP>::launder & 1) asm volatile("" : "+s"(mk));
-    if (SubstepsClass<TP>::launder & 2) {
+    int lane_k = lane_wave;
+    if (launder & 1) asm volatile("" : "+s"(mk));
+    if (launder & 2) {
       asm volatile("" : "+v"(lane_k));
       lane_k &= 63;                                  // gives the value range of threadIdx.x back to the optimiser
     }
+    const int glane_k = EPW == 1 ? lane_k : lane_k - (lane_k / LW) * LW;        // lane within the env's group
     const int j32 = lane_k & 31, h = lane_k >> 5;
     if (ctrl != MQE_CTRL_C) {          // P / V / T (legged_robot.py:384-390): a few FMAs per joint lane instead of the actuator network
-      for (int jt = lane_k; jt < nj; jt += 64) {
+      for (int jt = glane_k; jt < nj; jt += LW) {
         const size_t gi = (size_t)e * nj + jt;
         const int j = jt % 12;
         const float asc = st.actions[gi] * m->action_scale;          // no hip reduction (legged_robot.py:380)
@@ -1979,8 +2034,10 @@ __global__ void __launch_bounds__(64, SubstepsClass<TP>::waves) k_substeps(const
         else if (ctrl == MQE_CTRL_V) tau = m->kp * (asc - qd) - m->kd * (qd - st.last_dof_vel[gi]) / m->dt;
         tau = clampf(tau, -lim, lim);
         lds[L.tau + jt] = tau;
-        st.sub_tau[((size_t)e * 4 + (k < 4 ? k : 3)) * nj + jt] = tau;
-        if (last) st.torques[gi] = tau;
+        if (evalid) {
+          st.sub_tau[((size_t)e * 4 + (k < 4 ? k : 3)) * nj + jt] = tau;
+          if (last) st.torques[gi] = tau;
+        }
       }
     } else {                           // control type C: actuator network (one call site of the physics body below: it is
                                        // inlined, and two copies of its ~9 k instructions would not fit the instruction cache)
@@ -2003,20 +2060,29 @@ __global__ void __launch_bounds__(64, SubstepsClass<TP>::waves) k_substeps(const
         const int n = m->lag_steps + 1;
         pos = lag_pos + k; pos -= (pos / n) * n;
       }
+      // the network's columns are the joints of the WAVEFRONT: 12 A per env, the envs of the wavefront one after the other (EPW = 2:
+      // 48 joints in two tiles of 32); a column's lanes read and write the LDS state of the env the joint belongs to
+      const int njw = nj * EPW;
 #pragma unroll
       for (int t = 0; t < ACT_TILES; t++) {
-        if (t * 32 >= nj) break;                           // wave-uniform
-        const int jt = t * 32 + j32;
-        const bool ok = jt < nj;
-        const int jc = ok ? jt : 0, j = jc % 12;
-        const size_t gi = (size_t)e * nj + jc;
+        if (t * 32 >= njw) break;                          // wave-uniform
+        const int jw = t * 32 + j32;
+        const bool ok = jw < njw;
+        const int jwc = ok ? jw : 0;
+        const int ge = EPW == 1 ? 0 : jwc / nj;            // env of the wavefront this column belongs to
+        const int jt = jwc - ge * nj, jc = jt, j = jc % 12;
+        const bool ev = EPW == 1 || e_first + ge < m->N;
+        const int eg = ev ? e_first + ge : m->N - 1;
+        float* ldsg = lds_wave + ge * L.total;
+        float* acthg = ldsg + L.acth;
+        const size_t gi = (size_t)eg * nj + jc;
         float as = st.actions[gi] * m->action_scale;
         if (j % 3 == 0) as *= m->hip_scale_reduction;
         float tgt = as + m->default_dof_pos[j];
         if (m->lag_steps > 0 && ok) tgt = lag_target(m, st, gi, as, pos) + m->default_dof_pos[j];
         const float lim = m->torque_limits[j];
-        const float q = lds[L.dof + jc * 2], qd = lds[L.dof + jc * 2 + 1];
-        const float he1 = acth[jc], he2 = acth[nj + jc], hv1 = acth[2 * nj + jc], hv2 = acth[3 * nj + jc];
+        const float q = ldsg[L.dof + jc * 2], qd = ldsg[L.dof + jc * 2 + 1];
+        const float he1 = acthg[jc], he2 = acthg[nj + jc], hv1 = acthg[2 * nj + jc], hv2 = acthg[3 * nj + jc];
         const float err = q - tgt;
         f32x16_p acc1, acc2;
 #pragma unroll
@@ -2035,27 +2101,31 @@ __global__ void __launch_bounds__(64, SubstepsClass<TP>::waves) k_substeps(const
         tau = clampf(tau, -lim, lim);
         __syncthreads();                                   // every lane has read the history before it shifts
         if (ok && h == 0) {
-          acth[nj + jt] = he1; acth[jt] = err; acth[3 * nj + jt] = hv1; acth[2 * nj + jt] = qd;      // go1.py:347-350
-          lds[L.tau + jt] = tau;
-          st.sub_tau[((size_t)e * 4 + (k < 4 ? k : 3)) * nj + jt] = tau;          // post_decimation_step (legged_robot.py:113)
-          if (last) st.torques[gi] = tau;
+          acthg[nj + jt] = he1; acthg[jt] = err; acthg[3 * nj + jt] = hv1; acthg[2 * nj + jt] = qd;      // go1.py:347-350
+          ldsg[L.tau + jt] = tau;
+          if (ev) {
+            st.sub_tau[((size_t)eg * 4 + (k < 4 ? k : 3)) * nj + jt] = tau;          // post_decimation_step (legged_robot.py:113)
+            if (last) st.torques[gi] = tau;
+          }
         }
       }
     }
     __syncthreads();
-    phys_substep<TA, TP>(mk, st, lds, e, lane_k, last ? (PS_STORE_STATE | PS_WRITE_CF) : 0, 0, nodbg);
+    phys_substep<TA, TP, EPW>(mk, st, lds_wave, e_first, lane_k, last ? (PS_STORE_STATE | PS_WRITE_CF) : 0, 0, nodbg);
     // post_decimation_step (legged_robot.py:114-115): joint velocities and soft-limit flags after this substep, from the LDS state
-    for (int jt = lane_k; jt < nj; jt += 64) {
-      const float q = lds[L.dof + jt * 2], qd = lds[L.dof + jt * 2 + 1];
-      const int j = jt % 12;
-      const size_t o = ((size_t)e * 4 + (k < 4 ? k : 3)) * nj + jt;
-      st.sub_dof_vel[o] = qd;
-      st.sub_exceed[o] = (uint8_t)((q < m->soft_lo[j]) | (q > m->soft_hi[j]));
-    }
+    if (evalid)
+      for (int jt = glane_k; jt < nj; jt += LW) {
+        const float q = lds[L.dof + jt * 2], qd = lds[L.dof + jt * 2 + 1];
+        const int j = jt % 12;
+        const size_t o = ((size_t)e * 4 + (k < 4 ? k : 3)) * nj + jt;
+        st.sub_dof_vel[o] = qd;
+        st.sub_exceed[o] = (uint8_t)((q < m->soft_lo[j]) | (q > m->soft_hi[j]));
+      }
   }
   __syncthreads();
-  for (int i = lane; i < 4 * nj; i += 64) {
-    const int w = i / nj, jt = i - w * nj;
-    st.act_hist[(size_t)w * R12 + (size_t)e * nj + jt] = acth[i];
-  }
+  if (evalid)
+    for (int i = lane; i < 4 * nj; i += LW) {
+      const int w = i / nj, jt = i - w * nj;
+      st.act_hist[(size_t)w * R12 + (size_t)e * nj + jt] = acth[i];
+    }
 }

@@ -51,6 +51,8 @@ struct mqe_sim {
   int N, A, P, R, ND, NBR, Aw, D;
   int hist_pos = 0, n_post_steps = 0;
   void (*substeps_fn)(const DevModel*, DevState, int, int) = nullptr;    // the k_substeps specialisation of this scene
+  int substeps_epw = 1;               // envs per wavefront of that kernel (2: two-robot scenes without objects at large batches)
+  bool a2_scene = false;              // two robots, no objects: the scene k_simulate_a2 (phase taps) is compiled for
   int lag_pos = 0;                    // write slot of the action-lag ring (domain randomisation), advances per substep
   // policy network (fused first layer: [adaptation L0 | body L0 history part])
   GemmLayer l0;                       // K = 30*72 (ring), N = ada_h0 + body_h0
@@ -287,14 +289,33 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   if (m.ndof_env > 128 || m.nbody_env > 64) { return fail(-4, "env has more than 64 bodies or 128 generalized velocities: does not fit one wavefront"); }
   m.rowgs = (A + m.n_npc_dyn + (seesaw ? 1 : 0) <= 4) ? 1 : 0;      // one 16-lane row per actor; the <A,0> / <2,LINK> kernels assume it
   if (getenv("MQE_LANE_SWEEP")) m.rowgs = 0;      // tests: the other lane mapping of the contact sweep on the same scene (tests/test_gpu_parity.py)
-  PhysLds L = phys_lds_layout(A, P, s->ND, m.nbody_env, m.ndof_env, m.nsph_env, m.nprim_env, m.maxc, m.rowgs);
+  // padded link / contact records (kernels_physics.hpp: PhysPad): the robot-only kernels k_substeps<A, 0>, which the scene gets iff ...
+  const int pad = (m.rowgs && m.P == 0 && !m.has_seesaw && m.n_npc_dyn == 0 && !m.has_box && m.n_static == 0 && (A == 1 || A == 2)) ? 1 : 0;
+  PhysLds L = phys_lds_layout(A, P, s->ND, m.nbody_env, m.ndof_env, m.nsph_env, m.nprim_env, m.maxc, m.rowgs, pad);
   s->phys_lds_bytes = (size_t)L.total * 4;
   if (getenv("MQE_VERBOSE")) fprintf(stderr, "mqe: physics LDS %zu B per env (wavefront)\n", s->phys_lds_bytes);
   if (const char* pad = getenv("MQE_PHYS_LDS_PAD")) s->phys_lds_bytes += (size_t)atoi(pad);   // experiments: caps the physics kernel's waves per CU
   // the records the physics kernel moves as 16 B words must start on 16 B (kernels_physics.hpp)
-  if ((L.body | L.sph | L.prim | L.con | L.side | L.leg | L.legc | L.basei | L.sinv | L.fcol | L.acc | L.rhs | L.phi | L.srec) & 3) { return fail(-4, "physics LDS layout: a 16 B record area is misaligned"); }
+  if ((L.total | L.body | L.sph | L.prim | L.con | L.side | L.leg | L.legc | L.basei | L.sinv | L.fcol | L.acc | L.rhs | L.phi | L.srec) & 3) { return fail(-4, "physics LDS layout: a 16 B record area is misaligned"); }
   if (s->phys_lds_bytes > 160 * 1024) { return fail(-4, "physics LDS footprint exceeds 160 KiB"); }
   s->substeps_fn = pick_substeps(m, s->phys_lds_bytes);
+  s->a2_scene = s->substeps_fn == (void (*)(const DevModel*, DevState, int, int))k_substeps<2, 0>;
+  {
+    // Two envs per wavefront (kernels_physics.hpp, EPW): for robot-only scenes of <= 2 robots each half-wave runs an env of its own --
+    // 44 % fewer VALU instructions per env (the dynamics and sweep phases are shared, only contact generation runs per env), but half
+    // as many wavefronts, each with twice the LDS traffic per instruction.  It does NOT pay: the kernel is bound by the dependency
+    // chain of a wavefront through the LDS (a lone one-env wavefront takes 82 us for its 58 k cycles of issue; LDS 60 % busy per
+    // CU), and the two-env wavefront's chain is 1.5 x as long -- 2 of them per SIMD take what 4 one-env wavefronts take.  Kept as
+    // a selectable, bit-identical variant (MQE_ENVS_PER_WAVE=2; tests hold the two forms against each other), not the default.
+    const bool can = (s->substeps_fn == (void (*)(const DevModel*, DevState, int, int))k_substeps<2, 0> ||
+                      s->substeps_fn == (void (*)(const DevModel*, DevState, int, int))k_substeps<1, 0>) && 2 * s->phys_lds_bytes <= 64 * 1024;
+    int want = 1;      // measured (MI355X, go1gate, k_substeps us, EPW 1 / 2): 4096 envs 122 / 128, 8192 envs 238 / 237 -- see below
+    if (const char* ev = getenv("MQE_ENVS_PER_WAVE")) want = atoi(ev);
+    if (can && want == 2) {
+      s->substeps_fn = m.A == 2 ? (void (*)(const DevModel*, DevState, int, int))k_substeps<2, 0, 2> : (void (*)(const DevModel*, DevState, int, int))k_substeps<1, 0, 2>;
+      s->substeps_epw = 2;
+    }
+  }
   if (s->phys_lds_bytes > 48 * 1024)
     if (hipFuncSetAttribute((const void*)k_simulate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->phys_lds_bytes) != hipSuccess ||
         hipFuncSetAttribute((const void*)s->substeps_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->phys_lds_bytes) != hipSuccess) {
@@ -305,11 +326,12 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   if (const char* sp = getenv("MQE_DEBUG_STOP_PHASE")) {
     // per-phase counter runs: the wavefront leaves k_simulate_a2 after that phase tap WITHOUT writing the state back, so the
     // unfused path stops advancing.  Only the two-robot, no-object scene has that kernel: refuse everywhere else.
-    if (s->substeps_fn != (void (*)(const DevModel*, DevState, int, int))k_substeps<2, 0>) { return fail(-4, "MQE_DEBUG_STOP_PHASE applies to two-robot scenes without objects only (k_simulate_a2)"); }
+    if (!s->a2_scene) { return fail(-4, "MQE_DEBUG_STOP_PHASE applies to two-robot scenes without objects only (k_simulate_a2)"); }
     s->dbg_stop_phase = atoi(sp);
   }
   if (getenv("MQE_VERBOSE")) {
-    const char* names[] = {"MQE_LANE_SWEEP", "MQE_PHYS_LDS_PAD", "MQE_NO_FUSE_SUBSTEPS", "MQE_GEMM_SPLIT", "MQE_NO_FUSED_TAIL", "MQE_DEBUG_STOP_PHASE"};
+    const char* names[] = {"MQE_LANE_SWEEP", "MQE_PHYS_LDS_PAD", "MQE_NO_FUSE_SUBSTEPS", "MQE_GEMM_SPLIT", "MQE_NO_FUSED_TAIL", "MQE_DEBUG_STOP_PHASE", "MQE_ENVS_PER_WAVE"};
+    fprintf(stderr, "mqe: k_substeps runs %d env(s) per wavefront\n", s->substeps_epw);
     for (const char* n : names)
       if (const char* v = getenv(n)) fprintf(stderr, "mqe: override in effect: %s=%s\n", n, v);
   }
@@ -686,7 +708,7 @@ static void launch_post(mqe_sim* s, hipStream_t q, int wrapper_level) {
 
 extern "C" int mqe_debug_stop_phase(mqe_sim* s, int tap) {
   if (!s) return fail(-1, "null engine handle");
-  if (tap >= 0 && s->substeps_fn != (void (*)(const DevModel*, DevState, int, int))k_substeps<2, 0>) return fail(-4, "phase taps exist for two-robot scenes without objects only (k_simulate_a2)");
+  if (tap >= 0 && !s->a2_scene) return fail(-4, "phase taps exist for two-robot scenes without objects only (k_simulate_a2)");
   s->dbg_stop_phase = tap < 0 ? -1 : tap;
   return 0;
 }
@@ -824,7 +846,7 @@ static int run_substeps_and_post(mqe_sim* s, hipStream_t q) {
   if (s->fuse_substeps) {
     // decimation loop in one launch: state stays in LDS; actuator net on MFMA (C) or the PD / torque law (P, V, T) inside the wavefront
     ProfScope ps(s, PROF_SIMULATE, q);
-    hipLaunchKernelGGL(s->substeps_fn, dim3(s->N), dim3(64), s->phys_lds_bytes, q, s->dm, s->st, s->d.decimation, s->lag_pos);
+    hipLaunchKernelGGL(s->substeps_fn, dim3((s->N + s->substeps_epw - 1) / s->substeps_epw), dim3(64), s->phys_lds_bytes * s->substeps_epw, q, s->dm, s->st, s->d.decimation, s->lag_pos);
     advance_lag(s, s->d.decimation);
   } else {
     for (int k = 0; k < s->d.decimation; k++) {

@@ -175,6 +175,47 @@ def test_row_sweep_and_lane_sweep_agree(monkeypatch, task, N):
     assert int(er.tensor(abi.T_CONTACT_OVERFLOW).sum()) == int(el.tensor(abi.T_CONTACT_OVERFLOW).sum())
 
 
+@pytest.mark.parametrize("task,N", [("go1gate", 256), ("go1gate", 37), ("go1gate", 1), ("go1plane", 65)])
+def test_two_envs_per_wavefront_is_bit_identical(monkeypatch, task, N):
+    """k_substeps<.., EPW = 2>: each half-wave of 32 lanes runs an env of its own (robot-only scenes of <= 2 robots; the engine picks
+    it beyond 2048 envs, MQE_ENVS_PER_WAVE forces it).  Per env it is the same arithmetic in the same order as the one-env form, so
+    15 fused steps -- resets, contacts between the robots, joint limits, an odd batch whose last half-wave has no env -- agree BIT
+    FOR BIT in every state tensor, log and returned batch."""
+    monkeypatch.setenv("MQE_ENVS_PER_WAVE", "1")
+    d1, k1, _ = make_desc(task, N)
+    e1 = hip_engine(d1, k1)
+    monkeypatch.setenv("MQE_ENVS_PER_WAVE", "2")
+    d2, k2, _ = make_desc(task, N)
+    e2 = hip_engine(d2, k2)
+    monkeypatch.delenv("MQE_ENVS_PER_WAVE")
+    e1.reset_all(); e2.reset_all()
+    g = torch.Generator().manual_seed(3)
+    Aw = e1.tensor(abi.T_WRAPPER_OBS).shape[1]
+    A = d1.num_agents
+    kinds = (abi.T_ROOT_STATE, abi.T_DOF_STATE, abi.T_TORQUES, abi.T_CONTACT_FORCE, abi.T_ACT_HIST, abi.T_SUBSTEP_TORQUES, abi.T_SUBSTEP_DOF_VEL,
+             abi.T_SUBSTEP_EXCEED_DOF_POS_LIMITS, abi.T_RESET_BUF, abi.T_CONTACT_OVERFLOW, abi.T_OBS_BAG, abi.T_WRAPPER_OBS, abi.T_WRAPPER_REWARD)
+    resets = 0
+    for t in range(15):
+        a = (torch.rand(N, Aw, 3, generator=g) * 2 - 1).cuda().contiguous()
+        if t == 4 and A == 2:            # push the two robots of every third env into each other: robot-robot and self contacts
+            for e in (e1, e2):
+                r = e.tensor(abi.T_ROOT_STATE)
+                r[::3, 1, :3] = r[::3, 0, :3] + torch.tensor([0.05, 0.22, 0.0], device="cuda")
+        if t == 8:                       # and fold some legs far beyond their stops: joint-limit impulses in one half-wave only
+            for e in (e1, e2):
+                q = e.tensor(abi.T_DOF_STATE)
+                q[1::4, 2, 0] = -3.2; q[1::4, 2, 1] = -20.0
+        e1.step(a); e2.step(a)
+        torch.cuda.synchronize()
+        for kind in kinds:
+            x1, x2 = e1.tensor(kind), e2.tensor(kind)
+            assert torch.equal(x1.view(torch.uint8) if x1.dtype != torch.float32 else x1.view(torch.int32), x2.view(torch.uint8) if x2.dtype != torch.float32 else x2.view(torch.int32)), (t, kind)
+        resets += int(e1.tensor(abi.T_RESET_BUF).sum())
+    assert torch.isfinite(e2.tensor(abi.T_ROOT_STATE)).all()
+    if N >= 37 and A == 2:
+        assert resets > 0, "the rollout must include resets"
+
+
 @pytest.mark.parametrize("N,split", [(1, "0"), (1, "1"), (3, "1"), (37, "0"), (37, "1")])
 def test_tiny_and_ragged_batches(monkeypatch, N, split):
     """batch sizes far below a tile of any kernel (1 env = 2 robots: 2 of the 128 GEMM rows, 2 of the tail's 32, one physics
