@@ -1960,7 +1960,8 @@ template <int TP> struct SubstepsClass {
 #ifdef MQE_LAUNDER
   static constexpr int launder = MQE_LAUNDER;
 #else
-  static constexpr int launder = small ? 2 : 0;       // bit 0: the model pointer, bit 1: the lane id
+  static constexpr int launder = 2;       // bit 0: the model pointer, bit 1: the lane id.  (The larger scenes at 2 waves per SIMD spilled
+                                          // 12-44 registers with everything hoisted; laundered they need 136-154 and none: -4 % kernel time)
 #endif
 };
 template <int TA, int TP, int EPW = 1>
