@@ -28,7 +28,7 @@ extern "C" {
 #define MQE_ABI_VERSION 12
 #define MQE_MAX_SPHERES 32    /* feature points of one robot */
 #define MQE_MAX_PRIMS 20      /* collision primitives of one robot (Go1: 18) */
-#define MQE_MAX_SELF_PAIRS 128
+#define MQE_MAX_SELF_PAIRS 192
 #define MQE_NBODY 13      /* dynamic bodies of one Go1 after fixed-joint collapsing */
 #define MQE_NREP 17       /* reported rigid bodies of one Go1 (feet kept, go1.urdf dont_collapse) */
 #define MQE_NDOF 12
@@ -99,6 +99,9 @@ typedef struct {
    * (mqe/utils/urdf_model.py::_self_pair_candidates), ascending; entry = feature | primitive << 8 */
   int32_t n_self_pairs;
   uint16_t self_pair[MQE_MAX_SELF_PAIRS];
+  /* a box of joint angles around the stance inside which no candidate pair comes within 4 cm (dense sampling when the model file is
+   * built): a robot whose joints are all inside it skips the self-collision phase (lo > hi: no such box, never skip) */
+  float self_safe_lo[MQE_NDOF], self_safe_hi[MQE_NDOF];
 } mqe_robot_model;
 
 typedef struct {

@@ -320,6 +320,9 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   int selfp[NSP];
 #pragma unroll
   for (int k = 0; k < NSP; k++) selfp[k] = (m->self_collision && k * LW + lane < rm.n_self_pairs) ? (int)rm.self_pair[k * LW + lane] : -1;
+  // ... and this lane's joint of the self-collision "safe box" (lanes 0-11): a robot whose joint angles are all inside it cannot touch itself
+  const float ss_lo = (m->self_collision && lane < MQE_NDOF) ? rm.self_safe_lo[lane] : -1e30f;
+  const float ss_hi = (m->self_collision && lane < MQE_NDOF) ? rm.self_safe_hi[lane] : 1e30f;
   TSTAMP(0);
   // ---- coalesced state load (first substep of a launch only; afterwards the state stays in LDS) -----------------
   if (flags & PS_LOAD_STATE) {
@@ -1175,6 +1178,11 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     if (m->self_collision) {
       const int npairs = rm.n_self_pairs;
       for (int a = 0; a < A; a++) {
+        // joint-space screen: inside the model's safe box of joint angles (a walking robot is) no candidate pair is closer than 4 cm
+        {
+          const float qj = lds[L.dof + (a * 12 + (lane < MQE_NDOF ? lane : 0)) * 2];
+          if (gballot(qj < ss_lo || qj > ss_hi) == 0ull) continue;
+        }
         // screen: all passes at once (independent 16 B loads, one ballot).  Bounding SPHERES (11 cm for a thigh or calf, 20 cm for the
         // trunk) would let the neighbouring legs and the thigh tops through in every substep, so the screen is the distance to the
         // capsule's segment itself (a box: its bounding capsule); robots rarely touch themselves and the compaction below normally

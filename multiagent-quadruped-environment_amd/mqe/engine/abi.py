@@ -3,7 +3,7 @@ import ctypes as C
 
 ABI_VERSION = 12
 MAX_SPHERES, NBODY, NREP, NDOF = 32, 13, 17, 12
-MAX_SELF_PAIRS = 128
+MAX_SELF_PAIRS = 192
 MAX_PRIMS = 20
 PRIM_SPHERE, PRIM_CAPSULE, PRIM_BOX = 0, 1, 2
 MAX_AGENTS, MAX_NPCS, FRAME, HIST, MAX_LAYERS, MAX_REWARD_TERMS = 4, 9, 72, 30, 6, 12
@@ -45,6 +45,7 @@ class RobotModel(C.Structure):
         ("prim_center", (f32 * 3) * MAX_PRIMS), ("prim_axis", (f32 * 3) * MAX_PRIMS), ("prim_half", (f32 * 3) * MAX_PRIMS),
         ("prim_bound", f32 * MAX_PRIMS), ("feature_reach", f32),
         ("n_self_pairs", i32), ("self_pair", C.c_uint16 * MAX_SELF_PAIRS),
+        ("self_safe_lo", f32 * NDOF), ("self_safe_hi", f32 * NDOF),
     ]
 
 

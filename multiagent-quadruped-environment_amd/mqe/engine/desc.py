@@ -161,6 +161,8 @@ def build_desc(cfg, num_envs, terrain, env_origins, agent_origins, gate_pos=None
             r.prim_center[q][k], r.prim_axis[q][k], r.prim_half[q][k] = m["prim_center"][q][k], m["prim_axis"][q][k], m["prim_half"][q][k]
     # self-collision (asset.self_collisions is Isaac Gym's filter mask: 0 = links of one robot collide, go1_config.py:73):
     # the model file's (feature point, primitive) candidates -- links neither the same nor adjacent, reachable inside the joint limits
+    for j in range(abi.NDOF):
+        r.self_safe_lo[j], r.self_safe_hi[j] = m["self_safe_lo"][j], m["self_safe_hi"][j]
     pairs = [tuple(p) for p in m["self_pairs"]]
     assert len(pairs) <= abi.MAX_SELF_PAIRS, len(pairs)
     r.n_self_pairs = len(pairs)

@@ -183,6 +183,9 @@ def collapse(links, joints, root):
 PRIM_SPHERE, PRIM_CAPSULE, PRIM_BOX = 0, 1, 2
 MAX_PRIMS = 20
 SELF_PAIR_MARGIN = 0.03       # a (feature, primitive) pair is a self-collision candidate if some pose brings it this close [m]
+SELF_SAFE_MARGIN = 0.04       # inside the "safe box" of joint angles every candidate pair stays farther apart than this [m]
+# the stance the safe box is grown around: default_joint_angles of go1_config.py:88-103 in this model's joint order (FL, FR, RL, RR)
+SELF_SAFE_STANCE = [0.1, 0.8, -1.5, -0.1, 0.8, -1.5, 0.1, 1.0, -1.5, -0.1, 1.0, -1.5]
 
 
 def _capsule_for_bar(h):
@@ -257,8 +260,10 @@ def _collision_model_for_go1(bodies, reported_names):
                     # the calf's lower end lies inside the foot sphere (r 20 mm) and its upper end inside the thigh's lower end cap
                     # (same point -- the knee -- and the thigh is the thicker bar): the calf contributes the primitive only
                     continue
+                # lower end = the knee; the upper end lies inside the hip capsule (17 mm from its segment, 46 mm radius), so the thigh's
+                # second feature point is its MIDDLE: what a wall's or a box's edge meets when it cuts into the bar between its ends
                 feats.append(dict(body=bi, reported=ri, center=t + u, radius=float(r), prim=pi, tag="knee"))
-                feats.append(dict(body=bi, reported=ri, center=t - u, radius=float(r), prim=pi, tag="thigh"))
+                feats.append(dict(body=bi, reported=ri, center=t, radius=float(r), prim=pi, tag="thigh"))
     return prims, feats
 
 
@@ -275,9 +280,10 @@ def _self_pair_candidates(m, prims, feats, n_samples=200000, seed=0):
             if f["prim"] != j and f["body"] != q["body"] and par[f["body"]] != q["body"] and par[q["body"]] != f["body"]
             and not (q["type"] == PRIM_SPHERE and prims[f["prim"]]["type"] == PRIM_SPHERE and f["prim"] > j)]
     best = np.full(len(cand), np.inf)
-    B = 2000
-    for _ in range(n_samples // B):
-        q = lo + (hi - lo) * rng.rand(B, 12)
+
+    def gaps(q):
+        """(B, n_cand) signed gaps of every candidate pair at joint angles q (B, 12)"""
+        B = len(q)
         R = np.zeros((B, N_BODIES_DYN, 3, 3)); R[:, 0] = np.eye(3)
         p = np.zeros((B, N_BODIES_DYN, 3))
         for b in range(1, N_BODIES_DYN):
@@ -290,6 +296,7 @@ def _self_pair_candidates(m, prims, feats, n_samples=200000, seed=0):
         fc = np.stack([p[:, f["body"]] + R[:, f["body"]] @ f["center"] for f in feats], 1)          # (B, F, 3)
         qc = np.stack([p[:, g["body"]] + R[:, g["body"]] @ g["center"] for g in prims], 1)
         qu = np.stack([R[:, g["body"]] @ g["axis"] for g in prims], 1)
+        out = np.empty((B, len(cand)))
         for k, (i, j) in enumerate(cand):
             g = prims[j]
             d = fc[:, i] - qc[:, j]
@@ -301,8 +308,29 @@ def _self_pair_candidates(m, prims, feats, n_samples=200000, seed=0):
                 uu = max(float(g["axis"] @ g["axis"]), 1e-18)
                 tpar = np.clip(np.einsum("bi,bi->b", d, qu[:, j]) / uu, -1, 1)
                 dist = np.linalg.norm(d - tpar[:, None] * qu[:, j], axis=1) - g["half"][0]
-            best[k] = min(best[k], float((dist - feats[i]["radius"]).min()))
-    return [c for c, b in zip(cand, best) if b < SELF_PAIR_MARGIN], len(cand)
+            out[:, k] = dist - feats[i]["radius"]
+        return out
+    B = 2000
+    for _ in range(n_samples // B):
+        best = np.minimum(best, gaps(lo + (hi - lo) * rng.rand(B, 12)).min(0))
+    keep = [c for c, b in zip(cand, best) if b < SELF_PAIR_MARGIN]
+    # A joint-space box around the stance inside which NO candidate pair comes within SELF_SAFE_MARGIN: an env whose joints are all
+    # inside it skips the self-collision phase with one ballot (a walking robot is).  The box is the stance widened per joint type
+    # (hip / thigh / calf, the same for all legs) by the largest scale at which a dense sample INSIDE the box finds nothing closer.
+    stance = np.asarray(SELF_SAFE_STANCE, np.float64)
+    wid_lo, wid_hi = np.array([0.5, 0.9, 1.1] * 4), np.array([0.5, 0.9, 0.55] * 4)
+    blo, bhi = stance.copy(), stance.copy()
+    for scale in (1.0, 0.9, 0.8, 0.7, 0.6, 0.5, 0.4, 0.3, 0.2):
+        tlo, thi = np.maximum(stance - scale * wid_lo, lo), np.minimum(stance + scale * wid_hi, hi)
+        worst = np.inf
+        for _ in range(150):
+            worst = min(worst, float(gaps(tlo + (thi - tlo) * rng.rand(B, 12)).min()))
+            if worst < SELF_SAFE_MARGIN:
+                break
+        if worst >= SELF_SAFE_MARGIN:
+            blo, bhi = tlo, thi
+            break
+    return keep, len(cand), blo, bhi
 
 
 def build_go1_model(urdf_path):
@@ -365,9 +393,10 @@ def build_go1_model(urdf_path):
     def chain(b):
         return 0.0 if b == 0 else float(np.linalg.norm(m["joint_offset"][b])) + chain(m["parent"][b])
     m["feature_reach"] = max(chain(f["body"]) + float(np.linalg.norm(f["center"])) + f["radius"] for f in feats)
-    pairs, n_all = _self_pair_candidates(m, prims, feats)
+    pairs, n_all, safe_lo, safe_hi = _self_pair_candidates(m, prims, feats)
     m["self_pairs"] = [[int(i), int(j)] for i, j in pairs]
     m["self_pairs_unpruned"] = int(n_all)
+    m["self_safe_lo"], m["self_safe_hi"] = [float(x) for x in safe_lo], [float(x) for x in safe_hi]
     m["total_mass"] = float(sum(m["mass"]))
     return m
 

@@ -282,7 +282,7 @@ def test_self_contacts_match_oracle():
     folded legs, perturbed per env: identical contact lists, then 40 substeps tracked in joint space."""
     N = 16
     eh, eo, d = _pair("go1gate", N)
-    assert d.self_collision == 1 and d.robot.n_self_pairs == 124        # (feature point, primitive) candidates of the model file
+    assert d.self_collision == 1 and d.robot.n_self_pairs == 144        # (feature point, primitive) candidates of the model file
     eh.reset_all(); eo.reset_all()
     torch.cuda.synchronize()
     ro, do = eo.tensor(abi.T_ROOT_STATE), eo.tensor(abi.T_DOF_STATE)
