@@ -729,11 +729,44 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     float* sp = lds + L.sph + s * 4;
     *reinterpret_cast<float4*>(sp) = make_float4(c.x, c.y, c.z, rad);
   }
+  // Who can touch whom in this substep, decided before any pair geometry is built:
+  //  * broad phase of ALL actor pairs at once, lane = pair (a < b, row-major): actors farther apart than 1.2 m (robot vs the box:
+  //    1.8 m) cannot touch.  The 55 pairs of the 2 + 9 actors of go1sheep-hard used to cost 55 sequential LDS round trips per substep.
+  //  * self-collision: a robot whose joint angles are all inside the model's safe box (a walking robot is) cannot touch itself.
+  unsigned long long near0 = 0ull, near1 = 0ull;
+  unsigned int self_todo = 0u;                               // bit a: robot a is outside its safe box
+  {
+    const int nact = A + PD;
+    const int npa = (nact * (nact - 1)) / 2;
+    for (int t0 = 0; t0 < npa; t0 += LW) {
+      const int t = t0 + lane;
+      bool nr = false;
+      if (t < npa) {
+        int a = 0, rem = t;
+        while (rem >= nact - 1 - a) { rem -= nact - 1 - a; a++; }
+        const int b = a + 1 + rem;
+        const V3 pa = ld3(lds + L.body + (a < A ? a * MQE_NBODY : A * MQE_NBODY + (a - A)) * BODY_STRIDE + B_P);
+        const V3 pb = ld3(lds + L.body + (b < A ? b * MQE_NBODY : A * MQE_NBODY + (b - A)) * BODY_STRIDE + B_P);
+        const V3 dd = pa - pb;
+        if (shp.has_box && b >= A) nr = a < A && !(dot(dd, dd) > 1.8f * 1.8f);
+        else nr = !(dot(dd, dd) > 1.2f * 1.2f);
+      }
+      const unsigned long long bm = gballot(nr);
+      if (t0 == 0) near0 = bm; else near1 = bm;
+    }
+    if (m->self_collision)
+      for (int a = 0; a < A; a++) {
+        const float qj = lds[L.dof + (a * 12 + (lane < MQE_NDOF ? lane : 0)) * 2];
+        if (gballot(qj < ss_lo || qj > ss_hi) != 0ull) self_todo |= 1u << a;
+      }
+  }
   // the robots' primitives in world coordinates (what the OTHER actors' feature points and spheres are tested against): centre and
   // bounding radius, capsule half-segment and radius (a sphere is a capsule with a zero segment; a box keeps its link's rotation
-  // and is marked by a negative radius)
+  // and is marked by a negative radius).  Only built when something can touch a primitive at all: two robots walking apart from
+  // each other in ordinary poses skip it.
   const int npr = rm.n_prims;
-  for (int t = lane; t < A * npr; t += LW) {
+  const bool need_prims = near0 != 0ull || near1 != 0ull || self_todo != 0u;
+  for (int t = lane; need_prims && t < A * npr; t += LW) {
     const int r = t / npr, q = t - r * npr;
     const float* rec = lds + L.body + (r * MQE_NBODY + rm.prim_body[q]) * BODY_STRIDE;
     const float4 q0 = reinterpret_cast<const float4*>(rec)[0], q1 = reinterpret_cast<const float4*>(rec)[1], q2 = reinterpret_cast<const float4*>(rec)[2];
@@ -955,28 +988,6 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   // ---- sphere-sphere contacts between different actors (a < b; outer loop over b's spheres, lanes = a's spheres) -------
   {
     const int nact = A + PD;
-    // broad phase of ALL actor pairs at once, lane = pair (a < b, row-major): actors farther apart than 1.2 m (robot vs the box: 1.8 m)
-    // cannot touch.  The 55 pairs of the 2 + 9 actors of go1sheep-hard used to cost 55 sequential LDS round trips per substep.
-    unsigned long long near0 = 0ull, near1 = 0ull;
-    {
-      const int npa = (nact * (nact - 1)) / 2;
-      for (int t0 = 0; t0 < npa; t0 += LW) {
-        const int t = t0 + lane;
-        bool nr = false;
-        if (t < npa) {
-          int a = 0, rem = t;
-          while (rem >= nact - 1 - a) { rem -= nact - 1 - a; a++; }
-          const int b = a + 1 + rem;
-          const V3 pa = ld3(lds + L.body + (a < A ? a * MQE_NBODY : A * MQE_NBODY + (a - A)) * BODY_STRIDE + B_P);
-          const V3 pb = ld3(lds + L.body + (b < A ? b * MQE_NBODY : A * MQE_NBODY + (b - A)) * BODY_STRIDE + B_P);
-          const V3 dd = pa - pb;
-          if (shp.has_box && b >= A) nr = a < A && !(dot(dd, dd) > 1.8f * 1.8f);
-          else nr = !(dot(dd, dd) > 1.2f * 1.2f);
-        }
-        const unsigned long long bm = gballot(nr);
-        if (t0 == 0) near0 = bm; else near1 = bm;
-      }
-    }
     // pairs of two NPCs of one or two spheres (a flock) are tested lane-parallel, 64 sphere pairs per pass, after the robots' pairs:
     // in the canonical order (a, b, sphere of b, sphere of a) they come last anyway, and 36 wave-uniform iterations for 9 sheep
     // were a third of this phase
@@ -1178,11 +1189,8 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     if (m->self_collision) {
       const int npairs = rm.n_self_pairs;
       for (int a = 0; a < A; a++) {
-        // joint-space screen: inside the model's safe box of joint angles (a walking robot is) no candidate pair is closer than 4 cm
-        {
-          const float qj = lds[L.dof + (a * 12 + (lane < MQE_NDOF ? lane : 0)) * 2];
-          if (gballot(qj < ss_lo || qj > ss_hi) == 0ull) continue;
-        }
+        // joint-space screen (above): inside the model's safe box of joint angles no candidate pair is closer than 4 cm
+        if (!((self_todo >> a) & 1u)) continue;
         // screen: all passes at once (independent 16 B loads, one ballot).  Bounding SPHERES (11 cm for a thigh or calf, 20 cm for the
         // trunk) would let the neighbouring legs and the thigh tops through in every substep, so the screen is the distance to the
         // capsule's segment itself (a box: its bounding capsule); robots rarely touch themselves and the compaction below normally
