@@ -18,6 +18,8 @@ def load_library():
     if _LIB is None:
         path = os.environ.get("MQE_HIP_LIB", LIB_PATH)       # experiments: an alternative build of the same ABI
         if path != LIB_PATH:
+            import sys
+            print(f"mqe: override in effect: MQE_HIP_LIB={path} (not the in-tree build)", file=sys.stderr)      # never silent
             _LIB = C.CDLL(path)
             return _LIB
         if not os.path.isfile(LIB_PATH):
