@@ -1,0 +1,127 @@
+"""The round-3 collision model in the ORACLE, against answers computed here from the model file alone (tests/rigid_ref.py: a float64
+forward kinematics, nothing of the engine's geometry code): contacts found by the feature-point-vs-primitive tests have the
+separation, normal and links that the URDF shapes dictate.  The HIP engine is held to the oracle's contact lists in
+tests/test_gpu_parity.py; this file is what ties the oracle's lists to the geometry."""
+import numpy as np
+import torch
+
+import rigid_ref as rr
+from helpers import make_desc, oracle_engine
+from mqe.engine import abi
+from mqe.utils import urdf_model
+
+STANCE = np.array([0.1, 0.8, -1.5, -0.1, 0.8, -1.5, 0.1, 1.0, -1.5, -0.1, 1.0, -1.5])
+
+
+def _scene(task, z=2.0):
+    """robots frozen in the default stance high above the ground (no terrain contact), level, at rest"""
+    d, k, _ = make_desc(task, 1)
+    e = oracle_engine(d, k, f64=True)
+    e.reset_all()
+    root, dof = e.tensor(abi.T_ROOT_STATE), e.tensor(abi.T_DOF_STATE)
+    A = d.num_agents
+    for a in range(A):
+        dof[0, a * 12:(a + 1) * 12, 0] = torch.tensor(STANCE, dtype=torch.float32)
+    dof[..., 1] = 0
+    root[0, :, 3:7] = torch.tensor([0.0, 0.0, 0.0, 1.0])
+    root[0, :, 7:] = 0
+    root[0, :A, 2] = z
+    root[0, 1, 1] = root[0, 0, 1] + 5.0          # the second robot out of the way
+    return e, d, root, dof
+
+
+def _prim_world(m, q, base_p):
+    Rb, pb = rr.fk(rr.load_model(), np.asarray(base_p, np.float64), np.eye(3), STANCE)
+    b = m["prim_body"][q]
+    return pb[b] + Rb[b] @ np.array(m["prim_center"][q]), Rb[b] @ np.array(m["prim_axis"][q]), Rb[b]
+
+
+def test_ball_against_capsule_box_and_foot():
+    """go1football-1vs1: the ball (sphere r) set beside a thigh capsule, on top of the trunk box and under a foot sphere of the floating
+    robot: ONE contact each, between the ball and that link, with the gap / normal of sphere-vs-capsule, sphere-vs-box, sphere-vs-sphere"""
+    m = urdf_model.load_model("go1")
+    e, d, root, dof = _scene("go1football-1vs1")
+    A, r = d.num_agents, d.npc_sphere_radius[0]
+    base = root[0, 0, :3].numpy().astype(np.float64)
+    # FL thigh capsule = primitive 3 (body 2): beside its middle, along +y, 7 mm of air between the surfaces
+    c, u, _ = _prim_world(m, 3, base)
+    assert m["prim_type"][3] == 1 and m["prim_body"][3] == 2
+    rq = m["prim_half"][3][0]
+    uh = u / np.linalg.norm(u)
+    side = np.array([0.0, 1.0, 0.0]) - uh[1] * uh          # perpendicular to the (pitched and rolled) bar, towards +y
+    side /= np.linalg.norm(side)
+    root[0, A, :3] = torch.tensor(c + side * (rq + r + 0.007), dtype=torch.float32)
+    root[0, A, 7:] = 0
+    _, _, con = e.debug_dynamics(0, 0)
+    assert len(con) == 1 and con[0, 0] == 0 and con[0, 1] == 2 and con[0, 2] == A, con
+    assert abs(con[0, 4] - 0.007) < 1e-6 and np.allclose(con[0, 5:8], -side, atol=1e-5), con          # normal from the ball (B) to the robot (A)
+    # beyond the capsule's end: the distance is to the END POINT of the segment, not to the infinite line
+    end = c + u
+    dirv = u / np.linalg.norm(u)
+    root[0, A, :3] = torch.tensor(end + dirv * (rq + r + 0.004), dtype=torch.float32)
+    _, _, con = e.debug_dynamics(0, 0)
+    hit = [cc for cc in con if cc[1] == 2]
+    assert len(hit) == 1 and abs(hit[0][4] - 0.004) < 1e-6 and np.allclose(hit[0][5:8], -dirv, atol=1e-5), con
+    # on top of the trunk box (primitive 0): 3 mm above its top face, off-centre
+    c0, _, R0 = _prim_world(m, 0, base)
+    h0 = np.array(m["prim_half"][0])
+    root[0, A, :3] = torch.tensor(c0 + np.array([0.1, 0.02, h0[2] + r + 0.003]), dtype=torch.float32)
+    _, _, con = e.debug_dynamics(0, 0)
+    assert len(con) == 1 and con[0, 1] == 0 and con[0, 2] == A and abs(con[0, 4] - 0.003) < 1e-6 and np.allclose(con[0, 5:8], [0, 0, -1], atol=1e-5), con
+    # against the box's top front edge: closest point on the edge, normal along the diagonal
+    root[0, A, :3] = torch.tensor(c0 + np.array([h0[0] + (r + 0.002) / np.sqrt(2), 0.0, h0[2] + (r + 0.002) / np.sqrt(2)]), dtype=torch.float32)
+    _, _, con = e.debug_dynamics(0, 0)
+    trunk = [cc for cc in con if cc[1] == 0]
+    assert len(trunk) >= 1 and abs(trunk[0][4] - 0.002) < 1e-6 and np.allclose(trunk[0][5:8], [-np.sqrt(0.5), 0, -np.sqrt(0.5)], atol=1e-5), con
+    # under the FL foot (primitive 5, a sphere on body 3): 6 mm below it; the calf's end cap (r 9.7 mm inside the 20 mm foot) stays clear
+    cf, _, _ = _prim_world(m, 5, base)
+    rf = m["prim_half"][5][0]
+    root[0, A, :3] = torch.tensor(cf - np.array([0.0, 0.0, rf + r + 0.006]), dtype=torch.float32)
+    _, _, con = e.debug_dynamics(0, 0)
+    assert len(con) == 1 and con[0, 1] == 3 and abs(con[0, 4] - 0.006) < 1e-6 and np.allclose(con[0, 5:8], [0, 0, 1], atol=1e-5), con
+
+
+def test_trunk_corners_carry_a_collapsed_robot():
+    """a limp robot (zero torques) collapses from its stance onto its belly: the base comes to rest at the trunk box's half height
+    above the slab -- its four lower corners are feature points -- with the robot's weight on the ground and a good share of it on
+    the base link itself (round 2's sphere set floated the trunk on three r = 57 mm spheres: same height, but no flat face)"""
+    d, k, _ = make_desc("go1gate", 1)
+    e = oracle_engine(d, k)
+    e.reset_all()
+    root = e.tensor(abi.T_ROOT_STATE)
+    root[0, :, 7:] = 0
+    e.tensor(abi.T_TORQUES).zero_()
+    for _ in range(500):
+        e.simulate()
+    m = urdf_model.load_model("go1")
+    hz = m["prim_half"][0][2]
+    z = root[0, :, 2].numpy()
+    assert np.all(np.abs(z - (d.ground_z + hz)) < 4e-3), (z, d.ground_z + hz)              # resting on the box's lower face (contact margin + ERP slack)
+    assert root[0, :, 7:].abs().max() < 0.05
+    cf = e.tensor(abi.T_CONTACT_FORCE)[0].reshape(2, 17, 3)
+    total = cf[..., 2].sum(1).numpy()
+    mg = sum(d.robot.mass[b] for b in range(13)) * 9.81
+    assert np.all(np.abs(total - mg) < 0.08 * mg), (total, mg)
+    assert np.all(cf[:, 0, 2].numpy() > 0.2 * mg), cf[:, 0, 2]                                # a good share of it on the base link itself
+
+
+def test_two_robots_touch_with_their_primitives():
+    """robot 1 moved until its FL hip capsule's outer end is 5 mm from robot 0's trunk box side: the contact pairs robot 1's hip link
+    (a feature point) with robot 0's base (a primitive) at that gap, normal along the boxes' y axis"""
+    m = urdf_model.load_model("go1")
+    e, d, root, dof = _scene("go1gate")
+    base0 = root[0, 0, :3].numpy().astype(np.float64)
+    c0, _, _ = _prim_world(m, 0, base0)
+    h0 = np.array(m["prim_half"][0])
+    # robot 1's FL hip capsule (primitive 2, body 1): its -y end
+    cq, u, _ = _prim_world(m, 2, np.zeros(3))
+    rq = m["prim_half"][2][0]
+    end = cq + u if (cq + u)[1] < (cq - u)[1] else cq - u
+    # place robot 1 on the +y side of robot 0, same height and heading, hip end facing the trunk's +y face, clear of robot 0's own legs in x
+    target = c0 + np.array([0.0, h0[1] + rq + 0.005, 0.03])
+    root[0, 1, :3] = torch.tensor(target - end, dtype=torch.float32)
+    _, _, con = e.debug_dynamics(0, 0)
+    pair = [cc for cc in con if cc[2] >= 0 and cc[0] != cc[2]]
+    hip_trunk = [cc for cc in pair if {(int(cc[0]), int(cc[1])), (int(cc[2]), int(cc[3]))} == {(1, 1), (0, 0)}]
+    assert hip_trunk, con
+    assert any(abs(cc[4] - 0.005) < 2e-6 and abs(abs(cc[6]) - 1.0) < 1e-5 for cc in hip_trunk), hip_trunk
