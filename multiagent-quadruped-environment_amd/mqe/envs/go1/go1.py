@@ -246,12 +246,59 @@ class Go1:
         self.engine.reset_all()
         return self.obs_buf
 
+    # ---- plugin points of the reference's class stack ----------------------------------------------------------------------------
+    # The reference lets a subclass of LeggedRobot / Go1 replace pieces of the step (legged_robot.py:368-392 `_compute_torques`,
+    # :202-219 `compute_reward`, :153-157 `_post_physics_step_callback`).  Here those pieces run inside the engine; a subclass that
+    # OVERRIDES one of the three methods below is honoured on the Go1-level path: `step()` then runs the decimation loop unfused and
+    # calls the override where the reference calls it (torques: written into the live `torques` view before every `simulate`).
+    # Not overridable: `check_termination`, `reset_idx`, `_step_npc`, `compute_observations` -- termination, the in-kernel reset and
+    # the NPC scripts are one kernel (`k_post_physics`); a task that needs other rules is a new task kind in the engine.  The fused
+    # wrapper-level step (`step_fused`, what the task wrappers call) refuses to run with overrides in place.
+    def _compute_torques(self, actions):
+        """(N, 12 A) joint-space actions -> (N, 12 A) torques.  Default: the engine's law for cfg.control.control_type."""
+        return None
+
+    def compute_reward(self):
+        """fill self.rew_buf (legged_robot.py:202-219); Go1 registers no reward functions (go1.py:198-219): zeros"""
+
+    def _post_physics_step_callback(self):
+        """after the engine's post-physics step (legged_robot.py:153-157)"""
+
+    def _overridden(self, name):
+        return getattr(type(self), name) is not getattr(Go1, name)
+
+    @property
+    def has_overrides(self):
+        return any(self._overridden(n) for n in ("_compute_torques", "compute_reward", "_post_physics_step_callback"))
+
+    def _decimation_loop(self):
+        e = self.engine
+        custom_tau = self._overridden("_compute_torques")
+        for dec_i in range(self.decimation):
+            if custom_tau:
+                self.torques.copy_(self._compute_torques(self.actions).reshape(self.torques.shape))
+            else:
+                e.compute_torques()
+            e.simulate()
+            e.post_decimation_step(dec_i)
+        e.post_physics_step()
+        self.common_step_counter += 1
+        if self._overridden("_post_physics_step_callback"):
+            self._post_physics_step_callback()
+        if self._overridden("compute_reward"):
+            self.compute_reward()
+
     def step(self, action):
         """One policy step from already-scaled commands (go1.py:35-62); action: (N*A, 3) or (N, A, 3)."""
         if self.cfg.control.control_type != "C":
             # low-level control (go1.py:42-44): joint-space actions (N*A, 12) / (N, A*12), clipped to clip_actions inside
             # the engine (legged_robot.py:108-110); PD / torque law, 4 substeps and the post-physics step are one fused call
             a = action.reshape(-1, 12).to(self.engine.torch_device, torch.float32).contiguous()
+            if self.has_overrides:            # pre_physics_step (legged_robot.py:108-110), then the loop with the subclass's pieces
+                c = self.cfg.normalization.clip_actions
+                self.actions.copy_(torch.clip(a, -c, c).reshape(self.actions.shape))
+                self._decimation_loop()
+                return self.obs_buf, self.rew_buf, self.reset_buf, self.extras
             self.engine.step_joint(a)
             self.common_step_counter += 1
             return self.obs_buf, self.rew_buf, self.reset_buf, self.extras
@@ -265,17 +312,15 @@ class Go1:
             cmd = torch.cat([cmd.view(self.num_envs, 2, 3), dc.unsqueeze(1)], dim=1).reshape(-1, 3).contiguous()
         e.policy_step(cmd)
         self._steps_policy = getattr(self, "_steps_policy", 0) + 1
-        for dec_i in range(self.decimation):
-            e.compute_torques()
-            e.simulate()
-            e.post_decimation_step(dec_i)
-        e.post_physics_step()
-        self.common_step_counter += 1
+        self._decimation_loop()
         return self.obs_buf, self.rew_buf, self.reset_buf, self.extras
 
     def step_fused(self, actions):
         """Wrapper-level step: raw actions (N, A', 3) in [-1,1]; clip, task action scale, policy, 4 substeps,
         post-step, task observation and reward all inside the engine (mqe_step)."""
+        if self.has_overrides:
+            raise NotImplementedError("the fused wrapper-level step runs entirely inside the engine: a Go1 subclass that overrides "
+                                      "_compute_torques / compute_reward / _post_physics_step_callback is stepped through Go1.step()")
         a = actions.to(self.engine.torch_device, torch.float32).contiguous()
         self.engine.step(a, getattr(self, "between_policy_and_physics", None))   # hook of the env-sharded runner (bench.py)
         self._steps_policy = getattr(self, "_steps_policy", 0) + 1

@@ -332,3 +332,52 @@ def test_unsupported_switches_are_refused_not_ignored(oracle_backed):
     env.close()
     ENV_DICT["go1gate"]["config"] = base
     assert base.command.cfg.vel is True and base.terrain.curriculum is False      # the registered config was not touched
+
+
+def test_subclass_overrides_are_honoured_on_the_go1_level_path(oracle_backed):
+    """the reference's class-level plugin points.  A subclass that replaces `_compute_torques` (here: the PD law of
+    legged_robot.py:380-384 written in torch), `compute_reward` and `_post_physics_step_callback` is stepped with ITS pieces -- the
+    torch PD law reproduces the engine's own control type "P" -- and the fused wrapper step refuses such a class."""
+    from mqe.envs.configs.go1_gate_config import Go1GateCfg
+    from mqe.envs.go1.go1 import Go1
+    calls = {"tau": 0, "post": 0}
+
+    class MyGo1(Go1):
+        def _compute_torques(self, actions):
+            calls["tau"] += 1
+            ctl = self.cfg.control
+            kp, kd = 20.0, 0.5
+            tau = kp * (actions * ctl.action_scale + self.default_dof_pos - self.dof_pos) - kd * self.dof_vel
+            return torch.clip(tau, -self.torque_limits, self.torque_limits)
+
+        def compute_reward(self):
+            self.rew_buf[:] = -self.root_states[:, 2]
+
+        def _post_physics_step_callback(self):
+            calls["post"] += 1
+
+    old = Go1GateCfg.control.control_type
+    Go1GateCfg.control.control_type = "P"
+    saved_cls = ENV_DICT["go1gate"]["class"]
+    try:
+        a = args_for("go1gate", 3)
+        ref_env, _ = make_mqe_env("go1gate", a, custom_cfg(a))
+        ENV_DICT["go1gate"]["class"] = MyGo1
+        my_env, _ = make_mqe_env("go1gate", a, custom_cfg(a))
+        assert my_env.env.has_overrides and not ref_env.env.has_overrides
+        ref_env.reset(); my_env.reset()
+        g = torch.Generator().manual_seed(4)
+        for t in range(6):
+            act = (torch.rand(6, 12, generator=g) - 0.5) * 2.0
+            ref_env.env.step(act)
+            ob, rew, done, _ = my_env.env.step(act)
+            assert torch.allclose(my_env.env.dof_pos, ref_env.env.dof_pos, atol=2e-5) and torch.allclose(my_env.env.root_states, ref_env.env.root_states, atol=2e-5)
+            assert torch.allclose(my_env.env.torques, ref_env.env.torques, atol=1e-4)
+            assert torch.equal(rew, -my_env.env.root_states[:, 2]) and (ref_env.env.rew_buf == 0).all()
+        assert calls == {"tau": 24, "post": 6}
+        with pytest.raises(NotImplementedError, match="overrides"):
+            my_env.step(torch.zeros(3, 2, 3))
+        ref_env.close(); my_env.close()
+    finally:
+        Go1GateCfg.control.control_type = old
+        ENV_DICT["go1gate"]["class"] = saved_cls
