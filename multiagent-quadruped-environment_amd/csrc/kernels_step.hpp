@@ -869,7 +869,10 @@ __global__ void __launch_bounds__(64) k_post_physics(const DevModel* m, DevState
       for (int q = 0; q < NPASS; q++)
         if (a + q * LPE < P) sheep_apply(root, A, a + q * LPE, dvs[q]);
     }
-    __threadfence();
+    // (a WORKGROUP-scope fence: writer and readers are lanes of this one wavefront, i.e. one CU and one vector L1.  The device-scope
+    // __threadfence() that stood here writes the XCD's L2 back and invalidates it on gfx950 -- its L2s are not coherent with each other --
+    // which cost every step of every sheep task ~15 us: go1sheep-hard k_post_physics 38.6 -> see profiles/r03_bench_go1sheep-hard.json)
+    __threadfence_block();
     __syncthreads();                            // the sheep rows are final before the lead lane's reset / wrapper reads
   }
   if (lead) {
@@ -879,7 +882,7 @@ __global__ void __launch_bounds__(64) k_post_physics(const DevModel* m, DevState
     }
   }
   if (__ballot(reset != 0)) {                   // wave-uniform
-    __threadfence();                            // the lead lane's stores, then no stale L1 lines for the other robot lanes
+    __threadfence_block();                      // the lead lane's stores are visible to the other robot lanes of this wavefront (same CU, same L1)
     __syncthreads();
     if (reset) {
 #pragma unroll
