@@ -1424,7 +1424,9 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
           sr[q == 0 ? 8 : (q == 1 ? 10 : 9)] = dqn[ps];          // d10 = row 0 . row 1, d21 = row 1 . row 2, d20 = row 2 . row 0
         } else {
           sr[11] = 0.0f;
-          reinterpret_cast<float4*>(sr)[3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // lambda starts at zero
+          // lambda starts at zero; the fourth slot carries side A's first-joint offset (0, 3, 6, 9: which leg's three joints are
+          // the record's Z' columns) so that the sweep needs no second record read to find its coordinates
+          reinterpret_cast<float4*>(sr)[3] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float((infq[ps] >> 4) & 63));
         }
         if (q == 0) { rec[SIDE_INFO] = __int_as_float(infq[ps]); sr[3] = cbq[ps]; sr[4] = muq[ps]; }
       }
@@ -1659,7 +1661,26 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       e1 = l1 - q3.y;
       const float l2 = clampf(q3.z - (u2 + q2.y * e0 + q2.z * e1) * q1.w, -lim, lim);
       e2 = l2 - q3.z;
-      if (writer) reinterpret_cast<float4*>(sr)[3] = make_float4(ln, l1, l2, 0.0f);
+      if (writer) reinterpret_cast<float4*>(sr)[3] = make_float4(ln, l1, l2, q3.w);
+    };
+    // a one-sided contact of this row's ROBOT (scenes whose actors 0 .. A-1 are robots): 9 coordinates, the first at row * 18 -- only the
+    // leg offset comes from the contact (its solve record), so the step reads the side record's three columns and w[k], nothing else
+    auto row_products_robot = [&](const float* rec, const float* sr) {
+      RowStep r;
+      const int jo = __float_as_int(sr[15]);
+      r.on = k < 9;
+      r.widx = row * MQE_RD + k + (jo & klegmask);
+      const float ww = accv[r.on ? r.widx : 0];
+      r.ph0 = rec[koff]; r.ph1 = rec[koff + kstr]; r.ph2 = rec[koff + 2 * kstr];
+      r.wk = r.on ? ww : 0.0f;
+      float a0 = r.ph0 * r.wk, a1 = r.ph1 * r.wk, a2 = r.ph2 * r.wk;
+      asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2));
+      a0 += dpp_take<0xB1>(a0); a1 += dpp_take<0xB1>(a1); a2 += dpp_take<0xB1>(a2);
+      a0 += dpp_take<0x4E>(a0); a1 += dpp_take<0x4E>(a1); a2 += dpp_take<0x4E>(a2);
+      a0 += dpp_take<0x141>(a0); a1 += dpp_take<0x141>(a1); a2 += dpp_take<0x141>(a2);
+      a0 += dpp_take<0x140>(a0); a1 += dpp_take<0x140>(a1); a2 += dpp_take<0x140>(a2);
+      r.s0 = a0; r.s1 = a1; r.s2 = a2;
+      return r;
     };
     // (barriers inside: with two envs per wavefront the trip counts are the larger of the two envs'; a row without work idles)
     const int maxlen_w = wave_max_of_groups(maxlen), npair_w = wave_max_of_groups(npair);
@@ -1667,7 +1688,8 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       for (int sidx = 0; sidx < maxlen_w; sidx++) {
         if (row < nact && sidx < glen) {                     // the s-th one-sided contact of every actor, each in its own row
           const int c = gstart + sidx;
-          const RowStep r = row_products(lds + L.phi + c * SIDE_STRIDE);
+          const RowStep r = TP == 0 ? row_products_robot(lds + L.phi + c * SIDE_STRIDE, lds + L.srec + c * SREC_STRIDE)      // (all actors are robots)
+                                    : row_products(lds + L.phi + c * SIDE_STRIDE);
           float e0, e1, e2;
           row_solve(lds + L.srec + c * SREC_STRIDE, r.s0, r.s1, r.s2, k == 0, e0, e1, e2);
           if (r.on) accv[r.widx] = r.wk + r.ph0 * e0 + r.ph1 * e1 + r.ph2 * e2;
