@@ -117,11 +117,12 @@ def main():
     ap.add_argument("--no_strict_f32", action="store_true", help="skip the exact-f32 companion run")
     ap.add_argument("--cpu_sample_envs", type=int, default=0, help="CPU baseline batch (0 = the GPU run's num_envs, 8 steps)")
     ap.add_argument("--cpu_sample_steps", type=int, default=8)
-    ap.add_argument("--gather", choices=["between", "after"], default=os.environ.get("MQE_BENCH_GATHER", "between"),
-                    help="N > 1: where the all-gather of a step's returned batch is issued.  between (default): inside the NEXT step, after its policy "
+    ap.add_argument("--gather", choices=["between", "after", "tail"], default=os.environ.get("MQE_BENCH_GATHER", "tail"),
+                    help="N > 1: where the all-gather of a step's returned batch is issued (default: tail).  between: inside the NEXT step, after its policy "
                          "kernels and before its physics kernel (overlaps k_substeps; DESIGN.md 8).  after: right behind the step's own k_post_physics, "
                          "and the next step's first kernel waits for it (no RCCL block is ever resident beside the two machine-filling kernels; "
-                         "costs the gather's latency once per step)")
+                         "costs the gather's latency once per step).  tail: issued inside the next step after layer 0 of the policy, so that the RCCL kernel runs beside "
+                         "k_policy_tail (one 4-wave workgroup per CU: room to spare), and the physics kernel waits for it (costs what the gather takes beyond the tail's 26 us)")
     ap.add_argument("--no_gather", action="store_true", help="N > 1: per-GPU learners -- every rank keeps its own batch, no collective at all (SURVEY 8e)")
     args = ap.parse_args()
 
@@ -190,6 +191,15 @@ def main():
     use_gather = world > 1 and not args.no_gather
     if use_gather and args.gather == "between":
         env.env.between_policy_and_physics = issue_gather
+
+    def wait_gathers():               # stream-side: what the compute stream launches next waits for the collectives in flight
+        for b in range(2):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
+    if use_gather and args.gather == "tail":
+        env.env.before_policy_tail = issue_gather
+        env.env.between_policy_and_physics = wait_gathers
 
     def one_step():
         t = step_no[0]
@@ -347,7 +357,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic (U(-1,1) actions seed 1234; synthetic body MLP: body_latest.jit missing upstream)",
             "config": {"workload": f"{args.task}, {A} agents, num_envs={N} per GPU ({N * world} total), 4 substeps x 5 ms per step",
                        "parallelism": (f"env-sharded x{world}, " + ("no collective (per-GPU learners)" if args.no_gather else
-                                       f"all-gather of the returned batch issued {'between policy and physics of the next step' if args.gather == 'between' else 'after the step, next step waits'}"))
+                                       f"all-gather of the returned batch issued {dict(between='between policy and physics of the next step', after='after the step, next step waits', tail='after layer 0 of the next step (beside the policy tail), physics waits')[args.gather]}"))
                                       if world > 1 else "single GPU"},
             "collective": None if world == 1 else ("none" if args.no_gather else {"op": "all_gather_into_tensor", "schedule": args.gather, "bytes_per_rank": int(4 * env.returned_batch.numel()),
                                                                                   "gathers": n_gathers[0]}),

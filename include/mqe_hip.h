@@ -289,6 +289,13 @@ int mqe_step(mqe_sim* s, const float* actions, void* stream);
  * CUs) and not with the policy GEMM (one workgroup per CU: any displaced workgroup costs a whole extra round). */
 int mqe_step_begin(mqe_sim* s, const float* actions, void* stream);
 int mqe_step_end(mqe_sim* s, void* stream);
+/* mqe_step_begin in two parts, for a host that wants to place launches of its own between layer 0 of the policy and the rest of it:
+ * mqe_step_head = wrapper head + history frame + layer 0 (k_pre_policy, k_gemm_*), mqe_step_tail = the rest of the policy
+ * (k_policy_tail); then mqe_step_end as usual.  The env-sharded runner issues the previous batch's all-gather after the head -- the
+ * RCCL kernel then shares the GPU with the policy tail, which leaves every CU three quarters empty, instead of with either of the two
+ * kernels that fill the machine exactly -- and makes the physics kernel wait for it (bench.py --gather tail). */
+int mqe_step_head(mqe_sim* s, const float* actions, void* stream);
+int mqe_step_tail(mqe_sim* s, void* stream);
 /* Where the following launches write what a step returns (the MQE_T_WRAPPER_PACKED layout: obs | reward | done): a device
  * buffer of the caller, at least as large as MQE_T_WRAPPER_PACKED, or NULL for the engine's own buffer (the one the
  * MQE_T_WRAPPER_* views show).  Host-side switch only; a launch uses the buffer that was set when it was enqueued.  The

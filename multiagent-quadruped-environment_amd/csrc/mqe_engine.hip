@@ -68,7 +68,7 @@ struct mqe_sim {
   int dbg_stop_phase = -1;            // MQE_DEBUG_STOP_PHASE, read once at creation (tools/phase_counters.py)
   // profiling
   bool prof = false, prof_now = false;   // prof_now: this call is one of the sampled ones
-  bool step_open = false;                // between mqe_step_begin and mqe_step_end
+  int step_open = 0;                     // 0: no step in flight; 1: after mqe_step_head; 2: after mqe_step_tail / mqe_step_begin (mqe_step_end closes)
   int prof_every = 1; long prof_step = 0;
   std::vector<hipEvent_t> ev0[PROF_N], ev1[PROF_N];
   float prof_ms[PROF_N];
@@ -617,7 +617,14 @@ static void launch_gemm2(hipStream_t q, const uint16_t* A, int lda, int rot8, in
   hipLaunchKernelGGL(k_gemm_h2, dim3(grid), dim3(H2_THREADS), H2_LDS_BYTES, q, g);
 }
 
+static int policy_tail(mqe_sim* s, hipStream_t q);
+static void policy_head(mqe_sim* s, const float* command, hipStream_t q, const float* wrapper_actions);
 static int policy_step(mqe_sim* s, const float* command, hipStream_t q, const float* wrapper_actions = nullptr) {
+  policy_head(s, command, q, wrapper_actions);
+  return policy_tail(s, q);
+}
+// first half of the policy: the frame of this step into the history ring (wrapper head included) and layer 0 of both networks
+static void policy_head(mqe_sim* s, const float* command, hipStream_t q, const float* wrapper_actions) {
   const int R = s->R;
   {
     ProfScope ps(s, PROF_MISC, q);
@@ -634,6 +641,10 @@ static int policy_step(mqe_sim* s, const float* command, hipStream_t q, const fl
     else
       launch_gemm(q, s->st.hist, MQE_HIST * MQE_FRAME, s->hist_pos * (MQE_FRAME / 4), MQE_HIST * MQE_FRAME / 4, s->l0, s->P1, s->ldP1, R, s->ada_h0);
   }
+}
+// second half: everything after layer 0 (latent, body MLP, post-policy registers)
+static int policy_tail(mqe_sim* s, hipStream_t q) {
+  const int R = s->R;
   ProfScope ps(s, PROF_GEMM_REST, q);
   if (s->tail_fused) {
     TailArgs t;
@@ -821,7 +832,27 @@ extern "C" int mqe_step_begin(mqe_sim* s, const float* actions, void* stream) {
   if (s->step_open) return fail(-8, "mqe_step_begin: the previous step was not closed with mqe_step_end");
   s->prof_now = s->prof && (s->prof_step++ % s->prof_every == 0);
   policy_step(s, s->st.cmd, q, actions);
-  s->step_open = true;
+  s->step_open = 2;
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int mqe_step_head(mqe_sim* s, const float* actions, void* stream) {
+  if (!s) return fail(-1, "null engine handle");
+  if (s->d.control_type != MQE_CTRL_C) return fail(-7, "mqe_step_head drives the hierarchical controller (control type C)");
+  if (s->step_open) return fail(-8, "mqe_step_head: the previous step was not closed with mqe_step_end");
+  s->prof_now = s->prof && (s->prof_step++ % s->prof_every == 0);
+  policy_head(s, s->st.cmd, (hipStream_t)stream, actions);
+  s->step_open = 1;
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int mqe_step_tail(mqe_sim* s, void* stream) {
+  if (!s) return fail(-1, "null engine handle");
+  if (s->step_open != 1) return fail(-8, "mqe_step_tail without mqe_step_head");
+  policy_tail(s, (hipStream_t)stream);
+  s->step_open = 2;
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -837,8 +868,8 @@ extern "C" int mqe_set_return_buffer(mqe_sim* s, float* packed_dev) {
 
 extern "C" int mqe_step_end(mqe_sim* s, void* stream) {
   if (!s) return fail(-1, "null engine handle");
-  if (!s->step_open) return fail(-8, "mqe_step_end without mqe_step_begin");
-  s->step_open = false;
+  if (s->step_open != 2) return fail(-8, "mqe_step_end without mqe_step_begin (or mqe_step_head + mqe_step_tail)");
+  s->step_open = 0;
   return run_substeps_and_post(s, (hipStream_t)stream);
 }
 

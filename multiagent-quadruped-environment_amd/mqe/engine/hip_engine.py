@@ -42,7 +42,7 @@ class HipEngine(EngineBase):
         vp = C.c_void_p
         for name, args in (("policy_step", [vp, vp, vp]), ("compute_torques", [vp, vp]), ("simulate", [vp, vp]),
                            ("post_decimation_step", [vp, C.c_int, vp]), ("post_physics_step", [vp, vp]),
-                           ("reset_all", [vp, vp]), ("step", [vp, vp, vp]), ("step_begin", [vp, vp, vp]), ("step_end", [vp, vp]), ("set_return_buffer", [vp, vp]), ("step_joint", [vp, vp, vp]), ("defender_command", [vp, vp, vp]),
+                           ("reset_all", [vp, vp]), ("step", [vp, vp, vp]), ("step_begin", [vp, vp, vp]), ("step_end", [vp, vp]), ("step_head", [vp, vp, vp]), ("step_tail", [vp, vp]), ("set_return_buffer", [vp, vp]), ("step_joint", [vp, vp, vp]), ("defender_command", [vp, vp, vp]),
                            ("wrapper_eval", [vp, C.c_int, vp]),
                            ("debug_dynamics", [vp, C.c_int, C.c_int, vp, C.POINTER(C.c_int), vp]),
                            ("debug_stop_phase", [vp, C.c_int]),
@@ -83,12 +83,24 @@ class HipEngine(EngineBase):
         assert actions12.is_cuda and actions12.dtype == torch.float32 and actions12.is_contiguous()
         self._call("step_joint", C.c_void_p(actions12.data_ptr()), self._stream())
 
-    def step(self, actions, between=None):
+    def step(self, actions, between=None, before_tail=None):
         """mqe_step; with `between` (a callable) the two halves mqe_step_begin / mqe_step_end with the callable's own
-        launches placed after the policy kernels and before the physics kernel (see include/mqe_hip.h)."""
+        launches placed after the policy kernels and before the physics kernel; with `before_tail` as well the policy itself in two
+        parts, mqe_step_head / mqe_step_tail, with that callable's launches after layer 0 (see include/mqe_hip.h)."""
         assert actions.is_cuda and actions.dtype == torch.float32 and actions.is_contiguous()
-        if between is None:
+        if between is None and before_tail is None:
             self._call("step", C.c_void_p(actions.data_ptr()), self._stream())
+        elif before_tail is not None:
+            self._call("step_head", C.c_void_p(actions.data_ptr()), self._stream())
+            try:
+                before_tail()
+            finally:
+                self._call("step_tail", self._stream())
+                try:
+                    if between is not None:
+                        between()
+                finally:
+                    self._call("step_end", self._stream())
         else:
             self._call("step_begin", C.c_void_p(actions.data_ptr()), self._stream())
             try:

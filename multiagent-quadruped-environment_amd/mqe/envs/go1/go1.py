@@ -322,7 +322,11 @@ class Go1:
             raise NotImplementedError("the fused wrapper-level step runs entirely inside the engine: a Go1 subclass that overrides "
                                       "_compute_torques / compute_reward / _post_physics_step_callback is stepped through Go1.step()")
         a = actions.to(self.engine.torch_device, torch.float32).contiguous()
-        self.engine.step(a, getattr(self, "between_policy_and_physics", None))   # hook of the env-sharded runner (bench.py)
+        hooks = (getattr(self, "between_policy_and_physics", None), getattr(self, "before_policy_tail", None))   # the env-sharded runner's (bench.py)
+        if hooks[1] is not None:
+            self.engine.step(a, hooks[0], hooks[1])
+        else:
+            self.engine.step(a, hooks[0])
         self._steps_policy = getattr(self, "_steps_policy", 0) + 1
         self.common_step_counter += 1
 

@@ -31,14 +31,19 @@ def test_step_halves_equal_step():
         calls.append(1)
         scratch.add_(1.0)          # a launch of the host's own between the policy and the physics kernels
 
+    d2, k2, _ = make_desc("go1gate", N)
+    e2 = hip_engine(d2, k2)            # and in three parts: mqe_step_head; <host>; mqe_step_tail; <host>; mqe_step_end
+    e2.reset_all()
     for t in range(8):
         a = (torch.rand(N, 2, 3, generator=g) * 2 - 1).cuda().contiguous()
         e0.step(a)
         e1.step(a, between)
+        e2.step(a, between, between)
     torch.cuda.synchronize()
-    assert len(calls) == 8 and float(scratch[0]) == 8.0
+    assert len(calls) == 24 and float(scratch[0]) == 24.0
     for kind in (abi.T_ROOT_STATE, abi.T_DOF_STATE, abi.T_WRAPPER_OBS, abi.T_WRAPPER_REWARD, abi.T_RESET_BUF, abi.T_ACTIONS):
         assert torch.equal(e0.tensor(kind), e1.tensor(kind)), kind
+        assert torch.equal(e0.tensor(kind), e2.tensor(kind)), kind
 
 
 def test_packed_return_batch_is_obs_reward_done():
@@ -81,13 +86,20 @@ def test_step_end_without_begin_is_an_error():
     with pytest.raises(RuntimeError):          # a second begin before the end
         e._call("step_begin", a.data_ptr(), e._stream())
     e._call("step_end", e._stream())
+    with pytest.raises(RuntimeError):          # tail without head
+        e._call("step_tail", e._stream())
+    e._call("step_head", a.data_ptr(), e._stream())
+    with pytest.raises(RuntimeError):          # end before the tail
+        e._call("step_end", e._stream())
+    e._call("step_tail", e._stream())
+    e._call("step_end", e._stream())
     torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize("task,port,world,extra", [
-    ("go1gate", "29641", 2, []), ("go1football-defender", "29643", 2, []),
-    ("go1gate", "29645", 8, []), ("go1gate", "29647", 8, ["--gather", "after"]), ("go1football-defender", "29649", 8, ["--gather", "after"]),
-    ("go1gate", "29651", 8, ["--no_gather"])])
+    ("go1gate", "29641", 2, []), ("go1football-defender", "29643", 2, ["--gather", "between"]),
+    ("go1gate", "29645", 8, ["--gather", "between"]), ("go1gate", "29647", 8, ["--gather", "after"]), ("go1football-defender", "29649", 8, ["--gather", "after"]),
+    ("go1gate", "29651", 8, ["--no_gather"]), ("go1gate", "29653", 8, ["--gather", "tail"]), ("go1football-defender", "29655", 2, ["--gather", "tail"])])
 def test_bench_sharded_schedules_over_gloo(task, port, world, extra):
     """bench.py --gpus N as the driver launches it, all ranks on cuda:0 over gloo (world sizes 2 and 8 = the node the driver
     measures on): every step's batch is gathered and arrives whole -- bench.py asserts both -- under both schedules of the
@@ -108,7 +120,7 @@ def test_bench_sharded_schedules_over_gloo(task, port, world, extra):
     if "--no_gather" in extra:
         assert r["collective"] == "none" and "no collective" in r["config"]["parallelism"]
     else:
-        assert r["collective"]["schedule"] == ("after" if "after" in extra else "between") and r["collective"]["gathers"] == 15
+        assert r["collective"]["schedule"] == (extra[1] if extra else "tail") and r["collective"]["gathers"] == 15
 
 
 def test_rccl_process_group_options_single_rank():
