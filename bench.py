@@ -128,9 +128,15 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    # experiment switch (1-GPU boxes): run the sharded code path -- RCCL group of ONE rank, the all-gather and its schedule -- to see
+    # what each schedule costs on the compute stream; the JSON line then carries "collective" although n_gpus is 1
+    solo_group = world == 1 and bool(os.environ.get("MQE_BENCH_WORLD1_GATHER"))
+    if solo_group:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29571")
+        os.environ["RANK"], os.environ["WORLD_SIZE"] = "0", "1"
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or solo_group:
         import torch.distributed as dist
         if os.environ.get("MQE_BENCH_SELFTEST_GLOO"):      # logic check of the sharded path on a 1-GPU box: all ranks on cuda:0, gloo
             local_rank = 0
@@ -159,7 +165,7 @@ def main():
     gather = None
     pending = [None, None]
     sent = [None, None]                          # the snapshot each in-flight gather reads (kept alive until it is waited for)
-    if world > 1:
+    if world > 1 or solo_group:
         from mqe.engine import abi
         gather = [torch.empty(world * eng.tensor(abi.T_WRAPPER_PACKED).numel(), device=dev) for _ in range(2)]   # double buffer, [world][L]
 
@@ -188,7 +194,7 @@ def main():
             ready[0] = None
             n_gathers[0] += 1
 
-    use_gather = world > 1 and not args.no_gather
+    use_gather = (world > 1 or solo_group) and not args.no_gather
     if use_gather and args.gather == "between":
         env.env.between_policy_and_physics = issue_gather
 
@@ -359,7 +365,7 @@ def main():
                        "parallelism": (f"env-sharded x{world}, " + ("no collective (per-GPU learners)" if args.no_gather else
                                        f"all-gather of the returned batch issued {dict(between='between policy and physics of the next step', after='after the step, next step waits', tail='after layer 0 of the next step (beside the policy tail), physics waits')[args.gather]}"))
                                       if world > 1 else "single GPU"},
-            "collective": None if world == 1 else ("none" if args.no_gather else {"op": "all_gather_into_tensor", "schedule": args.gather, "bytes_per_rank": int(4 * env.returned_batch.numel()),
+            "collective": None if (world == 1 and not solo_group) else ("none" if args.no_gather else {"op": "all_gather_into_tensor", "schedule": args.gather, "bytes_per_rank": int(4 * env.returned_batch.numel()),
                                                                                   "gathers": n_gathers[0]}),
             "target_env_steps_per_s": 1.0e6,
             "physical_robot_steps_per_s": round(value * env.env.num_agents / A, 1),
@@ -392,7 +398,7 @@ def main():
                                       "sample": f"{args.task} 4 envs x 200 steps (BASELINE config 1 size), {secs4:.1f} s"}
         print(json.dumps(out))
     env.close()
-    if world > 1:
+    if world > 1 or solo_group:
         dist.destroy_process_group()
 
 
