@@ -241,3 +241,66 @@ def test_perlin_track_through_the_plugin_api():
                 del Go1GateCfg.terrain.TerrainPerlin_kwargs
             except AttributeError:
                 pass
+
+
+def test_terrain_classes_and_subclass_overrides_on_the_hip_engine():
+    """round-3 additions on the product engine: (1) an env on `TerrainPerlin` and on the legacy `Terrain` (registry, relief as the
+    ground) keeps its robots on the surface; (2) a Go1 subclass with its own `_compute_torques` (torch PD law) is stepped with it and
+    reproduces the engine's control type "P"."""
+    from helpers import task_cfg
+    base_t = task_cfg("go1gate").terrain
+    variants = {
+        "TerrainPerlin": type("PerlinClassTerrain", (base_t,), dict(selected="TerrainPerlin", num_rows=2, num_cols=2, terrain_length=4.0, terrain_width=4.0,
+                                                                     TerrainPerlin_kwargs=dict(zScale=0.1, frequency=5))),
+        "Terrain": type("LegacyTerrain", (base_t,), dict(selected="Terrain", mesh_type="trimesh", num_rows=2, num_cols=2, terrain_length=8.0, terrain_width=8.0,
+                                                         border_size=2.0, horizontal_scale=0.1, vertical_scale=0.005, curriculum=False,
+                                                         terrain_proportions=[1.0, 0.0, 0.0, 0.0, 0.0], slope_treshold=0.75)),
+    }
+    base_plane = ENV_DICT["go1plane"]["config"]
+    for name, tcfg in variants.items():
+        a = args_for("go1plane", 6)
+        np.random.seed(0)
+        try:
+            env, _ = make_mqe_env("go1plane", a, lambda c: type("Go1PlaneOn" + name, (custom_cfg(a)(c),), {"terrain": tcfg}))
+        finally:
+            ENV_DICT["go1plane"]["config"] = base_plane
+        assert type(env.env.terrain).__name__ == name
+        env.reset()
+        A = env.env.num_agents
+        for _ in range(60):
+            env.step(torch.zeros(6, A, 3, device="cuda"))
+        torch.cuda.synchronize()
+        rs = env.env.root_states.cpu()
+        gh, hsc = env.env.terrain.ground_height, tcfg.horizontal_scale
+        under = np.array([gh[int(round(float(x) / hsc)), int(round(float(y) / hsc))] for x, y in rs[:, :2]])
+        hgt = rs[:, 2].numpy() - under
+        # on the relief, not through it and not hovering (a pyramid's flank under a tilted robot reads up to a few dm at the base's xy)
+        assert np.isfinite(rs.numpy()).all() and (hgt > 0.05).all() and (hgt < 0.8).all(), (name, hgt)
+        env.close()
+
+    from mqe.envs.configs.go1_gate_config import Go1GateCfg
+
+    class MyGo1(Go1):
+        def _compute_torques(self, actions):
+            tau = 20.0 * (actions * self.cfg.control.action_scale + self.default_dof_pos - self.dof_pos) - 0.5 * self.dof_vel
+            return torch.clip(tau, -self.torque_limits, self.torque_limits)
+    old, saved_cls = Go1GateCfg.control.control_type, ENV_DICT["go1gate"]["class"]
+    Go1GateCfg.control.control_type = "P"
+    try:
+        a = args_for("go1gate", 8)
+        ref_env, _ = make_mqe_env("go1gate", a, custom_cfg(a))
+        ENV_DICT["go1gate"]["class"] = MyGo1
+        my_env, _ = make_mqe_env("go1gate", a, custom_cfg(a))
+        ref_env.reset(); my_env.reset()
+        g = torch.Generator().manual_seed(4)
+        for t in range(5):
+            act = ((torch.rand(16, 12, generator=g) - 0.5) * 2.0).cuda()
+            ref_env.env.step(act); my_env.env.step(act)
+            torch.cuda.synchronize()
+            assert torch.allclose(my_env.env.dof_pos, ref_env.env.dof_pos, atol=5e-5) and torch.allclose(my_env.env.root_states, ref_env.env.root_states, atol=5e-5)
+        with pytest.raises(NotImplementedError, match="overrides"):
+            my_env.step(torch.zeros(8, 2, 3, device="cuda"))
+        ref_env.close(); my_env.close()
+    finally:
+        Go1GateCfg.control.control_type = old
+        ENV_DICT["go1gate"]["class"] = saved_cls
