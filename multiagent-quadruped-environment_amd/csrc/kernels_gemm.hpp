@@ -154,6 +154,10 @@ struct Gemm2Args {
   int M, N, K;                                         // N multiple of 192, K multiple of 96
   int act_cols;                                        // multiple of 4
   float descale;                                       // 1 / (c_a c_w)
+  // rows whose compact history has frames that do not continue their predecessor (mqe_common.hpp, MQE_H2_FRAME): bit p of irr[row]
+  // = logical frame p; the epilogue adds W[., frame p, 54..65] (a2(p) - a1(p - 1)) from the f32 ring and the f32 weights.  irr may be null.
+  const unsigned* irr; const float* ring; int ring_pos;
+  const float* Wt32; int ldwt;                         // [frame * MQE_FRAME + column][ldwt] (GemmLayer::Wt)
 };
 
 __global__ void __launch_bounds__(H2_THREADS, 1) k_gemm_h2(Gemm2Args g) {
@@ -239,6 +243,26 @@ __global__ void __launch_bounds__(H2_THREADS, 1) k_gemm_h2(Gemm2Args g) {
     float4 v = *reinterpret_cast<const float4*>(ep + row * H2_EPS + c4 * 4);
     float4 bb = g.bias ? *reinterpret_cast<const float4*>(g.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
     v.x = fmaf(v.x, g.descale, bb.x); v.y = fmaf(v.y, g.descale, bb.y); v.z = fmaf(v.z, g.descale, bb.z); v.w = fmaf(v.w, g.descale, bb.w);
+    unsigned mk = g.irr && grow < g.M ? g.irr[grow] : 0u;
+    if (mk) {                     // rare: the first frame after a reset is still in the ring (29 steps per episode)
+      float4 cr = make_float4(0.f, 0.f, 0.f, 0.f);
+      do {
+        const int p = __ffs((int)mk) - 1;
+        mk &= mk - 1;
+        int s1 = g.ring_pos + p; if (s1 >= MQE_HIST) s1 -= MQE_HIST;
+        const int s0 = s1 > 0 ? s1 - 1 : MQE_HIST - 1;
+        const float* a2 = g.ring + ((size_t)grow * MQE_HIST + s1) * MQE_FRAME + 54;
+        const float* a1 = g.ring + ((size_t)grow * MQE_HIST + s0) * MQE_FRAME + 42;
+        const float* wr = g.Wt32 + (size_t)(p * MQE_FRAME + 54) * g.ldwt + col;
+#pragma unroll 4
+        for (int j = 0; j < 12; j++) {
+          const float r = a2[j] - a1[j];
+          const float4 w = *reinterpret_cast<const float4*>(wr + (size_t)j * g.ldwt);
+          cr.x = fmaf(r, w.x, cr.x); cr.y = fmaf(r, w.y, cr.y); cr.z = fmaf(r, w.z, cr.z); cr.w = fmaf(r, w.w, cr.w);
+        }
+      } while (mk);
+      v.x += cr.x; v.y += cr.y; v.z += cr.z; v.w += cr.w;
+    }
     if (col < g.act_cols) {       // ELU
       v.x = v.x > 0 ? v.x : __expf(v.x) - 1.0f; v.y = v.y > 0 ? v.y : __expf(v.y) - 1.0f;
       v.z = v.z > 0 ? v.z : __expf(v.z) - 1.0f; v.w = v.w > 0 ? v.w : __expf(v.w) - 1.0f;

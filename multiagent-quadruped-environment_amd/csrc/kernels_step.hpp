@@ -139,12 +139,35 @@ __global__ void k_pre_policy(const DevModel* m, DevState st, const float* __rest
   st.hist[hidx] = v;   // :102
   if (st.hist2) {      // the split-f16 GEMM's operand copy: two f16 planes, compact frames (mqe_common.hpp: MQE_H2_FRAME)
     const int cc = c < 70 ? h2_col(c) : (c == 70 ? MQE_H2_FLAG_COL : -1);      // thread 70 of the frame writes the presence flag
+    uint16_t* row2 = st.hist2 + (size_t)i * (2 * MQE_HIST * MQE_H2_FRAME);
+    const int oldest = hist_slot + 1 >= MQE_HIST ? 0 : hist_slot + 1;            // ring slot of logical frame 0 once this frame is in
     if (cc >= 0) {
       uint16_t h, l;
       split2(c < 70 ? v : 1.0f, MQE_H2_ASCALE, h, l);
-      uint16_t* row2 = st.hist2 + (size_t)i * (2 * MQE_HIST * MQE_H2_FRAME);
       const size_t k = (size_t)hist_slot * MQE_H2_FRAME + cc;
       row2[h2_index(k, 0)] = h; row2[h2_index(k, 1)] = l;
+    } else if (cc == -2) {
+      // last_two_locomotion_action is not stored (it is the previous frame's last_locomotion_action); the oldest frame's copy has no
+      // previous frame: component j rides on the carrier column of the frame at logical position j
+      const int j = c - 54;
+      int slot = oldest + j; if (slot >= MQE_HIST) slot -= MQE_HIST;
+      uint16_t h, l;
+      split2(st.hist[((size_t)i * MQE_HIST + oldest) * MQE_FRAME + c], MQE_H2_ASCALE, h, l);
+      const size_t k = (size_t)slot * MQE_H2_FRAME + MQE_H2_CARRIER_COL;
+      row2[h2_index(k, 0)] = h; row2[h2_index(k, 1)] = l;
+    } else if (c == 71) {
+      // does this frame continue its predecessor (bit for bit)?  Positions move down by one with every push; the oldest frame needs no
+      // partner (carrier columns), so bit 0 is dropped.
+      const int prev = hist_slot > 0 ? hist_slot - 1 : MQE_HIST - 1;
+      const float* pa = st.hist + ((size_t)i * MQE_HIST + prev) * MQE_FRAME + 42;
+      const float* na = st.last_two_loco + (size_t)i * 12;
+      unsigned diff = 0;
+#pragma unroll
+      for (int j = 0; j < 12; j++) diff |= __float_as_uint(pa[j]) ^ __float_as_uint(na[j]);
+      unsigned mk = st.hist_irr[i];
+      mk = (mk >> 1) & ~1u;
+      if (diff) mk |= 1u << (MQE_HIST - 1);
+      st.hist_irr[i] = mk;
     }
   }
 }
@@ -952,6 +975,7 @@ __global__ void __launch_bounds__(64) k_post_physics(const DevModel* m, DevState
       uint4* p4 = reinterpret_cast<uint4*>(st.hist2 + (size_t)er * m->A * (2 * MQE_HIST * MQE_H2_FRAME));
       const int per2 = m->A * (2 * MQE_HIST * MQE_H2_FRAME / 8);
       for (int k = threadIdx.x; k < per2; k += 64) p4[k] = make_uint4(0u, 0u, 0u, 0u);
+      if ((int)threadIdx.x < m->A) st.hist_irr[(size_t)er * m->A + threadIdx.x] = 0u;      // all frames zero: every frame continues its predecessor
     }
   }
 }
@@ -964,10 +988,11 @@ __global__ void k_reset_history(const DevModel* m, DevState st) {
   if (i >= m->R) return;
   if (!st.reset_buf[i / m->A]) return;
   reinterpret_cast<float4*>(st.hist)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (st.hist2) {      // the robot's compact f16 planes: 2 x 30 x 64 values = 480 16-byte words, one per thread of the first 480
+  if (st.hist2) {      // the robot's compact f16 planes: 2 x 30 x 48 values = 360 16-byte words, one per thread of the first 360
     const int w = idx - i * per;
     if (w < 2 * MQE_HIST * MQE_H2_FRAME / 8)
       reinterpret_cast<uint4*>(st.hist2 + (size_t)i * (2 * MQE_HIST * MQE_H2_FRAME))[w] = make_uint4(0u, 0u, 0u, 0u);
+    if (w == 0) st.hist_irr[i] = 0u;
   }
 }
 

@@ -367,14 +367,16 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   if (s->ada_h0 % GB_N || s->body_h0 % GB_N) return fail(-6, "first hidden sizes must be multiples of 64");
   std::vector<int> krow(2100);
   for (int k = 0; k < 2100; k++) krow[k] = (k / 70) * MQE_FRAME + (k % 70);
-  // the split-f16 operand has its own K order: compact frames of MQE_H2_FRAME columns (mqe_common.hpp), the twelve constant gait
-  // parameters of a frame folded onto its presence-flag column
+  // the split-f16 operand has its own K order: compact frames of MQE_H2_FRAME columns (mqe_common.hpp): the twelve constant gait
+  // parameters of a frame folded onto its presence-flag column, its last_two_locomotion_action onto the previous frame's
+  // last_locomotion_action (the oldest frame's: component j onto the carrier column of frame j)
   std::vector<int> k2row(2100);
   std::vector<float> k2scale(2100);
   for (int k = 0; k < 2100; k++) {
     const int f = k / 70, c = k % 70, cc = h2_col(c);
-    k2row[k] = f * MQE_H2_FRAME + (cc >= 0 ? cc : MQE_H2_FLAG_COL);
-    k2scale[k] = cc >= 0 ? 1.0f : d->command_obs[c];
+    if (cc == -2) k2row[k] = f > 0 ? (f - 1) * MQE_H2_FRAME + h2_col(c - 12) : (c - 54) * MQE_H2_FRAME + MQE_H2_CARRIER_COL;
+    else k2row[k] = f * MQE_H2_FRAME + (cc >= 0 ? cc : MQE_H2_FLAG_COL);
+    k2scale[k] = cc == -1 ? d->command_obs[c] : 1.0f;
   }
   if (make_layer(s, &s->l0, MQE_HIST * MQE_FRAME, s->ada_h0 + s->body_h0)) return fail(-5, "alloc");
   s->l0.Kpad3 = rup(MQE_HIST * MQE_H2_FRAME, H2_KMULT);
@@ -435,7 +437,8 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   DA(st.torques, (size_t)N * 12 * A); DA(st.actions, (size_t)N * 12 * A); DA(st.last_actions, (size_t)N * 12 * A);
   DA(st.loco_obs, (size_t)R * MQE_FRAME); DA(st.hist, (size_t)R * MQE_HIST * MQE_FRAME);
   st.hist2 = nullptr;
-  if (s->gemm_split) { DA(st.hist2, (size_t)2 * R * MQE_HIST * MQE_H2_FRAME); }
+  st.hist_irr = nullptr;
+  if (s->gemm_split) { DA(st.hist2, (size_t)2 * R * MQE_HIST * MQE_H2_FRAME); DA(st.hist_irr, (size_t)R); }
   DA(st.last_loco, (size_t)R * 12); DA(st.last_two_loco, (size_t)R * 12); DA(st.act_hist, (size_t)4 * R * 12);
   DA(st.gait, R); DA(st.clock, (size_t)R * 4); DA(st.blv, (size_t)R * 3); DA(st.bav, (size_t)R * 3); DA(st.pg, (size_t)R * 3);
   DA(st.bquat, (size_t)R * 4); DA(st.obs_bag, (size_t)R * MQE_OBS_BAG); DA(st.wobs, (size_t)N * s->Aw * s->D + (size_t)N * s->Aw + (N + 3) / 4); st.wrew = st.wobs + (size_t)N * s->Aw * s->D; st.wdone = (uint8_t*)(st.wrew + (size_t)N * s->Aw);   // one buffer: obs | reward | done (N bytes)
@@ -607,8 +610,9 @@ static void launch_gemm(hipStream_t q, const float* A, int lda, int rot4, int ri
 }
 
 static void launch_gemm2(hipStream_t q, const uint16_t* A, int lda, int rot8, int ring8, const GemmLayer& L,
-                         float* C, int ldc, int M, int act_cols) {
+                         float* C, int ldc, int M, int act_cols, const unsigned* irr = nullptr, const float* ring = nullptr, int ring_pos = 0) {
   Gemm2Args g;
+  g.irr = irr; g.ring = ring; g.ring_pos = ring_pos; g.Wt32 = L.Wt; g.ldwt = L.Npad;
   g.A = A; g.lda = lda; g.a_rot8 = rot8; g.a_ring8 = ring8;
   g.W = L.W2; g.ldw = 2 * L.Kpad3; g.bias = L.bias;
   g.C = C; g.ldc = ldc; g.M = M; g.N = L.Npad; g.K = L.Kpad3; g.act_cols = act_cols;
@@ -637,7 +641,7 @@ static void policy_head(mqe_sim* s, const float* command, hipStream_t q, const f
     // fused layer 0 of both networks over the ring: ELU on the adaptation columns only
     if (s->gemm_split)
       launch_gemm2(q, s->st.hist2, 2 * MQE_HIST * MQE_H2_FRAME, s->hist_pos * (MQE_H2_FRAME / 8), MQE_HIST * MQE_H2_FRAME / 8, s->l0,
-                   s->P1, s->ldP1, R, s->ada_h0);
+                   s->P1, s->ldP1, R, s->ada_h0, s->st.hist_irr, s->st.hist, s->hist_pos);
     else
       launch_gemm(q, s->st.hist, MQE_HIST * MQE_FRAME, s->hist_pos * (MQE_FRAME / 4), MQE_HIST * MQE_FRAME / 4, s->l0, s->P1, s->ldP1, R, s->ada_h0);
   }

@@ -100,6 +100,44 @@ def test_policy_layer0_paths_are_f32_equivalent(monkeypatch, split, N):
             close(eh.tensor(abi.T_ACTIONS), eo.tensor(abi.T_ACTIONS), atol=5e-5, what=f"policy actions step {t}")
 
 
+@pytest.mark.parametrize("split", ["1", "0"])
+def test_policy_layer0_compact_history_with_resets(monkeypatch, split):
+    """The split-f16 operand of layer 0 does not store last_two_locomotion_action: frame p's copy is frame p-1's
+    last_locomotion_action, its weights ride on that frame's columns (mqe_common.hpp, MQE_H2_FRAME).  The two places where the
+    identity has no partner -- the oldest frame of the ring, and the first frame after a reset (go1.py:139-145 zeroes the history but
+    not the action registers) -- are carried separately (carrier columns; residual term in k_gemm_h2's epilogue).  45 steps (the
+    ring turns over 1.5 times) with forced time-outs, two of them 2 steps apart in one env: the joint targets agree with the oracle's
+    plain f32 chain over the full 2100-column history at every step -- on the split path and on the exact-f32 path (whose history
+    operand is the ring itself).  This is also the only test that runs a policy long enough to fill the ring: the real adaptation
+    module's hidden activations exceed 1000 on a full history (kernels_tail.hpp, TL_ASCALE)."""
+    N = 16
+    monkeypatch.setenv("MQE_GEMM_SPLIT", split)
+    eh, eo, d = _pair("go1gate", N)
+    monkeypatch.delenv("MQE_GEMM_SPLIT")
+    eh.reset_all(); eo.reset_all()
+    g = torch.Generator().manual_seed(17)
+    forced = {5: [3], 20: [7], 22: [7, 8], 33: [0, 15], 34: [0]}
+    n_reset = 0
+    for t in range(45):
+        a = torch.rand(N, 2, 3, generator=g) * 2 - 1
+        for e in forced.get(t, []):
+            eh.tensor(abi.T_EPISODE_LENGTH)[e] = 10 ** 6
+            eo.tensor(abi.T_EPISODE_LENGTH)[e] = 10 ** 6
+        eh.step(a.cuda().contiguous()); eo.step(a)
+        torch.cuda.synchronize()
+        rb = eo.tensor(abi.T_RESET_BUF)
+        assert bool((eh.tensor(abi.T_RESET_BUF).cpu() == rb).all())
+        for e in forced.get(t, []):
+            assert int(rb[e]) == 1
+        n_reset += int(rb.sum())
+        close(eh.tensor(abi.T_ACTIONS), eo.tensor(abi.T_ACTIONS), atol=2e-5, what=f"policy actions step {t}")
+        # same trajectory AND the same action registers (they feed back into the history): step t compares the policy on identical histories
+        for k in (abi.T_ROOT_STATE, abi.T_DOF_STATE, abi.T_LAST_LOCO_ACTION, abi.T_LAST_TWO_LOCO_ACTION, abi.T_ACTIONS, abi.T_ACT_HIST,
+                  abi.T_OBS_BAG, abi.T_GAIT_INDICES, abi.T_CLOCK_INPUTS, abi.T_LAST_ACTIONS):
+            eh.tensor(k).copy_(eo.tensor(k).cuda())
+    assert n_reset >= 7
+
+
 def _record(kind, obj):
     """measured deviations, appended to gpurun_out/test_measurements.jsonl when that directory exists (what the bounds are set from)"""
     import json
