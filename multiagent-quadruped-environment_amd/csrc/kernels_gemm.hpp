@@ -154,12 +154,12 @@ struct Gemm2Args {
   int M, N, K;                                         // N multiple of 192, K multiple of 96
   int act_cols;                                        // multiple of 4
   float descale;                                       // 1 / (c_a c_w)
-  // rows whose compact history has frames that do not continue their predecessor (mqe_common.hpp, MQE_H2_FRAME): bit p of irr[row]
-  // = logical frame p; the epilogue adds W[., frame p, 54..65] (a2(p) - a1(p - 1)) from the f32 ring and the f32 weights.  irr may be null.
+  // rows whose compact history has frames that do not continue their predecessor (mqe_common.hpp, MQE_H2_FRAME): bit s of irr[row]
+  // = ring slot s; the epilogue adds W[., frame p, 54..65] (a2(p) - a1(p - 1)) from the f32 ring and the f32 weights for the frames
+  // at logical positions p >= 1 (ring_pos = slot of the oldest frame).  irr may be null.
   const unsigned* irr; const float* ring; int ring_pos;
   const float* Wt32; int ldwt;                         // [frame * MQE_FRAME + column][ldwt] (GemmLayer::Wt)
 };
-
 __global__ void __launch_bounds__(H2_THREADS, 1) k_gemm_h2(Gemm2Args g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds2[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -244,12 +244,13 @@ __global__ void __launch_bounds__(H2_THREADS, 1) k_gemm_h2(Gemm2Args g) {
     float4 bb = g.bias ? *reinterpret_cast<const float4*>(g.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
     v.x = fmaf(v.x, g.descale, bb.x); v.y = fmaf(v.y, g.descale, bb.y); v.z = fmaf(v.z, g.descale, bb.z); v.w = fmaf(v.w, g.descale, bb.w);
     unsigned mk = g.irr && grow < g.M ? g.irr[grow] : 0u;
-    if (mk) {                     // rare: the first frame after a reset is still in the ring (29 steps per episode)
+    if (mk) {                     // rare: the first frame after a reset is still in the ring (30 steps per episode)
       float4 cr = make_float4(0.f, 0.f, 0.f, 0.f);
       do {
-        const int p = __ffs((int)mk) - 1;
+        const int s1 = __ffs((int)mk) - 1;
         mk &= mk - 1;
-        int s1 = g.ring_pos + p; if (s1 >= MQE_HIST) s1 -= MQE_HIST;
+        const int p = s1 >= g.ring_pos ? s1 - g.ring_pos : s1 + MQE_HIST - g.ring_pos;
+        if (p == 0) continue;                  // the oldest frame has no partner by construction: carrier columns
         const int s0 = s1 > 0 ? s1 - 1 : MQE_HIST - 1;
         const float* a2 = g.ring + ((size_t)grow * MQE_HIST + s1) * MQE_FRAME + 54;
         const float* a1 = g.ring + ((size_t)grow * MQE_HIST + s0) * MQE_FRAME + 42;

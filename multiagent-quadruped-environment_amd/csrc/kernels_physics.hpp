@@ -2015,6 +2015,7 @@ __global__ void __launch_bounds__(64, EPW == 2 ? 2 : SubstepsClass<TP>::waves) k
   constexpr int launder = EPW == 2 ? 2 : SubstepsClass<TP>::launder;     // hoisting everything overflows even 256 VGPRs (43 spilled)
 #endif
   const int lane_wave = threadIdx.x, e_first = blockIdx.x * EPW;
+  if (st.wave_times && lane_wave == 0) st.wave_times[2 * blockIdx.x] = (long long)wall_clock64();      // MQE_WAVE_TIMES (tools/dev/wave_times.py)
   const int grp = EPW == 1 ? 0 : lane_wave / LW, lane = EPW == 1 ? lane_wave : lane_wave - grp * LW;
   const bool evalid = EPW == 1 || e_first + grp < m->N;
   const int e = evalid ? e_first + grp : m->N - 1;
@@ -2167,4 +2168,5 @@ __global__ void __launch_bounds__(64, EPW == 2 ? 2 : SubstepsClass<TP>::waves) k
       const int w = i / nj, jt = i - w * nj;
       st.act_hist[(size_t)w * R12 + (size_t)e * nj + jt] = acth[i];
     }
+  if (st.wave_times && lane_wave == 0) st.wave_times[2 * blockIdx.x + 1] = (long long)wall_clock64();
 }

@@ -101,13 +101,16 @@ __global__ void k_wrapper_command(const DevModel* m, DevState st, const float* _
 // frame is assembled and written once to the robot's ring slot (280 B) instead of re-concatenating 2100 floats.
 // `wrapper_actions` != nullptr (fused mqe_step): the wrapper head (k_wrapper_command) is evaluated here for the three
 // command columns instead of in a launch of its own; `command` is then ignored.
-__global__ void k_pre_policy(const DevModel* m, DevState st, const float* __restrict__ command, int hist_slot,
-                             const float* __restrict__ wrapper_actions) {
-  int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  int i = idx / MQE_FRAME, c = idx - i * MQE_FRAME;
-  if (i >= m->R) return;
-  float* lo = st.loco_obs + (size_t)i * MQE_FRAME;
+// Element c (0..71) of robot i's frame in two halves: everything that is READ (pre_policy_load) and everything that is WRITTEN
+// (pre_policy_store).  Every write is a pure function of state that this launch does not change (the action registers, the
+// observation bag, the other ring slots).  (Round 3 tried to let k_gemm_h2 write the frame of its 128 rows in its prologue and save
+// this launch: with 4 wavefronts per CU the loads and stores of 32 robots per wavefront serialise into four memory round trips,
+// +17 us on the GEMM against the 12 us of this kernel with its 590 k threads -- measured, dropped.)
+struct PreVal { float v, aux; unsigned mk; };
+__device__ __forceinline__ PreVal pre_policy_load(const DevModel* m, const DevState& st, const float* __restrict__ command, int hist_slot,
+                                                  const float* __restrict__ wrapper_actions, int i, int c) {
   const float* ob = st.obs_bag + (size_t)i * MQE_OBS_BAG;
+  PreVal r; r.aux = 0.0f; r.mk = 0u;
   float v;
   if (c < 3) v = ob[60 + c];                                   // projected gravity      :95
   else if (c < 6) {                                            // velocity command       :67-68 (+ clip :38)
@@ -119,11 +122,11 @@ __global__ void k_pre_policy(const DevModel* m, DevState st, const float* __rest
         defender_command_dev(m, st, e, c3);
         x = c3[k];
       } else if (a < Aw) {
-        float v = wrapper_actions[((size_t)e * Aw + a) * 3 + k];
-        if (m->task != MQE_TASK_TUG) v = clampf(v, -1.0f, 1.0f);        // the tug wrapper does not clip before scaling
-        x = m->task == MQE_TASK_PLAIN ? v : v * (k == 0 ? 2.0f : 0.5f);
+        float w = wrapper_actions[((size_t)e * Aw + a) * 3 + k];
+        if (m->task != MQE_TASK_TUG) w = clampf(w, -1.0f, 1.0f);        // the tug wrapper does not clip before scaling
+        x = m->task == MQE_TASK_PLAIN ? w : w * (k == 0 ? 2.0f : 0.5f);
       } else x = st.cmd[i * 3 + k];
-      st.cmd[i * 3 + k] = x;
+      r.aux = x;                                               // -> st.cmd
     } else x = command[i * 3 + (c - 3)];
     if (m->clip_command) x = clampf(x, -1.0f, 1.0f);
     v = x * (c < 5 ? m->cmd_lin_scale : m->cmd_ang_scale);
@@ -131,16 +134,40 @@ __global__ void k_pre_policy(const DevModel* m, DevState st, const float* __rest
   else if (c < 30) v = ob[6 + (c - 18)];                       // dof_pos                :96
   else if (c < 42) v = ob[18 + (c - 30)];                      // dof_vel                :97
   else if (c < 54) v = st.last_loco[i * 12 + (c - 42)];        //                        :98
-  else if (c < 66) v = st.last_two_loco[i * 12 + (c - 54)];    //                        :99
-  else if (c < 70) v = ob[63 + (c - 66)];                      // clock inputs           :100
-  else v = 0.0f;
-  lo[c] = v;
-  const size_t hidx = ((size_t)i * MQE_HIST + hist_slot) * MQE_FRAME + c;
-  st.hist[hidx] = v;   // :102
+  else if (c < 66) {                                           //                        :99
+    v = st.last_two_loco[i * 12 + (c - 54)];
+    if (st.hist2) {          // the oldest frame's copy of this column once this frame is in (carrier columns, mqe_common.hpp)
+      const int oldest = hist_slot + 1 >= MQE_HIST ? 0 : hist_slot + 1;
+      r.aux = st.hist[((size_t)i * MQE_HIST + oldest) * MQE_FRAME + c];
+    }
+  } else if (c < 70) v = ob[63 + (c - 66)];                    // clock inputs           :100
+  else {
+    v = 0.0f;
+    if (c == 71 && st.hist2) {
+      // does this frame continue its predecessor (bit for bit)?  One bit per RING SLOT, so that the update does not depend on the
+      // bit's old value (the element may be written twice)
+      const int prev = hist_slot > 0 ? hist_slot - 1 : MQE_HIST - 1;
+      const float* pa = st.hist + ((size_t)i * MQE_HIST + prev) * MQE_FRAME + 42;
+      const float* na = st.last_two_loco + (size_t)i * 12;
+      unsigned diff = 0;
+#pragma unroll
+      for (int j = 0; j < 12; j++) diff |= __float_as_uint(pa[j]) ^ __float_as_uint(na[j]);
+      const unsigned bit = 1u << hist_slot;
+      const unsigned mk = st.hist_irr[i];
+      r.mk = diff ? (mk | bit) : (mk & ~bit);
+    }
+  }
+  r.v = v;
+  return r;
+}
+__device__ __forceinline__ void pre_policy_store(const DevModel* m, const DevState& st, int hist_slot, bool have_wrapper_actions, int i, int c, const PreVal& r) {
+  const float v = r.v;
+  st.loco_obs[(size_t)i * MQE_FRAME + c] = v;
+  st.hist[((size_t)i * MQE_HIST + hist_slot) * MQE_FRAME + c] = v;   // :102
+  if (have_wrapper_actions && c >= 3 && c < 6) st.cmd[i * 3 + (c - 3)] = r.aux;
   if (st.hist2) {      // the split-f16 GEMM's operand copy: two f16 planes, compact frames (mqe_common.hpp: MQE_H2_FRAME)
-    const int cc = c < 70 ? h2_col(c) : (c == 70 ? MQE_H2_FLAG_COL : -1);      // thread 70 of the frame writes the presence flag
+    const int cc = c < 70 ? h2_col(c) : (c == 70 ? MQE_H2_FLAG_COL : -1);      // element 70 of the frame writes the presence flag
     uint16_t* row2 = st.hist2 + (size_t)i * (2 * MQE_HIST * MQE_H2_FRAME);
-    const int oldest = hist_slot + 1 >= MQE_HIST ? 0 : hist_slot + 1;            // ring slot of logical frame 0 once this frame is in
     if (cc >= 0) {
       uint16_t h, l;
       split2(c < 70 ? v : 1.0f, MQE_H2_ASCALE, h, l);
@@ -148,28 +175,29 @@ __global__ void k_pre_policy(const DevModel* m, DevState st, const float* __rest
       row2[h2_index(k, 0)] = h; row2[h2_index(k, 1)] = l;
     } else if (cc == -2) {
       // last_two_locomotion_action is not stored (it is the previous frame's last_locomotion_action); the oldest frame's copy has no
-      // previous frame: component j rides on the carrier column of the frame at logical position j
-      const int j = c - 54;
-      int slot = oldest + j; if (slot >= MQE_HIST) slot -= MQE_HIST;
+      // previous frame: component j rides on the carrier column of the frame at logical position MQE_H2_CARRIER0 + j (the newest twelve
+      // frames: the K range k_gemm_h2 reaches last, long after its own prologue has written them)
+      const int oldest = hist_slot + 1 >= MQE_HIST ? 0 : hist_slot + 1;            // ring slot of logical frame 0 once this frame is in
+      int slot = oldest + MQE_H2_CARRIER0 + (c - 54); if (slot >= MQE_HIST) slot -= MQE_HIST;
       uint16_t h, l;
-      split2(st.hist[((size_t)i * MQE_HIST + oldest) * MQE_FRAME + c], MQE_H2_ASCALE, h, l);
+      split2(r.aux, MQE_H2_ASCALE, h, l);
       const size_t k = (size_t)slot * MQE_H2_FRAME + MQE_H2_CARRIER_COL;
       row2[h2_index(k, 0)] = h; row2[h2_index(k, 1)] = l;
-    } else if (c == 71) {
-      // does this frame continue its predecessor (bit for bit)?  Positions move down by one with every push; the oldest frame needs no
-      // partner (carrier columns), so bit 0 is dropped.
-      const int prev = hist_slot > 0 ? hist_slot - 1 : MQE_HIST - 1;
-      const float* pa = st.hist + ((size_t)i * MQE_HIST + prev) * MQE_FRAME + 42;
-      const float* na = st.last_two_loco + (size_t)i * 12;
-      unsigned diff = 0;
-#pragma unroll
-      for (int j = 0; j < 12; j++) diff |= __float_as_uint(pa[j]) ^ __float_as_uint(na[j]);
-      unsigned mk = st.hist_irr[i];
-      mk = (mk >> 1) & ~1u;
-      if (diff) mk |= 1u << (MQE_HIST - 1);
-      st.hist_irr[i] = mk;
-    }
+    } else if (c == 71) st.hist_irr[i] = r.mk;
   }
+}
+__device__ __forceinline__ void pre_policy_element(const DevModel* m, const DevState& st, const float* __restrict__ command, int hist_slot,
+                                                   const float* __restrict__ wrapper_actions, int i, int c) {
+  const PreVal r = pre_policy_load(m, st, command, hist_slot, wrapper_actions, i, c);
+  pre_policy_store(m, st, hist_slot, wrapper_actions != nullptr, i, c, r);
+}
+
+__global__ void k_pre_policy(const DevModel* m, DevState st, const float* __restrict__ command, int hist_slot,
+                             const float* __restrict__ wrapper_actions) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  int i = idx / MQE_FRAME, c = idx - i * MQE_FRAME;
+  if (i >= m->R) return;
+  pre_policy_element(m, st, command, hist_slot, wrapper_actions, i, c);
 }
 
 // go1.py:106-107 + :40-41: shift the last-action registers and clip the new joint targets.  act: [R, ld]

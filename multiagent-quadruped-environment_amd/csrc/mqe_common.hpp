@@ -66,7 +66,8 @@ struct DevState {
   float* sub_dof_vel; uint8_t* sub_exceed; int32_t* overflow;   // per-substep logs (legged_robot.py:114-115); truncated-contact-list counter
   float *dparams, *lag_buf;                 // [R][8] friction / added mass / CoM shift (MQE_T_DOMAIN_PARAMS); [(lag + 1)][R][12] scaled actions
   uint16_t* hist2;                          // compact split-f16 copy of the history ring: [R][180 units][2 planes][8] (k_gemm_h2; MQE_H2_FRAME)
-  uint32_t* hist_irr;                       // [R] bit p: the frame at logical position p (0 = oldest) does not continue its predecessor's actions (MQE_H2_FRAME)
+  long long* wave_times;                    // debug (MQE_WAVE_TIMES=1): [waves of k_substeps][2] wall_clock64 at entry / exit, else null
+  uint32_t* hist_irr;                       // [R] bit s: the frame in ring slot s does not continue its predecessor's actions (MQE_H2_FRAME)
   int32_t *ep_len, *reset_count;
   uint8_t *reset_buf, *collide_buf, *time_out, *r_term, *p_term, *zh_term, *w_have_last, *w_delayed_reset;
   uint8_t* wdone;         // the reset flags once more, as the byte tail of the packed return batch (obs | reward | done)
@@ -97,14 +98,15 @@ __host__ __device__ __forceinline__ float mqe_u01(uint32_t seed, uint32_t genv, 
 //   * columns 54..65, last_two_locomotion_action (go1.py:99): frame p's copy IS frame p-1's last_locomotion_action (columns
 //     42..53; go1.py:106-107 shifts the one into the other), so its weights are added onto those of frame p-1's columns 42..53.
 //     Two places where that identity has no partner: (a) the oldest frame of the ring (its predecessor has left): its twelve
-//     values ride on the carrier columns of the frames at logical positions 0..11 (rewritten every step by k_pre_policy, weight
-//     = W[., frame 0, 54 + j] in frame j's carrier, zero in the others); (b) a frame whose predecessor in the ring does not hold
+//     values ride on the carrier columns of the frames at logical positions 18..29 (rewritten every step with the frame, weight
+//     = W[., frame 0, 54 + j] in frame 18 + j's carrier, zero in the others); (b) a frame whose predecessor in the ring does not hold
 //     its values -- the first frame after a reset (the history is zeroed, last_locomotion_action is not: go1.py:139-145) or
-//     registers written by the host: k_pre_policy compares bit for bit when it pushes a frame and records the position in
+//     registers written by the host: the push compares bit for bit and records the ring slot in
 //     DevState::hist_irr, and k_gemm_h2's epilogue adds W[., frame p, 54..65] (a2(p) - a1(p-1)) in f32 for those rows.
 #define MQE_H2_FRAME 48
 #define MQE_H2_FLAG_COL 46
 #define MQE_H2_CARRIER_COL 47
+#define MQE_H2_CARRIER0 18                 // logical positions MQE_H2_CARRIER0 .. +11 carry the oldest frame's last_two_locomotion_action
 // frame column -> compact column (-1: constant on the flag column, -2: folded onto the previous frame's columns 42..53)
 __host__ __device__ __forceinline__ int h2_col(int c) { return c < 6 ? c : (c < 18 ? -1 : (c < 54 ? c - 12 : (c < 66 ? -2 : c - 24))); }
 #define MQE_H2_ASCALE 64.0f                 // activation scale c_a: |x| <= 1023 representable, beyond that the value saturates

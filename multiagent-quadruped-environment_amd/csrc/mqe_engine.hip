@@ -369,12 +369,12 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   for (int k = 0; k < 2100; k++) krow[k] = (k / 70) * MQE_FRAME + (k % 70);
   // the split-f16 operand has its own K order: compact frames of MQE_H2_FRAME columns (mqe_common.hpp): the twelve constant gait
   // parameters of a frame folded onto its presence-flag column, its last_two_locomotion_action onto the previous frame's
-  // last_locomotion_action (the oldest frame's: component j onto the carrier column of frame j)
+  // last_locomotion_action (the oldest frame's: component j onto the carrier column of frame MQE_H2_CARRIER0 + j)
   std::vector<int> k2row(2100);
   std::vector<float> k2scale(2100);
   for (int k = 0; k < 2100; k++) {
     const int f = k / 70, c = k % 70, cc = h2_col(c);
-    if (cc == -2) k2row[k] = f > 0 ? (f - 1) * MQE_H2_FRAME + h2_col(c - 12) : (c - 54) * MQE_H2_FRAME + MQE_H2_CARRIER_COL;
+    if (cc == -2) k2row[k] = f > 0 ? (f - 1) * MQE_H2_FRAME + h2_col(c - 12) : (MQE_H2_CARRIER0 + c - 54) * MQE_H2_FRAME + MQE_H2_CARRIER_COL;
     else k2row[k] = f * MQE_H2_FRAME + (cc >= 0 ? cc : MQE_H2_FLAG_COL);
     k2scale[k] = cc == -1 ? d->command_obs[c] : 1.0f;
   }
@@ -438,6 +438,8 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   DA(st.loco_obs, (size_t)R * MQE_FRAME); DA(st.hist, (size_t)R * MQE_HIST * MQE_FRAME);
   st.hist2 = nullptr;
   st.hist_irr = nullptr;
+  st.wave_times = nullptr;
+  if (getenv("MQE_WAVE_TIMES")) { DA(st.wave_times, (size_t)2 * N); }
   if (s->gemm_split) { DA(st.hist2, (size_t)2 * R * MQE_HIST * MQE_H2_FRAME); DA(st.hist_irr, (size_t)R); }
   DA(st.last_loco, (size_t)R * 12); DA(st.last_two_loco, (size_t)R * 12); DA(st.act_hist, (size_t)4 * R * 12);
   DA(st.gait, R); DA(st.clock, (size_t)R * 4); DA(st.blv, (size_t)R * 3); DA(st.bav, (size_t)R * 3); DA(st.pg, (size_t)R * 3);
@@ -630,12 +632,13 @@ static int policy_step(mqe_sim* s, const float* command, hipStream_t q, const fl
 // first half of the policy: the frame of this step into the history ring (wrapper head included) and layer 0 of both networks
 static void policy_head(mqe_sim* s, const float* command, hipStream_t q, const float* wrapper_actions) {
   const int R = s->R;
+  const int slot = s->hist_pos;
+  s->hist_pos = (s->hist_pos + 1) % MQE_HIST;     // ring slot of the oldest frame
   {
     ProfScope ps(s, PROF_MISC, q);
     int n = R * MQE_FRAME;
-    hipLaunchKernelGGL(k_pre_policy, dim3((n + 255) / 256), dim3(256), 0, q, s->dm, s->st, command, s->hist_pos, wrapper_actions);
+    hipLaunchKernelGGL(k_pre_policy, dim3((n + 255) / 256), dim3(256), 0, q, s->dm, s->st, command, slot, wrapper_actions);
   }
-  s->hist_pos = (s->hist_pos + 1) % MQE_HIST;     // ring slot of the oldest frame
   {
     ProfScope ps(s, PROF_GEMM_L0, q);
     // fused layer 0 of both networks over the ring: ELU on the adaptation columns only
@@ -721,6 +724,13 @@ static void launch_post(mqe_sim* s, hipStream_t q, int wrapper_level) {
     hipLaunchKernelGGL(k_post_physics<MQE_MAX_AGENTS>, dim3((s->N + POST_EPW - 1) / POST_EPW), dim3(64), 0, q, s->dm, s->st, wrapper_level, push, s->n_post_steps);   // incl. history zeroing
 }
 
+extern "C" int mqe_debug_wave_times(mqe_sim* s, long long* out_host) {
+  if (!s) return fail(-1, "null engine handle");
+  if (!s->st.wave_times) return fail(-4, "create the handle with MQE_WAVE_TIMES=1");
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(out_host, s->st.wave_times, (size_t)2 * s->N * sizeof(long long), hipMemcpyDeviceToHost));
+  return 0;
+}
 extern "C" int mqe_debug_stop_phase(mqe_sim* s, int tap) {
   if (!s) return fail(-1, "null engine handle");
   if (tap >= 0 && !s->a2_scene) return fail(-4, "phase taps exist for two-robot scenes without objects only (k_simulate_a2)");

@@ -41,6 +41,7 @@ int main(int argc, char** argv) {
   Gemm2Args g;
   g.A = dA; g.lda = lda; g.a_rot8 = rot8; g.a_ring8 = ring8; g.W = dW; g.ldw = ldw; g.bias = dB; g.C = dC; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
   g.act_cols = argc > 4 ? atoi(argv[4]) : 256; g.descale = 1.0f / (MQE_H2_ASCALE * wscale);
+  g.irr = nullptr; g.ring = nullptr; g.ring_pos = 0; g.Wt32 = nullptr; g.ldwt = 0;      // no compact-history residuals in the harness
   CK(hipFuncSetAttribute((const void*)k_gemm_h2, hipFuncAttributeMaxDynamicSharedMemorySize, H2_LDS_BYTES));
   const int grid = ((M + H2_M - 1) / H2_M) * (N / H2_N);
   hipLaunchKernelGGL(k_gemm_h2, dim3(grid), dim3(H2_THREADS), H2_LDS_BYTES, 0, g);

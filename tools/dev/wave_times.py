@@ -1,0 +1,29 @@
+"""Spread of the run times of k_substeps' wavefronts inside one launch (MQE_WAVE_TIMES=1 -> mqe_debug_wave_times):
+    python tools/dev/wave_times.py [task] [num_envs] [steps]
+prints, for a few launches of a walking rollout, the percentiles of (exit - launch start) and of the wavefronts' own durations."""
+import os, sys, ctypes as C
+os.environ["MQE_WAVE_TIMES"] = "1"
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [os.path.join(ROOT, "tests"), os.path.join(ROOT, "multiagent-quadruped-environment_amd")]
+import numpy as np, torch
+from helpers import make_desc, hip_engine
+from mqe.engine import abi
+task = sys.argv[1] if len(sys.argv) > 1 else "go1gate"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 120
+d, k, _ = make_desc(task, n)
+e = hip_engine(d, k)
+e.reset_all()
+Aw = e.tensor(abi.T_WRAPPER_OBS).shape[1]
+g = torch.Generator(device="cuda"); g.manual_seed(1234)
+buf = np.zeros((n, 2), np.int64)
+for t in range(steps):
+    e.step(torch.rand(n, Aw, 3, device="cuda", generator=g) * 2 - 1)
+    if t in (5, 30, 60, 90, steps - 1):
+        e._call("debug_wave_times", C.c_void_p(buf.ctypes.data))
+        nw = int((buf[:, 1] > 0).sum())
+        b = buf[:nw].astype(np.float64) * 0.01            # 100 MHz -> us
+        t0 = b[:, 0].min()
+        end, dur, start = b[:, 1] - t0, b[:, 1] - b[:, 0], b[:, 0] - t0
+        pc = lambda x: " ".join(f"{np.percentile(x, q):7.1f}" for q in (0, 10, 50, 90, 99, 100))
+        print(f"step {t:3d} waves {nw}: start [{pc(start)}]  duration [{pc(dur)}]  exit [{pc(end)}] us  (min p10 p50 p90 p99 max)")
