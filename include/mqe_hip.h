@@ -316,7 +316,8 @@ int mqe_debug_times(long long* out16);   /* clock64 stamps of the phases of the 
  * The environment variable MQE_DEBUG_STOP_PHASE sets the same thing when the handle is created. */
 int mqe_debug_stop_phase(mqe_sim* s, int tap);
 /* handles created with MQE_WAVE_TIMES=1 in the environment: wall-clock stamps (100 MHz) of every wavefront of the last fused
- * decimation launch at entry and exit, [num wavefronts][2] (tools/dev/wave_times.py: the spread of the wavefronts' run times) */
+ * decimation launch at entry and exit + its HW_ID and XCC_ID registers, [num wavefronts][4] (tools/dev/wave_times.py: the spread
+ * of the wavefronts' run times and where the dispatcher put them) */
 int mqe_debug_wave_times(mqe_sim* s, long long* out_host);
 
 /* bookkeeping for benchmarks: time of the dominant kernel measured with HIP events on `stream` */

@@ -2015,7 +2015,11 @@ __global__ void __launch_bounds__(64, EPW == 2 ? 2 : SubstepsClass<TP>::waves) k
   constexpr int launder = EPW == 2 ? 2 : SubstepsClass<TP>::launder;     // hoisting everything overflows even 256 VGPRs (43 spilled)
 #endif
   const int lane_wave = threadIdx.x, e_first = blockIdx.x * EPW;
-  if (st.wave_times && lane_wave == 0) st.wave_times[2 * blockIdx.x] = (long long)wall_clock64();      // MQE_WAVE_TIMES (tools/dev/wave_times.py)
+  if (st.wave_times && lane_wave == 0) {      // MQE_WAVE_TIMES (tools/dev/wave_times.py): entry / exit time, HW_ID and XCC_ID of the wavefront
+    st.wave_times[4 * blockIdx.x] = (long long)wall_clock64();
+    st.wave_times[4 * blockIdx.x + 2] = (long long)__builtin_amdgcn_s_getreg(0xF804);
+    st.wave_times[4 * blockIdx.x + 3] = (long long)__builtin_amdgcn_s_getreg(0xF814);
+  }
   const int grp = EPW == 1 ? 0 : lane_wave / LW, lane = EPW == 1 ? lane_wave : lane_wave - grp * LW;
   const bool evalid = EPW == 1 || e_first + grp < m->N;
   const int e = evalid ? e_first + grp : m->N - 1;
@@ -2046,6 +2050,8 @@ __global__ void __launch_bounds__(64, EPW == 2 ? 2 : SubstepsClass<TP>::waves) k
     // Wave priority by progress.  At equal priority the SIMD's arbiter prefers its oldest wave: the four waves of a SIMD then finish
     // one after the other (lifetimes 81 .. 131 us measured) and the last one runs alone, with nobody to hide its latencies.  A wave
     // that is a substep behind goes first instead, so the four stay abreast and finish together: go1gate 136.6 -> 120.5 us.
+    // (Finer steps inside the last substep -- 3,3,2,1 and 0 from the sweep on -- do not help: A/B 117.3 vs 117.2 us; the exits of a
+    // SIMD's four waves still spread by +-5 us, tools/dev/wave_times.py, but the SIMD is busy until the last one leaves.)
     if (k == 0) __builtin_amdgcn_s_setprio(3); else if (k == 1) __builtin_amdgcn_s_setprio(2); else if (k == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
     // Register budget vs. recomputation (measured, MI355X).  Everything the body derives from the lane id and
     // the model alone (indices, LDS addresses, masks, per-lane model constants: ~330 VALU instructions, ~100 values) is invariant over
@@ -2168,5 +2174,5 @@ __global__ void __launch_bounds__(64, EPW == 2 ? 2 : SubstepsClass<TP>::waves) k
       const int w = i / nj, jt = i - w * nj;
       st.act_hist[(size_t)w * R12 + (size_t)e * nj + jt] = acth[i];
     }
-  if (st.wave_times && lane_wave == 0) st.wave_times[2 * blockIdx.x + 1] = (long long)wall_clock64();
+  if (st.wave_times && lane_wave == 0) st.wave_times[4 * blockIdx.x + 1] = (long long)wall_clock64();
 }

@@ -66,7 +66,7 @@ struct DevState {
   float* sub_dof_vel; uint8_t* sub_exceed; int32_t* overflow;   // per-substep logs (legged_robot.py:114-115); truncated-contact-list counter
   float *dparams, *lag_buf;                 // [R][8] friction / added mass / CoM shift (MQE_T_DOMAIN_PARAMS); [(lag + 1)][R][12] scaled actions
   uint16_t* hist2;                          // compact split-f16 copy of the history ring: [R][180 units][2 planes][8] (k_gemm_h2; MQE_H2_FRAME)
-  long long* wave_times;                    // debug (MQE_WAVE_TIMES=1): [waves of k_substeps][2] wall_clock64 at entry / exit, else null
+  long long* wave_times;                    // debug (MQE_WAVE_TIMES=1): [waves of k_substeps][4] wall_clock64 at entry / exit, HW_ID, XCC_ID, else null
   uint32_t* hist_irr;                       // [R] bit s: the frame in ring slot s does not continue its predecessor's actions (MQE_H2_FRAME)
   int32_t *ep_len, *reset_count;
   uint8_t *reset_buf, *collide_buf, *time_out, *r_term, *p_term, *zh_term, *w_have_last, *w_delayed_reset;

@@ -439,7 +439,7 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   st.hist2 = nullptr;
   st.hist_irr = nullptr;
   st.wave_times = nullptr;
-  if (getenv("MQE_WAVE_TIMES")) { DA(st.wave_times, (size_t)2 * N); }
+  if (getenv("MQE_WAVE_TIMES")) { DA(st.wave_times, (size_t)4 * N); }
   if (s->gemm_split) { DA(st.hist2, (size_t)2 * R * MQE_HIST * MQE_H2_FRAME); DA(st.hist_irr, (size_t)R); }
   DA(st.last_loco, (size_t)R * 12); DA(st.last_two_loco, (size_t)R * 12); DA(st.act_hist, (size_t)4 * R * 12);
   DA(st.gait, R); DA(st.clock, (size_t)R * 4); DA(st.blv, (size_t)R * 3); DA(st.bav, (size_t)R * 3); DA(st.pg, (size_t)R * 3);
@@ -728,7 +728,7 @@ extern "C" int mqe_debug_wave_times(mqe_sim* s, long long* out_host) {
   if (!s) return fail(-1, "null engine handle");
   if (!s->st.wave_times) return fail(-4, "create the handle with MQE_WAVE_TIMES=1");
   HIPCHK(hipDeviceSynchronize());
-  HIPCHK(hipMemcpy(out_host, s->st.wave_times, (size_t)2 * s->N * sizeof(long long), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(out_host, s->st.wave_times, (size_t)4 * s->N * sizeof(long long), hipMemcpyDeviceToHost));
   return 0;
 }
 extern "C" int mqe_debug_stop_phase(mqe_sim* s, int tap) {

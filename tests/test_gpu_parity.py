@@ -185,6 +185,40 @@ def test_fused_rollout_matches_oracle(task, N):
     assert int(eh.tensor(abi.T_CONTACT_OVERFLOW).sum()) == int(eo.tensor(abi.T_CONTACT_OVERFLOW).sum())
 
 
+def test_fused_rollout_past_the_history_horizon():
+    """The 20-step rollouts above stop before the 30-frame history has filled; this one runs go1gate for 60 fused steps with nothing
+    re-synchronised, i.e. through the regime the policy spends its life in (full ring, hidden activations of the adaptation module
+    beyond 1000, time-outs and falls -> frames after a reset).  Chaotic growth is what it is (contacts), so the bounds are on the
+    distribution: median and 90th percentile of the base-position deviation, and on the reset flags of the envs whose robots are
+    still within 1 mm of the oracle's."""
+    N = 128
+    eh, eo, d = _pair("go1gate", N)
+    eh.reset_all(); eo.reset_all()
+    g = torch.Generator().manual_seed(23)
+    dev = None
+    agree = torch.ones(N, dtype=torch.bool)
+    mism = 0
+    for t in range(60):
+        a = torch.rand(N, 2, 3, generator=g) * 2 - 1
+        eh.step(a.cuda().contiguous()); eo.step(a)
+        torch.cuda.synchronize()
+        rh, ro = eh.tensor(abi.T_ROOT_STATE).cpu(), eo.tensor(abi.T_ROOT_STATE)
+        rbh, rbo = eh.tensor(abi.T_RESET_BUF).cpu(), eo.tensor(abi.T_RESET_BUF)
+        mism += int(((rbh != rbo) & agree).sum())
+        dev = (rh[..., :3] - ro[..., :3]).abs().amax(dim=(-1, -2))
+        agree &= (dev < 1e-3) & (rbh == rbo)
+        if t == 39:
+            d40 = (float(dev.median()), float(dev.quantile(0.9)))
+    d60 = (float(dev.median()), float(dev.quantile(0.9)))
+    _record("rollout_long", {"task": "go1gate", "N": N, "median_p90_after_40": d40, "median_p90_after_60": d60, "envs_still_within_1mm": int(agree.sum())})
+    assert torch.isfinite(dev).all()
+    assert mism == 0, f"{mism} reset-flag mismatches in envs that were still within 1 mm"
+    # measured (MI355X, round 3): median / p90 after 40 steps 2.4e-7 / 4.8e-7 m, after 60 steps 3.6e-7 / 5.1e-7 m, all 128 envs within 1 mm
+    assert d40[0] < 5e-6 and d40[1] < 2e-5, d40
+    assert d60[0] < 1e-5 and d60[1] < 5e-5, d60
+    assert int(agree.sum()) >= N - N // 8, int(agree.sum())
+
+
 @pytest.mark.parametrize("task,N", [("go1gate", 256), ("go1seesaw", 64), ("go1tug", 32)])
 def test_row_sweep_and_lane_sweep_agree(monkeypatch, task, N):
     """The contact sweep has two lane mappings (kernels_physics.hpp: one DPP row per actor for scenes of robots and the 1-dof link,

@@ -16,7 +16,7 @@ e = hip_engine(d, k)
 e.reset_all()
 Aw = e.tensor(abi.T_WRAPPER_OBS).shape[1]
 g = torch.Generator(device="cuda"); g.manual_seed(1234)
-buf = np.zeros((n, 2), np.int64)
+buf = np.zeros((n, 4), np.int64)
 for t in range(steps):
     e.step(torch.rand(n, Aw, 3, device="cuda", generator=g) * 2 - 1)
     if t in (5, 30, 60, 90, steps - 1):
@@ -26,4 +26,20 @@ for t in range(steps):
         t0 = b[:, 0].min()
         end, dur, start = b[:, 1] - t0, b[:, 1] - b[:, 0], b[:, 0] - t0
         pc = lambda x: " ".join(f"{np.percentile(x, q):7.1f}" for q in (0, 10, 50, 90, 99, 100))
+        hw, xcc = buf[:nw, 2], buf[:nw, 3] & 0xF
+        simd, cu, sh, se = (hw >> 4) & 3, (hw >> 8) & 15, (hw >> 12) & 1, (hw >> 13) & 7
+        key = ((((xcc * 8 + se) * 2 + sh) * 16 + cu) * 4 + simd)
+        if t == steps - 1:
+            uniq, inv, cnt = np.unique(key, return_inverse=True, return_counts=True)
+            print("SIMDs used", len(uniq), "waves per SIMD: min", cnt.min(), "max", cnt.max())
+            # do the waves of one SIMD leave together?  spread of exits inside a SIMD vs between SIMD means
+            mean_exit = np.bincount(inv, weights=end) / cnt
+            within = np.sqrt(np.bincount(inv, weights=(end - mean_exit[inv]) ** 2).sum() / nw)
+            print(f"exit: std within a SIMD {within:.2f} us, std of SIMD means {mean_exit.std():.2f} us, std of all {end.std():.2f} us")
+            lastexit = np.zeros(len(uniq)); np.maximum.at(lastexit, inv, end)
+            print("last exit per SIMD percentiles [" + pc(lastexit) + "]")
+            for b in (0, 1, 2, 3, 8, 9, 1024, 2048, 3072):
+                print("  block", b, "xcc", xcc[b], "se", se[b], "sh", sh[b], "cu", cu[b], "simd", simd[b], "wave slot", hw[b] & 15)
+            # which block ids share a SIMD with block 0?
+            print("  blocks on block 0's SIMD:", np.nonzero(key == key[0])[0].tolist(), " on block 8's:", np.nonzero(key == key[8])[0].tolist())
         print(f"step {t:3d} waves {nw}: start [{pc(start)}]  duration [{pc(dur)}]  exit [{pc(end)}] us  (min p10 p50 p90 p99 max)")
