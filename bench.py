@@ -39,6 +39,7 @@ PROF_KERNEL = ["k_gemm_h2", "k_gemm_f32", "k_compute_torques_mfma", "k_substeps"
 PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak
 PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16 / bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec peak
+K_SPLIT = 30 * 48               # K of k_gemm_h2 over the history: MQE_HIST frames x MQE_H2_FRAME compact columns (csrc/mqe_common.hpp; tests/test_abi.py keeps the two in step)
 
 
 def make_args(task, num_envs, seed, device):
@@ -288,10 +289,11 @@ def main():
         # ---- policy layer 0: the one MFMA-bound kernel
         l0_ms = max(avg_ms(0), 1e-9)
         flops32 = 2.0 * R * 2100 * (h_a + h_b)                        # algorithmic: unpadded K = 30 x 70, f32 products
-        if split:   # every f32 product = three f16 x f16 terms on the matrix cores, K = 30 compact frames of 64 (58 changing columns + flag + pads)
+        if split:   # every f32 product = three f16 x f16 terms on the matrix cores, K = 30 compact frames of MQE_H2_FRAME = 48 columns (mqe_common.hpp)
             l0 = {"kernel": "k_gemm_h2 (fused layer 0 of adaptation+body MLP over the history ring; 2-plane split-f16 operands, 3 MFMA terms per product, f32-class accuracy)",
-                  "bound": "mfma", "achieved": round(3 * 2.0 * R * 1920 * (h_a + h_b) / (l0_ms * 1e-3) / 1e12, 2), "peak": PEAK_F16_MFMA_TFLOPS,
-                  "unit": "TFLOP/s", "f32_equivalent_TFLOPs": round(flops32 / (l0_ms * 1e-3) / 1e12, 2)}
+                  "bound": "mfma", "achieved": round(3 * 2.0 * R * K_SPLIT * (h_a + h_b) / (l0_ms * 1e-3) / 1e12, 2), "peak": PEAK_F16_MFMA_TFLOPS,
+                  "unit": "TFLOP/s", "f32_equivalent_TFLOPs": round(flops32 / (l0_ms * 1e-3) / 1e12, 2), "executed_K": K_SPLIT,
+                  "flops_basis": "executed f16 MFMA flops: 3 terms x 2 R (256 + 512) x K, K = 30 frames x 48 compact columns (12 constant and 12 repeated columns of the 70 are folded into the weights)"}
         else:
             l0 = {"kernel": "k_gemm_f32 (fused layer 0, exact f32 MFMA)", "bound": "mfma", "achieved": round(flops32 / (l0_ms * 1e-3) / 1e12, 3),
                   "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s"}

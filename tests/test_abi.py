@@ -43,3 +43,14 @@ def test_product_refuses_without_gpu():
     d, k, _ = make_desc("go1gate", 2)
     with pytest.raises(RuntimeError, match="no CPU path"):
         HipEngine(d, k)
+
+
+def test_bench_flop_basis_matches_the_kernel_constants():
+    """bench.py prices k_gemm_h2 with the K it executes: MQE_HIST frames x MQE_H2_FRAME compact columns (csrc/mqe_common.hpp)."""
+    import re
+    src = open(os.path.join(ROOT, "multiagent-quadruped-environment_amd", "csrc", "mqe_common.hpp")).read()
+    frame = int(re.search(r"#define MQE_H2_FRAME (\d+)", src).group(1))
+    hist = int(re.search(r"#define MQE_HIST (\d+)", open(os.path.join(ROOT, "include", "mqe_hip.h")).read()).group(1))
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    k = re.search(r"^K_SPLIT = (\d+) \* (\d+)", bench, re.M)
+    assert (int(k.group(1)), int(k.group(2))) == (hist, frame)
