@@ -205,6 +205,11 @@ typedef struct {
 enum {
   MQE_T_ROOT_STATE = 0, MQE_T_DOF_STATE, MQE_T_CONTACT_FORCE, MQE_T_TORQUES, MQE_T_ACTIONS, MQE_T_LAST_ACTIONS,
   MQE_T_LOCOMOTION_OBS, MQE_T_HISTORY, MQE_T_LAST_LOCO_ACTION, MQE_T_LAST_TWO_LOCO_ACTION,
+                           /* MQE_T_HISTORY [R][MQE_HIST][72] is the f32 ring (slot order; the newest frame sits in the slot written last).  It is an
+                              OUTPUT view: large batches run layer 0 on a compact split-f16 copy that the engine maintains frame by frame
+                              (csrc/mqe_common.hpp, MQE_H2_FRAME), so host writes into the ring do not reach the policy there.  The action
+                              registers, the observation bag and every other state tensor ARE inputs of the next step.  (Handles created
+                              with MQE_GEMM_SPLIT=0 read the ring itself.) */
   MQE_T_ACT_HIST,          /* [4][R][12]: pos_err_last, pos_err_last_last, vel_last, vel_last_last */
   MQE_T_GAIT_INDICES, MQE_T_CLOCK_INPUTS,
   MQE_T_BASE_LIN_VEL, MQE_T_BASE_ANG_VEL, MQE_T_PROJECTED_GRAVITY, MQE_T_BASE_QUAT,
