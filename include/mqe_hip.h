@@ -272,7 +272,7 @@ int mqe_post_decimation_step(mqe_sim* s, int dec_i, void* stream);
 /* post_physics_step (legged_robot_field.py:117-119 -> legged_robot.py:117-157) incl. termination, NPC script,
  * in-kernel reset, compute_observations, and the task wrapper's observation / reward */
 int mqe_post_physics_step(mqe_sim* s, void* stream);
-/* task wrapper observation + reward only (mqe/envs/wrappers/*.py step()/reset() bodies) from the current contents of
+/* task wrapper observation + reward only (mqe/envs/wrappers/go1_<task>_wrapper.py step()/reset() bodies) from the current contents of
  * MQE_T_OBS_BAG, MQE_T_ROOT_STATE (NPC rows), the termination flags and MQE_T_SHEEP_POS_*; part of
  * mqe_post_physics_step / mqe_reset_all, exposed separately so the wrappers can be checked against golden vectors */
 int mqe_wrapper_eval(mqe_sim* s, int is_reset_call, void* stream);

@@ -6,7 +6,7 @@
  * Pinning status:
  *   - everything AROUND the physics (policy MLPs, torque pipeline, command observation/history, gait clock,
  *     termination, reset bookkeeping, observation bag, task wrappers, NPC scripts) restates the reference's
- *     Python line by line (citations at each function) and is pinned by tests/golden/*.npz, which were produced
+ *     Python line by line (citations at each function) and is pinned by the .npz files of tests/golden, which were produced
  *     by importing that Python (tools/gen_golden.py).
  *   - the rigid-body physics (mqo_simulate) has NO reference to restate: in MQE it lives inside Isaac Gym
  *     Preview 4 / PhysX (closed source, CUDA only; call sites go1.py:52-56).  PARITY UNPINNED for that row: the
