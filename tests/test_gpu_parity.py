@@ -219,6 +219,41 @@ def test_fused_rollout_past_the_history_horizon():
     assert int(agree.sum()) >= N - N // 8, int(agree.sum())
 
 
+@pytest.mark.parametrize("task,N", [("go1gate", 64), ("go1sheep-hard", 10)])
+def test_time_outs_bring_both_engines_back_to_the_same_state(task, N):
+    """Episodes of 35 steps, 110 fused steps: every env times out three times (on top of whatever falls in between).  The in-kernel
+    reset draws its state from the hash RNG keyed by (seed, global env id, the env's reset count), so whatever the two trajectories
+    did to each other before a time-out, a few steps after it both engines are back within rounding of each other: the deviation of
+    the base positions is checked 4 steps after each wave of time-outs, the reset flags at every step for the envs that still agree."""
+    eh, eo, d = _pair(task, N, max_episode_length=35)
+    eh.reset_all(); eo.reset_all()
+    g = torch.Generator().manual_seed(29)
+    Aw = eo.tensor(abi.T_WRAPPER_OBS).shape[1]
+    agree = torch.ones(N, dtype=torch.bool)
+    after, n_time_outs, mism = [], 0, 0
+    since = torch.full((N,), 1000)
+    for t in range(110):
+        a = torch.rand(N, Aw, 3, generator=g) * 2 - 1
+        eh.step(a.cuda().contiguous()); eo.step(a)
+        torch.cuda.synchronize()
+        rh, ro = eh.tensor(abi.T_ROOT_STATE).cpu(), eo.tensor(abi.T_ROOT_STATE)
+        rbh, rbo = eh.tensor(abi.T_RESET_BUF).cpu().bool(), eo.tensor(abi.T_RESET_BUF).bool()
+        dev = (rh[..., :3] - ro[..., :3]).abs().amax(dim=(-1, -2))
+        mism += int(((rbh != rbo) & agree).sum())
+        n_time_outs += int(eo.tensor(abi.T_TIME_OUT_BUF).sum())
+        both = rbh & rbo
+        since = torch.where(both, torch.zeros_like(since), since + 1)
+        agree = torch.where(both, torch.ones_like(agree), agree & (dev < 1e-3) & (rbh == rbo))
+        sel = since == 4
+        if sel.any():
+            after.append(dev[sel])
+    after = torch.cat(after)
+    _record("time_out_resync", {"task": task, "N": N, "time_outs": n_time_outs, "checked": int(after.numel()), "median": float(after.median()), "max": float(after.max())})
+    assert n_time_outs >= 2 * N and after.numel() >= 2 * N
+    assert mism == 0, f"{mism} reset-flag mismatches in envs that still agreed"
+    assert float(after.median()) < 1e-6 and float(after.quantile(0.95)) < 1e-5, (float(after.median()), float(after.max()))
+
+
 @pytest.mark.parametrize("task,N", [("go1gate", 256), ("go1seesaw", 64), ("go1tug", 32)])
 def test_row_sweep_and_lane_sweep_agree(monkeypatch, task, N):
     """The contact sweep has two lane mappings (kernels_physics.hpp: one DPP row per actor for scenes of robots and the 1-dof link,
