@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MQE_ABI_VERSION 12
+#define MQE_ABI_VERSION 13
 #define MQE_MAX_SPHERES 32    /* feature points of one robot */
 #define MQE_MAX_PRIMS 20      /* collision primitives of one robot (Go1: 18) */
 #define MQE_MAX_SELF_PAIRS 192
@@ -149,6 +149,16 @@ typedef struct {
   float command_obs[70];                  /* _fill_command_obs (go1.py:411-479) */
   float cmd_lin_scale, cmd_ang_scale;     /* 2.0, 0.25 */
   int32_t clip_command;                   /* 1: Go1.step re-clips to +-1 (go1.py:38); 0: defender variant */
+  /* Which column of the command row feeds entry c (0..17) of the locomotion observation (Go1.preprocess_action, go1.py:64-93, with the
+   * slots that _fill_command_obs assigns for command.cfg.{vel, body_height, gait_freq, footswing_height, body_pose, stance_width,
+   * stance_length, aux_reward}, go1.py:411-479): -1 = the constant command_obs[c]; otherwise row[command_src[c]] * command_scale[c]
+   * (control.obs_scales).  Shipped configs: entries 3, 4, 5 <- columns 0, 1, 2, everything else constant, num_command_dims = 3.
+   * num_command_dims = width of the rows handed to mqe_policy_step / mqe_step_begin.  Anything but the default is served by the
+   * unfused entry points and the exact-f32 layer-0 kernel; the fused wrapper-level mqe_step refuses it (the task wrappers'
+   * (N, A, 3) action scaling cannot carry more columns upstream either). */
+  int32_t num_command_dims;
+  int32_t command_src[18];
+  float command_scale[18];
   /* terrain: 2D signed distance [m] to the wall set, raster entry (i, j) at the world point (i hs, j hs) = the vertices of the BarrierTrack heightfield mesh */
   const float* wall_sdf;                  /* host pointer, [sdf_nx][sdf_ny] */
   int32_t sdf_nx, sdf_ny;

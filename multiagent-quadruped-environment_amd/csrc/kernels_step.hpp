@@ -113,7 +113,15 @@ __device__ __forceinline__ PreVal pre_policy_load(const DevModel* m, const DevSt
   PreVal r; r.aux = 0.0f; r.mk = 0u;
   float v;
   if (c < 3) v = ob[60 + c];                                   // projected gravity      :95
-  else if (c < 6) {                                            // velocity command       :67-68 (+ clip :38)
+  else if (c < 18 && m->cmd_general) {                         // command.cfg beyond / without the velocity command (go1.py:66-93): desc.command_src
+    const int src = m->cmd_src[c];
+    if (src < 0) v = m->command_obs[c];
+    else {
+      float x = command[(size_t)i * m->cmd_dims + src];
+      if (m->clip_command) x = clampf(x, -1.0f, 1.0f);         // Go1.step clips the whole action row (go1.py:38)
+      v = x * m->cmd_scale[c];
+    }
+  } else if (c < 6) {                                          // velocity command       :67-68 (+ clip :38)
     float x;
     if (wrapper_actions) {
       const int A = m->A, Aw = m->Aw, e = i / A, a = i - e * A, k = c - 3;

@@ -40,6 +40,7 @@ struct DevModel {
   float ss_inertia, ss_vel_limit, ss_col_radius, ss_col_length, ss_theta_lo, ss_theta_hi;
   int control_type; float action_scale, hip_scale_reduction, clip_actions; float torque_limits[12]; float kp, kd;
   float default_dof_pos[12]; float command_obs[70]; float cmd_lin_scale, cmd_ang_scale; int clip_command;
+  int cmd_dims, cmd_general; int cmd_src[18]; float cmd_scale[18];      // desc.command_src / command_scale; cmd_general: not the shipped (x, y, yaw) layout
   const float* wall_sdf; int sdf_nx, sdf_ny; float hs, wall_height, ground_z;
   const float* wall_top;                           // per-cell wall top [m] (walls of different heights), or nullptr = wall_height
   const float* ground_height;                      // relief of the walkable surface above ground_z at the SDF's raster points, or nullptr

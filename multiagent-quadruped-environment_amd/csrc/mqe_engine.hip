@@ -62,6 +62,7 @@ struct mqe_sim {
   float *P1 = nullptr, *bufA = nullptr, *bufB = nullptr, *lat = nullptr, *act_out = nullptr;
   int ldP1, ldbuf, ldlat, ldact;
   bool gemm_split = false;
+  bool cmd_general = false;           // command layout other than (x, y, yaw) -> entries 3-5 (desc.command_src): unfused entry points, exact-f32 layer 0
   bool tail_fused = false;            // k_policy_tail: the reference network shapes (256-128-2 / 512-256-128-12 after layer 0)
   size_t phys_lds_bytes = 0;
   bool fuse_substeps = true;
@@ -268,6 +269,14 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   m.kp = d->kp; m.kd = d->kd; memcpy(m.default_dof_pos, d->default_dof_pos, sizeof m.default_dof_pos);
   memcpy(m.command_obs, d->command_obs, sizeof m.command_obs);
   m.cmd_lin_scale = d->cmd_lin_scale; m.cmd_ang_scale = d->cmd_ang_scale; m.clip_command = d->clip_command;
+  m.cmd_dims = d->num_command_dims; m.cmd_general = d->num_command_dims != 3;
+  for (int c = 0; c < 18; c++) {
+    m.cmd_src[c] = d->command_src[c]; m.cmd_scale[c] = d->command_scale[c];
+    if (d->command_src[c] >= d->num_command_dims) return fail(-6, "command_src points past num_command_dims");
+    if (d->command_src[c] != (c >= 3 && c < 6 ? c - 3 : -1)) m.cmd_general = 1;
+  }
+  if (d->num_command_dims < 1) return fail(-6, "num_command_dims must be >= 1");
+  s->cmd_general = m.cmd_general != 0;
   m.sdf_nx = d->sdf_nx; m.sdf_ny = d->sdf_ny; m.hs = d->horizontal_scale; m.wall_height = d->wall_height; m.ground_z = d->ground_z;
   m.termination_flags = d->termination_flags; m.terminate_on_base_contact = d->terminate_on_base_contact; m.max_episode_length = d->max_episode_length;
   m.roll_thr = d->roll_threshold; m.pitch_thr = d->pitch_threshold; m.zlow_thr = d->z_low_threshold; m.zhigh_thr = d->z_high_threshold;
@@ -399,7 +408,7 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
     const char* f = getenv("MQE_GEMM_SPLIT");
     const double rounds = std::ceil(((R + H2_M - 1) / H2_M) * (double)(s->l0.Npad / H2_N) / 256.0);
     const bool faster = rounds * 80.0 < 255.0 * R / 8192.0;
-    s->gemm_split = s->l0.Npad % H2_N == 0 && (f ? atoi(f) != 0 : faster);
+    s->gemm_split = s->l0.Npad % H2_N == 0 && (f ? atoi(f) != 0 : faster) && !s->cmd_general;      // the compact operand folds entries 6-17 into its weights
   }
   if (s->gemm_split) {
     if (finalize_layer(s, &s->l0)) return fail(-5, "upload");
@@ -834,6 +843,7 @@ extern "C" int mqe_step(mqe_sim* s, const float* actions, void* stream) {
   if (!s) return fail(-1, "null engine handle");
   hipStream_t q = (hipStream_t)stream;
   if (s->d.control_type != MQE_CTRL_C) return fail(-7, "mqe_step drives the hierarchical controller (control type C); use mqe_step_joint for P / V / T");
+  if (s->cmd_general) return fail(-7, "mqe_step takes wrapper-level (N, A', 3) actions; this handle's command layout (desc.command_src) is served by mqe_policy_step + the stage entry points");
   s->prof_now = s->prof && (s->prof_step++ % s->prof_every == 0);
   policy_step(s, s->st.cmd, q, actions);         // wrapper head (clip, task action scale, scripted defender) inside k_pre_policy
   return run_substeps_and_post(s, q);
@@ -844,6 +854,7 @@ extern "C" int mqe_step_begin(mqe_sim* s, const float* actions, void* stream) {
   hipStream_t q = (hipStream_t)stream;
   if (s->d.control_type != MQE_CTRL_C) return fail(-7, "mqe_step_begin drives the hierarchical controller (control type C)");
   if (s->step_open) return fail(-8, "mqe_step_begin: the previous step was not closed with mqe_step_end");
+  if (s->cmd_general) return fail(-7, "mqe_step_begin takes wrapper-level (N, A', 3) actions; this handle's command layout (desc.command_src) is served by mqe_policy_step + the stage entry points");
   s->prof_now = s->prof && (s->prof_step++ % s->prof_every == 0);
   policy_step(s, s->st.cmd, q, actions);
   s->step_open = 2;
@@ -855,6 +866,7 @@ extern "C" int mqe_step_head(mqe_sim* s, const float* actions, void* stream) {
   if (!s) return fail(-1, "null engine handle");
   if (s->d.control_type != MQE_CTRL_C) return fail(-7, "mqe_step_head drives the hierarchical controller (control type C)");
   if (s->step_open) return fail(-8, "mqe_step_head: the previous step was not closed with mqe_step_end");
+  if (s->cmd_general) return fail(-7, "mqe_step_head takes wrapper-level (N, A', 3) actions; this handle's command layout (desc.command_src) is served by mqe_policy_step + the stage entry points");
   s->prof_now = s->prof && (s->prof_step++ % s->prof_every == 0);
   policy_head(s, s->st.cmd, (hipStream_t)stream, actions);
   s->step_open = 1;

@@ -1,7 +1,7 @@
 """ctypes mirror of include/mqe_hip.h (keep in sync; tests/test_abi.py checks sizes against the built library)."""
 import ctypes as C
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 MAX_SPHERES, NBODY, NREP, NDOF = 32, 13, 17, 12
 MAX_SELF_PAIRS = 192
 MAX_PRIMS = 20
@@ -68,6 +68,7 @@ class SimDesc(C.Structure):
         ("control_type", i32), ("action_scale", f32), ("hip_scale_reduction", f32), ("clip_actions", f32),
         ("torque_limits", f32 * NDOF), ("kp", f32), ("kd", f32), ("default_dof_pos", f32 * NDOF),
         ("command_obs", f32 * 70), ("cmd_lin_scale", f32), ("cmd_ang_scale", f32), ("clip_command", i32),
+        ("num_command_dims", i32), ("command_src", i32 * 18), ("command_scale", f32 * 18),
         ("wall_sdf", FP), ("sdf_nx", i32), ("sdf_ny", i32),
         ("horizontal_scale", f32), ("wall_height", f32), ("ground_z", f32), ("ground_height", FP), ("wall_top", FP), ("soft_dof_pos_limit", f32),
         ("env_origins", FP), ("agent_origins", FP), ("base_init_state", FP), ("npc_init_state", FP), ("gate_pos", FP),

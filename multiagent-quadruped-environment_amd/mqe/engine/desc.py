@@ -296,15 +296,25 @@ def build_desc(cfg, num_envs, terrain, env_origins, agent_origins, gate_pos=None
     d.kp = next((v for k, v in ctl.stiffness.items() if k in names[0]), 0.0)
     d.kd = next((v for k, v in ctl.damping.items() if k in names[0]), 0.0)
     cmd, idx = fill_command_obs(cfg)
-    if idx != {"vel": 0}:
-        # go1.py:64-92 lets command.cfg.{body_height, gait_freq, footswing_height, body_pose, stance_width, stance_length, aux_reward}
-        # turn further action columns into live entries 6-17 of the locomotion observation (and vel = False freezes the velocity
-        # command).  The engine's action is the (x, y, yaw) velocity command only: columns 6-17 are constants of the scene, folded into
-        # the layer-0 operand when the handle is created ("compact K").  No shipped task sets these flags and the task
-        # wrappers' (N, A, 3) action scaling could not carry them either; refuse instead of running with the slots silently at 0.
-        extra = sorted(k for k in idx if k != "vel") + ([] if "vel" in idx else ["vel = False"])
-        raise NotImplementedError("command.cfg flags beyond the velocity command are not supported by the HIP engine: " + ", ".join(extra) +
-                                  " (reference go1.py:64-92; the gait parameters are fixed when the engine is created)")
+    if "gait" in idx:
+        # the reference raises in preprocess_action itself (go1.py:76-77)
+        raise NotImplementedError("command.cfg.gait: not implemented upstream either (go1.py:76-77 raises NotImplementedError)")
+    # Go1.preprocess_action (go1.py:64-93): which action column feeds which entry of the locomotion observation.  Shipped configs:
+    # only the velocity command (entries 3-5 <- columns 0-2); further flags turn entries 6-17 from constants of the scene into inputs.
+    sc = ctl.obs_scales
+    slots = {"vel": ((3, sc.lin_vel), (4, sc.lin_vel), (5, sc.ang_vel)), "body_height": ((6, sc.body_height),), "gait_freq": ((7, sc.gait_freq),),
+             "footswing_height": ((12, sc.footswing_height),), "body_pose": ((13, sc.body_pitch), (14, sc.body_roll)),
+             "stance_width": ((15, sc.stance_width),), "stance_length": ((16, sc.stance_length),), "aux_reward": ((17, sc.aux_reward),)}
+    for c in range(18):
+        d.command_src[c], d.command_scale[c] = -1, 0.0
+    width = 0
+    for flag, first in idx.items():
+        for j, (c, scale) in enumerate(slots[flag]):
+            d.command_src[c], d.command_scale[c] = first + j, float(scale)
+        width = max(width, first + len(slots[flag]))
+    if width == 0:
+        raise NotImplementedError("command.cfg switches every command off: Go1.step would take actions of width 0")
+    d.num_command_dims = width
     for k in range(70):
         d.command_obs[k] = cmd[k]
     d.cmd_lin_scale, d.cmd_ang_scale = ctl.obs_scales.lin_vel, ctl.obs_scales.ang_vel

@@ -302,7 +302,7 @@ class Go1:
             self.engine.step_joint(a)
             self.common_step_counter += 1
             return self.obs_buf, self.rew_buf, self.reset_buf, self.extras
-        cmd = action.reshape(-1, 3).to(self.engine.torch_device, torch.float32).contiguous()
+        cmd = action.reshape(-1, self.engine.desc.num_command_dims).to(self.engine.torch_device, torch.float32).contiguous()   # 3 unless command.cfg says otherwise (go1.py:64-93)
         e = self.engine
         if self.task == "football_defender" and cmd.shape[0] == self.num_envs * 2:
             # Go1FootballDefender.step (go1_football_defender.py:25-31): the scripted defender's command is appended to the two
@@ -321,6 +321,9 @@ class Go1:
         if self.has_overrides:
             raise NotImplementedError("the fused wrapper-level step runs entirely inside the engine: a Go1 subclass that overrides "
                                       "_compute_torques / compute_reward / _post_physics_step_callback is stepped through Go1.step()")
+        if self.engine.desc.num_command_dims != 3:
+            raise NotImplementedError("wrapper-level steps carry (N, A', 3) velocity commands; a config whose command.cfg adds action "
+                                      "columns (go1.py:64-93) is stepped through Go1.step()")
         a = actions.to(self.engine.torch_device, torch.float32).contiguous()
         hooks = (getattr(self, "between_policy_and_physics", None), getattr(self, "before_policy_tail", None))   # the env-sharded runner's (bench.py)
         if hooks[1] is not None:

@@ -64,6 +64,12 @@ class FusedTaskWrapper(EmptyWrapper):
             self.num_agents = self.wrapper_agents
             self.obs_ids = torch.eye(self.num_agents, dtype=torch.float32, device=env.device).repeat(self.num_envs, 1).reshape(self.num_envs, self.num_agents, -1)
         assert env.task == self.task, f"{type(self).__name__} wraps task '{self.task}', env was built for '{env.task}'"
+        dsc = env.engine.desc
+        if dsc.num_command_dims != 3 or [dsc.command_src[c] for c in range(18)] != [-1] * 3 + [0, 1, 2] + [-1] * 12:
+            # upstream's task wrappers multiply the (N, A, 3) action by a (1, 1, 3) scale (go1_*_wrapper.py step()): there is no room for the
+            # action columns that command.cfg.{body_height, gait_freq, ...} add (go1.py:64-93); such a config runs behind EmptyWrapper / Go1.step
+            raise NotImplementedError("command.cfg flags beyond the velocity command: the task wrappers carry exactly (x, y, yaw) per agent, "
+                                      "as upstream; step the Go1 env itself (EmptyWrapper, e.g. go1plane)")
         self.observation_space = Box(low=-float("inf"), high=float("inf"), shape=(self._obs_dim(),), dtype=float)
         self.action_space = Box(low=-1, high=1, shape=(3,), dtype=float)
         self.action_scale = torch.tensor([[[2, 0.5, 0.5]]], device=env.device).repeat(self.num_envs, self.num_agents, 1)

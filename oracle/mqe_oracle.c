@@ -443,12 +443,24 @@ int mqo_policy_step(mqo_sim* s, const float* command) {
   for (int i = 0; i < R; i++) {
     float* lo = s->loco_obs + (size_t)i * FR;
     const float* ob = s->obs_bag + (size_t)i * OBS_BAG;
-    float c[3];
-    for (int k = 0; k < 3; k++) {
-      c[k] = command[i * 3 + k];
-      if (d->clip_command) c[k] = fminf(fmaxf(c[k], -1.0f), 1.0f);   /* go1.py:38 */
+    int general = d->num_command_dims != 3;
+    for (int c = 0; c < 18; c++) if (d->command_src[c] != (c >= 3 && c < 6 ? c - 3 : -1)) general = 1;
+    if (!general) {
+      float c[3];
+      for (int k = 0; k < 3; k++) {
+        c[k] = command[i * 3 + k];
+        if (d->clip_command) c[k] = fminf(fmaxf(c[k], -1.0f), 1.0f);   /* go1.py:38 */
+      }
+      lo[3] = c[0] * d->cmd_lin_scale; lo[4] = c[1] * d->cmd_lin_scale; lo[5] = c[2] * d->cmd_ang_scale; /* :67-68 */
+    } else {                                                       /* command.cfg beyond / without the velocity command: go1.py:66-93 */
+      for (int c = 3; c < 18; c++) {
+        const int src = d->command_src[c];
+        if (src < 0) { lo[c] = d->command_obs[c]; continue; }
+        float x = command[(size_t)i * d->num_command_dims + src];
+        if (d->clip_command) x = fminf(fmaxf(x, -1.0f), 1.0f);
+        lo[c] = x * d->command_scale[c];
+      }
     }
-    lo[3] = c[0] * d->cmd_lin_scale; lo[4] = c[1] * d->cmd_lin_scale; lo[5] = c[2] * d->cmd_ang_scale; /* :67-68 */
     for (int k = 0; k < 3; k++) lo[k] = ob[60 + k];              /* projected gravity  :95 */
     for (int k = 0; k < 12; k++) lo[18 + k] = ob[6 + k];         /* dof_pos            :96 */
     for (int k = 0; k < 12; k++) lo[30 + k] = ob[18 + k];        /* dof_vel            :97 */
@@ -1841,6 +1853,7 @@ int mqo_defender_command(mqo_sim* s, float* out /*[N,3]*/) { for (int e = 0; e <
 int mqo_step(mqo_sim* s, const float* actions) {
   const mqe_sim_desc* d = &s->d;
   int N = s->N, A = s->A, Aw = s->Aw;
+  if (d->num_command_dims != 3) { snprintf(g_err, sizeof g_err, "mqo_step takes wrapper-level (N, A', 3) actions; use mqo_policy_step for this command layout"); return -7; }
   float* cmd = (float*)malloc((size_t)s->R * 3 * 4);
   static const float scale[3] = {2.0f, 0.5f, 0.5f};
   for (int e = 0; e < N; e++) {

@@ -51,11 +51,14 @@ def wall_heights_terrain(task, lo=0.3, hi=0.7, **cfg_over):
     return type("WallHeightsTerrain", (base,), dict(cfg_over, BarrierTrack_kwargs=kw))
 
 
-def make_desc(task, N, seed=0, levels=None, types=None, max_episode_length=None, npc_init=None, env_id_offset=0, terrain_cfg=None, **kw):
+def make_desc(task, N, seed=0, levels=None, types=None, max_episode_length=None, npc_init=None, env_id_offset=0, terrain_cfg=None, command_flags=None, **kw):
     """Scene exactly as Go1._create_scene builds it, but with explicit track assignment for replaying fixtures."""
     cfg = task_cfg(task)
     if terrain_cfg is not None:
         cfg = type(cfg.__name__ + "OnOtherTerrain", (cfg,), {"terrain": terrain_cfg})
+    if command_flags:            # command.cfg switches (go1.py:64-93): further action columns
+        cc = type("cfg", (cfg.command.cfg,), dict(command_flags))
+        cfg = type(cfg.__name__ + "Cmd", (cfg,), {"command": type("command", (cfg.command,), {"cfg": cc})})
     A = cfg.env.num_agents
     np.random.seed(seed)
     t = BarrierTrack(cfg.terrain, N, A).build()

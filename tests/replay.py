@@ -8,7 +8,9 @@ from helpers import golden, make_desc, bag, to_dev, close
 
 TASK_OF = {"gate": "go1gate", "seesaw": "go1seesaw", "football": "go1football-defender", "sheep": "go1sheep-hard",
            "football1v1": "go1football-1vs1", "football2v2": "go1football-2vs2", "pushbox": "go1pushbox", "rotation": "go1revolvingdoor",
-           "bridge": "go1bridge", "wrestling": "go1wrestling", "tug": "go1tug"}
+           "bridge": "go1bridge", "wrestling": "go1wrestling", "tug": "go1tug", "gate_cmd": "go1gate"}
+# fullstep_gate_cmd: the gate scene with every implemented command.cfg switch on (go1.py:64-93): 11 action columns per robot
+CMD_FLAGS = dict(body_height=True, gait_freq=True, footswing_height=True, body_pose=True, stance_width=True, stance_length=True, aux_reward=True)
 
 # tolerances: MLP outputs go through libm expm1/ELU and a different accumulation order than torch's GEMM
 TOL_POLICY = dict(atol=2e-5, rtol=1e-4)
@@ -23,7 +25,8 @@ def replay(name, make_engine):
     d, keep, ctx = make_desc(TASK_OF[name], N, levels=z["terrain_levels"], types=z["terrain_types"],
                              max_episode_length=int(z["max_episode_length"]),
                              npc_init=z["base_init_state_npc"][:P] if P else None,
-                             noise_mode=1 if name == "sheep" else 0)      # MQE_NOISE_SCRIPTED: the recorded randn sequence is injected
+                             noise_mode=1 if name == "sheep" else 0,      # MQE_NOISE_SCRIPTED: the recorded randn sequence is injected
+                             command_flags=CMD_FLAGS if name == "gate_cmd" else None)
     np.testing.assert_allclose(ctx["env_origins"], z["env_origins"], atol=0)
     np.testing.assert_allclose(ctx["agent_origins"], z["agent_origins"], atol=0)
     e = make_engine(d, keep)

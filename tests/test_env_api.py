@@ -5,6 +5,7 @@ import types
 import numpy as np
 import pytest
 import torch
+from mqe.engine import abi
 
 from helpers import golden
 from mqe.envs.go1.go1 import Go1
@@ -299,9 +300,44 @@ def test_sheep_random_walk_draws_oracle():
     assert abs(float(a.mean())) < 0.15 and 0.85 < float(a.std()) < 1.15
 
 
+def test_command_cfg_columns_reach_the_policy(oracle_backed):
+    """command.cfg.{body_height, gait_freq, footswing_height, body_pose, stance_width, stance_length, aux_reward} (go1.py:64-93): the
+    action rows grow by the slots _fill_command_obs assigns (go1.py:411-479), every slot lands scaled in its entry of the locomotion
+    observation, the gait clock follows a commanded frequency (go1.py:242), and clipping applies to the whole row (go1.py:38)."""
+    a = args_for("go1plane", 3)
+    base = ENV_DICT["go1plane"]["config"]
+
+    def edit(cfg):
+        cfg = custom_cfg(a)(cfg)
+        cc = type("cfg", (cfg.command.cfg,), dict(body_height=True, gait_freq=True, footswing_height=True, body_pose=True, stance_width=True, stance_length=True, aux_reward=True))
+        cmd = type("command", (cfg.command,), {"cfg": cc})
+        return type("Go1PlaneCmdCfg", (cfg,), {"command": cmd})
+    env, cfg = make_mqe_env("go1plane", a, edit)
+    ENV_DICT["go1plane"]["config"] = base
+    d = env.env.engine.desc
+    assert d.num_command_dims == 11 and [d.command_src[c] for c in range(18)] == [-1, -1, -1, 0, 1, 2, 3, 4, -1, -1, -1, -1, 5, 6, 7, 8, 9, 10]
+    env.reset()
+    A = env.num_agents
+    act = torch.zeros(3, A, 11)
+    act[:, :, 0] = 0.5; act[:, :, 3] = -0.4; act[:, :, 4] = 3.0; act[:, :, 5] = 0.2; act[:, :, 6] = -0.3; act[:, :, 7] = 0.1; act[:, :, 8] = 0.25; act[:, :, 9] = 0.4; act[:, :, 10] = -2.0
+    g0 = env.env.engine.tensor(abi.T_GAIT_INDICES).clone()
+    env.step(act)
+    lo = env.env.engine.tensor(abi.T_LOCOMOTION_OBS)[0, :18]
+    sc = cfg.control.obs_scales
+    want = {3: 0.5 * sc.lin_vel, 6: -0.4 * sc.body_height, 7: 1.0 * sc.gait_freq, 12: 0.2 * sc.footswing_height, 13: -0.3 * sc.body_pitch, 14: 0.1 * sc.body_roll,
+            15: 0.25 * sc.stance_width, 16: 0.4 * sc.stance_length, 17: -1.0 * sc.aux_reward}          # columns 4 and 10 are clipped to +-1 (go1.py:38)
+    for c, v in want.items():
+        assert abs(float(lo[c]) - v) < 1e-6, (c, float(lo[c]), v)
+    g1 = env.env.engine.tensor(abi.T_GAIT_INDICES)
+    assert torch.allclose((g1 - g0) % 1.0, torch.full_like(g1, (env.env.dt * 1.0 * sc.gait_freq) % 1.0), atol=1e-6)     # go1.py:247 with the commanded frequency
+    env.close()
+
+
 def test_unsupported_switches_are_refused_not_ignored(oracle_backed):
     """VERDICT r2 'Missing' 4/5: a config that turns extra command dimensions (go1.py:64-92) or the run-time terrain curriculum
-    (legged_robot.py:479-503) on must not run with the switch silently dropped."""
+    (legged_robot.py:479-503) on must not run with the switch silently dropped.  Command columns beyond (x, y, yaw) are implemented at
+    the Go1 level (test_command_cfg_columns_reach_the_policy, fullstep_gate_cmd trace) and refused by the task wrappers, whose (N, A, 3)
+    action scaling cannot carry them upstream either; command.cfg.gait raises upstream itself (go1.py:76-77)."""
     a = args_for("go1gate", 4)
     base = ENV_DICT["go1gate"]["config"]
 
@@ -312,8 +348,8 @@ def test_unsupported_switches_are_refused_not_ignored(oracle_backed):
             cmd = type("command", (cfg.command,), {"cfg": cc})
             return type("Go1GateCmdCfg", (cfg,), {"command": cmd})
         return edit
-    for flags in ({"body_height": True}, {"gait_freq": True, "footswing_height": True}, {"vel": False}, {"stance_width": True}):
-        with pytest.raises(NotImplementedError, match="command.cfg flags"):
+    for flags in ({"body_height": True}, {"gait_freq": True, "footswing_height": True}, {"vel": False}, {"stance_width": True}, {"gait": True}):
+        with pytest.raises(NotImplementedError, match="command.cfg"):
             make_mqe_env("go1gate", a, with_flags(**flags))
         ENV_DICT["go1gate"]["config"] = base          # make_mqe_env registers what the hook returns (as upstream, utils.py:113-116)
 

@@ -408,7 +408,7 @@ def obs_fields(ob):
     return d
 
 
-def gen_fullstep(name, cls, cfg, N, T, act, ada, action_gain=1.0, seed=0, ctrl="C"):
+def gen_fullstep(name, cls, cfg, N, T, act, ada, action_gain=1.0, seed=0, ctrl="C", nd=3):
     """Drive the reference's own step() (go1.py:35-62 / go1_football_defender.py:25-54) for T steps with the
     scripted simulator; record everything a replay needs and everything it must reproduce."""
     A = cfg.env.num_agents
@@ -481,7 +481,7 @@ def gen_fullstep(name, cls, cfg, N, T, act, ada, action_gain=1.0, seed=0, ctrl="
         root_script[ti] = allr.reshape(-1, 13)
         if ti == 7 and len(cfg.asset.terminate_after_contacts_on):
             contact_script[ti, 2 % N, 17 * (A - 1), :] = [0.5, 0.2, 3.0]  # base of last agent touches: collide
-    actions = (rng.uniform(-1.3, 1.3, (T, N * (A if cls is not Go1FootballDefender else A - 1), 3)) * action_gain).astype(np.float32)
+    actions = (rng.uniform(-1.3, 1.3, (T, N * (A if cls is not Go1FootballDefender else A - 1), nd)) * action_gain).astype(np.float32)     # nd > 3: command.cfg adds action columns (go1.py:64-93)
     if ctrl != "C":     # low-level control types: joint-space actions, some beyond clip_actions
         actions = rng.uniform(-1.0, 1.0, (T, N * A, 12)).astype(np.float32) * np.where(rng.rand(T, N * A, 12) < 0.02, 150.0, 1.0).astype(np.float32)
 
@@ -1132,6 +1132,12 @@ def main():
             ctl = type("control", (Go1GateCfg.control,), {"control_type": c})
             cfg_c = type("Go1Gate" + c + "Cfg", (Go1GateCfg,), {"control": ctl})
             run_stage(gen_fullstep, "fullstep_gate_" + c, Go1, cfg_c, N=3, T=10, act=act, ada=ada, ctrl=c)
+    if want("fullstep_cmd"):       # command.cfg beyond the velocity command (go1.py:64-93, slots of _fill_command_obs :411-479): 11 action columns per robot
+        from mqe.envs.configs.go1_gate_config import Go1GateCfg
+        cc = type("cfg", (Go1GateCfg.command.cfg,), dict(body_height=True, gait_freq=True, footswing_height=True, body_pose=True, stance_width=True, stance_length=True, aux_reward=True))
+        cmd = type("command", (Go1GateCfg.command,), {"cfg": cc})
+        cfg_c = type("Go1GateCmdCfg", (Go1GateCfg,), {"command": cmd})
+        run_stage(gen_fullstep, "fullstep_gate_cmd", Go1, cfg_c, N=3, T=12, act=act, ada=ada, nd=11)
     if want("fullstep_tug"):
         from mqe.envs.configs.go1_tug_config import Go1TugCfg
         run_stage(gen_fullstep, "fullstep_tug", Go1Object, Go1TugCfg, N=2, T=12, act=act, ada=ada)
