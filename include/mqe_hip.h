@@ -335,6 +335,15 @@ int mqe_debug_stop_phase(mqe_sim* s, int tap);
  * of the wavefronts' run times and where the dispatcher put them) */
 int mqe_debug_wave_times(mqe_sim* s, long long* out_host);
 
+/* Checkpoint / resume of the simulation state (the reference has none: SURVEY 5).  The blob holds every state buffer of the handle --
+ * the tensors of mqe_sim_tensor and the internal ones (the compact history operand and its ring position, the action-lag ring, wrapper
+ * bookkeeping, the reset counters that key the RNG streams, the domain parameters) -- and NOT the scene: load it into a handle created
+ * from the same descriptor (same shape and layer-0 path; checked).  A rollout continued after mqe_state_load is bit for bit the
+ * rollout that was not interrupted.  Both calls synchronise `stream`; `host_blob` is host memory of mqe_state_size() bytes. */
+long long mqe_state_size(mqe_sim* s);
+int mqe_state_save(mqe_sim* s, void* host_blob, void* stream);
+int mqe_state_load(mqe_sim* s, const void* host_blob, void* stream);
+
 /* bookkeeping for benchmarks: time of the dominant kernel measured with HIP events on `stream` */
 int mqe_profile_enable(mqe_sim* s, int on);
 int mqe_profile_read(mqe_sim* s, float* ms_per_kernel, int n, int* n_launches);

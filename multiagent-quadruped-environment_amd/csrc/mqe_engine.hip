@@ -47,6 +47,8 @@ struct mqe_sim {
   DevModel* dm = nullptr; // device copy
   DevState st;
   std::vector<void*> allocs;
+  std::vector<std::pair<void*, size_t>> state_bufs;     // the buffers of DevState, in allocation order (mqe_state_save / _load)
+  bool reg_state = false;
   void* tens[MQE_T_COUNT];
   int N, A, P, R, ND, NBR, Aw, D;
   int hist_pos = 0, n_post_steps = 0;
@@ -87,6 +89,7 @@ static int dalloc(mqe_sim* s, T** p, size_t n, int fill_zero = 1) {
   if (hipMalloc(&q, bytes) != hipSuccess) return -1;
   if (fill_zero && hipMemset(q, 0, bytes) != hipSuccess) return -1;
   s->allocs.push_back(q);
+  if (s->reg_state) s->state_bufs.push_back({q, bytes});
   *p = (T*)q;
   return 0;
 }
@@ -442,6 +445,7 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   DA(s->lat, (size_t)R * s->ldlat); DA(s->act_out, (size_t)R * s->ldact);
   // ---- state ---------------------------------------------------------------------------------------------------------
   DevState& st = s->st;
+  s->reg_state = true;
   DA(st.root, (size_t)N * (A + P) * 13); DA(st.dof, (size_t)N * s->ND * 2); DA(st.cf, (size_t)N * s->NBR * 3);
   DA(st.torques, (size_t)N * 12 * A); DA(st.actions, (size_t)N * 12 * A); DA(st.last_actions, (size_t)N * 12 * A);
   DA(st.loco_obs, (size_t)R * MQE_FRAME); DA(st.hist, (size_t)R * MQE_HIST * MQE_FRAME);
@@ -484,6 +488,7 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   if (s->hm.lag_steps > 0) { DA(st.lag_buf, (size_t)(s->hm.lag_steps + 1) * R * 12); }
   DA(st.reset_buf, N); DA(st.collide_buf, N); DA(st.time_out, N); DA(st.r_term, N); DA(st.p_term, N); DA(st.zh_term, N);
   DA(st.w_have_last, N); DA(st.w_delayed_reset, N);
+  s->reg_state = false;
   {
     // initial values the reference's buffers start from (base_task.py:77-84, legged_robot.py:567-622)
     std::vector<float> h((size_t)N * (A + P) * 13, 0.0f);
@@ -733,6 +738,46 @@ static void launch_post(mqe_sim* s, hipStream_t q, int wrapper_level) {
     hipLaunchKernelGGL(k_post_physics<MQE_MAX_AGENTS>, dim3((s->N + POST_EPW - 1) / POST_EPW), dim3(64), 0, q, s->dm, s->st, wrapper_level, push, s->n_post_steps);   // incl. history zeroing
 }
 
+// ---- checkpoint / resume: every buffer of DevState + the host-side counters -------------------------------------------------
+struct StateHeader { uint32_t magic, abi; int32_t N, A, P, nbuf; int32_t hist_pos, n_post_steps, lag_pos, reserved; uint64_t bytes; };
+static const uint32_t STATE_MAGIC = 0x5345514du;      // "MQES"
+extern "C" long long mqe_state_size(mqe_sim* s) {
+  if (!s) { fail(-1, "null engine handle"); return 0; }
+  size_t n = sizeof(StateHeader);
+  for (auto& b : s->state_bufs) n += (b.second + 15) / 16 * 16;
+  return (long long)n;
+}
+extern "C" int mqe_state_save(mqe_sim* s, void* host_blob, void* stream) {
+  if (!s || !host_blob) return fail(-1, "mqe_state_save: null argument");
+  if (s->step_open) return fail(-8, "mqe_state_save inside an open step (mqe_step_begin / _head without mqe_step_end)");
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  StateHeader h = {STATE_MAGIC, (uint32_t)MQE_ABI_VERSION, s->N, s->A, s->P, (int32_t)s->state_bufs.size(), s->hist_pos, s->n_post_steps, s->lag_pos, 0,
+                   (uint64_t)mqe_state_size(s)};
+  char* o = (char*)host_blob;
+  memcpy(o, &h, sizeof h); o += sizeof h;
+  for (auto& b : s->state_bufs) {
+    HIPCHK(hipMemcpy(o, b.first, b.second, hipMemcpyDeviceToHost));
+    o += (b.second + 15) / 16 * 16;
+  }
+  return 0;
+}
+extern "C" int mqe_state_load(mqe_sim* s, const void* host_blob, void* stream) {
+  if (!s || !host_blob) return fail(-1, "mqe_state_load: null argument");
+  if (s->step_open) return fail(-8, "mqe_state_load inside an open step");
+  StateHeader h;
+  memcpy(&h, host_blob, sizeof h);
+  if (h.magic != STATE_MAGIC || h.abi != (uint32_t)MQE_ABI_VERSION) return fail(-6, "mqe_state_load: not a state blob of this ABI version");
+  if (h.N != s->N || h.A != s->A || h.P != s->P || h.nbuf != (int32_t)s->state_bufs.size() || h.bytes != (uint64_t)mqe_state_size(s))
+    return fail(-6, "mqe_state_load: the blob was saved from a handle of another shape (envs, agents, NPCs, layer-0 path)");
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  const char* o = (const char*)host_blob + sizeof h;
+  for (auto& b : s->state_bufs) {
+    HIPCHK(hipMemcpy(b.first, o, b.second, hipMemcpyHostToDevice));
+    o += (b.second + 15) / 16 * 16;
+  }
+  s->hist_pos = h.hist_pos; s->n_post_steps = h.n_post_steps; s->lag_pos = h.lag_pos;
+  return 0;
+}
 extern "C" int mqe_debug_wave_times(mqe_sim* s, long long* out_host) {
   if (!s) return fail(-1, "null engine handle");
   if (!s->st.wave_times) return fail(-4, "create the handle with MQE_WAVE_TIMES=1");

@@ -47,6 +47,7 @@ class HipEngine(EngineBase):
                            ("debug_dynamics", [vp, C.c_int, C.c_int, vp, C.POINTER(C.c_int), vp]),
                            ("debug_stop_phase", [vp, C.c_int]),
                            ("debug_wave_times", [vp, vp]),
+                           ("state_save", [vp, vp, vp]), ("state_load", [vp, vp, vp]),
                            ("profile_enable", [vp, C.c_int]),
                            ("profile_read", [vp, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)])):
             f = getattr(lib, "mqe_" + name)
@@ -122,6 +123,19 @@ class HipEngine(EngineBase):
 
     def wrapper_eval(self, is_reset):
         self._call("wrapper_eval", int(is_reset), self._stream())
+
+    def save_state(self):
+        """Checkpoint: every state buffer of the handle + its ring positions as one host blob (numpy uint8); see mqe_state_save."""
+        self.lib.mqe_state_size.argtypes, self.lib.mqe_state_size.restype = [C.c_void_p], C.c_longlong
+        blob = np.empty(int(self.lib.mqe_state_size(self.h)) + 8, np.uint8)
+        self._call("state_save", C.c_void_p(blob.ctypes.data), self._stream())
+        blob[-8:] = np.frombuffer(np.int64(getattr(self, "_n_policy", 0)).tobytes(), np.uint8)      # host-side frame counter of history()
+        return blob
+
+    def load_state(self, blob):
+        blob = np.ascontiguousarray(blob, np.uint8)
+        self._call("state_load", C.c_void_p(blob.ctypes.data), self._stream())
+        self._n_policy = int(np.frombuffer(blob[-8:].tobytes(), np.int64)[0])
 
     def history(self):
         """(R, 2100) time-ordered locomotion history gathered from the ring (host-side bookkeeping of the slot)."""

@@ -333,6 +333,17 @@ class Go1:
         self._steps_policy = getattr(self, "_steps_policy", 0) + 1
         self.common_step_counter += 1
 
+    def get_state(self):
+        """Checkpoint of the whole simulation state: the engine's blob (every state tensor, history ring and its position, lag ring, wrapper
+        bookkeeping, RNG reset counters; mqe_state_save) + the host-side step counters.  The reference has no save / restore of the
+        simulation; a rollout continued after set_state() is bit for bit the uninterrupted one."""
+        return {"engine": self.engine.save_state(), "steps_policy": getattr(self, "_steps_policy", 0), "common_step_counter": self.common_step_counter}
+
+    def set_state(self, state):
+        self.engine.load_state(state["engine"])
+        self._steps_policy = int(state["steps_policy"])
+        self.common_step_counter = int(state["common_step_counter"])
+
     def get_observations(self):
         return self.obs_buf
 

@@ -304,3 +304,53 @@ def test_terrain_classes_and_subclass_overrides_on_the_hip_engine():
     finally:
         Go1GateCfg.control.control_type = old
         ENV_DICT["go1gate"]["class"] = saved_cls
+
+
+@pytest.mark.parametrize("task,N", [("go1gate", 192), ("go1sheep-hard", 12), ("go1seesaw", 16)])
+def test_checkpoint_and_resume_is_bit_exact(task, N):
+    """get_state() / set_state() (mqe_state_save / _load; the reference has no save / restore of the simulation): 40 steps --
+    the history ring has turned over, episodes of 25 steps have timed out, frames after resets sit in the compact layer-0 operand --
+    then a checkpoint; 15 more steps; back to the checkpoint, in the same handle and in a FRESH one made from the same configuration:
+    the continuation is bit for bit the first one (returned batch, root and joint states, every step).  go1gate at 192 envs runs
+    layer 0 on the split-f16 path only with MQE_GEMM_SPLIT=1; it is forced so that the derived operand is part of what is restored."""
+    import os
+    os.environ["MQE_GEMM_SPLIT"] = "1"
+    try:
+        a = args_for(task, N)
+
+        def short_episodes(cfg):
+            cfg = custom_cfg(a)(cfg)
+            return type(cfg.__name__ + "Short", (cfg,), {"env": type("env", (cfg.env,), {"episode_length_s": 0.5})})
+        base = ENV_DICT[task]["config"]
+        env, _ = make_mqe_env(task, a, short_episodes)
+        env2, _ = make_mqe_env(task, a, short_episodes)
+        ENV_DICT[task]["config"] = base
+    finally:
+        del os.environ["MQE_GEMM_SPLIT"]
+    env.reset(); env2.reset()
+    g = torch.Generator().manual_seed(41)
+    A = env.num_agents
+    acts = [(torch.rand(N, A, 3, generator=g) * 2 - 1).cuda() for _ in range(55)]
+    n_done = 0
+    for t in range(40):
+        _, _, done, _ = env.step(acts[t])
+        n_done += int(done.sum())
+    assert n_done >= N                                # every env has been through a reset
+    ck = env.env.get_state()
+
+    def run(e):
+        out = []
+        for t in range(40, 55):
+            obs, rew, done, _ = e.step(acts[t])
+            out.append((obs.clone(), rew.clone(), done.clone(), e.env.root_states.clone(), e.env.dof_state.clone()))
+        return out
+    first = run(env)
+    env.env.set_state(ck)
+    again = run(env)
+    env2.env.set_state(ck)
+    fresh = run(env2)
+    for t, (x, y, z) in enumerate(zip(first, again, fresh)):
+        for k in range(5):
+            assert torch.equal(x[k], y[k]), (task, "same handle", t, k)
+            assert torch.equal(x[k], z[k]), (task, "fresh handle", t, k)
+    env.close(); env2.close()
