@@ -85,6 +85,46 @@ def test_full_size_invariants(task, NF):
     e.close()
 
 
+def test_soak_two_full_episodes_at_full_size():
+    """go1gate, 4096 envs x 2 agents, 1100 fused steps with random commands = what bench.py measures, twice over: two waves of
+    time-outs of ALL envs (max_episode_length 500), the history ring turned over 36 times, thousands of falls.  No oracle at this
+    size and length; what must hold: finite state all along, unit quaternions, joint limits, robots on their tracks, episode
+    counters inside the episode length, every env reset at least twice, (almost) no truncated contact list, and a policy that is
+    still alive (the robots' mean speed does not collapse to zero or blow up)."""
+    NF = 4096
+    levels, types = assign_tracks("go1gate", NF)
+    d, k, ctx = shard_desc("go1gate", NF, 0, NF, levels, types)
+    e = hip_engine(d, k)
+    e.reset_all()
+    A = d.num_agents
+    g = torch.Generator(device="cuda").manual_seed(77)
+    root, dof = e.tensor(abi.T_ROOT_STATE), e.tensor(abi.T_DOF_STATE)
+    lo = torch.tensor([d.robot.dof_lower[j] for j in range(12)], device="cuda")
+    hi = torch.tensor([d.robot.dof_upper[j] for j in range(12)], device="cuda")
+    eo = torch.as_tensor(ctx["env_origins"], device="cuda")[:, None, :2]
+    n_time_out = 0
+    for t in range(1100):
+        e.step(torch.rand(NF, A, 3, device="cuda", generator=g) * 2 - 1)
+        if t % 50 == 49 or t in (500, 501, 1001, 1002):
+            torch.cuda.synchronize()
+            assert torch.isfinite(root).all() and torch.isfinite(dof).all() and torch.isfinite(e.tensor(abi.T_WRAPPER_OBS)).all(), t
+            assert ((root[:, :A, 3:7].norm(dim=-1) - 1).abs() < 1e-4).all(), t
+            assert root[:, :A, 2].min() > 0.0 and root[:, :A, 2].max() < 1.5, t
+            assert (root[:, :A, :2] - eo).abs().max() < 30.0, t
+            q = dof[:, :12 * A, 0].reshape(NF, A, 12)
+            assert (q > lo - 0.05).all() and (q < hi + 0.05).all(), t
+            assert int(e.tensor(abi.T_EPISODE_LENGTH).max()) <= d.max_episode_length + 1, t
+        n_time_out += int(e.tensor(abi.T_TIME_OUT_BUF).sum()) if t in (500, 1001) or t % 97 == 0 else 0
+    torch.cuda.synchronize()
+    assert int(e.tensor(abi.T_RESET_COUNT).min()) >= 3                      # the reset at the start + two time-outs at least
+    assert int(e.tensor(abi.T_CONTACT_OVERFLOW).sum()) <= NF * 1100 * 4 // 1000
+    speed = root[:, :A, 7:9].norm(dim=-1).mean()
+    assert 0.01 < float(speed) < 3.0, float(speed)
+    act = e.tensor(abi.T_ACTIONS)
+    assert float(act.abs().mean()) > 0.01 and float(act.abs().max()) <= d.clip_actions + 1e-6
+    e.close()
+
+
 @pytest.mark.parametrize("task,NF", FULL)
 def test_full_size_batch_is_the_union_of_its_shards(monkeypatch, task, NF):
     """20 fused steps: envs [g0, g0 + 32) of the full batch == the same global env ids run as a 32-env batch of their own (the size
