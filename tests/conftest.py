@@ -10,3 +10,21 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_sessionstart(session):
+    """Build what the tests load if it is missing or older than its sources: the CPU oracle (`make` compares time stamps; a stale
+    library built against an older descriptor layout would crash, not fail) and, where hipcc exists, the HIP engine (cross-compiles
+    without a GPU; __graft_entry__.build_engine compares time stamps too).  Building the checker is not using it."""
+    import shutil
+    import subprocess
+    try:
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s"])
+    except Exception as e:          # the tests that need the oracle will say so
+        print("conftest: could not build the oracle:", e)
+    if shutil.which("hipcc") or os.path.isfile("/opt/rocm/bin/hipcc"):
+        try:
+            import __graft_entry__ as g
+            g.build_engine()
+        except Exception as e:
+            print("conftest: could not build the HIP engine:", e)
