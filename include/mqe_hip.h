@@ -316,6 +316,12 @@ int mqe_step_tail(mqe_sim* s, void* stream);
  * MQE_T_WRAPPER_* views show).  Host-side switch only; a launch uses the buffer that was set when it was enqueued.  The
  * wrappers hand every step a fresh tensor this way (the reference returns new tensors each step) instead of copying. */
 int mqe_set_return_buffer(mqe_sim* s, float* packed_dev);
+/* Go1.step itself (go1.py:35-62) as one call for control type "C": `command` [R, num_command_dims] = the per-robot command rows
+ * Go1.step receives (already scaled by a task wrapper, if any; re-clipped to +-1 inside as go1.py:38 does unless the scene is the
+ * defender variant), policy, decimation loop and post-physics step as the five fused launches.  No wrapper head and no wrapper
+ * evaluation: the task wrapper's observation, reward and bookkeeping belong to mqe_step.  Equivalent to mqe_policy_step + decimation x
+ * (mqe_compute_torques, mqe_simulate, mqe_post_decimation_step) + mqe_post_physics_step. */
+int mqe_step_command(mqe_sim* s, const float* command, void* stream);
 /* The same for the low-level control types "P" / "V" / "T" (Go1.step's else branch, go1.py:42-44 -> pre_physics_step,
  * legged_robot.py:108-110, and the PD / torque laws of legged_robot.py:380-392): actions [R, 12] joint-space actions, clipped
  * to clip_actions inside; no locomotion policy runs.  The decimation loop, post-physics step and (plain) wrapper are the

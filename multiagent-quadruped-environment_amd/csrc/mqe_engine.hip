@@ -862,7 +862,7 @@ extern "C" int mqe_reset_all(mqe_sim* s, void* stream) {
   return 0;
 }
 
-static int run_substeps_and_post(mqe_sim* s, hipStream_t q);
+static int run_substeps_and_post(mqe_sim* s, hipStream_t q, int wrapper_level = 1);
 __global__ void k_post_decimation(const DevModel* m, DevState st, int dec_i);
 
 // clip to clip_actions (legged_robot.py:108-110) -> st.actions
@@ -882,6 +882,16 @@ extern "C" int mqe_step_joint(mqe_sim* s, const float* actions12, void* stream) 
     hipLaunchKernelGGL(k_set_joint_actions, dim3((n + 255) / 256), dim3(256), 0, q, s->dm, s->st, actions12);
   }
   return run_substeps_and_post(s, q);
+}
+
+extern "C" int mqe_step_command(mqe_sim* s, const float* command, void* stream) {
+  if (!s) return fail(-1, "null engine handle");
+  hipStream_t q = (hipStream_t)stream;
+  if (s->d.control_type != MQE_CTRL_C) return fail(-7, "mqe_step_command drives the hierarchical controller (control type C); use mqe_step_joint for P / V / T");
+  if (s->step_open) return fail(-8, "mqe_step_command inside an open step");
+  s->prof_now = s->prof && (s->prof_step++ % s->prof_every == 0);
+  policy_step(s, command, q);                    // Go1-level commands: no wrapper head
+  return run_substeps_and_post(s, q, 0);         // ... and no wrapper evaluation: the wrapper's bookkeeping belongs to wrapper-level steps
 }
 
 extern "C" int mqe_step(mqe_sim* s, const float* actions, void* stream) {
@@ -944,7 +954,7 @@ extern "C" int mqe_step_end(mqe_sim* s, void* stream) {
   return run_substeps_and_post(s, (hipStream_t)stream);
 }
 
-static int run_substeps_and_post(mqe_sim* s, hipStream_t q) {
+static int run_substeps_and_post(mqe_sim* s, hipStream_t q, int wrapper_level) {
   if (s->fuse_substeps) {
     // decimation loop in one launch: state stays in LDS; actuator net on MFMA (C) or the PD / torque law (P, V, T) inside the wavefront
     ProfScope ps(s, PROF_SIMULATE, q);
@@ -958,7 +968,7 @@ static int run_substeps_and_post(mqe_sim* s, hipStream_t q) {
       hipLaunchKernelGGL(k_post_decimation, dim3((n + 255) / 256), dim3(256), 0, q, s->dm, s->st, k < 4 ? k : 3);
     }
   }
-  launch_post(s, q, 1);
+  launch_post(s, q, wrapper_level);
   s->prof_now = s->prof;                      // the unfused entry points are always bracketed when profiling is on
   HIPCHK(hipGetLastError());
   return 0;

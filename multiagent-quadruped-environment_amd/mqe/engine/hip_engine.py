@@ -42,7 +42,7 @@ class HipEngine(EngineBase):
         vp = C.c_void_p
         for name, args in (("policy_step", [vp, vp, vp]), ("compute_torques", [vp, vp]), ("simulate", [vp, vp]),
                            ("post_decimation_step", [vp, C.c_int, vp]), ("post_physics_step", [vp, vp]),
-                           ("reset_all", [vp, vp]), ("step", [vp, vp, vp]), ("step_begin", [vp, vp, vp]), ("step_end", [vp, vp]), ("step_head", [vp, vp, vp]), ("step_tail", [vp, vp]), ("set_return_buffer", [vp, vp]), ("step_joint", [vp, vp, vp]), ("defender_command", [vp, vp, vp]),
+                           ("reset_all", [vp, vp]), ("step", [vp, vp, vp]), ("step_begin", [vp, vp, vp]), ("step_end", [vp, vp]), ("step_head", [vp, vp, vp]), ("step_tail", [vp, vp]), ("set_return_buffer", [vp, vp]), ("step_joint", [vp, vp, vp]), ("step_command", [vp, vp, vp]), ("defender_command", [vp, vp, vp]),
                            ("wrapper_eval", [vp, C.c_int, vp]),
                            ("debug_dynamics", [vp, C.c_int, C.c_int, vp, C.POINTER(C.c_int), vp]),
                            ("debug_stop_phase", [vp, C.c_int]),
@@ -79,6 +79,12 @@ class HipEngine(EngineBase):
 
     def reset_all(self):
         self._call("reset_all", self._stream())
+
+    def step_command(self, command):
+        """Fused Go1.step for control type C (mqe_step_command): (R, num_command_dims) per-robot command rows on the device."""
+        assert command.is_cuda and command.dtype == torch.float32 and command.is_contiguous()
+        self._call("step_command", C.c_void_p(command.data_ptr()), self._stream())
+        self._n_policy = getattr(self, "_n_policy", 0) + 1
 
     def step_joint(self, actions12):
         """Fused step for control types P / V / T: (R, 12) joint-space actions on the device."""

@@ -310,9 +310,14 @@ class Go1:
             dc = torch.empty(self.num_envs, 3, device=cmd.device)
             e.defender_command(dc)
             cmd = torch.cat([cmd.view(self.num_envs, 2, 3), dc.unsqueeze(1)], dim=1).reshape(-1, 3).contiguous()
-        e.policy_step(cmd)
-        self._steps_policy = getattr(self, "_steps_policy", 0) + 1
-        self._decimation_loop()
+        if self.has_overrides:           # the subclass's pieces run where the reference calls them: stage by stage
+            e.policy_step(cmd)
+            self._steps_policy = getattr(self, "_steps_policy", 0) + 1
+            self._decimation_loop()
+        else:                            # the same step as the engine's five fused launches (mqe_step_command)
+            e.step_command(cmd)
+            self._steps_policy = getattr(self, "_steps_policy", 0) + 1
+            self.common_step_counter += 1
         return self.obs_buf, self.rew_buf, self.reset_buf, self.extras
 
     def step_fused(self, actions):

@@ -72,6 +72,15 @@ class OracleEngine(EngineBase):
     def reset_all(self):
         self._call("reset_all")
 
+    def step_command(self, command):
+        """what mqe_step_command fuses, call by call (go1.py:35-62): policy, decimation x (torques, substep, logs), post-physics step"""
+        self.policy_step(command)
+        for k in range(self.desc.decimation):
+            self.compute_torques()
+            self.simulate()
+            self.post_decimation_step(k)
+        self.post_physics_step()
+
     def step_joint(self, actions12):
         a = np.ascontiguousarray(actions12.detach().cpu().numpy() if hasattr(actions12, "detach") else actions12, np.float32)
         self._call("step_joint", C.c_void_p(a.ctypes.data))
