@@ -315,13 +315,17 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   {
     // Two envs per wavefront (kernels_physics.hpp, EPW): for robot-only scenes of <= 2 robots each half-wave runs an env of its own --
     // 44 % fewer VALU instructions per env (the dynamics and sweep phases are shared, only contact generation runs per env), but half
-    // as many wavefronts, each with twice the LDS traffic per instruction.  It does NOT pay: the kernel is bound by the dependency
+    // as many wavefronts, each with twice the LDS traffic per instruction.  For two-robot envs it does NOT pay: the kernel is bound by the dependency
     // chain of a wavefront through the LDS (a lone one-env wavefront takes 82 us for its 58 k cycles of issue; LDS 60 % busy per
     // CU), and the two-env wavefront's chain is 1.5 x as long -- 2 of them per SIMD take what 4 one-env wavefronts take.  Kept as
-    // a selectable, bit-identical variant (MQE_ENVS_PER_WAVE=2; tests hold the two forms against each other), not the default.
+    // a selectable, bit-identical variant (MQE_ENVS_PER_WAVE=1 / 2; tests hold the two forms against each other); the default for
+    // single-robot scenes at full batches only (below).
     const bool can = (s->substeps_fn == (void (*)(const DevModel*, DevState, int, int))k_substeps<2, 0> ||
                       s->substeps_fn == (void (*)(const DevModel*, DevState, int, int))k_substeps<1, 0>) && 2 * s->phys_lds_bytes <= 64 * 1024;
-    int want = 1;      // measured (MI355X, go1gate, k_substeps us, EPW 1 / 2): 4096 envs 122 / 128, 8192 envs 238 / 237 -- see below
+    // measured (MI355X, k_substeps us, one / two envs per wavefront): go1gate (two robots per env) 4096 envs 122 / 128, 8192 envs 238 / 237;
+    // go1plane (ONE robot per env: a pair is exactly the lane population of a go1gate wavefront) 4096 envs 108.8 / 85.6 -- the pairing
+    // pays there once the batch fills the machine (4 one-env wavefronts per SIMD), so single-robot scenes of >= 4096 envs take it
+    int want = (m.A == 1 && N >= 4096) ? 2 : 1;
     if (const char* ev = getenv("MQE_ENVS_PER_WAVE")) want = atoi(ev);
     if (can && want == 2) {
       s->substeps_fn = m.A == 2 ? (void (*)(const DevModel*, DevState, int, int))k_substeps<2, 0, 2> : (void (*)(const DevModel*, DevState, int, int))k_substeps<1, 0, 2>;

@@ -285,7 +285,7 @@ def test_row_sweep_and_lane_sweep_agree(monkeypatch, task, N):
 @pytest.mark.parametrize("task,N", [("go1gate", 256), ("go1gate", 37), ("go1gate", 1), ("go1plane", 65)])
 def test_two_envs_per_wavefront_is_bit_identical(monkeypatch, task, N):
     """k_substeps<.., EPW = 2>: each half-wave of 32 lanes runs an env of its own (robot-only scenes of <= 2 robots; the engine picks
-    it beyond 2048 envs, MQE_ENVS_PER_WAVE forces it).  Per env it is the same arithmetic in the same order as the one-env form, so
+    it for single-robot scenes of >= 4096 envs, MQE_ENVS_PER_WAVE = 1 / 2 forces either form).  Per env it is the same arithmetic in the same order as the one-env form, so
     15 fused steps -- resets, contacts between the robots, joint limits, an odd batch whose last half-wave has no env -- agree BIT
     FOR BIT in every state tensor, log and returned batch."""
     monkeypatch.setenv("MQE_ENVS_PER_WAVE", "1")
