@@ -282,17 +282,28 @@ def test_row_sweep_and_lane_sweep_agree(monkeypatch, task, N):
     assert int(er.tensor(abi.T_CONTACT_OVERFLOW).sum()) == int(el.tensor(abi.T_CONTACT_OVERFLOW).sum())
 
 
-@pytest.mark.parametrize("task,N", [("go1gate", 256), ("go1gate", 37), ("go1gate", 1), ("go1plane", 65)])
-def test_two_envs_per_wavefront_is_bit_identical(monkeypatch, task, N):
+@pytest.mark.parametrize("task,N,dr", [("go1gate", 256, False), ("go1gate", 37, False), ("go1gate", 1, False), ("go1plane", 65, False), ("go1plane", 131, True), ("go1gate", 50, True)])
+def test_two_envs_per_wavefront_is_bit_identical(monkeypatch, task, N, dr):
     """k_substeps<.., EPW = 2>: each half-wave of 32 lanes runs an env of its own (robot-only scenes of <= 2 robots; the engine picks
     it for single-robot scenes of >= 4096 envs, MQE_ENVS_PER_WAVE = 1 / 2 forces either form).  Per env it is the same arithmetic in the same order as the one-env form, so
     15 fused steps -- resets, contacts between the robots, joint limits, an odd batch whose last half-wave has no env -- agree BIT
-    FOR BIT in every state tensor, log and returned batch."""
+    FOR BIT in every state tensor, log and returned batch.  `dr`: with every domain-randomisation hook on (friction buckets, added mass,
+    CoM shift, 5 substeps of action lag, a push every 4th step) -- per-env parameters and the lag ring are addressed per half-wave."""
+    def mk():
+        d, k, _ = make_desc(task, N)
+        if dr:
+            d.rand_friction, d.friction_lo, d.friction_hi = 1, 0.3, 1.5
+            d.rand_base_mass, d.added_mass_lo, d.added_mass_hi = 1, -1.0, 3.0
+            d.rand_com = 1
+            for c, (lo, hi) in enumerate(((-0.05, 0.15), (-0.1, 0.1), (-0.05, 0.05))):
+                d.com_lo[c], d.com_hi[c] = lo, hi
+            d.lag_timesteps, d.push_interval, d.max_push_vel_xy = 5, 4, 1.0
+        return d, k
     monkeypatch.setenv("MQE_ENVS_PER_WAVE", "1")
-    d1, k1, _ = make_desc(task, N)
+    d1, k1 = mk()
     e1 = hip_engine(d1, k1)
     monkeypatch.setenv("MQE_ENVS_PER_WAVE", "2")
-    d2, k2, _ = make_desc(task, N)
+    d2, k2 = mk()
     e2 = hip_engine(d2, k2)
     monkeypatch.delenv("MQE_ENVS_PER_WAVE")
     e1.reset_all(); e2.reset_all()
