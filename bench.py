@@ -49,6 +49,29 @@ def make_args(task, num_envs, seed, device):
     return finish_args(a)
 
 
+def binary_info():
+    """Which libmqe_hip.so ran: __graft_entry__.build_engine() recompiles only when a source is newer than the library, so a GPU box
+    normally loads the library that was cross-compiled in the build container and shipped with the snapshot; the sidecar written by
+    the build says where and when it was made."""
+    import hashlib
+    import socket
+    so = os.path.join(ROOT, "multiagent-quadruped-environment_amd", "csrc", "libmqe_hip.so")
+    so = os.environ.get("MQE_HIP_LIB", so)
+    info = {"path": os.path.relpath(so, ROOT), "so_mtime": None, "so_sha16": None, "built_on_box": None}
+    try:
+        info["so_mtime"] = time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime(os.path.getmtime(so)))
+        info["so_sha16"] = hashlib.sha256(open(so, "rb").read()).hexdigest()[:16]
+        side = json.load(open(so + ".buildinfo"))
+        info["built_on_box"] = bool(side.get("host") == socket.gethostname() and side.get("gpu_visible_at_build"))
+        info["built"] = {k: side.get(k) for k in ("host", "time", "gpu_visible_at_build", "hipcc")}
+        if side.get("so_sha16") not in (None, info["so_sha16"]):
+            info["built_on_box"] = None
+            info["note"] = "sidecar does not describe this library"
+    except Exception:
+        pass
+    return info
+
+
 def cpu_baseline(task, sample_envs, sample_steps, threads=None):
     """Time the CPU oracle (OpenMP over envs/robots) on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -195,24 +218,27 @@ def main():
             ready[0] = None
             n_gathers[0] += 1
 
-    use_gather = (world > 1 or solo_group) and not args.no_gather
-    if use_gather and args.gather == "between":
-        env.env.between_policy_and_physics = issue_gather
+    sharded = world > 1 or solo_group
+    sched = ["none" if (args.no_gather or not sharded) else args.gather]       # the schedule in effect (MQE_BENCH_SWEEP_GATHER re-times the others)
 
     def wait_gathers():               # stream-side: what the compute stream launches next waits for the collectives in flight
         for b in range(2):
             if pending[b] is not None:
                 pending[b].wait()
                 pending[b] = None
-    if use_gather and args.gather == "tail":
-        env.env.before_policy_tail = issue_gather
-        env.env.between_policy_and_physics = wait_gathers
+
+    def set_schedule(name):
+        sched[0] = name
+        env.env.before_policy_tail = issue_gather if name == "tail" else None
+        env.env.between_policy_and_physics = issue_gather if name == "between" else (wait_gathers if name == "tail" else None)
+    set_schedule(sched[0])
 
     def one_step():
         t = step_no[0]
-        a = actions[t]
+        a = actions[t % len(actions)]
         step_no[0] += 1
-        if use_gather and args.gather == "after":
+        use_gather = sched[0] != "none"
+        if use_gather and sched[0] == "after":
             # schedule "after": the gather of the previous batch was issued behind that step's last kernel; this step's first
             # kernel waits for it (stream-side), so the RCCL kernel never shares the GPU with the GEMM or the physics kernel
             for b in range(2):
@@ -222,12 +248,12 @@ def main():
         o, r, d, info = env.step(a)
         if use_gather:
             ready[0] = (t & 1, env.returned_batch)
-            if args.gather == "after":
+            if sched[0] == "after":
                 issue_gather()
         return o
 
     def drain():
-        if use_gather:
+        if sched[0] != "none":
             issue_gather()                            # the last step's batch
         for b in range(2):
             if pending[b] is not None:
@@ -241,19 +267,29 @@ def main():
     # pair costs ~4 us of GPU timeline; bracketing all 5 classes of every step would inflate ms_per_step by 7 %)
     prof_every = 0 if os.environ.get("MQE_BENCH_NOPROF") else max(1, int(os.environ.get("MQE_BENCH_PROF_EVERY", "16")))
     eng.profile_enable(prof_every)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    drain()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+
+    def timed(n):
+        """n steps bracketed by barrier + synchronize on both sides; seconds, MAX over ranks"""
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            one_step()
+        drain()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return el
+    elapsed = timed(args.steps)
+    use_gather = sched[0] != "none"
     if use_gather:   # every step's batch was gathered, and the last one arrived whole: this rank's slice is its own snapshot
         b = (args.warmup + args.steps - 1) & 1
         assert n_gathers[0] == args.warmup + args.steps, (n_gathers[0], args.warmup + args.steps)
@@ -263,11 +299,29 @@ def main():
     ms, _ = eng.profile_read(12)
     overflow_substeps = int(env.env.contact_overflow.sum().item())      # truncated contact lists over the whole run (after the clock stopped)
     eng.profile_enable(False)
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
     value = A * N * world * args.steps / elapsed
+    # A timed region shorter than 50 ms (the driver's --steps 20 is 4.6 ms) is below the resolution of everything that watches the
+    # box from outside (rocm-smi samples, the driver's own clock): the same loop is continued until >= 100 ms of GPU time have been
+    # timed and reported beside the contract's number as value_long (value itself stays the K steps the caller asked for).
+    long_run = None
+    if elapsed < 0.05 and not os.environ.get("MQE_BENCH_NO_LONG"):
+        n_long = int(min(20000, max(args.steps, -(-0.1 // (elapsed / args.steps)))))
+        el_long = timed(n_long)
+        long_run = {"steps": n_long, "ms_per_step": round(1e3 * el_long / n_long, 4), "value": round(A * N * world * n_long / el_long, 1),
+                    "note": "the timed loop continued (same engine, same schedule, fresh actions cycled) until >= 100 ms were timed"}
+    # MQE_BENCH_SWEEP_GATHER=1 (N > 1): one run decides the default schedule -- every all-gather schedule and the no-collective mode
+    # re-timed back to back on the same engine, ms per step each (the headline above is the schedule named in `collective`)
+    sweep = None
+    if sharded and not args.no_gather and os.environ.get("MQE_BENCH_SWEEP_GATHER"):
+        sweep = {}
+        n_sw = max(args.steps, 200)
+        for name in ("none", "tail", "between", "after"):
+            set_schedule(name)
+            timed(20)
+            sweep[name] = round(1e3 * timed(n_sw) / n_sw, 4)
+        set_schedule("none" if args.no_gather else args.gather)
+        base_ms = sweep["none"]
+        sweep = {"steps": n_sw, "ms_per_step": sweep, "overhead_vs_no_collective": {k: round(v / base_ms - 1.0, 4) for k, v in sweep.items() if k != "none"}}
 
     if rank == 0:
         kms = ms[:6]
@@ -362,7 +416,7 @@ def main():
             "metric": f"env-steps/sec (agents x envs x steps/s), {args.task} {N} envs x {A} agents per GPU",
             "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic (U(-1,1) actions seed 1234; synthetic body MLP: body_latest.jit missing upstream)",
+            "vs_baseline": None, "dtype": "f32 (policy GEMMs: 2-plane split-f16, 22-bit)" if split else "f32", "data": "synthetic (U(-1,1) actions seed 1234; synthetic body MLP: body_latest.jit missing upstream)",
             "config": {"workload": f"{args.task}, {A} agents, num_envs={N} per GPU ({N * world} total), 4 substeps x 5 ms per step",
                        "parallelism": (f"env-sharded x{world}, " + ("no collective (per-GPU learners)" if args.no_gather else
                                        f"all-gather of the returned batch issued {dict(between='between policy and physics of the next step', after='after the step, next step waits', tail='after layer 0 of the next step (beside the policy tail), physics waits')[args.gather]}"))
@@ -370,6 +424,9 @@ def main():
             "collective": None if (world == 1 and not solo_group) else ("none" if args.no_gather else {"op": "all_gather_into_tensor", "schedule": args.gather, "bytes_per_rank": int(4 * env.returned_batch.numel()),
                                                                                   "gathers": n_gathers[0]}),
             "target_env_steps_per_s": 1.0e6,
+            "value_long": long_run["value"] if long_run else None, "long_run": long_run,
+            "gather_schedule_sweep": sweep,
+            "binary": binary_info(),
             "physical_robot_steps_per_s": round(value * env.env.num_agents / A, 1),
             "roofline": roof,
             "roofline_policy_layer0": l0,

@@ -332,11 +332,13 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
       s->substeps_epw = 2;
     }
   }
-  if (s->phys_lds_bytes > 48 * 1024)
-    if (hipFuncSetAttribute((const void*)k_simulate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->phys_lds_bytes) != hipSuccess ||
-        hipFuncSetAttribute((const void*)s->substeps_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->phys_lds_bytes) != hipSuccess) {
+  {   // the dynamic LDS of each launch as it is actually requested: one env's layout for k_simulate, substeps_epw of them for k_substeps
+    const size_t lds_sub = s->phys_lds_bytes * (size_t)s->substeps_epw;
+    if (s->phys_lds_bytes > 48 * 1024 && hipFuncSetAttribute((const void*)k_simulate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->phys_lds_bytes) != hipSuccess)
       return fail(-4, "cannot raise dynamic LDS limit");
-    }
+    if (lds_sub > 48 * 1024 && hipFuncSetAttribute((const void*)s->substeps_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sub) != hipSuccess)
+      return fail(-4, "cannot raise dynamic LDS limit");
+  }
   s->fuse_substeps = getenv("MQE_NO_FUSE_SUBSTEPS") == nullptr && d->decimation <= 4;
   // Debug / experiment switches are read HERE, once per handle, never on the launch path; MQE_VERBOSE lists the ones in effect.
   if (const char* sp = getenv("MQE_DEBUG_STOP_PHASE")) {

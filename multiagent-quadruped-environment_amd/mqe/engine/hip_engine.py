@@ -131,7 +131,8 @@ class HipEngine(EngineBase):
         self._call("wrapper_eval", int(is_reset), self._stream())
 
     def save_state(self):
-        """Checkpoint: every state buffer of the handle + its ring positions as one host blob (numpy uint8); see mqe_state_save."""
+        """Checkpoint: every state buffer of the handle + its ring positions as one host blob (numpy uint8); see mqe_state_save.
+        Not part of it: a caller-owned return buffer (mqe_set_return_buffer) and the wrappers' host-side counters."""
         self.lib.mqe_state_size.argtypes, self.lib.mqe_state_size.restype = [C.c_void_p], C.c_longlong
         blob = np.empty(int(self.lib.mqe_state_size(self.h)) + 8, np.uint8)
         self._call("state_save", C.c_void_p(blob.ctypes.data), self._stream())
@@ -140,6 +141,10 @@ class HipEngine(EngineBase):
 
     def load_state(self, blob):
         blob = np.ascontiguousarray(blob, np.uint8)
+        self.lib.mqe_state_size.argtypes, self.lib.mqe_state_size.restype = [C.c_void_p], C.c_longlong
+        want = int(self.lib.mqe_state_size(self.h)) + 8
+        if blob.nbytes != want:     # the C side checks the header against the handle, not the length of the caller's buffer
+            raise ValueError(f"checkpoint blob has {blob.nbytes} bytes, this handle's state takes {want} (truncated file or another scene shape)")
         self._call("state_load", C.c_void_p(blob.ctypes.data), self._stream())
         self._n_policy = int(np.frombuffer(blob[-8:].tobytes(), np.int64)[0])
 

@@ -307,6 +307,9 @@ class Go1:
         if self.task == "football_defender" and cmd.shape[0] == self.num_envs * 2:
             # Go1FootballDefender.step (go1_football_defender.py:25-31): the scripted defender's command is appended to the two
             # learners' commands (mqe_defender_command evaluates _get_defender_action, :56-80, from the current state)
+            if e.desc.num_command_dims != 3:
+                raise NotImplementedError("the scripted defender issues (x, y, yaw) commands (go1_football_defender.py:56-80): command.cfg columns "
+                                          "beyond the velocity command are not defined for this task")
             dc = torch.empty(self.num_envs, 3, device=cmd.device)
             e.defender_command(dc)
             cmd = torch.cat([cmd.view(self.num_envs, 2, 3), dc.unsqueeze(1)], dim=1).reshape(-1, 3).contiguous()

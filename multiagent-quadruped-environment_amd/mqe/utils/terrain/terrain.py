@@ -254,4 +254,8 @@ class Terrain:
         self.height_field_raw[sx:ex, sy:ey] = terrain.height_field_raw
         x1, x2 = int((self.env_length / 2. - 1) / terrain.horizontal_scale), int((self.env_length / 2. + 1) / terrain.horizontal_scale)
         y1, y2 = int((self.env_width / 2. - 1) / terrain.horizontal_scale), int((self.env_width / 2. + 1) / terrain.horizontal_scale)
-        self.env_origins[i, j] = [(i + 0.5) * self.env_length, (j + 0.5) * self.env_width, np.max(terrain.height_field_raw[x1:x2, y1:y2]) * terrain.vertical_scale]
+        # The raster includes the border (this sub-terrain starts `border` pixels in) and the engine samples it from the world origin,
+        # whereas upstream keeps origins border-free and shifts the MESH by -border_size (legged_robot.py:698-699,715-716): the same
+        # scene in this engine's coordinates has the border added to the origins (robots spawn on their platform, not border_size off it).
+        bs = self.border * terrain.horizontal_scale
+        self.env_origins[i, j] = [bs + (i + 0.5) * self.env_length, bs + (j + 0.5) * self.env_width, np.max(terrain.height_field_raw[x1:x2, y1:y2]) * terrain.vertical_scale]

@@ -24,6 +24,8 @@ def build():
 def load_library(f64=False):
     name = "libmqe_oracle_f64.so" if f64 else "libmqe_oracle.so"
     if os.environ.get("MQE_ORACLE_LIB"):          # the sanitizer build (oracle/Makefile: asan), tests/test_oracle_sanitized.py
+        if f64:
+            raise RuntimeError("MQE_ORACLE_LIB overrides the f32 oracle only; unset it to load the f64 build")
         name = os.environ["MQE_ORACLE_LIB"]
     if name not in _LIBS:
         path = os.path.join(HERE, name)

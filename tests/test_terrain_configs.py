@@ -238,6 +238,15 @@ def test_legacy_terrain_generators():
     assert t1.height_field_raw.shape == (3 * 80 + 40, 4 * 80 + 40) and t1.env_origins.shape == (3, 4, 3) and t1.agent_origins.shape == (3, 4, 2, 3)
     assert (t1.height_field_raw[:20] == 0).all() and (t1.height_field_raw[:, :20] == 0).all()              # flat border
     assert t1.ground_height.shape == t1.height_field_raw.shape and not t1.wall.any()
+    # with border_size > 0 the raster contains the border and the engine samples it from the world origin, so the env origins
+    # carry the border too (upstream shifts the mesh by -border_size instead, legged_robot.py:698-699): the map under every origin reads
+    # the origin's own height (the platform in the middle of the sub-terrain), and the agents spawn around it
+    for i in range(3):
+        for j in range(4):
+            ox, oy, oz = t1.env_origins[i, j]
+            assert abs(ox - (2.0 + (i + 0.5) * 8.0)) < 1e-9 and abs(oy - (2.0 + (j + 0.5) * 8.0)) < 1e-9
+            assert abs(float(t1.ground_height[int(round(ox / 0.1)), int(round(oy / 0.1))]) - oz) < 1e-6, (i, j, oz)
+            assert np.abs(t1.agent_origins[i, j, :, :2] - t1.env_origins[i, j, :2]).max() < 4.0
     # curriculum: column = terrain type (slope, rough slope, stairs down, stairs up, obstacles), row = difficulty
     blocks = lambda i, j: t1.height_field_raw[20 + 80 * i: 100 + 80 * i, 20 + 80 * j: 100 + 80 * j].astype(float) * 0.005
     assert np.abs(blocks(2, 0)).max() > np.abs(blocks(1, 0)).max() > 0                                      # steeper pyramids in later rows
