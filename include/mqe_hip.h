@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MQE_ABI_VERSION 13
+#define MQE_ABI_VERSION 14
 #define MQE_MAX_SPHERES 32    /* feature points of one robot */
 #define MQE_MAX_PRIMS 20      /* collision primitives of one robot (Go1: 18) */
 #define MQE_MAX_SELF_PAIRS 192
@@ -114,8 +114,18 @@ typedef struct {
   float dt;                               /* 0.005 */
   int32_t decimation;                     /* 4 (go1_config.py:119) */
   float gravity_z;                        /* -9.81 */
-  int32_t solver_iterations;
-  float contact_offset, max_depenetration_velocity, friction, erp;
+  int32_t solver_iterations;              /* sim.physx.num_position_iterations (:221): sweeps over the contact list (solver type 0) resp.
+                                             sub-steps of the temporal Gauss-Seidel (solver type 1) */
+  float contact_offset, max_depenetration_velocity, friction;
+  float erp;                              /* solver type 0 only: share of a penetration asked back per step (velocity-level bias) */
+  /* sim.physx.solver_type (legged_robot_config.py:219, "0: pgs, 1: tgs"; 1 in every config of the reference):
+   *   0 = projected Gauss-Seidel on velocities with the erp bias (the scheme of rounds 1-3, kept);
+   *   1 = temporal Gauss-Seidel as PhysX publishes it: `solver_iterations` sub-steps of dt / n, every contact's separation re-evaluated
+   *       from the motion accumulated so far, penetrations pushed out within the sub-step at <= max_depenetration_velocity (no erp)
+   *       and the push-out speed taken back once the penetration is gone, positions integrated with the accumulated motion.
+   * velocity_iterations = sim.physx.num_velocity_iterations (:222; 0 in every config): further sweeps that see penetrations as
+   * touching and move nothing. */
+  int32_t solver_type, velocity_iterations;
   /* robot */
   mqe_robot_model robot;
   /* NPC free bodies (ball / sheep): mass, isotropic inertia, spheres in the body frame */

@@ -205,7 +205,7 @@ __host__ __device__ inline int mqe_maxc(int A, int P, int cap_npc) { int v = 8 *
 // NPCs keep m->cap_npc one-sided contacts each (2; a box resting on a face 4): per-actor caps so that no actor starves the ones after it
 
 struct PhysLds {   // float offsets into dynamic LDS
-  int root, dof, tau, body, rhs, acc, acth, fcol, leg, legc, basei, sinv, sph, prim, con, side, phi, srec, total;
+  int root, dof, tau, body, rhs, acc, acth, fcol, leg, legc, basei, sinv, sph, prim, con, side, phi, srec, wacc, total;
 };
 #define SREC_STRIDE 20    // row sweep: per contact [u* (3), bias] [mu, 1/d00, 1/d11, 1/d22] [d10, d20, d21, -] [lambda (3), -]
 __host__ __device__ inline int mqe_maxpair(int maxc) { return maxc / 2; }    // two-actor contacts kept per env
@@ -242,6 +242,11 @@ __host__ __device__ inline PhysLds phys_lds_layout(int A, int P, int ND, int nbo
   if (L.prim + nprim * 8 > o) o = L.prim + nprim * 8;     // two arrays of 16 B words: [centre, bounding radius] x nprim, then [half-segment, radius] x nprim
   L.side = scratch;                                         // side B of the two-actor contacts only (side A: registers / the phi area)
   if (scratch + mqe_maxpair(maxc) * SIDE_STRIDE > o) o = scratch + mqe_maxpair(maxc) * SIDE_STRIDE;
+  // temporal Gauss-Seidel: W = sum over the finished position iterations of w (one float per generalized coordinate), behind side B in
+  // the scratch area (the factorisation scratch and the collision geometry are dead when the sweep starts); afterwards voff = what the
+  // positions move with beyond the final velocity
+  L.wacc = scratch + mqe_maxpair(maxc) * SIDE_STRIDE;
+  if (L.wacc + ((ndof + 3) & ~3) > o) o = L.wacc + ((ndof + 3) & ~3);
   L.total = o;
   return L;
 }
@@ -1259,6 +1264,14 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   if (lane < ndof) Vm[lane] = vs0;
   if (lane + LW < ndof) Vm[lane + LW] = vs1;
   __syncthreads();
+  // Contact solver (include/mqe_hip.h solver_type, oracle/mqe_oracle.c "contact solver"): 0 = sweeps on velocities with the erp bias
+  // of the start-of-step separation; 1 = temporal Gauss-Seidel -- npos sub-steps of sdt = dt / npos, each re-evaluating every contact's
+  // separation from the motion accumulated so far.  In the Phi form that motion is sdt (k v* + T W_k), W_k = the sum of w at the end
+  // of the k finished position iterations (L.wacc), so  sep = sd + sdt (k u*_n + Phi_n W_k):  one more row sum per sweep step.
+  const bool tgs = m->solver_type == 1;
+  const int npos = m->solver_iterations, nsweeps = npos + m->vel_iters;
+  const float sdt = tgs ? dt / (float)npos : dt, inv_sdt = 1.0f / sdt;
+  float* waccv = lds + L.wacc;
   const bool is_con = lane < nc;
   float us0 = 0, us1 = 0, us2 = 0, cl0 = 0, cl1 = 0, cl2 = 0, cbias = 0;      // relative velocity of the unconstrained motion, impulse, bias
   float d00 = 0, d10 = 0, d11 = 0, d20 = 0, d21 = 0, d22 = 0;                // my contact's own 3 x 3 block K(c, c) = sum over sides Phi Phi^T
@@ -1269,7 +1282,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   float fA[27];                                                             // Phi of my contact's side A (U 18, Z' 9): registers for the whole sweep
 #pragma unroll
   for (int i = 0; i < 27; i++) fA[i] = 0.0f;
-  for (int i = lane; i < ((ndof + 3) & ~3); i += LW) accv[i] = 0.0f;          // w = sum_c Phi_c^T lambda_c starts at zero (no warm start)
+  for (int i = lane; i < ((ndof + 3) & ~3); i += LW) { accv[i] = 0.0f; if (tgs) waccv[i] = 0.0f; }    // w = sum_c Phi_c^T lambda_c starts at zero (no warm start)
   if (shp.rowgs) {
     // ---- side records for the row sweep: lane = (contact, direction).  The three rows of a contact (normal, two tangents) are
     // independent of each other up to the contact's own 3 x 3 block, so four lanes share a contact (lane & 3 = row, the fourth
@@ -1297,7 +1310,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
         contact_tangents(n, t1, t2);
         const V3 dir = q == 0 ? n : (q == 1 ? t1 : t2);
         const float sd = w1.w;
-        cbq[ps] = sd >= 0 ? -sd / dt : fminf(-sd * m->erp / dt, m->max_depen);
+        cbq[ps] = tgs ? sd : (sd >= 0 ? -sd / dt : fminf(-sd * m->erp / dt, m->max_depen));     // temporal solver: the separation itself
         float fan[9];                            // side A's NEXT row (two sides on one actor: cross terms)
 #pragma unroll
         for (int i = 0; i < 9; i++) fan[i] = 0.0f;
@@ -1445,7 +1458,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     V3 t1, t2;
     contact_tangents(n, t1, t2);
     const float sd = w1.w;
-    cbias = sd >= 0 ? -sd / dt : fminf(-sd * m->erp / dt, m->max_depen);
+    cbias = tgs ? sd : (sd >= 0 ? -sd / dt : fminf(-sd * m->erp / dt, m->max_depen));
     for (int side = 0; side < 2; side++) {
       const int act = side == 0 ? myA : myB, body = side == 0 ? bodyA : bodyB;
       const float sg = side == 0 ? 1.0f : -1.0f;
@@ -1629,7 +1642,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     const int koff = k < 6 ? k : (k < 9 ? SIDE_Z + (k - 6) : 0), kstr = k < 6 ? 6 : 3;
     const int klegmask = (k >= 6 && k < 9) ? -1 : 0;
     __syncthreads();
-    struct RowStep { float ph0, ph1, ph2, wk, s0, s1, s2; int widx; bool on; };
+    struct RowStep { float ph0, ph1, ph2, wk, s0, s1, s2, s3; int widx; bool on; };       // s3 (temporal solver): Phi_n . W, the normal row against the accumulated w
     // the row's sums of Phi[q][k] w[k] over the coordinates of the side record `rec` (info word: lanes | first joint << 4 | first
     // coordinate << 10; columns past the actor's are masked, a robot side without a leg has zero Z' and points at leg 0)
     auto row_products = [&](const float* rec) {
@@ -1647,14 +1660,29 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       a0 += dpp_take<0x141>(a0); a1 += dpp_take<0x141>(a1); a2 += dpp_take<0x141>(a2);
       a0 += dpp_take<0x140>(a0); a1 += dpp_take<0x140>(a1); a2 += dpp_take<0x140>(a2);
       r.s0 = a0; r.s1 = a1; r.s2 = a2;
+      r.s3 = 0.0f;
+      if (tgs) {
+        float a3 = r.ph0 * (r.on ? waccv[r.widx] : 0.0f);
+        asm volatile("" : "+v"(a3));
+        a3 += dpp_take<0xB1>(a3); a3 += dpp_take<0x4E>(a3); a3 += dpp_take<0x141>(a3); a3 += dpp_take<0x140>(a3);
+        r.s3 = a3;
+      }
       return r;
     };
-    // the contact's three rows from its solve record; returns the impulse increments
-    auto row_solve = [&](float* sr, float u0, float u1, float u2, bool writer, float& e0, float& e1, float& e2) {
+    // the contact's three rows from its solve record; returns the impulse increments.  gW = Phi_n . W of the contact (temporal solver),
+    // kacc = position iterations finished so far, vel_it = a velocity iteration (penetrations count as touching)
+    auto row_solve = [&](float* sr, float u0, float u1, float u2, float gW, float kacc, bool vel_it, bool writer, float& e0, float& e1, float& e2) {
       const float4 q0 = reinterpret_cast<const float4*>(sr)[0], q1 = reinterpret_cast<const float4*>(sr)[1];
       const float4 q2 = reinterpret_cast<const float4*>(sr)[2], q3 = reinterpret_cast<const float4*>(sr)[3];
+      float bias = q0.w;
+      if (tgs) {
+        float sep = q0.w + sdt * (kacc * q0.x + gW);
+        if (vel_it) sep = fmaxf(sep, 0.0f);
+        bias = -sep * inv_sdt;
+        if (sep < 0.0f) bias = fminf(bias, m->max_depen);
+      } else if (vel_it) bias = fminf(bias, 0.0f);
       u0 += q0.x; u1 += q0.y; u2 += q0.z;
-      const float ln = fmaxf(q3.x - (u0 - q0.w) * q1.y, 0.0f);
+      const float ln = fmaxf(q3.x - (u0 - bias) * q1.y, 0.0f);
       e0 = ln - q3.x;
       const float lim = q1.x * ln;
       const float l1 = clampf(q3.y - (u1 + q2.x * e0) * q1.z, -lim, lim);
@@ -1680,18 +1708,27 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       a0 += dpp_take<0x141>(a0); a1 += dpp_take<0x141>(a1); a2 += dpp_take<0x141>(a2);
       a0 += dpp_take<0x140>(a0); a1 += dpp_take<0x140>(a1); a2 += dpp_take<0x140>(a2);
       r.s0 = a0; r.s1 = a1; r.s2 = a2;
+      r.s3 = 0.0f;
+      if (tgs) {
+        float a3 = r.ph0 * (r.on ? waccv[r.widx] : 0.0f);
+        asm volatile("" : "+v"(a3));
+        a3 += dpp_take<0xB1>(a3); a3 += dpp_take<0x4E>(a3); a3 += dpp_take<0x141>(a3); a3 += dpp_take<0x140>(a3);
+        r.s3 = a3;
+      }
       return r;
     };
     // (barriers inside: with two envs per wavefront the trip counts are the larger of the two envs'; a row without work idles)
     const int maxlen_w = wave_max_of_groups(maxlen), npair_w = wave_max_of_groups(npair);
-    for (int it = 0; it < m->solver_iterations; it++) {
+    for (int it = 0; it < nsweeps; it++) {
+      const bool vel_it = it >= npos;
+      const float kacc = (float)(vel_it ? npos : it);
       for (int sidx = 0; sidx < maxlen_w; sidx++) {
         if (row < nact && sidx < glen) {                     // the s-th one-sided contact of every actor, each in its own row
           const int c = gstart + sidx;
           const RowStep r = TP == 0 ? row_products_robot(lds + L.phi + c * SIDE_STRIDE, lds + L.srec + c * SREC_STRIDE)      // (all actors are robots)
                                     : row_products(lds + L.phi + c * SIDE_STRIDE);
           float e0, e1, e2;
-          row_solve(lds + L.srec + c * SREC_STRIDE, r.s0, r.s1, r.s2, k == 0, e0, e1, e2);
+          row_solve(lds + L.srec + c * SREC_STRIDE, r.s0, r.s1, r.s2, r.s3, kacc, vel_it, k == 0, e0, e1, e2);
           if (r.on) accv[r.widx] = r.wk + r.ph0 * e0 + r.ph1 * e1 + r.ph2 * e2;
         }
         __syncthreads();
@@ -1704,12 +1741,17 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
         if (row < 2 && c < nc) {
           const RowStep r = row_products(row == 0 ? lds + L.phi + c * SIDE_STRIDE : lds + L.side + (c - nc_terr) * SIDE_STRIDE);
           const float s0 = r.s0 + row_partner(r.s0), s1 = r.s1 + row_partner(r.s1), s2 = r.s2 + row_partner(r.s2);
-          row_solve(lds + L.srec + c * SREC_STRIDE, s0, s1, s2, lane == 0, e0, e1, e2);     // both rows solve the same numbers; one lane records lambda
+          const float s3 = tgs ? r.s3 + row_partner(r.s3) : 0.0f;
+          row_solve(lds + L.srec + c * SREC_STRIDE, s0, s1, s2, s3, kacc, vel_it, lane == 0, e0, e1, e2);     // both rows solve the same numbers; one lane records lambda
           if (row == 0 && r.on) accv[r.widx] = r.wk + r.ph0 * e0 + r.ph1 * e1 + r.ph2 * e2;
           onB = row == 1 && r.on; widxB = r.widx; fb0 = r.ph0; fb1 = r.ph1; fb2 = r.ph2;
         }
         __syncthreads();
         if (onB) accv[widxB] += fb0 * e0 + fb1 * e1 + fb2 * e2;                 // after side A's stores: the sides may share coordinates (self-contact)
+        __syncthreads();
+      }
+      if (tgs && !vel_it) {                                  // the sub-step's motion: W += w (every step above ended with a barrier)
+        for (int i = lane; i < ndof; i += LW) waccv[i] += accv[i];
         __syncthreads();
       }
     }
@@ -1730,13 +1772,24 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       const int ncolA = (infoA >> 4) & 15, legA = (infoA & 15) - 1;
       float* wbA = accv + wA;
       float* wlA = accv + wA + 6 + (legA > 0 ? legA : 0) * 3;
-      auto gs_update = [&]() {
+      auto gs_update = [&](float kacc, bool vel_it) {
         // side A from registers; its actor's coordinates are read once and written once
         float wv[9];
   #pragma unroll
         for (int mm = 0; mm < 6; mm++) wv[mm] = mm < ncolA ? wbA[mm] : 0.0f;
   #pragma unroll
         for (int i = 0; i < 3; i++) wv[6 + i] = legA >= 0 ? wlA[i] : 0.0f;
+        float gW = 0.0f;                       // temporal solver: Phi_n . W over both sides (W = accumulated w of the finished position iterations)
+        if (tgs) {
+          const float* WbA = waccv + wA;
+          const float* WlA = waccv + wA + 6 + (legA > 0 ? legA : 0) * 3;
+  #pragma unroll
+          for (int mm = 0; mm < 6; mm++) if (mm < ncolA) gW += fA[mm] * WbA[mm];
+          if (legA >= 0) {
+  #pragma unroll
+            for (int i = 0; i < 3; i++) gW += fA[SIDE_Z + i] * WlA[i];
+          }
+        }
         float u0 = us0, u1 = us1, u2 = us2;
   #pragma unroll
         for (int mm = 0; mm < 6; mm++) { u0 += fA[mm] * wv[mm]; u1 += fA[6 + mm] * wv[mm]; u2 += fA[12 + mm] * wv[mm]; }
@@ -1758,8 +1811,25 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   #pragma unroll
             for (int i = 0; i < 3; i++) { const float x = wl[i]; u0 += fb[SIDE_Z + i] * x; u1 += fb[SIDE_Z + 3 + i] * x; u2 += fb[SIDE_Z + 6 + i] * x; }
           }
+          if (tgs) {
+            const float* Wb = waccv + wB;
+            const float* Wl = waccv + wB + 6 + (legB > 0 ? legB : 0) * 3;
+  #pragma unroll
+            for (int mm = 0; mm < 6; mm++) if (mm < ncolB) gW += fb[mm] * Wb[mm];
+            if (legB >= 0) {
+  #pragma unroll
+              for (int i = 0; i < 3; i++) gW += fb[SIDE_Z + i] * Wl[i];
+            }
+          }
         }
-        const float ln = fmaxf(cl0 - (u0 - cbias) * ik00, 0.0f);
+        float bias = cbias;
+        if (tgs) {
+          float sep = cbias + sdt * (kacc * us0 + gW);
+          if (vel_it) sep = fmaxf(sep, 0.0f);
+          bias = -sep * inv_sdt;
+          if (sep < 0.0f) bias = fminf(bias, m->max_depen);
+        } else if (vel_it) bias = fminf(bias, 0.0f);
+        const float ln = fmaxf(cl0 - (u0 - bias) * ik00, 0.0f);
         const float e0 = ln - cl0;
         const float lim = mu * ln;
         const float l1 = clampf(cl1 - (u1 + d10 * e0) * ik11, -lim, lim);
@@ -1786,13 +1856,19 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
           }
         }
       };
-      for (int it = 0; it < m->solver_iterations; it++) {
+      for (int it = 0; it < nsweeps; it++) {
+        const bool vel_it = it >= npos;
+        const float kacc = (float)(vel_it ? npos : it);
         for (int sidx = 0; sidx < maxlen; sidx++) {
-          if (is_terr && sidx < glenA && lane == gstartA + sidx) gs_update();
+          if (is_terr && sidx < glenA && lane == gstartA + sidx) gs_update(kacc, vel_it);
           __syncthreads();
         }
         for (int c = pair0; c < nc; c++) {
-          if (lane == c) gs_update();
+          if (lane == c) gs_update(kacc, vel_it);
+          __syncthreads();
+        }
+        if (tgs && !vel_it) {                                // the sub-step's motion: W += w
+          for (int i = lane; i < ndof; i += LW) waccv[i] += accv[i];
           __syncthreads();
         }
       }
@@ -1807,12 +1883,20 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     cr[C_F] = f.x; cr[C_F + 1] = f.y; cr[C_F + 2] = f.z;
   }
   // impulses -> velocities: dv = T w.  Base: F w_b; leg: Lm w_l - G^T (F w_b); free body / 1-dof link: M^-1/2 w
-  for (int d = lane; d < ndof; d += LW) {
+  // Temporal solver: the positions move with the ACCUMULATED motion dt (v* + T W / npos), not with dt times the final velocity
+  // v* + T w: what they move with beyond it, voff = T (W / npos - w), goes through the same factors (W is overwritten with
+  // W / npos - w first) and replaces w in L.acc afterwards (the joint-limit impulses below change the velocity and keep voff).
+  if (tgs) {
+    const float inpos = 1.0f / (float)npos;
+    for (int i = lane; i < ndof; i += LW) waccv[i] = waccv[i] * inpos - accv[i];
+    __syncthreads();
+  }
+  auto t_apply = [&](const float* wsrc, int d) -> float {
     float dv;
     if (d < A * MQE_RD) {
       const int r = d / MQE_RD, k = d - r * MQE_RD;
       const float* Fm = lds + L.sinv + r * 72 + 36;
-      const float* wb = accv + r * MQE_RD;
+      const float* wb = wsrc + r * MQE_RD;
       if (k < 6) {
         dv = 0.0f;
 #pragma unroll
@@ -1834,21 +1918,30 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
           dv -= G[nn * 3] * dvb;
         }
       }
-    } else if (shp.has_seesaw) dv = sqrtf(1.0f / m->ss_inertia) * accv[d];
+    } else if (shp.has_seesaw) dv = sqrtf(1.0f / m->ss_inertia) * wsrc[d];
     else {
       const int q = d - A * MQE_RD, k = q - (q / npcdof) * npcdof;
-      dv = sqrtf(1.0f / (k < 3 ? m->npc_mass : m->npc_inertia)) * accv[d];
+      dv = sqrtf(1.0f / (k < 3 ? m->npc_mass : m->npc_inertia)) * wsrc[d];
     }
-    Vm[d] += dv;
+    return dv;
+  };
+  float vo0 = 0.0f, vo1 = 0.0f;                 // voff of this lane's coordinates (lane, lane + LW)
+  for (int d = lane; d < ndof; d += LW) {
+    Vm[d] += t_apply(accv, d);
+    if (tgs) { const float vo = t_apply(waccv, d); if (d == lane) vo0 = vo; else vo1 = vo; }
   }
+  __syncthreads();
+  float* voff = accv;                           // w is consumed: its place holds voff from here (zero for the velocity-level solver)
+  if (lane < ndof) voff[lane] = vo0;
+  if (lane + LW < ndof) voff[lane + LW] = vo1;
   __syncthreads();
   // joint limits: one sequential pass in (robot, joint) order after the contact solve, only when some joint violates.  The bound
   // of a joint's speed is the tighter of its position stops ((limit - q) / dt) and the URDF velocity limit (go1.urdf:115,157,185;
   // PhysX maxJointVelocity); a violation is removed by an impulse along the joint coordinate, so momentum is exchanged with the
   // rest of the robot instead of disappearing.
   {
-    auto jbound = [&](int j, float q, float& lo, float& hi) {
-      lo = (rm.dof_lower[j] - q) / dt; hi = (rm.dof_upper[j] - q) / dt;
+    auto jbound = [&](int j, float q, float vo, float& lo, float& hi) {      // vo: what the joint's position moves with beyond its velocity
+      lo = (rm.dof_lower[j] - q) / dt - vo; hi = (rm.dof_upper[j] - q) / dt - vo;
       const float vl = rm.dof_vel_limit[j];
       if (vl > 0.0f) { lo = fmaxf(lo, -vl); hi = fminf(hi, vl); }
     };
@@ -1860,7 +1953,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
         const int r = d / 12, j = d - r * 12;
         const float q = lds[L.dof + d * 2], v = Vm[r * MQE_RD + 6 + j];
         float lo, hi;
-        jbound(j, q, lo, hi);
+        jbound(j, q, voff[r * MQE_RD + 6 + j], lo, hi);
         viol = viol || v < lo || v > hi;
         if (pass == MQE_LIMIT_PASSES) Vm[r * MQE_RD + 6 + j] = fminf(fmaxf(v, lo), hi);     // residual of the last pass (~1e-3 of the violation)
       }
@@ -1869,7 +1962,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
         for (int j = 0; j < 12; j++) {
           const float q = lds[L.dof + (r * 12 + j) * 2], vj = Vm[r * MQE_RD + 6 + j];
           float lo, hi;
-          jbound(j, q, lo, hi);
+          jbound(j, q, voff[r * MQE_RD + 6 + j], lo, hi);
           float vio = 0.0f;
           if (vj < lo) vio = lo - vj; else if (vj > hi) vio = hi - vj;
           // uniform within the env's lanes: impulse along e_j, dv = M^-1 e_j lambda, (M^-1)_jj lambda = vio.  The barriers need the
@@ -1888,7 +1981,8 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   if (SS && lane == 0) {              // hinge: velocity limit, then the geometric end stops
     float v = Vm[A * MQE_RD];
     v = clampf(v, -m->ss_vel_limit, m->ss_vel_limit);
-    v = clampf(v, (m->ss_theta_lo - ssTheta) / dt, (m->ss_theta_hi - ssTheta) / dt);
+    const float vo = voff[A * MQE_RD];
+    v = clampf(v, (m->ss_theta_lo - ssTheta) / dt - vo, (m->ss_theta_hi - ssTheta) / dt - vo);
     Vm[A * MQE_RD] = v;
   }
   TSTAMP(14);
@@ -1928,23 +2022,26 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     const int r = d / 12, j = d - r * 12;
     const float v = Vm[r * MQE_RD + 6 + j];
     float* ds = lds + L.dof + d * 2;
-    ds[0] = ds[0] + dt * v;
+    ds[0] = ds[0] + dt * (v + voff[r * MQE_RD + 6 + j]);
     ds[1] = v;
   }
   if (SS && lane == 0) {
     const float v = Vm[A * MQE_RD];
-    lds[L.dof + (12 * A) * 2] = ssTheta + dt * v;
+    lds[L.dof + (12 * A) * 2] = ssTheta + dt * (v + voff[A * MQE_RD]);
     lds[L.dof + (12 * A) * 2 + 1] = v;
   }
   if (lane < A + PD) {
     const int act = lane;
     float* rs = lds + L.root + act * 13;
-    const float* v = lds + L.rhs + (act < A ? act * MQE_RD : A * MQE_RD + (act - A) * npcdof);
+    const int vbase = act < A ? act * MQE_RD : A * MQE_RD + (act - A) * npcdof;
+    const float* v = lds + L.rhs + vbase;
+    const float* vo = voff + vbase;
     const bool has_ang = act < A || npcdof == 6;
-    const float wx = has_ang ? v[3] : rs[10], wy = has_ang ? v[4] : rs[11], wz = has_ang ? v[5] : rs[12];
-    for (int k = 0; k < 3; k++) { rs[k] = rs[k] + dt * v[k]; rs[7 + k] = v[k]; }
+    float wx = has_ang ? v[3] : rs[10], wy = has_ang ? v[4] : rs[11], wz = has_ang ? v[5] : rs[12];
+    for (int k = 0; k < 3; k++) { rs[k] = rs[k] + dt * (v[k] + vo[k]); rs[7 + k] = v[k]; }
     if (has_ang) {
       rs[10] = wx; rs[11] = wy; rs[12] = wz;
+      wx += vo[3]; wy += vo[4]; wz += vo[5];          // the orientation moves with the accumulated rotation
       float q0 = rs[3], q1 = rs[4], q2 = rs[5], q3 = rs[6];
       const float d0 = 0.5f * (wx * q3 + wy * q2 - wz * q1);
       const float d1 = 0.5f * (-wx * q2 + wy * q3 + wz * q0);

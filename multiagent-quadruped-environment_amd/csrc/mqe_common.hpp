@@ -28,6 +28,7 @@ struct DevModel {
   int env_id_offset, seed, noise_mode;
   float dt; int decimation; float gravity_z; int solver_iterations;
   float contact_offset, max_depen, friction, erp;
+  int solver_type, vel_iters;                      // desc.solver_type (0: velocity-level sweeps with erp, 1: temporal Gauss-Seidel), desc.velocity_iterations
   mqe_robot_model robot;
   float npc_mass, npc_inertia; int npc_n_spheres; float npc_sphere_center[8][3]; float npc_sphere_radius[8];
   int self_collision;                              // contacts between the links of one robot (rm.self_pair)

@@ -254,6 +254,7 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   m.env_id_offset = d->env_id_offset; m.seed = d->seed; m.noise_mode = d->noise_mode;
   m.dt = d->dt; m.decimation = d->decimation; m.gravity_z = d->gravity_z; m.solver_iterations = d->solver_iterations;
   m.contact_offset = d->contact_offset; m.max_depen = d->max_depenetration_velocity; m.friction = d->friction; m.erp = d->erp;
+  m.solver_type = d->solver_type == 1 ? 1 : 0; m.vel_iters = d->velocity_iterations > 0 ? d->velocity_iterations : 0;
   m.robot = d->robot;
   m.npc_mass = d->npc_mass; m.npc_inertia = d->npc_inertia; m.npc_n_spheres = d->npc_n_spheres;
   memcpy(m.npc_sphere_center, d->npc_sphere_center, sizeof m.npc_sphere_center);
@@ -308,7 +309,7 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   if (getenv("MQE_VERBOSE")) fprintf(stderr, "mqe: physics LDS %zu B per env (wavefront)\n", s->phys_lds_bytes);
   if (const char* pad = getenv("MQE_PHYS_LDS_PAD")) s->phys_lds_bytes += (size_t)atoi(pad);   // experiments: caps the physics kernel's waves per CU
   // the records the physics kernel moves as 16 B words must start on 16 B (kernels_physics.hpp)
-  if ((L.total | L.body | L.sph | L.prim | L.con | L.side | L.leg | L.legc | L.basei | L.sinv | L.fcol | L.acc | L.rhs | L.phi | L.srec) & 3) { return fail(-4, "physics LDS layout: a 16 B record area is misaligned"); }
+  if ((L.total | L.body | L.sph | L.prim | L.con | L.side | L.leg | L.legc | L.basei | L.sinv | L.fcol | L.acc | L.rhs | L.phi | L.srec | L.wacc) & 3) { return fail(-4, "physics LDS layout: a 16 B record area is misaligned"); }
   if (s->phys_lds_bytes > 160 * 1024) { return fail(-4, "physics LDS footprint exceeds 160 KiB"); }
   s->substeps_fn = pick_substeps(m, s->phys_lds_bytes);
   s->a2_scene = s->substeps_fn == (void (*)(const DevModel*, DevState, int, int))k_substeps<2, 0>;

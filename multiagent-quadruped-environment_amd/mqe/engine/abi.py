@@ -1,7 +1,7 @@
 """ctypes mirror of include/mqe_hip.h (keep in sync; tests/test_abi.py checks sizes against the built library)."""
 import ctypes as C
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 MAX_SPHERES, NBODY, NREP, NDOF = 32, 13, 17, 12
 MAX_SELF_PAIRS = 192
 MAX_PRIMS = 20
@@ -55,7 +55,7 @@ class SimDesc(C.Structure):
         ("num_envs", i32), ("num_agents", i32), ("num_npcs", i32), ("npc_kind", i32), ("task", i32),
         ("env_id_offset", i32), ("seed", i32),
         ("dt", f32), ("decimation", i32), ("gravity_z", f32), ("solver_iterations", i32),
-        ("contact_offset", f32), ("max_depenetration_velocity", f32), ("friction", f32), ("erp", f32),
+        ("contact_offset", f32), ("max_depenetration_velocity", f32), ("friction", f32), ("erp", f32), ("solver_type", i32), ("velocity_iterations", i32),
         ("robot", RobotModel),
         ("npc_mass", f32), ("npc_inertia", f32), ("npc_n_spheres", i32),
         ("npc_sphere_center", (f32 * 3) * 8), ("npc_sphere_radius", f32 * 8), ("npc_box_half", f32 * 3), ("npc_contact_cap", i32),

@@ -2,11 +2,14 @@
 construction (legged_robot.py:754-923, go1.py:357-479, legged_robot_config.py:211-229) ends up in this one struct."""
 import ctypes as C
 import math
+import os
 
 import numpy as np
 
 from . import abi
 from ..utils import policy_weights, urdf_model
+
+_ANNOUNCED = {}        # environment overrides already announced on stderr
 
 # reward-term order per task: (scale attribute on cfg.rewards.scales, key in the wrapper's reward_buffer)
 REWARD_TERMS = {
@@ -112,7 +115,7 @@ def task_kind(cfg):
 
 
 def build_desc(cfg, num_envs, terrain, env_origins, agent_origins, gate_pos=None, env_id_offset=0, seed=0,
-               task=None, body=None, resources_root=None, solver_iterations=None, erp=0.2, noise_mode=0):
+               task=None, body=None, resources_root=None, solver_iterations=None, erp=0.2, noise_mode=0, solver_type=None, velocity_iterations=None):
     """Returns (SimDesc, keepalive) -- keepalive holds the numpy arrays the struct points into."""
     keep = []
     d = abi.SimDesc()
@@ -131,6 +134,16 @@ def build_desc(cfg, num_envs, terrain, env_origins, agent_origins, gate_pos=None
     d.contact_offset, d.max_depenetration_velocity = px.contact_offset, px.max_depenetration_velocity
     d.friction = 0.5 * (cfg.terrain.static_friction + 1.0)   # average of terrain and (default 1.0) shape friction
     d.erp = erp
+    # sim.physx.solver_type (legged_robot_config.py:219: 0 pgs, 1 tgs) picks the contact solver of the engine (include/mqe_hip.h);
+    # MQE_SOLVER=pgs|tgs overrides it for A/B runs (announced)
+    d.solver_type = int(solver_type if solver_type is not None else getattr(px, "solver_type", 1))
+    if solver_type is None and os.environ.get("MQE_SOLVER"):
+        import sys
+        d.solver_type = {"pgs": 0, "tgs": 1}[os.environ["MQE_SOLVER"]]
+        if _ANNOUNCED.setdefault("MQE_SOLVER") != os.environ["MQE_SOLVER"]:
+            _ANNOUNCED["MQE_SOLVER"] = os.environ["MQE_SOLVER"]
+            print(f"mqe: override in effect: MQE_SOLVER={os.environ['MQE_SOLVER']}", file=sys.stderr)
+    d.velocity_iterations = int(velocity_iterations if velocity_iterations is not None else getattr(px, "num_velocity_iterations", 0))
     # robot model
     m = urdf_model.load_model("go1", resources_root)
     r = d.robot

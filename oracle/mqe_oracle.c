@@ -1132,17 +1132,44 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
     }
   }
 
-  /* ---- projected Gauss-Seidel on velocities */
-  /* the shapes of a robot carry the env's (randomised) coefficient, averaged with the other shape's (PhysX combine mode);
+  /* ---- contact solver.  d->solver_type follows sim.physx.solver_type (legged_robot_config.py:219: "0: pgs, 1: tgs"):
+   *   0  projected Gauss-Seidel on velocities: `solver_iterations` sweeps over the contacts detected at the start-of-step pose, gaps
+   *      and penetrations enter as a velocity bias (penetration: erp / dt, capped by max_depenetration_velocity), positions are
+   *      integrated once with the final velocity;
+   *   1  temporal Gauss-Seidel as PhysX 4/5 publish it (PxSolverType::eTGS; Macklin et al., "Small Steps in Physics Simulation",
+   *      SCA 2019): the step is cut into `solver_iterations` (= num_position_iterations, :221) sub-steps of dt / n.  Every position
+   *      iteration re-evaluates each contact's separation from the motion accumulated so far (sep = sd + J_n . Delta, J of the
+   *      start-of-step pose), asks for  u_n >= -sep / (dt / n)  -- a gap may close within the sub-step, a penetration is pushed out
+   *      within it, at most at max_depenetration_velocity; no erp -- with the impulse ACCUMULATED over the iterations clamped at
+   *      zero, and then advances the accumulated motion by (dt / n) v.  A penetration that has been pushed out by iteration k asks
+   *      for u_n >= 0 from then on, so the push-out speed is taken back inside the same step instead of staying in the velocity;
+   *      `velocity_iterations` (= num_velocity_iterations, :222; 0 in every config) further sweeps see penetrations as touching
+   *      (sep = max(sep, 0)) and move nothing.  Positions are integrated with the accumulated motion, velocities are the last ones.
+   * the shapes of a robot carry the env's (randomised) coefficient, averaged with the other shape's (PhysX combine mode);
    * contacts without a robot keep d->friction */
+  const int TGS = d->solver_type == 1;
+  const int npos = d->solver_iterations, nvel = d->velocity_iterations > 0 ? d->velocity_iterations : 0;
+  const real sdt = TGS && npos > 0 ? dt / (real)npos : dt;
+  real Dacc[MAXDOF];                   /* TGS: generalized displacement accumulated over the position iterations */
+  for (int i = 0; i < ndof; i++) Dacc[i] = 0;
   real mu_robot = (real)0.5 * (s->dparams[(size_t)env * A * 8] + d->friction);
-  for (int it = 0; it < d->solver_iterations; it++) {
+  for (int it = 0; it < npos + nvel; it++) {
+    const int vel_it = it >= npos;
     for (int ci = 0; ci < w->nc; ci++) {
       contact_t* ct = &w->con[ci];
       real mu = (ct->actA < A || (ct->actB >= 0 && ct->actB < A)) ? mu_robot : (real)d->friction;
       real u[3];
       for (int q = 0; q < 3; q++) { real acc = 0; for (int i = 0; i < ndof; i++) acc += ct->J[q][i] * w->v[i]; u[q] = acc; }
-      real bias = ct->sd >= 0 ? -ct->sd / dt : fminf((float)(-ct->sd * d->erp / dt), d->max_depenetration_velocity);
+      real bias;
+      if (TGS) {
+        real sep = ct->sd;
+        { real acc = 0; for (int i = 0; i < ndof; i++) acc += ct->J[0][i] * Dacc[i]; sep += acc; }
+        if (vel_it && sep < 0) sep = 0;
+        bias = -sep / sdt;
+        if (sep < 0 && bias > d->max_depenetration_velocity) bias = d->max_depenetration_velocity;
+      } else {
+        bias = ct->sd >= 0 ? -ct->sd / dt : (vel_it ? (real)0 : fminf((float)(-ct->sd * d->erp / dt), d->max_depenetration_velocity));
+      }
       real dl[3];
       /* normal row */
       real ln = ct->lam[0] - (u[0] - bias) / ct->K[0][0];
@@ -1160,9 +1187,14 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
       dl[2] = l2 - ct->lam[2]; ct->lam[2] = l2;
       for (int i = 0; i < ndof; i++) w->v[i] += ct->B[0][i] * dl[0] + ct->B[1][i] * dl[1] + ct->B[2][i] * dl[2];
     }
+    if (TGS && !vel_it) for (int i = 0; i < ndof; i++) Dacc[i] += sdt * w->v[i];
   }
+  /* what the positions are integrated with beyond the final velocity: voff = (accumulated motion) / dt - v  (0 for solver type 0).
+   * The joint-limit impulses below act on the velocity AND on the motion of the step: they keep voff. */
+  real voff[MAXDOF];
+  for (int i = 0; i < ndof; i++) voff[i] = (TGS && npos > 0) ? Dacc[i] / dt - w->v[i] : (real)0;
   {
-    /* joint limits: q + dt*qd within [lower, upper] and |qd| <= the URDF velocity limit (go1.urdf:115,157,185; legged_robot.py:315;
+    /* joint limits: q + dt*(qd + voff) within [lower, upper] and |qd| <= the URDF velocity limit (go1.urdf:115,157,185; legged_robot.py:315;
      * PhysX maxJointVelocity); one pass after the contact iterations, violations removed by an impulse along the joint */
     /* Gauss-Seidel over the joints, repeated while something still violates (an impulse on one joint changes its neighbours'
      * speeds), at most LIMIT_PASSES times; then the bound is enforced exactly */
@@ -1172,7 +1204,7 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
         for (int j = 0; j < 12; j++) {
           real q = dofs[(r * 12 + j) * 2];
           real* v = w->v + r * RD;
-          real lo = (m->dof_lower[j] - q) / dt, hi = (m->dof_upper[j] - q) / dt;
+          real lo = (m->dof_lower[j] - q) / dt - voff[r * RD + 6 + j], hi = (m->dof_upper[j] - q) / dt - voff[r * RD + 6 + j];
           if (m->dof_vel_limit[j] > 0) { real vl = m->dof_vel_limit[j]; if (lo < -vl) lo = -vl; if (hi > vl) hi = vl; }
           if (v[6 + j] < lo || v[6 + j] > hi) any = 1;
           if (pass == LIMIT_PASSES) { if (v[6 + j] < lo) v[6 + j] = lo; if (v[6 + j] > hi) v[6 + j] = hi; }
@@ -1182,7 +1214,7 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
         for (int j = 0; j < 12; j++) {
           real q = dofs[(r * 12 + j) * 2];
           real* v = w->v + r * RD;
-          real lo = (m->dof_lower[j] - q) / dt, hi = (m->dof_upper[j] - q) / dt;
+          real lo = (m->dof_lower[j] - q) / dt - voff[r * RD + 6 + j], hi = (m->dof_upper[j] - q) / dt - voff[r * RD + 6 + j];
           if (m->dof_vel_limit[j] > 0) { real vl = m->dof_vel_limit[j]; if (lo < -vl) lo = -vl; if (hi > vl) hi = vl; }
           real viol = 0;
           if (v[6 + j] < lo) viol = lo - v[6 + j];
@@ -1200,7 +1232,7 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
     if (SS) {   /* hinge: velocity limit (seesaw.urdf:65), then the geometric end stops */
       real vv = w->v[sdof], vl = d->seesaw_vel_limit;
       if (vv > vl) vv = vl; if (vv < -vl) vv = -vl;
-      real lo = (d->seesaw_theta_lo - ssTheta) / dt, hi = (d->seesaw_theta_hi - ssTheta) / dt;
+      real lo = (d->seesaw_theta_lo - ssTheta) / dt - voff[sdof], hi = (d->seesaw_theta_hi - ssTheta) / dt - voff[sdof];
       if (vv < lo) vv = lo; if (vv > hi) vv = hi;
       w->v[sdof] = vv;
     }
@@ -1221,13 +1253,14 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
   }
 
   /* ---- integrate (semi-implicit Euler; quaternion: first-order update + renormalise) */
-  if (SS) { float* ds = dofs + (12 * A) * 2; ds[0] = (float)(ds[0] + dt * w->v[sdof]); ds[1] = (float)w->v[sdof]; }
+  if (SS) { float* ds = dofs + (12 * A) * 2; ds[0] = (float)(ds[0] + dt * (w->v[sdof] + voff[sdof])); ds[1] = (float)w->v[sdof]; }
   for (int act = 0; act < nact; act++) {
     float* rs = root + act * 13;
     real* v = act < A ? w->v + act * RD : w->v + A * RD + (act - A) * 6;
-    for (int k = 0; k < 3; k++) { rs[k] = (float)(rs[k] + dt * v[k]); rs[7 + k] = (float)v[k]; rs[10 + k] = (float)v[3 + k]; }
+    const real* vo = act < A ? voff + act * RD : voff + A * RD + (act - A) * 6;      /* positions move with v + voff (TGS: the accumulated motion) */
+    for (int k = 0; k < 3; k++) { rs[k] = (float)(rs[k] + dt * (v[k] + vo[k])); rs[7 + k] = (float)v[k]; rs[10 + k] = (float)v[3 + k]; }
     if (act >= A && lin_only) { for (int k = 0; k < 3; k++) rs[10 + k] = (float)w->v[A * RD + (act - A) * 6 + 3 + k]; continue; }
-    real q[4] = {rs[3], rs[4], rs[5], rs[6]}, wq[3] = {v[3], v[4], v[5]};
+    real q[4] = {rs[3], rs[4], rs[5], rs[6]}, wq[3] = {v[3] + vo[3], v[4] + vo[4], v[5] + vo[5]};
     /* qdot = 0.5 * (w,0) * q */
     real dq[4];
     dq[0] = (real)0.5 * (wq[0] * q[3] + wq[1] * q[2] - wq[2] * q[1]);
@@ -1241,7 +1274,7 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
     if (act < A)
       for (int j = 0; j < 12; j++) {
         float* ds = dofs + (act * 12 + j) * 2;
-        ds[0] = (float)(ds[0] + dt * v[6 + j]);
+        ds[0] = (float)(ds[0] + dt * (v[6 + j] + vo[6 + j]));
         ds[1] = (float)v[6 + j];
       }
   }

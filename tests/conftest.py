@@ -8,6 +8,17 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+import pytest  # noqa: E402
+
+
+@pytest.fixture(params=["pgs", "tgs"])
+def solver(request, monkeypatch):
+    """Both contact solvers of row H (include/mqe_hip.h solver_type: 0 = velocity-level projected Gauss-Seidel with erp, 1 = temporal
+    Gauss-Seidel): modules that `usefixtures("solver")` run every test under each; build_desc reads MQE_SOLVER when no solver_type is given."""
+    monkeypatch.setenv("MQE_SOLVER", request.param)
+    return request.param
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -3,12 +3,14 @@ legged_robot.py:283-294,332-334,470-476, legged_robot_field.py:324-334, go1.py:2
 reference's task configs, so there is no reference trajectory to pin them to: physical known answers on the CPU oracle here,
 HIP-vs-oracle parity in test_gpu_parity.py."""
 import numpy as np
+import pytest
 import torch
 
 from helpers import make_desc, oracle_engine
 from mqe.engine import abi
 
 G = 9.81
+pytestmark = pytest.mark.usefixtures("solver")      # every test under both contact solvers (conftest.py)
 
 
 def _engine(N=2, task="go1gate", **fields):
@@ -78,7 +80,7 @@ def test_added_mass_and_com_shift_enter_the_dynamics():
     assert (e.tensor(abi.T_RESET_COUNT) == 1).all()
 
 
-def test_friction_coefficient_is_per_env_and_averaged_with_the_ground():
+def test_friction_coefficient_is_per_env_and_averaged_with_the_ground(solver):
     """limp robots (zero torque) lying on the ground, pushed sideways: deceleration = mu_contact g with
     mu_contact = (mu_env + mu_ground) / 2 -- 0.55 in env 0, 0.75 in env 1"""
     e, d = _engine()
@@ -89,13 +91,19 @@ def test_friction_coefficient_is_per_env_and_averaged_with_the_ground():
     root = e.tensor(abi.T_ROOT_STATE)
     for t in range(400):
         e.simulate()                                   # collapse and come to rest
-    assert root[:, :, 7:10].abs().max() < 0.15
+    # (the temporal solver's velocity ripple of a body lying on many contacts: tests/test_collision_model_oracle.py)
+    assert root[:, :, 7:10].abs().max() < (0.15 if solver == "pgs" else 0.35)
     root[:, :, 8] = 2.0
     for t in range(20):
         e.simulate()
     dec = (2.0 - root[:, :, 8]) / (20 * d.dt)
     # (4 Gauss-Seidel sweeps over the 8 contacts a lying robot keeps do not converge the friction rows completely: 10 % band)
-    assert (dec[0] / G - 0.55).abs().max() < 0.1 and (dec[1] / G - 0.75).abs().max() < 0.1, dec / G
+    # (the base's deceleration, not the centre of mass's: the push also tips the lying robot, and the two solvers tip it differently;
+    # measured worst deviation 0.08 g velocity-level, 0.115 g temporal -- the two coefficients, 0.2 g apart, stay resolved)
+    # per robot the temporal solver spreads more (0.44 / 0.66 g and 0.74 / 0.90 g); the mean over the env's two robots is the coefficient
+    band = 0.1 if solver == "pgs" else 0.2
+    assert (dec[0] / G - 0.55).abs().max() < band and (dec[1] / G - 0.75).abs().max() < band, dec / G
+    assert abs(float(dec[0].mean()) / G - 0.55) < 0.08 and abs(float(dec[1].mean()) / G - 0.75) < 0.08, dec / G
 
 
 def test_action_lag_delays_the_joint_targets_by_substeps():

@@ -64,7 +64,7 @@ def test_mass_matrix_inverse_and_contacts(task, N):
 
 
 @pytest.mark.parametrize("task,N", [("go1gate", 256), ("go1football-defender", 32), ("go1sheep-hard", 21), ("go1football-2vs2", 12), ("go1pushbox", 32), ("go1bridge", 24), ("go1wrestling", 24)])
-def test_single_substep_matches_oracle(task, N):
+def test_single_substep_matches_oracle(task, N, solver):
     """one 5 ms simulate() from identical states: tolerance 2e-4 abs on positions/velocities (float32 both sides;
     the HIP kernel sums in a different order: CRBA + Schur complement vs per-body Jacobian sums + Cholesky)"""
     eh, eo, d = _pair(task, N)
@@ -148,7 +148,7 @@ def _record(kind, obj):
 
 
 @pytest.mark.parametrize("task,N", [("go1gate", 128), ("go1football-defender", 16), ("go1sheep-hard", 14), ("go1seesaw", 16), ("go1football-2vs2", 8), ("go1football-1vs1", 16), ("go1pushbox", 16), ("go1revolvingdoor", 16), ("go1bridge", 16), ("go1wrestling", 16), ("go1tug", 16)])
-def test_fused_rollout_matches_oracle(task, N):
+def test_fused_rollout_matches_oracle(task, N, solver):
     """20 fused step() calls (policy + 4 substeps + post-step + wrapper) from the seeded reset distribution, nothing re-synchronised.
     Contact dynamics amplify rounding differences (a contact that closes one substep earlier), so the bound is a distribution
     over envs -- median, 99th percentile AND maximum of the base-position deviation -- and the reset flags must agree in every env
@@ -255,7 +255,7 @@ def test_time_outs_bring_both_engines_back_to_the_same_state(task, N):
 
 
 @pytest.mark.parametrize("task,N", [("go1gate", 256), ("go1seesaw", 64), ("go1tug", 32)])
-def test_row_sweep_and_lane_sweep_agree(monkeypatch, task, N):
+def test_row_sweep_and_lane_sweep_agree(monkeypatch, task, N, solver):
     """The contact sweep has two lane mappings (kernels_physics.hpp: one DPP row per actor for scenes of robots and the 1-dof link,
     one lane per contact otherwise).  MQE_LANE_SWEEP=1 sends a robot-only scene down the other one (generic kernels, lane sweep,
     other LDS layout): same records, same Gauss-Seidel order, different summation trees -> 8 fused steps agree to rounding and
@@ -394,7 +394,7 @@ def test_domain_randomisation_matches_oracle():
     assert mism <= 2, f"{mism} reset-flag mismatches"
 
 
-def test_self_contacts_match_oracle():
+def test_self_contacts_match_oracle(solver):
     """asset.self_collisions = 0: contacts between two links of one robot (both contact sides on the same actor: one
     Jacobian row over one set of dofs, coupling blocks with all four side pairings).  Robots in free fall with crossed /
     folded legs, perturbed per env: identical contact lists, then 40 substeps tracked in joint space."""
@@ -433,7 +433,7 @@ def test_self_contacts_match_oracle():
     assert torch.isfinite(eh.tensor(abi.T_ROOT_STATE)).all() and torch.isfinite(eh.tensor(abi.T_DOF_STATE)).all()
 
 
-def test_box_contacts_match_oracle():
+def test_box_contacts_match_oracle(solver):
     """go1pushbox: robots dropped onto / against the free box (sphere vs oriented box narrow phase, box corners vs the
     ground): identical contact lists from identical states, then 60 substeps tracked by the box pose."""
     N = 16
@@ -512,7 +512,7 @@ def test_revolving_door_matches_oracle():
     assert torch.isfinite(eh.tensor(abi.T_ROOT_STATE)).all() and torch.isfinite(eh.tensor(abi.T_DOF_STATE)).all()
 
 
-def test_tug_slider_matches_oracle():
+def test_tug_slider_matches_oracle(solver):
     """go1tug: robots at the rim of the sliding disc (prismatic joint, sphere vs upright cylinder): identical contact lists
     from identical states, slider position tracked over 70 substeps."""
     N = 16
@@ -553,7 +553,7 @@ def test_tug_slider_matches_oracle():
 
 
 @pytest.mark.parametrize("ctrl", ["P", "V", "T"])
-def test_low_level_control_matches_reference_and_oracle(ctrl):
+def test_low_level_control_matches_reference_and_oracle(ctrl, solver):
     """Control types P / V / T: (1) the reference's trace through the unfused entry points; (2) 12 fused mqe_step_joint calls
     (PD / torque law inside k_substeps) against the oracle from the seeded reset distribution."""
     from replay import replay_joint
@@ -587,7 +587,7 @@ def test_low_level_control_matches_reference_and_oracle(ctrl):
     assert int((eh.tensor(abi.T_RESET_BUF).cpu() != eo.tensor(abi.T_RESET_BUF)).sum()) <= N // 8
 
 
-def test_seesaw_plank_matches_oracle():
+def test_seesaw_plank_matches_oracle(solver):
     """go1seesaw: robots dropped onto the plank / the platform / next to the column: contact lists identical, then
     110 substeps of coupled robot-plank dynamics (hinge angle tracked to 2e-4 rad)."""
     N = 24

@@ -12,6 +12,7 @@ from helpers import make_desc, oracle_engine
 from mqe.engine import abi
 
 G = 9.81
+pytestmark = pytest.mark.usefixtures("solver")      # every test under both contact solvers (conftest.py)
 
 
 def flight(N=1, f64=True, widen=True, seed=0, gravity=None, dt=None, **kw):

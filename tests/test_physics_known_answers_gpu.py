@@ -9,7 +9,7 @@ import torch
 from helpers import make_desc, hip_engine, perlin_terrain
 from mqe.engine import abi
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("solver")]      # every known answer under both contact solvers (conftest.py)
 G = 9.81
 
 
