@@ -296,6 +296,7 @@ def main():
         mine = gather[b].view(world, -1)[rank]
         assert torch.equal(mine.view(torch.int32), env.returned_batch.view(torch.int32)), "all-gather: own slice differs from the returned batch"
         assert torch.equal(mine[obs.numel() + N * A:].view(torch.uint8)[:N].view(torch.bool), env.env.reset_buf), "all-gather: done flags"
+    gathers_contract = n_gathers[0]              # collectives of the warm-up + the K timed steps (the long run below adds its own)
     ms, _ = eng.profile_read(12)
     overflow_substeps = int(env.env.contact_overflow.sum().item())      # truncated contact lists over the whole run (after the clock stopped)
     eng.profile_enable(False)
@@ -422,7 +423,7 @@ def main():
                                        f"all-gather of the returned batch issued {dict(between='between policy and physics of the next step', after='after the step, next step waits', tail='after layer 0 of the next step (beside the policy tail), physics waits')[args.gather]}"))
                                       if world > 1 else "single GPU"},
             "collective": None if (world == 1 and not solo_group) else ("none" if args.no_gather else {"op": "all_gather_into_tensor", "schedule": args.gather, "bytes_per_rank": int(4 * env.returned_batch.numel()),
-                                                                                  "gathers": n_gathers[0]}),
+                                                                                  "gathers": gathers_contract, "gathers_incl_long_run_and_sweep": n_gathers[0]}),
             "target_env_steps_per_s": 1.0e6,
             "value_long": long_run["value"] if long_run else None, "long_run": long_run,
             "gather_schedule_sweep": sweep,

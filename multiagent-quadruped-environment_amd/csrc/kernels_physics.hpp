@@ -1268,12 +1268,32 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   // of the start-of-step separation; 1 = temporal Gauss-Seidel -- npos sub-steps of sdt = dt / npos, each re-evaluating every contact's
   // separation from the motion accumulated so far.  In the Phi form that motion is sdt (k v* + T W_k), W_k = the sum of w at the end
   // of the k finished position iterations (L.wacc), so  sep = sd + sdt (k u*_n + Phi_n W_k):  one more row sum per sweep step.
+  // The sweeps themselves are the same for both: a contact's normal row asks for u_n >= bias.  Solver 0 fixes the bias at the start;
+  // solver 1 re-derives it between the sweeps, all contacts at once (lane = contact): sep += sdt (u*_n + Phi_n . w), bias = -sep / sdt
+  // capped at the depenetration speed -- nothing is added to the 64 dependent steps of the sweep.  Velocity iterations (either solver)
+  // see a penetration as touching.  W itself is only needed for the positions at the end: a register per lane (coordinates lane, lane + LW).
   const bool tgs = m->solver_type == 1;
   const int npos = m->solver_iterations, nsweeps = npos + m->vel_iters;
   const float sdt = tgs ? dt / (float)npos : dt, inv_sdt = 1.0f / sdt;
   float* waccv = lds + L.wacc;
+  auto first_bias = [&](float sd) -> float {
+    if (!tgs) return sd >= 0 ? -sd / dt : (npos > 0 ? fminf(-sd * m->erp / dt, m->max_depen) : 0.0f);
+    const float s0 = npos > 0 ? sd : fmaxf(sd, 0.0f);
+    const float b = -s0 * inv_sdt;
+    return s0 < 0.0f ? fminf(b, m->max_depen) : b;
+  };
+  // bias of sweep `it + 1` from the separation after sweep `it`; sep is advanced by the sub-step's normal motion sdt * un when sweep `it` was a position iteration
+  auto next_bias = [&](float& sep, float un, float bias_now, int it) -> float {
+    const bool next_vel = it + 1 >= npos;
+    if (!tgs) return next_vel ? fminf(bias_now, 0.0f) : bias_now;
+    if (it < npos) sep += sdt * un;
+    const float s2 = next_vel ? fmaxf(sep, 0.0f) : sep;
+    const float b = -s2 * inv_sdt;
+    return s2 < 0.0f ? fminf(b, m->max_depen) : b;
+  };
+  float Wacc0 = 0.0f, Wacc1 = 0.0f;
   const bool is_con = lane < nc;
-  float us0 = 0, us1 = 0, us2 = 0, cl0 = 0, cl1 = 0, cl2 = 0, cbias = 0;      // relative velocity of the unconstrained motion, impulse, bias
+  float us0 = 0, us1 = 0, us2 = 0, cl0 = 0, cl1 = 0, cl2 = 0, cbias = 0, csep = 0;      // relative velocity of the unconstrained motion, impulse, bias
   float d00 = 0, d10 = 0, d11 = 0, d20 = 0, d21 = 0, d22 = 0;                // my contact's own 3 x 3 block K(c, c) = sum over sides Phi Phi^T
   int myA = -2, myB = -2;                                                   // actors of my contact's sides
   int wA = 0, wB = 0, infoA = 0, infoB = 0;                                  // first generalized coordinate of each side's actor; the side's info word
@@ -1282,7 +1302,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   float fA[27];                                                             // Phi of my contact's side A (U 18, Z' 9): registers for the whole sweep
 #pragma unroll
   for (int i = 0; i < 27; i++) fA[i] = 0.0f;
-  for (int i = lane; i < ((ndof + 3) & ~3); i += LW) { accv[i] = 0.0f; if (tgs) waccv[i] = 0.0f; }    // w = sum_c Phi_c^T lambda_c starts at zero (no warm start)
+  for (int i = lane; i < ((ndof + 3) & ~3); i += LW) accv[i] = 0.0f;          // w = sum_c Phi_c^T lambda_c starts at zero (no warm start)
   if (shp.rowgs) {
     // ---- side records for the row sweep: lane = (contact, direction).  The three rows of a contact (normal, two tangents) are
     // independent of each other up to the contact's own 3 x 3 block, so four lanes share a contact (lane & 3 = row, the fourth
@@ -1291,11 +1311,11 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     // every lane has read the link records (the records go on top of them); side B has its own area.
     constexpr int NPQ = 2;                       // passes of LW / 4 contacts: scenes of <= 4 actors keep <= 32 contacts, two robots alone <= 16
     const int q = lane & 3;
-    float rowA[NPQ][9], usq[NPQ], dqq[NPQ], dqn[NPQ], cbq[NPQ], muq[NPQ];
+    float rowA[NPQ][9], usq[NPQ], dqq[NPQ], dqn[NPQ], cbq[NPQ], muq[NPQ], sdq[NPQ];
     int infq[NPQ];
 #pragma unroll
     for (int ps = 0; ps < NPQ; ps++) {
-      usq[ps] = 0.0f; dqq[ps] = 0.0f; dqn[ps] = 0.0f; cbq[ps] = 0.0f; muq[ps] = m->friction; infq[ps] = 0;
+      usq[ps] = 0.0f; dqq[ps] = 0.0f; dqn[ps] = 0.0f; cbq[ps] = 0.0f; muq[ps] = m->friction; infq[ps] = 0; sdq[ps] = 0.0f;
 #pragma unroll
       for (int i = 0; i < 9; i++) rowA[ps][i] = 0.0f;
       const int c = ps * (LW / 4) + (lane >> 2);
@@ -1310,7 +1330,8 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
         contact_tangents(n, t1, t2);
         const V3 dir = q == 0 ? n : (q == 1 ? t1 : t2);
         const float sd = w1.w;
-        cbq[ps] = tgs ? sd : (sd >= 0 ? -sd / dt : fminf(-sd * m->erp / dt, m->max_depen));     // temporal solver: the separation itself
+        cbq[ps] = first_bias(sd);
+        sdq[ps] = sd;
         float fan[9];                            // side A's NEXT row (two sides on one actor: cross terms)
 #pragma unroll
         for (int i = 0; i < 9; i++) fan[i] = 0.0f;
@@ -1441,7 +1462,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
           // the record's Z' columns) so that the sweep needs no second record read to find its coordinates
           reinterpret_cast<float4*>(sr)[3] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float((infq[ps] >> 4) & 63));
         }
-        if (q == 0) { rec[SIDE_INFO] = __int_as_float(infq[ps]); sr[3] = cbq[ps]; sr[4] = muq[ps]; }
+        if (q == 0) { rec[SIDE_INFO] = __int_as_float(infq[ps]); sr[3] = cbq[ps]; sr[4] = muq[ps]; sr[16] = sdq[ps]; }      // [16]: the running separation (temporal solver)
       }
     }
     if (is_con) {                                // the sweep groups the contacts by actor: lane = contact again
@@ -1458,7 +1479,8 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     V3 t1, t2;
     contact_tangents(n, t1, t2);
     const float sd = w1.w;
-    cbias = tgs ? sd : (sd >= 0 ? -sd / dt : fminf(-sd * m->erp / dt, m->max_depen));
+    cbias = first_bias(sd);
+    csep = sd;
     for (int side = 0; side < 2; side++) {
       const int act = side == 0 ? myA : myB, body = side == 0 ? bodyA : bodyB;
       const float sg = side == 0 ? 1.0f : -1.0f;
@@ -1642,7 +1664,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     const int koff = k < 6 ? k : (k < 9 ? SIDE_Z + (k - 6) : 0), kstr = k < 6 ? 6 : 3;
     const int klegmask = (k >= 6 && k < 9) ? -1 : 0;
     __syncthreads();
-    struct RowStep { float ph0, ph1, ph2, wk, s0, s1, s2, s3; int widx; bool on; };       // s3 (temporal solver): Phi_n . W, the normal row against the accumulated w
+    struct RowStep { float ph0, ph1, ph2, wk, s0, s1, s2; int widx; bool on; };
     // the row's sums of Phi[q][k] w[k] over the coordinates of the side record `rec` (info word: lanes | first joint << 4 | first
     // coordinate << 10; columns past the actor's are masked, a robot side without a leg has zero Z' and points at leg 0)
     auto row_products = [&](const float* rec) {
@@ -1660,29 +1682,14 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       a0 += dpp_take<0x141>(a0); a1 += dpp_take<0x141>(a1); a2 += dpp_take<0x141>(a2);
       a0 += dpp_take<0x140>(a0); a1 += dpp_take<0x140>(a1); a2 += dpp_take<0x140>(a2);
       r.s0 = a0; r.s1 = a1; r.s2 = a2;
-      r.s3 = 0.0f;
-      if (tgs) {
-        float a3 = r.ph0 * (r.on ? waccv[r.widx] : 0.0f);
-        asm volatile("" : "+v"(a3));
-        a3 += dpp_take<0xB1>(a3); a3 += dpp_take<0x4E>(a3); a3 += dpp_take<0x141>(a3); a3 += dpp_take<0x140>(a3);
-        r.s3 = a3;
-      }
       return r;
     };
-    // the contact's three rows from its solve record; returns the impulse increments.  gW = Phi_n . W of the contact (temporal solver),
-    // kacc = position iterations finished so far, vel_it = a velocity iteration (penetrations count as touching)
-    auto row_solve = [&](float* sr, float u0, float u1, float u2, float gW, float kacc, bool vel_it, bool writer, float& e0, float& e1, float& e2) {
+    // the contact's three rows from its solve record; returns the impulse increments
+    auto row_solve = [&](float* sr, float u0, float u1, float u2, bool writer, float& e0, float& e1, float& e2) {
       const float4 q0 = reinterpret_cast<const float4*>(sr)[0], q1 = reinterpret_cast<const float4*>(sr)[1];
       const float4 q2 = reinterpret_cast<const float4*>(sr)[2], q3 = reinterpret_cast<const float4*>(sr)[3];
-      float bias = q0.w;
-      if (tgs) {
-        float sep = q0.w + sdt * (kacc * q0.x + gW);
-        if (vel_it) sep = fmaxf(sep, 0.0f);
-        bias = -sep * inv_sdt;
-        if (sep < 0.0f) bias = fminf(bias, m->max_depen);
-      } else if (vel_it) bias = fminf(bias, 0.0f);
       u0 += q0.x; u1 += q0.y; u2 += q0.z;
-      const float ln = fmaxf(q3.x - (u0 - bias) * q1.y, 0.0f);
+      const float ln = fmaxf(q3.x - (u0 - q0.w) * q1.y, 0.0f);
       e0 = ln - q3.x;
       const float lim = q1.x * ln;
       const float l1 = clampf(q3.y - (u1 + q2.x * e0) * q1.z, -lim, lim);
@@ -1708,27 +1715,18 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       a0 += dpp_take<0x141>(a0); a1 += dpp_take<0x141>(a1); a2 += dpp_take<0x141>(a2);
       a0 += dpp_take<0x140>(a0); a1 += dpp_take<0x140>(a1); a2 += dpp_take<0x140>(a2);
       r.s0 = a0; r.s1 = a1; r.s2 = a2;
-      r.s3 = 0.0f;
-      if (tgs) {
-        float a3 = r.ph0 * (r.on ? waccv[r.widx] : 0.0f);
-        asm volatile("" : "+v"(a3));
-        a3 += dpp_take<0xB1>(a3); a3 += dpp_take<0x4E>(a3); a3 += dpp_take<0x141>(a3); a3 += dpp_take<0x140>(a3);
-        r.s3 = a3;
-      }
       return r;
     };
     // (barriers inside: with two envs per wavefront the trip counts are the larger of the two envs'; a row without work idles)
     const int maxlen_w = wave_max_of_groups(maxlen), npair_w = wave_max_of_groups(npair);
     for (int it = 0; it < nsweeps; it++) {
-      const bool vel_it = it >= npos;
-      const float kacc = (float)(vel_it ? npos : it);
       for (int sidx = 0; sidx < maxlen_w; sidx++) {
         if (row < nact && sidx < glen) {                     // the s-th one-sided contact of every actor, each in its own row
           const int c = gstart + sidx;
           const RowStep r = TP == 0 ? row_products_robot(lds + L.phi + c * SIDE_STRIDE, lds + L.srec + c * SREC_STRIDE)      // (all actors are robots)
                                     : row_products(lds + L.phi + c * SIDE_STRIDE);
           float e0, e1, e2;
-          row_solve(lds + L.srec + c * SREC_STRIDE, r.s0, r.s1, r.s2, r.s3, kacc, vel_it, k == 0, e0, e1, e2);
+          row_solve(lds + L.srec + c * SREC_STRIDE, r.s0, r.s1, r.s2, k == 0, e0, e1, e2);
           if (r.on) accv[r.widx] = r.wk + r.ph0 * e0 + r.ph1 * e1 + r.ph2 * e2;
         }
         __syncthreads();
@@ -1741,8 +1739,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
         if (row < 2 && c < nc) {
           const RowStep r = row_products(row == 0 ? lds + L.phi + c * SIDE_STRIDE : lds + L.side + (c - nc_terr) * SIDE_STRIDE);
           const float s0 = r.s0 + row_partner(r.s0), s1 = r.s1 + row_partner(r.s1), s2 = r.s2 + row_partner(r.s2);
-          const float s3 = tgs ? r.s3 + row_partner(r.s3) : 0.0f;
-          row_solve(lds + L.srec + c * SREC_STRIDE, s0, s1, s2, s3, kacc, vel_it, lane == 0, e0, e1, e2);     // both rows solve the same numbers; one lane records lambda
+          row_solve(lds + L.srec + c * SREC_STRIDE, s0, s1, s2, lane == 0, e0, e1, e2);     // both rows solve the same numbers; one lane records lambda
           if (row == 0 && r.on) accv[r.widx] = r.wk + r.ph0 * e0 + r.ph1 * e1 + r.ph2 * e2;
           onB = row == 1 && r.on; widxB = r.widx; fb0 = r.ph0; fb1 = r.ph1; fb2 = r.ph2;
         }
@@ -1750,11 +1747,31 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
         if (onB) accv[widxB] += fb0 * e0 + fb1 * e1 + fb2 * e2;                 // after side A's stores: the sides may share coordinates (self-contact)
         __syncthreads();
       }
-      if (tgs && !vel_it) {                                  // the sub-step's motion: W += w (every step above ended with a barrier)
-        for (int i = lane; i < ndof; i += LW) waccv[i] += accv[i];
+      if (tgs && it < npos) { Wacc0 += lane < ndof ? accv[lane] : 0.0f; Wacc1 += lane + LW < ndof ? accv[lane + LW] : 0.0f; }    // (every step above ended with a barrier)
+      if (it + 1 < nsweeps && (tgs || it + 1 >= npos)) {     // what the next sweep asks of the normal rows, lane = contact
+        if (is_con) {
+          float* sr = lds + L.srec + lane * SREC_STRIDE;
+          float g = 0.0f;
+          if (tgs && it < npos) {                            // Phi_n . w from the side records' normal rows
+            for (int side = 0; side < 2; side++) {
+              if (side == 1 && !is_pair) break;
+              const float* rec = side == 0 ? lds + L.phi + lane * SIDE_STRIDE : lds + L.side + (lane - nc_terr) * SIDE_STRIDE;
+              const int info = __float_as_int(rec[SIDE_INFO]);
+              const int ncl = info & 15, jo = (info >> 4) & 63;
+              const float* wb = accv + (info >> 10);
+#pragma unroll
+              for (int mm = 0; mm < 6; mm++) g += rec[mm] * (mm < ncl ? wb[mm] : 0.0f);
+              if (ncl == 9) g += rec[SIDE_Z] * wb[6 + jo] + rec[SIDE_Z + 1] * wb[7 + jo] + rec[SIDE_Z + 2] * wb[8 + jo];
+            }
+          }
+          float sep = sr[16];
+          sr[3] = next_bias(sep, sr[0] + g, sr[3], it);
+          sr[16] = sep;
+        }
         __syncthreads();
       }
     }
+    if (tgs) { if (lane < ndof) waccv[lane] = Wacc0; if (lane + LW < ndof) waccv[lane + LW] = Wacc1; }     // W = the sum of w over the position iterations
     if (is_con) { const float4 q3 = reinterpret_cast<const float4*>(lds + L.srec + lane * SREC_STRIDE)[3]; cl0 = q3.x; cl1 = q3.y; cl2 = q3.z; }
   } else
     {
@@ -1772,24 +1789,13 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       const int ncolA = (infoA >> 4) & 15, legA = (infoA & 15) - 1;
       float* wbA = accv + wA;
       float* wlA = accv + wA + 6 + (legA > 0 ? legA : 0) * 3;
-      auto gs_update = [&](float kacc, bool vel_it) {
+      auto gs_update = [&]() {
         // side A from registers; its actor's coordinates are read once and written once
         float wv[9];
   #pragma unroll
         for (int mm = 0; mm < 6; mm++) wv[mm] = mm < ncolA ? wbA[mm] : 0.0f;
   #pragma unroll
         for (int i = 0; i < 3; i++) wv[6 + i] = legA >= 0 ? wlA[i] : 0.0f;
-        float gW = 0.0f;                       // temporal solver: Phi_n . W over both sides (W = accumulated w of the finished position iterations)
-        if (tgs) {
-          const float* WbA = waccv + wA;
-          const float* WlA = waccv + wA + 6 + (legA > 0 ? legA : 0) * 3;
-  #pragma unroll
-          for (int mm = 0; mm < 6; mm++) if (mm < ncolA) gW += fA[mm] * WbA[mm];
-          if (legA >= 0) {
-  #pragma unroll
-            for (int i = 0; i < 3; i++) gW += fA[SIDE_Z + i] * WlA[i];
-          }
-        }
         float u0 = us0, u1 = us1, u2 = us2;
   #pragma unroll
         for (int mm = 0; mm < 6; mm++) { u0 += fA[mm] * wv[mm]; u1 += fA[6 + mm] * wv[mm]; u2 += fA[12 + mm] * wv[mm]; }
@@ -1811,25 +1817,8 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   #pragma unroll
             for (int i = 0; i < 3; i++) { const float x = wl[i]; u0 += fb[SIDE_Z + i] * x; u1 += fb[SIDE_Z + 3 + i] * x; u2 += fb[SIDE_Z + 6 + i] * x; }
           }
-          if (tgs) {
-            const float* Wb = waccv + wB;
-            const float* Wl = waccv + wB + 6 + (legB > 0 ? legB : 0) * 3;
-  #pragma unroll
-            for (int mm = 0; mm < 6; mm++) if (mm < ncolB) gW += fb[mm] * Wb[mm];
-            if (legB >= 0) {
-  #pragma unroll
-              for (int i = 0; i < 3; i++) gW += fb[SIDE_Z + i] * Wl[i];
-            }
-          }
         }
-        float bias = cbias;
-        if (tgs) {
-          float sep = cbias + sdt * (kacc * us0 + gW);
-          if (vel_it) sep = fmaxf(sep, 0.0f);
-          bias = -sep * inv_sdt;
-          if (sep < 0.0f) bias = fminf(bias, m->max_depen);
-        } else if (vel_it) bias = fminf(bias, 0.0f);
-        const float ln = fmaxf(cl0 - (u0 - bias) * ik00, 0.0f);
+        const float ln = fmaxf(cl0 - (u0 - cbias) * ik00, 0.0f);
         const float e0 = ln - cl0;
         const float lim = mu * ln;
         const float l1 = clampf(cl1 - (u1 + d10 * e0) * ik11, -lim, lim);
@@ -1857,21 +1846,35 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
         }
       };
       for (int it = 0; it < nsweeps; it++) {
-        const bool vel_it = it >= npos;
-        const float kacc = (float)(vel_it ? npos : it);
         for (int sidx = 0; sidx < maxlen; sidx++) {
-          if (is_terr && sidx < glenA && lane == gstartA + sidx) gs_update(kacc, vel_it);
+          if (is_terr && sidx < glenA && lane == gstartA + sidx) gs_update();
           __syncthreads();
         }
         for (int c = pair0; c < nc; c++) {
-          if (lane == c) gs_update(kacc, vel_it);
+          if (lane == c) gs_update();
           __syncthreads();
         }
-        if (tgs && !vel_it) {                                // the sub-step's motion: W += w
-          for (int i = lane; i < ndof; i += LW) waccv[i] += accv[i];
-          __syncthreads();
+        if (tgs && it < npos) { Wacc0 += lane < ndof ? accv[lane] : 0.0f; Wacc1 += lane + LW < ndof ? accv[lane + LW] : 0.0f; }
+        if (it + 1 < nsweeps && (tgs || it + 1 >= npos) && is_con) {       // what the next sweep asks of my normal row (reads w only: no barrier)
+          float g = 0.0f;
+          if (tgs && it < npos) {
+  #pragma unroll
+            for (int mm = 0; mm < 6; mm++) g += fA[mm] * (mm < ncolA ? wbA[mm] : 0.0f);
+            if (legA >= 0) g += fA[SIDE_Z] * wlA[0] + fA[SIDE_Z + 1] * wlA[1] + fA[SIDE_Z + 2] * wlA[2];
+            if (is_pair) {
+              const float* rb = lds + L.side + (lane - nc_terr) * SIDE_STRIDE;
+              const int ncolB = (infoB >> 4) & 15, legB = (infoB & 15) - 1;
+              const float* wb = accv + wB;
+              const float* wl = accv + wB + 6 + (legB > 0 ? legB : 0) * 3;
+  #pragma unroll
+              for (int mm = 0; mm < 6; mm++) g += rb[mm] * (mm < ncolB ? wb[mm] : 0.0f);
+              if (legB >= 0) g += rb[SIDE_Z] * wl[0] + rb[SIDE_Z + 1] * wl[1] + rb[SIDE_Z + 2] * wl[2];
+            }
+          }
+          cbias = next_bias(csep, us0 + g, cbias, it);
         }
       }
+      if (tgs) { if (lane < ndof) waccv[lane] = Wacc0; if (lane + LW < ndof) waccv[lane + LW] = Wacc1; }
     }
   TSTAMP(13);
   if (is_con && (flags & PS_WRITE_CF)) {        // the contact's force on its side A, for the per-body sums further down
@@ -1891,45 +1894,45 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     for (int i = lane; i < ndof; i += LW) waccv[i] = waccv[i] * inpos - accv[i];
     __syncthreads();
   }
-  auto t_apply = [&](const float* wsrc, int d) -> float {
-    float dv;
+  // both through one pass over the factors (the coefficient loads are shared): dv = T w, vo = T (W / npos - w)
+  auto t_apply2 = [&](int d) __attribute__((always_inline)) -> float2 {
+    const float* w1 = accv; const float* w2 = waccv;
+    float dv = 0.0f, vo = 0.0f;
     if (d < A * MQE_RD) {
       const int r = d / MQE_RD, k = d - r * MQE_RD;
       const float* Fm = lds + L.sinv + r * 72 + 36;
-      const float* wb = wsrc + r * MQE_RD;
+      const float* wb = w1 + r * MQE_RD; const float* xb = w2 + r * MQE_RD;
       if (k < 6) {
-        dv = 0.0f;
 #pragma unroll
-        for (int mm = 0; mm < 6; mm++) dv += Fm[k * 6 + mm] * wb[mm];
+        for (int mm = 0; mm < 6; mm++) { const float c = Fm[k * 6 + mm]; dv += c * wb[mm]; if (tgs) vo += c * xb[mm]; }
       } else {
         const int lg = (k - 6) / 3, i = (k - 6) - lg * 3;
         const float* rec = lds + L.leg + (r * 4 + lg) * LEG_STRIDE;
-        const float* wl = wb + 6 + lg * 3;
+        const float* wl = wb + 6 + lg * 3; const float* xl = xb + 6 + lg * 3;
         const float* Lm = rec + LEG_LM + (i * (i + 1)) / 2;
-        dv = Lm[0] * wl[0];
-        if (i >= 1) dv += Lm[1] * wl[1];
-        if (i >= 2) dv += Lm[2] * wl[2];
+        dv = Lm[0] * wl[0]; if (tgs) vo = Lm[0] * xl[0];
+        if (i >= 1) { dv += Lm[1] * wl[1]; if (tgs) vo += Lm[1] * xl[1]; }
+        if (i >= 2) { dv += Lm[2] * wl[2]; if (tgs) vo += Lm[2] * xl[2]; }
         const float* G = rec + LEG_G + i;
 #pragma unroll
         for (int nn = 0; nn < 6; nn++) {
-          float dvb = 0.0f;
+          float dvb = 0.0f, vob = 0.0f;
 #pragma unroll
-          for (int mm = 0; mm < 6; mm++) dvb += Fm[nn * 6 + mm] * wb[mm];
-          dv -= G[nn * 3] * dvb;
+          for (int mm = 0; mm < 6; mm++) { const float c = Fm[nn * 6 + mm]; dvb += c * wb[mm]; if (tgs) vob += c * xb[mm]; }
+          dv -= G[nn * 3] * dvb; if (tgs) vo -= G[nn * 3] * vob;
         }
       }
-    } else if (shp.has_seesaw) dv = sqrtf(1.0f / m->ss_inertia) * wsrc[d];
-    else {
-      const int q = d - A * MQE_RD, k = q - (q / npcdof) * npcdof;
-      dv = sqrtf(1.0f / (k < 3 ? m->npc_mass : m->npc_inertia)) * wsrc[d];
+    } else {
+      float c;
+      if (shp.has_seesaw) c = sqrtf(1.0f / m->ss_inertia);
+      else { const int q = d - A * MQE_RD, k = q - (q / npcdof) * npcdof; c = sqrtf(1.0f / (k < 3 ? m->npc_mass : m->npc_inertia)); }
+      dv = c * w1[d]; if (tgs) vo = c * w2[d];
     }
-    return dv;
+    return make_float2(dv, vo);
   };
   float vo0 = 0.0f, vo1 = 0.0f;                 // voff of this lane's coordinates (lane, lane + LW)
-  for (int d = lane; d < ndof; d += LW) {
-    Vm[d] += t_apply(accv, d);
-    if (tgs) { const float vo = t_apply(waccv, d); if (d == lane) vo0 = vo; else vo1 = vo; }
-  }
+  if (lane < ndof) { const float2 t = t_apply2(lane); Vm[lane] += t.x; vo0 = t.y; }
+  if (lane + LW < ndof) { const float2 t = t_apply2(lane + LW); Vm[lane + LW] += t.x; vo1 = t.y; }
   __syncthreads();
   float* voff = accv;                           // w is consumed: its place holds voff from here (zero for the velocity-level solver)
   if (lane < ndof) voff[lane] = vo0;

@@ -1174,6 +1174,9 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
       /* normal row */
       real ln = ct->lam[0] - (u[0] - bias) / ct->K[0][0];
       if (ln < 0) ln = 0;
+#ifdef MQO_TRACE_ENV
+      if (env == MQO_TRACE_ENV) fprintf(stderr, "ora k %d c %d sd %g bias %g u0 %g lam %g -> %g\n", it, ci, (double)ct->sd, (double)bias, (double)u[0], (double)ct->lam[0], (double)ln);
+#endif
       dl[0] = ln - ct->lam[0]; ct->lam[0] = ln;
       u[1] += ct->K[1][0] * dl[0]; u[2] += ct->K[2][0] * dl[0];
       /* tangent rows, box friction |lt| <= mu ln */

