@@ -425,6 +425,7 @@ def main():
             "collective": None if (world == 1 and not solo_group) else ("none" if args.no_gather else {"op": "all_gather_into_tensor", "schedule": args.gather, "bytes_per_rank": int(4 * env.returned_batch.numel()),
                                                                                   "gathers": gathers_contract, "gathers_incl_long_run_and_sweep": n_gathers[0]}),
             "target_env_steps_per_s": 1.0e6,
+            "contact_solver": {0: "pgs: velocity-level projected Gauss-Seidel, erp %.2f" % d.erp, 1: "tgs: temporal Gauss-Seidel, %d sub-steps of dt / %d (sim.physx.solver_type = 1)" % (d.solver_iterations, d.solver_iterations)}[int(d.solver_type)],
             "value_long": long_run["value"] if long_run else None, "long_run": long_run,
             "gather_schedule_sweep": sweep,
             "binary": binary_info(),
@@ -446,6 +447,11 @@ def main():
             sms, _ = time_variant(args.task, N, dev, min(args.steps, 100), min(args.warmup, 10), {"MQE_GEMM_SPLIT": "0", "MQE_NO_FUSED_TAIL": "1"})
             out["strict_f32"] = {"value": round(A * N / (sms * 1e-3), 1), "unit": "env-steps/s", "ms_per_step": round(sms, 4), "steps": min(args.steps, 100),
                                  "switches": "MQE_GEMM_SPLIT=0 MQE_NO_FUSED_TAIL=1 (k_gemm_f32 for every policy layer)"}
+        if world == 1 and not args.no_strict_f32 and not os.environ.get("MQE_BENCH_NOPROF") and not os.environ.get("MQE_SOLVER"):
+            # what the choice of contact solver costs: the same workload on the velocity-level sweeps of rounds 1-3 (solver_type 0)
+            pms, _ = time_variant(args.task, N, dev, min(args.steps, 100), min(args.warmup, 10), {"MQE_SOLVER": "pgs"})
+            out["solver_pgs"] = {"value": round(A * N / (pms * 1e-3), 1), "unit": "env-steps/s", "ms_per_step": round(pms, 4), "steps": min(args.steps, 100),
+                                 "switches": "MQE_SOLVER=pgs (desc.solver_type = 0: velocity-level projected Gauss-Seidel with the erp bias)"}
         if not args.no_cpu_baseline and world == 1:
             torch.set_num_threads(os.cpu_count() or 1)
             # the CPU restatement at the headline size (few steps) and at the reference's own CPU-runnable size (N = 4)
