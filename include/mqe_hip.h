@@ -187,6 +187,22 @@ typedef struct {
   const float* base_init_state;           /* [A,13] */
   const float* npc_init_state;            /* [P,13] */
   const float* gate_pos;                  /* [N,2] task specific (wrappers' gate_pos / football gate) or NULL */
+  /* Run-time terrain curriculum (terrain.curriculum with several rows; legged_robot.py:479-503, called first in reset_idx,
+   * go1.py:123-125), upstream's code restated with its accidents (fixture tests/golden/fullstep_seesaw_curriculum.npz): when env e
+   * is reset -- the first reset() included, init_done is set before it -- the distance walked is measured on ROW e of the agents'
+   * root-state tensor (robot e % A of env e / A: single-agent code left in place) against env e's origin, as the rows stood before
+   * any reset of this step; farther than terrain_env_length / 2 moves the env one level up; the commands Go1 never samples are zero,
+   * so nothing ever moves down; past the last level a level is re-drawn uniformly; then ONLY env_origins[e] is re-read from the
+   * origin table -- the live tensor behind the NPCs' respawn (:437) and the football / push-box wrappers; agent_origins (where the
+   * robots respawn), the env_origins_repeat copy behind obs.base_pos, env_info and the copies made at construction (sheep
+   * wrapper, gate positions) keep the first track.  terrain_origins [rows][cols][3], terrain_levels / terrain_types [N] are host
+   * pointers read at creation; the live values are MQE_T_TERRAIN_LEVELS / MQE_T_ENV_ORIGINS.  A shard of a larger batch
+   * (env_id_offset != 0) cannot evaluate it: row e belongs to another shard's env. */
+  int32_t terrain_curriculum, terrain_num_rows, terrain_num_cols;
+  float terrain_env_length;
+  const float* terrain_origins;
+  const int32_t* terrain_levels;
+  const int32_t* terrain_types;
   /* termination (reference go1_config.py:187-207, legged_robot.py:159-169) */
   int32_t termination_flags, terminate_on_base_contact, max_episode_length;
   float roll_threshold, pitch_threshold, z_low_threshold, z_high_threshold;
@@ -252,6 +268,9 @@ enum {
   MQE_T_SUBSTEP_EXCEED_DOF_POS_LIMITS,   /* uint8 [N,4,12A] joint outside its soft position limits after each substep (legged_robot.py:115) */
   MQE_T_CONTACT_OVERFLOW,  /* int32 [N]: substeps so far in which the bounded contact list of the env dropped a touching pair (per-actor
                               cap or list end); 0 everywhere = no contact was ever truncated */
+  MQE_T_ENV_ORIGINS,       /* [N,3] the LIVE env origins (legged_robot.py:495): what the NPCs respawn around and the football / push-box
+                              wrappers subtract; equal to desc.env_origins unless the terrain curriculum has moved an env */
+  MQE_T_TERRAIN_LEVELS,    /* int32 [N] terrain level of each env (legged_robot.py:983,490) */
   MQE_T_COUNT
 };
 

@@ -383,11 +383,33 @@ __device__ __forceinline__ void compute_observations_env(const DevModel* m, cons
   }
 }
 
+// Run-time terrain curriculum (legged_robot.py:479-503; include/mqe_hip.h terrain_curriculum).  k_curriculum_snapshot copies the xy of the
+// agents' root-state ROWS 0 .. N-1 (row e = robot e % A of env e / A: upstream indexes that tensor with env ids) before the post-physics
+// kernel resets anything; the reset of env e then moves the env's level and re-reads ITS origin only.
+__global__ void __launch_bounds__(256) k_curriculum_snapshot(const DevModel* m, DevState st) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= m->N) return;
+  const float* rs = st.root + ((size_t)(e / m->A) * (m->A + m->P) + e % m->A) * 13;
+  st.curr_xy[e * 2] = rs[0]; st.curr_xy[e * 2 + 1] = rs[1];
+}
+__device__ __forceinline__ void curriculum_move_dev(const DevModel* m, const DevState& st, int e) {
+  const float dx = st.curr_xy[e * 2] - st.env_origins_live[e * 3], dy = st.curr_xy[e * 2 + 1] - st.env_origins_live[e * 3 + 1];
+  const float distance = sqrtf(dx * dx + dy * dy);
+  const int move_up = distance > m->terrain_env_length / 2 ? 1 : 0;      // (move_down: distance < |commands| * ... with commands == 0: never)
+  int lvl = st.terrain_levels[e] + move_up;
+  if (lvl >= m->terrain_rows) lvl = (int)(mqe_u01((uint32_t)m->seed, (uint32_t)(e + m->env_id_offset), (uint32_t)st.reset_count[e], 250u) * (float)m->terrain_rows);
+  else if (lvl < 0) lvl = 0;
+  if (lvl >= m->terrain_rows) lvl = m->terrain_rows - 1;
+  st.terrain_levels[e] = lvl;
+  for (int k = 0; k < 3; k++) st.env_origins_live[e * 3 + k] = m->terrain_origins[((size_t)lvl * m->terrain_cols + m->terrain_types[e]) * 3 + k];
+}
+
 __device__ __forceinline__ void reset_env_dev(const DevModel* m, const DevState& st, int e) {
   int A = m->A, P = m->P;
   float* root = st.root + (size_t)e * (A + P) * 13;
   float* dofs = st.dof + (size_t)e * m->ND * 2;
   int cnt = st.reset_count[e];
+  if (m->curriculum) curriculum_move_dev(m, st, e);          // go1.py:123-125: first thing in reset_idx
   for (int a = 0; a < A; a++)
     for (int j = 0; j < 12; j++) {
       float ratio = mqe_rand(m, e, cnt, (uint32_t)(a * 12 + j), m->dof_ratio_lo, m->dof_ratio_hi);
@@ -403,7 +425,7 @@ __device__ __forceinline__ void reset_env_dev(const DevModel* m, const DevState&
   for (int p = 0; p < P; p++) {
     float* rs = root + (A + p) * 13;
     for (int k = 0; k < 13; k++) rs[k] = m->npc_init[p * 13 + k];
-    for (int k = 0; k < 3; k++) rs[k] += m->env_origins[e * 3 + k];
+    for (int k = 0; k < 3; k++) rs[k] += st.env_origins_live[e * 3 + k];
   }
   if (m->has_base_pos_range)
     for (int a = 0; a < A; a++) {
@@ -520,13 +542,13 @@ __device__ void wrapper_env_dev(const DevModel* m, const DevState& st, int e, in
     }
     if (m->task == MQE_TASK_GATE || m->task == MQE_TASK_SHEEP || m->task == MQE_TASK_PUSHBOX) { o[c++] = m->gate_pos[e * 2]; o[c++] = m->gate_pos[e * 2 + 1]; }
     if (m->task == MQE_TASK_PUSHBOX) {              // go1_pushbox_wrapper.py:44-48: box xy rel. env origin, box quaternion
-      o[c++] = npc[0] - m->env_origins[e * 3]; o[c++] = npc[1] - m->env_origins[e * 3 + 1];
+      o[c++] = npc[0] - st.env_origins_live[e * 3]; o[c++] = npc[1] - st.env_origins_live[e * 3 + 1];
       for (int k = 0; k < 4; k++) o[c++] = npc[3 + k];
     }
     if (m->task == MQE_TASK_SHEEP)
       for (int p = 0; p < P; p++) { o[c++] = npc[p * 13] - m->env_origins[e * 3]; o[c++] = npc[p * 13 + 1] - m->env_origins[e * 3 + 1]; }
     if (m->task == MQE_TASK_FOOTBALL_DEFENDER) {
-      for (int k = 0; k < 3; k++) o[c++] = npc[k] - m->env_origins[e * 3 + k];
+      for (int k = 0; k < 3; k++) o[c++] = npc[k] - st.env_origins_live[e * 3 + k];
       for (int k = 0; k < 3; k++) o[c++] = npc[7 + k];
     }
   }
@@ -751,7 +773,7 @@ __device__ void wrapper_env_dev(const DevModel* m, const DevState& st, int e, in
     return;
   }
   if (m->task == MQE_TASK_PUSHBOX) {                // go1_pushbox_wrapper.py:52-88
-    const float bx = npc[0] - m->env_origins[e * 3];
+    const float bx = npc[0] - st.env_origins_live[e * 3];
     if (sc[0] != 0 && st.w_have_last[e]) {
       float xm = bx - st.w_last2[e * 2];
       if (was_reset) xm = 0;                        // x_movement[reset_ids] = 0
@@ -764,7 +786,7 @@ __device__ void wrapper_env_dev(const DevModel* m, const DevState& st, int e, in
     return;
   }
   if (m->task == MQE_TASK_FOOTBALL_DEFENDER) {
-    float bx = npc[0] - m->env_origins[e * 3], by = npc[1] - m->env_origins[e * 3 + 1];
+    float bx = npc[0] - st.env_origins_live[e * 3], by = npc[1] - st.env_origins_live[e * 3 + 1];
     if (sc[0] != 0) { if (bx > m->gate_pos[e * 2]) { r_env += sc[0]; rs[0] += sc[0]; } }
     if (sc[1] != 0) {
       float dg = sqrtf((bx - m->gate_pos[e * 2]) * (bx - m->gate_pos[e * 2]) + (by - m->gate_pos[e * 2 + 1]) * (by - m->gate_pos[e * 2 + 1]));

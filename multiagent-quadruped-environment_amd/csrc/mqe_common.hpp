@@ -46,7 +46,9 @@ struct DevModel {
   const float* wall_top;                           // per-cell wall top [m] (walls of different heights), or nullptr = wall_height
   const float* ground_height;                      // relief of the walkable surface above ground_z at the SDF's raster points, or nullptr
   float soft_lo[12], soft_hi[12];                  // soft joint position limits (legged_robot.py:317-321) of MQE_T_SUBSTEP_EXCEED_DOF_POS_LIMITS
-  const float *env_origins, *agent_origins, *base_init, *npc_init, *gate_pos;
+  const float *env_origins, *agent_origins, *base_init, *npc_init, *gate_pos;   // env_origins: the values at construction (obs.base_pos, sheep wrapper, gate height); the live ones are DevState::env_origins_live
+  int curriculum, terrain_rows, terrain_cols; float terrain_env_length;            // run-time terrain curriculum (include/mqe_hip.h terrain_curriculum)
+  const float* terrain_origins; const int32_t* terrain_types;                      // [rows][cols][3]; [N]
   int termination_flags, terminate_on_base_contact, max_episode_length;
   float roll_thr, pitch_thr, zlow_thr, zhigh_thr;
   float dof_ratio_lo, dof_ratio_hi; int has_base_pos_range, has_npc_pos_range;
@@ -72,6 +74,8 @@ struct DevState {
   uint32_t* hist_irr;                       // [R] bit s: the frame in ring slot s does not continue its predecessor's actions (MQE_H2_FRAME)
   int32_t *ep_len, *reset_count;
   uint8_t *reset_buf, *collide_buf, *time_out, *r_term, *p_term, *zh_term, *w_have_last, *w_delayed_reset;
+  float *env_origins_live, *curr_xy;        // MQE_T_ENV_ORIGINS [N][3]; pre-reset xy of the agents' root-state rows 0 .. N-1 (terrain curriculum)
+  int32_t* terrain_levels;                  // MQE_T_TERRAIN_LEVELS [N]
   uint8_t* wdone;         // the reset flags once more, as the byte tail of the packed return batch (obs | reward | done)
 };
 

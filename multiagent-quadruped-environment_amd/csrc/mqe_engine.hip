@@ -367,6 +367,16 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   }
   UP(m.env_origins, d->env_origins, (size_t)N * 3);
   UP(m.agent_origins, d->agent_origins, (size_t)N * A * 3);
+  m.curriculum = d->terrain_curriculum ? 1 : 0; m.terrain_rows = d->terrain_num_rows; m.terrain_cols = d->terrain_num_cols; m.terrain_env_length = d->terrain_env_length;
+  m.terrain_origins = nullptr; m.terrain_types = nullptr;
+  if (m.curriculum) {
+    if (d->env_id_offset != 0) return fail(-6, "terrain curriculum: not defined for a shard of a larger batch (row e of the agents' root states belongs to another shard's env)");
+    if (!d->terrain_origins || !d->terrain_levels || !d->terrain_types || d->terrain_num_rows < 1 || d->terrain_num_cols < 1) return fail(-6, "terrain curriculum: origin table / levels / types missing");
+    UP(m.terrain_origins, d->terrain_origins, (size_t)d->terrain_num_rows * d->terrain_num_cols * 3);
+    const float* tt = nullptr;
+    UP(tt, reinterpret_cast<const float*>(d->terrain_types), (size_t)N);
+    m.terrain_types = reinterpret_cast<const int32_t*>(tt);
+  }
   UP(m.base_init, d->base_init_state, (size_t)A * 13);
   UP(m.npc_init, d->npc_init_state, (size_t)P * 13);
   UP(m.gate_pos, d->gate_pos, (size_t)N * 2);
@@ -469,6 +479,9 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   DA(st.sub_tau, (size_t)N * 4 * 12 * A); DA(st.npc_noise, (size_t)N * (P ? P : 1) * 3);
   DA(st.w_last, (size_t)N * MQE_MAX_AGENTS); DA(st.w_last2, (size_t)N * 2); DA(st.cmd, (size_t)R * 3);
   DA(st.ep_len, N); DA(st.reset_count, N); DA(st.last_dof_vel, (size_t)R * 12);
+  DA(st.env_origins_live, (size_t)N * 3); DA(st.curr_xy, (size_t)N * 2); DA(st.terrain_levels, N);
+  if (hipMemcpy(st.env_origins_live, d->env_origins, (size_t)N * 12, hipMemcpyHostToDevice) != hipSuccess) return fail(-5, "upload");
+  if (d->terrain_curriculum && hipMemcpy(st.terrain_levels, d->terrain_levels, (size_t)N * 4, hipMemcpyHostToDevice) != hipSuccess) return fail(-5, "upload");
   // domain parameters (include/mqe_hip.h): drawn once, keyed by the global env id so that a sharded run sees the same robots
   {
     std::vector<float> dp((size_t)R * 8, 0.0f);
@@ -525,6 +538,7 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   t[MQE_T_SUBSTEP_TORQUES] = st.sub_tau; t[MQE_T_NPC_NOISE] = st.npc_noise; t[MQE_T_WRAPPER_PACKED] = st.wobs;
   t[MQE_T_DOMAIN_PARAMS] = st.dparams;
   t[MQE_T_SUBSTEP_DOF_VEL] = st.sub_dof_vel; t[MQE_T_SUBSTEP_EXCEED_DOF_POS_LIMITS] = st.sub_exceed; t[MQE_T_CONTACT_OVERFLOW] = st.overflow;
+  t[MQE_T_ENV_ORIGINS] = st.env_origins_live; t[MQE_T_TERRAIN_LEVELS] = st.terrain_levels;
   HIPCHK(hipDeviceSynchronize());
   guard.s = nullptr;
   *out = s;
@@ -572,7 +586,8 @@ extern "C" int mqe_sim_tensor(mqe_sim* s, int kind, mqe_tensor_view* v) {
     case MQE_T_SHEEP_POS_VAR: SH(1, N, 0, 0, 0, 0); break;
     case MQE_T_SUBSTEP_TORQUES: case MQE_T_SUBSTEP_DOF_VEL: SH(3, N, 4, 12 * A, 0, 0); break;
     case MQE_T_SUBSTEP_EXCEED_DOF_POS_LIMITS: SH(3, N, 4, 12 * A, 0, 2); break;
-    case MQE_T_CONTACT_OVERFLOW: SH(1, N, 0, 0, 0, 1); break;
+    case MQE_T_CONTACT_OVERFLOW: case MQE_T_TERRAIN_LEVELS: SH(1, N, 0, 0, 0, 1); break;
+    case MQE_T_ENV_ORIGINS: SH(2, N, 3, 0, 0, 0); break;
     case MQE_T_NPC_NOISE: SH(3, N, P, 3, 0, 0); break;
     case MQE_T_WRAPPER_PACKED: SH(1, N * s->Aw * s->D + N * s->Aw + (N + 3) / 4, 0, 0, 0, 0); break;
     case MQE_T_DOMAIN_PARAMS: SH(2, s->R, 8, 0, 0, 0); break;
@@ -739,6 +754,7 @@ static void launch_post(mqe_sim* s, hipStream_t q, int wrapper_level) {
   ProfScope ps(s, PROF_POST, q);
   s->n_post_steps++;                          // = common_step_counter after its increment (legged_robot.py:127)
   const int push = (s->d.push_interval > 0 && s->n_post_steps % s->d.push_interval == 0) ? (int)(s->n_post_steps / s->d.push_interval) : 0;
+  if (s->hm.curriculum) hipLaunchKernelGGL(k_curriculum_snapshot, dim3((s->N + 255) / 256), dim3(256), 0, q, s->dm, s->st);   // the rows every reset of this step measures
   if (s->hm.A <= 2)
     hipLaunchKernelGGL(k_post_physics<2>, dim3((s->N + POST_EPW - 1) / POST_EPW), dim3(64), 0, q, s->dm, s->st, wrapper_level, push, s->n_post_steps);
   else
@@ -862,6 +878,7 @@ extern "C" int mqe_set_dof_state_indexed(mqe_sim*, const int32_t*, int, void*) {
 extern "C" int mqe_reset_all(mqe_sim* s, void* stream) {
   if (!s) return fail(-1, "null engine handle");
   hipStream_t q = (hipStream_t)stream;
+  if (s->hm.curriculum) hipLaunchKernelGGL(k_curriculum_snapshot, dim3((s->N + 255) / 256), dim3(256), 0, q, s->dm, s->st);
   hipLaunchKernelGGL(k_reset_all, dim3((s->N + 63) / 64), dim3(64), 0, q, s->dm, s->st, s->n_post_steps == 0 ? 1 : 0);
   int n = s->R * (MQE_HIST * MQE_FRAME / 4);
   hipLaunchKernelGGL(k_reset_history, dim3((n + 255) / 256), dim3(256), 0, q, s->dm, s->st);

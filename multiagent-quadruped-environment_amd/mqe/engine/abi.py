@@ -19,7 +19,7 @@ TERM = dict(roll=1, pitch=2, z_low=4, z_high=8)
  T_BASE_ANG_VEL, T_PROJECTED_GRAVITY, T_BASE_QUAT, T_EPISODE_LENGTH, T_RESET_BUF, T_COLLIDE_BUF, T_TIME_OUT_BUF,
  T_R_TERM, T_P_TERM, T_Z_HIGH_TERM, T_OBS_BAG, T_WRAPPER_OBS, T_WRAPPER_REWARD, T_REWARD_SUMS, T_SHEEP_POS_AVG,
  T_SHEEP_POS_VAR, T_RESET_COUNT, T_SUBSTEP_TORQUES, T_NPC_NOISE, T_WRAPPER_PACKED, T_DOMAIN_PARAMS, T_SUBSTEP_DOF_VEL,
- T_SUBSTEP_EXCEED_DOF_POS_LIMITS, T_CONTACT_OVERFLOW, T_COUNT) = range(39)
+ T_SUBSTEP_EXCEED_DOF_POS_LIMITS, T_CONTACT_OVERFLOW, T_ENV_ORIGINS, T_TERRAIN_LEVELS, T_COUNT) = range(41)
 
 # slices of one OBS_BAG row (compute_observations, reference go1.py:153-196)
 BAG = dict(base_pos=(0, 3), base_rpy=(3, 6), dof_pos=(6, 18), dof_vel=(18, 30), lin_vel=(30, 33), ang_vel=(33, 36),
@@ -72,6 +72,8 @@ class SimDesc(C.Structure):
         ("wall_sdf", FP), ("sdf_nx", i32), ("sdf_ny", i32),
         ("horizontal_scale", f32), ("wall_height", f32), ("ground_z", f32), ("ground_height", FP), ("wall_top", FP), ("soft_dof_pos_limit", f32),
         ("env_origins", FP), ("agent_origins", FP), ("base_init_state", FP), ("npc_init_state", FP), ("gate_pos", FP),
+        ("terrain_curriculum", i32), ("terrain_num_rows", i32), ("terrain_num_cols", i32), ("terrain_env_length", f32),
+        ("terrain_origins", FP), ("terrain_levels", C.POINTER(i32)), ("terrain_types", C.POINTER(i32)),
         ("termination_flags", i32), ("terminate_on_base_contact", i32), ("max_episode_length", i32),
         ("roll_threshold", f32), ("pitch_threshold", f32), ("z_low_threshold", f32), ("z_high_threshold", f32),
         ("noise_mode", i32), ("dof_ratio_lo", f32), ("dof_ratio_hi", f32),

@@ -115,7 +115,8 @@ def task_kind(cfg):
 
 
 def build_desc(cfg, num_envs, terrain, env_origins, agent_origins, gate_pos=None, env_id_offset=0, seed=0,
-               task=None, body=None, resources_root=None, solver_iterations=None, erp=0.2, noise_mode=0, solver_type=None, velocity_iterations=None):
+               task=None, body=None, resources_root=None, solver_iterations=None, erp=0.2, noise_mode=0, solver_type=None, velocity_iterations=None,
+               terrain_levels=None, terrain_types=None):
     """Returns (SimDesc, keepalive) -- keepalive holds the numpy arrays the struct points into."""
     keep = []
     d = abi.SimDesc()
@@ -346,6 +347,18 @@ def build_desc(cfg, num_envs, terrain, env_origins, agent_origins, gate_pos=None
         d.wall_top = _fp(wt, keep)
     d.soft_dof_pos_limit = float(getattr(cfg.rewards, "soft_dof_pos_limit", 1.0))
     d.env_origins = _fp(env_origins, keep)
+    # run-time terrain curriculum (legged_robot.py:479-503): the per-track origin table and each env's (level, type) at construction
+    if getattr(cfg.terrain, "curriculum", False) and int(cfg.terrain.num_rows) > 1 and terrain_levels is not None:
+        tab = np.ascontiguousarray(terrain.env_origins, np.float32)
+        assert tab.shape == (cfg.terrain.num_rows, cfg.terrain.num_cols, 3), tab.shape
+        lv, ty = np.ascontiguousarray(terrain_levels, np.int32), np.ascontiguousarray(terrain_types, np.int32)
+        assert lv.shape == (num_envs,) and ty.shape == (num_envs,)
+        keep += [tab, lv, ty]
+        d.terrain_curriculum, d.terrain_num_rows, d.terrain_num_cols = 1, int(cfg.terrain.num_rows), int(cfg.terrain.num_cols)
+        d.terrain_env_length = float(terrain.env_length)
+        d.terrain_origins = tab.ctypes.data_as(abi.FP)
+        d.terrain_levels = lv.ctypes.data_as(C.POINTER(C.c_int32))
+        d.terrain_types = ty.ctypes.data_as(C.POINTER(C.c_int32))
     d.agent_origins = _fp(agent_origins, keep)
     st = cfg.init_state
     if getattr(st, "multi_init_state", False):

@@ -39,6 +39,22 @@ def _default_engine_factory(desc, keep, device):
     return HipEngine(desc, keep, device=device)
 
 
+class _EpisodeInfo(dict):
+    """extras["episode"]: with the run-time terrain curriculum on, "terrain_level" is the mean of the LIVE levels (_fill_extras,
+    legged_robot.py:1069-1071), computed when it is read -- the step itself launches nothing for it."""
+
+    def __init__(self, levels=None):
+        super().__init__()
+        self._levels = levels
+        if levels is not None:
+            dict.__setitem__(self, "terrain_level", None)
+
+    def __getitem__(self, k):
+        if k == "terrain_level" and self._levels is not None:
+            return torch.mean(self._levels.float())
+        return dict.__getitem__(self, k)
+
+
 class Go1:
     # engine_factory(desc, keepalive, device) -> engine; the default (and only product) engine is the HIP one.
     engine_factory = staticmethod(_default_engine_factory)
@@ -79,17 +95,11 @@ class Go1:
         self.max_episode_length_s = cfg.env.episode_length_s
         self.max_episode_length = np.ceil(self.max_episode_length_s / self.dt)
         cfg.env.max_episode_length = self.max_episode_length
-        if getattr(cfg.terrain, "curriculum", False) and cfg.terrain.num_rows > 1:
-            # reset_idx -> _update_terrain_curriculum (legged_robot.py:185-186,479-503) moves an env between the rows of the track grid
-            # at run time.  Upstream the rule reads root_states[env_ids] (robot rows indexed by ENV ids), compares with the never
-            # sampled self.commands (all zero: nobody ever moves down), and rewrites env_origins only -- agent_origins, the copy
-            # env_origins_repeat behind obs_buf.base_pos and env_info keep the old track, so the robots stay where they were while
-            # NPCs and the wrappers' relative positions jump.  The engine's in-kernel reset uses fixed per-env origins; rather than
-            # ignore the switch (or reproduce the above) it is refused.  The INITIAL level draw (max_init_terrain_level) and the
-            # per-row difficulty of the generated tracks are supported: with one row the run-time move is the identity.
-            raise NotImplementedError("cfg.terrain.curriculum = True with num_rows > 1: the run-time terrain curriculum "
-                                      "(legged_robot.py:479-503) is not implemented by the HIP engine; set curriculum = False "
-                                      "(tracks of all rows are still generated and assigned as legged_robot.py:980-993 does)")
+        if getattr(cfg.terrain, "curriculum", False) and cfg.terrain.num_rows > 1 and self.shard is not None and self.shard[0] != self.num_envs:
+            # reset_idx -> _update_terrain_curriculum (legged_robot.py:479-503) measures the walked distance on root_states[env_ids]: ROW e
+            # of the agents' tensor is robot e % A of env e // A, another shard's env for almost every e
+            raise NotImplementedError("cfg.terrain.curriculum = True with num_rows > 1 on an env-sharded batch: upstream's run-time terrain "
+                                      "curriculum indexes the agents' root states with env ids across the whole batch; run it on one GPU")
 
     # ---- scene construction (reference create_sim, legged_robot.py:255-261,754-923,972-997) ---------------------
     def _create_scene(self):
@@ -115,7 +125,7 @@ class Go1:
         self.task = task_kind(cfg)
         gate_pos = self._task_gate_pos()
         desc, keep = build_desc(cfg, N, t, self._env_origins_np, self._agent_origins_np, gate_pos=gate_pos,
-                                env_id_offset=g0, seed=engine_seed(), task=self.task)
+                                env_id_offset=g0, seed=engine_seed(), task=self.task, terrain_levels=levels.numpy(), terrain_types=types_.numpy())
         self.body_is_synthetic = dict(k for k in keep if isinstance(k, tuple)).get("body_is_synthetic", True)
         self.engine = type(self).engine_factory(desc, keep, self.device)
         self.device = str(self.engine.torch_device) if hasattr(self.engine, "torch_device") else self.device
@@ -186,10 +196,23 @@ class Go1:
         # over the handle's life).  A device tensor -- reading it is the caller's sync, the step never does.
         self.contact_overflow = T(abi.T_CONTACT_OVERFLOW)
         self.rew_buf = torch.zeros(N * A, device=dev)                    # Go1 registers no reward functions (go1.py:198-219)
-        self.env_origins = torch.from_numpy(self._env_origins_np).to(dev)
-        self.env_origins_repeat = self.env_origins.unsqueeze(1).repeat(1, A, 1).reshape(-1, 3)
+        # env_origins is the engine's LIVE tensor (the run-time terrain curriculum rewrites rows of it, legged_robot.py:495); the copies
+        # upstream makes at construction -- env_origins_repeat (:992), the sheep task's npc_env_origins (go1_sheep.py:120) -- stay copies
+        self.env_origins = T(abi.T_ENV_ORIGINS)
+        self.env_origins_repeat = self.env_origins.clone().unsqueeze(1).repeat(1, A, 1).reshape(-1, 3)
         self.agent_origins = torch.from_numpy(self._agent_origins_np).to(dev)
-        self.npc_env_origins = self.env_origins.unsqueeze(1).repeat(1, max(P, 1), 1)[:, :P]
+        self.npc_env_origins = self.env_origins.clone().unsqueeze(1).repeat(1, max(P, 1), 1)[:, :P]
+        self.terrain_levels = T(abi.T_TERRAIN_LEVELS) if self.engine.desc.terrain_curriculum else self.terrain_levels.to(dev)
+        self.terrain_types = self.terrain_types.to(dev)
+        self.terrain_origins = torch.from_numpy(np.asarray(self.terrain.env_origins, np.float32)).to(dev)
+        if self.engine.desc.terrain_curriculum:
+            # what the first reset()'s curriculum step measures (init_done is set before it): the actors' spawn poses, env origin +
+            # U(+-x_init_range, +-y_init_range) per robot (legged_robot.py:864-869: torch_rand_float on the global generator)
+            xr, yr = float(getattr(self.cfg.terrain, "x_init_range", 0.0)), float(getattr(self.cfg.terrain, "y_init_range", 0.0))
+            spawn = self.env_origins.clone().unsqueeze(1).repeat(1, A, 1)
+            spawn[..., 0] += (torch.rand(N, A, device=dev) * 2 - 1) * xr
+            spawn[..., 1] += (torch.rand(N, A, device=dev) * 2 - 1) * yr
+            self._root3[:, :A, :3] = spawn
         self.env_info = {k: torch.from_numpy(v).to(dev) for k, v in self._env_info_np.items()}
         self.default_dof_pos = torch.tensor([self.engine.desc.default_dof_pos[j] for j in range(12)] * A, device=dev).unsqueeze(0)
         self.torque_limits = torch.tensor([self.engine.desc.torque_limits[j] for j in range(12)] * A, device=dev)
@@ -201,7 +224,8 @@ class Go1:
         self.npc_indices = self.actor_indices[:, A:]
         self.obs_buf = ObsBag(self.cfg.obs, T(abi.T_OBS_BAG), self.env_info if self.env_info else None)
         self.privileged_obs_buf = None
-        self.extras = {"time_outs": self.time_out_buf, "episode": {}, "contact_overflow": self.contact_overflow}
+        self.extras = {"time_outs": self.time_out_buf, "episode": _EpisodeInfo(self.terrain_levels if self.engine.desc.terrain_curriculum else None),
+                       "contact_overflow": self.contact_overflow}
         self.common_step_counter = 0
         if self.task == "football_defender":
             self.gate_pos = torch.zeros(N, 3, device=dev)

@@ -65,6 +65,8 @@ typedef struct mqo_sim {
   float* ground_height;             /* relief of the walkable surface at the SDF's raster points, or NULL (flat slab) */
   float* wall_top;                  /* per-cell wall top (walls of different heights), or NULL */
   float *env_origins, *agent_origins, *base_init, *npc_init, *gate_pos;
+  float *env_origins_live, *terrain_origins, *curr_xy;   /* terrain curriculum: MQE_T_ENV_ORIGINS, the origin table, pre-reset xy of the robot rows */
+  int32_t *terrain_levels, *terrain_types;
   /* state */
   float *root, *dof, *cf, *torques, *actions, *last_actions, *loco_obs, *hist, *last_loco, *last_two_loco;
   float *act_hist, *gait, *clock, *blv, *bav, *pg, *bquat, *obs_bag, *wobs, *wrew, *rsum, *sheep_avg, *sheep_var;
@@ -300,6 +302,17 @@ int mqo_sim_create(const mqe_sim_desc* d, mqo_sim** out) {
   s->ground_height = d->ground_height ? (float*)dupmem(d->ground_height, (size_t)d->sdf_nx * d->sdf_ny * 4) : NULL;
   s->wall_top = d->wall_top ? (float*)dupmem(d->wall_top, (size_t)d->sdf_nx * d->sdf_ny * 4) : NULL;
   s->env_origins = (float*)dupmem(d->env_origins, (size_t)N * 3 * 4);
+  s->env_origins_live = (float*)dupmem(d->env_origins, (size_t)N * 3 * 4);
+  s->terrain_levels = (int32_t*)calloc((size_t)N, 4);
+  s->terrain_types = (int32_t*)calloc((size_t)N, 4);
+  s->curr_xy = (float*)calloc((size_t)N * 2, 4);
+  if (d->terrain_curriculum) {
+    if (d->env_id_offset != 0) { snprintf(g_err, sizeof g_err, "terrain curriculum: not defined for a shard of a larger batch"); return -6; }
+    if (!d->terrain_origins || !d->terrain_levels || !d->terrain_types || d->terrain_num_rows < 1 || d->terrain_num_cols < 1) { snprintf(g_err, sizeof g_err, "terrain curriculum: origin table / levels / types missing"); return -6; }
+    s->terrain_origins = (float*)dupmem(d->terrain_origins, (size_t)d->terrain_num_rows * d->terrain_num_cols * 3 * 4);
+    memcpy(s->terrain_levels, d->terrain_levels, (size_t)N * 4);
+    memcpy(s->terrain_types, d->terrain_types, (size_t)N * 4);
+  }
   s->agent_origins = (float*)dupmem(d->agent_origins, (size_t)N * A * 3 * 4);
   s->base_init = (float*)dupmem(d->base_init_state, (size_t)A * 13 * 4);
   s->npc_init = (float*)dupmem(d->npc_init_state, (size_t)P * 13 * 4);
@@ -391,6 +404,7 @@ int mqo_sim_create(const mqe_sim_desc* d, mqo_sim** out) {
   t[MQE_T_SUBSTEP_TORQUES] = s->sub_tau; t[MQE_T_NPC_NOISE] = s->npc_noise; t[MQE_T_WRAPPER_PACKED] = s->wobs;
   t[MQE_T_DOMAIN_PARAMS] = s->dparams;
   t[MQE_T_SUBSTEP_DOF_VEL] = s->sub_dof_vel; t[MQE_T_SUBSTEP_EXCEED_DOF_POS_LIMITS] = s->sub_exceed; t[MQE_T_CONTACT_OVERFLOW] = s->overflow;
+  t[MQE_T_ENV_ORIGINS] = s->env_origins_live; t[MQE_T_TERRAIN_LEVELS] = s->terrain_levels;
   *out = s;
   return 0;
 }
@@ -426,7 +440,8 @@ int mqo_sim_tensor(mqo_sim* s, int kind, mqe_tensor_view* v) {
     case MQE_T_SHEEP_POS_VAR: SH(1, N, 0, 0, 0, 0); break;
     case MQE_T_SUBSTEP_TORQUES: case MQE_T_SUBSTEP_DOF_VEL: SH(3, N, 4, 12 * A, 0, 0); break;
     case MQE_T_SUBSTEP_EXCEED_DOF_POS_LIMITS: SH(3, N, 4, 12 * A, 0, 2); break;
-    case MQE_T_CONTACT_OVERFLOW: SH(1, N, 0, 0, 0, 1); break;
+    case MQE_T_CONTACT_OVERFLOW: case MQE_T_TERRAIN_LEVELS: SH(1, N, 0, 0, 0, 1); break;
+    case MQE_T_ENV_ORIGINS: SH(2, N, 3, 0, 0, 0); break;
     case MQE_T_NPC_NOISE: SH(3, N, P, 3, 0, 0); break;
     case MQE_T_WRAPPER_PACKED: SH(1, N * s->Aw * s->D + N * s->Aw + (N + 3) / 4, 0, 0, 0, 0); break;
     case MQE_T_DOMAIN_PARAMS: SH(2, s->R, 8, 0, 0, 0); break;
@@ -1362,11 +1377,38 @@ static void compute_observations_env(mqo_sim* s, int e, int in_step) { /* go1.py
  * [33:36] ang_vel, [36:48] last_action, [48:60] last_last_action, [60:63] projected_gravity, [63:67] clock_inputs,
  * [67:71] base_quat, [71:74] pad.  mqo_policy_step reads gravity/clock at these offsets. */
 
+/* pre-reset xy of the agents' root-state ROWS 0 .. N-1 (row e = robot e % A of env e / A): what _get_terrain_curriculum_move indexes
+ * with env ids (legged_robot.py:498), taken before any env of the step is reset (the curriculum runs first in reset_idx) */
+static void curriculum_snapshot(mqo_sim* s) {
+  if (!s->d.terrain_curriculum) return;
+  int A = s->A, P = s->P;
+  for (int e = 0; e < s->N; e++) {
+    const float* rs = s->root + ((size_t)(e / A) * (A + P) + e % A) * 13;
+    s->curr_xy[e * 2] = rs[0]; s->curr_xy[e * 2 + 1] = rs[1];
+  }
+}
+/* _update_terrain_curriculum (legged_robot.py:479-503) for one env that is being reset */
+static void curriculum_move(mqo_sim* s, int e) {
+  const mqe_sim_desc* d = &s->d;
+  float dx = s->curr_xy[e * 2] - s->env_origins_live[e * 3], dy = s->curr_xy[e * 2 + 1] - s->env_origins_live[e * 3 + 1];
+  float distance = sqrtf(dx * dx + dy * dy);                                   /* :498 */
+  int move_up = distance > d->terrain_env_length / 2;                          /* :500 */
+  int move_down = (distance < 0.0f * 0.5f) && !move_up;                        /* :502 with the commands Go1 never samples (zero) */
+  int lvl = s->terrain_levels[e] + move_up - move_down;                        /* :490 */
+  if (lvl >= d->terrain_num_rows)                                              /* :492-494: past the last level -> a random one */
+    lvl = (int)(mqo_u01((uint32_t)d->seed, (uint32_t)(e + d->env_id_offset), (uint32_t)s->reset_count[e], 250u) * (float)d->terrain_num_rows);
+  else if (lvl < 0) lvl = 0;
+  if (lvl >= d->terrain_num_rows) lvl = d->terrain_num_rows - 1;
+  s->terrain_levels[e] = lvl;
+  for (int k = 0; k < 3; k++) s->env_origins_live[e * 3 + k] = s->terrain_origins[((size_t)lvl * d->terrain_num_cols + s->terrain_types[e]) * 3 + k];   /* :495 */
+}
+
 static void reset_env(mqo_sim* s, int e) { /* go1.py:110-145, legged_robot.py:394-470,647-652 */
   const mqe_sim_desc* d = &s->d;
   int A = s->A, P = s->P;
   float* root = s->root + (size_t)e * (A + P) * 13;
   float* dofs = s->dof + (size_t)e * s->ND * 2;
+  if (d->terrain_curriculum) curriculum_move(s, e);                            /* go1.py:123-125: first thing in reset_idx */
   for (int a = 0; a < A; a++)
     for (int j = 0; j < 12; j++) {
       float ratio = mqo_rand(s, e, (uint32_t)(a * 12 + j), d->dof_ratio_lo, d->dof_ratio_hi);
@@ -1382,7 +1424,7 @@ static void reset_env(mqo_sim* s, int e) { /* go1.py:110-145, legged_robot.py:39
   for (int p = 0; p < P; p++) {
     float* rs = root + (A + p) * 13;
     memcpy(rs, s->npc_init + p * 13, 13 * 4);                      /* :436 */
-    for (int k = 0; k < 3; k++) rs[k] += s->env_origins[e * 3 + k];  /* :437 */
+    for (int k = 0; k < 3; k++) rs[k] += s->env_origins_live[e * 3 + k];  /* :437 (the live tensor) */
   }
   if (d->has_base_pos_range)
     for (int a = 0; a < A; a++) {
@@ -1479,6 +1521,7 @@ int mqo_post_physics_step(mqo_sim* s) {
   const mqe_sim_desc* d = &s->d;
   int N = s->N, A = s->A, P = s->P;
   float dtp = d->dt * (float)d->decimation;     /* self.dt = decimation * sim dt (legged_robot.py:1014) */
+  curriculum_snapshot(s);
   for (int e = 0; e < N; e++) {
     float* root = s->root + (size_t)e * (A + P) * 13;
     s->ep_len[e] += 1;                                                           /* legged_robot.py:126 */
@@ -1572,6 +1615,7 @@ int mqo_post_physics_step(mqo_sim* s) {
 }
 
 int mqo_reset_all(mqo_sim* s) { /* Go1.reset go1.py:147-151 + wrapper.reset() */
+  curriculum_snapshot(s);
   for (int e = 0; e < s->N; e++) {
     reset_env(s, e);
     /* base_quat is a view of the root_states tensor made in _init_buffers (legged_robot.py:568-570).  Without NPCs
@@ -1619,13 +1663,13 @@ static void wrapper_env(mqo_sim* s, int e, int is_reset_call, const float* npc) 
     if (d->task != MQE_TASK_PLAIN) { base_info(s, e * A + (Aw - 1 - a), o + c); c += 6; }  /* torch.flip(base_info,[1]) */
     if (d->task == MQE_TASK_GATE || d->task == MQE_TASK_SHEEP || d->task == MQE_TASK_PUSHBOX) { o[c++] = s->gate_pos[e * 2]; o[c++] = s->gate_pos[e * 2 + 1]; }
     if (d->task == MQE_TASK_PUSHBOX) {              /* go1_pushbox_wrapper.py:44-48: box xy (rel. env origin), box quaternion */
-      o[c++] = npc[0] - s->env_origins[e * 3]; o[c++] = npc[1] - s->env_origins[e * 3 + 1];
+      o[c++] = npc[0] - s->env_origins_live[e * 3]; o[c++] = npc[1] - s->env_origins_live[e * 3 + 1];
       for (int k = 0; k < 4; k++) o[c++] = npc[3 + k];
     }
     if (d->task == MQE_TASK_SHEEP)
       for (int p = 0; p < P; p++) { o[c++] = npc[p * 13] - s->env_origins[e * 3]; o[c++] = npc[p * 13 + 1] - s->env_origins[e * 3 + 1]; }
     if (d->task == MQE_TASK_FOOTBALL_DEFENDER) {
-      for (int k = 0; k < 3; k++) o[c++] = npc[k] - s->env_origins[e * 3 + k];
+      for (int k = 0; k < 3; k++) o[c++] = npc[k] - s->env_origins_live[e * 3 + k];
       for (int k = 0; k < 3; k++) o[c++] = npc[7 + k];
     }
   }
@@ -1828,7 +1872,7 @@ static void wrapper_env(mqo_sim* s, int e, int is_reset_call, const float* npc) 
     return;
   }
   if (d->task == MQE_TASK_PUSHBOX) {              /* go1_pushbox_wrapper.py:52-88 */
-    float bx = npc[0] - s->env_origins[e * 3];
+    float bx = npc[0] - s->env_origins_live[e * 3];
     if (sc[0] != 0 && s->w_have_last[e]) {
       float xm = bx - s->w_last2[e * 2];
       if (was_reset) xm = 0;                      /* x_movement[reset_ids] = 0 */
@@ -1841,7 +1885,7 @@ static void wrapper_env(mqo_sim* s, int e, int is_reset_call, const float* npc) 
     return;
   }
   if (d->task == MQE_TASK_FOOTBALL_DEFENDER) {   /* go1_football_wrapper.py:57-91 */
-    float bx = npc[0] - s->env_origins[e * 3], by = npc[1] - s->env_origins[e * 3 + 1];
+    float bx = npc[0] - s->env_origins_live[e * 3], by = npc[1] - s->env_origins_live[e * 3 + 1];
     if (sc[0] != 0) { if (bx > s->gate_pos[e * 2]) { r_env += sc[0]; rs[0] += sc[0]; } }
     if (sc[1] != 0) {
       float dg = sqrtf((bx - s->gate_pos[e * 2]) * (bx - s->gate_pos[e * 2]) + (by - s->gate_pos[e * 2 + 1]) * (by - s->gate_pos[e * 2 + 1]));

@@ -43,6 +43,12 @@ def perlin_terrain(task, zScale=0.12, frequency=10, **cfg_over):
     return type("PerlinTerrain", (base,), dict(cfg_over, BarrierTrack_kwargs=kw, TerrainPerlin_kwargs=dict(zScale=zScale, frequency=frequency)))
 
 
+def curriculum_terrain(task, num_rows=3, num_cols=2, max_init_terrain_level=1):
+    """the task's own terrain config as a grid of tracks with the run-time terrain curriculum switched on (legged_robot.py:479-503)"""
+    base = task_cfg(task).terrain
+    return type("CurriculumTerrain", (base,), dict(num_rows=num_rows, num_cols=num_cols, curriculum=True, max_init_terrain_level=max_init_terrain_level))
+
+
 def wall_heights_terrain(task, lo=0.3, hi=0.7, **cfg_over):
     """the task's own terrain config with a (lo, hi) wall_height: one wall height per block (barrier_track.py:167-173,191-199,218-239)"""
     base = task_cfg(task).terrain
@@ -80,7 +86,7 @@ def make_desc(task, N, seed=0, levels=None, types=None, max_episode_length=None,
     elif tk == "football_defender":
         gate = eo[:, :2].copy()
         gate[:, 0] += kwb["init"]["block_length"] + kwb["plane"]["block_length"]
-    d, keep = build_desc(cfg, N, t, eo, ao, gate_pos=gate, env_id_offset=env_id_offset, seed=0, **kw)
+    d, keep = build_desc(cfg, N, t, eo, ao, gate_pos=gate, env_id_offset=env_id_offset, seed=0, terrain_levels=np.asarray(levels), terrain_types=np.asarray(types), **kw)
     if max_episode_length is not None:
         d.max_episode_length = int(max_episode_length)
     if npc_init is not None:

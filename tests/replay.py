@@ -4,11 +4,13 @@ import numpy as np
 import torch
 
 from mqe.engine import abi
-from helpers import golden, make_desc, bag, to_dev, close
+from helpers import golden, make_desc, bag, to_dev, close, curriculum_terrain
 
 TASK_OF = {"gate": "go1gate", "seesaw": "go1seesaw", "football": "go1football-defender", "sheep": "go1sheep-hard",
            "football1v1": "go1football-1vs1", "football2v2": "go1football-2vs2", "pushbox": "go1pushbox", "rotation": "go1revolvingdoor",
-           "bridge": "go1bridge", "wrestling": "go1wrestling", "tug": "go1tug", "gate_cmd": "go1gate"}
+           "bridge": "go1bridge", "wrestling": "go1wrestling", "tug": "go1tug", "gate_cmd": "go1gate", "pushbox_curriculum": "go1pushbox"}
+# fullstep_pushbox_curriculum: the push-box scene on 3 rows x 2 columns of tracks with terrain.curriculum = True -- the reference's reset_idx moves
+# envs between the rows at run time (legged_robot.py:479-503); the trace also holds the spawn poses the first reset() measures
 # fullstep_gate_cmd: the gate scene with every implemented command.cfg switch on (go1.py:64-93): 11 action columns per robot
 CMD_FLAGS = dict(body_height=True, gait_freq=True, footswing_height=True, body_pose=True, stance_width=True, stance_length=True, aux_reward=True)
 
@@ -26,13 +28,22 @@ def replay(name, make_engine):
                              max_episode_length=int(z["max_episode_length"]),
                              npc_init=z["base_init_state_npc"][:P] if P else None,
                              noise_mode=1 if name == "sheep" else 0,      # MQE_NOISE_SCRIPTED: the recorded randn sequence is injected
-                             command_flags=CMD_FLAGS if name == "gate_cmd" else None)
+                             command_flags=CMD_FLAGS if name == "gate_cmd" else None,
+                             terrain_cfg=curriculum_terrain(TASK_OF[name]) if name.endswith("_curriculum") else None)
     np.testing.assert_allclose(ctx["env_origins"], z["env_origins"], atol=0)
     np.testing.assert_allclose(ctx["agent_origins"], z["agent_origins"], atol=0)
     e = make_engine(d, keep)
     Tn = e.tensor
     R = N * A
+    curr = "spawn_all_root" in z.files
+    if curr:
+        assert d.terrain_curriculum == 1
+        np.testing.assert_allclose(np.ctypeslib.as_array(d.terrain_origins, shape=z["terrain_origins"].shape), z["terrain_origins"], atol=0)
+        Tn(abi.T_ROOT_STATE).copy_(to_dev(e, z["spawn_all_root"].reshape(N, A + P, 13)))     # the simulator's state before the first reset()
     e.reset_all()
+    if curr:
+        assert (Tn(abi.T_TERRAIN_LEVELS).cpu().numpy() == z["reset_terrain_levels"]).all(), (Tn(abi.T_TERRAIN_LEVELS), z["reset_terrain_levels"])
+        close(Tn(abi.T_ENV_ORIGINS), z["reset_env_origins"], what="env origins after the first reset", **TOL_EXACT)
     close(Tn(abi.T_ROOT_STATE).reshape(-1, 13), z["reset_all_root"], what="reset root", **TOL_EXACT)
     close(Tn(abi.T_DOF_STATE).reshape(-1, 2), z["reset_all_dof"], what="reset dof", **TOL_EXACT)
     for k in ("base_pos", "base_quat", "dof_pos", "dof_vel", "lin_vel", "ang_vel", "last_action", "last_last_action",
@@ -69,6 +80,9 @@ def replay(name, make_engine):
         if d.terminate_on_base_contact:
             assert (Tn(abi.T_COLLIDE_BUF).cpu().numpy().astype(bool) == z["collide_buf"][t]).all(), (t, "collide")
         assert (Tn(abi.T_EPISODE_LENGTH).cpu().numpy() == z["episode_length"][t]).all(), (t, "episode_length")
+        if curr:
+            assert (Tn(abi.T_TERRAIN_LEVELS).cpu().numpy() == z["live_terrain_levels"][t]).all(), (t, Tn(abi.T_TERRAIN_LEVELS), z["live_terrain_levels"][t])
+            close(Tn(abi.T_ENV_ORIGINS), z["live_env_origins"][t], what=f"t{t} live env origins", **TOL_EXACT)
         close(Tn(abi.T_GAIT_INDICES), z["gait_indices"][t], what=f"t{t} gait", atol=2e-6)
         # sheep script: pow(x, 1.4) / norms differ in the last bits between torch (SLEEF) and libm / the GPU
         tol_root = dict(atol=3e-5, rtol=1e-5) if name == "sheep" else TOL_EXACT

@@ -359,14 +359,35 @@ def test_unsupported_switches_are_refused_not_ignored(oracle_backed):
             ter = type("terrain", (cfg.terrain,), {"curriculum": True, "num_rows": rows, "max_init_terrain_level": 0})
             return type("Go1GateCurCfg", (cfg,), {"terrain": ter})
         return edit
-    with pytest.raises(NotImplementedError, match="terrain curriculum"):
-        make_mqe_env("go1gate", a, curriculum(3))
+    # the run-time terrain curriculum is implemented (round 4: tests/golden/fullstep_pushbox_curriculum.npz pins it to upstream's reset_idx);
+    # what is still refused is an env-SHARDED batch, on which upstream's rule (rows of the agents' root states indexed by env ids) has no meaning
+    from mqe.envs.go1.go1 import Go1
+    old_shard = Go1.shard
+    Go1.shard = (8, 4)
+    try:
+        with pytest.raises(NotImplementedError, match="terrain curriculum"):
+            make_mqe_env("go1gate", a, curriculum(3))
+    finally:
+        Go1.shard = old_shard
     ENV_DICT["go1gate"]["config"] = base
-    env, _ = make_mqe_env("go1gate", a, curriculum(1))        # one row: the run-time move is the identity
-    env.reset()
-    env.step(torch.zeros(4, 2, 3))
-    env.close()
-    ENV_DICT["go1gate"]["config"] = base
+    for rows in (1, 3):      # (one row: the run-time move is the identity)
+        env, _ = make_mqe_env("go1gate", a, curriculum(rows))
+        lv0 = env.env.terrain_levels.clone()
+        if rows == 3:
+            # the first reset() already runs the curriculum on the actors' spawn poses: ROWS 2 and 3 of the agents' root states (the robots of
+            # env 1) are put a track length away -> envs 2 and 3 (upstream indexes that tensor with env ids) move up, envs 0 and 1 stay
+            env.env.root_states.view(4, 2, 13)[1, :, 0] += float(env.env.terrain.env_length)
+        env.reset()
+        for _ in range(3):
+            env.step(torch.zeros(4, 2, 3))
+        if rows == 3:
+            lv = env.env.terrain_levels
+            assert lv.tolist() == [int(lv0[0]), int(lv0[1]), int(lv0[2]) + 1, int(lv0[3]) + 1], (lv0, lv)
+            assert torch.equal(env.env.env_origins, env.env.terrain_origins[lv.long(), env.env.terrain_types.long()])
+            assert not torch.equal(env.env.env_origins_repeat.view(4, 2, 3)[:, 0], env.env.env_origins)      # the copy behind obs.base_pos keeps the first track
+            assert float(env.env.extras["episode"]["terrain_level"]) == float(lv.float().mean())
+        env.close()
+        ENV_DICT["go1gate"]["config"] = base
     assert base.command.cfg.vel is True and base.terrain.curriculum is False      # the registered config was not touched
 
 

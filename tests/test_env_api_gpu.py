@@ -376,3 +376,43 @@ def test_go1_level_step_is_the_fused_step_command():
         for kind in (abi.T_ROOT_STATE, abi.T_DOF_STATE, abi.T_OBS_BAG, abi.T_LAST_LOCO_ACTION, abi.T_RESET_BUF, abi.T_GAIT_INDICES):
             assert torch.equal(ea.tensor(kind), eb.tensor(kind)), (t, kind)
     ea.close(); eb.close()
+
+
+def test_terrain_curriculum_moves_envs_on_the_hip_engine():
+    """the run-time terrain curriculum (legged_robot.py:479-503; pinned to upstream's reset_idx by fullstep_pushbox_curriculum) through
+    make_mqe_env on the HIP engine, fused wrapper steps: envs whose row of the agents' root states lies a track length away from their
+    origin move one level up at the reset, their LIVE origin follows (the box respawns on the new track, the push-box wrapper subtracts
+    it), the robots and the copies made at construction keep the first track; time-outs move them again."""
+    a = args_for("go1pushbox", 4)
+    base = ENV_DICT["go1pushbox"]["config"]
+
+    def edit(cfg):
+        cfg = custom_cfg(a)(cfg)
+        ter = type("terrain", (cfg.terrain,), {"curriculum": True, "num_rows": 3, "num_cols": 2, "max_init_terrain_level": 0})
+        return type("Go1PushboxCurCfg", (cfg,), {"terrain": ter, "env": type("env", (cfg.env,), {"episode_length_s": 0.1})})     # time-outs every 5 steps
+    try:
+        env, _ = make_mqe_env("go1pushbox", a, edit)
+        g = env.env
+        assert g.engine.desc.terrain_curriculum == 1 and g.terrain_levels.tolist() == [0, 0, 0, 0]
+        g._root3[1, :2, 0] += float(g.terrain.env_length)           # rows 2 and 3 = the robots of env 1
+        torch.cuda.synchronize()
+        obs = env.reset()
+        torch.cuda.synchronize()
+        # env 0 measures its own robot 0 (at its origin: stays); env 1 measures robot 1 of env 0 -- the neighbouring track, 5 m > env_length / 2
+        # away -- and envs 2, 3 the shifted robots of env 1: all three move up
+        assert g.terrain_levels.tolist() == [0, 1, 1, 1]
+        assert torch.equal(g.env_origins, g.terrain_origins[g.terrain_levels.long(), g.terrain_types.long()])
+        box = g.root_states_npc.view(4, 13)
+        init = torch.tensor(np.ctypeslib.as_array(g.engine.desc.npc_init_state, shape=(1, 13)).copy(), device="cuda")
+        assert torch.allclose(box[:, :3] - g.env_origins, init[:, :3].expand(4, 3), atol=0.6)               # the box sits on each env's LIVE track (+ init_npc_base_pos_range)
+        assert torch.allclose(obs[:, 0, -6:-4], (box[:, :2] - g.env_origins[:, :2]), atol=1e-5)             # ... and the wrapper's box position is relative to it
+        assert torch.allclose(g.root_states.view(4, 2, 13)[:, :, :2] - g.agent_origins[:, :, :2], g.base_init_state.view(4, 2, 13)[:, :, :2], atol=0.6)   # robots: still their first track
+        lv = g.terrain_levels.clone()
+        for t in range(12):            # two waves of time-outs: rows far from their env's origin keep moving up, past the last level a level is drawn
+            env.step(torch.zeros(4, 2, 3, device="cuda"))
+        torch.cuda.synchronize()
+        assert (g.terrain_levels >= 0).all() and (g.terrain_levels < 3).all() and not torch.equal(g.terrain_levels, lv)
+        assert torch.equal(g.env_origins, g.terrain_origins[g.terrain_levels.long(), g.terrain_types.long()])
+        env.close()
+    finally:
+        ENV_DICT["go1pushbox"]["config"] = base

@@ -5,7 +5,7 @@ from helpers import oracle_engine
 from replay import replay
 
 
-@pytest.mark.parametrize("name", ["gate", "seesaw", "football", "sheep", "football1v1", "football2v2", "pushbox", "rotation", "bridge", "wrestling", "tug", "gate_cmd"])
+@pytest.mark.parametrize("name", ["gate", "seesaw", "football", "sheep", "football1v1", "football2v2", "pushbox", "rotation", "bridge", "wrestling", "tug", "gate_cmd", "pushbox_curriculum"])
 def test_oracle_matches_reference_trace(name):
     assert replay(name, oracle_engine)
 

@@ -408,7 +408,7 @@ def obs_fields(ob):
     return d
 
 
-def gen_fullstep(name, cls, cfg, N, T, act, ada, action_gain=1.0, seed=0, ctrl="C", nd=3):
+def gen_fullstep(name, cls, cfg, N, T, act, ada, action_gain=1.0, seed=0, ctrl="C", nd=3, curriculum=False):
     """Drive the reference's own step() (go1.py:35-62 / go1_football_defender.py:25-54) for T steps with the
     scripted simulator; record everything a replay needs and everything it must reproduce."""
     A = cfg.env.num_agents
@@ -418,6 +418,18 @@ def gen_fullstep(name, cls, cfg, N, T, act, ada, action_gain=1.0, seed=0, ctrl="
     t = barrier_track_for(cfg, N)
     eo, ao, info, levels, types_ = origins_from_terrain(t, cfg, N)
     env = make_env(cls, cfg, N)
+    if curriculum:
+        # the actors' spawn poses (legged_robot.py:864-869: env origin + U(+-x_init_range, +-y_init_range) per robot): the simulator's
+        # state when _init_buffers wraps it (:566-568) and when the first reset() -- which already runs the curriculum, init_done is
+        # set before it -- measures the rows; counter RNG streams 200 / 208
+        xr, yr = np.float32(cfg.terrain.x_init_range), np.float32(cfg.terrain.y_init_range)
+        spawn = env._all_root.view(N, A + P, 13)
+        for i in range(N):
+            for j in range(A):
+                spawn[i, j, :3] = eo[i]
+                spawn[i, j, 0] += float((np.float32(2) * hash_u01(0, i, 0xC0DE, 200 + j) - np.float32(1)) * xr)
+                spawn[i, j, 1] += float((np.float32(2) * hash_u01(0, i, 0xC0DE, 208 + j) - np.float32(1)) * yr)
+        spawn_root = env._all_root.clone()
     finish_env(env, eo, ao, info, Ws, bs, ada)
     if cls is Go1Sheep:
         env.sheep_movement_scale = cfg.asset.sheep_movement_scale
@@ -442,6 +454,20 @@ def gen_fullstep(name, cls, cfg, N, T, act, ada, action_gain=1.0, seed=0, ctrl="
     rng = np.random.RandomState(seed + 7)
     sr = ScriptedRand(env)
     ref_lr.torch_rand_float = sr
+    if curriculum:
+        # what _get_env_origins (legged_robot.py:980-993) leaves behind for the run-time terrain curriculum (:479-503), which this trace
+        # drives through the reference's own reset_idx (go1.py:123-125): levels / types / the origin table / the terrain (env_length)
+        assert cfg.terrain.curriculum and cfg.terrain.num_rows > 1
+        env.terrain = t
+        env.terrain_levels, env.terrain_types = levels.clone(), types_.clone()
+        env.max_terrain_level = cfg.terrain.num_rows
+        env.terrain_origins = torch.from_numpy(t.env_origins).float()
+
+        def scripted_randint_like(x, high):      # torch.randint_like(levels[env_ids], max_level) -> the engine's counter RNG, stream 250
+            import sys as _s
+            ids = [int(e) for e in _s._getframe(1).f_locals["env_ids"]]
+            return torch.tensor([int(hash_u01(0, e, sr.counts.get(e, 0), 250) * np.float32(high)) for e in ids], dtype=x.dtype)
+        torch.randint_like = scripted_randint_like
     noise_script = rng.standard_normal((T, N, P, 3)).astype(np.float32) if P else None
     _state = {"t": 0}
     if cls is Go1Sheep:
@@ -496,6 +522,9 @@ def gen_fullstep(name, cls, cfg, N, T, act, ada, action_gain=1.0, seed=0, ctrl="
     rec = {"reset_" + k: v for k, v in obs_fields(ob).items()}
     rec["reset_all_root"] = env.all_root_states.clone()
     rec["reset_all_dof"] = env.all_dof_states.clone()
+    if curriculum:
+        rec.update(spawn_all_root=spawn_root, reset_env_origins=env.env_origins.clone(), reset_terrain_levels=env.terrain_levels.clone(),
+                   terrain_origins=env.terrain_origins.clone())
     out = {k: [] for k in ("torques", "reset_buf", "collide_buf", "time_out", "episode_length", "gait_indices",
                            "locomotion_obs", "history_tail", "history_sum", "loco_action", "actions_clipped",
                            "post_all_root", "post_all_dof", "r_term", "p_term", "rew")}
@@ -526,6 +555,9 @@ def gen_fullstep(name, cls, cfg, N, T, act, ada, action_gain=1.0, seed=0, ctrl="
         out["rew"].append(rew.clone())
         for k, v in obs_fields(ob).items():
             obs_out.setdefault("obs_" + k, []).append(v)
+        if curriculum:
+            extra.setdefault("live_env_origins", []).append(env.env_origins.clone())
+            extra.setdefault("live_terrain_levels", []).append(env.terrain_levels.clone())
         if cls is Go1Sheep:
             extra.setdefault("sheep_pos_avg", []).append(env.sheep_pos_avg.clone())
             extra.setdefault("sheep_pos_var", []).append(env.sheep_pos_var.clone())
@@ -1138,6 +1170,11 @@ def main():
         cmd = type("command", (Go1GateCfg.command,), {"cfg": cc})
         cfg_c = type("Go1GateCmdCfg", (Go1GateCfg,), {"command": cmd})
         run_stage(gen_fullstep, "fullstep_gate_cmd", Go1, cfg_c, N=3, T=12, act=act, ada=ada, nd=11)
+    if want("fullstep_curriculum"):       # the run-time terrain curriculum (legged_robot.py:479-503 through go1.py:123-125) on the push-box scene: 3 rows x 2 columns of tracks
+        from mqe.envs.configs.go1_pushbox_config import Go1PushboxCfg
+        ter = type("terrain", (Go1PushboxCfg.terrain,), dict(num_rows=3, num_cols=2, curriculum=True, max_init_terrain_level=1))
+        cfg_c = type("Go1PushboxCurriculumCfg", (Go1PushboxCfg,), {"terrain": ter})
+        run_stage(gen_fullstep, "fullstep_pushbox_curriculum", Go1Object, cfg_c, N=6, T=14, act=act, ada=ada, curriculum=True)
     if want("fullstep_tug"):
         from mqe.envs.configs.go1_tug_config import Go1TugCfg
         run_stage(gen_fullstep, "fullstep_tug", Go1Object, Go1TugCfg, N=2, T=12, act=act, ada=ada)
