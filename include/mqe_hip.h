@@ -26,9 +26,9 @@ extern "C" {
 #endif
 
 #define MQE_ABI_VERSION 14
-#define MQE_MAX_SPHERES 32    /* feature points of one robot */
+#define MQE_MAX_SPHERES 64    /* feature points of one robot (the capsule model has 32, the exact one 60) */
 #define MQE_MAX_PRIMS 20      /* collision primitives of one robot (Go1: 18) */
-#define MQE_MAX_SELF_PAIRS 192
+#define MQE_MAX_SELF_PAIRS 384
 #define MQE_NBODY 13      /* dynamic bodies of one Go1 after fixed-joint collapsing */
 #define MQE_NREP 17       /* reported rigid bodies of one Go1 (feet kept, go1.urdf dont_collapse) */
 #define MQE_NDOF 12
@@ -77,7 +77,11 @@ typedef struct {
    * ("spheres": centre + radius, rigidly on a link) are what is tested AGAINST the terrain maps, the scenery, the 1-dof link,
    * the free box and the other actors' primitives: the foot spheres, the capsules' end points (capsule radius) and the boxes'
    * corners (radius 0) -- a convex body's outermost point against a plane is always one of them.  Order = priority in the
-   * bounded contact list (feet, trunk, head, knees, thigh tops, hips). */
+   * bounded contact list (feet, trunk, head, knees, thigh tops, hips).
+   * Two models ship (assets/go1_model.json; desc builder `collision_model`): "capsule" (default; the bars as best-fitting capsules,
+   * 32 feature points, surface within 6 mm of the URDF's) and "exact" (round 4: the thigh and calf bars as the URDF's own
+   * link-aligned boxes, go1.urdf:170,198, and every box corner that can be outermost -- 60 feature points; the union's support
+   * function to < 1 mm, tests/test_models_oracle.py). */
   int32_t n_spheres;
   int32_t sphere_body[MQE_MAX_SPHERES];
   int32_t sphere_reported[MQE_MAX_SPHERES];

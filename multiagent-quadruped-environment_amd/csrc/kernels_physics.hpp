@@ -321,7 +321,9 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
 
   // this lane's self-collision candidates, one per pass of 64 (requested here, consumed after the terrain contacts: the
   // table sits in global memory and a load inside the pass loop put its full latency on every pass)
-  constexpr int NSP = (MQE_MAX_SELF_PAIRS + LW - 1) / LW;
+  // (192 candidates at a time: the capsule model has 144; the exact one, 350, takes a second chunk whose table entries are loaded when it runs)
+  constexpr int SELF_CHUNK = 192;
+  constexpr int NSP = (SELF_CHUNK + LW - 1) / LW;
   int selfp[NSP];
 #pragma unroll
   for (int k = 0; k < NSP; k++) selfp[k] = (m->self_collision && k * LW + lane < rm.n_self_pairs) ? (int)rm.self_pair[k * LW + lane] : -1;
@@ -1022,6 +1024,57 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
           }
           nc += __popcll(bh);
           if (nc > pair_lim) { nc = pair_lim; ovf = 1; }
+          // ... and the box's own eight corners (radius 0) against the robot's primitives (lanes = primitives): a corner of the box pressing
+          // into a face of the trunk or into a bar between its ends.  Corners farther from the robot's base than any feature point reaches
+          // are dropped with one ballot (lane = corner): a robot pushing a face of the 1 m box has none.
+          unsigned long long cmask;
+          {
+            const V3 pbase = ld3(lds + L.body + a * MQE_NBODY * BODY_STRIDE + B_P);
+            const V3 hbx = v3(m->npc_box_half[0], m->npc_box_half[1], m->npc_box_half[2]);
+            bool nearc = false;
+            if (lane < 8) {
+              const V3 cw = pb + mat_vec(brec + B_R, v3((lane & 4) ? hbx.x : -hbx.x, (lane & 2) ? hbx.y : -hbx.y, (lane & 1) ? hbx.z : -hbx.z));
+              const V3 db = cw - pbase;
+              const float reach = rm.feature_reach + m->contact_offset;
+              nearc = !(dot(db, db) > reach * reach);
+            }
+            cmask = gballot(nearc);
+          }
+          if (cmask != 0ull) {
+            float4 w0 = make_float4(0, 0, 0, 0), w1 = w0; int pbody = 0, prep = 0; V3 ph = v3(0, 0, 0);
+            if (lane < npr) {
+              const float4* pw = reinterpret_cast<const float4*>(lds + L.prim) + (a * npr + lane);
+              w0 = pw[0]; w1 = pw[m->nprim_env];
+              pbody = rm.prim_body[lane]; prep = rm.prim_reported[lane];
+              ph = v3(rm.prim_half[lane][0], rm.prim_half[lane][1], rm.prim_half[lane][2]);
+            }
+            const V3 hbx = v3(m->npc_box_half[0], m->npc_box_half[1], m->npc_box_half[2]);
+            while (cmask != 0ull) {
+              const int cn = __ffsll((long long)cmask) - 1;
+              cmask &= cmask - 1ull;
+              const V3 cc = pb + mat_vec(brec + B_R, v3((cn & 4) ? hbx.x : -hbx.x, (cn & 2) ? hbx.y : -hbx.y, (cn & 1) ? hbx.z : -hbx.z));
+              bool hit2 = false; float sd2 = 0; V3 n2 = v3(0, 0, 1);
+              if (lane < npr) {
+                const V3 cq = v3(w0.x, w0.y, w0.z);
+                if (w1.w < 0.0f) {
+                  sd2 = sphere_box(cc, 0.0f, cq, lds + L.body + (a * MQE_NBODY + pbody) * BODY_STRIDE + B_R, ph, n2);
+                  hit2 = sd2 < m->contact_offset;
+                } else {
+                  const bool ok = sphere_capsule(cc, 0.0f, cq, v3(w1.x, w1.y, w1.z), w1.w, sd2, n2);
+                  hit2 = ok && sd2 < m->contact_offset;
+                }
+              }
+              const unsigned long long bh2 = gballot(hit2);
+              if (bh2 == 0ull) continue;
+              const int slot2 = nc + __popcll(bh2 & lower);
+              if (hit2 && slot2 < pair_lim) {
+                float* cr = lds + L.con + slot2 * CON_STRIDE;
+                con_store(cr, a, pbody, b, 0, cc - (0.5f * sd2) * n2, v3(-n2.x, -n2.y, -n2.z), sd2, a * MQE_NREP + prep, A * MQE_NREP + (b - A));
+              }
+              nc += __popcll(bh2);
+              if (nc > pair_lim) { nc = pair_lim; ovf = 1; }
+            }
+          }
           continue;
         }
         if (b < A) {
@@ -1034,7 +1087,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
             if (lane < nsr) {
               const float4 qf = *reinterpret_cast<const float4*>(lds + L.sph + (fa * nsr + lane) * 4);
               c = v3(qf.x, qf.y, qf.z); ra = qf.w;
-              foot = ((m->feat_sphere_mask >> lane) & 1u) != 0u;
+              foot = ((m->feat_sphere_mask >> lane) & 1ull) != 0ull;
             }
             // which primitives of qa reach into the ball around fa's base that holds all of fa's feature points in THIS pose (its
             // radius: a maximum over the feature lanes; lane = primitive, one ballot): two robots walking side by side normally
@@ -1191,11 +1244,17 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     // links of one robot against each other (asset.self_collisions = 0): lanes = the model's candidate (feature point, primitive)
     // pairs (links neither the same nor adjacent, reachable inside the joint limits), 64 per pass; both contact sides belong to the
     // same actor.  Last in the list: they only take the two-actor slots that the contacts with other actors left over.
-    if (m->self_collision) {
-      const int npairs = rm.n_self_pairs;
-      for (int a = 0; a < A; a++) {
+    if (m->self_collision && self_todo != 0u)
+      for (int ac = 0; ac < A * ((rm.n_self_pairs + SELF_CHUNK - 1) / SELF_CHUNK); ac++) {      // robot by robot, each robot chunk by chunk (list order)
+        const int nchunk = (rm.n_self_pairs + SELF_CHUNK - 1) / SELF_CHUNK;
+        const int a = ac / nchunk, chunk0 = (ac - a * nchunk) * SELF_CHUNK;
+        const int npairs = min(rm.n_self_pairs - chunk0, SELF_CHUNK);          // candidates of this chunk
         // joint-space screen (above): inside the model's safe box of joint angles no candidate pair is closer than 4 cm
         if (!((self_todo >> a) & 1u)) continue;
+        if (nchunk > 1) {                                                      // (a one-chunk model keeps the entries requested at the top)
+#pragma unroll
+          for (int k = 0; k < NSP; k++) selfp[k] = k * LW + lane < npairs ? (int)rm.self_pair[chunk0 + k * LW + lane] : -1;
+        }
         // screen: all passes at once (independent 16 B loads, one ballot).  Bounding SPHERES (11 cm for a thigh or calf, 20 cm for the
         // trunk) would let the neighbouring legs and the thigh tops through in every substep, so the screen is the distance to the
         // capsule's segment itself (a box: its bounding capsule); robots rarely touch themselves and the compaction below normally
@@ -1249,7 +1308,6 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
           if (nc > pair_lim) { nc = pair_lim; ovf = 1; }
         }
       }
-    }
   }
   __syncthreads();
 

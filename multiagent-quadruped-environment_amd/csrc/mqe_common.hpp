@@ -59,7 +59,7 @@ struct DevModel {
   DevMlp actuator;
   // physics kernel geometry
   int nbody_env, ndof_env, nsph_env, nprim_env, maxc;
-  unsigned int feat_sphere_mask;                   // bit f: feature point f of the robot model belongs to a sphere primitive (a foot)
+  unsigned long long feat_sphere_mask;                   // bit f: feature point f of the robot model belongs to a sphere primitive (a foot)
 };
 
 // device pointers of all state tensors (kernel argument by value)

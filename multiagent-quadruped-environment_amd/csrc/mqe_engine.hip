@@ -295,9 +295,10 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   m.ndof_env = A * MQE_RD + m.n_npc_dyn * m.npc_dofs_each + (seesaw ? 1 : 0);
   m.nsph_env = A * d->robot.n_spheres + m.n_npc_dyn * d->npc_n_spheres;
   m.nprim_env = A * d->robot.n_prims;
-  m.feat_sphere_mask = 0u;
+  m.feat_sphere_mask = 0ull;
   for (int f = 0; f < d->robot.n_spheres; f++)
-    if (d->robot.prim_type[d->robot.sphere_prim[f]] == MQE_PRIM_SPHERE) m.feat_sphere_mask |= 1u << f;
+    if (d->robot.prim_type[d->robot.sphere_prim[f]] == MQE_PRIM_SPHERE) m.feat_sphere_mask |= 1ull << f;
+  if (d->robot.n_spheres > MQE_MAX_SPHERES || d->robot.n_prims > MQE_MAX_PRIMS || d->robot.n_self_pairs > MQE_MAX_SELF_PAIRS) return fail(-6, "robot model: too many feature points / primitives / self-collision pairs");
   m.maxc = mqe_maxc(A, P, m.cap_npc);
   if (m.ndof_env > 128 || m.nbody_env > 64) { return fail(-4, "env has more than 64 bodies or 128 generalized velocities: does not fit one wavefront"); }
   m.rowgs = (A + m.n_npc_dyn + (seesaw ? 1 : 0) <= 4) ? 1 : 0;      // one 16-lane row per actor; the <A,0> / <2,LINK> kernels assume it
@@ -322,7 +323,7 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
     // a selectable, bit-identical variant (MQE_ENVS_PER_WAVE=1 / 2; tests hold the two forms against each other); the default for
     // single-robot scenes at full batches only (below).
     const bool can = (s->substeps_fn == (void (*)(const DevModel*, DevState, int, int))k_substeps<2, 0> ||
-                      s->substeps_fn == (void (*)(const DevModel*, DevState, int, int))k_substeps<1, 0>) && 2 * s->phys_lds_bytes <= 64 * 1024;
+                      s->substeps_fn == (void (*)(const DevModel*, DevState, int, int))k_substeps<1, 0>) && 2 * s->phys_lds_bytes <= 64 * 1024 && d->robot.n_spheres <= 32;      // (a half-wave tests 32 feature points per pass)
     // measured (MI355X, k_substeps us, one / two envs per wavefront): go1gate (two robots per env) 4096 envs 122 / 128, 8192 envs 238 / 237;
     // go1plane (ONE robot per env: a pair is exactly the lane population of a go1gate wavefront) 4096 envs 108.8 / 85.6 -- the pairing
     // pays there once the batch fills the machine (4 one-env wavefronts per SIMD), so single-robot scenes of >= 4096 envs take it

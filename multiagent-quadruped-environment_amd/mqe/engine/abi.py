@@ -2,8 +2,8 @@
 import ctypes as C
 
 ABI_VERSION = 14
-MAX_SPHERES, NBODY, NREP, NDOF = 32, 13, 17, 12
-MAX_SELF_PAIRS = 192
+MAX_SPHERES, NBODY, NREP, NDOF = 64, 13, 17, 12
+MAX_SELF_PAIRS = 384
 MAX_PRIMS = 20
 PRIM_SPHERE, PRIM_CAPSULE, PRIM_BOX = 0, 1, 2
 MAX_AGENTS, MAX_NPCS, FRAME, HIST, MAX_LAYERS, MAX_REWARD_TERMS = 4, 9, 72, 30, 6, 12

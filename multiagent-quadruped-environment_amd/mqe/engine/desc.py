@@ -116,7 +116,7 @@ def task_kind(cfg):
 
 def build_desc(cfg, num_envs, terrain, env_origins, agent_origins, gate_pos=None, env_id_offset=0, seed=0,
                task=None, body=None, resources_root=None, solver_iterations=None, erp=0.2, noise_mode=0, solver_type=None, velocity_iterations=None,
-               terrain_levels=None, terrain_types=None):
+               terrain_levels=None, terrain_types=None, collision_model=None):
     """Returns (SimDesc, keepalive) -- keepalive holds the numpy arrays the struct points into."""
     keep = []
     d = abi.SimDesc()
@@ -147,6 +147,12 @@ def build_desc(cfg, num_envs, terrain, env_origins, agent_origins, gate_pos=None
     d.velocity_iterations = int(velocity_iterations if velocity_iterations is not None else getattr(px, "num_velocity_iterations", 0))
     # robot model
     m = urdf_model.load_model("go1", resources_root)
+    # collision model of the robot (include/mqe_hip.h mqe_robot_model): "capsule" (default) or "exact" (thigh / calf as the URDF's boxes,
+    # 60 feature points); cfg.asset.collision_model or MQE_COLLISION_MODEL pick it when the caller does not
+    cm = collision_model or os.environ.get("MQE_COLLISION_MODEL") or getattr(cfg.asset, "collision_model", "capsule")
+    assert cm in ("capsule", "exact"), cm
+    if cm == "exact":
+        m = dict(m, **m["exact"])
     r = d.robot
     for b in range(abi.NBODY):
         r.mass[b] = m["mass"][b]

@@ -24,7 +24,7 @@ import xml.etree.ElementTree as ET
 import numpy as np
 
 LEG_ORDER = ("FL", "FR", "RL", "RR")
-MAX_SPHERES = 32
+MAX_SPHERES = 64
 N_BODIES_DYN = 13       # base + 4 x (hip, thigh, calf)
 N_BODIES_REPORTED = 17  # + 4 feet
 N_DOF = 12
@@ -209,7 +209,7 @@ def _capsule_for_bar(h):
     return long_ax, 0.5 * (lo + hi), r
 
 
-def _collision_model_for_go1(bodies, reported_names):
+def _collision_model_for_go1(bodies, reported_names, exact=False):
     """The Go1 collision model of the engine: the URDF's 18 primitives themselves (go1.urdf:56 trunk box, :80 head box, hip cylinders
     -> capsules as `replace_cylinder_with_capsule` does (go1_config.py:75), thigh / calf bars -> capsules (`_capsule_for_bar`), foot
     spheres) = what OTHER bodies collide with, and their FEATURE POINTS (sphere-swept: capsule end points with the capsule's radius,
@@ -245,9 +245,28 @@ def _collision_model_for_go1(bodies, reported_names):
                 for c in corners:
                     # the head box (4 x 10 x 10 cm in front of the trunk): its four rear corners are never the outermost point of
                     # the trunk + head pair by more than 3 mm (y: 50 vs 46.75 mm, z: 50 vs 57 mm), so only the front four are kept
-                    if is_head and c[0] < 0:
+                    # (the exact model keeps all eight)
+                    if is_head and c[0] < 0 and not exact:
                         continue
                     feats.append(dict(body=bi, reported=ri, center=t + c, radius=0.0, prim=pi, tag="head" if is_head else "trunk"))
+            elif kind == "box" and exact:   # thigh / calf bar as the URDF has it: a link-aligned box (go1.urdf:170,198: rpy = (0, pi / 2, 0))
+                h = np.asarray(prm, np.float64)
+                assert np.allclose(np.abs(R), np.round(np.abs(R)), atol=1e-9), "leg bars must be aligned with their link frame"
+                hl = np.abs(R) @ h
+                la = int(np.argmax(hl))
+                ax = np.zeros(3); ax[la] = hl[la]
+                prims.append(dict(type=PRIM_BOX, body=bi, reported=ri, center=t, axis=ax, half=hl, bound=float(np.linalg.norm(hl))))
+                far = 1.0 if t[la] > 0 else -1.0         # the end of the bar away from the link's own joint (the joint sits at the link origin)
+                for sa in (-1, 1):
+                    for sb in (-1, 1):
+                        c = np.zeros(3)
+                        c[la] = (far if "thigh" in b.name else -far) * hl[la]
+                        o = [k for k in range(3) if k != la]
+                        c[o[0]], c[o[1]] = sa * hl[o[0]], sb * hl[o[1]]
+                        # thigh: the four corners of its LOWER end (the knee); its upper corners lie 14 mm inside the hip capsule whatever the
+                        # joint angles.  calf: the four corners of its UPPER end (they stick out of the folded knee by up to 8 mm sin(angle));
+                        # its lower corners lie inside the foot sphere (11.3 mm from its centre, r = 20 mm).
+                        feats.append(dict(body=bi, reported=ri, center=t + c, radius=0.0, prim=pi, tag="knee" if "thigh" in b.name else "thigh"))
             elif kind == "box":             # thigh / calf bar -> capsule
                 h = np.asarray(prm, np.float64)
                 long_ax, a, r = _capsule_for_bar(h)
@@ -370,33 +389,40 @@ def build_go1_model(urdf_path):
     }
     for b in ordered[1:]:
         assert np.allclose(b.joint_R, np.eye(3)), "engine assumes joint frames are pure translations (true for go1.urdf)"
-    prims, feats = _collision_model_for_go1(ordered, reported)
-    # priority order of the feature points for the bounded contact list: feet first (they carry the robot), then the trunk and head
-    # corners (base contact is what check_termination thresholds), then knees, thigh tops and hips
-    rank = {"foot": 0, "trunk": 1, "head": 2, "knee": 3, "thigh": 4, "hip": 5}
-    feats.sort(key=lambda f: (rank[f["tag"]], f["body"]))
-    assert len(feats) <= MAX_SPHERES and len(prims) <= MAX_PRIMS, (len(feats), len(prims))
-    m["sphere_body"] = [int(f["body"]) for f in feats]
-    m["sphere_center"] = [np.asarray(f["center"]).tolist() for f in feats]
-    m["sphere_radius"] = [float(f["radius"]) for f in feats]
-    m["sphere_reported"] = [int(f["reported"]) for f in feats]
-    m["sphere_prim"] = [int(f["prim"]) for f in feats]
-    m["sphere_tag"] = [f["tag"] for f in feats]
-    m["prim_type"] = [int(g["type"]) for g in prims]
-    m["prim_body"] = [int(g["body"]) for g in prims]
-    m["prim_reported"] = [int(g["reported"]) for g in prims]
-    m["prim_center"] = [np.asarray(g["center"]).tolist() for g in prims]
-    m["prim_axis"] = [np.asarray(g["axis"]).tolist() for g in prims]
-    m["prim_half"] = [np.asarray(g["half"]).tolist() for g in prims]
-    m["prim_bound"] = [float(g["bound"]) for g in prims]
-    # upper bound of |feature point - base origin| + its radius over all joint angles: joint offsets along the chain + the local centre
-    def chain(b):
-        return 0.0 if b == 0 else float(np.linalg.norm(m["joint_offset"][b])) + chain(m["parent"][b])
-    m["feature_reach"] = max(chain(f["body"]) + float(np.linalg.norm(f["center"])) + f["radius"] for f in feats)
-    pairs, n_all, safe_lo, safe_hi = _self_pair_candidates(m, prims, feats)
-    m["self_pairs"] = [[int(i), int(j)] for i, j in pairs]
-    m["self_pairs_unpruned"] = int(n_all)
-    m["self_safe_lo"], m["self_safe_hi"] = [float(x) for x in safe_lo], [float(x) for x in safe_hi]
+    def pack(out, exact):
+        prims, feats = _collision_model_for_go1(ordered, reported, exact=exact)
+        # priority order of the feature points for the bounded contact list: feet first (they carry the robot), then the trunk and head
+        # corners (base contact is what check_termination thresholds), then knees, thigh tops and hips
+        rank = {"foot": 0, "trunk": 1, "head": 2, "knee": 3, "thigh": 4, "hip": 5}
+        feats.sort(key=lambda f: (rank[f["tag"]], f["body"]))
+        assert len(feats) <= MAX_SPHERES and len(prims) <= MAX_PRIMS, (len(feats), len(prims))
+        out["sphere_body"] = [int(f["body"]) for f in feats]
+        out["sphere_center"] = [np.asarray(f["center"]).tolist() for f in feats]
+        out["sphere_radius"] = [float(f["radius"]) for f in feats]
+        out["sphere_reported"] = [int(f["reported"]) for f in feats]
+        out["sphere_prim"] = [int(f["prim"]) for f in feats]
+        out["sphere_tag"] = [f["tag"] for f in feats]
+        out["prim_type"] = [int(g["type"]) for g in prims]
+        out["prim_body"] = [int(g["body"]) for g in prims]
+        out["prim_reported"] = [int(g["reported"]) for g in prims]
+        out["prim_center"] = [np.asarray(g["center"]).tolist() for g in prims]
+        out["prim_axis"] = [np.asarray(g["axis"]).tolist() for g in prims]
+        out["prim_half"] = [np.asarray(g["half"]).tolist() for g in prims]
+        out["prim_bound"] = [float(g["bound"]) for g in prims]
+        # upper bound of |feature point - base origin| + its radius over all joint angles: joint offsets along the chain + the local centre
+
+        def chain(b):
+            return 0.0 if b == 0 else float(np.linalg.norm(m["joint_offset"][b])) + chain(m["parent"][b])
+        out["feature_reach"] = max(chain(f["body"]) + float(np.linalg.norm(f["center"])) + f["radius"] for f in feats)
+        pairs, n_all, safe_lo, safe_hi = _self_pair_candidates(m, prims, feats)
+        out["self_pairs"] = [[int(i), int(j)] for i, j in pairs]
+        out["self_pairs_unpruned"] = int(n_all)
+        out["self_safe_lo"], out["self_safe_hi"] = [float(x) for x in safe_lo], [float(x) for x in safe_hi]
+    pack(m, False)
+    # the same robot with the thigh and calf bars as the URDF's own boxes (go1.urdf:170,198) and every corner of theirs that can be
+    # outermost as a feature point: desc `collision_model = "exact"` (mqe/engine/desc.py)
+    m["exact"] = {}
+    pack(m["exact"], True)
     m["total_mass"] = float(sum(m["mass"]))
     return m
 

@@ -1038,6 +1038,29 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
             for (int k = 0; k < 3; k++) { ct->n[k] = n[k]; ct->p[k] = ca[k] - n[k] * (w->sph_r[a][sa] + (real)0.5 * sd); }
           }
         }
+        /* ... and the box's own eight corners (radius 0) against the robot's primitives: what a feature point of the robot cannot
+         * see -- a corner of the box pressing into a face of the trunk or into a bar between its ends.  Corner by corner (-,-,-),
+         * (-,-,+), ... (+,+,+), primitive by primitive; normal from B (the box) to A */
+        for (int cn = 0; cn < 8; cn++) {
+          real cl[3] = {(cn & 4 ? hb[0] : -hb[0]), (cn & 2 ? hb[1] : -hb[1]), (cn & 1 ? hb[2] : -hb[2])}, cw[3], cc[3];
+          mat3_vec(w->npcR[b - A], cl, cw);
+          for (int k = 0; k < 3; k++) cc[k] = npc_pos[b - A][k] + cw[k];
+          real db[3] = {cc[0] - pa[0], cc[1] - pa[1], cc[2] - pa[2]};
+          real reach = m->feature_reach + d->contact_offset;
+          if (dot3(db, db) > reach * reach) continue;          /* no primitive reaches farther from the base than the feature points do */
+          for (int q = 0; q < m->n_prims; q++) {
+            real n[3], sd;
+            if (!feat_vs_prim(m, w, a, q, cc, (real)0, &sd, n)) continue;
+            if (sd < d->contact_offset && !(w->nc < pair_lim)) ovf = 1;
+            if (sd < d->contact_offset && w->nc < pair_lim) {
+              contact_t* ct = &w->con[w->nc++];
+              memset(ct, 0, sizeof *ct);
+              ct->kind = 1; ct->actA = a; ct->actB = b; ct->sd = sd;
+              ct->bodyA = m->prim_body[q]; ct->repA = a * MQE_NREP + m->prim_reported[q]; ct->bodyB = 0; ct->repB = A * MQE_NREP + (b - A);
+              for (int k = 0; k < 3; k++) { ct->n[k] = -n[k]; ct->p[k] = cc[k] - n[k] * ((real)0.5 * sd); }
+            }
+          }
+        }
         continue;
       }
       if (dot3(dd, dd) > (real)(1.2 * 1.2)) continue;   /* broad phase: actors farther apart than 1.2 m cannot touch */

@@ -15,9 +15,9 @@ pytestmark = pytest.mark.usefixtures("solver")      # every test under both cont
 STANCE = np.array([0.1, 0.8, -1.5, -0.1, 0.8, -1.5, 0.1, 1.0, -1.5, -0.1, 1.0, -1.5])
 
 
-def _scene(task, z=2.0):
+def _scene(task, z=2.0, **kw):
     """robots frozen in the default stance high above the ground (no terrain contact), level, at rest"""
-    d, k, _ = make_desc(task, 1)
+    d, k, _ = make_desc(task, 1, **kw)
     e = oracle_engine(d, k, f64=True)
     e.reset_all()
     root, dof = e.tensor(abi.T_ROOT_STATE), e.tensor(abi.T_DOF_STATE)
@@ -30,6 +30,40 @@ def _scene(task, z=2.0):
     root[0, :A, 2] = z
     root[0, 1, 1] = root[0, 0, 1] + 5.0          # the second robot out of the way
     return e, d, root, dof
+
+
+def test_exact_model_collides_the_thigh_and_calf_boxes_themselves():
+    """collision_model = "exact" (round 4): the thigh and calf bars are the URDF's boxes (go1.urdf:170,198: 213 x 24.5 x 34 mm and
+    213 x 16 x 16 mm, link-aligned).  The ball beside a thigh's FLAT side face and beside its EDGE sees the box -- 12.25 mm from the
+    axis on the face, hypot(12.25, 17) = 20.95 mm on the edge -- where the capsule model sees r = 16.6 mm all around."""
+    m0 = urdf_model.load_model("go1")
+    m = dict(m0, **m0["exact"])
+    assert m["prim_type"][3] == 2 and m["prim_body"][3] == 2 and np.allclose(sorted(m["prim_half"][3]), [0.01225, 0.017, 0.1065])
+    e, d, root, dof = _scene("go1football-1vs1", collision_model="exact")
+    assert d.robot.n_spheres == 60 and d.robot.prim_type[3] == 2
+    A, r = d.num_agents, d.npc_sphere_radius[0]
+    base = root[0, 0, :3].numpy().astype(np.float64)
+    c, _, Rl = _prim_world(m, 3, base)
+    h = np.array(m["prim_half"][3])
+    ay, ax = Rl[:, 1], Rl[:, 0]                     # the link's y axis (the bar's 24.5 mm) and x axis (34 mm)
+    root[0, A, :3] = torch.tensor(c + ay * (h[1] + r + 0.005), dtype=torch.float32)           # beside the flat side face, 5 mm of air
+    root[0, A, 7:] = 0
+    _, _, con = e.debug_dynamics(0, 0)
+    hit = [cc for cc in con if cc[1] == 2 and cc[2] == A]
+    assert len(hit) == 1 and abs(hit[0][4] - 0.005) < 1e-6 and np.allclose(hit[0][5:8], -ay, atol=1e-5), con
+    dg = (ay * h[1] + ax * h[0])
+    n = (ay + ax) / np.sqrt(2.0)
+    root[0, A, :3] = torch.tensor(c + dg + n * (r + 0.003), dtype=torch.float32)               # off the long edge, along its diagonal
+    _, _, con = e.debug_dynamics(0, 0)
+    hit = [cc for cc in con if cc[1] == 2 and cc[2] == A]
+    assert len(hit) == 1 and abs(hit[0][4] - 0.003) < 1e-6 and np.allclose(hit[0][5:8], -n, atol=1e-5), con
+    # the same ball positions against the capsule model: 16.6 mm all around -> 4.35 mm closer on the face, 4.35 mm farther on the edge
+    e2, d2, root2, _ = _scene("go1football-1vs1")
+    root2[0, A, :3] = torch.tensor(c + ay * (h[1] + r + 0.005), dtype=torch.float32)
+    root2[0, A, 7:] = 0
+    _, _, con2 = e2.debug_dynamics(0, 0)
+    hit2 = [cc for cc in con2 if cc[1] == 2 and cc[2] == A]
+    assert len(hit2) == 1 and abs(hit2[0][4] - (0.005 + h[1] - m0["prim_half"][3][0])) < 2e-4, con2
 
 
 def _prim_world(m, q, base_p):
@@ -138,3 +172,31 @@ def test_two_robots_touch_with_their_primitives():
     hip_trunk = [cc for cc in pair if {(int(cc[0]), int(cc[1])), (int(cc[2]), int(cc[3]))} == {(1, 1), (0, 0)}]
     assert hip_trunk, con
     assert any(abs(cc[4] - 0.005) < 2e-6 and abs(abs(cc[6]) - 1.0) < 1e-5 for cc in hip_trunk), hip_trunk
+
+
+def test_box_corner_presses_into_the_trunk_face():
+    """go1pushbox (round 4): the free box's own corners are tested against the robots' primitives.  A box balanced on one corner 3 mm above
+    the middle of the trunk's top face -- no feature point of the robot (corners, capsule ends, feet) is anywhere near it -- gives ONE
+    contact between the box and the base link, separation 3 mm, normal straight down onto the robot (from B, the box, to A)."""
+    e, d, root, dof = _scene("go1pushbox")
+    m = urdf_model.load_model("go1")
+    A = d.num_agents
+    base = root[0, 0, :3].numpy().astype(np.float64)
+    c0, _, _ = _prim_world(m, 0, base)
+    top = c0 + np.array([0.03, 0.01, m["prim_half"][0][2]])                  # a point on the trunk's top face, away from its edges
+    h = np.array([d.npc_box_half[0], d.npc_box_half[1], d.npc_box_half[2]], np.float64)
+    # rotation that turns the box's (-,-,-) diagonal straight down
+    v = -h / np.linalg.norm(h); t = np.array([0.0, 0.0, -1.0])
+    ax = np.cross(v, t); s_, c_ = np.linalg.norm(ax), float(v @ t); ax /= s_
+    K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    R = np.eye(3) + s_ * K + (1 - c_) * K @ K
+    ang = np.arctan2(s_, c_)
+    quat = np.concatenate([ax * np.sin(ang / 2), [np.cos(ang / 2)]])
+    centre = top + np.array([0, 0, 0.003]) - R @ (-h)
+    root[0, A, :3] = torch.tensor(centre, dtype=torch.float32)
+    root[0, A, 3:7] = torch.tensor(quat, dtype=torch.float32)
+    root[0, A, 7:] = 0
+    _, _, con = e.debug_dynamics(0, 0)
+    hit = [cc for cc in con if cc[2] == A]
+    assert len(hit) == 1 and hit[0][0] == 0 and hit[0][1] == 0, con
+    assert abs(hit[0][4] - 0.003) < 2e-6 and np.allclose(hit[0][5:8], [0, 0, -1], atol=1e-5), hit

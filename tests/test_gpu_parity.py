@@ -154,6 +154,77 @@ def test_policy_layer0_compact_history_with_resets(monkeypatch, split):
     assert n_reset >= 7
 
 
+@pytest.mark.parametrize("task,N", [("go1gate", 96), ("go1football-defender", 16), ("go1plane", 130), ("go1pushbox", 16)])
+def test_exact_collision_model_matches_oracle(task, N):
+    """collision_model = "exact" (thigh / calf as the URDF's boxes, 60 feature points per robot: one robot per terrain pass, the
+    self-collision candidates in two chunks, no env pairing): identical contact lists from identical rough states, one substep and a
+    12-step fused rollout against the oracle."""
+    eh, eo, d = _pair(task, N, collision_model="exact")
+    assert d.robot.n_spheres == 60
+    _randomize(eh, eo, 5, drop=0.12)
+    for env in (0, N // 2, N - 1):
+        _, ch = eh.debug_dynamics(env, 0)
+        _, _, co = eo.debug_dynamics(env, 0)
+        assert ch.shape == co.shape and (ch[:, :4] == co[:, :4]).all(), (env, ch[:, :4], co[:, :4])
+        close(ch[:, 4:], co[:, 4:], atol=2e-5, what="contact separation / normal")
+    eh.simulate(); eo.simulate()
+    torch.cuda.synchronize()
+    err = (eh.tensor(abi.T_DOF_STATE)[..., 0].cpu() - eo.tensor(abi.T_DOF_STATE)[..., 0]).abs().reshape(N, -1).max(dim=1).values
+    assert int((err > 2e-5).sum()) <= max(1, N // 50) and float(err.max()) < 5e-3, err.topk(3)
+    eh.reset_all(); eo.reset_all()
+    g = torch.Generator().manual_seed(3)
+    Aw = eo.tensor(abi.T_WRAPPER_OBS).shape[1]
+    for t in range(12):
+        a = torch.rand(N, Aw, 3, generator=g) * 2 - 1
+        eh.step(a.cuda().contiguous()); eo.step(a)
+    torch.cuda.synchronize()
+    dev = (eh.tensor(abi.T_ROOT_STATE).cpu()[..., :3] - eo.tensor(abi.T_ROOT_STATE)[..., :3]).abs().amax(dim=(1, 2))
+    assert float(dev.median()) < 2e-6 and float(dev.quantile(0.99)) < 1e-4 and float(dev.max()) < 2e-3, (dev.median(), dev.max())
+    assert torch.equal(eh.tensor(abi.T_RESET_BUF).cpu(), eo.tensor(abi.T_RESET_BUF))
+    assert int(eh.tensor(abi.T_CONTACT_OVERFLOW).sum()) == int(eo.tensor(abi.T_CONTACT_OVERFLOW).sum())
+
+
+def test_box_corner_contacts_match_oracle(solver):
+    """go1pushbox: the free box balanced on one corner over the trunks of floating robots (its corners against the robots' primitives,
+    round 4): identical contact lists -- box against base link -- and the same motion over 8 substeps."""
+    N = 8
+    eh, eo, d = _pair("go1pushbox", N)
+    eh.reset_all(); eo.reset_all()
+    torch.cuda.synchronize()
+    ro, do = eo.tensor(abi.T_ROOT_STATE), eo.tensor(abi.T_DOF_STATE)
+    g = torch.Generator().manual_seed(2)
+    A = 2
+    h = np.array([d.npc_box_half[0], d.npc_box_half[1], d.npc_box_half[2]], np.float64)
+    v = -h / np.linalg.norm(h); t = np.array([0.0, 0.0, -1.0])
+    ax = np.cross(v, t); s_, c_ = np.linalg.norm(ax), float(v @ t); ax /= s_
+    K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    R = np.eye(3) + s_ * K + (1 - c_) * K @ K
+    ang = np.arctan2(s_, c_)
+    quat = torch.tensor(np.concatenate([ax * np.sin(ang / 2), [np.cos(ang / 2)]]), dtype=torch.float32)
+    ro[:, 0, 2] = 2.0; ro[:, 1, 2] = 2.0; ro[:, 1, 1] += 3.0
+    ro[:, :, 3:7] = torch.tensor([0.0, 0.0, 0.0, 1.0]); ro[:, :, 7:] = 0; do[..., 1] = 0
+    top = ro[:, 0, :3].clone()
+    top[:, 0] += (torch.rand(N, generator=g) - 0.5) * 0.2
+    top[:, 1] += (torch.rand(N, generator=g) - 0.5) * 0.05
+    top[:, 2] += 0.057 + 0.002                                    # the trunk box's half height (go1.urdf:56) + 2 mm
+    ro[:, A, :3] = top - torch.tensor(R @ (-h), dtype=torch.float32)
+    ro[:, A, 3:7] = quat
+    eh.tensor(abi.T_ROOT_STATE).copy_(ro.cuda()); eh.tensor(abi.T_DOF_STATE).copy_(do.cuda())
+    eh.tensor(abi.T_TORQUES).zero_(); eo.tensor(abi.T_TORQUES).zero_()
+    saw = 0
+    for env in range(N):
+        _, ch = eh.debug_dynamics(env, 0)
+        _, _, co = eo.debug_dynamics(env, 0)
+        assert ch.shape == co.shape and (ch[:, :4] == co[:, :4]).all(), (env, ch, co)
+        close(ch[:, 4:], co[:, 4:], atol=2e-5, what="contact separation / normal")
+        saw += int(((co[:, 0] == 0) & (co[:, 1] == 0) & (co[:, 2] == A)).sum())
+    assert saw >= N, "every env must hold the corner-on-trunk contact"
+    for k in range(8):
+        eh.simulate(); eo.simulate()
+    torch.cuda.synchronize()
+    close(eh.tensor(abi.T_ROOT_STATE)[..., :7], eo.tensor(abi.T_ROOT_STATE)[..., :7], atol=2e-4, what="poses after 8 substeps")
+
+
 def _record(kind, obj):
     """measured deviations, appended to gpurun_out/test_measurements.jsonl when that directory exists (what the bounds are set from)"""
     import json

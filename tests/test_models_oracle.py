@@ -2,6 +2,7 @@
 import ctypes as C
 
 import numpy as np
+import pytest
 import torch
 
 from helpers import golden, make_desc, oracle_engine
@@ -255,7 +256,8 @@ def _model_prim_surface(m, q, Rb, pb, rng, n=400):
     return c + m["prim_half"][q][0] * v
 
 
-def test_collision_model_stays_close_to_the_urdf_collision_primitives():
+@pytest.mark.parametrize("variant", ["capsule", "exact"])
+def test_collision_model_stays_close_to_the_urdf_collision_primitives(variant):
     """go1.urdf declares 2 boxes on the base (:56, :80), a cylinder per hip (-> capsule, go1_config.py:75), a box per thigh and calf
     and a sphere per foot.  The engine collides those primitives themselves, except that the thigh / calf bars are capsules
     (VERDICT r2 missing #2).  Two-sided bound on the WHOLE robot, default stance and random poses: (a) how far the URDF primitives'
@@ -265,6 +267,8 @@ def test_collision_model_stays_close_to_the_urdf_collision_primitives():
     import rigid_ref as rr
     f = _urdf_facts()
     m = urdf_model.load_model("go1")
+    if variant == "exact":        # desc collision_model = "exact": thigh / calf as the URDF's boxes, 60 feature points (round 4)
+        m = dict(m, **m["exact"])
     mr = rr.load_model()
     rng = np.random.default_rng(0)
     q_def = np.array([0.1, 0.8, -1.5, -0.1, 0.8, -1.5, 0.1, 1.0, -1.5, -0.1, 1.0, -1.5])
@@ -312,13 +316,29 @@ def test_collision_model_stays_close_to_the_urdf_collision_primitives():
         pts_m = pts_m[sdf_model(pts_m) > -1e-9]
         dirs = rng.normal(size=(3000, 3)); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
         hp = (pts_u @ dirs.T).max(0)
+        if variant == "exact":        # the URDF union's support function in closed form (the sampled one is short by up to a few mm)
+            sup = []
+            for c in prims:
+                dl = dirs @ c["_R"]
+                if c["type"] == "box":
+                    sup.append(dirs @ c["_t"] + np.abs(dl) @ (np.array(c["params"]["size"]) / 2))
+                elif c["type"] == "sphere":
+                    sup.append(dirs @ c["_t"] + c["params"]["radius"][0])
+                else:
+                    sup.append(dirs @ c["_t"] + np.abs(dl[:, 2]) * c["params"]["length"][0] / 2 + c["params"]["radius"][0])
+            hp = np.max(sup, axis=0)
         hs = np.max([c @ dirs.T + r for c, r in feat], axis=0)
         down = dirs[:, 2] < -0.8                                # towards the ground
         res.append(dict(surface_out=float(sdf_model(pts_u).max()), surface_in=float(sdf_urdf(pts_m).max()),
                         support_out=float((hp - hs).max()), support_in=float((hs - hp).max()),
                         ground_out=float((hp - hs)[down].max()), ground_in=float((hs - hp)[down].max())))
     worst = {k: max(r[k] for r in res) for k in res[0]}
-    print("collision-model bounds [m]:", {k: round(v, 4) for k, v in worst.items()})
+    print("collision-model bounds [m]:", variant, {k: round(v, 5) for k, v in worst.items()})
+    if variant == "exact":
+        # every primitive is the URDF's own shape (surface deviation: rounding) and the feature points carry the
+        # union's support function to 1 mm in every direction (what is left out: corners that lie inside a neighbouring shape)
+        assert max(worst.values()) < 1e-3, worst
+        return
     # towards the ground the robot is its feet: the URDF's own spheres -> exact (sampling noise of the surface points only)
     assert worst["ground_out"] < 2e-3 and worst["ground_in"] < 2e-3, worst
     # any plane: the feature points reach as far as the primitives to 6 mm (a thigh bar's end corner against the round cap of its
