@@ -1775,6 +1775,22 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       r.s0 = a0; r.s1 = a1; r.s2 = a2;
       return r;
     };
+    // temporal solver: what the contact's own lane keeps for the separation updates between the sweeps -- side A's normal row, u*_n, the
+    // running separation (side B of a two-actor contact is re-read from its slot: rare)
+    float nrow[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, usn = 0.0f;
+    const float* nwb = accv; const float* nwl = accv;
+    if (tgs && is_con) {
+      const float4* r4 = reinterpret_cast<const float4*>(lds + L.phi + lane * SIDE_STRIDE);
+      const float4 a0 = r4[0], a1 = r4[1], a4 = r4[4], a5 = r4[5], a6 = r4[6];
+      const int info = __float_as_int(a6.w), ncl = info & 15;
+      nrow[0] = a0.x; nrow[1] = ncl > 1 ? a0.y : 0.0f; nrow[2] = ncl > 2 ? a0.z : 0.0f; nrow[3] = ncl > 3 ? a0.w : 0.0f; nrow[4] = ncl > 4 ? a1.x : 0.0f; nrow[5] = ncl > 5 ? a1.y : 0.0f;
+      const bool legc = ncl == 9;
+      nrow[6] = legc ? a4.z : 0.0f; nrow[7] = legc ? a4.w : 0.0f; nrow[8] = legc ? a5.x : 0.0f;
+      nwb = accv + (info >> 10);
+      nwl = nwb + (legc ? 6 + ((info >> 4) & 63) : 0);            // (no leg columns: three zero weights on the base's first coordinates)
+      const float* sr = lds + L.srec + lane * SREC_STRIDE;
+      usn = sr[0]; csep = sr[16];
+    }
     // (barriers inside: with two envs per wavefront the trip counts are the larger of the two envs'; a row without work idles)
     const int maxlen_w = wave_max_of_groups(maxlen), npair_w = wave_max_of_groups(npair);
     for (int it = 0; it < nsweeps; it++) {
@@ -1810,10 +1826,11 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
         if (is_con) {
           float* sr = lds + L.srec + lane * SREC_STRIDE;
           float g = 0.0f;
-          if (tgs && it < npos) {                            // Phi_n . w from the side records' normal rows
-            for (int side = 0; side < 2; side++) {
-              if (side == 1 && !is_pair) break;
-              const float* rec = side == 0 ? lds + L.phi + lane * SIDE_STRIDE : lds + L.side + (lane - nc_terr) * SIDE_STRIDE;
+          if (tgs && it < npos) {                            // Phi_n . w: side A from the lane's registers
+            g = nrow[0] * nwb[0] + nrow[1] * nwb[1] + nrow[2] * nwb[2] + nrow[3] * nwb[3] + nrow[4] * nwb[4] + nrow[5] * nwb[5]
+              + nrow[6] * nwl[0] + nrow[7] * nwl[1] + nrow[8] * nwl[2];
+            if (is_pair) {
+              const float* rec = lds + L.side + (lane - nc_terr) * SIDE_STRIDE;
               const int info = __float_as_int(rec[SIDE_INFO]);
               const int ncl = info & 15, jo = (info >> 4) & 63;
               const float* wb = accv + (info >> 10);
@@ -1822,9 +1839,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
               if (ncl == 9) g += rec[SIDE_Z] * wb[6 + jo] + rec[SIDE_Z + 1] * wb[7 + jo] + rec[SIDE_Z + 2] * wb[8 + jo];
             }
           }
-          float sep = sr[16];
-          sr[3] = next_bias(sep, sr[0] + g, sr[3], it);
-          sr[16] = sep;
+          sr[3] = tgs ? next_bias(csep, usn + g, 0.0f, it) : next_bias(csep, 0.0f, sr[3], it);
         }
         __syncthreads();
       }
