@@ -183,6 +183,16 @@ typedef struct {
   /* walls of different heights in one scene (barrier_track.py:167-173,191-199,218-239: a (lo, hi) wall_height draws one height per
    * block): top [m] of the wall nearest to each raster point, [sdf_nx][sdf_ny] host pointer, or NULL = wall_height everywhere */
   const float* wall_top;
+  /* Edge contacts (round 4): what a test of feature POINTS against shapes cannot see -- an edge cutting into a primitive between its
+   * feature points.  edge_contacts is a bit mask: 1 = the vertical edges of the wall prisms (wall_corner: per raster point the world
+   * (x, y) of the nearest convex corner of the wall set, [sdf_nx][sdf_ny][2] host pointer, or NULL) against the robots' primitives --
+   * a capsule's axis against the edge, the edge against a box primitive's faces; 2 = the robots' capsule axes against the oriented
+   * boxes of the scene (1-dof link plank / door, free box, scenery boxes): the closest point of the whole segment, not of its two end
+   * points; 4 = the twelve edges of those boxes against the robots' box primitives.  The closest approach of a segment to a convex box
+   * is a one-dimensional convex minimisation: both engines run the same 18-evaluation golden-section search.  Such a contact is kept
+   * when it lies BETWEEN feature points (segment parameter inside 5 .. 95 %); 0 = round 3's behaviour. */
+  int32_t edge_contacts;
+  const float* wall_corner;
   float soft_dof_pos_limit;               /* rewards.soft_dof_pos_limit (legged_robot.py:317-321): fraction of the URDF joint range
                                              outside of which MQE_T_SUBSTEP_EXCEED_DOF_POS_LIMITS flags a joint; 0 = 1.0 */
   /* per-env constants, host pointers */

@@ -137,6 +137,58 @@ __device__ __forceinline__ bool sphere_capsule(V3 c, float r, V3 cq, V3 u, float
   return dist > 1e-9f;
 }
 
+// Closest approach of the segment p0 + t (p1 - p0), t in [0, 1], swept by the radius r, to a box (centre bc, rotation R, half extents h):
+// the signed distance to a convex set is convex along a line -> golden-section search, two first evaluations and sixteen refinements (the bracket ends at 0.05 % of the segment), the
+// sequence of oracle/mqe_oracle.c::seg_box.  Returns the signed distance at the final t; tb = that t, n = box -> point, pt = the point.
+__device__ __forceinline__ float seg_box_dev(V3 p0, V3 p1, float r, V3 bc, const float* R, V3 h, float& tb, V3& n, V3& pt) {
+  const float gr = 0.6180339887498949f;
+  const V3 dp = p1 - p0;
+  float a = 0.0f, b = 1.0f;
+  V3 nn;
+  float c = b - gr * (b - a), dd = a + gr * (b - a);
+  float fc = sphere_box(p0 + c * dp, r, bc, R, h, nn);
+  float fd = sphere_box(p0 + dd * dp, r, bc, R, h, nn);
+#pragma clang loop unroll(disable)
+  for (int it = 0; it < 16; it++) {
+    const bool left = fc < fd;
+    float tn;
+    if (left) { b = dd; dd = c; fd = fc; c = b - gr * (b - a); tn = c; }
+    else { a = c; c = dd; fc = fd; dd = a + gr * (b - a); tn = dd; }
+    const float fn = sphere_box(p0 + tn * dp, r, bc, R, h, nn);
+    if (left) fc = fn; else fd = fn;
+  }
+  tb = 0.5f * (a + b);
+  pt = p0 + tb * dp;
+  return sphere_box(pt, r, bc, R, h, n);
+}
+// Edge contact of one robot primitive (lane-local data) with a convex box: a capsule's AXIS against the box; a box primitive against the
+// box's own axis segment when the box is degenerate (a wall's vertical edge: h = (0, 0, L / 2)).  The rules of oracle/mqe_oracle.c::edge_vs_box:
+// kept between the end points only (5 .. 95 % of a capsule's axis), not next to a feature point on the axis, not when tunnelled.
+// ptype: MQE_PRIM_CAPSULE / MQE_PRIM_BOX; cq / uq: centre, half-axis; rq: capsule radius; hb / Rb: box primitive's half extents / rotation.
+__device__ __forceinline__ bool edge_vs_box_dev(int ptype, V3 cq, V3 uq, float rq, V3 hb, const float* Rb, float tf0, float tf1,
+                                                V3 bc, const float* R, V3 h, bool is_wall_edge, float& sd, V3& n, V3& pa) {
+  const bool cap = ptype == MQE_PRIM_CAPSULE;
+  if (!cap && !is_wall_edge) return false;
+  // one call site: the capsule's axis against the obstacle box, or the wall edge (the obstacle's own z axis) against the box primitive
+  const V3 ez = v3(R[2] * h.z, R[5] * h.z, R[8] * h.z);
+  const V3 p0 = cap ? cq - uq : bc - ez, p1 = cap ? cq + uq : bc + ez;
+  float Rs[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) Rs[k] = cap ? R[k] : Rb[k];
+  float tb; V3 nn, pt;
+  const float v = seg_box_dev(p0, p1, cap ? rq : 0.0f, cap ? bc : cq, Rs, cap ? h : hb, tb, nn, pt);
+  if (cap) {
+    if (!(tb > 0.05f && tb < 0.95f)) return false;
+    if ((tb > tf0 - 0.1f && tb < tf0 + 0.1f) || (tb > tf1 - 0.1f && tb < tf1 + 0.1f)) return false;
+    if (v + rq < 0.0f) return false;
+    sd = v; n = nn; pa = pt - rq * nn;
+    return true;
+  }
+  if (v < -0.02f) return false;
+  sd = v; n = v3(-nn.x, -nn.y, -nn.z); pa = pt;
+  return true;
+}
+
 __device__ __forceinline__ float wave_sum(float x) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
@@ -839,6 +891,66 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       const int p = pass - n_rpass;
       if (lane < m->npc_n_spheres) { act = A + p; sidx = lane; s = A * nsr + p * m->npc_n_spheres + lane; }
     }
+    // ---- edge contacts of the pass's robots with the static world (desc.edge_contacts; oracle: "edge contacts of a robot with the static
+    // world"): lane = primitive of the lane's robot; per primitive the deepest of the nearest vertical wall edge and the scenery boxes.
+    // Computed first, ranked behind the robot's feature contacts below.
+    bool eflag = false; float esd = 1e3f; V3 en = v3(0, 0, 1), epa = v3(0, 0, 0); int ebody = 0, erep = 0;
+    if (rob && m->edge_mask != 0 && ((m->edge_mask & 1) != 0 && m->wall_corner != nullptr || (m->edge_mask & 2) != 0 && shp.n_static > 0)) {
+      const int l = lane - sub * nsr, r = pass * rpp + sub;
+      const bool isp = l >= 0 && l < npr && r < A && rm.prim_type[l < npr ? (l < 0 ? 0 : l) : 0] != MQE_PRIM_SPHERE;
+      const int q = isp ? l : 0;
+      V3 cq = v3(0, 0, 0), uq = v3(0, 0, 0), hb = v3(0, 0, 0);
+      float Rb[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+      const int ptype = rm.prim_type[q];
+      if (isp) {
+        const float* rec = lds + L.body + (r * MQE_NBODY + rm.prim_body[q]) * BODY_STRIDE;
+        const float4 q0 = reinterpret_cast<const float4*>(rec)[0], q1 = reinterpret_cast<const float4*>(rec)[1], q2 = reinterpret_cast<const float4*>(rec)[2];
+        Rb[0] = q0.x; Rb[1] = q0.y; Rb[2] = q0.z; Rb[3] = q0.w; Rb[4] = q1.x; Rb[5] = q1.y; Rb[6] = q1.z; Rb[7] = q1.w; Rb[8] = q2.x;
+        cq = v3(q2.y, q2.z, q2.w) + mat_vec(Rb, v3(rm.prim_center[q][0], rm.prim_center[q][1], rm.prim_center[q][2]));
+        uq = mat_vec(Rb, v3(rm.prim_axis[q][0], rm.prim_axis[q][1], rm.prim_axis[q][2]));
+        hb = v3(rm.prim_half[q][0], rm.prim_half[q][1], rm.prim_half[q][2]);
+        ebody = rm.prim_body[q]; erep = r * MQE_NREP + rm.prim_reported[q];
+      }
+      const float reach = rm.prim_bound[q] + m->contact_offset;
+      const float I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+      const int njobs = 1 + ((m->edge_mask & 2) ? shp.n_static : 0);
+      for (int j = 0; j < njobs; j++) {
+        bool valid = false; V3 bc = v3(0, 0, 0), hh = v3(0, 0, 0);
+        if (j == 0) {
+          if (isp && (m->edge_mask & 1) != 0 && m->wall_corner != nullptr) {
+            const float hs = m->hs;
+            int ix = (int)floorf(cq.x / hs + 0.5f), iy = (int)floorf(cq.y / hs + 0.5f);
+            ix = min(max(ix, 0), m->sdf_nx - 1); iy = min(max(iy, 0), m->sdf_ny - 1);
+            const float2 cc = reinterpret_cast<const float2*>(m->wall_corner)[(size_t)ix * m->sdf_ny + iy];
+            const float dx = cq.x - cc.x, dy = cq.y - cc.y;
+            if (dx * dx + dy * dy < reach * reach) {
+              // the wall's top at the corner: one height per scene or the map's value at the raster point nearest to the corner
+              float zt = m->wall_height;
+              if (m->wall_top != nullptr) {
+                float fx = fminf(fmaxf(cc.x / hs, 0.0f), (float)(m->sdf_nx - 1)), fy = fminf(fmaxf(cc.y / hs, 0.0f), (float)(m->sdf_ny - 1));
+                int jx = min((int)fx, m->sdf_nx - 2), jy = min((int)fy, m->sdf_ny - 2);
+                zt = m->wall_top[(size_t)((fx - jx) < 0.5f ? jx : jx + 1) * m->sdf_ny + ((fy - jy) < 0.5f ? jy : jy + 1)];
+              }
+              bc = v3(cc.x, cc.y, 0.5f * (m->ground_z + zt)); hh = v3(0, 0, 0.5f * (zt - m->ground_z));
+              valid = true;
+            }
+          }
+        } else if (isp && ptype == MQE_PRIM_CAPSULE) {
+          const V3 nb = ld3(lds + L.root + A * 13);
+          bc = nb + v3(m->sb_center[j - 1][0], m->sb_center[j - 1][1], m->sb_center[j - 1][2]);
+          hh = v3(m->sb_half[j - 1][0], m->sb_half[j - 1][1], m->sb_half[j - 1][2]);
+          valid = fabsf(cq.x - bc.x) < hh.x + reach && fabsf(cq.y - bc.y) < hh.y + reach && fabsf(cq.z - bc.z) < hh.z + reach;
+        }
+        if (gballot(valid) == 0ull) continue;                 // (wave-wide skip: nobody near a wall edge / this box)
+        if (valid) {
+          float sdj; V3 nj, pj;
+          if (edge_vs_box_dev(ptype, cq, uq, hb.x, hb, Rb, m->prim_feat_t[q][0], m->prim_feat_t[q][1], bc, I3, hh, j == 0, sdj, nj, pj) && (!eflag || sdj < esd)) {
+            eflag = true; esd = sdj; en = nj; epa = pj;
+          }
+        }
+      }
+      eflag = eflag && esd < m->contact_offset;
+    }
     bool gflag = false, wflag = false, bflag = false, cflag = false;   // ground, wall, seesaw platform, seesaw column
     float gsd = 0, wsd = 0, bsd = 0, csd = 0; V3 gn = v3(0, 0, 1), wn = v3(0, 0, 1), bn = v3(0, 0, 1), cn3 = v3(0, 0, 1); V3 c = v3(0, 0, 0); float rad = 0;
     int body = 0, rep = 0;
@@ -909,17 +1021,18 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       }
     }
     const unsigned long long bg = gballot(gflag), bw2 = gballot(wflag), bb2 = gballot(bflag), bc2 = gballot(cflag);
+    const unsigned long long be = m->edge_mask != 0 ? gballot(eflag) : 0ull;     // edge contacts: behind ALL feature contacts of their robot
     const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const unsigned long long gl = gm & lower;
     const int pre = __popcll(bg & gl) + __popcll(bw2 & gl) + __popcll(bb2 & gl) + __popcll(bc2 & gl);   // rank in my actor
-    int tot0 = __popcll(bg & m0) + __popcll(bw2 & m0) + __popcll(bb2 & m0) + __popcll(bc2 & m0);          // first robot of the pass
+    int tot0 = __popcll(bg & m0) + __popcll(bw2 & m0) + __popcll(bb2 & m0) + __popcll(bc2 & m0) + __popcll(be & m0);          // first robot of the pass
     int tot1 = 0;
     if (tot0 > cap) { tot0 = cap; if (rob || !npc_one) ovf = 1; }       // (the all-NPC pass recounts per actor below)
     int base = nc;
     if (rob) {
       if (rpp == 2) {
         const unsigned long long m1 = m0 << nsr;
-        tot1 = __popcll(bg & m1) + __popcll(bw2 & m1) + __popcll(bb2 & m1) + __popcll(bc2 & m1);
+        tot1 = __popcll(bg & m1) + __popcll(bw2 & m1) + __popcll(bb2 & m1) + __popcll(bc2 & m1) + __popcll(be & m1);
         if (tot1 > cap) { tot1 = cap; ovf = 1; }
       }
       base = nc + (sub ? tot0 : 0);
@@ -959,12 +1072,57 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
         }
       }
     }
+    if (eflag) {                                   // behind every feature contact of my robot, primitive by primitive
+      const int rk = __popcll(bg & gm) + __popcll(bw2 & gm) + __popcll(bb2 & gm) + __popcll(bc2 & gm) + __popcll(be & gl), slot = base + rk;
+      if (slot < maxc && rk < cap) {
+        float* cr = lds + L.con + slot * CON_STRIDE;
+        con_store(cr, pass * rpp + sub, ebody, -1, 0, epa, en, esd, erep, -1);
+      }
+    }
     nc += tot0 + tot1;
     if (nc > maxc) { nc = maxc; ovf = 1; }
   }
   // robot spheres vs the seesaw plank (dynamic: couples the robots through the hinge); after all terrain contacts
   const int nc_terr = nc;                                   // one-sided contacts end here; two-actor contacts follow
   const int pair_lim = nc_terr + mqe_maxpair(maxc) < maxc ? nc_terr + mqe_maxpair(maxc) : maxc;
+  // edge contacts of robot a's capsule primitives (lanes) with a moving box of the scene -- the plank / door, the free box -- (desc.edge_contacts
+  // bit 2; oracle: "... and the plank's / door's edges", "... and its edges against the robot's primitives"): the closest approach of the
+  // capsule's whole axis.  `room` = how many more contacts this robot may add (the plank's per-robot share), actor / reported body of the box.
+  auto pair_edges = [&](int a, V3 bc, const float* Rbx, V3 hbx, int actB, int repB, int room) {
+    const bool isp = lane < npr && rm.prim_type[lane < npr ? lane : 0] == MQE_PRIM_CAPSULE;
+    const int q = isp ? lane : 0;
+    V3 cq = v3(0, 0, 0), uq = v3(0, 0, 0);
+    bool valid = false;
+    if (isp) {
+      const float* rec = lds + L.body + (a * MQE_NBODY + rm.prim_body[q]) * BODY_STRIDE;
+      const float4 q0 = reinterpret_cast<const float4*>(rec)[0], q1 = reinterpret_cast<const float4*>(rec)[1], q2 = reinterpret_cast<const float4*>(rec)[2];
+      const float Rr[9] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x};
+      cq = v3(q2.y, q2.z, q2.w) + mat_vec(Rr, v3(rm.prim_center[q][0], rm.prim_center[q][1], rm.prim_center[q][2]));
+      uq = mat_vec(Rr, v3(rm.prim_axis[q][0], rm.prim_axis[q][1], rm.prim_axis[q][2]));
+      // screen: the primitive's bounding sphere against the box's (a point inside the box passes too)
+      const V3 dd = cq - bc;
+      const float reach = rm.prim_bound[q] + m->contact_offset + sqrtf(dot(hbx, hbx));
+      valid = dot(dd, dd) < reach * reach;
+    }
+    if (gballot(valid) == 0ull) return;
+    bool hit = false; float sd = 0; V3 n = v3(0, 0, 1), pa = v3(0, 0, 0);
+    if (valid) {
+      const float I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+      hit = edge_vs_box_dev(MQE_PRIM_CAPSULE, cq, uq, rm.prim_half[q][0], v3(0, 0, 0), I9, m->prim_feat_t[q][0], m->prim_feat_t[q][1], bc, Rbx, hbx, false, sd, n, pa) && sd < m->contact_offset;
+    }
+    const unsigned long long bh = gballot(hit);
+    if (bh == 0ull) return;
+    const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int rk = __popcll(bh & lower), slot = nc + rk;
+    if (hit && rk < room && slot < pair_lim) {
+      float* cr = lds + L.con + slot * CON_STRIDE;
+      con_store(cr, a, rm.prim_body[q], actB, 0, pa, n, sd, a * MQE_NREP + rm.prim_reported[q], repB);
+    }
+    int tot = __popcll(bh);
+    if (tot > room) { tot = room < 0 ? 0 : room; ovf = 1; }
+    nc += tot;
+    if (nc > pair_lim) { nc = pair_lim; ovf = 1; }
+  };
   if (SS) {
     const int capP = mqe_maxpair(maxc) / A;              // per robot, so that the first robot cannot starve the others
     for (int a = 0; a < A; a++) {                        // one robot per iteration: lanes = its spheres
@@ -989,6 +1147,8 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       if (tot > capP) { tot = capP; ovf = 1; }
       nc += tot;
       if (nc > pair_lim) { nc = pair_lim; ovf = 1; }
+      if ((m->edge_mask & 2) != 0 && !m->ss_link_cyl)
+        pair_edges(a, ssC, ssR, v3(m->ss_plank_half[0], m->ss_plank_half[1], m->ss_plank_half[2]), A, A * MQE_NREP + 1, capP - tot);
     }
   }
   TSTAMP(9);
@@ -1075,6 +1235,8 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
               if (nc > pair_lim) { nc = pair_lim; ovf = 1; }
             }
           }
+          if ((m->edge_mask & 2) != 0)
+            pair_edges(a, pb, brec + B_R, v3(m->npc_box_half[0], m->npc_box_half[1], m->npc_box_half[2]), b, A * MQE_NREP + (b - A), 64);
           continue;
         }
         if (b < A) {

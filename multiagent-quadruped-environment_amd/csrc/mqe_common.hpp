@@ -44,6 +44,9 @@ struct DevModel {
   int cmd_dims, cmd_general; int cmd_src[18]; float cmd_scale[18];      // desc.command_src / command_scale; cmd_general: not the shipped (x, y, yaw) layout
   const float* wall_sdf; int sdf_nx, sdf_ny; float hs, wall_height, ground_z;
   const float* wall_top;                           // per-cell wall top [m] (walls of different heights), or nullptr = wall_height
+  const float* wall_corner;                        // per raster point the (x, y) of the nearest convex corner of the wall set, or nullptr (edge contacts)
+  int edge_mask;                                   // desc.edge_contacts: 1 wall edges, 2 capsule axes against the scene's boxes
+  float prim_feat_t[MQE_MAX_PRIMS][2];             // axis parameters (0 .. 1) of the feature points that sit ON a capsule primitive's axis between its ends (-9: none)
   const float* ground_height;                      // relief of the walkable surface above ground_z at the SDF's raster points, or nullptr
   float soft_lo[12], soft_hi[12];                  // soft joint position limits (legged_robot.py:317-321) of MQE_T_SUBSTEP_EXCEED_DOF_POS_LIMITS
   const float *env_origins, *agent_origins, *base_init, *npc_init, *gate_pos;   // env_origins: the values at construction (obs.base_pos, sheep wrapper, gate height); the live ones are DevState::env_origins_live

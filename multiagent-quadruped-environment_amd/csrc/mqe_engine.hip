@@ -359,6 +359,23 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   UP(m.wall_sdf, d->wall_sdf, (size_t)d->sdf_nx * d->sdf_ny);
   UP(m.ground_height, d->ground_height, (size_t)d->sdf_nx * d->sdf_ny);
   UP(m.wall_top, d->wall_top, (size_t)d->sdf_nx * d->sdf_ny);
+  if (d->edge_contacts & ~3) return fail(-6, "edge_contacts: the HIP engine implements bits 1 (wall edges) and 2 (capsule axes against the scene's boxes); bit 4 (box edges against box primitives) exists in the CPU oracle only");
+  m.edge_mask = d->edge_contacts & 3;
+  m.wall_corner = nullptr;
+  if ((m.edge_mask & 1) && d->wall_corner) { UP(m.wall_corner, d->wall_corner, (size_t)d->sdf_nx * d->sdf_ny * 2); }
+  for (int q = 0; q < MQE_MAX_PRIMS; q++) {       // feature points on a capsule's axis strictly between its ends (the thigh's middle): an edge contact next to one would duplicate it
+    m.prim_feat_t[q][0] = m.prim_feat_t[q][1] = -9.0f;
+    if (q >= d->robot.n_prims || d->robot.prim_type[q] != MQE_PRIM_CAPSULE) continue;
+    const float* ax = d->robot.prim_axis[q];
+    const float aa = ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2];
+    int k = 0;
+    for (int f = 0; f < d->robot.n_spheres && aa > 0.0f; f++)
+      if (d->robot.sphere_prim[f] == q) {
+        const float df[3] = {d->robot.sphere_center[f][0] - d->robot.prim_center[q][0], d->robot.sphere_center[f][1] - d->robot.prim_center[q][1], d->robot.sphere_center[f][2] - d->robot.prim_center[q][2]};
+        const float tf = 0.5f + 0.5f * (df[0] * ax[0] + df[1] * ax[1] + df[2] * ax[2]) / aa;
+        if (tf > -0.05f && tf < 1.05f && k < 2) m.prim_feat_t[q][k++] = tf;       // (the ends themselves are outside the 5 .. 95 % window anyway)
+      }
+  }
   {
     const float soft = d->soft_dof_pos_limit > 0.0f ? d->soft_dof_pos_limit : 1.0f;
     for (int j = 0; j < MQE_NDOF; j++) {          // legged_robot.py:317-321

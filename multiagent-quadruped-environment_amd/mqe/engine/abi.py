@@ -70,7 +70,7 @@ class SimDesc(C.Structure):
         ("command_obs", f32 * 70), ("cmd_lin_scale", f32), ("cmd_ang_scale", f32), ("clip_command", i32),
         ("num_command_dims", i32), ("command_src", i32 * 18), ("command_scale", f32 * 18),
         ("wall_sdf", FP), ("sdf_nx", i32), ("sdf_ny", i32),
-        ("horizontal_scale", f32), ("wall_height", f32), ("ground_z", f32), ("ground_height", FP), ("wall_top", FP), ("soft_dof_pos_limit", f32),
+        ("horizontal_scale", f32), ("wall_height", f32), ("ground_z", f32), ("ground_height", FP), ("wall_top", FP), ("edge_contacts", i32), ("wall_corner", FP), ("soft_dof_pos_limit", f32),
         ("env_origins", FP), ("agent_origins", FP), ("base_init_state", FP), ("npc_init_state", FP), ("gate_pos", FP),
         ("terrain_curriculum", i32), ("terrain_num_rows", i32), ("terrain_num_cols", i32), ("terrain_env_length", f32),
         ("terrain_origins", FP), ("terrain_levels", C.POINTER(i32)), ("terrain_types", C.POINTER(i32)),

@@ -116,7 +116,7 @@ def task_kind(cfg):
 
 def build_desc(cfg, num_envs, terrain, env_origins, agent_origins, gate_pos=None, env_id_offset=0, seed=0,
                task=None, body=None, resources_root=None, solver_iterations=None, erp=0.2, noise_mode=0, solver_type=None, velocity_iterations=None,
-               terrain_levels=None, terrain_types=None, collision_model=None):
+               terrain_levels=None, terrain_types=None, collision_model=None, edge_contacts=None):
     """Returns (SimDesc, keepalive) -- keepalive holds the numpy arrays the struct points into."""
     keep = []
     d = abi.SimDesc()
@@ -351,6 +351,12 @@ def build_desc(cfg, num_envs, terrain, env_origins, agent_origins, gate_pos=None
     if wt is not None:
         assert wt.shape == terrain.wall_sdf.shape
         d.wall_top = _fp(wt, keep)
+    # edge contacts (include/mqe_hip.h edge_contacts): on by default; MQE_EDGE_CONTACTS=<mask> overrides (0: round 3's feature-point tests only)
+    d.edge_contacts = int(os.environ.get("MQE_EDGE_CONTACTS", edge_contacts if edge_contacts is not None else 3))        # (bit 4, box edges against box primitives: CPU oracle only)
+    wc = getattr(terrain, "wall_corner", None)
+    if wc is not None and (d.edge_contacts & 1):
+        assert wc.shape == terrain.wall_sdf.shape + (2,)
+        d.wall_corner = _fp(wc, keep)
     d.soft_dof_pos_limit = float(getattr(cfg.rewards, "soft_dof_pos_limit", 1.0))
     d.env_origins = _fp(env_origins, keep)
     # run-time terrain curriculum (legged_robot.py:479-503): the per-track origin table and each env's (level, type) at construction

@@ -266,7 +266,35 @@ class BarrierTrack:
         self.ground_height = (relief * cfg.vertical_scale).astype(np.float32) if perlin_map else None
         self.wall = wall
         self.wall_sdf = self._signed_distance(wall, hs)
+        self.wall_corner = self._nearest_convex_corner(wall, hs)
         return self
+
+    @staticmethod
+    def _nearest_convex_corner(wall, hs):
+        """(nx, ny, 2) float32: for every raster point the world (x, y) of the nearest CONVEX corner of the wall pixel set -- the vertical
+        edges of the wall prisms (a pixel = the hs x hs square centred on its raster point, so corners sit on the half-integer lattice).
+        What the engine tests the robots' primitives against between their feature points: a gate post's corner pressing into the side
+        of the trunk.  None when the set has no convex corner."""
+        W = np.pad(np.asarray(wall, bool), 1)
+        q = W[:-1, :-1].astype(np.int8) + W[1:, :-1] + W[:-1, 1:] + W[1:, 1:]      # wall pixels around lattice node (a, b) = world ((a - .5) hs, (b - .5) hs)
+        convex = q == 1
+        if not convex.any():
+            return None
+        _, (ia, ib) = ndimage.distance_transform_edt(~convex, return_indices=True)
+        nx, ny = wall.shape
+        ii, jj = np.meshgrid(np.arange(nx), np.arange(ny), indexing="ij")
+        best, bd = None, None
+        for da in (0, 1):                      # the four lattice nodes around a raster point: the nearest of their nearest corners
+            for db in (0, 1):
+                ca, cb = ia[ii + da, jj + db], ib[ii + da, jj + db]
+                dist = (ca - 0.5 - ii) ** 2 + (cb - 0.5 - jj) ** 2
+                cand = np.stack([(ca - 0.5) * hs, (cb - 0.5) * hs], -1)
+                if best is None:
+                    best, bd = cand, dist
+                else:
+                    m = dist < bd
+                    best[m], bd[m] = cand[m], dist[m]
+        return np.ascontiguousarray(best, np.float32)
 
     def add_terrain_to_sim(self, gym=None, sim=None, device="cpu"):
         """Name kept for source compatibility (reference barrier_track.py:501); gym/sim are ignored."""

@@ -64,6 +64,7 @@ typedef struct mqo_sim {
   float* sdf;
   float* ground_height;             /* relief of the walkable surface at the SDF's raster points, or NULL (flat slab) */
   float* wall_top;                  /* per-cell wall top (walls of different heights), or NULL */
+  float* wall_corner;               /* per raster point the (x, y) of the nearest convex corner of the wall set, or NULL (edge contacts) */
   float *env_origins, *agent_origins, *base_init, *npc_init, *gate_pos;
   float *env_origins_live, *terrain_origins, *curr_xy;   /* terrain curriculum: MQE_T_ENV_ORIGINS, the origin table, pre-reset xy of the robot rows */
   int32_t *terrain_levels, *terrain_types;
@@ -301,6 +302,7 @@ int mqo_sim_create(const mqe_sim_desc* d, mqo_sim** out) {
   s->sdf = (float*)dupmem(d->wall_sdf, (size_t)d->sdf_nx * d->sdf_ny * 4);
   s->ground_height = d->ground_height ? (float*)dupmem(d->ground_height, (size_t)d->sdf_nx * d->sdf_ny * 4) : NULL;
   s->wall_top = d->wall_top ? (float*)dupmem(d->wall_top, (size_t)d->sdf_nx * d->sdf_ny * 4) : NULL;
+  s->wall_corner = d->wall_corner ? (float*)dupmem(d->wall_corner, (size_t)d->sdf_nx * d->sdf_ny * 8) : NULL;
   s->env_origins = (float*)dupmem(d->env_origins, (size_t)N * 3 * 4);
   s->env_origins_live = (float*)dupmem(d->env_origins, (size_t)N * 3 * 4);
   s->terrain_levels = (int32_t*)calloc((size_t)N, 4);
@@ -654,6 +656,39 @@ static real sphere_box(const real* c, real r, const real* bc, const real* R, con
   return sd;
 }
 
+/* Closest approach of the segment p0 + t (p1 - p0), t in [0, 1], swept by the radius r, to a box: the signed distance of a point to a
+ * convex set is convex along a line, so a golden-section search finds its minimum -- two first evaluations and sixteen refinements (the bracket ends at 0.05 % of the segment), the
+ * same sequence in the engine (csrc/kernels_physics.hpp seg_box).  Returns the signed distance at the final t, *tb = that t, n = the
+ * normal from the box to the point. */
+#define SEGBOX_ITERS 16
+static real seg_box(const real* p0, const real* p1, real r, const real* bc, const real* R, const real* h, real* tb, real* n, real* pt) {
+  const real gr = (real)0.6180339887498949;
+  real a = 0, b = 1, nn[3], x[3];
+  real c = b - gr * (b - a), dd = a + gr * (b - a);
+  for (int k = 0; k < 3; k++) x[k] = p0[k] + c * (p1[k] - p0[k]);
+  real fc = sphere_box(x, r, bc, R, h, nn);
+  for (int k = 0; k < 3; k++) x[k] = p0[k] + dd * (p1[k] - p0[k]);
+  real fd = sphere_box(x, r, bc, R, h, nn);
+  for (int it = 0; it < SEGBOX_ITERS; it++) {
+    if (fc < fd) { b = dd; dd = c; fd = fc; c = b - gr * (b - a); for (int k = 0; k < 3; k++) x[k] = p0[k] + c * (p1[k] - p0[k]); fc = sphere_box(x, r, bc, R, h, nn); }
+    else { a = c; c = dd; fc = fd; dd = a + gr * (b - a); for (int k = 0; k < 3; k++) x[k] = p0[k] + dd * (p1[k] - p0[k]); fd = sphere_box(x, r, bc, R, h, nn); }
+  }
+  real t = (real)0.5 * (a + b);
+  for (int k = 0; k < 3; k++) pt[k] = p0[k] + t * (p1[k] - p0[k]);
+  *tb = t;
+  return sphere_box(pt, r, bc, R, h, n);
+}
+/* the twelve edges of a box (centre bc, rotation R, half extents h): edge e = axis e / 4, the two other coordinates' signs from bits 0, 1 */
+static void box_edge(const real* bc, const real* R, const real* h, int e, real* p0, real* p1) {
+  int ax = e >> 2, o1 = (ax + 1) % 3, o2 = (ax + 2) % 3;
+  real l0[3], l1[3];
+  l0[ax] = -h[ax]; l1[ax] = h[ax];
+  l0[o1] = l1[o1] = (e & 1) ? h[o1] : -h[o1];
+  l0[o2] = l1[o2] = (e & 2) ? h[o2] : -h[o2];
+  mat3_vec(R, l0, p0); mat3_vec(R, l1, p1);
+  for (int k = 0; k < 3; k++) { p0[k] += bc[k]; p1[k] += bc[k]; }
+}
+
 static void make_tangents(const real* n, real* t1, real* t2) {
   real a[3] = {0, 0, 1};
   if (fabs((double)n[2]) > 0.7) { a[0] = 1; a[2] = 0; }
@@ -768,6 +803,49 @@ static int feat_vs_prim(const mqe_robot_model* m, const envwork_t* w, int rob, i
   *sd = dist - r - m->prim_half[q][0];
   n[0] = e[0] / dist; n[1] = e[1] / dist; n[2] = e[2] / dist;
   return 1;
+}
+
+/* Edge contact between primitive q of robot `rob` and a convex box (centre bc, rotation R, half extents h; a wall's vertical edge is the
+ * degenerate box h = (0, 0, L / 2) with n_edges = 1: its own axis): a capsule's AXIS against the box (mask bit 2), the box's edges against
+ * a box primitive (mask bit 4) -- the deepest edge.  Kept when the closest approach lies between the segment's end points (5 .. 95 %:
+ * the ends are feature points of the robot resp. corners).  Returns 1 with sd, n (from the obstacle to the robot), pa (the point on the
+ * robot's side: the capsule's surface point resp. the edge point). */
+static int edge_vs_box(const mqo_sim* s, const envwork_t* w, int rob, int q, const real* bc, const real* R, const real* h, int n_edges, int mask, real* sd, real* n, real* pa) {
+  const mqe_robot_model* m = &s->d.robot;
+  const real* cq = w->prim_c[rob][q];
+  if (m->prim_type[q] == MQE_PRIM_CAPSULE) {
+    const real* u = w->prim_u[rob][q];
+    if (!(mask & 2) || dot3(u, u) <= 0) return 0;
+    real p0[3] = {cq[0] - u[0], cq[1] - u[1], cq[2] - u[2]}, p1[3] = {cq[0] + u[0], cq[1] + u[1], cq[2] + u[2]}, tb, nn[3], pt[3];
+    real r = m->prim_half[q][0];
+    real v = seg_box(p0, p1, r, bc, R, h, &tb, nn, pt);
+    if (!(tb > (real)0.05 && tb < (real)0.95)) return 0;
+    for (int f = 0; f < m->n_spheres; f++)          /* ... nor next to a feature point that sits ON the axis (the thigh's middle) */
+      if (m->sphere_prim[f] == q) {
+        real df[3] = {m->sphere_center[f][0] - m->prim_center[q][0], m->sphere_center[f][1] - m->prim_center[q][1], m->sphere_center[f][2] - m->prim_center[q][2]};
+        real ax[3] = {m->prim_axis[q][0], m->prim_axis[q][1], m->prim_axis[q][2]};
+        real tf = (real)0.5 + (real)0.5 * dot3(df, ax) / dot3(ax, ax);
+        if (tb > tf - (real)0.1 && tb < tf + (real)0.1) return 0;
+      }
+    if (v + r < 0) return 0;      /* the axis itself is inside the box: a link that has tunnelled through a thin plate has no meaningful normal here */
+    *sd = v;
+    for (int k = 0; k < 3; k++) { n[k] = nn[k]; pa[k] = pt[k] - r * nn[k]; }
+    return 1;
+  }
+  if (m->prim_type[q] != MQE_PRIM_BOX || !(mask & 4)) return 0;
+  real hb[3] = {m->prim_half[q][0], m->prim_half[q][1], m->prim_half[q][2]};
+  const real* Rb = w->bk[rob][m->prim_body[q]].R;
+  int found = 0;
+  for (int e = 0; e < n_edges; e++) {
+    real p0[3], p1[3], tb, nn[3], pt[3];
+    if (n_edges == 1) { for (int k = 0; k < 3; k++) { p0[k] = bc[k] - (R[k * 3 + 2] * h[2]); p1[k] = bc[k] + (R[k * 3 + 2] * h[2]); } }
+    else box_edge(bc, R, h, e, p0, p1);
+    real v = seg_box(p0, p1, (real)0, cq, Rb, hb, &tb, nn, pt);
+    if (n_edges > 1 && !(tb > (real)0.05 && tb < (real)0.95)) continue;
+    if (v < (real)-0.02) continue;  /* an edge deeper than 2 cm inside the primitive: tunnelled, left to the feature points */
+    if (!found || v < *sd) { found = 1; *sd = v; for (int k = 0; k < 3; k++) { n[k] = -nn[k]; pa[k] = pt[k]; } }
+  }
+  return found;
 }
 
 static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
@@ -995,6 +1073,47 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
         }
       }
     }
+    /* edge contacts of a robot with the static world (include/mqe_hip.h edge_contacts), primitive by primitive after its feature points:
+     * per primitive the deepest of the nearest vertical wall edge and the static scenery boxes */
+    if (act < A && d->edge_contacts)
+      for (int q = 0; q < m->n_prims; q++) {
+        if (m->prim_type[q] == MQE_PRIM_SPHERE) continue;
+        const real* cq = w->prim_c[act][q];
+        real sd = (real)1e3, n[3] = {0, 0, 1}, pa[3] = {0, 0, 0};
+        int got = 0;
+        real I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        if ((d->edge_contacts & 1) && s->wall_corner) {
+          real hs = d->horizontal_scale;
+          int ix = (int)floor((double)(cq[0] / hs) + 0.5), iy = (int)floor((double)(cq[1] / hs) + 0.5);
+          if (ix < 0) ix = 0; if (iy < 0) iy = 0; if (ix > d->sdf_nx - 1) ix = d->sdf_nx - 1; if (iy > d->sdf_ny - 1) iy = d->sdf_ny - 1;
+          real cx = s->wall_corner[((size_t)ix * d->sdf_ny + iy) * 2], cy = s->wall_corner[((size_t)ix * d->sdf_ny + iy) * 2 + 1];
+          real dxy2 = (cq[0] - cx) * (cq[0] - cx) + (cq[1] - cy) * (cq[1] - cy);
+          real reach = m->prim_bound[q] + d->contact_offset;
+          if (dxy2 < reach * reach) {          /* the edge passes the primitive's bounding sphere */
+            real z0 = d->ground_z, z1 = wall_top_at(s, cx, cy);
+            real bc[3] = {cx, cy, (real)0.5 * (z0 + z1)}, hh[3] = {0, 0, (real)0.5 * (z1 - z0)};
+            got = edge_vs_box(s, w, act, q, bc, I3, hh, 1, 6, &sd, n, pa);
+          }
+        }
+        if ((d->edge_contacts & 6) && d->n_static_boxes > 0 && !SS) {
+          const float* nb = root + A * 13;
+          for (int bx = 0; bx < d->n_static_boxes; bx++) {
+            real bc[3] = {nb[0] + d->static_box_center[bx][0], nb[1] + d->static_box_center[bx][1], nb[2] + d->static_box_center[bx][2]};
+            real hb[3] = {d->static_box_half[bx][0], d->static_box_half[bx][1], d->static_box_half[bx][2]}, sdb, nn[3], pp[3];
+            if (edge_vs_box(s, w, act, q, bc, I3, hb, 12, d->edge_contacts, &sdb, nn, pp) && (!got || sdb < sd)) { got = 1; sd = sdb; for (int k = 0; k < 3; k++) { n[k] = nn[k]; pa[k] = pp[k]; } }
+          }
+        }
+        if (!got) continue;
+        if (sd < d->contact_offset && !(w->nc < maxc && mine < cap)) ovf = 1;
+        if (sd < d->contact_offset && w->nc < maxc && mine < cap) {
+          mine++;
+          contact_t* ct = &w->con[w->nc++];
+          memset(ct, 0, sizeof *ct);
+          ct->kind = 0; ct->actA = act; ct->actB = -1; ct->sd = sd; ct->repB = -1;
+          ct->bodyA = m->prim_body[q]; ct->repA = act * MQE_NREP + m->prim_reported[q];
+          for (int k = 0; k < 3; k++) { ct->n[k] = n[k]; ct->p[k] = pa[k]; }
+        }
+      }
   }
   /* two-actor contacts (plank, sphere pairs): at most maxc/2 of them (the engine slot-allocates their second side) */
   const int pair_lim = w->nc + maxc / 2 < maxc ? w->nc + maxc / 2 : maxc;
@@ -1016,6 +1135,21 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
           for (int k = 0; k < 3; k++) { ct->n[k] = n[k]; ct->p[k] = c[k] - r * n[k]; }
         }
       }
+      /* ... and the plank's / door's edges against the robot's primitives between their feature points (edge_contacts bits 2, 4) */
+      if ((d->edge_contacts & 6) && !d->seesaw_link_cylinder)
+        for (int q = 0; q < m->n_prims; q++) {
+          real hp[3] = {d->seesaw_plank_half[0], d->seesaw_plank_half[1], d->seesaw_plank_half[2]}, sd, n[3], pa[3];
+          if (!edge_vs_box(s, w, act, q, ssC, ssR, hp, 12, d->edge_contacts, &sd, n, pa)) continue;
+          if (sd < d->contact_offset && !(w->nc < pair_lim && mine < (maxc / 2) / A)) ovf = 1;
+          if (sd < d->contact_offset && w->nc < pair_lim && mine < (maxc / 2) / A) {
+            mine++;
+            contact_t* ct = &w->con[w->nc++];
+            memset(ct, 0, sizeof *ct);
+            ct->kind = 2; ct->actA = act; ct->actB = A; ct->sd = sd;
+            ct->bodyA = m->prim_body[q]; ct->repA = act * MQE_NREP + m->prim_reported[q]; ct->bodyB = 0; ct->repB = A * MQE_NREP + 1;
+            for (int k = 0; k < 3; k++) { ct->n[k] = n[k]; ct->p[k] = pa[k]; }
+          }
+        }
     }
   for (int a = 0; a < nact; a++)
     for (int b = a + 1; b < nact; b++) {
@@ -1061,6 +1195,20 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
             }
           }
         }
+        /* ... and its edges against the robot's primitives between their feature points (edge_contacts bits 2, 4) */
+        if (d->edge_contacts & 6)
+          for (int q = 0; q < m->n_prims; q++) {
+            real sd, n[3], pa[3];
+            if (!edge_vs_box(s, w, a, q, npc_pos[b - A], w->npcR[b - A], hb, 12, d->edge_contacts, &sd, n, pa)) continue;
+            if (sd < d->contact_offset && !(w->nc < pair_lim)) ovf = 1;
+            if (sd < d->contact_offset && w->nc < pair_lim) {
+              contact_t* ct = &w->con[w->nc++];
+              memset(ct, 0, sizeof *ct);
+              ct->kind = 1; ct->actA = a; ct->actB = b; ct->sd = sd;
+              ct->bodyA = m->prim_body[q]; ct->repA = a * MQE_NREP + m->prim_reported[q]; ct->bodyB = 0; ct->repB = A * MQE_NREP + (b - A);
+              for (int k = 0; k < 3; k++) { ct->n[k] = n[k]; ct->p[k] = pa[k]; }
+            }
+          }
         continue;
       }
       if (dot3(dd, dd) > (real)(1.2 * 1.2)) continue;   /* broad phase: actors farther apart than 1.2 m cannot touch */

@@ -200,3 +200,70 @@ def test_box_corner_presses_into_the_trunk_face():
     hit = [cc for cc in con if cc[2] == A]
     assert len(hit) == 1 and hit[0][0] == 0 and hit[0][1] == 0, con
     assert abs(hit[0][4] - 0.003) < 2e-6 and np.allclose(hit[0][5:8], [0, 0, -1], atol=1e-5), hit
+
+
+def test_wall_corner_presses_into_the_side_of_the_trunk():
+    """edge contacts (round 4, include/mqe_hip.h edge_contacts bit 1): a gate post's vertical corner 3 mm from the middle of the trunk's side
+    face -- between the legs, no feature point of the robot near it, the wall's signed-distance field says 5 cm of air at every trunk
+    corner -- gives ONE contact on the base link: separation 3 mm, normal from the post to the robot.  With edge_contacts = 0 (round 3)
+    there is none."""
+    m = urdf_model.load_model("go1")
+    for mask, want in ((7, 1), (0, 0)):
+        d, k, ctx = make_desc("go1gate", 1, edge_contacts=mask)
+        t = ctx["terrain"]
+        corners = np.unique(t.wall_corner.reshape(-1, 2), axis=0)
+        gate = corners[np.argsort(np.abs(corners[:, 0] - corners[:, 0].mean()))[:4]]            # the four corners of the two gate posts (mid-track)
+        lo = gate[gate[:, 1] < gate[:, 1].mean()]
+        cx, cy = lo[np.argmin(lo[:, 0])]                                                          # the lower post's corner that faces the opening, near side
+        e = oracle_engine(d, k, f64=True)
+        e.reset_all()
+        root, dof = e.tensor(abi.T_ROOT_STATE), e.tensor(abi.T_DOF_STATE)
+        dof[0, :, 0] = torch.tensor(np.tile(STANCE, 2), dtype=torch.float32); dof[..., 1] = 0
+        root[0, :, 3:7] = torch.tensor([0.0, 0.0, 0.0, 1.0]); root[0, :, 7:] = 0
+        hy = m["prim_half"][0][1]
+        root[0, 0, 0] = float(cx) - m["prim_center"][0][0]                                               # the corner at the middle of the trunk box
+        root[0, 0, 1] = float(cy) + hy + 0.003 - m["prim_center"][0][1]
+        root[0, 0, 2] = 0.32
+        root[0, 1, :2] = torch.tensor([1.5, 2.7])                                                 # the other robot out of the way
+        _, _, con = e.debug_dynamics(0, 0)
+        hit = [c for c in con if c[0] == 0 and c[1] == 0]
+        assert len(hit) == want, (mask, con)
+        if want:
+            assert abs(hit[0][4] - 0.003) < 1e-5 and np.allclose(hit[0][5:8], [0, 1, 0], atol=1e-4), hit
+
+
+def test_box_edge_cuts_into_a_thigh_and_into_the_trunk_face():
+    """edge contacts bits 2 and 4 on go1pushbox: (a) the free box's top edge under the MIDDLE of a thigh capsule -- both ends of the capsule
+    (its feature points) are centimetres away -- is found by the closest approach of the capsule's whole axis; (b) the box's vertical edge
+    3 mm from the middle of the trunk's side face (box corners at z = 0 and 1 m, trunk corners 19 cm away) is found by the edge-vs-box
+    search.  Expected separations from the model file's geometry alone."""
+    m = urdf_model.load_model("go1")
+    e, d, root, dof = _scene("go1pushbox", edge_contacts=7)         # (bit 4 -- box edges against box primitives -- exists in the oracle only)
+    A = d.num_agents
+    h = np.array([d.npc_box_half[0], d.npc_box_half[1], d.npc_box_half[2]], np.float64)
+    base = root[0, 0, :3].numpy().astype(np.float64)
+    # (a) FL thigh capsule (primitive 3): the box's vertical edge stands r + 4 mm off the bar's axis, on its outer side, BETWEEN the bar's
+    # feature points (upper end, middle, knee)
+    c, u, _ = _prim_world(m, 3, base)
+    rq = m["prim_half"][3][0]
+    uh = u / np.linalg.norm(u)
+    nrm = np.cross(uh, [0.0, 0.0, 1.0]); nrm /= np.linalg.norm(nrm)       # the common perpendicular of the bar and a vertical line
+    if nrm[1] > 0:
+        nrm = -nrm                                         # from the edge (outside, +y of the left leg) to the bar
+    line = (c - 0.4 * u) - nrm * (rq + 0.004)              # at 30 % of the axis: 4 cm from the bar's middle (a feature point), 6 cm from its upper end
+    root[0, A, :3] = torch.tensor([line[0] + h[0], line[1] + h[1], float(base[2])], dtype=torch.float32)      # the box's (-x, -y) vertical edge on that line
+    root[0, A, 3:7] = torch.tensor([0.0, 0.0, 0.0, 1.0]); root[0, A, 7:] = 0
+    _, _, con = e.debug_dynamics(0, 0)
+    hit = [cc for cc in con if cc[0] == 0 and cc[1] == 2 and cc[2] == A]
+    # (the golden-section search stops within 0.05 % of the segment: the separation is flat there, the normal within a milliradian)
+    assert len(hit) == 1 and abs(hit[0][4] - 0.004) < 2e-5 and np.allclose(hit[0][5:8], nrm, atol=2e-3), (con, nrm)
+    # (b) the box's vertical edge (x = -hx, y = +hy ... chosen by position) against the trunk's +y side face, mid-length
+    c0, _, _ = _prim_world(m, 0, base)
+    hy0 = m["prim_half"][0][1]
+    line = np.array([c0[0], c0[1] + hy0 + 0.003])          # where the vertical edge stands (x, y)
+    # the box turned by 45 degrees about z: its (-x, -y) vertical edge points at the trunk like a wedge, the faces recede at 45 degrees
+    root[0, A, :3] = torch.tensor([line[0], line[1] + h[0] * np.sqrt(2.0), float(base[2])], dtype=torch.float32)
+    root[0, A, 3:7] = torch.tensor([0.0, 0.0, np.sin(np.pi / 8), np.cos(np.pi / 8)], dtype=torch.float32)
+    _, _, con = e.debug_dynamics(0, 0)
+    hit = [cc for cc in con if cc[0] == 0 and cc[1] == 0 and cc[2] == A]
+    assert len(hit) == 1 and abs(hit[0][4] - 0.003) < 2e-5 and np.allclose(hit[0][5:8], [0, -1, 0], atol=1e-3), con

@@ -225,6 +225,69 @@ def test_box_corner_contacts_match_oracle(solver):
     close(eh.tensor(abi.T_ROOT_STATE)[..., :7], eo.tensor(abi.T_ROOT_STATE)[..., :7], atol=2e-4, what="poses after 8 substeps")
 
 
+def test_edge_contacts_match_oracle():
+    """edge contacts (round 4; include/mqe_hip.h edge_contacts bits 1 and 2): robots scattered around the gate posts at every yaw -- post
+    corners against the sides of trunks, heads and legs -- and robots leaning over the free box's edges: the contact lists of the two
+    engines are identical (ids and order exact, separations 5e-5, normals 2e-2 where the golden-section search ends on a flat stretch), some
+    contact is an edge contact, and a substep agrees."""
+    for task, N in (("go1gate", 96), ("go1pushbox", 48), ("go1seesaw", 32)):
+        eh, eo, d = _pair(task, N)
+        eh.reset_all(); eo.reset_all()
+        torch.cuda.synchronize()
+        ro, do = eo.tensor(abi.T_ROOT_STATE), eo.tensor(abi.T_DOF_STATE)
+        g = torch.Generator().manual_seed(21)
+        A = 2
+        yaw = torch.rand(N, A, generator=g) * 6.283
+        ro[:, :A, 3] = 0; ro[:, :A, 4] = 0; ro[:, :A, 5] = torch.sin(yaw / 2); ro[:, :A, 6] = torch.cos(yaw / 2)
+        if task == "go1gate":
+            gate = torch.tensor(np.ctypeslib.as_array(d.gate_pos, shape=(N, 2)).copy())
+            eo_ = torch.tensor(np.ctypeslib.as_array(d.env_origins, shape=(N, 3)).copy())
+            centre = eo_[:, :2] + gate                      # the gate's middle in the world; the posts stand +-0.29 m beside it
+            for a in range(A):
+                ro[:, a, 0] = centre[:, 0] + (torch.rand(N, generator=g) - 0.5) * 0.5
+                ro[:, a, 1] = centre[:, 1] + (1 if a else -1) * (0.29 + 0.05 + torch.rand(N, generator=g) * 0.12)
+                ro[:, a, 2] = 0.30 + torch.rand(N, generator=g) * 0.05
+        elif task == "go1pushbox":
+            box = ro[:, A, :3].clone()
+            ro[:, A, 2] = d.ground_z + d.npc_box_half[2]
+            ro[:, A, 5] = 0.3827; ro[:, A, 6] = 0.9239                               # the box turned by 45 degrees: its vertical edges point outwards
+            for a in range(A):                                                       # robot 0 at the +x edge, robot 1 at the -x edge
+                sx = 1.0 if a == 0 else -1.0
+                ro[:, a, 0] = box[:, 0] + sx * (d.npc_box_half[0] * 1.4142 + 0.02 + torch.rand(N, generator=g) * 0.2)
+                ro[:, a, 1] = box[:, 1] + (torch.rand(N, generator=g) - 0.5) * 0.4
+                ro[:, a, 2] = 0.31
+        else:
+            hinge = ro[:, A, :3].clone()
+            for a in range(A):
+                ro[:, a, 0] = hinge[:, 0] - 2.4 + (torch.rand(N, generator=g) - 0.5) * 3.0
+                ro[:, a, 1] = hinge[:, 1] + (1 if a else -1) * (0.5 + 0.02 + torch.rand(N, generator=g) * 0.1)      # beside the plank's long edges
+                ro[:, a, 2] = 0.545 + 0.05 + torch.rand(N, generator=g) * 0.2
+        ro[:, :, 7:] = 0; do[..., 1] = 0
+        do[:, :12 * A, 0] += (torch.rand(N, 12 * A, generator=g) - 0.5) * 0.6
+        eh.tensor(abi.T_ROOT_STATE).copy_(ro.cuda()); eh.tensor(abi.T_DOF_STATE).copy_(do.cuda())
+        eh.tensor(abi.T_TORQUES).zero_(); eo.tensor(abi.T_TORQUES).zero_()
+        d0, k0, _ = make_desc(task, N, edge_contacts=0)           # the same scene without edge contacts: what they add
+        e0 = oracle_engine(d0, k0)
+        e0.reset_all()
+        e0.tensor(abi.T_ROOT_STATE).copy_(ro); e0.tensor(abi.T_DOF_STATE).copy_(do)
+        edges = 0
+        for env in range(N):
+            _, ch = eh.debug_dynamics(env, 0)
+            _, _, co = eo.debug_dynamics(env, 0)
+            assert ch.shape == co.shape and (ch[:, :4] == co[:, :4]).all(), (task, env, ch[:, :5], co[:, :5])
+            close(ch[:, 4], co[:, 4], atol=5e-5, what="contact separation")
+            # (an edge contact's normal: where the separation is flat along the axis to the rounding of the distance function -- 1e-6 m at
+            # 3 m from the origin -- the search may stop anywhere within sqrt(2 d 1e-6) = 0.2 mm, i.e. 1e-2 rad at d = 2 cm)
+            close(ch[:, 5:], co[:, 5:], atol=2e-2, what="contact normal")
+            edges += len(co) - len(e0.debug_dynamics(env, 0)[2])
+        assert edges >= N // 16, (task, edges)                    # the scatter does produce edge contacts
+        eh.simulate(); eo.simulate()
+        torch.cuda.synchronize()
+        err = (eh.tensor(abi.T_ROOT_STATE)[..., :7].cpu() - eo.tensor(abi.T_ROOT_STATE)[..., :7]).abs().reshape(N, -1).max(dim=1).values
+        assert int((err > 5e-5).sum()) <= max(1, N // 30) and float(err.max()) < 5e-3, (task, err.topk(3))
+        _record("edge_contacts", {"task": task, "N": N, "contacts_on_links_without_feature_points": edges})
+
+
 def _record(kind, obj):
     """measured deviations, appended to gpurun_out/test_measurements.jsonl when that directory exists (what the bounds are set from)"""
     import json
