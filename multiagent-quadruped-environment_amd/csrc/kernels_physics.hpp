@@ -895,7 +895,23 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     // world"): lane = primitive of the lane's robot; per primitive the deepest of the nearest vertical wall edge and the scenery boxes.
     // Computed first, ranked behind the robot's feature contacts below.
     bool eflag = false; float esd = 1e3f; V3 en = v3(0, 0, 1), epa = v3(0, 0, 0); int ebody = 0, erep = 0;
-    if (rob && m->edge_mask != 0 && ((m->edge_mask & 1) != 0 && m->wall_corner != nullptr || (m->edge_mask & 2) != 0 && shp.n_static > 0)) {
+    bool edge_pass = rob && (m->edge_mask & 2) != 0 && shp.n_static > 0;
+    if (rob && !edge_pass && (m->edge_mask & 1) != 0 && m->wall_corner != nullptr) {
+      // is any robot of the pass within reach of a wall edge at all?  One look-up per robot (its base's raster point): no primitive
+      // reaches farther from the base than feature_reach, so a corner beyond that + the margin of the map's nearest-of-four choice is out
+      const int l = lane - sub * nsr, r = pass * rpp + sub;
+      bool nearw = false;
+      if (l == 0 && r < A) {
+        const V3 pbase = ld3(lds + L.body + r * MQE_NBODY * BODY_STRIDE + B_P);
+        int ix = (int)floorf(pbase.x / m->hs + 0.5f), iy = (int)floorf(pbase.y / m->hs + 0.5f);
+        ix = min(max(ix, 0), m->sdf_nx - 1); iy = min(max(iy, 0), m->sdf_ny - 1);
+        const float2 cc = reinterpret_cast<const float2*>(m->wall_corner)[(size_t)ix * m->sdf_ny + iy];
+        const float dx = pbase.x - cc.x, dy = pbase.y - cc.y, rr = 2.0f * rm.feature_reach + 0.1f;
+        nearw = dx * dx + dy * dy < rr * rr;
+      }
+      edge_pass = gballot(nearw) != 0ull;
+    }
+    if (edge_pass) {
       const int l = lane - sub * nsr, r = pass * rpp + sub;
       const bool isp = l >= 0 && l < npr && r < A && rm.prim_type[l < npr ? (l < 0 ? 0 : l) : 0] != MQE_PRIM_SPHERE;
       const int q = isp ? l : 0;
