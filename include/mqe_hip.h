@@ -325,6 +325,19 @@ int mqe_post_decimation_step(mqe_sim* s, int dec_i, void* stream);
 /* post_physics_step (legged_robot_field.py:117-119 -> legged_robot.py:117-157) incl. termination, NPC script,
  * in-kernel reset, compute_observations, and the task wrapper's observation / reward */
 int mqe_post_physics_step(mqe_sim* s, void* stream);
+/* The same in the stages the reference's method has (legged_robot.py:117-157), for a host that runs code of its own between them -- a
+ * subclass's check_termination / _step_npc / reset_idx / compute_observations: any OR of
+ *   MQE_POST_FRAME    episode counter, body-frame velocities, gravity, gait clock, the wrapper's copy of the NPC rows (:126-139) and the
+ *                     default check_termination (:159-169, legged_robot_field.py:121-146) -> MQE_T_RESET_BUF & co;
+ *   MQE_POST_NPC      the task's NPC script (:146: the sheep's flocking walk);
+ *   MQE_POST_RESET    reset_idx of the envs whose MQE_T_RESET_BUF is set WHEN THIS STAGE RUNS (:147-148), terrain curriculum included;
+ *   MQE_POST_OBS      compute_observations, last_actions, last_dof_vel (:149-152);
+ *   MQE_POST_WRAPPER  the task wrapper's observation / reward and the periodic push; the step counter advances with this stage.
+ * Stages of one call run in this order; mqe_post_physics_step == MQE_POST_ALL in one launch (the staged form is a plain
+ * thread-per-env kernel per call: bit-identical results, not the fast path). */
+enum { MQE_POST_FRAME = 1, MQE_POST_NPC = 2, MQE_POST_RESET = 4, MQE_POST_OBS = 8, MQE_POST_WRAPPER = 16, MQE_POST_ALL = 31,
+       MQE_POST_WRAPPER_LEVEL = 32 };   /* modifier of MQE_POST_WRAPPER: the call comes from a task wrapper's step() (go1tug re-poses its slider then) */
+int mqe_post_physics_stage(mqe_sim* s, int stages, void* stream);
 /* task wrapper observation + reward only (mqe/envs/wrappers/go1_<task>_wrapper.py step()/reset() bodies) from the current contents of
  * MQE_T_OBS_BAG, MQE_T_ROOT_STATE (NPC rows), the termination flags and MQE_T_SHEEP_POS_*; part of
  * mqe_post_physics_step / mqe_reset_all, exposed separately so the wrappers can be checked against golden vectors */

@@ -1054,6 +1054,110 @@ __global__ void k_reset_history(const DevModel* m, DevState st) {
   }
 }
 
+// post_physics_step in the stages the reference's method has (include/mqe_hip.h mqe_post_physics_stage; oracle: post_stages): one thread
+// per env, the per-env device functions of the fused kernel in the same arithmetic -- the results are bit for bit those of k_post_physics.
+// Not the fast path: it exists so that a subclass's check_termination / _step_npc / reset_idx / compute_observations can run in between.
+__global__ void __launch_bounds__(64) k_post_staged(const DevModel* m, DevState st, int stages, int wrapper_level, int push_count, int step_no) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= m->N) return;
+  const int A = m->A, P = m->P;
+  float* root = st.root + (size_t)e * (A + P) * 13;
+  float* npc_pre = st.npc_pre + (size_t)e * (P ? P : 1) * 13;
+  const float dtp = m->dt * (float)m->decimation;
+  if (stages & MQE_POST_FRAME) {
+    const int ep = st.ep_len[e] + 1;
+    unsigned fl = 0;
+    for (int a = 0; a < A; a++) {
+      const int i = e * A + a;
+      float rs[13];
+      for (int k = 0; k < 13; k++) rs[k] = root[a * 13 + k];
+      const float q[4] = {rs[3], rs[4], rs[5], rs[6]}, v[3] = {rs[7], rs[8], rs[9]}, w[3] = {rs[10], rs[11], rs[12]};
+      const float g3[3] = {0.0f, 0.0f, -1.0f};
+      float lv[3], av[3], pgr[3], clk[4];
+      quat_rotate_inverse_f(q, v, lv);
+      quat_rotate_inverse_f(q, w, av);
+      quat_rotate_inverse_f(q, g3, pgr);
+      const float* lo = st.loco_obs + (size_t)i * MQE_FRAME;
+      const float f = lo[7], ph = lo[8], off = lo[9], bnd = lo[10], dur = lo[11];
+      float gi = st.gait[i] + dtp * f;
+      gi = gi - floorf(gi);
+      float fi[4] = {gi + ph + off + bnd, gi + off, gi + bnd, gi + ph};
+      for (int k = 0; k < 4; k++) {
+        const float r = fi[k] - floorf(fi[k]);
+        if (r < dur) fi[k] = r * (0.5f / dur);
+        else if (r > dur) fi[k] = 0.5f + (r - dur) * (0.5f / (1.0f - dur));
+        clk[k] = sinf(6.2831855f * fi[k]);
+      }
+      const float* f3 = st.cf + ((size_t)e * m->NBR + a * MQE_NREP) * 3;
+      if (m->terminate_on_base_contact && sqrtf(f3[0] * f3[0] + f3[1] * f3[1] + f3[2] * f3[2]) > 1.0f) fl |= 1u;
+      float rpy[3];
+      euler_xyz_f(q, rpy);
+      float r = rpy[0], p = rpy[1];
+      if (r > 3.1415927f) r -= 6.2831855f;
+      if (p > 3.1415927f) p -= 6.2831855f;
+      const float z = rs[2] - m->agent_origins[(size_t)i * 3 + 2];
+      if ((m->termination_flags & MQE_TERM_ROLL) && fabsf(r) > m->roll_thr) fl |= 2u;
+      if ((m->termination_flags & MQE_TERM_PITCH) && fabsf(p) > m->pitch_thr) fl |= 4u;
+      if ((m->termination_flags & MQE_TERM_Z_HIGH) && z > m->zhigh_thr) fl |= 8u;
+      if ((m->termination_flags & MQE_TERM_Z_LOW) && z < m->zlow_thr) fl |= 16u;
+      for (int k = 0; k < 3; k++) { st.blv[i * 3 + k] = lv[k]; st.bav[i * 3 + k] = av[k]; st.pg[i * 3 + k] = pgr[k]; }
+      for (int k = 0; k < 4; k++) { st.bquat[i * 4 + k] = q[k]; st.clock[i * 4 + k] = clk[k]; }
+      st.gait[i] = gi;
+    }
+    const uint8_t to = ep > m->max_episode_length, reset = (uint8_t)(fl != 0 || to);
+    st.ep_len[e] = ep;
+    st.time_out[e] = to;
+    if (m->termination_flags & MQE_TERM_ROLL) st.r_term[e] = (fl >> 1) & 1;
+    if (m->termination_flags & MQE_TERM_PITCH) st.p_term[e] = (fl >> 2) & 1;
+    if (m->termination_flags & MQE_TERM_Z_HIGH) st.zh_term[e] = (fl >> 3) & 1;
+    st.reset_buf[e] = reset;
+    st.wdone[e] = reset;
+    if (m->terminate_on_base_contact) st.collide_buf[e] = reset;
+    for (int k = 0; k < P * 13; k++) npc_pre[k] = root[A * 13 + k];       // the wrapper's copy of the NPC rows, before the NPC script (legged_robot.py:136)
+  }
+  if ((stages & MQE_POST_NPC) && m->npc_kind == MQE_NPC_SHEEP) {
+    float avg[3], dvs[MQE_MAX_NPCS][3];
+    sheep_flock_mean(m, root, avg);
+    sheep_flock_stats(m, st, e, root, avg);
+    for (int p = 0; p < P; p++) sheep_increment(m, st, e, p, root, avg, step_no, dvs[p]);    // every increment from the pre-update flock
+    for (int p = 0; p < P; p++) sheep_apply(root, A, p, dvs[p]);
+  }
+  if (stages & MQE_POST_RESET) {
+    const uint8_t reset = st.reset_buf[e];       // as it stands NOW: a subclass's check_termination may have changed it since FRAME
+    st.wdone[e] = reset;
+    if (reset) {
+      reset_env_dev(m, st, e);
+      for (int k = 0; k < P * 13; k++) npc_pre[k] = root[A * 13 + k];
+      if (P == 0)
+        for (int a = 0; a < A; a++) for (int k = 0; k < 4; k++) st.bquat[(e * A + a) * 4 + k] = root[a * 13 + 3 + k];
+      // go1.py:145: the history of the env's robots (the f32 ring and, when present, its compact f16 planes)
+      float4* h4 = reinterpret_cast<float4*>(st.hist) + (size_t)e * A * (MQE_HIST * MQE_FRAME / 4);
+      for (int k = 0; k < A * (MQE_HIST * MQE_FRAME / 4); k++) h4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (st.hist2) {
+        uint4* p4 = reinterpret_cast<uint4*>(st.hist2 + (size_t)e * A * (2 * MQE_HIST * MQE_H2_FRAME));
+        for (int k = 0; k < A * (2 * MQE_HIST * MQE_H2_FRAME / 8); k++) p4[k] = make_uint4(0u, 0u, 0u, 0u);
+        for (int a = 0; a < A; a++) st.hist_irr[(size_t)e * A + a] = 0u;
+      }
+    }
+  }
+  if (stages & MQE_POST_OBS) {
+    compute_observations_env(m, st, e, 1);
+    for (int k = 0; k < 12 * A; k++) {
+      st.last_actions[(size_t)e * 12 * A + k] = st.actions[(size_t)e * 12 * A + k];
+      st.last_dof_vel[(size_t)e * 12 * A + k] = st.dof[((size_t)e * m->ND + k) * 2 + 1];
+    }
+  }
+  if (stages & MQE_POST_WRAPPER) {
+    wrapper_env_dev(m, st, e, 0, npc_pre, wrapper_level);
+    if (push_count > 0 && !st.reset_buf[e])
+      for (int b = 0; b < A; b++) {
+        float* rv = root + b * 13 + 7;
+        rv[0] = mqe_rand(m, e, (int)(MQE_RNG_PUSH + (uint32_t)push_count), (uint32_t)(2 * b), -m->max_push, m->max_push);
+        rv[1] = mqe_rand(m, e, (int)(MQE_RNG_PUSH + (uint32_t)push_count), (uint32_t)(2 * b + 1), -m->max_push, m->max_push);
+      }
+  }
+}
+
 __global__ void __launch_bounds__(64) k_reset_all(const DevModel* m, DevState st, int no_post_step_yet) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= m->N) return;

@@ -77,6 +77,7 @@ struct DevState {
   uint32_t* hist_irr;                       // [R] bit s: the frame in ring slot s does not continue its predecessor's actions (MQE_H2_FRAME)
   int32_t *ep_len, *reset_count;
   uint8_t *reset_buf, *collide_buf, *time_out, *r_term, *p_term, *zh_term, *w_have_last, *w_delayed_reset;
+  float* npc_pre;                           // [N][P][13] the wrapper's copy of the NPC rows (staged post-physics path only)
   float *env_origins_live, *curr_xy;        // MQE_T_ENV_ORIGINS [N][3]; pre-reset xy of the agents' root-state rows 0 .. N-1 (terrain curriculum)
   int32_t* terrain_levels;                  // MQE_T_TERRAIN_LEVELS [N]
   uint8_t* wdone;         // the reset flags once more, as the byte tail of the packed return batch (obs | reward | done)

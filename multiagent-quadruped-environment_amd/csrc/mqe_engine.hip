@@ -497,7 +497,7 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   DA(st.sub_tau, (size_t)N * 4 * 12 * A); DA(st.npc_noise, (size_t)N * (P ? P : 1) * 3);
   DA(st.w_last, (size_t)N * MQE_MAX_AGENTS); DA(st.w_last2, (size_t)N * 2); DA(st.cmd, (size_t)R * 3);
   DA(st.ep_len, N); DA(st.reset_count, N); DA(st.last_dof_vel, (size_t)R * 12);
-  DA(st.env_origins_live, (size_t)N * 3); DA(st.curr_xy, (size_t)N * 2); DA(st.terrain_levels, N);
+  DA(st.env_origins_live, (size_t)N * 3); DA(st.curr_xy, (size_t)N * 2); DA(st.terrain_levels, N); DA(st.npc_pre, (size_t)N * (P ? P : 1) * 13);
   if (hipMemcpy(st.env_origins_live, d->env_origins, (size_t)N * 12, hipMemcpyHostToDevice) != hipSuccess) return fail(-5, "upload");
   if (d->terrain_curriculum && hipMemcpy(st.terrain_levels, d->terrain_levels, (size_t)N * 4, hipMemcpyHostToDevice) != hipSuccess) return fail(-5, "upload");
   // domain parameters (include/mqe_hip.h): drawn once, keyed by the global env id so that a sharded run sees the same robots
@@ -881,6 +881,18 @@ extern "C" int mqe_post_decimation_step(mqe_sim* s, int dec_i, void* stream) {
 extern "C" int mqe_post_physics_step(mqe_sim* s, void* stream) {
   if (!s) return fail(-1, "null engine handle");
   launch_post(s, (hipStream_t)stream, 0);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+extern "C" int mqe_post_physics_stage(mqe_sim* s, int stages, void* stream) {
+  if (!s) return fail(-1, "null engine handle");
+  if ((stages & ~(MQE_POST_ALL | MQE_POST_WRAPPER_LEVEL)) != 0 || (stages & MQE_POST_ALL) == 0) return fail(-2, "mqe_post_physics_stage: stages must be an OR of MQE_POST_*");
+  hipStream_t q = (hipStream_t)stream;
+  const int step_no = s->n_post_steps + 1;           // = common_step_counter after its increment (legged_robot.py:127), the same for every stage of the step
+  const int push = (s->d.push_interval > 0 && step_no % s->d.push_interval == 0) ? (int)(step_no / s->d.push_interval) : 0;
+  if ((stages & MQE_POST_RESET) && s->hm.curriculum) hipLaunchKernelGGL(k_curriculum_snapshot, dim3((s->N + 255) / 256), dim3(256), 0, q, s->dm, s->st);
+  hipLaunchKernelGGL(k_post_staged, dim3((s->N + 63) / 64), dim3(64), 0, q, s->dm, s->st, stages & MQE_POST_ALL, (stages & MQE_POST_WRAPPER_LEVEL) ? 1 : 0, push, step_no);
+  if (stages & MQE_POST_WRAPPER) s->n_post_steps++;
   HIPCHK(hipGetLastError());
   return 0;
 }

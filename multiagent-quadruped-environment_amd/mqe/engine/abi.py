@@ -13,6 +13,7 @@ TASK = dict(plain=0, gate=1, sheep=2, seesaw=3, football_defender=4, pushbox=5, 
 NPC = dict(none=0, ball=1, sheep=2, seesaw=3, box=4, rotation=3, bridge=5, wrestling=5, circular=3)     # the revolving door shares the seesaw's fixed-base + 1-dof-link structure
 CTRL = dict(C=0, P=1, V=2, T=3)
 TERM = dict(roll=1, pitch=2, z_low=4, z_high=8)
+POST_FRAME, POST_NPC, POST_RESET, POST_OBS, POST_WRAPPER, POST_ALL, POST_WRAPPER_LEVEL = 1, 2, 4, 8, 16, 31, 32      # mqe_post_physics_stage
 
 (T_ROOT_STATE, T_DOF_STATE, T_CONTACT_FORCE, T_TORQUES, T_ACTIONS, T_LAST_ACTIONS, T_LOCOMOTION_OBS, T_HISTORY,
  T_LAST_LOCO_ACTION, T_LAST_TWO_LOCO_ACTION, T_ACT_HIST, T_GAIT_INDICES, T_CLOCK_INPUTS, T_BASE_LIN_VEL,

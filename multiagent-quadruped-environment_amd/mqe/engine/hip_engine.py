@@ -41,7 +41,7 @@ class HipEngine(EngineBase):
         lib = self.lib
         vp = C.c_void_p
         for name, args in (("policy_step", [vp, vp, vp]), ("compute_torques", [vp, vp]), ("simulate", [vp, vp]),
-                           ("post_decimation_step", [vp, C.c_int, vp]), ("post_physics_step", [vp, vp]),
+                           ("post_decimation_step", [vp, C.c_int, vp]), ("post_physics_step", [vp, vp]), ("post_physics_stage", [vp, C.c_int, vp]),
                            ("reset_all", [vp, vp]), ("step", [vp, vp, vp]), ("step_begin", [vp, vp, vp]), ("step_end", [vp, vp]), ("step_head", [vp, vp, vp]), ("step_tail", [vp, vp]), ("set_return_buffer", [vp, vp]), ("step_joint", [vp, vp, vp]), ("step_command", [vp, vp, vp]), ("defender_command", [vp, vp, vp]),
                            ("wrapper_eval", [vp, C.c_int, vp]),
                            ("debug_dynamics", [vp, C.c_int, C.c_int, vp, C.POINTER(C.c_int), vp]),
@@ -76,6 +76,10 @@ class HipEngine(EngineBase):
 
     def post_physics_step(self):
         self._call("post_physics_step", self._stream())
+
+    def post_physics_stage(self, stages):
+        """mqe_post_physics_stage: an OR of abi.POST_* (post_physics_step in the stages the reference's method has)"""
+        self._call("post_physics_stage", int(stages), self._stream())
 
     def reset_all(self):
         self._call("reset_all", self._stream())

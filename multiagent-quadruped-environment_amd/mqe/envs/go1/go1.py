@@ -271,13 +271,14 @@ class Go1:
         return self.obs_buf
 
     # ---- plugin points of the reference's class stack ----------------------------------------------------------------------------
-    # The reference lets a subclass of LeggedRobot / Go1 replace pieces of the step (legged_robot.py:368-392 `_compute_torques`,
-    # :202-219 `compute_reward`, :153-157 `_post_physics_step_callback`).  Here those pieces run inside the engine; a subclass that
-    # OVERRIDES one of the three methods below is honoured on the Go1-level path: `step()` then runs the decimation loop unfused and
-    # calls the override where the reference calls it (torques: written into the live `torques` view before every `simulate`).
-    # Not overridable: `check_termination`, `reset_idx`, `_step_npc`, `compute_observations` -- termination, the in-kernel reset and
-    # the NPC scripts are one kernel (`k_post_physics`); a task that needs other rules is a new task kind in the engine.  The fused
-    # wrapper-level step (`step_fused`, what the task wrappers call) refuses to run with overrides in place.
+    # The reference lets a subclass of LeggedRobot / Go1 replace pieces of the step: `_compute_torques` (legged_robot.py:368-392),
+    # `_post_physics_step_callback` (:153-157), `check_termination` (:159-169), `compute_reward` (:202-219), `_step_npc` (:146, the NPC
+    # tasks' scripts), `reset_idx` (:171-200) and `compute_observations` (go1.py:153-196).  Here those pieces run inside the engine; a
+    # subclass that OVERRIDES any of the methods below is honoured on the Go1-level path: `step()` then runs the decimation loop unfused
+    # and the post-physics step in the reference's stages (mqe_post_physics_stage), calling each override where the reference calls it.
+    # The engine's own piece has already run when an override is entered (so `super().check_termination()` etc. are no-ops that keep
+    # the reference's call pattern working), except `_step_npc`: an override REPLACES the engine's script, as a subclass's does upstream.
+    # The fused wrapper-level step (`step_fused`, what the task wrappers call) refuses to run with overrides in place.
     def _compute_torques(self, actions):
         """(N, 12 A) joint-space actions -> (N, 12 A) torques.  Default: the engine's law for cfg.control.control_type."""
         return None
@@ -286,14 +287,32 @@ class Go1:
         """fill self.rew_buf (legged_robot.py:202-219); Go1 registers no reward functions (go1.py:198-219): zeros"""
 
     def _post_physics_step_callback(self):
-        """after the engine's post-physics step (legged_robot.py:153-157)"""
+        """after the frame quantities, before check_termination (legged_robot.py:141, :153-157; go1.py:221-238: the gait clock, in the engine)"""
+
+    def check_termination(self):
+        """legged_robot.py:159-169 + legged_robot_field.py:121-146, evaluated by the engine before an override is called: reset_buf,
+        time_out_buf, collide_buf, r/p/z term buffers hold this step's flags; an override edits them in place (`self.reset_buf |= ...`)"""
+
+    def _step_npc(self):
+        """the task's NPC script (legged_robot.py:146; go1_sheep.py:35-64 in the engine).  An override replaces it: it moves
+        `root_states_npc` (a live view of the engine's root-state tensor)"""
+
+    def reset_idx(self, env_ids):
+        """legged_robot.py:171-200 / go1.py:110-145, done by the engine (in-kernel) for the envs whose reset_buf is set when the stage
+        runs; an override is called afterwards with those env ids, like a subclass that calls super().reset_idx(env_ids) first"""
+
+    def compute_observations(self):
+        """go1.py:153-196: the engine fills obs_buf; an override runs afterwards and may add to / edit it"""
+
+    _PLUGIN_POINTS = ("_compute_torques", "compute_reward", "_post_physics_step_callback", "check_termination", "_step_npc", "reset_idx",
+                      "compute_observations")
 
     def _overridden(self, name):
         return getattr(type(self), name) is not getattr(Go1, name)
 
     @property
     def has_overrides(self):
-        return any(self._overridden(n) for n in ("_compute_torques", "compute_reward", "_post_physics_step_callback"))
+        return any(self._overridden(n) for n in self._PLUGIN_POINTS)
 
     def _decimation_loop(self):
         e = self.engine
@@ -305,12 +324,27 @@ class Go1:
                 e.compute_torques()
             e.simulate()
             e.post_decimation_step(dec_i)
-        e.post_physics_step()
+        # post_physics_step in the reference's order (legged_robot.py:117-157): frame quantities -> callback -> check_termination ->
+        # compute_reward -> _step_npc -> reset_idx -> compute_observations
+        e.post_physics_stage(abi.POST_FRAME)
         self.common_step_counter += 1
         if self._overridden("_post_physics_step_callback"):
             self._post_physics_step_callback()
+        if self._overridden("check_termination"):
+            self.check_termination()
         if self._overridden("compute_reward"):
             self.compute_reward()
+        if self._overridden("_step_npc"):
+            self._step_npc()
+        else:
+            e.post_physics_stage(abi.POST_NPC)
+        e.post_physics_stage(abi.POST_RESET)
+        if self._overridden("reset_idx"):
+            self.reset_idx(self.reset_buf.nonzero(as_tuple=False).flatten())
+        e.post_physics_stage(abi.POST_OBS)
+        if self._overridden("compute_observations"):
+            self.compute_observations()
+        e.post_physics_stage(abi.POST_WRAPPER)
 
     def step(self, action):
         """One policy step from already-scaled commands (go1.py:35-62); action: (N*A, 3) or (N, A, 3)."""

@@ -66,6 +66,7 @@ typedef struct mqo_sim {
   float* wall_top;                  /* per-cell wall top (walls of different heights), or NULL */
   float* wall_corner;               /* per raster point the (x, y) of the nearest convex corner of the wall set, or NULL (edge contacts) */
   float *env_origins, *agent_origins, *base_init, *npc_init, *gate_pos;
+  float* pre_npc;                   /* [N][P][13] the wrapper's copy of the NPC rows, taken before the NPC script (legged_robot.py:136) */
   float *env_origins_live, *terrain_origins, *curr_xy;   /* terrain curriculum: MQE_T_ENV_ORIGINS, the origin table, pre-reset xy of the robot rows */
   int32_t *terrain_levels, *terrain_types;
   /* state */
@@ -1688,11 +1689,19 @@ static void wrapper_env(mqo_sim* s, int e, int is_reset_call, const float* pre_n
 static inline float div_ieee(float a, float b) { return b != 0.0f ? a / b : (a > 0.0f ? 3.0e38f : (a < 0.0f ? -3.0e38f : 0.0f)); }
 static inline float atan_ratio(float a, float b) { return b != 0.0f ? atanf(a / b) : (a > 0.0f ? 1.5707964f : (a < 0.0f ? -1.5707964f : 0.0f)); }
 
-int mqo_post_physics_step(mqo_sim* s) {
+/* post_physics_step in the stages the reference's own method has (legged_robot.py:117-157), so that a subclass's check_termination /
+ * _step_npc / reset_idx / compute_observations can run between them (include/mqe_hip.h mqe_post_physics_stage): FRAME = episode counter,
+ * body-frame quantities, gait clock, the wrapper's copy of the NPC rows (:126-139) + the default check_termination (:159-169, field:121-146);
+ * NPC = the task's NPC script (:146); RESET = reset_idx of the envs whose reset_buf is set NOW (:147-148); OBS = compute_observations +
+ * last_actions / last_dof_vel (:149-152); WRAPPER = the task wrapper's observation / reward + the periodic push; the step counter
+ * advances with it.  mqo_post_physics_step = all of them. */
+static int post_stages(mqo_sim* s, int stages) {
   const mqe_sim_desc* d = &s->d;
   int N = s->N, A = s->A, P = s->P;
   float dtp = d->dt * (float)d->decimation;     /* self.dt = decimation * sim dt (legged_robot.py:1014) */
-  curriculum_snapshot(s);
+  if (P && !s->pre_npc) s->pre_npc = (float*)malloc((size_t)N * P * 13 * 4);
+  float* pre_npc = P ? s->pre_npc : NULL;
+  if (stages & MQE_POST_FRAME)
   for (int e = 0; e < N; e++) {
     float* root = s->root + (size_t)e * (A + P) * 13;
     s->ep_len[e] += 1;                                                           /* legged_robot.py:126 */
@@ -1751,39 +1760,48 @@ int mqo_post_physics_step(mqo_sim* s) {
     s->wdone[e] = (uint8_t)reset;
     /* reset_buf aliases collide_buf when contact termination is on (legged_robot.py:165) */
     if (d->terminate_on_base_contact) s->collide_buf[e] = reset;
+    /* the wrapper's view of root_states_npc: the copy taken before the NPC script (:136) */
+    if (P) memcpy(pre_npc + (size_t)e * P * 13, s->root + ((size_t)e * (A + P) + A) * 13, (size_t)P * 13 * 4);
   }
   /* NPC script before resets (legged_robot.py:146), sees this step's post-physics states */
-  float* pre_npc = NULL;
-  if (P) {
-    pre_npc = (float*)malloc((size_t)N * P * 13 * 4);
-    for (int e = 0; e < N; e++) memcpy(pre_npc + (size_t)e * P * 13, s->root + ((size_t)e * (A + P) + A) * 13, (size_t)P * 13 * 4);
-  }
-  if (d->npc_kind == MQE_NPC_SHEEP) for (int e = 0; e < N; e++) step_sheep_env(s, e);
+  if ((stages & MQE_POST_NPC) && d->npc_kind == MQE_NPC_SHEEP) for (int e = 0; e < N; e++) step_sheep_env(s, e);
+  if (stages & MQE_POST_RESET) curriculum_snapshot(s);
   for (int e = 0; e < N; e++) {
-    if (s->reset_buf[e]) {
-      reset_env(s, e);                                                            /* :148 */
-      if (P) memcpy(pre_npc + (size_t)e * P * 13, s->root + ((size_t)e * (A + P) + A) * 13, (size_t)P * 13 * 4);
-      if (P == 0) /* root_states is a live view when there are no NPCs: base_quat shows the post-reset value */
-        for (int a = 0; a < A; a++) for (int k = 0; k < 4; k++) s->bquat[(e * A + a) * 4 + k] = s->root[((size_t)e * A + a) * 13 + 3 + k];
+    if (stages & MQE_POST_RESET) {
+      s->wdone[e] = s->reset_buf[e];            /* (a subclass's check_termination may have changed the flag since FRAME) */
+      if (s->reset_buf[e]) {
+        reset_env(s, e);                                                            /* :148 */
+        if (P) memcpy(pre_npc + (size_t)e * P * 13, s->root + ((size_t)e * (A + P) + A) * 13, (size_t)P * 13 * 4);
+        if (P == 0) /* root_states is a live view when there are no NPCs: base_quat shows the post-reset value */
+          for (int a = 0; a < A; a++) for (int k = 0; k < 4; k++) s->bquat[(e * A + a) * 4 + k] = s->root[((size_t)e * A + a) * 13 + 3 + k];
+      }
     }
-    compute_observations_env(s, e, 1);                                            /* :149 */
-    for (int k = 0; k < 12 * A; k++) s->last_actions[(size_t)e * 12 * A + k] = s->actions[(size_t)e * 12 * A + k];  /* :151 */
-    for (int k = 0; k < 12 * A; k++) s->last_dof_vel[(size_t)e * 12 * A + k] = s->dof[((size_t)e * s->ND + k) * 2 + 1];    /* :152 */
-    wrapper_env(s, e, 0, pre_npc ? pre_npc + (size_t)e * P * 13 : NULL);
-    /* _push_robots (go1.py:237, legged_robot.py:470-476): after this step's frame quantities were taken, before reset_idx,
-     * whose base velocities replace the push in the envs that reset; one draw per robot */
-    if (d->push_interval > 0 && (s->n_post_steps + 1) % d->push_interval == 0 && !s->reset_buf[e]) {
-      uint32_t cnt = 0x50000000u + (uint32_t)((s->n_post_steps + 1) / d->push_interval);
-      for (int a = 0; a < A; a++)
-        for (int c = 0; c < 2; c++)
-          s->root[((size_t)e * (A + P) + a) * 13 + 7 + c] =
-              2 * d->max_push_vel_xy * mqo_u01((uint32_t)d->seed, (uint32_t)(e + d->env_id_offset), cnt, (uint32_t)(2 * a + c)) + -d->max_push_vel_xy;
+    if (stages & MQE_POST_OBS) {
+      compute_observations_env(s, e, 1);                                            /* :149 */
+      for (int k = 0; k < 12 * A; k++) s->last_actions[(size_t)e * 12 * A + k] = s->actions[(size_t)e * 12 * A + k];  /* :151 */
+      for (int k = 0; k < 12 * A; k++) s->last_dof_vel[(size_t)e * 12 * A + k] = s->dof[((size_t)e * s->ND + k) * 2 + 1];    /* :152 */
+    }
+    if (stages & MQE_POST_WRAPPER) {
+      const int keep = s->wrapper_side_effects;
+      if (stages & MQE_POST_WRAPPER_LEVEL) s->wrapper_side_effects = 1;
+      wrapper_env(s, e, 0, pre_npc ? pre_npc + (size_t)e * P * 13 : NULL);
+      s->wrapper_side_effects = keep;
+      /* _push_robots (go1.py:237, legged_robot.py:470-476): after this step's frame quantities were taken, before reset_idx,
+       * whose base velocities replace the push in the envs that reset; one draw per robot */
+      if (d->push_interval > 0 && (s->n_post_steps + 1) % d->push_interval == 0 && !s->reset_buf[e]) {
+        uint32_t cnt = 0x50000000u + (uint32_t)((s->n_post_steps + 1) / d->push_interval);
+        for (int a = 0; a < A; a++)
+          for (int c = 0; c < 2; c++)
+            s->root[((size_t)e * (A + P) + a) * 13 + 7 + c] =
+                2 * d->max_push_vel_xy * mqo_u01((uint32_t)d->seed, (uint32_t)(e + d->env_id_offset), cnt, (uint32_t)(2 * a + c)) + -d->max_push_vel_xy;
+      }
     }
   }
-  free(pre_npc);
-  s->n_post_steps++;
+  if (stages & MQE_POST_WRAPPER) s->n_post_steps++;
   return 0;
 }
+int mqo_post_physics_step(mqo_sim* s) { return post_stages(s, MQE_POST_ALL); }
+int mqo_post_physics_stage(mqo_sim* s, int stages) { return post_stages(s, stages); }
 
 int mqo_reset_all(mqo_sim* s) { /* Go1.reset go1.py:147-151 + wrapper.reset() */
   curriculum_snapshot(s);

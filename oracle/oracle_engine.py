@@ -44,7 +44,7 @@ class OracleEngine(EngineBase):
         super().__init__(load_library(f64), desc, keepalive)
         vp = C.c_void_p
         for name, args in (("policy_step", [vp, vp]), ("compute_torques", [vp]), ("simulate", [vp]),
-                           ("post_decimation_step", [vp, C.c_int]), ("post_physics_step", [vp]),
+                           ("post_decimation_step", [vp, C.c_int]), ("post_physics_step", [vp]), ("post_physics_stage", [vp, C.c_int]),
                            ("reset_all", [vp]), ("step", [vp, vp]), ("step_joint", [vp, vp]), ("hist_pos", [vp]), ("wrapper_eval", [vp, C.c_int])):
             f = getattr(self.lib, "mqo_" + name)
             f.argtypes, f.restype = args, C.c_int
@@ -70,6 +70,9 @@ class OracleEngine(EngineBase):
 
     def post_physics_step(self):
         self._call("post_physics_step")
+
+    def post_physics_stage(self, stages):
+        self._call("post_physics_stage", int(stages))
 
     def reset_all(self):
         self._call("reset_all")

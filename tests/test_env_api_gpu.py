@@ -416,3 +416,9 @@ def test_terrain_curriculum_moves_envs_on_the_hip_engine():
         env.close()
     finally:
         ENV_DICT["go1pushbox"]["config"] = base
+
+
+def test_termination_npc_reset_and_observation_overrides_on_the_hip_engine():
+    """check_termination / _step_npc / reset_idx / compute_observations of a Go1 subclass, on the HIP engine (mqe_post_physics_stage)"""
+    from test_env_api import _plugin_points_check
+    _plugin_points_check(args_for, "cuda")

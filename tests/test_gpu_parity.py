@@ -288,6 +288,35 @@ def test_edge_contacts_match_oracle():
         _record("edge_contacts", {"task": task, "N": N, "contacts_on_links_without_feature_points": edges})
 
 
+@pytest.mark.parametrize("task", ["go1sheep-hard", "go1pushbox", "go1gate"])
+def test_staged_post_physics_is_the_single_launch(task):
+    """the five stages of mqe_post_physics_stage (k_post_staged: a thread per env) in sequence == mqe_post_physics_step (k_post_physics, the
+    fused kernel), BIT FOR BIT: NPC script, in-kernel resets with history zeroing, observations, wrapper, over 9 steps with time-outs"""
+    N = 70
+    engs = []
+    for _ in range(2):
+        d, k, _c = make_desc(task, N, max_episode_length=4)
+        e = hip_engine(d, k); e.reset_all(); engs.append(e)
+    g = torch.Generator().manual_seed(0)
+    for t in range(9):
+        cmd = (torch.rand(N * 2, 3, generator=g) * 2 - 1).cuda()
+        for i, e in enumerate(engs):
+            e.policy_step(cmd)
+            for k_ in range(4):
+                e.compute_torques(); e.simulate(); e.post_decimation_step(k_)
+            if i == 0:
+                e.post_physics_step()
+            else:
+                for st in (abi.POST_FRAME, abi.POST_NPC, abi.POST_RESET, abi.POST_OBS, abi.POST_WRAPPER):
+                    e.post_physics_stage(st)
+        torch.cuda.synchronize()
+        for kind in (abi.T_ROOT_STATE, abi.T_DOF_STATE, abi.T_OBS_BAG, abi.T_WRAPPER_OBS, abi.T_WRAPPER_REWARD, abi.T_RESET_BUF, abi.T_EPISODE_LENGTH,
+                     abi.T_HISTORY, abi.T_GAIT_INDICES, abi.T_CLOCK_INPUTS, abi.T_BASE_LIN_VEL, abi.T_LAST_ACTIONS, abi.T_REWARD_SUMS):
+            a, b = engs[0].tensor(kind), engs[1].tensor(kind)
+            assert torch.equal(a.view(torch.uint8) if a.dtype != torch.float32 else a.view(torch.int32), b.view(torch.uint8) if b.dtype != torch.float32 else b.view(torch.int32)), (task, t, kind)
+    assert int(engs[0].tensor(abi.T_RESET_COUNT).sum()) > N
+
+
 def _record(kind, obj):
     """measured deviations, appended to gpurun_out/test_measurements.jsonl when that directory exists (what the bounds are set from)"""
     import json
