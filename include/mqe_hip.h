@@ -334,7 +334,7 @@ int mqe_post_physics_step(mqe_sim* s, void* stream);
  *   MQE_POST_OBS      compute_observations, last_actions, last_dof_vel (:149-152);
  *   MQE_POST_WRAPPER  the task wrapper's observation / reward and the periodic push; the step counter advances with this stage.
  * Stages of one call run in this order; mqe_post_physics_step == MQE_POST_ALL in one launch (the staged form is a plain
- * thread-per-env kernel per call: bit-identical results, not the fast path). */
+ * thread-per-env kernel per call: the same arithmetic -- results equal to the last bit or two -- not the fast path). */
 enum { MQE_POST_FRAME = 1, MQE_POST_NPC = 2, MQE_POST_RESET = 4, MQE_POST_OBS = 8, MQE_POST_WRAPPER = 16, MQE_POST_ALL = 31,
        MQE_POST_WRAPPER_LEVEL = 32 };   /* modifier of MQE_POST_WRAPPER: the call comes from a task wrapper's step() (go1tug re-poses its slider then) */
 int mqe_post_physics_stage(mqe_sim* s, int stages, void* stream);

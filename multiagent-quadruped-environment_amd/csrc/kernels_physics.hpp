@@ -2353,8 +2353,10 @@ template <int TP> struct SubstepsClass {
                                           // 12-44 registers with everything hoisted; laundered they need 136-154 and none: -4 % kernel time)
 #endif
 };
+// the post-physics step as this kernel's epilogue (kernels_step.hpp post_body): on = 0 leaves it to its own launch
+struct PostArgs { int on, wrapper_level, push_count, step_no; };
 template <int TA, int TP, int EPW = 1>
-__global__ void __launch_bounds__(64, EPW == 2 ? 2 : SubstepsClass<TP>::waves) k_substeps(const DevModel* __restrict__ m, DevState st, int nsub, int lag_pos) {
+__global__ void __launch_bounds__(64, EPW == 2 ? 2 : SubstepsClass<TP>::waves) k_substeps(const DevModel* __restrict__ m, DevState st, int nsub, int lag_pos, PostArgs pa) {
   extern __shared__ float lds_wave[];
   // EPW = 2 (phys_substep): the two halves of the wavefront run envs 2 b and 2 b + 1; `lane` / `lds` / `e` below are the group's.
   // 2048 wavefronts for 4096 envs = 2 per SIMD with the whole register file each: nothing is laundered, everything invariant
@@ -2525,5 +2527,23 @@ __global__ void __launch_bounds__(64, EPW == 2 ? 2 : SubstepsClass<TP>::waves) k
       const int w = i / nj, jt = i - w * nj;
       st.act_hist[(size_t)w * R12 + (size_t)e * nj + jt] = acth[i];
     }
+  if constexpr (TP == 0 && !(TA == 2 && EPW == 2)) if (pa.on) {      // (robot-only scenes: with NPC / link code in the same kernel the 128-register classes spill)
+    // ---- post_physics_step of this wavefront's env(s) (legged_robot.py:117-157 + the task wrapper), from the state just written: the
+    // writer and the readers are lanes of this one wavefront (one CU, one vector L1), a workgroup-scope fence orders them
+    __threadfence_block();
+    __syncthreads();
+    constexpr int AMP = (TA == 1 || TA == 2) ? 2 : MQE_MAX_AGENTS;
+    // LDS: root and joint states are still where the physics kept them (L.root, L.dof of each env's layout); the staging rows of the
+    // post step go into the dead torque / bias / history area behind them ... no: into the link-record area (L.body .. : dead since the sweep)
+    float* sb = lds_wave + L.body;                           // obs rows, last-action rows, NPC rows, the env's actions: < 500 floats of the >= 832 there
+    float* act_l = sb + EPW * AMP * (MQE_OBS_BAG + 24) + EPW * MQE_MAX_NPCS * 13;
+    for (int i = lane_wave; i < EPW * nj; i += 64) {          // the wavefront's actions, one coalesced load
+      const int ge = i / nj, jt = i - ge * nj;
+      if (e_first + ge < m->N) act_l[ge * nj + jt] = st.actions[(size_t)(e_first + ge) * nj + jt];
+    }
+    __syncthreads();
+    post_body<AMP, EPW>(m, st, (int)blockIdx.x, lane_wave, sb, sb + EPW * AMP * MQE_OBS_BAG, sb + EPW * AMP * (MQE_OBS_BAG + 24), pa.wrapper_level, pa.push_count, pa.step_no,
+                        lds_wave + L.root, lds_wave + L.dof, act_l, L.total, nj);
+  }
   if (st.wave_times && lane_wave == 0) st.wave_times[4 * blockIdx.x + 1] = (long long)wall_clock64();
 }

@@ -813,30 +813,32 @@ __device__ void wrapper_env_dev(const DevModel* m, const DevState& st, int e, in
 #endif
 
 // One block's rows of a [R][W] tensor (contiguous for the block's consecutive envs) from LDS to HBM, 16 B per lane.
-__device__ __forceinline__ void post_flush_rows(float* __restrict__ g, const float* lds, const int n) {
+__device__ __forceinline__ void post_flush_rows(float* __restrict__ g, const float* lds, const int n, const int tid) {
   const int n4 = n >> 2;
-  for (int i = threadIdx.x; i < n4; i += 64) reinterpret_cast<float4*>(g)[i] = reinterpret_cast<const float4*>(lds)[i];
-  for (int i = (n4 << 2) + threadIdx.x; i < n; i += 64) g[i] = lds[i];
+  for (int i = tid; i < n4; i += 64) reinterpret_cast<float4*>(g)[i] = reinterpret_cast<const float4*>(lds)[i];
+  for (int i = (n4 << 2) + tid; i < n; i += 64) g[i] = lds[i];
 }
 
-// AM: compile-time bound of the agent lanes (>= m->A; 2 for the two-robot tasks, MQE_MAX_AGENTS otherwise)
-template <int AM>
-__global__ void __launch_bounds__(64) k_post_physics(const DevModel* m, DevState st, int wrapper_level, int push_count, int step_no) {
-  static_assert(POST_EPW * AM <= 64 && (POST_EPW & (POST_EPW - 1)) == 0, "agent lanes of POST_EPW envs must fit one wavefront");
-  // The per-robot rows this block produces (obs bag 74, last action 12, last dof velocity 12) are contiguous in HBM over
-  // the block's envs: the robot lanes write them to LDS (the wrapper reads the obs rows back from there, not through L2)
-  // and the whole wavefront stores them 16 B per lane.
-  __shared__ float4 s_bag4[POST_EPW * AM * MQE_OBS_BAG / 4], s_la4[POST_EPW * AM * 24 / 4];
-  __shared__ float s_npc[POST_EPW * MQE_MAX_NPCS * 13];
-  float* s_bag = reinterpret_cast<float*>(s_bag4);
-  float* s_la = reinterpret_cast<float*>(s_la4);
+// The body of the post-physics step for ONE wavefront that serves PEPW consecutive envs (blk = their group's index): the stand-alone
+// kernel k_post_physics runs it with PEPW = POST_EPW and static LDS; the fused decimation kernel k_substeps runs it as its epilogue
+// with PEPW = its envs per wavefront and the physics' dead LDS (mqe_step: one launch less and no second pass over the state).
+// AM: compile-time bound of the agent lanes (>= m->A; 2 for the two-robot tasks, MQE_MAX_AGENTS otherwise); tid = lane;
+// s_bag / s_la / s_npc: LDS of PEPW * AM * 74, PEPW * AM * 24 and PEPW * MQE_MAX_NPCS * 13 floats, 16 B aligned.
+// root_l / dof_l / act_l (fused epilogue only, else nullptr): the env's root rows, joint states and actions in LDS -- [PEPW] x ([A + P][13],
+// [ND][2], [12 A]) at the given strides -- so that the robot lanes' 49 scattered global loads become LDS reads (in the epilogue every
+// wavefront has 2 active lanes per vector-memory instruction: 8 x the instructions of the stand-alone kernel for the same bytes).
+template <int AM, int PEPW>
+__device__ __forceinline__ void post_body(const DevModel* m, const DevState& st, const int blk, const int tid, float* s_bag, float* s_la, float* s_npc,
+                                          int wrapper_level, int push_count, int step_no,
+                                          const float* root_l = nullptr, const float* dof_l = nullptr, const float* act_l = nullptr, int lds_env_stride = 0, int act_env_stride = 0) {
+  static_assert(PEPW * AM <= 64 && (PEPW & (PEPW - 1)) == 0, "agent lanes of PEPW envs must fit one wavefront");
   const int A = m->A, P = m->P;
-  const int le = threadIdx.x & (POST_EPW - 1), a = threadIdx.x / POST_EPW;
-  const int e = blockIdx.x * POST_EPW + le;
+  const int le = tid & (PEPW - 1), a = tid / PEPW;
+  const int e = blk * PEPW + le;
   const bool mine = e < m->N && a < A;          // this lane's robot exists
   const bool lead = e < m->N && a == 0;         // this lane does its env's env-level work
   const int i = e * A + a;
-  const int nrow = min(POST_EPW, m->N - blockIdx.x * POST_EPW) * A;   // robots of this block
+  const int nrow = min(PEPW, m->N - blk * PEPW) * A;   // robots of this block
   const float dtp = m->dt * (float)m->decimation;
   float* root = st.root + (size_t)e * (A + P) * 13;
   float* bag = s_bag + le * A * MQE_OBS_BAG;    // this env's rows, agent-major like the tensor
@@ -848,8 +850,9 @@ __global__ void __launch_bounds__(64) k_post_physics(const DevModel* m, DevState
     ep = st.ep_len[e] + 1;
 #pragma unroll
     for (int k = 0; k < 3; k++) eo[k] = m->env_origins[e * 3 + k];
+    const float* root_src = root_l != nullptr ? root_l + le * lds_env_stride : root;
 #pragma unroll
-    for (int k = 0; k < 13; k++) rs[k] = root[a * 13 + k];
+    for (int k = 0; k < 13; k++) rs[k] = root_src[a * 13 + k];
     const float* lo = st.loco_obs + (size_t)i * MQE_FRAME;
 #pragma unroll
     for (int k = 0; k < 5; k++) gpar[k] = lo[7 + k];
@@ -858,11 +861,12 @@ __global__ void __launch_bounds__(64) k_post_physics(const DevModel* m, DevState
 #pragma unroll
     for (int k = 0; k < 3; k++) f3[k] = cf3[k];
     aoz = m->agent_origins[(size_t)i * 3 + 2];
-    const float* ds = st.dof + ((size_t)e * m->ND + a * 12) * 2;
+    const float* ds = dof_l != nullptr ? dof_l + le * lds_env_stride + a * 24 : st.dof + ((size_t)e * m->ND + a * 12) * 2;
 #pragma unroll
     for (int k = 0; k < 24; k++) dq[k] = ds[k];
+    const float* as = act_l != nullptr ? act_l + le * act_env_stride + a * 12 : st.actions + (size_t)i * 12;
 #pragma unroll
-    for (int k = 0; k < 12; k++) act[k] = st.actions[(size_t)i * 12 + k];
+    for (int k = 0; k < 12; k++) act[k] = as[k];
   }
   // ---- body-frame quantities, gait clock, termination (registers only) ------------------------------------------------------
   float bq[4], lv[3], av[3], pgr[3], clk[4], gi1 = 0.f;
@@ -899,9 +903,9 @@ __global__ void __launch_bounds__(64) k_post_physics(const DevModel* m, DevState
     if ((m->termination_flags & MQE_TERM_Z_HIGH) && z > m->zhigh_thr) fl |= 8u;
     if ((m->termination_flags & MQE_TERM_Z_LOW) && z < m->zlow_thr) fl |= 16u;
   }
-  // any robot of the env: OR over the agent lanes (lane ^ POST_EPW, ^ 2 POST_EPW stay inside the POST_EPW * AM robot lanes)
+  // any robot of the env: OR over the agent lanes (lane ^ PEPW, ^ 2 PEPW stay inside the PEPW * AM robot lanes)
 #pragma unroll
-  for (int d = POST_EPW; d < POST_EPW * AM; d <<= 1) fl |= (unsigned)__shfl_xor((int)fl, d);
+  for (int d = PEPW; d < PEPW * AM; d <<= 1) fl |= (unsigned)__shfl_xor((int)fl, d);
   const uint8_t to = ep > m->max_episode_length, rterm = (fl >> 1) & 1, pterm = (fl >> 2) & 1, zh = (fl >> 3) & 1;
   const uint8_t reset = (uint8_t)(mine && (fl != 0 || to));       // the same value on all robot lanes of the env
   // ---- stores of the frame quantities and flags ------------------------------------------------------------------------------
@@ -926,15 +930,15 @@ __global__ void __launch_bounds__(64) k_post_physics(const DevModel* m, DevState
   // (staged in LDS by the whole wavefront: as a per-lane array of P * 13 floats it lived in scratch memory)
   float* npc_pre = s_npc + le * MQE_MAX_NPCS * 13;
   {
-    const int e0 = blockIdx.x * POST_EPW, nenv = min(POST_EPW, m->N - e0), per = P * 13;
-    for (int t = threadIdx.x; t < nenv * per; t += 64) {
+    const int e0 = blk * PEPW, nenv = min(PEPW, m->N - e0), per = P * 13;
+    for (int t = tid; t < nenv * per; t += 64) {
       const int sl = t / per, r = t - sl * per;
       s_npc[sl * MQE_MAX_NPCS * 13 + r] = st.root[((size_t)(e0 + sl) * (A + P) + A) * 13 + r];
     }
     __syncthreads();
   }
-  if (m->npc_kind == MQE_NPC_SHEEP) {           // wave-uniform.  The 64 / POST_EPW lanes of an env share its sheep (lane a: sheep a, a + 8, ..)
-    constexpr int LPE = 64 / POST_EPW, NPASS = (MQE_MAX_NPCS + LPE - 1) / LPE;
+  if (m->npc_kind == MQE_NPC_SHEEP) {           // wave-uniform.  The 64 / PEPW lanes of an env share its sheep (lane a: sheep a, a + 8, ..)
+    constexpr int LPE = 64 / PEPW, NPASS = (MQE_MAX_NPCS + LPE - 1) / LPE;
     float dvs[NPASS][3];
     if (e < m->N) {
       float avg[3];
@@ -991,7 +995,7 @@ __global__ void __launch_bounds__(64) k_post_physics(const DevModel* m, DevState
       ob[36 + j] = act[j];
       ob[48 + j] = act[j];
       la[a * 12 + j] = act[j];
-      la[POST_EPW * AM * 12 + a * 12 + j] = dq[2 * j + 1];             // legged_robot.py:152
+      la[PEPW * AM * 12 + a * 12 + j] = dq[2 * j + 1];             // legged_robot.py:152
     }
 #pragma unroll
     for (int k = 0; k < 3; k++) { ob[30 + k] = lv[k] * 2.0f; ob[33 + k] = av[k] * 0.25f; ob[60 + k] = pgr[k]; }
@@ -1014,10 +1018,10 @@ __global__ void __launch_bounds__(64) k_post_physics(const DevModel* m, DevState
       }
   }
   {
-    const size_t r0 = (size_t)blockIdx.x * POST_EPW * A;
-    post_flush_rows(st.obs_bag + r0 * MQE_OBS_BAG, s_bag, nrow * MQE_OBS_BAG);
-    post_flush_rows(st.last_actions + r0 * 12, s_la, nrow * 12);
-    post_flush_rows(st.last_dof_vel + r0 * 12, s_la + POST_EPW * AM * 12, nrow * 12);
+    const size_t r0 = (size_t)blk * PEPW * A;
+    post_flush_rows(st.obs_bag + r0 * MQE_OBS_BAG, s_bag, nrow * MQE_OBS_BAG, tid);
+    post_flush_rows(st.last_actions + r0 * 12, s_la, nrow * 12, tid);
+    post_flush_rows(st.last_dof_vel + r0 * 12, s_la + PEPW * AM * 12, nrow * 12, tid);
   }
   // go1.py:145: history[agent_ids] = 0 for the envs that reset this step -- rare, so the whole wavefront zeroes them,
   // 16 B per lane per request: the f32 ring and, when present, its two f16 planes
@@ -1025,17 +1029,27 @@ __global__ void __launch_bounds__(64) k_post_physics(const DevModel* m, DevState
   while (rm) {
     const int l = __ffsll((long long)rm) - 1;
     rm &= rm - 1;
-    const int er = blockIdx.x * POST_EPW + l;
+    const int er = blk * PEPW + l;
     const int per = m->A * (MQE_HIST * MQE_FRAME / 4);                 // float4 units of this env's robots (contiguous)
     float4* h4 = reinterpret_cast<float4*>(st.hist) + (size_t)er * per;
-    for (int k = threadIdx.x; k < per; k += 64) h4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = tid; k < per; k += 64) h4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (st.hist2) {                                                    // same robots, 2 planes interleaved: the same bytes
       uint4* p4 = reinterpret_cast<uint4*>(st.hist2 + (size_t)er * m->A * (2 * MQE_HIST * MQE_H2_FRAME));
       const int per2 = m->A * (2 * MQE_HIST * MQE_H2_FRAME / 8);
-      for (int k = threadIdx.x; k < per2; k += 64) p4[k] = make_uint4(0u, 0u, 0u, 0u);
-      if ((int)threadIdx.x < m->A) st.hist_irr[(size_t)er * m->A + threadIdx.x] = 0u;      // all frames zero: every frame continues its predecessor
+      for (int k = tid; k < per2; k += 64) p4[k] = make_uint4(0u, 0u, 0u, 0u);
+      if ((int)tid < m->A) st.hist_irr[(size_t)er * m->A + tid] = 0u;      // all frames zero: every frame continues its predecessor
     }
   }
+}
+
+template <int AM>
+__global__ void __launch_bounds__(64) k_post_physics(const DevModel* m, DevState st, int wrapper_level, int push_count, int step_no) {
+  // The per-robot rows this block produces (obs bag 74, last action 12, last dof velocity 12) are contiguous in HBM over
+  // the block's envs: the robot lanes write them to LDS (the wrapper reads the obs rows back from there, not through L2)
+  // and the whole wavefront stores them 16 B per lane.
+  __shared__ float4 s_bag4[POST_EPW * AM * MQE_OBS_BAG / 4], s_la4[POST_EPW * AM * 24 / 4];
+  __shared__ float s_npc[POST_EPW * MQE_MAX_NPCS * 13];
+  post_body<AM, POST_EPW>(m, st, blockIdx.x, threadIdx.x, reinterpret_cast<float*>(s_bag4), reinterpret_cast<float*>(s_la4), s_npc, wrapper_level, push_count, step_no);
 }
 
 // go1.py:145: history[agent_ids] = 0 for envs that reset this step.  One float4 per thread, R*540 threads.
@@ -1055,7 +1069,7 @@ __global__ void k_reset_history(const DevModel* m, DevState st) {
 }
 
 // post_physics_step in the stages the reference's method has (include/mqe_hip.h mqe_post_physics_stage; oracle: post_stages): one thread
-// per env, the per-env device functions of the fused kernel in the same arithmetic -- the results are bit for bit those of k_post_physics.
+// per env, the per-env device functions of the fused kernel in the same arithmetic (results equal k_post_physics' to the last bit or two).
 // Not the fast path: it exists so that a subclass's check_termination / _step_npc / reset_idx / compute_observations can run in between.
 __global__ void __launch_bounds__(64) k_post_staged(const DevModel* m, DevState st, int stages, int wrapper_level, int push_count, int step_no) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;

@@ -52,7 +52,7 @@ struct mqe_sim {
   void* tens[MQE_T_COUNT];
   int N, A, P, R, ND, NBR, Aw, D;
   int hist_pos = 0, n_post_steps = 0;
-  void (*substeps_fn)(const DevModel*, DevState, int, int) = nullptr;    // the k_substeps specialisation of this scene
+  void (*substeps_fn)(const DevModel*, DevState, int, int, PostArgs) = nullptr;    // the k_substeps specialisation of this scene
   int substeps_epw = 1;               // envs per wavefront of that kernel (2: two-robot scenes without objects at large batches)
   bool a2_scene = false;              // two robots, no objects: the scene k_simulate_a2 (phase taps) is compiled for
   int lag_pos = 0;                    // write slot of the action-lag ring (domain randomisation), advances per substep
@@ -68,6 +68,7 @@ struct mqe_sim {
   bool tail_fused = false;            // k_policy_tail: the reference network shapes (256-128-2 / 512-256-128-12 after layer 0)
   size_t phys_lds_bytes = 0;
   bool fuse_substeps = true;
+  bool fuse_post = true;              // the post-physics step as the epilogue of k_substeps (mqe_step & co; MQE_NO_FUSE_POST=1: its own launch)
   int dbg_stop_phase = -1;            // MQE_DEBUG_STOP_PHASE, read once at creation (tools/phase_counters.py)
   // profiling
   bool prof = false, prof_now = false;   // prof_now: this call is one of the sampled ones
@@ -185,7 +186,7 @@ static int finalize_frag(mqe_sim* s, GemmLayer* L) {
 
 // k_substeps is compiled for the env shapes of the shipped tasks (kernels_physics.hpp: PhysShape); everything else takes the
 // runtime form
-static void (*pick_substeps(const DevModel& m, size_t lds_bytes))(const DevModel*, DevState, int, int) {
+static void (*pick_substeps(const DevModel& m, size_t lds_bytes))(const DevModel*, DevState, int, int, PostArgs) {
   const int feat = (m.has_seesaw ? PS_F_LINK : 0) | (m.n_npc_dyn > 0 ? PS_F_NPC : 0) | (m.has_box ? PS_F_BOX : 0) | (m.n_static > 0 ? PS_F_STATIC : 0);
   // the small class (row sweep compiled in, 128 VGPRs, every env resident): <= 4 actors and 16 LDS footprints per CU
   if (m.rowgs && lds_bytes <= 10240) {                                       // (MQE_LANE_SWEEP=1 sends these scenes to the kernels below)
@@ -313,7 +314,7 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   if ((L.total | L.body | L.sph | L.prim | L.con | L.side | L.leg | L.legc | L.basei | L.sinv | L.fcol | L.acc | L.rhs | L.phi | L.srec | L.wacc) & 3) { return fail(-4, "physics LDS layout: a 16 B record area is misaligned"); }
   if (s->phys_lds_bytes > 160 * 1024) { return fail(-4, "physics LDS footprint exceeds 160 KiB"); }
   s->substeps_fn = pick_substeps(m, s->phys_lds_bytes);
-  s->a2_scene = s->substeps_fn == (void (*)(const DevModel*, DevState, int, int))k_substeps<2, 0>;
+  s->a2_scene = s->substeps_fn == (void (*)(const DevModel*, DevState, int, int, PostArgs))k_substeps<2, 0>;
   {
     // Two envs per wavefront (kernels_physics.hpp, EPW): for robot-only scenes of <= 2 robots each half-wave runs an env of its own --
     // 44 % fewer VALU instructions per env (the dynamics and sweep phases are shared, only contact generation runs per env), but half
@@ -322,15 +323,15 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
     // CU), and the two-env wavefront's chain is 1.5 x as long -- 2 of them per SIMD take what 4 one-env wavefronts take.  Kept as
     // a selectable, bit-identical variant (MQE_ENVS_PER_WAVE=1 / 2; tests hold the two forms against each other); the default for
     // single-robot scenes at full batches only (below).
-    const bool can = (s->substeps_fn == (void (*)(const DevModel*, DevState, int, int))k_substeps<2, 0> ||
-                      s->substeps_fn == (void (*)(const DevModel*, DevState, int, int))k_substeps<1, 0>) && 2 * s->phys_lds_bytes <= 64 * 1024 && d->robot.n_spheres <= 32;      // (a half-wave tests 32 feature points per pass)
+    const bool can = (s->substeps_fn == (void (*)(const DevModel*, DevState, int, int, PostArgs))k_substeps<2, 0> ||
+                      s->substeps_fn == (void (*)(const DevModel*, DevState, int, int, PostArgs))k_substeps<1, 0>) && 2 * s->phys_lds_bytes <= 64 * 1024 && d->robot.n_spheres <= 32;      // (a half-wave tests 32 feature points per pass)
     // measured (MI355X, k_substeps us, one / two envs per wavefront): go1gate (two robots per env) 4096 envs 122 / 128, 8192 envs 238 / 237;
     // go1plane (ONE robot per env: a pair is exactly the lane population of a go1gate wavefront) 4096 envs 108.8 / 85.6 -- the pairing
     // pays there once the batch fills the machine (4 one-env wavefronts per SIMD), so single-robot scenes of >= 4096 envs take it
     int want = (m.A == 1 && N >= 4096) ? 2 : 1;
     if (const char* ev = getenv("MQE_ENVS_PER_WAVE")) want = atoi(ev);
     if (can && want == 2) {
-      s->substeps_fn = m.A == 2 ? (void (*)(const DevModel*, DevState, int, int))k_substeps<2, 0, 2> : (void (*)(const DevModel*, DevState, int, int))k_substeps<1, 0, 2>;
+      s->substeps_fn = m.A == 2 ? (void (*)(const DevModel*, DevState, int, int, PostArgs))k_substeps<2, 0, 2> : (void (*)(const DevModel*, DevState, int, int, PostArgs))k_substeps<1, 0, 2>;
       s->substeps_epw = 2;
     }
   }
@@ -342,6 +343,11 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
       return fail(-4, "cannot raise dynamic LDS limit");
   }
   s->fuse_substeps = getenv("MQE_NO_FUSE_SUBSTEPS") == nullptr && d->decimation <= 4;
+  // the run-time terrain curriculum needs its snapshot launch between the physics and the resets: no epilogue fusion there
+  // ... and only the robot-only kernels k_substeps<1 | 2, 0, *> carry the epilogue (go1gate, go1plane)
+  s->fuse_post = s->fuse_substeps && getenv("MQE_NO_FUSE_POST") == nullptr && !m.curriculum &&
+                 (s->substeps_fn == (void (*)(const DevModel*, DevState, int, int, PostArgs))k_substeps<2, 0> || s->substeps_fn == (void (*)(const DevModel*, DevState, int, int, PostArgs))k_substeps<1, 0> ||
+                  s->substeps_fn == (void (*)(const DevModel*, DevState, int, int, PostArgs))k_substeps<1, 0, 2>);
   // Debug / experiment switches are read HERE, once per handle, never on the launch path; MQE_VERBOSE lists the ones in effect.
   if (const char* sp = getenv("MQE_DEBUG_STOP_PHASE")) {
     // per-phase counter runs: the wavefront leaves k_simulate_a2 after that phase tap WITHOUT writing the state back, so the
@@ -1012,8 +1018,19 @@ static int run_substeps_and_post(mqe_sim* s, hipStream_t q, int wrapper_level) {
   if (s->fuse_substeps) {
     // decimation loop in one launch: state stays in LDS; actuator net on MFMA (C) or the PD / torque law (P, V, T) inside the wavefront
     ProfScope ps(s, PROF_SIMULATE, q);
-    hipLaunchKernelGGL(s->substeps_fn, dim3((s->N + s->substeps_epw - 1) / s->substeps_epw), dim3(64), s->phys_lds_bytes * s->substeps_epw, q, s->dm, s->st, s->d.decimation, s->lag_pos);
+    PostArgs pa = {0, 0, 0, 0};
+    if (s->fuse_post) {                        // the post-physics step rides along as the kernel's epilogue (launch_post's bookkeeping here)
+      s->n_post_steps++;
+      pa.on = 1; pa.wrapper_level = wrapper_level; pa.step_no = s->n_post_steps;
+      pa.push_count = (s->d.push_interval > 0 && s->n_post_steps % s->d.push_interval == 0) ? (int)(s->n_post_steps / s->d.push_interval) : 0;
+    }
+    hipLaunchKernelGGL(s->substeps_fn, dim3((s->N + s->substeps_epw - 1) / s->substeps_epw), dim3(64), s->phys_lds_bytes * s->substeps_epw, q, s->dm, s->st, s->d.decimation, s->lag_pos, pa);
     advance_lag(s, s->d.decimation);
+    if (s->fuse_post) {
+      s->prof_now = s->prof;
+      HIPCHK(hipGetLastError());
+      return 0;
+    }
   } else {
     for (int k = 0; k < s->d.decimation; k++) {
       launch_torques(s, k < 4 ? k : 3, q);

