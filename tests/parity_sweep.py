@@ -43,5 +43,7 @@ for task in ENV_DICT:
     rec["seconds"] = round(time.time() - t0, 1)
     out[task] = rec
     print(task, json.dumps(rec))
+out["_config"] = {"contact_solver": os.environ.get("MQE_SOLVER", "tgs (default)"), "edge_contacts": os.environ.get("MQE_EDGE_CONTACTS", "3 (default)"),
+                  "collision_model": os.environ.get("MQE_COLLISION_MODEL", "capsule (default)")}
 if len(sys.argv) > 2:
     json.dump(out, open(sys.argv[2], "w"), indent=1)
