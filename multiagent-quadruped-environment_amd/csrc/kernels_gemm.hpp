@@ -159,17 +159,16 @@ struct Gemm2Args {
   // at logical positions p >= 1 (ring_pos = slot of the oldest frame).  irr may be null.
   const unsigned* irr; const float* ring; int ring_pos;
   const float* Wt32; int ldwt;                         // [frame * MQE_FRAME + column][ldwt] (GemmLayer::Wt)
+  int full_blocks, full_rows;                          // blocks that run full 128-row tiles and the rows they cover; the rest: half tiles
 };
-__global__ void __launch_bounds__(H2_THREADS, 1) k_gemm_h2(Gemm2Args g) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds2[];
+// One block tile: TA = 2 the full 128 x 192 tile, TA = 1 the HALF tile of 64 x 192 (multiplier waves 2 x 2 on 32 x 96 wave tiles, two
+// staging blocks of A; same LDS layout, same W tile, same epilogue) for the rows that do not fill a round of full tiles -- a round is
+// 256 / (N / 192) M-tiles = 8192 rows of layer 0, and a started round costs the same whether one tile or 256 of them run in it.
+template <int TA>
+__device__ __forceinline__ void gemm_h2_tile(const Gemm2Args& g, const int m0, const int n0, unsigned char* lds2) {
+  constexpr int HM = 64 * TA;                                   // rows of this block tile
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = (wave >> 1) & 1, wn = wave & 1;               // multiplier waves 0..3 as 2 x 2
-  const int ntn = g.N / H2_N, ntm = (g.M + H2_M - 1) / H2_M;
-  int bid = blockIdx.x;
-  const int total = ntn * ntm;
-  if ((total & 7) == 0) { const int xcd = bid & 7, slot = bid >> 3; bid = xcd * (total >> 3) + slot; }
-  const int tm = bid / ntn, tn = bid - tm * ntn;
-  const int m0 = tm * H2_M, n0 = tn * H2_N;
   f32x16 acc00, acc01, acc02, acc10, acc11, acc12;
 #pragma unroll
   for (int i = 0; i < 16; i++) { acc00[i] = 0.0f; acc01[i] = 0.0f; acc02[i] = 0.0f; acc10[i] = 0.0f; acc11[i] = 0.0f; acc12[i] = 0.0f; }
@@ -179,12 +178,13 @@ __global__ void __launch_bounds__(H2_THREADS, 1) k_gemm_h2(Gemm2Args g) {
   const int stid = tid & 255, srow = stid >> 3, sc = stid & 7, sj = sc >> 1, sp = sc & 1;
   const char* Abase = reinterpret_cast<const char*>(g.A);
   const char* Wbase = reinterpret_cast<const char*>(g.W) + (size_t)n0 * g.ldw * 2;
-  const unsigned a_row0 = (unsigned)min(m0 + srow, g.M - 1) * g.lda * 2, a_row1 = (unsigned)min(m0 + 32 + srow, g.M - 1) * g.lda * 2,
-                 a_row2 = (unsigned)min(m0 + 64 + srow, g.M - 1) * g.lda * 2, a_row3 = (unsigned)min(m0 + 96 + srow, g.M - 1) * g.lda * 2;
+  const unsigned a_row0 = (unsigned)min(m0 + srow, g.M - 1) * g.lda * 2, a_row1 = (unsigned)min(m0 + 32 + srow, g.M - 1) * g.lda * 2;
+  const unsigned a_row2 = TA == 2 ? (unsigned)min(m0 + 64 + srow, g.M - 1) * g.lda * 2 : 0u, a_row3 = TA == 2 ? (unsigned)min(m0 + 96 + srow, g.M - 1) * g.lda * 2 : 0u;
+  (void)a_row2; (void)a_row3;
   const unsigned w_row = (unsigned)srow * g.ldw * 2, w_row32 = 32u * g.ldw * 2;
   const unsigned st_ofs = sp * H2_PLANE + srow * H2_ROWB + sj * 16;
   const int frow = lane & 31, fk = (lane >> 5) * 16;           // fragment: row, byte offset of its 8 k inside a 16-k step
-  const unsigned fa_ofs = (wm * 64 + frow) * H2_ROWB + fk, fb_ofs = (H2_M + wn * 96 + frow) * H2_ROWB + fk;
+  const unsigned fa_ofs = (wm * 32 * TA + frow) * H2_ROWB + fk, fb_ofs = (H2_M + wn * 96 + frow) * H2_ROWB + fk;
   const int nkt = g.K / H2_K;                                   // multiple of 3
   // All blocks walk K in the same order on purpose: the 64 blocks that share a W tile then touch the same window of W at
   // about the same time and it stays L2-resident.  (Rotating the k order per M-tile, which cured an L2-channel hot spot
@@ -216,7 +216,11 @@ __global__ void __launch_bounds__(H2_THREADS, 1) k_gemm_h2(Gemm2Args g) {
 #define H2_F16(x_) __builtin_bit_cast(f16x8, x_)
 #define H2_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x16_f16(H2_F16(a_), H2_F16(b_), c_, 0, 0, 0)
 #define H2_PIN() __builtin_amdgcn_sched_barrier(0)
+  if constexpr (TA == 2) {
 #include "kernels_gemm_h2_loop.inc"
+  } else {
+#include "kernels_gemm_h2_loop_half.inc"
+  }
 #undef H2_ADDR
 #undef H2_LDA
 #undef H2_LDW
@@ -232,12 +236,15 @@ __global__ void __launch_bounds__(H2_THREADS, 1) k_gemm_h2(Gemm2Args g) {
   float* ep = reinterpret_cast<float*>(lds2);
 #define H2_EPW(acc_, t_, u_)                                                                                    \
   _Pragma("unroll") for (int r = 0; r < 16; r++)                                                                \
-    ep[(wm * 64 + (t_) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * H2_EPS + wn * 96 + (u_) * 32 + (lane & 31)] = acc_[r];
-  if (wave < 4) { H2_EPW(acc00, 0, 0) H2_EPW(acc01, 0, 1) H2_EPW(acc02, 0, 2) H2_EPW(acc10, 1, 0) H2_EPW(acc11, 1, 1) H2_EPW(acc12, 1, 2) }
+    ep[(wm * 32 * TA + (t_) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * H2_EPS + wn * 96 + (u_) * 32 + (lane & 31)] = acc_[r];
+  if (wave < 4) {
+    H2_EPW(acc00, 0, 0) H2_EPW(acc01, 0, 1) H2_EPW(acc02, 0, 2)
+    if constexpr (TA == 2) { H2_EPW(acc10, 1, 0) H2_EPW(acc11, 1, 1) H2_EPW(acc12, 1, 2) }
+  }
 #undef H2_EPW
   __syncthreads();
 #pragma unroll 4
-  for (int it = 0; it < (H2_M * H2_N / 4) / H2_THREADS; it++) {
+  for (int it = 0; it < (HM * H2_N / 4) / H2_THREADS; it++) {
     const int i = it * H2_THREADS + tid, row = i / (H2_N / 4), c4 = i - row * (H2_N / 4);
     const int col = n0 + c4 * 4, grow = m0 + row;
     float4 v = *reinterpret_cast<const float4*>(ep + row * H2_EPS + c4 * 4);
@@ -269,5 +276,36 @@ __global__ void __launch_bounds__(H2_THREADS, 1) k_gemm_h2(Gemm2Args g) {
       v.z = v.z > 0 ? v.z : __expf(v.z) - 1.0f; v.w = v.w > 0 ? v.w : __expf(v.w) - 1.0f;
     }
     if (grow < g.M) *reinterpret_cast<float4*>(g.C + (size_t)grow * g.ldc + col) = v;
+  }
+}
+// k_gemm_h2: full tiles only (what the headline batch runs: 8192 rows = exactly one round).  k_gemm_h2_mix: blocks [0, full_blocks) run
+// full tiles over the rows [0, full_rows), the others half tiles over the rows behind them (launch_gemm2 picks the split: whole rounds
+// of full tiles, and a remainder of at most half a round as half tiles, which then fill twice the CUs at 0.63 of a full tile's time).
+// Two kernels because the one with both tile bodies allocates twice the registers and its full-tile path measured ~1 % slower.
+// The XCD-aware numbering is applied inside each part.
+__global__ void __launch_bounds__(H2_THREADS, 1) k_gemm_h2(Gemm2Args g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds2[];
+  const int ntn = g.N / H2_N, ntm = (g.M + H2_M - 1) / H2_M;
+  int bid = blockIdx.x;
+  const int total = ntn * ntm;
+  if ((total & 7) == 0) { const int xcd = bid & 7, slot = bid >> 3; bid = xcd * (total >> 3) + slot; }
+  const int tm = bid / ntn, tn = bid - tm * ntn;
+  gemm_h2_tile<2>(g, tm * H2_M, tn * H2_N, lds2);
+}
+__global__ void __launch_bounds__(H2_THREADS, 1) k_gemm_h2_mix(Gemm2Args g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds2[];
+  const int ntn = g.N / H2_N;
+  int bid = blockIdx.x;
+  if (bid < g.full_blocks) {
+    const int total = g.full_blocks;
+    if ((total & 7) == 0) { const int xcd = bid & 7, slot = bid >> 3; bid = xcd * (total >> 3) + slot; }
+    const int tm = bid / ntn, tn = bid - tm * ntn;
+    gemm_h2_tile<2>(g, tm * H2_M, tn * H2_N, lds2);
+  } else {
+    bid -= g.full_blocks;
+    const int total = (int)gridDim.x - g.full_blocks;
+    if ((total & 7) == 0) { const int xcd = bid & 7, slot = bid >> 3; bid = xcd * (total >> 3) + slot; }
+    const int tm = bid / ntn, tn = bid - tm * ntn;
+    gemm_h2_tile<1>(g, g.full_rows + tm * (H2_M / 2), tn * H2_N, lds2);
   }
 }

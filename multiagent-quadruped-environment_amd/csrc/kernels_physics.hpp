@@ -40,20 +40,17 @@ __device__ __forceinline__ V3 sym_vec(const float* S, V3 v) {
 }
 
 // value of the neighbouring lane through the DPP wave shifts of the VALU (a modifier of v_mov, no LDS crossbar round trip as
-// in ds_bpermute / __shfl): lane i reads lane i + 1 (wave_shl:1) resp. lane i - 1 (wave_shr:1); the end lanes keep their own value
-__device__ __forceinline__ float lane_next(float x) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x130, 0xF, 0xF, false));
+// in ds_bpermute / __shfl): lane i reads lane i + 1 (wave_shl:1) resp. lane i - 1 (wave_shr:1); the end lanes read zero (bound_ctrl: no
+// "old" value to keep, so no copy in front of the shift, and a value with a single consumer becomes that instruction's DPP operand)
+template <int CTRL> __device__ __forceinline__ float dpp_take(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
 }
-__device__ __forceinline__ float lane_prev(float x) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x138, 0xF, 0xF, false));
-}
+__device__ __forceinline__ float lane_next(float x) { return dpp_take<0x130>(x); }
+__device__ __forceinline__ float lane_prev(float x) { return dpp_take<0x138>(x); }
 
 // sum over the 16 lanes of a DPP row, delivered to every lane of the row: four butterfly steps (lane ^ 1, lane ^ 2 as quad
 // permutations, then the mirror inside each half row and inside the row).  Both partners of a step add the same two operands, so
 // all 16 lanes end with bitwise the same sum.
-template <int CTRL> __device__ __forceinline__ float dpp_take(float x) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
-}
 __device__ __forceinline__ float row16_sum(float x) {
   x += dpp_take<0xB1>(x);      // quad_perm [1,0,3,2]
   x += dpp_take<0x4E>(x);      // quad_perm [2,3,0,1]
@@ -523,10 +520,22 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     V3 no = nc + cross(rc, f);
     X[10] = no.x; X[11] = no.y; X[12] = no.z; X[13] = f.x; X[14] = f.y; X[15] = f.z;
   }
-#pragma unroll
-  for (int k = 0; k < 16; k++) { float t = lane_next(X[k]); if (depth == 2) X[k] += t; }
-#pragma unroll
-  for (int k = 0; k < 16; k++) { float t = lane_next(X[k]); if (depth == 1) X[k] += t; }
+  {
+    // thigh += calf, then hip += thigh: x + 1.0 * t rounds like x + t and x + 0.0 * t is x, so the lane's depth enters as a factor and each
+    // term is ONE instruction -- v_fmac_f32 with the wave shift (lane + 1; zero past the end) as the operand's DPP modifier -- instead of
+    // shift + add + select.  Written out: the compiler keeps the shift as a v_mov_dpp of its own.  (s_nop 1: a DPP operand must not have
+    // been written by the two instructions before; inside the block the second round reads what the first wrote 16 instructions earlier.)
+    const float on2 = depth == 2 ? 1.0f : 0.0f, on1 = depth == 1 ? 1.0f : 0.0f;
+#define MQE_FD(i, o) "v_fmac_f32_dpp %" #i ", %" #i ", %" #o " wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+#define MQE_FD16(o) MQE_FD(0, o) MQE_FD(1, o) MQE_FD(2, o) MQE_FD(3, o) MQE_FD(4, o) MQE_FD(5, o) MQE_FD(6, o) MQE_FD(7, o) \
+                    MQE_FD(8, o) MQE_FD(9, o) MQE_FD(10, o) MQE_FD(11, o) MQE_FD(12, o) MQE_FD(13, o) MQE_FD(14, o) MQE_FD(15, o)
+    asm volatile("s_nop 1\n\t" MQE_FD16(16) MQE_FD16(17)
+                 : "+v"(X[0]), "+v"(X[1]), "+v"(X[2]), "+v"(X[3]), "+v"(X[4]), "+v"(X[5]), "+v"(X[6]), "+v"(X[7]),
+                   "+v"(X[8]), "+v"(X[9]), "+v"(X[10]), "+v"(X[11]), "+v"(X[12]), "+v"(X[13]), "+v"(X[14]), "+v"(X[15])
+                 : "v"(on2), "v"(on1));
+#undef MQE_FD16
+#undef MQE_FD
+  }
   {
     // the four hip composites of a robot -> its base lane, through LDS (4 x 16 B stores per hip lane, 16 x 16 B loads per base
     // lane, in the joint-force-column area that is written further down): 20 LDS instructions instead of 64 ds_bpermute
@@ -2165,6 +2174,9 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
         if (i >= 1) { dv += Lm[1] * wl[1]; if (tgs) vo += Lm[1] * xl[1]; }
         if (i >= 2) { dv += Lm[2] * wl[2]; if (tgs) vo += Lm[2] * xl[2]; }
         const float* G = rec + LEG_G + i;
+        // (F w_b is recomputed by every joint lane on purpose: computed once per robot and shared through the LDS it is 60 VALU instructions
+        // less and one LDS round trip more, and the round trip is what costs -- A/B round 4: no gain at 4 wavefronts per SIMD, +2 % on the
+        // scenes that run at 2)
 #pragma unroll
         for (int nn = 0; nn < 6; nn++) {
           float dvb = 0.0f, vob = 0.0f;

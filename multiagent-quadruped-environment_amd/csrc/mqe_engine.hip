@@ -222,6 +222,19 @@ static int wrapper_dims(const mqe_sim_desc* d, int* Aw, int* D) {
   return 0;
 }
 
+// M-tiles of k_gemm_h2 for M rows and ntn column blocks: whole rounds of full tiles (a round = 256 / ntn M-tiles, one block per CU); the
+// remainder as full tiles too when it fills more than half a round, else as half tiles (MQE_GEMM_HALF=0: never).  A half tile costs a CU
+// ~0.6 of a full one, so a remainder of r <= half a round takes 0.6 of a round's time on 2 r tiles instead of a whole round on r.
+static void h2_tiling(int M, int ntn, int* full_tiles, int* half_tiles) {
+  static const bool use_half = getenv("MQE_GEMM_HALF") == nullptr || atoi(getenv("MQE_GEMM_HALF")) != 0;
+  const int ntm = (M + H2_M - 1) / H2_M, per_round = 256 / ntn > 0 ? 256 / ntn : 1;
+  const int rem = ntm % per_round;
+  *full_tiles = ntm; *half_tiles = 0;
+  if (use_half && rem != 0 && 2 * rem <= per_round) {
+    *full_tiles = ntm - rem;
+    *half_tiles = (M - *full_tiles * H2_M + H2_M / 2 - 1) / (H2_M / 2);
+  }
+}
 extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   if (!d || !out) return fail(-1, "null argument");
   if (d->abi_version != MQE_ABI_VERSION) return fail(-1, "abi version mismatch");
@@ -450,13 +463,17 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
     // started round of 256 tiles), the exact-f32 kernel scales linearly (255 us at R = 8192).  Pick the faster one for this
     // batch unless MQE_GEMM_SPLIT forces a choice.
     const char* f = getenv("MQE_GEMM_SPLIT");
-    const double rounds = std::ceil(((R + H2_M - 1) / H2_M) * (double)(s->l0.Npad / H2_N) / 256.0);
+    int ft = 0, ht = 0;
+    const int ntn0 = s->l0.Npad / H2_N > 0 ? s->l0.Npad / H2_N : 1;
+    h2_tiling(R, ntn0, &ft, &ht);
+    const double rounds = std::ceil(ft * (double)ntn0 / 256.0) + (ht ? 0.6 : 0.0);       // a (partial) round of half tiles: ~0.6 of a full one
     const bool faster = rounds * 80.0 < 255.0 * R / 8192.0;
     s->gemm_split = s->l0.Npad % H2_N == 0 && (f ? atoi(f) != 0 : faster) && !s->cmd_general;      // the compact operand folds entries 6-17 into its weights
   }
   if (s->gemm_split) {
     if (finalize_layer(s, &s->l0)) return fail(-5, "upload");
-    if (hipFuncSetAttribute((const void*)k_gemm_h2, hipFuncAttributeMaxDynamicSharedMemorySize, H2_LDS_BYTES) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)k_gemm_h2, hipFuncAttributeMaxDynamicSharedMemorySize, H2_LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_gemm_h2_mix, hipFuncAttributeMaxDynamicSharedMemorySize, H2_LDS_BYTES) != hipSuccess)
       return fail(-4, "cannot raise dynamic LDS limit");
   }
   for (int l = 1; l < ad.n_layers; l++) {
@@ -679,8 +696,12 @@ static void launch_gemm2(hipStream_t q, const uint16_t* A, int lda, int rot8, in
   g.W = L.W2; g.ldw = 2 * L.Kpad3; g.bias = L.bias;
   g.C = C; g.ldc = ldc; g.M = M; g.N = L.Npad; g.K = L.Kpad3; g.act_cols = act_cols;
   g.descale = 1.0f / (MQE_H2_ASCALE * L.wscale);
-  int grid = ((M + H2_M - 1) / H2_M) * (L.Npad / H2_N);
-  hipLaunchKernelGGL(k_gemm_h2, dim3(grid), dim3(H2_THREADS), H2_LDS_BYTES, q, g);
+  int full_tiles, half_tiles;
+  h2_tiling(M, L.Npad / H2_N, &full_tiles, &half_tiles);
+  g.full_blocks = full_tiles * (L.Npad / H2_N); g.full_rows = full_tiles * H2_M;
+  const int grid = (full_tiles + half_tiles) * (L.Npad / H2_N);
+  if (half_tiles == 0) hipLaunchKernelGGL(k_gemm_h2, dim3(grid), dim3(H2_THREADS), H2_LDS_BYTES, q, g);
+  else hipLaunchKernelGGL(k_gemm_h2_mix, dim3(grid), dim3(H2_THREADS), H2_LDS_BYTES, q, g);
 }
 
 static int policy_tail(mqe_sim* s, hipStream_t q);

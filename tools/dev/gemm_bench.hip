@@ -2,6 +2,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DH2_...] tools/dev/gemm_bench.hip -o gemm_bench && ./gemm_bench
 #include "../../multiagent-quadruped-environment_amd/csrc/kernels_gemm.hpp"
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <cmath>
 #include <vector>
@@ -44,8 +45,21 @@ int main(int argc, char** argv) {
   g.act_cols = argc > 4 ? atoi(argv[4]) : 256; g.descale = 1.0f / (MQE_H2_ASCALE * wscale);
   g.irr = nullptr; g.ring = nullptr; g.ring_pos = 0; g.Wt32 = nullptr; g.ldwt = 0;      // no compact-history residuals in the harness
   CK(hipFuncSetAttribute((const void*)k_gemm_h2, hipFuncAttributeMaxDynamicSharedMemorySize, H2_LDS_BYTES));
-  const int grid = ((M + H2_M - 1) / H2_M) * (N / H2_N);
-  hipLaunchKernelGGL(k_gemm_h2, dim3(grid), dim3(H2_THREADS), H2_LDS_BYTES, 0, g);
+  CK(hipFuncSetAttribute((const void*)k_gemm_h2_mix, hipFuncAttributeMaxDynamicSharedMemorySize, H2_LDS_BYTES));
+  // GEMM_MODE: "half" = every row in half tiles (64 x 192), "mix" = whole rounds of full tiles + a remainder of at most half a round as half tiles
+  // (the engine's rule, mqe_engine.hip::h2_tiling), default = full tiles only
+  const char* mode = getenv("GEMM_MODE") ? getenv("GEMM_MODE") : "full";
+  const int ntn = N / H2_N, ntm = (M + H2_M - 1) / H2_M, per_round = 256 / ntn;
+  int full_tiles = ntm, half_tiles = 0;
+  if (!strcmp(mode, "half")) { full_tiles = 0; half_tiles = (M + 63) / 64; }
+  else if (!strcmp(mode, "mix") && ntm % per_round != 0 && 2 * (ntm % per_round) <= per_round) {
+    full_tiles = ntm - ntm % per_round; half_tiles = (M - full_tiles * H2_M + 63) / 64;
+  }
+  g.full_blocks = full_tiles * ntn; g.full_rows = full_tiles * H2_M;
+  const int grid = (full_tiles + half_tiles) * ntn;
+  printf("mode %s: %d full + %d half M-tiles\n", mode, full_tiles, half_tiles);
+  auto KERNEL = half_tiles ? k_gemm_h2_mix : k_gemm_h2;
+  hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(H2_THREADS), H2_LDS_BYTES, 0, g);
   CK(hipDeviceSynchronize());
   std::vector<float> C((size_t)M * ldc);
   CK(hipMemcpy(C.data(), dC, C.size() * 4, hipMemcpyDeviceToHost));
@@ -60,9 +74,9 @@ int main(int argc, char** argv) {
     maxerr = std::max(maxerr, std::fabs(acc - (double)C[(size_t)r * ldc + c]));
   }
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int i = 0; i < 20; i++) hipLaunchKernelGGL(k_gemm_h2, dim3(grid), dim3(H2_THREADS), H2_LDS_BYTES, 0, g);
+  for (int i = 0; i < 20; i++) hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(H2_THREADS), H2_LDS_BYTES, 0, g);
   CK(hipEventRecord(e0, 0));
-  for (int i = 0; i < reps; i++) hipLaunchKernelGGL(k_gemm_h2, dim3(grid), dim3(H2_THREADS), H2_LDS_BYTES, 0, g);
+  for (int i = 0; i < reps; i++) hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(H2_THREADS), H2_LDS_BYTES, 0, g);
   CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   const double us = ms * 1e3 / reps;
