@@ -301,8 +301,8 @@ __host__ __device__ inline PhysLds phys_lds_layout(int A, int P, int ND, int nbo
 }
 
 struct PhysDebug { float* minv; int* nc; float* contacts; int robot; long long* times; int stop_after; };
-// phase tap: shader clock of lane 0 and, for per-phase counter runs (tools/phase_counters.py), an early exit of the whole wavefront
-#define TSTAMP(i) do { if (dbg.times != nullptr && lane == 0) dbg.times[i] = clock64(); if (dbg.stop_after == (i)) return; } while (0)
+// phase tap: the 100 MHz wall clock at lane 0 and, for per-phase counter runs (tools/phase_counters.py), an early exit of the whole wavefront
+#define TSTAMP(i) do { if (dbg.times != nullptr && lane == 0) dbg.times[i] = (long long)wall_clock64(); if (dbg.stop_after == (i)) return; } while (0)
 
 // flags of one physics substep executed by a wavefront
 enum { PS_LOAD_STATE = 1, PS_LOAD_TAU = 2, PS_STORE_STATE = 4, PS_WRITE_CF = 8 };
@@ -2367,7 +2367,10 @@ template <int TP> struct SubstepsClass {
 };
 // the post-physics step as this kernel's epilogue (kernels_step.hpp post_body): on = 0 leaves it to its own launch
 struct PostArgs { int on, wrapper_level, push_count, step_no; };
-template <int TA, int TP, int EPW = 1>
+// TIMED (MQE_PHASE_TIMES=1, tools/dev/phase_walltimes.py): the same kernel with the phase taps of phys_substep live -- every wavefront
+// writes the wall clock at the 15 taps of each of its substeps (+ [15]: the substep's end) behind the entry / exit stamps of
+// st.wave_times: where the time of a FULL launch goes, phase by phase, as opposed to the lone wavefront of tools/phase_times.py.
+template <int TA, int TP, int EPW = 1, bool TIMED = false>
 __global__ void __launch_bounds__(64, EPW == 2 ? 2 : SubstepsClass<TP>::waves) k_substeps(const DevModel* __restrict__ m, DevState st, int nsub, int lag_pos, PostArgs pa) {
   extern __shared__ float lds_wave[];
   // EPW = 2 (phys_substep): the two halves of the wavefront run envs 2 b and 2 b + 1; `lane` / `lds` / `e` below are the group's.
@@ -2522,6 +2525,12 @@ __global__ void __launch_bounds__(64, EPW == 2 ? 2 : SubstepsClass<TP>::waves) k
       }
     }
     __syncthreads();
+    if constexpr (TIMED) {
+      long long* tt = st.wave_times + 4 * (size_t)gridDim.x + ((size_t)blockIdx.x * 4 + (k < 4 ? k : 3)) * 16;
+      const PhysDebug tdbg = {nullptr, nullptr, nullptr, 0, tt, -1};
+      phys_substep<TA, TP, EPW>(mk, st, lds_wave, e_first, lane_k, last ? (PS_STORE_STATE | PS_WRITE_CF) : 0, 0, tdbg);
+      if (lane_wave == 0) tt[15] = (long long)wall_clock64();
+    } else
     phys_substep<TA, TP, EPW>(mk, st, lds_wave, e_first, lane_k, last ? (PS_STORE_STATE | PS_WRITE_CF) : 0, 0, nodbg);
     // post_decimation_step (legged_robot.py:114-115): joint velocities and soft-limit flags after this substep, from the LDS state
     if (evalid)

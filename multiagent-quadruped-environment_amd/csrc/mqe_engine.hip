@@ -328,6 +328,7 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   if (s->phys_lds_bytes > 160 * 1024) { return fail(-4, "physics LDS footprint exceeds 160 KiB"); }
   s->substeps_fn = pick_substeps(m, s->phys_lds_bytes);
   s->a2_scene = s->substeps_fn == (void (*)(const DevModel*, DevState, int, int, PostArgs))k_substeps<2, 0>;
+  const bool phase_timed = s->a2_scene && getenv("MQE_PHASE_TIMES") != nullptr;      // tools/dev/phase_walltimes.py: the same kernel with its phase taps live
   {
     // Two envs per wavefront (kernels_physics.hpp, EPW): for robot-only scenes of <= 2 robots each half-wave runs an env of its own --
     // 44 % fewer VALU instructions per env (the dynamics and sweep phases are shared, only contact generation runs per env), but half
@@ -355,11 +356,13 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
     if (lds_sub > 48 * 1024 && hipFuncSetAttribute((const void*)s->substeps_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sub) != hipSuccess)
       return fail(-4, "cannot raise dynamic LDS limit");
   }
+  if (phase_timed && s->substeps_epw == 1) s->substeps_fn = (void (*)(const DevModel*, DevState, int, int, PostArgs))k_substeps<2, 0, 1, true>;
   s->fuse_substeps = getenv("MQE_NO_FUSE_SUBSTEPS") == nullptr && d->decimation <= 4;
   // the run-time terrain curriculum needs its snapshot launch between the physics and the resets: no epilogue fusion there
   // ... and only the robot-only kernels k_substeps<1 | 2, 0, *> carry the epilogue (go1gate, go1plane)
   s->fuse_post = s->fuse_substeps && getenv("MQE_NO_FUSE_POST") == nullptr && !m.curriculum &&
                  (s->substeps_fn == (void (*)(const DevModel*, DevState, int, int, PostArgs))k_substeps<2, 0> || s->substeps_fn == (void (*)(const DevModel*, DevState, int, int, PostArgs))k_substeps<1, 0> ||
+                  s->substeps_fn == (void (*)(const DevModel*, DevState, int, int, PostArgs))k_substeps<2, 0, 1, true> ||
                   s->substeps_fn == (void (*)(const DevModel*, DevState, int, int, PostArgs))k_substeps<1, 0, 2>);
   // Debug / experiment switches are read HERE, once per handle, never on the launch path; MQE_VERBOSE lists the ones in effect.
   if (const char* sp = getenv("MQE_DEBUG_STOP_PHASE")) {
@@ -510,7 +513,7 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   st.hist2 = nullptr;
   st.hist_irr = nullptr;
   st.wave_times = nullptr;
-  if (getenv("MQE_WAVE_TIMES")) { DA(st.wave_times, (size_t)4 * N); }
+  if (getenv("MQE_WAVE_TIMES") || getenv("MQE_PHASE_TIMES")) { DA(st.wave_times, (size_t)(4 + 64) * N); }      // [N][4] entry / exit / ids, then [N][4 substeps][16 taps]
   if (s->gemm_split) { DA(st.hist2, (size_t)2 * R * MQE_HIST * MQE_H2_FRAME); DA(st.hist_irr, (size_t)R); }
   DA(st.last_loco, (size_t)R * 12); DA(st.last_two_loco, (size_t)R * 12); DA(st.act_hist, (size_t)4 * R * 12);
   DA(st.gait, R); DA(st.clock, (size_t)R * 4); DA(st.blv, (size_t)R * 3); DA(st.bav, (size_t)R * 3); DA(st.pg, (size_t)R * 3);
@@ -844,6 +847,13 @@ extern "C" int mqe_state_load(mqe_sim* s, const void* host_blob, void* stream) {
     o += (b.second + 15) / 16 * 16;
   }
   s->hist_pos = h.hist_pos; s->n_post_steps = h.n_post_steps; s->lag_pos = h.lag_pos;
+  return 0;
+}
+extern "C" int mqe_debug_phase_times(mqe_sim* s, long long* out_host) {
+  if (!s) return fail(-1, "null engine handle");
+  if (!s->st.wave_times || !getenv("MQE_PHASE_TIMES")) return fail(-4, "create the handle with MQE_PHASE_TIMES=1");
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(out_host, s->st.wave_times + (size_t)4 * s->N, (size_t)64 * s->N * sizeof(long long), hipMemcpyDeviceToHost));
   return 0;
 }
 extern "C" int mqe_debug_wave_times(mqe_sim* s, long long* out_host) {
