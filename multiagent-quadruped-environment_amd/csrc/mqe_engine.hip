@@ -64,6 +64,7 @@ struct mqe_sim {
   float *P1 = nullptr, *bufA = nullptr, *bufB = nullptr, *lat = nullptr, *act_out = nullptr;
   int ldP1, ldbuf, ldlat, ldact;
   bool gemm_split = false;
+  bool gemm_half = true;              // k_gemm_h2_mix: half tiles for a remainder of at most half a round (MQE_GEMM_HALF=0: full tiles only)
   bool cmd_general = false;           // command layout other than (x, y, yaw) -> entries 3-5 (desc.command_src): unfused entry points, exact-f32 layer 0
   bool tail_fused = false;            // k_policy_tail: the reference network shapes (256-128-2 / 512-256-128-12 after layer 0)
   size_t phys_lds_bytes = 0;
@@ -225,8 +226,7 @@ static int wrapper_dims(const mqe_sim_desc* d, int* Aw, int* D) {
 // M-tiles of k_gemm_h2 for M rows and ntn column blocks: whole rounds of full tiles (a round = 256 / ntn M-tiles, one block per CU); the
 // remainder as full tiles too when it fills more than half a round, else as half tiles (MQE_GEMM_HALF=0: never).  A half tile costs a CU
 // ~0.6 of a full one, so a remainder of r <= half a round takes 0.6 of a round's time on 2 r tiles instead of a whole round on r.
-static void h2_tiling(int M, int ntn, int* full_tiles, int* half_tiles) {
-  static const bool use_half = getenv("MQE_GEMM_HALF") == nullptr || atoi(getenv("MQE_GEMM_HALF")) != 0;
+static void h2_tiling(int M, int ntn, bool use_half, int* full_tiles, int* half_tiles) {
   const int ntm = (M + H2_M - 1) / H2_M, per_round = 256 / ntn > 0 ? 256 / ntn : 1;
   const int rem = ntm % per_round;
   *full_tiles = ntm; *half_tiles = 0;
@@ -468,7 +468,8 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
     const char* f = getenv("MQE_GEMM_SPLIT");
     int ft = 0, ht = 0;
     const int ntn0 = s->l0.Npad / H2_N > 0 ? s->l0.Npad / H2_N : 1;
-    h2_tiling(R, ntn0, &ft, &ht);
+    s->gemm_half = getenv("MQE_GEMM_HALF") == nullptr || atoi(getenv("MQE_GEMM_HALF")) != 0;      // read per handle (tests build both forms in one process)
+    h2_tiling(R, ntn0, s->gemm_half, &ft, &ht);
     const double rounds = std::ceil(ft * (double)ntn0 / 256.0) + (ht ? 0.6 : 0.0);       // a (partial) round of half tiles: ~0.6 of a full one
     const bool faster = rounds * 80.0 < 255.0 * R / 8192.0;
     s->gemm_split = s->l0.Npad % H2_N == 0 && (f ? atoi(f) != 0 : faster) && !s->cmd_general;      // the compact operand folds entries 6-17 into its weights
@@ -692,7 +693,7 @@ static void launch_gemm(hipStream_t q, const float* A, int lda, int rot4, int ri
 }
 
 static void launch_gemm2(hipStream_t q, const uint16_t* A, int lda, int rot8, int ring8, const GemmLayer& L,
-                         float* C, int ldc, int M, int act_cols, const unsigned* irr = nullptr, const float* ring = nullptr, int ring_pos = 0) {
+                         float* C, int ldc, int M, int act_cols, const unsigned* irr = nullptr, const float* ring = nullptr, int ring_pos = 0, bool use_half = true) {
   Gemm2Args g;
   g.irr = irr; g.ring = ring; g.ring_pos = ring_pos; g.Wt32 = L.Wt; g.ldwt = L.Npad;
   g.A = A; g.lda = lda; g.a_rot8 = rot8; g.a_ring8 = ring8;
@@ -700,7 +701,7 @@ static void launch_gemm2(hipStream_t q, const uint16_t* A, int lda, int rot8, in
   g.C = C; g.ldc = ldc; g.M = M; g.N = L.Npad; g.K = L.Kpad3; g.act_cols = act_cols;
   g.descale = 1.0f / (MQE_H2_ASCALE * L.wscale);
   int full_tiles, half_tiles;
-  h2_tiling(M, L.Npad / H2_N, &full_tiles, &half_tiles);
+  h2_tiling(M, L.Npad / H2_N, use_half, &full_tiles, &half_tiles);
   g.full_blocks = full_tiles * (L.Npad / H2_N); g.full_rows = full_tiles * H2_M;
   const int grid = (full_tiles + half_tiles) * (L.Npad / H2_N);
   if (half_tiles == 0) hipLaunchKernelGGL(k_gemm_h2, dim3(grid), dim3(H2_THREADS), H2_LDS_BYTES, q, g);
@@ -728,7 +729,7 @@ static void policy_head(mqe_sim* s, const float* command, hipStream_t q, const f
     // fused layer 0 of both networks over the ring: ELU on the adaptation columns only
     if (s->gemm_split)
       launch_gemm2(q, s->st.hist2, 2 * MQE_HIST * MQE_H2_FRAME, s->hist_pos * (MQE_H2_FRAME / 8), MQE_HIST * MQE_H2_FRAME / 8, s->l0,
-                   s->P1, s->ldP1, R, s->ada_h0, s->st.hist_irr, s->st.hist, s->hist_pos);
+                   s->P1, s->ldP1, R, s->ada_h0, s->st.hist_irr, s->st.hist, s->hist_pos, s->gemm_half);
     else
       launch_gemm(q, s->st.hist, MQE_HIST * MQE_FRAME, s->hist_pos * (MQE_FRAME / 4), MQE_HIST * MQE_FRAME / 4, s->l0, s->P1, s->ldP1, R, s->ada_h0);
   }

@@ -116,6 +116,29 @@ def test_policy_layer0_paths_are_f32_equivalent(monkeypatch, split, N):
             close(eh.tensor(abi.T_ACTIONS), eo.tensor(abi.T_ACTIONS), atol=5e-5, what=f"policy actions step {t}")
 
 
+def test_layer0_half_tiles_equal_full_tiles_bit_for_bit(monkeypatch):
+    """k_gemm_h2_mix (round 4): whole rounds of 128 x 192 tiles and a remainder of at most half a round as 64 x 192 tiles.  A half tile walks K
+    in the same order with the same three plane products per element, so its outputs equal a full tile's bit for bit: two HIP engines at a
+    batch that mixes both (4132 envs = 8264 rows: 64 full M-tiles + 2 half tiles, the second ragged) against MQE_GEMM_HALF=0 (65 full tiles),
+    and at 2048 envs (32 full tiles = exactly half a round -> 64 half tiles)."""
+    for N in (4132, 2048):
+        d1, k1, _ = make_desc("go1gate", N)
+        e1 = hip_engine(d1, k1)
+        monkeypatch.setenv("MQE_GEMM_HALF", "0")
+        d2, k2, _ = make_desc("go1gate", N)
+        e2 = hip_engine(d2, k2)
+        monkeypatch.delenv("MQE_GEMM_HALF")
+        e1.reset_all(); e2.reset_all()
+        g = torch.Generator(device="cuda").manual_seed(3)
+        for t in range(4):
+            a = torch.rand(N, 2, 3, device="cuda", generator=g) * 2 - 1
+            e1.step(a); e2.step(a)
+        torch.cuda.synchronize()
+        for k in (abi.T_ACTIONS, abi.T_ROOT_STATE, abi.T_DOF_STATE, abi.T_WRAPPER_OBS):
+            assert torch.equal(e1.tensor(k), e2.tensor(k)), (N, k)
+        del e1, e2
+
+
 @pytest.mark.parametrize("split", ["1", "0"])
 def test_policy_layer0_compact_history_with_resets(monkeypatch, split):
     """The split-f16 operand of layer 0 does not store last_two_locomotion_action: frame p's copy is frame p-1's
