@@ -2457,16 +2457,19 @@ __global__ void __launch_bounds__(64, EPW == 2 ? 2 : SubstepsClass<TP>::waves) k
                                        // inlined, and two copies of its ~9 k instructions would not fit the instruction cache)
       // weight fragments (A operands): row = hidden unit j32, k = this half-wave's element of each k pair; re-read every substep
       // (L1/L2 resident, 5 kB shared by every wave)
-      const float* W0 = mk->actuator.W[0]; const float* b0 = mk->actuator.b[0];      // through the laundered pointer: the 70 fragment
-      const float* W1 = mk->actuator.W[1]; const float* b1 = mk->actuator.b[1];      // loads below stay inside the substep loop
+      const float* b0 = mk->actuator.b[0];      // through the laundered pointer: the 70 fragment
+      const float* b1 = mk->actuator.b[1];      // loads below stay inside the substep loop
       const float* W2 = mk->actuator.W[2]; const float* b2 = mk->actuator.b[2];
       float a1[3], a2[16], w3[16], bb0[16], bb1[16];
+      // (the two matrix operands from the fragment-ordered copy: lane-contiguous, one 256 B request per fragment -- W1[j32 * 32 + u] itself
+      // is 64 lanes x a 128 B stride, 64 cache lines per instruction, 16 instructions per substep and wavefront)
+      const float* fragw = mk->act_frag + lane_k;
 #pragma unroll
-      for (int s2 = 0; s2 < 3; s2++) a1[s2] = W0[j32 * 6 + 2 * s2 + h];
+      for (int s2 = 0; s2 < 3; s2++) a1[s2] = fragw[(16 + s2) * 64];
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const int u = (r & 3) + 8 * (r >> 2) + 4 * h;
-        a2[r] = W1[j32 * 32 + u]; w3[r] = W2[u]; bb0[r] = b0[u]; bb1[r] = b1[u];
+        a2[r] = fragw[r * 64]; w3[r] = W2[u]; bb0[r] = b0[u]; bb1[r] = b1[u];
       }
       const float bout = b2[0];
       int pos = 0;

@@ -60,6 +60,9 @@ struct DevModel {
   float sheep_scale, sheep_rand;
   float reward_scale[MQE_MAX_REWARD_TERMS]; float wrapper_param[8];
   DevMlp actuator;
+  // the actuator network's weights in the order k_substeps' lanes consume them, [fragment][lane] (64 floats = one coalesced 256 B load per
+  // fragment instead of 64 lanes x a 128 B stride): fragments 0-15 = layer 2 rows (W1[(lane & 31) * 32 + u(r, lane >> 5)]), 16-18 = layer 1
+  const float* act_frag;
   // physics kernel geometry
   int nbody_env, ndof_env, nsph_env, nprim_env, maxc;
   unsigned long long feat_sphere_mask;                   // bit f: feature point f of the robot model belongs to a sphere primitive (a foot)

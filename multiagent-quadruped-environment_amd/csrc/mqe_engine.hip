@@ -428,6 +428,15 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
     UP(m.actuator.W[l], d->actuator.W[l], (size_t)d->actuator.dims[l] * d->actuator.dims[l + 1]);
     UP(m.actuator.b[l], d->actuator.b[l], (size_t)d->actuator.dims[l + 1]);
   }
+  {   // the same weights in k_substeps' fragment order (DevModel::act_frag): [19][64]
+    std::vector<float> fr((size_t)19 * 64);
+    for (int lane = 0; lane < 64; lane++) {
+      const int j32 = lane & 31, h = lane >> 5;
+      for (int r = 0; r < 16; r++) fr[(size_t)r * 64 + lane] = d->actuator.W[1][j32 * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+      for (int s2 = 0; s2 < 3; s2++) fr[(size_t)(16 + s2) * 64 + lane] = d->actuator.W[0][j32 * 6 + 2 * s2 + h];
+    }
+    UP(m.act_frag, fr.data(), fr.size());
+  }
   // ---- policy network: fused layer 0 over the ring-buffer history ------------------------------------------------
   const mqe_mlp& ad = d->adaptation; const mqe_mlp& bd = d->body;
   if (ad.dims[0] != 2100 || bd.dims[0] != 2102 || bd.dims[bd.n_layers] != 12 || ad.dims[ad.n_layers] != 2)
