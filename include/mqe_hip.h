@@ -259,7 +259,9 @@ enum {
                               OUTPUT view: large batches run layer 0 on a compact split-f16 copy that the engine maintains frame by frame
                               (csrc/mqe_common.hpp, MQE_H2_FRAME), so host writes into the ring do not reach the policy there.  The action
                               registers, the observation bag and every other state tensor ARE inputs of the next step.  (Handles created
-                              with MQE_GEMM_SPLIT=0 read the ring itself.) */
+                              with MQE_GEMM_SPLIT=0 read the ring itself.)  A host that WRITES the ring calls mqe_history_sync afterwards:
+                              the compact operand is rebuilt from it (columns 6..17 of a written frame must hold the scene's constants,
+                              desc.command_obs -- the compact form carries them on the frame's presence flag). */
   MQE_T_ACT_HIST,          /* [4][R][12]: pos_err_last, pos_err_last_last, vel_last, vel_last_last */
   MQE_T_GAIT_INDICES, MQE_T_CLOCK_INPUTS,
   MQE_T_BASE_LIN_VEL, MQE_T_BASE_ANG_VEL, MQE_T_PROJECTED_GRAVITY, MQE_T_BASE_QUAT,
@@ -383,6 +385,11 @@ int mqe_step_command(mqe_sim* s, const float* command, void* stream);
  * to clip_actions inside; no locomotion policy runs.  The decimation loop, post-physics step and (plain) wrapper are the
  * fused ones. */
 int mqe_step_joint(mqe_sim* s, const float* actions12, void* stream);
+
+/* After host writes into MQE_T_HISTORY (obs_history of the reference, go1.py:102,145): rebuilds what the engine derives from the ring --
+ * the compact split-f16 operand of layer 0, the presence flags (a frame of 70 zeros is absent), the carrier columns, the continuity
+ * bits.  A no-op for handles whose layer 0 reads the ring itself.  Enqueued on `stream`. */
+int mqe_history_sync(mqe_sim* s, void* stream);
 
 /* debug taps (tests): M^-1 (18 x 18) of one robot and the contact list of one env ([<= 64][8]: actor A, link A, actor B (-1 static),
  * link B, separation, normal xyz) from the CURRENT state, without advancing it; outputs are host pointers */

@@ -1068,6 +1068,47 @@ __global__ void k_reset_history(const DevModel* m, DevState st) {
   }
 }
 
+// mqe_history_sync: the compact split-f16 operand of layer 0 (and the continuity bits) rebuilt from the f32 ring, for a host that has
+// WRITTEN MQE_T_HISTORY (the engine itself keeps the two in step frame by frame: pre_policy_store).  One thread per (robot, ring slot):
+// the slot's 46 stored columns, its presence flag (a frame is present unless all of its 70 entries are zero: what a reset leaves), its
+// carrier column (the oldest frame's last_two_locomotion_action, component j on the frame at logical position MQE_H2_CARRIER0 + j, zero
+// elsewhere) and its continuity bit (columns 54..65 against the previous slot's 42..53, bit for bit).  `oldest` = ring slot of logical
+// frame 0 = the slot the next step overwrites.
+__global__ void k_hist2_rebuild(const DevModel* m, DevState st, int oldest) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = idx / MQE_HIST, slot = idx - i * MQE_HIST;
+  if (i >= m->R || !st.hist2) return;
+  const float* fr = st.hist + ((size_t)i * MQE_HIST + slot) * MQE_FRAME;
+  uint16_t* row2 = st.hist2 + (size_t)i * (2 * MQE_HIST * MQE_H2_FRAME);
+  unsigned any = 0u;
+  for (int c = 0; c < 70; c++) {
+    const float v = fr[c];
+    any |= __float_as_uint(v) & 0x7FFFFFFFu;
+    const int cc = h2_col(c);
+    if (cc >= 0) {
+      uint16_t h, l;
+      split2(v, MQE_H2_ASCALE, h, l);
+      const size_t k = (size_t)slot * MQE_H2_FRAME + cc;
+      row2[h2_index(k, 0)] = h; row2[h2_index(k, 1)] = l;
+    }
+  }
+  uint16_t h, l;
+  split2(any ? 1.0f : 0.0f, MQE_H2_ASCALE, h, l);
+  size_t k = (size_t)slot * MQE_H2_FRAME + MQE_H2_FLAG_COL;
+  row2[h2_index(k, 0)] = h; row2[h2_index(k, 1)] = l;
+  int p = slot - oldest; if (p < 0) p += MQE_HIST;             // logical position of this slot's frame
+  float carry = 0.0f;
+  if (p >= MQE_H2_CARRIER0 && p < MQE_H2_CARRIER0 + 12) carry = st.hist[((size_t)i * MQE_HIST + oldest) * MQE_FRAME + 54 + (p - MQE_H2_CARRIER0)];
+  split2(carry, MQE_H2_ASCALE, h, l);
+  k = (size_t)slot * MQE_H2_FRAME + MQE_H2_CARRIER_COL;
+  row2[h2_index(k, 0)] = h; row2[h2_index(k, 1)] = l;
+  const int prev = slot > 0 ? slot - 1 : MQE_HIST - 1;
+  const float* pa = st.hist + ((size_t)i * MQE_HIST + prev) * MQE_FRAME + 42;
+  unsigned diff = 0u;
+  for (int j = 0; j < 12; j++) diff |= __float_as_uint(pa[j]) ^ __float_as_uint(fr[54 + j]);
+  if (diff) atomicOr(&st.hist_irr[i], 1u << slot);
+}
+
 // post_physics_step in the stages the reference's method has (include/mqe_hip.h mqe_post_physics_stage; oracle: post_stages): one thread
 // per env, the per-env device functions of the fused kernel in the same arithmetic (results equal k_post_physics' to the last bit or two).
 // Not the fast path: it exists so that a subclass's check_termination / _step_npc / reset_idx / compute_observations can run in between.

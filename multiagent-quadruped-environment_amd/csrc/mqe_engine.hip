@@ -859,6 +859,15 @@ extern "C" int mqe_state_load(mqe_sim* s, const void* host_blob, void* stream) {
   s->hist_pos = h.hist_pos; s->n_post_steps = h.n_post_steps; s->lag_pos = h.lag_pos;
   return 0;
 }
+extern "C" int mqe_history_sync(mqe_sim* s, void* stream) {
+  if (!s) return fail(-1, "null engine handle");
+  if (!s->st.hist2) return 0;                    // the exact-f32 layer 0 reads the ring itself
+  hipStream_t q = (hipStream_t)stream;
+  if (hipMemsetAsync(s->st.hist_irr, 0, (size_t)s->R * sizeof(uint32_t), q) != hipSuccess) return fail(-4, "memset failed");
+  const int n = s->R * MQE_HIST;
+  hipLaunchKernelGGL(k_hist2_rebuild, dim3((n + 255) / 256), dim3(256), 0, q, s->dm, s->st, s->hist_pos);
+  return hipGetLastError() == hipSuccess ? 0 : fail(-4, "k_hist2_rebuild launch failed");
+}
 extern "C" int mqe_debug_phase_times(mqe_sim* s, long long* out_host) {
   if (!s) return fail(-1, "null engine handle");
   if (!s->st.wave_times || !getenv("MQE_PHASE_TIMES")) return fail(-4, "create the handle with MQE_PHASE_TIMES=1");

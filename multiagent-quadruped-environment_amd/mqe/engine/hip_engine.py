@@ -48,6 +48,7 @@ class HipEngine(EngineBase):
                            ("debug_stop_phase", [vp, C.c_int]),
                            ("debug_wave_times", [vp, vp]),
                            ("debug_phase_times", [vp, vp]),
+                           ("history_sync", [vp, vp]),
                            ("state_save", [vp, vp, vp]), ("state_load", [vp, vp, vp]),
                            ("profile_enable", [vp, C.c_int]),
                            ("profile_read", [vp, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)])):
@@ -152,6 +153,10 @@ class HipEngine(EngineBase):
             raise ValueError(f"checkpoint blob has {blob.nbytes} bytes, this handle's state takes {want} (truncated file or another scene shape)")
         self._call("state_load", C.c_void_p(blob.ctypes.data), self._stream())
         self._n_policy = int(np.frombuffer(blob[-8:].tobytes(), np.int64)[0])
+
+    def history_sync(self):
+        """after writing tensor(T_HISTORY): the compact layer-0 operand is rebuilt from the ring (mqe_history_sync)"""
+        self._call("history_sync", self._stream())
 
     def history(self):
         """(R, 2100) time-ordered locomotion history gathered from the ring (host-side bookkeeping of the slot)."""

@@ -264,6 +264,17 @@ class Go1:
     def _hist_pos(self):
         return getattr(self, "_steps_policy", 0) % abi.HIST
 
+    @property
+    def obs_history_ring(self):
+        """The engine's own history tensor (R, 30, 72), ring order (slot `_hist_pos()` holds the oldest frame), zero copy.  It may be
+        WRITTEN -- the reference's obs_history is a plain tensor (go1.py:102,145) -- followed by history_written()."""
+        return self.engine.tensor(abi.T_HISTORY)
+
+    def history_written(self):
+        """after a write into obs_history_ring: what the engine derives from the ring (the compact operand of the policy's first layer)
+        is rebuilt from it (mqe_history_sync)"""
+        self.engine.history_sync()
+
     # ---- reference API --------------------------------------------------------------------------------------------
     def reset(self):
         """Reset all robots (go1.py:147-151): no physics step, observations recomputed."""

@@ -115,6 +115,9 @@ class OracleEngine(EngineBase):
         f(self.h, int(env), int(robot), C.c_void_p(M.ctypes.data), C.c_void_p(minv.ctypes.data), C.byref(nc), C.c_void_p(con.ctypes.data))
         return M, minv, con[:nc.value]
 
+    def history_sync(self):
+        pass      # the oracle's layer 0 reads the f32 ring itself
+
     def history(self):
         R = self.desc.num_envs * self.desc.num_agents
         out = np.zeros((R, 2100), np.float32)

@@ -139,6 +139,48 @@ def test_layer0_half_tiles_equal_full_tiles_bit_for_bit(monkeypatch):
         del e1, e2
 
 
+def test_history_written_by_the_host_reaches_the_policy(monkeypatch):
+    """MQE_T_HISTORY is the reference's obs_history: a host may write it.  Large batches run layer 0 on a compact split-f16 copy of the ring,
+    which mqe_history_sync rebuilds from the ring (presence flags, carrier columns, continuity bits included): after an edit of the ring --
+    frames rescaled, one frame zeroed as a reset would, the action columns of one frame changed so that it no longer continues its
+    predecessor -- the split path's joint targets equal those of the exact-f32 path, which reads the ring itself, to the usual 5e-5."""
+    N = 48
+    monkeypatch.setenv("MQE_GEMM_SPLIT", "1")
+    d1, k1, _ = make_desc("go1gate", N)
+    e1 = hip_engine(d1, k1)
+    monkeypatch.setenv("MQE_GEMM_SPLIT", "0")
+    d2, k2, _ = make_desc("go1gate", N)
+    e2 = hip_engine(d2, k2)
+    monkeypatch.delenv("MQE_GEMM_SPLIT")
+    e1.reset_all(); e2.reset_all()
+    g = torch.Generator(device="cuda").manual_seed(9)
+    for t in range(34):                                   # the ring turns over once
+        a = torch.rand(N, 2, 3, device="cuda", generator=g) * 2 - 1
+        e1.step(a); e2.step(a)
+        for k in (abi.T_ROOT_STATE, abi.T_DOF_STATE, abi.T_LAST_LOCO_ACTION, abi.T_LAST_TWO_LOCO_ACTION, abi.T_ACTIONS, abi.T_LAST_ACTIONS, abi.T_HISTORY):
+            e2.tensor(k).copy_(e1.tensor(k))             # both engines on one trajectory and one ring
+    h = e1.tensor(abi.T_HISTORY).clone()
+    scale = 0.5 + torch.rand(h.shape[0], abi.HIST, 1, device="cuda", generator=g)
+    keep = torch.ones(72, device="cuda"); keep[6:18] = 0   # the gait parameters stay the scene's constants
+    h = h * (1 + (scale - 1) * keep)
+    h[::3, 7] = 0.0                                        # a frame of zeros in every third robot
+    h[1::3, 11, 54:66] += 0.25                             # a frame that does not continue its predecessor
+    h[2::3, 20, 42:54] -= 0.125                            # ... and a predecessor changed under its successor
+    for e in (e1, e2):
+        e.tensor(abi.T_HISTORY).copy_(h)
+    e1.history_sync()
+    a = torch.rand(N, 2, 3, device="cuda", generator=g) * 2 - 1
+    e1.step(a); e2.step(a)
+    torch.cuda.synchronize()
+    close(e1.tensor(abi.T_ACTIONS), e2.tensor(abi.T_ACTIONS), atol=5e-5, what="joint targets after a host edit of the history ring")
+    # and without the sync the compact copy is stale: the same comparison must FAIL (the test would be vacuous otherwise)
+    for e in (e1, e2):
+        e.tensor(abi.T_HISTORY).copy_(h * 0.5 * keep + h * (1 - keep))
+    e1.step(a); e2.step(a)
+    torch.cuda.synchronize()
+    assert float((e1.tensor(abi.T_ACTIONS) - e2.tensor(abi.T_ACTIONS)).abs().max()) > 1e-3
+
+
 @pytest.mark.parametrize("split", ["1", "0"])
 def test_policy_layer0_compact_history_with_resets(monkeypatch, split):
     """The split-f16 operand of layer 0 does not store last_two_locomotion_action: frame p's copy is frame p-1's
