@@ -343,13 +343,22 @@ struct PhysShape {
 // env) say so.  The arithmetic per env is the same either way: both forms produce bit-identical states (tests/test_gpu_parity.py).
 template <int TA, int TP, int EPW = 1>
 __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, const DevState& st, float* lds_wave, const int e_first, const int lane_wave,
-                                             const int flags, const int no_write, const PhysDebug& dbg) {
+                                             const int flags, const int no_write, const PhysDebug& dbg, const int hotv) {
   static_assert(EPW == 1 || (EPW == 2 && TP == 0 && (TA == 1 || TA == 2)), "two envs per wavefront: robot-only scenes of at most two robots");
+  // the model's wave-uniform constants from the table k_substeps loaded once per launch (DevModel::hot: lane i of `hotv` = entry i)
+  auto HI = [&](int i) -> int { return __builtin_amdgcn_readlane(hotv, i); };
+  auto HF = [&](int i) -> float { return __int_as_float(__builtin_amdgcn_readlane(hotv, i)); };
+  auto HP = [&](int i) -> const float* {
+    return reinterpret_cast<const float*>(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(hotv, i + 1) << 32) | (unsigned long long)(unsigned)__builtin_amdgcn_readlane(hotv, i));
+  };
+  auto HMASK = [&]() -> unsigned long long {
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(hotv, HOT_FEAT_MASK_HI) << 32) | (unsigned long long)(unsigned)__builtin_amdgcn_readlane(hotv, HOT_FEAT_MASK_LO);
+  };
   constexpr int LW = 64 / EPW;                                   // lanes of one env
   const int grp = EPW == 1 ? 0 : lane_wave / LW;                 // which env of the wavefront this lane works for
   const int lane = EPW == 1 ? lane_wave : lane_wave - grp * LW;  // lane within the env's group
-  const bool evalid = EPW == 1 || e_first + grp < m->N;          // an odd batch leaves the last wavefront's second half without an env:
-  const int e = evalid ? e_first + grp : m->N - 1;               // it recomputes the last env and stores nothing
+  const bool evalid = EPW == 1 || e_first + grp < HI(HOT_N);          // an odd batch leaves the last wavefront's second half without an env:
+  const int e = evalid ? e_first + grp : HI(HOT_N) - 1;               // it recomputes the last env and stores nothing
   auto gballot = [&](bool p) -> unsigned long long {             // the group's bits of a ballot, in the low LW bits
     const unsigned long long b = __ballot(p);
     return EPW == 1 ? b : ((b >> (grp * LW)) & ((1ull << (LW & 63)) - 1ull));
@@ -359,11 +368,11 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   };
   const PhysShape<TA, TP> shp(m);
   const int A = shp.A, P = shp.P, PD = shp.PD, npcdof = shp.npcdof;
-  const int nbody = shp.nbody, ndof = shp.ndof, nsph = m->nsph_env, maxc = shp.maxc;
+  const int nbody = shp.nbody, ndof = shp.ndof, nsph = HI(HOT_NSPH_ENV), maxc = shp.maxc;
   constexpr int BODY_STRIDE = BODY_STRIDE_OF(PhysPad<TP>::on), CON_STRIDE = CON_STRIDE_OF(PhysPad<TP>::on);
-  const PhysLds L = phys_lds_layout(A, P, shp.ND, nbody, ndof, nsph, m->nprim_env, maxc, shp.rowgs, PhysPad<TP>::on);
+  const PhysLds L = phys_lds_layout(A, P, shp.ND, nbody, ndof, nsph, HI(HOT_NPRIM_ENV), maxc, shp.rowgs, PhysPad<TP>::on);
   float* lds = lds_wave + grp * L.total;
-  const float dt = m->dt;
+  const float dt = HF(HOT_DT);
   const mqe_robot_model& rm = m->robot;
   float* g_root = st.root + (size_t)e * (A + P) * 13;
   float* g_dof = st.dof + (size_t)e * shp.ND * 2;
@@ -375,10 +384,10 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   constexpr int NSP = (SELF_CHUNK + LW - 1) / LW;
   int selfp[NSP];
 #pragma unroll
-  for (int k = 0; k < NSP; k++) selfp[k] = (m->self_collision && k * LW + lane < rm.n_self_pairs) ? (int)rm.self_pair[k * LW + lane] : -1;
+  for (int k = 0; k < NSP; k++) selfp[k] = (HI(HOT_SELF_COLLISION) && k * LW + lane < HI(HOT_N_SELF_PAIRS)) ? (int)rm.self_pair[k * LW + lane] : -1;
   // ... and this lane's joint of the self-collision "safe box" (lanes 0-11): a robot whose joint angles are all inside it cannot touch itself
-  const float ss_lo = (m->self_collision && lane < MQE_NDOF) ? rm.self_safe_lo[lane] : -1e30f;
-  const float ss_hi = (m->self_collision && lane < MQE_NDOF) ? rm.self_safe_hi[lane] : 1e30f;
+  const float ss_lo = (HI(HOT_SELF_COLLISION) && lane < MQE_NDOF) ? rm.self_safe_lo[lane] : -1e30f;
+  const float ss_hi = (HI(HOT_SELF_COLLISION) && lane < MQE_NDOF) ? rm.self_safe_hi[lane] : 1e30f;
   TSTAMP(0);
   // ---- coalesced state load (first substep of a launch only; afterwards the state stays in LDS) -----------------
   if (flags & PS_LOAD_STATE) {
@@ -515,7 +524,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     X[7] = Iw[3] - bmass * rc.x * rc.y; X[8] = Iw[4] - bmass * rc.x * rc.z; X[9] = Iw[5] - bmass * rc.y * rc.z;
     V3 rcb = bc - bp;
     V3 ac = bap + cross(bal, rcb) + cross(bw, cross(bw, rcb));
-    V3 f = bmass * (ac - v3(0, 0, m->gravity_z));
+    V3 f = bmass * (ac - v3(0, 0, HF(HOT_GRAVITY_Z)));
     V3 nc = sym_vec(Iw, bal) + cross(bw, sym_vec(Iw, bw));
     V3 no = nc + cross(rc, f);
     X[10] = no.x; X[11] = no.y; X[12] = no.z; X[13] = f.x; X[14] = f.y; X[15] = f.z;
@@ -770,7 +779,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     if (shp.has_seesaw) return lds[L.dof + (12 * A) * 2 + 1];       // the plank's hinge: COM on the axis, no drive
     const int q = d - A * MQE_RD, p = q / npcdof, k = q - p * npcdof;
     float v = lds[L.root + (A + p) * 13 + 7 + k];
-    if (k == 2) v += dt * m->gravity_z;
+    if (k == 2) v += dt * HF(HOT_GRAVITY_Z);
     return v;
   };
   const float vs0 = lane < ndof ? vstar(lane) : 0.0f;
@@ -778,7 +787,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
 
   TSTAMP(7);
   // ---- collision spheres ----------------------------------------------------------------------------------------------
-  const int nsr = rm.n_spheres;
+  const int nsr = HI(HOT_N_SPHERES);
   for (int s = lane; s < nsph; s += LW) {
     V3 c; float rad;
     if (s < A * nsr) {
@@ -789,7 +798,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       c = v3(q2.y, q2.z, q2.w) + mat_vec(Rr, v3(rm.sphere_center[si][0], rm.sphere_center[si][1], rm.sphere_center[si][2]));
       rad = rm.sphere_radius[si];
     } else {
-      const int q = s - A * nsr, p = q / m->npc_n_spheres, si = q - p * m->npc_n_spheres;
+      const int q = s - A * nsr, p = q / HI(HOT_NPC_N_SPHERES), si = q - p * HI(HOT_NPC_N_SPHERES);
       const float* rec = lds + L.body + (A * MQE_NBODY + p) * BODY_STRIDE;
       c = ld3(rec + B_P) + mat_vec(rec + B_R, v3(m->npc_sphere_center[si][0], m->npc_sphere_center[si][1], m->npc_sphere_center[si][2]));
       rad = m->npc_sphere_radius[si];
@@ -822,7 +831,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       const unsigned long long bm = gballot(nr);
       if (t0 == 0) near0 = bm; else near1 = bm;
     }
-    if (m->self_collision)
+    if (HI(HOT_SELF_COLLISION))
       for (int a = 0; a < A; a++) {
         const float qj = lds[L.dof + (a * 12 + (lane < MQE_NDOF ? lane : 0)) * 2];
         if (gballot(qj < ss_lo || qj > ss_hi) != 0ull) self_todo |= 1u << a;
@@ -832,7 +841,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   // bounding radius, capsule half-segment and radius (a sphere is a capsule with a zero segment; a box keeps its link's rotation
   // and is marked by a negative radius).  Only built when something can touch a primitive at all: two robots walking apart from
   // each other in ordinary poses skip it.
-  const int npr = rm.n_prims;
+  const int npr = HI(HOT_N_PRIMS);
   const bool need_prims = near0 != 0ull || near1 != 0ull || self_todo != 0u;
   for (int t = lane; need_prims && t < A * npr; t += LW) {
     const int r = t / npr, q = t - r * npr;
@@ -842,7 +851,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     const V3 c = v3(q2.y, q2.z, q2.w) + mat_vec(Rr, v3(rm.prim_center[q][0], rm.prim_center[q][1], rm.prim_center[q][2]));
     const V3 u = mat_vec(Rr, v3(rm.prim_axis[q][0], rm.prim_axis[q][1], rm.prim_axis[q][2]));
     float4* pw0 = reinterpret_cast<float4*>(lds + L.prim) + t;
-    float4* pw1 = pw0 + m->nprim_env;
+    float4* pw1 = pw0 + HI(HOT_NPRIM_ENV);
     pw0[0] = make_float4(c.x, c.y, c.z, rm.prim_bound[q]);
     // radius; a box carries MINUS the radius of its bounding capsule about its longest edge (the sign marks it; screens use |.|)
     float rad = rm.prim_half[q][0];
@@ -877,7 +886,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   // wall / platform / column -- because a lane's slot = contacts of earlier groups (capped) + its rank in its group.
   const int rpp = (2 * nsr <= LW) ? 2 : 1;
   const int n_rpass = (A + rpp - 1) / rpp;
-  const int nsn = m->npc_n_spheres;
+  const int nsn = HI(HOT_NPC_N_SPHERES);
   const bool npc_one = PD * nsn <= LW;                     // every sphere of every free NPC in ONE pass, lane = (npc, sphere): 9 sheep x 2
   const int n_pass = n_rpass + (PD > 0 ? (npc_one ? 1 : PD) : 0);
   const unsigned long long mns = (nsn < 64) ? ((1ull << nsn) - 1ull) : ~0ull;
@@ -885,7 +894,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     int act = -1, sidx = 0, s = nsph, sub = 0;
     unsigned long long gm = ~0ull;                         // lanes of my group (= my actor)
     const bool rob = pass < n_rpass;
-    const int cap = rob ? CAP_ROBOT : m->cap_npc;
+    const int cap = rob ? CAP_ROBOT : HI(HOT_CAP_NPC);
     const unsigned long long m0 = (nsr < 64) ? ((1ull << nsr) - 1ull) : ~0ull;
     if (rob) {
       sub = (rpp == 2 && lane >= nsr) ? 1 : 0;
@@ -898,24 +907,24 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       gm = mns << (pl * nsn);
     } else {
       const int p = pass - n_rpass;
-      if (lane < m->npc_n_spheres) { act = A + p; sidx = lane; s = A * nsr + p * m->npc_n_spheres + lane; }
+      if (lane < HI(HOT_NPC_N_SPHERES)) { act = A + p; sidx = lane; s = A * nsr + p * HI(HOT_NPC_N_SPHERES) + lane; }
     }
     // ---- edge contacts of the pass's robots with the static world (desc.edge_contacts; oracle: "edge contacts of a robot with the static
     // world"): lane = primitive of the lane's robot; per primitive the deepest of the nearest vertical wall edge and the scenery boxes.
     // Computed first, ranked behind the robot's feature contacts below.
     bool eflag = false; float esd = 1e3f; V3 en = v3(0, 0, 1), epa = v3(0, 0, 0); int ebody = 0, erep = 0;
-    bool edge_pass = rob && (m->edge_mask & 2) != 0 && shp.n_static > 0;
-    if (rob && !edge_pass && (m->edge_mask & 1) != 0 && m->wall_corner != nullptr) {
+    bool edge_pass = rob && (HI(HOT_EDGE_MASK) & 2) != 0 && shp.n_static > 0;
+    if (rob && !edge_pass && (HI(HOT_EDGE_MASK) & 1) != 0 && HP(HOT_WALL_CORNER_LO) != nullptr) {
       // is any robot of the pass within reach of a wall edge at all?  One look-up per robot (its base's raster point): no primitive
       // reaches farther from the base than feature_reach, so a corner beyond that + the margin of the map's nearest-of-four choice is out
       const int l = lane - sub * nsr, r = pass * rpp + sub;
       bool nearw = false;
       if (l == 0 && r < A) {
         const V3 pbase = ld3(lds + L.body + r * MQE_NBODY * BODY_STRIDE + B_P);
-        int ix = (int)floorf(pbase.x / m->hs + 0.5f), iy = (int)floorf(pbase.y / m->hs + 0.5f);
-        ix = min(max(ix, 0), m->sdf_nx - 1); iy = min(max(iy, 0), m->sdf_ny - 1);
-        const float2 cc = reinterpret_cast<const float2*>(m->wall_corner)[(size_t)ix * m->sdf_ny + iy];
-        const float dx = pbase.x - cc.x, dy = pbase.y - cc.y, rr = 2.0f * rm.feature_reach + 0.1f;
+        int ix = (int)floorf(pbase.x / HF(HOT_HS) + 0.5f), iy = (int)floorf(pbase.y / HF(HOT_HS) + 0.5f);
+        ix = min(max(ix, 0), HI(HOT_SDF_NX) - 1); iy = min(max(iy, 0), HI(HOT_SDF_NY) - 1);
+        const float2 cc = reinterpret_cast<const float2*>(HP(HOT_WALL_CORNER_LO))[(size_t)ix * HI(HOT_SDF_NY) + iy];
+        const float dx = pbase.x - cc.x, dy = pbase.y - cc.y, rr = 2.0f * HF(HOT_FEATURE_REACH) + 0.1f;
         nearw = dx * dx + dy * dy < rr * rr;
       }
       edge_pass = gballot(nearw) != 0ull;
@@ -936,27 +945,27 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
         hb = v3(rm.prim_half[q][0], rm.prim_half[q][1], rm.prim_half[q][2]);
         ebody = rm.prim_body[q]; erep = r * MQE_NREP + rm.prim_reported[q];
       }
-      const float reach = rm.prim_bound[q] + m->contact_offset;
+      const float reach = rm.prim_bound[q] + HF(HOT_CONTACT_OFFSET);
       const float I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-      const int njobs = 1 + ((m->edge_mask & 2) ? shp.n_static : 0);
+      const int njobs = 1 + ((HI(HOT_EDGE_MASK) & 2) ? shp.n_static : 0);
       for (int j = 0; j < njobs; j++) {
         bool valid = false; V3 bc = v3(0, 0, 0), hh = v3(0, 0, 0);
         if (j == 0) {
-          if (isp && (m->edge_mask & 1) != 0 && m->wall_corner != nullptr) {
-            const float hs = m->hs;
+          if (isp && (HI(HOT_EDGE_MASK) & 1) != 0 && HP(HOT_WALL_CORNER_LO) != nullptr) {
+            const float hs = HF(HOT_HS);
             int ix = (int)floorf(cq.x / hs + 0.5f), iy = (int)floorf(cq.y / hs + 0.5f);
-            ix = min(max(ix, 0), m->sdf_nx - 1); iy = min(max(iy, 0), m->sdf_ny - 1);
-            const float2 cc = reinterpret_cast<const float2*>(m->wall_corner)[(size_t)ix * m->sdf_ny + iy];
+            ix = min(max(ix, 0), HI(HOT_SDF_NX) - 1); iy = min(max(iy, 0), HI(HOT_SDF_NY) - 1);
+            const float2 cc = reinterpret_cast<const float2*>(HP(HOT_WALL_CORNER_LO))[(size_t)ix * HI(HOT_SDF_NY) + iy];
             const float dx = cq.x - cc.x, dy = cq.y - cc.y;
             if (dx * dx + dy * dy < reach * reach) {
               // the wall's top at the corner: one height per scene or the map's value at the raster point nearest to the corner
-              float zt = m->wall_height;
-              if (m->wall_top != nullptr) {
-                float fx = fminf(fmaxf(cc.x / hs, 0.0f), (float)(m->sdf_nx - 1)), fy = fminf(fmaxf(cc.y / hs, 0.0f), (float)(m->sdf_ny - 1));
-                int jx = min((int)fx, m->sdf_nx - 2), jy = min((int)fy, m->sdf_ny - 2);
-                zt = m->wall_top[(size_t)((fx - jx) < 0.5f ? jx : jx + 1) * m->sdf_ny + ((fy - jy) < 0.5f ? jy : jy + 1)];
+              float zt = HF(HOT_WALL_HEIGHT);
+              if (HP(HOT_WALL_TOP_LO) != nullptr) {
+                float fx = fminf(fmaxf(cc.x / hs, 0.0f), (float)(HI(HOT_SDF_NX) - 1)), fy = fminf(fmaxf(cc.y / hs, 0.0f), (float)(HI(HOT_SDF_NY) - 1));
+                int jx = min((int)fx, HI(HOT_SDF_NX) - 2), jy = min((int)fy, HI(HOT_SDF_NY) - 2);
+                zt = HP(HOT_WALL_TOP_LO)[(size_t)((fx - jx) < 0.5f ? jx : jx + 1) * HI(HOT_SDF_NY) + ((fy - jy) < 0.5f ? jy : jy + 1)];
               }
-              bc = v3(cc.x, cc.y, 0.5f * (m->ground_z + zt)); hh = v3(0, 0, 0.5f * (zt - m->ground_z));
+              bc = v3(cc.x, cc.y, 0.5f * (HF(HOT_GROUND_Z) + zt)); hh = v3(0, 0, 0.5f * (zt - HF(HOT_GROUND_Z)));
               valid = true;
             }
           }
@@ -974,7 +983,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
           }
         }
       }
-      eflag = eflag && esd < m->contact_offset;
+      eflag = eflag && esd < HF(HOT_CONTACT_OFFSET);
     }
     bool gflag = false, wflag = false, bflag = false, cflag = false;   // ground, wall, seesaw platform, seesaw column
     float gsd = 0, wsd = 0, bsd = 0, csd = 0; V3 gn = v3(0, 0, 1), wn = v3(0, 0, 1), bn = v3(0, 0, 1), cn3 = v3(0, 0, 1); V3 c = v3(0, 0, 0); float rad = 0;
@@ -987,26 +996,26 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       // terrain maps are sampled bilinearly; raster entry (i, j) sits at the world point (i hs, j hs) -- the vertices of upstream's
       // convert_heightfield_to_trimesh mesh (barrier_track.py:483-497): the wall set's signed distance and, when the scene has one,
       // the relief of the walkable surface (Perlin noise, barrier_track.py:372-393)
-      const float hs = m->hs;
+      const float hs = HF(HOT_HS);
       float fx = c.x / hs, fy = c.y / hs;
-      const int nx = m->sdf_nx, ny = m->sdf_ny;
+      const int nx = HI(HOT_SDF_NX), ny = HI(HOT_SDF_NY);
       fx = fminf(fmaxf(fx, 0.0f), (float)(nx - 1)); fy = fminf(fmaxf(fy, 0.0f), (float)(ny - 1));
       int ix = (int)fx, iy = (int)fy;
       if (ix > nx - 2) ix = nx - 2;
       if (iy > ny - 2) iy = ny - 2;
       const float tx = fx - ix, ty = fy - iy;
-      gsd = c.z - m->ground_z - rad;
-      if (m->ground_height != nullptr) {       // heightfield ground: first-order distance to the surface along its normal
-        const float* gh = m->ground_height + (size_t)ix * ny + iy;
+      gsd = c.z - HF(HOT_GROUND_Z) - rad;
+      if (HP(HOT_GROUND_HEIGHT_LO) != nullptr) {       // heightfield ground: first-order distance to the surface along its normal
+        const float* gh = HP(HOT_GROUND_HEIGHT_LO) + (size_t)ix * ny + iy;
         const float h00 = gh[0], h01 = gh[1], h10 = gh[ny], h11 = gh[ny + 1];
         const float b0 = h00 + (h01 - h00) * ty, b1 = h10 + (h11 - h10) * ty;
         const float hx = (b1 - b0) / hs, hy = ((h01 - h00) + ((h11 - h10) - (h01 - h00)) * tx) / hs;
         const float inl = 1.0f / sqrtf(hx * hx + hy * hy + 1.0f);
         gn = v3(-hx * inl, -hy * inl, inl);
-        gsd = (c.z - m->ground_z - (b0 + (b1 - b0) * tx)) * inl - rad;
+        gsd = (c.z - HF(HOT_GROUND_Z) - (b0 + (b1 - b0) * tx)) * inl - rad;
       }
-      gflag = gsd < m->contact_offset;
-      const float* sd = m->wall_sdf + (size_t)ix * ny + iy;
+      gflag = gsd < HF(HOT_CONTACT_OFFSET);
+      const float* sd = HP(HOT_WALL_SDF_LO) + (size_t)ix * ny + iy;
       const float s00 = sd[0], s01 = sd[1], s10 = sd[ny], s11 = sd[ny + 1];
       const float a0 = s00 + (s01 - s00) * ty, a1 = s10 + (s11 - s10) * ty;
       float gx = (a1 - a0) / hs;
@@ -1017,14 +1026,14 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       gx /= gl; gy /= gl;
       // top of the wall this sphere is next to: one height per scene, or (walls of different heights) that of the wall nearest to
       // the sphere's own cell
-      const float wtop = m->wall_top != nullptr ? m->wall_top[(size_t)(tx < 0.5f ? ix : ix + 1) * ny + (ty < 0.5f ? iy : iy + 1)] : m->wall_height;
+      const float wtop = HP(HOT_WALL_TOP_LO) != nullptr ? HP(HOT_WALL_TOP_LO)[(size_t)(tx < 0.5f ? ix : ix + 1) * ny + (ty < 0.5f ? iy : iy + 1)] : HF(HOT_WALL_HEIGHT);
       const float dz = c.z - wtop;
       if (dz <= 0) {
         if (sh <= 0 && -sh > -dz) { wsd = dz - rad; wn = v3(0, 0, 1); }
         else { wsd = sh - rad; wn = v3(gx, gy, 0); }
       } else if (sh <= 0) { wsd = dz - rad; wn = v3(0, 0, 1); }
       else { const float dist = sqrtf(sh * sh + dz * dz); wsd = dist - rad; wn = v3(gx * sh / dist, gy * sh / dist, dz / dist); }
-      wflag = wsd < m->contact_offset;
+      wflag = wsd < HF(HOT_CONTACT_OFFSET);
       if (shp.n_static > 0 && act < A) {     // static scenery: the world-aligned box with the smallest signed distance
         const float I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
         const V3 nb = ld3(lds + L.root + A * 13);
@@ -1035,18 +1044,18 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
                                        v3(m->sb_half[bx][0], m->sb_half[bx][1], m->sb_half[bx][2]), nn);
           if (sdb < bsd) { bsd = sdb; bn = nn; }
         }
-        bflag = bsd < m->contact_offset;
+        bflag = bsd < HF(HOT_CONTACT_OFFSET);
       }
       if (SS && act < A) {
         const float I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
         bsd = sphere_box(c, rad, ssB, I3, v3(m->ss_base_half[0], m->ss_base_half[1], m->ss_base_half[2]), bn);
-        bflag = bsd < m->contact_offset && m->ss_base_half[0] > 0.0f;       // no platform: tug-of-war slider
+        bflag = bsd < HF(HOT_CONTACT_OFFSET) && m->ss_base_half[0] > 0.0f;       // no platform: tug-of-war slider
         const float dx = c.x - ssB.x, dy = c.y - ssB.y, rho = sqrtf(dx * dx + dy * dy);
-        if (c.z < ssB.z && c.z > ssB.z - m->ss_col_length && rho > 1e-6f) { csd = rho - m->ss_col_radius - rad; cn3 = v3(dx / rho, dy / rho, 0); cflag = csd < m->contact_offset; }
+        if (c.z < ssB.z && c.z > ssB.z - m->ss_col_length && rho > 1e-6f) { csd = rho - m->ss_col_radius - rad; cn3 = v3(dx / rho, dy / rho, 0); cflag = csd < HF(HOT_CONTACT_OFFSET); }
       }
     }
     const unsigned long long bg = gballot(gflag), bw2 = gballot(wflag), bb2 = gballot(bflag), bc2 = gballot(cflag);
-    const unsigned long long be = m->edge_mask != 0 ? gballot(eflag) : 0ull;     // edge contacts: behind ALL feature contacts of their robot
+    const unsigned long long be = HI(HOT_EDGE_MASK) != 0 ? gballot(eflag) : 0ull;     // edge contacts: behind ALL feature contacts of their robot
     const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const unsigned long long gl = gm & lower;
     const int pre = __popcll(bg & gl) + __popcll(bw2 & gl) + __popcll(bb2 & gl) + __popcll(bc2 & gl);   // rank in my actor
@@ -1126,14 +1135,14 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       uq = mat_vec(Rr, v3(rm.prim_axis[q][0], rm.prim_axis[q][1], rm.prim_axis[q][2]));
       // screen: the primitive's bounding sphere against the box's (a point inside the box passes too)
       const V3 dd = cq - bc;
-      const float reach = rm.prim_bound[q] + m->contact_offset + sqrtf(dot(hbx, hbx));
+      const float reach = rm.prim_bound[q] + HF(HOT_CONTACT_OFFSET) + sqrtf(dot(hbx, hbx));
       valid = dot(dd, dd) < reach * reach;
     }
     if (gballot(valid) == 0ull) return;
     bool hit = false; float sd = 0; V3 n = v3(0, 0, 1), pa = v3(0, 0, 0);
     if (valid) {
       const float I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-      hit = edge_vs_box_dev(MQE_PRIM_CAPSULE, cq, uq, rm.prim_half[q][0], v3(0, 0, 0), I9, m->prim_feat_t[q][0], m->prim_feat_t[q][1], bc, Rbx, hbx, false, sd, n, pa) && sd < m->contact_offset;
+      hit = edge_vs_box_dev(MQE_PRIM_CAPSULE, cq, uq, rm.prim_half[q][0], v3(0, 0, 0), I9, m->prim_feat_t[q][0], m->prim_feat_t[q][1], bc, Rbx, hbx, false, sd, n, pa) && sd < HF(HOT_CONTACT_OFFSET);
     }
     const unsigned long long bh = gballot(hit);
     if (bh == 0ull) return;
@@ -1159,7 +1168,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
         body = rm.sphere_body[lane]; rep = a * MQE_NREP + rm.sphere_reported[lane];
         sd = m->ss_link_cyl ? sphere_vcyl(c, rad, ssC, m->ss_plank_half[0], m->ss_plank_half[2], n)
                             : sphere_box(c, rad, ssC, ssR, v3(m->ss_plank_half[0], m->ss_plank_half[1], m->ss_plank_half[2]), n);
-        hit = sd < m->contact_offset;
+        hit = sd < HF(HOT_CONTACT_OFFSET);
       }
       const unsigned long long bh = gballot(hit);
       const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -1172,7 +1181,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       if (tot > capP) { tot = capP; ovf = 1; }
       nc += tot;
       if (nc > pair_lim) { nc = pair_lim; ovf = 1; }
-      if ((m->edge_mask & 2) != 0 && !m->ss_link_cyl)
+      if ((HI(HOT_EDGE_MASK) & 2) != 0 && !m->ss_link_cyl)
         pair_edges(a, ssC, ssR, v3(m->ss_plank_half[0], m->ss_plank_half[1], m->ss_plank_half[2]), A, A * MQE_NREP + 1, capP - tot);
     }
   }
@@ -1183,7 +1192,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     // pairs of two NPCs of one or two spheres (a flock) are tested lane-parallel, 64 sphere pairs per pass, after the robots' pairs:
     // in the canonical order (a, b, sphere of b, sphere of a) they come last anyway, and 36 wave-uniform iterations for 9 sheep
     // were a third of this phase
-    const bool npc_pass = PD > 1 && m->npc_n_spheres <= 2 && !shp.has_box;
+    const bool npc_pass = PD > 1 && HI(HOT_NPC_N_SPHERES) <= 2 && !shp.has_box;
     const int a_end = npc_pass ? A : nact;
     int tp = -1;
     for (int a = 0; a < a_end; a++)
@@ -1198,7 +1207,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
             const float* spa = lds + L.sph + (a * nsr + lane) * 4;
             { const float4 q = *reinterpret_cast<const float4*>(spa); c = v3(q.x, q.y, q.z); ra = q.w; }
             sd = sphere_box(c, ra, pb, brec + B_R, v3(m->npc_box_half[0], m->npc_box_half[1], m->npc_box_half[2]), n);
-            hit = sd < m->contact_offset;
+            hit = sd < HF(HOT_CONTACT_OFFSET);
           }
           const unsigned long long bh = gballot(hit);
           const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -1220,7 +1229,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
             if (lane < 8) {
               const V3 cw = pb + mat_vec(brec + B_R, v3((lane & 4) ? hbx.x : -hbx.x, (lane & 2) ? hbx.y : -hbx.y, (lane & 1) ? hbx.z : -hbx.z));
               const V3 db = cw - pbase;
-              const float reach = rm.feature_reach + m->contact_offset;
+              const float reach = HF(HOT_FEATURE_REACH) + HF(HOT_CONTACT_OFFSET);
               nearc = !(dot(db, db) > reach * reach);
             }
             cmask = gballot(nearc);
@@ -1229,7 +1238,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
             float4 w0 = make_float4(0, 0, 0, 0), w1 = w0; int pbody = 0, prep = 0; V3 ph = v3(0, 0, 0);
             if (lane < npr) {
               const float4* pw = reinterpret_cast<const float4*>(lds + L.prim) + (a * npr + lane);
-              w0 = pw[0]; w1 = pw[m->nprim_env];
+              w0 = pw[0]; w1 = pw[HI(HOT_NPRIM_ENV)];
               pbody = rm.prim_body[lane]; prep = rm.prim_reported[lane];
               ph = v3(rm.prim_half[lane][0], rm.prim_half[lane][1], rm.prim_half[lane][2]);
             }
@@ -1243,10 +1252,10 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
                 const V3 cq = v3(w0.x, w0.y, w0.z);
                 if (w1.w < 0.0f) {
                   sd2 = sphere_box(cc, 0.0f, cq, lds + L.body + (a * MQE_NBODY + pbody) * BODY_STRIDE + B_R, ph, n2);
-                  hit2 = sd2 < m->contact_offset;
+                  hit2 = sd2 < HF(HOT_CONTACT_OFFSET);
                 } else {
                   const bool ok = sphere_capsule(cc, 0.0f, cq, v3(w1.x, w1.y, w1.z), w1.w, sd2, n2);
-                  hit2 = ok && sd2 < m->contact_offset;
+                  hit2 = ok && sd2 < HF(HOT_CONTACT_OFFSET);
                 }
               }
               const unsigned long long bh2 = gballot(hit2);
@@ -1260,7 +1269,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
               if (nc > pair_lim) { nc = pair_lim; ovf = 1; }
             }
           }
-          if ((m->edge_mask & 2) != 0)
+          if ((HI(HOT_EDGE_MASK) & 2) != 0)
             pair_edges(a, pb, brec + B_R, v3(m->npc_box_half[0], m->npc_box_half[1], m->npc_box_half[2]), b, A * MQE_NREP + (b - A), 64);
           continue;
         }
@@ -1274,7 +1283,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
             if (lane < nsr) {
               const float4 qf = *reinterpret_cast<const float4*>(lds + L.sph + (fa * nsr + lane) * 4);
               c = v3(qf.x, qf.y, qf.z); ra = qf.w;
-              foot = ((m->feat_sphere_mask >> lane) & 1ull) != 0ull;
+              foot = ((HMASK() >> lane) & 1ull) != 0ull;
             }
             // which primitives of qa reach into the ball around fa's base that holds all of fa's feature points in THIS pose (its
             // radius: a maximum over the feature lanes; lane = primitive, one ballot): two robots walking side by side normally
@@ -1288,7 +1297,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
               if (lane < npr) {
                 const float4 w0 = reinterpret_cast<const float4*>(lds + L.prim)[qa * npr + lane];
                 const V3 df = v3(w0.x, w0.y, w0.z) - pbase;
-                const float reach = w0.w + rfeat + m->contact_offset;
+                const float reach = w0.w + rfeat + HF(HOT_CONTACT_OFFSET);
                 act = dot(df, df) < reach * reach;
               }
               qmask = gballot(act);
@@ -1297,11 +1306,11 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
               const int q = __ffsll((long long)qmask) - 1;
               qmask &= qmask - 1ull;
               const float4* pw = reinterpret_cast<const float4*>(lds + L.prim) + (qa * npr + q);
-              const float4 w0 = pw[0], w1 = pw[m->nprim_env];
+              const float4 w0 = pw[0], w1 = pw[HI(HOT_NPRIM_ENV)];
               const V3 cq = v3(w0.x, w0.y, w0.z);
               const bool qbox = w1.w < 0.0f, qsph = !qbox && w1.x == 0.0f && w1.y == 0.0f && w1.z == 0.0f;      // wave-uniform
               const V3 dq = c - cq;
-              const float reach = ra + w0.w + m->contact_offset;
+              const float reach = ra + w0.w + HF(HOT_CONTACT_OFFSET);
               bool cand = lane < nsr && dot(dq, dq) < reach * reach && !(dir == 1 && foot && qsph);
               if (gballot(cand) == 0ull) continue;
               bool hit = false; float sd = 0; V3 n = v3(0, 0, 1);
@@ -1309,10 +1318,10 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
                 if (qbox) {
                   sd = sphere_box(c, ra, cq, lds + L.body + (qa * MQE_NBODY + rm.prim_body[q]) * BODY_STRIDE + B_R,
                                   v3(rm.prim_half[q][0], rm.prim_half[q][1], rm.prim_half[q][2]), n);
-                  hit = sd < m->contact_offset;
+                  hit = sd < HF(HOT_CONTACT_OFFSET);
                 } else {
                   const bool ok = sphere_capsule(c, ra, cq, v3(w1.x, w1.y, w1.z), w1.w, sd, n);
-                  hit = ok && sd < m->contact_offset;
+                  hit = ok && sd < HF(HOT_CONTACT_OFFSET);
                 }
               }
               const unsigned long long bh = gballot(hit);
@@ -1333,11 +1342,11 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
         if (a < A) {
           // robot a against the collision spheres of free NPC b (ball, sheep): lanes = the robot's primitives, one sphere of b per
           // iteration; the contact's normal points from B (the NPC) to A
-          const int nb = m->npc_n_spheres, ob = A * nsr + (b - A) * m->npc_n_spheres;
+          const int nb = HI(HOT_NPC_N_SPHERES), ob = A * nsr + (b - A) * HI(HOT_NPC_N_SPHERES);
           float4 w0 = make_float4(0, 0, 0, 0), w1 = w0; int ptype = MQE_PRIM_SPHERE, pbody = 0, prep = 0; V3 ph = v3(0, 0, 0);
           if (lane < npr) {
             const float4* pw = reinterpret_cast<const float4*>(lds + L.prim) + (a * npr + lane);
-            w0 = pw[0]; w1 = pw[m->nprim_env];
+            w0 = pw[0]; w1 = pw[HI(HOT_NPRIM_ENV)];
             ptype = w1.w < 0.0f ? MQE_PRIM_BOX : MQE_PRIM_CAPSULE; pbody = rm.prim_body[lane]; prep = rm.prim_reported[lane];
             ph = v3(rm.prim_half[lane][0], rm.prim_half[lane][1], rm.prim_half[lane][2]);
           }
@@ -1349,10 +1358,10 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
               const V3 cq = v3(w0.x, w0.y, w0.z);
               if (ptype == MQE_PRIM_BOX) {
                 sd = sphere_box(cb, rb, cq, lds + L.body + (a * MQE_NBODY + pbody) * BODY_STRIDE + B_R, ph, n);
-                hit = sd < m->contact_offset;
+                hit = sd < HF(HOT_CONTACT_OFFSET);
               } else {
                 const bool ok = sphere_capsule(cb, rb, cq, v3(w1.x, w1.y, w1.z), w1.w, sd, n);
-                hit = ok && sd < m->contact_offset;
+                hit = ok && sd < HF(HOT_CONTACT_OFFSET);
               }
             }
             const unsigned long long bh = gballot(hit);
@@ -1368,9 +1377,9 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
           }
           continue;
         }
-        const int na = m->npc_n_spheres, nb = m->npc_n_spheres;        // two free NPCs: sphere pairs (flocks take the lane-parallel pass below)
-        const int oa = A * nsr + (a - A) * m->npc_n_spheres;
-        const int ob = A * nsr + (b - A) * m->npc_n_spheres;
+        const int na = HI(HOT_NPC_N_SPHERES), nb = HI(HOT_NPC_N_SPHERES);        // two free NPCs: sphere pairs (flocks take the lane-parallel pass below)
+        const int oa = A * nsr + (a - A) * HI(HOT_NPC_N_SPHERES);
+        const int ob = A * nsr + (b - A) * HI(HOT_NPC_N_SPHERES);
         for (int sb = 0; sb < nb; sb++) {
           const float* spb = lds + L.sph + (ob + sb) * 4;
           const float4 qb = *reinterpret_cast<const float4*>(spb);
@@ -1381,7 +1390,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
             { const float4 q = *reinterpret_cast<const float4*>(spa); ev = v3(q.x, q.y, q.z) - cb; ra = q.w; }
             dist = sqrtf(dot(ev, ev));
             sd = dist - ra - rb;
-            hit = sd < m->contact_offset && dist > 1e-9f;
+            hit = sd < HF(HOT_CONTACT_OFFSET) && dist > 1e-9f;
           }
           const unsigned long long bh = gballot(hit);
           if (bh == 0ull) continue;
@@ -1397,7 +1406,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
         }
       }
     if (npc_pass) {
-      const int ns = m->npc_n_spheres, ns2 = ns * ns;
+      const int ns = HI(HOT_NPC_N_SPHERES), ns2 = ns * ns;
       const int np2 = ((PD * (PD - 1)) / 2) * ns2;
       for (int t0 = 0; t0 < np2; t0 += LW) {
         const int t = t0 + lane;
@@ -1413,7 +1422,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
           ev = v3(qa.x, qa.y, qa.z) - cb;
           dist = sqrtf(dot(ev, ev));
           sd = dist - qa.w - rb;
-          hit = sd < m->contact_offset && dist > 1e-9f;
+          hit = sd < HF(HOT_CONTACT_OFFSET) && dist > 1e-9f;
         }
         const unsigned long long bh = gballot(hit);
         if (bh == 0ull) continue;
@@ -1431,11 +1440,11 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     // links of one robot against each other (asset.self_collisions = 0): lanes = the model's candidate (feature point, primitive)
     // pairs (links neither the same nor adjacent, reachable inside the joint limits), 64 per pass; both contact sides belong to the
     // same actor.  Last in the list: they only take the two-actor slots that the contacts with other actors left over.
-    if (m->self_collision && self_todo != 0u)
-      for (int ac = 0; ac < A * ((rm.n_self_pairs + SELF_CHUNK - 1) / SELF_CHUNK); ac++) {      // robot by robot, each robot chunk by chunk (list order)
-        const int nchunk = (rm.n_self_pairs + SELF_CHUNK - 1) / SELF_CHUNK;
+    if (HI(HOT_SELF_COLLISION) && self_todo != 0u)
+      for (int ac = 0; ac < A * ((HI(HOT_N_SELF_PAIRS) + SELF_CHUNK - 1) / SELF_CHUNK); ac++) {      // robot by robot, each robot chunk by chunk (list order)
+        const int nchunk = (HI(HOT_N_SELF_PAIRS) + SELF_CHUNK - 1) / SELF_CHUNK;
         const int a = ac / nchunk, chunk0 = (ac - a * nchunk) * SELF_CHUNK;
-        const int npairs = min(rm.n_self_pairs - chunk0, SELF_CHUNK);          // candidates of this chunk
+        const int npairs = min(HI(HOT_N_SELF_PAIRS) - chunk0, SELF_CHUNK);          // candidates of this chunk
         // joint-space screen (above): inside the model's safe box of joint angles no candidate pair is closer than 4 cm
         if (!((self_todo >> a) & 1u)) continue;
         if (nchunk > 1) {                                                      // (a one-chunk model keeps the entries requested at the top)
@@ -1455,12 +1464,12 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
           const int pr = selfp[k] < 0 ? 0 : selfp[k];
           si4[k] = *reinterpret_cast<const float4*>(sp0 + (pr & 255) * 4);
           sj4[k] = pp0[pr >> 8];
-          const float4 uj = pp0[m->nprim_env + (pr >> 8)];
+          const float4 uj = pp0[HI(HOT_NPRIM_ENV) + (pr >> 8)];
           const V3 u = v3(uj.x, uj.y, uj.z), dq = v3(si4[k].x - sj4[k].x, si4[k].y - sj4[k].y, si4[k].z - sj4[k].z);
           const float uu = dot(u, u);
           const float t = uu > 0.0f ? fminf(fmaxf(dot(dq, u) * __builtin_amdgcn_rcpf(uu), -1.0f), 1.0f) : 0.0f;
           const V3 e = dq - t * u;
-          const float lim = si4[k].w + fabsf(uj.w) + m->contact_offset + 1e-5f;                                       // (+ the screen's own rounding)
+          const float lim = si4[k].w + fabsf(uj.w) + HF(HOT_CONTACT_OFFSET) + 1e-5f;                                       // (+ the screen's own rounding)
           any |= (int)(selfp[k] >= 0) & (int)(dot(e, e) < lim * lim);
         }
         if (gballot(any != 0) == 0ull) continue;
@@ -1472,14 +1481,14 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
             f = selfp[k] & 255; q = selfp[k] >> 8;
             c = v3(si4[k].x, si4[k].y, si4[k].z); ra = si4[k].w;
             const V3 cq = v3(sj4[k].x, sj4[k].y, sj4[k].z);
-            const float4 w1 = pp0[m->nprim_env + q];
+            const float4 w1 = pp0[HI(HOT_NPRIM_ENV) + q];
             if (w1.w < 0.0f) {
               sd = sphere_box(c, ra, cq, lds + L.body + (a * MQE_NBODY + rm.prim_body[q]) * BODY_STRIDE + B_R,
                               v3(rm.prim_half[q][0], rm.prim_half[q][1], rm.prim_half[q][2]), n);
-              hit = sd < m->contact_offset;
+              hit = sd < HF(HOT_CONTACT_OFFSET);
             } else {
               const bool ok = sphere_capsule(c, ra, cq, v3(w1.x, w1.y, w1.z), w1.w, sd, n);
-              hit = ok && sd < m->contact_offset;
+              hit = ok && sd < HF(HOT_CONTACT_OFFSET);
             }
           }
           const unsigned long long bh = gballot(hit);
@@ -1503,8 +1512,8 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   // Per side the columns are [base lin xyz, base ang xyz, the <=3 joints of the chain to the touching link] (robot) or
   // [lin xyz, (ang xyz)] (ball / sheep).  Column value in the contact frame: dirs . (axis x (p - anchor)) = (r x dirs) . axis.
   // friction of a contact: the shapes of a robot carry the env's (randomised) coefficient, averaged with the other shape's
-  // (terrain / objects: m->friction) as PhysX does; contacts without a robot keep m->friction
-  const float mu_robot = 0.5f * (mu_env + m->friction);
+  // (terrain / objects: HF(HOT_FRICTION)) as PhysX does; contacts without a robot keep HF(HOT_FRICTION)
+  const float mu_robot = 0.5f * (mu_env + HF(HOT_FRICTION));
   float* Vm = lds + L.rhs;           // v* (unconstrained velocity) over the consumed bias vector, read through the sparse Jacobian rows
   if (lane < ndof) Vm[lane] = vs0;
   if (lane + LW < ndof) Vm[lane + LW] = vs1;
@@ -1517,15 +1526,15 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   // solver 1 re-derives it between the sweeps, all contacts at once (lane = contact): sep += sdt (u*_n + Phi_n . w), bias = -sep / sdt
   // capped at the depenetration speed -- nothing is added to the 64 dependent steps of the sweep.  Velocity iterations (either solver)
   // see a penetration as touching.  W itself is only needed for the positions at the end: a register per lane (coordinates lane, lane + LW).
-  const bool tgs = m->solver_type == 1;
-  const int npos = m->solver_iterations, nsweeps = npos + m->vel_iters;
+  const bool tgs = HI(HOT_SOLVER_TYPE) == 1;
+  const int npos = HI(HOT_SOLVER_ITERATIONS), nsweeps = npos + HI(HOT_VEL_ITERS);
   const float sdt = tgs ? dt / (float)npos : dt, inv_sdt = 1.0f / sdt;
   float* waccv = lds + L.wacc;
   auto first_bias = [&](float sd) -> float {
-    if (!tgs) return sd >= 0 ? -sd / dt : (npos > 0 ? fminf(-sd * m->erp / dt, m->max_depen) : 0.0f);
+    if (!tgs) return sd >= 0 ? -sd / dt : (npos > 0 ? fminf(-sd * HF(HOT_ERP) / dt, HF(HOT_MAX_DEPEN)) : 0.0f);
     const float s0 = npos > 0 ? sd : fmaxf(sd, 0.0f);
     const float b = -s0 * inv_sdt;
-    return s0 < 0.0f ? fminf(b, m->max_depen) : b;
+    return s0 < 0.0f ? fminf(b, HF(HOT_MAX_DEPEN)) : b;
   };
   // bias of sweep `it + 1` from the separation after sweep `it`; sep is advanced by the sub-step's normal motion sdt * un when sweep `it` was a position iteration
   auto next_bias = [&](float& sep, float un, float bias_now, int it) -> float {
@@ -1534,7 +1543,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     if (it < npos) sep += sdt * un;
     const float s2 = next_vel ? fmaxf(sep, 0.0f) : sep;
     const float b = -s2 * inv_sdt;
-    return s2 < 0.0f ? fminf(b, m->max_depen) : b;
+    return s2 < 0.0f ? fminf(b, HF(HOT_MAX_DEPEN)) : b;
   };
   float Wacc0 = 0.0f, Wacc1 = 0.0f;
   const bool is_con = lane < nc;
@@ -1543,7 +1552,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   int myA = -2, myB = -2;                                                   // actors of my contact's sides
   int wA = 0, wB = 0, infoA = 0, infoB = 0;                                  // first generalized coordinate of each side's actor; the side's info word
   int lgA = 0, lgB = 0;                                                     // leg + 1 of each side's touching link (0: base / not a robot)
-  float mu = m->friction;
+  float mu = HF(HOT_FRICTION);
   float fA[27];                                                             // Phi of my contact's side A (U 18, Z' 9): registers for the whole sweep
 #pragma unroll
   for (int i = 0; i < 27; i++) fA[i] = 0.0f;
@@ -1560,7 +1569,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     int infq[NPQ];
 #pragma unroll
     for (int ps = 0; ps < NPQ; ps++) {
-      usq[ps] = 0.0f; dqq[ps] = 0.0f; dqn[ps] = 0.0f; cbq[ps] = 0.0f; muq[ps] = m->friction; infq[ps] = 0; sdq[ps] = 0.0f;
+      usq[ps] = 0.0f; dqq[ps] = 0.0f; dqn[ps] = 0.0f; cbq[ps] = 0.0f; muq[ps] = HF(HOT_FRICTION); infq[ps] = 0; sdq[ps] = 0.0f;
 #pragma unroll
       for (int i = 0; i < 9; i++) rowA[ps][i] = 0.0f;
       const int c = ps * (LW / 4) + (lane >> 2);
@@ -2268,8 +2277,8 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
 
   // ---- net contact force per reported body (deterministic: contact order) ---------------------------------------------------
   if ((flags & PS_WRITE_CF) && evalid) {
-    float* g_cf = st.cf + (size_t)e * m->NBR * 3;
-    for (int rb = lane; rb < m->NBR; rb += LW) {
+    float* g_cf = st.cf + (size_t)e * HI(HOT_NBR) * 3;
+    for (int rb = lane; rb < HI(HOT_NBR); rb += LW) {
       V3 F = v3(0, 0, 0);
       for (int c = 0; c < nc; c++) {
         const float* cr = lds + L.con + c * CON_STRIDE;
@@ -2327,12 +2336,12 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
 
 __global__ void __launch_bounds__(64) k_simulate(const DevModel* __restrict__ m, DevState st, int env_base, int no_write, PhysDebug dbg) {
   extern __shared__ float lds[];
-  phys_substep<0, -1>(m, st, lds, env_base + blockIdx.x, threadIdx.x, PS_LOAD_STATE | PS_LOAD_TAU | PS_STORE_STATE | PS_WRITE_CF, no_write, dbg);
+  phys_substep<0, -1>(m, st, lds, env_base + blockIdx.x, threadIdx.x, PS_LOAD_STATE | PS_LOAD_TAU | PS_STORE_STATE | PS_WRITE_CF, no_write, dbg, (int)m->hot[threadIdx.x]);
 }
 // the same substep compiled for the two-robot, no-NPC shape (what k_substeps<2,0> runs): only the per-phase counter tool launches it
 __global__ void __launch_bounds__(64) k_simulate_a2(const DevModel* __restrict__ m, DevState st, int env_base, int no_write, PhysDebug dbg) {
   extern __shared__ float lds[];
-  phys_substep<2, 0>(m, st, lds, env_base + blockIdx.x, threadIdx.x, PS_LOAD_STATE | PS_LOAD_TAU | PS_STORE_STATE | PS_WRITE_CF, no_write, dbg);
+  phys_substep<2, 0>(m, st, lds, env_base + blockIdx.x, threadIdx.x, PS_LOAD_STATE | PS_LOAD_TAU | PS_STORE_STATE | PS_WRITE_CF, no_write, dbg, (int)m->hot[threadIdx.x]);
 }
 
 // ----------------------------------------------------------------------------------------------------------------------
@@ -2383,6 +2392,7 @@ __global__ void __launch_bounds__(64, EPW == 2 ? 2 : SubstepsClass<TP>::waves) k
   constexpr int launder = EPW == 2 ? 2 : SubstepsClass<TP>::launder;     // hoisting everything overflows even 256 VGPRs (43 spilled)
 #endif
   const int lane_wave = threadIdx.x, e_first = blockIdx.x * EPW;
+  const int hotv = (int)m->hot[lane_wave];        // DevModel::hot: the physics' wave-uniform constants, one entry per lane, read by v_readlane
   if (st.wave_times && lane_wave == 0) {      // MQE_WAVE_TIMES (tools/dev/wave_times.py): entry / exit time, HW_ID and XCC_ID of the wavefront
     st.wave_times[4 * blockIdx.x] = (long long)wall_clock64();
     st.wave_times[4 * blockIdx.x + 2] = (long long)__builtin_amdgcn_s_getreg(0xF804);
@@ -2531,10 +2541,10 @@ __global__ void __launch_bounds__(64, EPW == 2 ? 2 : SubstepsClass<TP>::waves) k
     if constexpr (TIMED) {
       long long* tt = st.wave_times + 4 * (size_t)gridDim.x + ((size_t)blockIdx.x * 4 + (k < 4 ? k : 3)) * 16;
       const PhysDebug tdbg = {nullptr, nullptr, nullptr, 0, tt, -1};
-      phys_substep<TA, TP, EPW>(mk, st, lds_wave, e_first, lane_k, last ? (PS_STORE_STATE | PS_WRITE_CF) : 0, 0, tdbg);
+      phys_substep<TA, TP, EPW>(mk, st, lds_wave, e_first, lane_k, last ? (PS_STORE_STATE | PS_WRITE_CF) : 0, 0, tdbg, hotv);
       if (lane_wave == 0) tt[15] = (long long)wall_clock64();
     } else
-    phys_substep<TA, TP, EPW>(mk, st, lds_wave, e_first, lane_k, last ? (PS_STORE_STATE | PS_WRITE_CF) : 0, 0, nodbg);
+    phys_substep<TA, TP, EPW>(mk, st, lds_wave, e_first, lane_k, last ? (PS_STORE_STATE | PS_WRITE_CF) : 0, 0, nodbg, hotv);
     // post_decimation_step (legged_robot.py:114-115): joint velocities and soft-limit flags after this substep, from the LDS state
     if (evalid)
       for (int jt = glane_k; jt < nj; jt += LW) {

@@ -512,7 +512,7 @@ __device__ __forceinline__ void sheep_apply(float* root, int A, int p, const flo
 // wrapper observation + reward for env e.  npc = the `root_states_npc` rows the wrapper sees ([P][13]); see oracle.
 // side_effects: 1 on the wrapper-level paths (mqe_step, mqe_wrapper_eval); the Go1-level mqe_post_physics_step passes 0 so that the
 // state stays exactly what Go1.step leaves (go1tug re-poses its slider from the wrapper)
-__device__ void wrapper_env_dev(const DevModel* m, const DevState& st, int e, int is_reset_call, const float* npc, int side_effects = 1, const float* bag = nullptr) {
+__device__ __forceinline__ void wrapper_env_dev(const DevModel* m, const DevState& st, int e, int is_reset_call, const float* npc, int side_effects = 1, const float* bag = nullptr) {
   if (!bag) bag = st.obs_bag + (size_t)e * m->A * MQE_OBS_BAG;   // this env's rows (k_post_physics passes its LDS copy)
   int A = m->A, P = m->P, Aw = m->Aw, D = m->D;
   float* obs = st.wobs + (size_t)e * Aw * D;

@@ -7,6 +7,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "../../include/mqe_hip.h"
 
@@ -59,6 +60,11 @@ struct DevModel {
   float base_vel_lo, base_vel_hi;
   float sheep_scale, sheep_rand;
   float reward_scale[MQE_MAX_REWARD_TERMS]; float wrapper_param[8];
+  // The wave-uniform constants the physics kernel reads in every substep, once more as ONE 64-entry table (bit patterns; pointers as two
+  // entries): k_substeps loads it with one coalesced request per launch -- lane i holds entry i -- and reads an entry with v_readlane
+  // where the field itself would be an s_load from this struct in every substep (the compiler does not keep ~40 of them in SGPRs across
+  // the loop: 106 are in use), i.e. a scalar-cache round trip at the head of most phases of a wavefront whose time is its chain of waits.
+  uint32_t hot[64];
   DevMlp actuator;
   // the actuator network's weights in the order k_substeps' lanes consume them, [fragment][lane] (64 floats = one coalesced 256 B load per
   // fragment instead of 64 lanes x a 128 B stride): fragments 0-15 = layer 2 rows (W1[(lane & 31) * 32 + u(r, lane >> 5)]), 16-18 = layer 1
@@ -67,6 +73,16 @@ struct DevModel {
   int nbody_env, ndof_env, nsph_env, nprim_env, maxc;
   unsigned long long feat_sphere_mask;                   // bit f: feature point f of the robot model belongs to a sphere primitive (a foot)
 };
+
+enum {   // DevModel::hot
+  HOT_DT = 0, HOT_GRAVITY_Z, HOT_CONTACT_OFFSET, HOT_FRICTION, HOT_MAX_DEPEN, HOT_ERP, HOT_HS, HOT_WALL_HEIGHT, HOT_GROUND_Z, HOT_FEATURE_REACH,
+  HOT_SDF_NX, HOT_SDF_NY, HOT_EDGE_MASK, HOT_SOLVER_TYPE, HOT_SOLVER_ITERATIONS, HOT_VEL_ITERS, HOT_SELF_COLLISION, HOT_NSPH_ENV, HOT_NPRIM_ENV,
+  HOT_N, HOT_NBR, HOT_N_SPHERES, HOT_N_PRIMS, HOT_N_SELF_PAIRS, HOT_CAP_NPC, HOT_NPC_N_SPHERES, HOT_FEAT_MASK_LO, HOT_FEAT_MASK_HI,
+  HOT_WALL_SDF_LO, HOT_WALL_SDF_HI, HOT_GROUND_HEIGHT_LO, HOT_GROUND_HEIGHT_HI, HOT_WALL_TOP_LO, HOT_WALL_TOP_HI, HOT_WALL_CORNER_LO, HOT_WALL_CORNER_HI,
+  HOT_COUNT
+};
+static_assert(HOT_COUNT <= 64, "DevModel::hot");
+__host__ inline void mqe_fill_hot(struct DevModel& m);
 
 // device pointers of all state tensors (kernel argument by value)
 struct DevState {
@@ -133,3 +149,21 @@ __host__ __device__ __forceinline__ void split2(float x, float scale, uint16_t& 
 }
 // element offset of (row-local element k, plane p) in the plane-interleaved layout of k_gemm_h2
 __host__ __device__ __forceinline__ size_t h2_index(size_t k, int p) { return ((k >> 3) * 2 + p) * 8 + (k & 7); }
+
+__host__ inline void mqe_fill_hot(DevModel& m) {
+  auto f = [](float x) { uint32_t u; memcpy(&u, &x, 4); return u; };
+  auto lo = [](const void* p) { return (uint32_t)((uintptr_t)p & 0xFFFFFFFFull); };
+  auto hi = [](const void* p) { return (uint32_t)((uintptr_t)p >> 32); };
+  memset(m.hot, 0, sizeof m.hot);
+  m.hot[HOT_DT] = f(m.dt); m.hot[HOT_GRAVITY_Z] = f(m.gravity_z); m.hot[HOT_CONTACT_OFFSET] = f(m.contact_offset); m.hot[HOT_FRICTION] = f(m.friction);
+  m.hot[HOT_MAX_DEPEN] = f(m.max_depen); m.hot[HOT_ERP] = f(m.erp); m.hot[HOT_HS] = f(m.hs); m.hot[HOT_WALL_HEIGHT] = f(m.wall_height);
+  m.hot[HOT_GROUND_Z] = f(m.ground_z); m.hot[HOT_FEATURE_REACH] = f(m.robot.feature_reach);
+  m.hot[HOT_SDF_NX] = (uint32_t)m.sdf_nx; m.hot[HOT_SDF_NY] = (uint32_t)m.sdf_ny; m.hot[HOT_EDGE_MASK] = (uint32_t)m.edge_mask;
+  m.hot[HOT_SOLVER_TYPE] = (uint32_t)m.solver_type; m.hot[HOT_SOLVER_ITERATIONS] = (uint32_t)m.solver_iterations; m.hot[HOT_VEL_ITERS] = (uint32_t)m.vel_iters;
+  m.hot[HOT_SELF_COLLISION] = (uint32_t)m.self_collision; m.hot[HOT_NSPH_ENV] = (uint32_t)m.nsph_env; m.hot[HOT_NPRIM_ENV] = (uint32_t)m.nprim_env;
+  m.hot[HOT_N] = (uint32_t)m.N; m.hot[HOT_NBR] = (uint32_t)m.NBR; m.hot[HOT_N_SPHERES] = (uint32_t)m.robot.n_spheres; m.hot[HOT_N_PRIMS] = (uint32_t)m.robot.n_prims;
+  m.hot[HOT_N_SELF_PAIRS] = (uint32_t)m.robot.n_self_pairs; m.hot[HOT_CAP_NPC] = (uint32_t)m.cap_npc; m.hot[HOT_NPC_N_SPHERES] = (uint32_t)m.npc_n_spheres;
+  m.hot[HOT_FEAT_MASK_LO] = (uint32_t)(m.feat_sphere_mask & 0xFFFFFFFFull); m.hot[HOT_FEAT_MASK_HI] = (uint32_t)(m.feat_sphere_mask >> 32);
+  m.hot[HOT_WALL_SDF_LO] = lo(m.wall_sdf); m.hot[HOT_WALL_SDF_HI] = hi(m.wall_sdf); m.hot[HOT_GROUND_HEIGHT_LO] = lo(m.ground_height); m.hot[HOT_GROUND_HEIGHT_HI] = hi(m.ground_height);
+  m.hot[HOT_WALL_TOP_LO] = lo(m.wall_top); m.hot[HOT_WALL_TOP_HI] = hi(m.wall_top); m.hot[HOT_WALL_CORNER_LO] = lo(m.wall_corner); m.hot[HOT_WALL_CORNER_HI] = hi(m.wall_corner);
+}

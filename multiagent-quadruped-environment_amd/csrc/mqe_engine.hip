@@ -577,6 +577,7 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   }
   DevModel* dmp;
   if (dalloc(s, &dmp, 1)) return fail(-5, "alloc");
+  mqe_fill_hot(m);
   HIPCHK(hipMemcpy(dmp, &m, sizeof m, hipMemcpyHostToDevice));
   s->dm = dmp;
   void** t = s->tens;
