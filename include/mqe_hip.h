@@ -188,7 +188,7 @@ typedef struct {
    * (x, y) of the nearest convex corner of the wall set, [sdf_nx][sdf_ny][2] host pointer, or NULL) against the robots' primitives --
    * a capsule's axis against the edge, the edge against a box primitive's faces; 2 = the robots' capsule axes against the oriented
    * boxes of the scene (1-dof link plank / door, free box, scenery boxes): the closest point of the whole segment, not of its two end
-   * points; 4 = the twelve edges of those boxes against the robots' box primitives.  The closest approach of a segment to a convex box
+   * points; 4 = the twelve edges of those boxes against the robots' box primitives (off by default: desc builder default 3).  The closest approach of a segment to a convex box
    * is a one-dimensional convex minimisation: both engines run the same 18-evaluation golden-section search.  Such a contact is kept
    * when it lies BETWEEN feature points (segment parameter inside 5 .. 95 %); 0 = round 3's behaviour. */
   int32_t edge_contacts;

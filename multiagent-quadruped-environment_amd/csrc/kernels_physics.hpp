@@ -186,6 +186,31 @@ __device__ __forceinline__ bool edge_vs_box_dev(int ptype, V3 cq, V3 uq, float r
   return true;
 }
 
+// desc.edge_contacts bit 4 (oracle/mqe_oracle.c::edge_vs_box, box primitives): the twelve edges of a convex box (centre bc, rotation R, half
+// extents h) against a BOX primitive of a robot (centre cq, rotation Rb, half extents hb) -- an edge of the plank / the free box / a scenery
+// box cutting into the trunk between its corners.  Per edge the closest approach of the segment to the primitive (seg_box_dev, radius 0),
+// kept between the edge's end points (5 .. 95 %: the ends are the box's corners) and not deeper than 2 cm (tunnelled: left to the feature
+// points); the deepest edge wins.  n points from the obstacle to the robot, pa is the edge point.
+__device__ __forceinline__ bool box_edges_vs_prim_dev(V3 cq, V3 hb, const float* Rb, V3 bc, const float* R, V3 h, float& sd, V3& n, V3& pa) {
+  bool found = false;
+#pragma clang loop unroll(disable)
+  for (int e = 0; e < 12; e++) {
+    const int ax = e >> 2;                                    // the edge runs along axis ax; bits 0, 1: the signs of the two other coordinates
+    const float s1 = (e & 1) ? 1.0f : -1.0f, s2 = (e & 2) ? 1.0f : -1.0f;
+    // component c of the end points: -+h_c along the edge's axis, s1 h_c on axis (ax + 1) % 3, s2 h_c on axis (ax + 2) % 3
+    const float x0 = ax == 0 ? -h.x : (ax == 2 ? s1 : s2) * h.x, x1 = ax == 0 ? h.x : x0;
+    const float y0 = ax == 1 ? -h.y : (ax == 0 ? s1 : s2) * h.y, y1 = ax == 1 ? h.y : y0;
+    const float z0 = ax == 2 ? -h.z : (ax == 1 ? s1 : s2) * h.z, z1 = ax == 2 ? h.z : z0;
+    const V3 p0 = bc + mat_vec(R, v3(x0, y0, z0)), p1 = bc + mat_vec(R, v3(x1, y1, z1));
+    float tb; V3 nn, pt;
+    const float v = seg_box_dev(p0, p1, 0.0f, cq, Rb, hb, tb, nn, pt);
+    if (!(tb > 0.05f && tb < 0.95f)) continue;
+    if (v < -0.02f) continue;
+    if (!found || v < sd) { found = true; sd = v; n = v3(-nn.x, -nn.y, -nn.z); pa = pt; }
+  }
+  return found;
+}
+
 __device__ __forceinline__ float wave_sum(float x) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
@@ -913,7 +938,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     // world"): lane = primitive of the lane's robot; per primitive the deepest of the nearest vertical wall edge and the scenery boxes.
     // Computed first, ranked behind the robot's feature contacts below.
     bool eflag = false; float esd = 1e3f; V3 en = v3(0, 0, 1), epa = v3(0, 0, 0); int ebody = 0, erep = 0;
-    bool edge_pass = rob && (HI(HOT_EDGE_MASK) & 2) != 0 && shp.n_static > 0;
+    bool edge_pass = rob && (HI(HOT_EDGE_MASK) & 6) != 0 && shp.n_static > 0;
     if (rob && !edge_pass && (HI(HOT_EDGE_MASK) & 1) != 0 && HP(HOT_WALL_CORNER_LO) != nullptr) {
       // is any robot of the pass within reach of a wall edge at all?  One look-up per robot (its base's raster point): no primitive
       // reaches farther from the base than feature_reach, so a corner beyond that + the margin of the map's nearest-of-four choice is out
@@ -947,7 +972,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       }
       const float reach = rm.prim_bound[q] + HF(HOT_CONTACT_OFFSET);
       const float I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-      const int njobs = 1 + ((HI(HOT_EDGE_MASK) & 2) ? shp.n_static : 0);
+      const int njobs = 1 + ((HI(HOT_EDGE_MASK) & 6) ? shp.n_static : 0);
       for (int j = 0; j < njobs; j++) {
         bool valid = false; V3 bc = v3(0, 0, 0), hh = v3(0, 0, 0);
         if (j == 0) {
@@ -969,7 +994,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
               valid = true;
             }
           }
-        } else if (isp && ptype == MQE_PRIM_CAPSULE) {
+        } else if (isp && (ptype == MQE_PRIM_CAPSULE ? (HI(HOT_EDGE_MASK) & 2) != 0 : (HI(HOT_EDGE_MASK) & 4) != 0)) {      // capsule axes (bit 2) / box primitives (bit 4)
           const V3 nb = ld3(lds + L.root + A * 13);
           bc = nb + v3(m->sb_center[j - 1][0], m->sb_center[j - 1][1], m->sb_center[j - 1][2]);
           hh = v3(m->sb_half[j - 1][0], m->sb_half[j - 1][1], m->sb_half[j - 1][2]);
@@ -978,7 +1003,9 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
         if (gballot(valid) == 0ull) continue;                 // (wave-wide skip: nobody near a wall edge / this box)
         if (valid) {
           float sdj; V3 nj, pj;
-          if (edge_vs_box_dev(ptype, cq, uq, hb.x, hb, Rb, m->prim_feat_t[q][0], m->prim_feat_t[q][1], bc, I3, hh, j == 0, sdj, nj, pj) && (!eflag || sdj < esd)) {
+          const bool got = (j > 0 && ptype == MQE_PRIM_BOX) ? box_edges_vs_prim_dev(cq, hb, Rb, bc, I3, hh, sdj, nj, pj)
+                                                            : edge_vs_box_dev(ptype, cq, uq, hb.x, hb, Rb, m->prim_feat_t[q][0], m->prim_feat_t[q][1], bc, I3, hh, j == 0, sdj, nj, pj);
+          if (got && (!eflag || sdj < esd)) {
             eflag = true; esd = sdj; en = nj; epa = pj;
           }
         }
@@ -1123,14 +1150,16 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   // bit 2; oracle: "... and the plank's / door's edges", "... and its edges against the robot's primitives"): the closest approach of the
   // capsule's whole axis.  `room` = how many more contacts this robot may add (the plank's per-robot share), actor / reported body of the box.
   auto pair_edges = [&](int a, V3 bc, const float* Rbx, V3 hbx, int actB, int repB, int room) {
-    const bool isp = lane < npr && rm.prim_type[lane < npr ? lane : 0] == MQE_PRIM_CAPSULE;
+    const int ptq = rm.prim_type[lane < npr ? lane : 0];
+    const bool isp = lane < npr && (ptq == MQE_PRIM_CAPSULE ? (HI(HOT_EDGE_MASK) & 2) != 0 : (ptq == MQE_PRIM_BOX && (HI(HOT_EDGE_MASK) & 4) != 0));
     const int q = isp ? lane : 0;
     V3 cq = v3(0, 0, 0), uq = v3(0, 0, 0);
+    float Rr[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     bool valid = false;
     if (isp) {
       const float* rec = lds + L.body + (a * MQE_NBODY + rm.prim_body[q]) * BODY_STRIDE;
       const float4 q0 = reinterpret_cast<const float4*>(rec)[0], q1 = reinterpret_cast<const float4*>(rec)[1], q2 = reinterpret_cast<const float4*>(rec)[2];
-      const float Rr[9] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x};
+      Rr[0] = q0.x; Rr[1] = q0.y; Rr[2] = q0.z; Rr[3] = q0.w; Rr[4] = q1.x; Rr[5] = q1.y; Rr[6] = q1.z; Rr[7] = q1.w; Rr[8] = q2.x;
       cq = v3(q2.y, q2.z, q2.w) + mat_vec(Rr, v3(rm.prim_center[q][0], rm.prim_center[q][1], rm.prim_center[q][2]));
       uq = mat_vec(Rr, v3(rm.prim_axis[q][0], rm.prim_axis[q][1], rm.prim_axis[q][2]));
       // screen: the primitive's bounding sphere against the box's (a point inside the box passes too)
@@ -1142,7 +1171,9 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     bool hit = false; float sd = 0; V3 n = v3(0, 0, 1), pa = v3(0, 0, 0);
     if (valid) {
       const float I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-      hit = edge_vs_box_dev(MQE_PRIM_CAPSULE, cq, uq, rm.prim_half[q][0], v3(0, 0, 0), I9, m->prim_feat_t[q][0], m->prim_feat_t[q][1], bc, Rbx, hbx, false, sd, n, pa) && sd < HF(HOT_CONTACT_OFFSET);
+      hit = (ptq == MQE_PRIM_BOX ? box_edges_vs_prim_dev(cq, v3(rm.prim_half[q][0], rm.prim_half[q][1], rm.prim_half[q][2]), Rr, bc, Rbx, hbx, sd, n, pa)
+                                 : edge_vs_box_dev(MQE_PRIM_CAPSULE, cq, uq, rm.prim_half[q][0], v3(0, 0, 0), I9, m->prim_feat_t[q][0], m->prim_feat_t[q][1], bc, Rbx, hbx, false, sd, n, pa))
+            && sd < HF(HOT_CONTACT_OFFSET);
     }
     const unsigned long long bh = gballot(hit);
     if (bh == 0ull) return;
@@ -1181,7 +1212,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       if (tot > capP) { tot = capP; ovf = 1; }
       nc += tot;
       if (nc > pair_lim) { nc = pair_lim; ovf = 1; }
-      if ((HI(HOT_EDGE_MASK) & 2) != 0 && !m->ss_link_cyl)
+      if ((HI(HOT_EDGE_MASK) & 6) != 0 && !m->ss_link_cyl)
         pair_edges(a, ssC, ssR, v3(m->ss_plank_half[0], m->ss_plank_half[1], m->ss_plank_half[2]), A, A * MQE_NREP + 1, capP - tot);
     }
   }
@@ -1269,7 +1300,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
               if (nc > pair_lim) { nc = pair_lim; ovf = 1; }
             }
           }
-          if ((HI(HOT_EDGE_MASK) & 2) != 0)
+          if ((HI(HOT_EDGE_MASK) & 6) != 0)
             pair_edges(a, pb, brec + B_R, v3(m->npc_box_half[0], m->npc_box_half[1], m->npc_box_half[2]), b, A * MQE_NREP + (b - A), 64);
           continue;
         }

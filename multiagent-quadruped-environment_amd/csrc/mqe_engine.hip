@@ -381,8 +381,8 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   UP(m.wall_sdf, d->wall_sdf, (size_t)d->sdf_nx * d->sdf_ny);
   UP(m.ground_height, d->ground_height, (size_t)d->sdf_nx * d->sdf_ny);
   UP(m.wall_top, d->wall_top, (size_t)d->sdf_nx * d->sdf_ny);
-  if (d->edge_contacts & ~3) return fail(-6, "edge_contacts: the HIP engine implements bits 1 (wall edges) and 2 (capsule axes against the scene's boxes); bit 4 (box edges against box primitives) exists in the CPU oracle only");
-  m.edge_mask = d->edge_contacts & 3;
+  if (d->edge_contacts & ~7) return fail(-6, "edge_contacts: bits 1 (wall edges), 2 (capsule axes against the scene's boxes) and 4 (box edges against box primitives)");
+  m.edge_mask = d->edge_contacts & 7;
   m.wall_corner = nullptr;
   if ((m.edge_mask & 1) && d->wall_corner) { UP(m.wall_corner, d->wall_corner, (size_t)d->sdf_nx * d->sdf_ny * 2); }
   for (int q = 0; q < MQE_MAX_PRIMS; q++) {       // feature points on a capsule's axis strictly between its ends (the thigh's middle): an edge contact next to one would duplicate it

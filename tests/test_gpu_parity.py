@@ -291,12 +291,15 @@ def test_box_corner_contacts_match_oracle(solver):
 
 
 def test_edge_contacts_match_oracle():
-    """edge contacts (round 4; include/mqe_hip.h edge_contacts bits 1 and 2): robots scattered around the gate posts at every yaw -- post
+    """edge contacts (round 4; include/mqe_hip.h edge_contacts bits 1, 2 and 4): robots scattered around the gate posts at every yaw -- post
     corners against the sides of trunks, heads and legs -- and robots leaning over the free box's edges: the contact lists of the two
     engines are identical (ids and order exact, separations 5e-5, normals 2e-2 where the golden-section search ends on a flat stretch), some
     contact is an edge contact, and a substep agrees."""
-    for task, N in (("go1gate", 96), ("go1pushbox", 48), ("go1seesaw", 32)):
-        eh, eo, d = _pair(task, N)
+    box_edge_contacts = 0
+    for task, N, mask in (("go1gate", 96, 3), ("go1pushbox", 48, 3), ("go1seesaw", 32, 3), ("go1pushbox", 48, 7), ("go1seesaw", 32, 7), ("go1bridge", 32, 7)):
+        # (mask 7 adds bit 4, the scene boxes' EDGES against the robots' box primitives -- the trunk's side on the box's vertical edge, the
+        # plank's long edge under the trunk -- which the HIP engine refused until round 4's last session)
+        eh, eo, d = _pair(task, N, edge_contacts=mask)
         eh.reset_all(); eo.reset_all()
         torch.cuda.synchronize()
         ro, do = eo.tensor(abi.T_ROOT_STATE), eo.tensor(abi.T_DOF_STATE)
@@ -321,6 +324,13 @@ def test_edge_contacts_match_oracle():
                 ro[:, a, 0] = box[:, 0] + sx * (d.npc_box_half[0] * 1.4142 + 0.02 + torch.rand(N, generator=g) * 0.2)
                 ro[:, a, 1] = box[:, 1] + (torch.rand(N, generator=g) - 0.5) * 0.4
                 ro[:, a, 2] = 0.31
+        elif task == "go1bridge":                            # static scenery: robots hanging over the long top edges of the first box
+            nb = ro[:, A, :3].clone()
+            c0 = torch.tensor([d.static_box_center[0][k] for k in range(3)]); h0 = torch.tensor([d.static_box_half[0][k] for k in range(3)])
+            for a in range(A):
+                ro[:, a, 0] = nb[:, 0] + c0[0] + (torch.rand(N, generator=g) - 0.5) * 1.6 * h0[0]
+                ro[:, a, 1] = nb[:, 1] + c0[1] + (1 if a else -1) * (h0[1] + 0.02 + torch.rand(N, generator=g) * 0.1)
+                ro[:, a, 2] = nb[:, 2] + c0[2] + h0[2] + 0.03 + torch.rand(N, generator=g) * 0.2
         else:
             hinge = ro[:, A, :3].clone()
             for a in range(A):
@@ -331,7 +341,7 @@ def test_edge_contacts_match_oracle():
         do[:, :12 * A, 0] += (torch.rand(N, 12 * A, generator=g) - 0.5) * 0.6
         eh.tensor(abi.T_ROOT_STATE).copy_(ro.cuda()); eh.tensor(abi.T_DOF_STATE).copy_(do.cuda())
         eh.tensor(abi.T_TORQUES).zero_(); eo.tensor(abi.T_TORQUES).zero_()
-        d0, k0, _ = make_desc(task, N, edge_contacts=0)           # the same scene without edge contacts: what they add
+        d0, k0, _ = make_desc(task, N, edge_contacts=0 if mask == 3 else 3)           # the same scene without edge contacts (mask 7: without bit 4): what they add
         e0 = oracle_engine(d0, k0)
         e0.reset_all()
         e0.tensor(abi.T_ROOT_STATE).copy_(ro); e0.tensor(abi.T_DOF_STATE).copy_(do)
@@ -345,12 +355,16 @@ def test_edge_contacts_match_oracle():
             # 3 m from the origin -- the search may stop anywhere within sqrt(2 d 1e-6) = 0.2 mm, i.e. 1e-2 rad at d = 2 cm)
             close(ch[:, 5:], co[:, 5:], atol=2e-2, what="contact normal")
             edges += len(co) - len(e0.debug_dynamics(env, 0)[2])
-        assert edges >= N // 16, (task, edges)                    # the scatter does produce edge contacts
+        if mask == 3:
+            assert edges >= N // 16, (task, edges)                # the scatter does produce edge contacts
+        else:
+            box_edge_contacts += edges
         eh.simulate(); eo.simulate()
         torch.cuda.synchronize()
         err = (eh.tensor(abi.T_ROOT_STATE)[..., :7].cpu() - eo.tensor(abi.T_ROOT_STATE)[..., :7]).abs().reshape(N, -1).max(dim=1).values
         assert int((err > 5e-5).sum()) <= max(1, N // 30) and float(err.max()) < 5e-3, (task, err.topk(3))
-        _record("edge_contacts", {"task": task, "N": N, "contacts_on_links_without_feature_points": edges})
+        _record("edge_contacts", {"task": task, "N": N, "mask": mask, "contacts_on_links_without_feature_points": edges})
+    assert box_edge_contacts >= 2, box_edge_contacts              # ... and box edges on box primitives
 
 
 @pytest.mark.parametrize("task", ["go1sheep-hard", "go1pushbox", "go1gate"])
