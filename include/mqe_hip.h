@@ -386,6 +386,17 @@ int mqe_step_command(mqe_sim* s, const float* command, void* stream);
  * fused ones. */
 int mqe_step_joint(mqe_sim* s, const float* actions12, void* stream);
 
+/* The onboard forward depth camera of LeggedRobotField (legged_robot_field.py:23-93: create_camera_sensor + attach_camera_to_body on the
+ * base link, :196-223: get_camera_image_gpu_tensor(IMAGE_DEPTH)) for every robot, from the CURRENT state: out_dev [R][height][width]
+ * device floats, Isaac Gym's IMAGE_DEPTH convention -- the NEGATIVE distance along the optical axis to the first surface, -inf where
+ * nothing lies within far_m.  cam_pos3 / cam_rpy3 (host pointers) = cfg.sensor.forward_camera.position / .rotation (ZYX Euler) in the base
+ * link; the camera looks along its +x, +z up; pixel (0, 0) is the top-left corner.  What is seen is what the physics collides with: the
+ * ground (slab or relief), the wall prisms, the OTHER robots' collision primitives, free NPCs, the 1-dof link, the scenery boxes -- a ray
+ * caster (csrc/kernels_camera.hpp), not the reference's rasteriser, which is closed: geometric known answers only
+ * (tests/test_camera_gpu.py).  Colour images (IMAGE_COLOR) are not offered. */
+int mqe_render_depth(mqe_sim* s, float* out_dev, int height, int width, float horizontal_fov_deg, const float* cam_pos3, const float* cam_rpy3,
+                     float far_m, void* stream);
+
 /* After host writes into MQE_T_HISTORY (obs_history of the reference, go1.py:102,145): rebuilds what the engine derives from the ring --
  * the compact split-f16 operand of layer 0, the presence flags (a frame of 70 zeros is absent), the carrier columns, the continuity
  * bits.  A no-op for handles whose layer 0 reads the ring itself.  Enqueued on `stream`. */

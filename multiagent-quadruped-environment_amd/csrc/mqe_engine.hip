@@ -15,6 +15,7 @@
 #include "kernels_tail.hpp"
 #include "kernels_gemm.hpp"
 #include "kernels_physics.hpp"
+#include "kernels_camera.hpp"
 
 static thread_local char g_err[512] = "";
 static int fail(int code, const char* fmt, const char* a = "") {
@@ -859,6 +860,18 @@ extern "C" int mqe_state_load(mqe_sim* s, const void* host_blob, void* stream) {
   }
   s->hist_pos = h.hist_pos; s->n_post_steps = h.n_post_steps; s->lag_pos = h.lag_pos;
   return 0;
+}
+extern "C" int mqe_render_depth(mqe_sim* s, float* out_dev, int height, int width, float horizontal_fov_deg, const float* cam_pos3, const float* cam_rpy3,
+                                float far_m, void* stream) {
+  if (!s || !out_dev || !cam_pos3 || !cam_rpy3) return fail(-1, "null argument");
+  if (height <= 0 || width <= 0 || height * width > 1 << 16) return fail(-6, "camera resolution out of range");
+  if (!(horizontal_fov_deg > 1.0f && horizontal_fov_deg < 179.0f) || !(far_m > 0.0f)) return fail(-6, "camera field of view / far plane out of range");
+  CamArgs ca;
+  ca.out = out_dev; ca.H = height; ca.W = width; ca.tan_half_h = tanf(0.5f * horizontal_fov_deg * 3.14159265358979f / 180.0f);
+  for (int k = 0; k < 3; k++) { ca.pos[k] = cam_pos3[k]; ca.rpy[k] = cam_rpy3[k]; }
+  ca.far_ = far_m;
+  hipLaunchKernelGGL(k_depth_camera, dim3(s->N), dim3(256), 0, (hipStream_t)stream, s->dm, s->st, ca);
+  return hipGetLastError() == hipSuccess ? 0 : fail(-4, "k_depth_camera launch failed");
 }
 extern "C" int mqe_history_sync(mqe_sim* s, void* stream) {
   if (!s) return fail(-1, "null engine handle");

@@ -154,6 +154,21 @@ class HipEngine(EngineBase):
         self._call("state_load", C.c_void_p(blob.ctypes.data), self._stream())
         self._n_policy = int(np.frombuffer(blob[-8:].tobytes(), np.int64)[0])
 
+    def render_depth(self, height, width, hfov_deg, pos, rpy, far=20.0, out=None):
+        """forward depth images of every robot from the current state: (R, height, width) device tensor, negative depth along the optical
+        axis, -inf = nothing within `far` (mqe_render_depth)"""
+        R = self.desc.num_envs * self.desc.num_agents
+        if out is None:
+            out = torch.empty(R, int(height), int(width), dtype=torch.float32, device=self.torch_device)
+        f = self.lib.mqe_render_depth
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_void_p]
+        f.restype = C.c_int
+        p3, r3 = (C.c_float * 3)(*[float(x) for x in pos]), (C.c_float * 3)(*[float(x) for x in rpy])
+        rc = f(self.h, C.c_void_p(out.data_ptr()), int(height), int(width), float(hfov_deg), p3, r3, float(far), self._stream())
+        if rc != 0:
+            raise RuntimeError(f"mqe_render_depth failed ({rc}): {self.lib.mqe_last_error().decode()}")
+        return out
+
     def history_sync(self):
         """after writing tensor(T_HISTORY): the compact layer-0 operand is rebuilt from the ring (mqe_history_sync)"""
         self._call("history_sync", self._stream())

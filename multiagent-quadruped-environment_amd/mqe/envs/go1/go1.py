@@ -275,6 +275,38 @@ class Go1:
         is rebuilt from it (mqe_history_sync)"""
         self.engine.history_sync()
 
+    # ---- onboard sensors (legged_robot_field.py:23-93,196-223) ------------------------------------------------------------------
+    def forward_depth(self, far=20.0):
+        """(num_envs, num_agents, H, W) forward depth images from the CURRENT state, Isaac Gym's IMAGE_DEPTH convention (negative depth
+        along the optical axis, -inf = nothing within `far` metres); camera = cfg.sensor.forward_camera (resolution, position, ZYX rotation
+        on the base link, horizontal_fov in degrees if present, else Isaac Gym's default 90).  A ray caster over the collision geometry
+        (mqe_render_depth), not the reference's rasteriser."""
+        cam = self.cfg.sensor.forward_camera
+        H, W = int(cam.resolution[0]), int(cam.resolution[1])
+        fov = getattr(cam, "horizontal_fov", 90.0)
+        if isinstance(fov, (tuple, list)):
+            fov = 0.5 * (float(fov[0]) + float(fov[1]))          # upstream draws one value per camera from the range; the engine's cameras share the middle
+        pos, rot = cam.position, cam.rotation
+        if isinstance(pos, dict):
+            pos = pos["mean"]
+        if isinstance(rot, dict):
+            rot = [0.5 * (lo + hi) for lo, hi in zip(rot["lower"], rot["upper"])]
+        img = self.engine.render_depth(H, W, float(fov), pos, rot, far)
+        return img.view(self.num_envs, self.num_agents, H, W)
+
+    @property
+    def sensor_tensor_dict(self):
+        """as upstream's (legged_robot_field.py:196-223): {"forward_depth": [one (num_agents, H, W) tensor per env]} when
+        cfg.obs.cfgs.depth_image is set, empty otherwise; rendered when read (upstream refreshes its image tensors inside
+        LeggedRobotField.compute_observations, which Go1 overrides without calling it: go1.py:153)."""
+        from collections import defaultdict
+        out = defaultdict(list)
+        if getattr(self.cfg.obs.cfgs, "depth_image", False):
+            out["forward_depth"] = list(self.forward_depth().unbind(0))
+        if getattr(self.cfg.obs.cfgs, "rgb_image", False):
+            raise NotImplementedError("colour images need a rasteriser; only the depth camera exists (mqe_render_depth)")
+        return out
+
     # ---- reference API --------------------------------------------------------------------------------------------
     def reset(self):
         """Reset all robots (go1.py:147-151): no physics step, observations recomputed."""

@@ -118,6 +118,9 @@ class OracleEngine(EngineBase):
     def history_sync(self):
         pass      # the oracle's layer 0 reads the f32 ring itself
 
+    def render_depth(self, *a, **k):
+        raise NotImplementedError("the depth camera exists in the HIP engine only (csrc/kernels_camera.hpp; known answers: tests/test_camera_gpu.py)")
+
     def history(self):
         R = self.desc.num_envs * self.desc.num_agents
         out = np.zeros((R, 2100), np.float32)
