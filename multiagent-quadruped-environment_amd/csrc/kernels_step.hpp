@@ -111,17 +111,27 @@ __device__ __forceinline__ PreVal pre_policy_load(const DevModel* m, const DevSt
                                                   const float* __restrict__ wrapper_actions, int i, int c) {
   const float* ob = st.obs_bag + (size_t)i * MQE_OBS_BAG;
   PreVal r; r.aux = 0.0f; r.mk = 0u;
-  float v;
-  if (c < 3) v = ob[60 + c];                                   // projected gravity      :95
-  else if (c < 18 && m->cmd_general) {                         // command.cfg beyond / without the velocity command (go1.py:66-93): desc.command_src
-    const int src = m->cmd_src[c];
-    if (src < 0) v = m->command_obs[c];
+  // Most entries of the frame are plain copies: their source ADDRESS is selected first (no memory access in the selection, so the
+  // compiler turns it into conditional moves) and ONE load follows -- the if-chain over the columns with a load in every arm made a
+  // wavefront, whose 64 lanes span 64 of the 72 columns, walk eight dependent memory round trips one after the other (10.4 us kernel).
+  const bool cmd_col = c >= 3 && (c < 6 || (c < 18 && m->cmd_general));      // filled from the command / the wrapper's actions below
+  const float* src = nullptr;
+  if (c < 3) src = ob + 60 + c;                                  // projected gravity      :95
+  else if (c < 18) src = cmd_col ? nullptr : m->command_obs + c;  // fixed gait parameters (constants of the scene: desc.command_obs)
+  else if (c < 42) src = ob + (c - 12);                          // dof_pos :96 (ob[6 ..]), dof_vel :97 (ob[18 ..])
+  else if (c < 54) src = st.last_loco + (size_t)i * 12 + (c - 42);           //             :98
+  else if (c < 66) src = st.last_two_loco + (size_t)i * 12 + (c - 54);       //             :99
+  else if (c < 70) src = ob + (c - 3);                           // clock inputs           :100 (ob[63 ..])
+  float v = src != nullptr ? *src : 0.0f;
+  if (cmd_col && m->cmd_general) {                               // command.cfg beyond / without the velocity command (go1.py:66-93): desc.command_src
+    const int srcc = m->cmd_src[c];
+    if (srcc < 0) v = m->command_obs[c];
     else {
-      float x = command[(size_t)i * m->cmd_dims + src];
-      if (m->clip_command) x = clampf(x, -1.0f, 1.0f);         // Go1.step clips the whole action row (go1.py:38)
+      float x = command[(size_t)i * m->cmd_dims + srcc];
+      if (m->clip_command) x = clampf(x, -1.0f, 1.0f);           // Go1.step clips the whole action row (go1.py:38)
       v = x * m->cmd_scale[c];
     }
-  } else if (c < 6) {                                          // velocity command       :67-68 (+ clip :38)
+  } else if (cmd_col) {                                          // velocity command       :67-68 (+ clip :38)
     float x;
     if (wrapper_actions) {
       const int A = m->A, Aw = m->Aw, e = i / A, a = i - e * A, k = c - 3;
@@ -138,32 +148,23 @@ __device__ __forceinline__ PreVal pre_policy_load(const DevModel* m, const DevSt
     } else x = command[i * 3 + (c - 3)];
     if (m->clip_command) x = clampf(x, -1.0f, 1.0f);
     v = x * (c < 5 ? m->cmd_lin_scale : m->cmd_ang_scale);
-  } else if (c < 18) v = m->command_obs[c];                    // fixed gait parameters (constants of the scene: desc.command_obs)
-  else if (c < 30) v = ob[6 + (c - 18)];                       // dof_pos                :96
-  else if (c < 42) v = ob[18 + (c - 30)];                      // dof_vel                :97
-  else if (c < 54) v = st.last_loco[i * 12 + (c - 42)];        //                        :98
-  else if (c < 66) {                                           //                        :99
-    v = st.last_two_loco[i * 12 + (c - 54)];
-    if (st.hist2) {          // the oldest frame's copy of this column once this frame is in (carrier columns, mqe_common.hpp)
-      const int oldest = hist_slot + 1 >= MQE_HIST ? 0 : hist_slot + 1;
-      r.aux = st.hist[((size_t)i * MQE_HIST + oldest) * MQE_FRAME + c];
-    }
-  } else if (c < 70) v = ob[63 + (c - 66)];                    // clock inputs           :100
-  else {
-    v = 0.0f;
-    if (c == 71 && st.hist2) {
-      // does this frame continue its predecessor (bit for bit)?  One bit per RING SLOT, so that the update does not depend on the
-      // bit's old value (the element may be written twice)
-      const int prev = hist_slot > 0 ? hist_slot - 1 : MQE_HIST - 1;
-      const float* pa = st.hist + ((size_t)i * MQE_HIST + prev) * MQE_FRAME + 42;
-      const float* na = st.last_two_loco + (size_t)i * 12;
-      unsigned diff = 0;
+  }
+  if (c >= 54 && c < 66 && st.hist2) {     // the oldest frame's copy of this column once this frame is in (carrier columns, mqe_common.hpp)
+    const int oldest = hist_slot + 1 >= MQE_HIST ? 0 : hist_slot + 1;
+    r.aux = st.hist[((size_t)i * MQE_HIST + oldest) * MQE_FRAME + c];
+  }
+  if (c == 71 && st.hist2) {
+    // does this frame continue its predecessor (bit for bit)?  One bit per RING SLOT, so that the update does not depend on the
+    // bit's old value (the element may be written twice)
+    const int prev = hist_slot > 0 ? hist_slot - 1 : MQE_HIST - 1;
+    const float* pa = st.hist + ((size_t)i * MQE_HIST + prev) * MQE_FRAME + 42;
+    const float* na = st.last_two_loco + (size_t)i * 12;
+    unsigned diff = 0;
 #pragma unroll
-      for (int j = 0; j < 12; j++) diff |= __float_as_uint(pa[j]) ^ __float_as_uint(na[j]);
-      const unsigned bit = 1u << hist_slot;
-      const unsigned mk = st.hist_irr[i];
-      r.mk = diff ? (mk | bit) : (mk & ~bit);
-    }
+    for (int j = 0; j < 12; j++) diff |= __float_as_uint(pa[j]) ^ __float_as_uint(na[j]);
+    const unsigned bit = 1u << hist_slot;
+    const unsigned mk = st.hist_irr[i];
+    r.mk = diff ? (mk | bit) : (mk & ~bit);
   }
   r.v = v;
   return r;
