@@ -374,7 +374,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   auto HI = [&](int i) -> int { return __builtin_amdgcn_readlane(hotv, i); };
   auto HF = [&](int i) -> float { return __int_as_float(__builtin_amdgcn_readlane(hotv, i)); };
   auto HP = [&](int i) -> const float* {
-    return reinterpret_cast<const float*>(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(hotv, i + 1) << 32) | (unsigned long long)(unsigned)__builtin_amdgcn_readlane(hotv, i));
+    return as_global(reinterpret_cast<const float*>(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(hotv, i + 1) << 32) | (unsigned long long)(unsigned)__builtin_amdgcn_readlane(hotv, i)));
   };
   auto HMASK = [&]() -> unsigned long long {
     return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(hotv, HOT_FEAT_MASK_HI) << 32) | (unsigned long long)(unsigned)__builtin_amdgcn_readlane(hotv, HOT_FEAT_MASK_LO);
@@ -2367,6 +2367,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
 
 __global__ void __launch_bounds__(64) k_simulate(const DevModel* __restrict__ m, DevState st, int env_base, int no_write, PhysDebug dbg) {
   extern __shared__ float lds[];
+  own_state(st);
   phys_substep<0, -1>(m, st, lds, env_base + blockIdx.x, threadIdx.x, PS_LOAD_STATE | PS_LOAD_TAU | PS_STORE_STATE | PS_WRITE_CF, no_write, dbg, (int)m->hot[threadIdx.x]);
 }
 // the same substep compiled for the two-robot, no-NPC shape (what k_substeps<2,0> runs): only the per-phase counter tool launches it
@@ -2423,6 +2424,7 @@ __global__ void __launch_bounds__(64, EPW == 2 ? 2 : SubstepsClass<TP>::waves) k
   constexpr int launder = EPW == 2 ? 2 : SubstepsClass<TP>::launder;     // hoisting everything overflows even 256 VGPRs (43 spilled)
 #endif
   const int lane_wave = threadIdx.x, e_first = blockIdx.x * EPW;
+  own_state(st);                                  // every pointer in a register pair of its own (mqe_common.hpp)
   const int hotv = (int)m->hot[lane_wave];        // DevModel::hot: the physics' wave-uniform constants, one entry per lane, read by v_readlane
   if (st.wave_times && lane_wave == 0) {      // MQE_WAVE_TIMES (tools/dev/wave_times.py): entry / exit time, HW_ID and XCC_ID of the wavefront
     st.wave_times[4 * blockIdx.x] = (long long)wall_clock64();
@@ -2498,13 +2500,13 @@ __global__ void __launch_bounds__(64, EPW == 2 ? 2 : SubstepsClass<TP>::waves) k
                                        // inlined, and two copies of its ~9 k instructions would not fit the instruction cache)
       // weight fragments (A operands): row = hidden unit j32, k = this half-wave's element of each k pair; re-read every substep
       // (L1/L2 resident, 5 kB shared by every wave)
-      const float* b0 = mk->actuator.b[0];      // through the laundered pointer: the 70 fragment
-      const float* b1 = mk->actuator.b[1];      // loads below stay inside the substep loop
-      const float* W2 = mk->actuator.W[2]; const float* b2 = mk->actuator.b[2];
+      const float* b0 = as_global(mk->actuator.b[0]);      // through the laundered pointer: the 70 fragment
+      const float* b1 = as_global(mk->actuator.b[1]);      // loads below stay inside the substep loop (global_load, not flat_load:
+      const float* W2 = as_global(mk->actuator.W[2]); const float* b2 = as_global(mk->actuator.b[2]);     // mqe_common.hpp as_global)
       float a1[3], a2[16], w3[16], bb0[16], bb1[16];
       // (the two matrix operands from the fragment-ordered copy: lane-contiguous, one 256 B request per fragment -- W1[j32 * 32 + u] itself
       // is 64 lanes x a 128 B stride, 64 cache lines per instruction, 16 instructions per substep and wavefront)
-      const float* fragw = mk->act_frag + lane_k;
+      const float* fragw = as_global(mk->act_frag) + lane_k;
 #pragma unroll
       for (int s2 = 0; s2 < 3; s2++) a1[s2] = fragw[(16 + s2) * 64];
 #pragma unroll

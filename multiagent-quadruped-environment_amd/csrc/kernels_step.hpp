@@ -61,7 +61,7 @@ __device__ __forceinline__ void defender_command_dev(const DevModel* m, const De
   const float* root = st.root + (size_t)e * (A + P) * 13;
   const float* dp = root + 2 * 13;
   const float* bp = root + A * 13;
-  float gate[3] = {m->gate_pos[e * 2], m->gate_pos[e * 2 + 1], m->env_origins[e * 3 + 2]};
+  float gate[3] = {as_global(m->gate_pos)[e * 2], as_global(m->gate_pos)[e * 2 + 1], as_global(m->env_origins)[e * 3 + 2]};
   float tp[3];
   for (int k = 0; k < 3; k++) tp[k] = 0.6f * bp[k] + 0.4f * gate[k];
   float yaw = st.obs_bag[(size_t)(e * A + 2) * MQE_OBS_BAG + 5];
@@ -365,7 +365,7 @@ __device__ __forceinline__ void compute_observations_env(const DevModel* m, cons
     int i = e * A + a;
     float* ob = st.obs_bag + (size_t)i * MQE_OBS_BAG;
     const float* rs = st.root + ((size_t)e * (A + m->P) + a) * 13;
-    for (int k = 0; k < 3; k++) ob[k] = rs[k] - m->env_origins[e * 3 + k];
+    for (int k = 0; k < 3; k++) ob[k] = rs[k] - as_global(m->env_origins)[e * 3 + k];
     euler_xyz_f(st.bquat + i * 4, ob + 3);
     for (int j = 0; j < 12; j++) {
       const float* ds = st.dof + ((size_t)e * m->ND + a * 12 + j) * 2;
@@ -402,7 +402,7 @@ __device__ __forceinline__ void curriculum_move_dev(const DevModel* m, const Dev
   else if (lvl < 0) lvl = 0;
   if (lvl >= m->terrain_rows) lvl = m->terrain_rows - 1;
   st.terrain_levels[e] = lvl;
-  for (int k = 0; k < 3; k++) st.env_origins_live[e * 3 + k] = m->terrain_origins[((size_t)lvl * m->terrain_cols + m->terrain_types[e]) * 3 + k];
+  for (int k = 0; k < 3; k++) st.env_origins_live[e * 3 + k] = as_global(m->terrain_origins)[((size_t)lvl * m->terrain_cols + as_global(m->terrain_types)[e]) * 3 + k];
 }
 
 __device__ __forceinline__ void reset_env_dev(const DevModel* m, const DevState& st, int e) {
@@ -420,12 +420,12 @@ __device__ __forceinline__ void reset_env_dev(const DevModel* m, const DevState&
   for (int k = 12 * A; k < m->ND; k++) { dofs[k * 2] = m->seesaw_default_angle; dofs[k * 2 + 1] *= 0.0f; }
   for (int a = 0; a < A; a++) {
     float* rs = root + a * 13;
-    for (int k = 0; k < 13; k++) rs[k] = m->base_init[a * 13 + k];
-    for (int k = 0; k < 3; k++) rs[k] += m->agent_origins[((size_t)e * A + a) * 3 + k];
+    for (int k = 0; k < 13; k++) rs[k] = as_global(m->base_init)[a * 13 + k];
+    for (int k = 0; k < 3; k++) rs[k] += as_global(m->agent_origins)[((size_t)e * A + a) * 3 + k];
   }
   for (int p = 0; p < P; p++) {
     float* rs = root + (A + p) * 13;
-    for (int k = 0; k < 13; k++) rs[k] = m->npc_init[p * 13 + k];
+    for (int k = 0; k < 13; k++) rs[k] = as_global(m->npc_init)[p * 13 + k];
     for (int k = 0; k < 3; k++) rs[k] += st.env_origins_live[e * 3 + k];
   }
   if (m->has_base_pos_range)
@@ -541,13 +541,13 @@ __device__ __forceinline__ void wrapper_env_dev(const DevModel* m, const DevStat
       const float* ob2 = bag + ((Aw - 1 - a)) * MQE_OBS_BAG;
       for (int k = 0; k < 6; k++) o[c++] = ob2[k];
     }
-    if (m->task == MQE_TASK_GATE || m->task == MQE_TASK_SHEEP || m->task == MQE_TASK_PUSHBOX) { o[c++] = m->gate_pos[e * 2]; o[c++] = m->gate_pos[e * 2 + 1]; }
+    if (m->task == MQE_TASK_GATE || m->task == MQE_TASK_SHEEP || m->task == MQE_TASK_PUSHBOX) { o[c++] = as_global(m->gate_pos)[e * 2]; o[c++] = as_global(m->gate_pos)[e * 2 + 1]; }
     if (m->task == MQE_TASK_PUSHBOX) {              // go1_pushbox_wrapper.py:44-48: box xy rel. env origin, box quaternion
       o[c++] = npc[0] - st.env_origins_live[e * 3]; o[c++] = npc[1] - st.env_origins_live[e * 3 + 1];
       for (int k = 0; k < 4; k++) o[c++] = npc[3 + k];
     }
     if (m->task == MQE_TASK_SHEEP)
-      for (int p = 0; p < P; p++) { o[c++] = npc[p * 13] - m->env_origins[e * 3]; o[c++] = npc[p * 13 + 1] - m->env_origins[e * 3 + 1]; }
+      for (int p = 0; p < P; p++) { o[c++] = npc[p * 13] - as_global(m->env_origins)[e * 3]; o[c++] = npc[p * 13 + 1] - as_global(m->env_origins)[e * 3 + 1]; }
     if (m->task == MQE_TASK_FOOTBALL_DEFENDER) {
       for (int k = 0; k < 3; k++) o[c++] = npc[k] - st.env_origins_live[e * 3 + k];
       for (int k = 0; k < 3; k++) o[c++] = npc[7 + k];
@@ -663,7 +663,7 @@ __device__ __forceinline__ void wrapper_env_dev(const DevModel* m, const DevStat
     // loads first (see k_post_physics), then the same sums in the same order as the straightforward loop nest
     float r_ag[MQE_MAX_AGENTS] = {0, 0, 0, 0}, bx[MQE_MAX_AGENTS] = {0, 0, 0, 0}, by[MQE_MAX_AGENTS] = {0, 0, 0, 0}, wl[MQE_MAX_AGENTS] = {0, 0, 0, 0};
     const uint8_t have = st.w_have_last[e];
-    const float gx = m->gate_pos[e * 2], colf = (float)st.collide_buf[e];
+    const float gx = as_global(m->gate_pos)[e * 2], colf = (float)st.collide_buf[e];
     float rs0 = rs[0], rs1 = rs[1], rs2 = rs[2], rs3 = rs[3];
 #pragma unroll
     for (int a = 0; a < MQE_MAX_AGENTS; a++)
@@ -708,10 +708,10 @@ __device__ __forceinline__ void wrapper_env_dev(const DevModel* m, const DevStat
     return;
   }
   if (m->task == MQE_TASK_SHEEP) {
-    float gate_x = m->gate_pos[e * 2];
+    float gate_x = as_global(m->gate_pos)[e * 2];
     if (sc[0] != 0) {
       int cnt = 0;
-      for (int p = 0; p < P; p++) if ((npc[p * 13] - m->env_origins[e * 3]) - gate_x > 0) cnt++;
+      for (int p = 0; p < P; p++) if ((npc[p * 13] - as_global(m->env_origins)[e * 3]) - gate_x > 0) cnt++;
       r_env = (float)cnt;
       rs[0] += (float)cnt;
     }
@@ -729,8 +729,8 @@ __device__ __forceinline__ void wrapper_env_dev(const DevModel* m, const DevStat
     if (sc[3] != 0) {
       float acc = 0;
       for (int p = 0; p < P; p++) {
-        float x = npc[p * 13] - m->env_origins[e * 3], y = npc[p * 13 + 1] - m->env_origins[e * 3 + 1];
-        float dg = sqrtf((x - gate_x) * (x - gate_x) + (y - m->gate_pos[e * 2 + 1]) * (y - m->gate_pos[e * 2 + 1]));
+        float x = npc[p * 13] - as_global(m->env_origins)[e * 3], y = npc[p * 13 + 1] - as_global(m->env_origins)[e * 3 + 1];
+        float dg = sqrtf((x - gate_x) * (x - gate_x) + (y - as_global(m->gate_pos)[e * 2 + 1]) * (y - as_global(m->gate_pos)[e * 2 + 1]));
         float v = expf(-dg / 2.0f) * sc[3];
         if (x >= gate_x) v = sc[3];
         acc += v;
@@ -788,9 +788,9 @@ __device__ __forceinline__ void wrapper_env_dev(const DevModel* m, const DevStat
   }
   if (m->task == MQE_TASK_FOOTBALL_DEFENDER) {
     float bx = npc[0] - st.env_origins_live[e * 3], by = npc[1] - st.env_origins_live[e * 3 + 1];
-    if (sc[0] != 0) { if (bx > m->gate_pos[e * 2]) { r_env += sc[0]; rs[0] += sc[0]; } }
+    if (sc[0] != 0) { if (bx > as_global(m->gate_pos)[e * 2]) { r_env += sc[0]; rs[0] += sc[0]; } }
     if (sc[1] != 0) {
-      float dg = sqrtf((bx - m->gate_pos[e * 2]) * (bx - m->gate_pos[e * 2]) + (by - m->gate_pos[e * 2 + 1]) * (by - m->gate_pos[e * 2 + 1]));
+      float dg = sqrtf((bx - as_global(m->gate_pos)[e * 2]) * (bx - as_global(m->gate_pos)[e * 2]) + (by - as_global(m->gate_pos)[e * 2 + 1]) * (by - as_global(m->gate_pos)[e * 2 + 1]));
       float v = sc[1] * expf(-dg / 3.0f);
       r_env += v; rs[1] += v;
     }
@@ -850,7 +850,7 @@ __device__ __forceinline__ void post_body(const DevModel* m, const DevState& st,
   if (mine) {
     ep = st.ep_len[e] + 1;
 #pragma unroll
-    for (int k = 0; k < 3; k++) eo[k] = m->env_origins[e * 3 + k];
+    for (int k = 0; k < 3; k++) eo[k] = as_global(m->env_origins)[e * 3 + k];
     const float* root_src = root_l != nullptr ? root_l + le * lds_env_stride : root;
 #pragma unroll
     for (int k = 0; k < 13; k++) rs[k] = root_src[a * 13 + k];
@@ -861,7 +861,7 @@ __device__ __forceinline__ void post_body(const DevModel* m, const DevState& st,
     const float* cf3 = st.cf + ((size_t)e * m->NBR + a * MQE_NREP) * 3;
 #pragma unroll
     for (int k = 0; k < 3; k++) f3[k] = cf3[k];
-    aoz = m->agent_origins[(size_t)i * 3 + 2];
+    aoz = as_global(m->agent_origins)[(size_t)i * 3 + 2];
     const float* ds = dof_l != nullptr ? dof_l + le * lds_env_stride + a * 24 : st.dof + ((size_t)e * m->ND + a * 12) * 2;
 #pragma unroll
     for (int k = 0; k < 24; k++) dq[k] = ds[k];
@@ -1151,7 +1151,7 @@ __global__ void __launch_bounds__(64) k_post_staged(const DevModel* m, DevState 
       float r = rpy[0], p = rpy[1];
       if (r > 3.1415927f) r -= 6.2831855f;
       if (p > 3.1415927f) p -= 6.2831855f;
-      const float z = rs[2] - m->agent_origins[(size_t)i * 3 + 2];
+      const float z = rs[2] - as_global(m->agent_origins)[(size_t)i * 3 + 2];
       if ((m->termination_flags & MQE_TERM_ROLL) && fabsf(r) > m->roll_thr) fl |= 2u;
       if ((m->termination_flags & MQE_TERM_PITCH) && fabsf(p) > m->pitch_thr) fl |= 4u;
       if ((m->termination_flags & MQE_TERM_Z_HIGH) && z > m->zhigh_thr) fl |= 8u;

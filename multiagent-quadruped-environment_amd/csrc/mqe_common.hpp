@@ -102,6 +102,31 @@ struct DevState {
   uint8_t* wdone;         // the reset flags once more, as the byte tail of the packed return batch (obs | reward | done)
 };
 
+// A kernel that takes DevState by value gets its ~60 pointers as a few 16-register kernarg loads, and under register pressure the
+// allocator spills and reloads those TUPLES whole: 16 v_readlane for the one pointer a store needs (k_substeps<2, 0>: 1750 static
+// v_readlane, a sixth of its vector instructions).  own_global gives a pointer a scalar register pair of its own (the inline asm cuts it
+// off the tuple) and keeps it a GLOBAL pointer for the address-space inference (through an integer, so that the accesses stay
+// global_load / global_store instead of becoming flat_*, whose completion also holds up every LDS wait).
+template <class T> __device__ __forceinline__ void own_global(T*& p) {
+  unsigned long long u;
+  asm volatile("s_mov_b64 %0, %1" : "=s"(u) : "s"((unsigned long long)p));     // (a tied "+s" operand is coalesced back into the tuple)
+  p = (T*)(__attribute__((address_space(1))) T*)u;
+}
+// a pointer read out of a structure in memory (DevModel's tables): tell the compiler it is a global one
+template <class T> __device__ __forceinline__ const T* as_global(const T* p) {
+  return (const T*)(const __attribute__((address_space(1))) T*)(unsigned long long)p;
+}
+__device__ __forceinline__ void own_state(DevState& st) {
+  own_global(st.root); own_global(st.dof); own_global(st.cf); own_global(st.torques); own_global(st.actions); own_global(st.last_actions); own_global(st.loco_obs);
+  own_global(st.hist); own_global(st.last_loco); own_global(st.last_two_loco); own_global(st.act_hist); own_global(st.gait); own_global(st.clock); own_global(st.blv);
+  own_global(st.bav); own_global(st.pg); own_global(st.bquat); own_global(st.obs_bag); own_global(st.wobs); own_global(st.wrew); own_global(st.rsum);
+  own_global(st.sheep_avg); own_global(st.sheep_var); own_global(st.sub_tau); own_global(st.npc_noise); own_global(st.w_last); own_global(st.w_last2); own_global(st.cmd);
+  own_global(st.last_dof_vel); own_global(st.sub_dof_vel); own_global(st.sub_exceed); own_global(st.overflow); own_global(st.dparams); own_global(st.lag_buf);
+  own_global(st.hist2); own_global(st.wave_times); own_global(st.hist_irr); own_global(st.ep_len); own_global(st.reset_count); own_global(st.reset_buf);
+  own_global(st.collide_buf); own_global(st.time_out); own_global(st.r_term); own_global(st.p_term); own_global(st.zh_term); own_global(st.w_have_last);
+  own_global(st.w_delayed_reset); own_global(st.npc_pre); own_global(st.env_origins_live); own_global(st.curr_xy); own_global(st.terrain_levels); own_global(st.wdone);
+}
+
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
 
 // counter-based RNG of the reset distribution and the domain randomisation: keyed by (seed, GLOBAL env id, count, stream)

@@ -329,7 +329,14 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   if (s->phys_lds_bytes > 160 * 1024) { return fail(-4, "physics LDS footprint exceeds 160 KiB"); }
   s->substeps_fn = pick_substeps(m, s->phys_lds_bytes);
   s->a2_scene = s->substeps_fn == (void (*)(const DevModel*, DevState, int, int, PostArgs))k_substeps<2, 0>;
-  const bool phase_timed = s->a2_scene && getenv("MQE_PHASE_TIMES") != nullptr;      // tools/dev/phase_walltimes.py: the same kernel with its phase taps live
+  typedef void (*substeps_fn_t)(const DevModel*, DevState, int, int, PostArgs);
+  substeps_fn_t timed_fn = nullptr;                   // tools/dev/phase_walltimes.py: the same kernel with its phase taps live (go1gate and the two large scenes)
+  if (getenv("MQE_PHASE_TIMES")) {
+    if (s->a2_scene) timed_fn = k_substeps<2, 0, 1, true>;
+    else if (s->substeps_fn == (substeps_fn_t)k_substeps<2, PS_F_NPC>) timed_fn = k_substeps<2, PS_F_NPC, 1, true>;
+    else if (s->substeps_fn == (substeps_fn_t)k_substeps<3, PS_F_NPC | PS_F_ROW>) timed_fn = k_substeps<3, PS_F_NPC | PS_F_ROW, 1, true>;
+  }
+  const bool phase_timed = timed_fn != nullptr;
   {
     // Two envs per wavefront (kernels_physics.hpp, EPW): for robot-only scenes of <= 2 robots each half-wave runs an env of its own --
     // 44 % fewer VALU instructions per env (the dynamics and sweep phases are shared, only contact generation runs per env), but half
@@ -357,7 +364,7 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
     if (lds_sub > 48 * 1024 && hipFuncSetAttribute((const void*)s->substeps_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sub) != hipSuccess)
       return fail(-4, "cannot raise dynamic LDS limit");
   }
-  if (phase_timed && s->substeps_epw == 1) s->substeps_fn = (void (*)(const DevModel*, DevState, int, int, PostArgs))k_substeps<2, 0, 1, true>;
+  if (phase_timed && s->substeps_epw == 1) s->substeps_fn = timed_fn;
   s->fuse_substeps = getenv("MQE_NO_FUSE_SUBSTEPS") == nullptr && d->decimation <= 4;
   // the run-time terrain curriculum needs its snapshot launch between the physics and the resets: no epilogue fusion there
   // ... and only the robot-only kernels k_substeps<1 | 2, 0, *> carry the epilogue (go1gate, go1plane)
