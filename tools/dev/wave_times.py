@@ -17,8 +17,12 @@ e.reset_all()
 Aw = e.tensor(abi.T_WRAPPER_OBS).shape[1]
 g = torch.Generator(device="cuda"); g.manual_seed(1234)
 buf = np.zeros((n, 4), np.int64)
+prev_dur = None
 for t in range(steps):
     e.step(torch.rand(n, Aw, 3, device="cuda", generator=g) * 2 - 1)
+    if t == steps - 2:      # how well does a wavefront's duration in one step predict the next step's (load balancing by last step's load)?
+        e._call("debug_wave_times", C.c_void_p(buf.ctypes.data))
+        prev_dur = (buf[:, 1] - buf[:, 0]).astype(np.float64) * 0.01
     if t in (5, 30, 60, 90, steps - 1):
         e._call("debug_wave_times", C.c_void_p(buf.ctypes.data))
         nw = int((buf[:, 1] > 0).sum())
@@ -38,6 +42,11 @@ for t in range(steps):
             print(f"exit: std within a SIMD {within:.2f} us, std of SIMD means {mean_exit.std():.2f} us, std of all {end.std():.2f} us")
             lastexit = np.zeros(len(uniq)); np.maximum.at(lastexit, inv, end)
             print("last exit per SIMD percentiles [" + pc(lastexit) + "]")
+            print(f"launch waits {lastexit.max() - lastexit.mean():.1f} us for its slowest SIMD beyond the mean SIMD (what a perfect balance of the envs over the SIMDs could win)")
+            if prev_dur is not None:
+                print(f"correlation of a wavefront's duration with its duration one step earlier: {np.corrcoef(prev_dur[:nw], dur)[0, 1]:.2f}")
+                sumdur = np.bincount(inv, weights=dur)
+                print(f"per SIMD: sum of its waves' durations vs its last exit: corr {np.corrcoef(sumdur, lastexit)[0, 1]:.2f}; max duration vs last exit: corr {np.corrcoef(np.maximum.reduceat(dur[np.argsort(inv, kind='stable')], np.r_[0, np.cumsum(cnt)[:-1]]), lastexit)[0, 1]:.2f}")
             for b in (0, 1, 2, 3, 8, 9, 1024, 2048, 3072):
                 print("  block", b, "xcc", xcc[b], "se", se[b], "sh", sh[b], "cu", cu[b], "simd", simd[b], "wave slot", hw[b] & 15)
             # which block ids share a SIMD with block 0?
