@@ -2471,6 +2471,12 @@ __global__ void __launch_bounds__(64, EPW == 2 ? 2 : SubstepsClass<TP>::waves) k
     // with a handful of spills, at the price of re-deriving those values every substep; what depends on the model alone is
     // wave-uniform, lives in SGPRs and stays hoisted (laundering the model pointer too, bit 0, costs 5-12 %).  That pays exactly when
     // the LDS footprint lets 16 waves sit on a CU (SubstepsClass::small): 4096 envs then run as one round instead of two.
+#ifdef MQE_DUMMY_VALU
+    {   // experiment: MQE_DUMMY_VALU independent vector instructions per substep -- is the kernel bound by the number of VALU instructions it issues?
+      int dummy;
+      asm volatile(".rept %1\n v_mov_b32 %0, 0\n .endr" : "=v"(dummy) : "n"(MQE_DUMMY_VALU));
+    }
+#endif
     const DevModel* mk = m;
     int lane_k = lane_wave;
     if (launder & 1) asm volatile("" : "+s"(mk));
