@@ -26,3 +26,8 @@ rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_IN
 cd $R
 python tests/parity_sweep.py 256 gpurun_out/${T}_parity_sweep.json > gpurun_out/${T}_parity.log 2>&1
 MQE_SOLVER=pgs python tests/parity_sweep.py 256 gpurun_out/${T}_parity_sweep_pgs.json > gpurun_out/${T}_parity_pgs.log 2>&1
+# where a full launch's time goes, phase by phase (every wavefront stamps the wall clock at its taps), for the headline and the two large scenes
+python tools/dev/phase_walltimes.py 4096 60 go1gate > gpurun_out/${T}_phase_walltimes_go1gate.txt 2>&1
+python tools/dev/phase_walltimes.py 2048 60 go1sheep-hard > gpurun_out/${T}_phase_walltimes_go1sheep-hard.txt 2>&1
+python tools/dev/phase_walltimes.py 4096 60 go1football-defender > gpurun_out/${T}_phase_walltimes_go1football-defender.txt 2>&1
+python tools/dev/wave_times.py go1gate 4096 120 > gpurun_out/${T}_wave_times_go1gate.txt 2>&1
