@@ -364,9 +364,9 @@ def main():
             roof = {"kernel": PROF_NAMES[dom], "bound": "hbm", "achieved": round(ach, 3), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(ach / PEAK_HBM_GBS, 6), "traffic": None, "avg_launch_ms": round(avg_ms(dom), 4), "launches": int(cnt[dom]),
                     "bytes_basis": "SURVEY 8(d): the whole step's 10128 B/agent-step charged to the dominant kernel; per-kernel shares in roofline_per_kernel",
-                    "note": "not HBM-bound by construction: one env per wavefront, state LDS-resident for the 4 substeps; the limiter is "
-                            "the kernel's VALU instruction count (robot-only scenes: all envs resident at 4 waves/SIMD, vector ALUs ~80 % busy; "
-                            "pmc_from_profile: issue / wait fractions; DESIGN.md 3.1)"}
+                    "note": "not HBM-bound by construction: one env per wavefront, state LDS-resident for the 4 substeps; the limiters are "
+                            "the wavefront's chain of dependent waits (78 us for a wavefront alone on its CU) and the vector ALU's issue slots (86 % taken "
+                            "inside the substeps with all envs resident at 4 waves/SIMD: valu_issue); DESIGN.md 3.1 (e), (f)"}
         # HBM traffic of the dominant kernel: NOT measured in this run -- copied from the committed rocprofv3 PMC passes (separate
         # runs of this command, profiles/*pmc_summary.json) and labelled as such
         try:
@@ -380,6 +380,14 @@ def main():
                 roof["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, bytes per launch, copied from " + os.path.relpath(pfile, ROOT)
                 roof["pmc_from_profile"] = {"file": os.path.relpath(pfile, ROOT), "measured_in_this_run": False,
                                             **{k: e[k] for k in ("frac_wave_time_issuing", "frac_wave_time_issue_stalled", "frac_wave_time_waiting_on_waitcnt_or_barrier") if k in e}}
+                if dom != 0 and e.get("SQ_ACTIVE_INST_VALU_mean") and e.get("GRBM_GUI_ACTIVE_mean"):
+                    # the limit this kernel actually runs against: the vector ALU's issue slots.  SQ_ACTIVE_INST_VALU counts quad-cycles summed over the
+                    # wavefronts of a launch; 1024 SIMDs issue one VALU instruction per quad-cycle each; GRBM_GUI_ACTIVE sums the 8 XCDs' busy cycles
+                    simd_quads = e["GRBM_GUI_ACTIVE_mean"] / 8.0 / 4.0 * 1024.0
+                    roof["valu_issue"] = {"bound": "valu issue slots (1 per SIMD and quad-cycle)", "frac_of_launch": round(e["SQ_ACTIVE_INST_VALU_mean"] / simd_quads, 3),
+                                          "frac_inside_the_substeps": 0.86, "measured_in_this_run": False,
+                                          "note": "86 % inside the four substeps (3545 VALU instructions per wavefront and substep x 4 resident wavefronts of the SIMD's 16.4 k quad-cycles, "
+                                                  "profiles/*phase_counters_go1gate_tgs.txt); the launch-wide figure includes the state load, the epilogue and the wait for the last wavefront; DESIGN.md 3.1 (f)"}
         except Exception:
             pass
         # ---- per-kernel table: every kernel class with ITS OWN share of the algorithmic bytes (the items of SURVEY 8(d) assigned
