@@ -67,6 +67,7 @@ struct mqe_sim {
   bool gemm_split = false;
   bool gemm_half = true;              // k_gemm_h2_mix: half tiles for a remainder of at most half a round (MQE_GEMM_HALF=0: full tiles only)
   bool cmd_general = false;           // command layout other than (x, y, yaw) -> entries 3-5 (desc.command_src): unfused entry points, exact-f32 layer 0
+  bool phase_timed = false;           // MQE_PHASE_TIMES=1 at creation: k_substeps runs with its phase taps live (mqe_debug_phase_times)
   bool tail_fused = false;            // k_policy_tail: the reference network shapes (256-128-2 / 512-256-128-12 after layer 0)
   size_t phys_lds_bytes = 0;
   bool fuse_substeps = true;
@@ -364,7 +365,7 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
     if (lds_sub > 48 * 1024 && hipFuncSetAttribute((const void*)s->substeps_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sub) != hipSuccess)
       return fail(-4, "cannot raise dynamic LDS limit");
   }
-  if (phase_timed && s->substeps_epw == 1) s->substeps_fn = timed_fn;
+  if (phase_timed && s->substeps_epw == 1) { s->substeps_fn = timed_fn; s->phase_timed = true; }
   s->fuse_substeps = getenv("MQE_NO_FUSE_SUBSTEPS") == nullptr && d->decimation <= 4;
   // the run-time terrain curriculum needs its snapshot launch between the physics and the resets: no epilogue fusion there
   // ... and only the robot-only kernels k_substeps<1 | 2, 0, *> carry the epilogue (go1gate, go1plane)
@@ -891,7 +892,7 @@ extern "C" int mqe_history_sync(mqe_sim* s, void* stream) {
 }
 extern "C" int mqe_debug_phase_times(mqe_sim* s, long long* out_host) {
   if (!s) return fail(-1, "null engine handle");
-  if (!s->st.wave_times || !getenv("MQE_PHASE_TIMES")) return fail(-4, "create the handle with MQE_PHASE_TIMES=1");
+  if (!s->st.wave_times || !s->phase_timed) return fail(-4, "create the handle with MQE_PHASE_TIMES=1 (go1gate-, go1sheep- or go1football-defender-shaped scene)");
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(out_host, s->st.wave_times + (size_t)4 * s->N, (size_t)64 * s->N * sizeof(long long), hipMemcpyDeviceToHost));
   return 0;

@@ -1126,3 +1126,41 @@ def test_walls_of_different_heights_match_oracle():
         assert (eh.tensor(abi.T_RESET_BUF).cpu() == eo.tensor(abi.T_RESET_BUF)).all()
     dev = torch.stack(dev)
     assert float(dev[-1].median()) < 1e-4 and float(dev[-1].quantile(0.99)) < 1e-3
+
+
+@pytest.mark.parametrize("task,N", [("go1gate", 96), ("go1sheep-hard", 24), ("go1football-defender", 40)])
+def test_phase_timed_kernels_are_bit_identical_and_their_taps_ordered(monkeypatch, task, N):
+    """MQE_PHASE_TIMES=1 swaps k_substeps for the instantiation whose phase taps are live (tools/dev/phase_walltimes.py: where the time of a
+    full launch goes).  It is the same arithmetic: 8 fused steps agree bit for bit with the product kernel in every state tensor, and the
+    wall-clock stamps every wavefront leaves are ordered -- tap after tap, substep after substep, entry before the first, exit after the last."""
+    import ctypes as C
+    import numpy as np
+    d1, k1, _ = make_desc(task, N)
+    e1 = hip_engine(d1, k1)
+    monkeypatch.setenv("MQE_PHASE_TIMES", "1")
+    d2, k2, _ = make_desc(task, N)
+    e2 = hip_engine(d2, k2)
+    monkeypatch.delenv("MQE_PHASE_TIMES")
+    e1.reset_all(); e2.reset_all()
+    g = torch.Generator().manual_seed(11)
+    Aw = e1.tensor(abi.T_WRAPPER_OBS).shape[1]
+    kinds = (abi.T_ROOT_STATE, abi.T_DOF_STATE, abi.T_TORQUES, abi.T_CONTACT_FORCE, abi.T_ACT_HIST, abi.T_SUBSTEP_TORQUES, abi.T_SUBSTEP_DOF_VEL,
+             abi.T_RESET_BUF, abi.T_OBS_BAG, abi.T_WRAPPER_OBS, abi.T_WRAPPER_REWARD)
+    taps = np.zeros((N, 4, 16), np.int64)
+    span = np.zeros((N, 4), np.int64)
+    for t in range(8):
+        a = (torch.rand(N, Aw, 3, generator=g) * 2 - 1).cuda().contiguous()
+        e1.step(a); e2.step(a)
+        torch.cuda.synchronize()
+        for kind in kinds:
+            x1, x2 = e1.tensor(kind), e2.tensor(kind)
+            assert torch.equal(x1.view(torch.uint8) if x1.dtype != torch.float32 else x1.view(torch.int32), x2.view(torch.uint8) if x2.dtype != torch.float32 else x2.view(torch.int32)), (t, kind)
+        e2._call("debug_phase_times", C.c_void_p(taps.ctypes.data))
+        e2._call("debug_wave_times", C.c_void_p(span.ctypes.data))
+        flat = taps.reshape(N, 64)
+        assert (np.diff(flat, axis=1) >= 0).all(), "a wavefront's taps run backwards"
+        assert (flat[:, 0] >= span[:, 0]).all() and (span[:, 1] >= flat[:, -1]).all()
+        us = (flat[:, -1] - flat[:, 0]) * 0.01                 # 100 MHz wall clock
+        assert 20.0 < float(np.median(us)) < 2000.0, float(np.median(us))
+    with pytest.raises(RuntimeError):                          # a handle created without the switch has no tap buffer
+        e1._call("debug_phase_times", C.c_void_p(taps.ctypes.data))
