@@ -154,3 +154,13 @@ def test_hip_momentum_budget_in_free_flight_under_joint_torques():
         eL = np.abs(L1 - L0).max()
         eC = np.abs(C1 - (C0 + P0 / mt * t + 0.5 * np.array([0, 0, -G]) * t * (t + d.dt))).max()
         assert eP < 5e-3 and eL < 4e-2 and eC < 3e-3, (env, r, eP, eL, eC)
+
+
+def test_hip_penetration_recovery_follows_the_solvers_rule():
+    """the depenetration rule of each contact solver (tests/test_physics_oracle.py::check_penetration_recovery), asked of the HIP engine"""
+    from test_physics_oracle import _buried_ball, check_penetration_recovery
+    d, k, ctx = make_desc("go1football-defender", 3)
+    e = hip_engine(d, k)
+    e.reset_all()
+    z, v = _buried_ball(e, d, e.tensor(abi.T_ROOT_STATE), (0.001, 0.003, 0.06), 40)
+    check_penetration_recovery(d, z, v)

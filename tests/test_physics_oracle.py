@@ -393,3 +393,45 @@ def test_walls_of_different_heights_carry_a_ball_at_their_own_top():
     for env in range(2):
         assert abs(float(root[env, A, 2]) - (want[env] + r)) < 2e-3, (env, float(root[env, A, 2]), want[env] + r)
         assert root[env, A, 7:10].abs().max() < 1e-2
+
+
+def _buried_ball(e, d, root, depths, steps):
+    """the football of env i starts `depths[i]` below its rest height, at rest; returns per step its height above rest and its vertical speed"""
+    A, r = d.num_agents, d.npc_sphere_radius[0]
+    root[:, :A, 2] += 30.0                       # the robots out of the way
+    root[:, A, 0] += 1.0
+    root[..., 7:] = 0
+    for i, dep in enumerate(depths):
+        root[i, A, 2] = d.ground_z + r - dep
+    z, v = [], []
+    for t in range(steps):
+        e.simulate()
+        z.append((root[:, A, 2] - d.ground_z - r).clone()); v.append(root[:, A, 9].clone())
+    return torch.stack(z).cpu().numpy().astype(np.float64), torch.stack(v).cpu().numpy().astype(np.float64)
+
+
+def check_penetration_recovery(d, z, v):
+    """What each contact solver's rule says about a sphere that starts 1 mm, 3 mm and 60 mm inside the ground, at rest.
+    Temporal Gauss-Seidel: a penetration leaves at no more than max_depenetration_velocity and within the sub-steps it needs -- 1 mm and 3 mm
+    are gone inside the first step (one resp. three sub-steps of 1.25 mm) and, the later sub-steps asking for nothing, NO velocity is left;
+    60 mm take twelve whole steps at exactly 1 m/s, and that speed is what the ball leaves with (PhysX's pop-out, which the cap bounds).
+    Velocity-level sweeps with erp = 0.2: a fifth of the penetration per step, as velocity erp * depth / dt (capped at the same 1 m/s)."""
+    dt, cap = d.dt, d.max_depenetration_velocity
+    if d.solver_type == 1:
+        assert np.abs(z[:, :2]).max() < 2e-5 and np.abs(v[:, :2]).max() < 1e-3, (z[0], v[0])         # resolved in the first step, at rest ever after
+        np.testing.assert_allclose(z[:12, 2], -0.06 + cap * dt * np.arange(1, 13), atol=2e-5)          # 5 mm per step
+        np.testing.assert_allclose(v[:12, 2], cap, atol=1e-3)
+        np.testing.assert_allclose(v[12:16, 2], cap - G * dt * np.arange(1, 5), atol=2e-3)             # then a free flight that starts at the cap
+        assert z[:, 2].max() < cap * cap / (2 * G) + 1e-3                                              # and never rises beyond its ballistic height
+    else:
+        for i, dep in enumerate((0.001, 0.003)):
+            np.testing.assert_allclose(z[:8, i], -dep * 0.8 ** np.arange(1, 9), rtol=2e-2, atol=2e-6)
+            np.testing.assert_allclose(v[:8, i], 0.2 * dep * 0.8 ** np.arange(8) / dt, rtol=2e-2, atol=1e-4)
+        np.testing.assert_allclose(v[:8, 2], cap, atol=1e-3)                                           # 0.2 * 60 mm / dt = 2.4 m/s asks for more than the cap
+    assert np.isfinite(z).all() and np.isfinite(v).all()
+
+
+def test_penetration_recovery_follows_the_solvers_rule():
+    e, d, root, dof = fresh("go1football-defender", 3)
+    z, v = _buried_ball(e, d, root, (0.001, 0.003, 0.06), 40)
+    check_penetration_recovery(d, z, v)
