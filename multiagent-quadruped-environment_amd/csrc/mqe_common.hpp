@@ -116,6 +116,7 @@ template <class T> __device__ __forceinline__ void own_global(T*& p) {
 template <class T> __device__ __forceinline__ const T* as_global(const T* p) {
   return (const T*)(const __attribute__((address_space(1))) T*)(unsigned long long)p;
 }
+static_assert(sizeof(DevState) == 52 * sizeof(void*), "DevState is pointers only, and own_state() below lists every one of them");
 __device__ __forceinline__ void own_state(DevState& st) {
   own_global(st.root); own_global(st.dof); own_global(st.cf); own_global(st.torques); own_global(st.actions); own_global(st.last_actions); own_global(st.loco_obs);
   own_global(st.hist); own_global(st.last_loco); own_global(st.last_two_loco); own_global(st.act_hist); own_global(st.gait); own_global(st.clock); own_global(st.blv);
