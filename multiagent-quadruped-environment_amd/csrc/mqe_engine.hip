@@ -368,11 +368,15 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   if (phase_timed && s->substeps_epw == 1) { s->substeps_fn = timed_fn; s->phase_timed = true; }
   s->fuse_substeps = getenv("MQE_NO_FUSE_SUBSTEPS") == nullptr && d->decimation <= 4;
   // the run-time terrain curriculum needs its snapshot launch between the physics and the resets: no epilogue fusion there
-  // ... and only the robot-only kernels k_substeps<1 | 2, 0, *> carry the epilogue (go1gate, go1plane)
+  // ... and only the kernels of the small class carry the epilogue (ShapeClass<TP>::small: go1gate, go1plane, the two-robot tasks with one more object)
   s->fuse_post = s->fuse_substeps && getenv("MQE_NO_FUSE_POST") == nullptr && !m.curriculum &&
                  (s->substeps_fn == (void (*)(const DevModel*, DevState, int, int, PostArgs))k_substeps<2, 0> || s->substeps_fn == (void (*)(const DevModel*, DevState, int, int, PostArgs))k_substeps<1, 0> ||
                   s->substeps_fn == (void (*)(const DevModel*, DevState, int, int, PostArgs))k_substeps<2, 0, 1, true> ||
-                  s->substeps_fn == (void (*)(const DevModel*, DevState, int, int, PostArgs))k_substeps<1, 0, 2>);
+                  s->substeps_fn == (void (*)(const DevModel*, DevState, int, int, PostArgs))k_substeps<1, 0, 2> ||
+                  // ... and, since every DevState pointer has a register pair of its own (own_state), the other kernels of the 16-envs-per-CU class: no spills
+                  (getenv("MQE_FUSE_POST_ROBOTS_ONLY") == nullptr &&
+                   (s->substeps_fn == (substeps_fn_t)k_substeps<2, PS_F_LINK> || s->substeps_fn == (substeps_fn_t)k_substeps<2, PS_F_NPC | PS_F_FEW> ||
+                    s->substeps_fn == (substeps_fn_t)k_substeps<2, PS_F_NPC | PS_F_BOX | PS_F_FEW> || s->substeps_fn == (substeps_fn_t)k_substeps<2, PS_F_STATIC | PS_F_FEW>)));
   // Debug / experiment switches are read HERE, once per handle, never on the launch path; MQE_VERBOSE lists the ones in effect.
   if (const char* sp = getenv("MQE_DEBUG_STOP_PHASE")) {
     // per-phase counter runs: the wavefront leaves k_simulate_a2 after that phase tap WITHOUT writing the state back, so the
