@@ -2600,7 +2600,7 @@ __global__ void __launch_bounds__(64, EPW == 2 ? 2 : SubstepsClass<TP>::waves) k
       const int w = i / nj, jt = i - w * nj;
       st.act_hist[(size_t)w * R12 + (size_t)e * nj + jt] = acth[i];
     }
-  if constexpr (ShapeClass<TP>::small && !(TA == 2 && EPW == 2)) if (pa.on) {      // (every kernel of the 16-envs-per-CU class; with the DevState pointers in register pairs of their own none of them spills)
+  if constexpr ((ShapeClass<TP>::small || TP > 0) && !(TA == 2 && EPW == 2)) if (pa.on) {      // (every kernel of the 16-envs-per-CU class; with the DevState pointers in register pairs of their own none of them spills)
     // ---- post_physics_step of this wavefront's env(s) (legged_robot.py:117-157 + the task wrapper), from the state just written: the
     // writer and the readers are lanes of this one wavefront (one CU, one vector L1), a workgroup-scope fence orders them
     __threadfence_block();

@@ -376,7 +376,14 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
                   // ... and, since every DevState pointer has a register pair of its own (own_state), the other kernels of the 16-envs-per-CU class: no spills
                   (getenv("MQE_FUSE_POST_ROBOTS_ONLY") == nullptr &&
                    (s->substeps_fn == (substeps_fn_t)k_substeps<2, PS_F_LINK> || s->substeps_fn == (substeps_fn_t)k_substeps<2, PS_F_NPC | PS_F_FEW> ||
-                    s->substeps_fn == (substeps_fn_t)k_substeps<2, PS_F_NPC | PS_F_BOX | PS_F_FEW> || s->substeps_fn == (substeps_fn_t)k_substeps<2, PS_F_STATIC | PS_F_FEW>)));
+                    s->substeps_fn == (substeps_fn_t)k_substeps<2, PS_F_NPC | PS_F_BOX | PS_F_FEW> || s->substeps_fn == (substeps_fn_t)k_substeps<2, PS_F_STATIC | PS_F_FEW> ||
+                    // ... and the flock and 2-vs-2 shapes (one round at 2 wavefronts per SIMD, registers to spare: go1sheep-hard +3.2 %, go1football-2vs2
+                    // +1.5 %).  NOT go1football-defender, whose 4096 envs run in two rounds: both pay the epilogue's ~10 us chain, -1 % (MQE_FUSE_POST_ALL=1 tries it)
+                    (getenv("MQE_FUSE_POST_SMALL_ONLY") == nullptr &&
+                     (s->substeps_fn == (substeps_fn_t)k_substeps<2, PS_F_NPC> || s->substeps_fn == (substeps_fn_t)k_substeps<4, PS_F_NPC> ||
+                      s->substeps_fn == (substeps_fn_t)k_substeps<2, PS_F_NPC, 1, true> ||
+                      (getenv("MQE_FUSE_POST_ALL") != nullptr &&
+                       (s->substeps_fn == (substeps_fn_t)k_substeps<3, PS_F_NPC | PS_F_ROW> || s->substeps_fn == (substeps_fn_t)k_substeps<3, PS_F_NPC | PS_F_ROW, 1, true>)))))));
   // Debug / experiment switches are read HERE, once per handle, never on the launch path; MQE_VERBOSE lists the ones in effect.
   if (const char* sp = getenv("MQE_DEBUG_STOP_PHASE")) {
     // per-phase counter runs: the wavefront leaves k_simulate_a2 after that phase tap WITHOUT writing the state back, so the
