@@ -399,6 +399,8 @@ def main():
             3: (52 + 96 + 192, 52 + 96 + 192 + 204),   # k_substeps: root, dof, actuator history -> the same + net contact forces
             4: (4, 4 + 284 + 64 + 4),             # k_post_physics: gait index -> gait, obs bag, wrapper obs, reward
         }
+        if cnt[4] <= 0:      # the post-physics step ran as k_substeps' epilogue: its bytes are that launch's
+            own_bytes[3] = (own_bytes[3][0] + own_bytes[4][0], own_bytes[3][1] + own_bytes[4][1])
         tail_flops = 2.0 * R * (sum(d.adaptation.dims[l] * d.adaptation.dims[l + 1] for l in range(1, d.adaptation.n_layers)) +
                                 sum(d.body.dims[l] * d.body.dims[l + 1] for l in range(1, d.body.n_layers)) + 2 * h_b)
         act_flops = 2.0 * R * 12 * 4 * 1248
