@@ -130,6 +130,83 @@ def time_variant(task, N, dev, steps, warmup, env_vars):
     return 1e3 * el / steps, A
 
 
+SUBSTEPS_BOUND = "valu-issue / latency (not hbm)"
+SUBSTEPS_NOTE = ("achieved / peak / frac are the PRESCRIBED form -- the whole step's algorithmic HBM bytes over this kernel's average launch time against the HBM peak -- "
+                 "but HBM is not what binds it: one env per wavefront, state LDS-resident for the 4 substeps; the limiters are the wavefront's chain of dependent "
+                 "waits (78 us for a wavefront alone on its CU) and the vector ALU's issue slots (86 % taken inside the substeps with all envs resident at "
+                 "4 waves/SIMD: valu_issue); DESIGN.md 3.1 (e), (f)")
+
+# the other BASELINE.json configs that fit one GPU (+ the headline with the URDF's exact thigh / calf boxes): timed on the driver's
+# own line (`configs`), same protocol as the headline -- fresh U(-1,1) actions, inputs resident, device-synchronised
+EXTRA_CONFIGS = [
+    ("go1sheep-hard", 2048, {}, "BASELINE config 3"),
+    ("go1seesaw", 4096, {}, "BASELINE config 4"),
+    ("go1football-defender", 4096, {}, "BASELINE config 5's per-GPU shard (32768 envs over 8 GPUs)"),
+    ("go1gate", 4096, {"MQE_COLLISION_MODEL": "exact"}, "BASELINE config 2 with the URDF's thigh / calf boxes (60 feature points per robot)"),
+]
+
+
+def time_config(task, N, dev, env_vars, label, min_ms=100.0, warmup=10):
+    """One more workload on the same line: >= min_ms of timed steps of a fresh env created under `env_vars`, with the physics kernel's
+    HIP-event time (every 16th step bracketed) and the prescribed roofline form on it."""
+    from mqe.envs.utils import make_mqe_env, custom_cfg
+    old = {k: os.environ.get(k) for k in env_vars}
+    os.environ.update(env_vars)
+    try:
+        margs = make_args(task, N, 0, dev)
+        with contextlib.redirect_stdout(sys.stderr):
+            env, _ = make_mqe_env(task, margs, custom_cfg(margs))
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    A = env.num_agents
+    A_phys = env.env.num_agents
+    P = env.env.num_npcs
+    eng = env.env.engine
+    gen = torch.Generator(device=dev).manual_seed(1234)
+    env.reset()
+    pool = [torch.rand(N, A, 3, device=dev, generator=gen) * 2 - 1 for _ in range(64)]
+    for t in range(warmup):
+        env.step(pool[t % 64])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(8):
+        env.step(pool[(warmup + t) % 64])
+    torch.cuda.synchronize()
+    est = (time.perf_counter() - t0) / 8
+    steps = int(min(5000, max(32, -(-min_ms * 1e-3 // est))))
+    eng.profile_enable(16)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(steps):
+        env.step(pool[t % 64])
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ms, _ = eng.profile_read(12)
+    eng.profile_enable(False)
+    overflow = int(env.env.contact_overflow.sum().item())
+    kms, cnt = ms[:6], ms[6:12]
+    sub_ms = kms[3] / max(cnt[3], 1)
+    R = N * A_phys
+    step_bytes = 10128.0 * R + 2 * 104.0 * N * P
+    ach = step_bytes / (sub_ms * 1e-3) / 1e9 if sub_ms > 0 else 0.0
+    value = A * N * steps / el
+    row = {"workload": f"{task}, {A} agents" + (f" (+ {A_phys - A} scripted)" if A_phys != A else "") + (f" + {P} NPC" if P else "") + f", num_envs={N}",
+           "what": label, "switches": env_vars or None,
+           "value": round(value, 1), "unit": "env-steps/s", "ms_per_step": round(1e3 * el / steps, 4), "steps": steps, "warmup": warmup + 8,
+           "physical_robot_steps_per_s": round(value * A_phys / A, 1),
+           "roofline": {"kernel": "k_substeps", "bound": SUBSTEPS_BOUND, "achieved": round(ach, 3), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": round(ach / PEAK_HBM_GBS, 6), "avg_launch_ms": round(sub_ms, 4), "launches": int(cnt[3]), "traffic": None,
+                        "bytes_basis": "SURVEY 8(d): 10128 B per robot-step + 208 B per free NPC body and env step, charged to the dominant kernel"},
+           "kernel_avg_launch_ms": {PROF_KERNEL[i]: round(kms[i] / max(cnt[i], 1), 4) for i in range(6) if cnt[i] > 0},
+           "contact_overflow_substeps": overflow}
+    env.close()
+    return row
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -139,6 +216,7 @@ def main():
     ap.add_argument("--num_envs", type=int, default=4096, help="envs PER GPU (weak scaling)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_strict_f32", action="store_true", help="skip the exact-f32 companion run")
+    ap.add_argument("--no_configs", action="store_true", help="skip the other single-GPU BASELINE configs (`configs` on the line)")
     ap.add_argument("--cpu_sample_envs", type=int, default=0, help="CPU baseline batch (0 = the GPU run's num_envs, 8 steps)")
     ap.add_argument("--cpu_sample_steps", type=int, default=8)
     ap.add_argument("--gather", choices=["between", "after", "tail"], default=os.environ.get("MQE_BENCH_GATHER", "tail"),
@@ -361,12 +439,10 @@ def main():
         else:
             byts = step_bytes / launches_per_step(dom)
             ach = byts / (avg_ms(dom) * 1e-3) / 1e9
-            roof = {"kernel": PROF_NAMES[dom], "bound": "hbm", "achieved": round(ach, 3), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            roof = {"kernel": PROF_NAMES[dom], "bound": SUBSTEPS_BOUND if dom == 3 else "hbm", "achieved": round(ach, 3), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(ach / PEAK_HBM_GBS, 6), "traffic": None, "avg_launch_ms": round(avg_ms(dom), 4), "launches": int(cnt[dom]),
                     "bytes_basis": "SURVEY 8(d): the whole step's 10128 B/agent-step charged to the dominant kernel; per-kernel shares in roofline_per_kernel",
-                    "note": "not HBM-bound by construction: one env per wavefront, state LDS-resident for the 4 substeps; the limiters are "
-                            "the wavefront's chain of dependent waits (78 us for a wavefront alone on its CU) and the vector ALU's issue slots (86 % taken "
-                            "inside the substeps with all envs resident at 4 waves/SIMD: valu_issue); DESIGN.md 3.1 (e), (f)"}
+                    "note": SUBSTEPS_NOTE}
         # HBM traffic of the dominant kernel: NOT measured in this run -- copied from the committed rocprofv3 PMC passes (separate
         # runs of this command, profiles/*pmc_summary.json) and labelled as such
         try:
@@ -419,7 +495,7 @@ def main():
             elif i == 1:
                 row.update({"bound": "latency (L2 weight stream, 6 dependent stages)", "f32_equivalent_TFLOPs": round(tail_flops / launches_per_step(i) / t / 1e12, 2)})
             elif i == 3:
-                row.update({"bound": "latency (occupancy-limited, LDS-resident state)", "actuator_mlp_f32_mfma_TFLOPs": round(act_flops / t / 1e12, 2)})
+                row.update({"bound": SUBSTEPS_BOUND, "actuator_mlp_f32_mfma_TFLOPs": round(act_flops / t / 1e12, 2)})
             else:
                 row.update({"bound": "latency / hbm"})
             table.append(row)
@@ -462,6 +538,10 @@ def main():
             pms, _ = time_variant(args.task, N, dev, min(args.steps, 100), min(args.warmup, 10), {"MQE_SOLVER": "pgs"})
             out["solver_pgs"] = {"value": round(A * N / (pms * 1e-3), 1), "unit": "env-steps/s", "ms_per_step": round(pms, 4), "steps": min(args.steps, 100),
                                  "switches": "MQE_SOLVER=pgs (desc.solver_type = 0: velocity-level projected Gauss-Seidel with the erp bias)"}
+        lean = args.no_strict_f32 and args.no_cpu_baseline          # the A/B and profiling scripts under tools/: the headline alone
+        if world == 1 and not args.no_configs and not lean and not os.environ.get("MQE_BENCH_NOPROF") and args.task == "go1gate" and N == 4096:
+            # absolute env-steps/s and the roofline fraction of every config that fits one GPU, on the driver's line
+            out["configs"] = [time_config(t, n, dev, ev, what) for (t, n, ev, what) in EXTRA_CONFIGS]
         if not args.no_cpu_baseline and world == 1:
             torch.set_num_threads(os.cpu_count() or 1)
             # the CPU restatement at the headline size (few steps) and at the reference's own CPU-runnable size (N = 4)

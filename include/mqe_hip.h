@@ -202,7 +202,7 @@ typedef struct {
   const float* npc_init_state;            /* [P,13] */
   const float* gate_pos;                  /* [N,2] task specific (wrappers' gate_pos / football gate) or NULL */
   /* Run-time terrain curriculum (terrain.curriculum with several rows; legged_robot.py:479-503, called first in reset_idx,
-   * go1.py:123-125), upstream's code restated with its accidents (fixture tests/golden/fullstep_seesaw_curriculum.npz): when env e
+   * go1.py:123-125), upstream's code restated with its accidents (fixture tests/golden/fullstep_pushbox_curriculum.npz): when env e
    * is reset -- the first reset() included, init_done is set before it -- the distance walked is measured on ROW e of the agents'
    * root-state tensor (robot e % A of env e / A: single-agent code left in place) against env e's origin, as the rows stood before
    * any reset of this step; farther than terrain_env_length / 2 moves the env one level up; the commands Go1 never samples are zero,

@@ -325,6 +325,8 @@ __host__ __device__ inline PhysLds phys_lds_layout(int A, int P, int ND, int nbo
   return L;
 }
 
+// floats the post-physics epilogue of k_substeps stages from L.body on (obs-bag rows, last-action rows, NPC rows, the actions)
+__host__ __device__ inline int post_staging_floats(int epw, int amp, int nj) { return epw * amp * (MQE_OBS_BAG + 24) + epw * MQE_MAX_NPCS * 13 + epw * nj; }
 struct PhysDebug { float* minv; int* nc; float* contacts; int robot; long long* times; int stop_after; };
 // phase tap: the 100 MHz wall clock at lane 0 and, for per-phase counter runs (tools/phase_counters.py), an early exit of the whole wavefront
 #define TSTAMP(i) do { if (dbg.times != nullptr && lane == 0) dbg.times[i] = (long long)wall_clock64(); if (dbg.stop_after == (i)) return; } while (0)
@@ -2608,7 +2610,10 @@ __global__ void __launch_bounds__(64, EPW == 2 ? 2 : SubstepsClass<TP>::waves) k
     constexpr int AMP = (TA == 1 || TA == 2) ? 2 : MQE_MAX_AGENTS;
     // LDS: root and joint states are still where the physics kept them (L.root, L.dof of each env's layout); the staging rows of the
     // post step go into the dead torque / bias / history area behind them ... no: into the link-record area (L.body .. : dead since the sweep)
-    float* sb = lds_wave + L.body;                           // obs rows, last-action rows, NPC rows, the env's actions: < 500 floats of the >= 832 there
+    // obs rows, last-action rows, NPC rows, the env's actions: post_staging_floats(EPW, AMP, nj) floats from L.body on -- 337 of the 936 there for
+    // go1gate, 650 of the 740 in front of the second env's root rows for the paired go1plane kernel, 557 for four robots; mqe_sim_create
+    // checks the actual layout against the same formula and keeps the separate launch when it does not fit
+    float* sb = lds_wave + L.body;
     float* act_l = sb + EPW * AMP * (MQE_OBS_BAG + 24) + EPW * MQE_MAX_NPCS * 13;
     for (int i = lane_wave; i < EPW * nj; i += 64) {          // the wavefront's actions, one coalesced load
       const int ge = i / nj, jt = i - ge * nj;

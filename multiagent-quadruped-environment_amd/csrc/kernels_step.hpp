@@ -1181,6 +1181,7 @@ __global__ void __launch_bounds__(64) k_post_staged(const DevModel* m, DevState 
   if (stages & MQE_POST_RESET) {
     const uint8_t reset = st.reset_buf[e];       // as it stands NOW: a subclass's check_termination may have changed it since FRAME
     st.wdone[e] = reset;
+    if (m->terminate_on_base_contact) st.collide_buf[e] = reset;      // upstream's collide_buf IS reset_buf then (legged_robot.py:165): an override's edit shows in both
     if (reset) {
       reset_env_dev(m, st, e);
       for (int k = 0; k < P * 13; k++) npc_pre[k] = root[A * 13 + k];

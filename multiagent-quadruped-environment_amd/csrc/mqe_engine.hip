@@ -271,6 +271,8 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   m.dt = d->dt; m.decimation = d->decimation; m.gravity_z = d->gravity_z; m.solver_iterations = d->solver_iterations;
   m.contact_offset = d->contact_offset; m.max_depen = d->max_depenetration_velocity; m.friction = d->friction; m.erp = d->erp;
   m.solver_type = d->solver_type == 1 ? 1 : 0; m.vel_iters = d->velocity_iterations > 0 ? d->velocity_iterations : 0;
+  if (m.solver_type == 1 && d->solver_iterations < 1) return fail(-6, "solver_type = 1 (temporal Gauss-Seidel) needs num_position_iterations >= 1: its sub-step is dt / n");
+  if (d->solver_iterations < 0 || d->solver_iterations > 64) return fail(-6, "solver_iterations out of range (0 .. 64)");
   m.robot = d->robot;
   m.npc_mass = d->npc_mass; m.npc_inertia = d->npc_inertia; m.npc_n_spheres = d->npc_n_spheres;
   memcpy(m.npc_sphere_center, d->npc_sphere_center, sizeof m.npc_sphere_center);
@@ -384,6 +386,19 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
                       s->substeps_fn == (substeps_fn_t)k_substeps<2, PS_F_NPC, 1, true> ||
                       (getenv("MQE_FUSE_POST_ALL") != nullptr &&
                        (s->substeps_fn == (substeps_fn_t)k_substeps<3, PS_F_NPC | PS_F_ROW> || s->substeps_fn == (substeps_fn_t)k_substeps<3, PS_F_NPC | PS_F_ROW, 1, true>)))))));
+  if (s->fuse_post) {
+    // the epilogue stages its observation / last-action / NPC rows and the env's actions in the link-record area (k_substeps: `sb`):
+    // EPW * AMP * (MQE_OBS_BAG + 24) + EPW * MQE_MAX_NPCS * 13 + EPW * 12 A floats from L.body on.  With one env per wavefront they must
+    // end inside the env's own layout; with two, before the SECOND env's root rows (which post_body still reads).  A layout that does
+    // not leave that room (another stride, a larger bag, more NPC rows) keeps the separate launch instead of overwriting live state.
+    const int epw = s->substeps_epw, amp = (A == 1 || A == 2) ? 2 : MQE_MAX_AGENTS;
+    const int need = post_staging_floats(epw, amp, 12 * A);
+    const int room = (epw == 1 ? L.total : L.total + L.root) - L.body;
+    if (need > room) {
+      if (getenv("MQE_VERBOSE")) fprintf(stderr, "mqe: post-physics epilogue needs %d floats of staging, the layout has %d: separate launch\n", need, room);
+      s->fuse_post = false;
+    }
+  }
   // Debug / experiment switches are read HERE, once per handle, never on the launch path; MQE_VERBOSE lists the ones in effect.
   if (const char* sp = getenv("MQE_DEBUG_STOP_PHASE")) {
     // per-phase counter runs: the wavefront leaves k_simulate_a2 after that phase tap WITHOUT writing the state back, so the

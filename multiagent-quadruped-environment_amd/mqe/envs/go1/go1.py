@@ -39,22 +39,6 @@ def _default_engine_factory(desc, keep, device):
     return HipEngine(desc, keep, device=device)
 
 
-class _EpisodeInfo(dict):
-    """extras["episode"]: with the run-time terrain curriculum on, "terrain_level" is the mean of the LIVE levels (_fill_extras,
-    legged_robot.py:1069-1071), computed when it is read -- the step itself launches nothing for it."""
-
-    def __init__(self, levels=None):
-        super().__init__()
-        self._levels = levels
-        if levels is not None:
-            dict.__setitem__(self, "terrain_level", None)
-
-    def __getitem__(self, k):
-        if k == "terrain_level" and self._levels is not None:
-            return torch.mean(self._levels.float())
-        return dict.__getitem__(self, k)
-
-
 class Go1:
     # engine_factory(desc, keepalive, device) -> engine; the default (and only product) engine is the HIP one.
     engine_factory = staticmethod(_default_engine_factory)
@@ -224,13 +208,23 @@ class Go1:
         self.npc_indices = self.actor_indices[:, A:]
         self.obs_buf = ObsBag(self.cfg.obs, T(abi.T_OBS_BAG), self.env_info if self.env_info else None)
         self.privileged_obs_buf = None
-        self.extras = {"time_outs": self.time_out_buf, "episode": _EpisodeInfo(self.terrain_levels if self.engine.desc.terrain_curriculum else None),
-                       "contact_overflow": self.contact_overflow}
+        # extras["episode"]: a plain dict.  With the run-time terrain curriculum on, "terrain_level" is a REAL 0-dim device tensor (upstream
+        # stores torch.mean(terrain_levels.float()), _fill_extras, legged_robot.py:1069-1071), refreshed in place after every reset / step
+        # (levels only move inside resets), so .items(), .get(), dict(...) and ** all see the value -- one tiny launch, on that path only
+        self.extras = {"time_outs": self.time_out_buf, "episode": {}, "contact_overflow": self.contact_overflow}
+        if self.engine.desc.terrain_curriculum:
+            self.extras["episode"]["terrain_level"] = torch.zeros((), device=dev)
+            self._refresh_extras()
         self.common_step_counter = 0
         if self.task == "football_defender":
             self.gate_pos = torch.zeros(N, 3, device=dev)
             self.gate_pos[:, :2] = torch.from_numpy(self._task_gate_pos()).to(dev)
             self.gate_pos[:, 2] = self.env_origins[:, 2]
+
+    def _refresh_extras(self):
+        ep = self.extras["episode"]
+        if "terrain_level" in ep:
+            torch.mean(self.terrain_levels.float(), dim=0, out=ep["terrain_level"])
 
     # ---- derived views ------------------------------------------------------------------------------------------
     @property
@@ -311,6 +305,7 @@ class Go1:
     def reset(self):
         """Reset all robots (go1.py:147-151): no physics step, observations recomputed."""
         self.engine.reset_all()
+        self._refresh_extras()
         return self.obs_buf
 
     # ---- plugin points of the reference's class stack ----------------------------------------------------------------------------
@@ -399,9 +394,11 @@ class Go1:
                 c = self.cfg.normalization.clip_actions
                 self.actions.copy_(torch.clip(a, -c, c).reshape(self.actions.shape))
                 self._decimation_loop()
+                self._refresh_extras()
                 return self.obs_buf, self.rew_buf, self.reset_buf, self.extras
             self.engine.step_joint(a)
             self.common_step_counter += 1
+            self._refresh_extras()
             return self.obs_buf, self.rew_buf, self.reset_buf, self.extras
         cmd = action.reshape(-1, self.engine.desc.num_command_dims).to(self.engine.torch_device, torch.float32).contiguous()   # 3 unless command.cfg says otherwise (go1.py:64-93)
         e = self.engine
@@ -422,14 +419,15 @@ class Go1:
             e.step_command(cmd)
             self._steps_policy = getattr(self, "_steps_policy", 0) + 1
             self.common_step_counter += 1
+        self._refresh_extras()
         return self.obs_buf, self.rew_buf, self.reset_buf, self.extras
 
     def step_fused(self, actions):
         """Wrapper-level step: raw actions (N, A', 3) in [-1,1]; clip, task action scale, policy, 4 substeps,
         post-step, task observation and reward all inside the engine (mqe_step)."""
         if self.has_overrides:
-            raise NotImplementedError("the fused wrapper-level step runs entirely inside the engine: a Go1 subclass that overrides "
-                                      "_compute_torques / compute_reward / _post_physics_step_callback is stepped through Go1.step()")
+            raise NotImplementedError("the fused wrapper-level step runs entirely inside the engine: a Go1 subclass that overrides any of "
+                                      + " / ".join(self._PLUGIN_POINTS) + " is stepped through Go1.step()")
         if self.engine.desc.num_command_dims != 3:
             raise NotImplementedError("wrapper-level steps carry (N, A', 3) velocity commands; a config whose command.cfg adds action "
                                       "columns (go1.py:64-93) is stepped through Go1.step()")
@@ -441,6 +439,7 @@ class Go1:
             self.engine.step(a, hooks[0])
         self._steps_policy = getattr(self, "_steps_policy", 0) + 1
         self.common_step_counter += 1
+        self._refresh_extras()
 
     def get_state(self):
         """Checkpoint of the whole simulation state: the engine's blob (every state tensor, history ring and its position, lag ring, wrapper

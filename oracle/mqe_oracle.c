@@ -288,6 +288,8 @@ static int wrapper_dims(const mqe_sim_desc* d, int* Aw, int* D) {
 int mqo_sim_create(const mqe_sim_desc* d, mqo_sim** out) {
   if (d->abi_version != MQE_ABI_VERSION) { snprintf(g_err, sizeof g_err, "abi version mismatch"); return -1; }
   if (d->num_agents > MAXA || d->num_npcs > MAXP) { snprintf(g_err, sizeof g_err, "too many agents/npcs"); return -2; }
+  if (d->solver_type == 1 && d->solver_iterations < 1) { snprintf(g_err, sizeof g_err, "solver_type = 1 (temporal Gauss-Seidel) needs num_position_iterations >= 1"); return -6; }
+  if (d->solver_iterations < 0 || d->solver_iterations > 64) { snprintf(g_err, sizeof g_err, "solver_iterations out of range (0 .. 64)"); return -6; }
   mqo_sim* s = (mqo_sim*)calloc(1, sizeof *s);
   s->d = *d;
   int N = s->N = d->num_envs, A = s->A = d->num_agents, P = s->P = d->num_npcs;
@@ -1769,6 +1771,7 @@ static int post_stages(mqo_sim* s, int stages) {
   for (int e = 0; e < N; e++) {
     if (stages & MQE_POST_RESET) {
       s->wdone[e] = s->reset_buf[e];            /* (a subclass's check_termination may have changed the flag since FRAME) */
+      if (d->terminate_on_base_contact) s->collide_buf[e] = s->reset_buf[e];   /* ... and collide_buf aliases it (legged_robot.py:165) */
       if (s->reset_buf[e]) {
         reset_env(s, e);                                                            /* :148 */
         if (P) memcpy(pre_npc + (size_t)e * P * 13, s->root + ((size_t)e * (A + P) + A) * 13, (size_t)P * 13 * 4);

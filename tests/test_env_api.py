@@ -386,6 +386,12 @@ def test_unsupported_switches_are_refused_not_ignored(oracle_backed):
             assert torch.equal(env.env.env_origins, env.env.terrain_origins[lv.long(), env.env.terrain_types.long()])
             assert not torch.equal(env.env.env_origins_repeat.view(4, 2, 3)[:, 0], env.env.env_origins)      # the copy behind obs.base_pos keeps the first track
             assert float(env.env.extras["episode"]["terrain_level"]) == float(lv.float().mean())
+            # ... and it is a real value in a plain dict: every way a logger may read it sees the tensor, not a placeholder
+            ep = env.env.extras["episode"]
+            want = float(lv.float().mean())
+            assert float(dict(ep)["terrain_level"]) == want and float(ep.get("terrain_level")) == want and float(ep.copy()["terrain_level"]) == want
+            assert [float(v) for k, v in ep.items() if k == "terrain_level"] == [want] and float({**ep}["terrain_level"]) == want
+            assert isinstance(ep["terrain_level"], torch.Tensor) and ep["terrain_level"].dim() == 0
         env.close()
         ENV_DICT["go1gate"]["config"] = base
     assert base.command.cfg.vel is True and base.terrain.curriculum is False      # the registered config was not touched
