@@ -201,7 +201,8 @@ def time_config(task, N, dev, env_vars, label, min_ms=100.0, warmup=10):
            "roofline": {"kernel": "k_substeps", "bound": SUBSTEPS_BOUND, "achieved": round(ach, 3), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": round(ach / PEAK_HBM_GBS, 6), "avg_launch_ms": round(sub_ms, 4), "launches": int(cnt[3]), "traffic": None,
                         "bytes_basis": "SURVEY 8(d): 10128 B per robot-step + 208 B per free NPC body and env step, charged to the dominant kernel"},
-           "kernel_avg_launch_ms": {PROF_KERNEL[i]: round(kms[i] / max(cnt[i], 1), 4) for i in range(6) if cnt[i] > 0},
+           "kernel_avg_launch_ms": {("k_gemm_h2", "k_policy_tail", "k_compute_torques_mfma", "k_substeps", "k_post_physics", "k_pre_policy")[i]: round(kms[i] / max(cnt[i], 1), 4)
+                                    for i in range(6) if cnt[i] > 0},
            "contact_overflow_substeps": overflow}
     env.close()
     return row
