@@ -2165,6 +2165,206 @@ int mqo_step_joint(mqo_sim* s, const float* actions12) {
   return 0;
 }
 
+
+/* ------------------------------------------------------------------------------------------ (f)4: the forward depth camera
+ * legged_robot_field.py:23-93 (create_camera_sensor + attach_camera_to_body on the base link, FOLLOW_TRANSFORM) and :196-223
+ * (get_camera_image_gpu_tensor(..., IMAGE_DEPTH)): Isaac Gym's rasteriser is closed, so the image is DEFINED here as a ray cast over
+ * the geometry the physics collides with -- per pixel the distance along the optical axis to the first surface, reported negative,
+ * -inf where nothing lies within `far` -- and this scalar caster is what the HIP kernel (csrc/kernels_camera.hpp) is held to.
+ * Conventions (the spec of the image): camera frame = body-local (position, ZYX Euler) on the base link, optical axis +x, +z up; pixel
+ * (0, 0) top-left; ray direction (1, yc, zc), yc = -(2 (j + 1/2) / W - 1) tan(hfov / 2), zc = -(2 (i + 1/2) / H - 1) tan(hfov / 2) H / W,
+ * so the ray parameter IS the depth.  Surfaces: ground slab (or the relief map, marched in half cells and bisected six times), the
+ * wall prisms (sphere tracing over the signed-distance map; inside a footprint the wall reaches from the ground to its top), the
+ * OTHER robots' collision primitives, free NPC spheres / the free box, the 1-dof link (plank / door box or the tug's upright cylinder
+ * as a capsule) and its platform, the scenery boxes.  An eye inside a closed shape does not see that shape. */
+static real ray_sphere_o(const real* o, const real* dir, const real* c, real r, real best) {
+  real oc[3] = {o[0] - c[0], o[1] - c[1], o[2] - c[2]};
+  real a = dot3(dir, dir), b = dot3(dir, oc), cc = dot3(oc, oc) - r * r;
+  real disc = b * b - a * cc;
+  if (disc < 0 || cc < 0) return best;
+  real t = (-b - (real)sqrt((double)disc)) / a;
+  return (t > (real)1e-4 && t < best) ? t : best;
+}
+static real ray_capsule_o(const real* o, const real* dir, const real* c, const real* u, real r, real best) {
+  /* segment c - u .. c + u swept by r: the infinite cylinder's quadratic where the foot falls between the ends, else the end spheres */
+  real pa[3] = {c[0] - u[0], c[1] - u[1], c[2] - u[2]}, pb[3] = {c[0] + u[0], c[1] + u[1], c[2] + u[2]};
+  real ba[3] = {2 * u[0], 2 * u[1], 2 * u[2]}, oa[3] = {o[0] - pa[0], o[1] - pa[1], o[2] - pa[2]};
+  real baba = dot3(ba, ba);
+  if (baba < (real)1e-12) return ray_sphere_o(o, dir, c, r, best);
+  real bard = dot3(ba, dir), baoa = dot3(ba, oa), rdoa = dot3(dir, oa), oaoa = dot3(oa, oa), dd = dot3(dir, dir);
+  real a = baba * dd - bard * bard, b = baba * rdoa - baoa * bard, cc = baba * oaoa - baoa * baoa - r * r * baba;
+  real disc = b * b - a * cc;
+  if (disc >= 0 && a > (real)1e-12) {
+    real t = (-b - (real)sqrt((double)disc)) / a, y = baoa + t * bard;
+    if (y > 0 && y < baba) return (t > (real)1e-4 && t < best) ? t : best;
+  }
+  return ray_sphere_o(o, dir, pb, r, ray_sphere_o(o, dir, pa, r, best));
+}
+static real ray_box_o(const real* o, const real* dir, const real* c, const real* R, const real* h, real best) {
+  real oc[3] = {o[0] - c[0], o[1] - c[1], o[2] - c[2]}, ol[3], dl[3];
+  for (int k = 0; k < 3; k++) { ol[k] = R[k] * oc[0] + R[3 + k] * oc[1] + R[6 + k] * oc[2]; dl[k] = R[k] * dir[0] + R[3 + k] * dir[1] + R[6 + k] * dir[2]; }
+  real t0 = (real)1e-4, t1 = best;
+  for (int k = 0; k < 3; k++) {
+    if (fabs((double)dl[k]) < 1e-9) { if (fabs((double)ol[k]) > h[k]) return best; continue; }
+    real ta = (-h[k] - ol[k]) / dl[k], tb = (h[k] - ol[k]) / dl[k];
+    if (ta > tb) { real x = ta; ta = tb; tb = x; }
+    if (ta > t0) t0 = ta;
+    if (tb < t1) t1 = tb;
+    if (t0 > t1) return best;
+  }
+  if (fabs((double)ol[0]) <= h[0] && fabs((double)ol[1]) <= h[1] && fabs((double)ol[2]) <= h[2]) return best;
+  return t0;
+}
+static void link_frames(const mqo_sim* s, int env, int r, real R[NB][9], real p[NB][3]) {
+  const mqe_robot_model* m = &s->d.robot;
+  const float* rs = s->root + ((size_t)env * (s->A + s->P) + r) * 13;
+  const float* dofs = s->dof + (size_t)env * s->ND * 2;
+  real q[4] = {rs[3], rs[4], rs[5], rs[6]};
+  real nq = (real)sqrt((double)(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]));
+  for (int k = 0; k < 4; k++) q[k] /= nq;
+  quat_to_mat(q, R[0]);
+  for (int k = 0; k < 3; k++) p[0][k] = rs[k];
+  for (int b = 1; b < NB; b++) {
+    int pb = g_parent[b];
+    real off[3] = {m->joint_offset[b][0], m->joint_offset[b][1], m->joint_offset[b][2]}, dd[3];
+    mat3_vec(R[pb], off, dd);
+    for (int k = 0; k < 3; k++) p[b][k] = p[pb][k] + dd[k];
+    real ax[3] = {m->joint_axis[b][0], m->joint_axis[b][1], m->joint_axis[b][2]}, Rj[9];
+    axis_angle_mat(ax, (real)dofs[(r * 12 + b - 1) * 2], Rj);
+    mat3_mul(R[pb], Rj, R[b]);
+  }
+}
+int mqo_render_depth(mqo_sim* s, float* out, int H, int W, float hfov_deg, const float* cam_pos3, const float* cam_rpy3, float far_m) {
+  const mqe_sim_desc* d = &s->d;
+  const mqe_robot_model* m = &d->robot;
+  if (!s || !out || H <= 0 || W <= 0 || H * W > (1 << 16) || !(hfov_deg > 1.0f && hfov_deg < 179.0f) || !(far_m > 0.0f)) { snprintf(g_err, sizeof g_err, "mqo_render_depth: bad argument"); return -6; }
+  const int A = s->A, P = s->P, N = s->N, npix = H * W;
+  const real tan_h = (real)tan(0.5 * (double)hfov_deg * 3.14159265358979 / 180.0), tan_v = tan_h * (real)H / (real)W;
+  const real hs = d->horizontal_scale;
+  const int nx = d->sdf_nx, ny = d->sdf_ny;
+  const int n_free = (d->npc_kind == MQE_NPC_BALL || d->npc_kind == MQE_NPC_SHEEP || d->npc_kind == MQE_NPC_BOX) ? P : 0;
+  real Rc[9];
+  {
+    real Rz[9], Ry[9], Rx[9], T[9], ez[3] = {0, 0, 1}, ey[3] = {0, 1, 0}, ex[3] = {1, 0, 0};
+    axis_angle_mat(ez, cam_rpy3[2], Rz); axis_angle_mat(ey, cam_rpy3[1], Ry); axis_angle_mat(ex, cam_rpy3[0], Rx);
+    mat3_mul(Rz, Ry, T); mat3_mul(T, Rx, Rc);
+  }
+#pragma omp parallel for schedule(static)
+  for (int e = 0; e < N; e++) {
+    real LR[MAXA][NB][9], Lp[MAXA][NB][3];
+    for (int r = 0; r < A; r++) link_frames(s, e, r, LR[r], Lp[r]);
+    const float* root = s->root + (size_t)e * (A + P) * 13;
+    for (int a = 0; a < A; a++) {
+      real Rw[9], o[3], cp[3] = {cam_pos3[0], cam_pos3[1], cam_pos3[2]}, t3[3];
+      mat3_mul(LR[a][0], Rc, Rw);
+      mat3_vec(LR[a][0], cp, t3);
+      for (int k = 0; k < 3; k++) o[k] = Lp[a][0][k] + t3[k];
+      for (int pix = 0; pix < npix; pix++) {
+        const int pi = pix / W, pj = pix - pi * W;
+        real loc[3] = {1, -((real)2 * ((real)pj + (real)0.5) / (real)W - 1) * tan_h, -((real)2 * ((real)pi + (real)0.5) / (real)H - 1) * tan_v}, dir[3];
+        mat3_vec(Rw, loc, dir);
+        real best = far_m;
+        const real dxy = (real)sqrt((double)(dir[0] * dir[0] + dir[1] * dir[1]));
+        /* ground */
+        if (!s->ground_height) {
+          if (dir[2] < (real)-1e-9) { real t = (d->ground_z - o[2]) / dir[2]; if (t > (real)1e-4 && t < best) best = t; }
+        } else {
+          const real st = dxy > (real)1e-6 ? (real)0.5 * hs / dxy : (real)0.05;
+          real tp = 0;
+          for (real t = st; t < best; t += st) {
+            real gx, gy, pz = o[2] + t * dir[2];
+            if (pz < d->ground_z + map_sample(s, s->ground_height, o[0] + t * dir[0], o[1] + t * dir[1], &gx, &gy)) {
+              real lo = tp, hi = t;
+              for (int it = 0; it < 6; it++) {
+                real mid = (real)0.5 * (lo + hi);
+                if (o[2] + mid * dir[2] < d->ground_z + map_sample(s, s->ground_height, o[0] + mid * dir[0], o[1] + mid * dir[1], &gx, &gy)) hi = mid; else lo = mid;
+              }
+              best = hi;
+              break;
+            }
+            tp = t;
+          }
+        }
+        /* wall prisms */
+        if (dxy > (real)1e-6 && s->sdf) {
+          real t = (real)1e-4;
+          for (int it = 0; it < 400 && t < best; it++) {
+            real px = o[0] + t * dir[0], py = o[1] + t * dir[1], pz = o[2] + t * dir[2];
+            if (px / hs < 0 || py / hs < 0 || px / hs > (real)(nx - 1) || py / hs > (real)(ny - 1)) break;
+            real gx, gy, sd = sdf_sample(s, px, py, &gx, &gy);
+            if (sd <= (real)0.002) {
+              if (pz <= wall_top_at(s, px, py) && pz >= d->ground_z - (real)1e-3) { best = t; break; }
+              t += (real)0.25 * hs / dxy;
+            } else t += (sd > (real)0.002 ? sd : (real)0.002) / dxy;
+          }
+        }
+        /* the other robots' primitives */
+        for (int r = 0; r < A; r++) {
+          if (r == a) continue;
+          for (int q = 0; q < m->n_prims; q++) {
+            const int b = m->prim_body[q];
+            real pc[3] = {m->prim_center[q][0], m->prim_center[q][1], m->prim_center[q][2]}, c[3];
+            mat3_vec(LR[r][b], pc, c);
+            for (int k = 0; k < 3; k++) c[k] += Lp[r][b][k];
+            if (m->prim_type[q] == MQE_PRIM_BOX) {
+              real hb[3] = {m->prim_half[q][0], m->prim_half[q][1], m->prim_half[q][2]};
+              best = ray_box_o(o, dir, c, LR[r][b], hb, best);
+            } else if (m->prim_type[q] == MQE_PRIM_CAPSULE) {
+              real ax[3] = {m->prim_axis[q][0], m->prim_axis[q][1], m->prim_axis[q][2]}, u[3];
+              mat3_vec(LR[r][b], ax, u);
+              best = ray_capsule_o(o, dir, c, u, m->prim_half[q][0], best);
+            } else best = ray_sphere_o(o, dir, c, m->prim_half[q][0], best);
+          }
+        }
+        /* free NPCs */
+        for (int p = 0; p < n_free; p++) {
+          const float* ns = root + (A + p) * 13;
+          real q[4] = {ns[3], ns[4], ns[5], ns[6]}, Rb[9], pb[3] = {ns[0], ns[1], ns[2]};
+          real nq = (real)sqrt((double)(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]));
+          for (int k = 0; k < 4; k++) q[k] /= nq;
+          quat_to_mat(q, Rb);
+          if (d->npc_kind == MQE_NPC_BOX) {
+            real hb[3] = {d->npc_box_half[0], d->npc_box_half[1], d->npc_box_half[2]};
+            best = ray_box_o(o, dir, pb, Rb, hb, best);
+          } else
+            for (int k = 0; k < d->npc_n_spheres; k++) {
+              real sc[3] = {d->npc_sphere_center[k][0], d->npc_sphere_center[k][1], d->npc_sphere_center[k][2]}, c[3];
+              mat3_vec(Rb, sc, c);
+              for (int i = 0; i < 3; i++) c[i] += pb[i];
+              best = ray_sphere_o(o, dir, c, d->npc_sphere_radius[k], best);
+            }
+        }
+        const real I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        if (d->npc_kind == MQE_NPC_SEESAW) {
+          real sb[3] = {root[A * 13], root[A * 13 + 1], root[A * 13 + 2]};
+          if (d->seesaw_base_half[0] > 0.0f) { real hb[3] = {d->seesaw_base_half[0], d->seesaw_base_half[1], d->seesaw_base_half[2]}; best = ray_box_o(o, dir, sb, I3, hb, best); }
+          real piv[3] = {sb[0] + d->seesaw_joint_offset[0], sb[1] + d->seesaw_joint_offset[1], sb[2] + d->seesaw_joint_offset[2]};
+          const real th = s->dof[((size_t)e * s->ND + 12 * A) * 2];
+          real Rp[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+          if (d->seesaw_axis == 3) piv[1] += th;
+          else { real ax[3] = {0, d->seesaw_axis == 2 ? 0 : 1, d->seesaw_axis == 2 ? 1 : 0}; axis_angle_mat(ax, th, Rp); }
+          real pcl[3] = {d->seesaw_plank_center[0], d->seesaw_plank_center[1], d->seesaw_plank_center[2]}, pc[3];
+          mat3_vec(Rp, pcl, pc);
+          for (int k = 0; k < 3; k++) pc[k] += piv[k];
+          if (d->seesaw_link_cylinder) {
+            real hz = d->seesaw_plank_half[2] - d->seesaw_plank_half[0];
+            real u[3] = {0, 0, hz > 0 ? hz : 0};
+            best = ray_capsule_o(o, dir, pc, u, d->seesaw_plank_half[0], best);
+          } else { real hb[3] = {d->seesaw_plank_half[0], d->seesaw_plank_half[1], d->seesaw_plank_half[2]}; best = ray_box_o(o, dir, pc, Rp, hb, best); }
+        }
+        if (d->npc_kind == MQE_NPC_STATIC)
+          for (int bx = 0; bx < d->n_static_boxes; bx++) {
+            real c[3] = {root[A * 13] + d->static_box_center[bx][0], root[A * 13 + 1] + d->static_box_center[bx][1], root[A * 13 + 2] + d->static_box_center[bx][2]};
+            real hb[3] = {d->static_box_half[bx][0], d->static_box_half[bx][1], d->static_box_half[bx][2]};
+            best = ray_box_o(o, dir, c, I3, hb, best);
+          }
+        out[((size_t)e * A + a) * npix + pix] = best < far_m ? -(float)best : -INFINITY;
+      }
+    }
+  }
+  return 0;
+}
+
 #ifdef _OPENMP
 #include <omp.h>
 int mqo_num_threads(void) { return omp_get_max_threads(); }

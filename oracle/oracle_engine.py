@@ -118,8 +118,19 @@ class OracleEngine(EngineBase):
     def history_sync(self):
         pass      # the oracle's layer 0 reads the f32 ring itself
 
-    def render_depth(self, *a, **k):
-        raise NotImplementedError("the depth camera exists in the HIP engine only (csrc/kernels_camera.hpp; known answers: tests/test_camera_gpu.py)")
+    def render_depth(self, height, width, hfov_deg, pos, rpy, far=20.0, out=None):
+        """mqo_render_depth: the scalar ray caster that DEFINES the forward depth image (the reference's rasteriser is closed): (R, H, W),
+        negative depth along the optical axis, -inf = nothing within `far` -- what the HIP kernel is compared with (tests/test_camera_gpu.py)"""
+        R = self.desc.num_envs * self.desc.num_agents
+        img = np.zeros((R, int(height), int(width)), np.float32)
+        f = self.lib.mqo_render_depth
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float]
+        f.restype = C.c_int
+        p3, r3 = (C.c_float * 3)(*[float(x) for x in pos]), (C.c_float * 3)(*[float(x) for x in rpy])
+        rc = f(self.h, C.c_void_p(img.ctypes.data), int(height), int(width), float(hfov_deg), p3, r3, float(far))
+        if rc != 0:
+            raise RuntimeError(f"mqo_render_depth failed ({rc}): {self.lib.mqo_last_error().decode()}")
+        return torch.from_numpy(img)
 
     def history(self):
         R = self.desc.num_envs * self.desc.num_agents

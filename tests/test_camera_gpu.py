@@ -1,112 +1,68 @@
-"""The forward depth camera (mqe_render_depth, csrc/kernels_camera.hpp; reference legged_robot_field.py:23-93,196-223).  The reference renders
-with Isaac Gym's rasteriser, which cannot run here: these are GEOMETRIC known answers of the ray caster -- the flat ground from a known
-height, a wall found by marching the scene's own signed-distance map on the host, another robot's trunk at a known distance, a ball --
-in Isaac Gym's IMAGE_DEPTH convention (negative depth along the optical axis, -inf where nothing is hit)."""
-import math
+"""The forward depth camera on the HIP engine (mqe_render_depth, csrc/kernels_camera.hpp; reference legged_robot_field.py:23-93,196-223):
+(1) the geometric known answers of tests/camera_cases.py, (2) HIP == the CPU specification's scalar ray caster (oracle/: mqo_render_depth)
+pixel by pixel on scenes with every kind of surface -- walls, relief, other robots, sheep, the free box, the plank, scenery -- after a
+few random steps, (3) the sensor dictionary through the plugin API."""
 import numpy as np
 import pytest
 import torch
-from helpers import make_desc, hip_engine
+
+import camera_cases as cc
+from helpers import make_desc, hip_engine, oracle_engine, perlin_terrain
 from mqe.engine import abi
 
 pytestmark = pytest.mark.gpu
-H = W = 16
-POS, ROT = [0.26, 0.0, 0.03], [0.0, 0.0, 0.0]            # cfg.sensor.forward_camera (legged_robot_field_config.py:72-76)
-
-
-def _upright(e, A):
-    ro, do = e.tensor(abi.T_ROOT_STATE).clone(), e.tensor(abi.T_DOF_STATE).clone()
-    ro[:, :A, 3:7] = torch.tensor([0.0, 0.0, 0.0, 1.0], device=ro.device)
-    ro[:, :A, 7:] = 0
-    return ro, do
 
 
 def test_flat_ground_from_a_known_height():
-    N = 4
-    d, k, _ = make_desc("go1plane", N)
-    e = hip_engine(d, k)
-    e.reset_all()
-    ro, do = _upright(e, 1)
-    ro[:, 0, 2] = d.ground_z + 0.40
-    e.tensor(abi.T_ROOT_STATE).copy_(ro)
-    img = e.render_depth(H, W, 90.0, POS, ROT, far=50.0).cpu().view(N, H, W)
-    cam_h = 0.40 + POS[2]
-    for i in range(H):
-        zc = -(2 * (i + 0.5) / H - 1)                     # tan(45 deg) = 1, square image
-        want = cam_h / -zc if zc < 0 else None            # depth along the axis at which a ray of slope zc reaches the ground
-        row = img[:, i, 5:11]                             # (the outer columns see the track's side walls first)
-        if want is not None and want < 3.0:               # (farther out the track's border walls may come first)
-            assert torch.allclose(row, torch.full_like(row, -want), atol=2e-4), (i, want, row[0])
-        elif zc > 0:
-            assert (row <= -0.5).all() or torch.isinf(row).all()      # above the horizon: walls far away or nothing
+    cc.flat_ground_from_a_known_height(hip_engine)
 
 
 def test_a_wall_where_the_signed_distance_map_says():
-    N = 8
-    d, k, _ = make_desc("go1gate", N)
-    e = hip_engine(d, k)
-    e.reset_all()
-    ro, do = _upright(e, 2)
-    nx, ny, hs = d.sdf_nx, d.sdf_ny, d.horizontal_scale
-    sdf = np.ctypeslib.as_array(d.wall_sdf, shape=(nx, ny)).copy()
-    # robot 0 of every env looks along +x from its reset position at mid wall height; robot 1 is moved out of the way
-    ro[:, 0, 2] = d.ground_z + 0.15
-    ro[:, 1, 1] += 50.0 * hs
-    e.tensor(abi.T_ROOT_STATE).copy_(ro)
-    img = e.render_depth(H, W, 90.0, [0.26, 0.0, 0.0], ROT, far=30.0).cpu().view(N, 2, H, W)
-    checked = 0
-    for env in range(N):
-        ox, oy = float(ro[env, 0, 0]) + 0.26, float(ro[env, 0, 1])
-        # host march of the same map along the central ray (two central columns straddle it: yc = -+1/16)
-        t, hit = 0.0, None
-        while t < 20.0:
-            fx, fy = (ox + t) / hs, oy / hs
-            if fx >= nx - 1 or fy >= ny - 1 or fx < 0 or fy < 0:
-                break
-            ix, iy = int(fx), int(fy)
-            tx, ty = fx - ix, fy - iy
-            s = (sdf[ix, iy] * (1 - ty) + sdf[ix, iy + 1] * ty) * (1 - tx) + (sdf[ix + 1, iy] * (1 - ty) + sdf[ix + 1, iy + 1] * ty) * tx
-            if s <= 0.002:
-                hit = t
-                break
-            t += max(s, 0.002)
-        if hit is None or hit < 0.3:
-            continue
-        # the four central pixels look 1/16 of the half width off axis and 1/16 below / above it: a wall face normal to x gives the same depth
-        c = -img[env, 0, H // 2 - 1:H // 2 + 1, W // 2 - 1:W // 2 + 1]
-        assert torch.isfinite(c).all() and float((c - hit).abs().max()) < 3 * hs + 0.02 * hit, (env, hit, c)
-        checked += 1
-    assert checked >= 2
+    cc.a_wall_where_the_signed_distance_map_says(hip_engine)
 
 
 def test_another_robots_trunk_and_a_ball():
-    N = 2
-    d, k, _ = make_desc("go1football-1vs1", N)
-    e = hip_engine(d, k)
-    e.reset_all()
-    ro, do = _upright(e, 2)
-    do[:, :, 0] = torch.tensor(np.ctypeslib.as_array(d.default_dof_pos, shape=(12,)).copy(), device=do.device).repeat(2)[None, :] if do.shape[1] >= 24 else do[:, :, 0]
-    base = ro[:, 0, :3].clone()
-    base[:, 2] = d.ground_z + 0.32
-    ro[:, 0, :3] = base
-    ro[:, 1, :3] = base + torch.tensor([1.0, 0.0, 0.0], device=ro.device)           # robot 1 one metre ahead, same heading
-    ball_r = float(d.npc_sphere_radius[0])
-    ro[:, 2, :3] = base + torch.tensor([0.9, 0.6, 0.0], device=ro.device)           # the ball up and to the left, at camera height
-    ro[:, 2, 2] = d.ground_z + 0.32 + POS[2]
-    e.tensor(abi.T_ROOT_STATE).copy_(ro); e.tensor(abi.T_DOF_STATE).copy_(do)
-    img = e.render_depth(64, 64, 90.0, POS, ROT, far=10.0).cpu().view(N, 2, 64, 64)
-    # central pixels of robot 0's camera: the rear face of robot 1's trunk box (go1.urdf:56: 0.3762 long, centred on the base)
-    want = 1.0 - 0.3762 / 2 - POS[0]
-    c = -img[:, 0, 31:33, 31:33]
-    assert float((c - want).abs().max()) < 2e-3, (want, c)
-    # the ball: its nearest point along the ray through its centre; the pixel that looks at the centre
-    bx, by = 0.9 - POS[0], 0.6
-    j = int((1 - by / bx) / 2 * 64)                       # yc = by / bx -> column
-    depth_centre = bx - ball_r * bx / math.hypot(bx, by)  # axial depth of the sphere's nearest point on that ray
-    got = -img[:, 0, 31:33, j - 1:j + 2]
-    assert float((got - depth_centre).abs().min()) < 0.01, (depth_centre, got)
-    # robot 1 looks away from both: nothing but ground / far walls in its centre
-    assert not torch.isfinite(img[:, 1, 31, 31]).any() or float((-img[:, 1, 31, 31]).min()) > 1.5
+    cc.another_robots_trunk_and_a_ball(hip_engine)
+
+
+@pytest.mark.parametrize("task,relief", [("go1gate", False), ("go1sheep-hard", False), ("go1pushbox", False), ("go1seesaw", False), ("go1bridge", False),
+                                         ("go1football-defender", False), ("go1tug", False), ("go1gate", True)])
+def test_hip_depth_image_is_the_specifications(task, relief):
+    """VERDICT r4 "Next" 7: the kernel against the oracle's ray caster on the SAME state (copied from the HIP engine after 6 random steps,
+    robots scattered and tilted so that they see each other, the NPCs and the walls): identical hit / miss masks up to silhouette pixels
+    (<= 0.2 % may differ: a ray grazing an edge or a march step falling on the other side of a threshold in f32 vs f64), depths to 1e-4 m
+    + 1e-5 relative on the rest."""
+    N = 16
+    kw = dict(terrain_cfg=perlin_terrain(task, zScale=0.08)) if relief else {}
+    d1, k1, _ = make_desc(task, N, **kw)
+    d2, k2, _ = make_desc(task, N, **kw)
+    eh, eo = hip_engine(d1, k1), oracle_engine(d2, k2, f64=True)
+    eh.reset_all(); eo.reset_all()
+    g = torch.Generator().manual_seed(3)
+    Aw = eh.tensor(abi.T_WRAPPER_OBS).shape[1]
+    for t in range(6):
+        eh.step((torch.rand(N, Aw, 3, generator=g) * 2 - 1).cuda())
+    A = d1.num_agents
+    ro, do = eh.tensor(abi.T_ROOT_STATE), eh.tensor(abi.T_DOF_STATE)
+    # robots turned towards each other / the NPCs, some pitched and rolled
+    yaw = torch.rand(N, A, generator=g) * 6.283
+    pitch = (torch.rand(N, A, generator=g) - 0.5) * 0.6
+    roll = (torch.rand(N, A, generator=g) - 0.5) * 0.4
+    cy, sy, cp, sp, cr_, sr = torch.cos(yaw / 2), torch.sin(yaw / 2), torch.cos(pitch / 2), torch.sin(pitch / 2), torch.cos(roll / 2), torch.sin(roll / 2)
+    q = torch.stack([sr * cp * cy - cr_ * sp * sy, cr_ * sp * cy + sr * cp * sy, cr_ * cp * sy - sr * sp * cy, cr_ * cp * cy + sr * sp * sy], -1)
+    ro[:, :A, 3:7] = q.cuda()
+    torch.cuda.synchronize()
+    eo.tensor(abi.T_ROOT_STATE).copy_(ro.cpu()); eo.tensor(abi.T_DOF_STATE).copy_(do.cpu())
+    for (hh, ww, fov, pos, rpy, far) in ((24, 32, 87.0, [0.26, 0.0, 0.03], [0.0, 0.0, 0.0], 20.0), (16, 16, 60.0, [0.2, 0.05, 0.1], [0.1, 0.35, -0.4], 6.0)):
+        ih = eh.render_depth(hh, ww, fov, pos, rpy, far).cpu().numpy().astype(np.float64)
+        io = eo.render_depth(hh, ww, fov, pos, rpy, far).numpy().astype(np.float64)
+        mh, mo = np.isfinite(ih), np.isfinite(io)
+        assert mo.mean() > 0.3                                      # the cameras do see something
+        both = mh & mo
+        off = np.abs(ih[both] - io[both]) > 1e-4 + 1e-5 * np.abs(io[both])
+        bad = (mh != mo).sum() + off.sum()
+        assert bad <= 2e-3 * ih.size, (task, relief, int((mh != mo).sum()), int(off.sum()), ih.size, float(np.abs(ih[both] - io[both]).max()))
+        assert np.median(np.abs(ih[both] - io[both])) < 2e-6
 
 
 def test_sensor_dict_through_the_plugin_api():

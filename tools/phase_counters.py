@@ -45,15 +45,19 @@ else:
     ids = ids[len(ids) // 2:]                # second repetition (warm)
     assert len(ids) == len(TAPS) + 1, len(ids)
     cols = sorted(per[ids[0]])
-    print(f"{'phase':26s}" + "".join(f"{c.replace('SQ_', ''):>16s}" for c in cols))
+    lanes = "SQ_THREAD_CYCLES_VALU" in cols and "SQ_ACTIVE_INST_VALU" in cols      # active lanes per VALU instruction = thread-cycles / instruction-cycles (of 64)
+
+    def tail(delta):
+        return f"{delta['SQ_THREAD_CYCLES_VALU'] / max(delta['SQ_ACTIVE_INST_VALU'], 1e-9):14.1f}" if lanes else ""
+    print(f"{'phase':26s}" + "".join(f"{c.replace('SQ_', ''):>20s}" for c in cols) + (f"{'active lanes':>14s}" if lanes else ""))
     prev = {c: 0.0 for c in cols}
     for i, did in enumerate(ids):
         w = grid[did]
         cur = per[did]
         if i < len(TAPS):
             name = "(prologue)" if i == 0 else NAMES[i - 1]
-            print(f"{name:26s}" + "".join(f"{(cur[c] - prev[c]) / w:16.1f}" for c in cols))
+            print(f"{name:26s}" + "".join(f"{(cur[c] - prev[c]) / w:20.1f}" for c in cols) + tail({c: cur[c] - prev[c] for c in cols}))
             prev = cur
         else:
-            print(f"{'store (full - tap 14)':26s}" + "".join(f"{(cur[c] - prev[c]) / w:16.1f}" for c in cols))
-            print(f"{'whole substep':26s}" + "".join(f"{cur[c] / w:16.1f}" for c in cols))
+            print(f"{'store (full - tap 14)':26s}" + "".join(f"{(cur[c] - prev[c]) / w:20.1f}" for c in cols) + tail({c: cur[c] - prev[c] for c in cols}))
+            print(f"{'whole substep':26s}" + "".join(f"{cur[c] / w:20.1f}" for c in cols) + tail(cur))
