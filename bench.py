@@ -504,7 +504,7 @@ def main():
             "metric": f"env-steps/sec (agents x envs x steps/s), {args.task} {N} envs x {A} agents per GPU",
             "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32 (policy GEMMs: 2-plane split-f16, 22-bit)" if split else "f32", "data": "synthetic (U(-1,1) actions seed 1234; synthetic body MLP: body_latest.jit missing upstream)",
+            "vs_baseline": None, "dtype": "f32 (policy GEMMs and the actuator network's 32 x 32 layer: 2-plane split-f16, 22-bit)" if split else "f32", "data": "synthetic (U(-1,1) actions seed 1234; synthetic body MLP: body_latest.jit missing upstream)",
             "config": {"workload": f"{args.task}, {A} agents, num_envs={N} per GPU ({N * world} total), 4 substeps x 5 ms per step",
                        "parallelism": (f"env-sharded x{world}, " + ("no collective (per-GPU learners)" if args.no_gather else
                                        f"all-gather of the returned batch issued {dict(between='between policy and physics of the next step', after='after the step, next step waits', tail='after layer 0 of the next step (beside the policy tail), physics waits')[args.gather]}"))
@@ -526,14 +526,14 @@ def main():
             "gpu_busy_ms_per_step": round(tot / sampled, 4),
             "contact_overflow_substeps": overflow_substeps,      # env-substeps whose bounded contact list was truncated (of envs x 4 x steps)
             "hip_event_sampling": f"kernel classes of every {prof_every}-th timed step bracketed" if prof_every else "off",
-            "dtype_note": "state, physics, actuator net: f32.  Policy layer 0 + tail: f32 operands carried as two f16 planes (22 significand bits, "
-                          "3 MFMA terms), held to the same 5e-5 bound as exact f32; strict_f32 = the same run on the exact-f32 kernels",
+            "dtype_note": "state and physics: f32.  Policy layer 0 + tail and (round 5) layer 2 of the actuator network: f32 operands carried as two f16 planes "
+                          "(22 significand bits, 3 MFMA terms), held to the same 5e-5 bound as exact f32; strict_f32 = the same run on the exact-f32 kernels",
         }
         if world == 1 and not args.no_strict_f32 and not os.environ.get("MQE_BENCH_NOPROF"):
             # the dtype claim's companion: identical workload with every policy GEMM on the exact-f32 kernels
-            sms, _ = time_variant(args.task, N, dev, min(args.steps, 100), min(args.warmup, 10), {"MQE_GEMM_SPLIT": "0", "MQE_NO_FUSED_TAIL": "1"})
+            sms, _ = time_variant(args.task, N, dev, min(args.steps, 100), min(args.warmup, 10), {"MQE_GEMM_SPLIT": "0", "MQE_NO_FUSED_TAIL": "1", "MQE_ACT_F32": "1"})
             out["strict_f32"] = {"value": round(A * N / (sms * 1e-3), 1), "unit": "env-steps/s", "ms_per_step": round(sms, 4), "steps": min(args.steps, 100),
-                                 "switches": "MQE_GEMM_SPLIT=0 MQE_NO_FUSED_TAIL=1 (k_gemm_f32 for every policy layer)"}
+                                 "switches": "MQE_GEMM_SPLIT=0 MQE_NO_FUSED_TAIL=1 (k_gemm_f32 for every policy layer) MQE_ACT_F32=1 (actuator network: the f32 MFMA chain)"}
         if world == 1 and not args.no_strict_f32 and not os.environ.get("MQE_BENCH_NOPROF") and not os.environ.get("MQE_SOLVER"):
             # what the choice of contact solver costs: the same workload on the velocity-level sweeps of rounds 1-3 (solver_type 0)
             pms, _ = time_variant(args.task, N, dev, min(args.steps, 100), min(args.warmup, 10), {"MQE_SOLVER": "pgs"})

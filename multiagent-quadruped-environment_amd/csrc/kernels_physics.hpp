@@ -2413,7 +2413,10 @@ struct PostArgs { int on, wrapper_level, push_count, step_no; };
 // TIMED (MQE_PHASE_TIMES=1, tools/dev/phase_walltimes.py): the same kernel with the phase taps of phys_substep live -- every wavefront
 // writes the wall clock at the 15 taps of each of its substeps (+ [15]: the substep's end) behind the entry / exit stamps of
 // st.wave_times: where the time of a FULL launch goes, phase by phase, as opposed to the lone wavefront of tools/phase_times.py.
-template <int TA, int TP, int EPW = 1, bool TIMED = false>
+// ACT32: the actuator network's layer 2 as the exact f32 MFMA chain (MQE_ACT_F32=1: torques bit for bit the oracle's fmaf chain); default:
+// two-plane split-f16 operands on v_mfma_f32_32x32x16_f16 (f32-class accuracy, 22 significand bits per operand).  A compile-time choice: with
+// both forms behind a run-time branch the 128-register kernels spilled 20-50 registers.
+template <int TA, int TP, int EPW = 1, bool TIMED = false, bool ACT32 = false>
 __global__ void __launch_bounds__(64, EPW == 2 ? 2 : SubstepsClass<TP>::waves) k_substeps(const DevModel* __restrict__ m, DevState st, int nsub, int lag_pos, PostArgs pa) {
   extern __shared__ float lds_wave[];
   // EPW = 2 (phys_substep): the two halves of the wavefront run envs 2 b and 2 b + 1; `lane` / `lds` / `e` below are the group's.
@@ -2511,6 +2514,7 @@ __global__ void __launch_bounds__(64, EPW == 2 ? 2 : SubstepsClass<TP>::waves) k
       const float* b0 = as_global(mk->actuator.b[0]);      // through the laundered pointer: the 70 fragment
       const float* b1 = as_global(mk->actuator.b[1]);      // loads below stay inside the substep loop (global_load, not flat_load:
       const float* W2 = as_global(mk->actuator.W[2]); const float* b2 = as_global(mk->actuator.b[2]);     // mqe_common.hpp as_global)
+      constexpr bool act16 = !ACT32;
       float a1[3], a2[16], w3[16], bb0[16], bb1[16];
       // (the two matrix operands from the fragment-ordered copy: lane-contiguous, one 256 B request per fragment -- W1[j32 * 32 + u] itself
       // is 64 lanes x a 128 B stride, 64 cache lines per instruction, 16 instructions per substep and wavefront)
@@ -2520,9 +2524,21 @@ __global__ void __launch_bounds__(64, EPW == 2 ? 2 : SubstepsClass<TP>::waves) k
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const int u = (r & 3) + 8 * (r >> 2) + 4 * h;
-        a2[r] = fragw[r * 64]; w3[r] = W2[u]; bb0[r] = b0[u]; bb1[r] = b1[u];
+        if constexpr (!act16) a2[r] = fragw[r * 64];
+        w3[r] = W2[u]; bb0[r] = b0[u]; bb1[r] = b1[u];
       }
       const float bout = b2[0];
+      // layer 2 on the f16 matrix cores (DevModel::act_f16; MQE_ACT_F32=1 keeps the f32 MFMA chain above): W1 as two f16 planes of 2^14 w in
+      // the fragment order of v_mfma_f32_32x32x16_f16 -- [k-step][plane][lane][8] -- one 16 B load per fragment
+      // (the four fragments live in the sixteen registers the f32 chain keeps its layer-2 operand in: one set of registers for both forms)
+      if constexpr (act16) {
+        const h2_gvec* f16w = (const h2_gvec*)(unsigned long long)mk->act_frag16 + lane_k;
+#pragma unroll
+        for (int f = 0; f < 4; f++) {
+          const h2_u32x4 t = f16w[f * 64];
+          a2[4 * f] = __uint_as_float(t.x); a2[4 * f + 1] = __uint_as_float(t.y); a2[4 * f + 2] = __uint_as_float(t.z); a2[4 * f + 3] = __uint_as_float(t.w);
+        }
+      }
       int pos = 0;
       if (m->lag_steps > 0) {          // go1.py:337-339: the lag buffer shifts in every _compute_torques call, i.e. per substep
         const int n = m->lag_steps + 1;
@@ -2560,8 +2576,15 @@ __global__ void __launch_bounds__(64, EPW == 2 ? 2 : SubstepsClass<TP>::waves) k
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[2], h ? hv2 : hv1, acc1, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 16; r++) acc1[r] = softsign_p(acc1[r]);
+        if constexpr (act16) {
+          // layer 2 on the f16 matrix cores (mqe_common.hpp: act_layer2_f16) -- the one phase of the substep that grew at 4 wavefronts per SIMD,
+          // where all four reach it together and queue for the SIMD's one matrix pipe.  Torques then equal the oracle's f32 fmaf chain to
+          // ~1e-6 instead of bit for bit.
+          acc2 = act_layer2_f16(acc1, acc2, a2);
+        } else {
 #pragma unroll
-        for (int r = 0; r < 16; r++) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[r], acc1[r], acc2, 0, 0, 0);
+          for (int r = 0; r < 16; r++) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[r], acc1[r], acc2, 0, 0, 0);
+        }
         float part = 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; r++) part = fmaf(w3[r], softsign_p(acc2[r]), part);

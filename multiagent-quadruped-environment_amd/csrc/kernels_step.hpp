@@ -321,7 +321,7 @@ __global__ void __launch_bounds__(256) k_compute_torques_mfma(const DevModel* m,
 #pragma unroll
   for (int r = 0; r < 16; r++) {
     const int u = (r & 3) + 8 * (r >> 2) + 4 * h;
-    a2[r] = W1[j32 * 32 + u];
+    a2[r] = W1[j32 * 32 + u];             // (act_f16: overwritten below with the four f16 fragments)
     w3[r] = W2[u];
     acc1[r] = b0[u];
     acc2[r] = b1[u];
@@ -339,9 +339,20 @@ __global__ void __launch_bounds__(256) k_compute_torques_mfma(const DevModel* m,
   acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[2], h ? x5 : x4, acc1, 0, 0, 0);
 #pragma unroll
   for (int r = 0; r < 16; r++) acc1[r] = softsign_f(acc1[r]);
-  // layer 2 (K = 32): step r consumes hidden units u(r,0), u(r,1)
+  // layer 2 (K = 32): step r consumes hidden units u(r,0), u(r,1); or -- DevModel::act_f16, the default -- the split-f16 form k_substeps uses
+  // (mqe_common.hpp: act_layer2_f16; the same instruction sequence on the same bits, so the staged step stays the fused one bit for bit)
+  if (m->act_f16) {
+    const mqe_u32x4* f16w = reinterpret_cast<const mqe_u32x4*>(m->act_frag16) + lane;
 #pragma unroll
-  for (int r = 0; r < 16; r++) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[r], acc1[r], acc2, 0, 0, 0);
+    for (int f = 0; f < 4; f++) {
+      const mqe_u32x4 t = f16w[f * 64];
+      a2[4 * f] = __uint_as_float(t.x); a2[4 * f + 1] = __uint_as_float(t.y); a2[4 * f + 2] = __uint_as_float(t.z); a2[4 * f + 3] = __uint_as_float(t.w);
+    }
+    acc2 = act_layer2_f16(acc1, acc2, a2);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[r], acc1[r], acc2, 0, 0, 0);
+  }
   float part = 0.0f;
 #pragma unroll
   for (int r = 0; r < 16; r++) part = fmaf(w3[r], softsign_f(acc2[r]), part);

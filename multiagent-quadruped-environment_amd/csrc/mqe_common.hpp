@@ -69,6 +69,10 @@ struct DevModel {
   // the actuator network's weights in the order k_substeps' lanes consume them, [fragment][lane] (64 floats = one coalesced 256 B load per
   // fragment instead of 64 lanes x a 128 B stride): fragments 0-15 = layer 2 rows (W1[(lane & 31) * 32 + u(r, lane >> 5)]), 16-18 = layer 1
   const float* act_frag;
+  // ... and layer 2 once more for the f16 matrix cores: two f16 planes of 2^14 W1 in the fragment order of v_mfma_f32_32x32x16_f16,
+  // [k-step 2][plane 2][lane 64][8]: element i of lane (row, g) in k-step s = W1[row][(i & 3) + 16 s + 8 (i >> 2) + 4 g] -- the order in
+  // which layer 1's accumulator registers hold the hidden units (kernels_physics.hpp, k_substeps).  act_f16: use it (MQE_ACT_F32=1: no)
+  const uint16_t* act_frag16; int act_f16;
   // physics kernel geometry
   int nbody_env, ndof_env, nsph_env, nprim_env, maxc;
   unsigned long long feat_sphere_mask;                   // bit f: feature point f of the robot model belongs to a sphere primitive (a foot)
@@ -129,6 +133,44 @@ __device__ __forceinline__ void own_state(DevState& st) {
 }
 
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+
+// Layer 2 of the actuator network (32 x 32, unitree_go1.pt; go1.py:345) on the f16 matrix cores, shared by k_substeps and the stand-alone
+// k_compute_torques_mfma so that the fused and the staged step stay bit for bit the same: acc2 (= the bias on entry) += W1 s1 with both
+// operands as two f16 planes (x 2^14: |w| <= 1.06, |s1| < 1), products hh + hl + lh on v_mfma_f32_32x32x16_f16 (each exact, f32
+// accumulation; the dropped ll term is <= 2^-22 of a product): 6 MFMAs of 32 cycles instead of the 16 x 64 cycles of the f32 chain.
+// Layer 1's accumulator IS the B operand: register r of lane (joint, h) holds hidden unit (r & 3) + 8 (r >> 2) + 4 h, i.e. registers
+// 8 s .. 8 s + 7 are the eight k of half h in k-step s once the weight columns are permuted the same way (DevModel::act_frag16).
+// wbits: this lane's four weight fragments [k-step][plane] as 16 dwords.  k-step by k-step: eight activations split, three MFMAs; the next
+// eight are split while these run.
+typedef _Float16 mqe_f16x8 __attribute__((ext_vector_type(8)));
+typedef float mqe_f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int mqe_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ mqe_f32x16 act_layer2_f16(const mqe_f32x16& s1, mqe_f32x16 acc2, const float* wbits) {
+#pragma unroll
+  for (int r = 0; r < 16; r++) acc2[r] *= 268435456.0f;                 // the bias in the products' scale, 2^28 (exact)
+#pragma unroll
+  for (int s2 = 0; s2 < 2; s2++) {
+    mqe_f16x8 bh, bl;
+#pragma unroll
+    for (int i8 = 0; i8 < 8; i8++) {
+      const float y = s1[8 * s2 + i8] * 16384.0f;
+      const _Float16 hh = (_Float16)y;
+      bh[i8] = hh;
+      bl[i8] = (_Float16)(y - (float)hh);
+    }
+    mqe_u32x4 th, tl;
+    th.x = __float_as_uint(wbits[8 * s2]); th.y = __float_as_uint(wbits[8 * s2 + 1]); th.z = __float_as_uint(wbits[8 * s2 + 2]); th.w = __float_as_uint(wbits[8 * s2 + 3]);
+    tl.x = __float_as_uint(wbits[8 * s2 + 4]); tl.y = __float_as_uint(wbits[8 * s2 + 5]); tl.z = __float_as_uint(wbits[8 * s2 + 6]); tl.w = __float_as_uint(wbits[8 * s2 + 7]);
+    const mqe_f16x8 ah = __builtin_bit_cast(mqe_f16x8, th), al = __builtin_bit_cast(mqe_f16x8, tl);
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc2, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc2, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; r++) acc2[r] *= 3.7252902984619140625e-9f;    // 2^-28
+  return acc2;
+}
 
 // counter-based RNG of the reset distribution and the domain randomisation: keyed by (seed, GLOBAL env id, count, stream)
 __host__ __device__ __forceinline__ uint32_t mqe_hash(uint32_t seed, uint32_t genv, uint32_t count, uint32_t k) {

@@ -54,6 +54,7 @@ struct mqe_sim {
   int N, A, P, R, ND, NBR, Aw, D;
   int hist_pos = 0, n_post_steps = 0;
   void (*substeps_fn)(const DevModel*, DevState, int, int, PostArgs) = nullptr;    // the k_substeps specialisation of this scene
+  int substeps_shape = 0;             // SubShape
   int substeps_epw = 1;               // envs per wavefront of that kernel (2: two-robot scenes without objects at large batches)
   bool a2_scene = false;              // two robots, no objects: the scene k_simulate_a2 (phase taps) is compiled for
   int lag_pos = 0;                    // write slot of the action-lag ring (domain randomisation), advances per substep
@@ -189,25 +190,51 @@ static int finalize_frag(mqe_sim* s, GemmLayer* L) {
 
 // k_substeps is compiled for the env shapes of the shipped tasks (kernels_physics.hpp: PhysShape); everything else takes the
 // runtime form
-static void (*pick_substeps(const DevModel& m, size_t lds_bytes))(const DevModel*, DevState, int, int, PostArgs) {
+typedef void (*substeps_fn_t)(const DevModel*, DevState, int, int, PostArgs);
+enum SubShape { SH_A2, SH_A1, SH_A2_LINK, SH_A2_NPC_FEW, SH_A2_BOX_FEW, SH_A2_STATIC_FEW, SH_A3_NPC_ROW, SH_A2_NPC, SH_A4_NPC, SH_A2_GEN, SH_GEN };
+static SubShape pick_shape(const DevModel& m, size_t lds_bytes) {
   const int feat = (m.has_seesaw ? PS_F_LINK : 0) | (m.n_npc_dyn > 0 ? PS_F_NPC : 0) | (m.has_box ? PS_F_BOX : 0) | (m.n_static > 0 ? PS_F_STATIC : 0);
   // the small class (row sweep compiled in, 128 VGPRs, every env resident): <= 4 actors and 16 LDS footprints per CU
   if (m.rowgs && lds_bytes <= 10240) {                                       // (MQE_LANE_SWEEP=1 sends these scenes to the kernels below)
     if (feat == 0 && m.P == 0) {
-      if (m.A == 2) return k_substeps<2, 0>;                                 // go1gate
-      if (m.A == 1) return k_substeps<1, 0>;                                 // go1plane
+      if (m.A == 2) return SH_A2;                                            // go1gate
+      if (m.A == 1) return SH_A1;                                            // go1plane
     }
-    if (m.A == 2 && feat == PS_F_LINK) return k_substeps<2, PS_F_LINK>;      // go1seesaw, go1revolvingdoor, go1tug
-    if (m.A == 2 && feat == PS_F_NPC) return k_substeps<2, PS_F_NPC | PS_F_FEW>;                  // go1football-1vs1, a single sheep
-    if (m.A == 2 && feat == (PS_F_NPC | PS_F_BOX)) return k_substeps<2, PS_F_NPC | PS_F_BOX | PS_F_FEW>;   // go1pushbox
-    if (m.A == 2 && feat == PS_F_STATIC) return k_substeps<2, PS_F_STATIC | PS_F_FEW>;           // go1bridge, go1wrestling
+    if (m.A == 2 && feat == PS_F_LINK) return SH_A2_LINK;                    // go1seesaw, go1revolvingdoor, go1tug
+    if (m.A == 2 && feat == PS_F_NPC) return SH_A2_NPC_FEW;                  // go1football-1vs1, a single sheep
+    if (m.A == 2 && feat == (PS_F_NPC | PS_F_BOX)) return SH_A2_BOX_FEW;     // go1pushbox
+    if (m.A == 2 && feat == PS_F_STATIC) return SH_A2_STATIC_FEW;            // go1bridge, go1wrestling
   }
   // larger scenes: 2 waves per SIMD; the sweep variant is compiled in (the kernel's LDS layout has to be the one computed from m.rowgs)
-  if (m.A == 3 && feat == PS_F_NPC && m.rowgs) return k_substeps<3, PS_F_NPC | PS_F_ROW>;   // go1football-defender
-  if (m.A == 2 && feat == PS_F_NPC && !m.rowgs) return k_substeps<2, PS_F_NPC>;             // go1sheep-* (flocks)
-  if (m.A == 4 && feat == PS_F_NPC && !m.rowgs) return k_substeps<4, PS_F_NPC>;             // go1football-2vs2
-  if (m.A == 2) return k_substeps<2, -1>;
-  return k_substeps<0, -1>;
+  if (m.A == 3 && feat == PS_F_NPC && m.rowgs) return SH_A3_NPC_ROW;         // go1football-defender
+  if (m.A == 2 && feat == PS_F_NPC && !m.rowgs) return SH_A2_NPC;            // go1sheep-* (flocks)
+  if (m.A == 4 && feat == PS_F_NPC && !m.rowgs) return SH_A4_NPC;            // go1football-2vs2
+  if (m.A == 2) return SH_A2_GEN;
+  return SH_GEN;
+}
+// the kernel of a shape: envs per wavefront (2: SH_A2 / SH_A1 only), phase taps live (TIMED: three shapes, f16 actuator only), and the
+// actuator network's layer 2 as the exact f32 MFMA chain (ACT32: MQE_ACT_F32=1) instead of the split-f16 form
+template <bool ACT32>
+static substeps_fn_t shape_fn(SubShape sh, int epw) {
+  switch (sh) {
+    case SH_A2: return epw == 2 ? (substeps_fn_t)k_substeps<2, 0, 2, false, ACT32> : (substeps_fn_t)k_substeps<2, 0, 1, false, ACT32>;
+    case SH_A1: return epw == 2 ? (substeps_fn_t)k_substeps<1, 0, 2, false, ACT32> : (substeps_fn_t)k_substeps<1, 0, 1, false, ACT32>;
+    case SH_A2_LINK: return k_substeps<2, PS_F_LINK, 1, false, ACT32>;
+    case SH_A2_NPC_FEW: return k_substeps<2, PS_F_NPC | PS_F_FEW, 1, false, ACT32>;
+    case SH_A2_BOX_FEW: return k_substeps<2, PS_F_NPC | PS_F_BOX | PS_F_FEW, 1, false, ACT32>;
+    case SH_A2_STATIC_FEW: return k_substeps<2, PS_F_STATIC | PS_F_FEW, 1, false, ACT32>;
+    case SH_A3_NPC_ROW: return k_substeps<3, PS_F_NPC | PS_F_ROW, 1, false, ACT32>;
+    case SH_A2_NPC: return k_substeps<2, PS_F_NPC, 1, false, ACT32>;
+    case SH_A4_NPC: return k_substeps<4, PS_F_NPC, 1, false, ACT32>;
+    case SH_A2_GEN: return k_substeps<2, -1, 1, false, ACT32>;
+    default: return k_substeps<0, -1, 1, false, ACT32>;
+  }
+}
+static substeps_fn_t shape_fn_timed(SubShape sh) {
+  if (sh == SH_A2) return k_substeps<2, 0, 1, true>;
+  if (sh == SH_A2_NPC) return k_substeps<2, PS_F_NPC, 1, true>;
+  if (sh == SH_A3_NPC_ROW) return k_substeps<3, PS_F_NPC | PS_F_ROW, 1, true>;
+  return nullptr;
 }
 
 static int wrapper_dims(const mqe_sim_desc* d, int* Aw, int* D) {
@@ -330,15 +357,19 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   // the records the physics kernel moves as 16 B words must start on 16 B (kernels_physics.hpp)
   if ((L.total | L.body | L.sph | L.prim | L.con | L.side | L.leg | L.legc | L.basei | L.sinv | L.fcol | L.acc | L.rhs | L.phi | L.srec | L.wacc) & 3) { return fail(-4, "physics LDS layout: a 16 B record area is misaligned"); }
   if (s->phys_lds_bytes > 160 * 1024) { return fail(-4, "physics LDS footprint exceeds 160 KiB"); }
-  s->substeps_fn = pick_substeps(m, s->phys_lds_bytes);
-  s->a2_scene = s->substeps_fn == (void (*)(const DevModel*, DevState, int, int, PostArgs))k_substeps<2, 0>;
-  typedef void (*substeps_fn_t)(const DevModel*, DevState, int, int, PostArgs);
-  substeps_fn_t timed_fn = nullptr;                   // tools/dev/phase_walltimes.py: the same kernel with its phase taps live (go1gate and the two large scenes)
-  if (getenv("MQE_PHASE_TIMES")) {
-    if (s->a2_scene) timed_fn = k_substeps<2, 0, 1, true>;
-    else if (s->substeps_fn == (substeps_fn_t)k_substeps<2, PS_F_NPC>) timed_fn = k_substeps<2, PS_F_NPC, 1, true>;
-    else if (s->substeps_fn == (substeps_fn_t)k_substeps<3, PS_F_NPC | PS_F_ROW>) timed_fn = k_substeps<3, PS_F_NPC | PS_F_ROW, 1, true>;
+  {   // the actuator network's layer 2 on the f16 matrix cores (k_substeps<..., ACT32 = false>) unless MQE_ACT_F32=1 asks for the exact f32 chain
+      // or the weights do not fit the f16 planes: |w| 2^14 must stay inside f16 (65504); the shipped net's largest layer-2 weight is 1.06
+    float w1max = 0.0f;
+    if (d->actuator.n_layers == 3 && d->actuator.dims[1] == 32 && d->actuator.dims[2] == 32 && d->actuator.W[1])
+      for (int i = 0; i < 32 * 32; i++) w1max = std::max(w1max, std::fabs(d->actuator.W[1][i]));
+    m.act_f16 = (getenv("MQE_ACT_F32") == nullptr && w1max < 3.99f) ? 1 : 0;
   }
+  const SubShape shape = pick_shape(m, s->phys_lds_bytes);
+  s->substeps_shape = (int)shape;
+  s->a2_scene = shape == SH_A2;
+  const bool act32 = m.act_f16 == 0;                 // MQE_ACT_F32=1 (or a network whose weights do not fit the f16 planes): the exact f32 chain
+  substeps_fn_t timed_fn = nullptr;                   // tools/dev/phase_walltimes.py: the same kernel with its phase taps live (go1gate and the two large scenes)
+  if (getenv("MQE_PHASE_TIMES") && !act32) timed_fn = shape_fn_timed(shape);
   const bool phase_timed = timed_fn != nullptr;
   {
     // Two envs per wavefront (kernels_physics.hpp, EPW): for robot-only scenes of <= 2 robots each half-wave runs an env of its own --
@@ -348,44 +379,40 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
     // CU), and the two-env wavefront's chain is 1.5 x as long -- 2 of them per SIMD take what 4 one-env wavefronts take.  Kept as
     // a selectable, bit-identical variant (MQE_ENVS_PER_WAVE=1 / 2; tests hold the two forms against each other); the default for
     // single-robot scenes at full batches only (below).
-    const bool can = (s->substeps_fn == (void (*)(const DevModel*, DevState, int, int, PostArgs))k_substeps<2, 0> ||
-                      s->substeps_fn == (void (*)(const DevModel*, DevState, int, int, PostArgs))k_substeps<1, 0>) && 2 * s->phys_lds_bytes <= 64 * 1024 && d->robot.n_spheres <= 32;      // (a half-wave tests 32 feature points per pass)
+    const bool can = (shape == SH_A2 || shape == SH_A1) && 2 * s->phys_lds_bytes <= 64 * 1024 && d->robot.n_spheres <= 32;      // (a half-wave tests 32 feature points per pass)
     // measured (MI355X, k_substeps us, one / two envs per wavefront): go1gate (two robots per env) 4096 envs 122 / 128, 8192 envs 238 / 237;
     // go1plane (ONE robot per env: a pair is exactly the lane population of a go1gate wavefront) 4096 envs 108.8 / 85.6 -- the pairing
     // pays there once the batch fills the machine (4 one-env wavefronts per SIMD), so single-robot scenes of >= 4096 envs take it
     int want = (m.A == 1 && N >= 4096) ? 2 : 1;
     if (const char* ev = getenv("MQE_ENVS_PER_WAVE")) want = atoi(ev);
-    if (can && want == 2) {
-      s->substeps_fn = m.A == 2 ? (void (*)(const DevModel*, DevState, int, int, PostArgs))k_substeps<2, 0, 2> : (void (*)(const DevModel*, DevState, int, int, PostArgs))k_substeps<1, 0, 2>;
-      s->substeps_epw = 2;
-    }
+    s->substeps_epw = (can && want == 2) ? 2 : 1;
   }
+  s->substeps_fn = act32 ? shape_fn<true>(shape, s->substeps_epw) : shape_fn<false>(shape, s->substeps_epw);
   {   // the dynamic LDS of each launch as it is actually requested: one env's layout for k_simulate, substeps_epw of them for k_substeps
     const size_t lds_sub = s->phys_lds_bytes * (size_t)s->substeps_epw;
     if (s->phys_lds_bytes > 48 * 1024 && hipFuncSetAttribute((const void*)k_simulate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->phys_lds_bytes) != hipSuccess)
       return fail(-4, "cannot raise dynamic LDS limit");
     if (lds_sub > 48 * 1024 && hipFuncSetAttribute((const void*)s->substeps_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sub) != hipSuccess)
       return fail(-4, "cannot raise dynamic LDS limit");
+    if (timed_fn && lds_sub > 48 * 1024 && hipFuncSetAttribute((const void*)timed_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sub) != hipSuccess)
+      return fail(-4, "cannot raise dynamic LDS limit");
   }
   if (phase_timed && s->substeps_epw == 1) { s->substeps_fn = timed_fn; s->phase_timed = true; }
   s->fuse_substeps = getenv("MQE_NO_FUSE_SUBSTEPS") == nullptr && d->decimation <= 4;
   // the run-time terrain curriculum needs its snapshot launch between the physics and the resets: no epilogue fusion there
   // ... and only the kernels of the small class carry the epilogue (ShapeClass<TP>::small: go1gate, go1plane, the two-robot tasks with one more object)
-  s->fuse_post = s->fuse_substeps && getenv("MQE_NO_FUSE_POST") == nullptr && !m.curriculum &&
-                 (s->substeps_fn == (void (*)(const DevModel*, DevState, int, int, PostArgs))k_substeps<2, 0> || s->substeps_fn == (void (*)(const DevModel*, DevState, int, int, PostArgs))k_substeps<1, 0> ||
-                  s->substeps_fn == (void (*)(const DevModel*, DevState, int, int, PostArgs))k_substeps<2, 0, 1, true> ||
-                  s->substeps_fn == (void (*)(const DevModel*, DevState, int, int, PostArgs))k_substeps<1, 0, 2> ||
-                  // ... and, since every DevState pointer has a register pair of its own (own_state), the other kernels of the 16-envs-per-CU class: no spills
-                  (getenv("MQE_FUSE_POST_ROBOTS_ONLY") == nullptr &&
-                   (s->substeps_fn == (substeps_fn_t)k_substeps<2, PS_F_LINK> || s->substeps_fn == (substeps_fn_t)k_substeps<2, PS_F_NPC | PS_F_FEW> ||
-                    s->substeps_fn == (substeps_fn_t)k_substeps<2, PS_F_NPC | PS_F_BOX | PS_F_FEW> || s->substeps_fn == (substeps_fn_t)k_substeps<2, PS_F_STATIC | PS_F_FEW> ||
-                    // ... and the flock and 2-vs-2 shapes (one round at 2 wavefronts per SIMD, registers to spare: go1sheep-hard +3.2 %, go1football-2vs2
-                    // +1.5 %).  NOT go1football-defender, whose 4096 envs run in two rounds: both pay the epilogue's ~10 us chain, -1 % (MQE_FUSE_POST_ALL=1 tries it)
-                    (getenv("MQE_FUSE_POST_SMALL_ONLY") == nullptr &&
-                     (s->substeps_fn == (substeps_fn_t)k_substeps<2, PS_F_NPC> || s->substeps_fn == (substeps_fn_t)k_substeps<4, PS_F_NPC> ||
-                      s->substeps_fn == (substeps_fn_t)k_substeps<2, PS_F_NPC, 1, true> ||
-                      (getenv("MQE_FUSE_POST_ALL") != nullptr &&
-                       (s->substeps_fn == (substeps_fn_t)k_substeps<3, PS_F_NPC | PS_F_ROW> || s->substeps_fn == (substeps_fn_t)k_substeps<3, PS_F_NPC | PS_F_ROW, 1, true>)))))));
+  {
+    const bool robots_only = shape == SH_A2 || shape == SH_A1;
+    // ... and, since every DevState pointer has a register pair of its own (own_state), the other kernels of the 16-envs-per-CU class: no spills
+    const bool few = shape == SH_A2_LINK || shape == SH_A2_NPC_FEW || shape == SH_A2_BOX_FEW || shape == SH_A2_STATIC_FEW;
+    // ... and the flock and 2-vs-2 shapes (one round at 2 wavefronts per SIMD, registers to spare: go1sheep-hard +3.2 %, go1football-2vs2
+    // +1.5 %).  NOT go1football-defender, whose 4096 envs run in two rounds: both pay the epilogue's ~10 us chain, -1 % (MQE_FUSE_POST_ALL=1 tries it)
+    const bool flock = shape == SH_A2_NPC || shape == SH_A4_NPC;
+    const bool defender = shape == SH_A3_NPC_ROW;
+    s->fuse_post = s->fuse_substeps && getenv("MQE_NO_FUSE_POST") == nullptr && !m.curriculum && !(shape == SH_A2 && s->substeps_epw == 2) &&
+                   (robots_only || (getenv("MQE_FUSE_POST_ROBOTS_ONLY") == nullptr &&
+                                    (few || (getenv("MQE_FUSE_POST_SMALL_ONLY") == nullptr && (flock || (getenv("MQE_FUSE_POST_ALL") != nullptr && defender))))));
+  }
   if (s->fuse_post) {
     // the epilogue stages its observation / last-action / NPC rows and the env's actions in the link-record area (k_substeps: `sb`):
     // EPW * AMP * (MQE_OBS_BAG + 24) + EPW * MQE_MAX_NPCS * 13 + EPW * 12 A floats from L.body on.  With one env per wavefront they must
@@ -407,7 +434,7 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
     s->dbg_stop_phase = atoi(sp);
   }
   if (getenv("MQE_VERBOSE")) {
-    const char* names[] = {"MQE_LANE_SWEEP", "MQE_PHYS_LDS_PAD", "MQE_NO_FUSE_SUBSTEPS", "MQE_GEMM_SPLIT", "MQE_NO_FUSED_TAIL", "MQE_DEBUG_STOP_PHASE", "MQE_ENVS_PER_WAVE"};
+    const char* names[] = {"MQE_LANE_SWEEP", "MQE_PHYS_LDS_PAD", "MQE_NO_FUSE_SUBSTEPS", "MQE_GEMM_SPLIT", "MQE_NO_FUSED_TAIL", "MQE_DEBUG_STOP_PHASE", "MQE_ENVS_PER_WAVE", "MQE_ACT_F32"};
     fprintf(stderr, "mqe: k_substeps runs %d env(s) per wavefront\n", s->substeps_epw);
     for (const char* n : names)
       if (const char* v = getenv(n)) fprintf(stderr, "mqe: override in effect: %s=%s\n", n, v);
@@ -471,6 +498,23 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
       for (int s2 = 0; s2 < 3; s2++) fr[(size_t)(16 + s2) * 64 + lane] = d->actuator.W[0][j32 * 6 + 2 * s2 + h];
     }
     UP(m.act_frag, fr.data(), fr.size());
+    // layer 2 for the f16 matrix cores: two planes of 2^14 W1 in k_substeps' B-operand order (DevModel::act_frag16)
+    std::vector<uint16_t> f16((size_t)2 * 2 * 64 * 8);
+    float w1max = 0.0f;
+    for (int i = 0; i < 32 * 32; i++) w1max = std::max(w1max, std::fabs(d->actuator.W[1][i]));
+    for (int s2 = 0; s2 < 2; s2++)
+      for (int lane = 0; lane < 64; lane++)
+        for (int i8 = 0; i8 < 8; i8++) {
+          const int row = lane & 31, g = lane >> 5, u = (i8 & 3) + 16 * s2 + 8 * (i8 >> 2) + 4 * g;
+          uint16_t hh, ll;
+          split2(d->actuator.W[1][row * 32 + u], 16384.0f, hh, ll);
+          f16[((size_t)(s2 * 2 + 0) * 64 + lane) * 8 + i8] = hh;
+          f16[((size_t)(s2 * 2 + 1) * 64 + lane) * 8 + i8] = ll;
+        }
+    const float* t16;
+    UP(t16, reinterpret_cast<const float*>(f16.data()), f16.size() / 2);
+    m.act_frag16 = reinterpret_cast<const uint16_t*>(t16);
+    (void)w1max;
   }
   // ---- policy network: fused layer 0 over the ring-buffer history ------------------------------------------------
   const mqe_mlp& ad = d->adaptation; const mqe_mlp& bd = d->body;
