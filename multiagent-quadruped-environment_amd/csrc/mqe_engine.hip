@@ -191,15 +191,16 @@ static int finalize_frag(mqe_sim* s, GemmLayer* L) {
 // k_substeps is compiled for the env shapes of the shipped tasks (kernels_physics.hpp: PhysShape); everything else takes the
 // runtime form
 typedef void (*substeps_fn_t)(const DevModel*, DevState, int, int, PostArgs);
-enum SubShape { SH_A2, SH_A1, SH_A2_LINK, SH_A2_NPC_FEW, SH_A2_BOX_FEW, SH_A2_STATIC_FEW, SH_A3_NPC_ROW, SH_A2_NPC, SH_A4_NPC, SH_A2_GEN, SH_GEN };
-static SubShape pick_shape(const DevModel& m, size_t lds_bytes) {
+enum SubShape { SH_A2, SH_A1, SH_A2_NOPAD, SH_A2_LINK, SH_A2_NPC_FEW, SH_A2_BOX_FEW, SH_A2_STATIC_FEW, SH_A3_NPC_ROW, SH_A2_NPC, SH_A4_NPC, SH_A2_GEN, SH_GEN };
+static SubShape pick_shape(const DevModel& m, size_t lds_bytes, int pad) {
   const int feat = (m.has_seesaw ? PS_F_LINK : 0) | (m.n_npc_dyn > 0 ? PS_F_NPC : 0) | (m.has_box ? PS_F_BOX : 0) | (m.n_static > 0 ? PS_F_STATIC : 0);
   // the small class (row sweep compiled in, 128 VGPRs, every env resident): <= 4 actors and 16 LDS footprints per CU
   if (m.rowgs && lds_bytes <= 10240) {                                       // (MQE_LANE_SWEEP=1 sends these scenes to the kernels below)
-    if (feat == 0 && m.P == 0) {
+    if (feat == 0 && m.P == 0 && pad) {
       if (m.A == 2) return SH_A2;                                            // go1gate
       if (m.A == 1) return SH_A1;                                            // go1plane
     }
+    if (feat == 0 && m.P == 0 && !pad && m.A == 2) return SH_A2_NOPAD;       // go1gate with the exact collision model (unpadded records)
     if (m.A == 2 && feat == PS_F_LINK) return SH_A2_LINK;                    // go1seesaw, go1revolvingdoor, go1tug
     if (m.A == 2 && feat == PS_F_NPC) return SH_A2_NPC_FEW;                  // go1football-1vs1, a single sheep
     if (m.A == 2 && feat == (PS_F_NPC | PS_F_BOX)) return SH_A2_BOX_FEW;     // go1pushbox
@@ -219,6 +220,7 @@ static substeps_fn_t shape_fn(SubShape sh, int epw) {
   switch (sh) {
     case SH_A2: return epw == 2 ? (substeps_fn_t)k_substeps<2, 0, 2, false, ACT32> : (substeps_fn_t)k_substeps<2, 0, 1, false, ACT32>;
     case SH_A1: return epw == 2 ? (substeps_fn_t)k_substeps<1, 0, 2, false, ACT32> : (substeps_fn_t)k_substeps<1, 0, 1, false, ACT32>;
+    case SH_A2_NOPAD: return k_substeps<2, PS_F_FEW, 1, false, ACT32>;
     case SH_A2_LINK: return k_substeps<2, PS_F_LINK, 1, false, ACT32>;
     case SH_A2_NPC_FEW: return k_substeps<2, PS_F_NPC | PS_F_FEW, 1, false, ACT32>;
     case SH_A2_BOX_FEW: return k_substeps<2, PS_F_NPC | PS_F_BOX | PS_F_FEW, 1, false, ACT32>;
@@ -349,8 +351,15 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   m.rowgs = (A + m.n_npc_dyn + (seesaw ? 1 : 0) <= 4) ? 1 : 0;      // one 16-lane row per actor; the <A,0> / <2,LINK> kernels assume it
   if (getenv("MQE_LANE_SWEEP")) m.rowgs = 0;      // tests: the other lane mapping of the contact sweep on the same scene (tests/test_gpu_parity.py)
   // padded link / contact records (kernels_physics.hpp: PhysPad): the robot-only kernels k_substeps<A, 0>, which the scene gets iff ...
-  const int pad = (m.rowgs && m.P == 0 && !m.has_seesaw && m.n_npc_dyn == 0 && !m.has_box && m.n_static == 0 && (A == 1 || A == 2)) ? 1 : 0;
+  int pad = (m.rowgs && m.P == 0 && !m.has_seesaw && m.n_npc_dyn == 0 && !m.has_box && m.n_static == 0 && (A == 1 || A == 2)) ? 1 : 0;
   PhysLds L = phys_lds_layout(A, P, s->ND, m.nbody_env, m.ndof_env, m.nsph_env, m.nprim_env, m.maxc, m.rowgs, pad);
+  // ... and whose padded layout still lets 16 envs sit on a CU.  The "exact" collision model (60 feature points per robot) needs 10768 B
+  // padded and 10096 B unpadded: it takes the unpadded robots-only kernel (k_substeps<2, PS_F_FEW>: SH_A2_NOPAD) and stays in the 16-envs-per-CU
+  // class (fused epilogue, 4 wavefronts per SIMD) instead of falling to the generic kernel at 2 per SIMD
+  if (pad && (size_t)L.total * 4 > 10240) {
+    pad = 0;
+    L = phys_lds_layout(A, P, s->ND, m.nbody_env, m.ndof_env, m.nsph_env, m.nprim_env, m.maxc, m.rowgs, pad);
+  }
   s->phys_lds_bytes = (size_t)L.total * 4;
   if (getenv("MQE_VERBOSE")) fprintf(stderr, "mqe: physics LDS %zu B per env (wavefront)\n", s->phys_lds_bytes);
   if (const char* pad = getenv("MQE_PHYS_LDS_PAD")) s->phys_lds_bytes += (size_t)atoi(pad);   // experiments: caps the physics kernel's waves per CU
@@ -364,7 +373,7 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
       for (int i = 0; i < 32 * 32; i++) w1max = std::max(w1max, std::fabs(d->actuator.W[1][i]));
     m.act_f16 = (getenv("MQE_ACT_F32") == nullptr && w1max < 3.99f) ? 1 : 0;
   }
-  const SubShape shape = pick_shape(m, s->phys_lds_bytes);
+  const SubShape shape = pick_shape(m, s->phys_lds_bytes, pad);
   s->substeps_shape = (int)shape;
   s->a2_scene = shape == SH_A2;
   const bool act32 = m.act_f16 == 0;                 // MQE_ACT_F32=1 (or a network whose weights do not fit the f16 planes): the exact f32 chain
@@ -404,7 +413,7 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   {
     const bool robots_only = shape == SH_A2 || shape == SH_A1;
     // ... and, since every DevState pointer has a register pair of its own (own_state), the other kernels of the 16-envs-per-CU class: no spills
-    const bool few = shape == SH_A2_LINK || shape == SH_A2_NPC_FEW || shape == SH_A2_BOX_FEW || shape == SH_A2_STATIC_FEW;
+    const bool few = shape == SH_A2_NOPAD || shape == SH_A2_LINK || shape == SH_A2_NPC_FEW || shape == SH_A2_BOX_FEW || shape == SH_A2_STATIC_FEW;
     // ... and the flock and 2-vs-2 shapes (one round at 2 wavefronts per SIMD, registers to spare: go1sheep-hard +3.2 %, go1football-2vs2
     // +1.5 %).  NOT go1football-defender, whose 4096 envs run in two rounds: both pay the epilogue's ~10 us chain, -1 % (MQE_FUSE_POST_ALL=1 tries it)
     const bool flock = shape == SH_A2_NPC || shape == SH_A4_NPC;
