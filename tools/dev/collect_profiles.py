@@ -14,7 +14,8 @@ def cp(src, dst):
 
 for f in (f"{T}_bench_driver_style.json", f"{T}_other_tasks.txt", f"{T}_parity_sweep.json", f"{T}_parity_sweep_pgs.json", f"{T}_phase_counters_go1gate_tgs.txt",
           f"{T}_phase_counters_go1gate_pgs.txt", f"{T}_phase_walltimes_go1gate.txt", f"{T}_phase_walltimes_go1sheep-hard.txt", f"{T}_phase_walltimes_go1football-defender.txt",
-          f"{T}_wave_times_go1gate.txt", f"{T}_batch_sweep.json"):
+          f"{T}_wave_times_go1gate.txt", f"{T}_batch_sweep.json", f"{T}_phase_lanes_go1gate.txt", f"{T}_dt_convergence.json", f"{T}_graph_probe.txt",
+          f"{T}_parity_sweep_long.json"):
     cp(f, f)
 for task in ("go1sheep-hard", "go1seesaw", "go1football-defender"):
     cp(f"{T}t_{task}_bench.json", f"{T}_bench_{task}.json")

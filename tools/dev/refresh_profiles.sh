@@ -22,6 +22,9 @@ for s in tgs pgs; do
   MQE_SOLVER=$s rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_SMEM --kernel-trace --output-format csv -d $R/gpurun_out/${T}_phase_$s -- python $R/tools/phase_counters.py run go1gate 4096 > $R/gpurun_out/${T}_phase_$s.log 2>&1
   (cd $R; python tools/phase_counters.py report gpurun_out/${T}_phase_$s > gpurun_out/${T}_phase_counters_go1gate_$s.txt 2>&1)
 done
+# lane utilisation per phase: active lanes per VALU instruction = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU (of 64)
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $R/gpurun_out/${T}_phase_lanes -- python $R/tools/phase_counters.py run go1gate 4096 > $R/gpurun_out/${T}_phase_lanes.log 2>&1
+(cd $R; python tools/phase_counters.py report gpurun_out/${T}_phase_lanes > gpurun_out/${T}_phase_lanes_go1gate.txt 2>&1)
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $R/gpurun_out/${T}_pmc_lds -- python $R/bench.py --steps 30 --warmup 5 --no_cpu_baseline --no_strict_f32 > $R/gpurun_out/${T}_pmc_lds.log 2>&1
 cd $R
 python tests/parity_sweep.py 256 gpurun_out/${T}_parity_sweep.json > gpurun_out/${T}_parity.log 2>&1
@@ -31,3 +34,7 @@ python tools/dev/phase_walltimes.py 4096 60 go1gate > gpurun_out/${T}_phase_wall
 python tools/dev/phase_walltimes.py 2048 60 go1sheep-hard > gpurun_out/${T}_phase_walltimes_go1sheep-hard.txt 2>&1
 python tools/dev/phase_walltimes.py 4096 60 go1football-defender > gpurun_out/${T}_phase_walltimes_go1football-defender.txt 2>&1
 python tools/dev/wave_times.py go1gate 4096 120 > gpurun_out/${T}_wave_times_go1gate.txt 2>&1
+python tools/dt_convergence.py gpurun_out/${T}_dt_convergence.json 32 > gpurun_out/${T}_dt_convergence.txt 2>&1
+python tools/dev/graph_probe.py go1gate 4096 400 > gpurun_out/${T}_graph_probe.txt 2>&1
+# the long form of the parity sweep last (11 minutes of CPU oracle): 1024 envs x 200 fused steps, nothing re-synchronised
+python tests/parity_sweep.py 1024 gpurun_out/${T}_parity_sweep_long.json 200 > gpurun_out/${T}_parity_long.log 2>&1
