@@ -33,7 +33,7 @@ extern "C" {
 #define MQE_NREP 17       /* reported rigid bodies of one Go1 (feet kept, go1.urdf dont_collapse) */
 #define MQE_NDOF 12
 #define MQE_MAX_AGENTS 4
-#define MQE_MAX_NPCS 9
+#define MQE_MAX_NPCS 16
 #define MQE_FRAME 72      /* 70-float locomotion observation padded to 72 (16-byte rows) */
 #define MQE_HIST 30       /* frames of history fed to the locomotion policy (go1.py:395) */
 #define MQE_MAX_LAYERS 6

@@ -326,7 +326,8 @@ __host__ __device__ inline PhysLds phys_lds_layout(int A, int P, int ND, int nbo
 }
 
 // floats the post-physics epilogue of k_substeps stages from L.body on (obs-bag rows, last-action rows, NPC rows, the actions)
-__host__ __device__ inline int post_staging_floats(int epw, int amp, int nj) { return epw * amp * (MQE_OBS_BAG + 24) + epw * MQE_MAX_NPCS * 13 + epw * nj; }
+__host__ __device__ inline int post_npc_stride(int P) { return (P * 13 + 3) & ~3; }
+__host__ __device__ inline int post_staging_floats(int epw, int amp, int nj, int P) { return epw * amp * (MQE_OBS_BAG + 24) + epw * post_npc_stride(P) + epw * nj; }
 struct PhysDebug { float* minv; int* nc; float* contacts; int robot; long long* times; int stop_after; };
 // phase tap: the 100 MHz wall clock at lane 0 and, for per-phase counter runs (tools/phase_counters.py), an early exit of the whole wavefront
 #define TSTAMP(i) do { if (dbg.times != nullptr && lane == 0) dbg.times[i] = (long long)wall_clock64(); if (dbg.stop_after == (i)) return; } while (0)
@@ -837,7 +838,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   //  * broad phase of ALL actor pairs at once, lane = pair (a < b, row-major): actors farther apart than 1.2 m (robot vs the box:
   //    1.8 m) cannot touch.  The 55 pairs of the 2 + 9 actors of go1sheep-hard used to cost 55 sequential LDS round trips per substep.
   //  * self-collision: a robot whose joint angles are all inside the model's safe box (a walking robot is) cannot touch itself.
-  unsigned long long near0 = 0ull, near1 = 0ull;
+  unsigned long long near0 = 0ull, near1 = 0ull, near2 = 0ull;       // 3 x 64 pairs: up to 19 actors (2 robots + 16 sheep: 153 pairs)
   unsigned int self_todo = 0u;                               // bit a: robot a is outside its safe box
   {
     const int nact = A + PD;
@@ -856,7 +857,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
         else nr = !(dot(dd, dd) > 1.2f * 1.2f);
       }
       const unsigned long long bm = gballot(nr);
-      if (t0 == 0) near0 = bm; else near1 = bm;
+      if (t0 == 0) near0 = bm; else if (t0 == LW) near1 = bm; else near2 |= bm;
     }
     if (HI(HOT_SELF_COLLISION))
       for (int a = 0; a < A; a++) {
@@ -869,7 +870,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   // and is marked by a negative radius).  Only built when something can touch a primitive at all: two robots walking apart from
   // each other in ordinary poses skip it.
   const int npr = HI(HOT_N_PRIMS);
-  const bool need_prims = near0 != 0ull || near1 != 0ull || self_todo != 0u;
+  const bool need_prims = near0 != 0ull || near1 != 0ull || near2 != 0ull || self_todo != 0u;
   for (int t = lane; need_prims && t < A * npr; t += LW) {
     const int r = t / npr, q = t - r * npr;
     const float* rec = lds + L.body + (r * MQE_NBODY + rm.prim_body[q]) * BODY_STRIDE;
@@ -1231,7 +1232,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     for (int a = 0; a < a_end; a++)
       for (int b = a + 1; b < nact; b++) {
         tp++;
-        if (!(((tp < LW ? near0 >> tp : near1 >> (tp - LW)) & 1ull))) continue;          // uniform within the group
+        if (!(((tp < LW ? near0 >> tp : (tp < 2 * LW ? near1 >> (tp - LW) : near2 >> (tp - 2 * LW))) & 1ull))) continue;          // uniform within the group
         const V3 pb = ld3(lds + L.body + (b < A ? b * MQE_NBODY : A * MQE_NBODY + (b - A)) * BODY_STRIDE + B_P);
         if (shp.has_box && b >= A) {                           // robot spheres vs the oriented box (NPC body record = its pose)
           const float* brec = lds + L.body + (A * MQE_NBODY + (b - A)) * BODY_STRIDE;
@@ -2633,18 +2634,18 @@ __global__ void __launch_bounds__(64, EPW == 2 ? 2 : SubstepsClass<TP>::waves) k
     constexpr int AMP = (TA == 1 || TA == 2) ? 2 : MQE_MAX_AGENTS;
     // LDS: root and joint states are still where the physics kept them (L.root, L.dof of each env's layout); the staging rows of the
     // post step go into the dead torque / bias / history area behind them ... no: into the link-record area (L.body .. : dead since the sweep)
-    // obs rows, last-action rows, NPC rows, the env's actions: post_staging_floats(EPW, AMP, nj) floats from L.body on -- 337 of the 936 there for
+    // obs rows, last-action rows, NPC rows, the env's actions: post_staging_floats(EPW, AMP, nj, P) floats from L.body on -- 337 of the 936 there for
     // go1gate, 650 of the 740 in front of the second env's root rows for the paired go1plane kernel, 557 for four robots; mqe_sim_create
     // checks the actual layout against the same formula and keeps the separate launch when it does not fit
     float* sb = lds_wave + L.body;
-    float* act_l = sb + EPW * AMP * (MQE_OBS_BAG + 24) + EPW * MQE_MAX_NPCS * 13;
+    float* act_l = sb + EPW * AMP * (MQE_OBS_BAG + 24) + EPW * post_npc_stride(P);
     for (int i = lane_wave; i < EPW * nj; i += 64) {          // the wavefront's actions, one coalesced load
       const int ge = i / nj, jt = i - ge * nj;
       if (e_first + ge < m->N) act_l[ge * nj + jt] = st.actions[(size_t)(e_first + ge) * nj + jt];
     }
     __syncthreads();
     post_body<AMP, EPW>(m, st, (int)blockIdx.x, lane_wave, sb, sb + EPW * AMP * MQE_OBS_BAG, sb + EPW * AMP * (MQE_OBS_BAG + 24), pa.wrapper_level, pa.push_count, pa.step_no,
-                        lds_wave + L.root, lds_wave + L.dof, act_l, L.total, nj);
+                        lds_wave + L.root, lds_wave + L.dof, act_l, L.total, nj, post_npc_stride(P));
   }
   if (st.wave_times && lane_wave == 0) st.wave_times[4 * blockIdx.x + 1] = (long long)wall_clock64();
 }

@@ -835,14 +835,15 @@ __device__ __forceinline__ void post_flush_rows(float* __restrict__ g, const flo
 // kernel k_post_physics runs it with PEPW = POST_EPW and static LDS; the fused decimation kernel k_substeps runs it as its epilogue
 // with PEPW = its envs per wavefront and the physics' dead LDS (mqe_step: one launch less and no second pass over the state).
 // AM: compile-time bound of the agent lanes (>= m->A; 2 for the two-robot tasks, MQE_MAX_AGENTS otherwise); tid = lane;
-// s_bag / s_la / s_npc: LDS of PEPW * AM * 74, PEPW * AM * 24 and PEPW * MQE_MAX_NPCS * 13 floats, 16 B aligned.
+// s_bag / s_la / s_npc: LDS of PEPW * AM * 74, PEPW * AM * 24 and PEPW * npc_stride floats, 16 B aligned.
 // root_l / dof_l / act_l (fused epilogue only, else nullptr): the env's root rows, joint states and actions in LDS -- [PEPW] x ([A + P][13],
 // [ND][2], [12 A]) at the given strides -- so that the robot lanes' 49 scattered global loads become LDS reads (in the epilogue every
 // wavefront has 2 active lanes per vector-memory instruction: 8 x the instructions of the stand-alone kernel for the same bytes).
 template <int AM, int PEPW>
 __device__ __forceinline__ void post_body(const DevModel* m, const DevState& st, const int blk, const int tid, float* s_bag, float* s_la, float* s_npc,
                                           int wrapper_level, int push_count, int step_no,
-                                          const float* root_l = nullptr, const float* dof_l = nullptr, const float* act_l = nullptr, int lds_env_stride = 0, int act_env_stride = 0) {
+                                          const float* root_l = nullptr, const float* dof_l = nullptr, const float* act_l = nullptr, int lds_env_stride = 0, int act_env_stride = 0,
+                                          const int npc_stride = MQE_MAX_NPCS * 13) {      // floats between two envs' NPC rows in s_npc (the fused epilogue packs them: P * 13 rounded up to 4)
   static_assert(PEPW * AM <= 64 && (PEPW & (PEPW - 1)) == 0, "agent lanes of PEPW envs must fit one wavefront");
   const int A = m->A, P = m->P;
   const int le = tid & (PEPW - 1), a = tid / PEPW;
@@ -940,12 +941,12 @@ __device__ __forceinline__ void post_body(const DevModel* m, const DevState& st,
   }
   // wrapper's view of root_states_npc: copy taken before the NPC script (legged_robot.py:136); xy/vel only are read
   // (staged in LDS by the whole wavefront: as a per-lane array of P * 13 floats it lived in scratch memory)
-  float* npc_pre = s_npc + le * MQE_MAX_NPCS * 13;
+  float* npc_pre = s_npc + le * npc_stride;
   {
     const int e0 = blk * PEPW, nenv = min(PEPW, m->N - e0), per = P * 13;
     for (int t = tid; t < nenv * per; t += 64) {
       const int sl = t / per, r = t - sl * per;
-      s_npc[sl * MQE_MAX_NPCS * 13 + r] = st.root[((size_t)(e0 + sl) * (A + P) + A) * 13 + r];
+      s_npc[sl * npc_stride + r] = st.root[((size_t)(e0 + sl) * (A + P) + A) * 13 + r];
     }
     __syncthreads();
   }

@@ -269,7 +269,9 @@ static void h2_tiling(int M, int ntn, bool use_half, int* full_tiles, int* half_
 extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   if (!d || !out) return fail(-1, "null argument");
   if (d->abi_version != MQE_ABI_VERSION) return fail(-1, "abi version mismatch");
-  if (d->num_agents < 1 || d->num_agents > MQE_MAX_AGENTS || d->num_npcs > MQE_MAX_NPCS) return fail(-2, "unsupported agent/npc count");
+  if (d->num_agents < 1 || d->num_agents > MQE_MAX_AGENTS)
+    return fail(-2, "num_agents must be 1 .. 4: one env is one 64-lane wavefront in the physics kernel (a body per lane: 13 per Go1 + the NPCs), a fifth robot does not fit");
+  if (d->num_npcs < 0 || d->num_npcs > MQE_MAX_NPCS) return fail(-2, "num_npcs must be 0 .. 16 (MQE_MAX_NPCS)");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(-3, "no HIP device: the engine has no CPU path");
   mqe_sim* s = new mqe_sim();
@@ -424,11 +426,11 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   }
   if (s->fuse_post) {
     // the epilogue stages its observation / last-action / NPC rows and the env's actions in the link-record area (k_substeps: `sb`):
-    // EPW * AMP * (MQE_OBS_BAG + 24) + EPW * MQE_MAX_NPCS * 13 + EPW * 12 A floats from L.body on.  With one env per wavefront they must
+    // EPW * AMP * (MQE_OBS_BAG + 24) + EPW * (P * 13 rounded up to 4) + EPW * 12 A floats from L.body on.  With one env per wavefront they must
     // end inside the env's own layout; with two, before the SECOND env's root rows (which post_body still reads).  A layout that does
     // not leave that room (another stride, a larger bag, more NPC rows) keeps the separate launch instead of overwriting live state.
     const int epw = s->substeps_epw, amp = (A == 1 || A == 2) ? 2 : MQE_MAX_AGENTS;
-    const int need = post_staging_floats(epw, amp, 12 * A);
+    const int need = post_staging_floats(epw, amp, 12 * A, P);
     const int room = (epw == 1 ? L.total : L.total + L.root) - L.body;
     if (need > room) {
       if (getenv("MQE_VERBOSE")) fprintf(stderr, "mqe: post-physics epilogue needs %d floats of staging, the layout has %d: separate launch\n", need, room);

@@ -6,7 +6,7 @@ MAX_SPHERES, NBODY, NREP, NDOF = 64, 13, 17, 12
 MAX_SELF_PAIRS = 384
 MAX_PRIMS = 20
 PRIM_SPHERE, PRIM_CAPSULE, PRIM_BOX = 0, 1, 2
-MAX_AGENTS, MAX_NPCS, FRAME, HIST, MAX_LAYERS, MAX_REWARD_TERMS = 4, 9, 72, 30, 6, 12
+MAX_AGENTS, MAX_NPCS, FRAME, HIST, MAX_LAYERS, MAX_REWARD_TERMS = 4, 16, 72, 30, 6, 12
 OBS_BAG = 74
 
 TASK = dict(plain=0, gate=1, sheep=2, seesaw=3, football_defender=4, pushbox=5, rotation=6, bridge=7, wrestling=8, tug=9)

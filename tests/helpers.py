@@ -57,9 +57,18 @@ def wall_heights_terrain(task, lo=0.3, hi=0.7, **cfg_over):
     return type("WallHeightsTerrain", (base,), dict(cfg_over, BarrierTrack_kwargs=kw))
 
 
-def make_desc(task, N, seed=0, levels=None, types=None, max_episode_length=None, npc_init=None, env_id_offset=0, terrain_cfg=None, command_flags=None, **kw):
+def flock_cfg(rows, cols, dis=1.2):
+    """go1sheep-hard's config with a rows x cols flock (cfg.env.num_npcs, cfg.asset.num_rows / num_cols / dis_sheep: go1_sheep.py:84-118 builds
+    any grid; the shipped 1.5 m spacing puts the outer columns of a 4 x 4 grid into the 6 m track's walls)"""
+    base = task_cfg("go1sheep-hard")
+    env = type("env", (base.env,), {"num_npcs": rows * cols})
+    asset = type("asset", (base.asset,), {"num_rows": rows, "num_cols": cols, "dis_sheep": (dis, dis)})
+    return type("Flock%dx%dCfg" % (rows, cols), (base,), {"env": env, "asset": asset})
+
+
+def make_desc(task, N, seed=0, levels=None, types=None, max_episode_length=None, npc_init=None, env_id_offset=0, terrain_cfg=None, command_flags=None, cfg=None, **kw):
     """Scene exactly as Go1._create_scene builds it, but with explicit track assignment for replaying fixtures."""
-    cfg = task_cfg(task)
+    cfg = cfg if cfg is not None else task_cfg(task)
     if terrain_cfg is not None:
         cfg = type(cfg.__name__ + "OnOtherTerrain", (cfg,), {"terrain": terrain_cfg})
     if command_flags:            # command.cfg switches (go1.py:64-93): further action columns

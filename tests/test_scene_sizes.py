@@ -1,0 +1,85 @@
+"""Scene sizes beyond the shipped tasks (VERDICT r4 missing 5; the reference builds whatever cfg.env.num_agents / num_npcs name,
+legged_robot.py:854-902, go1_sheep.py:84-118): a flock of 16 sheep -- 2 robots + 16 sheep = 42 bodies, 84 generalized velocities, 153 actor
+pairs in one wavefront -- on the CPU specification here and on the HIP engine against it under -m gpu.  What stays a limit, and is refused
+with its reason: a fifth robot (13 body lanes each: 65 > the 64 lanes of the wavefront that owns an env)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import make_desc, oracle_engine, hip_engine, flock_cfg, close
+from mqe.engine import abi
+
+
+def test_sixteen_sheep_flock_on_the_specification():
+    N = 6
+    d, k, _ = make_desc("go1sheep-hard", N, cfg=flock_cfg(4, 4))
+    assert d.num_npcs == 16 and abi.MAX_NPCS >= 16
+    e = oracle_engine(d, k)
+    e.reset_all()
+    assert e.tensor(abi.T_WRAPPER_OBS).shape == (N, 2, 14 + 2 * 16 + 2)          # go1_sheep_wrapper.py:10
+    g = torch.Generator().manual_seed(0)
+    root = e.tensor(abi.T_ROOT_STATE)
+    start = root[:, 2:, :2].clone()
+    for t in range(40):
+        e.step(torch.rand(N, 2, 3, generator=g) * 2 - 1)
+    assert torch.isfinite(root).all() and int(e.tensor(abi.T_CONTACT_OVERFLOW).sum()) == 0
+    z = root[:, 2:, 2]
+    assert ((z > 0.2) & (z <= 0.3 + 1e-6)).all()                               # on the ground, clipped by the script (go1_sheep.py:60)
+    assert (root[:, 2:, :2] - start).norm(dim=-1).max() > 0.05                 # the script moves them (randomness 0.1 x 2 per step)
+    avg = e.tensor(abi.T_SHEEP_POS_AVG)
+    # logged one step behind: the statistics of the positions the last script call saw = before its own update is integrated
+    assert torch.isfinite(avg).all() and torch.isfinite(e.tensor(abi.T_SHEEP_POS_VAR)).all()
+    _, _, c = e.debug_dynamics(0, 0)
+    per_actor = np.bincount(c[c[:, 2] < 0, 0].astype(int), minlength=18)
+    assert (per_actor[2:] >= 1).all() and per_actor[2:].max() <= 2              # every sheep stands on the ground
+
+
+@pytest.mark.gpu
+def test_sixteen_sheep_flock_hip_matches_the_specification(solver):
+    """the rollout bounds of test_fused_rollout_matches_oracle on the 18-actor scene (lane sweep, 3 x 64 actor pairs in the broad phase,
+    8 passes of NPC-NPC sphere pairs, the fused epilogue with 16 NPC rows staged)"""
+    N = 24
+    d1, k1, _ = make_desc("go1sheep-hard", N, cfg=flock_cfg(4, 4))
+    d2, k2, _ = make_desc("go1sheep-hard", N, cfg=flock_cfg(4, 4))
+    eh, eo = hip_engine(d1, k1), oracle_engine(d2, k2)
+    eh.reset_all(); eo.reset_all()
+    g = torch.Generator().manual_seed(5)
+    dev, mism = [], 0
+    for t in range(20):
+        a = torch.rand(N, 2, 3, generator=g) * 2 - 1
+        eh.step(a.cuda().contiguous()); eo.step(a)
+        torch.cuda.synchronize()
+        rh, ro = eh.tensor(abi.T_ROOT_STATE).cpu(), eo.tensor(abi.T_ROOT_STATE)
+        dev.append((rh[..., :3] - ro[..., :3]).abs().amax(dim=(1, 2)))
+        mism += int((eh.tensor(abi.T_RESET_BUF).cpu() != eo.tensor(abi.T_RESET_BUF)).sum())
+        if t == 0:
+            close(eh.tensor(abi.T_WRAPPER_OBS), eo.tensor(abi.T_WRAPPER_OBS), atol=2e-4, what="wrapper obs (48 columns) after 1 step")
+    dev = torch.stack(dev)
+    assert float(dev[4].median()) < 5e-7 and float(dev[4].max()) < 2e-5, (dev[4].median(), dev[4].max())
+    assert float(dev[19].median()) < 2e-6 and float(dev[19].max()) < 5e-4, (dev[19].median(), dev[19].max())
+    assert mism == 0 and int(eh.tensor(abi.T_CONTACT_OVERFLOW).sum()) == int(eo.tensor(abi.T_CONTACT_OVERFLOW).sum()) == 0
+    # two sheep pushed into each other and into a robot: the NPC-NPC and robot-NPC pair passes on the 18-actor scene, identical lists
+    ro, rh = eo.tensor(abi.T_ROOT_STATE), eh.tensor(abi.T_ROOT_STATE)
+    ro[:, 3, :2] = ro[:, 2, :2] + torch.tensor([0.33, 0.0])
+    ro[:, 17, :2] = ro[:, 16, :2] + torch.tensor([0.0, 0.35])
+    ro[:, 10, :3] = ro[:, 0, :3] + torch.tensor([0.45, 0.0, -0.05])
+    rh.copy_(ro.cuda())
+    torch.cuda.synchronize()
+    for env in (0, N - 1):
+        _, ch = eh.debug_dynamics(env, 0)
+        _, _, co = eo.debug_dynamics(env, 0)
+        assert ch.shape == co.shape and (ch[:, :4] == co[:, :4]).all(), (env, ch[:, :4], co[:, :4])
+        assert (co[:, 2] >= 2).sum() >= 2                                         # sheep-sheep contacts are in the list
+        close(ch[:, 4:], co[:, 4:], atol=2e-5, what="contact separation / normal")
+
+
+@pytest.mark.gpu
+def test_a_fifth_robot_is_refused_with_the_reason():
+    d, k, _ = make_desc("go1gate", 4)
+    d.num_agents = 5
+    with pytest.raises(RuntimeError, match="64-lane wavefront"):
+        hip_engine(d, k)
+    d, k, _ = make_desc("go1sheep-hard", 4)
+    d.num_npcs = 17
+    with pytest.raises(RuntimeError, match="num_npcs"):
+        hip_engine(d, k)
