@@ -32,8 +32,8 @@ extern "C" {
 #define MQE_NBODY 13      /* dynamic bodies of one Go1 after fixed-joint collapsing */
 #define MQE_NREP 17       /* reported rigid bodies of one Go1 (feet kept, go1.urdf dont_collapse) */
 #define MQE_NDOF 12
-#define MQE_MAX_AGENTS 4
-#define MQE_MAX_NPCS 16
+#define MQE_MAX_AGENTS 4  /* one env = one 64-lane wavefront of the physics kernel, a body per lane: 13 per Go1 (+ the NPCs): a fifth robot does not fit */
+#define MQE_MAX_NPCS 16   /* round 5 (was 9): a 4 x 4 sheep flock = 18 actors, 42 bodies, 84 generalized velocities per env */
 #define MQE_FRAME 72      /* 70-float locomotion observation padded to 72 (16-byte rows) */
 #define MQE_HIST 30       /* frames of history fed to the locomotion policy (go1.py:395) */
 #define MQE_MAX_LAYERS 6
@@ -392,8 +392,9 @@ int mqe_step_joint(mqe_sim* s, const float* actions12, void* stream);
  * nothing lies within far_m.  cam_pos3 / cam_rpy3 (host pointers) = cfg.sensor.forward_camera.position / .rotation (ZYX Euler) in the base
  * link; the camera looks along its +x, +z up; pixel (0, 0) is the top-left corner.  What is seen is what the physics collides with: the
  * ground (slab or relief), the wall prisms, the OTHER robots' collision primitives, free NPCs, the 1-dof link, the scenery boxes -- a ray
- * caster (csrc/kernels_camera.hpp), not the reference's rasteriser, which is closed: geometric known answers only
- * (tests/test_camera_gpu.py).  Colour images (IMAGE_COLOR) are not offered. */
+ * caster (csrc/kernels_camera.hpp), not the reference's rasteriser, which is closed: the image is SPECIFIED by the scalar caster of the CPU
+ * oracle (oracle/mqe_oracle.c: mqo_render_depth -- conventions, surfaces, marching rules), which passes geometric known answers on its own
+ * (tests/test_camera_oracle.py); the kernel equals it pixel by pixel (tests/test_camera_gpu.py).  Colour images (IMAGE_COLOR) are not offered. */
 int mqe_render_depth(mqe_sim* s, float* out_dev, int height, int width, float horizontal_fov_deg, const float* cam_pos3, const float* cam_rpy3,
                      float far_m, void* stream);
 
