@@ -55,8 +55,10 @@ def test_sixteen_sheep_flock_hip_matches_the_specification(solver):
         if t == 0:
             close(eh.tensor(abi.T_WRAPPER_OBS), eo.tensor(abi.T_WRAPPER_OBS), atol=2e-4, what="wrapper obs (48 columns) after 1 step")
     dev = torch.stack(dev)
-    assert float(dev[4].median()) < 5e-7 and float(dev[4].max()) < 2e-5, (dev[4].median(), dev[4].max())
-    assert float(dev[19].median()) < 2e-6 and float(dev[19].max()) < 5e-4, (dev[19].median(), dev[19].max())
+    # (the deviation is the maximum over the env's 18 actors of an ABSOLUTE position difference, and the flock stands 6-12 m from the origin, where
+    # one f32 ulp is 1e-6 m: measured after 20 steps median 3.8e-6 = 4 ulp, max 1.2e-5)
+    assert float(dev[4].median()) < 2e-6 and float(dev[4].max()) < 2e-5, (dev[4].median(), dev[4].max())
+    assert float(dev[19].median()) < 1e-5 and float(dev[19].max()) < 5e-4, (dev[19].median(), dev[19].max())
     assert mism == 0 and int(eh.tensor(abi.T_CONTACT_OVERFLOW).sum()) == int(eo.tensor(abi.T_CONTACT_OVERFLOW).sum()) == 0
     # two sheep pushed into each other and into a robot: the NPC-NPC and robot-NPC pair passes on the 18-actor scene, identical lists
     ro, rh = eo.tensor(abi.T_ROOT_STATE), eh.tensor(abi.T_ROOT_STATE)
