@@ -2527,6 +2527,12 @@ __global__ void __launch_bounds__(64, EPW == 2 ? 2 : SubstepsClass<TP>::waves) k
         const int u = (r & 3) + 8 * (r >> 2) + 4 * h;
         if constexpr (!act16) a2[r] = fragw[r * 64];
         w3[r] = W2[u]; bb0[r] = b0[u]; bb1[r] = b1[u];
+#ifdef MQE_ACT_DUPLOAD
+        {   // experiment: the 48 two-address dword loads issued once more (volatile: kept) -- what do they cost at 4 wavefronts per SIMD?
+          const float d0 = *(const volatile float*)(W2 + u), d1 = *(const volatile float*)(b0 + u), d2 = *(const volatile float*)(b1 + u);
+          asm volatile("" :: "v"(d0), "v"(d1), "v"(d2));
+        }
+#endif
       }
       const float bout = b2[0];
       // layer 2 on the f16 matrix cores (DevModel::act_f16; MQE_ACT_F32=1 keeps the f32 MFMA chain above): W1 as two f16 planes of 2^14 w in
