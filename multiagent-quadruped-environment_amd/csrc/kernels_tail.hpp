@@ -5,7 +5,7 @@
 //               b2 = ELU(b1 Wb2 + b)  (256 -> 128),  joint targets = b2 Wb3 + b  (128 -> 12)
 //   post        last-action registers shifted, targets clipped into `actions`
 // Replaces five k_gemm_f32 launches + k_body_l0_finish + k_post_policy, which were launch/latency-bound (84 us for
-// 3.3 GFLOP at R = 8192).  One 256-thread workgroup owns 32 robots (R = 8192 -> 256 workgroups = one per CU) and walks
+// 3.3 GFLOP at R = 8192).  One 512-thread workgroup owns 32 robots (R = 8192 -> 256 workgroups = one per CU) and walks
 // the six dependent stages with the activations in LDS.
 //
 // Arithmetic: the same two-plane split-f16 scheme as k_gemm_h2 (x = h + l in f16 after a power-of-two scale, products
@@ -17,7 +17,7 @@
 //     lane l holds the 8 k of column ct * 32 + l % 32, k half l / 32 -- so a wave streams its column tiles from L2 with
 //     fully coalesced 16 B per lane loads, straight into the B operand, through a ring of registers that runs 8-16 k
 //     steps ahead (a CU hosts a single workgroup: memory-level parallelism has to come from the wave itself).
-//   * no K split: wave w owns column tile(s) w (two for the 256-wide layer) over the whole K, so there are no partial
+//   * no K split: wave w owns column tile w over the whole K (the 256-wide layer has eight tiles = all eight waves, the 128-wide ones four), so there are no partial
 //     sums to reduce through LDS; the two narrow layers (2 and 12 outputs, padded to one column tile) run on wave 0.
 //     The first ring fill of every stage is issued one stage early, so no stage starts by waiting for L2.
 //   * every CU streams the same weights: each workgroup starts its k loop at a different step so that the 32 CUs of an
@@ -27,6 +27,10 @@
 #include "kernels_gemm.hpp"
 
 #define TL_ROWS 32
+#ifndef TL_THREADS
+#define TL_THREADS 512                   // eight wavefronts (round 5; -DTL_THREADS=256: the four of rounds 2-4): stage 4's eight column tiles one per wavefront, the
+#endif                                   // elementwise stages on twice the lanes; the same sums in the same order, bit for bit.  A/B one box: 27.5 -> 23.8 us
+
 #define TL_SX (2 * 512 + 16)             // row strides in bytes of the activation planes: b0 (K = 512)
 #define TL_SY (2 * 256 + 16)             // h0, b1 (K = 256)
 #define TL_SZ (2 * 128 + 16)             // h1, b2 (K = 128)
@@ -121,7 +125,9 @@ __device__ __forceinline__ void tl_store_act(const f32x16& acc, float descale, c
   }
 }
 
-__global__ void __launch_bounds__(256, 1) k_policy_tail(TailArgs g) {
+__global__ void __launch_bounds__(TL_THREADS, 1) k_policy_tail(TailArgs g) {
+  constexpr int TLT = TL_THREADS, NW = TLT / 64, NT4 = 8 / NW, QH = 2048 / TLT, QB = 4096 / TLT;
+  constexpr int D1 = TLT == 256 ? 16 : 8;      // k-steps of weights in flight in the 16-step stages (eight wavefronts: 256 registers each)
   extern __shared__ __attribute__((aligned(16))) unsigned char tl_lds[];
   unsigned char* X = tl_lds;                  // b0 planes
   unsigned char* Y = X + 2 * TL_PX;           // h0, later b1
@@ -141,33 +147,33 @@ __global__ void __launch_bounds__(256, 1) k_policy_tail(TailArgs g) {
   const h2_gvec* Wb2 = (const h2_gvec*)(g.b2.W) + lane;
   const h2_gvec* Wb3 = (const h2_gvec*)(g.b3.W) + lane;
   // ---- weights of the first two stages, then all of this workgroup's P1 rows, are requested before anything else
-  TlRing<16, 1, 16> q1;  TlRing<8, 1, 8> q2;
-  tl_fill(Wa1 + wave * (16 * 128), 0, krot, q1);
+  TlRing<16, 1, D1> q1;  TlRing<8, 1, 8> q2;
+  if (wave < 4) tl_fill(Wa1 + wave * (16 * 128), 0, krot, q1);
   if (wave == 0) tl_fill(Wa2, 0, 0, q2);
   // ---- all of this workgroup's P1 rows (P1 was written by the previous launch:
   // far-memory latency); h0 is consumed right away, the body pre-activations after the latent exists (stage 3)
-  float4 vh[8], vb[16];
+  float4 vh[QH], vb[QB];
 #pragma unroll
-  for (int q = 0; q < 8; q++) {
-    const int idx = tid + 256 * q, row = idx >> 6, k4 = idx & 63;
+  for (int q = 0; q < QH; q++) {
+    const int idx = tid + TLT * q, row = idx >> 6, k4 = idx & 63;
     vh[q] = *reinterpret_cast<const float4*>(g.P1 + (size_t)min(r0 + row, g.R - 1) * g.ldp + k4 * 4);
   }
 #pragma unroll
-  for (int q = 0; q < 16; q++) {
-    const int idx = tid + 256 * q, row = idx >> 7, k4 = idx & 127;
+  for (int q = 0; q < QB; q++) {
+    const int idx = tid + TLT * q, row = idx >> 7, k4 = idx & 127;
     vb[q] = *reinterpret_cast<const float4*>(g.P1 + (size_t)min(r0 + row, g.R - 1) * g.ldp + g.ada_h0 + k4 * 4);
   }
   // ---- the small vectors (biases, latent weight columns) -> LDS
   {
-    for (int i = tid; i < 128; i += 256) { bA1[i] = g.a1.bias[i]; bB2[i] = g.b2.bias[i]; }
-    for (int i = tid; i < 64; i += 256) { bA2[i] = g.a2.bias[i]; bB3[i] = g.b3.bias[i]; }
-    for (int i = tid; i < 256; i += 256) bB1[i] = g.b1.bias[i];
-    for (int i = tid; i < 512; i += 256) { wL0[i] = g.wl0[i]; wL1[i] = g.wl1[i]; }
+    for (int i = tid; i < 128; i += TLT) { bA1[i] = g.a1.bias[i]; bB2[i] = g.b2.bias[i]; }
+    for (int i = tid; i < 64; i += TLT) { bA2[i] = g.a2.bias[i]; bB3[i] = g.b3.bias[i]; }
+    for (int i = tid; i < 256; i += TLT) bB1[i] = g.b1.bias[i];
+    for (int i = tid; i < 512; i += TLT) { wL0[i] = g.wl0[i]; wL1[i] = g.wl1[i]; }
   }
   // ---- stage 0: h0 (adaptation layer-0 activations) -> Y as split planes [row][k]
 #pragma unroll
-  for (int q = 0; q < 8; q++) {
-    const int idx = tid + 256 * q, row = idx >> 6, k4 = idx & 63;
+  for (int q = 0; q < QH; q++) {
+    const int idx = tid + TLT * q, row = idx >> 6, k4 = idx & 63;
     uint16_t h0, l0, h1, l1, h2, l2, h3, l3;
     split2(vh[q].x, TL_ASCALE, h0, l0); split2(vh[q].y, TL_ASCALE, h1, l1); split2(vh[q].z, TL_ASCALE, h2, l2); split2(vh[q].w, TL_ASCALE, h3, l3);
     *reinterpret_cast<uint2*>(Y + row * TL_SY + k4 * 8) = make_uint2(h0 | ((unsigned)h1 << 16), h2 | ((unsigned)h3 << 16));
@@ -177,13 +183,13 @@ __global__ void __launch_bounds__(256, 1) k_policy_tail(TailArgs g) {
   f32x16 acc[2];
 #define TL_ZERO(n_) _Pragma("unroll") for (int t_ = 0; t_ < (n_); t_++) _Pragma("unroll") for (int i_ = 0; i_ < 16; i_++) acc[t_][i_] = 0.0f;
   // ---- stage 1: h1 = ELU(h0 Wa1 + b): 256 -> 128, wave w = column tile w
-  {
+  if (wave < 4) {
     TL_ZERO(1)
     tl_mm(Y + frow * TL_SY + fhalf * 16, TL_PY, Wa1 + wave * (16 * 128), 0, krot, q1, acc);
     tl_store_act(acc[0], g.a1.descale, bA1, wave * 32, Z, TL_SZ, TL_PZ, lane);
   }
-  TlRing<32, 2, 8> q4;                          // stage 4's first weights travel during stages 2 and 3
-  tl_fill(Wb1 + (2 * wave) * (32 * 128), 32 * 128, krot, q4);
+  TlRing<32, NT4, 8> q4;                        // stage 4's first weights travel during stages 2 and 3
+  tl_fill(Wb1 + (NT4 * wave) * (32 * 128), 32 * 128, krot, q4);
   __syncthreads();
   // ---- stage 2: latent = h1 Wa2 + b: 128 -> 2 (one column tile, wave 0)
   if (wave == 0) {
@@ -202,8 +208,8 @@ __global__ void __launch_bounds__(256, 1) k_policy_tail(TailArgs g) {
   __syncthreads();
   // ---- stage 3: b0 = ELU(pre0 + latent . w_lat) -> X
 #pragma unroll
-  for (int q = 0; q < 16; q++) {
-    const int idx = tid + 256 * q, row = idx >> 7, k4 = idx & 127;
+  for (int q = 0; q < QB; q++) {
+    const int idx = tid + TLT * q, row = idx >> 7, k4 = idx & 127;
     const float4 w0 = *reinterpret_cast<const float4*>(wL0 + k4 * 4), w1 = *reinterpret_cast<const float4*>(wL1 + k4 * 4);
     const float l0 = latS[row * 2], l1 = latS[row * 2 + 1];
     uint16_t h0, q0, h1, q1, h2, q2, h3, q3;
@@ -216,16 +222,16 @@ __global__ void __launch_bounds__(256, 1) k_policy_tail(TailArgs g) {
   }
   __syncthreads();
   // ---- stage 4: b1 = ELU(b0 Wb1 + b): 512 -> 256, wave w = column tiles 2 w, 2 w + 1
-  TL_ZERO(2)
-  tl_mm(X + frow * TL_SX + fhalf * 16, TL_PX, Wb1 + (2 * wave) * (32 * 128), 32 * 128, krot, q4, acc);
-  TlRing<16, 1, 16> q5;  TlRing<8, 1, 8> q6;
-  tl_fill(Wb2 + wave * (16 * 128), 0, krot, q5);
+  TL_ZERO(NT4)
+  tl_mm(X + frow * TL_SX + fhalf * 16, TL_PX, Wb1 + (NT4 * wave) * (32 * 128), 32 * 128, krot, q4, acc);
+  TlRing<16, 1, D1> q5;  TlRing<8, 1, 8> q6;
+  if (wave < 4) tl_fill(Wb2 + wave * (16 * 128), 0, krot, q5);
   if (wave == 0) tl_fill(Wb3, 0, 0, q6);
-  tl_store_act(acc[0], g.b1.descale, bB1, (2 * wave) * 32, Y, TL_SY, TL_PY, lane);     // h0 is dead since stage 1
-  tl_store_act(acc[1], g.b1.descale, bB1, (2 * wave + 1) * 32, Y, TL_SY, TL_PY, lane);
+#pragma unroll
+  for (int t = 0; t < NT4; t++) tl_store_act(acc[t], g.b1.descale, bB1, (NT4 * wave + t) * 32, Y, TL_SY, TL_PY, lane);     // h0 is dead since stage 1
   __syncthreads();
   // ---- stage 5: b2 = ELU(b1 Wb2 + b): 256 -> 128
-  {
+  if (wave < 4) {
     TL_ZERO(1)
     tl_mm(Y + frow * TL_SY + fhalf * 16, TL_PY, Wb2 + wave * (16 * 128), 0, krot, q5, acc);
     tl_store_act(acc[0], g.b2.descale, bB2, wave * 32, Z, TL_SZ, TL_PZ, lane);           // h1 is dead since stage 2
@@ -240,7 +246,7 @@ __global__ void __launch_bounds__(256, 1) k_policy_tail(TailArgs g) {
   }
 #undef TL_ZERO
   __syncthreads();
-  for (int idx = tid; idx < TL_ROWS * 12; idx += 256) {
+  for (int idx = tid; idx < TL_ROWS * 12; idx += TLT) {
     const int row = idx / 12, c = idx - row * 12;
     if (r0 + row >= g.R) continue;
     const float v = fmaf(nar[row * 33 + c], g.b3.descale, bB3[c]);

@@ -849,7 +849,7 @@ static int policy_tail(mqe_sim* s, hipStream_t q) {
     t.last_loco = s->st.last_loco; t.last_two_loco = s->st.last_two_loco; t.actions = s->st.actions; t.clip_actions = s->hm.clip_actions;
     t.R = R;
     t.block0 = (int)(((long long)s->d.env_id_offset * s->A) / TL_ROWS);
-    hipLaunchKernelGGL(k_policy_tail, dim3((R + TL_ROWS - 1) / TL_ROWS), dim3(256), TL_LDS_BYTES, q, t);
+    hipLaunchKernelGGL(k_policy_tail, dim3((R + TL_ROWS - 1) / TL_ROWS), dim3(TL_THREADS), TL_LDS_BYTES, q, t);
     return 0;
   }
   // adaptation tail -> latent
