@@ -415,6 +415,9 @@ int mqe_debug_stop_phase(mqe_sim* s, int tap);
  * decimation launch at entry and exit + its HW_ID and XCC_ID registers, [num wavefronts][4] (tools/dev/wave_times.py: the spread
  * of the wavefronts' run times and where the dispatcher put them) */
 int mqe_debug_wave_times(mqe_sim* s, long long* out_host);
+/* handles created with MQE_TAIL_TIMES=1 (fused policy tail): wall-clock stamps (100 MHz) of every workgroup of the last k_policy_tail launch at
+ * its entry [0], after each of its eight barriers [1 .. 8] and at its end [9], [row blocks of 32 robots][16] (tools/dev/tail_times.py) */
+int mqe_debug_tail_times(mqe_sim* s, long long* out_host);
 /* handles created with MQE_PHASE_TIMES=1 (two robots without objects, two robots + a flock, three robots + ball): the fused decimation launch runs with its phase taps
  * live; [num_envs][4 substeps][16] wall-clock stamps (100 MHz) of the last launch: taps 0..14 of the substep (kernels_physics.hpp
  * TSTAMP), [15] = its end (tools/dev/phase_walltimes.py: where the time of a full launch goes, phase by phase) */

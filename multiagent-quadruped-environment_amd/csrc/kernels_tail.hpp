@@ -58,7 +58,9 @@ struct TailArgs {
   float *last_loco, *last_two_loco, *actions; float clip_actions;   // post-policy registers [R][12]
   int R;
   int block0;                                 // index of this batch's first row block among the GLOBAL rows (env_id_offset * A / TL_ROWS)
+  long long* times;                           // debug (MQE_TAIL_TIMES=1, tools/dev/tail_times.py): [blocks][16] wall clock at the stage boundaries, else null
 };
+#define TL_STAMP(i) do { if (g.times != nullptr && tid == 0) g.times[(size_t)blockIdx.x * 16 + (i)] = (long long)wall_clock64(); } while (0)
 
 // ELU with exp(v) - 1 on the hardware exponential: absolute error <= 1.2e-7 (the branchy expm1f polynomial costs more than
 // the matrix work around it)
@@ -137,6 +139,7 @@ __global__ void __launch_bounds__(TL_THREADS, 1) k_policy_tail(TailArgs g) {
   float* wL0 = bB3 + 64;   float* wL1 = wL0 + 512;  float* nar = wL1 + 512;   // nar: [32][33] raw output of a narrow stage
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r0 = blockIdx.x * TL_ROWS;
+  TL_STAMP(0);
   // k order rotated per row block to spread the L2 requests for the weights; keyed by the GLOBAL row block, so that an env's
   // summation order (hence its bits) does not depend on which shard of the batch it is computed in
   const int krot = ((blockIdx.x + g.block0) * 7) & 31;
@@ -180,6 +183,7 @@ __global__ void __launch_bounds__(TL_THREADS, 1) k_policy_tail(TailArgs g) {
     *reinterpret_cast<uint2*>(Y + TL_PY + row * TL_SY + k4 * 8) = make_uint2(l0 | ((unsigned)l1 << 16), l2 | ((unsigned)l3 << 16));
   }
   __syncthreads();
+  TL_STAMP(1);
   f32x16 acc[2];
 #define TL_ZERO(n_) _Pragma("unroll") for (int t_ = 0; t_ < (n_); t_++) _Pragma("unroll") for (int i_ = 0; i_ < 16; i_++) acc[t_][i_] = 0.0f;
   // ---- stage 1: h1 = ELU(h0 Wa1 + b): 256 -> 128, wave w = column tile w
@@ -188,9 +192,13 @@ __global__ void __launch_bounds__(TL_THREADS, 1) k_policy_tail(TailArgs g) {
     tl_mm(Y + frow * TL_SY + fhalf * 16, TL_PY, Wa1 + wave * (16 * 128), 0, krot, q1, acc);
     tl_store_act(acc[0], g.a1.descale, bA1, wave * 32, Z, TL_SZ, TL_PZ, lane);
   }
-  TlRing<32, NT4, 8> q4;                        // stage 4's first weights travel during stages 2 and 3
+#ifndef TL_D4
+#define TL_D4 8
+#endif
+  TlRing<32, NT4, TL_D4> q4;                    // stage 4's first weights travel during stages 2 and 3
   tl_fill(Wb1 + (NT4 * wave) * (32 * 128), 32 * 128, krot, q4);
   __syncthreads();
+  TL_STAMP(2);
   // ---- stage 2: latent = h1 Wa2 + b: 128 -> 2 (one column tile, wave 0)
   if (wave == 0) {
     TL_ZERO(1)
@@ -199,6 +207,7 @@ __global__ void __launch_bounds__(TL_THREADS, 1) k_policy_tail(TailArgs g) {
     for (int r = 0; r < 16; r++) nar[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 33 + (lane & 31)] = acc[0][r];
   }
   __syncthreads();
+  TL_STAMP(3);
   if (tid < TL_ROWS * 2) {
     const int row = tid >> 1, c = tid & 1;
     const float v = fmaf(nar[row * 33 + c], g.a2.descale, bA2[c]);
@@ -206,6 +215,7 @@ __global__ void __launch_bounds__(TL_THREADS, 1) k_policy_tail(TailArgs g) {
     if (r0 + row < g.R) g.lat[(size_t)(r0 + row) * g.ldl + c] = v;
   }
   __syncthreads();
+  TL_STAMP(4);
   // ---- stage 3: b0 = ELU(pre0 + latent . w_lat) -> X
 #pragma unroll
   for (int q = 0; q < QB; q++) {
@@ -221,6 +231,7 @@ __global__ void __launch_bounds__(TL_THREADS, 1) k_policy_tail(TailArgs g) {
     *reinterpret_cast<uint2*>(X + TL_PX + row * TL_SX + k4 * 8) = make_uint2(q0 | ((unsigned)q1 << 16), q2 | ((unsigned)q3 << 16));
   }
   __syncthreads();
+  TL_STAMP(5);
   // ---- stage 4: b1 = ELU(b0 Wb1 + b): 512 -> 256, wave w = column tiles 2 w, 2 w + 1
   TL_ZERO(NT4)
   tl_mm(X + frow * TL_SX + fhalf * 16, TL_PX, Wb1 + (NT4 * wave) * (32 * 128), 32 * 128, krot, q4, acc);
@@ -230,6 +241,7 @@ __global__ void __launch_bounds__(TL_THREADS, 1) k_policy_tail(TailArgs g) {
 #pragma unroll
   for (int t = 0; t < NT4; t++) tl_store_act(acc[t], g.b1.descale, bB1, (NT4 * wave + t) * 32, Y, TL_SY, TL_PY, lane);     // h0 is dead since stage 1
   __syncthreads();
+  TL_STAMP(6);
   // ---- stage 5: b2 = ELU(b1 Wb2 + b): 256 -> 128
   if (wave < 4) {
     TL_ZERO(1)
@@ -237,6 +249,7 @@ __global__ void __launch_bounds__(TL_THREADS, 1) k_policy_tail(TailArgs g) {
     tl_store_act(acc[0], g.b2.descale, bB2, wave * 32, Z, TL_SZ, TL_PZ, lane);           // h1 is dead since stage 2
   }
   __syncthreads();
+  TL_STAMP(7);
   // ---- stage 6: joint targets = b2 Wb3 + b: 128 -> 12 (wave 0); post-policy registers (go1.py:106-107, :40-41)
   if (wave == 0) {
     TL_ZERO(1)
@@ -246,6 +259,7 @@ __global__ void __launch_bounds__(TL_THREADS, 1) k_policy_tail(TailArgs g) {
   }
 #undef TL_ZERO
   __syncthreads();
+  TL_STAMP(8);
   for (int idx = tid; idx < TL_ROWS * 12; idx += TLT) {
     const int row = idx / 12, c = idx - row * 12;
     if (r0 + row >= g.R) continue;
@@ -256,4 +270,5 @@ __global__ void __launch_bounds__(TL_THREADS, 1) k_policy_tail(TailArgs g) {
     g.last_loco[i * 12 + c] = v;
     g.actions[i * 12 + c] = clampf(v, -g.clip_actions, g.clip_actions);
   }
+  TL_STAMP(9);
 }

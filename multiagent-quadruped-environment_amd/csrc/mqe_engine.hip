@@ -70,6 +70,7 @@ struct mqe_sim {
   bool cmd_general = false;           // command layout other than (x, y, yaw) -> entries 3-5 (desc.command_src): unfused entry points, exact-f32 layer 0
   bool phase_timed = false;           // MQE_PHASE_TIMES=1 at creation: k_substeps runs with its phase taps live (mqe_debug_phase_times)
   bool tail_fused = false;            // k_policy_tail: the reference network shapes (256-128-2 / 512-256-128-12 after layer 0)
+  long long* tail_times = nullptr;    // MQE_TAIL_TIMES=1: [row blocks][16] stage stamps of the last k_policy_tail launch (mqe_debug_tail_times)
   size_t phys_lds_bytes = 0;
   bool fuse_substeps = true;
   bool fuse_post = true;              // the post-physics step as the epilogue of k_substeps (mqe_step & co; MQE_NO_FUSE_POST=1: its own launch)
@@ -597,6 +598,7 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
     for (auto& g : s->ada_rest) if (finalize_frag(s, &g)) return fail(-5, "upload");
     for (auto& g : s->body_rest) if (finalize_frag(s, &g)) return fail(-5, "upload");
   }
+  if (s->tail_fused && getenv("MQE_TAIL_TIMES")) { if (dalloc(s, &s->tail_times, (size_t)16 * ((R + TL_ROWS - 1) / TL_ROWS))) return fail(-5, "alloc"); }
   int maxw = 64;
   for (auto& g : s->ada_rest) maxw = std::max(maxw, g.Npad);
   for (auto& g : s->body_rest) maxw = std::max(maxw, g.Npad);
@@ -849,6 +851,7 @@ static int policy_tail(mqe_sim* s, hipStream_t q) {
     t.last_loco = s->st.last_loco; t.last_two_loco = s->st.last_two_loco; t.actions = s->st.actions; t.clip_actions = s->hm.clip_actions;
     t.R = R;
     t.block0 = (int)(((long long)s->d.env_id_offset * s->A) / TL_ROWS);
+    t.times = s->tail_times;
     hipLaunchKernelGGL(k_policy_tail, dim3((R + TL_ROWS - 1) / TL_ROWS), dim3(TL_THREADS), TL_LDS_BYTES, q, t);
     return 0;
   }
@@ -976,6 +979,13 @@ extern "C" int mqe_debug_phase_times(mqe_sim* s, long long* out_host) {
   if (!s->st.wave_times || !s->phase_timed) return fail(-4, "create the handle with MQE_PHASE_TIMES=1 (go1gate-, go1sheep- or go1football-defender-shaped scene)");
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(out_host, s->st.wave_times + (size_t)4 * s->N, (size_t)64 * s->N * sizeof(long long), hipMemcpyDeviceToHost));
+  return 0;
+}
+extern "C" int mqe_debug_tail_times(mqe_sim* s, long long* out_host) {
+  if (!s) return fail(-1, "null engine handle");
+  if (!s->tail_times) return fail(-4, "create the handle with MQE_TAIL_TIMES=1 (fused policy tail)");
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(out_host, s->tail_times, (size_t)16 * ((s->R + TL_ROWS - 1) / TL_ROWS) * sizeof(long long), hipMemcpyDeviceToHost));
   return 0;
 }
 extern "C" int mqe_debug_wave_times(mqe_sim* s, long long* out_host) {
