@@ -2235,9 +2235,10 @@ static void link_frames(const mqo_sim* s, int env, int r, real R[NB][9], real p[
   }
 }
 int mqo_render_depth(mqo_sim* s, float* out, int H, int W, float hfov_deg, const float* cam_pos3, const float* cam_rpy3, float far_m) {
+  if (!s) { snprintf(g_err, sizeof g_err, "mqo_render_depth: null handle"); return -1; }
   const mqe_sim_desc* d = &s->d;
   const mqe_robot_model* m = &d->robot;
-  if (!s || !out || H <= 0 || W <= 0 || H * W > (1 << 16) || !(hfov_deg > 1.0f && hfov_deg < 179.0f) || !(far_m > 0.0f)) { snprintf(g_err, sizeof g_err, "mqo_render_depth: bad argument"); return -6; }
+  if (!out || H <= 0 || W <= 0 || H * W > (1 << 16) || !(hfov_deg > 1.0f && hfov_deg < 179.0f) || !(far_m > 0.0f)) { snprintf(g_err, sizeof g_err, "mqo_render_depth: bad argument"); return -6; }
   const int A = s->A, P = s->P, N = s->N, npix = H * W;
   const real tan_h = (real)tan(0.5 * (double)hfov_deg * 3.14159265358979 / 180.0), tan_v = tan_h * (real)H / (real)W;
   const real hs = d->horizontal_scale;
