@@ -521,18 +521,6 @@ __device__ __forceinline__ void sheep_apply(float* root, int A, int p, const flo
   sp[2] = clampf(sp[2], 0.0f, 0.3f);
   sp[3] = 0.0f; sp[4] = 0.0f;
 }
-// the same update with the sheep's row READ from `src` (the fused epilogue's LDS copy of the root rows: the values k_substeps has just written back) and
-// written to the state tensor: no load from global memory, the same arithmetic
-__device__ __forceinline__ void sheep_apply_from(const float* src, float* root, int A, int p, const float* dv) {
-  const float* sq = src + (A + p) * 13;
-  float* sp = root + (A + p) * 13;
-  float v[3];
-  for (int k = 0; k < 3; k++) v[k] = sq[7 + k] + dv[k];
-  for (int k = 0; k < 2; k++) v[k] = clampf(v[k], -2.0f, 2.0f);
-  for (int k = 0; k < 3; k++) sp[7 + k] = v[k];
-  sp[2] = clampf(sq[2], 0.0f, 0.3f);
-  sp[3] = 0.0f; sp[4] = 0.0f;
-}
 // wrapper observation + reward for env e.  npc = the `root_states_npc` rows the wrapper sees ([P][13]); see oracle.
 // side_effects: 1 on the wrapper-level paths (mqe_step, mqe_wrapper_eval); the Go1-level mqe_post_physics_step passes 0 so that the
 // state stays exactly what Go1.step leaves (go1tug re-poses its slider from the wrapper)
@@ -958,32 +946,26 @@ __device__ __forceinline__ void post_body(const DevModel* m, const DevState& st,
     const int e0 = blk * PEPW, nenv = min(PEPW, m->N - e0), per = P * 13;
     for (int t = tid; t < nenv * per; t += 64) {
       const int sl = t / per, r = t - sl * per;
-      s_npc[sl * npc_stride + r] = root_l != nullptr ? root_l[sl * lds_env_stride + A * 13 + r] : st.root[((size_t)(e0 + sl) * (A + P) + A) * 13 + r];
+      s_npc[sl * npc_stride + r] = st.root[((size_t)(e0 + sl) * (A + P) + A) * 13 + r];
     }
     __syncthreads();
   }
   if (m->npc_kind == MQE_NPC_SHEEP) {           // wave-uniform.  The 64 / PEPW lanes of an env share its sheep (lane a: sheep a, a + 8, ..)
     constexpr int LPE = 64 / PEPW, NPASS = (MQE_MAX_NPCS + LPE - 1) / LPE;
     float dvs[NPASS][3];
-    // (fused epilogue: the root rows are still in the physics' LDS, bit for bit what was written back -- the script reads them there instead of
-    // through three dependent global round trips)
-    const float* rsrc = root_l != nullptr ? root_l + le * lds_env_stride : root;
     if (e < m->N) {
       float avg[3];
-      sheep_flock_mean(m, rsrc, avg);           // every lane of the env, the same loop -> the same bits
-      if (lead) sheep_flock_stats(m, st, e, rsrc, avg);
+      sheep_flock_mean(m, root, avg);           // every lane of the env, the same loop -> the same bits
+      if (lead) sheep_flock_stats(m, st, e, root, avg);
 #pragma unroll
       for (int q = 0; q < NPASS; q++)
-        if (a + q * LPE < P) sheep_increment(m, st, e, a + q * LPE, rsrc, avg, step_no, dvs[q]);
+        if (a + q * LPE < P) sheep_increment(m, st, e, a + q * LPE, root, avg, step_no, dvs[q]);
     }
     __syncthreads();                            // every increment is formed from the pre-update flock
     if (e < m->N) {
 #pragma unroll
       for (int q = 0; q < NPASS; q++)
-        if (a + q * LPE < P) {
-          if (root_l != nullptr) sheep_apply_from(rsrc, root, A, a + q * LPE, dvs[q]);
-          else sheep_apply(root, A, a + q * LPE, dvs[q]);
-        }
+        if (a + q * LPE < P) sheep_apply(root, A, a + q * LPE, dvs[q]);
     }
     // (a WORKGROUP-scope fence: writer and readers are lanes of this one wavefront, i.e. one CU and one vector L1.  The device-scope
     // __threadfence() that stood here writes the XCD's L2 back and invalidates it on gfx950 -- its L2s are not coherent with each other --
