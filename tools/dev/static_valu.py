@@ -13,7 +13,7 @@ CSRC = os.path.join(ROOT, "multiagent-quadruped-environment_amd", "csrc")
 LLVM = "/opt/rocm/lib/llvm/bin"
 T = "/tmp/static_valu"
 os.makedirs(T, exist_ok=True)
-sym_sub = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("--") else "k_substepsILi2ELi0ELi1ELb0EE"
+sym_sub = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("--") else "k_substepsILi2ELi0ELi1ELb0ELb0EE"
 lines_rng = None
 if "--lines" in sys.argv:
     i = sys.argv.index("--lines"); lines_rng = (int(sys.argv[i + 1]), int(sys.argv[i + 2]))
