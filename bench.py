@@ -427,7 +427,9 @@ def main():
             l0 = {"kernel": "k_gemm_h2 (fused layer 0 of adaptation+body MLP over the history ring; 2-plane split-f16 operands, 3 MFMA terms per product, f32-class accuracy)",
                   "bound": "mfma", "achieved": round(3 * 2.0 * R * K_SPLIT * (h_a + h_b) / (l0_ms * 1e-3) / 1e12, 2), "peak": PEAK_F16_MFMA_TFLOPS,
                   "unit": "TFLOP/s", "f32_equivalent_TFLOPs": round(flops32 / (l0_ms * 1e-3) / 1e12, 2), "executed_K": K_SPLIT,
-                  "flops_basis": "executed f16 MFMA flops: 3 terms x 2 R (256 + 512) x K, K = 30 frames x 48 compact columns (12 constant and 12 repeated columns of the 70 are folded into the weights)"}
+                  "flops_basis": "executed f16 MFMA flops: 3 terms x 2 R (256 + 512) x K, K = 30 frames x 48 compact columns (12 constant and 12 repeated columns of the 70 are folded into the weights)",
+                  "note": "the peak assumes 2.4 GHz; measured with in-kernel clocks (profiles/r05_gemm_h2_bound.txt, not in this run): the shader clock is ~1.56 GHz during this kernel's K loop "
+                          "(2.3 GHz when the same loop multiplies zeros: same tick count) -- the matrix pipe is busy 73 % of the loop's shader-clock ticks, 62 % of the kernel's"}
         else:
             l0 = {"kernel": "k_gemm_f32 (fused layer 0, exact f32 MFMA)", "bound": "mfma", "achieved": round(flops32 / (l0_ms * 1e-3) / 1e12, 3),
                   "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s"}

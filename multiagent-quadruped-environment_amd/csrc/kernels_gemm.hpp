@@ -160,7 +160,11 @@ struct Gemm2Args {
   const unsigned* irr; const float* ring; int ring_pos;
   const float* Wt32; int ldwt;                         // [frame * MQE_FRAME + column][ldwt] (GemmLayer::Wt)
   int full_blocks, full_rows;                          // blocks that run full 128-row tiles and the rows they cover; the rest: half tiles
+  long long* times; int times_blocks;                  // debug (MQE_TAIL_TIMES=1, tools/dev/tail_times.py): slots 10..15 of the tail's [blocks][16] stamp table
+                                                       // = wall clock (100 MHz) at entry / end of the K loop / exit, then the shader clock at the same points
 };
+#define H2_STAMP(i) do { if (g.times != nullptr && threadIdx.x == 0 && (int)blockIdx.x < g.times_blocks) {                          \
+    g.times[(size_t)blockIdx.x * 16 + 10 + (i)] = (long long)wall_clock64(); g.times[(size_t)blockIdx.x * 16 + 13 + (i)] = (long long)clock64(); } } while (0)
 // One block tile: TA = 2 the full 128 x 192 tile, TA = 1 the HALF tile of 64 x 192 (multiplier waves 2 x 2 on 32 x 96 wave tiles, two
 // staging blocks of A; same LDS layout, same W tile, same epilogue) for the rows that do not fill a round of full tiles -- a round is
 // 256 / (N / 192) M-tiles = 8192 rows of layer 0, and a started round costs the same whether one tile or 256 of them run in it.
@@ -170,6 +174,7 @@ __device__ __forceinline__ void gemm_h2_tile(const Gemm2Args& g, const int m0, c
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = (wave >> 1) & 1, wn = wave & 1;               // multiplier waves 0..3 as 2 x 2
   f32x16 acc00, acc01, acc02, acc10, acc11, acc12;
+  H2_STAMP(0);
 #pragma unroll
   for (int i = 0; i < 16; i++) { acc00[i] = 0.0f; acc01[i] = 0.0f; acc02[i] = 0.0f; acc10[i] = 0.0f; acc11[i] = 0.0f; acc12[i] = 0.0f; }
   // staging (waves 4..7, 256 threads): 8 consecutive threads move the 128 B a row contributes to a k-tile (chunk c = unit
@@ -208,19 +213,55 @@ __device__ __forceinline__ void gemm_h2_tile(const Gemm2Args& g, const int m0, c
     if (g.a_ring8) { u_ += g.a_rot8; if (u_ >= g.a_ring8) u_ -= g.a_ring8; if (u_ >= g.a_ring8) u_ -= g.a_ring8; } \
     aoff = (unsigned)(u_ * 2 + sp) * 16u;                                                                       \
   }
+  // (tools/dev/gemm_bench.hip may predefine H2_LDA / H2_LDW / H2_ST / H2_MFMA to take one of the loop's streams out: what bounds the loop)
+#ifndef H2_LDA
 #define H2_LDA(dst, i_) dst = *(const h2_gvec*)(Abase + a_row##i_ + aoff);
+#endif
+#ifndef H2_LDW
 #define H2_LDW(dst, i_) dst = *(const h2_gvec*)(Wbase + (size_t)(i_) * w_row32 + woff);
+#endif
+#ifndef H2_ST
 #define H2_ST(buf_, src_, r_) *reinterpret_cast<h2_u32x4*>((buf_) + st_ofs + (r_) * H2_ROWB) = src_;
+#endif
 #define H2_RDA(buf_, p_, t_, ks_) *reinterpret_cast<const h2_u32x4*>((buf_) + fa_ofs + (p_) * H2_PLANE + (t_) * 32 * H2_ROWB + (ks_) * 32)
 #define H2_RDB(buf_, p_, u_, ks_) *reinterpret_cast<const h2_u32x4*>((buf_) + fb_ofs + (p_) * H2_PLANE + (u_) * 32 * H2_ROWB + (ks_) * 32)
 #define H2_F16(x_) __builtin_bit_cast(f16x8, x_)
+#ifndef H2_MFMA
 #define H2_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x16_f16(H2_F16(a_), H2_F16(b_), c_, 0, 0, 0)
+#endif
 #define H2_PIN() __builtin_amdgcn_sched_barrier(0)
+  // dev instrumentation of the loop (tools/dev/gemm_bench.hip -DH2_STAGER_TIMES / -DH2_MULT_TIMES): shader-clock sums between the hooks the
+  // generator leaves in the loop, written to slots 0..5 of the stamp table; empty in the product
+#if defined(H2_STAGER_TIMES) || defined(H2_MULT_TIMES)
+  long long ts_prev = clock64(), ts_sum0 = 0, ts_sum1 = 0, ts_sum2 = 0, ts_sum3 = 0, tm_sum0 = 0, tm_sum1 = 0;
+#endif
+#ifdef H2_STAGER_TIMES
+#define H2_TS(n) { const long long c_ = clock64(); ts_sum##n += c_ - ts_prev; ts_prev = c_; }
+#define H2_TS_WAITV() asm volatile("s_waitcnt vmcnt(20)" ::: "memory")
+#else
+#define H2_TS(n)
+#define H2_TS_WAITV()
+#endif
+#ifdef H2_MULT_TIMES
+#define H2_TM(n) { const long long c_ = clock64(); tm_sum##n += c_ - ts_prev; ts_prev = c_; }
+#else
+#define H2_TM(n)
+#endif
   if constexpr (TA == 2) {
 #include "kernels_gemm_h2_loop.inc"
   } else {
 #include "kernels_gemm_h2_loop_half.inc"
   }
+#if defined(H2_STAGER_TIMES) || defined(H2_MULT_TIMES)
+  if (g.times != nullptr && lane == 0 && (int)blockIdx.x < g.times_blocks) {
+    long long* o = g.times + (size_t)blockIdx.x * 16;
+    if (wave == 4) { o[0] = ts_sum0; o[1] = ts_sum1; o[2] = ts_sum2; o[3] = ts_sum3; }
+    if (wave == 0) { o[4] = tm_sum0; o[5] = tm_sum1; }
+  }
+#endif
+#undef H2_TS
+#undef H2_TS_WAITV
+#undef H2_TM
 #undef H2_ADDR
 #undef H2_LDA
 #undef H2_LDW
@@ -232,6 +273,7 @@ __device__ __forceinline__ void gemm_h2_tile(const Gemm2Args& g, const int m0, c
 #undef H2_PIN
   // epilogue: the accumulators hold 4-row column slivers, so they go through the (now idle) LDS once and leave as 16 B per
   // lane = whole row segments, stored by all 8 waves (dword stores of 128 B half-rows measured 13 us for the 25 MB)
+  H2_STAMP(1);
   __syncthreads();
   float* ep = reinterpret_cast<float*>(lds2);
 #define H2_EPW(acc_, t_, u_)                                                                                    \
@@ -277,6 +319,7 @@ __device__ __forceinline__ void gemm_h2_tile(const Gemm2Args& g, const int m0, c
     }
     if (grow < g.M) *reinterpret_cast<float4*>(g.C + (size_t)grow * g.ldc + col) = v;
   }
+  H2_STAMP(2);
 }
 // k_gemm_h2: full tiles only (what the headline batch runs: 8192 rows = exactly one round).  k_gemm_h2_mix: blocks [0, full_blocks) run
 // full tiles over the rows [0, full_rows), the others half tiles over the rows behind them (launch_gemm2 picks the split: whole rounds

@@ -795,8 +795,9 @@ static void launch_gemm(hipStream_t q, const float* A, int lda, int rot4, int ri
 }
 
 static void launch_gemm2(hipStream_t q, const uint16_t* A, int lda, int rot8, int ring8, const GemmLayer& L,
-                         float* C, int ldc, int M, int act_cols, const unsigned* irr = nullptr, const float* ring = nullptr, int ring_pos = 0, bool use_half = true) {
+                         float* C, int ldc, int M, int act_cols, const unsigned* irr = nullptr, const float* ring = nullptr, int ring_pos = 0, bool use_half = true, long long* times = nullptr, int times_blocks = 0) {
   Gemm2Args g;
+  g.times = times; g.times_blocks = times_blocks;
   g.irr = irr; g.ring = ring; g.ring_pos = ring_pos; g.Wt32 = L.Wt; g.ldwt = L.Npad;
   g.A = A; g.lda = lda; g.a_rot8 = rot8; g.a_ring8 = ring8;
   g.W = L.W2; g.ldw = 2 * L.Kpad3; g.bias = L.bias;
@@ -831,7 +832,7 @@ static void policy_head(mqe_sim* s, const float* command, hipStream_t q, const f
     // fused layer 0 of both networks over the ring: ELU on the adaptation columns only
     if (s->gemm_split)
       launch_gemm2(q, s->st.hist2, 2 * MQE_HIST * MQE_H2_FRAME, s->hist_pos * (MQE_H2_FRAME / 8), MQE_HIST * MQE_H2_FRAME / 8, s->l0,
-                   s->P1, s->ldP1, R, s->ada_h0, s->st.hist_irr, s->st.hist, s->hist_pos, s->gemm_half);
+                   s->P1, s->ldP1, R, s->ada_h0, s->st.hist_irr, s->st.hist, s->hist_pos, s->gemm_half, s->tail_times, (R + TL_ROWS - 1) / TL_ROWS);
     else
       launch_gemm(q, s->st.hist, MQE_HIST * MQE_FRAME, s->hist_pos * (MQE_FRAME / 4), MQE_HIST * MQE_FRAME / 4, s->l0, s->P1, s->ldP1, R, s->ada_h0);
   }
