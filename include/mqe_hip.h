@@ -416,7 +416,9 @@ int mqe_debug_stop_phase(mqe_sim* s, int tap);
  * of the wavefronts' run times and where the dispatcher put them) */
 int mqe_debug_wave_times(mqe_sim* s, long long* out_host);
 /* handles created with MQE_TAIL_TIMES=1 (fused policy tail): wall-clock stamps (100 MHz) of every workgroup of the last k_policy_tail launch at
- * its entry [0], after each of its eight barriers [1 .. 8] and at its end [9], [row blocks of 32 robots][16] (tools/dev/tail_times.py) */
+ * its entry [0], after each of its eight barriers [1 .. 8] and at its end [9], [row blocks of 32 robots][16] (tools/dev/tail_times.py); slots
+ * [10 .. 15] of the same rows carry the split-f16 layer-0 kernel's (k_gemm_h2) stamps of the same step, workgroup by workgroup: the wall clock at
+ * entry / end of the K loop / exit, then the shader clock (s_memtime) at the same three points */
 int mqe_debug_tail_times(mqe_sim* s, long long* out_host);
 /* handles created with MQE_PHASE_TIMES=1 (two robots without objects, two robots + a flock, three robots + ball): the fused decimation launch runs with its phase taps
  * live; [num_envs][4 substeps][16] wall-clock stamps (100 MHz) of the last launch: taps 0..14 of the substep (kernels_physics.hpp

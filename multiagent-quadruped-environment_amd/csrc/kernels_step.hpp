@@ -883,6 +883,7 @@ __device__ __forceinline__ void post_body(const DevModel* m, const DevState& st,
   }
   // ---- body-frame quantities, gait clock, termination (registers only) ------------------------------------------------------
   float bq[4], lv[3], av[3], pgr[3], clk[4], gi1 = 0.f;
+  float rpy[3] = {0.f, 0.f, 0.f};               // Euler angles of bq: the termination test's and the observation's (one evaluation: ~170 instructions a second one costs)
   unsigned fl = 0;                              // bit 0 base contact, 1 roll, 2 pitch, 3 z high, 4 z low
   if (mine) {
     const float q[4] = {rs[3], rs[4], rs[5], rs[6]}, v[3] = {rs[7], rs[8], rs[9]}, w[3] = {rs[10], rs[11], rs[12]};
@@ -905,7 +906,6 @@ __device__ __forceinline__ void post_body(const DevModel* m, const DevState& st,
       clk[k] = sinf(6.2831855f * fi[k]);
     }
     if (m->terminate_on_base_contact && sqrtf(f3[0] * f3[0] + f3[1] * f3[1] + f3[2] * f3[2]) > 1.0f) fl |= 1u;
-    float rpy[3];
     euler_xyz_f(q, rpy);
     float r = rpy[0], p = rpy[1];
     if (r > 3.1415927f) r -= 6.2831855f;
@@ -991,14 +991,13 @@ __device__ __forceinline__ void post_body(const DevModel* m, const DevState& st,
       if (P == 0) {
 #pragma unroll
         for (int k = 0; k < 4; k++) { bq[k] = rs[3 + k]; st.bquat[i * 4 + k] = bq[k]; }
+        euler_xyz_f(bq, rpy);
       }
     }
   }
   // ---- compute_observations (legged_robot_field.py:117-146) from registers; obs.last_last_action aliases the current action
   if (mine) {
     float* ob = bag + a * MQE_OBS_BAG;
-    float rpy[3];
-    euler_xyz_f(bq, rpy);
 #pragma unroll
     for (int k = 0; k < 3; k++) { ob[k] = rs[k] - eo[k]; ob[3 + k] = rpy[k]; }
 #pragma unroll

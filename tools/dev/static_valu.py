@@ -49,7 +49,8 @@ def phase(ln):
     return "15 store/integrate"
 
 
-byphase, byline, other = collections.Counter(), collections.Counter(), collections.Counter()
+byphase, byline, other, bypost = collections.Counter(), collections.Counter(), collections.Counter(), collections.Counter()
+src_step = open(os.path.join(CSRC, "kernels_step.hpp")).read().split("\n")
 nv = 0
 for op, b in zip(ops, blocks):
     if not op.startswith("v_"):
@@ -62,6 +63,9 @@ for op, b in zip(ops, blocks):
         if fn.startswith("phys_substep") and "kernels_physics.hpp" in loc:
             ln = int(loc.split(":")[-2])
     if ln is None:
+        for fn, loc in frames:                  # --post: the epilogue's instructions by the line of post_body that (transitively) issued them
+            if fn.startswith("post_body") and "kernels_step.hpp" in loc:
+                bypost[int(loc.split(":")[-2])] += 1
         other["post_body (epilogue)" if any("post_body" in f[0] for f in frames) else "k_substeps (actuator net, loads, logs)"] += 1
     else:
         byphase[phase(ln)] += 1; byline[ln] += 1
@@ -75,3 +79,9 @@ if lines_rng:
     for ln in sorted(byline):
         if lines_rng[0] <= ln < lines_rng[1] and byline[ln] >= 4:
             print(f"    {ln:5d} {byline[ln]:4d}  {src[ln - 1].strip()[:120]}")
+if "--post" in sys.argv:
+    acc = 0
+    for ln in sorted(bypost):
+        acc += bypost[ln]
+        if bypost[ln] >= 6:
+            print(f"    {ln:5d} {bypost[ln]:4d}  {src_step[ln - 1].strip()[:140]}")
