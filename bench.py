@@ -413,7 +413,8 @@ def main():
         split = os.environ.get("MQE_GEMM_SPLIT", "1") != "0"
         d = eng.desc
         h_a, h_b = d.adaptation.dims[1], d.body.dims[1]
-        sampled = max(1, -(-args.steps // max(prof_every, 1)))         # env steps whose launches were bracketed
+        pe = max(prof_every, 1)                                        # env steps whose launches were bracketed: the third of every `prof_every` (mqe_engine.hip prof_phase)
+        sampled = max(1, sum(1 for i in range(args.steps) if i % pe == (2 if pe > 2 else 0)))
 
         def avg_ms(i):
             return kms[i] / max(cnt[i], 1)

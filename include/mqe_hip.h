@@ -434,7 +434,8 @@ long long mqe_state_size(mqe_sim* s);
 int mqe_state_save(mqe_sim* s, void* host_blob, void* stream);
 int mqe_state_load(mqe_sim* s, const void* host_blob, void* stream);
 
-/* bookkeeping for benchmarks: time of the dominant kernel measured with HIP events on `stream` */
+/* bookkeeping for benchmarks: time of every kernel class measured with HIP events on `stream`; `on` = N > 0 brackets the launches of one step in every N
+ * (the third step of each period: the first one after a synchronisation starts on an idle GPU), 0 switches it off */
 int mqe_profile_enable(mqe_sim* s, int on);
 int mqe_profile_read(mqe_sim* s, float* ms_per_kernel, int n, int* n_launches);
 
