@@ -72,6 +72,24 @@ def binary_info():
     return info
 
 
+def usable_cpus():
+    """CPUs this process may use: the scheduler affinity, capped by the cgroup's CPU quota (cgroup v2 cpu.max / v1 cfs_quota_us)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(task, sample_envs, sample_steps, threads=None):
     """Time the CPU oracle (OpenMP over envs/robots) on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -81,10 +99,11 @@ def cpu_baseline(task, sample_envs, sample_steps, threads=None):
     from mqe.engine import abi
     d, keep, _ = make_desc(task, sample_envs)
     e = OracleEngine(d, keep)
-    # the oracle's OpenMP loops (over envs / robots) peak around 32 threads on the box's 256 hardware threads and
-    # collapse when oversubscribed, so the baseline is timed at its best setting, which is reported as `cores`
+    # the oracle's OpenMP loops (over envs / robots) scale linearly up to the CPUs the container may actually use -- the GPU box shows 256
+    # hardware threads but its cgroup grants 16 (cpu.max 1600000 100000: 11.6 k / 24.0 k / 34.4 k / 46.3 k env-steps/s on 4 / 8 / 12 / 16
+    # threads, 37 k on 32, 2.6 k on 256) -- so the baseline runs on exactly that many threads, reported as `cores`
     if threads is None:
-        threads = int(os.environ.get("MQE_CPU_THREADS", min(32, os.cpu_count() or 1)))
+        threads = int(os.environ.get("MQE_CPU_THREADS", usable_cpus()))
     e.lib.mqo_set_num_threads(int(threads))
     e.reset_all()
     g = torch.Generator().manual_seed(1234)
@@ -218,8 +237,8 @@ def main():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_strict_f32", action="store_true", help="skip the exact-f32 companion run")
     ap.add_argument("--no_configs", action="store_true", help="skip the other single-GPU BASELINE configs (`configs` on the line)")
-    ap.add_argument("--cpu_sample_envs", type=int, default=0, help="CPU baseline batch (0 = the GPU run's num_envs, 8 steps)")
-    ap.add_argument("--cpu_sample_steps", type=int, default=8)
+    ap.add_argument("--cpu_sample_envs", type=int, default=0, help="CPU baseline batch (0 = the GPU run's num_envs, 32 steps)")
+    ap.add_argument("--cpu_sample_steps", type=int, default=32)
     ap.add_argument("--gather", choices=["between", "after", "tail"], default=os.environ.get("MQE_BENCH_GATHER", "tail"),
                     help="N > 1: where the all-gather of a step's returned batch is issued (default: tail).  between: inside the NEXT step, after its policy "
                          "kernels and before its physics kernel (overlaps k_substeps; DESIGN.md 8).  after: right behind the step's own k_post_physics, "
@@ -549,9 +568,9 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             torch.set_num_threads(os.cpu_count() or 1)
             # the CPU restatement at the headline size (few steps) and at the reference's own CPU-runnable size (N = 4)
-            big_n, big_steps = (args.cpu_sample_envs, args.cpu_sample_steps) if args.cpu_sample_envs else (N, 8)
+            big_n, big_steps = (args.cpu_sample_envs, args.cpu_sample_steps) if args.cpu_sample_envs else (N, 32)
             v, secs, nthr = cpu_baseline(args.task, big_n, big_steps)
-            out["cpu_baseline"] = {"value": round(v, 1), "unit": "env-steps/s", "cores": nthr, "host_threads_available": os.cpu_count(),
+            out["cpu_baseline"] = {"value": round(v, 1), "unit": "env-steps/s", "cores": nthr, "host_threads_available": os.cpu_count(), "host_cpus_usable": usable_cpus(),
                                    "kind": "port", "sample": f"{args.task} {big_n} envs x {big_steps} steps, build's CPU restatement (oracle/, OpenMP over envs), {secs:.1f} s"}
             v4, secs4, nthr4 = cpu_baseline(args.task, 4, 200, threads=4)
             out["cpu_baseline_n4"] = {"value": round(v4, 1), "unit": "env-steps/s", "cores": nthr4, "kind": "port",

@@ -183,7 +183,12 @@ static inline float dot_chain(const float* w, const float* x, int K) {
   return acc;
 }
 /* y[o] = chain(W[o,:], x) for O outputs: identical per-output k-ordered chains, eight outputs interleaved so that the
- * CPU pipelines them (the dependency chain of one output is the bottleneck otherwise) */
+ * CPU pipelines them (the dependency chain of one output is the bottleneck otherwise).  Two clones, picked by the loader from the
+ * host's CPUID: with FMA3 every fmaf is one vfmadd instruction, without it the libm call -- the same correctly rounded result
+ * either way (5 x the checker's speed on the policy layers, which is what bench.py's cpu_baseline spends its time in) */
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(MQO_NO_FMA_CLONE)    /* (tests build the checker once without the clone and compare bit for bit) */
+__attribute__((target_clones("fma", "default")))
+#endif
 static void matvec_chain(const float* W, const float* x, int K, int O, int ldw, float* y) {
   int o = 0;
   for (; o + 8 <= O; o += 8) {

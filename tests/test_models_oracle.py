@@ -352,3 +352,31 @@ def test_collision_model_stays_close_to_the_urdf_collision_primitives(variant):
     for leg in ("FL", "FR", "RL", "RR"):
         foot = f["links"][leg + "_foot"]["collisions"][0]
         assert foot["type"] == "sphere" and foot["params"]["radius"][0] in [m["sphere_radius"][i] for i in range(4)]
+
+
+def test_fma_clone_of_the_policy_layers_is_bit_identical(tmp_path, monkeypatch):
+    """oracle/mqe_oracle.c builds matvec_chain twice (target_clones: FMA3 / default) and the loader picks one by CPUID: a fused multiply-add is
+    correctly rounded whether libm or the vfmadd instruction computes it, so a build WITHOUT the clone must give the same bits."""
+    import os
+    import subprocess
+    import torch
+    from helpers import make_desc, oracle_engine
+    from mqe.engine import abi
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = str(tmp_path / "libmqe_oracle_noclone.so")
+    subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-fopenmp", "-std=gnu11", "-DMQO_NO_FMA_CLONE", "-w", "-o", lib,
+                           os.path.join(root, "oracle", "mqe_oracle.c"), "-lm"])
+    outs = []
+    for which in (None, lib):
+        if which:
+            monkeypatch.setenv("MQE_ORACLE_LIB", which)
+        d, k, _ = make_desc("go1gate", 6)
+        e = oracle_engine(d, k)
+        e.reset_all()
+        g = torch.Generator().manual_seed(5)
+        for t in range(35):                                  # past the 30-frame history horizon: every column of layer 0 carries data
+            e.step(torch.rand(6, 2, 3, generator=g) * 2 - 1)
+        outs.append([e.tensor(t).clone() for t in (abi.T_ROOT_STATE, abi.T_DOF_STATE, abi.T_TORQUES, abi.T_WRAPPER_OBS, abi.T_ACTIONS)])
+        e.close()
+    for a, b in zip(*outs):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
