@@ -237,8 +237,8 @@ def main():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_strict_f32", action="store_true", help="skip the exact-f32 companion run")
     ap.add_argument("--no_configs", action="store_true", help="skip the other single-GPU BASELINE configs (`configs` on the line)")
-    ap.add_argument("--cpu_sample_envs", type=int, default=0, help="CPU baseline batch (0 = the GPU run's num_envs, 32 steps)")
-    ap.add_argument("--cpu_sample_steps", type=int, default=32)
+    ap.add_argument("--cpu_sample_envs", type=int, default=0, help="CPU baseline batch (0 = the GPU run's num_envs, 64 steps)")
+    ap.add_argument("--cpu_sample_steps", type=int, default=64)
     ap.add_argument("--gather", choices=["between", "after", "tail"], default=os.environ.get("MQE_BENCH_GATHER", "tail"),
                     help="N > 1: where the all-gather of a step's returned batch is issued (default: tail).  between: inside the NEXT step, after its policy "
                          "kernels and before its physics kernel (overlaps k_substeps; DESIGN.md 8).  after: right behind the step's own k_post_physics, "
@@ -568,13 +568,13 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             torch.set_num_threads(os.cpu_count() or 1)
             # the CPU restatement at the headline size (few steps) and at the reference's own CPU-runnable size (N = 4)
-            big_n, big_steps = (args.cpu_sample_envs, args.cpu_sample_steps) if args.cpu_sample_envs else (N, 32)
+            big_n, big_steps = (args.cpu_sample_envs, args.cpu_sample_steps) if args.cpu_sample_envs else (N, 64)
             v, secs, nthr = cpu_baseline(args.task, big_n, big_steps)
             out["cpu_baseline"] = {"value": round(v, 1), "unit": "env-steps/s", "cores": nthr, "host_threads_available": os.cpu_count(), "host_cpus_usable": usable_cpus(),
                                    "kind": "port", "sample": f"{args.task} {big_n} envs x {big_steps} steps, build's CPU restatement (oracle/, OpenMP over envs), {secs:.1f} s"}
-            v4, secs4, nthr4 = cpu_baseline(args.task, 4, 200, threads=4)
+            v4, secs4, nthr4 = cpu_baseline(args.task, 4, 2000, threads=4)
             out["cpu_baseline_n4"] = {"value": round(v4, 1), "unit": "env-steps/s", "cores": nthr4, "kind": "port",
-                                      "sample": f"{args.task} 4 envs x 200 steps (BASELINE config 1 size), {secs4:.1f} s"}
+                                      "sample": f"{args.task} 4 envs x 2000 steps (BASELINE config 1 size), {secs4:.1f} s"}
         print(json.dumps(out))
     env.close()
     if world > 1 or solo_group:
