@@ -72,30 +72,12 @@ def binary_info():
     return info
 
 
-def usable_cpus():
-    """CPUs this process may use: the scheduler affinity, capped by the cgroup's CPU quota (cgroup v2 cpu.max / v1 cfs_quota_us)"""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        if q != "max":
-            n = min(n, max(1, int(int(q) / int(p))))
-    except (OSError, ValueError):
-        try:
-            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
-            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-            if q > 0:
-                n = min(n, max(1, q // p))
-        except (OSError, ValueError):
-            pass
-    return n
-
-
 def cpu_baseline(task, sample_envs, sample_steps, threads=None):
     """Time the CPU oracle (OpenMP over envs/robots) on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import make_desc
-    from oracle_engine import OracleEngine
+    from oracle_engine import OracleEngine, usable_cpus
     from mqe.engine import abi
     d, keep, _ = make_desc(task, sample_envs)
     e = OracleEngine(d, keep)
@@ -570,7 +552,7 @@ def main():
             # the CPU restatement at the headline size (few steps) and at the reference's own CPU-runnable size (N = 4)
             big_n, big_steps = (args.cpu_sample_envs, args.cpu_sample_steps) if args.cpu_sample_envs else (N, 64)
             v, secs, nthr = cpu_baseline(args.task, big_n, big_steps)
-            out["cpu_baseline"] = {"value": round(v, 1), "unit": "env-steps/s", "cores": nthr, "host_threads_available": os.cpu_count(), "host_cpus_usable": usable_cpus(),
+            out["cpu_baseline"] = {"value": round(v, 1), "unit": "env-steps/s", "cores": nthr, "host_threads_available": os.cpu_count(), "host_cpus_usable": nthr if not os.environ.get("MQE_CPU_THREADS") else None,
                                    "kind": "port", "sample": f"{args.task} {big_n} envs x {big_steps} steps, build's CPU restatement (oracle/, OpenMP over envs), {secs:.1f} s"}
             v4, secs4, nthr4 = cpu_baseline(args.task, 4, 2000, threads=4)
             out["cpu_baseline_n4"] = {"value": round(v4, 1), "unit": "env-steps/s", "cores": nthr4, "kind": "port",

@@ -21,6 +21,25 @@ def build():
     subprocess.check_call(["make", "-C", HERE, "-s"])
 
 
+def usable_cpus():
+    """CPUs this process may use: the scheduler affinity, capped by the cgroup's CPU quota (cgroup v2 cpu.max / v1 cfs_quota_us).  libgomp sizes its
+    team by the hardware threads it sees (256 on the GPU box, whose container is granted 16 CPUs: the checker then runs 18 x slower than on 16 threads)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def load_library(f64=False):
     name = "libmqe_oracle_f64.so" if f64 else "libmqe_oracle.so"
     if os.environ.get("MQE_ORACLE_LIB"):          # the sanitizer build (oracle/Makefile: asan), tests/test_oracle_sanitized.py
@@ -32,6 +51,8 @@ def load_library(f64=False):
         if not os.path.isfile(path):
             build()
         _LIBS[name] = C.CDLL(path)
+        if not os.environ.get("OMP_NUM_THREADS"):       # one OpenMP runtime per process: the setting holds for every build of the checker loaded afterwards
+            _LIBS[name].mqo_set_num_threads(usable_cpus())
     return _LIBS[name]
 
 

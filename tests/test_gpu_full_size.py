@@ -5,7 +5,9 @@
   config 4  go1seesaw             4096 envs x (2 agents + articulated seesaw)
   config 5  go1football-defender  4096 envs x (3 agents + ball) = the per-GPU shard of the 32768-env, 8-GPU configuration
 
-The oracle cannot run these sizes in seconds; what ties them to the small batches it does check is SIZE INDEPENDENCE: envs
+Until the end of round 5 the oracle could not run these sizes in seconds (its policy layers' fmaf chain was a libm call per multiply-add, and
+libgomp oversubscribed the 16 CPUs of the GPU box's container with 256 threads); it can now, and test_full_size_rollout_matches_oracle holds the
+four configurations to it directly.  What tied them to the small batches before, and still does, is SIZE INDEPENDENCE: envs
 [g0, g0 + NS) of the full batch and the same GLOBAL env ids run alone (env_id_offset, same track assignment) must agree bit for
 bit over a fused rollout -- every kernel treats a row / an env independently of its neighbours and every random draw is keyed by
 the global env id.  Plus invariants that need no oracle: finite state, unit quaternions, bodies inside the arena, joint limits,
@@ -14,7 +16,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import make_desc, hip_engine, task_cfg
+from helpers import make_desc, hip_engine, oracle_engine, task_cfg
 from mqe.engine import abi
 
 pytestmark = pytest.mark.gpu
@@ -163,3 +165,34 @@ def test_full_size_batch_is_the_union_of_its_shards(monkeypatch, task, NF):
     ef.close()
     for _, e in small:
         e.close()
+
+
+@pytest.mark.parametrize("task,NF", FULL)
+def test_full_size_rollout_matches_oracle(task, NF):
+    """BASELINE.json's single-GPU configurations at their full sizes, HIP engine against the CPU oracle: 20 fused steps from the seeded reset distribution
+    with the same random wrapper actions.  Bounds = ~10 x what profiles/r05_parity_sweep_full_size.json measured at step 20 over the 13 tasks (median
+    <= 7.2e-7 m, 99th percentile <= 7.3e-4 m, worst env 1.1e-2 m -- all three in go1revolvingdoor; these four: <= 2.4e-7 / 3.8e-5 / 2.5e-3; no reset flag
+    differed in 5.2 M)."""
+    levels, types = assign_tracks(task, NF)
+    d1, k1, _ = shard_desc(task, NF, 0, NF, levels, types)
+    d2, k2, _ = shard_desc(task, NF, 0, NF, levels, types)
+    eh, eo = hip_engine(d1, k1), oracle_engine(d2, k2)
+    eh.reset_all(); eo.reset_all()
+    A = d1.num_agents
+    Aw = eo.tensor(abi.T_WRAPPER_OBS).shape[1]
+    g = torch.Generator().manual_seed(7)
+    flags = 0
+    for t in range(20):
+        a = torch.rand(NF, Aw, 3, generator=g) * 2 - 1
+        eh.step(a.cuda().contiguous()); eo.step(a)
+        flags += int((eh.tensor(abi.T_RESET_BUF).cpu() != eo.tensor(abi.T_RESET_BUF)).sum())
+        if t == 0:
+            assert (eh.tensor(abi.T_ACTIONS).cpu() - eo.tensor(abi.T_ACTIONS)).abs().max() < 5e-6          # the policy's joint targets (measured 1.8e-7)
+    rh, ro = eh.tensor(abi.T_ROOT_STATE).cpu(), eo.tensor(abi.T_ROOT_STATE)
+    assert torch.isfinite(rh).all() and torch.isfinite(ro).all()
+    dev = (rh[:, :A, :3] - ro[:, :A, :3]).abs().amax(dim=(1, 2))
+    assert float(dev.median()) < 5e-6 and float(dev.quantile(0.99)) < 5e-4 and float(dev.max()) < 3e-2, (float(dev.median()), float(dev.quantile(0.99)), float(dev.max()))
+    assert flags <= 2, flags
+    assert (eh.tensor(abi.T_WRAPPER_OBS).cpu() - eo.tensor(abi.T_WRAPPER_OBS)).abs().median() < 1e-5
+    assert int(eh.tensor(abi.T_CONTACT_OVERFLOW).sum()) == int(eo.tensor(abi.T_CONTACT_OVERFLOW).sum()) == 0
+    eh.close(); eo.close()
