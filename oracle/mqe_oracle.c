@@ -86,6 +86,9 @@ typedef struct mqo_sim {
   int hist_pos;                     /* ring slot that holds the OLDEST frame == next write slot */
   int n_post_steps;                 /* post_physics_step calls so far (base_quat aliasing, see mqo_reset_all) */
   void* tens[MQE_T_COUNT];
+  /* EXPERIMENT (MQO_WARM_START=<factor> in the environment at creation; not part of the specification, not in the HIP engine): contact
+   * impulses of the previous substep as the sweep's starting point, matched by (kind, actors, links) and position (tools/warm_start_delta.py) */
+  float warm; int32_t* wc_n; int32_t* wc_key; float* wc_p; float* wc_lam;
 } mqo_sim;
 
 /* ------------------------------------------------------------------------------------------ small math */
@@ -360,6 +363,11 @@ int mqo_sim_create(const mqe_sim_desc* d, mqo_sim** out) {
   s->sub_dof_vel = ALLOCF((size_t)N * 4 * 12 * A);
   s->sub_exceed = (uint8_t*)calloc((size_t)N * 4 * 12 * A, 1);
   s->overflow = (int32_t*)calloc(N, 4);
+  if (getenv("MQO_WARM_START") && atof(getenv("MQO_WARM_START")) > 0) {      /* EXPERIMENT, see mqo_sim::warm */
+    s->warm = (float)atof(getenv("MQO_WARM_START"));
+    s->wc_n = (int32_t*)calloc(N, 4); s->wc_key = (int32_t*)calloc((size_t)N * MAXC * 5, 4);
+    s->wc_p = (float*)calloc((size_t)N * MAXC * 3, 4); s->wc_lam = (float*)calloc((size_t)N * MAXC * 3, 4);
+  }
   {
     const float soft = d->soft_dof_pos_limit > 0.0f ? d->soft_dof_pos_limit : 1.0f;
     for (int j = 0; j < 12; j++) {                           /* legged_robot.py:317-321 */
@@ -1326,6 +1334,29 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
     }
   }
 
+  if (s->warm > 0) {          /* EXPERIMENT: warm start (see mqo_sim::warm) */
+    const int n_old = s->wc_n[env];
+    const int32_t* ok = s->wc_key + (size_t)env * MAXC * 5;
+    const float* op = s->wc_p + (size_t)env * MAXC * 3;
+    const float* ol = s->wc_lam + (size_t)env * MAXC * 3;
+    unsigned char used[MAXC];
+    for (int j = 0; j < n_old; j++) used[j] = 0;
+    for (int ci = 0; ci < w->nc; ci++) {
+      contact_t* ct = &w->con[ci];
+      int best = -1; real bd = (real)(0.02 * 0.02);
+      for (int j = 0; j < n_old; j++) {
+        if (used[j] || ok[j * 5] != ct->kind || ok[j * 5 + 1] != ct->actA || ok[j * 5 + 2] != ct->bodyA || ok[j * 5 + 3] != ct->actB || ok[j * 5 + 4] != ct->bodyB) continue;
+        real d2 = 0;
+        for (int k = 0; k < 3; k++) { real dd = ct->p[k] - (real)op[j * 3 + k]; d2 += dd * dd; }
+        if (d2 < bd) { bd = d2; best = j; }
+      }
+      if (best < 0) continue;
+      used[best] = 1;
+      for (int q = 0; q < 3; q++) ct->lam[q] = (real)s->warm * (real)ol[best * 3 + q];
+      for (int i = 0; i < ndof; i++) w->v[i] += ct->B[0][i] * ct->lam[0] + ct->B[1][i] * ct->lam[1] + ct->B[2][i] * ct->lam[2];
+    }
+  }
+
   /* ---- contact solver.  d->solver_type follows sim.physx.solver_type (legged_robot_config.py:219: "0: pgs, 1: tgs"):
    *   0  projected Gauss-Seidel on velocities: `solver_iterations` sweeps over the contacts detected at the start-of-step pose, gaps
    *      and penetrations enter as a velocity bias (penetration: erp / dt, capped by max_depenetration_velocity), positions are
@@ -1385,6 +1416,17 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
       for (int i = 0; i < ndof; i++) w->v[i] += ct->B[0][i] * dl[0] + ct->B[1][i] * dl[1] + ct->B[2][i] * dl[2];
     }
     if (TGS && !vel_it) for (int i = 0; i < ndof; i++) Dacc[i] += sdt * w->v[i];
+  }
+  if (s->warm > 0) {          /* EXPERIMENT: remember this substep's impulses */
+    int32_t* ok = s->wc_key + (size_t)env * MAXC * 5;
+    float* op = s->wc_p + (size_t)env * MAXC * 3;
+    float* ol = s->wc_lam + (size_t)env * MAXC * 3;
+    s->wc_n[env] = w->nc;
+    for (int ci = 0; ci < w->nc; ci++) {
+      const contact_t* ct = &w->con[ci];
+      ok[ci * 5] = ct->kind; ok[ci * 5 + 1] = ct->actA; ok[ci * 5 + 2] = ct->bodyA; ok[ci * 5 + 3] = ct->actB; ok[ci * 5 + 4] = ct->bodyB;
+      for (int k = 0; k < 3; k++) { op[ci * 3 + k] = (float)ct->p[k]; ol[ci * 3 + k] = (float)ct->lam[k]; }
+    }
   }
   /* what the positions are integrated with beyond the final velocity: voff = (accumulated motion) / dt - v  (0 for solver type 0).
    * The joint-limit impulses below act on the velocity AND on the motion of the step: they keep voff. */
@@ -1584,6 +1626,7 @@ static void curriculum_move(mqo_sim* s, int e) {
 
 static void reset_env(mqo_sim* s, int e) { /* go1.py:110-145, legged_robot.py:394-470,647-652 */
   const mqe_sim_desc* d = &s->d;
+  if (s->warm > 0) s->wc_n[e] = 0;
   int A = s->A, P = s->P;
   float* root = s->root + (size_t)e * (A + P) * 13;
   float* dofs = s->dof + (size_t)e * s->ND * 2;
