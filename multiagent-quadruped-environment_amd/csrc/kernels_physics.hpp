@@ -441,8 +441,10 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   const bool dbase = is_rbody && bb == 0;
   const float dp_mass = dbase ? dp[1] : 0.0f, dp_cx = dbase ? dp[2] : 0.0f, dp_cy = dbase ? dp[3] : 0.0f, dp_cz = dbase ? dp[4] : 0.0f;
   const float mu_env = st.dparams[(size_t)e * A * 8];
-  float Rm[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-  V3 bp = v3(0, 0, 0), bw = bp, bvp = bp, bax = bp, bal = bp, bap = bp, bc = bp;
+  // (no initial values for what is only read where it has been written -- Rm, bp, bw, bvp of a body lane; the joint frame of a joint lane: a
+  // constant costs one v_mov per register and substep for the whole wavefront.  The base lanes do read bax / bal / bap = 0.)
+  float Rm[9];
+  V3 bp, bw, bvp, bax = v3(0, 0, 0), bal = bax, bap = bax, bc = bax;
   float Iw[6] = {0, 0, 0, 0, 0, 0};
   float bmass = 0.0f;
   float* myrec = lds + L.body + lane * BODY_STRIDE;
@@ -464,8 +466,8 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   }
   // joint-local quantities do not depend on the parent: computed once for all joint lanes, outside the level loop
   // (whose divergent body would otherwise run the sin/cos code three times)
-  float Rj[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, qdj = 0.0f;
-  V3 joff = v3(0, 0, 0), jax = v3(0, 0, 0);
+  float Rj[9], qdj;
+  V3 joff, jax;
   if (depth > 0) {
     const int j = bb - 1;
     const float qj = lds[L.dof + (br * 12 + j) * 2];
@@ -1603,11 +1605,11 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     int infq[NPQ];
 #pragma unroll
     for (int ps = 0; ps < NPQ; ps++) {
-      usq[ps] = 0.0f; dqq[ps] = 0.0f; dqn[ps] = 0.0f; cbq[ps] = 0.0f; muq[ps] = HF(HOT_FRICTION); infq[ps] = 0; sdq[ps] = 0.0f;
-#pragma unroll
-      for (int i = 0; i < 9; i++) rowA[ps][i] = 0.0f;
+      // (what a pass leaves behind is read further down under the pass's own condition: nothing is initialised outside it -- a skipped pass, the
+      // second one of a two-robot scene, then costs nothing; rowA / fan / infq / cbq / sdq are written by side A of every contact before they are read)
       const int c = ps * (LW / 4) + (lane >> 2);
       if (ps * (LW / 4) < nc && c < nc) {
+        usq[ps] = 0.0f; dqq[ps] = 0.0f; dqn[ps] = 0.0f; muq[ps] = HF(HOT_FRICTION);
         const float* cr = lds + L.con + c * CON_STRIDE;
         const float4 w0 = reinterpret_cast<const float4*>(cr)[0], w1 = reinterpret_cast<const float4*>(cr)[1], w2 = reinterpret_cast<const float4*>(cr)[2];
         const int cA = __float_as_int(w0.x), cB = __float_as_int(w0.z);
@@ -1621,8 +1623,6 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
         cbq[ps] = first_bias(sd);
         sdq[ps] = sd;
         float fan[9];                            // side A's NEXT row (two sides on one actor: cross terms)
-#pragma unroll
-        for (int i = 0; i < 9; i++) fan[i] = 0.0f;
         int lgA_ = 0;
         for (int side = 0; side < 2; side++) {
           const int act = side == 0 ? cA : cB, body = side == 0 ? bodyA : bodyB;
