@@ -346,6 +346,8 @@ def main():
     # HIP events around each kernel class on the launch stream, on every PROF_EVERY-th step of the timed region (an event
     # pair costs ~4 us of GPU timeline; bracketing all 5 classes of every step would inflate ms_per_step by 7 %)
     prof_every = 0 if os.environ.get("MQE_BENCH_NOPROF") else max(1, int(os.environ.get("MQE_BENCH_PROF_EVERY", "16")))
+    if prof_every > 2 and args.steps < 3:
+        prof_every = 1          # the brackets sit on the third step of every period: a run of one or two steps brackets every step instead
     eng.profile_enable(prof_every)
 
     def timed(n):
