@@ -211,6 +211,30 @@ __device__ __forceinline__ bool box_edges_vs_prim_dev(V3 cq, V3 hb, const float*
   return found;
 }
 
+// sin and cos of a joint angle in ~25 instructions instead of libm's ~100 + ~100 (each with its own argument reduction and a
+// Payne-Hanek path that a joint angle never takes): one reduction to r = q - k pi/2 (three Cody-Waite steps, exact for |k| <= 5), the
+// single-precision minimax kernels on |r| <= pi/4, quadrant swap / sign.  <= 1.5 ulp (9e-8 absolute) against the double-precision
+// functions on |q| <= 8 (measured on a 1e-5 grid; ocml's sinf / cosf are 1-2 ulp); beyond that -- no joint of the URDF gets there, a
+// state written through the API could -- libm.
+__device__ __forceinline__ void joint_sincos(float q, float& s, float& c) {
+  if (__builtin_expect(fabsf(q) > 8.0f, 0)) { s = sinf(q); c = cosf(q); return; }
+  const float kf = __builtin_rintf(q * 0.63661977236758134f);
+  float r = __builtin_fmaf(kf, -1.57079601287841796875f, q);
+  r = __builtin_fmaf(kf, -3.1391647326017846353352069854736328125e-7f, r);
+  r = __builtin_fmaf(kf, -5.390302529957764765544681040410068817436695098876953125e-15f, r);
+  const float r2 = r * r;
+  float sp = __builtin_fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
+  sp = __builtin_fmaf(sp, r2, -1.6666654611e-1f);
+  const float sr = __builtin_fmaf(sp * r2, r, r);
+  float cp = __builtin_fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+  cp = __builtin_fmaf(cp, r2, 4.166664568298827e-2f);
+  const float cr = __builtin_fmaf(cp * r2, r2, __builtin_fmaf(r2, -0.5f, 1.0f));
+  const int k = (int)kf;
+  const float ss = (k & 1) ? cr : sr, cc = (k & 1) ? sr : cr;
+  s = (k & 2) ? -ss : ss;
+  c = ((k + 1) & 2) ? -cc : cc;
+}
+
 __device__ __forceinline__ float wave_sum(float x) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
@@ -281,7 +305,22 @@ __host__ __device__ inline int mqe_maxc(int A, int P, int cap_npc) { int v = 8 *
 struct PhysLds {   // float offsets into dynamic LDS
   int root, dof, tau, body, rhs, acc, acth, fcol, leg, legc, basei, sinv, sph, prim, con, side, phi, srec, wacc, total;
 };
-#define SREC_STRIDE 20    // row sweep: per contact [u* (3), bias] [mu, 1/d00, 1/d11, 1/d22] [d10, d20, d21, -] [lambda (3), -]
+// Row sweep (scenes of <= 4 actors): ONE record per contact, in the order a sweep step reads it -- three 16 B words that every lane of the
+// row reads (broadcast), then ten 3-float slots, one per lane of the row:
+//   [0..3] mu, 1/d00, 1/d11, 1/d22   [4..7] d10, d20, d21, info   [8..11] lambda (3), running separation
+//   [12 + 3 k + q], k = 0..8: column k of side A's Phi (k < 6: U[q][k]; 6..8: Z'[q][k - 6]) for the rows q = normal, tangent 1, tangent 2
+//   [12 + 27 + q]: slot 9 = (u*_n - bias, u*_t1, u*_t2) -- lane 9 multiplies it by 1, so the butterfly sums arrive as u* - bias + Phi w
+//   [42] bias, [43] u*_n (the contact's own lane keeps both for the separation updates of the temporal solver)
+// info = first-joint offset of the leg (0, 3, 6, 9) | lanes << 8 | first coordinate << 16.  Side B of a two-actor contact: its ten slots
+// (the tenth zero) and its info word at [30] in the pair area.  Round 6: the record used to be two (side record 28 + solve record 20 floats,
+// column k at q * 6 + k resp. 18 + q * 3 + k - 6, the leg offset in a word of its own); a step now forms two addresses instead of
+// seven and adds u* - bias inside the butterfly -- 52 -> 37 vector instructions per step.
+#define RS_STRIDE 44
+#define RS_SLOT 12
+#define RS_BIAS 42
+#define RS_USN 43
+#define RSB_STRIDE 32
+#define RSB_INFO 30
 __host__ __device__ inline int mqe_maxpair(int maxc) { return maxc / 2; }    // two-actor contacts kept per env
 __host__ __device__ inline PhysLds phys_lds_layout(int A, int P, int ND, int nbody, int ndof, int nsph, int nprim, int maxc, int rowgs, int pad) {
   const int BODY_STRIDE = BODY_STRIDE_OF(pad), CON_STRIDE = CON_STRIDE_OF(pad);
@@ -306,8 +345,8 @@ __host__ __device__ inline PhysLds phys_lds_layout(int A, int P, int ND, int nbo
   L.body = o; o += nbody * BODY_STRIDE;
   // row sweep (scenes of <= 4 actors): side A of every contact and the per-contact solve record, written over the link records once the
   // last Jacobian row has been read
-  L.phi = L.body; L.srec = L.phi + maxc * SIDE_STRIDE;
-  if (rowgs && L.srec + maxc * SREC_STRIDE > o) o = L.srec + maxc * SREC_STRIDE;
+  L.phi = L.body; L.srec = L.phi;
+  if (rowgs && L.phi + maxc * RS_STRIDE > o) o = L.phi + maxc * RS_STRIDE;
   const int scratch = o;
   L.fcol = o; o += A * 4 * FCOL_STRIDE;                                  // the four hip composites of every robot on their way to the base lane
   L.legc = o; o += A * 4 * LEGC_STRIDE;
@@ -315,11 +354,11 @@ __host__ __device__ inline PhysLds phys_lds_layout(int A, int P, int ND, int nbo
   L.sph = scratch; L.prim = scratch + nsph * 4;
   if (L.prim + nprim * 8 > o) o = L.prim + nprim * 8;     // two arrays of 16 B words: [centre, bounding radius] x nprim, then [half-segment, radius] x nprim
   L.side = scratch;                                         // side B of the two-actor contacts only (side A: registers / the phi area)
-  if (scratch + mqe_maxpair(maxc) * SIDE_STRIDE > o) o = scratch + mqe_maxpair(maxc) * SIDE_STRIDE;
+  if (scratch + mqe_maxpair(maxc) * RSB_STRIDE > o) o = scratch + mqe_maxpair(maxc) * RSB_STRIDE;      // (RSB_STRIDE >= SIDE_STRIDE: either sweep's side B fits)
   // temporal Gauss-Seidel: W = sum over the finished position iterations of w (one float per generalized coordinate), behind side B in
   // the scratch area (the factorisation scratch and the collision geometry are dead when the sweep starts); afterwards voff = what the
   // positions move with beyond the final velocity
-  L.wacc = scratch + mqe_maxpair(maxc) * SIDE_STRIDE;
+  L.wacc = scratch + mqe_maxpair(maxc) * RSB_STRIDE;
   if (L.wacc + ((ndof + 3) & ~3) > o) o = L.wacc + ((ndof + 3) & ~3);
   L.total = o;
   return L;
@@ -475,7 +514,9 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     joff = v3(rm.joint_offset[bb][0], rm.joint_offset[bb][1], rm.joint_offset[bb][2]);
     jax = v3(rm.joint_axis[bb][0], rm.joint_axis[bb][1], rm.joint_axis[bb][2]);
     const V3 ax = jax;
-    const float c = cosf(qj), s = sinf(qj), t = 1 - c;
+    float c, s;
+    joint_sincos(qj, s, c);
+    const float t = 1 - c;
     Rj[0] = t * ax.x * ax.x + c; Rj[1] = t * ax.x * ax.y - s * ax.z; Rj[2] = t * ax.x * ax.z + s * ax.y;
     Rj[3] = t * ax.x * ax.y + s * ax.z; Rj[4] = t * ax.y * ax.y + c; Rj[5] = t * ax.y * ax.z - s * ax.x;
     Rj[6] = t * ax.x * ax.z - s * ax.y; Rj[7] = t * ax.y * ax.z + s * ax.x; Rj[8] = t * ax.z * ax.z + c;
@@ -1700,20 +1741,19 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
 #pragma unroll
           for (int i = 0; i < 9; i++) { sqq += fq[i] * fq[i]; sqn += fq[i] * fn[i]; }
           dqq[ps] += sqq; dqn[ps] += sqn;
-          const int info = (ncol == 6 && act < A ? 9 : ncol) | ((legi > 0 ? legi * 3 : 0) << 4) | (wbase << 10);   // lanes | first joint offset | first coordinate
+          const int info = (legi > 0 ? legi * 3 : 0) | ((ncol == 6 && act < A ? 9 : ncol) << 8) | (wbase << 16);   // first joint offset | lanes | first coordinate
           if (side == 0) {
             infq[ps] = info; lgA_ = legi + 1;
 #pragma unroll
             for (int i = 0; i < 9; i++) { rowA[ps][i] = fq[i]; fan[i] = fn[i]; }
           } else {                               // side B (two-actor contacts only): straight into its slot
-            float* rec = lds + L.side + (c - nc_terr) * SIDE_STRIDE;
+            float* rec = lds + L.side + (c - nc_terr) * RSB_STRIDE;
             if (q < 3) {
 #pragma unroll
-              for (int mm = 0; mm < 6; mm++) rec[q * 6 + mm] = fq[mm];
-#pragma unroll
-              for (int i = 0; i < 3; i++) rec[SIDE_Z + q * 3 + i] = fq[6 + i];
+              for (int i = 0; i < 9; i++) rec[i * 3 + q] = fq[i];
+              rec[27 + q] = 0.0f;                // slot 9 (side A's carries u* - bias): lane 9 of side B's row multiplies it by zero
             }
-            if (q == 0) rec[SIDE_INFO] = __int_as_float(info);
+            if (q == 0) rec[RSB_INFO] = __int_as_float(info);
             if (cB == cA) {                      // both sides on ONE actor (two links of a robot): the sides share coordinates -> cross terms
               const bool same_leg = lgA_ != 0 && lgA_ == legi + 1;
               float xqq = 0.0f, xqn = 0.0f, xnq = 0.0f;      // A_q . B_q,  A_q . B_next,  A_next . B_q
@@ -1734,23 +1774,18 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     for (int ps = 0; ps < NPQ; ps++) {
       const int c = ps * (LW / 4) + (lane >> 2);
       if (ps * (LW / 4) < nc && c < nc) {
-        float* rec = lds + L.phi + c * SIDE_STRIDE;
-        float* sr = lds + L.srec + c * SREC_STRIDE;
+        float* rc = lds + L.phi + c * RS_STRIDE;
         if (q < 3) {
 #pragma unroll
-          for (int mm = 0; mm < 6; mm++) rec[q * 6 + mm] = rowA[ps][mm];
-#pragma unroll
-          for (int i = 0; i < 3; i++) rec[SIDE_Z + q * 3 + i] = rowA[ps][6 + i];
-          sr[q] = usq[ps];
-          sr[5 + q] = 1.0f / dqq[ps];
-          sr[q == 0 ? 8 : (q == 1 ? 10 : 9)] = dqn[ps];          // d10 = row 0 . row 1, d21 = row 1 . row 2, d20 = row 2 . row 0
+          for (int i = 0; i < 9; i++) rc[RS_SLOT + i * 3 + q] = rowA[ps][i];
+          rc[RS_SLOT + 27 + q] = q == 0 ? usq[ps] - cbq[ps] : usq[ps];
+          rc[1 + q] = 1.0f / dqq[ps];
+          rc[q == 0 ? 4 : (q == 1 ? 6 : 5)] = dqn[ps];           // d10 = row 0 . row 1, d21 = row 1 . row 2, d20 = row 2 . row 0
+          if (q == 0) { rc[RS_USN] = usq[ps]; rc[RS_BIAS] = cbq[ps]; }
         } else {
-          sr[11] = 0.0f;
-          // lambda starts at zero; the fourth slot carries side A's first-joint offset (0, 3, 6, 9: which leg's three joints are
-          // the record's Z' columns) so that the sweep needs no second record read to find its coordinates
-          reinterpret_cast<float4*>(sr)[3] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float((infq[ps] >> 4) & 63));
+          reinterpret_cast<float4*>(rc)[2] = make_float4(0.0f, 0.0f, 0.0f, sdq[ps]);      // lambda starts at zero; the running separation (temporal solver)
+          rc[0] = muq[ps]; rc[7] = __int_as_float(infq[ps]);
         }
-        if (q == 0) { rec[SIDE_INFO] = __int_as_float(infq[ps]); sr[3] = cbq[ps]; sr[4] = muq[ps]; sr[16] = sdq[ps]; }      // [16]: the running separation (temporal solver)
       }
     }
     if (is_con) {                                // the sweep groups the contacts by actor: lane = contact again
@@ -1948,90 +1983,68 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     }
     const int npair = __popcll(gballot(is_pair));
     const int pair0 = nc - npair;
-    // where lane k finds its column in a side record: U[q][k] at q * 6 + k, Z'[q][k - 6] at 18 + q * 3 + (k - 6)
-    const int koff = k < 6 ? k : (k < 9 ? SIDE_Z + (k - 6) : 0), kstr = k < 6 ? 6 : 3;
-    const int klegmask = (k >= 6 && k < 9) ? -1 : 0;
+    // lane k of a row reads slot k of a record (three floats: its column of Phi for the three rows of the contact); lanes 6-8 own the joints
+    // of the contact's leg (first-joint offset in the info word), lane 9 the u* - bias slot, the lanes beyond multiply slot 0 by zero
+    const int k3 = (k < 10 ? k : 0) * 3;
+    const int legm = (k >= 6 && k < 9) ? 63 : 0;
+    const float wdef = k == 9 ? 1.0f : 0.0f;
     __syncthreads();
-    struct RowStep { float ph0, ph1, ph2, wk, s0, s1, s2; int widx; bool on; };
-    // the row's sums of Phi[q][k] w[k] over the coordinates of the side record `rec` (info word: lanes | first joint << 4 | first
-    // coordinate << 10; columns past the actor's are masked, a robot side without a leg has zero Z' and points at leg 0)
-    auto row_products = [&](const float* rec) {
-      RowStep r;
-      const int info = __float_as_int(rec[SIDE_INFO]);
-      r.on = k < (info & 15);
-      r.widx = (info >> 10) + k + (((info >> 4) & 63) & klegmask);
-      const float ww = accv[r.on ? r.widx : 0];
-      r.ph0 = rec[koff]; r.ph1 = rec[koff + kstr]; r.ph2 = rec[koff + 2 * kstr];   // lanes past the side's coordinates read finite record words ...
-      r.wk = r.on ? ww : 0.0f;                                                     // ... and multiply them by zero
-      float a0 = r.ph0 * r.wk, a1 = r.ph1 * r.wk, a2 = r.ph2 * r.wk;       // three independent butterflies, interleaved
+    // sums over the row of slot[q] * w -- three independent butterflies, interleaved; every lane of the row ends with bitwise the same sums
+    auto row_sums = [&](float ph0, float ph1, float ph2, float wk, float& s0, float& s1, float& s2) {
+      float a0 = ph0 * wk, a1 = ph1 * wk, a2 = ph2 * wk;
       asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2));    // products stay products: contracted into the first step they cost mov_dpp + fma each
       a0 += dpp_take<0xB1>(a0); a1 += dpp_take<0xB1>(a1); a2 += dpp_take<0xB1>(a2);
       a0 += dpp_take<0x4E>(a0); a1 += dpp_take<0x4E>(a1); a2 += dpp_take<0x4E>(a2);
       a0 += dpp_take<0x141>(a0); a1 += dpp_take<0x141>(a1); a2 += dpp_take<0x141>(a2);
       a0 += dpp_take<0x140>(a0); a1 += dpp_take<0x140>(a1); a2 += dpp_take<0x140>(a2);
-      r.s0 = a0; r.s1 = a1; r.s2 = a2;
-      return r;
+      s0 = a0; s1 = a1; s2 = a2;
     };
-    // the contact's three rows from its solve record; returns the impulse increments
-    auto row_solve = [&](float* sr, float u0, float u1, float u2, bool writer, float& e0, float& e1, float& e2) {
-      const float4 q0 = reinterpret_cast<const float4*>(sr)[0], q1 = reinterpret_cast<const float4*>(sr)[1];
-      const float4 q2 = reinterpret_cast<const float4*>(sr)[2], q3 = reinterpret_cast<const float4*>(sr)[3];
-      u0 += q0.x; u1 += q0.y; u2 += q0.z;
-      const float ln = fmaxf(q3.x - (u0 - q0.w) * q1.y, 0.0f);
+    // the contact's three rows from the record's constants (q1: mu, 1 / d; q2: couplings; q3: lambda) and the sums u - bias (normal row),
+    // u (tangents): the new impulses and their increments
+    auto row_solve = [&](const float4 q1, const float4 q2, const float4 q3, float u0, float u1, float u2, float& ln, float& l1, float& l2, float& e0, float& e1, float& e2) {
+      ln = fmaxf(q3.x - u0 * q1.y, 0.0f);
       e0 = ln - q3.x;
       const float lim = q1.x * ln;
-      const float l1 = clampf(q3.y - (u1 + q2.x * e0) * q1.z, -lim, lim);
+      l1 = __builtin_amdgcn_fmed3f(q3.y - (u1 + q2.x * e0) * q1.z, -lim, lim);      // lim >= 0: the median IS the clamp, one instruction
       e1 = l1 - q3.y;
-      const float l2 = clampf(q3.z - (u2 + q2.y * e0 + q2.z * e1) * q1.w, -lim, lim);
+      l2 = __builtin_amdgcn_fmed3f(q3.z - (u2 + q2.y * e0 + q2.z * e1) * q1.w, -lim, lim);
       e2 = l2 - q3.z;
-      if (writer) reinterpret_cast<float4*>(sr)[3] = make_float4(ln, l1, l2, q3.w);
-    };
-    // a one-sided contact of this row's ROBOT (scenes whose actors 0 .. A-1 are robots): 9 coordinates, the first at row * 18 -- only the
-    // leg offset comes from the contact (its solve record), so the step reads the side record's three columns and w[k], nothing else
-    auto row_products_robot = [&](const float* rec, const float* sr) {
-      RowStep r;
-      const int jo = __float_as_int(sr[15]);
-      r.on = k < 9;
-      r.widx = row * MQE_RD + k + (jo & klegmask);
-      const float ww = accv[r.on ? r.widx : 0];
-      r.ph0 = rec[koff]; r.ph1 = rec[koff + kstr]; r.ph2 = rec[koff + 2 * kstr];
-      r.wk = r.on ? ww : 0.0f;
-      float a0 = r.ph0 * r.wk, a1 = r.ph1 * r.wk, a2 = r.ph2 * r.wk;
-      asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2));
-      a0 += dpp_take<0xB1>(a0); a1 += dpp_take<0xB1>(a1); a2 += dpp_take<0xB1>(a2);
-      a0 += dpp_take<0x4E>(a0); a1 += dpp_take<0x4E>(a1); a2 += dpp_take<0x4E>(a2);
-      a0 += dpp_take<0x141>(a0); a1 += dpp_take<0x141>(a1); a2 += dpp_take<0x141>(a2);
-      a0 += dpp_take<0x140>(a0); a1 += dpp_take<0x140>(a1); a2 += dpp_take<0x140>(a2);
-      r.s0 = a0; r.s1 = a1; r.s2 = a2;
-      return r;
     };
     // temporal solver: what the contact's own lane keeps for the separation updates between the sweeps -- side A's normal row, u*_n, the
-    // running separation (side B of a two-actor contact is re-read from its slot: rare)
-    float nrow[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, usn = 0.0f;
+    // running separation, the bias (side B of a two-actor contact is re-read from its slot: rare)
+    float nrow[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, usn = 0.0f, cbias_r = 0.0f;
     const float* nwb = accv; const float* nwl = accv;
-    if (tgs && is_con) {
-      const float4* r4 = reinterpret_cast<const float4*>(lds + L.phi + lane * SIDE_STRIDE);
-      const float4 a0 = r4[0], a1 = r4[1], a4 = r4[4], a5 = r4[5], a6 = r4[6];
-      const int info = __float_as_int(a6.w), ncl = info & 15;
-      nrow[0] = a0.x; nrow[1] = ncl > 1 ? a0.y : 0.0f; nrow[2] = ncl > 2 ? a0.z : 0.0f; nrow[3] = ncl > 3 ? a0.w : 0.0f; nrow[4] = ncl > 4 ? a1.x : 0.0f; nrow[5] = ncl > 5 ? a1.y : 0.0f;
-      const bool legc = ncl == 9;
-      nrow[6] = legc ? a4.z : 0.0f; nrow[7] = legc ? a4.w : 0.0f; nrow[8] = legc ? a5.x : 0.0f;
-      nwb = accv + (info >> 10);
-      nwl = nwb + (legc ? 6 + ((info >> 4) & 63) : 0);            // (no leg columns: three zero weights on the base's first coordinates)
-      const float* sr = lds + L.srec + lane * SREC_STRIDE;
-      usn = sr[0]; csep = sr[16];
+    float* myrc = lds + L.phi + (is_con ? lane : 0) * RS_STRIDE;
+    if (is_con) {
+      const int info = __float_as_int(myrc[7]);
+      if (tgs) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) nrow[i] = myrc[RS_SLOT + i * 3];          // columns beyond the side's are stored as zeros
+        nwb = accv + (info >> 16);
+        nwl = nwb + (((info >> 8) & 15) == 9 ? 6 + (info & 63) : 0);          // (no leg columns: three zero weights on the base's first coordinates)
+      }
+      usn = myrc[RS_USN]; cbias_r = myrc[RS_BIAS]; csep = myrc[11];
     }
     // (barriers inside: with two envs per wavefront the trip counts are the larger of the two envs'; a row without work idles)
     const int maxlen_w = wave_max_of_groups(maxlen), npair_w = wave_max_of_groups(npair);
+    const int rowk = row * MQE_RD + k;
     for (int it = 0; it < nsweeps; it++) {
       for (int sidx = 0; sidx < maxlen_w; sidx++) {
         if (row < nact && sidx < glen) {                     // the s-th one-sided contact of every actor, each in its own row
-          const int c = gstart + sidx;
-          const RowStep r = TP == 0 ? row_products_robot(lds + L.phi + c * SIDE_STRIDE, lds + L.srec + c * SREC_STRIDE)      // (all actors are robots)
-                                    : row_products(lds + L.phi + c * SIDE_STRIDE);
-          float e0, e1, e2;
-          row_solve(lds + L.srec + c * SREC_STRIDE, r.s0, r.s1, r.s2, k == 0, e0, e1, e2);
-          if (r.on) accv[r.widx] = r.wk + r.ph0 * e0 + r.ph1 * e1 + r.ph2 * e2;
+          float* rc = lds + L.phi + (gstart + sidx) * RS_STRIDE;
+          const float4 q1 = reinterpret_cast<const float4*>(rc)[0], q2 = reinterpret_cast<const float4*>(rc)[1], q3 = reinterpret_cast<const float4*>(rc)[2];
+          const int info = __float_as_int(q2.w);
+          // a robot's row (scenes whose actors 0 .. A-1 are robots): 9 coordinates, the first at row * 18 -- only the leg offset comes from the contact
+          const bool on = TP == 0 ? k < 9 : k < ((info >> 8) & 15);
+          const int widx = (TP == 0 ? rowk : (info >> 16) + k) + (info & legm);
+          const float ww = accv[TP == 0 ? widx : (on ? widx : 0)];            // (a robot row's idle lanes read a neighbouring coordinate and drop it)
+          const float ph0 = rc[RS_SLOT + k3], ph1 = rc[RS_SLOT + k3 + 1], ph2 = rc[RS_SLOT + k3 + 2];
+          const float wk = on ? ww : wdef;
+          float s0, s1, s2, ln, l1, l2, e0, e1, e2;
+          row_sums(ph0, ph1, ph2, wk, s0, s1, s2);
+          row_solve(q1, q2, q3, s0, s1, s2, ln, l1, l2, e0, e1, e2);
+          if (k == 0) reinterpret_cast<float4*>(rc)[2] = make_float4(ln, l1, l2, q3.w);
+          if (on) accv[widx] = wk + ph0 * e0 + ph1 * e1 + ph2 * e2;
         }
         __syncthreads();
       }
@@ -2041,11 +2054,23 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
         int widxB = 0;
         bool onB = false;
         if (row < 2 && c < nc) {
-          const RowStep r = row_products(row == 0 ? lds + L.phi + c * SIDE_STRIDE : lds + L.side + (c - nc_terr) * SIDE_STRIDE);
-          const float s0 = r.s0 + row_partner(r.s0), s1 = r.s1 + row_partner(r.s1), s2 = r.s2 + row_partner(r.s2);
-          row_solve(lds + L.srec + c * SREC_STRIDE, s0, s1, s2, lane == 0, e0, e1, e2);     // both rows solve the same numbers; one lane records lambda
-          if (row == 0 && r.on) accv[r.widx] = r.wk + r.ph0 * e0 + r.ph1 * e1 + r.ph2 * e2;
-          onB = row == 1 && r.on; widxB = r.widx; fb0 = r.ph0; fb1 = r.ph1; fb2 = r.ph2;
+          float* rc = lds + L.phi + c * RS_STRIDE;
+          const float* rb = lds + L.side + (c - nc_terr) * RSB_STRIDE;
+          const float4 q1 = reinterpret_cast<const float4*>(rc)[0], q2 = reinterpret_cast<const float4*>(rc)[1], q3 = reinterpret_cast<const float4*>(rc)[2];
+          const int info = row == 0 ? __float_as_int(q2.w) : __float_as_int(rb[RSB_INFO]);
+          const float* slot = (row == 0 ? rc + RS_SLOT : rb) + k3;
+          const bool on = k < ((info >> 8) & 15);
+          const int widx = (info >> 16) + k + (info & legm);
+          const float ww = accv[on ? widx : 0];
+          const float ph0 = slot[0], ph1 = slot[1], ph2 = slot[2];
+          const float wk = on ? ww : (row == 0 ? wdef : 0.0f);               // u* - bias enters once, through side A's row
+          float s0, s1, s2, ln, l1, l2;
+          row_sums(ph0, ph1, ph2, wk, s0, s1, s2);
+          s0 += row_partner(s0); s1 += row_partner(s1); s2 += row_partner(s2);
+          row_solve(q1, q2, q3, s0, s1, s2, ln, l1, l2, e0, e1, e2);          // both rows solve the same numbers; one lane records lambda
+          if (lane == 0) reinterpret_cast<float4*>(rc)[2] = make_float4(ln, l1, l2, q3.w);
+          if (row == 0 && on) accv[widx] = wk + ph0 * e0 + ph1 * e1 + ph2 * e2;
+          onB = row == 1 && on; widxB = widx; fb0 = ph0; fb1 = ph1; fb2 = ph2;
         }
         __syncthreads();
         if (onB) accv[widxB] += fb0 * e0 + fb1 * e1 + fb2 * e2;                 // after side A's stores: the sides may share coordinates (self-contact)
@@ -2054,28 +2079,28 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       if (tgs && it < npos) { Wacc0 += lane < ndof ? accv[lane] : 0.0f; Wacc1 += lane + LW < ndof ? accv[lane + LW] : 0.0f; }    // (every step above ended with a barrier)
       if (it + 1 < nsweeps && (tgs || it + 1 >= npos)) {     // what the next sweep asks of the normal rows, lane = contact
         if (is_con) {
-          float* sr = lds + L.srec + lane * SREC_STRIDE;
           float g = 0.0f;
           if (tgs && it < npos) {                            // Phi_n . w: side A from the lane's registers
             g = nrow[0] * nwb[0] + nrow[1] * nwb[1] + nrow[2] * nwb[2] + nrow[3] * nwb[3] + nrow[4] * nwb[4] + nrow[5] * nwb[5]
               + nrow[6] * nwl[0] + nrow[7] * nwl[1] + nrow[8] * nwl[2];
             if (is_pair) {
-              const float* rec = lds + L.side + (lane - nc_terr) * SIDE_STRIDE;
-              const int info = __float_as_int(rec[SIDE_INFO]);
-              const int ncl = info & 15, jo = (info >> 4) & 63;
-              const float* wb = accv + (info >> 10);
+              const float* rec = lds + L.side + (lane - nc_terr) * RSB_STRIDE;
+              const int info = __float_as_int(rec[RSB_INFO]);
+              const int ncl = (info >> 8) & 15, jo = info & 63;
+              const float* wb = accv + (info >> 16);
 #pragma unroll
-              for (int mm = 0; mm < 6; mm++) g += rec[mm] * (mm < ncl ? wb[mm] : 0.0f);
-              if (ncl == 9) g += rec[SIDE_Z] * wb[6 + jo] + rec[SIDE_Z + 1] * wb[7 + jo] + rec[SIDE_Z + 2] * wb[8 + jo];
+              for (int mm = 0; mm < 6; mm++) g += rec[mm * 3] * (mm < ncl ? wb[mm] : 0.0f);
+              if (ncl == 9) g += rec[18] * wb[6 + jo] + rec[21] * wb[7 + jo] + rec[24] * wb[8 + jo];
             }
           }
-          sr[3] = tgs ? next_bias(csep, usn + g, 0.0f, it) : next_bias(csep, 0.0f, sr[3], it);
+          cbias_r = tgs ? next_bias(csep, usn + g, 0.0f, it) : next_bias(csep, 0.0f, cbias_r, it);
+          myrc[RS_SLOT + 27] = usn - cbias_r;
         }
         __syncthreads();
       }
     }
     if (tgs) { if (lane < ndof) waccv[lane] = Wacc0; if (lane + LW < ndof) waccv[lane + LW] = Wacc1; }     // W = the sum of w over the position iterations
-    if (is_con) { const float4 q3 = reinterpret_cast<const float4*>(lds + L.srec + lane * SREC_STRIDE)[3]; cl0 = q3.x; cl1 = q3.y; cl2 = q3.z; }
+    if (is_con) { const float4 q3 = reinterpret_cast<const float4*>(myrc)[2]; cl0 = q3.x; cl1 = q3.y; cl2 = q3.z; }
   } else
     {
       const bool is_terr = is_con && myB < 0, is_pair = is_con && myB >= 0;
@@ -2124,9 +2149,9 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
         const float ln = fmaxf(cl0 - (u0 - cbias) * ik00, 0.0f);
         const float e0 = ln - cl0;
         const float lim = mu * ln;
-        const float l1 = clampf(cl1 - (u1 + d10 * e0) * ik11, -lim, lim);
+        const float l1 = __builtin_amdgcn_fmed3f(cl1 - (u1 + d10 * e0) * ik11, -lim, lim);
         const float e1 = l1 - cl1;
-        const float l2 = clampf(cl2 - (u2 + d20 * e0 + d21 * e1) * ik22, -lim, lim);
+        const float l2 = __builtin_amdgcn_fmed3f(cl2 - (u2 + d20 * e0 + d21 * e1) * ik22, -lim, lim);
         const float e2 = l2 - cl2;
         cl0 = ln; cl1 = l1; cl2 = l2;
   #pragma unroll
