@@ -348,7 +348,7 @@ __host__ __device__ inline PhysLds phys_lds_layout(int A, int P, int ND, int nbo
   L.phi = L.body; L.srec = L.phi;
   if (rowgs && L.phi + maxc * RS_STRIDE > o) o = L.phi + maxc * RS_STRIDE;
   const int scratch = o;
-  L.fcol = o; o += A * 4 * FCOL_STRIDE;                                  // the four hip composites of every robot on their way to the base lane
+  L.fcol = o; o += A * 5 * FCOL_STRIDE;                                  // the four hip composites of every robot and the base body's own, on their way into the base block
   L.legc = o; o += A * 4 * LEGC_STRIDE;
   L.basei = o; o += A * 24;                                 // per robot: upper triangle of the base block, then of the Schur complement (21 values)
   L.sph = scratch; L.prim = scratch + nsph * 4;
@@ -617,25 +617,15 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
 #undef MQE_FD
   }
   {
-    // the four hip composites of a robot -> its base lane, through LDS (4 x 16 B stores per hip lane, 16 x 16 B loads per base
-    // lane, in the joint-force-column area that is written further down): 20 LDS instructions instead of 64 ds_bpermute
+    // The base block wants the robot's TOTAL composite = the base body's own + the four hip composites.  It is not summed on the base lane
+    // (16 x 16 B loads and 64 additions with two lanes of the wavefront active, round 5): the five records go to LDS here -- 4 x 16 B
+    // stores per lane -- and the lanes that assemble the Schur complement further down gather their entry's five terms themselves.
     float* hx = lds + L.fcol;
-    if (depth == 1) {
-      float4* w = reinterpret_cast<float4*>(hx + (br * 4 + (bb - 1) / 3) * FCOL_STRIDE);
+    if (is_rbody && depth <= 1) {
+      float4* w = reinterpret_cast<float4*>(hx + (br * 5 + (bb == 0 ? 4 : (bb - 1) / 3)) * FCOL_STRIDE);
 #pragma unroll
       for (int k = 0; k < 4; k++) w[k] = make_float4(X[4 * k], X[4 * k + 1], X[4 * k + 2], X[4 * k + 3]);
     }
-    __syncthreads();
-    if (is_rbody && bb == 0) {
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const float4* rd = reinterpret_cast<const float4*>(hx + br * 4 * FCOL_STRIDE) + k;
-        const float4 h0 = rd[0], h1 = rd[FCOL_STRIDE / 4], h2 = rd[2 * (FCOL_STRIDE / 4)], h3 = rd[3 * (FCOL_STRIDE / 4)];
-        X[4 * k] += h0.x + h1.x + h2.x + h3.x; X[4 * k + 1] += h0.y + h1.y + h2.y + h3.y;
-        X[4 * k + 2] += h0.z + h1.z + h2.z + h3.z; X[4 * k + 3] += h0.w + h1.w + h2.w + h3.w;
-      }
-    }
-    __syncthreads();
   }
   // ---- mass-matrix columns (CRBA in the common frame) and generalized bias ------------------------------------
   // joint lane: S = (w: a, v_o: (p - o) x a);  F = Ic S = (f, n)
@@ -657,15 +647,6 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       if (depth >= 2) cpl1 = dot(Sa1, Fn) + dot(Sv1, Ff);
       if (depth == 3) cpl2 = dot(Sa2, Fn) + dot(Sv2, Ff);
       lds[L.rhs + br * MQE_RD + 6 + j] = lds[L.tau + br * 12 + j] - hj;
-    } else if (is_rbody) {
-      // base block M_bb = [m 1, -[h]x; [h]x, Ibar] as its upper triangle, row-major (00 01 .. 05 11 .. 55): what the leg blocks'
-      // C terms are subtracted from, entry by entry, further down
-      float4* b4 = reinterpret_cast<float4*>(lds + L.basei + br * 24);
-      b4[0] = make_float4(X[0], 0.0f, 0.0f, 0.0f);      b4[1] = make_float4(X[3], -X[2], X[0], 0.0f);
-      b4[2] = make_float4(-X[3], 0.0f, X[1], X[0]);     b4[3] = make_float4(X[2], -X[1], 0.0f, X[4]);
-      b4[4] = make_float4(X[7], X[8], X[5], X[9]);      b4[5] = make_float4(X[6], 0.0f, 0.0f, 0.0f);
-      float* rh = lds + L.rhs + br * MQE_RD;
-      rh[0] = -X[13]; rh[1] = -X[14]; rh[2] = -X[15]; rh[3] = -X[10]; rh[4] = -X[11]; rh[5] = -X[12];
     }
     // ---- leg blocks on the hip lanes: Mi = Mll^-1, G = Mbl Mi (6x3), C = G Mbl^T (6x6 sym).  The thigh's and the calf's
     // force columns and matrix entries come from lanes + 1 and + 2 through DPP wave shifts (every lane executes the shifts: a DPP
@@ -712,12 +693,28 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   TSTAMP(3);
   TSTAMP(4);
   // ---- Schur complement S = M_bb - sum_legs C, one lane per entry of the upper triangle (the six lanes that factor it below would
-  // otherwise each subtract all four C matrices) -----------------------------------------------------------------------------------
-  for (int t = lane; t < A * 21; t += LW) {
-    const int r = t / 21, q = t - r * 21;
-    float* sb = lds + L.basei + r * 24 + q;
-    const float* cq = lds + L.legc + r * 4 * LEGC_STRIDE + q;
-    *sb = (((*sb - cq[0]) - cq[LEGC_STRIDE]) - cq[2 * LEGC_STRIDE]) - cq[3 * LEGC_STRIDE];
+  // otherwise each subtract all four C matrices), and the base part of the generalized bias.  M_bb = [m 1, -[h]x; [h]x, Ibar] and
+  // -(force, moment) are entries of the robot's total composite X = base body + four hips (records of L.fcol; X[0] = m, X[1:4] = h,
+  // X[4:10] = Ibar, X[10:13] = moment, X[13:16] = force), summed in the order the base lane used to: own + (((h0 + h1) + h2) + h3).
+  // Entry t of a robot: 0-20 the upper triangle row by row, 21-26 the bias; which X it is, its sign, and whether it is a structural zero: 4 + 1 + 1 bits each.
+  for (int t = lane; t < A * 27; t += LW) {
+    const int r = (int)(t >= 27) + (int)(t >= 54) + (int)(t >= 81), q = t - r * 27;
+    //                     q:  0  1  2  3  4  5   6  7  8  9 10  11 12 13 14  15 16 17  18 19  20 | 21 22 23 24 25 26
+    //                     X:  0  -  -  -  3 -2   0  - -3  -  1   0  2 -1  -   4  7  8   5  9   6 |-13-14-15-10-11-12
+    const int xi = (int)((q < 16 ? (0x4012010300230000ull >> (4 * q)) : (0xCBAFED69587ull >> (4 * (q - 16)))) & 15ull);
+    const bool neg = ((0x7E02120u >> q) & 1u) != 0u, none = ((0x428Eu >> q) & 1u) != 0u;
+    float v = 0.0f;
+    if (!none) {
+      const float* hb = lds + L.fcol + r * 5 * FCOL_STRIDE + xi;
+      v = hb[4 * FCOL_STRIDE] + (((hb[0] + hb[FCOL_STRIDE]) + hb[2 * FCOL_STRIDE]) + hb[3 * FCOL_STRIDE]);
+      v = neg ? -v : v;
+    }
+    if (q < 21) {
+      const float* cq = lds + L.legc + r * 4 * LEGC_STRIDE + q;
+      lds[L.basei + r * 24 + q] = (((v - cq[0]) - cq[LEGC_STRIDE]) - cq[2 * LEGC_STRIDE]) - cq[3 * LEGC_STRIDE];
+    } else {
+      lds[L.rhs + r * MQE_RD + (q - 21)] = v;
+    }
   }
   __syncthreads();
   // ---- 6x6 Schur complement inverse: lane (robot, column) --------------------------------------------------------
@@ -862,7 +859,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   for (int s = lane; s < nsph; s += LW) {
     V3 c; float rad;
     if (s < A * nsr) {
-      const int r = s / nsr, si = s - r * nsr;
+      const int r = (int)(s >= nsr) + (int)(s >= 2 * nsr) + (int)(s >= 3 * nsr), si = s - r * nsr;       // s / nsr for at most four robots, without the division
       const float* rec = lds + L.body + (r * MQE_NBODY + rm.sphere_body[si]) * BODY_STRIDE;
       const float4 q0 = reinterpret_cast<const float4*>(rec)[0], q1 = reinterpret_cast<const float4*>(rec)[1], q2 = reinterpret_cast<const float4*>(rec)[2];
       const float Rr[9] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x};
@@ -915,7 +912,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   const int npr = HI(HOT_N_PRIMS);
   const bool need_prims = near0 != 0ull || near1 != 0ull || near2 != 0ull || self_todo != 0u;
   for (int t = lane; need_prims && t < A * npr; t += LW) {
-    const int r = t / npr, q = t - r * npr;
+    const int r = (int)(t >= npr) + (int)(t >= 2 * npr) + (int)(t >= 3 * npr), q = t - r * npr;
     const float* rec = lds + L.body + (r * MQE_NBODY + rm.prim_body[q]) * BODY_STRIDE;
     const float4 q0 = reinterpret_cast<const float4*>(rec)[0], q1 = reinterpret_cast<const float4*>(rec)[1], q2 = reinterpret_cast<const float4*>(rec)[2];
     const float Rr[9] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x};
@@ -956,7 +953,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   // (multi-sphere NPCs: one per pass).  The list order stays canonical -- actor by actor, sphere by sphere, ground /
   // wall / platform / column -- because a lane's slot = contacts of earlier groups (capped) + its rank in its group.
   const int rpp = (2 * nsr <= LW) ? 2 : 1;
-  const int n_rpass = (A + rpp - 1) / rpp;
+  const int n_rpass = rpp == 2 ? (A + 1) >> 1 : A;          // (a division by a run-time value is ~25 vector instructions, wave-uniform or not)
   const int nsn = HI(HOT_NPC_N_SPHERES);
   const bool npc_one = PD * nsn <= LW;                     // every sphere of every free NPC in ONE pass, lane = (npc, sphere): 9 sheep x 2
   const int n_pass = n_rpass + (PD > 0 ? (npc_one ? 1 : PD) : 0);
@@ -2246,10 +2243,10 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
         // less and one LDS round trip more, and the round trip is what costs -- A/B round 4: no gain at 4 wavefronts per SIMD, +2 % on the
         // scenes that run at 2)
 #pragma unroll
-        for (int nn = 0; nn < 6; nn++) {
+        for (int nn = 0; nn < 6; nn++) {          // F is upper triangular (stored 6 x 6 with its zeros): row nn starts at column nn -- the 15 skipped terms were exact zeros
           float dvb = 0.0f, vob = 0.0f;
 #pragma unroll
-          for (int mm = 0; mm < 6; mm++) { const float c = Fm[nn * 6 + mm]; dvb += c * wb[mm]; if (tgs) vob += c * xb[mm]; }
+          for (int mm = nn; mm < 6; mm++) { const float c = Fm[nn * 6 + mm]; dvb += c * wb[mm]; if (tgs) vob += c * xb[mm]; }
           dv -= G[nn * 3] * dvb; if (tgs) vo -= G[nn * 3] * vob;
         }
       }
