@@ -42,6 +42,11 @@ PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec peak
 K_SPLIT = 30 * 48               # K of k_gemm_h2 over the history: MQE_HIST frames x MQE_H2_FRAME compact columns (csrc/mqe_common.hpp; tests/test_abi.py keeps the two in step)
 
 
+def abi_mod():
+    from mqe.engine import abi
+    return abi
+
+
 def make_args(task, num_envs, seed, device):
     from mqe.utils.helpers import finish_args
     a = types.SimpleNamespace(task=task, num_envs=num_envs, seed=seed, headless=True, record_video=False,
@@ -131,6 +136,30 @@ def time_variant(task, N, dev, steps, warmup, env_vars):
     return 1e3 * el / steps, A
 
 
+def event_pair_overhead_ms(n=32):
+    """what a HIP event pair with NOTHING between its two records reports on the current stream: the share of a bracketed kernel's event time
+    that is the bracket's own (subtracted from the per-kernel averages below; both figures are on the line)"""
+    torch.cuda.synchronize()
+    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for a, b in pairs:
+        a.record(); b.record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in pairs)
+    return ts[len(ts) // 2]
+
+
+def profile_pass(eng, step_fn, brackets=24, every=4):
+    """HIP events around each kernel class on the launch stream, OUTSIDE every timed region (VERDICT r5 "Next" 7: the brackets perturb what
+    they measure -- an event pair costs ~4 us of GPU timeline -- so no timed step carries one): `brackets` steps, one per period of `every`,
+    of a run of brackets x every further steps of the same loop.  Returns (ms per class, launches per class, bracketed steps)."""
+    eng.profile_enable(every)
+    for _ in range(brackets * every):
+        step_fn()
+    ms, _ = eng.profile_read(12)
+    eng.profile_enable(False)
+    return ms[:6], ms[6:12], brackets
+
+
 SUBSTEPS_BOUND = "valu-issue / latency (not hbm)"
 SUBSTEPS_NOTE = ("achieved / peak / frac are the PRESCRIBED form -- the whole step's algorithmic HBM bytes over this kernel's average launch time against the HBM peak -- "
                  "but HBM is not what binds it: one env per wavefront, state LDS-resident for the 4 substeps; the limiters are the wavefront's chain of dependent "
@@ -179,7 +208,10 @@ def time_config(task, N, dev, env_vars, label, min_ms=100.0, warmup=10):
     torch.cuda.synchronize()
     est = (time.perf_counter() - t0) / 8
     steps = int(min(5000, max(32, -(-min_ms * 1e-3 // est))))
-    eng.profile_enable(16)
+    # (>= 100 ms timed: one step in `every` carries the brackets -- >= 16 of them, spread over the whole rollout, whose contact counts drift --
+    # at a cost of ~16 us per bracketed step, < 0.5 % of the region)
+    every = max(3, steps // 20)
+    eng.profile_enable(every)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for t in range(steps):
@@ -188,8 +220,11 @@ def time_config(task, N, dev, env_vars, label, min_ms=100.0, warmup=10):
     el = time.perf_counter() - t0
     ms, _ = eng.profile_read(12)
     eng.profile_enable(False)
-    overflow = int(env.env.contact_overflow.sum().item())
     kms, cnt = ms[:6], ms[6:12]
+    overflow = int(env.env.contact_overflow.sum().item())
+    reduced = int(env.env.engine.tensor(abi_mod().T_CONTACT_REDUCED).sum().item())
+    ovh = event_pair_overhead_ms()
+    kms = [max(kms[i] - ovh * cnt[i], 0.0) for i in range(6)]
     sub_ms = kms[3] / max(cnt[3], 1)
     R = N * A_phys
     step_bytes = 10128.0 * R + 2 * 104.0 * N * P
@@ -204,7 +239,8 @@ def time_config(task, N, dev, env_vars, label, min_ms=100.0, warmup=10):
                         "bytes_basis": "SURVEY 8(d): 10128 B per robot-step + 208 B per free NPC body and env step, charged to the dominant kernel"},
            "kernel_avg_launch_ms": {("k_gemm_h2", "k_policy_tail", "k_compute_torques_mfma", "k_substeps", "k_post_physics", "k_pre_policy")[i]: round(kms[i] / max(cnt[i], 1), 4)
                                     for i in range(6) if cnt[i] > 0},
-           "contact_overflow_substeps": overflow}
+           "contact_overflow_substeps": overflow, "contact_reduced_substeps": reduced,
+           "hip_event_sampling": "one step in %d bracketed; event-pair overhead %.4f ms subtracted per launch" % (every, ovh)}
     env.close()
     return row
 
@@ -343,12 +379,8 @@ def main():
     for _ in range(args.warmup):
         one_step()
     drain()
-    # HIP events around each kernel class on the launch stream, on every PROF_EVERY-th step of the timed region (an event
-    # pair costs ~4 us of GPU timeline; bracketing all 5 classes of every step would inflate ms_per_step by 7 %)
-    prof_every = 0 if os.environ.get("MQE_BENCH_NOPROF") else max(1, int(os.environ.get("MQE_BENCH_PROF_EVERY", "16")))
-    if prof_every > 2 and args.steps < 3:
-        prof_every = 1          # the brackets sit on the third step of every period: a run of one or two steps brackets every step instead
-    eng.profile_enable(prof_every)
+    # (no HIP-event brackets inside any timed region: profile_pass() below runs after the clocks have stopped)
+    prof_on = not os.environ.get("MQE_BENCH_NOPROF")
 
     def timed(n):
         """n steps bracketed by barrier + synchronize on both sides; seconds, MAX over ranks"""
@@ -379,9 +411,8 @@ def main():
         assert torch.equal(mine.view(torch.int32), env.returned_batch.view(torch.int32)), "all-gather: own slice differs from the returned batch"
         assert torch.equal(mine[obs.numel() + N * A:].view(torch.uint8)[:N].view(torch.bool), env.env.reset_buf), "all-gather: done flags"
     gathers_contract = n_gathers[0]              # collectives of the warm-up + the K timed steps (the long run below adds its own)
-    ms, _ = eng.profile_read(12)
     overflow_substeps = int(env.env.contact_overflow.sum().item())      # truncated contact lists over the whole run (after the clock stopped)
-    eng.profile_enable(False)
+    reduced_substeps = int(eng.tensor(abi_mod().T_CONTACT_REDUCED).sum().item())   # env-substeps with a robot's contacts reduced to its deepest eight
     value = A * N * world * args.steps / elapsed
     # A timed region shorter than 50 ms (the driver's --steps 20 is 4.6 ms) is below the resolution of everything that watches the
     # box from outside (rocm-smi samples, the driver's own clock): the same loop is continued until >= 100 ms of GPU time have been
@@ -392,6 +423,15 @@ def main():
         el_long = timed(n_long)
         long_run = {"steps": n_long, "ms_per_step": round(1e3 * el_long / n_long, 4), "value": round(A * N * world * n_long / el_long, 1),
                     "note": "the timed loop continued (same engine, same schedule, fresh actions cycled) until >= 100 ms were timed"}
+    # per-kernel-class HIP-event times: 24 bracketed steps of the same loop, after both clocks have stopped
+    ms = [0.0] * 12
+    sampled = 1
+    pair_ms = 0.0
+    if prof_on:
+        kms_, cnt_, sampled = profile_pass(eng, one_step)
+        drain()
+        pair_ms = event_pair_overhead_ms()
+        ms = list(kms_) + list(cnt_)
     # MQE_BENCH_SWEEP_GATHER=1 (N > 1): one run decides the default schedule -- every all-gather schedule and the no-collective mode
     # re-timed back to back on the same engine, ms per step each (the headline above is the schedule named in `collective`)
     sweep = None
@@ -407,8 +447,9 @@ def main():
         sweep = {"steps": n_sw, "ms_per_step": sweep, "overhead_vs_no_collective": {k: round(v / base_ms - 1.0, 4) for k, v in sweep.items() if k != "none"}}
 
     if rank == 0:
-        kms = ms[:6]
+        kms_raw = ms[:6]
         cnt = ms[6:12]
+        kms = [max(kms_raw[i] - pair_ms * cnt[i], 0.0) for i in range(6)]      # the bracket's own share out (event_pair_overhead_ms)
         tot = sum(kms) or 1.0
         dom = max(range(6), key=lambda i: kms[i])
         R = N * A
@@ -416,8 +457,6 @@ def main():
         split = os.environ.get("MQE_GEMM_SPLIT", "1") != "0"
         d = eng.desc
         h_a, h_b = d.adaptation.dims[1], d.body.dims[1]
-        pe = max(prof_every, 1)                                        # env steps whose launches were bracketed: the third of every `prof_every` (mqe_engine.hip prof_phase)
-        sampled = max(1, sum(1 for i in range(args.steps) if i % pe == (2 if pe > 2 else 0)))
 
         def avg_ms(i):
             return kms[i] / max(cnt[i], 1)
@@ -519,7 +558,7 @@ def main():
                                                                                   "gathers": gathers_contract, "gathers_incl_long_run_and_sweep": n_gathers[0]}),
             "target_env_steps_per_s": 1.0e6,
             "contact_solver": {0: "pgs: velocity-level projected Gauss-Seidel, erp %.2f" % d.erp, 1: "tgs: temporal Gauss-Seidel, %d sub-steps of dt / %d (sim.physx.solver_type = 1)" % (d.solver_iterations, d.solver_iterations)}[int(d.solver_type)],
-            "value_long": long_run["value"] if long_run else None, "long_run": long_run,
+            "value_long": long_run["value"] if long_run else None, "ms_per_step_long": long_run["ms_per_step"] if long_run else None, "long_run": long_run,
             "gather_schedule_sweep": sweep,
             "binary": binary_info(),
             "physical_robot_steps_per_s": round(value * env.env.num_agents / A, 1),
@@ -530,8 +569,13 @@ def main():
             "hbm_step_algorithmic_frac": round(step_bytes * args.steps / elapsed / 1e9 / PEAK_HBM_GBS, 5),
             "kernel_time_share": {PROF_NAMES[i]: round(kms[i] / tot, 4) for i in range(6)},
             "gpu_busy_ms_per_step": round(tot / sampled, 4),
-            "contact_overflow_substeps": overflow_substeps,      # env-substeps whose bounded contact list was truncated (of envs x 4 x steps)
-            "hip_event_sampling": f"kernel classes of every {prof_every}-th timed step bracketed" if prof_every else "off",
+            "gpu_busy_ms_per_step_raw_event_times": round(sum(kms_raw) / sampled, 4),
+            # the kernel classes' GPU time per step cannot exceed the un-bracketed step (which also holds the gaps between the launches)
+            "gpu_busy_le_ms_per_step": bool(tot / sampled <= (long_run["ms_per_step"] if long_run else 1e3 * elapsed / args.steps) * 1.001) if prof_on else None,
+            "contact_overflow_substeps": overflow_substeps,      # env-substeps in which a touching pair found no slot (of envs x 4 x steps)
+            "contact_reduced_substeps": reduced_substeps,        # env-substeps in which a robot's one-sided contacts were reduced to its deepest eight
+            "hip_event_sampling": (f"{sampled} steps bracketed (one per period of 4) AFTER the timed regions; an empty event pair reads {pair_ms:.4f} ms on this stream, "
+                                   "subtracted per launch (raw sums beside)") if prof_on else "off",
             "dtype_note": "state and physics: f32.  Policy layer 0 + tail and (round 5) layer 2 of the actuator network: f32 operands carried as two f16 planes "
                           "(22 significand bits, 3 MFMA terms), held to the same 5e-5 bound as exact f32; strict_f32 = the same run on the exact-f32 kernels",
         }

@@ -25,7 +25,13 @@
 extern "C" {
 #endif
 
-#define MQE_ABI_VERSION 14
+/* Bumped on EVERY change of a limit, an export, a descriptor field or the meaning of a call (a binding compiled against another header is
+ * refused by mqe_sim_create and can compare mqe_abi_limits() with the constants it was built with).  v15 (round 6) over v14: mqe_abi_limits
+ * (new export); MQE_MAX_NPCS 16 and mqe_debug_tail_times / mqe_profile_enable(on = N) as shipped late in round 5 under v14; an env's contact
+ * list holds the sum of its per-actor caps (+ 8 two-actor slots in scenes of more than four actors, at most 64) instead of min(40, .), and
+ * mqe_sim_create refuses a scene whose caps exceed 64; edge_contacts bit 8 + MQE_T_CONTACT_REDUCED (new tensor): optional manifold reduction of a
+ * robot's one-sided contacts to its DEEPEST eight instead of the first eight in feature order. */
+#define MQE_ABI_VERSION 15
 #define MQE_MAX_SPHERES 64    /* feature points of one robot (the capsule model has 32, the exact one 60) */
 #define MQE_MAX_PRIMS 20      /* collision primitives of one robot (Go1: 18) */
 #define MQE_MAX_SELF_PAIRS 384
@@ -190,7 +196,12 @@ typedef struct {
    * boxes of the scene (1-dof link plank / door, free box, scenery boxes): the closest point of the whole segment, not of its two end
    * points; 4 = the twelve edges of those boxes against the robots' box primitives (off by default: desc builder default 3).  The closest approach of a segment to a convex box
    * is a one-dimensional convex minimisation: both engines run the same 18-evaluation golden-section search.  Such a contact is kept
-   * when it lies BETWEEN feature points (segment parameter inside 5 .. 95 %); 0 = round 3's behaviour. */
+   * when it lies BETWEEN feature points (segment parameter inside 5 .. 95 %); 0 = round 3's behaviour.
+   * Bit 8 (round 6, off by default; not an edge contact, it shares the contact-generation option word): manifold reduction -- a robot that
+   * touches the static world at more points than its eight one-sided slots keeps the DEEPEST ones (separation in classes of 2 mm centred on
+   * zero, so that the contacts of a body at rest tie; ties in feature order) instead of the first eight in feature order, counted in
+   * MQE_T_CONTACT_REDUCED instead of MQE_T_CONTACT_OVERFLOW.  Built in both engines and parity-tested; not the default because a robot
+   * collapsed on its belly rests worse with it under the velocity-level solver. */
   int32_t edge_contacts;
   const float* wall_corner;
   float soft_dof_pos_limit;               /* rewards.soft_dof_pos_limit (legged_robot.py:317-321): fraction of the URDF joint range
@@ -287,6 +298,10 @@ enum {
   MQE_T_ENV_ORIGINS,       /* [N,3] the LIVE env origins (legged_robot.py:495): what the NPCs respawn around and the football / push-box
                               wrappers subtract; equal to desc.env_origins unless the terrain curriculum has moved an env */
   MQE_T_TERRAIN_LEVELS,    /* int32 [N] terrain level of each env (legged_robot.py:983,490) */
+  MQE_T_CONTACT_REDUCED,   /* int32 [N]: with edge_contacts bit 8: substeps so far in which a robot of the env touched the static world at more
+                            * points than its eight one-sided slots and the set was reduced to the DEEPEST eight (2 mm classes, ties in feature
+                            * order: feet first); MQE_T_CONTACT_OVERFLOW then counts only what is dropped in list order (NPC caps, the two-actor
+                            * share, the end of the list).  Without the bit (default): always zero, robots' extra contacts count as overflow */
   MQE_T_COUNT
 };
 
@@ -301,6 +316,10 @@ typedef struct mqe_sim mqe_sim;
 
 const char* mqe_last_error(void);
 int mqe_abi_version(void);
+/* the compile-time limits of the library, for a binding to compare with the header it was built against: writes up to n of
+ * { MQE_ABI_VERSION, MQE_MAX_AGENTS, MQE_MAX_NPCS, MQE_MAX_SPHERES, MQE_MAX_PRIMS, MQE_MAX_SELF_PAIRS, MQE_MAX_LAYERS, MQE_MAX_REWARD_TERMS,
+ *   MQE_NBODY, MQE_NREP, MQE_NDOF, MQE_FRAME, MQE_HIST, MQE_T_COUNT } and returns how many there are (14) */
+int mqe_abi_limits(int32_t* out, int n);
 int mqe_sizeof_desc(void);   /* sizeof(mqe_sim_desc): lets a foreign-language binding verify its struct mirror */
 
 /* gym.create_sim + load_asset + create_env/create_actor + add_triangle_mesh + prepare_sim
@@ -394,7 +413,7 @@ int mqe_step_joint(mqe_sim* s, const float* actions12, void* stream);
  * ground (slab or relief), the wall prisms, the OTHER robots' collision primitives, free NPCs, the 1-dof link, the scenery boxes -- a ray
  * caster (csrc/kernels_camera.hpp), not the reference's rasteriser, which is closed: the image is SPECIFIED by the scalar caster of the CPU
  * oracle (oracle/mqe_oracle.c: mqo_render_depth -- conventions, surfaces, marching rules), which passes geometric known answers on its own
- * (tests/test_camera_oracle.py); the kernel equals it pixel by pixel (tests/test_camera_gpu.py).  Colour images (IMAGE_COLOR) are not offered. */
+ * (tests/test_camera_oracle.py); the kernel is held to it per pixel on 8 scenes (tests/test_camera_gpu.py: <= 0.2 % of the pixels -- silhouettes -- may differ in hit / miss or depth, the rest agree to 1e-4 m + 1e-5 relative).  Colour images (IMAGE_COLOR) are not offered. */
 int mqe_render_depth(mqe_sim* s, float* out_dev, int height, int width, float horizontal_fov_deg, const float* cam_pos3, const float* cam_rpy3,
                      float far_m, void* stream);
 

@@ -297,7 +297,13 @@ __device__ __forceinline__ void con_store(float* cr, int a, int linkA, int b, in
   c4[3] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(repB));
 }
 
-__host__ __device__ inline int mqe_maxc(int A, int P, int cap_npc) { int v = 8 * A + cap_npc * P; return v > 40 ? 40 : v; }
+// Contact slots of an env = the sum of the per-actor caps of its one-sided contacts (8 per robot, cap_npc per NPC) -- the pool the two-actor
+// contacts share (at most half of it) in the scenes of at most four actors -- plus, for the larger scenes (flocks, 2 vs 2 + ball), eight slots
+// that only two-actor contacts can take: a packed flock under two fallen robots fills every one-sided slot and still keeps its robot-sheep
+// contacts.  One lane per contact in the sweep: at most 64; mqe_sim_create refuses a scene whose caps do not fit (round 5 clipped the
+// sum at 40, so the last sheep of a 16-sheep flock could lose their ground contacts).
+__host__ __device__ inline int mqe_maxc_uncapped(int A, int P, int cap_npc) { return 8 * A + cap_npc * P + (A + P > 4 ? 8 : 0); }
+__host__ __device__ inline int mqe_maxc(int A, int P, int cap_npc) { const int v = mqe_maxc_uncapped(A, P, cap_npc); return v > 64 ? 64 : v; }
 #define MQE_LIMIT_PASSES 4   // Gauss-Seidel passes of the joint position / speed limits per substep (oracle: the same constant)
 #define CAP_ROBOT 8     // terrain / static-object contacts kept per robot (spheres are priority ordered: feet first)
 // NPCs keep m->cap_npc one-sided contacts each (2; a box resting on a face 4): per-actor caps so that no actor starves the ones after it
@@ -482,6 +488,10 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   const float mu_env = st.dparams[(size_t)e * A * 8];
   // (no initial values for what is only read where it has been written -- Rm, bp, bw, bvp of a body lane; the joint frame of a joint lane: a
   // constant costs one v_mov per register and substep for the whole wavefront.  The base lanes do read bax / bal / bap = 0.)
+  // (ADVICE r5 asked for defined values here.  Both ways of giving them one were built in round 6 and cost what the zeros cost: a frozen value
+  // (__builtin_nondeterministic_value) +66, the output of an empty asm statement +63 static vector instructions in the substep -- the register
+  // allocator materialises either.  Left as they are: every consumer of these registers is guarded by the lane's role, the wave shifts and the
+  // unconditional cross product at "Sv =" only move / combine bits that nobody reads.)
   float Rm[9];
   V3 bp, bw, bvp, bax = v3(0, 0, 0), bal = bax, bap = bax, bc = bax;
   float Iw[6] = {0, 0, 0, 0, 0, 0};
@@ -949,6 +959,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   // ---- contact generation: terrain (ground plane, wall SDF), canonical order --------------------------------------------
   int nc = 0;
   int ovf = 0;                      // wave-uniform: a touching pair did not fit the bounded list (per-actor cap or list end)
+  int red = 0;                      // per env: a robot's one-sided contacts were reduced to the deepest CAP_ROBOT (MQE_T_CONTACT_REDUCED)
   // Passes over whole actors, lane = sphere: two robots per pass (2 x 27 spheres), all single-sphere NPCs in one pass
   // (multi-sphere NPCs: one per pass).  The list order stays canonical -- actor by actor, sphere by sphere, ground /
   // wall / platform / column -- because a lane's slot = contacts of earlier groups (capped) + its rank in its group.
@@ -1122,6 +1133,46 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
         bflag = bsd < HF(HOT_CONTACT_OFFSET) && m->ss_base_half[0] > 0.0f;       // no platform: tug-of-war slider
         const float dx = c.x - ssB.x, dy = c.y - ssB.y, rho = sqrtf(dx * dx + dy * dy);
         if (c.z < ssB.z && c.z > ssB.z - m->ss_col_length && rho > 1e-6f) { csd = rho - m->ss_col_radius - rad; cn3 = v3(dx / rho, dy / rho, 0); cflag = csd < HF(HOT_CONTACT_OFFSET); }
+      }
+    }
+    // ---- desc.edge_contacts bit 8 (round 6, off by default): a robot that touches the static world at more points than it has slots keeps the
+    // DEEPEST ones (otherwise, as in rounds 1-5: the first ones in feature order, the rest counted as overflow).  Depth in classes of 2 mm centred on zero (the contacts of a body at rest tie), ties in the canonical order (feature by
+    // feature: ground, wall, platform, column; then the edge contacts, primitive by primitive) -- the steps keep the choice the same in
+    // the oracle and here when a body lies flat and many separations agree to rounding.  Rare (a fallen robot): one wave-uniform test per
+    // pass; the ranking walks the wavefront's candidates with v_readlane (oracle/mqe_oracle.c "manifold reduction").
+    if (rob && (HI(HOT_EDGE_MASK) & 8) != 0) {
+      const unsigned long long wg = __ballot(gflag), ww = __ballot(wflag), wb = __ballot(bflag), wc = __ballot(cflag), we = (HI(HOT_EDGE_MASK) & 7) != 0 ? __ballot(eflag) : 0ull;
+      const unsigned long long mine_m = EPW == 1 ? gm : (gm << (grp * LW));                  // my robot's lanes, as lanes of the wavefront
+      const int cnt = __popcll(wg & mine_m) + __popcll(ww & mine_m) + __popcll(wb & mine_m) + __popcll(wc & mine_m) + __popcll(we & mine_m);
+      const bool over = cnt > cap && act >= 0;
+      if (__ballot(cnt > cap) != 0ull) {
+        auto bucket = [](float sd) -> int { return (int)floorf((sd + 1e-3f) * 500.0f); };
+        const int lw = lane_wave;
+        const int kb[5] = {bucket(gsd), bucket(wsd), bucket(bsd), bucket(csd), bucket(esd)};
+        int rk[5] = {0, 0, 0, 0, 0};
+        unsigned long long um = wg | ww | wb | wc | we;
+        while (um != 0ull) {
+          const int j = __ffsll((long long)um) - 1;                 // wave-uniform
+          um &= um - 1ull;
+          const bool same = ((mine_m >> j) & 1ull) != 0ull;          // candidate lane j belongs to my robot
+          const int bj[5] = {__builtin_amdgcn_readlane(kb[0], j), __builtin_amdgcn_readlane(kb[1], j), __builtin_amdgcn_readlane(kb[2], j),
+                             __builtin_amdgcn_readlane(kb[3], j), __builtin_amdgcn_readlane(kb[4], j)};
+          const bool fj[5] = {((wg >> j) & 1ull) != 0ull, ((ww >> j) & 1ull) != 0ull, ((wb >> j) & 1ull) != 0ull, ((wc >> j) & 1ull) != 0ull, ((we >> j) & 1ull) != 0ull};
+#pragma unroll
+          for (int t2 = 0; t2 < 5; t2++) {
+            if (!fj[t2]) continue;                                   // wave-uniform
+            const int keyj = (t2 == 4 ? 4096 : 0) + j * 4 + (t2 == 4 ? 0 : t2);
+#pragma unroll
+            for (int t = 0; t < 5; t++) {
+              const int keym = (t == 4 ? 4096 : 0) + lw * 4 + (t == 4 ? 0 : t);
+              rk[t] += (int)(same && (bj[t2] < kb[t] || (bj[t2] == kb[t] && keyj < keym)));
+            }
+          }
+        }
+        if (over) {
+          gflag = gflag && rk[0] < cap; wflag = wflag && rk[1] < cap; bflag = bflag && rk[2] < cap; cflag = cflag && rk[3] < cap; eflag = eflag && rk[4] < cap;
+          red = 1;
+        }
       }
     }
     const unsigned long long bg = gballot(gflag), bw2 = gballot(wflag), bb2 = gballot(bflag), bc2 = gballot(cflag);
@@ -2330,6 +2381,9 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   }
   if (no_write) return;
   if (ovf && lane == 0 && evalid) st.overflow[e] += 1;          // MQE_T_CONTACT_OVERFLOW: this substep's list was truncated
+  if (__ballot(red != 0 && evalid) != 0ull) {                   // MQE_T_CONTACT_REDUCED (second half of the same buffer): per env of the wavefront
+    if (gballot(red != 0) != 0ull && lane == 0 && evalid) st.overflow[HI(HOT_N) + e] += 1;
+  }
 
   // ---- net contact force per reported body (deterministic: contact order) ---------------------------------------------------
   if ((flags & PS_WRITE_CF) && evalid) {
@@ -2654,7 +2708,7 @@ __global__ void __launch_bounds__(64, EPW == 2 ? 2 : SubstepsClass<TP>::waves) k
       const int w = i / nj, jt = i - w * nj;
       st.act_hist[(size_t)w * R12 + (size_t)e * nj + jt] = acth[i];
     }
-  if constexpr ((ShapeClass<TP>::small || TP > 0) && !(TA == 2 && EPW == 2)) if (pa.on) {      // (every kernel of the 16-envs-per-CU class; with the DevState pointers in register pairs of their own none of them spills)
+  if constexpr (ShapeClass<TP>::small || TP > 0) if (pa.on) {      // (every kernel of the 16-envs-per-CU class; with the DevState pointers in register pairs of their own none of them spills)
     // ---- post_physics_step of this wavefront's env(s) (legged_robot.py:117-157 + the task wrapper), from the state just written: the
     // writer and the readers are lanes of this one wavefront (one CU, one vector L1), a workgroup-scope fence orders them
     __threadfence_block();

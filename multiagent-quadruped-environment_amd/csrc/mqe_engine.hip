@@ -86,6 +86,13 @@ struct mqe_sim {
 
 extern "C" const char* mqe_last_error(void) { return g_err; }
 extern "C" int mqe_abi_version(void) { return MQE_ABI_VERSION; }
+extern "C" int mqe_abi_limits(int32_t* out, int n) {
+  const int32_t v[] = {MQE_ABI_VERSION, MQE_MAX_AGENTS, MQE_MAX_NPCS, MQE_MAX_SPHERES, MQE_MAX_PRIMS, MQE_MAX_SELF_PAIRS, MQE_MAX_LAYERS, MQE_MAX_REWARD_TERMS,
+                       MQE_NBODY, MQE_NREP, MQE_NDOF, MQE_FRAME, MQE_HIST, MQE_T_COUNT};
+  const int cnt = (int)(sizeof v / sizeof v[0]);
+  for (int i = 0; i < cnt && i < n; i++) out[i] = v[i];
+  return cnt;
+}
 extern "C" int mqe_sizeof_desc(void) { return (int)sizeof(mqe_sim_desc); }
 
 template <typename T>
@@ -350,6 +357,7 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
     if (d->robot.prim_type[d->robot.sphere_prim[f]] == MQE_PRIM_SPHERE) m.feat_sphere_mask |= 1ull << f;
   if (d->robot.n_spheres > MQE_MAX_SPHERES || d->robot.n_prims > MQE_MAX_PRIMS || d->robot.n_self_pairs > MQE_MAX_SELF_PAIRS) return fail(-6, "robot model: too many feature points / primitives / self-collision pairs");
   m.maxc = mqe_maxc(A, P, m.cap_npc);
+  if (mqe_maxc_uncapped(A, P, m.cap_npc) > 64) return fail(-4, "the per-actor contact caps of this scene (8 per robot + cap per NPC + 8 two-actor slots) exceed the 64 contact lanes of the wavefront that owns an env");
   if (m.ndof_env > 128 || m.nbody_env > 64) { return fail(-4, "env has more than 64 bodies or 128 generalized velocities: does not fit one wavefront"); }
   m.rowgs = (A + m.n_npc_dyn + (seesaw ? 1 : 0) <= 4) ? 1 : 0;      // one 16-lane row per actor; the <A,0> / <2,LINK> kernels assume it
   if (getenv("MQE_LANE_SWEEP")) m.rowgs = 0;      // tests: the other lane mapping of the contact sweep on the same scene (tests/test_gpu_parity.py)
@@ -421,7 +429,7 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
     // +1.5 %).  NOT go1football-defender, whose 4096 envs run in two rounds: both pay the epilogue's ~10 us chain, -1 % (MQE_FUSE_POST_ALL=1 tries it)
     const bool flock = shape == SH_A2_NPC || shape == SH_A4_NPC;
     const bool defender = shape == SH_A3_NPC_ROW;
-    s->fuse_post = s->fuse_substeps && getenv("MQE_NO_FUSE_POST") == nullptr && !m.curriculum && !(shape == SH_A2 && s->substeps_epw == 2) &&
+    s->fuse_post = s->fuse_substeps && getenv("MQE_NO_FUSE_POST") == nullptr && !m.curriculum &&
                    (robots_only || (getenv("MQE_FUSE_POST_ROBOTS_ONLY") == nullptr &&
                                     (few || (getenv("MQE_FUSE_POST_SMALL_ONLY") == nullptr && (flock || (getenv("MQE_FUSE_POST_ALL") != nullptr && defender))))));
   }
@@ -455,8 +463,8 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   UP(m.wall_sdf, d->wall_sdf, (size_t)d->sdf_nx * d->sdf_ny);
   UP(m.ground_height, d->ground_height, (size_t)d->sdf_nx * d->sdf_ny);
   UP(m.wall_top, d->wall_top, (size_t)d->sdf_nx * d->sdf_ny);
-  if (d->edge_contacts & ~7) return fail(-6, "edge_contacts: bits 1 (wall edges), 2 (capsule axes against the scene's boxes) and 4 (box edges against box primitives)");
-  m.edge_mask = d->edge_contacts & 7;
+  if (d->edge_contacts & ~15) return fail(-6, "edge_contacts: bits 1 (wall edges), 2 (capsule axes against the scene's boxes), 4 (box edges against box primitives) and 8 (manifold reduction to the deepest contacts)");
+  m.edge_mask = d->edge_contacts & 15;
   m.wall_corner = nullptr;
   if ((m.edge_mask & 1) && d->wall_corner) { UP(m.wall_corner, d->wall_corner, (size_t)d->sdf_nx * d->sdf_ny * 2); }
   for (int q = 0; q < MQE_MAX_PRIMS; q++) {       // feature points on a capsule's axis strictly between its ends (the thigh's middle): an edge contact next to one would duplicate it
@@ -621,7 +629,7 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   DA(st.gait, R); DA(st.clock, (size_t)R * 4); DA(st.blv, (size_t)R * 3); DA(st.bav, (size_t)R * 3); DA(st.pg, (size_t)R * 3);
   DA(st.bquat, (size_t)R * 4); DA(st.obs_bag, (size_t)R * MQE_OBS_BAG); DA(st.wobs, (size_t)N * s->Aw * s->D + (size_t)N * s->Aw + (N + 3) / 4); st.wrew = st.wobs + (size_t)N * s->Aw * s->D; st.wdone = (uint8_t*)(st.wrew + (size_t)N * s->Aw);   // one buffer: obs | reward | done (N bytes)
   DA(st.rsum, (size_t)N * MQE_MAX_REWARD_TERMS); DA(st.sheep_avg, (size_t)N * 2); DA(st.sheep_var, N);
-  DA(st.sub_dof_vel, (size_t)N * 4 * 12 * A); DA(st.sub_exceed, (size_t)N * 4 * 12 * A); DA(st.overflow, N);
+  DA(st.sub_dof_vel, (size_t)N * 4 * 12 * A); DA(st.sub_exceed, (size_t)N * 4 * 12 * A); DA(st.overflow, 2 * (size_t)N);      /* [0, N): MQE_T_CONTACT_OVERFLOW, [N, 2 N): MQE_T_CONTACT_REDUCED */
   DA(st.sub_tau, (size_t)N * 4 * 12 * A); DA(st.npc_noise, (size_t)N * (P ? P : 1) * 3);
   DA(st.w_last, (size_t)N * MQE_MAX_AGENTS); DA(st.w_last2, (size_t)N * 2); DA(st.cmd, (size_t)R * 3);
   DA(st.ep_len, N); DA(st.reset_count, N); DA(st.last_dof_vel, (size_t)R * 12);
@@ -686,6 +694,7 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   t[MQE_T_DOMAIN_PARAMS] = st.dparams;
   t[MQE_T_SUBSTEP_DOF_VEL] = st.sub_dof_vel; t[MQE_T_SUBSTEP_EXCEED_DOF_POS_LIMITS] = st.sub_exceed; t[MQE_T_CONTACT_OVERFLOW] = st.overflow;
   t[MQE_T_ENV_ORIGINS] = st.env_origins_live; t[MQE_T_TERRAIN_LEVELS] = st.terrain_levels;
+  t[MQE_T_CONTACT_REDUCED] = st.overflow + s->N;
   HIPCHK(hipDeviceSynchronize());
   guard.s = nullptr;
   *out = s;
@@ -733,7 +742,7 @@ extern "C" int mqe_sim_tensor(mqe_sim* s, int kind, mqe_tensor_view* v) {
     case MQE_T_SHEEP_POS_VAR: SH(1, N, 0, 0, 0, 0); break;
     case MQE_T_SUBSTEP_TORQUES: case MQE_T_SUBSTEP_DOF_VEL: SH(3, N, 4, 12 * A, 0, 0); break;
     case MQE_T_SUBSTEP_EXCEED_DOF_POS_LIMITS: SH(3, N, 4, 12 * A, 0, 2); break;
-    case MQE_T_CONTACT_OVERFLOW: case MQE_T_TERRAIN_LEVELS: SH(1, N, 0, 0, 0, 1); break;
+    case MQE_T_CONTACT_OVERFLOW: case MQE_T_TERRAIN_LEVELS: case MQE_T_CONTACT_REDUCED: SH(1, N, 0, 0, 0, 1); break;
     case MQE_T_ENV_ORIGINS: SH(2, N, 3, 0, 0, 0); break;
     case MQE_T_NPC_NOISE: SH(3, N, P, 3, 0, 0); break;
     case MQE_T_WRAPPER_PACKED: SH(1, N * s->Aw * s->D + N * s->Aw + (N + 3) / 4, 0, 0, 0, 0); break;

@@ -1,7 +1,7 @@
 """ctypes mirror of include/mqe_hip.h (keep in sync; tests/test_abi.py checks sizes against the built library)."""
 import ctypes as C
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 MAX_SPHERES, NBODY, NREP, NDOF = 64, 13, 17, 12
 MAX_SELF_PAIRS = 384
 MAX_PRIMS = 20
@@ -20,7 +20,7 @@ POST_FRAME, POST_NPC, POST_RESET, POST_OBS, POST_WRAPPER, POST_ALL, POST_WRAPPER
  T_BASE_ANG_VEL, T_PROJECTED_GRAVITY, T_BASE_QUAT, T_EPISODE_LENGTH, T_RESET_BUF, T_COLLIDE_BUF, T_TIME_OUT_BUF,
  T_R_TERM, T_P_TERM, T_Z_HIGH_TERM, T_OBS_BAG, T_WRAPPER_OBS, T_WRAPPER_REWARD, T_REWARD_SUMS, T_SHEEP_POS_AVG,
  T_SHEEP_POS_VAR, T_RESET_COUNT, T_SUBSTEP_TORQUES, T_NPC_NOISE, T_WRAPPER_PACKED, T_DOMAIN_PARAMS, T_SUBSTEP_DOF_VEL,
- T_SUBSTEP_EXCEED_DOF_POS_LIMITS, T_CONTACT_OVERFLOW, T_ENV_ORIGINS, T_TERRAIN_LEVELS, T_COUNT) = range(41)
+ T_SUBSTEP_EXCEED_DOF_POS_LIMITS, T_CONTACT_OVERFLOW, T_ENV_ORIGINS, T_TERRAIN_LEVELS, T_CONTACT_REDUCED, T_COUNT) = range(42)
 
 # slices of one OBS_BAG row (compute_observations, reference go1.py:153-196)
 BAG = dict(base_pos=(0, 3), base_rpy=(3, 6), dof_pos=(6, 18), dof_vel=(18, 30), lin_vel=(30, 33), ang_vel=(33, 36),

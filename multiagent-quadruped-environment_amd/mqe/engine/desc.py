@@ -353,6 +353,8 @@ def build_desc(cfg, num_envs, terrain, env_origins, agent_origins, gate_pos=None
         d.wall_top = _fp(wt, keep)
     # edge contacts (include/mqe_hip.h edge_contacts): on by default; MQE_EDGE_CONTACTS=<mask> overrides (0: round 3's feature-point tests only)
     d.edge_contacts = int(os.environ.get("MQE_EDGE_CONTACTS", edge_contacts if edge_contacts is not None else 3))        # (bit 4, box edges against box primitives: available, off by default)
+    if os.environ.get("MQE_CONTACT_REDUCTION", "0") not in ("0", ""):      # bit 8: manifold reduction of a robot's one-sided contacts to its deepest eight (off by default)
+        d.edge_contacts |= 8
     wc = getattr(terrain, "wall_corner", None)
     if wc is not None and (d.edge_contacts & 1):
         assert wc.shape == terrain.wall_sdf.shape + (2,)

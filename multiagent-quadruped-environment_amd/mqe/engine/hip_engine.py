@@ -189,7 +189,9 @@ class HipEngine(EngineBase):
         return minv, con[:nc.value]
 
     def profile_enable(self, on=True):
-        """on: False/0 = off, True/1 = bracket every fused step with HIP events, k > 1 = every k-th fused step."""
+        """on: False/0 = off, True/1 = bracket every fused step with HIP events, k > 1 = one fused step per period of k (the THIRD of each
+        period, so that a run's first steps -- allocator and clock warm-up -- are never the sample; a run shorter than three steps with k > 2
+        records nothing: profile_read() then returns cnt == 0 and callers must handle that)."""
         self._call("profile_enable", int(on))
 
     def profile_read(self, n=16):

@@ -209,8 +209,9 @@ class Go1:
         self.obs_buf = ObsBag(self.cfg.obs, T(abi.T_OBS_BAG), self.env_info if self.env_info else None)
         self.privileged_obs_buf = None
         # extras["episode"]: a plain dict.  With the run-time terrain curriculum on, "terrain_level" is a REAL 0-dim device tensor (upstream
-        # stores torch.mean(terrain_levels.float()), _fill_extras, legged_robot.py:1069-1071), refreshed in place after every reset / step
-        # (levels only move inside resets), so .items(), .get(), dict(...) and ** all see the value -- one tiny launch, on that path only
+        # stores torch.mean(terrain_levels.float()), _fill_extras, legged_robot.py:1069-1071): a FRESH tensor after every reset / step, as
+        # upstream assigns one per reset (refreshed in place, a logger that kept the object saw its past entries change), so
+        # .items(), .get(), dict(...) and ** all see the current value -- two tiny launches, on that path only
         self.extras = {"time_outs": self.time_out_buf, "episode": {}, "contact_overflow": self.contact_overflow}
         if self.engine.desc.terrain_curriculum:
             self.extras["episode"]["terrain_level"] = torch.zeros((), device=dev)
@@ -224,7 +225,7 @@ class Go1:
     def _refresh_extras(self):
         ep = self.extras["episode"]
         if "terrain_level" in ep:
-            torch.mean(self.terrain_levels.float(), dim=0, out=ep["terrain_level"])
+            ep["terrain_level"] = torch.mean(self.terrain_levels.float())
 
     # ---- derived views ------------------------------------------------------------------------------------------
     @property

@@ -36,7 +36,7 @@ typedef REAL real;
 #define RD 18                       /* dofs of one robot: 3 lin + 3 ang + 12 joints */
 #define MAXDOF (MAXA * RD + MAXP * 6 + 1)
 #define MAXC 64                     /* storage; the active bound is env_maxc() */
-static inline int env_maxc(int A, int P, int cap_npc) { int v = 8 * A + cap_npc * P; return v > 40 ? 40 : v; } /* = mqe_maxc() of the engine */
+static inline int env_maxc(int A, int P, int cap_npc) { int v = 8 * A + cap_npc * P + (A + P > 4 ? 8 : 0); return v > 64 ? 64 : v; } /* = mqe_maxc() of the engine: per-actor caps + eight pair-only slots in scenes of more than four actors */
 #define LIMIT_PASSES 4 /* Gauss-Seidel passes of the joint position / speed limits per substep (= MQE_LIMIT_PASSES of the engine) */
 #define CAP_ROBOT 8   /* terrain / static-object contacts kept per robot (spheres are priority ordered: feet first) */
 #define FR MQE_FRAME
@@ -47,6 +47,10 @@ const char* mqo_last_error(void) { return g_err; }
 int mqo_sizeof_desc(void) { return (int)sizeof(mqe_sim_desc); }
 int mqo_num_threads(void);
 void mqo_set_num_threads(int n);
+/* the checker's own team size (omp_set_num_threads would change every other OpenMP user of the process -- torch's CPU ops share
+ * libgomp): 0 = the runtime's default; the parallel regions below carry it as their num_threads clause */
+static int g_team = 0;
+static inline int mqo_team(void);
 
 typedef struct {
   int n_layers;
@@ -362,7 +366,7 @@ int mqo_sim_create(const mqe_sim_desc* d, mqo_sim** out) {
   s->sub_tau = ALLOCF((size_t)N * 4 * 12 * A);
   s->sub_dof_vel = ALLOCF((size_t)N * 4 * 12 * A);
   s->sub_exceed = (uint8_t*)calloc((size_t)N * 4 * 12 * A, 1);
-  s->overflow = (int32_t*)calloc(N, 4);
+  s->overflow = (int32_t*)calloc(2 * (size_t)N, 4);      /* [0, N): MQE_T_CONTACT_OVERFLOW, [N, 2 N): MQE_T_CONTACT_REDUCED */
   if (getenv("MQO_WARM_START") && atof(getenv("MQO_WARM_START")) > 0) {      /* EXPERIMENT, see mqo_sim::warm */
     s->warm = (float)atof(getenv("MQO_WARM_START"));
     s->wc_n = (int32_t*)calloc(N, 4); s->wc_key = (int32_t*)calloc((size_t)N * MAXC * 5, 4);
@@ -423,6 +427,7 @@ int mqo_sim_create(const mqe_sim_desc* d, mqo_sim** out) {
   t[MQE_T_DOMAIN_PARAMS] = s->dparams;
   t[MQE_T_SUBSTEP_DOF_VEL] = s->sub_dof_vel; t[MQE_T_SUBSTEP_EXCEED_DOF_POS_LIMITS] = s->sub_exceed; t[MQE_T_CONTACT_OVERFLOW] = s->overflow;
   t[MQE_T_ENV_ORIGINS] = s->env_origins_live; t[MQE_T_TERRAIN_LEVELS] = s->terrain_levels;
+  t[MQE_T_CONTACT_REDUCED] = s->overflow + s->N;
   *out = s;
   return 0;
 }
@@ -458,7 +463,7 @@ int mqo_sim_tensor(mqo_sim* s, int kind, mqe_tensor_view* v) {
     case MQE_T_SHEEP_POS_VAR: SH(1, N, 0, 0, 0, 0); break;
     case MQE_T_SUBSTEP_TORQUES: case MQE_T_SUBSTEP_DOF_VEL: SH(3, N, 4, 12 * A, 0, 0); break;
     case MQE_T_SUBSTEP_EXCEED_DOF_POS_LIMITS: SH(3, N, 4, 12 * A, 0, 2); break;
-    case MQE_T_CONTACT_OVERFLOW: case MQE_T_TERRAIN_LEVELS: SH(1, N, 0, 0, 0, 1); break;
+    case MQE_T_CONTACT_OVERFLOW: case MQE_T_TERRAIN_LEVELS: case MQE_T_CONTACT_REDUCED: SH(1, N, 0, 0, 0, 1); break;
     case MQE_T_ENV_ORIGINS: SH(2, N, 3, 0, 0, 0); break;
     case MQE_T_NPC_NOISE: SH(3, N, P, 3, 0, 0); break;
     case MQE_T_WRAPPER_PACKED: SH(1, N * s->Aw * s->D + N * s->Aw + (N + 3) / 4, 0, 0, 0, 0); break;
@@ -503,7 +508,7 @@ int mqo_policy_step(mqo_sim* s, const float* command) {
     memcpy(s->hist + ((size_t)i * MQE_HIST + s->hist_pos) * FR, lo, FR * 4);  /* :102 (ring write) */
   }
   s->hist_pos = (s->hist_pos + 1) % MQE_HIST;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(mqo_team())
   for (int i = 0; i < R; i++) {
     float h[2100], lat[2], a12[12];
     gather_history(s, i, h);
@@ -522,7 +527,7 @@ int mqo_compute_torques(mqo_sim* s) {
   const mqe_sim_desc* d = &s->d;
   int R = s->R, A = s->A;
   float* e1 = s->act_hist; float* e2 = e1 + (size_t)R * 12; float* v1 = e2 + (size_t)R * 12; float* v2 = v1 + (size_t)R * 12;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(mqo_team())
   for (int i = 0; i < R; i++) {
     int env = i / A, a = i % A;
     for (int j = 0; j < 12; j++) {
@@ -751,7 +756,7 @@ typedef struct {
   real prim_c[MAXA][MQE_MAX_PRIMS][3], prim_u[MAXA][MQE_MAX_PRIMS][3];   /* robots' primitives: centre, capsule half-segment (world) */
   real npcR[MAXP][9];
   real v[MAXDOF], tau[MAXDOF];
-  contact_t con[MAXC];
+  contact_t con[MAXC + 320];          /* + room for a robot's one-sided candidates before their reduction to CAP_ROBOT */
   int nc;
 } envwork_t;
 
@@ -1020,10 +1025,21 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
    * wall; then sphere pairs for actor pairs (a<b), outer loop over b's spheres, inner over a's) */
   int nact = A + P;
   int ovf = 0;                          /* a touching pair did not fit the bounded list (MQE_T_CONTACT_OVERFLOW) */
+  int red = 0;                          /* a robot's one-sided contacts were reduced to the deepest CAP_ROBOT (MQE_T_CONTACT_REDUCED) */
   w->nc = 0;
   for (int act = 0; act < nact; act++) {
     int mine = 0;                       /* no actor may starve the ones after it */
     const int cap = act < A ? CAP_ROBOT : cap_npc;
+    /* manifold reduction (round 6; desc.edge_contacts bit 8, off by default): a ROBOT's one-sided contacts are collected first -- in the canonical order: feature by feature (ground,
+     * wall, platform, column), then the edge contacts primitive by primitive -- and when there are more than its slots the DEEPEST are kept:
+     * separation in classes of 2 mm centred on zero (a body lying flat keeps the same set from substep to substep: its touching points tie and fall back to the feature order), ties in the canonical order (feet first).  The kept ones enter the list in the canonical order.  (Rounds
+     * 1-5 kept the first CAP_ROBOT and counted the rest as overflow; an NPC's cap still works that way.)  The engine does the same with a
+     * ranking over the wavefront's candidate lanes (kernels_physics.hpp "keeps the DEEPEST ones"). */
+    const int robot_first = w->nc;
+    const int robot_cap = cap;
+    const int reduce = (d->edge_contacts & 8) != 0;      /* optional (include/mqe_hip.h edge_contacts bit 8); off: the first CAP_ROBOT in feature order, the rest is overflow */
+    const int cap_eff = (act < A && reduce) ? MAXC + 320 : cap;      /* robots then collect without a cap and reduce */
+#define cap cap_eff
     for (int si = 0; si < w->sph_n[act]; si++) {
       const real* c = w->sph_c[act][si];
       real r = w->sph_r[act][si];
@@ -1077,8 +1093,8 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
             sd = dist - r; n[0] = gx * sh / dist; n[1] = gy * sh / dist; n[2] = dz / dist;
           }
         }
-        if (sd < d->contact_offset && !(w->nc < maxc && mine < cap)) ovf = 1;
-        if (sd < d->contact_offset && w->nc < maxc && mine < cap) {
+        if (sd < d->contact_offset && !(w->nc < ((act < A && reduce) ? MAXC + 320 : maxc) && mine < cap)) ovf = 1;
+        if (sd < d->contact_offset && w->nc < ((act < A && reduce) ? MAXC + 320 : maxc) && mine < cap) {
           mine++;
           contact_t* ct = &w->con[w->nc++];
           memset(ct, 0, sizeof *ct);
@@ -1091,7 +1107,7 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
     }
     /* edge contacts of a robot with the static world (include/mqe_hip.h edge_contacts), primitive by primitive after its feature points:
      * per primitive the deepest of the nearest vertical wall edge and the static scenery boxes */
-    if (act < A && d->edge_contacts)
+    if (act < A && (d->edge_contacts & 7))
       for (int q = 0; q < m->n_prims; q++) {
         if (m->prim_type[q] == MQE_PRIM_SPHERE) continue;
         const real* cq = w->prim_c[act][q];
@@ -1120,8 +1136,8 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
           }
         }
         if (!got) continue;
-        if (sd < d->contact_offset && !(w->nc < maxc && mine < cap)) ovf = 1;
-        if (sd < d->contact_offset && w->nc < maxc && mine < cap) {
+        if (sd < d->contact_offset && !(w->nc < ((act < A && reduce) ? MAXC + 320 : maxc) && mine < cap)) ovf = 1;
+        if (sd < d->contact_offset && w->nc < ((act < A && reduce) ? MAXC + 320 : maxc) && mine < cap) {
           mine++;
           contact_t* ct = &w->con[w->nc++];
           memset(ct, 0, sizeof *ct);
@@ -1130,6 +1146,24 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
           for (int k = 0; k < 3; k++) { ct->n[k] = n[k]; ct->p[k] = pa[k]; }
         }
       }
+#undef cap
+    if (act < A && reduce && mine > robot_cap) {
+      int keep[MAXC + 320];
+      for (int i = 0; i < mine; i++) {
+        const int bi = (int)floor((double)(((float)w->con[robot_first + i].sd + 1e-3f) * 500.0f));
+        int rank = 0;
+        for (int j = 0; j < mine; j++) {
+          const int bj = (int)floor((double)(((float)w->con[robot_first + j].sd + 1e-3f) * 500.0f));
+          if (bj < bi || (bj == bi && j < i)) rank++;
+        }
+        keep[i] = rank < robot_cap;
+      }
+      int o = robot_first;
+      for (int i = 0; i < mine; i++)
+        if (keep[i]) { if (o != robot_first + i) w->con[o] = w->con[robot_first + i]; o++; }
+      w->nc = o;
+      red = 1;
+    }
   }
   /* two-actor contacts (plank, sphere pairs): at most maxc/2 of them (the engine slot-allocates their second side) */
   const int pair_lim = w->nc + maxc / 2 < maxc ? w->nc + maxc / 2 : maxc;
@@ -1478,6 +1512,7 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
   }
 
   if (ovf) s->overflow[env] += 1;
+  if (red) s->overflow[s->N + env] += 1;
   /* ---- net contact forces per reported body (gym.refresh_net_contact_force_tensor analogue) */
   float* cf = s->cf + (size_t)env * s->NBR * 3;
   memset(cf, 0, (size_t)s->NBR * 3 * 4);
@@ -1520,7 +1555,7 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
 }
 
 int mqo_simulate(mqo_sim* s) {
-#pragma omp parallel
+#pragma omp parallel num_threads(mqo_team())
   {
     envwork_t* w = (envwork_t*)malloc(sizeof(envwork_t));
 #pragma omp for schedule(static)
@@ -1539,9 +1574,9 @@ int mqo_debug_dynamics(mqo_sim* s, int env, int robot, float* M_out /*18x18*/, f
   float* r0 = (float*)dupmem(s->root + env * nr, nr * 4);
   float* d0 = (float*)dupmem(s->dof + env * ndf, ndf * 4);
   float* c0 = (float*)dupmem(s->cf + env * ncf, ncf * 4);
-  const int32_t ov0 = s->overflow[env];
+  const int32_t ov0 = s->overflow[env], rd0 = s->overflow[s->N + env];
   simulate_env(s, env, w);
-  s->overflow[env] = ov0;
+  s->overflow[env] = ov0; s->overflow[s->N + env] = rd0;
   memcpy(s->root + env * nr, r0, nr * 4); memcpy(s->dof + env * ndf, d0, ndf * 4); memcpy(s->cf + env * ncf, c0, ncf * 4);
   free(r0); free(d0); free(c0);
   const real* L = w->L[robot];
@@ -2298,7 +2333,7 @@ int mqo_render_depth(mqo_sim* s, float* out, int H, int W, float hfov_deg, const
     axis_angle_mat(ez, cam_rpy3[2], Rz); axis_angle_mat(ey, cam_rpy3[1], Ry); axis_angle_mat(ex, cam_rpy3[0], Rx);
     mat3_mul(Rz, Ry, T); mat3_mul(T, Rx, Rc);
   }
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(mqo_team())
   for (int e = 0; e < N; e++) {
     real LR[MAXA][NB][9], Lp[MAXA][NB][3];
     for (int r = 0; r < A; r++) link_frames(s, e, r, LR[r], Lp[r]);
@@ -2416,9 +2451,11 @@ int mqo_render_depth(mqo_sim* s, float* out, int H, int W, float hfov_deg, const
 
 #ifdef _OPENMP
 #include <omp.h>
-int mqo_num_threads(void) { return omp_get_max_threads(); }
-void mqo_set_num_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+static inline int mqo_team(void) { return g_team > 0 ? g_team : omp_get_max_threads(); }
+int mqo_num_threads(void) { return mqo_team(); }
+void mqo_set_num_threads(int n) { if (n > 0) g_team = n; }
 #else
+static inline int mqo_team(void) { return 1; }
 int mqo_num_threads(void) { return 1; }
-void mqo_set_num_threads(int n) { (void)n; }
+void mqo_set_num_threads(int n) { (void)n; (void)g_team; }
 #endif

@@ -33,6 +33,31 @@ def test_struct_mirror_size():
     assert oracle_engine.load_library().mqo_sizeof_desc() == C.sizeof(abi.SimDesc)
 
 
+def test_limits_agree_between_header_library_and_python_mirror():
+    """VERDICT r5 "Next" 8: a limit, an export or a call's meaning changes -> MQE_ABI_VERSION changes; the three places that state the limits
+    (include/mqe_hip.h, the built library through mqe_abi_limits, mqe/engine/abi.py) agree."""
+    h = open(os.path.join(ROOT, "include", "mqe_hip.h")).read()
+    hdr = {k: int(v) for k, v in re.findall(r"^#define (MQE_[A-Z_]+) (\d+)\b", h, re.M)}
+    hc = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
+    enum = hc[hc.index("MQE_T_ROOT_STATE"):hc.index("MQE_T_COUNT")]
+    t_count = len(set(re.findall(r"\bMQE_T_[A-Z_0-9]+\b", enum)))                       # enumerators before MQE_T_COUNT
+    lib = C.CDLL(LIB_PATH)
+    out = (C.c_int32 * 32)()
+    n = lib.mqe_abi_limits(out, 32)
+    names = ["MQE_ABI_VERSION", "MQE_MAX_AGENTS", "MQE_MAX_NPCS", "MQE_MAX_SPHERES", "MQE_MAX_PRIMS", "MQE_MAX_SELF_PAIRS", "MQE_MAX_LAYERS",
+             "MQE_MAX_REWARD_TERMS", "MQE_NBODY", "MQE_NREP", "MQE_NDOF", "MQE_FRAME", "MQE_HIST"]
+    assert n == len(names) + 1
+    got = dict(zip(names, list(out)[:len(names)]))
+    for k in names:
+        assert got[k] == hdr[k], (k, got[k], hdr[k])
+    assert out[len(names)] == abi.T_COUNT == t_count, (out[len(names)], abi.T_COUNT, t_count)
+    py = dict(MQE_ABI_VERSION=abi.ABI_VERSION, MQE_MAX_AGENTS=abi.MAX_AGENTS, MQE_MAX_NPCS=abi.MAX_NPCS, MQE_MAX_SPHERES=abi.MAX_SPHERES, MQE_MAX_PRIMS=abi.MAX_PRIMS,
+              MQE_MAX_SELF_PAIRS=abi.MAX_SELF_PAIRS, MQE_MAX_LAYERS=abi.MAX_LAYERS, MQE_MAX_REWARD_TERMS=abi.MAX_REWARD_TERMS, MQE_NBODY=abi.NBODY,
+              MQE_NREP=abi.NREP, MQE_NDOF=abi.NDOF, MQE_FRAME=abi.FRAME, MQE_HIST=abi.HIST)
+    assert py == {k: hdr[k] for k in py}
+    assert lib.mqe_abi_version() == hdr["MQE_ABI_VERSION"] >= 15
+
+
 def test_product_refuses_without_gpu():
     import pytest
     import torch

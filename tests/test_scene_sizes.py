@@ -75,6 +75,65 @@ def test_sixteen_sheep_flock_hip_matches_the_specification(solver):
         close(ch[:, 4:], co[:, 4:], atol=2e-5, what="contact separation / normal")
 
 
+def _pile_up(e, N):
+    """both robots lying on their sides in the middle of the flock, the sheep packed around them: every actor's one-sided contacts at their caps"""
+    root = e.tensor(abi.T_ROOT_STATE)
+    r = root.cpu().clone() if root.is_cuda else root.clone()
+    c = r[:, 2:, :2].mean(dim=1)                                   # flock centre
+    for a in range(2):
+        r[:, a, 0] = c[:, 0] + (0.35 if a else -0.35); r[:, a, 1] = c[:, 1]; r[:, a, 2] = 0.14
+        r[:, a, 3:7] = torch.tensor([0.70710678, 0.0, 0.0, 0.70710678])      # rolled 90 degrees about x: lying on the side
+        r[:, a, 7:] = 0.0
+    for p in range(16):                                              # a 4 x 4 grid at 0.36 m pitch (sheep radius 0.2: neighbours overlap), robots on top of it
+        r[:, 2 + p, 0] = c[:, 0] + ((p % 4) - 1.5) * 0.36; r[:, 2 + p, 1] = c[:, 1] + ((p // 4) - 1.5) * 0.36
+        r[:, 2 + p, 7:] = 0.0
+    root.copy_(r.to(root.device))
+
+
+def test_packed_flock_under_fallen_robots_keeps_every_contact_class():
+    """2 robots + 16 sheep have 8 * 2 + 2 * 16 = 48 one-sided slots -- round 5 clipped the list at 40, so with both robots down
+    and every sheep on the ground the last sheep lost their ground contacts and no robot-sheep contact fitted.  The list now holds the sum of the
+    per-actor caps plus eight slots only two-actor contacts can take (mqe_maxc)."""
+    N = 4
+    d, k, _ = make_desc("go1sheep-hard", N, cfg=flock_cfg(4, 4))
+    e = oracle_engine(d, k)
+    e.reset_all()
+    for t in range(10):
+        e.step(torch.zeros(N, 2, 3))                                  # the sheep settle on the ground
+    _pile_up(e, N)
+    _, _, c = e.debug_dynamics(0, 0)
+    one = c[c[:, 2] < 0]
+    per_actor = np.bincount(one[:, 0].astype(int), minlength=18)
+    assert (per_actor[2:] >= 1).all(), per_actor                     # every sheep keeps its ground contact, the last ones included
+    assert per_actor[0] == 8 and per_actor[1] == 8, per_actor        # both robots at their cap (lying on the side: > 8 feature points touch)
+    pairs = c[c[:, 2] >= 0]
+    assert ((pairs[:, 0] < 2) & (pairs[:, 2] >= 2)).sum() >= 1, pairs[:, :4]      # robot-sheep contacts survive
+    assert len(pairs) >= 8 and len(c) <= 56                           # the eight pair-only slots at least (here the sheep leave more of the pool free)
+    for t in range(3):
+        e.step(torch.zeros(N, 2, 3))
+    assert torch.isfinite(e.tensor(abi.T_ROOT_STATE)).all()
+
+
+@pytest.mark.gpu
+def test_packed_flock_under_fallen_robots_hip_matches_the_specification():
+    N = 4
+    d1, k1, _ = make_desc("go1sheep-hard", N, cfg=flock_cfg(4, 4))
+    d2, k2, _ = make_desc("go1sheep-hard", N, cfg=flock_cfg(4, 4))
+    eh, eo = hip_engine(d1, k1), oracle_engine(d2, k2)
+    eh.reset_all(); eo.reset_all()
+    for t in range(10):
+        eo.step(torch.zeros(N, 2, 3))
+    _pile_up(eo, N)
+    eh.tensor(abi.T_ROOT_STATE).copy_(eo.tensor(abi.T_ROOT_STATE).cuda())
+    eh.tensor(abi.T_DOF_STATE).copy_(eo.tensor(abi.T_DOF_STATE).cuda())
+    torch.cuda.synchronize()
+    for env in (0, N - 1):
+        _, ch = eh.debug_dynamics(env, 0)
+        _, _, co = eo.debug_dynamics(env, 0)
+        assert ch.shape == co.shape and (ch[:, :4] == co[:, :4]).all(), (env, ch[:, :4], co[:, :4])
+        close(ch[:, 4:], co[:, 4:], atol=2e-5, what="contact separation / normal")
+
+
 @pytest.mark.gpu
 def test_a_fifth_robot_is_refused_with_the_reason():
     d, k, _ = make_desc("go1gate", 4)
