@@ -391,7 +391,8 @@ enum { PS_F_LINK = 1, PS_F_NPC = 2, PS_F_BOX = 4, PS_F_STATIC = 8,
        PS_F_ROW = 32 };   // at most 4 actors: row sweep compiled in (without it a TP >= 0 kernel of a larger scene has the lane sweep only)
 template <int TP> struct ShapeClass {
   static constexpr bool small = TP == 0 || TP == PS_F_LINK || (TP > 0 && (TP & PS_F_FEW) != 0);
-  static constexpr int sweep = small || (TP > 0 && (TP & PS_F_ROW) != 0) ? 1 : (TP < 0 ? -1 : 0);    // 1 row, 0 lane, -1 the model says (generic kernels)
+  static constexpr int sweep = TP >= 0 ? 1 : -1;    // 1 row (round 6: also the flocks and 2 vs 2 + ball -- robots in rows, NPCs in lanes), -1 the model says (generic kernels)
+  static constexpr int npq = (small || (TP > 0 && (TP & PS_F_ROW) != 0)) ? 2 : 4;      // passes of 16 contacts when the side records are built: <= 32 contacts, else <= 64
 };
 template <int TA, int TP>
 struct PhysShape {
@@ -493,9 +494,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   // allocator materialises either.  Left as they are: every consumer of these registers is guarded by the lane's role, the wave shifts and the
   // unconditional cross product at "Sv =" only move / combine bits that nobody reads.)
   float Rm[9];
-  V3 bp, bw, bvp, bax = v3(0, 0, 0), bal = bax, bap = bax, bc = bax;
-  float Iw[6] = {0, 0, 0, 0, 0, 0};
-  float bmass = 0.0f;
+  V3 bp, bw, bvp, bax = v3(0, 0, 0), bal = bax, bap = bax;
   float* myrec = lds + L.body + lane * BODY_STRIDE;
   if (is_body && depth == 0) {
     const float* rs = lds + L.root + (is_rbody ? br : (A + (lane - A * MQE_NBODY))) * 13;
@@ -572,10 +571,19 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     }
   }
   __syncthreads();
-  // world COM / inertia of robot bodies
+  TSTAMP(2);
+  // ---- spatial inertia + bias wrench about o = base origin; composite sums up each leg ------------------------
+  // X[0]=m, X[1:4]=h=m*(c-o), X[4:10]=Ibar (sym6), X[10:13]=moment about o, X[13:16]=force
+  float X[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) X[k] = 0.0f;
+  V3 o = v3(0, 0, 0);
+  // world COM / inertia of robot bodies, then their share of the composite -- ONE block (round 6: two blocks under the same condition carried
+  // Iw, the mass and the COM across their join as zero-initialised values: 18 moves per substep)
   if (is_rbody) {
-    bmass = rm.mass[bb] + dp_mass;
-    bc = bp + mat_vec(Rm, v3(rm.com[bb][0] + dp_cx, rm.com[bb][1] + dp_cy, rm.com[bb][2] + dp_cz));
+    float Iw[6];
+    const float bmass = rm.mass[bb] + dp_mass;
+    const V3 bc = bp + mat_vec(Rm, v3(rm.com[bb][0] + dp_cx, rm.com[bb][1] + dp_cy, rm.com[bb][2] + dp_cz));
     const float* S = rm.inertia[bb];
     float Il[9] = {S[0], S[3], S[4], S[3], S[1], S[5], S[4], S[5], S[2]}, T[9];
     for (int r = 0; r < 3; r++)
@@ -587,16 +595,6 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     Iw[3] = T[0] * Rm[3] + T[1] * Rm[4] + T[2] * Rm[5];
     Iw[4] = T[0] * Rm[6] + T[1] * Rm[7] + T[2] * Rm[8];
     Iw[5] = T[3] * Rm[6] + T[4] * Rm[7] + T[5] * Rm[8];
-  }
-
-  TSTAMP(2);
-  // ---- spatial inertia + bias wrench about o = base origin; composite sums up each leg ------------------------
-  // X[0]=m, X[1:4]=h=m*(c-o), X[4:10]=Ibar (sym6), X[10:13]=moment about o, X[13:16]=force
-  float X[16];
-#pragma unroll
-  for (int k = 0; k < 16; k++) X[k] = 0.0f;
-  V3 o = v3(0, 0, 0);
-  if (is_rbody) {
     o = ld3(lds + L.body + br * MQE_NBODY * BODY_STRIDE + B_P);
     V3 rc = bc - o;
     X[0] = bmass; X[1] = bmass * rc.x; X[2] = bmass * rc.y; X[3] = bmass * rc.z;
@@ -1688,7 +1686,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     // idles), each builds ONE row of Phi per side, and the block's couplings come from the neighbour's row through a quad
     // permutation: a third of the instructions of the one-lane-per-contact form below.  Rows of side A wait in registers until
     // every lane has read the link records (the records go on top of them); side B has its own area.
-    constexpr int NPQ = 2;                       // passes of LW / 4 contacts: scenes of <= 4 actors keep <= 32 contacts, two robots alone <= 16
+    constexpr int NPQ = EPW == 2 ? 2 : ShapeClass<TP>::npq;      // passes of LW / 4 contacts: scenes of <= 4 actors keep <= 32 contacts (two robots alone <= 16), flocks <= 64
     const int q = lane & 3;
     float rowA[NPQ][9], usq[NPQ], dqq[NPQ], dqn[NPQ], cbq[NPQ], muq[NPQ], sdq[NPQ];
     int infq[NPQ];
@@ -2023,12 +2021,23 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     const int row = lane >> 4, k = lane & 15;
     int gstart = 0, glen = 0, maxlen = 0;                    // the one-sided contacts of my row's actor: first list index, count
     const int nact = A + PD + (SS ? 1 : 0);
+    // Scenes of more than four actors (flocks, 2 vs 2 + ball; round 6 -- they ran the lane sweep before): the ROBOTS keep their rows, a free
+    // NPC's one-sided contacts (<= 6 coordinates, no leg) are stepped by ONE lane each -- lane p = NPC p -- right behind the robots' step of
+    // the same index: different actors, different coordinates of w.  Two-actor contacts take rows 0 and 1 as everywhere.
+    const bool hyb = ShapeClass<TP>::npq == 4 && nact > 4;      // (the kernels of the 16-envs-per-CU class and go1football-defender's hold at most four actors: mqe_engine.hip pick_shape)
+    int gstartN = 0, glenN = 0, maxlenN = 0;                 // hybrid: the one-sided contacts of NPC `lane`
     for (int a = 0; a < nact; a++) {
       const unsigned long long bm = gballot(is_terr && myA == a);
       const int len = __popcll(bm), start = bm ? __ffsll((long long)bm) - 1 : 0;
-      maxlen = len > maxlen ? len : maxlen;
-      if (row == a) { gstart = start; glen = len; }
+      if (!hyb || a < A) {
+        maxlen = len > maxlen ? len : maxlen;
+        if (row == a) { gstart = start; glen = len; }
+      } else {
+        maxlenN = len > maxlenN ? len : maxlenN;
+        if (lane == a - A) { gstartN = start; glenN = len; }
+      }
     }
+    const int nrow_act = hyb ? A : nact;                     // actors that own a row
     const int npair = __popcll(gballot(is_pair));
     const int pair0 = nc - npair;
     // lane k of a row reads slot k of a record (three floats: its column of Phi for the three rows of the contact); lanes 6-8 own the joints
@@ -2074,11 +2083,31 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       usn = myrc[RS_USN]; cbias_r = myrc[RS_BIAS]; csep = myrc[11];
     }
     // (barriers inside: with two envs per wavefront the trip counts are the larger of the two envs'; a row without work idles)
-    const int maxlen_w = wave_max_of_groups(maxlen), npair_w = wave_max_of_groups(npair);
+    const int maxlen_w = wave_max_of_groups(maxlen > maxlenN ? maxlen : maxlenN), npair_w = wave_max_of_groups(npair);
     const int rowk = row * MQE_RD + k;
     for (int it = 0; it < nsweeps; it++) {
       for (int sidx = 0; sidx < maxlen_w; sidx++) {
-        if (row < nact && sidx < glen) {                     // the s-th one-sided contact of every actor, each in its own row
+        if (hyb && lane < PD && sidx < glenN) {              // hybrid: the s-th one-sided contact of NPC `lane`, the whole step on this lane
+          float* rc = lds + L.phi + (gstartN + sidx) * RS_STRIDE;
+          const float4 q1 = reinterpret_cast<const float4*>(rc)[0], q2 = reinterpret_cast<const float4*>(rc)[1], q3 = reinterpret_cast<const float4*>(rc)[2];
+          float* wb = accv + A * MQE_RD + lane * npcdof;
+          float u0 = rc[RS_SLOT + 27], u1 = rc[RS_SLOT + 28], u2 = rc[RS_SLOT + 29];       // u* - bias, u*, u*
+          float wv[6], ph[18];
+#pragma unroll
+          for (int mm = 0; mm < 6; mm++) {
+            const bool on = mm < npcdof;
+            wv[mm] = on ? wb[on ? mm : 0] : 0.0f;
+            ph[3 * mm] = rc[RS_SLOT + 3 * mm]; ph[3 * mm + 1] = rc[RS_SLOT + 3 * mm + 1]; ph[3 * mm + 2] = rc[RS_SLOT + 3 * mm + 2];      // (columns beyond the body's are stored as zeros)
+            u0 += ph[3 * mm] * wv[mm]; u1 += ph[3 * mm + 1] * wv[mm]; u2 += ph[3 * mm + 2] * wv[mm];
+          }
+          float ln, l1, l2, e0, e1, e2;
+          row_solve(q1, q2, q3, u0, u1, u2, ln, l1, l2, e0, e1, e2);
+          reinterpret_cast<float4*>(rc)[2] = make_float4(ln, l1, l2, q3.w);
+#pragma unroll
+          for (int mm = 0; mm < 6; mm++)
+            if (mm < npcdof) wb[mm] = wv[mm] + ph[3 * mm] * e0 + ph[3 * mm + 1] * e1 + ph[3 * mm + 2] * e2;
+        }
+        if (row < nrow_act && sidx < glen) {                 // the s-th one-sided contact of every actor that owns a row
           float* rc = lds + L.phi + (gstart + sidx) * RS_STRIDE;
           const float4 q1 = reinterpret_cast<const float4*>(rc)[0], q2 = reinterpret_cast<const float4*>(rc)[1], q3 = reinterpret_cast<const float4*>(rc)[2];
           const int info = __float_as_int(q2.w);

@@ -203,7 +203,7 @@ enum SubShape { SH_A2, SH_A1, SH_A2_NOPAD, SH_A2_LINK, SH_A2_NPC_FEW, SH_A2_BOX_
 static SubShape pick_shape(const DevModel& m, size_t lds_bytes, int pad) {
   const int feat = (m.has_seesaw ? PS_F_LINK : 0) | (m.n_npc_dyn > 0 ? PS_F_NPC : 0) | (m.has_box ? PS_F_BOX : 0) | (m.n_static > 0 ? PS_F_STATIC : 0);
   // the small class (row sweep compiled in, 128 VGPRs, every env resident): <= 4 actors and 16 LDS footprints per CU
-  if (m.rowgs && lds_bytes <= 10240) {                                       // (MQE_LANE_SWEEP=1 sends these scenes to the kernels below)
+  if (m.rowgs && lds_bytes <= 10240 && m.maxc <= 32 && m.A + m.n_npc_dyn + (m.has_seesaw ? 1 : 0) <= 4) {                       // (MQE_LANE_SWEEP=1 sends these scenes to the kernels below; <= 32 contacts: two record passes)
     if (feat == 0 && m.P == 0 && pad) {
       if (m.A == 2) return SH_A2;                                            // go1gate
       if (m.A == 1) return SH_A1;                                            // go1plane
@@ -215,9 +215,9 @@ static SubShape pick_shape(const DevModel& m, size_t lds_bytes, int pad) {
     if (m.A == 2 && feat == PS_F_STATIC) return SH_A2_STATIC_FEW;            // go1bridge, go1wrestling
   }
   // larger scenes: 2 waves per SIMD; the sweep variant is compiled in (the kernel's LDS layout has to be the one computed from m.rowgs)
-  if (m.A == 3 && feat == PS_F_NPC && m.rowgs) return SH_A3_NPC_ROW;         // go1football-defender
-  if (m.A == 2 && feat == PS_F_NPC && !m.rowgs) return SH_A2_NPC;            // go1sheep-* (flocks)
-  if (m.A == 4 && feat == PS_F_NPC && !m.rowgs) return SH_A4_NPC;            // go1football-2vs2
+  if (m.A == 3 && feat == PS_F_NPC && m.rowgs && m.maxc <= 32 && m.A + m.n_npc_dyn <= 4) return SH_A3_NPC_ROW;         // go1football-defender
+  if (m.A == 2 && feat == PS_F_NPC && m.rowgs) return SH_A2_NPC;             // go1sheep-* (flocks): robots in rows, sheep in lanes
+  if (m.A == 4 && feat == PS_F_NPC && m.rowgs) return SH_A4_NPC;             // go1football-2vs2
   if (m.A == 2) return SH_A2_GEN;
   return SH_GEN;
 }
@@ -359,7 +359,7 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   m.maxc = mqe_maxc(A, P, m.cap_npc);
   if (mqe_maxc_uncapped(A, P, m.cap_npc) > 64) return fail(-4, "the per-actor contact caps of this scene (8 per robot + cap per NPC + 8 two-actor slots) exceed the 64 contact lanes of the wavefront that owns an env");
   if (m.ndof_env > 128 || m.nbody_env > 64) { return fail(-4, "env has more than 64 bodies or 128 generalized velocities: does not fit one wavefront"); }
-  m.rowgs = (A + m.n_npc_dyn + (seesaw ? 1 : 0) <= 4) ? 1 : 0;      // one 16-lane row per actor; the <A,0> / <2,LINK> kernels assume it
+  m.rowgs = 1;      // one 16-lane row per actor (<= 4 actors), or (round 6) per ROBOT with the free NPCs' one-sided contacts stepped by a lane each; the compiled shapes assume it
   if (getenv("MQE_LANE_SWEEP")) m.rowgs = 0;      // tests: the other lane mapping of the contact sweep on the same scene (tests/test_gpu_parity.py)
   // padded link / contact records (kernels_physics.hpp: PhysPad): the robot-only kernels k_substeps<A, 0>, which the scene gets iff ...
   int pad = (m.rowgs && m.P == 0 && !m.has_seesaw && m.n_npc_dyn == 0 && !m.has_box && m.n_static == 0 && (A == 1 || A == 2)) ? 1 : 0;
