@@ -874,7 +874,8 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       c = v3(q2.y, q2.z, q2.w) + mat_vec(Rr, v3(rm.sphere_center[si][0], rm.sphere_center[si][1], rm.sphere_center[si][2]));
       rad = rm.sphere_radius[si];
     } else {
-      const int q = s - A * nsr, p = q / HI(HOT_NPC_N_SPHERES), si = q - p * HI(HOT_NPC_N_SPHERES);
+      const int nsn_ = HI(HOT_NPC_N_SPHERES);
+      const int q = s - A * nsr, p = nsn_ == 1 ? q : (nsn_ == 2 ? q >> 1 : q / nsn_), si = q - p * nsn_;      // (one or two spheres per NPC in every shipped scene: no run-time division)
       const float* rec = lds + L.body + (A * MQE_NBODY + p) * BODY_STRIDE;
       c = ld3(rec + B_P) + mat_vec(rec + B_R, v3(m->npc_sphere_center[si][0], m->npc_sphere_center[si][1], m->npc_sphere_center[si][2]));
       rad = m->npc_sphere_radius[si];
@@ -902,6 +903,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
         const V3 pb = ld3(lds + L.body + (b < A ? b * MQE_NBODY : A * MQE_NBODY + (b - A)) * BODY_STRIDE + B_P);
         const V3 dd = pa - pb;
         if (shp.has_box && b >= A) nr = a < A && !(dot(dd, dd) > 1.8f * 1.8f);
+        else if (a >= A) nr = !(dot(dd, dd) > HF(HOT_NPC_PAIR_REACH) * HF(HOT_NPC_PAIR_REACH));      // two free NPCs: their own size, not a robot's (round 6: sheep 1.5 m apart used to be "near")
         else nr = !(dot(dd, dd) > 1.2f * 1.2f);
       }
       const unsigned long long bm = gballot(nr);
@@ -918,7 +920,13 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
   // and is marked by a negative radius).  Only built when something can touch a primitive at all: two robots walking apart from
   // each other in ordinary poses skip it.
   const int npr = HI(HOT_N_PRIMS);
-  const bool need_prims = near0 != 0ull || near1 != 0ull || near2 != 0ull || self_todo != 0u;
+  // (only a near pair that HAS a robot needs them: the pair bits are a-major, the robots' pairs are the first A (nact - 1) - A (A - 1) / 2)
+  const int n_rpairs = A * (A + PD - 1) - (A * (A - 1)) / 2;
+  const unsigned long long rmask0 = n_rpairs >= 64 ? ~0ull : ((1ull << n_rpairs) - 1ull);
+  const unsigned long long rmask1 = n_rpairs <= 64 ? 0ull : (n_rpairs >= 128 ? ~0ull : ((1ull << (n_rpairs - 64)) - 1ull));
+  const bool near_robot = (near0 & rmask0) != 0ull || (near1 & rmask1) != 0ull || (n_rpairs > 128 && near2 != 0ull);
+  const bool near_npcs = (near0 & ~rmask0) != 0ull || (near1 & ~rmask1) != 0ull || near2 != 0ull;
+  const bool need_prims = near_robot || self_todo != 0u;
   for (int t = lane; need_prims && t < A * npr; t += LW) {
     const int r = (int)(t >= npr) + (int)(t >= 2 * npr) + (int)(t >= 3 * npr), q = t - r * npr;
     const float* rec = lds + L.body + (r * MQE_NBODY + rm.prim_body[q]) * BODY_STRIDE;
@@ -1528,7 +1536,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
           if (nc > pair_lim) { nc = pair_lim; ovf = 1; }
         }
       }
-    if (npc_pass) {
+    if (npc_pass && near_npcs) {                       // (wave-uniform: a flock in which no two sheep are within reach of each other skips its pair passes)
       const int ns = HI(HOT_NPC_N_SPHERES), ns2 = ns * ns;
       const int np2 = ((PD * (PD - 1)) / 2) * ns2;
       for (int t0 = 0; t0 < np2; t0 += LW) {
@@ -2092,20 +2100,35 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
           const float4 q1 = reinterpret_cast<const float4*>(rc)[0], q2 = reinterpret_cast<const float4*>(rc)[1], q3 = reinterpret_cast<const float4*>(rc)[2];
           float* wb = accv + A * MQE_RD + lane * npcdof;
           float u0 = rc[RS_SLOT + 27], u1 = rc[RS_SLOT + 28], u2 = rc[RS_SLOT + 29];       // u* - bias, u*, u*
-          float wv[6], ph[18];
-#pragma unroll
-          for (int mm = 0; mm < 6; mm++) {
-            const bool on = mm < npcdof;
-            wv[mm] = on ? wb[on ? mm : 0] : 0.0f;
-            ph[3 * mm] = rc[RS_SLOT + 3 * mm]; ph[3 * mm + 1] = rc[RS_SLOT + 3 * mm + 1]; ph[3 * mm + 2] = rc[RS_SLOT + 3 * mm + 2];      // (columns beyond the body's are stored as zeros)
-            u0 += ph[3 * mm] * wv[mm]; u1 += ph[3 * mm + 1] * wv[mm]; u2 += ph[3 * mm + 2] * wv[mm];
-          }
           float ln, l1, l2, e0, e1, e2;
-          row_solve(q1, q2, q3, u0, u1, u2, ln, l1, l2, e0, e1, e2);
-          reinterpret_cast<float4*>(rc)[2] = make_float4(ln, l1, l2, q3.w);
+          if (npcdof == 3) {                                 // wave-uniform: ball, sheep (translation only) -- nine record floats, three of w
+            float wv[3], ph[9];
 #pragma unroll
-          for (int mm = 0; mm < 6; mm++)
-            if (mm < npcdof) wb[mm] = wv[mm] + ph[3 * mm] * e0 + ph[3 * mm + 1] * e1 + ph[3 * mm + 2] * e2;
+            for (int i = 0; i < 9; i++) ph[i] = rc[RS_SLOT + i];
+#pragma unroll
+            for (int mm = 0; mm < 3; mm++) {
+              wv[mm] = wb[mm];
+              u0 += ph[3 * mm] * wv[mm]; u1 += ph[3 * mm + 1] * wv[mm]; u2 += ph[3 * mm + 2] * wv[mm];
+            }
+            row_solve(q1, q2, q3, u0, u1, u2, ln, l1, l2, e0, e1, e2);
+            reinterpret_cast<float4*>(rc)[2] = make_float4(ln, l1, l2, q3.w);
+#pragma unroll
+            for (int mm = 0; mm < 3; mm++) wb[mm] = wv[mm] + ph[3 * mm] * e0 + ph[3 * mm + 1] * e1 + ph[3 * mm + 2] * e2;
+          } else {
+            float wv[6], ph[18];
+#pragma unroll
+            for (int mm = 0; mm < 6; mm++) {
+              const bool on = mm < npcdof;
+              wv[mm] = on ? wb[on ? mm : 0] : 0.0f;
+              ph[3 * mm] = rc[RS_SLOT + 3 * mm]; ph[3 * mm + 1] = rc[RS_SLOT + 3 * mm + 1]; ph[3 * mm + 2] = rc[RS_SLOT + 3 * mm + 2];      // (columns beyond the body's are stored as zeros)
+              u0 += ph[3 * mm] * wv[mm]; u1 += ph[3 * mm + 1] * wv[mm]; u2 += ph[3 * mm + 2] * wv[mm];
+            }
+            row_solve(q1, q2, q3, u0, u1, u2, ln, l1, l2, e0, e1, e2);
+            reinterpret_cast<float4*>(rc)[2] = make_float4(ln, l1, l2, q3.w);
+#pragma unroll
+            for (int mm = 0; mm < 6; mm++)
+              if (mm < npcdof) wb[mm] = wv[mm] + ph[3 * mm] * e0 + ph[3 * mm + 1] * e1 + ph[3 * mm + 2] * e2;
+          }
         }
         if (row < nrow_act && sidx < glen) {                 // the s-th one-sided contact of every actor that owns a row
           float* rc = lds + L.phi + (gstart + sidx) * RS_STRIDE;

@@ -83,6 +83,7 @@ enum {   // DevModel::hot
   HOT_SDF_NX, HOT_SDF_NY, HOT_EDGE_MASK, HOT_SOLVER_TYPE, HOT_SOLVER_ITERATIONS, HOT_VEL_ITERS, HOT_SELF_COLLISION, HOT_NSPH_ENV, HOT_NPRIM_ENV,
   HOT_N, HOT_NBR, HOT_N_SPHERES, HOT_N_PRIMS, HOT_N_SELF_PAIRS, HOT_CAP_NPC, HOT_NPC_N_SPHERES, HOT_FEAT_MASK_LO, HOT_FEAT_MASK_HI,
   HOT_WALL_SDF_LO, HOT_WALL_SDF_HI, HOT_GROUND_HEIGHT_LO, HOT_GROUND_HEIGHT_HI, HOT_WALL_TOP_LO, HOT_WALL_TOP_HI, HOT_WALL_CORNER_LO, HOT_WALL_CORNER_HI,
+  HOT_NPC_PAIR_REACH,      // two free NPCs whose origins are farther apart than this cannot touch: 2 x (largest |sphere centre| + radius) + contact offset
   HOT_COUNT
 };
 static_assert(HOT_COUNT <= 64, "DevModel::hot");
@@ -233,5 +234,14 @@ __host__ inline void mqe_fill_hot(DevModel& m) {
   m.hot[HOT_N_SELF_PAIRS] = (uint32_t)m.robot.n_self_pairs; m.hot[HOT_CAP_NPC] = (uint32_t)m.cap_npc; m.hot[HOT_NPC_N_SPHERES] = (uint32_t)m.npc_n_spheres;
   m.hot[HOT_FEAT_MASK_LO] = (uint32_t)(m.feat_sphere_mask & 0xFFFFFFFFull); m.hot[HOT_FEAT_MASK_HI] = (uint32_t)(m.feat_sphere_mask >> 32);
   m.hot[HOT_WALL_SDF_LO] = lo(m.wall_sdf); m.hot[HOT_WALL_SDF_HI] = hi(m.wall_sdf); m.hot[HOT_GROUND_HEIGHT_LO] = lo(m.ground_height); m.hot[HOT_GROUND_HEIGHT_HI] = hi(m.ground_height);
+  {
+    float bnd = 0.0f;
+    for (int i = 0; i < m.npc_n_spheres && i < 8; i++) {
+      const float* c = m.npc_sphere_center[i];
+      const float r = sqrtf(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]) + m.npc_sphere_radius[i];
+      bnd = r > bnd ? r : bnd;
+    }
+    m.hot[HOT_NPC_PAIR_REACH] = f(2.0f * bnd + m.contact_offset + 1e-3f);
+  }
   m.hot[HOT_WALL_TOP_LO] = lo(m.wall_top); m.hot[HOT_WALL_TOP_HI] = hi(m.wall_top); m.hot[HOT_WALL_CORNER_LO] = lo(m.wall_corner); m.hot[HOT_WALL_CORNER_HI] = hi(m.wall_corner);
 }
