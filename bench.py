@@ -163,8 +163,8 @@ def profile_pass(eng, step_fn, brackets=24, every=4):
 SUBSTEPS_BOUND = "valu-issue / latency (not hbm)"
 SUBSTEPS_NOTE = ("achieved / peak / frac are the PRESCRIBED form -- the whole step's algorithmic HBM bytes over this kernel's average launch time against the HBM peak -- "
                  "but HBM is not what binds it: one env per wavefront, state LDS-resident for the 4 substeps; the limiters are the wavefront's chain of dependent "
-                 "waits (78 us for a wavefront alone on its CU) and the vector ALU's issue slots (86 % taken inside the substeps with all envs resident at "
-                 "4 waves/SIMD: valu_issue); DESIGN.md 3.1 (e), (f)")
+                 "waits (~75 us for a wavefront alone on its CU) and the vector ALU's issue slots (the larger part of them taken with all envs resident at "
+                 "4 waves/SIMD: valu_issue; round 6 took 12 % of the instructions out and the launch got 12 % shorter); DESIGN.md 3.1")
 
 # the other BASELINE.json configs that fit one GPU (+ the headline with the URDF's exact thigh / calf boxes): timed on the driver's
 # own line (`configs`), same protocol as the headline -- fresh U(-1,1) actions, inputs resident, device-synchronised
@@ -173,6 +173,8 @@ EXTRA_CONFIGS = [
     ("go1seesaw", 4096, {}, "BASELINE config 4"),
     ("go1football-defender", 4096, {}, "BASELINE config 5's per-GPU shard (32768 envs over 8 GPUs)"),
     ("go1gate", 4096, {"MQE_COLLISION_MODEL": "exact"}, "BASELINE config 2 with the URDF's thigh / calf boxes (60 feature points per robot)"),
+    ("go1gate", 8192, {}, "BASELINE config 2 at twice the batch (two residency rounds of k_substeps: 16 envs per CU are what 9.9 kB of LDS per env allow)"),
+    ("go1gate", 16384, {}, "BASELINE config 2 at four times the batch"),
 ]
 
 
@@ -506,10 +508,19 @@ def main():
                     # the limit this kernel actually runs against: the vector ALU's issue slots.  SQ_ACTIVE_INST_VALU counts quad-cycles summed over the
                     # wavefronts of a launch; 1024 SIMDs issue one VALU instruction per quad-cycle each; GRBM_GUI_ACTIVE sums the 8 XCDs' busy cycles
                     simd_quads = e["GRBM_GUI_ACTIVE_mean"] / 8.0 / 4.0 * 1024.0
+                    per_sub = None
+                    try:      # VALU instructions per wavefront and substep: the last line of the newest per-phase counter table
+                        pc = sorted(glob.glob(os.path.join(ROOT, "profiles", "*phase_counters_go1gate_tgs.txt")))[-1]
+                        hdr = open(pc).readline().split()
+                        row = [l for l in open(pc) if l.startswith("whole substep")][-1].split()
+                        per_sub = float(row[2 + hdr.index("INSTS_VALU") - 1])
+                    except Exception:
+                        pass
                     roof["valu_issue"] = {"bound": "valu issue slots (1 per SIMD and quad-cycle)", "frac_of_launch": round(e["SQ_ACTIVE_INST_VALU_mean"] / simd_quads, 3),
-                                          "frac_inside_the_substeps": 0.86, "measured_in_this_run": False,
-                                          "note": "86 % inside the four substeps (3545 VALU instructions per wavefront and substep x 4 resident wavefronts of the SIMD's 16.4 k quad-cycles, "
-                                                  "profiles/*phase_counters_go1gate_tgs.txt); the launch-wide figure includes the state load, the epilogue and the wait for the last wavefront; DESIGN.md 3.1 (f)"}
+                                          "valu_instructions_per_wavefront_launch": round(e["SQ_INSTS_VALU_mean"] / max(e.get("SQ_WAVES_mean", 1.0), 1.0), 1) if e.get("SQ_INSTS_VALU_mean") else None,
+                                          "valu_instructions_per_wavefront_substep": per_sub, "measured_in_this_run": False,
+                                          "note": "SQ_ACTIVE_INST_VALU over the launch's SIMD quad-cycles (profiles/*pmc_summary.json); per substep from profiles/*phase_counters_go1gate_tgs.txt; "
+                                                  "the launch-wide figure includes the state load, the epilogue and the wait for the last wavefront; DESIGN.md 3.1"}
         except Exception:
             pass
         # ---- per-kernel table: every kernel class with ITS OWN share of the algorithmic bytes (the items of SURVEY 8(d) assigned
