@@ -110,11 +110,14 @@ def time_variant(task, N, dev, steps, warmup, env_vars):
     from mqe.envs.utils import make_mqe_env, custom_cfg
     old = {k: os.environ.get(k) for k in env_vars}
     os.environ.update(env_vars)
+    from mqe.envs.go1.go1 import Go1
+    shard0, Go1.shard = Go1.shard, None       # a batch of its own, not a shard of the headline's (main() keys the scene by GLOBAL env ids: Go1.shard)
     try:
         margs = make_args(task, N, 0, dev)
         with contextlib.redirect_stdout(sys.stderr):
             env, _ = make_mqe_env(task, margs, custom_cfg(margs))
     finally:
+        Go1.shard = shard0
         for k, v in old.items():
             if v is None:
                 os.environ.pop(k, None)
@@ -184,11 +187,14 @@ def time_config(task, N, dev, env_vars, label, min_ms=100.0, warmup=10):
     from mqe.envs.utils import make_mqe_env, custom_cfg
     old = {k: os.environ.get(k) for k in env_vars}
     os.environ.update(env_vars)
+    from mqe.envs.go1.go1 import Go1
+    shard0, Go1.shard = Go1.shard, None       # a batch of its own, not a shard of the headline's (main() keys the scene by GLOBAL env ids: Go1.shard)
     try:
         margs = make_args(task, N, 0, dev)
         with contextlib.redirect_stdout(sys.stderr):
             env, _ = make_mqe_env(task, margs, custom_cfg(margs))
     finally:
+        Go1.shard = shard0
         for k, v in old.items():
             if v is None:
                 os.environ.pop(k, None)
