@@ -518,12 +518,12 @@ def test_time_outs_bring_both_engines_back_to_the_same_state(task, N):
     assert float(after.median()) < 1e-6 and float(after.quantile(0.95)) < 1e-5, (float(after.median()), float(after.max()))
 
 
-@pytest.mark.parametrize("task,N", [("go1gate", 256), ("go1seesaw", 64), ("go1tug", 32)])
+@pytest.mark.parametrize("task,N", [("go1gate", 256), ("go1seesaw", 64), ("go1tug", 32), ("go1sheep-hard", 48), ("go1football-2vs2", 32), ("go1football-defender", 32)])
 def test_row_sweep_and_lane_sweep_agree(monkeypatch, task, N, solver):
-    """The contact sweep has two lane mappings (kernels_physics.hpp: one DPP row per actor for scenes of robots and the 1-dof link,
-    one lane per contact otherwise).  MQE_LANE_SWEEP=1 sends a robot-only scene down the other one (generic kernels, lane sweep,
-    other LDS layout): same records, same Gauss-Seidel order, different summation trees -> 8 fused steps agree to rounding and
-    every reset flag and contact-overflow count is identical."""
+    """The contact sweep has two lane mappings (kernels_physics.hpp: one DPP row per actor -- round 6: per ROBOT, with the free NPCs of a
+    scene of more than four actors stepped by a lane each: go1sheep-hard, go1football-2vs2 -- or one lane per contact).  MQE_LANE_SWEEP=1
+    sends a scene down the other one (generic kernels, lane sweep, other LDS layout): same records, same Gauss-Seidel order, different
+    summation trees -> 8 fused steps agree to rounding and every reset flag and contact-overflow count is identical."""
     d, keep, _ = make_desc(task, N)
     er = hip_engine(d, keep)
     monkeypatch.setenv("MQE_LANE_SWEEP", "1")
