@@ -134,6 +134,60 @@ def test_packed_flock_under_fallen_robots_hip_matches_the_specification():
         close(ch[:, 4:], co[:, 4:], atol=2e-5, what="contact separation / normal")
 
 
+def _four_robots_and_a_box_cfg():
+    """go1football-2vs2's four robots with go1pushbox's free box instead of the ball: five actors, one of them a 6-dof NPC with four contact slots --
+    the scene shape that takes the hybrid sweep's general NPC lane step (kernels_physics.hpp) on the generic kernel"""
+    from helpers import task_cfg
+    base, box = task_cfg("go1football-2vs2"), task_cfg("go1pushbox")
+    asset = type("asset", (base.asset,), {"file_npc": box.asset.file_npc, "name_npc": box.asset.name_npc})
+    init = type("init_state", (base.init_state,), {"init_states_npc": box.init_state.init_states_npc})
+    return type("FourRobotsAndABoxCfg", (base,), {"asset": asset, "init_state": init})
+
+
+def test_four_robots_and_a_box_on_the_specification():
+    N = 3
+    d, k, _ = make_desc("go1football-2vs2", N, cfg=_four_robots_and_a_box_cfg())
+    assert d.num_agents == 4 and d.num_npcs == 1 and d.npc_kind == abi.NPC["box"]
+    e = oracle_engine(d, k)
+    e.reset_all()
+    g = torch.Generator().manual_seed(2)
+    for t in range(15):
+        e.step(torch.rand(N, e.tensor(abi.T_WRAPPER_OBS).shape[1], 3, generator=g) * 2 - 1)
+    root = e.tensor(abi.T_ROOT_STATE)
+    assert torch.isfinite(root).all() and int(e.tensor(abi.T_CONTACT_OVERFLOW).sum()) == 0
+    assert (root[:, 4, 2] > 0.3).all()                               # the box rests on the ground (half height 0.5 m)
+
+
+@pytest.mark.gpu
+def test_four_robots_and_a_box_hip_matches_the_specification(solver):
+    N = 16
+    d1, k1, _ = make_desc("go1football-2vs2", N, cfg=_four_robots_and_a_box_cfg())
+    d2, k2, _ = make_desc("go1football-2vs2", N, cfg=_four_robots_and_a_box_cfg())
+    eh, eo = hip_engine(d1, k1), oracle_engine(d2, k2)
+    eh.reset_all(); eo.reset_all()
+    # two robots pushed against the box so that robot-box pairs and the box's own ground contacts are in the list from the first step
+    ro = eo.tensor(abi.T_ROOT_STATE)
+    ro[:, 0, :2] = ro[:, 4, :2] + torch.tensor([-0.78, 0.0]); ro[:, 2, :2] = ro[:, 4, :2] + torch.tensor([0.0, 0.80])
+    eh.tensor(abi.T_ROOT_STATE).copy_(ro.cuda())
+    g = torch.Generator().manual_seed(9)
+    Aw = eo.tensor(abi.T_WRAPPER_OBS).shape[1]
+    dev = []
+    for t in range(12):
+        a = torch.rand(N, Aw, 3, generator=g) * 2 - 1
+        eh.step(a.cuda().contiguous()); eo.step(a)
+        torch.cuda.synchronize()
+        dev.append((eh.tensor(abi.T_ROOT_STATE).cpu()[..., :3] - eo.tensor(abi.T_ROOT_STATE)[..., :3]).abs().amax(dim=(1, 2)))
+        assert (eh.tensor(abi.T_RESET_BUF).cpu() == eo.tensor(abi.T_RESET_BUF)).all()
+    dev = torch.stack(dev)
+    assert float(dev[3].median()) < 5e-6 and float(dev[3].max()) < 2e-4, (dev[3].median(), dev[3].max())
+    assert float(dev[11].median()) < 2e-5 and float(dev[11].max()) < 2e-3, (dev[11].median(), dev[11].max())
+    assert int(eh.tensor(abi.T_CONTACT_OVERFLOW).sum()) == int(eo.tensor(abi.T_CONTACT_OVERFLOW).sum())
+    for env in (0, N - 1):
+        _, ch = eh.debug_dynamics(env, 0)
+        _, _, co = eo.debug_dynamics(env, 0)
+        assert ch.shape == co.shape and (ch[:, :4] == co[:, :4]).all(), (env, ch[:, :4], co[:, :4])
+
+
 @pytest.mark.gpu
 def test_a_fifth_robot_is_refused_with_the_reason():
     d, k, _ = make_desc("go1gate", 4)
