@@ -21,6 +21,15 @@ from mqe.engine import abi
 
 pytestmark = pytest.mark.gpu
 
+
+def _log(**kw):
+    """measured deviations, appended to gpurun_out/test_measurements.jsonl when that directory exists (what the bounds are set from)"""
+    import json, os
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "test_measurements.jsonl"), "a") as f:
+            f.write(json.dumps(kw) + "\n")
+
 FULL = [("go1gate", 4096), ("go1sheep-hard", 2048), ("go1seesaw", 4096), ("go1football-defender", 4096)]
 
 
@@ -167,12 +176,16 @@ def test_full_size_batch_is_the_union_of_its_shards(monkeypatch, task, NF):
         e.close()
 
 
+# step-20 deviations (median, 99th percentile, worst env [m]) of these four at the final round-6 physics; bounds = 3 x these (floors 1e-6 / 2e-5 / 1e-3)
+FULL_MEASURED = {"go1gate": (2.4e-07, 7.2e-06, 8.8e-04), "go1sheep-hard": (6.0e-08, 3.2e-04, 6.0e-03),
+                 "go1seesaw": (2.4e-07, 4.1e-05, 2.5e-03), "go1football-defender": (2.4e-07, 1.1e-06, 1.2e-05)}
+
+
 @pytest.mark.parametrize("task,NF", FULL)
 def test_full_size_rollout_matches_oracle(task, NF):
     """BASELINE.json's single-GPU configurations at their full sizes, HIP engine against the CPU oracle: 20 fused steps from the seeded reset distribution
-    with the same random wrapper actions.  Bounds = ~10 x what profiles/r05_parity_sweep_full_size.json measured at step 20 over the 13 tasks (median
-    <= 7.2e-7 m, 99th percentile <= 7.3e-4 m, worst env 1.1e-2 m -- all three in go1revolvingdoor; these four: <= 2.4e-7 / 3.8e-5 / 2.5e-3; no reset flag
-    differed in 5.2 M)."""
+    with the same random wrapper actions.  Bounds = 3 x what the final round-6 physics measures at step 20 (FULL_MEASURED; both engines are deterministic,
+    so the figures reproduce on any box), no reset flag may differ."""
     levels, types = assign_tracks(task, NF)
     d1, k1, _ = shard_desc(task, NF, 0, NF, levels, types)
     d2, k2, _ = shard_desc(task, NF, 0, NF, levels, types)
@@ -191,19 +204,23 @@ def test_full_size_rollout_matches_oracle(task, NF):
     rh, ro = eh.tensor(abi.T_ROOT_STATE).cpu(), eo.tensor(abi.T_ROOT_STATE)
     assert torch.isfinite(rh).all() and torch.isfinite(ro).all()
     dev = (rh[:, :A, :3] - ro[:, :A, :3]).abs().amax(dim=(1, 2))
-    assert float(dev.median()) < 5e-6 and float(dev.quantile(0.99)) < 5e-4 and float(dev.max()) < 3e-2, (float(dev.median()), float(dev.quantile(0.99)), float(dev.max()))
-    assert flags <= 2, flags
+    got = (float(dev.median()), float(dev.quantile(0.99)), float(dev.max()))
+    _log(kind="full_size_rollout", task=task, N=NF, dev=got, flags=flags)
+    med, p99, worst = FULL_MEASURED[task]
+    assert got[0] < max(3 * med, 1e-6) and got[1] < max(3 * p99, 2e-5) and got[2] < max(3 * worst, 1e-3), got
+    assert flags == 0, flags
     assert (eh.tensor(abi.T_WRAPPER_OBS).cpu() - eo.tensor(abi.T_WRAPPER_OBS)).abs().median() < 1e-5
     assert int(eh.tensor(abi.T_CONTACT_OVERFLOW).sum()) == int(eo.tensor(abi.T_CONTACT_OVERFLOW).sum()) == 0
     eh.close(); eo.close()
 
 
-# the other nine tasks of ENV_DICT at 4096 envs (go1football-2vs2: four robots per env): step-20 deviations of profiles/r05_parity_sweep_full_size.json
-# (median, 99th percentile, worst env [m]); the bounds below are 10 x these with floors of 5e-6 / 1e-4 / 1e-2.  go1revolvingdoor's door contact is
+# the other nine tasks of ENV_DICT at 4096 envs (go1football-2vs2: four robots per env): step-20 deviations measured at the final round-6 physics
+# (median, 99th percentile, worst env [m]; gpurun_out/test_measurements.jsonl -> profiles/r06_full_size_measurements.jsonl); the bounds below are 3 x these with
+# floors of 1e-6 / 2e-5 / 1e-3 (they were 10 x with floors ten times higher), and no reset flag may differ (none did in 5.2 M).  go1revolvingdoor's door contact is
 # the one place where two correct rollouts part by a centimetre within 20 steps (a robot leaning on the moving wing)
-OTHER = {"go1plane": (6.0e-08, 3.9e-06, 1.1e-03), "go1sheep-easy": (2.4e-07, 5.4e-05, 1.7e-03), "go1football-1vs1": (8.9e-08, 9.5e-07, 7.7e-06),
-         "go1football-2vs2": (3.0e-07, 1.9e-06, 1.5e-05), "go1pushbox": (2.4e-07, 3.8e-05, 3.2e-03), "go1revolvingdoor": (7.2e-07, 7.3e-04, 1.1e-02),
-         "go1tug": (2.4e-07, 5.8e-05, 8.5e-04), "go1bridge": (2.4e-07, 1.4e-06, 4.8e-06), "go1wrestling": (9.5e-07, 3.8e-05, 3.3e-04)}
+OTHER = {"go1bridge": (2.4e-07, 1.9e-06, 1.0e-05), "go1football-1vs1": (8.9e-08, 9.5e-07, 9.2e-06), "go1football-2vs2": (2.7e-07, 1.4e-06, 3.2e-05),
+         "go1plane": (6.0e-08, 3.9e-06, 1.0e-03), "go1pushbox": (2.4e-07, 4.1e-05, 2.2e-03), "go1revolvingdoor": (7.2e-07, 6.6e-04, 1.1e-02),
+         "go1sheep-easy": (2.4e-07, 5.7e-05, 2.7e-03), "go1tug": (2.4e-07, 6.3e-05, 9.4e-04), "go1wrestling": (9.5e-07, 4.1e-05, 2.6e-04)}
 
 
 @pytest.mark.parametrize("task", sorted(OTHER))
@@ -226,7 +243,8 @@ def test_every_other_task_at_4096_envs_matches_oracle(task):
     dev = (rh[:, :A, :3] - ro[:, :A, :3]).abs().amax(dim=(1, 2))
     med, p99, worst = OTHER[task]
     got = (float(dev.median()), float(dev.quantile(0.99)), float(dev.max()))
-    assert got[0] < max(10 * med, 5e-6) and got[1] < max(10 * p99, 1e-4) and got[2] < max(10 * worst, 1e-2), got
-    assert flags <= 2, flags
+    _log(kind="full_size_rollout", task=task, N=NF, dev=got, flags=flags)
+    assert got[0] < max(3 * med, 1e-6) and got[1] < max(3 * p99, 2e-5) and got[2] < max(3 * worst, 1e-3), got
+    assert flags == 0, flags
     assert int(eh.tensor(abi.T_CONTACT_OVERFLOW).sum()) == int(eo.tensor(abi.T_CONTACT_OVERFLOW).sum()) == 0
     eh.close(); eo.close()
