@@ -176,6 +176,9 @@ EXTRA_CONFIGS = [
     ("go1seesaw", 4096, {}, "BASELINE config 4"),
     ("go1football-defender", 4096, {}, "BASELINE config 5's per-GPU shard (32768 envs over 8 GPUs)"),
     ("go1gate", 4096, {"MQE_COLLISION_MODEL": "exact"}, "BASELINE config 2 with the URDF's thigh / calf boxes (60 feature points per robot)"),
+    ("go1gate", 4096, {"MQE_COLLISION_MODEL": "exact", "MQE_CONTACT_REDUCTION": "1"},
+     "the same with the optional manifold reduction (desc.edge_contacts bit 8): a robot's contacts beyond its eight slots reduced to the deepest instead of truncated -- "
+     "contact_overflow_substeps 0, contact_reduced_substeps instead; off by default (DESIGN.md section 0, round 6, item 4)"),
     ("go1gate", 8192, {}, "BASELINE config 2 at twice the batch (two residency rounds of k_substeps: 16 envs per CU are what 9.9 kB of LDS per env allow)"),
     ("go1gate", 16384, {}, "BASELINE config 2 at four times the batch"),
 ]
