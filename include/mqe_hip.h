@@ -198,10 +198,10 @@ typedef struct {
    * is a one-dimensional convex minimisation: both engines run the same 18-evaluation golden-section search.  Such a contact is kept
    * when it lies BETWEEN feature points (segment parameter inside 5 .. 95 %); 0 = round 3's behaviour.
    * Bit 8 (round 6, off by default; not an edge contact, it shares the contact-generation option word): manifold reduction -- a robot that
-   * touches the static world at more points than its eight one-sided slots keeps the DEEPEST ones (separation in classes of 2 mm centred on
-   * zero, so that the contacts of a body at rest tie; ties in feature order) instead of the first eight in feature order, counted in
-   * MQE_T_CONTACT_REDUCED instead of MQE_T_CONTACT_OVERFLOW.  Built in both engines and parity-tested; not the default because a robot
-   * collapsed on its belly rests worse with it under the velocity-level solver. */
+   * touches the static world at more points than its eight one-sided slots keeps every contact penetrating by more than 1 mm first (deepest
+   * 2 mm class first) and fills the rest in feature order, instead of the first eight in feature order whatever their depth; counted in
+   * MQE_T_CONTACT_REDUCED instead of MQE_T_CONTACT_OVERFLOW.  Built in both engines and parity-tested; not the default because a limp robot
+   * collapsing onto its belly comes to rest in another pose with it. */
   int32_t edge_contacts;
   const float* wall_corner;
   float soft_dof_pos_limit;               /* rewards.soft_dof_pos_limit (legged_robot.py:317-321): fraction of the URDF joint range
@@ -299,7 +299,7 @@ enum {
                               wrappers subtract; equal to desc.env_origins unless the terrain curriculum has moved an env */
   MQE_T_TERRAIN_LEVELS,    /* int32 [N] terrain level of each env (legged_robot.py:983,490) */
   MQE_T_CONTACT_REDUCED,   /* int32 [N]: with edge_contacts bit 8: substeps so far in which a robot of the env touched the static world at more
-                            * points than its eight one-sided slots and the set was reduced to the DEEPEST eight (2 mm classes, ties in feature
+                            * points than its eight one-sided slots and the set was reduced (penetrations of more than 1 mm first, deepest 2 mm class first, then feature
                             * order: feet first); MQE_T_CONTACT_OVERFLOW then counts only what is dropped in list order (NPC caps, the two-actor
                             * share, the end of the list).  Without the bit (default): always zero, robots' extra contacts count as overflow */
   MQE_T_COUNT

@@ -1142,7 +1142,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       }
     }
     // ---- desc.edge_contacts bit 8 (round 6, off by default): a robot that touches the static world at more points than it has slots keeps the
-    // DEEPEST ones (otherwise, as in rounds 1-5: the first ones in feature order, the rest counted as overflow).  Depth in classes of 2 mm centred on zero (the contacts of a body at rest tie), ties in the canonical order (feature by
+    // DEEPEST ones (otherwise, as in rounds 1-5: the first ones in feature order, the rest counted as overflow).  Depth counts from 1 mm of penetration on, in classes of 2 mm; everything shallower -- resting and speculative contacts -- is one class, so that a body at rest keeps the feature order's spread (feet, knees, hips, trunk corners) and the same set from substep to substep; ties in the canonical order (feature by
     // feature: ground, wall, platform, column; then the edge contacts, primitive by primitive) -- the steps keep the choice the same in
     // the oracle and here when a body lies flat and many separations agree to rounding.  Rare (a fallen robot): one wave-uniform test per
     // pass; the ranking walks the wavefront's candidates with v_readlane (oracle/mqe_oracle.c "manifold reduction").
@@ -1152,7 +1152,7 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
       const int cnt = __popcll(wg & mine_m) + __popcll(ww & mine_m) + __popcll(wb & mine_m) + __popcll(wc & mine_m) + __popcll(we & mine_m);
       const bool over = cnt > cap && act >= 0;
       if (__ballot(cnt > cap) != 0ull) {
-        auto bucket = [](float sd) -> int { return (int)floorf((sd + 1e-3f) * 500.0f); };
+        auto bucket = [](float sd) -> int { return sd < -1e-3f ? (int)floorf((sd + 1e-3f) * 500.0f) : 0; };
         const int lw = lane_wave;
         const int kb[5] = {bucket(gsd), bucket(wsd), bucket(bsd), bucket(csd), bucket(esd)};
         int rk[5] = {0, 0, 0, 0, 0};

@@ -1032,7 +1032,7 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
     const int cap = act < A ? CAP_ROBOT : cap_npc;
     /* manifold reduction (round 6; desc.edge_contacts bit 8, off by default): a ROBOT's one-sided contacts are collected first -- in the canonical order: feature by feature (ground,
      * wall, platform, column), then the edge contacts primitive by primitive -- and when there are more than its slots the DEEPEST are kept:
-     * separation in classes of 2 mm centred on zero (a body lying flat keeps the same set from substep to substep: its touching points tie and fall back to the feature order), ties in the canonical order (feet first).  The kept ones enter the list in the canonical order.  (Rounds
+     * penetrations of more than 1 mm first, the deepest 2 mm class first; everything shallower -- resting and speculative contacts -- ties (a body lying flat keeps the feature order's spread and the same set from substep to substep), ties in the canonical order (feet first).  The kept ones enter the list in the canonical order.  (Rounds
      * 1-5 kept the first CAP_ROBOT and counted the rest as overflow; an NPC's cap still works that way.)  The engine does the same with a
      * ranking over the wavefront's candidate lanes (kernels_physics.hpp "keeps the DEEPEST ones"). */
     const int robot_first = w->nc;
@@ -1150,10 +1150,12 @@ static void simulate_env(mqo_sim* s, int env, envwork_t* w) {
     if (act < A && reduce && mine > robot_cap) {
       int keep[MAXC + 320];
       for (int i = 0; i < mine; i++) {
-        const int bi = (int)floor((double)(((float)w->con[robot_first + i].sd + 1e-3f) * 500.0f));
+        const float sdi = (float)w->con[robot_first + i].sd;
+        const int bi = sdi < -1e-3f ? (int)floor((double)((sdi + 1e-3f) * 500.0f)) : 0;
         int rank = 0;
         for (int j = 0; j < mine; j++) {
-          const int bj = (int)floor((double)(((float)w->con[robot_first + j].sd + 1e-3f) * 500.0f));
+          const float sdj = (float)w->con[robot_first + j].sd;
+          const int bj = sdj < -1e-3f ? (int)floor((double)((sdj + 1e-3f) * 500.0f)) : 0;
           if (bj < bi || (bj == bi && j < i)) rank++;
         }
         keep[i] = rank < robot_cap;

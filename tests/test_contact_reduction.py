@@ -1,5 +1,6 @@
 """Manifold reduction of a robot's one-sided contacts (round 6, VERDICT r5 "Next" 4; desc.edge_contacts bit 8, off by default): a robot that touches the static world at more points than
-its eight slots keeps the DEEPEST ones -- separation in 2 mm classes, ties in feature order -- instead of the first eight in feature order.
+its eight slots keeps every contact that penetrates by more than 1 mm first (deepest 2 mm class first), then feature order -- instead of the first eight in
+feature order whatever their depth.
 Counted in MQE_T_CONTACT_REDUCED; MQE_T_CONTACT_OVERFLOW stays zero for it.  The specification is oracle/mqe_oracle.c ("manifold reduction");
 the HIP engine ranks the wavefront's candidate lanes (kernels_physics.hpp) and must produce the same list."""
 import numpy as np
