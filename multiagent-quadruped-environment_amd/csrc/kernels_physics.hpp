@@ -956,7 +956,8 @@ __device__ __forceinline__ void phys_substep(const DevModel* __restrict__ m, con
     ssB = ld3(lds + L.root + A * 13);
     ssPiv = ssB + v3(m->ss_joint_offset[0], m->ss_joint_offset[1], m->ss_joint_offset[2]);
     ssTheta = lds[L.dof + (12 * A) * 2];
-    const float cth = cosf(ssTheta), sth = sinf(ssTheta);
+    float cth, sth;
+    joint_sincos(ssTheta, sth, cth);                    // (libm beyond |theta| = 8: a revolving door goes round)
     if (m->ss_axis == 3) ssPiv.y += ssTheta;                                                // slider: translation along +y, no rotation
     else if (m->ss_axis == 2) { ssR[0] = cth; ssR[1] = -sth; ssR[3] = sth; ssR[4] = cth; }  // door: rotation about +z
     else { ssR[0] = cth; ssR[2] = sth; ssR[6] = -sth; ssR[8] = cth; }                       // plank: rotation about +y
