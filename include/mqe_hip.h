@@ -30,8 +30,9 @@ extern "C" {
  * (new export); MQE_MAX_NPCS 16 and mqe_debug_tail_times / mqe_profile_enable(on = N) as shipped late in round 5 under v14; an env's contact
  * list holds the sum of its per-actor caps (+ 8 two-actor slots in scenes of more than four actors, at most 64) instead of min(40, .), and
  * mqe_sim_create refuses a scene whose caps exceed 64; edge_contacts bit 8 + MQE_T_CONTACT_REDUCED (new tensor): optional manifold reduction of a
- * robot's one-sided contacts to its DEEPEST eight instead of the first eight in feature order. */
-#define MQE_ABI_VERSION 15
+ * robot's one-sided contacts to its DEEPEST eight instead of the first eight in feature order.  v16 (round 6) over v15: mqe_debug_epilogue_times
+ * (new export). */
+#define MQE_ABI_VERSION 16
 #define MQE_MAX_SPHERES 64    /* feature points of one robot (the capsule model has 32, the exact one 60) */
 #define MQE_MAX_PRIMS 20      /* collision primitives of one robot (Go1: 18) */
 #define MQE_MAX_SELF_PAIRS 384
@@ -443,6 +444,11 @@ int mqe_debug_tail_times(mqe_sim* s, long long* out_host);
  * live; [num_envs][4 substeps][16] wall-clock stamps (100 MHz) of the last launch: taps 0..14 of the substep (kernels_physics.hpp
  * TSTAMP), [15] = its end (tools/dev/phase_walltimes.py: where the time of a full launch goes, phase by phase) */
 int mqe_debug_phase_times(mqe_sim* s, long long* out_host);
+/* the same handles (scenes whose post-physics step is the decimation kernel's epilogue): [num_envs][16] stamps of the epilogue of the last launch --
+ * [0] after the actuator history's write-back, [1] actions staged, [2] loads + frame quantities, [3] flag / frame stores, [4] NPC rows staged,
+ * [5] NPC script, [6] reset, [7] observation rows staged, [8] task wrapper (one lane per env), [9] rows flushed, [10] end
+ * (tools/dev/epilogue_taps.py, round 6: the wrapper's serialised load -> store chains were half of the epilogue) */
+int mqe_debug_epilogue_times(mqe_sim* s, long long* out_host);
 
 /* Checkpoint / resume of the simulation state (the reference has none: SURVEY 5).  The blob holds every state buffer of the handle --
  * the tensors of mqe_sim_tensor and the internal ones (the compact history operand and its ring position, the action-lag ring, wrapper

@@ -2764,6 +2764,8 @@ __global__ void __launch_bounds__(64, EPW == 2 ? 2 : SubstepsClass<TP>::waves) k
   if constexpr (ShapeClass<TP>::small || TP > 0) if (pa.on) {      // (every kernel of the 16-envs-per-CU class; with the DevState pointers in register pairs of their own none of them spills)
     // ---- post_physics_step of this wavefront's env(s) (legged_robot.py:117-157 + the task wrapper), from the state just written: the
     // writer and the readers are lanes of this one wavefront (one CU, one vector L1), a workgroup-scope fence orders them
+    long long* et = nullptr;
+    if constexpr (TIMED) { et = st.wave_times + 68 * (size_t)gridDim.x + (size_t)blockIdx.x * 16; if (lane_wave == 0) et[0] = (long long)wall_clock64(); }
     __threadfence_block();
     __syncthreads();
     constexpr int AMP = (TA == 1 || TA == 2) ? 2 : MQE_MAX_AGENTS;
@@ -2779,8 +2781,10 @@ __global__ void __launch_bounds__(64, EPW == 2 ? 2 : SubstepsClass<TP>::waves) k
       if (e_first + ge < m->N) act_l[ge * nj + jt] = st.actions[(size_t)(e_first + ge) * nj + jt];
     }
     __syncthreads();
-    post_body<AMP, EPW>(m, st, (int)blockIdx.x, lane_wave, sb, sb + EPW * AMP * MQE_OBS_BAG, sb + EPW * AMP * (MQE_OBS_BAG + 24), pa.wrapper_level, pa.push_count, pa.step_no,
-                        lds_wave + L.root, lds_wave + L.dof, act_l, L.total, nj, post_npc_stride(P));
+    if constexpr (TIMED) { if (lane_wave == 0) et[1] = (long long)wall_clock64(); }
+    post_body<AMP, EPW, true>(m, st, (int)blockIdx.x, lane_wave, sb, sb + EPW * AMP * MQE_OBS_BAG, sb + EPW * AMP * (MQE_OBS_BAG + 24), pa.wrapper_level, pa.push_count, pa.step_no,
+                        lds_wave + L.root, lds_wave + L.dof, act_l, L.total, nj, post_npc_stride(P), et);
+    if constexpr (TIMED) { if (lane_wave == 0) et[10] = (long long)wall_clock64(); }
   }
   if (st.wave_times && lane_wave == 0) st.wave_times[4 * blockIdx.x + 1] = (long long)wall_clock64();
 }

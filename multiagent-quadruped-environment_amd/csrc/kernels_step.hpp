@@ -3,6 +3,7 @@
 // Each kernel cites the reference lines it replaces; arithmetic order follows the reference / the CPU oracle so that
 // integer and flag results are identical and float results agree to the last bits where libm allows.
 #pragma once
+#include <type_traits>
 #include "mqe_common.hpp"
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -471,26 +472,32 @@ __device__ __forceinline__ float mqe_randn(const DevModel* m, int e, int step_no
 // The sheep script (go1_sheep.py:35-64) in three pieces so that k_post_physics can spread an env's sheep over lanes: flock mean
 // (+ the two logged statistics), one sheep's velocity increment from the pre-update state, and its write-back.  All increments are
 // formed before any row is written, as in the reference's vectorised update.
-__device__ __forceinline__ void sheep_flock_mean(const DevModel* m, const float* root, float* avg) {
-  const int A = m->A, P = m->P;
+// npc_rows: the env's NPC rows [P][13] before the update, rob_rows: its robots' rows [A][13] -- global memory, or the caller's LDS copies
+// (post_body: a row read back from global memory behind a store costs a full round trip, and the script had six of them in a row)
+typedef const __attribute__((address_space(3))) float* lds_cptr;
+template <class NP>
+__device__ __forceinline__ void sheep_flock_mean(const DevModel* m, NP npc_rows, float* avg) {
+  const int P = m->P;
   avg[0] = 0; avg[1] = 0; avg[2] = 0;
-  for (int p = 0; p < P; p++) for (int k = 0; k < 3; k++) avg[k] += root[(A + p) * 13 + k];
+  for (int p = 0; p < P; p++) for (int k = 0; k < 3; k++) avg[k] += npc_rows[p * 13 + k];
   for (int k = 0; k < 3; k++) avg[k] /= (float)P;
 }
-__device__ __forceinline__ void sheep_flock_stats(const DevModel* m, const DevState& st, int e, const float* root, const float* avg) {
-  const int A = m->A, P = m->P;
-  st.sheep_avg[e * 2] = avg[0]; st.sheep_avg[e * 2 + 1] = avg[1];
+template <class NP>
+__device__ __forceinline__ void sheep_flock_stats(const DevModel* m, const DevState& st, int e, NP npc_rows, const float* avg) {
+  const int P = m->P;
   float var = 0;
   for (int k = 0; k < 2; k++) {
     float acc = 0;
-    for (int p = 0; p < P; p++) { float t = root[(A + p) * 13 + k] - avg[k]; acc += t * t; }
+    for (int p = 0; p < P; p++) { float t = npc_rows[p * 13 + k] - avg[k]; acc += t * t; }
     var += acc / (float)P;
   }
+  st.sheep_avg[e * 2] = avg[0]; st.sheep_avg[e * 2 + 1] = avg[1];
   st.sheep_var[e] = var;
 }
-__device__ __forceinline__ void sheep_increment(const DevModel* m, const DevState& st, int e, int p, const float* root, const float* avg, int step_no, float* dv) {
+template <class NP, class RP>
+__device__ __forceinline__ void sheep_increment(const DevModel* m, const DevState& st, int e, int p, NP npc_rows, RP rob_rows, const float* avg, int step_no, float* dv) {
   const int A = m->A, P = m->P;
-  const float* sp = root + (A + p) * 13;
+  NP sp = npc_rows + p * 13;
   for (int k = 0; k < 3; k++) {
     // MQE_NOISE_SCRIPTED: the injected sequence (golden traces); otherwise a fresh draw every step, as the reference's randn_like
     const float z = m->noise_mode == MQE_NOISE_SCRIPTED ? st.npc_noise[((size_t)e * P + p) * 3 + k]
@@ -505,7 +512,7 @@ __device__ __forceinline__ void sheep_increment(const DevModel* m, const DevStat
     if (nr > 0.0f) for (int k = 0; k < 3; k++) dv[k] += m->sheep_rand * rel[k] / nr / 1.5f;
   }
   for (int a = 0; a < A; a++) {
-    const float* dp = root + a * 13;
+    RP dp = rob_rows + a * 13;
     float rel[3] = {sp[0] - dp[0], sp[1] - dp[1], sp[2] - dp[2]};
     float sq[3] = {rel[0] * rel[0], rel[1] * rel[1], rel[2] * rel[2]};
     float dis = sqrtf(sq[0] * sq[0] + sq[1] * sq[1] + sq[2] * sq[2]);
@@ -514,61 +521,240 @@ __device__ __forceinline__ void sheep_increment(const DevModel* m, const DevStat
   }
   dv[2] = 0.0f;
 }
-__device__ __forceinline__ void sheep_apply(float* root, int A, int p, const float* dv) {
+// the sheep's new row entries from its row before the update (npc_rows) -- stores only
+template <class NP>
+__device__ __forceinline__ void sheep_apply(float* root, int A, int p, NP npc_rows, const float* dv) {
   float* sp = root + (A + p) * 13;
-  for (int k = 0; k < 3; k++) sp[7 + k] += dv[k];
-  for (int k = 0; k < 2; k++) sp[7 + k] = clampf(sp[7 + k], -2.0f, 2.0f);
-  sp[2] = clampf(sp[2], 0.0f, 0.3f);
+  NP old = npc_rows + p * 13;
+  const float v0 = clampf(old[7] + dv[0], -2.0f, 2.0f), v1 = clampf(old[8] + dv[1], -2.0f, 2.0f), v2 = old[9] + dv[2];
+  sp[7] = v0; sp[8] = v1; sp[9] = v2;
+  sp[2] = clampf(old[2], 0.0f, 0.3f);
   sp[3] = 0.0f; sp[4] = 0.0f;
 }
 // wrapper observation + reward for env e.  npc = the `root_states_npc` rows the wrapper sees ([P][13]); see oracle.
 // side_effects: 1 on the wrapper-level paths (mqe_step, mqe_wrapper_eval); the Go1-level mqe_post_physics_step passes 0 so that the
 // state stays exactly what Go1.step leaves (go1tug re-poses its slider from the wrapper)
-__device__ __forceinline__ void wrapper_env_dev(const DevModel* m, const DevState& st, int e, int is_reset_call, const float* npc, int side_effects = 1, const float* bag = nullptr) {
-  if (!bag) bag = st.obs_bag + (size_t)e * m->A * MQE_OBS_BAG;   // this env's rows (k_post_physics passes its LDS copy)
+// BAG_LDS: `bag_in` is the caller's LDS copy of the env's observation rows (post_body), read as LDS (ds_read) -- as a generic pointer
+// (null = "read the tensor") the rows were fetched with flat_load, whose completion counts on vmcnt like the stores in front of it: every
+// element of the observation copy below waited for the previous element's store to be acknowledged (5.6 of the epilogue's 10.7 us on go1gate).
+template <bool BAG_LDS = false>
+__device__ __forceinline__ void wrapper_env_dev(const DevModel* m, const DevState& st, int e, int is_reset_call, const float* npc, int side_effects = 1, const float* bag_in = nullptr) {
+  typedef typename std::conditional<BAG_LDS, const __attribute__((address_space(3))) float*, const float*>::type bag_ptr;
+  bag_ptr bag;
+  if constexpr (BAG_LDS) bag = (bag_ptr)bag_in;
+  else bag = bag_in ? bag_in : st.obs_bag + (size_t)e * m->A * MQE_OBS_BAG;   // this env's rows
   int A = m->A, P = m->P, Aw = m->Aw, D = m->D;
+  const int task = m->task;
   float* obs = st.wobs + (size_t)e * Aw * D;
   float* rew = st.wrew + (size_t)e * Aw;
   float* rs = st.rsum + (size_t)e * MQE_MAX_REWARD_TERMS;
-  const float* sc = m->reward_scale;
+  float sc[7];
+#pragma unroll
+  for (int k = 0; k < 7; k++) sc[k] = m->reward_scale[k];
+  // Loads first, and no load behind a store (see post_body): the per-env constants the rows and the reward read, once; then -- for the tasks
+  // whose reward does not touch the observation rows -- the reward (its loads are the first memory operations of the call), then the
+  // observation rows, which read nothing but LDS and registers.  The rows and the reward share no tensor, so the order changes no value.
+  const bool early = task == MQE_TASK_GATE || task == MQE_TASK_SHEEP || task == MQE_TASK_SEESAW || task == MQE_TASK_PUSHBOX || task == MQE_TASK_FOOTBALL_DEFENDER;
+  float gp0 = 0.0f, gp1 = 0.0f, eol[3] = {0.0f, 0.0f, 0.0f}, eo0 = 0.0f, eo1 = 0.0f;
+  if (task == MQE_TASK_GATE || task == MQE_TASK_SHEEP || task == MQE_TASK_PUSHBOX || (task == MQE_TASK_FOOTBALL_DEFENDER && !is_reset_call && (sc[0] != 0 || sc[1] != 0))) {
+    gp0 = as_global(m->gate_pos)[e * 2]; gp1 = as_global(m->gate_pos)[e * 2 + 1];
+  }
+  if (task == MQE_TASK_PUSHBOX || task == MQE_TASK_FOOTBALL_DEFENDER)
+    for (int k = 0; k < 3; k++) eol[k] = st.env_origins_live[e * 3 + k];
+  if (task == MQE_TASK_SHEEP) { eo0 = as_global(m->env_origins)[e * 3]; eo1 = as_global(m->env_origins)[e * 3 + 1]; }
+  if (early) {
+    if (is_reset_call) { for (int a = 0; a < Aw; a++) rew[a] = 0; }
+    else {
+      float r_env = 0.0f;
+      uint8_t was_reset = st.reset_buf[e];
+      float rsv[7];                               // the env's reward sums: read once, accumulated in registers, written once (`rs[k] += v` is a
+#pragma unroll
+      for (int k = 0; k < 7; k++) rsv[k] = rs[k];   // load behind the previous term's store: one memory round trip per reward term)
+      if (task == MQE_TASK_GATE) {
+        // loads first (see k_post_physics), then the same sums in the same order as the straightforward loop nest
+        float r_ag[MQE_MAX_AGENTS] = {0, 0, 0, 0}, bx[MQE_MAX_AGENTS] = {0, 0, 0, 0}, by[MQE_MAX_AGENTS] = {0, 0, 0, 0}, wl[MQE_MAX_AGENTS] = {0, 0, 0, 0};
+        const uint8_t have = st.w_have_last[e];
+        const float gx = gp0, colf = (float)st.collide_buf[e];
+        float rs0 = rsv[0], rs1 = rsv[1], rs2 = rsv[2], rs3 = rsv[3];
+        const float wp0 = m->wrapper_param[0], wp1 = m->wrapper_param[1];
+#pragma unroll
+        for (int a = 0; a < MQE_MAX_AGENTS; a++)
+          if (a < A) {
+            bag_ptr ob = bag + (a) * MQE_OBS_BAG;
+            bx[a] = ob[0]; by[a] = ob[1];
+            wl[a] = st.w_last[e * MQE_MAX_AGENTS + a];
+          }
+        float tsum = 0;
+#pragma unroll
+        for (int a = 0; a < MQE_MAX_AGENTS; a++)
+          if (a < A) {
+            const float tx = wp0, ty = (a == 0 ? 1.0f : -1.0f) * wp1;
+            const float dist = sqrtf((bx[a] - tx) * (bx[a] - tx) + (by[a] - ty) * (by[a] - ty));
+            const float last = have ? wl[a] : dist;
+            tsum += last - dist;
+            st.w_last[e * MQE_MAX_AGENTS + a] = dist;
+          }
+        st.w_have_last[e] = 1;
+        if (was_reset) tsum = 0;
+        tsum *= sc[0];
+        const float col = sc[1] * colf;
+        rs0 += tsum;
+        rs1 += col;
+#pragma unroll
+        for (int a = 0; a < MQE_MAX_AGENTS; a++)
+          if (a < A) {
+            r_ag[a] += tsum;
+            r_ag[a] += col;
+            if (bx[a] > gx + 0.25f) { r_ag[a] += sc[2]; rs2 += sc[2]; }
+            const int pa = A - 1 - a;
+            const float px = pa == 0 ? bx[0] : (pa == 1 ? bx[1] : (pa == 2 ? bx[2] : bx[3]));
+            const float py = pa == 0 ? by[0] : (pa == 1 ? by[1] : (pa == 2 ? by[2] : by[3]));
+            const float d2 = (bx[a] - px) * (bx[a] - px) + (by[a] - py) * (by[a] - py);
+            if (d2 < 0.25f) { const float pn = div_ieee(sc[3], d2); r_ag[a] += pn; rs3 += pn; }
+          }
+        rsv[0] = rs0; rsv[1] = rs1; rsv[2] = rs2; rsv[3] = rs3;
+        float tot = 0;
+#pragma unroll
+        for (int a = 0; a < MQE_MAX_AGENTS; a++) if (a < A) tot += r_ag[a];
+        for (int a = 0; a < A; a++) rew[a] = tot;
+      } else if (task == MQE_TASK_SHEEP) {
+        float gate_x = gp0;
+        const float colf = (float)st.collide_buf[e], avg0 = st.sheep_avg[e * 2], avg1 = st.sheep_avg[e * 2 + 1], wl20 = st.w_last2[e * 2], svar = st.sheep_var[e];
+        const uint8_t have = st.w_have_last[e], delayed = st.w_delayed_reset[e];
+        if (sc[0] != 0) {
+          int cnt = 0;
+          for (int p = 0; p < P; p++) if ((npc[p * 13] - eo0) - gate_x > 0) cnt++;
+          r_env = (float)cnt;
+          rsv[0] += (float)cnt;
+        }
+        if (sc[1] != 0) { float c = sc[1] * colf; r_env += c; rsv[1] += c; }
+        if (sc[2] != 0) {
+          if (have) {
+            float xm = avg0 - wl20;
+            if (delayed) xm = 0;
+            float v = sc[2] * xm;
+            r_env += v; rsv[2] += v;
+          }
+          st.w_last2[e * 2] = avg0; st.w_last2[e * 2 + 1] = avg1;
+          st.w_have_last[e] = 1;
+        }
+        if (sc[3] != 0) {
+          float acc = 0;
+          for (int p = 0; p < P; p++) {
+            float x = npc[p * 13] - eo0, y = npc[p * 13 + 1] - eo1;
+            float dg = sqrtf((x - gate_x) * (x - gate_x) + (y - gp1) * (y - gp1));
+            float v = expf(-dg / 2.0f) * sc[3];
+            if (x >= gate_x) v = sc[3];
+            acc += v;
+          }
+          r_env += acc; rsv[3] += acc;
+        }
+        if (sc[4] != 0 || sc[5] != 0) {
+          float v = sc[5] * (svar - 1.0f) + sc[4] * expf(svar / 2.0f - 1.0f);
+          r_env += v; rsv[4] += v;
+        }
+        st.w_delayed_reset[e] = was_reset;
+        for (int a = 0; a < Aw; a++) rew[a] = r_env;
+      } else if (task == MQE_TASK_SEESAW) {
+        float xs = 0, zs = 0, y2 = 0, wl[MQE_MAX_AGENTS] = {0, 0, 0, 0};
+        const uint8_t have = st.w_have_last[e];
+        const float colf = (float)st.collide_buf[e];
+        const bool fell = sc[6] != 0 && (st.r_term[e] | st.p_term[e]) != 0;
+#pragma unroll
+        for (int a = 0; a < MQE_MAX_AGENTS; a++) if (a < A) wl[a] = st.w_last[e * MQE_MAX_AGENTS + a];
+#pragma unroll
+        for (int a = 0; a < MQE_MAX_AGENTS; a++)
+          if (a < A) {
+            bag_ptr ob = bag + (a) * MQE_OBS_BAG;
+            const float x = ob[0];
+            xs += x - (have ? wl[a] : x);             // (no last position yet: it is taken to be this one)
+            st.w_last[e * MQE_MAX_AGENTS + a] = x;
+            zs += ob[2]; y2 += ob[1] * ob[1];
+          }
+        st.w_have_last[e] = 1;
+        if (sc[0] != 0) { if (was_reset) xs = 0; xs *= sc[0]; r_env += xs; rsv[0] += xs; }
+        if (sc[1] != 0) { float v = sc[1] * (zs - 0.56f); r_env += v; rsv[1] += v; }
+        if (sc[2] != 0) { float v = sc[2] * (y2 - 0.5f); r_env += v; rsv[2] += v; }
+        if (sc[3] != 0) { float v = sc[3] * colf; r_env += v; rsv[3] += v; }
+        if (sc[4] != 0) {
+          bag_ptr o0 = bag; bag_ptr o1 = bag + (A - 1) * MQE_OBS_BAG;
+          float d2 = (o0[0] - o1[0]) * (o0[0] - o1[0]) + (o0[1] - o1[1]) * (o0[1] - o1[1]);
+          if (d2 < 0.25f) { float v = div_ieee(sc[4], d2); r_env += v; rsv[4] += v; }
+        }
+        if (sc[5] != 0) {
+          int cnt = 0;
+          for (int a = 0; a < A; a++) { bag_ptr ob = bag + (a) * MQE_OBS_BAG; if (ob[0] > 7.7f && ob[2] > 1.3f) cnt++; }
+          float v = sc[5] * (float)cnt; r_env += v; rsv[5] += v;
+        }
+        if (fell) { r_env += sc[6]; rsv[6] += sc[6]; }
+        for (int a = 0; a < Aw; a++) rew[a] = r_env;
+      } else if (task == MQE_TASK_PUSHBOX) {                // go1_pushbox_wrapper.py:52-88
+        const float bx = npc[0] - eol[0], wl20 = st.w_last2[e * 2];
+        const uint8_t have = st.w_have_last[e];
+        if (sc[0] != 0 && have) {
+          float xm = bx - wl20;
+          if (was_reset) xm = 0;                        // x_movement[reset_ids] = 0
+          const float v = sc[0] * xm;
+          r_env += v; rsv[0] += v;
+        }
+        st.w_last2[e * 2] = bx;
+        st.w_have_last[e] = 1;
+        for (int a = 0; a < Aw; a++) rew[a] = r_env;
+      } else if (task == MQE_TASK_FOOTBALL_DEFENDER) {
+        float bx = npc[0] - eol[0], by = npc[1] - eol[1];
+        if (sc[0] != 0) { if (bx > gp0) { r_env += sc[0]; rsv[0] += sc[0]; } }
+        if (sc[1] != 0) {
+          float dg = sqrtf((bx - gp0) * (bx - gp0) + (by - gp1) * (by - gp1));
+          float v = sc[1] * expf(-dg / 3.0f);
+          r_env += v; rsv[1] += v;
+        }
+        for (int a = 0; a < Aw; a++) rew[a] = r_env;
+      }
+#pragma unroll
+      for (int k = 0; k < 7; k++) rs[k] = rsv[k];
+    }
+  }
   for (int a = 0; a < Aw; a++) {
     float* o = obs + a * D;
     int c = 0;
-    if (m->task == MQE_TASK_TUG) {                // go1_tug_wrapper.py:47-57: [base info, slider (pos, vel), distance to it, slider pos]
+    if (task == MQE_TASK_TUG) {                // go1_tug_wrapper.py:47-57: [base info, slider (pos, vel), distance to it, slider pos]
       const float npos = st.dof[((size_t)e * m->ND + 12 * A) * 2], nvel = st.dof[((size_t)e * m->ND + 12 * A) * 2 + 1];
       const float sgn = a == 1 ? -1.0f : 1.0f;    // agent 1 sees the mirrored scene: entries 1, 4, 6, 9 negated
-      const float* ob = bag + (a) * MQE_OBS_BAG;
-      for (int k = 0; k < 6; k++) o[k] = ob[k];
-      const float dx = o[0] - 1.6f, dy = o[1] - npos;
-      o[1] *= sgn; o[4] *= sgn;
+      bag_ptr ob = bag + (a) * MQE_OBS_BAG;
+      float v6[6];
+      for (int k = 0; k < 6; k++) v6[k] = ob[k];
+      const float dx = v6[0] - 1.6f, dy = v6[1] - npos;
+      v6[1] *= sgn; v6[4] *= sgn;
+      for (int k = 0; k < 6; k++) o[k] = v6[k];
       o[6] = sgn * npos; o[7] = nvel; o[8] = sqrtf(dx * dx + dy * dy); o[9] = sgn * npos;
       continue;
     }
-    if (m->task != MQE_TASK_ROTATION && m->task != MQE_TASK_BRIDGE && m->task != MQE_TASK_WRESTLING)
+    if (task != MQE_TASK_ROTATION && task != MQE_TASK_BRIDGE && task != MQE_TASK_WRESTLING)
       for (int k = 0; k < Aw; k++) o[c++] = (k == a) ? 1.0f : 0.0f;
-    const float* ob = bag + (a) * MQE_OBS_BAG;
+    bag_ptr ob = bag + (a) * MQE_OBS_BAG;
     for (int k = 0; k < 6; k++) o[c++] = ob[k];
-    if (m->task != MQE_TASK_PLAIN) {
-      const float* ob2 = bag + ((Aw - 1 - a)) * MQE_OBS_BAG;
+    if (task != MQE_TASK_PLAIN) {
+      bag_ptr ob2 = bag + ((Aw - 1 - a)) * MQE_OBS_BAG;
       for (int k = 0; k < 6; k++) o[c++] = ob2[k];
     }
-    if (m->task == MQE_TASK_GATE || m->task == MQE_TASK_SHEEP || m->task == MQE_TASK_PUSHBOX) { o[c++] = as_global(m->gate_pos)[e * 2]; o[c++] = as_global(m->gate_pos)[e * 2 + 1]; }
-    if (m->task == MQE_TASK_PUSHBOX) {              // go1_pushbox_wrapper.py:44-48: box xy rel. env origin, box quaternion
-      o[c++] = npc[0] - st.env_origins_live[e * 3]; o[c++] = npc[1] - st.env_origins_live[e * 3 + 1];
+    if (task == MQE_TASK_GATE || task == MQE_TASK_SHEEP || task == MQE_TASK_PUSHBOX) { o[c++] = gp0; o[c++] = gp1; }
+    if (task == MQE_TASK_PUSHBOX) {              // go1_pushbox_wrapper.py:44-48: box xy rel. env origin, box quaternion
+      o[c++] = npc[0] - eol[0]; o[c++] = npc[1] - eol[1];
       for (int k = 0; k < 4; k++) o[c++] = npc[3 + k];
     }
-    if (m->task == MQE_TASK_SHEEP)
-      for (int p = 0; p < P; p++) { o[c++] = npc[p * 13] - as_global(m->env_origins)[e * 3]; o[c++] = npc[p * 13 + 1] - as_global(m->env_origins)[e * 3 + 1]; }
-    if (m->task == MQE_TASK_FOOTBALL_DEFENDER) {
-      for (int k = 0; k < 3; k++) o[c++] = npc[k] - st.env_origins_live[e * 3 + k];
+    if (task == MQE_TASK_SHEEP)
+      for (int p = 0; p < P; p++) { o[c++] = npc[p * 13] - eo0; o[c++] = npc[p * 13 + 1] - eo1; }
+    if (task == MQE_TASK_FOOTBALL_DEFENDER) {
+      for (int k = 0; k < 3; k++) o[c++] = npc[k] - eol[k];
       for (int k = 0; k < 3; k++) o[c++] = npc[7 + k];
     }
   }
-  if (m->task == MQE_TASK_TUG) {                  // go1_tug_wrapper.py:59-136
+  if (early) return;
+  if (task == MQE_TASK_TUG) {                  // go1_tug_wrapper.py:59-136
     float* nd = st.dof + ((size_t)e * m->ND + 12 * A) * 2;
     const float npos = nd[0];
-    const float* ob0 = bag;
-    const float* ob1 = bag + (1) * MQE_OBS_BAG;
+    bag_ptr ob0 = bag;
+    bag_ptr ob1 = bag + (1) * MQE_OBS_BAG;
     const float x0 = ob0[0], y0 = ob0[1], x1 = ob1[0], y1 = ob1[1];
     if (is_reset_call) {                          // _init_extras (:37-40)
       st.w_last[e * MQE_MAX_AGENTS] = x0; st.w_last[e * MQE_MAX_AGENTS + 1] = y0;
@@ -599,9 +785,9 @@ __device__ __forceinline__ void wrapper_env_dev(const DevModel* m, const DevStat
     }
     return;
   }
-  if (m->task == MQE_TASK_BRIDGE) {               // go1_bridge_wrapper.py
-    const float* ob0 = bag;
-    const float* ob1 = bag + (1) * MQE_OBS_BAG;
+  if (task == MQE_TASK_BRIDGE) {               // go1_bridge_wrapper.py
+    bag_ptr ob0 = bag;
+    bag_ptr ob1 = bag + (1) * MQE_OBS_BAG;
     const float x0 = ob0[0], z0 = ob0[2], x1 = ob1[0], z1 = ob1[2];
     float S = st.w_last[e * MQE_MAX_AGENTS], tgt = st.w_last[e * MQE_MAX_AGENTS + 1];
     if (is_reset_call) {                          // _init_extras (:27-29): target_pos = flip(base_pos at reset)
@@ -619,14 +805,14 @@ __device__ __forceinline__ void wrapper_env_dev(const DevModel* m, const DevStat
     for (int a = 1; a < Aw; a++) rew[a] = 0;
     return;
   }
-  if (m->task == MQE_TASK_WRESTLING) {            // go1_wrestling_wrapper.py
+  if (task == MQE_TASK_WRESTLING) {            // go1_wrestling_wrapper.py
     float* o1 = obs + 1 * D;
     o1[1] = -o1[1]; o1[4] = -o1[4]; o1[7] = -o1[7]; o1[10] = -o1[10];
     if (is_reset_call) { for (int a = 0; a < Aw; a++) rew[a] = 0; return; }
     float r0 = 0.0f;
     bool down0, down1;
     {
-      const float* ob = bag;
+      bag_ptr ob = bag;
       float r = ob[3], p = ob[4];
       if (r > 3.1415927f) r -= 6.2831855f;
       if (p > 3.1415927f) p -= 6.2831855f;
@@ -643,12 +829,12 @@ __device__ __forceinline__ void wrapper_env_dev(const DevModel* m, const DevStat
     for (int a = 1; a < Aw; a++) rew[a] = 0;
     return;
   }
-  if (m->task == MQE_TASK_ROTATION) {             // go1_rotation_wrapper.py:46-50,90-93: agent 1 sees the mirrored scene
+  if (task == MQE_TASK_ROTATION) {             // go1_rotation_wrapper.py:46-50,90-93: agent 1 sees the mirrored scene
     float* o1 = obs + 1 * D;
     o1[1] = -o1[1]; o1[4] = -o1[4]; o1[7] = -o1[7]; o1[10] = -o1[10];
     const float tgt = m->wrapper_param[0];
-    const float* ob0 = bag;
-    const float* ob1 = bag + (1) * MQE_OBS_BAG;
+    bag_ptr ob0 = bag;
+    bag_ptr ob1 = bag + (1) * MQE_OBS_BAG;
     const float x0 = ob0[0], y0 = ob0[1], x1 = ob1[0];
     if (is_reset_call) {                          // _init_extras (:30-38): only x is shifted by the target here
       st.w_last[e * MQE_MAX_AGENTS] = sqrtf((x0 - tgt) * (x0 - tgt) + y0 * y0);
@@ -667,148 +853,7 @@ __device__ __forceinline__ void wrapper_env_dev(const DevModel* m, const DevStat
     for (int a = 1; a < Aw; a++) rew[a] = 0;
     return;
   }
-  if (is_reset_call) { for (int a = 0; a < Aw; a++) rew[a] = 0; return; }
-  float r_env = 0.0f;
-  uint8_t was_reset = st.reset_buf[e];
-  if (m->task == MQE_TASK_GATE) {
-    // loads first (see k_post_physics), then the same sums in the same order as the straightforward loop nest
-    float r_ag[MQE_MAX_AGENTS] = {0, 0, 0, 0}, bx[MQE_MAX_AGENTS] = {0, 0, 0, 0}, by[MQE_MAX_AGENTS] = {0, 0, 0, 0}, wl[MQE_MAX_AGENTS] = {0, 0, 0, 0};
-    const uint8_t have = st.w_have_last[e];
-    const float gx = as_global(m->gate_pos)[e * 2], colf = (float)st.collide_buf[e];
-    float rs0 = rs[0], rs1 = rs[1], rs2 = rs[2], rs3 = rs[3];
-#pragma unroll
-    for (int a = 0; a < MQE_MAX_AGENTS; a++)
-      if (a < A) {
-        const float* ob = bag + (a) * MQE_OBS_BAG;
-        bx[a] = ob[0]; by[a] = ob[1];
-        wl[a] = st.w_last[e * MQE_MAX_AGENTS + a];
-      }
-    float tsum = 0;
-#pragma unroll
-    for (int a = 0; a < MQE_MAX_AGENTS; a++)
-      if (a < A) {
-        const float tx = m->wrapper_param[0], ty = (a == 0 ? 1.0f : -1.0f) * m->wrapper_param[1];
-        const float dist = sqrtf((bx[a] - tx) * (bx[a] - tx) + (by[a] - ty) * (by[a] - ty));
-        const float last = have ? wl[a] : dist;
-        tsum += last - dist;
-        st.w_last[e * MQE_MAX_AGENTS + a] = dist;
-      }
-    st.w_have_last[e] = 1;
-    if (was_reset) tsum = 0;
-    tsum *= sc[0];
-    const float col = sc[1] * colf;
-    rs0 += tsum;
-    rs1 += col;
-#pragma unroll
-    for (int a = 0; a < MQE_MAX_AGENTS; a++)
-      if (a < A) {
-        r_ag[a] += tsum;
-        r_ag[a] += col;
-        if (bx[a] > gx + 0.25f) { r_ag[a] += sc[2]; rs2 += sc[2]; }
-        const int pa = A - 1 - a;
-        const float px = pa == 0 ? bx[0] : (pa == 1 ? bx[1] : (pa == 2 ? bx[2] : bx[3]));
-        const float py = pa == 0 ? by[0] : (pa == 1 ? by[1] : (pa == 2 ? by[2] : by[3]));
-        const float d2 = (bx[a] - px) * (bx[a] - px) + (by[a] - py) * (by[a] - py);
-        if (d2 < 0.25f) { const float pn = div_ieee(sc[3], d2); r_ag[a] += pn; rs3 += pn; }
-      }
-    rs[0] = rs0; rs[1] = rs1; rs[2] = rs2; rs[3] = rs3;
-    float tot = 0;
-#pragma unroll
-    for (int a = 0; a < MQE_MAX_AGENTS; a++) if (a < A) tot += r_ag[a];
-    for (int a = 0; a < A; a++) rew[a] = tot;
-    return;
-  }
-  if (m->task == MQE_TASK_SHEEP) {
-    float gate_x = as_global(m->gate_pos)[e * 2];
-    if (sc[0] != 0) {
-      int cnt = 0;
-      for (int p = 0; p < P; p++) if ((npc[p * 13] - as_global(m->env_origins)[e * 3]) - gate_x > 0) cnt++;
-      r_env = (float)cnt;
-      rs[0] += (float)cnt;
-    }
-    if (sc[1] != 0) { float c = sc[1] * (float)st.collide_buf[e]; r_env += c; rs[1] += c; }
-    if (sc[2] != 0) {
-      if (st.w_have_last[e]) {
-        float xm = st.sheep_avg[e * 2] - st.w_last2[e * 2];
-        if (st.w_delayed_reset[e]) xm = 0;
-        float v = sc[2] * xm;
-        r_env += v; rs[2] += v;
-      }
-      st.w_last2[e * 2] = st.sheep_avg[e * 2]; st.w_last2[e * 2 + 1] = st.sheep_avg[e * 2 + 1];
-      st.w_have_last[e] = 1;
-    }
-    if (sc[3] != 0) {
-      float acc = 0;
-      for (int p = 0; p < P; p++) {
-        float x = npc[p * 13] - as_global(m->env_origins)[e * 3], y = npc[p * 13 + 1] - as_global(m->env_origins)[e * 3 + 1];
-        float dg = sqrtf((x - gate_x) * (x - gate_x) + (y - as_global(m->gate_pos)[e * 2 + 1]) * (y - as_global(m->gate_pos)[e * 2 + 1]));
-        float v = expf(-dg / 2.0f) * sc[3];
-        if (x >= gate_x) v = sc[3];
-        acc += v;
-      }
-      r_env += acc; rs[3] += acc;
-    }
-    if (sc[4] != 0 || sc[5] != 0) {
-      float v = sc[5] * (st.sheep_var[e] - 1.0f) + sc[4] * expf(st.sheep_var[e] / 2.0f - 1.0f);
-      r_env += v; rs[4] += v;
-    }
-    st.w_delayed_reset[e] = was_reset;
-    for (int a = 0; a < Aw; a++) rew[a] = r_env;
-    return;
-  }
-  if (m->task == MQE_TASK_SEESAW) {
-    float xs = 0, zs = 0, y2 = 0;
-    for (int a = 0; a < A; a++) {
-      const float* ob = bag + (a) * MQE_OBS_BAG;
-      if (!st.w_have_last[e]) st.w_last[e * MQE_MAX_AGENTS + a] = ob[0];
-      xs += ob[0] - st.w_last[e * MQE_MAX_AGENTS + a];
-      st.w_last[e * MQE_MAX_AGENTS + a] = ob[0];
-      zs += ob[2]; y2 += ob[1] * ob[1];
-    }
-    st.w_have_last[e] = 1;
-    if (sc[0] != 0) { if (was_reset) xs = 0; xs *= sc[0]; r_env += xs; rs[0] += xs; }
-    if (sc[1] != 0) { float v = sc[1] * (zs - 0.56f); r_env += v; rs[1] += v; }
-    if (sc[2] != 0) { float v = sc[2] * (y2 - 0.5f); r_env += v; rs[2] += v; }
-    if (sc[3] != 0) { float v = sc[3] * (float)st.collide_buf[e]; r_env += v; rs[3] += v; }
-    if (sc[4] != 0) {
-      const float* o0 = bag; const float* o1 = bag + (A - 1) * MQE_OBS_BAG;
-      float d2 = (o0[0] - o1[0]) * (o0[0] - o1[0]) + (o0[1] - o1[1]) * (o0[1] - o1[1]);
-      if (d2 < 0.25f) { float v = div_ieee(sc[4], d2); r_env += v; rs[4] += v; }
-    }
-    if (sc[5] != 0) {
-      int cnt = 0;
-      for (int a = 0; a < A; a++) { const float* ob = bag + (a) * MQE_OBS_BAG; if (ob[0] > 7.7f && ob[2] > 1.3f) cnt++; }
-      float v = sc[5] * (float)cnt; r_env += v; rs[5] += v;
-    }
-    if (sc[6] != 0) { if (st.r_term[e] | st.p_term[e]) { r_env += sc[6]; rs[6] += sc[6]; } }
-    for (int a = 0; a < Aw; a++) rew[a] = r_env;
-    return;
-  }
-  if (m->task == MQE_TASK_PUSHBOX) {                // go1_pushbox_wrapper.py:52-88
-    const float bx = npc[0] - st.env_origins_live[e * 3];
-    if (sc[0] != 0 && st.w_have_last[e]) {
-      float xm = bx - st.w_last2[e * 2];
-      if (was_reset) xm = 0;                        // x_movement[reset_ids] = 0
-      const float v = sc[0] * xm;
-      r_env += v; rs[0] += v;
-    }
-    st.w_last2[e * 2] = bx;
-    st.w_have_last[e] = 1;
-    for (int a = 0; a < Aw; a++) rew[a] = r_env;
-    return;
-  }
-  if (m->task == MQE_TASK_FOOTBALL_DEFENDER) {
-    float bx = npc[0] - st.env_origins_live[e * 3], by = npc[1] - st.env_origins_live[e * 3 + 1];
-    if (sc[0] != 0) { if (bx > as_global(m->gate_pos)[e * 2]) { r_env += sc[0]; rs[0] += sc[0]; } }
-    if (sc[1] != 0) {
-      float dg = sqrtf((bx - as_global(m->gate_pos)[e * 2]) * (bx - as_global(m->gate_pos)[e * 2]) + (by - as_global(m->gate_pos)[e * 2 + 1]) * (by - as_global(m->gate_pos)[e * 2 + 1]));
-      float v = sc[1] * expf(-dg / 3.0f);
-      r_env += v; rs[1] += v;
-    }
-    for (int a = 0; a < Aw; a++) rew[a] = r_env;
-    return;
-  }
-  for (int a = 0; a < Aw; a++) rew[a] = 0;
+  for (int a = 0; a < Aw; a++) rew[a] = 0;         // the remaining tasks (reset call or not)
 }
 
 // Launch geometry: POST_EPW envs per 64-lane wavefront, lane = (agent, env): lane a * POST_EPW + le holds robot a of the
@@ -839,12 +884,15 @@ __device__ __forceinline__ void post_flush_rows(float* __restrict__ g, const flo
 // root_l / dof_l / act_l (fused epilogue only, else nullptr): the env's root rows, joint states and actions in LDS -- [PEPW] x ([A + P][13],
 // [ND][2], [12 A]) at the given strides -- so that the robot lanes' 49 scattered global loads become LDS reads (in the epilogue every
 // wavefront has 2 active lanes per vector-memory instruction: 8 x the instructions of the stand-alone kernel for the same bytes).
-template <int AM, int PEPW>
+// LDS_STATE: root_l / dof_l / act_l are given -- a compile-time flag, not a null test: a pointer that is "LDS or global" at run time is a
+// generic one, and its flat_load waits for every global store in front of it as well as for the LDS.
+template <int AM, int PEPW, bool LDS_STATE = false>
 __device__ __forceinline__ void post_body(const DevModel* m, const DevState& st, const int blk, const int tid, float* s_bag, float* s_la, float* s_npc,
                                           int wrapper_level, int push_count, int step_no,
                                           const float* root_l = nullptr, const float* dof_l = nullptr, const float* act_l = nullptr, int lds_env_stride = 0, int act_env_stride = 0,
-                                          const int npc_stride = MQE_MAX_NPCS * 13) {      // floats between two envs' NPC rows in s_npc (the fused epilogue packs them: P * 13 rounded up to 4)
+                                          const int npc_stride = MQE_MAX_NPCS * 13, long long* taps = nullptr) {      // floats between two envs' NPC rows in s_npc (the fused epilogue packs them: P * 13 rounded up to 4)
   static_assert(PEPW * AM <= 64 && (PEPW & (PEPW - 1)) == 0, "agent lanes of PEPW envs must fit one wavefront");
+#define ETAP(i) do { if (taps != nullptr && tid == 0) taps[i] = (long long)wall_clock64(); } while (0)
   const int A = m->A, P = m->P;
   const int le = tid & (PEPW - 1), a = tid / PEPW;
   const int e = blk * PEPW + le;
@@ -855,6 +903,9 @@ __device__ __forceinline__ void post_body(const DevModel* m, const DevState& st,
   const float dtp = m->dt * (float)m->decimation;
   float* root = st.root + (size_t)e * (A + P) * 13;
   float* bag = s_bag + le * A * MQE_OBS_BAG;    // this env's rows, agent-major like the tensor
+  typedef typename std::conditional<LDS_STATE, lds_cptr, const float*>::type state_ptr;
+  state_ptr root_src;                           // the env's root rows as the physics left them
+  if constexpr (LDS_STATE) root_src = (lds_cptr)(root_l + le * lds_env_stride); else root_src = root;
   float* la = s_la + le * A * 12;
   // ---- loads --------------------------------------------------------------------------------------------------------------
   float rs[13], gpar[5], gi0 = 0.f, f3[3], aoz = 0.f, dq[24], act[12], eo[3];
@@ -863,7 +914,6 @@ __device__ __forceinline__ void post_body(const DevModel* m, const DevState& st,
     ep = st.ep_len[e] + 1;
 #pragma unroll
     for (int k = 0; k < 3; k++) eo[k] = as_global(m->env_origins)[e * 3 + k];
-    const float* root_src = root_l != nullptr ? root_l + le * lds_env_stride : root;
 #pragma unroll
     for (int k = 0; k < 13; k++) rs[k] = root_src[a * 13 + k];
     const float* lo = st.loco_obs + (size_t)i * MQE_FRAME;
@@ -874,10 +924,11 @@ __device__ __forceinline__ void post_body(const DevModel* m, const DevState& st,
 #pragma unroll
     for (int k = 0; k < 3; k++) f3[k] = cf3[k];
     aoz = as_global(m->agent_origins)[(size_t)i * 3 + 2];
-    const float* ds = dof_l != nullptr ? dof_l + le * lds_env_stride + a * 24 : st.dof + ((size_t)e * m->ND + a * 12) * 2;
+    state_ptr ds, as;
+    if constexpr (LDS_STATE) { ds = (lds_cptr)(dof_l + le * lds_env_stride + a * 24); as = (lds_cptr)(act_l + le * act_env_stride + a * 12); }
+    else { ds = st.dof + ((size_t)e * m->ND + a * 12) * 2; as = st.actions + (size_t)i * 12; }
 #pragma unroll
     for (int k = 0; k < 24; k++) dq[k] = ds[k];
-    const float* as = act_l != nullptr ? act_l + le * act_env_stride + a * 12 : st.actions + (size_t)i * 12;
 #pragma unroll
     for (int k = 0; k < 12; k++) act[k] = as[k];
   }
@@ -916,6 +967,7 @@ __device__ __forceinline__ void post_body(const DevModel* m, const DevState& st,
     if ((m->termination_flags & MQE_TERM_Z_HIGH) && z > m->zhigh_thr) fl |= 8u;
     if ((m->termination_flags & MQE_TERM_Z_LOW) && z < m->zlow_thr) fl |= 16u;
   }
+  ETAP(2);
   // any robot of the env: OR over the agent lanes (lane ^ PEPW, ^ 2 PEPW stay inside the PEPW * AM robot lanes)
 #pragma unroll
   for (int d = PEPW; d < PEPW * AM; d <<= 1) fl |= (unsigned)__shfl_xor((int)fl, d);
@@ -939,6 +991,7 @@ __device__ __forceinline__ void post_body(const DevModel* m, const DevState& st,
     for (int k = 0; k < 4; k++) { st.bquat[i * 4 + k] = bq[k]; st.clock[i * 4 + k] = clk[k]; }
     st.gait[i] = gi1;
   }
+  ETAP(3);
   // wrapper's view of root_states_npc: copy taken before the NPC script (legged_robot.py:136); xy/vel only are read
   // (staged in LDS by the whole wavefront: as a per-lane array of P * 13 floats it lived in scratch memory)
   float* npc_pre = s_npc + le * npc_stride;
@@ -946,26 +999,29 @@ __device__ __forceinline__ void post_body(const DevModel* m, const DevState& st,
     const int e0 = blk * PEPW, nenv = min(PEPW, m->N - e0), per = P * 13;
     for (int t = tid; t < nenv * per; t += 64) {
       const int sl = t / per, r = t - sl * per;
-      s_npc[sl * npc_stride + r] = st.root[((size_t)(e0 + sl) * (A + P) + A) * 13 + r];
+      if constexpr (LDS_STATE) s_npc[sl * npc_stride + r] = ((lds_cptr)(root_l + sl * lds_env_stride))[A * 13 + r];
+      else s_npc[sl * npc_stride + r] = st.root[((size_t)(e0 + sl) * (A + P) + A) * 13 + r];
     }
     __syncthreads();
   }
+  ETAP(4);
   if (m->npc_kind == MQE_NPC_SHEEP) {           // wave-uniform.  The 64 / PEPW lanes of an env share its sheep (lane a: sheep a, a + 8, ..)
     constexpr int LPE = 64 / PEPW, NPASS = (MQE_MAX_NPCS + LPE - 1) / LPE;
     float dvs[NPASS][3];
     if (e < m->N) {
       float avg[3];
-      sheep_flock_mean(m, root, avg);           // every lane of the env, the same loop -> the same bits
-      if (lead) sheep_flock_stats(m, st, e, root, avg);
+      // (the flock before the update = the LDS copy just taken; the robots' rows: the physics' LDS state or the tensor)
+      sheep_flock_mean(m, (lds_cptr)npc_pre, avg);           // every lane of the env, the same loop -> the same bits
+      if (lead) sheep_flock_stats(m, st, e, (lds_cptr)npc_pre, avg);
 #pragma unroll
       for (int q = 0; q < NPASS; q++)
-        if (a + q * LPE < P) sheep_increment(m, st, e, a + q * LPE, root, avg, step_no, dvs[q]);
+        if (a + q * LPE < P) sheep_increment(m, st, e, a + q * LPE, (lds_cptr)npc_pre, root_src, avg, step_no, dvs[q]);
     }
     __syncthreads();                            // every increment is formed from the pre-update flock
     if (e < m->N) {
 #pragma unroll
       for (int q = 0; q < NPASS; q++)
-        if (a + q * LPE < P) sheep_apply(root, A, a + q * LPE, dvs[q]);
+        if (a + q * LPE < P) sheep_apply(root, A, a + q * LPE, (lds_cptr)npc_pre, dvs[q]);
     }
     // (a WORKGROUP-scope fence: writer and readers are lanes of this one wavefront, i.e. one CU and one vector L1.  The device-scope
     // __threadfence() that stood here writes the XCD's L2 back and invalidates it on gfx950 -- its L2s are not coherent with each other --
@@ -973,6 +1029,7 @@ __device__ __forceinline__ void post_body(const DevModel* m, const DevState& st,
     __threadfence_block();
     __syncthreads();                            // the sheep rows are final before the lead lane's reset / wrapper reads
   }
+  ETAP(5);
   if (lead) {
     if (reset) {                                // rare: the reset writes memory, the robot lanes refresh their registers from it
       reset_env_dev(m, st, e);
@@ -995,6 +1052,7 @@ __device__ __forceinline__ void post_body(const DevModel* m, const DevState& st,
       }
     }
   }
+  ETAP(6);
   // ---- compute_observations (legged_robot_field.py:117-146) from registers; obs.last_last_action aliases the current action
   if (mine) {
     float* ob = bag + a * MQE_OBS_BAG;
@@ -1017,8 +1075,9 @@ __device__ __forceinline__ void post_body(const DevModel* m, const DevState& st,
     for (int k = 71; k < MQE_OBS_BAG; k++) ob[k] = 0.0f;               // row padding (the LDS copy is stored whole)
   }
   __syncthreads();
+  ETAP(7);
   if (lead) {
-    wrapper_env_dev(m, st, e, 0, npc_pre, wrapper_level, bag);
+    wrapper_env_dev<true>(m, st, e, 0, npc_pre, wrapper_level, bag);
     // _push_robots (go1.py:237, legged_robot.py:470-476): after this step's frame quantities were taken, before reset_idx --
     // whose U(-0.5, 0.5) base velocities replace the push in the envs that reset.  One draw per robot (the reference draws
     // (num_envs, 2) for a (num_envs * num_agents, 2) slice, which only broadcasts for a single agent).
@@ -1029,6 +1088,7 @@ __device__ __forceinline__ void post_body(const DevModel* m, const DevState& st,
         rv[1] = mqe_rand(m, e, (int)(MQE_RNG_PUSH + (uint32_t)push_count), (uint32_t)(2 * b + 1), -m->max_push, m->max_push);
       }
   }
+  ETAP(8);
   {
     const size_t r0 = (size_t)blk * PEPW * A;
     post_flush_rows(st.obs_bag + r0 * MQE_OBS_BAG, s_bag, nrow * MQE_OBS_BAG, tid);
@@ -1037,6 +1097,7 @@ __device__ __forceinline__ void post_body(const DevModel* m, const DevState& st,
   }
   // go1.py:145: history[agent_ids] = 0 for the envs that reset this step -- rare, so the whole wavefront zeroes them,
   // 16 B per lane per request: the f32 ring and, when present, its two f16 planes
+  ETAP(9);
   unsigned long long rm = __ballot(lead && reset != 0);
   while (rm) {
     const int l = __ffsll((long long)rm) - 1;
@@ -1184,10 +1245,11 @@ __global__ void __launch_bounds__(64) k_post_staged(const DevModel* m, DevState 
   }
   if ((stages & MQE_POST_NPC) && m->npc_kind == MQE_NPC_SHEEP) {
     float avg[3], dvs[MQE_MAX_NPCS][3];
-    sheep_flock_mean(m, root, avg);
-    sheep_flock_stats(m, st, e, root, avg);
-    for (int p = 0; p < P; p++) sheep_increment(m, st, e, p, root, avg, step_no, dvs[p]);    // every increment from the pre-update flock
-    for (int p = 0; p < P; p++) sheep_apply(root, A, p, dvs[p]);
+    const float* nrows = root + A * 13;          // the live rows (a subclass hook may have changed them since the FRAME stage): all increments first, then the rows
+    sheep_flock_mean(m, nrows, avg);
+    sheep_flock_stats(m, st, e, nrows, avg);
+    for (int p = 0; p < P; p++) sheep_increment(m, st, e, p, nrows, (const float*)root, avg, step_no, dvs[p]);    // every increment from the pre-update flock
+    for (int p = 0; p < P; p++) sheep_apply(root, A, p, nrows, dvs[p]);
   }
   if (stages & MQE_POST_RESET) {
     const uint8_t reset = st.reset_buf[e];       // as it stands NOW: a subclass's check_termination may have changed it since FRAME

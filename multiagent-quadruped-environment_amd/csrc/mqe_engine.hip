@@ -623,7 +623,7 @@ extern "C" int mqe_sim_create(const mqe_sim_desc* d, mqe_sim** out) {
   st.hist2 = nullptr;
   st.hist_irr = nullptr;
   st.wave_times = nullptr;
-  if (getenv("MQE_WAVE_TIMES") || getenv("MQE_PHASE_TIMES")) { DA(st.wave_times, (size_t)(4 + 64) * N); }      // [N][4] entry / exit / ids, then [N][4 substeps][16 taps]
+  if (getenv("MQE_WAVE_TIMES") || getenv("MQE_PHASE_TIMES")) { DA(st.wave_times, (size_t)(4 + 64 + 16) * N); }      // [N][4] entry / exit / ids, then [N][4 substeps][16 taps]
   if (s->gemm_split) { DA(st.hist2, (size_t)2 * R * MQE_HIST * MQE_H2_FRAME); DA(st.hist_irr, (size_t)R); }
   DA(st.last_loco, (size_t)R * 12); DA(st.last_two_loco, (size_t)R * 12); DA(st.act_hist, (size_t)4 * R * 12);
   DA(st.gait, R); DA(st.clock, (size_t)R * 4); DA(st.blv, (size_t)R * 3); DA(st.bav, (size_t)R * 3); DA(st.pg, (size_t)R * 3);
@@ -992,6 +992,13 @@ extern "C" int mqe_debug_phase_times(mqe_sim* s, long long* out_host) {
   if (!s->st.wave_times || !s->phase_timed) return fail(-4, "create the handle with MQE_PHASE_TIMES=1 (go1gate-, go1sheep- or go1football-defender-shaped scene)");
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(out_host, s->st.wave_times + (size_t)4 * s->N, (size_t)64 * s->N * sizeof(long long), hipMemcpyDeviceToHost));
+  return 0;
+}
+extern "C" int mqe_debug_epilogue_times(mqe_sim* s, long long* out_host) {
+  if (!s) return fail(-1, "null engine handle");
+  if (!s->st.wave_times || !s->phase_timed) return fail(-4, "create the handle with MQE_PHASE_TIMES=1 (go1gate-, go1sheep- or go1football-defender-shaped scene)");
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(out_host, s->st.wave_times + (size_t)68 * s->N, (size_t)16 * s->N * sizeof(long long), hipMemcpyDeviceToHost));
   return 0;
 }
 extern "C" int mqe_debug_tail_times(mqe_sim* s, long long* out_host) {

@@ -1,7 +1,7 @@
 """ctypes mirror of include/mqe_hip.h (keep in sync; tests/test_abi.py checks sizes against the built library)."""
 import ctypes as C
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 MAX_SPHERES, NBODY, NREP, NDOF = 64, 13, 17, 12
 MAX_SELF_PAIRS = 384
 MAX_PRIMS = 20

@@ -47,7 +47,7 @@ class HipEngine(EngineBase):
                            ("debug_dynamics", [vp, C.c_int, C.c_int, vp, C.POINTER(C.c_int), vp]),
                            ("debug_stop_phase", [vp, C.c_int]),
                            ("debug_wave_times", [vp, vp]), ("debug_tail_times", [vp, vp]),
-                           ("debug_phase_times", [vp, vp]),
+                           ("debug_phase_times", [vp, vp]), ("debug_epilogue_times", [vp, vp]),
                            ("history_sync", [vp, vp]),
                            ("state_save", [vp, vp, vp]), ("state_load", [vp, vp, vp]),
                            ("profile_enable", [vp, C.c_int]),
