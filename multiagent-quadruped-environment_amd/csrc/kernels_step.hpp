@@ -202,12 +202,90 @@ __device__ __forceinline__ void pre_policy_element(const DevModel* m, const DevS
   pre_policy_store(m, st, hist_slot, wrapper_actions != nullptr, i, c, r);
 }
 
-__global__ void k_pre_policy(const DevModel* m, DevState st, const float* __restrict__ command, int hist_slot,
-                             const float* __restrict__ wrapper_actions) {
-  int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  int i = idx / MQE_FRAME, c = idx - i * MQE_FRAME;
+// One WAVEFRONT per robot: lane l holds element l of the frame, lanes 0..7 element 64 + l as well.  Every load of the wavefront is issued
+// before the first wait -- the source of the plain copies, the wrapper's action / the command, the oldest frame's copy of the action columns
+// and the previous frame's action column the "continues its predecessor" bit compares -- through ADDRESSES selected without memory accesses
+// (a lane that does not need a load reads its robot's observation row instead).  One thread per (robot, element) with the loads in the arms of
+// the column if-chain walked ~10 memory round trips one after the other (the wavefront's 64 lanes span 64 of the 72 columns, so every arm runs,
+// and the 24 + 1 loads of element 71 sat behind all of them): 8.8 us for a kernel that moves 7 MB.  With the robot in one wavefront the bit is a
+// ballot over the lanes that hold the action columns.  The general command layout (desc.command_src) and the scripted defender's robot keep the
+// per-element form (pre_policy_element), a wavefront-uniform choice.
+__global__ void __launch_bounds__(256) k_pre_policy(const DevModel* m, DevState st, const float* __restrict__ command, int hist_slot,
+                                                    const float* __restrict__ wrapper_actions) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (i >= m->R) return;
-  pre_policy_element(m, st, command, hist_slot, wrapper_actions, i, c);
+  const int A = m->A, Aw = m->Aw, task = m->task, clip_command = m->clip_command;
+  const float lin = m->cmd_lin_scale, ang = m->cmd_ang_scale;
+  const int e = i / A, a = i - e * A;
+  const bool wrap = wrapper_actions != nullptr;
+  if (m->cmd_general || (wrap && task == MQE_TASK_FOOTBALL_DEFENDER && a == 2)) {      // wavefront-uniform
+    pre_policy_element(m, st, command, hist_slot, wrapper_actions, i, lane);
+    if (lane < MQE_FRAME - 64) pre_policy_element(m, st, command, hist_slot, wrapper_actions, i, 64 + lane);
+    return;
+  }
+  const bool h2 = st.hist2 != nullptr;
+  const float* ob = st.obs_bag + (size_t)i * MQE_OBS_BAG;
+  const int oldest = hist_slot + 1 >= MQE_HIST ? 0 : hist_slot + 1, prev = hist_slot > 0 ? hist_slot - 1 : MQE_HIST - 1;
+  const float* hist_i = st.hist + (size_t)i * MQE_HIST * MQE_FRAME;
+  const unsigned mk = h2 ? st.hist_irr[i] : 0u;
+  float x1[2], x2[2], x3[2], x4[2];
+  bool on[2], cmdc[2], actc[2];
+  int cc[2];
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    const int c = q * 64 + lane;
+    cc[q] = c;
+    on[q] = c < MQE_FRAME;
+    cmdc[q] = c >= 3 && c < 6;
+    actc[q] = c >= 54 && c < 66;                                // last_two_locomotion_action
+    const float* a1 = ob;                                       // (a load nobody reads)
+    if (c < 3) a1 = ob + 60 + c;                                // projected gravity      :95
+    else if (c < 6) a1 = ob;
+    else if (c < 18) a1 = m->command_obs + c;                   // fixed gait parameters (constants of the scene: desc.command_obs)
+    else if (c < 42) a1 = ob + (c - 12);                        // dof_pos :96 (ob[6 ..]), dof_vel :97 (ob[18 ..])
+    else if (c < 54) a1 = st.last_loco + (size_t)i * 12 + (c - 42);            //             :98
+    else if (c < 66) a1 = st.last_two_loco + (size_t)i * 12 + (c - 54);        //             :99
+    else if (c < 70) a1 = ob + (c - 3);                         // clock inputs           :100 (ob[63 ..])
+    const float* a2 = ob;
+    if (cmdc[q]) a2 = wrap ? (a < Aw ? wrapper_actions + ((size_t)e * Aw + a) * 3 + (c - 3) : st.cmd + i * 3 + (c - 3)) : command + i * 3 + (c - 3);
+    const float* a3 = ob;
+    const float* a4 = ob;
+    if (actc[q] && h2) { a3 = hist_i + oldest * MQE_FRAME + c; a4 = hist_i + prev * MQE_FRAME + (c - 12); }
+    x1[q] = on[q] ? *a1 : 0.0f; x2[q] = on[q] ? *a2 : 0.0f; x3[q] = on[q] ? *a3 : 0.0f; x4[q] = on[q] ? *a4 : 0.0f;
+  }
+  // ---- values
+  PreVal r[2];
+  bool differs = false;
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    const int c = cc[q];
+    float v = (c < 70 && !cmdc[q]) ? x1[q] : 0.0f;
+    r[q].aux = 0.0f; r[q].mk = 0u;
+    if (cmdc[q]) {                                              // velocity command       :67-68 (+ clip :38)
+      float x = x2[q];
+      if (wrap) {
+        if (a < Aw) {
+          if (task != MQE_TASK_TUG) x = clampf(x, -1.0f, 1.0f);            // the tug wrapper does not clip before scaling
+          x = task == MQE_TASK_PLAIN ? x : x * (c == 3 ? 2.0f : 0.5f);
+        }
+        r[q].aux = x;                                           // -> st.cmd
+      }
+      if (clip_command) x = clampf(x, -1.0f, 1.0f);
+      v = x * (c < 5 ? lin : ang);
+    }
+    if (actc[q] && h2) {
+      r[q].aux = x3[q];                                         // the oldest frame's copy of this column once this frame is in
+      differs = differs || (on[q] && __float_as_uint(x4[q]) != __float_as_uint(x1[q]));
+    }
+    r[q].v = v;
+  }
+  // does this frame continue its predecessor (bit for bit)?  One bit per RING SLOT: the update does not depend on the bit's old value
+  const bool diff = __ballot(differs) != 0ull;
+  const unsigned bit = 1u << hist_slot;
+  if (lane == MQE_FRAME - 1 - 64) r[1].mk = diff ? (mk | bit) : (mk & ~bit);
+  pre_policy_store(m, st, hist_slot, wrap, i, lane, r[0]);
+  if (lane < MQE_FRAME - 64) pre_policy_store(m, st, hist_slot, wrap, i, 64 + lane, r[1]);
 }
 
 // go1.py:106-107 + :40-41: shift the last-action registers and clip the new joint targets.  act: [R, ld]

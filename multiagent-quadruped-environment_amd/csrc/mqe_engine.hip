@@ -836,8 +836,7 @@ static void policy_head(mqe_sim* s, const float* command, hipStream_t q, const f
   s->hist_pos = (s->hist_pos + 1) % MQE_HIST;     // ring slot of the oldest frame
   {
     ProfScope ps(s, PROF_MISC, q);
-    int n = R * MQE_FRAME;
-    hipLaunchKernelGGL(k_pre_policy, dim3((n + 255) / 256), dim3(256), 0, q, s->dm, s->st, command, slot, wrapper_actions);
+    hipLaunchKernelGGL(k_pre_policy, dim3((R + 3) / 4), dim3(256), 0, q, s->dm, s->st, command, slot, wrapper_actions);      // one wavefront per robot
   }
   {
     ProfScope ps(s, PROF_GEMM_L0, q);
