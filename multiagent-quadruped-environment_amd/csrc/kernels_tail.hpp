@@ -166,8 +166,20 @@ __global__ void __launch_bounds__(TL_THREADS, 1) k_policy_tail(TailArgs g) {
     const int idx = tid + TLT * q, row = idx >> 7, k4 = idx & 127;
     vb[q] = *reinterpret_cast<const float4*>(g.P1 + (size_t)min(r0 + row, g.R - 1) * g.ldp + g.ada_h0 + k4 * 4);
   }
-  // ---- the small vectors (biases, latent weight columns) -> LDS
-  {
+  // (the last-action register this thread shifts at the very end: an input of the launch, requested here instead of behind the target's store)
+  float ll_pre = 0.0f;
+  if constexpr (TLT >= TL_ROWS * 12) { const int row = tid / 12; if (tid < TL_ROWS * 12 && r0 + row < g.R) ll_pre = g.last_loco[(size_t)r0 * 12 + tid]; }
+  // ---- the small vectors (biases, latent weight columns) -> LDS.  All of them are requested before the first is stored (clamped indices: no
+  // branch around a load): as `if (tid < n) lds[tid] = g[tid]` blocks each block waited for its own load, five memory round trips one after
+  // the other behind the P1 rows
+  if constexpr (TLT == 512) {
+    const float s0 = g.a1.bias[tid & 127], s1 = g.b2.bias[tid & 127], s2 = g.a2.bias[tid & 63], s3 = g.b3.bias[tid & 63], s4 = g.b1.bias[tid & 255],
+                s5 = g.wl0[tid], s6 = g.wl1[tid];
+    if (tid < 128) { bA1[tid] = s0; bB2[tid] = s1; }
+    if (tid < 64) { bA2[tid] = s2; bB3[tid] = s3; }
+    if (tid < 256) bB1[tid] = s4;
+    wL0[tid] = s5; wL1[tid] = s6;
+  } else {
     for (int i = tid; i < 128; i += TLT) { bA1[i] = g.a1.bias[i]; bB2[i] = g.b2.bias[i]; }
     for (int i = tid; i < 64; i += TLT) { bA2[i] = g.a2.bias[i]; bB3[i] = g.b3.bias[i]; }
     for (int i = tid; i < 256; i += TLT) bB1[i] = g.b1.bias[i];
@@ -266,7 +278,7 @@ __global__ void __launch_bounds__(TL_THREADS, 1) k_policy_tail(TailArgs g) {
     const float v = fmaf(nar[row * 33 + c], g.b3.descale, bB3[c]);
     const size_t i = (size_t)(r0 + row);
     g.act[i * g.lda + c] = v;
-    g.last_two_loco[i * 12 + c] = g.last_loco[i * 12 + c];
+    g.last_two_loco[i * 12 + c] = TLT >= TL_ROWS * 12 ? ll_pre : g.last_loco[i * 12 + c];
     g.last_loco[i * 12 + c] = v;
     g.actions[i * 12 + c] = clampf(v, -g.clip_actions, g.clip_actions);
   }
