@@ -285,14 +285,26 @@ __device__ __forceinline__ void gemm_h2_tile(const Gemm2Args& g, const int m0, c
   }
 #undef H2_EPW
   __syncthreads();
-#pragma unroll 4
-  for (int it = 0; it < (HM * H2_N / 4) / H2_THREADS; it++) {
+  // every bias segment and row mask of this thread's twelve (six) output segments is requested before the first segment is stored: with the
+  // loads inside the store loop each iteration waited for its loads BEHIND the previous iteration's store (one counter for both on gfx9):
+  // twelve store acknowledgements one after the other, 5.4 us of a 52 us kernel
+  constexpr int EP_IT = (HM * H2_N / 4) / H2_THREADS;
+  float4 bbs[EP_IT];
+  unsigned mks[EP_IT];
+#pragma unroll
+  for (int it = 0; it < EP_IT; it++) {
+    const int i = it * H2_THREADS + tid, row = i / (H2_N / 4), c4 = i - row * (H2_N / 4);
+    bbs[it] = g.bias ? *reinterpret_cast<const float4*>(g.bias + n0 + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    mks[it] = g.irr && m0 + row < g.M ? g.irr[m0 + row] : 0u;
+  }
+#pragma unroll
+  for (int it = 0; it < EP_IT; it++) {
     const int i = it * H2_THREADS + tid, row = i / (H2_N / 4), c4 = i - row * (H2_N / 4);
     const int col = n0 + c4 * 4, grow = m0 + row;
     float4 v = *reinterpret_cast<const float4*>(ep + row * H2_EPS + c4 * 4);
-    float4 bb = g.bias ? *reinterpret_cast<const float4*>(g.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 bb = bbs[it];
     v.x = fmaf(v.x, g.descale, bb.x); v.y = fmaf(v.y, g.descale, bb.y); v.z = fmaf(v.z, g.descale, bb.z); v.w = fmaf(v.w, g.descale, bb.w);
-    unsigned mk = g.irr && grow < g.M ? g.irr[grow] : 0u;
+    unsigned mk = mks[it];
     if (mk) {                     // rare: the first frame after a reset is still in the ring (30 steps per episode)
       float4 cr = make_float4(0.f, 0.f, 0.f, 0.f);
       do {
