@@ -2696,11 +2696,24 @@ __global__ void __launch_bounds__(64, EPW == 2 ? 2 : SubstepsClass<TP>::waves) k
         float* ldsg = lds_wave + ge * L.total;
         float* acthg = ldsg + L.acth;
         const size_t gi = (size_t)eg * nj + jc;
-        float as = st.actions[gi] * m->action_scale;
+        // the joint's inputs are requested together, right behind the weight fragments: the action, its rest angle and torque limit and --
+        // with actuator lag -- the ring's oldest slot, which this substep's write (into ANOTHER slot: the ring has lag_steps + 1 >= 2) does
+        // not change.  One after the other behind `if (lag && ok)` they were three memory round trips per substep that no other
+        // wavefront hides: the four of a SIMD reach this phase together.
+        const bool lagged = m->lag_steps > 0;                        // wave-uniform
+        const float a_raw = st.actions[gi], ddp = m->default_dof_pos[j], lim = m->torque_limits[j];
+        float lag_old = 0.0f;
+        size_t lag_wr = 0;
+        if (lagged) {                                                // go1.py:337-339 (kernels_step.hpp lag_target: the same ring)
+          const size_t R12l = (size_t)m->R * 12;
+          const int rd = pos + 1 >= m->lag_steps + 1 ? 0 : pos + 1;
+          lag_old = st.lag_buf[(size_t)rd * R12l + gi];
+          lag_wr = (size_t)pos * R12l + gi;
+        }
+        float as = a_raw * m->action_scale;
         if (j % 3 == 0) as *= m->hip_scale_reduction;
-        float tgt = as + m->default_dof_pos[j];
-        if (m->lag_steps > 0 && ok) tgt = lag_target(m, st, gi, as, pos) + m->default_dof_pos[j];
-        const float lim = m->torque_limits[j];
+        float tgt = as + ddp;
+        if (lagged && ok) tgt = lag_old + ddp;                    // (this substep's slot is written with the torque below: no store in front of a wait)
         const float q = ldsg[L.dof + jc * 2], qd = ldsg[L.dof + jc * 2 + 1];
         const float he1 = acthg[jc], he2 = acthg[nj + jc], hv1 = acthg[2 * nj + jc], hv2 = acthg[3 * nj + jc];
         const float err = q - tgt;
@@ -2733,6 +2746,7 @@ __global__ void __launch_bounds__(64, EPW == 2 ? 2 : SubstepsClass<TP>::waves) k
           if (ev) {
             st.sub_tau[((size_t)eg * 4 + (k < 4 ? k : 3)) * nj + jt] = tau;          // post_decimation_step (legged_robot.py:113)
             if (last) st.torques[gi] = tau;
+            if (lagged) st.lag_buf[lag_wr] = as;
           }
         }
       }
