@@ -329,7 +329,19 @@ __device__ __forceinline__ void gemm_h2_tile(const Gemm2Args& g, const int m0, c
       v.x = v.x > 0 ? v.x : __expf(v.x) - 1.0f; v.y = v.y > 0 ? v.y : __expf(v.y) - 1.0f;
       v.z = v.z > 0 ? v.z : __expf(v.z) - 1.0f; v.w = v.w > 0 ? v.w : __expf(v.w) - 1.0f;
     }
-    if (grow < g.M) *reinterpret_cast<float4*>(g.C + (size_t)grow * g.ldc + col) = v;
+    if (grow < g.M) {
+      // streaming store: the 25 MB of C are read next by another kernel on (mostly) another XCD, i.e. through memory whatever this L2 keeps; stored
+      // plainly they sit dirty in the eight L2s until the dispatch's release writes them back.  Back to back in tools/dev/gemm_bench.hip 58.8 ->
+      // 57.3 us per launch (write-through sc0 sc1: 57.5), in the step +0.5 % (3 / 3 alternating runs, profiles/r06_ab_gemm_nt_store.txt);
+      // -DH2_PLAIN_STORE keeps the plain form.  tools/dev/gap_bench.hip: what a dispatch costs beyond its wavefronts' run time, by dirty bytes.
+#ifdef H2_PLAIN_STORE
+      *reinterpret_cast<float4*>(g.C + (size_t)grow * g.ldc + col) = v;
+#else
+      typedef float h2_f4 __attribute__((ext_vector_type(4)));
+      h2_f4 nv; nv.x = v.x; nv.y = v.y; nv.z = v.z; nv.w = v.w;
+      __builtin_nontemporal_store(nv, reinterpret_cast<h2_f4*>(g.C + (size_t)grow * g.ldc + col));
+#endif
+    }
   }
   H2_STAMP(2);
 }
